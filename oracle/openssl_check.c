@@ -1,0 +1,54 @@
+/*
+ * openssl_check.c — independent third opinion for the oracle: OpenSSL libcrypto's
+ * ECDSA_do_verify on the raw 160-byte ABI tuple (r|s|hash|Qx|Qy, big-endian).
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle/p256_oracle.c header).  OpenSSL is NOT the
+ * reference (that is Go crypto/ecdsa, absent here); it agrees with Go on every
+ * mathematically defined case (range, on-curve, group law) and is used to pin the
+ * restatement on those classes, and as a second CPU timing ("openssl") beside the port.
+ */
+#define OPENSSL_SUPPRESS_DEPRECATED 1
+#include <openssl/bn.h>
+#include <openssl/ec.h>
+#include <openssl/ecdsa.h>
+#include <openssl/obj_mac.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <string.h>
+
+int sbvssl_p256_verify_tuple(const uint8_t t[160]) {
+    int ok = 0;
+    EC_KEY *key = EC_KEY_new_by_curve_name(NID_X9_62_prime256v1);
+    BIGNUM *x = BN_bin2bn(t + 96, 32, NULL), *y = BN_bin2bn(t + 128, 32, NULL);
+    BIGNUM *r = BN_bin2bn(t, 32, NULL), *s = BN_bin2bn(t + 32, 32, NULL);
+    ECDSA_SIG *sig = ECDSA_SIG_new();
+    if (key && x && y && r && s && sig && EC_KEY_set_public_key_affine_coordinates(key, x, y) == 1) {
+        ECDSA_SIG_set0(sig, r, s); r = s = NULL;   /* ownership moved */
+        ok = ECDSA_do_verify(t + 64, 32, sig, key) == 1;
+    }
+    BN_free(x); BN_free(y); BN_free(r); BN_free(s);
+    ECDSA_SIG_free(sig); EC_KEY_free(key);
+    return ok;
+}
+
+typedef struct { const uint8_t *tuples; size_t lo, hi; uint8_t *bitmap; } job_t;
+static void *worker(void *arg) {
+    job_t *j = (job_t *)arg;
+    for (size_t i = j->lo; i < j->hi; ++i)
+        if (sbvssl_p256_verify_tuple(j->tuples + 160 * i)) j->bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+    return NULL;
+}
+void sbvssl_p256_verify_batch(const uint8_t *tuples, size_t n, uint8_t *bitmap, int threads) {
+    memset(bitmap, 0, (n + 7) / 8);
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256]; job_t jobs[256];
+    size_t per = ((n + threads - 1) / threads + 7) & ~(size_t)7;
+    int started = 0;
+    for (int t = 0; t < threads; ++t) {
+        size_t lo = (size_t)t * per, hi = lo + per; if (lo >= n) break; if (hi > n) hi = n;
+        jobs[t] = (job_t){tuples, lo, hi, bitmap};
+        pthread_create(&th[t], NULL, worker, &jobs[t]); ++started;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+}
