@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — ECDSA P-256 verifies/sec at batch = 2^20 per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path (stage A + stage B kernels, through the C-ABI's
+device-pointer entry) over one batch of 2^20 synthetic tuples already resident in HBM.  With
+N > 1 ranks the global batch of N * 2^20 tuples is sharded by tuple (weak scaling), and — as
+the batch then outgrows one GPU — each step ends with an RCCL all-gather of the per-rank
+accept bitmaps (128 KiB per rank).  Prints ONE JSON line on rank 0.
+
+PyTorch is plumbing here (device memory, streams, torch.distributed); the product is libsbv.so.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+ALGO_BYTES_PER_VERIFY = 160.125          # 5 x 32 B in + 1 bit out
+HBM_PEAK_GBPS = 8000.0                   # /opt/skills/guides/MI355X_MICROARCH.md (spec)
+SEED = 0x5B7F2026
+
+
+def cpu_baseline(tuples, n, gpu_bitmap):
+    """Reference-side CPU number, timed on this box's host cores on a bounded sample.
+
+    kind = "port": the reference (Go crypto/ecdsa behind api.Verifier) cannot run here (no Go
+    toolchain); the oracle is a scalar C restatement, OpenSSL's assembly P-256
+    is reported beside it as the closer proxy for Go's nistec assembly.  This is the ONLY place
+    bench.py touches oracle/ — as the thing timed for the baseline and as a parity check of the
+    sample, never as the measured product."""
+    cores = os.cpu_count() or 1
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsbv_oracle.so"))
+    lib.sbvo_p256_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+    probe = min(n, 256)
+    out = ctypes.create_string_buffer(max(1, (n + 7) // 8))
+    t0 = time.perf_counter()
+    lib.sbvo_p256_verify_batch(tuples.ctypes.data, probe, out, 1)
+    per_thread = probe / (time.perf_counter() - t0)
+    sample = int(min(n, max(1024, per_thread * cores * 2.0))) & ~7       # ~2 s wall, ~2*cores core-seconds
+    t0 = time.perf_counter()
+    lib.sbvo_p256_verify_batch(tuples.ctypes.data, sample, out, cores)
+    dt = time.perf_counter() - t0
+    parity = out.raw[:sample // 8] == bytes(gpu_bitmap[:sample // 8])
+    res = {"value": sample / dt, "unit": "verifies/s", "cores": cores, "kind": "port",
+           "sample": f"first {sample} tuples of the same batch, oracle/p256_oracle.c on {cores} threads, {dt:.2f} s",
+           "parity_with_gpu_on_sample": parity}
+    ssl_path = os.path.join(ROOT, "oracle", "libsbv_openssl.so")
+    if os.path.exists(ssl_path):
+        ssl = ctypes.CDLL(ssl_path)
+        ssl.sbvssl_p256_verify_batch.argtypes = lib.sbvo_p256_verify_batch.argtypes
+        s2 = int(min(n, sample * 4)) & ~7
+        t0 = time.perf_counter()
+        ssl.sbvssl_p256_verify_batch(tuples.ctypes.data, s2, out, cores)
+        dt2 = time.perf_counter() - t0
+        res["openssl_value"] = s2 / dt2
+        res["openssl_parity_with_gpu_on_sample"] = out.raw[:s2 // 8] == bytes(gpu_bitmap[:s2 // 8])
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--tuples", type=int, default=1 << 20, help="tuples per GPU (default: the headline 2^20)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import consensus_amd as sbv
+    import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("no GPU visible: bench.py measures the HIP path only (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    sbv.init(local_rank)
+
+    n = args.tuples
+    tuples, valid = synth.gen_batch(SEED + rank, n)            # rank r holds shard r of the global batch
+    d_tuples = torch.from_numpy(tuples).cuda()
+    nbytes = (n + 7) // 8
+    d_bitmap = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    d_all = torch.zeros(nbytes * world, dtype=torch.uint8, device="cuda") if world > 1 else None
+    stream = torch.cuda.current_stream()
+
+    def step():
+        sbv.verify_batch_dev(d_tuples.data_ptr(), n, d_bitmap.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_bitmap)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    sbv.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prep_us, verify_us, launches = sbv.profile_read()
+    sbv.profile_enable(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    got = d_bitmap.cpu().numpy()
+    ok = bool((got == valid).all())
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+        # the gathered bitmap must hold this rank's shard at its slot
+        ok = ok and bool((d_all[rank * nbytes:(rank + 1) * nbytes].cpu().numpy() == valid).all())
+
+    if rank == 0:
+        total = n * world * args.steps
+        value = total / elapsed
+        kern_s = (verify_us / max(1, launches)) * 1e-6
+        achieved = ALGO_BYTES_PER_VERIFY * n / kern_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")      # per-launch HBM bytes from a rocprofv3 --pmc run
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_p256_verify_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "ECDSA P-256 verifies/sec at batch=1M", "value": value, "unit": "verifies/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "configs[1]: standalone kernel, 2^20 synthetic P-256 (r,s,hash,pk) tuples per GPU, "
+                                   "accept-bitmap out; 1024 keys, 7/8 valid + 1/8 single-bit-corrupted",
+                       "tuples_per_gpu": n, "global_batch": n * world,
+                       "parallelism": "shard-by-tuple" + (f" x{world} + RCCL all-gather of bitmaps" if world > 1 else "")},
+            "bitmap_correct": ok,
+            "kernel_us": {"k_p256_prep": prep_us / max(1, launches), "k_p256_verify": verify_us / max(1, launches),
+                          "launches": launches},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "k_p256_verify",
+                         "note": "algorithmic bytes = 160.125 B/verify x tuples per launch / avg kernel time "
+                                 "(HIP events on the launch stream); the path is integer-ALU bound, see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(tuples, n, got)
+        print(json.dumps(line), flush=True)
+        if not ok:
+            sys.exit(3)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+"""consensus_amd — MI355X-native batch signature verification behind SmartBFT's api.Verifier.
+
+This package is a thin ctypes binding over the product's C-ABI (include/sbv.h,
+consensus_amd/libsbv.so).  It holds no verification logic and **no CPU fallback**: if the HIP
+library is missing or no gfx950 device is usable, every compute call raises.
+
+Reference seam: /root/reference/pkg/api/dependencies.go:54-71 (api.Verifier).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsbv.so")
+TUPLE_BYTES = 160
+
+SBV_OK = 0
+ERRORS = {-1: "SBV_ENODEV", -2: "SBV_EINVAL", -3: "SBV_ENOMEM", -4: "SBV_EDEVICE", -5: "SBV_ENOTINIT",
+          -6: "SBV_EPARSE"}
+
+
+class SbvError(RuntimeError):
+    def __init__(self, code: int, detail: str = ""):
+        self.code = code
+        super().__init__(f"libsbv: {ERRORS.get(code, code)} {detail}".strip())
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("h2d_us", ctypes.c_double), ("prep_us", ctypes.c_double), ("verify_us", ctypes.c_double),
+                ("d2h_us", ctypes.c_double), ("total_us", ctypes.c_double), ("n", ctypes.c_uint64)]
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libsbv.so (built by __graft_entry__.build() / consensus_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(the product has no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.sbv_init.argtypes = [ctypes.c_int]
+    lib.sbv_p256_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.sbv_p256_verify_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    lib.sbv_p256_parse_der.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    lib.sbv_sha256_batch.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, ctypes.c_char_p]
+    lib.sbv_last_timing.argtypes = [ctypes.POINTER(Timing)]
+    lib.sbv_profile_enable.argtypes = [ctypes.c_int]
+    lib.sbv_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                     ctypes.POINTER(ctypes.c_uint64)]
+    lib.sbv_last_error.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != SBV_OK:
+        raise SbvError(rc, load().sbv_last_error().decode(errors="replace"))
+
+
+def init(device: int = 0) -> None:
+    _check(load().sbv_init(device))
+
+
+def shutdown() -> None:
+    _check(load().sbv_shutdown())
+
+
+def device_count() -> int:
+    return load().sbv_device_count()
+
+
+def verify_batch(tuples: bytes, n: Optional[int] = None) -> bytes:
+    """Verify n 160-byte tuples held in host memory; returns the ceil(n/8)-byte accept bitmap."""
+    if n is None:
+        if len(tuples) % TUPLE_BYTES:
+            raise ValueError("tuple buffer is not a multiple of 160 bytes")
+        n = len(tuples) // TUPLE_BYTES
+    if len(tuples) < n * TUPLE_BYTES:
+        raise ValueError("tuple buffer too short")
+    out = ctypes.create_string_buffer(max(1, (n + 7) // 8))
+    buf = (ctypes.c_char * len(tuples)).from_buffer_copy(tuples) if n else None
+    _check(load().sbv_p256_verify_batch(buf, n, out))
+    return out.raw[:(n + 7) // 8]
+
+
+def verify_batch_ptr(host_ptr: int, n: int, out_ptr: int) -> None:
+    """Raw-pointer form (e.g. numpy buffers) of sbv_p256_verify_batch."""
+    _check(load().sbv_p256_verify_batch(host_ptr, n, out_ptr))
+
+
+def verify_batch_dev(d_tuples_ptr: int, n: int, d_bitmap_ptr: int, stream: int = 0) -> None:
+    """Asynchronous verification of device-resident tuples on `stream` (a hipStream_t value)."""
+    _check(load().sbv_p256_verify_batch_dev(d_tuples_ptr, n, d_bitmap_ptr, stream))
+
+
+def parse_der(sig: bytes) -> Optional[bytes]:
+    """Strict DER -> r|s (64 bytes), or None when Go's parseSignature would fail."""
+    out = ctypes.create_string_buffer(64)
+    rc = load().sbv_p256_parse_der(sig, len(sig), out)
+    if rc == SBV_OK:
+        return out.raw
+    if rc == -6:
+        return None
+    _check(rc)
+    return None
+
+
+def sha256_batch(msgs) -> bytes:
+    blob = b"".join(msgs)
+    offs = (ctypes.c_uint64 * (len(msgs) + 1))()
+    acc = 0
+    for i, m in enumerate(msgs):
+        offs[i] = acc
+        acc += len(m)
+    offs[len(msgs)] = acc
+    out = ctypes.create_string_buffer(32 * max(1, len(msgs)))
+    _check(load().sbv_sha256_batch(blob, offs, len(msgs), out))
+    return out.raw[:32 * len(msgs)]
+
+
+def last_timing() -> Timing:
+    t = Timing()
+    _check(load().sbv_last_timing(ctypes.byref(t)))
+    return t
+
+
+def profile_enable(on: bool) -> None:
+    _check(load().sbv_profile_enable(1 if on else 0))
+
+
+def profile_read():
+    """(prep_us_sum, verify_us_sum, launches) of the device-pointer calls since the last read."""
+    p, v, k = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint64()
+    _check(load().sbv_profile_read(ctypes.byref(p), ctypes.byref(v), ctypes.byref(k)))
+    return p.value, v.value, k.value
+
+
+def bitmap_to_list(bm: bytes, n: int):
+    return [bool((bm[i >> 3] >> (i & 7)) & 1) for i in range(n)]

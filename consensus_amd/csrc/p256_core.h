@@ -1,0 +1,312 @@
+// p256_core.h — the two per-lane stages of batch ECDSA P-256 verification.
+//
+// Semantics = Go >= 1.20 crypto/ecdsa.verifyNISTEC on one 160-byte tuple r|s|hash|Qx|Qy
+// (5 x 32 B big-endian): what a stock implementation of the reference's api.Verifier
+// (pkg/api/dependencies.go:54-71: VerifyRequest / VerifySignature / VerifyConsenterSig, and
+// the K request signatures inside VerifyProposal, internal/bft/view.go:555) computes per
+// signature after DER parsing and hashing.
+//
+//   stage A  prep_chunk   : range checks (bigmod SetBytes / IsZero, pointFromAffine's
+//                           coordinate < p), e = hash mod N (hashToNat), s^-1 by Montgomery's
+//                           trick over the thread's chunk of T tuples (one Fermat inversion
+//                           per T signatures), u1 = e*s^-1, u2 = r*s^-1.  Writes a limb-major
+//                           (SoA) scratch so stage B's loads are coalesced.
+//   stage B  verify_lane  : on-curve check, R = u1*G + u2*Q with signed fixed windows
+//                           (4-bit for Q from a per-signature table, 8-bit comb for G from a
+//                           precomputed table), R != infinity, R.x == r (mod N) checked
+//                           projectively: X == r*Z^2 or (r + N < p and X == (r+N)*Z^2).
+//
+// The same source is compiled by hipcc for gfx950 (kernels in p256_kernels.hip) and by g++
+// for tests/emul (CPU test tier: lane-by-lane emulation diffed against the oracle).
+#pragma once
+#include "p256_fe.h"
+#include "p256_pt.h"
+#include "p256_sc.h"
+
+namespace sbv {
+
+// ---- scratch between stage A and stage B ---------------------------------------------------------
+// Limb-major arrays: word (l, i) of field F lives at F[l * cap + i] so that lane i of a
+// wavefront reads consecutive dwords.  cap = n rounded up to the launch granularity.
+struct Scratch {
+    u32* r;      // signature r (plain integer)
+    u32* u1;     // e * s^-1 mod N (plain); also temp: exclusive prefix products during stage A
+    u32* u2;     // r * s^-1 mod N (plain); also temp: e during stage A
+    u32* qx;     // public key x (plain)
+    u32* qy;     // public key y (plain)
+    u32* sm;     // temp: s in Montgomery form (stage A only)
+    uint8_t* ok; // 1 = passed the range checks
+    size_t cap;
+};
+
+SBV_HD void soa_store(u32* base, size_t cap, size_t i, const u256& v) {
+    SBV_UNROLL
+    for (int l = 0; l < 8; ++l) base[(size_t)l * cap + i] = v.v[l];
+}
+SBV_HD void soa_load(u256& v, const u32* base, size_t cap, size_t i) {
+    SBV_UNROLL
+    for (int l = 0; l < 8; ++l) v.v[l] = base[(size_t)l * cap + i];
+}
+
+// field f (0..4 = r, s, hash, Qx, Qy) of a tuple given as 40 packed big-endian dwords
+// (`w` points at the tuple's first dword, `stride` is the distance between dwords in u32 units).
+template <typename WordPtr>
+SBV_HD void tuple_field(u256& out, WordPtr w, int f) {
+    SBV_UNROLL
+    for (int l = 0; l < 8; ++l) out.v[l] = bswap32(w[f * 8 + (7 - l)]);
+}
+
+// ---- stage A ----------------------------------------------------------------------------------------
+// One thread handles tuples idx_k = first + k * step, k = 0..T-1 (those with idx_k < n).
+// `TupleWords` is a callable (k, idx) -> indexable giving the 40 big-endian dwords of tuple
+// idx; it is invoked by every thread for every k (it may contain workgroup barriers: the
+// kernel stages each 64-tuple slab through LDS with coalesced 16-byte loads).
+template <typename TupleWords>
+SBV_HD void prep_chunk(TupleWords words, size_t n, const Scratch& sc_, size_t first, size_t step, int T) {
+    const sc n_ = sc_n();
+    const fe p_ = fe_p();
+    sc acc = sc_one_mont();
+    for (int k = 0; k < T; ++k) {
+        const size_t idx = first + (size_t)k * step;
+        auto w = words(k, idx);
+        if (idx < n) {
+            u256 r, s, e, qx, qy;
+            tuple_field(r, w, 0);
+            tuple_field(s, w, 1);
+            tuple_field(e, w, 2);
+            tuple_field(qx, w, 3);
+            tuple_field(qy, w, 4);
+            const bool ok = !is_zero256(r) && lt256(r, n_) && !is_zero256(s) && lt256(s, n_) &&
+                            lt256(qx, p_) && lt256(qy, p_);
+            // hashToNat: e < 2^256 < 2N, one conditional subtraction
+            sc_cond_sub_n(e, e, 0);
+            sc sM;
+            sc_to_mont(sM, s);                 // garbage if s >= N, replaced below
+            const sc one = sc_one_mont();
+            select256(sM, ok, sM, one);        // keep the product chain invertible
+            soa_store(sc_.u1, sc_.cap, idx, acc);   // exclusive prefix product
+            soa_store(sc_.sm, sc_.cap, idx, sM);
+            soa_store(sc_.u2, sc_.cap, idx, e);
+            soa_store(sc_.r, sc_.cap, idx, r);
+            soa_store(sc_.qx, sc_.cap, idx, qx);
+            soa_store(sc_.qy, sc_.cap, idx, qy);
+            sc_.ok[idx] = ok ? 1 : 0;
+            sc_mul(acc, acc, sM);
+        }
+    }
+    sc inv;
+    sc_inv(inv, acc);                      // (prod s_k)^-1, Montgomery form
+    for (int k = T - 1; k >= 0; --k) {
+        const size_t idx = first + (size_t)k * step;
+        if (idx >= n) continue;
+        sc pre, sM, w;
+        u256 e, r, u1, u2;
+        soa_load(pre, sc_.u1, sc_.cap, idx);
+        soa_load(sM, sc_.sm, sc_.cap, idx);
+        soa_load(e, sc_.u2, sc_.cap, idx);
+        soa_load(r, sc_.r, sc_.cap, idx);
+        sc_mul(w, inv, pre);               // s_k^-1 (Montgomery)
+        sc_mul(inv, inv, sM);              // drop s_k from the running inverse
+        sc_mul(u1, w, e);                  // Montgomery(w) * plain(e) = plain(e * w)
+        sc_mul(u2, w, r);
+        soa_store(sc_.u1, sc_.cap, idx, u1);
+        soa_store(sc_.u2, sc_.cap, idx, u2);
+    }
+}
+
+// ---- stage B ----------------------------------------------------------------------------------------
+#define SBV_QTAB_ENTRIES 8
+#define SBV_GTAB_WINDOWS 33
+#define SBV_GTAB_PER_WINDOW 128
+
+struct alignas(16) vec4 { u32 x, y, z, w; };
+
+SBV_HD void fe_store16(u32* dst, const fe& a) {
+    vec4* d = reinterpret_cast<vec4*>(dst);
+    vec4 lo = {a.v[0], a.v[1], a.v[2], a.v[3]}, hi = {a.v[4], a.v[5], a.v[6], a.v[7]};
+    d[0] = lo;
+    d[1] = hi;
+}
+SBV_HD void fe_load16(fe& a, const u32* src) {
+    const vec4* s = reinterpret_cast<const vec4*>(src);
+    const vec4 lo = s[0], hi = s[1];
+    a.v[0] = lo.x; a.v[1] = lo.y; a.v[2] = lo.z; a.v[3] = lo.w;
+    a.v[4] = hi.x; a.v[5] = hi.y; a.v[6] = hi.z; a.v[7] = hi.w;
+}
+SBV_HD void qent_store(u32* dst, const jpt& p) {
+    fe zz, zzz;
+    fe_sqr(zz, p.Z);
+    fe_mul(zzz, zz, p.Z);
+    fe_store16(dst, p.X);
+    fe_store16(dst + 8, p.Y);
+    fe_store16(dst + 16, p.Z);
+    fe_store16(dst + 24, zz);
+    fe_store16(dst + 32, zzz);
+}
+SBV_HD void qent_load(qent& q, const u32* src) {
+    fe_load16(q.X, src);
+    fe_load16(q.Y, src + 8);
+    fe_load16(q.Z, src + 16);
+    fe_load16(q.ZZ, src + 24);
+    fe_load16(q.ZZZ, src + 32);
+}
+
+// v + c as a 257-bit value: returns the low 256 bits, `top` = bit 256
+SBV_HD u32 add_const_limbs(u256& out, const u256& v, u32 c_limb) {
+    u32 c = 0;
+    SBV_UNROLL
+    for (int l = 0; l < 8; ++l) out.v[l] = addc(v.v[l], c_limb, c);
+    return c;
+}
+
+// Returns accept (true) / reject for lane `i`.  `qtab` = this lane's private table space
+// (SBV_QTAB_ENTRIES * 40 dwords, 16-byte aligned), `gtab` = 33 x 128 affine multiples of G:
+// gtab[j * 128 + (k-1)] = k * 2^(8j) * G.
+SBV_HD bool verify_lane(const Scratch& s, size_t i, u32* qtab, const apt* gtab) {
+    u256 r, u1, u2, qx, qy;
+    soa_load(r, s.r, s.cap, i);
+    soa_load(u1, s.u1, s.cap, i);
+    soa_load(u2, s.u2, s.cap, i);
+    soa_load(qx, s.qx, s.cap, i);
+    soa_load(qy, s.qy, s.cap, i);
+    bool ok = s.ok[i] != 0;
+
+    apt Q;
+    fe_to_mont(Q.x, qx);
+    fe_to_mont(Q.y, qy);
+    ok = ok && pt_on_curve(Q.x, Q.y);
+
+    // per-signature table: k*Q for k = 1..8, Jacobian with cached Z^2, Z^3
+    {
+        jpt t;
+        t.X = Q.x; t.Y = Q.y; t.Z = fe_one();
+        qent_store(qtab, t);
+        pt_dbl(t, t);
+        qent_store(qtab + 40, t);
+        for (int k = 3; k <= SBV_QTAB_ENTRIES; ++k) {
+            pt_add_mixed(t, Q, false, false);
+            qent_store(qtab + (k - 1) * 40, t);
+        }
+    }
+
+    // signed-window recoding: u + 0x88..8 has nibbles d+8, d in [-8,7]; bit 256 is a final +1 digit
+    u256 k2, k1;
+    const u32 top2 = add_const_limbs(k2, u2, 0x88888888u);
+    const u32 top1 = add_const_limbs(k1, u1, 0x80808080u);
+
+    jpt R;
+    {
+        // digit 64 of u2 (0 or 1)
+        const fe one = fe_one();
+        const bool t = top2 != 0;
+        SBV_UNROLL
+        for (int l = 0; l < 8; ++l) {
+            R.X.v[l] = t ? Q.x.v[l] : 0u;
+            R.Y.v[l] = t ? Q.y.v[l] : 0u;
+            R.Z.v[l] = t ? one.v[l] : 0u;
+        }
+    }
+    for (int w = 63; w >= 0; --w) {
+        pt_dbl(R, R);
+        pt_dbl(R, R);
+        pt_dbl(R, R);
+        pt_dbl(R, R);
+        const int d = (int)((k2.v[w >> 3] >> ((w & 7) * 4)) & 15u) - 8;
+        const int ad = d < 0 ? -d : d;
+        const int idx = ad == 0 ? 0 : ad - 1;
+        qent e;
+        qent_load(e, qtab + idx * 40);
+        pt_add_qent(R, e, d < 0, d == 0);
+    }
+    // fixed-base part: 32 signed 8-bit windows + the carry window
+    for (int j = 0; j < 32; ++j) {
+        const int d = (int)((k1.v[j >> 2] >> ((j & 3) * 8)) & 255u) - 128;
+        const int ad = d < 0 ? -d : d;
+        const int idx = ad == 0 ? 0 : ad - 1;
+        apt g;
+        const u32* gp = reinterpret_cast<const u32*>(gtab + (size_t)j * SBV_GTAB_PER_WINDOW + idx);
+        fe_load16(g.x, gp);
+        fe_load16(g.y, gp + 8);
+        pt_add_mixed(R, g, d < 0, d == 0);
+    }
+    {
+        apt g;
+        const u32* gp = reinterpret_cast<const u32*>(gtab + (size_t)32 * SBV_GTAB_PER_WINDOW);
+        fe_load16(g.x, gp);
+        fe_load16(g.y, gp + 8);
+        pt_add_mixed(R, g, false, top1 == 0);
+    }
+
+    // R.x mod N == r  <=>  X == r Z^2  or  (r + N < p and X == (r + N) Z^2)   (mod p)
+    if (pt_is_inf(R)) ok = false;
+    fe zz, rM, t;
+    fe_sqr(zz, R.Z);
+    fe_to_mont(rM, r);                      // r < N < p when ok
+    fe_mul(t, rM, zz);
+    bool match = fe_eq(t, R.X);
+    {
+        const sc n_ = sc_n();
+        const fe p_ = fe_p();
+        u256 rn;
+        const u32 carry = add256(rn, r, n_);
+        const bool wrap_possible = (carry == 0) && lt256(rn, p_);
+        if (wrap_possible) {                // only for r < p - N ~ 2^128: essentially never
+            fe_to_mont(rM, rn);
+            fe_mul(t, rM, zz);
+            match = match || fe_eq(t, R.X);
+        }
+    }
+    return ok && match;
+}
+
+// ---- fixed-base table generation (host, once per sbv_init; also used by tests/emul) -----------------
+// out[j * 128 + (k-1)] = k * 2^(8j) * G for j = 0..32, k = 1..128 (affine, Montgomery form).
+inline void build_gtable(apt* out) {
+    const u256 gx = {{0xD898C296u, 0xF4A13945u, 0x2DEB33A0u, 0x77037D81u, 0x63A440F2u, 0xF8BCE6E5u, 0xE12C4247u, 0x6B17D1F2u}};
+    const u256 gy = {{0x37BF51F5u, 0xCBB64068u, 0x6B315ECEu, 0x2BCE3357u, 0x7C0F9E16u, 0x8EE7EB4Au, 0xFE1A7F9Bu, 0x4FE342E2u}};
+    apt base;
+    fe_to_mont(base.x, gx);
+    fe_to_mont(base.y, gy);
+    jpt* row = new jpt[SBV_GTAB_PER_WINDOW];
+    fe* pre = new fe[SBV_GTAB_PER_WINDOW];
+    for (int j = 0; j < SBV_GTAB_WINDOWS; ++j) {
+        jpt t;
+        t.X = base.x; t.Y = base.y; t.Z = fe_one();
+        row[0] = t;
+        pt_dbl(t, t);
+        row[1] = t;
+        for (int k = 3; k <= SBV_GTAB_PER_WINDOW; ++k) {
+            pt_add_mixed(t, base, false, false);
+            row[k - 1] = t;
+        }
+        // batch-invert the Z's (Montgomery's trick)
+        fe acc = fe_one();
+        for (int k = 0; k < SBV_GTAB_PER_WINDOW; ++k) { pre[k] = acc; fe_mul(acc, acc, row[k].Z); }
+        fe inv;
+        fe_inv(inv, acc);
+        for (int k = SBV_GTAB_PER_WINDOW - 1; k >= 0; --k) {
+            fe zi, zi2, zi3;
+            fe_mul(zi, inv, pre[k]);
+            fe_mul(inv, inv, row[k].Z);
+            fe_sqr(zi2, zi);
+            fe_mul(zi3, zi2, zi);
+            apt a;
+            fe_mul(a.x, row[k].X, zi2);
+            fe_mul(a.y, row[k].Y, zi3);
+            out[(size_t)j * SBV_GTAB_PER_WINDOW + k] = a;
+        }
+        // next base = 2^8 * base = 2 * (128 * base)
+        jpt nb = row[SBV_GTAB_PER_WINDOW - 1];
+        pt_dbl(nb, nb);
+        fe zi, zi2, zi3;
+        fe_inv(zi, nb.Z);
+        fe_sqr(zi2, zi);
+        fe_mul(zi3, zi2, zi);
+        fe_mul(base.x, nb.X, zi2);
+        fe_mul(base.y, nb.Y, zi3);
+    }
+    delete[] row;
+    delete[] pre;
+}
+
+}  // namespace sbv

@@ -1,0 +1,98 @@
+// p256_kernels.hip — gfx950 kernels for batch ECDSA P-256 verification (one tuple per lane).
+//
+//   k_p256_prep   : stage A.  One 64-lane workgroup (= one wavefront) walks T slabs of 64
+//                   tuples.  Each slab (64 x 160 B = 10 KiB, contiguous in HBM) is fetched
+//                   with coalesced 16-byte loads (global_load_dwordx4, lane l reads bytes
+//                   16*l..) into LDS with a 41-dword row pitch (41 is odd -> the per-lane
+//                   ds_read_b32 column walk is bank-conflict free), then every lane reads
+//                   its own tuple's 40 dwords back from LDS.  Montgomery's trick runs along
+//                   the T slabs inside each lane: one Fermat inversion per T signatures.
+//   k_p256_verify : stage B.  256 lanes per workgroup; all inputs come from the limb-major
+//                   scratch (coalesced dword loads); the per-signature window table lives
+//                   in HBM scratch (1280 B / lane, written and read only by its lane); the
+//                   fixed-base table (270 KiB) is read-only and L2/L1 resident.  The accept
+//                   bits are gathered with a 64-wide ballot and written as bitmap bytes.
+//
+// No MFMA: this is 256-bit modular integer arithmetic (v_mad_u64_u32 + carry chains).
+#include <hip/hip_runtime.h>
+
+#include "p256_core.h"
+#include "p256_kernels.h"
+
+namespace sbv {
+
+constexpr int kPrepLanes = 64;
+constexpr int kLdsPitch = 41;   // dwords per staged tuple (40 + 1 pad)
+
+struct LdsTuple {
+    const u32* row;
+    __device__ __forceinline__ u32 operator[](int i) const { return row[i]; }
+};
+
+__global__ __launch_bounds__(kPrepLanes) void k_p256_prep(const uint8_t* __restrict__ tuples, size_t n,
+                                                          Scratch s, int T) {
+    __shared__ u32 lds[kPrepLanes * kLdsPitch];
+    const size_t block_first = (size_t)blockIdx.x * kPrepLanes * (size_t)T;
+    const int lane = threadIdx.x;
+    auto words = [&](int k, size_t) -> LdsTuple {
+        const size_t slab = block_first + (size_t)k * kPrepLanes;      // first tuple of the slab
+        __syncthreads();                                               // previous slab fully consumed
+        const uint4* src = reinterpret_cast<const uint4*>(tuples + slab * SBV_TUPLE_BYTES);
+#pragma unroll
+        for (int it = 0; it < 10; ++it) {
+            const int e = it * kPrepLanes + lane;                      // 16-byte element of the slab
+            const int t = e / 10, part = e - t * 10;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (slab + (size_t)t < n) v = src[e];
+            u32* dst = lds + t * kLdsPitch + part * 4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        __syncthreads();
+        return LdsTuple{lds + lane * kLdsPitch};
+    };
+    prep_chunk(words, n, s, block_first + (size_t)lane, (size_t)kPrepLanes, T);
+}
+
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify(Scratch s, size_t n, u32* __restrict__ qtab,
+                                                                 const apt* __restrict__ gtab,
+                                                                 uint8_t* __restrict__ bitmap) {
+    const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    bool accept = false;
+    if (i < n) accept = verify_lane(s, i, qtab + i * (size_t)(SBV_QTAB_ENTRIES * 40), gtab);
+    const unsigned long long m = __ballot(accept);
+    const int lane = threadIdx.x & 63;
+    const size_t wave_first = i - (size_t)lane;
+    if (lane < 8) {
+        const size_t byte = (wave_first >> 3) + (size_t)lane;
+        if (byte < ((n + 7) >> 3)) bitmap[byte] = (uint8_t)(m >> (8 * lane));
+    }
+}
+
+int prep_chunk_T(size_t n) {
+    // small batches: one inversion per tuple (latency); large batches: amortise over 32
+    size_t t = (n + 16383) / 16384;
+    if (t < 1) t = 1;
+    if (t > 32) t = 32;
+    return (int)t;
+}
+
+hipError_t launch_p256_prep(const uint8_t* d_tuples, size_t n, const Scratch& s, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const int T = prep_chunk_T(n);
+    const size_t per_block = (size_t)kPrepLanes * T;
+    const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
+    hipLaunchKernelGGL(k_p256_prep, dim3(grid), dim3(kPrepLanes), 0, stream, d_tuples, n, s, T);
+    return hipGetLastError();
+}
+
+hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt* d_gtab, uint8_t* d_bitmap,
+                              hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
+    hipLaunchKernelGGL(k_p256_verify, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gtab, d_bitmap);
+    return hipGetLastError();
+}
+
+void host_build_gtable(apt* out) { build_gtable(out); }
+
+}  // namespace sbv

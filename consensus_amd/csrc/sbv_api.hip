@@ -1,0 +1,293 @@
+// sbv_api.hip — C-ABI of libsbv.so (include/sbv.h): context, HBM buffers, launches.
+//
+// One context per process.  HBM layout (device `dev`, sized for `cap` tuples, grown on demand):
+//   tuples    cap * 160 B            staging for the host-pointer entry point (AoS, as received)
+//   scratch   6 x cap * 32 B + cap   limb-major r, u1, u2, Qx, Qy, sM + ok flags   (stage A -> B)
+//   qtab      cap * 1280 B           per-signature window tables k*Q, k = 1..8      (stage B)
+//   gtab      33 * 128 * 64 B        fixed-base table k * 2^(8j) * G                (read-only)
+//   bitmap    cap / 8 B
+// For the 2^20-tuple headline batch that is 0.17 + 0.20 + 1.34 GB: sized for 288 GB of HBM3E,
+// not for a cache.  There is no CPU verification path in this library.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sbv.h"
+#include "p256_kernels.h"
+
+namespace {
+
+using sbv::u32;
+
+struct Context {
+    bool ready = false;
+    int device = -1;
+    size_t cap = 0;
+    uint8_t* d_tuples = nullptr;
+    uint8_t* d_scratch = nullptr;
+    u32* d_qtab = nullptr;
+    sbv::apt* d_gtab = nullptr;
+    uint8_t* d_bitmap = nullptr;
+    uint8_t* h_bitmap = nullptr;        // pinned
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t busy = nullptr;          // completion of the last launch that used the scratch
+    bool busy_valid = false;
+    sbv_timing timing{};
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_events;   // triples: before prep, after prep, after verify
+    size_t prof_used = 0;
+};
+
+Context g_ctx;
+std::mutex g_mu;
+std::string g_err;
+
+int fail(int code, const char* what, hipError_t e) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return code;
+}
+#define HIP_TRY(code, call)                                     \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return fail(code, #call, e_);     \
+    } while (0)
+
+constexpr size_t kMaxChunk = (size_t)1 << 21;   // tuples per launch; bounds scratch at ~3.3 GB
+
+void free_buffers(Context& c) {
+    if (c.d_tuples) (void)hipFree(c.d_tuples);
+    if (c.d_scratch) (void)hipFree(c.d_scratch);
+    if (c.d_qtab) (void)hipFree(c.d_qtab);
+    if (c.d_bitmap) (void)hipFree(c.d_bitmap);
+    if (c.h_bitmap) (void)hipHostFree(c.h_bitmap);
+    c.d_tuples = c.d_scratch = c.d_bitmap = c.h_bitmap = nullptr;
+    c.d_qtab = nullptr;
+    c.cap = 0;
+}
+
+// make room for `n` tuples per launch (n <= kMaxChunk)
+int ensure_capacity(Context& c, size_t n) {
+    size_t want = (n + 1023) & ~(size_t)1023;
+    if (want <= c.cap) return SBV_OK;
+    if (c.busy_valid) { HIP_TRY(SBV_EDEVICE, hipEventSynchronize(c.busy)); c.busy_valid = false; }
+    free_buffers(c);
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_tuples, want * SBV_TUPLE_BYTES));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_scratch, want * (6 * 32 + 1)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_qtab, want * (size_t)(SBV_QTAB_ENTRIES * 160)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_bitmap, want / 8));
+    HIP_TRY(SBV_ENOMEM, hipHostMalloc(&c.h_bitmap, want / 8, hipHostMallocDefault));
+    c.cap = want;
+    return SBV_OK;
+}
+
+sbv::Scratch scratch_view(const Context& c) {
+    sbv::Scratch s;
+    u32* base = reinterpret_cast<u32*>(c.d_scratch);
+    const size_t stride = c.cap * 8;
+    s.r = base;
+    s.u1 = base + stride;
+    s.u2 = base + 2 * stride;
+    s.qx = base + 3 * stride;
+    s.qy = base + 4 * stride;
+    s.sm = base + 5 * stride;
+    s.ok = c.d_scratch + 6 * stride * sizeof(u32);
+    s.cap = c.cap;
+    return s;
+}
+
+// enqueue stage A + stage B for n <= cap tuples on `stream`
+int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream,
+            hipEvent_t after_prep) {
+    const sbv::Scratch s = scratch_view(c);
+    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_tuples, n, s, stream));
+    if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
+    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify(s, n, c.d_qtab, c.d_gtab, d_bitmap, stream));
+    return SBV_OK;
+}
+
+double ms_between(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.0;
+    return ms;
+}
+
+}  // namespace
+
+extern "C" int sbv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return SBV_ENODEV;
+    return n;
+}
+
+extern "C" int sbv_init(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (c.ready) return c.device == device ? SBV_OK : SBV_EINVAL;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_err = "no HIP device visible (libsbv has no CPU fallback)";
+        return SBV_ENODEV;
+    }
+    if (device < 0 || device >= ndev) { g_err = "device index out of range"; return SBV_EINVAL; }
+    HIP_TRY(SBV_ENODEV, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(SBV_ENODEV, hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        g_err = std::string("device is ") + prop.gcnArchName + ", libsbv is built for gfx950 only";
+        return SBV_ENODEV;
+    }
+    HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    for (auto& ev : c.ev) HIP_TRY(SBV_ENODEV, hipEventCreate(&ev));
+    HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(&c.busy, hipEventDisableTiming));
+    // fixed-base table: computed once on the host with the same field code, then resident in HBM
+    const size_t gcount = (size_t)SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW;
+    std::vector<sbv::apt> h_gtab(gcount);
+    sbv::host_build_gtable(h_gtab.data());
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_gtab, gcount * sizeof(sbv::apt)));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_gtab, h_gtab.data(), gcount * sizeof(sbv::apt), hipMemcpyHostToDevice));
+    c.device = device;
+    c.ready = true;
+    g_err.clear();
+    return SBV_OK;
+}
+
+extern "C" int sbv_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) return SBV_OK;
+    (void)hipSetDevice(c.device);
+    (void)hipDeviceSynchronize();
+    free_buffers(c);
+    if (c.d_gtab) (void)hipFree(c.d_gtab);
+    c.d_gtab = nullptr;
+    for (auto& ev : c.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    for (auto& ev : c.prof_events) (void)hipEventDestroy(ev);
+    c.prof_events.clear();
+    c.prof_used = 0;
+    if (c.busy) { (void)hipEventDestroy(c.busy); c.busy = nullptr; }
+    if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
+    c.busy_valid = false;
+    c.ready = false;
+    c.device = -1;
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, void* hip_stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (n == 0) return SBV_OK;
+    if (!d_tuples || !d_bitmap || (reinterpret_cast<uintptr_t>(d_tuples) & 15)) {
+        g_err = "null or misaligned device pointer";
+        return SBV_EINVAL;
+    }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    int rc = ensure_capacity(c, n < kMaxChunk ? n : kMaxChunk);
+    if (rc != SBV_OK) return rc;
+    // the scratch is single-flight: order this call after the previous one even across streams
+    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(stream, c.busy, 0));
+    const uint8_t* src = static_cast<const uint8_t*>(d_tuples);
+    uint8_t* dst = static_cast<uint8_t*>(d_bitmap);
+    for (size_t off = 0; off < n; off += kMaxChunk) {       // kMaxChunk is a multiple of 8
+        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        hipEvent_t mid = nullptr, end = nullptr;
+        if (c.profiling) {
+            if (c.prof_used + 3 > c.prof_events.size()) {
+                for (int k = 0; k < 3; ++k) {
+                    hipEvent_t ev;
+                    HIP_TRY(SBV_EDEVICE, hipEventCreate(&ev));
+                    c.prof_events.push_back(ev);
+                }
+            }
+            HIP_TRY(SBV_EDEVICE, hipEventRecord(c.prof_events[c.prof_used], stream));
+            mid = c.prof_events[c.prof_used + 1];
+            end = c.prof_events[c.prof_used + 2];
+            c.prof_used += 3;
+        }
+        rc = enqueue(c, src + off * SBV_TUPLE_BYTES, m, dst + off / 8, stream, mid);
+        if (rc != SBV_OK) return rc;
+        if (end) HIP_TRY(SBV_EDEVICE, hipEventRecord(end, stream));
+    }
+    HIP_TRY(SBV_EDEVICE, hipEventRecord(c.busy, stream));
+    c.busy_valid = true;
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (n == 0) return SBV_OK;
+    if (!tuples || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    int rc = ensure_capacity(c, n < kMaxChunk ? n : kMaxChunk);
+    if (rc != SBV_OK) return rc;
+    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(c.stream, c.busy, 0));
+    sbv_timing tm{};
+    tm.n = n;
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[0], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_tuples, tuples + off * SBV_TUPLE_BYTES, m * SBV_TUPLE_BYTES,
+                                            hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
+        rc = enqueue(c, c.d_tuples, m, c.d_bitmap, c.stream, c.ev[2]);
+        if (rc != SBV_OK) return rc;
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.h_bitmap, c.d_bitmap, (m + 7) / 8, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[4], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(c.stream));
+        memcpy(accept_bitmap + off / 8, c.h_bitmap, (m + 7) / 8);
+        tm.h2d_us += 1e3 * ms_between(c.ev[0], c.ev[1]);
+        tm.prep_us += 1e3 * ms_between(c.ev[1], c.ev[2]);
+        tm.verify_us += 1e3 * ms_between(c.ev[2], c.ev[3]);
+        tm.d2h_us += 1e3 * ms_between(c.ev[3], c.ev[4]);
+    }
+    c.busy_valid = false;   // stream is idle
+    tm.total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    c.timing = tm;
+    return SBV_OK;
+}
+
+extern "C" int sbv_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_ctx.profiling = on != 0;
+    return SBV_OK;
+}
+
+extern "C" int sbv_profile_read(double* prep_us, double* verify_us, uint64_t* launches) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) return SBV_ENOTINIT;
+    double p = 0, v = 0;
+    for (size_t i = 0; i + 3 <= c.prof_used; i += 3) {
+        HIP_TRY(SBV_EDEVICE, hipEventSynchronize(c.prof_events[i + 2]));
+        p += 1e3 * ms_between(c.prof_events[i], c.prof_events[i + 1]);
+        v += 1e3 * ms_between(c.prof_events[i + 1], c.prof_events[i + 2]);
+    }
+    if (prep_us) *prep_us = p;
+    if (verify_us) *verify_us = v;
+    if (launches) *launches = c.prof_used / 3;
+    c.prof_used = 0;
+    return SBV_OK;
+}
+
+extern "C" int sbv_last_timing(sbv_timing* out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!out) return SBV_EINVAL;
+    *out = g_ctx.timing;
+    return SBV_OK;
+}
+
+extern "C" const char* sbv_last_error(void) {
+    // the string is only replaced under g_mu; callers read it right after a failing call
+    return g_err.c_str();
+}

@@ -1,0 +1,105 @@
+/*
+ * sbv.h — C-ABI of libsbv.so: MI355X (gfx950) batch signature verification for SmartBFT.
+ *
+ * This is the drop-in boundary below the reference's plugin seam
+ *     api.Verifier            /root/reference/pkg/api/dependencies.go:54-71
+ * A Go (cgo) implementation of api.Verifier — see INTEGRATION.md — parses / hashes each
+ * types.Signature{ID, Value, Msg} (pkg/types/types.go:25-29) or request into one 160-byte
+ * tuple and hands whole batches to the functions below.  The reference has no FFI for this
+ * path (every Verifier it ships is a no-op: examples/naive_chain/node.go:86-96,
+ * test/test_app.go:231-248); each entry point cites the reference call site whose work it
+ * takes over.
+ *
+ * Conventions
+ *   - every function returns SBV_OK (0) or a negative SBV_E* infrastructure error.  A return
+ *     value NEVER means "signature invalid": verdicts are only in the accept bitmap, and a
+ *     caller must treat <0 as "could not verify" (fall back to its own CPU path) — returning
+ *     a Go error for a device fault would depose an honest leader (internal/bft/view.go:387-392).
+ *   - tuple layout (big-endian, 5 x 32 bytes):  r | s | hash | Qx | Qy
+ *       r, s   : signature integers (from sbv_p256_parse_der; a parse failure is encoded as
+ *                r = s = 0, which the range check rejects)
+ *       hash   : leftmost 32 bytes of the message digest, or the shorter digest left-padded
+ *                with zeros (crypto/ecdsa hashToNat)
+ *       Qx, Qy : affine public key
+ *   - accept bitmap: ceil(n/8) bytes, bit (i & 7) of byte (i >> 3) = tuple i (LSB first),
+ *     1 = crypto/ecdsa.VerifyASN1 would return true.
+ *   - there is NO CPU fallback inside the library: without a usable gfx950 device every
+ *     compute entry point returns SBV_ENODEV.
+ *   - all functions are thread-safe; device work is serialised internally (one context per
+ *     process, selected device = sbv_init's argument).
+ */
+#ifndef SBV_H_
+#define SBV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SBV_OK 0
+#define SBV_ENODEV (-1)    /* no HIP device / not a gfx950 / runtime failure at init */
+#define SBV_EINVAL (-2)    /* bad argument */
+#define SBV_ENOMEM (-3)    /* device or pinned-host allocation failed */
+#define SBV_EDEVICE (-4)   /* a HIP call failed during the batch (see sbv_last_error) */
+#define SBV_ENOTINIT (-5)  /* sbv_init has not succeeded */
+#define SBV_EPARSE (-6)    /* sbv_p256_parse_der: not a strict DER ECDSA-Sig-Value */
+
+#define SBV_P256_TUPLE_BYTES 160
+
+/* Initialise the context on HIP device `device` (>= 0): uploads the fixed-base table and
+ * sizes scratch lazily.  Must be called once before Consensus.Start()
+ * (pkg/consensus/consensus.go:107; the Verifier is injected at :35). Idempotent. */
+int sbv_init(int device);
+int sbv_shutdown(void);
+/* Number of visible HIP devices (<0 on runtime failure). */
+int sbv_device_count(void);
+
+/* Verify n tuples in host memory; blocks until the bitmap is written.
+ * Takes over: the K request signatures of VerifyProposal (internal/bft/view.go:555), the
+ * coalesced VerifyConsenterSig calls of processCommits (view.go:537-541, 834-838) and
+ * verifyPrevCommitSignatures (view.go:630-635), VerifyRequest (controller.go:239) under
+ * Pool.Prune (controller.go:742-745), ValidateLastDecision / VerifySignature
+ * (viewchanger.go:598, 660, 718, 983, 1022, 1076). */
+int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap);
+
+/* Same, on device-resident buffers, asynchronous on `hip_stream` (a hipStream_t; NULL = the
+ * default stream).  d_tuples: n*160 bytes, 16-byte aligned.  d_bitmap: ceil(n/8) bytes.
+ * The caller synchronises the stream.  Used by bench.py / multi-GPU shards. */
+int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, void* hip_stream);
+
+/* Strict DER parse of an ECDSA-Sig-Value with Go x/crypto/cryptobyte rules
+ * (crypto/ecdsa.parseSignature): out = r | s, 32 bytes each, big-endian, zero padded.
+ * Returns SBV_OK or SBV_EPARSE (then out is all zero, which every verify rejects). */
+int sbv_p256_parse_der(const uint8_t* der, size_t len, uint8_t out_rs[64]);
+
+/* SHA-256 of n messages packed back to back (offsets[i]..offsets[i+1]) -> n*32 bytes.
+ * Host implementation used to build tuples (hash = SHA-256(Signature.Msg)). */
+int sbv_sha256_batch(const uint8_t* msgs, const uint64_t* offsets, size_t n, uint8_t* out_hashes);
+
+typedef struct sbv_timing {
+    double h2d_us;      /* host -> device copy of the tuples   (host-pointer entry only) */
+    double prep_us;     /* stage A kernel (range checks, s^-1, u1, u2)                   */
+    double verify_us;   /* stage B kernel (u1*G + u2*Q, final comparison)                */
+    double d2h_us;      /* bitmap device -> host                                          */
+    double total_us;    /* wall clock of the whole call                                   */
+    uint64_t n;         /* tuples in the call                                             */
+} sbv_timing;
+/* Timing of the most recent sbv_p256_verify_batch call made by any thread. */
+int sbv_last_timing(sbv_timing* out);
+
+/* Per-kernel timing of the device-pointer entry (bench.py's roofline leg).  While enabled,
+ * every sbv_p256_verify_batch_dev call records HIP events around its two kernels ON THE
+ * CALLER'S STREAM; sbv_profile_read waits for them and returns the sums (microseconds) and the
+ * number of stage-B launches since the previous read. */
+int sbv_profile_enable(int on);
+int sbv_profile_read(double* prep_us, double* verify_us, uint64_t* launches);
+
+/* Human-readable description of the last failure in this process ("" if none). */
+const char* sbv_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBV_H_ */

@@ -1,0 +1,69 @@
+// emul.cc — CPU TEST TIER ONLY: lane-by-lane emulation of the device algorithm.
+//
+// Compiles the very headers the gfx950 kernels are built from (consensus_amd/csrc/p256_*.h)
+// with g++ and runs stage A (prep_chunk, with the same thread -> tuple mapping as the
+// kernel) and stage B (verify_lane) sequentially, so the build container (no GPU) can diff
+// the device algorithm against the oracle and the golden vectors.  It is NOT part of
+// libsbv.so, is never shipped and is not a fallback: the product fails loudly without a GPU.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../../consensus_amd/csrc/p256_core.h"
+
+using namespace sbv;
+
+static apt* g_gtab = nullptr;
+static const apt* gtab() {
+    if (!g_gtab) {
+        g_gtab = (apt*)aligned_alloc(64, sizeof(apt) * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
+        build_gtable(g_gtab);
+    }
+    return g_gtab;
+}
+
+struct HostWords {
+    const uint8_t* tuples;
+    struct W {
+        const uint8_t* p;
+        u32 operator[](int i) const { u32 v; memcpy(&v, p + 4 * i, 4); return v; }
+    };
+    W operator()(int, size_t idx) const { return W{tuples + 160 * idx}; }
+};
+
+extern "C" {
+
+// block = threads per emulated workgroup, T = tuples per thread (chunk for Montgomery's trick)
+void sbve_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap, int block, int T) {
+    size_t cap = (n + 63) & ~(size_t)63;
+    if (cap == 0) cap = 64;
+    std::vector<u32> r(8 * cap), u1(8 * cap), u2(8 * cap), qx(8 * cap), qy(8 * cap), sm(8 * cap);
+    std::vector<uint8_t> ok(cap, 0);
+    Scratch s{r.data(), u1.data(), u2.data(), qx.data(), qy.data(), sm.data(), ok.data(), cap};
+    const size_t per_block = (size_t)block * T;
+    const size_t nblocks = (n + per_block - 1) / per_block;
+    HostWords hw{tuples};
+    for (size_t b = 0; b < nblocks; ++b)
+        for (int t = 0; t < block; ++t) prep_chunk(hw, n, s, b * per_block + t, (size_t)block, T);
+    memset(bitmap, 0, (n + 7) / 8);
+    u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB_ENTRIES * 40 * 4);
+    for (size_t i = 0; i < n; ++i)
+        if (verify_lane(s, i, qtab, gtab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+    free(qtab);
+}
+
+// ---- unit hooks (plain little-endian limb arrays) ---------------------------------------------------
+void sbve_fe_mul(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe_mul(z, x, y); memcpy(out, &z, 32); }
+void sbve_fe_sqr(const u32* a, u32* out) { fe x, z; memcpy(&x, a, 32); fe_sqr(z, x); memcpy(out, &z, 32); }
+void sbve_fe_add(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe_add(z, x, y); memcpy(out, &z, 32); }
+void sbve_fe_sub(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe_sub(z, x, y); memcpy(out, &z, 32); }
+void sbve_fe_inv(const u32* a, u32* out) { fe x, z; memcpy(&x, a, 32); fe_inv(z, x); memcpy(out, &z, 32); }
+void sbve_mul_wide(const u32* a, const u32* b, u32* out16) { mul_wide(out16, a, b); }
+void sbve_sqr_wide(const u32* a, u32* out16) { sqr_wide(out16, a); }
+void sbve_mont_reduce(const u32* t16, u32* out) { fe z; fe_mont_reduce(z, t16); memcpy(out, &z, 32); }
+void sbve_sc_mul(const u32* a, const u32* b, u32* out) { sc x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); sc_mul(z, x, y); memcpy(out, &z, 32); }
+void sbve_sc_inv(const u32* a, u32* out) { sc x, z; memcpy(&x, a, 32); sc_inv(z, x); memcpy(out, &z, 32); }
+// affine Montgomery-form G-table entry (j, k): 16 dwords
+void sbve_gtab_entry(int j, int k, u32* out16) { memcpy(out16, &gtab()[(size_t)j * SBV_GTAB_PER_WINDOW + (k - 1)], 64); }
+
+}  // extern "C"

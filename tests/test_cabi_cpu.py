@@ -1,0 +1,88 @@
+"""CPU tier for the product boundary: libsbv.so loads, exports every symbol include/sbv.h
+declares, its host-side logic (DER, SHA-256) matches the twin, and — with no GPU in the
+container — every compute entry point fails loudly instead of falling back to a CPU path."""
+import ctypes
+import hashlib
+import os
+import random
+import re
+
+import pytest
+
+import consensus_amd as sbv
+import p256_py as ec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "sbv.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sbv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = sbv.load()
+    names = declared_symbols()
+    assert {"sbv_init", "sbv_shutdown", "sbv_device_count", "sbv_p256_verify_batch", "sbv_p256_verify_batch_dev",
+            "sbv_p256_parse_der", "sbv_sha256_batch", "sbv_last_timing", "sbv_last_error"} <= set(names)
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_product_library_does_not_link_the_oracle():
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", sbv.LIB_PATH]).decode()
+    assert "sbvo_" not in out and "sbvssl_" not in out and "sbve_" not in out
+    ldd = subprocess.check_output(["readelf", "-d", sbv.LIB_PATH]).decode()
+    assert "oracle" not in ldd and "libcrypto" not in ldd
+
+
+def test_parse_der_matches_go_rules(golden_vectors):
+    rng = random.Random(21)
+    sigs = [bytes.fromhex(v["sig"]) for v in golden_vectors if v["kind"] == "asn1"]
+    base = [s for s in sigs if ec.parse_der_sig(s) is not None]
+    for _ in range(4000):
+        b = bytearray(rng.choice(base))
+        op = rng.randrange(4)
+        if op == 0 and b:
+            b[rng.randrange(len(b))] = rng.randrange(256)
+        elif op == 1 and b:
+            del b[rng.randrange(len(b))]
+        elif op == 2:
+            b.insert(rng.randrange(len(b) + 1), rng.randrange(256))
+        else:
+            b = b[:rng.randrange(len(b) + 1)]
+        sigs.append(bytes(b))
+    for sig in sigs:
+        got = sbv.parse_der(sig)
+        want = ec.parse_der_sig(sig)
+        if want is None or len(want[0]) > 32 or len(want[1]) > 32:
+            assert got is None, sig.hex()
+        else:
+            assert got == want[0].rjust(32, b"\0") + want[1].rjust(32, b"\0"), sig.hex()
+
+
+def test_sha256_batch_matches_hashlib():
+    rng = random.Random(22)
+    msgs = [bytes(rng.randrange(256) for _ in range(n)) for n in [0, 1, 55, 56, 63, 64, 65, 119, 120, 300, 4096]]
+    out = sbv.sha256_batch(msgs)
+    for i, m in enumerate(msgs):
+        assert out[32 * i:32 * i + 32] == hashlib.sha256(m).digest()
+
+
+def _has_gpu():
+    try:
+        return sbv.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful where no GPU is visible")
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    with pytest.raises(sbv.SbvError) as ei:
+        sbv.init(0)
+    assert ei.value.code == -1                      # SBV_ENODEV
+    with pytest.raises(sbv.SbvError) as ei:
+        sbv.verify_batch(bytes(160), 1)
+    assert ei.value.code == -5                      # SBV_ENOTINIT

@@ -1,0 +1,147 @@
+"""CPU tier: the device algorithm (consensus_amd/csrc/p256_*.h compiled by g++ into tests/emul)
+diffed against Python big ints, the oracle and the golden vectors.  This is how the kernels'
+arithmetic is debugged in the build container (no GPU); the `-m gpu` tests then run the same
+checks through the real HIP kernels via the C-ABI."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+import p256_py as ec
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P, N = ec.P, ec.N
+R = 1 << 256
+
+
+@pytest.fixture(scope="module")
+def emul():
+    src = os.path.join(HERE, "emul", "emul.cc")
+    so = os.path.join(HERE, "emul", "libsbv_emul.so")
+    csrc = os.path.join(HERE, "..", "consensus_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-misleading-indentation",
+                               src, "-o", so])
+    lib = ctypes.CDLL(so)
+    lib.sbve_p256_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    return lib
+
+
+def limbs(x):
+    return (ctypes.c_uint32 * 8)(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+
+
+def val(arr):
+    return sum(int(v) << (32 * i) for i, v in enumerate(arr))
+
+
+def edge_values(m):
+    vals = [0, 1, 2, m - 1, m - 2, (m - 1) // 2, 2**32 - 1, 2**32, 2**64 - 1, 2**96, 2**128 - 1, 2**192, 2**224 - 1,
+            2**255 % m, (2**256 - 1) % m, 0xFFFFFFFF00000000FFFFFFFF00000000FFFFFFFF00000000FFFFFFFF00000000 % m,
+            0x00000000FFFFFFFF00000000FFFFFFFF00000000FFFFFFFF00000000FFFFFFFF % m, R % m, (R * R) % m]
+    return vals
+
+
+def test_fe_mul_sqr_add_sub_match_bigint(emul):
+    rng = random.Random(11)
+    vals = edge_values(P) + [rng.randrange(P) for _ in range(400)]
+    rinv = pow(R, -1, P)
+    out = (ctypes.c_uint32 * 8)()
+    for i, a in enumerate(vals):
+        emul.sbve_fe_sqr(limbs(a), out)
+        assert val(out) == a * a * rinv % P, hex(a)
+        for b in (vals[(i * 7 + 3) % len(vals)], vals[(i * 13 + 5) % len(vals)]):
+            emul.sbve_fe_mul(limbs(a), limbs(b), out)
+            assert val(out) == a * b * rinv % P, (hex(a), hex(b))
+            emul.sbve_fe_add(limbs(a), limbs(b), out)
+            assert val(out) == (a + b) % P
+            emul.sbve_fe_sub(limbs(a), limbs(b), out)
+            assert val(out) == (a - b) % P
+
+
+def test_wide_products_and_reduction_match_bigint(emul):
+    rng = random.Random(12)
+    vals = edge_values(P) + [2**256 - 1, 2**256 - 2**32, 2**255] + [rng.randrange(R) for _ in range(300)]
+    out16 = (ctypes.c_uint32 * 16)()
+    out = (ctypes.c_uint32 * 8)()
+    rinv = pow(R, -1, P)
+    for i, a in enumerate(vals):
+        b = vals[(i * 5 + 1) % len(vals)]
+        emul.sbve_mul_wide(limbs(a), limbs(b), out16)
+        assert val(out16) == a * b
+        emul.sbve_sqr_wide(limbs(a), out16)
+        assert val(out16) == a * a
+    # reduction on arbitrary T < p * 2^256 (including values no product can reach)
+    for _ in range(2000):
+        t = rng.randrange(P * R)
+        if rng.random() < 0.2:
+            t = (rng.randrange(P) << 256) | rng.choice([0, 1, R - 1, R - 2**224, 2**96 - 1])
+        arr = (ctypes.c_uint32 * 16)(*[(t >> (32 * i)) & 0xFFFFFFFF for i in range(16)])
+        emul.sbve_mont_reduce(arr, out)
+        assert val(out) == t * rinv % P, hex(t)
+
+
+def test_fe_inv_and_sc_ops_match_bigint(emul):
+    rng = random.Random(13)
+    out = (ctypes.c_uint32 * 8)()
+    for a in [1, 2, P - 1, R % P] + [rng.randrange(1, P) for _ in range(20)]:
+        emul.sbve_fe_inv(limbs(a), out)          # Montgomery in, Montgomery out
+        x = a * pow(R, -1, P) % P
+        assert val(out) == pow(x, -1, P) * R % P
+    rinv = pow(R, -1, N)
+    vals = edge_values(N) + [rng.randrange(N) for _ in range(300)]
+    for i, a in enumerate(vals):
+        b = vals[(i * 3 + 2) % len(vals)]
+        emul.sbve_sc_mul(limbs(a), limbs(b), out)
+        assert val(out) == a * b * rinv % N
+    for a in [1, 2, N - 1, R % N] + [rng.randrange(1, N) for _ in range(20)]:
+        emul.sbve_sc_inv(limbs(a), out)
+        x = a * rinv % N
+        assert val(out) == pow(x, -1, N) * R % N
+
+
+def test_gtable_entries(emul):
+    out = (ctypes.c_uint32 * 16)()
+    rinv = pow(R, -1, P)
+    for j, k in [(0, 1), (0, 2), (0, 3), (0, 128), (1, 1), (1, 77), (15, 128), (31, 1), (31, 128), (32, 1)]:
+        emul.sbve_gtab_entry(j, k, out)
+        x = val(out[0:8]) * rinv % P
+        y = val(out[8:16]) * rinv % P
+        want = ec.pt_mul(k * (1 << (8 * j)) % N, ec.G)
+        assert (x, y) == want, (j, k)
+
+
+def _bitmap_list(bm, n):
+    return [bool((bm[i >> 3] >> (i & 7)) & 1) for i in range(n)]
+
+
+def test_golden_tuple_vectors_through_device_algorithm(emul, golden_vectors):
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+    for block, T in [(64, 1), (64, 4), (16, 3)]:
+        bm = ctypes.create_string_buffer((len(vs) + 7) // 8)
+        emul.sbve_p256_verify_batch(blob, len(vs), bm, block, T)
+        got = _bitmap_list(bm.raw, len(vs))
+        for v, g in zip(vs, got):
+            assert g == v["accept"], (v["name"], block, T)
+
+
+def test_random_batch_matches_oracle(emul, oracle):
+    n = 1500      # deliberately not a multiple of anything
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0x1234, n, 17, 5, tup, exp, 4)
+    bm = ctypes.create_string_buffer((n + 7) // 8)
+    emul.sbve_p256_verify_batch(tup.raw, n, bm, 64, 8)
+    assert bm.raw == exp.raw
+    # random garbage tuples: all rejected, no crash
+    rng = random.Random(5)
+    junk = bytes(rng.randrange(256) for _ in range(160 * 64))
+    bm = ctypes.create_string_buffer(8)
+    emul.sbve_p256_verify_batch(junk, 64, bm, 64, 2)
+    ob = ctypes.create_string_buffer(8)
+    oracle.sbvo_p256_verify_batch(junk, 64, ob, 1)
+    assert bm.raw == ob.raw == bytes(8)

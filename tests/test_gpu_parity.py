@@ -1,0 +1,141 @@
+"""GPU tier (`-m gpu`): the HIP path, called through the C-ABI (include/sbv.h), against the
+oracle on the same inputs.  Bit-exact: the accept bitmap must equal the oracle's byte for byte.
+
+The reference's own tests pin only control flow at this seam; these tests pin the
+arithmetic: golden vectors (tests/golden), seeded synthetic batches at ragged sizes, and the
+full 2^20 batch of BASELINE.json config[1]."""
+import ctypes
+import hashlib
+import os
+import random
+
+import pytest
+
+import consensus_amd as sbv
+import p256_py as ec
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    sbv.init(0)          # raises (loudly) when the HIP library or a gfx950 device is missing
+    yield sbv
+    sbv.shutdown()
+
+
+def _expect(oracle, tuples: bytes, n: int, threads: int = 0) -> bytes:
+    bm = ctypes.create_string_buffer(max(1, (n + 7) // 8))
+    oracle.sbvo_p256_verify_batch(tuples, n, bm, threads or (os.cpu_count() or 1))
+    return bm.raw[:(n + 7) // 8]
+
+
+def test_golden_tuple_vectors(gpu, golden_vectors):
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+    got = sbv.bitmap_to_list(gpu.verify_batch(blob), len(vs))
+    bad = [v["name"] for v, g in zip(vs, got) if g != v["accept"]]
+    assert not bad, bad
+
+
+def test_golden_asn1_vectors_via_parse_der(gpu, golden_vectors):
+    """VerifyASN1-level vectors: host DER parse + hash truncation, then the kernel."""
+    vs = [v for v in golden_vectors if v["kind"] == "asn1"]
+    tuples = []
+    for v in vs:
+        rs = gpu.parse_der(bytes.fromhex(v["sig"])) or bytes(64)   # parse failure -> r = s = 0
+        h = bytes.fromhex(v["hash"])
+        h32 = h[:32] if len(h) >= 32 else bytes(32 - len(h)) + h
+        tuples.append(rs + h32 + bytes.fromhex(v["qx"]) + bytes.fromhex(v["qy"]))
+    got = sbv.bitmap_to_list(gpu.verify_batch(b"".join(tuples)), len(vs))
+    bad = [v["name"] for v, g in zip(vs, got) if g != v["accept"]]
+    assert not bad, bad
+
+
+def test_rfc6979_known_answers(gpu, rfc6979):
+    qx, qy = bytes.fromhex(rfc6979["qx"]), bytes.fromhex(rfc6979["qy"])
+    tuples = []
+    for sig in rfc6979["signatures"]:
+        h = bytes.fromhex(sig["hash"])
+        h32 = h[:32] if len(h) >= 32 else bytes(32 - len(h)) + h
+        tuples.append(bytes.fromhex(sig["r"]) + bytes.fromhex(sig["s"]) + h32 + qx + qy)
+    n = len(tuples)
+    assert gpu.verify_batch(b"".join(tuples)) == bytes([0xFF] * (n // 8)) + (bytes([(1 << (n % 8)) - 1]) if n % 8 else b"")
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 63, 64, 65, 255, 256, 257, 1000, 4097, 20000])
+def test_ragged_sizes_match_oracle(gpu, oracle, n):
+    if n == 0:
+        assert gpu.verify_batch(b"", 0) == b""
+        return
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0xA000 + n, n, 33, 3, tup, exp, os.cpu_count() or 1)
+    got = gpu.verify_batch(tup.raw, n)
+    assert got == exp.raw[:(n + 7) // 8]
+    assert got == _expect(oracle, tup.raw, n)
+
+
+def test_garbage_and_all_invalid(gpu, oracle):
+    rng = random.Random(99)
+    n = 3000
+    junk = bytes(rng.getrandbits(8) for _ in range(160 * n))
+    assert gpu.verify_batch(junk, n) == _expect(oracle, junk, n) == bytes((n + 7) // 8)
+    zeros = bytes(160 * 100)
+    assert gpu.verify_batch(zeros, 100) == bytes(13)
+    ones = b"\xff" * (160 * 100)
+    assert gpu.verify_batch(ones, 100) == bytes(13)
+
+
+def test_same_key_and_same_signature_lanes(gpu, oracle):
+    """All lanes of a wavefront with identical data, and with one key (consenter-style)."""
+    n = 512
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer(n // 8)
+    oracle.sbvo_gen_batch(7, n, 1, 0, tup, exp, 4)              # one key, all valid
+    assert gpu.verify_batch(tup.raw, n) == exp.raw == b"\xff" * (n // 8)
+    same = tup.raw[:160] * n
+    assert gpu.verify_batch(same, n) == b"\xff" * (n // 8)
+
+
+def test_full_batch_2_20_bitmap_equals_generator_and_checksum(gpu, oracle):
+    """BASELINE.json config[1]: 2^20 tuples, 1024 keys, 7/8 valid + 1/8 single-bit-corrupted.
+    Full-size properties: bitmap == the generator's verdicts (oracle-checked on every corrupted
+    tuple), popcount == 7n/8, and a SHA-256 of the bitmap agrees with the oracle's own bitmap on
+    a 64 Ki-tuple slice (the oracle cannot redo 2^20 in seconds)."""
+    n = 1 << 20
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer(n // 8)
+    oracle.sbvo_gen_batch(0x5B7F2026, n, 1024, 8, tup, exp, os.cpu_count() or 1)
+    got = ctypes.create_string_buffer(n // 8)
+    gpu.verify_batch_ptr(ctypes.addressof(tup), n, ctypes.addressof(got))
+    assert got.raw == exp.raw
+    assert sum(bin(b).count("1") for b in got.raw) == n - n // 8
+    m = 1 << 16
+    sl = _expect(oracle, tup.raw[:160 * m], m)
+    assert hashlib.sha256(got.raw[:m // 8]).digest() == hashlib.sha256(sl).digest()
+    t = gpu.last_timing()
+    print(f"\n[2^20 batch] h2d {t.h2d_us:.0f} us  prep {t.prep_us:.0f} us  verify {t.verify_us:.0f} us  "
+          f"d2h {t.d2h_us:.0f} us  -> {n / (t.prep_us + t.verify_us) :.2f} M verifies/s (kernels)")
+
+
+def test_device_pointer_entry_with_torch(gpu, oracle):
+    import torch
+    n = 10000
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0xD0D0, n, 16, 4, tup, exp, os.cpu_count() or 1)
+    d_t = torch.frombuffer(bytearray(tup.raw), dtype=torch.uint8).cuda()
+    d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream()
+    gpu.verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+    stream.synchronize()
+    assert bytes(d_b.cpu().numpy().tobytes()) == exp.raw[:(n + 7) // 8]
+    # twice in a row on different streams: the internal scratch is ordered by an event
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        d_b2 = torch.zeros_like(d_b)
+        gpu.verify_batch_dev(d_t.data_ptr(), n, d_b2.data_ptr(), s2.cuda_stream)
+    gpu.verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    assert bytes(d_b2.cpu().numpy().tobytes()) == bytes(d_b.cpu().numpy().tobytes()) == exp.raw[:(n + 7) // 8]
