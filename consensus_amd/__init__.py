@@ -35,6 +35,31 @@ class Timing(ctypes.Structure):
 _lib: Optional[ctypes.CDLL] = None
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (soname
+    libamdhip64.so.7, same as /opt/rocm's).  If libsbv.so pulled in the system copy first and
+    torch were imported later, the process would hold two HIP runtimes and torch would report
+    "No HIP GPUs are available".  Loading torch's copy first (when torch is installed) makes
+    libsbv's NEEDED libamdhip64.so.7 resolve to it by soname, whatever the import order.
+    Without torch the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                      # torch already loaded its runtime; the soname match does the rest
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> ctypes.CDLL:
     """Load libsbv.so (built by __graft_entry__.build() / consensus_amd/csrc/Makefile)."""
     global _lib
@@ -43,6 +68,7 @@ def load() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                 "(the product has no CPU fallback)")
+    _preload_hip_runtime()
     lib = ctypes.CDLL(LIB_PATH)
     lib.sbv_init.argtypes = [ctypes.c_int]
     lib.sbv_p256_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]

@@ -170,41 +170,32 @@ SBV_HD void fe_mont_reduce(fe& r, const u32 t[16]) {
         m[7] = addc(m[7], (t[1] << 1) | (t[0] >> 31), c);
         m[7] -= t[0];
     }
-    // k = round((t7 + M4 + M1 - M7 - M0) / 2^32): carry from the low half, in {-2..2}
+    // k = round((t7 + M4 + M1 - M7 - M0) / 2^32): carry from the low half, in {-1..2}
     int64_t V = (int64_t)((u64)t[7] + m[4] + m[1]) - (int64_t)((u64)m[7] + m[0]);
     int32_t k = (int32_t)((V + (int64_t)0x80000000ll) >> 32);
-    u32 kp1 = (u32)(k + 1);   // 0..3
-    // acc (9 limbs) = T_hi + M
+    const u32 kp1 = (u32)(k + 1);   // 0..3, fed in as the carry-ins of the three add chains;
+                                    // the matching -1 is the borrow-in of the subtract chain
+    // acc (9 limbs) = T_hi + M + [kp1 >= 1]
     u32 acc[9];
-    u32 c = 0;
+    u32 c = kp1 >= 1u ? 1u : 0u;
     SBV_UNROLL
     for (int i = 0; i < 8; ++i) acc[i] = addc(t[8 + i], m[i], c);
     acc[8] = c;
-    // acc += M >> 64
-    c = 0;
+    // acc += (M >> 64) + [kp1 >= 2]
+    c = kp1 >= 2u ? 1u : 0u;
     SBV_UNROLL
     for (int i = 0; i < 6; ++i) acc[i] = addc(acc[i], m[i + 2], c);
     acc[6] = addc(acc[6], 0u, c);
     acc[7] = addc(acc[7], 0u, c);
     acc[8] += c;
-    // acc += W, W = (M >> 160) + (k + 1)  (4 limbs)
-    {
-        u32 cw = 0;
-        const u32 w0 = addc(m[5], kp1, cw);
-        const u32 w1 = addc(m[6], 0u, cw);
-        const u32 w2 = addc(m[7], 0u, cw);
-        const u32 w3 = cw;
-        c = 0;
-        acc[0] = addc(acc[0], w0, c);
-        acc[1] = addc(acc[1], w1, c);
-        acc[2] = addc(acc[2], w2, c);
-        acc[3] = addc(acc[3], w3, c);
-        acc[4] = addc(acc[4], 0u, c);
-        acc[5] = addc(acc[5], 0u, c);
-        acc[6] = addc(acc[6], 0u, c);
-        acc[7] = addc(acc[7], 0u, c);
-        acc[8] += c;
-    }
+    // acc += (M >> 160) + [kp1 >= 3]
+    c = kp1 >= 3u ? 1u : 0u;
+    acc[0] = addc(acc[0], m[5], c);
+    acc[1] = addc(acc[1], m[6], c);
+    acc[2] = addc(acc[2], m[7], c);
+    SBV_UNROLL
+    for (int i = 3; i < 8; ++i) acc[i] = addc(acc[i], 0u, c);
+    acc[8] += c;
     // acc -= (M >> 32) + 1
     u32 bw = 1;
     SBV_UNROLL

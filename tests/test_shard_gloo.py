@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the shard + all-gather logic.
+The per-rank verifier is a stand-in (the oracle) because the container has no GPU; on the GPU
+box the same code runs over RCCL with the HIP path (bench.py --gpus N)."""
+import ctypes
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from consensus_amd import shard  # noqa: E402
+
+
+def test_shard_bounds_cover_and_align():
+    for n in [0, 1, 511, 512, 513, 1000, 4096, 550000, 1 << 20, (1 << 20) + 7]:
+        for world in [1, 2, 3, 4, 8]:
+            prev = 0
+            for r in range(world):
+                lo, hi = shard.shard_bounds(n, world, r)
+                assert lo == prev or lo == n
+                assert lo % 512 == 0 or lo == n
+                assert hi - lo <= shard.shard_capacity_bytes(n, world) * 8
+                prev = hi
+            assert prev == n
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsbv_oracle.so"))
+    lib.sbvo_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lib.sbvo_p256_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    lib.sbvo_gen_batch(0xBEEF, n, 16, 3, tup, exp, 1)
+
+    calls = []
+
+    def stand_in(tuples, m):
+        calls.append(m)
+        bm = ctypes.create_string_buffer(max(1, (m + 7) // 8))
+        lib.sbvo_p256_verify_batch(tuples, m, bm, 1)
+        return bm.raw[:(m + 7) // 8]
+
+    full = shard.sharded_verify(tup.raw, n, verify_fn=stand_in)
+    lo, hi = shard.shard_bounds(n, world, rank)
+    out_q.put((rank, full == exp.raw[:(n + 7) // 8], calls == ([hi - lo] if hi > lo else [])))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1500, 300])
+def test_world_size_2_gloo_gathers_full_bitmap(n):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), "gathered bitmap differs from the single-process result"
+    assert all(r[2] for r in res), "a rank verified something other than exactly its shard"
