@@ -207,10 +207,10 @@ SBV_HD bool verify_lane(const Scratch& s, size_t i, u32* qtab, const apt* gtab) 
         }
     }
     for (int w = 63; w >= 0; --w) {
-        pt_dbl(R, R);
-        pt_dbl(R, R);
-        pt_dbl(R, R);
-        pt_dbl(R, R);
+        // keep ONE copy of the doubling in the instruction stream: dbl (13 KB) + add (21 KB) must
+        // stay inside the 64 KB instruction cache two CUs share; 4 inlined copies did not.
+        SBV_NOUNROLL
+        for (int t = 0; t < 4; ++t) pt_dbl(R, R);
         const int d = (int)((k2.v[w >> 3] >> ((w & 7) * 4)) & 15u) - 8;
         const int ad = d < 0 ? -d : d;
         const int idx = ad == 0 ? 0 : ad - 1;

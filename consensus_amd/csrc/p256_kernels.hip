@@ -15,6 +15,7 @@
 //
 // No MFMA: this is 256-bit modular integer arithmetic (v_mad_u64_u32 + carry chains).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "p256_core.h"
 #include "p256_kernels.h"
@@ -53,9 +54,10 @@ __global__ __launch_bounds__(kPrepLanes) void k_p256_prep(const uint8_t* __restr
     prep_chunk(words, n, s, block_first + (size_t)lane, (size_t)kPrepLanes, T);
 }
 
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify(Scratch s, size_t n, u32* __restrict__ qtab,
-                                                                 const apt* __restrict__ gtab,
-                                                                 uint8_t* __restrict__ bitmap) {
+// The stage-B body; stamped out with different register budgets (waves per SIMD) so that the
+// occupancy / spill trade-off can be A/B-tested on hardware (env SBV_VERIFY_VARIANT, default 0).
+__device__ __forceinline__ void verify_body(const Scratch& s, size_t n, u32* __restrict__ qtab,
+                                            const apt* __restrict__ gtab, uint8_t* __restrict__ bitmap) {
     const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     bool accept = false;
     if (i < n) accept = verify_lane(s, i, qtab + i * (size_t)(SBV_QTAB_ENTRIES * 40), gtab);
@@ -66,6 +68,22 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify(Scratch s, siz
         const size_t byte = (wave_first >> 3) + (size_t)lane;
         if (byte < ((n + 7) >> 3)) bitmap[byte] = (uint8_t)(m >> (8 * lane));
     }
+}
+
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify(Scratch s, size_t n, u32* __restrict__ qtab,
+                                                                 const apt* __restrict__ gtab,
+                                                                 uint8_t* __restrict__ bitmap) {
+    verify_body(s, n, qtab, gtab, bitmap);
+}
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_w2(Scratch s, size_t n, u32* __restrict__ qtab,
+                                                                       const apt* __restrict__ gtab,
+                                                                       uint8_t* __restrict__ bitmap) {
+    verify_body(s, n, qtab, gtab, bitmap);
+}
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 4) void k_p256_verify_w4(Scratch s, size_t n, u32* __restrict__ qtab,
+                                                                       const apt* __restrict__ gtab,
+                                                                       uint8_t* __restrict__ bitmap) {
+    verify_body(s, n, qtab, gtab, bitmap);
 }
 
 int prep_chunk_T(size_t n) {
@@ -89,7 +107,13 @@ hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt
                               hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned grid = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
-    hipLaunchKernelGGL(k_p256_verify, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gtab, d_bitmap);
+    static const int variant = [] { const char* e = getenv("SBV_VERIFY_VARIANT"); return e ? atoi(e) : 0; }();
+    if (variant == 2)
+        hipLaunchKernelGGL(k_p256_verify_w2, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gtab, d_bitmap);
+    else if (variant == 4)
+        hipLaunchKernelGGL(k_p256_verify_w4, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gtab, d_bitmap);
+    else
+        hipLaunchKernelGGL(k_p256_verify, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gtab, d_bitmap);
     return hipGetLastError();
 }
 

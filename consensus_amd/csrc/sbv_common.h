@@ -21,8 +21,10 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SBV_UNROLL _Pragma("unroll")
+#define SBV_NOUNROLL _Pragma("unroll 1")
 #else
 #define SBV_UNROLL
+#define SBV_NOUNROLL
 #endif
 
 namespace sbv {
