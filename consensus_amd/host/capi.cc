@@ -1,0 +1,285 @@
+// capi.cc — flat C facade over the C++ Verifier/Signer mirror (for the ctypes tests and the replay
+// driver), plus the replay routines that reproduce the reference's call pattern at the seam
+//  for BASELINE.json configs 3 and 4 and the commit-quorum latency (M2).
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <vector>
+
+#include "p256_host.h"
+#include "verifier.h"
+
+using namespace sbvhost;
+
+namespace {
+struct VHandle {
+    std::shared_ptr<Backend> be;
+    std::unique_ptr<Verifier> v;
+};
+bytes B(const void* p, size_t n) { return bytes((const char*)p, n); }
+size_t put(const bytes& s, void* out, size_t cap) {
+    if (out && s.size() <= cap) memcpy(out, s.data(), s.size());
+    return s.size();
+}
+double now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+Proposal make_prop(const void* payload, size_t pl, const void* header, size_t hl, const void* meta, size_t ml, int64_t vseq) {
+    Proposal p;
+    p.payload = B(payload, pl); p.header = B(header, hl); p.metadata = B(meta, ml); p.verification_sequence = vseq;
+    return p;
+}
+void parallel_for(size_t n, int threads, const std::function<void(size_t)>& fn) {
+    if (threads < 1) threads = 1;
+    std::atomic<size_t> next(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t)
+        th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); });
+    for (auto& t : th) t.join();
+}
+}  // namespace
+
+extern "C" {
+
+// backend_kind 0: libsbv.so on `device`; 1: callback (tests inject a stand-in, like mocks.VerifierMock)
+void* sbvh_verifier_new(int backend_kind, int device, backend_fn fn, void* user, size_t coalesce_max, int coalesce_wait_us, int cache) {
+    VHandle* h = new VHandle;
+    h->be = backend_kind == 0 ? make_sbv_backend(device) : make_callback_backend(fn, user);
+    VerifierOptions o;
+    o.coalesce_max = coalesce_max;
+    o.coalesce_wait = std::chrono::microseconds(coalesce_wait_us);
+    o.cache_verified = cache != 0;
+    h->v.reset(new Verifier(h->be, o));
+    return h;
+}
+void sbvh_verifier_free(void* h) { delete (VHandle*)h; }
+void sbvh_register_consenter(void* h, uint64_t id, const uint8_t q[64]) { ((VHandle*)h)->v->RegisterConsenter(id, q); }
+void sbvh_register_client(void* h, const char* client, const uint8_t q[64]) { ((VHandle*)h)->v->RegisterClient(client, q); }
+void sbvh_set_verification_sequence(void* h, uint64_t s) { ((VHandle*)h)->v->SetVerificationSequence(s); }
+uint64_t sbvh_verification_sequence(void* h) { return ((VHandle*)h)->v->VerificationSequence(); }
+
+// status: 0 OK (Go: nil error), 1 INVALID (Go: error), 2 UNAVAILABLE (device fault -> CPU fallback in Go)
+int sbvh_verify_signature(void* h, uint64_t id, const void* value, size_t vl, const void* msg, size_t ml) {
+    Signature s; s.id = id; s.value = B(value, vl); s.msg = B(msg, ml);
+    return ((VHandle*)h)->v->VerifySignature(s).code;
+}
+int sbvh_verify_consenter_sig(void* h, uint64_t id, const void* value, size_t vl, const void* msg, size_t ml,
+                              const void* payload, size_t pl, const void* header, size_t hl, const void* meta, size_t mtl,
+                              int64_t vseq, void* aux_out, size_t aux_cap, size_t* aux_len) {
+    Signature s; s.id = id; s.value = B(value, vl); s.msg = B(msg, ml);
+    bytes aux;
+    const Status st = ((VHandle*)h)->v->VerifyConsenterSig(s, make_prop(payload, pl, header, hl, meta, mtl, vseq), &aux);
+    if (aux_len) *aux_len = st.ok() ? put(aux, aux_out, aux_cap) : 0;
+    return st.code;
+}
+size_t sbvh_auxiliary_data(void* h, const void* msg, size_t ml, void* out, size_t cap) {
+    return put(((VHandle*)h)->v->AuxiliaryData(B(msg, ml)), out, cap);
+}
+// infos are returned as "client\0id\0" pairs
+int sbvh_verify_request(void* h, const void* raw, size_t n, void* info_out, size_t cap, size_t* info_len) {
+    RequestInfo ri;
+    const Status st = ((VHandle*)h)->v->VerifyRequest(B(raw, n), &ri);
+    bytes s = ri.client_id; s.push_back('\0'); s += ri.id; s.push_back('\0');
+    if (info_len) *info_len = st.ok() ? put(s, info_out, cap) : 0;
+    return st.code;
+}
+size_t sbvh_request_id(void* h, const void* raw, size_t n, void* info_out, size_t cap) {
+    const RequestInfo ri = ((VHandle*)h)->v->RequestID(B(raw, n));
+    bytes s = ri.client_id; s.push_back('\0'); s += ri.id; s.push_back('\0');
+    return put(s, info_out, cap);
+}
+int sbvh_verify_proposal(void* h, const void* payload, size_t pl, const void* header, size_t hl, const void* meta, size_t ml,
+                         int64_t vseq, void* infos_out, size_t cap, size_t* infos_len, size_t* count) {
+    std::vector<RequestInfo> infos;
+    const Status st = ((VHandle*)h)->v->VerifyProposal(make_prop(payload, pl, header, hl, meta, ml, vseq), &infos);
+    bytes s;
+    for (const auto& ri : infos) { s += ri.client_id; s.push_back('\0'); s += ri.id; s.push_back('\0'); }
+    if (infos_len) *infos_len = put(s, infos_out, cap);
+    if (count) *count = infos.size();
+    return st.code;
+}
+size_t sbvh_requests_from_proposal(void* h, const void* payload, size_t pl, void* infos_out, size_t cap, size_t* count) {
+    Proposal p; p.payload = B(payload, pl);
+    const auto infos = ((VHandle*)h)->v->RequestsFromProposal(p);
+    bytes s;
+    for (const auto& ri : infos) { s += ri.client_id; s.push_back('\0'); s += ri.id; s.push_back('\0'); }
+    if (count) *count = infos.size();
+    return put(s, infos_out, cap);
+}
+void sbvh_stats(void* h, uint64_t* calls, uint64_t* batches, uint64_t* max_batch) {
+    const CoalescerStats s = ((VHandle*)h)->v->stats();
+    if (calls) *calls = s.calls;
+    if (batches) *batches = s.batches;
+    if (max_batch) *max_batch = s.max_batch;
+}
+
+// ---- signer ----------------------------------------------------------------------------------------
+void* sbvh_signer_new(uint64_t id, const uint8_t sk[32]) { return new Signer(id, sk); }
+void sbvh_signer_free(void* s) { delete (Signer*)s; }
+void sbvh_signer_public_key(void* s, uint8_t q[64]) { memcpy(q, ((Signer*)s)->public_key(), 64); }
+size_t sbvh_sign(void* s, const void* msg, size_t n, void* out, size_t cap) { return put(((Signer*)s)->Sign(B(msg, n)), out, cap); }
+void sbvh_sign_proposal(void* s, const void* payload, size_t pl, const void* header, size_t hl, const void* meta, size_t ml,
+                        int64_t vseq, const void* aux, size_t al, void* msg_out, size_t msg_cap, size_t* msg_len,
+                        void* val_out, size_t val_cap, size_t* val_len) {
+    const Signature sig = ((Signer*)s)->SignProposal(make_prop(payload, pl, header, hl, meta, ml, vseq), B(aux, al));
+    *msg_len = put(sig.msg, msg_out, msg_cap);
+    *val_len = put(sig.value, val_out, val_cap);
+}
+int sbvh_sign_with_nonce(const uint8_t d[32], const uint8_t k[32], const uint8_t digest[32], uint8_t rs[64]) {
+    return sign_with_nonce(d, k, digest, rs) ? 0 : -1;
+}
+int sbvh_sign_rfc6979(const uint8_t d[32], const uint8_t digest[32], uint8_t rs[64]) { return sign_rfc6979(d, digest, rs) ? 0 : -1; }
+int sbvh_pubkey(const uint8_t d[32], uint8_t q[64]) { return pubkey_from_private(d, q) ? 0 : -1; }
+
+// ---- formats ---------------------------------------------------------------------------------------
+void sbvh_proposal_digest(const void* payload, size_t pl, const void* header, size_t hl, const void* meta, size_t ml,
+                          int64_t vseq, char hex_out[65]) {
+    const std::string d = proposal_digest(make_prop(payload, pl, header, hl, meta, ml, vseq));
+    memcpy(hex_out, d.c_str(), 65);
+}
+void sbvh_compute_quorum(uint64_t n, int* q, int* f) { compute_quorum(n, q, f); }
+
+// ---- replay: the reference's call pattern at the seam -------------------------------------------------
+struct sbvh_replay_result {
+    double setup_s;              // signing the synthetic traffic (not part of any metric)
+    double verify_proposal_us;   // median VerifyProposal (K request signatures, one backend batch)
+    double prev_commits_us;      // median serial verifyPrevCommitSignatures pass (Q-1 calls)
+    double commit_quorum_us;     // median "N-1 votes available -> Q-1 accepted" (concurrent calls, coalesced)
+    double batch_total_us;       // config 4: all proposals x Q signatures in one VerifyConsenterSigBatch
+    uint64_t batch_tuples;
+    uint64_t proposals_with_quorum;
+    uint64_t backend_batches;
+    uint64_t max_backend_batch;
+    int status;                  // 0 ok, 2 backend unavailable, 1 unexpected reject
+};
+
+static double median(std::vector<double> v) {
+    if (v.empty()) return 0;
+    std::sort(v.begin(), v.end());
+    return v[v.size() / 2];
+}
+
+// One node's view of `sequences` decisions in an n_nodes cluster with K requests per proposal
+// (config 3: n_nodes = 4, K = 10000;  config 1 shape: K = 100), through the Verifier interface:
+//   VerifyProposal(K sigs)  ->  verifyPrevCommitSignatures (Q-1 serial calls, view.go:630)
+//   -> processCommits: N-1 concurrent VerifyConsenterSig calls, wait for Q-1 (view.go:537-541, 531)
+// and, when decisions > 0, config 4: `decisions` proposals x Q signatures verified as one batch.
+int sbvh_replay(void* h, int n_nodes, int K, int sequences, int decisions, int threads, sbvh_replay_result* out) {
+    Verifier& V = *((VHandle*)h)->v;
+    memset(out, 0, sizeof *out);
+    int Q = 0, F = 0;
+    compute_quorum((uint64_t)n_nodes, &Q, &F);
+    const double t_setup = now_us();
+    std::vector<std::unique_ptr<Signer>> nodes;
+    for (int i = 0; i < n_nodes; ++i) {
+        uint8_t sk[32];
+        bytes seed = "sbv-node-" + std::to_string(i);
+        sha256(seed.data(), seed.size(), sk);
+        sk[0] &= 0x7f;
+        nodes.emplace_back(new Signer((uint64_t)i + 1, sk));
+        V.RegisterConsenter((uint64_t)i + 1, nodes.back()->public_key());
+    }
+    const int n_clients = 64;
+    std::vector<std::unique_ptr<Signer>> clients;
+    for (int i = 0; i < n_clients; ++i) {
+        uint8_t sk[32];
+        bytes seed = "sbv-client-" + std::to_string(i);
+        sha256(seed.data(), seed.size(), sk);
+        sk[0] &= 0x7f;
+        clients.emplace_back(new Signer(0, sk));
+        V.RegisterClient("client-" + std::to_string(i), clients.back()->public_key());
+    }
+    V.SetVerificationSequence(0);
+    // proposals: one per sequence, K signed requests each
+    std::vector<Proposal> props((size_t)sequences);
+    for (int s = 0; s < sequences; ++s) {
+        std::vector<bytes> reqs((size_t)K);
+        parallel_for((size_t)K, threads, [&](size_t i) {
+            const int c = (int)(i % n_clients);
+            const bytes u = request_unsigned("client-" + std::to_string(c), "req-" + std::to_string(s) + "-" + std::to_string(i),
+                                             bytes(32, (char)(i & 0xff)));
+            reqs[i] = request_encode(u, clients[(size_t)c]->Sign(u));
+        });
+        props[(size_t)s].payload = payload_encode(reqs);
+        props[(size_t)s].header = "hdr-" + std::to_string(s);
+        props[(size_t)s].metadata = "md-" + std::to_string(s);
+    }
+    // commit signatures of every node on every proposal
+    std::vector<std::vector<Signature>> commits((size_t)sequences, std::vector<Signature>((size_t)n_nodes));
+    parallel_for((size_t)sequences * n_nodes, threads, [&](size_t i) {
+        const size_t s = i / n_nodes, nd = i % n_nodes;
+        commits[s][nd] = nodes[nd]->SignProposal(props[s], "prepares-from-" + std::to_string(nd));
+    });
+    // config 4 material
+    std::vector<Proposal> dprops((size_t)decisions);
+    std::vector<Signature> dsigs((size_t)decisions * Q);
+    if (decisions > 0) {
+        parallel_for((size_t)decisions, threads, [&](size_t d) {
+            dprops[d].payload = "decision-payload-" + std::to_string(d);
+            dprops[d].header = "h"; dprops[d].metadata = "m";
+            for (int j = 0; j < Q; ++j) dsigs[d * Q + j] = nodes[(d + j) % n_nodes]->SignProposal(dprops[d], "aux");
+        });
+    }
+    out->setup_s = (now_us() - t_setup) * 1e-6;
+
+    std::vector<double> t_prop, t_prev, t_quorum;
+    for (int s = 0; s < sequences; ++s) {
+        std::vector<RequestInfo> infos;
+        double t0 = now_us();
+        Status st = V.VerifyProposal(props[(size_t)s], &infos);
+        t_prop.push_back(now_us() - t0);
+        if (!st.ok() || (int)infos.size() != K) { out->status = st.code ? st.code : 1; return out->status; }
+        if (s > 0) {                      // previous decision's commit signatures, serial (view.go:630-644)
+            t0 = now_us();
+            for (int j = 0; j < Q - 1; ++j) {
+                bytes aux;
+                st = V.VerifyConsenterSig(commits[(size_t)s - 1][(size_t)j + 1], props[(size_t)s - 1], &aux);
+                if (!st.ok()) { out->status = st.code; return out->status; }
+            }
+            t_prev.push_back(now_us() - t0);
+        }
+        // N-1 concurrent votes; done when Q-1 accepted (view.go:531)
+        std::atomic<int> accepted(0), failed(0);
+        std::vector<std::thread> voters;
+        double t_done = 0;
+        std::mutex m;
+        t0 = now_us();
+        for (int nd = 1; nd < n_nodes; ++nd)
+            voters.emplace_back([&, nd] {
+                bytes aux;
+                const Status r = V.VerifyConsenterSig(commits[(size_t)s][(size_t)nd], props[(size_t)s], &aux);
+                if (r.ok()) { if (accepted.fetch_add(1) + 1 == Q - 1) { std::lock_guard<std::mutex> lk(m); t_done = now_us(); } }
+                else failed.fetch_add(1);
+            });
+        for (auto& t : voters) t.join();
+        if (failed.load() || accepted.load() < Q - 1) { out->status = 1; return 1; }
+        t_quorum.push_back(t_done - t0);
+    }
+    out->verify_proposal_us = median(t_prop);
+    out->prev_commits_us = median(t_prev);
+    out->commit_quorum_us = median(t_quorum);
+    if (decisions > 0) {
+        std::vector<const Proposal*> pp(dsigs.size());
+        for (size_t i = 0; i < dsigs.size(); ++i) pp[i] = &dprops[i / Q];
+        std::vector<uint8_t> ok;
+        const double t0 = now_us();
+        const Status st = V.VerifyConsenterSigBatch(dsigs, pp, &ok);
+        out->batch_total_us = now_us() - t0;
+        if (!st.ok()) { out->status = st.code; return out->status; }
+        out->batch_tuples = dsigs.size();
+        for (int d = 0; d < decisions; ++d) {
+            int good = 0;
+            for (int j = 0; j < Q; ++j) good += ok[(size_t)d * Q + j];
+            if (good >= Q - 1) ++out->proposals_with_quorum;
+        }
+    }
+    const CoalescerStats cs = V.stats();
+    out->backend_batches = cs.batches;
+    out->max_backend_batch = cs.max_batch;
+    return 0;
+}
+
+}  // extern "C"

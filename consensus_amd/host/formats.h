@@ -1,0 +1,55 @@
+// formats.h — value types crossing the api.Verifier seam and the signed-data formats the
+// application must fix (the reference defines none for signed data: SURVEY.md Appendix C).
+//
+//   Proposal / Signature / RequestInfo mirror pkg/types/types.go:18-29, 41-48.
+//   proposal_digest() restates Proposal.Digest() (types.go:50-69): SHA-256 over Go's
+//   encoding/asn1 DER of SEQUENCE{OCTET STRING Payload, OCTET STRING Header, OCTET STRING
+//   Metadata, INTEGER VerificationSequence}, hex encoded.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace sbvhost {
+
+typedef std::string bytes;
+
+struct Proposal {                 // pkg/types/types.go:18-23
+    bytes payload, header, metadata;
+    int64_t verification_sequence = 0;
+};
+struct Signature {                // pkg/types/types.go:25-29
+    uint64_t id = 0;
+    bytes value;                  // ASN.1 DER ECDSA-Sig-Value
+    bytes msg;                    // signed bytes; hash = SHA-256(msg)
+};
+struct RequestInfo {              // pkg/types/types.go:41-48
+    std::string client_id, id;
+    bool operator==(const RequestInfo& o) const { return client_id == o.client_id && id == o.id; }
+};
+
+bytes asn1_marshal_proposal(const Proposal& p);     // Go asn1.Marshal(Proposal{...})
+bytes proposal_digest_raw(const Proposal& p);       // 32-byte SHA-256 of the above
+std::string proposal_digest(const Proposal& p);     // hex, == Proposal.Digest()
+
+// ---- client request:  u16 len|ClientID  u16 len|ID  u32 len|payload  u16 len|sig  (big-endian lengths)
+struct Request {
+    std::string client_id, id;
+    bytes payload;
+    bytes sig;        // DER
+    bytes signed_part;  // everything before the signature length field
+};
+bytes request_unsigned(const std::string& client_id, const std::string& id, const bytes& payload);
+bytes request_encode(const bytes& unsigned_part, const bytes& sig_der);
+bool request_parse(const bytes& raw, Request* out);
+
+// ---- proposal payload:  u32 count  (u32 len | request)*
+bytes payload_encode(const std::vector<bytes>& requests);
+bool payload_split(const bytes& payload, std::vector<bytes>* out);
+
+// ---- consenter signature message:  "SBV1" | SHA-256(asn1(proposal)) | u32 len | aux
+bytes consenter_msg(const Proposal& p, const bytes& aux);
+bool consenter_msg_split(const bytes& msg, bytes* binding32, bytes* aux);
+
+}  // namespace sbvhost

@@ -1,0 +1,293 @@
+#include "verifier.h"
+
+#include <string.h>
+
+#include "../../include/sbv.h"
+#include "p256_host.h"
+
+namespace sbvhost {
+
+// ---- backends ------------------------------------------------------------------------------------
+namespace {
+class SbvBackend : public Backend {
+ public:
+    explicit SbvBackend(int device) { rc_ = sbv_init(device); }
+    int verify(const uint8_t* tuples, size_t n, uint8_t* bitmap) override {
+        if (rc_ != SBV_OK) return rc_;                 // no device: every batch is UNAVAILABLE, never a CPU guess
+        return sbv_p256_verify_batch(tuples, n, bitmap);
+    }
+ private:
+    int rc_;
+};
+class CallbackBackend : public Backend {
+ public:
+    CallbackBackend(backend_fn fn, void* user) : fn_(fn), user_(user) {}
+    int verify(const uint8_t* tuples, size_t n, uint8_t* bitmap) override { return fn_(tuples, n, bitmap, user_); }
+ private:
+    backend_fn fn_;
+    void* user_;
+};
+}  // namespace
+std::shared_ptr<Backend> make_sbv_backend(int device) { return std::make_shared<SbvBackend>(device); }
+std::shared_ptr<Backend> make_callback_backend(backend_fn fn, void* user) { return std::make_shared<CallbackBackend>(fn, user); }
+
+// ---- coalescer -----------------------------------------------------------------------------------
+Coalescer::Coalescer(std::shared_ptr<Backend> be, size_t max_batch, std::chrono::microseconds max_wait)
+    : be_(be), max_batch_(max_batch ? max_batch : 1), max_wait_(max_wait), th_([this] { run(); }) {}
+
+Coalescer::~Coalescer() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_job_.notify_all();
+    th_.join();
+}
+
+int Coalescer::submit(const uint8_t tuple[160]) {
+    Job j;
+    memcpy(j.tuple, tuple, 160);
+    std::unique_lock<std::mutex> lk(mu_);
+    q_.push_back(&j);
+    ++st_.calls;
+    cv_job_.notify_one();
+    cv_done_.wait(lk, [&] { return j.done; });
+    return j.result;
+}
+
+int Coalescer::submit_many(const uint8_t* tuples, size_t n, uint8_t* bitmap) {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        ++st_.batches;
+        if (n > st_.max_batch) st_.max_batch = n;
+    }
+    return be_->verify(tuples, n, bitmap);      // the backend serialises device work itself
+}
+
+CoalescerStats Coalescer::stats() {
+    std::lock_guard<std::mutex> lk(mu_);
+    return st_;
+}
+
+void Coalescer::run() {
+    std::vector<Job*> batch;
+    std::vector<uint8_t> tuples, bitmap;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_job_.wait(lk, [&] { return stop_ || !q_.empty(); });
+            if (stop_ && q_.empty()) return;
+            // first job is here: give concurrent callers a short window to join the batch
+            const auto deadline = std::chrono::steady_clock::now() + max_wait_;
+            while (q_.size() < max_batch_ && !stop_) {
+                if (cv_job_.wait_until(lk, deadline) == std::cv_status::timeout) break;
+            }
+            batch.clear();
+            while (!q_.empty() && batch.size() < max_batch_) { batch.push_back(q_.front()); q_.pop_front(); }
+            ++st_.batches;
+            if (batch.size() > st_.max_batch) st_.max_batch = batch.size();
+        }
+        const size_t n = batch.size();
+        tuples.resize(n * 160);
+        bitmap.assign((n + 7) / 8, 0);
+        for (size_t i = 0; i < n; ++i) memcpy(&tuples[i * 160], batch[i]->tuple, 160);
+        const int rc = be_->verify(tuples.data(), n, bitmap.data());
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t i = 0; i < n; ++i) {
+                batch[i]->result = rc != 0 ? (rc < 0 ? rc : -1) : ((bitmap[i >> 3] >> (i & 7)) & 1);
+                batch[i]->done = true;
+            }
+        }
+        cv_done_.notify_all();
+    }
+}
+
+// ---- verifier ------------------------------------------------------------------------------------
+Verifier::Verifier(std::shared_ptr<Backend> be, const VerifierOptions& opt)
+    : opt_(opt), co_(be, opt.coalesce_max, opt.coalesce_wait) {}
+
+void Verifier::RegisterConsenter(uint64_t id, const uint8_t q[64]) {
+    std::lock_guard<std::mutex> lk(mu_);
+    consenters_[id] = bytes((const char*)q, 64);
+}
+void Verifier::RegisterClient(const std::string& client_id, const uint8_t q[64]) {
+    std::lock_guard<std::mutex> lk(mu_);
+    clients_[client_id] = bytes((const char*)q, 64);
+}
+void Verifier::SetVerificationSequence(uint64_t s) { std::lock_guard<std::mutex> lk(mu_); seq_ = s; }
+uint64_t Verifier::VerificationSequence() { std::lock_guard<std::mutex> lk(mu_); return seq_; }
+
+bool Verifier::consenter_key(uint64_t id, uint8_t q[64]) {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = consenters_.find(id);
+    if (it == consenters_.end()) return false;
+    memcpy(q, it->second.data(), 64);
+    return true;
+}
+bool Verifier::client_key(const std::string& id, uint8_t q[64]) {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = clients_.find(id);
+    if (it == clients_.end()) return false;
+    memcpy(q, it->second.data(), 64);
+    return true;
+}
+
+// r|s|hash|Qx|Qy.  A DER failure leaves r = s = 0, which the kernel's range check rejects — the
+// same verdict crypto/ecdsa.VerifyASN1 gives, without a second code path.
+void Verifier::make_tuple(const uint8_t q[64], const bytes& msg, const bytes& sig_der, uint8_t out[160]) {
+    sbv_p256_parse_der((const uint8_t*)sig_der.data(), sig_der.size(), out);
+    sha256(msg.data(), msg.size(), out + 64);
+    memcpy(out + 96, q, 64);
+}
+
+Status Verifier::verify_one(const uint8_t q[64], const bytes& msg, const bytes& sig) {
+    std::string key;
+    if (opt_.cache_verified) {
+        bytes cat((const char*)q, 64);
+        cat += sig; cat += msg;
+        key = sha256(cat);
+        std::lock_guard<std::mutex> lk(cache_mu_);
+        auto it = cache_.find(key);
+        if (it != cache_.end()) return it->second ? Status::Ok() : Status::Invalid("invalid signature (cached)");
+    }
+    uint8_t t[160];
+    make_tuple(q, msg, sig, t);
+    const int r = co_.submit(t);
+    if (r < 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());
+    if (opt_.cache_verified) {
+        std::lock_guard<std::mutex> lk(cache_mu_);
+        if (cache_.size() > (1u << 20)) cache_.clear();
+        cache_[key] = r == 1;
+    }
+    return r == 1 ? Status::Ok() : Status::Invalid("invalid signature");
+}
+
+Status Verifier::VerifySignature(const Signature& s) {        // viewchanger.go:598, 660, 983, 1022, 1076
+    uint8_t q[64];
+    if (!consenter_key(s.id, q)) return Status::Invalid("unknown signer");
+    return verify_one(q, s.msg, s.value);
+}
+
+Status Verifier::VerifyConsenterSig(const Signature& s, const Proposal& prop, bytes* aux) {   // view.go:631, 834
+    bytes binding, a;
+    if (!consenter_msg_split(s.msg, &binding, &a)) return Status::Invalid("malformed signature message");
+    if (binding != proposal_digest_raw(prop)) return Status::Invalid("signature message does not match proposal");
+    Status st = VerifySignature(s);
+    if (!st.ok()) return st;
+    if (aux) *aux = a;
+    return Status::Ok();
+}
+
+bytes Verifier::AuxiliaryData(const bytes& msg) {               // view.go:1029, 1071 — no verification
+    bytes a;
+    consenter_msg_split(msg, nullptr, &a);
+    return a;
+}
+
+RequestInfo Verifier::RequestID(const bytes& raw) {
+    Request r;
+    RequestInfo info;
+    if (request_parse(raw, &r)) { info.client_id = r.client_id; info.id = r.id; }
+    return info;
+}
+
+Status Verifier::VerifyRequest(const bytes& raw, RequestInfo* info) {   // controller.go:239, :742-745
+    Request r;
+    if (!request_parse(raw, &r)) return Status::Invalid("malformed request");
+    uint8_t q[64];
+    if (!client_key(r.client_id, q)) return Status::Invalid("unknown client");
+    Status st = verify_one(q, r.signed_part, r.sig);
+    if (!st.ok()) return st;
+    if (info) { info->client_id = r.client_id; info->id = r.id; }
+    return Status::Ok();
+}
+
+std::vector<RequestInfo> Verifier::RequestsFromProposal(const Proposal& p) {   // view.go:395, 419
+    std::vector<RequestInfo> out;
+    std::vector<bytes> reqs;
+    if (!payload_split(p.payload, &reqs)) return out;
+    for (const bytes& raw : reqs) out.push_back(RequestID(raw));
+    return out;
+}
+
+// All K request signatures of the proposal in ONE backend batch (view.go:555).
+Status Verifier::VerifyProposal(const Proposal& p, std::vector<RequestInfo>* requests) {
+    std::vector<bytes> reqs;
+    if (!payload_split(p.payload, &reqs)) return Status::Invalid("malformed proposal payload");
+    if ((uint64_t)p.verification_sequence != VerificationSequence()) return Status::Invalid("verification sequence mismatch");
+    const size_t n = reqs.size();
+    std::vector<uint8_t> tuples(n * 160), bitmap((n + 7) / 8, 0);
+    std::vector<RequestInfo> infos(n);
+    for (size_t i = 0; i < n; ++i) {
+        Request r;
+        if (!request_parse(reqs[i], &r)) return Status::Invalid("malformed request in proposal");
+        uint8_t q[64];
+        if (!client_key(r.client_id, q)) return Status::Invalid("unknown client in proposal");
+        make_tuple(q, r.signed_part, r.sig, &tuples[i * 160]);
+        infos[i].client_id = r.client_id;
+        infos[i].id = r.id;
+    }
+    if (n) {
+        const int rc = co_.submit_many(tuples.data(), n, bitmap.data());
+        if (rc != 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());
+        for (size_t i = 0; i < n; ++i)
+            if (!((bitmap[i >> 3] >> (i & 7)) & 1)) return Status::Invalid("invalid request signature in proposal");
+    }
+    if (requests) *requests = infos;
+    return Status::Ok();
+}
+
+Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, const std::vector<const Proposal*>& props,
+                                         std::vector<uint8_t>* out) {
+    const size_t n = sigs.size();
+    if (props.size() != n) return Status::Invalid("size mismatch");
+    std::vector<uint8_t> tuples(n * 160, 0), bitmap((n + 7) / 8, 0), pre(n, 1);
+    const Proposal* last = nullptr;
+    bytes last_digest;
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t q[64];
+        bytes binding;
+        if (props[i] != last) { last = props[i]; last_digest = proposal_digest_raw(*last); }
+        if (!consenter_key(sigs[i].id, q) || !consenter_msg_split(sigs[i].msg, &binding, nullptr) || binding != last_digest) {
+            pre[i] = 0;                 // tuple stays all-zero: rejected by the range check as well
+            continue;
+        }
+        make_tuple(q, sigs[i].msg, sigs[i].value, &tuples[i * 160]);
+    }
+    if (n) {
+        const int rc = co_.submit_many(tuples.data(), n, bitmap.data());
+        if (rc != 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());
+    }
+    out->assign(n, 0);
+    for (size_t i = 0; i < n; ++i) (*out)[i] = pre[i] && ((bitmap[i >> 3] >> (i & 7)) & 1);
+    return Status::Ok();
+}
+
+// ---- signer --------------------------------------------------------------------------------------
+Signer::Signer(uint64_t id, const uint8_t private_key[32]) : id_(id) {
+    memcpy(d_, private_key, 32);
+    memset(q_, 0, 64);
+    pubkey_from_private(d_, q_);
+}
+bytes Signer::Sign(const bytes& msg) {
+    uint8_t h[32], rs[64];
+    sha256(msg.data(), msg.size(), h);
+    if (!sign_rfc6979(d_, h, rs)) return bytes();
+    return der_encode_sig(rs);
+}
+Signature Signer::SignProposal(const Proposal& proposal, const bytes& auxiliary_input) {    // view.go:481
+    Signature s;
+    s.id = id_;
+    s.msg = consenter_msg(proposal, auxiliary_input);
+    s.value = Sign(s.msg);
+    return s;
+}
+
+void compute_quorum(uint64_t n, int* q, int* f) {
+    const int ff = ((int)n - 1) / 3;
+    if (f) *f = ff;
+    if (q) *q = (int)(((int)n + ff + 1 + 1) / 2);     // ceil((n + f + 1) / 2)
+}
+
+}  // namespace sbvhost

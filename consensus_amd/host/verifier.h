@@ -1,0 +1,146 @@
+// verifier.h — C++ mirror of the reference's plugin pair for this path:
+//   api.Verifier  pkg/api/dependencies.go:54-71   (same method names, argument meaning, error behaviour)
+//   api.Signer    pkg/api/dependencies.go:46-52
+// written in C++ because the reference is compiled code and this image has no Go toolchain; the Go
+// cgo adapter a maintainer would add is in INTEGRATION.md and has exactly this structure.
+//
+// Error behaviour: Go's `error == nil` <=> Status::OK.  Status::INVALID is the Go `error` the
+// protocol acts on (vote dropped: internal/bft/view.go:839-842; proposal rejected and leader accused:
+// view.go:387-392; request not pooled: controller.go:239-245).  Status::UNAVAILABLE means the
+// backend could not answer (device fault, library missing): the Go adapter then verifies with stock
+// crypto/ecdsa — this C++ mirror has no CPU verifier on purpose and surfaces the condition instead
+// of ever turning it into INVALID.
+#pragma once
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
+
+#include "formats.h"
+
+namespace sbvhost {
+
+struct Status {
+    enum Code { OK = 0, INVALID = 1, UNAVAILABLE = 2 } code = OK;
+    std::string msg;
+    bool ok() const { return code == OK; }
+    static Status Ok() { return Status(); }
+    static Status Invalid(const std::string& m) { Status s; s.code = INVALID; s.msg = m; return s; }
+    static Status Unavailable(const std::string& m) { Status s; s.code = UNAVAILABLE; s.msg = m; return s; }
+};
+
+// What sits below the seam: n tuples -> accept bitmap; returns 0 or a negative infrastructure error
+// (include/sbv.h convention).  The product backend is libsbv.so; tests may inject a stand-in, the
+// way the reference's own tests inject mocks.VerifierMock (internal/bft/mocks/verifier_mock.go).
+class Backend {
+ public:
+    virtual ~Backend() {}
+    virtual int verify(const uint8_t* tuples, size_t n, uint8_t* bitmap) = 0;
+};
+std::shared_ptr<Backend> make_sbv_backend(int device);     // sbv_init(device) + sbv_p256_verify_batch
+typedef int (*backend_fn)(const uint8_t* tuples, size_t n, uint8_t* bitmap, void* user);
+std::shared_ptr<Backend> make_callback_backend(backend_fn fn, void* user);
+
+struct CoalescerStats {
+    uint64_t calls = 0;        // single-signature submissions
+    uint64_t batches = 0;      // backend invocations
+    uint64_t max_batch = 0;
+};
+
+// Collects concurrent single-tuple submissions into one backend batch: a dispatcher thread takes the
+// first pending tuple, waits up to `max_wait` for more (or until `max_batch`), and ships them in one
+// call.  This is what turns the <= N-1 goroutines of View.processCommits (view.go:537-541) into one
+// GPU micro-batch.  submit_many() bypasses the wait (a VerifyProposal already is a batch).
+class Coalescer {
+ public:
+    Coalescer(std::shared_ptr<Backend> be, size_t max_batch, std::chrono::microseconds max_wait);
+    ~Coalescer();
+    // 1 = accept, 0 = reject, <0 = backend error
+    int submit(const uint8_t tuple[160]);
+    int submit_many(const uint8_t* tuples, size_t n, uint8_t* bitmap);
+    CoalescerStats stats();
+
+ private:
+    struct Job { uint8_t tuple[160]; int result = -100; bool done = false; };
+    void run();
+    std::shared_ptr<Backend> be_;
+    size_t max_batch_;
+    std::chrono::microseconds max_wait_;
+    std::mutex mu_;
+    std::condition_variable cv_job_, cv_done_;
+    std::deque<Job*> q_;
+    bool stop_ = false;
+    CoalescerStats st_;
+    std::thread th_;
+};
+
+struct VerifierOptions {
+    size_t coalesce_max = 4096;
+    std::chrono::microseconds coalesce_wait{50};
+    bool cache_verified = true;     // commit sigs of sequence s reappear at s+1 (view.go:376, 630)
+};
+
+class Verifier {
+ public:
+    Verifier(std::shared_ptr<Backend> be, const VerifierOptions& opt = VerifierOptions());
+
+    // key registry (id -> affine public key Qx|Qy); the kernel re-validates every key
+    void RegisterConsenter(uint64_t id, const uint8_t q[64]);
+    void RegisterClient(const std::string& client_id, const uint8_t q[64]);
+    void SetVerificationSequence(uint64_t s);
+
+    // ---- api.Verifier ---------------------------------------------------------------------------
+    Status VerifyProposal(const Proposal& proposal, std::vector<RequestInfo>* requests);
+    Status VerifyRequest(const bytes& val, RequestInfo* info);
+    Status VerifyConsenterSig(const Signature& signature, const Proposal& prop, bytes* aux);
+    Status VerifySignature(const Signature& signature);
+    uint64_t VerificationSequence();
+    std::vector<RequestInfo> RequestsFromProposal(const Proposal& proposal);
+    bytes AuxiliaryData(const bytes& msg);
+    // ---- api.RequestInspector (pkg/api/dependencies.go:80-83) ------------------------------------
+    RequestInfo RequestID(const bytes& req);
+
+    // Batch form used by decision replay / sync (pkg/types/types.go:31-34): all signatures of many
+    // decisions in one backend call; out[i] = 1 accept / 0 reject.
+    Status VerifyConsenterSigBatch(const std::vector<Signature>& sigs, const std::vector<const Proposal*>& props,
+                                   std::vector<uint8_t>* out);
+    CoalescerStats stats() { return co_.stats(); }
+
+ private:
+    bool consenter_key(uint64_t id, uint8_t q[64]);
+    bool client_key(const std::string& id, uint8_t q[64]);
+    void make_tuple(const uint8_t q[64], const bytes& msg, const bytes& sig_der, uint8_t out[160]);
+    Status verify_one(const uint8_t q[64], const bytes& msg, const bytes& sig);
+    std::mutex mu_;
+    std::map<uint64_t, bytes> consenters_;
+    std::map<std::string, bytes> clients_;
+    uint64_t seq_ = 0;
+    VerifierOptions opt_;
+    Coalescer co_;
+    std::mutex cache_mu_;
+    std::unordered_map<std::string, bool> cache_;
+};
+
+// api.Signer for one node (pkg/api/dependencies.go:46-52)
+class Signer {
+ public:
+    Signer(uint64_t id, const uint8_t private_key[32]);
+    uint64_t id() const { return id_; }
+    const uint8_t* public_key() const { return q_; }
+    bytes Sign(const bytes& msg);                                           // DER over SHA-256(msg)
+    Signature SignProposal(const Proposal& proposal, const bytes& auxiliary_input);
+
+ private:
+    uint64_t id_;
+    uint8_t d_[32], q_[64];
+};
+
+// f = (n-1)/3, q = ceil((n+f+1)/2)   internal/bft/util.go:183-187
+void compute_quorum(uint64_t n, int* q, int* f);
+
+}  // namespace sbvhost

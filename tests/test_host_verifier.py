@@ -1,0 +1,281 @@
+"""CPU tier for the host side above the C-ABI: the C++ mirror of api.Verifier / api.Signer
+(consensus_amd/host), exercised the way the reference's own tests exercise the seam — with a
+stand-in below it (the reference uses mocks.VerifierMock; here the stand-in backend is the oracle,
+injected by the test) — and pinned on what those tests pin:
+
+  * an error from VerifyConsenterSig drops that vote        (view_test.go:466 TestBadCommit)
+  * Q-1 good foreign signatures decide                       (view_test.go:533 TestNormalPath)
+  * VerifyRequest error at the leader => request not pooled  (controller_test.go:548)
+  * Pool.Prune removes exactly the requests whose predicate errs (requestpool_test.go:264)
+  * aux returned by VerifyConsenterSig == aux given to SignProposal (controller_test.go:720)
+  * quorum table                                             (util_test.go:135-163)
+"""
+import ctypes
+import hashlib
+import os
+import threading
+
+import pytest
+
+import hostlib
+import p256_py as ec
+from hostlib import INVALID, OK, UNAVAILABLE
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return hostlib.load()
+
+
+class Harness:
+    """A Verifier wired to a stand-in backend + N consenter signers + clients."""
+
+    def __init__(self, lib, oracle, n_nodes=4, fail_rc=0, wait_us=2000, cache=0):
+        self.lib, self.batches, self.fail_rc = lib, [], fail_rc
+
+        def backend(tuples, n, bitmap, _user):
+            self.batches.append(n)
+            if self.fail_rc:
+                return self.fail_rc
+            oracle.sbvo_p256_verify_batch(tuples, n, bitmap, 1)
+            return 0
+
+        self._cb = hostlib.BACKEND_FN(backend)          # keep alive
+        self.v = lib.sbvh_verifier_new(1, 0, self._cb, None, 4096, wait_us, cache)
+        self.nodes = []
+        for i in range(n_nodes):
+            s = lib.sbvh_signer_new(i + 1, hashlib.sha256(b"node%d" % i).digest())
+            q = ctypes.create_string_buffer(64)
+            lib.sbvh_signer_public_key(s, q)
+            lib.sbvh_register_consenter(self.v, i + 1, q.raw)
+            self.nodes.append(s)
+        self.clients = {}
+        for i in range(3):
+            s = lib.sbvh_signer_new(0, hashlib.sha256(b"client%d" % i).digest())
+            q = ctypes.create_string_buffer(64)
+            lib.sbvh_signer_public_key(s, q)
+            lib.sbvh_register_client(self.v, b"alice%d" % i, q.raw)
+            self.clients["alice%d" % i] = s
+
+    def close(self):
+        self.lib.sbvh_verifier_free(self.v)
+
+    def sign(self, signer, msg: bytes) -> bytes:
+        out = ctypes.create_string_buffer(80)
+        n = self.lib.sbvh_sign(signer, msg, len(msg), out, 80)
+        return out.raw[:n]
+
+    def request(self, client: str, rid: str, payload=b"tx", corrupt=False) -> bytes:
+        u = hostlib.request_unsigned(client, rid, payload)
+        sig = bytearray(self.sign(self.clients[client], u))
+        if corrupt:
+            sig[-1] ^= 1
+        return hostlib.request_encode(u, bytes(sig))
+
+    def sign_proposal(self, node, prop, aux: bytes):
+        msg = ctypes.create_string_buffer(4096)
+        val = ctypes.create_string_buffer(80)
+        ml, vl = ctypes.c_size_t(), ctypes.c_size_t()
+        p, h, m, vs = prop
+        self.lib.sbvh_sign_proposal(self.nodes[node], p, len(p), h, len(h), m, len(m), vs, aux, len(aux), msg, 4096,
+                                    ctypes.byref(ml), val, 80, ctypes.byref(vl))
+        return node + 1, val.raw[:vl.value], msg.raw[:ml.value]
+
+    def verify_consenter_sig(self, sig, prop):
+        sid, val, msg = sig
+        p, h, m, vs = prop
+        aux = ctypes.create_string_buffer(4096)
+        al = ctypes.c_size_t()
+        st = self.lib.sbvh_verify_consenter_sig(self.v, sid, val, len(val), msg, len(msg), p, len(p), h, len(h), m, len(m), vs,
+                                                aux, 4096, ctypes.byref(al))
+        return st, aux.raw[:al.value]
+
+    def verify_request(self, raw):
+        out = ctypes.create_string_buffer(1024)
+        n = ctypes.c_size_t()
+        st = self.lib.sbvh_verify_request(self.v, raw, len(raw), out, 1024, ctypes.byref(n))
+        return st, (hostlib.split_infos(out.raw[:n.value]) or [None])[0]
+
+    def verify_proposal(self, prop):
+        p, h, m, vs = prop
+        out = ctypes.create_string_buffer(1 << 20)
+        n, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+        st = self.lib.sbvh_verify_proposal(self.v, p, len(p), h, len(h), m, len(m), vs, out, 1 << 20, ctypes.byref(n), ctypes.byref(cnt))
+        return st, hostlib.split_infos(out.raw[:n.value])
+
+
+@pytest.fixture()
+def hx(lib, oracle):
+    h = Harness(lib, oracle)
+    yield h
+    h.close()
+
+
+def test_quorum_table_matches_reference(lib):
+    table = [(4, 1, 3), (5, 1, 4), (6, 1, 4), (7, 2, 5), (8, 2, 6), (9, 2, 6), (10, 3, 7), (11, 3, 8), (12, 3, 8), (16, 5, 11)]
+    for n, f, q in table:
+        qq, ff = ctypes.c_int(), ctypes.c_int()
+        lib.sbvh_compute_quorum(n, ctypes.byref(qq), ctypes.byref(ff))
+        assert (qq.value, ff.value) == (q, f), n
+
+
+def test_signer_reproduces_rfc6979_known_answers(lib, rfc6979):
+    d = bytes.fromhex(rfc6979["private_key"])
+    q = ctypes.create_string_buffer(64)
+    assert lib.sbvh_pubkey(d, q) == 0
+    assert q.raw == bytes.fromhex(rfc6979["qx"]) + bytes.fromhex(rfc6979["qy"])
+    n = 0
+    for sig in rfc6979["signatures"]:
+        if sig["hash_alg"] != "sha256":
+            continue                       # the deterministic nonce depends on the hash used by HMAC
+        rs = ctypes.create_string_buffer(64)
+        assert lib.sbvh_sign_rfc6979(d, bytes.fromhex(sig["hash"]), rs) == 0
+        assert rs.raw.hex() == sig["r"] + sig["s"], sig["message"]
+        n += 1
+    assert n == 2
+
+
+def test_proposal_digest_matches_go_asn1_restated_in_python(lib):
+    cases = [(b"", b"", b"", 0), (b"p", b"h", b"m", 1), (b"x" * 127, b"y" * 128, b"z" * 300, 127), (b"a" * 70000, b"", b"m", 128),
+             (b"p", b"h", b"m", -1), (b"p", b"h", b"m", -129), (b"p", b"h", b"m", 2**40 + 5), (b"p", b"h", b"m", 2**63 - 1),
+             (b"p", b"h", b"m", -2**63), (b"p", b"h", b"m", 255), (b"p", b"h", b"m", 256), (b"p", b"h", b"m", -128)]
+    for p, h, m, vs in cases:
+        out = ctypes.create_string_buffer(65)
+        lib.sbvh_proposal_digest(p, len(p), h, len(h), m, len(m), vs, out)
+        assert out.value.decode() == hostlib.proposal_digest(p, h, m, vs), (len(p), vs)
+
+
+def test_bad_commit_vote_is_an_error_good_vote_returns_aux(hx):
+    prop = (hostlib.payload_encode([]), b"header", b"metadata", 0)
+    aux = b"\x0a\x02\x01\x02"                       # stands for a PreparesFrom protobuf
+    sig = hx.sign_proposal(1, prop, aux)
+    st, got = hx.verify_consenter_sig(sig, prop)
+    assert st == OK and got == aux                   # controller_test.go:720: aux must round-trip
+    # the message format is the documented one
+    assert sig[2] == hostlib.consenter_msg(*prop, aux)
+    # corrupted signature value: "Couldn't verify 2's signature" — the vote is dropped (view.go:839-842)
+    bad = (sig[0], sig[1][:-1] + bytes([sig[1][-1] ^ 1]), sig[2])
+    assert hx.verify_consenter_sig(bad, prop)[0] == INVALID
+    # right signature, wrong signer id
+    assert hx.verify_consenter_sig((3, sig[1], sig[2]), prop)[0] == INVALID
+    # right signature over a DIFFERENT proposal: rejected before any crypto is spent
+    other = (prop[0], b"other header", prop[2], prop[3])
+    nb = len(hx.batches)
+    assert hx.verify_consenter_sig(sig, other)[0] == INVALID
+    assert len(hx.batches) == nb
+    # AuxiliaryData extracts without verifying, even from the corrupted one (view.go:1029, 1071)
+    out = ctypes.create_string_buffer(64)
+    n = hx.lib.sbvh_auxiliary_data(hx.v, bad[2], len(bad[2]), out, 64)
+    assert out.raw[:n] == aux
+
+
+def test_normal_path_concurrent_commit_votes_are_coalesced(hx):
+    """N = 4, Q = 3: the View fires N-1 verifyVote goroutines back to back (view.go:537-541)."""
+    prop = (hostlib.payload_encode([]), b"h", b"m", 0)
+    sigs = [hx.sign_proposal(i, prop, b"aux%d" % i) for i in range(1, 4)]
+    results = [None] * 3
+    hx.batches.clear()
+
+    def vote(i):
+        results[i] = hx.verify_consenter_sig(sigs[i], prop)
+
+    th = [threading.Thread(target=vote, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert [r[0] for r in results] == [OK] * 3
+    assert [r[1] for r in results] == [b"aux1", b"aux2", b"aux3"]
+    assert sum(hx.batches) == 3 and len(hx.batches) <= 2      # one micro-batch (two if a thread was late)
+
+
+def test_leader_request_handling(hx):
+    good = hx.request("alice0", "req-1")
+    st, info = hx.verify_request(good)
+    assert st == OK and info == ("alice0", "req-1")
+    out = ctypes.create_string_buffer(256)
+    n = hx.lib.sbvh_request_id(hx.v, good, len(good), out, 256)
+    assert hostlib.split_infos(out.raw[:n]) == [info]          # RequestInspector agrees (requestpool.go:192)
+    assert hx.verify_request(hx.request("alice0", "req-2", corrupt=True))[0] == INVALID   # not pooled
+    stranger = hostlib.request_encode(hostlib.request_unsigned("mallory", "x", b""), b"\x30\x00")
+    assert hx.verify_request(stranger)[0] == INVALID
+    assert hx.verify_request(good[:-3])[0] == INVALID
+    assert hx.verify_request(b"")[0] == INVALID
+
+
+def test_pool_prune_removes_exactly_the_invalid_requests(hx):
+    pool = [hx.request("alice%d" % (i % 3), "r%d" % i, corrupt=(i % 4 == 1)) for i in range(12)]
+    kept = [r for r in pool if hx.verify_request(r)[0] == OK]           # Pool.Prune(predicate) requestpool.go:335-354
+    assert kept == [r for i, r in enumerate(pool) if i % 4 != 1]
+
+
+def test_verify_proposal_batches_all_request_signatures(hx):
+    reqs = [hx.request("alice%d" % (i % 3), "r%d" % i, payload=bytes([i])) for i in range(100)]    # default K = 100
+    prop = (hostlib.payload_encode(reqs), b"h", b"m", 0)
+    hx.batches.clear()
+    st, infos = hx.verify_proposal(prop)
+    assert st == OK and infos == [("alice%d" % (i % 3), "r%d" % i) for i in range(100)]
+    assert hx.batches == [100]                                   # ONE backend call for K signatures
+    out = ctypes.create_string_buffer(1 << 16)
+    cnt = ctypes.c_size_t()
+    n = hx.lib.sbvh_requests_from_proposal(hx.v, prop[0], len(prop[0]), out, 1 << 16, ctypes.byref(cnt))
+    assert hostlib.split_infos(out.raw[:n]) == infos             # view.go:395, 419
+    reqs[57] = hx.request("alice0", "r57", corrupt=True)
+    assert hx.verify_proposal((hostlib.payload_encode(reqs), b"h", b"m", 0))[0] == INVALID
+    assert hx.verify_proposal((prop[0], b"h", b"m", 7))[0] == INVALID        # verification sequence mismatch
+    assert hx.verify_proposal((prop[0][:-1], b"h", b"m", 0))[0] == INVALID   # malformed payload
+    assert hx.verify_proposal((hostlib.payload_encode([]), b"h", b"m", 0)) == (OK, [])
+
+
+def test_device_fault_is_unavailable_never_invalid(lib, oracle):
+    hx = Harness(lib, oracle, fail_rc=-4)
+    try:
+        prop = (hostlib.payload_encode([hx.request("alice0", "r")]), b"h", b"m", 0)
+        assert hx.verify_proposal(prop)[0] == UNAVAILABLE
+        assert hx.verify_request(hx.request("alice0", "r"))[0] == UNAVAILABLE
+        assert hx.verify_consenter_sig(hx.sign_proposal(1, prop, b""), prop)[0] == UNAVAILABLE
+    finally:
+        hx.close()
+
+
+def test_signature_cache_skips_the_backend_for_prev_commit_signatures(lib, oracle):
+    hx = Harness(lib, oracle, cache=1, wait_us=10)
+    try:
+        prop = (hostlib.payload_encode([]), b"h", b"m", 0)
+        sig = hx.sign_proposal(2, prop, b"a")
+        assert hx.verify_consenter_sig(sig, prop)[0] == OK
+        nb = len(hx.batches)
+        assert hx.verify_consenter_sig(sig, prop)[0] == OK       # seq s+1 re-verifies seq s's commits (view.go:630)
+        assert len(hx.batches) == nb
+    finally:
+        hx.close()
+
+
+def test_product_backend_without_gpu_is_unavailable(lib):
+    import consensus_amd
+    if consensus_amd.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    cb = hostlib.BACKEND_FN(lambda *a: 0)
+    v = lib.sbvh_verifier_new(0, 0, cb, None, 64, 10, 0)
+    try:
+        s = lib.sbvh_signer_new(1, hashlib.sha256(b"k").digest())
+        q = ctypes.create_string_buffer(64)
+        lib.sbvh_signer_public_key(s, q)
+        lib.sbvh_register_consenter(v, 1, q.raw)
+        out = ctypes.create_string_buffer(80)
+        n = lib.sbvh_sign(s, b"m", 1, out, 80)
+        assert lib.sbvh_verify_signature(v, 1, out.raw[:n], n, b"m", 1) == UNAVAILABLE    # no CPU guess
+    finally:
+        lib.sbvh_verifier_free(v)
+
+
+def test_replay_driver_runs_the_reference_call_pattern(lib, oracle):
+    hx = Harness(lib, oracle, wait_us=500)
+    try:
+        res = hostlib.ReplayResult()
+        rc = lib.sbvh_replay(hx.v, 4, 20, 3, 6, 4, ctypes.byref(res))
+        assert rc == 0 and res.status == 0
+        assert res.batch_tuples == 6 * 3 and res.proposals_with_quorum == 6
+        assert res.max_backend_batch >= 20
+    finally:
+        hx.close()
