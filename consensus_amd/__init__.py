@@ -75,6 +75,10 @@ def load() -> ctypes.CDLL:
     lib.sbv_p256_verify_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     lib.sbv_p256_parse_der.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
     lib.sbv_sha256_batch.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t, ctypes.c_char_p]
+    lib.sbv_p256_register_keys.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint32)]
+    lib.sbv_p256_verify_batch_keyed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.sbv_p256_verify_batch_keyed_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
+                                                    ctypes.c_void_p]
     lib.sbv_last_timing.argtypes = [ctypes.POINTER(Timing)]
     lib.sbv_profile_enable.argtypes = [ctypes.c_int]
     lib.sbv_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
@@ -123,6 +127,40 @@ def verify_batch_ptr(host_ptr: int, n: int, out_ptr: int) -> None:
 def verify_batch_dev(d_tuples_ptr: int, n: int, d_bitmap_ptr: int, stream: int = 0) -> None:
     """Asynchronous verification of device-resident tuples on `stream` (a hipStream_t value)."""
     _check(load().sbv_p256_verify_batch_dev(d_tuples_ptr, n, d_bitmap_ptr, stream))
+
+
+def register_keys(keys) -> list:
+    """keys: iterable of 64-byte Qx|Qy -> list of slots (equal keys share a slot)."""
+    keys = list(keys)
+    blob = b"".join(keys)
+    if len(blob) != 64 * len(keys):
+        raise ValueError("every key must be 64 bytes")
+    out = (ctypes.c_uint32 * max(1, len(keys)))()
+    _check(load().sbv_p256_register_keys(blob, len(keys), out))
+    return list(out[:len(keys)])
+
+
+def key_count() -> int:
+    return load().sbv_p256_key_count()
+
+
+def clear_keys() -> None:
+    _check(load().sbv_p256_clear_keys())
+
+
+def verify_batch_keyed(rsh: bytes, slots, n: Optional[int] = None) -> bytes:
+    """Registered-key form: rsh = n x 96 bytes (r|s|hash), slots = n key slots."""
+    if n is None:
+        n = len(rsh) // 96
+    arr = (ctypes.c_uint32 * max(1, n))(*slots)
+    out = ctypes.create_string_buffer(max(1, (n + 7) // 8))
+    buf = (ctypes.c_char * len(rsh)).from_buffer_copy(rsh) if n else None
+    _check(load().sbv_p256_verify_batch_keyed(buf, arr, n, out))
+    return out.raw[:(n + 7) // 8]
+
+
+def verify_batch_keyed_dev(d_rsh_ptr: int, d_slots_ptr: int, n: int, d_bitmap_ptr: int, stream: int = 0) -> None:
+    _check(load().sbv_p256_verify_batch_keyed_dev(d_rsh_ptr, d_slots_ptr, n, d_bitmap_ptr, stream))
 
 
 def parse_der(sig: bytes) -> Optional[bytes]:

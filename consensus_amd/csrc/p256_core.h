@@ -61,7 +61,9 @@ SBV_HD void tuple_field(u256& out, WordPtr w, int f) {
 // `TupleWords` is a callable (k, idx) -> indexable giving the 40 big-endian dwords of tuple
 // idx; it is invoked by every thread for every k (it may contain workgroup barriers: the
 // kernel stages each 64-tuple slab through LDS with coalesced 16-byte loads).
-template <typename TupleWords>
+// HAS_Q = false is the registered-key form: tuples are r|s|hash (96 B), the public key comes from
+// a key slot validated at registration, so only r and s are range-checked here.
+template <bool HAS_Q, typename TupleWords>
 SBV_HD void prep_chunk(TupleWords words, size_t n, const Scratch& sc_, size_t first, size_t step, int T) {
     const sc n_ = sc_n();
     const fe p_ = fe_p();
@@ -74,10 +76,12 @@ SBV_HD void prep_chunk(TupleWords words, size_t n, const Scratch& sc_, size_t fi
             tuple_field(r, w, 0);
             tuple_field(s, w, 1);
             tuple_field(e, w, 2);
-            tuple_field(qx, w, 3);
-            tuple_field(qy, w, 4);
-            const bool ok = !is_zero256(r) && lt256(r, n_) && !is_zero256(s) && lt256(s, n_) &&
-                            lt256(qx, p_) && lt256(qy, p_);
+            bool ok = !is_zero256(r) && lt256(r, n_) && !is_zero256(s) && lt256(s, n_);
+            if (HAS_Q) {
+                tuple_field(qx, w, 3);
+                tuple_field(qy, w, 4);
+                ok = ok && lt256(qx, p_) && lt256(qy, p_);
+            }
             // hashToNat: e < 2^256 < 2N, one conditional subtraction
             sc_cond_sub_n(e, e, 0);
             sc sM;
@@ -88,8 +92,10 @@ SBV_HD void prep_chunk(TupleWords words, size_t n, const Scratch& sc_, size_t fi
             soa_store(sc_.sm, sc_.cap, idx, sM);
             soa_store(sc_.u2, sc_.cap, idx, e);
             soa_store(sc_.r, sc_.cap, idx, r);
-            soa_store(sc_.qx, sc_.cap, idx, qx);
-            soa_store(sc_.qy, sc_.cap, idx, qy);
+            if (HAS_Q) {
+                soa_store(sc_.qx, sc_.cap, idx, qx);
+                soa_store(sc_.qy, sc_.cap, idx, qy);
+            }
             sc_.ok[idx] = ok ? 1 : 0;
             sc_mul(acc, acc, sM);
         }
@@ -157,6 +163,28 @@ SBV_HD u32 add_const_limbs(u256& out, const u256& v, u32 c_limb) {
     SBV_UNROLL
     for (int l = 0; l < 8; ++l) out.v[l] = addc(v.v[l], c_limb, c);
     return c;
+}
+
+// R.x mod N == r  <=>  R != infinity and (X == r Z^2  or  (r + N < p and X == (r + N) Z^2))  (mod p),
+// with r < N; no inversion.
+SBV_HD bool rx_matches(const jpt& R, const u256& r) {
+    if (pt_is_inf(R)) return false;
+    fe zz, rM, t;
+    fe_sqr(zz, R.Z);
+    fe_to_mont(rM, r);
+    fe_mul(t, rM, zz);
+    bool match = fe_eq(t, R.X);
+    const sc n_ = sc_n();
+    const fe p_ = fe_p();
+    u256 rn;
+    const u32 carry = add256(rn, r, n_);
+    const bool wrap_possible = (carry == 0) && lt256(rn, p_);
+    if (wrap_possible) {                    // only for r < p - N ~ 2^128: essentially never
+        fe_to_mont(rM, rn);
+        fe_mul(t, rM, zz);
+        match = match || fe_eq(t, R.X);
+    }
+    return match;
 }
 
 // Returns accept (true) / reject for lane `i`.  `qtab` = this lane's private table space
@@ -237,36 +265,86 @@ SBV_HD bool verify_lane(const Scratch& s, size_t i, u32* qtab, const apt* gtab) 
         pt_add_mixed(R, g, false, top1 == 0);
     }
 
-    // R.x mod N == r  <=>  X == r Z^2  or  (r + N < p and X == (r + N) Z^2)   (mod p)
-    if (pt_is_inf(R)) ok = false;
-    fe zz, rM, t;
-    fe_sqr(zz, R.Z);
-    fe_to_mont(rM, r);                      // r < N < p when ok
-    fe_mul(t, rM, zz);
-    bool match = fe_eq(t, R.X);
+    return ok && rx_matches(R, r);
+}
+
+// ---- stage B, registered-key form -------------------------------------------------------------------
+// The public key was registered once (sbv_p256_register_keys): ktab holds, per key slot, the same
+// 33 x 128 comb as gtab but for Q.  R = u1*G + u2*Q is then 66 mixed additions and NO doublings
+// (~4.7x fewer field multiplications than the generic form).  Consenter keys are a fixed registry in
+// SmartBFT (Signature.ID selects the key, pkg/types/types.go:25-29), so this is the shape of
+// VerifyConsenterSig / decision replay (BASELINE.json config 4).
+SBV_HD void comb_digit(const u256& k, u32 top, int j, int& idx, bool& neg, bool& skip) {
+    if (j == 32) { idx = 0; neg = false; skip = top == 0; return; }
+    const int d = (int)((k.v[j >> 2] >> ((j & 3) * 8)) & 255u) - 128;
+    const int ad = d < 0 ? -d : d;
+    idx = ad == 0 ? 0 : ad - 1;
+    neg = d < 0;
+    skip = d == 0;
+}
+
+SBV_HD bool verify_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys, const apt* ktab,
+                              const uint8_t* kvalid, const apt* gtab) {
+    u256 r, u1, u2;
+    soa_load(r, s.r, s.cap, i);
+    soa_load(u1, s.u1, s.cap, i);
+    soa_load(u2, s.u2, s.cap, i);
+    bool ok = s.ok[i] != 0 && slot < nkeys;
+    if (slot >= nkeys) slot = 0;
+    ok = ok && kvalid[slot] != 0;
+    const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
+    u256 k1, k2;
+    const u32 top1 = add_const_limbs(k1, u1, 0x80808080u);
+    const u32 top2 = add_const_limbs(k2, u2, 0x80808080u);
+    jpt R;
+    pt_set_inf(R);
+    // one rolled loop over 66 (table, window) steps: a single mixed-add body in the instruction stream
+    apt cur;
+    int idx; bool neg, skip;
+    comb_digit(k1, top1, 0, idx, neg, skip);
     {
-        const sc n_ = sc_n();
-        const fe p_ = fe_p();
-        u256 rn;
-        const u32 carry = add256(rn, r, n_);
-        const bool wrap_possible = (carry == 0) && lt256(rn, p_);
-        if (wrap_possible) {                // only for r < p - N ~ 2^128: essentially never
-            fe_to_mont(rM, rn);
-            fe_mul(t, rM, zz);
-            match = match || fe_eq(t, R.X);
-        }
+        const u32* gp = reinterpret_cast<const u32*>(gtab + idx);
+        fe_load16(cur.x, gp); fe_load16(cur.y, gp + 8);
     }
-    return ok && match;
+    SBV_NOUNROLL
+    for (int t = 0; t < 66; ++t) {
+        // software prefetch of the next step's table entry while this step's addition runs
+        const int tn = t + 1 < 66 ? t + 1 : 65;
+        const int jn = tn >> 1;
+        int idxn; bool negn, skipn;
+        if (tn & 1) comb_digit(k2, top2, jn, idxn, negn, skipn); else comb_digit(k1, top1, jn, idxn, negn, skipn);
+        const apt* tab = (tn & 1) ? qtab : gtab;
+        const u32* gp = reinterpret_cast<const u32*>(tab + (size_t)jn * SBV_GTAB_PER_WINDOW + idxn);
+        apt nxt;
+        fe_load16(nxt.x, gp); fe_load16(nxt.y, gp + 8);
+        pt_add_mixed(R, cur, neg, skip);
+        cur = nxt; neg = negn; skip = skipn;
+    }
+    return ok && rx_matches(R, r);
 }
 
 // ---- fixed-base table generation (host, once per sbv_init; also used by tests/emul) -----------------
-// out[j * 128 + (k-1)] = k * 2^(8j) * G for j = 0..32, k = 1..128 (affine, Montgomery form).
+// out[j * 128 + (k-1)] = k * 2^(8j) * P for j = 0..32, k = 1..128 (affine, Montgomery form); P = (px, py)
+// plain coordinates of a point ON the curve (callers validate first).
+inline void build_comb_table(const u256& px, const u256& py, apt* out);
 inline void build_gtable(apt* out) {
     const u256 gx = {{0xD898C296u, 0xF4A13945u, 0x2DEB33A0u, 0x77037D81u, 0x63A440F2u, 0xF8BCE6E5u, 0xE12C4247u, 0x6B17D1F2u}};
     const u256 gy = {{0x37BF51F5u, 0xCBB64068u, 0x6B315ECEu, 0x2BCE3357u, 0x7C0F9E16u, 0x8EE7EB4Au, 0xFE1A7F9Bu, 0x4FE342E2u}};
+    build_comb_table(gx, gy, out);
+}
+// pointFromAffine's checks on a registered key: coordinates < p and on the curve
+inline bool key_is_valid(const u256& px, const u256& py) {
+    const fe p_ = fe_p();
+    if (!lt256(px, p_) || !lt256(py, p_)) return false;
+    fe x, y;
+    fe_to_mont(x, px);
+    fe_to_mont(y, py);
+    return pt_on_curve(x, y);
+}
+inline void build_comb_table(const u256& px, const u256& py, apt* out) {
     apt base;
-    fe_to_mont(base.x, gx);
-    fe_to_mont(base.y, gy);
+    fe_to_mont(base.x, px);
+    fe_to_mont(base.y, py);
     jpt* row = new jpt[SBV_GTAB_PER_WINDOW];
     fe* pre = new fe[SBV_GTAB_PER_WINDOW];
     for (int j = 0; j < SBV_GTAB_WINDOWS; ++j) {

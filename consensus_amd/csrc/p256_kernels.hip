@@ -23,35 +23,66 @@
 namespace sbv {
 
 constexpr int kPrepLanes = 64;
-constexpr int kLdsPitch = 41;   // dwords per staged tuple (40 + 1 pad)
+
 
 struct LdsTuple {
     const u32* row;
     __device__ __forceinline__ u32 operator[](int i) const { return row[i]; }
 };
 
-__global__ __launch_bounds__(kPrepLanes) void k_p256_prep(const uint8_t* __restrict__ tuples, size_t n,
-                                                          Scratch s, int T) {
-    __shared__ u32 lds[kPrepLanes * kLdsPitch];
+// TD = dwords per input tuple: 40 (r|s|hash|Qx|Qy) or 24 (r|s|hash, registered-key form).
+template <int TD, bool HAS_Q>
+__device__ __forceinline__ void prep_body(const uint8_t* __restrict__ tuples, size_t n, const Scratch& s, int T) {
+    constexpr int kPitch = TD + 1;                 // odd -> conflict-free per-lane ds_read_b32 walk
+    constexpr int kVec = TD / 4;                   // 16-byte elements per tuple
+    __shared__ u32 lds[kPrepLanes * kPitch];
     const size_t block_first = (size_t)blockIdx.x * kPrepLanes * (size_t)T;
     const int lane = threadIdx.x;
     auto words = [&](int k, size_t) -> LdsTuple {
         const size_t slab = block_first + (size_t)k * kPrepLanes;      // first tuple of the slab
         __syncthreads();                                               // previous slab fully consumed
-        const uint4* src = reinterpret_cast<const uint4*>(tuples + slab * SBV_TUPLE_BYTES);
+        const uint4* src = reinterpret_cast<const uint4*>(tuples + slab * (size_t)(TD * 4));
 #pragma unroll
-        for (int it = 0; it < 10; ++it) {
+        for (int it = 0; it < kVec; ++it) {
             const int e = it * kPrepLanes + lane;                      // 16-byte element of the slab
-            const int t = e / 10, part = e - t * 10;
+            const int t = e / kVec, part = e - t * kVec;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (slab + (size_t)t < n) v = src[e];
-            u32* dst = lds + t * kLdsPitch + part * 4;
+            u32* dst = lds + t * kPitch + part * 4;
             dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
         }
         __syncthreads();
-        return LdsTuple{lds + lane * kLdsPitch};
+        return LdsTuple{lds + lane * kPitch};
     };
-    prep_chunk(words, n, s, block_first + (size_t)lane, (size_t)kPrepLanes, T);
+    prep_chunk<HAS_Q>(words, n, s, block_first + (size_t)lane, (size_t)kPrepLanes, T);
+}
+
+__global__ __launch_bounds__(kPrepLanes) void k_p256_prep(const uint8_t* __restrict__ tuples, size_t n,
+                                                          Scratch s, int T) {
+    prep_body<40, true>(tuples, n, s, T);
+}
+__global__ __launch_bounds__(kPrepLanes) void k_p256_prep_keyed(const uint8_t* __restrict__ rsh, size_t n,
+                                                                Scratch s, int T) {
+    prep_body<24, false>(rsh, n, s, T);
+}
+
+// Stage B, registered-key form: 66 mixed additions per lane from two combs (G and the key's).
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_keyed(Scratch s, size_t n,
+                                                                       const u32* __restrict__ slots, u32 nkeys,
+                                                                       const apt* __restrict__ ktab,
+                                                                       const uint8_t* __restrict__ kvalid,
+                                                                       const apt* __restrict__ gtab,
+                                                                       uint8_t* __restrict__ bitmap) {
+    const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    bool accept = false;
+    if (i < n) accept = verify_lane_keyed(s, i, slots[i], nkeys, ktab, kvalid, gtab);
+    const unsigned long long m = __ballot(accept);
+    const int lane = threadIdx.x & 63;
+    const size_t wave_first = i - (size_t)lane;
+    if (lane < 8) {
+        const size_t byte = (wave_first >> 3) + (size_t)lane;
+        if (byte < ((n + 7) >> 3)) bitmap[byte] = (uint8_t)(m >> (8 * lane));
+    }
 }
 
 // The stage-B body; stamped out with different register budgets (waves per SIMD) so that the
@@ -94,12 +125,22 @@ int prep_chunk_T(size_t n) {
     return (int)t;
 }
 
-hipError_t launch_p256_prep(const uint8_t* d_tuples, size_t n, const Scratch& s, hipStream_t stream) {
+hipError_t launch_p256_prep(const uint8_t* d_tuples, size_t n, const Scratch& s, hipStream_t stream, bool keyed) {
     if (n == 0) return hipSuccess;
     const int T = prep_chunk_T(n);
     const size_t per_block = (size_t)kPrepLanes * T;
     const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
-    hipLaunchKernelGGL(k_p256_prep, dim3(grid), dim3(kPrepLanes), 0, stream, d_tuples, n, s, T);
+    if (keyed) hipLaunchKernelGGL(k_p256_prep_keyed, dim3(grid), dim3(kPrepLanes), 0, stream, d_tuples, n, s, T);
+    else hipLaunchKernelGGL(k_p256_prep, dim3(grid), dim3(kPrepLanes), 0, stream, d_tuples, n, s, T);
+    return hipGetLastError();
+}
+
+hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
+                                    const uint8_t* d_kvalid, const apt* d_gtab, uint8_t* d_bitmap, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
+    hipLaunchKernelGGL(k_p256_verify_keyed, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab,
+                       d_kvalid, d_gtab, d_bitmap);
     return hipGetLastError();
 }
 
@@ -118,5 +159,14 @@ hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt
 }
 
 void host_build_gtable(apt* out) { build_gtable(out); }
+
+bool host_build_key_table(const uint8_t q[64], apt* out) {
+    u256 x, y;
+    from_be32(x, q);
+    from_be32(y, q + 32);
+    if (!key_is_valid(x, y)) return false;
+    build_comb_table(x, y, out);
+    return true;
+}
 
 }  // namespace sbv

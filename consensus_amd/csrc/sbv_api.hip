@@ -14,6 +14,8 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/sbv.h"
@@ -38,6 +40,12 @@ struct Context {
     hipEvent_t busy = nullptr;          // completion of the last launch that used the scratch
     bool busy_valid = false;
     sbv_timing timing{};
+    // registered keys
+    sbv::apt* d_ktab = nullptr;
+    uint8_t* d_kvalid = nullptr;
+    u32* d_slots = nullptr;             // staging for the host-pointer keyed entry (cap entries)
+    size_t key_cap = 0, nkeys = 0;
+    std::unordered_map<std::string, u32> key_index;
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;   // triples: before prep, after prep, after verify
     size_t prof_used = 0;
@@ -65,6 +73,8 @@ void free_buffers(Context& c) {
     if (c.d_qtab) (void)hipFree(c.d_qtab);
     if (c.d_bitmap) (void)hipFree(c.d_bitmap);
     if (c.h_bitmap) (void)hipHostFree(c.h_bitmap);
+    if (c.d_slots) (void)hipFree(c.d_slots);
+    c.d_slots = nullptr;
     c.d_tuples = c.d_scratch = c.d_bitmap = c.h_bitmap = nullptr;
     c.d_qtab = nullptr;
     c.cap = 0;
@@ -80,6 +90,7 @@ int ensure_capacity(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_scratch, want * (6 * 32 + 1)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_qtab, want * (size_t)(SBV_QTAB_ENTRIES * 160)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_bitmap, want / 8));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_slots, want * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipHostMalloc(&c.h_bitmap, want / 8, hipHostMallocDefault));
     c.cap = want;
     return SBV_OK;
@@ -107,6 +118,39 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_tuples, n, s, stream));
     if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify(s, n, c.d_qtab, c.d_gtab, d_bitmap, stream));
+    return SBV_OK;
+}
+
+int enqueue_keyed(Context& c, const uint8_t* d_rsh, const u32* d_slots, size_t n, uint8_t* d_bitmap, hipStream_t stream,
+                  hipEvent_t after_prep) {
+    const sbv::Scratch s = scratch_view(c);
+    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_rsh, n, s, stream, true));
+    if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
+    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_keyed(s, n, d_slots, (u32)c.nkeys, c.d_ktab, c.d_kvalid, c.d_gtab, d_bitmap, stream));
+    return SBV_OK;
+}
+
+constexpr size_t kKeyTabBytes = (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt);
+
+int ensure_key_capacity(Context& c, size_t want) {
+    if (want <= c.key_cap) return SBV_OK;
+    size_t cap = c.key_cap ? c.key_cap : 16;
+    while (cap < want) cap *= 2;
+    sbv::apt* nt = nullptr;
+    uint8_t* nv = nullptr;
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&nt, cap * kKeyTabBytes));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&nv, cap));
+    HIP_TRY(SBV_EDEVICE, hipMemset(nv, 0, cap));
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());          // nothing in flight may still read the old tables
+    if (c.nkeys) {
+        HIP_TRY(SBV_EDEVICE, hipMemcpy(nt, c.d_ktab, c.nkeys * kKeyTabBytes, hipMemcpyDeviceToDevice));
+        HIP_TRY(SBV_EDEVICE, hipMemcpy(nv, c.d_kvalid, c.nkeys, hipMemcpyDeviceToDevice));
+    }
+    if (c.d_ktab) (void)hipFree(c.d_ktab);
+    if (c.d_kvalid) (void)hipFree(c.d_kvalid);
+    c.d_ktab = nt;
+    c.d_kvalid = nv;
+    c.key_cap = cap;
     return SBV_OK;
 }
 
@@ -166,6 +210,10 @@ extern "C" int sbv_shutdown(void) {
     free_buffers(c);
     if (c.d_gtab) (void)hipFree(c.d_gtab);
     c.d_gtab = nullptr;
+    if (c.d_ktab) (void)hipFree(c.d_ktab);
+    if (c.d_kvalid) (void)hipFree(c.d_kvalid);
+    c.d_ktab = nullptr; c.d_kvalid = nullptr; c.key_cap = c.nkeys = 0;
+    c.key_index.clear();
     for (auto& ev : c.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
     for (auto& ev : c.prof_events) (void)hipEventDestroy(ev);
     c.prof_events.clear();
@@ -252,6 +300,142 @@ extern "C" int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* a
         tm.d2h_us += 1e3 * ms_between(c.ev[3], c.ev[4]);
     }
     c.busy_valid = false;   // stream is idle
+    tm.total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    c.timing = tm;
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_register_keys(const uint8_t* keys, size_t m, uint32_t* slots_out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (m == 0) return SBV_OK;
+    if (!keys || !slots_out) { g_err = "null pointer"; return SBV_EINVAL; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    // de-duplicate, assign slots
+    std::vector<size_t> fresh;                      // indices into keys[] that need a table
+    for (size_t i = 0; i < m; ++i) {
+        const std::string k((const char*)keys + 64 * i, 64);
+        auto it = c.key_index.find(k);
+        if (it == c.key_index.end()) {
+            const u32 slot = (u32)(c.nkeys + fresh.size());
+            c.key_index.emplace(k, slot);
+            fresh.push_back(i);
+            slots_out[i] = slot;
+        } else {
+            slots_out[i] = it->second;
+        }
+    }
+    if (fresh.empty()) return SBV_OK;
+    int rc = ensure_key_capacity(c, c.nkeys + fresh.size());
+    if (rc != SBV_OK) { for (size_t i : fresh) c.key_index.erase(std::string((const char*)keys + 64 * i, 64)); return rc; }
+    // tables are built on the host (one-time setup, same field code as the kernels), in parallel
+    std::vector<sbv::apt> tabs(fresh.size() * (size_t)SBV_KEYTAB_ENTRIES);
+    std::vector<uint8_t> valid(fresh.size(), 0);
+    {
+        size_t nt = std::thread::hardware_concurrency();
+        if (nt == 0) nt = 1;
+        if (nt > 64) nt = 64;
+        if (nt > fresh.size()) nt = fresh.size();
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                for (size_t j = t; j < fresh.size(); j += nt)
+                    valid[j] = sbv::host_build_key_table(keys + 64 * fresh[j], &tabs[j * (size_t)SBV_KEYTAB_ENTRIES]) ? 1 : 0;
+            });
+        for (auto& x : th) x.join();
+    }
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_ktab + c.nkeys * (size_t)SBV_KEYTAB_ENTRIES, tabs.data(), tabs.size() * sizeof(sbv::apt),
+                                   hipMemcpyHostToDevice));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_kvalid + c.nkeys, valid.data(), valid.size(), hipMemcpyHostToDevice));
+    c.nkeys += fresh.size();
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_key_count(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_ctx.ready ? (int)g_ctx.nkeys : SBV_ENOTINIT;
+}
+
+extern "C" int sbv_p256_clear_keys(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) return SBV_ENOTINIT;
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    c.key_index.clear();
+    c.nkeys = 0;
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_verify_batch_keyed_dev(const void* d_rsh, const void* d_slots, size_t n, void* d_bitmap, void* hip_stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (n == 0) return SBV_OK;
+    if (!d_rsh || !d_slots || !d_bitmap || (reinterpret_cast<uintptr_t>(d_rsh) & 15)) { g_err = "null or misaligned device pointer"; return SBV_EINVAL; }
+    if (c.nkeys == 0) { g_err = "no keys registered"; return SBV_EINVAL; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    int rc = ensure_capacity(c, n < kMaxChunk ? n : kMaxChunk);
+    if (rc != SBV_OK) return rc;
+    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(stream, c.busy, 0));
+    const uint8_t* src = static_cast<const uint8_t*>(d_rsh);
+    const u32* sl = static_cast<const u32*>(d_slots);
+    uint8_t* dst = static_cast<uint8_t*>(d_bitmap);
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        hipEvent_t mid = nullptr, end = nullptr;
+        if (c.profiling) {
+            if (c.prof_used + 3 > c.prof_events.size())
+                for (int k = 0; k < 3; ++k) { hipEvent_t ev; HIP_TRY(SBV_EDEVICE, hipEventCreate(&ev)); c.prof_events.push_back(ev); }
+            HIP_TRY(SBV_EDEVICE, hipEventRecord(c.prof_events[c.prof_used], stream));
+            mid = c.prof_events[c.prof_used + 1];
+            end = c.prof_events[c.prof_used + 2];
+            c.prof_used += 3;
+        }
+        rc = enqueue_keyed(c, src + off * 96, sl + off, m, dst + off / 8, stream, mid);
+        if (rc != SBV_OK) return rc;
+        if (end) HIP_TRY(SBV_EDEVICE, hipEventRecord(end, stream));
+    }
+    HIP_TRY(SBV_EDEVICE, hipEventRecord(c.busy, stream));
+    c.busy_valid = true;
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* accept_bitmap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (n == 0) return SBV_OK;
+    if (!rsh || !slots || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
+    if (c.nkeys == 0) { g_err = "no keys registered"; return SBV_EINVAL; }
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    int rc = ensure_capacity(c, n < kMaxChunk ? n : kMaxChunk);
+    if (rc != SBV_OK) return rc;
+    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(c.stream, c.busy, 0));
+    sbv_timing tm{};
+    tm.n = n;
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[0], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_tuples, rsh + off * 96, m * 96, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_slots, slots + off, m * sizeof(u32), hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
+        rc = enqueue_keyed(c, c.d_tuples, c.d_slots, m, c.d_bitmap, c.stream, c.ev[2]);
+        if (rc != SBV_OK) return rc;
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.h_bitmap, c.d_bitmap, (m + 7) / 8, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[4], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(c.stream));
+        memcpy(accept_bitmap + off / 8, c.h_bitmap, (m + 7) / 8);
+        tm.h2d_us += 1e3 * ms_between(c.ev[0], c.ev[1]);
+        tm.prep_us += 1e3 * ms_between(c.ev[1], c.ev[2]);
+        tm.verify_us += 1e3 * ms_between(c.ev[2], c.ev[3]);
+        tm.d2h_us += 1e3 * ms_between(c.ev[3], c.ev[4]);
+    }
+    c.busy_valid = false;
     tm.total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     c.timing = tm;
     return SBV_OK;

@@ -2,10 +2,37 @@
 
 #include <string.h>
 
+#include <atomic>
+#include <thread>
+#include <vector>
+
 #include "../../include/sbv.h"
 #include "p256_host.h"
 
 namespace sbvhost {
+
+namespace {
+// Host-side tuple preparation (SHA-256 of Msg, DER parse, digest binding) is ~1 us per signature
+// per core; for 10^4..10^6-signature batches it must not run on one thread or it — not the GPU —
+// bounds the batch.  Plain fork-join over hardware threads.
+template <typename F>
+void parallel_chunks(size_t n, F fn) {
+    const size_t min_per_thread = 2048;
+    size_t threads = std::thread::hardware_concurrency();
+    if (threads == 0) threads = 1;
+    if (threads > 64) threads = 64;
+    if (n / min_per_thread < threads) threads = n / min_per_thread;
+    if (threads <= 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + threads - 1) / threads;
+    for (size_t t = 0; t < threads; ++t) {
+        const size_t lo = t * per, hi = lo + per < n ? lo + per : n;
+        if (lo >= hi) break;
+        th.emplace_back([=, &fn] { fn(lo, hi); });
+    }
+    for (auto& t : th) t.join();
+}
+}  // namespace
 
 // ---- backends ------------------------------------------------------------------------------------
 namespace {
@@ -219,15 +246,20 @@ Status Verifier::VerifyProposal(const Proposal& p, std::vector<RequestInfo>* req
     const size_t n = reqs.size();
     std::vector<uint8_t> tuples(n * 160), bitmap((n + 7) / 8, 0);
     std::vector<RequestInfo> infos(n);
-    for (size_t i = 0; i < n; ++i) {
-        Request r;
-        if (!request_parse(reqs[i], &r)) return Status::Invalid("malformed request in proposal");
-        uint8_t q[64];
-        if (!client_key(r.client_id, q)) return Status::Invalid("unknown client in proposal");
-        make_tuple(q, r.signed_part, r.sig, &tuples[i * 160]);
-        infos[i].client_id = r.client_id;
-        infos[i].id = r.id;
-    }
+    std::atomic<int> bad(0);            // 1 = malformed request, 2 = unknown client
+    parallel_chunks(n, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            Request r;
+            if (!request_parse(reqs[i], &r)) { bad.store(1); return; }
+            uint8_t q[64];
+            if (!client_key(r.client_id, q)) { bad.store(2); return; }
+            make_tuple(q, r.signed_part, r.sig, &tuples[i * 160]);
+            infos[i].client_id = r.client_id;
+            infos[i].id = r.id;
+        }
+    });
+    if (bad.load() == 1) return Status::Invalid("malformed request in proposal");
+    if (bad.load() == 2) return Status::Invalid("unknown client in proposal");
     if (n) {
         const int rc = co_.submit_many(tuples.data(), n, bitmap.data());
         if (rc != 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());
@@ -243,18 +275,20 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
     const size_t n = sigs.size();
     if (props.size() != n) return Status::Invalid("size mismatch");
     std::vector<uint8_t> tuples(n * 160, 0), bitmap((n + 7) / 8, 0), pre(n, 1);
-    const Proposal* last = nullptr;
-    bytes last_digest;
-    for (size_t i = 0; i < n; ++i) {
-        uint8_t q[64];
-        bytes binding;
-        if (props[i] != last) { last = props[i]; last_digest = proposal_digest_raw(*last); }
-        if (!consenter_key(sigs[i].id, q) || !consenter_msg_split(sigs[i].msg, &binding, nullptr) || binding != last_digest) {
-            pre[i] = 0;                 // tuple stays all-zero: rejected by the range check as well
-            continue;
+    parallel_chunks(n, [&](size_t lo, size_t hi) {
+        const Proposal* last = nullptr;
+        bytes last_digest;
+        for (size_t i = lo; i < hi; ++i) {
+            uint8_t q[64];
+            bytes binding;
+            if (props[i] != last) { last = props[i]; last_digest = proposal_digest_raw(*last); }
+            if (!consenter_key(sigs[i].id, q) || !consenter_msg_split(sigs[i].msg, &binding, nullptr) || binding != last_digest) {
+                pre[i] = 0;             // tuple stays all-zero: rejected by the range check as well
+                continue;
+            }
+            make_tuple(q, sigs[i].msg, sigs[i].value, &tuples[i * 160]);
         }
-        make_tuple(q, sigs[i].msg, sigs[i].value, &tuples[i * 160]);
-    }
+    });
     if (n) {
         const int rc = co_.submit_many(tuples.data(), n, bitmap.data());
         if (rc != 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());

@@ -69,6 +69,24 @@ int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitma
  * The caller synchronises the stream.  Used by bench.py / multi-GPU shards. */
 int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, void* hip_stream);
 
+/* ---- registered public keys ---------------------------------------------------------------------
+ * SmartBFT's consenter set (and an application's client set) is a registry: types.Signature.ID
+ * selects the key (pkg/types/types.go:25-29), it is not carried per signature.  Registering a key
+ * builds a fixed-base comb for it (33 x 128 affine multiples, 270 KiB of HBM per key) once, after
+ * which a verification against that key needs NO point doublings: R = u1*G + u2*Q is 66 mixed
+ * additions (~4.7x fewer field multiplications than the generic form).  Verdicts are identical to
+ * the generic entry points: a key that crypto/ecdsa would refuse (coordinate >= p, off curve) still
+ * gets a slot, flagged invalid, and every signature against it is rejected.
+ *   keys: m x 64 bytes (Qx|Qy big-endian).  slots_out[i] = slot of keys[i] (equal keys share a slot). */
+int sbv_p256_register_keys(const uint8_t* keys, size_t m, uint32_t* slots_out);
+int sbv_p256_key_count(void);
+int sbv_p256_clear_keys(void);
+/* rsh: n x 96 bytes (r|s|hash, big-endian), slots: n key slots.  Takes over VerifyConsenterSig
+ * (view.go:631, 834), VerifySignature (viewchanger.go:598...) and decision replay for registered
+ * signers.  An out-of-range slot is a reject, not an error. */
+int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* accept_bitmap);
+int sbv_p256_verify_batch_keyed_dev(const void* d_rsh, const void* d_slots, size_t n, void* d_bitmap, void* hip_stream);
+
 /* Strict DER parse of an ECDSA-Sig-Value with Go x/crypto/cryptobyte rules
  * (crypto/ecdsa.parseSignature): out = r | s, 32 bytes each, big-endian, zero padded.
  * Returns SBV_OK or SBV_EPARSE (then out is all zero, which every verify rejects). */

@@ -24,11 +24,12 @@ static const apt* gtab() {
 
 struct HostWords {
     const uint8_t* tuples;
+    size_t stride = 160;
     struct W {
         const uint8_t* p;
         u32 operator[](int i) const { u32 v; memcpy(&v, p + 4 * i, 4); return v; }
     };
-    W operator()(int, size_t idx) const { return W{tuples + 160 * idx}; }
+    W operator()(int, size_t idx) const { return W{tuples + stride * idx}; }
 };
 
 extern "C" {
@@ -42,14 +43,42 @@ void sbve_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap, in
     Scratch s{r.data(), u1.data(), u2.data(), qx.data(), qy.data(), sm.data(), ok.data(), cap};
     const size_t per_block = (size_t)block * T;
     const size_t nblocks = (n + per_block - 1) / per_block;
-    HostWords hw{tuples};
+    HostWords hw{tuples, 160};
     for (size_t b = 0; b < nblocks; ++b)
-        for (int t = 0; t < block; ++t) prep_chunk(hw, n, s, b * per_block + t, (size_t)block, T);
+        for (int t = 0; t < block; ++t) prep_chunk<true>(hw, n, s, b * per_block + t, (size_t)block, T);
     memset(bitmap, 0, (n + 7) / 8);
     u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB_ENTRIES * 40 * 4);
     for (size_t i = 0; i < n; ++i)
         if (verify_lane(s, i, qtab, gtab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
     free(qtab);
+}
+
+// registered-key form: rsh = n x 96 B (r|s|hash), slots[i] indexes keys (nkeys x 64 B, Qx|Qy)
+void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n, const uint8_t* keys, u32 nkeys,
+                                  uint8_t* bitmap, int block, int T) {
+    size_t cap = (n + 63) & ~(size_t)63;
+    if (cap == 0) cap = 64;
+    std::vector<u32> r(8 * cap), u1(8 * cap), u2(8 * cap), sm(8 * cap);
+    std::vector<uint8_t> ok(cap, 0);
+    Scratch s{r.data(), u1.data(), u2.data(), nullptr, nullptr, sm.data(), ok.data(), cap};
+    const size_t per_block = (size_t)block * T;
+    const size_t nblocks = (n + per_block - 1) / per_block;
+    HostWords hw{rsh, 96};
+    for (size_t b = 0; b < nblocks; ++b)
+        for (int t = 0; t < block; ++t) prep_chunk<false>(hw, n, s, b * per_block + t, (size_t)block, T);
+    const size_t per_key = (size_t)SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW;
+    std::vector<apt> ktab(per_key * (nkeys ? nkeys : 1));
+    std::vector<uint8_t> kvalid(nkeys ? nkeys : 1, 0);
+    for (u32 k = 0; k < nkeys; ++k) {
+        u256 x, y;
+        from_be32(x, keys + 64 * k);
+        from_be32(y, keys + 64 * k + 32);
+        kvalid[k] = key_is_valid(x, y) ? 1 : 0;
+        if (kvalid[k]) build_comb_table(x, y, &ktab[per_key * k]);
+    }
+    memset(bitmap, 0, (n + 7) / 8);
+    for (size_t i = 0; i < n; ++i)
+        if (verify_lane_keyed(s, i, slots[i], nkeys, ktab.data(), kvalid.data(), gtab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
 }
 
 // ---- unit hooks (plain little-endian limb arrays) ---------------------------------------------------

