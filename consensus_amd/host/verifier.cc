@@ -43,6 +43,15 @@ class SbvBackend : public Backend {
         if (rc_ != SBV_OK) return rc_;                 // no device: every batch is UNAVAILABLE, never a CPU guess
         return sbv_p256_verify_batch(tuples, n, bitmap);
     }
+    long register_key(const uint8_t q[64]) override {
+        if (rc_ != SBV_OK) return -1;
+        uint32_t slot = 0;
+        return sbv_p256_register_keys(q, 1, &slot) == SBV_OK ? (long)slot : -1;
+    }
+    int verify_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap) override {
+        if (rc_ != SBV_OK) return rc_;
+        return sbv_p256_verify_batch_keyed(rsh, slots, n, bitmap);
+    }
  private:
     int rc_;
 };
@@ -71,9 +80,10 @@ Coalescer::~Coalescer() {
     th_.join();
 }
 
-int Coalescer::submit(const uint8_t tuple[160]) {
+int Coalescer::submit(const uint8_t tuple[160], long slot) {
     Job j;
     memcpy(j.tuple, tuple, 160);
+    j.slot = slot;
     std::unique_lock<std::mutex> lk(mu_);
     q_.push_back(&j);
     ++st_.calls;
@@ -89,6 +99,15 @@ int Coalescer::submit_many(const uint8_t* tuples, size_t n, uint8_t* bitmap) {
         if (n > st_.max_batch) st_.max_batch = n;
     }
     return be_->verify(tuples, n, bitmap);      // the backend serialises device work itself
+}
+
+int Coalescer::submit_many_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap) {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        ++st_.batches;
+        if (n > st_.max_batch) st_.max_batch = n;
+    }
+    return be_->verify_keyed(rsh, slots, n, bitmap);
 }
 
 CoalescerStats Coalescer::stats() {
@@ -115,10 +134,20 @@ void Coalescer::run() {
             if (batch.size() > st_.max_batch) st_.max_batch = batch.size();
         }
         const size_t n = batch.size();
-        tuples.resize(n * 160);
         bitmap.assign((n + 7) / 8, 0);
-        for (size_t i = 0; i < n; ++i) memcpy(&tuples[i * 160], batch[i]->tuple, 160);
-        const int rc = be_->verify(tuples.data(), n, bitmap.data());
+        bool all_keyed = true;
+        for (size_t i = 0; i < n; ++i) all_keyed = all_keyed && batch[i]->slot >= 0;
+        int rc;
+        if (all_keyed) {                 // the commit-vote burst: every signer is a registered consenter
+            tuples.resize(n * 96);
+            std::vector<uint32_t> slots(n);
+            for (size_t i = 0; i < n; ++i) { memcpy(&tuples[i * 96], batch[i]->tuple, 96); slots[i] = (uint32_t)batch[i]->slot; }
+            rc = be_->verify_keyed(tuples.data(), slots.data(), n, bitmap.data());
+        } else {
+            tuples.resize(n * 160);
+            for (size_t i = 0; i < n; ++i) memcpy(&tuples[i * 160], batch[i]->tuple, 160);
+            rc = be_->verify(tuples.data(), n, bitmap.data());
+        }
         {
             std::lock_guard<std::mutex> lk(mu_);
             for (size_t i = 0; i < n; ++i) {
@@ -135,8 +164,10 @@ Verifier::Verifier(std::shared_ptr<Backend> be, const VerifierOptions& opt)
     : opt_(opt), co_(be, opt.coalesce_max, opt.coalesce_wait) {}
 
 void Verifier::RegisterConsenter(uint64_t id, const uint8_t q[64]) {
+    const long slot = co_.backend().register_key(q);     // -1: backend without a key registry
     std::lock_guard<std::mutex> lk(mu_);
     consenters_[id] = bytes((const char*)q, 64);
+    consenter_slot_[id] = slot;
 }
 void Verifier::RegisterClient(const std::string& client_id, const uint8_t q[64]) {
     std::lock_guard<std::mutex> lk(mu_);
@@ -145,11 +176,12 @@ void Verifier::RegisterClient(const std::string& client_id, const uint8_t q[64])
 void Verifier::SetVerificationSequence(uint64_t s) { std::lock_guard<std::mutex> lk(mu_); seq_ = s; }
 uint64_t Verifier::VerificationSequence() { std::lock_guard<std::mutex> lk(mu_); return seq_; }
 
-bool Verifier::consenter_key(uint64_t id, uint8_t q[64]) {
+bool Verifier::consenter_key(uint64_t id, uint8_t q[64], long* slot) {
     std::lock_guard<std::mutex> lk(mu_);
     auto it = consenters_.find(id);
     if (it == consenters_.end()) return false;
     memcpy(q, it->second.data(), 64);
+    if (slot) *slot = consenter_slot_[id];
     return true;
 }
 bool Verifier::client_key(const std::string& id, uint8_t q[64]) {
@@ -168,7 +200,7 @@ void Verifier::make_tuple(const uint8_t q[64], const bytes& msg, const bytes& si
     memcpy(out + 96, q, 64);
 }
 
-Status Verifier::verify_one(const uint8_t q[64], const bytes& msg, const bytes& sig) {
+Status Verifier::verify_one(const uint8_t q[64], const bytes& msg, const bytes& sig, long slot) {
     std::string key;
     if (opt_.cache_verified) {
         bytes cat((const char*)q, 64);
@@ -180,7 +212,7 @@ Status Verifier::verify_one(const uint8_t q[64], const bytes& msg, const bytes& 
     }
     uint8_t t[160];
     make_tuple(q, msg, sig, t);
-    const int r = co_.submit(t);
+    const int r = co_.submit(t, slot);
     if (r < 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());
     if (opt_.cache_verified) {
         std::lock_guard<std::mutex> lk(cache_mu_);
@@ -192,8 +224,9 @@ Status Verifier::verify_one(const uint8_t q[64], const bytes& msg, const bytes& 
 
 Status Verifier::VerifySignature(const Signature& s) {        // viewchanger.go:598, 660, 983, 1022, 1076
     uint8_t q[64];
-    if (!consenter_key(s.id, q)) return Status::Invalid("unknown signer");
-    return verify_one(q, s.msg, s.value);
+    long slot = -1;
+    if (!consenter_key(s.id, q, &slot)) return Status::Invalid("unknown signer");
+    return verify_one(q, s.msg, s.value, slot);
 }
 
 Status Verifier::VerifyConsenterSig(const Signature& s, const Proposal& prop, bytes* aux) {   // view.go:631, 834
@@ -275,22 +308,33 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
     const size_t n = sigs.size();
     if (props.size() != n) return Status::Invalid("size mismatch");
     std::vector<uint8_t> tuples(n * 160, 0), bitmap((n + 7) / 8, 0), pre(n, 1);
+    std::vector<uint32_t> slots(n, 0);
+    std::atomic<int> unkeyed(0);
     parallel_chunks(n, [&](size_t lo, size_t hi) {
         const Proposal* last = nullptr;
         bytes last_digest;
         for (size_t i = lo; i < hi; ++i) {
             uint8_t q[64];
             bytes binding;
+            long slot = -1;
             if (props[i] != last) { last = props[i]; last_digest = proposal_digest_raw(*last); }
-            if (!consenter_key(sigs[i].id, q) || !consenter_msg_split(sigs[i].msg, &binding, nullptr) || binding != last_digest) {
+            if (!consenter_key(sigs[i].id, q, &slot) || !consenter_msg_split(sigs[i].msg, &binding, nullptr) || binding != last_digest) {
                 pre[i] = 0;             // tuple stays all-zero: rejected by the range check as well
                 continue;
             }
             make_tuple(q, sigs[i].msg, sigs[i].value, &tuples[i * 160]);
+            if (slot < 0) unkeyed.store(1); else slots[i] = (uint32_t)slot;
         }
     });
     if (n) {
-        const int rc = co_.submit_many(tuples.data(), n, bitmap.data());
+        int rc;
+        if (!unkeyed.load()) {          // every signer registered with the backend: r|s|hash + slot, no doublings
+            std::vector<uint8_t> rsh(n * 96);
+            parallel_chunks(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) memcpy(&rsh[i * 96], &tuples[i * 160], 96); });
+            rc = co_.submit_many_keyed(rsh.data(), slots.data(), n, bitmap.data());
+        } else {
+            rc = co_.submit_many(tuples.data(), n, bitmap.data());
+        }
         if (rc != 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());
     }
     out->assign(n, 0);

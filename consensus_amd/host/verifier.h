@@ -41,6 +41,13 @@ class Backend {
  public:
     virtual ~Backend() {}
     virtual int verify(const uint8_t* tuples, size_t n, uint8_t* bitmap) = 0;
+    // Optional registered-key form (include/sbv.h: sbv_p256_register_keys / verify_batch_keyed).
+    // register_key returns a slot >= 0, or -1 when the backend has no key registry (then callers
+    // use verify() with the key carried in the tuple).
+    virtual long register_key(const uint8_t q[64]) { (void)q; return -1; }
+    virtual int verify_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap) {
+        (void)rsh; (void)slots; (void)n; (void)bitmap; return -2;
+    }
 };
 std::shared_ptr<Backend> make_sbv_backend(int device);     // sbv_init(device) + sbv_p256_verify_batch
 typedef int (*backend_fn)(const uint8_t* tuples, size_t n, uint8_t* bitmap, void* user);
@@ -61,12 +68,15 @@ class Coalescer {
     Coalescer(std::shared_ptr<Backend> be, size_t max_batch, std::chrono::microseconds max_wait);
     ~Coalescer();
     // 1 = accept, 0 = reject, <0 = backend error
-    int submit(const uint8_t tuple[160]);
+    // slot >= 0: the signer's key is registered with the backend (tuple[96..160) is then ignored)
+    int submit(const uint8_t tuple[160], long slot = -1);
     int submit_many(const uint8_t* tuples, size_t n, uint8_t* bitmap);
+    int submit_many_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap);
+    Backend& backend() { return *be_; }
     CoalescerStats stats();
 
  private:
-    struct Job { uint8_t tuple[160]; int result = -100; bool done = false; };
+    struct Job { uint8_t tuple[160]; long slot = -1; int result = -100; bool done = false; };
     void run();
     std::shared_ptr<Backend> be_;
     size_t max_batch_;
@@ -112,12 +122,13 @@ class Verifier {
     CoalescerStats stats() { return co_.stats(); }
 
  private:
-    bool consenter_key(uint64_t id, uint8_t q[64]);
+    bool consenter_key(uint64_t id, uint8_t q[64], long* slot = nullptr);
     bool client_key(const std::string& id, uint8_t q[64]);
     void make_tuple(const uint8_t q[64], const bytes& msg, const bytes& sig_der, uint8_t out[160]);
-    Status verify_one(const uint8_t q[64], const bytes& msg, const bytes& sig);
+    Status verify_one(const uint8_t q[64], const bytes& msg, const bytes& sig, long slot = -1);
     std::mutex mu_;
     std::map<uint64_t, bytes> consenters_;
+    std::map<uint64_t, long> consenter_slot_;
     std::map<std::string, bytes> clients_;
     uint64_t seq_ = 0;
     VerifierOptions opt_;
