@@ -79,6 +79,10 @@ def load() -> ctypes.CDLL:
     lib.sbv_p256_verify_batch_keyed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.sbv_p256_verify_batch_keyed_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p,
                                                     ctypes.c_void_p]
+    lib.sbv_ed25519_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.sbv_ed25519_verify_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    lib.sbv_ed25519_make_tuples.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
+                                            ctypes.c_size_t, ctypes.c_char_p]
     lib.sbv_last_timing.argtypes = [ctypes.POINTER(Timing)]
     lib.sbv_profile_enable.argtypes = [ctypes.c_int]
     lib.sbv_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
@@ -161,6 +165,33 @@ def verify_batch_keyed(rsh: bytes, slots, n: Optional[int] = None) -> bytes:
 
 def verify_batch_keyed_dev(d_rsh_ptr: int, d_slots_ptr: int, n: int, d_bitmap_ptr: int, stream: int = 0) -> None:
     _check(load().sbv_p256_verify_batch_keyed_dev(d_rsh_ptr, d_slots_ptr, n, d_bitmap_ptr, stream))
+
+
+def ed25519_make_tuples(sigs, pks, msgs) -> bytes:
+    """(64-byte sig, 32-byte pk, message) triples -> n x 128-byte tuples (R | S | pk | k)."""
+    n = len(sigs)
+    offs = (ctypes.c_uint64 * (n + 1))()
+    acc = 0
+    for i, m in enumerate(msgs):
+        offs[i] = acc
+        acc += len(m)
+    offs[n] = acc
+    out = ctypes.create_string_buffer(max(1, 128 * n))
+    _check(load().sbv_ed25519_make_tuples(b"".join(sigs), b"".join(pks), b"".join(msgs), offs, n, out))
+    return out.raw[:128 * n]
+
+
+def ed25519_verify_batch(tuples: bytes, n: Optional[int] = None) -> bytes:
+    if n is None:
+        n = len(tuples) // 128
+    out = ctypes.create_string_buffer(max(1, (n + 7) // 8))
+    buf = (ctypes.c_char * len(tuples)).from_buffer_copy(tuples) if n else None
+    _check(load().sbv_ed25519_verify_batch(buf, n, out))
+    return out.raw[:(n + 7) // 8]
+
+
+def ed25519_verify_batch_dev(d_tuples_ptr: int, n: int, d_bitmap_ptr: int, stream: int = 0) -> None:
+    _check(load().sbv_ed25519_verify_batch_dev(d_tuples_ptr, n, d_bitmap_ptr, stream))
 
 
 def parse_der(sig: bytes) -> Optional[bytes]:

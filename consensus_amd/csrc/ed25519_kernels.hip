@@ -1,0 +1,64 @@
+// ed25519_kernels.hip — gfx950 kernel for the Ed25519 verifier variant (BASELINE.json configs[4]).
+//
+// One 128-byte tuple (R | S | A | k) per lane, 256 lanes per workgroup.  The workgroup's 32 KiB
+// tile of tuples is contiguous in HBM: it is fetched with coalesced 16-byte loads into LDS
+// (33-dword row pitch -> conflict-free per-lane ds_read_b32) and each lane then reads its own row.
+// [k](-A): 64 signed 4-bit windows from a per-signature projective-Niels table kept in HBM
+// (1 KiB per lane); [S]B: 32 signed 8-bit comb windows from a 393 KiB affine-Niels table (L2
+// resident).  Complete unified addition, no exceptional cases; one field inversion per lane to
+// re-encode R for the byte-wise comparison Go performs.  No scalar inversion -> no stage A.
+#include <hip/hip_runtime.h>
+
+#include "ed25519_core.h"
+#include "p256_kernels.h"
+
+namespace sbv {
+
+constexpr int kEdPitch = 33;
+
+struct EdLdsTuple {
+    const u32* row;
+    __device__ __forceinline__ u32 operator[](int i) const { return row[i]; }
+};
+
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_ed25519_verify(const uint8_t* __restrict__ tuples, size_t n,
+                                                                    u32* __restrict__ qtab,
+                                                                    const aniels* __restrict__ btab,
+                                                                    uint8_t* __restrict__ bitmap) {
+    __shared__ u32 lds[SBV_VERIFY_BLOCK * kEdPitch];
+    const size_t tile = (size_t)blockIdx.x * SBV_VERIFY_BLOCK;
+    const int tid = threadIdx.x;
+    const uint4* src = reinterpret_cast<const uint4*>(tuples + tile * 128);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = it * SBV_VERIFY_BLOCK + tid;          // 16-byte element of the tile (8 per tuple)
+        const int t = e >> 3, part = e & 7;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (tile + (size_t)t < n) v = src[e];
+        u32* dst = lds + t * kEdPitch + part * 4;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    __syncthreads();
+    const size_t i = tile + (size_t)tid;
+    bool accept = false;
+    if (i < n) accept = ed25519_verify_lane(EdLdsTuple{lds + tid * kEdPitch}, qtab + i * (size_t)(SBV_ED_QTAB_ENTRIES * 32), btab);
+    const unsigned long long m = __ballot(accept);
+    const int lane = tid & 63;
+    const size_t wave_first = i - (size_t)lane;
+    if (lane < 8) {
+        const size_t byte = (wave_first >> 3) + (size_t)lane;
+        if (byte < ((n + 7) >> 3)) bitmap[byte] = (uint8_t)(m >> (8 * lane));
+    }
+}
+
+hipError_t launch_ed25519_verify(const uint8_t* d_tuples, size_t n, u32* d_qtab, const aniels* d_btab, uint8_t* d_bitmap,
+                                 hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
+    hipLaunchKernelGGL(k_ed25519_verify, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, n, d_qtab, d_btab, d_bitmap);
+    return hipGetLastError();
+}
+
+void host_build_ed_btable(aniels* out) { build_ed_btable(out); }
+
+}  // namespace sbv

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/sbv.h"
+#include "ed25519_kernels.h"
 #include "p256_kernels.h"
 
 namespace {
@@ -40,6 +41,7 @@ struct Context {
     hipEvent_t busy = nullptr;          // completion of the last launch that used the scratch
     bool busy_valid = false;
     sbv_timing timing{};
+    sbv::aniels* d_btab = nullptr;      // Ed25519 base-point comb, built on first use
     // registered keys
     sbv::apt* d_ktab = nullptr;
     uint8_t* d_kvalid = nullptr;
@@ -146,6 +148,8 @@ int ensure_key_capacity(Context& c, size_t want) {
         HIP_TRY(SBV_EDEVICE, hipMemcpy(nt, c.d_ktab, c.nkeys * kKeyTabBytes, hipMemcpyDeviceToDevice));
         HIP_TRY(SBV_EDEVICE, hipMemcpy(nv, c.d_kvalid, c.nkeys, hipMemcpyDeviceToDevice));
     }
+    if (c.d_btab) (void)hipFree(c.d_btab);
+    c.d_btab = nullptr;
     if (c.d_ktab) (void)hipFree(c.d_ktab);
     if (c.d_kvalid) (void)hipFree(c.d_kvalid);
     c.d_ktab = nt;
@@ -210,6 +214,8 @@ extern "C" int sbv_shutdown(void) {
     free_buffers(c);
     if (c.d_gtab) (void)hipFree(c.d_gtab);
     c.d_gtab = nullptr;
+    if (c.d_btab) (void)hipFree(c.d_btab);
+    c.d_btab = nullptr;
     if (c.d_ktab) (void)hipFree(c.d_ktab);
     if (c.d_kvalid) (void)hipFree(c.d_kvalid);
     c.d_ktab = nullptr; c.d_kvalid = nullptr; c.key_cap = c.nkeys = 0;
@@ -433,6 +439,85 @@ extern "C" int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* s
         tm.h2d_us += 1e3 * ms_between(c.ev[0], c.ev[1]);
         tm.prep_us += 1e3 * ms_between(c.ev[1], c.ev[2]);
         tm.verify_us += 1e3 * ms_between(c.ev[2], c.ev[3]);
+        tm.d2h_us += 1e3 * ms_between(c.ev[3], c.ev[4]);
+    }
+    c.busy_valid = false;
+    tm.total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    c.timing = tm;
+    return SBV_OK;
+}
+
+namespace {
+int ensure_ed_table(Context& c) {
+    if (c.d_btab) return SBV_OK;
+    std::vector<sbv::aniels> h((size_t)SBV_ED_BTAB_ENTRIES);
+    sbv::host_build_ed_btable(h.data());
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_btab, h.size() * sizeof(sbv::aniels)));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_btab, h.data(), h.size() * sizeof(sbv::aniels), hipMemcpyHostToDevice));
+    return SBV_OK;
+}
+}  // namespace
+
+extern "C" int sbv_ed25519_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, void* hip_stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (n == 0) return SBV_OK;
+    if (!d_tuples || !d_bitmap || (reinterpret_cast<uintptr_t>(d_tuples) & 15)) { g_err = "null or misaligned device pointer"; return SBV_EINVAL; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    int rc = ensure_capacity(c, n < kMaxChunk ? n : kMaxChunk);
+    if (rc != SBV_OK) return rc;
+    if ((rc = ensure_ed_table(c)) != SBV_OK) return rc;
+    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(stream, c.busy, 0));
+    const uint8_t* src = static_cast<const uint8_t*>(d_tuples);
+    uint8_t* dst = static_cast<uint8_t*>(d_bitmap);
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        hipEvent_t end = nullptr;
+        if (c.profiling) {
+            if (c.prof_used + 3 > c.prof_events.size())
+                for (int k = 0; k < 3; ++k) { hipEvent_t ev; HIP_TRY(SBV_EDEVICE, hipEventCreate(&ev)); c.prof_events.push_back(ev); }
+            HIP_TRY(SBV_EDEVICE, hipEventRecord(c.prof_events[c.prof_used], stream));
+            HIP_TRY(SBV_EDEVICE, hipEventRecord(c.prof_events[c.prof_used + 1], stream));     // no stage A
+            end = c.prof_events[c.prof_used + 2];
+            c.prof_used += 3;
+        }
+        HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify(src + off * 128, m, c.d_qtab, c.d_btab, dst + off / 8, stream));
+        if (end) HIP_TRY(SBV_EDEVICE, hipEventRecord(end, stream));
+    }
+    HIP_TRY(SBV_EDEVICE, hipEventRecord(c.busy, stream));
+    c.busy_valid = true;
+    return SBV_OK;
+}
+
+extern "C" int sbv_ed25519_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (n == 0) return SBV_OK;
+    if (!tuples || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    int rc = ensure_capacity(c, n < kMaxChunk ? n : kMaxChunk);
+    if (rc != SBV_OK) return rc;
+    if ((rc = ensure_ed_table(c)) != SBV_OK) return rc;
+    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(c.stream, c.busy, 0));
+    sbv_timing tm{};
+    tm.n = n;
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[0], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_tuples, tuples + off * 128, m * 128, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
+        HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify(c.d_tuples, m, c.d_qtab, c.d_btab, c.d_bitmap, c.stream));
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.h_bitmap, c.d_bitmap, (m + 7) / 8, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[4], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(c.stream));
+        memcpy(accept_bitmap + off / 8, c.h_bitmap, (m + 7) / 8);
+        tm.h2d_us += 1e3 * ms_between(c.ev[0], c.ev[1]);
+        tm.verify_us += 1e3 * ms_between(c.ev[1], c.ev[3]);
         tm.d2h_us += 1e3 * ms_between(c.ev[3], c.ev[4]);
     }
     c.busy_valid = false;

@@ -108,7 +108,100 @@ void sha256(const uint8_t* msg, size_t len, uint8_t out[32]) {
     }
 }
 
+// ---- SHA-512 and reduction mod L for Ed25519's k = H(R || A || M) ------------------------------------
+const uint64_t kSha512K[80] = {
+    0x428a2f98d728ae22ull, 0x7137449123ef65cdull, 0xb5c0fbcfec4d3b2full, 0xe9b5dba58189dbbcull, 0x3956c25bf348b538ull,
+    0x59f111f1b605d019ull, 0x923f82a4af194f9bull, 0xab1c5ed5da6d8118ull, 0xd807aa98a3030242ull, 0x12835b0145706fbeull,
+    0x243185be4ee4b28cull, 0x550c7dc3d5ffb4e2ull, 0x72be5d74f27b896full, 0x80deb1fe3b1696b1ull, 0x9bdc06a725c71235ull,
+    0xc19bf174cf692694ull, 0xe49b69c19ef14ad2ull, 0xefbe4786384f25e3ull, 0x0fc19dc68b8cd5b5ull, 0x240ca1cc77ac9c65ull,
+    0x2de92c6f592b0275ull, 0x4a7484aa6ea6e483ull, 0x5cb0a9dcbd41fbd4ull, 0x76f988da831153b5ull, 0x983e5152ee66dfabull,
+    0xa831c66d2db43210ull, 0xb00327c898fb213full, 0xbf597fc7beef0ee4ull, 0xc6e00bf33da88fc2ull, 0xd5a79147930aa725ull,
+    0x06ca6351e003826full, 0x142929670a0e6e70ull, 0x27b70a8546d22ffcull, 0x2e1b21385c26c926ull, 0x4d2c6dfc5ac42aedull,
+    0x53380d139d95b3dfull, 0x650a73548baf63deull, 0x766a0abb3c77b2a8ull, 0x81c2c92e47edaee6ull, 0x92722c851482353bull,
+    0xa2bfe8a14cf10364ull, 0xa81a664bbc423001ull, 0xc24b8b70d0f89791ull, 0xc76c51a30654be30ull, 0xd192e819d6ef5218ull,
+    0xd69906245565a910ull, 0xf40e35855771202aull, 0x106aa07032bbd1b8ull, 0x19a4c116b8d2d0c8ull, 0x1e376c085141ab53ull,
+    0x2748774cdf8eeb99ull, 0x34b0bcb5e19b48a8ull, 0x391c0cb3c5c95a63ull, 0x4ed8aa4ae3418acbull, 0x5b9cca4f7763e373ull,
+    0x682e6ff3d6b2b8a3ull, 0x748f82ee5defb2fcull, 0x78a5636f43172f60ull, 0x84c87814a1f0ab72ull, 0x8cc702081a6439ecull,
+    0x90befffa23631e28ull, 0xa4506cebde82bde9ull, 0xbef9a3f7b2c67915ull, 0xc67178f2e372532bull, 0xca273eceea26619cull,
+    0xd186b8c721c0c207ull, 0xeada7dd6cde0eb1eull, 0xf57d4f7fee6ed178ull, 0x06f067aa72176fbaull, 0x0a637dc5a2c898a6ull,
+    0x113f9804bef90daeull, 0x1b710b35131c471bull, 0x28db77f523047d84ull, 0x32caab7b40c72493ull, 0x3c9ebe0a15c9bebcull,
+    0x431d67c49c100d4cull, 0x4cc5d4becb3e42b6ull, 0x597f299cfc657e2aull, 0x5fcb6fab3ad6faecull, 0x6c44198c4a475817ull};
+inline uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+void sha512_compress(uint64_t st[8], const uint8_t* blk) {
+    uint64_t w[80];
+    for (int i = 0; i < 16; ++i) { uint64_t x = 0; for (int j = 0; j < 8; ++j) x = (x << 8) | blk[8 * i + j]; w[i] = x; }
+    for (int i = 16; i < 80; ++i)
+        w[i] = w[i - 16] + (rotr64(w[i - 15], 1) ^ rotr64(w[i - 15], 8) ^ (w[i - 15] >> 7)) + w[i - 7] +
+               (rotr64(w[i - 2], 19) ^ rotr64(w[i - 2], 61) ^ (w[i - 2] >> 6));
+    uint64_t v[8];
+    memcpy(v, st, sizeof v);
+    for (int i = 0; i < 80; ++i) {
+        const uint64_t t1 = v[7] + (rotr64(v[4], 14) ^ rotr64(v[4], 18) ^ rotr64(v[4], 41)) + ((v[4] & v[5]) ^ (~v[4] & v[6])) + kSha512K[i] + w[i];
+        const uint64_t t2 = (rotr64(v[0], 28) ^ rotr64(v[0], 34) ^ rotr64(v[0], 39)) + ((v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]));
+        v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + t1;
+        v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = t1 + t2;
+    }
+    for (int i = 0; i < 8; ++i) st[i] += v[i];
+}
+// SHA-512 over three concatenated pieces (R, A, M) without building the concatenation
+void sha512_3(const uint8_t* a, size_t al, const uint8_t* b, size_t bl, const uint8_t* c, size_t cl, uint8_t out[64]) {
+    uint64_t st[8] = {0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+                      0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull};
+    uint8_t buf[128];
+    size_t fill = 0;
+    const uint8_t* parts[3] = {a, b, c};
+    const size_t lens[3] = {al, bl, cl};
+    for (int p = 0; p < 3; ++p)
+        for (size_t i = 0; i < lens[p];) {
+            const size_t take = lens[p] - i < 128 - fill ? lens[p] - i : 128 - fill;
+            memcpy(buf + fill, parts[p] + i, take);
+            fill += take; i += take;
+            if (fill == 128) { sha512_compress(st, buf); fill = 0; }
+        }
+    const uint64_t bits = (uint64_t)(al + bl + cl) * 8;
+    buf[fill++] = 0x80;
+    if (fill > 112) { memset(buf + fill, 0, 128 - fill); sha512_compress(st, buf); fill = 0; }
+    memset(buf + fill, 0, 128 - fill);
+    for (int i = 0; i < 8; ++i) buf[127 - i] = (uint8_t)(bits >> (8 * i));
+    sha512_compress(st, buf);
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) out[8 * i + j] = (uint8_t)(st[i] >> (56 - 8 * j));
+}
+// x (64 bytes little-endian) mod L -> 32 bytes little-endian (edwards25519 Scalar.SetUniformBytes)
+void reduce_mod_l(const uint8_t in[64], uint8_t out[32]) {
+    static const uint64_t Lm[4] = {0x5812631a5cf5d3edull, 0x14def9dea2f79cd6ull, 0, 0x1000000000000000ull};
+    uint64_t acc[5] = {0, 0, 0, 0, 0};
+    for (int bit = 511; bit >= 0; --bit) {
+        uint64_t carry = (in[bit >> 3] >> (bit & 7)) & 1;
+        for (int i = 0; i < 5; ++i) { const uint64_t nc = acc[i] >> 63; acc[i] = (acc[i] << 1) | carry; carry = nc; }
+        uint64_t d[5], borrow = 0;
+        for (int i = 0; i < 5; ++i) {
+            const unsigned __int128 x = (unsigned __int128)acc[i] - (i < 4 ? Lm[i] : 0) - borrow;
+            d[i] = (uint64_t)x; borrow = (uint64_t)(x >> 64) & 1;
+        }
+        if (!borrow) memcpy(acc, d, sizeof d);
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) out[8 * i + j] = (uint8_t)(acc[i] >> (8 * j));
+}
+
 }  // namespace
+
+extern "C" int sbv_ed25519_make_tuples(const uint8_t* sigs, const uint8_t* pks, const uint8_t* msgs, const uint64_t* offsets,
+                                       size_t n, uint8_t* tuples_out) {
+    if (n == 0) return SBV_OK;
+    if (!sigs || !pks || !offsets || !tuples_out) return SBV_EINVAL;
+    static const uint8_t empty = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i]) return SBV_EINVAL;
+        uint8_t* t = tuples_out + 128 * i;
+        memcpy(t, sigs + 64 * i, 64);
+        memcpy(t + 64, pks + 32 * i, 32);
+        uint8_t h[64];
+        const size_t ml = (size_t)(offsets[i + 1] - offsets[i]);
+        sha512_3(sigs + 64 * i, 32, pks + 32 * i, 32, ml ? msgs + offsets[i] : &empty, ml, h);
+        reduce_mod_l(h, t + 96);
+    }
+    return SBV_OK;
+}
 
 extern "C" int sbv_p256_parse_der(const uint8_t* der, size_t len, uint8_t out_rs[64]) {
     if (!out_rs) return SBV_EINVAL;

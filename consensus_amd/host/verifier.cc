@@ -280,12 +280,18 @@ Status Verifier::VerifyProposal(const Proposal& p, std::vector<RequestInfo>* req
     std::vector<uint8_t> tuples(n * 160), bitmap((n + 7) / 8, 0);
     std::vector<RequestInfo> infos(n);
     std::atomic<int> bad(0);            // 1 = malformed request, 2 = unknown client
+    std::map<std::string, bytes> clients;           // snapshot: the workers must not contend on mu_
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        clients = clients_;
+    }
     parallel_chunks(n, [&](size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
             Request r;
             if (!request_parse(reqs[i], &r)) { bad.store(1); return; }
-            uint8_t q[64];
-            if (!client_key(r.client_id, q)) { bad.store(2); return; }
+            auto it = clients.find(r.client_id);
+            if (it == clients.end()) { bad.store(2); return; }
+            const uint8_t* q = (const uint8_t*)it->second.data();
             make_tuple(q, r.signed_part, r.sig, &tuples[i * 160]);
             infos[i].client_id = r.client_id;
             infos[i].id = r.id;
@@ -310,19 +316,27 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
     std::vector<uint8_t> tuples(n * 160, 0), bitmap((n + 7) / 8, 0), pre(n, 1);
     std::vector<uint32_t> slots(n, 0);
     std::atomic<int> unkeyed(0);
+    std::map<uint64_t, bytes> keys;                 // snapshot: the workers must not contend on mu_
+    std::map<uint64_t, long> key_slots;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        keys = consenters_;
+        key_slots = consenter_slot_;
+    }
     parallel_chunks(n, [&](size_t lo, size_t hi) {
         const Proposal* last = nullptr;
         bytes last_digest;
         for (size_t i = lo; i < hi; ++i) {
-            uint8_t q[64];
             bytes binding;
-            long slot = -1;
             if (props[i] != last) { last = props[i]; last_digest = proposal_digest_raw(*last); }
-            if (!consenter_key(sigs[i].id, q, &slot) || !consenter_msg_split(sigs[i].msg, &binding, nullptr) || binding != last_digest) {
+            auto it = keys.find(sigs[i].id);
+            if (it == keys.end() || !consenter_msg_split(sigs[i].msg, &binding, nullptr) || binding != last_digest) {
                 pre[i] = 0;             // tuple stays all-zero: rejected by the range check as well
                 continue;
             }
-            make_tuple(q, sigs[i].msg, sigs[i].value, &tuples[i * 160]);
+            make_tuple((const uint8_t*)it->second.data(), sigs[i].msg, sigs[i].value, &tuples[i * 160]);
+            const auto ks = key_slots.find(sigs[i].id);
+            const long slot = ks == key_slots.end() ? -1 : ks->second;
             if (slot < 0) unkeyed.store(1); else slots[i] = (uint32_t)slot;
         }
     });

@@ -87,6 +87,20 @@ int sbv_p256_clear_keys(void);
 int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* accept_bitmap);
 int sbv_p256_verify_batch_keyed_dev(const void* d_rsh, const void* d_slots, size_t n, void* d_bitmap, void* hip_stream);
 
+/* ---- Ed25519 variant (BASELINE.json configs[4]) ----------------------------------------------------
+ * Semantics of Go crypto/ed25519.Verify(pk, msg, sig) (crypto/internal/edwards25519): S canonical,
+ * A decoded with Go's leniency (non-canonical y accepted, no small-order rejection), cofactorless
+ * [S]B = R + [k]A checked by re-encoding R byte-wise.
+ * Tuple, 128 bytes little-endian as on the wire:  R (32) | S (32) | public key (32) | k (32), where
+ * k = SHA-512(R || pk || msg) mod L is produced by sbv_ed25519_hram_batch (host).  A tuple with
+ * k >= L or S >= L is rejected.  len(sig) != 64 is the caller's reject (encode as all-zero R, S = L). */
+#define SBV_ED25519_TUPLE_BYTES 128
+int sbv_ed25519_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap);
+int sbv_ed25519_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, void* hip_stream);
+/* Builds the tuples: sigs n x 64, pks n x 32, msgs packed (offsets[i]..offsets[i+1]) -> tuples n x 128. */
+int sbv_ed25519_make_tuples(const uint8_t* sigs, const uint8_t* pks, const uint8_t* msgs, const uint64_t* offsets,
+                            size_t n, uint8_t* tuples_out);
+
 /* Strict DER parse of an ECDSA-Sig-Value with Go x/crypto/cryptobyte rules
  * (crypto/ecdsa.parseSignature): out = r | s, 32 bytes each, big-endian, zero padded.
  * Returns SBV_OK or SBV_EPARSE (then out is all zero, which every verify rejects). */

@@ -52,3 +52,17 @@ void sbvssl_p256_verify_batch(const uint8_t *tuples, size_t n, uint8_t *bitmap, 
     }
     for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
 }
+
+/* Ed25519 third opinion (EVP_DigestVerify).  OpenSSL follows RFC 8032 with its own choices on
+ * non-canonical / small-order inputs, so tests consult it only on honest and bit-flipped
+ * signatures, where every correct implementation must agree. */
+#include <openssl/evp.h>
+int sbvssl_ed25519_verify(const uint8_t pk[32], const uint8_t *msg, size_t len, const uint8_t sig[64]) {
+    int ok = 0;
+    EVP_PKEY *key = EVP_PKEY_new_raw_public_key(EVP_PKEY_ED25519, NULL, pk, 32);
+    EVP_MD_CTX *ctx = EVP_MD_CTX_new();
+    if (key && ctx && EVP_DigestVerifyInit(ctx, NULL, NULL, NULL, key) == 1)
+        ok = EVP_DigestVerify(ctx, sig, 64, msg, len) == 1;
+    EVP_MD_CTX_free(ctx); EVP_PKEY_free(key);
+    return ok;
+}

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../consensus_amd/csrc/p256_core.h"
+#include "../../consensus_amd/csrc/ed25519_core.h"
 
 using namespace sbv;
 
@@ -80,6 +81,33 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
     for (size_t i = 0; i < n; ++i)
         if (verify_lane_keyed(s, i, slots[i], nkeys, ktab.data(), kvalid.data(), gtab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
 }
+
+// ---- Ed25519 -----------------------------------------------------------------------------------------
+static aniels* g_btab = nullptr;
+static const aniels* btab() {
+    if (!g_btab) {
+        g_btab = (aniels*)aligned_alloc(64, sizeof(aniels) * SBV_ED_BTAB_WINDOWS * SBV_ED_BTAB_PER_WINDOW);
+        build_ed_btable(g_btab);
+    }
+    return g_btab;
+}
+struct EdWords {
+    const uint8_t* p;
+    u32 operator[](int i) const { u32 v; memcpy(&v, p + 4 * i, 4); return v; }
+};
+void sbve_ed25519_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap) {
+    memset(bitmap, 0, (n + 7) / 8);
+    u32* qtab = (u32*)aligned_alloc(16, SBV_ED_QTAB_ENTRIES * 32 * 4);
+    for (size_t i = 0; i < n; ++i)
+        if (ed25519_verify_lane(EdWords{tuples + 128 * i}, qtab, btab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+    free(qtab);
+}
+void sbve_fe25_mul(const u32* a, const u32* b, u32* out) { fe25 x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe25_mul(z, x, y); memcpy(out, &z, 32); }
+void sbve_fe25_sqr(const u32* a, u32* out) { fe25 x, z; memcpy(&x, a, 32); fe25_sqr(z, x); memcpy(out, &z, 32); }
+void sbve_fe25_add(const u32* a, const u32* b, u32* out) { fe25 x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe25_add(z, x, y); memcpy(out, &z, 32); }
+void sbve_fe25_sub(const u32* a, const u32* b, u32* out) { fe25 x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe25_sub(z, x, y); memcpy(out, &z, 32); }
+void sbve_fe25_inv(const u32* a, u32* out) { fe25 x, z; memcpy(&x, a, 32); fe25_inv(z, x); memcpy(out, &z, 32); }
+void sbve_fe25_freeze(const u32* a, u32* out) { fe25 x, z; memcpy(&x, a, 32); fe25_freeze(z, x); memcpy(out, &z, 32); }
 
 // ---- unit hooks (plain little-endian limb arrays) ---------------------------------------------------
 void sbve_fe_mul(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe_mul(z, x, y); memcpy(out, &z, 32); }

@@ -1,0 +1,87 @@
+"""CPU tier for the Ed25519 variant (BASELINE.json configs[4]): oracle vs RFC 8032 / golden vectors /
+twin / OpenSSL, and the device algorithm (consensus_amd/csrc/ed25519_*.h) emulated lane by lane."""
+import ctypes
+import json
+import os
+import random
+
+import pytest
+
+import ed25519_py as ed
+from test_emul_device_algo import emul, limbs, val  # noqa: F401  (fixture + helpers)
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+P = ed.P
+
+
+@pytest.fixture(scope="module")
+def ed_vectors():
+    return json.load(open(os.path.join(GOLDEN, "ed25519_vectors.json")))["vectors"]
+
+
+def _tuples(vs):
+    return b"".join(ed.pack_tuple(bytes.fromhex(v["pk"]), bytes.fromhex(v["msg"]), bytes.fromhex(v["sig"])) for v in vs)
+
+
+def _bits(bm, n):
+    return [bool((bm[i >> 3] >> (i & 7)) & 1) for i in range(n)]
+
+
+def test_oracle_matches_vectors_and_openssl(oracle, openssl_check, ed_vectors):
+    oracle.sbvo_ed25519_verify.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    openssl_check.sbvssl_ed25519_verify.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    assert len(ed_vectors) >= 80 and sum(v["class"] == "rfc8032" for v in ed_vectors) == 3
+    n_ssl = 0
+    for v in ed_vectors:
+        pk, msg, sig = bytes.fromhex(v["pk"]), bytes.fromhex(v["msg"]), bytes.fromhex(v["sig"])
+        assert bool(oracle.sbvo_ed25519_verify(pk, msg, len(msg), sig, len(sig))) == v["accept"], v["name"]
+        if v["class"] in ("rfc8032", "honest", "bitflip"):
+            assert bool(openssl_check.sbvssl_ed25519_verify(pk, msg, len(msg), sig)) == v["accept"], v["name"]
+            n_ssl += 1
+    assert n_ssl >= 40
+
+
+def test_fe25_ops_match_bigint(emul):
+    rng = random.Random(25519)
+    R = 1 << 256
+    vals = [0, 1, 2, 19, P - 1, P, P + 1, 2 * P - 1, 2 * P, 2 * P + 37, R - 1, R - 38, R - 39, 2**255 - 1, 2**255, 2**255 + 18,
+            2**32 - 1, 2**224, (1 << 256) - (1 << 224)] + [rng.randrange(R) for _ in range(300)]
+    out = (ctypes.c_uint32 * 8)()
+    for i, a in enumerate(vals):
+        b = vals[(i * 7 + 3) % len(vals)]
+        emul.sbve_fe25_mul(limbs(a), limbs(b), out); assert val(out) % P == a * b % P and val(out) < R
+        emul.sbve_fe25_sqr(limbs(a), out); assert val(out) % P == a * a % P
+        emul.sbve_fe25_add(limbs(a), limbs(b), out); assert val(out) % P == (a + b) % P
+        emul.sbve_fe25_sub(limbs(a), limbs(b), out); assert val(out) % P == (a - b) % P
+        emul.sbve_fe25_freeze(limbs(a), out); assert val(out) == a % P
+    for a in [1, 2, P - 1, R - 1] + [rng.randrange(1, R) for _ in range(10)]:
+        if a % P == 0:
+            continue
+        emul.sbve_fe25_inv(limbs(a), out)
+        assert val(out) % P == pow(a % P, -1, P)
+
+
+def test_device_algorithm_on_golden_vectors_and_random_batch(emul, oracle, ed_vectors):
+    emul.sbve_ed25519_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    blob = _tuples(ed_vectors)
+    n = len(ed_vectors)
+    bm = ctypes.create_string_buffer((n + 7) // 8)
+    emul.sbve_ed25519_verify_batch(blob, n, bm)
+    bad = [v["name"] for v, g in zip(ed_vectors, _bits(bm.raw, n)) if g != v["accept"]]
+    assert not bad, bad
+    # tuples with k >= L or S >= L are rejected
+    t = bytearray(blob[:128])
+    t[96:128] = ed.L.to_bytes(32, "little")
+    emul.sbve_ed25519_verify_batch(bytes(t), 1, bm)
+    assert not _bits(bm.raw, 1)[0]
+    # seeded batch vs the C oracle
+    oracle.sbvo_ed25519_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int]
+    m = 700
+    tup = ctypes.create_string_buffer(128 * m)
+    exp = ctypes.create_string_buffer((m + 7) // 8)
+    oracle.sbvo_ed25519_gen_batch(0xED, m, 11, 3, tup, exp, 4)
+    bm = ctypes.create_string_buffer((m + 7) // 8)
+    emul.sbve_ed25519_verify_batch(tup.raw, m, bm)
+    assert bm.raw == exp.raw
+    assert sum(_bits(exp.raw, m)) == m - m // 3

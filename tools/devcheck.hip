@@ -11,15 +11,16 @@
 
 #include <vector>
 
+#include "../consensus_amd/csrc/ed25519_kernels.h"
 #include "../consensus_amd/csrc/p256_kernels.h"
 
 using namespace sbv;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
-enum { OP_MULW, OP_SQRW, OP_RED, OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_SCMUL, OP_SCINV, OP_DBL, OP_ADDM, OP_ADDQ, OP_ONCURVE, OP_REDDBG, OP_COUNT };
+enum { OP_MULW, OP_SQRW, OP_RED, OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_SCMUL, OP_SCINV, OP_DBL, OP_ADDM, OP_ADDQ, OP_ONCURVE, OP_REDDBG, OP_ED_MUL, OP_ED_SQR, OP_ED_ADD, OP_ED_SUB, OP_ED_FREEZE, OP_ED_INV, OP_ED_DBL, OP_ED_ADDP, OP_ED_DECOMP, OP_COUNT };
 static const char* kNames[OP_COUNT] = {"mul_wide", "sqr_wide", "fe_mont_reduce", "fe_mul", "fe_sqr", "fe_add", "fe_sub",
-                                       "sc_mul", "sc_inv", "pt_dbl", "pt_add_mixed", "pt_add_qent", "pt_on_curve", "reduce_debug_taps"};
+                                       "sc_mul", "sc_inv", "pt_dbl", "pt_add_mixed", "pt_add_qent", "pt_on_curve", "reduce_debug_taps", "fe25_mul", "fe25_sqr", "fe25_add", "fe25_sub", "fe25_freeze", "fe25_inv", "ed_dbl", "ed_add_pniels", "ed_decompress"};
 constexpr int IN_WORDS = 64, OUT_WORDS = 32;
 
 // fe_mont_reduce with taps: out[0..7] = M, out[8] = k+1, out[9..17] = acc after T_hi+M,
@@ -80,9 +81,30 @@ __host__ __device__ inline void run_op(int op, const u32* in, u32* out) {
     }
 }
 
+__host__ __device__ inline void run_op_ed(int op, const u32* in, u32* out) {
+    for (int i = 0; i < OUT_WORDS; ++i) out[i] = 0;
+    fe a, b, c, d;
+    memcpy(&a, in, 32); memcpy(&b, in + 8, 32); memcpy(&c, in + 16, 32); memcpy(&d, in + 24, 32);
+    switch (op) {
+        case OP_ED_MUL: { fe25 r; fe25_mul(r, a, b); memcpy(out, &r, 32); break; }
+        case OP_ED_SQR: { fe25 r; fe25_sqr(r, a); memcpy(out, &r, 32); break; }
+        case OP_ED_ADD: { fe25 r; fe25_add(r, a, b); memcpy(out, &r, 32); break; }
+        case OP_ED_SUB: { fe25 r; fe25_sub(r, a, b); memcpy(out, &r, 32); break; }
+        case OP_ED_FREEZE: { fe25 r; fe25_freeze(r, a); memcpy(out, &r, 32); break; }
+        case OP_ED_INV: { fe25 r; fe25_inv(r, a); memcpy(out, &r, 32); break; }
+        case OP_ED_DBL: { ept p{a, b, c, d}, r; ed_dbl(r, p); memcpy(out, &r, 128); break; }
+        case OP_ED_ADDP: { ept p{a, b, c, d}; pniels q; memcpy(&q, in + 32, 128); ed_add_pniels(p, q, (in[0] & 1) != 0, (in[1] & 3) == 0); memcpy(out, &p, 128); break; }
+        case OP_ED_DECOMP: { ept p; const bool ok = ed_decompress(p, in); memcpy(out, &p, 96); out[31] = ok ? 1u : 0u; break; }
+    }
+}
+
 __global__ void k_unit(int op, const u32* in, u32* out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) run_op(op, in + (size_t)i * IN_WORDS, out + (size_t)i * OUT_WORDS);
+}
+__global__ void k_unit_ed(int op, const u32* in, u32* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) run_op_ed(op, in + (size_t)i * IN_WORDS, out + (size_t)i * OUT_WORDS);
 }
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
@@ -109,17 +131,21 @@ static int unit_tests() {
                 const int mode = (i >> 4) & 3;          // mix in extreme limbs
                 w[k] = mode == 0 ? r : mode == 1 ? ((r & 1) ? 0xFFFFFFFFu : 0u) : mode == 2 ? (r | 0xFFFF0000u) : (r & 0xFFFFu);
             }
-            if (op != OP_MULW && op != OP_SQRW) {
+            if (op != OP_MULW && op != OP_SQRW && op < OP_ED_MUL) {
                 const u32* mod = (op == OP_SCMUL || op == OP_SCINV) ? nn.v : p.v;
                 for (int f = 0; f < 8; ++f) reduce_mod(w + 8 * f, mod);
                 if (op == OP_RED || op == OP_REDDBG) reduce_mod(w + 8, p.v);       // T < p * 2^256
             }
         }
-        const int cnt = op == OP_SCINV ? 256 : n;
-        for (int i = 0; i < cnt; ++i) run_op(op, &in[(size_t)i * IN_WORDS], &out_h[(size_t)i * OUT_WORDS]);
+        const int cnt = (op == OP_SCINV || op == OP_ED_INV || op == OP_ED_DECOMP) ? 256 : n;
+        for (int i = 0; i < cnt; ++i) {
+            if (op >= OP_ED_MUL) run_op_ed(op, &in[(size_t)i * IN_WORDS], &out_h[(size_t)i * OUT_WORDS]);
+            else run_op(op, &in[(size_t)i * IN_WORDS], &out_h[(size_t)i * OUT_WORDS]);
+        }
         CHECK(hipMemcpy(d_in, in.data(), in.size() * 4, hipMemcpyHostToDevice));
         CHECK(hipMemset(d_out, 0xAB, out_d.size() * 4));
-        hipLaunchKernelGGL(k_unit, dim3((cnt + 63) / 64), dim3(64), 0, 0, op, d_in, d_out, cnt);
+        if (op >= OP_ED_MUL) hipLaunchKernelGGL(k_unit_ed, dim3((cnt + 63) / 64), dim3(64), 0, 0, op, d_in, d_out, cnt);
+        else hipLaunchKernelGGL(k_unit, dim3((cnt + 63) / 64), dim3(64), 0, 0, op, d_in, d_out, cnt);
         CHECK(hipDeviceSynchronize());
         CHECK(hipMemcpy(out_d.data(), d_out, out_d.size() * 4, hipMemcpyDeviceToHost));
         int bad = 0, first = -1;
@@ -220,6 +246,7 @@ static int pipeline_test(const char* path) {
 }
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, NULL, _IONBF, 0);
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     printf("device %s (%s)\n", prop.name, prop.gcnArchName);
