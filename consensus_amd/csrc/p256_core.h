@@ -139,10 +139,11 @@ SBV_HD void fe_load16(fe& a, const u32* src) {
     a.v[0] = lo.x; a.v[1] = lo.y; a.v[2] = lo.z; a.v[3] = lo.w;
     a.v[4] = hi.x; a.v[5] = hi.y; a.v[6] = hi.z; a.v[7] = hi.w;
 }
-SBV_HD void qent_store(u32* dst, const jpt& p) {
+template <bool FAST = false>
+SBV_HD void qent_store(u32* dst, const jpt& p, u32* st = nullptr) {
     fe zz, zzz;
-    fe_sqr(zz, p.Z);
-    fe_mul(zzz, zz, p.Z);
+    fe_sqr<FAST>(zz, p.Z, st);
+    fe_mul<FAST>(zzz, zz, p.Z, st);
     fe_store16(dst, p.X);
     fe_store16(dst + 8, p.Y);
     fe_store16(dst + 16, p.Z);
@@ -167,12 +168,13 @@ SBV_HD u32 add_const_limbs(u256& out, const u256& v, u32 c_limb) {
 
 // R.x mod N == r  <=>  R != infinity and (X == r Z^2  or  (r + N < p and X == (r + N) Z^2))  (mod p),
 // with r < N; no inversion.
-SBV_HD bool rx_matches(const jpt& R, const u256& r) {
+template <bool FAST = false>
+SBV_HD bool rx_matches(const jpt& R, const u256& r, u32* st = nullptr) {
     if (pt_is_inf(R)) return false;
     fe zz, rM, t;
-    fe_sqr(zz, R.Z);
-    fe_to_mont(rM, r);
-    fe_mul(t, rM, zz);
+    fe_sqr<FAST>(zz, R.Z, st);
+    fe_to_mont<FAST>(rM, r, st);
+    fe_mul<FAST>(t, rM, zz, st);
     bool match = fe_eq(t, R.X);
     const sc n_ = sc_n();
     const fe p_ = fe_p();
@@ -180,8 +182,8 @@ SBV_HD bool rx_matches(const jpt& R, const u256& r) {
     const u32 carry = add256(rn, r, n_);
     const bool wrap_possible = (carry == 0) && lt256(rn, p_);
     if (wrap_possible) {                    // only for r < p - N ~ 2^128: essentially never
-        fe_to_mont(rM, rn);
-        fe_mul(t, rM, zz);
+        fe_to_mont<FAST>(rM, rn, st);
+        fe_mul<FAST>(t, rM, zz, st);
         match = match || fe_eq(t, R.X);
     }
     return match;
@@ -190,7 +192,10 @@ SBV_HD bool rx_matches(const jpt& R, const u256& r) {
 // Returns accept (true) / reject for lane `i`.  `qtab` = this lane's private table space
 // (SBV_QTAB_ENTRIES * 40 dwords, 16-byte aligned), `gtab` = 33 x 128 affine multiples of G:
 // gtab[j * 128 + (k-1)] = k * 2^(8j) * G.
-SBV_HD bool verify_lane(const Scratch& s, size_t i, u32* qtab, const apt* gtab) {
+// FAST = true is the first pass (see fe_cond_sub_p_t): *st must start at 0 and the caller re-runs
+// FAST = false for lanes whose sticky word came back 0xFFFFFFFF.
+template <bool FAST = false>
+SBV_HD bool verify_lane(const Scratch& s, size_t i, u32* qtab, const apt* gtab, u32* st = nullptr) {
     u256 r, u1, u2, qx, qy;
     soa_load(r, s.r, s.cap, i);
     soa_load(u1, s.u1, s.cap, i);
@@ -200,20 +205,20 @@ SBV_HD bool verify_lane(const Scratch& s, size_t i, u32* qtab, const apt* gtab) 
     bool ok = s.ok[i] != 0;
 
     apt Q;
-    fe_to_mont(Q.x, qx);
-    fe_to_mont(Q.y, qy);
-    ok = ok && pt_on_curve(Q.x, Q.y);
+    fe_to_mont<FAST>(Q.x, qx, st);
+    fe_to_mont<FAST>(Q.y, qy, st);
+    ok = ok && pt_on_curve<FAST>(Q.x, Q.y, st);
 
     // per-signature table: k*Q for k = 1..8, Jacobian with cached Z^2, Z^3
     {
         jpt t;
         t.X = Q.x; t.Y = Q.y; t.Z = fe_one();
-        qent_store(qtab, t);
-        pt_dbl(t, t);
-        qent_store(qtab + 40, t);
+        qent_store<FAST>(qtab, t, st);
+        pt_dbl<FAST>(t, t, st);
+        qent_store<FAST>(qtab + 40, t, st);
         for (int k = 3; k <= SBV_QTAB_ENTRIES; ++k) {
-            pt_add_mixed(t, Q, false, false);
-            qent_store(qtab + (k - 1) * 40, t);
+            pt_add_mixed<FAST>(t, Q, false, false, st);
+            qent_store<FAST>(qtab + (k - 1) * 40, t, st);
         }
     }
 
@@ -238,13 +243,13 @@ SBV_HD bool verify_lane(const Scratch& s, size_t i, u32* qtab, const apt* gtab) 
         // keep ONE copy of the doubling in the instruction stream: dbl (13 KB) + add (21 KB) must
         // stay inside the 64 KB instruction cache two CUs share; 4 inlined copies did not.
         SBV_NOUNROLL
-        for (int t = 0; t < 4; ++t) pt_dbl(R, R);
+        for (int t = 0; t < 4; ++t) pt_dbl<FAST>(R, R, st);
         const int d = (int)((k2.v[w >> 3] >> ((w & 7) * 4)) & 15u) - 8;
         const int ad = d < 0 ? -d : d;
         const int idx = ad == 0 ? 0 : ad - 1;
         qent e;
         qent_load(e, qtab + idx * 40);
-        pt_add_qent(R, e, d < 0, d == 0);
+        pt_add_qent<FAST>(R, e, d < 0, d == 0, st);
     }
     // fixed-base part: 32 signed 8-bit windows + the carry window
     for (int j = 0; j < 32; ++j) {
@@ -255,17 +260,17 @@ SBV_HD bool verify_lane(const Scratch& s, size_t i, u32* qtab, const apt* gtab) 
         const u32* gp = reinterpret_cast<const u32*>(gtab + (size_t)j * SBV_GTAB_PER_WINDOW + idx);
         fe_load16(g.x, gp);
         fe_load16(g.y, gp + 8);
-        pt_add_mixed(R, g, d < 0, d == 0);
+        pt_add_mixed<FAST>(R, g, d < 0, d == 0, st);
     }
     {
         apt g;
         const u32* gp = reinterpret_cast<const u32*>(gtab + (size_t)32 * SBV_GTAB_PER_WINDOW);
         fe_load16(g.x, gp);
         fe_load16(g.y, gp + 8);
-        pt_add_mixed(R, g, false, top1 == 0);
+        pt_add_mixed<FAST>(R, g, false, top1 == 0, st);
     }
 
-    return ok && rx_matches(R, r);
+    return ok && rx_matches<FAST>(R, r, st);
 }
 
 // ---- stage B, registered-key form -------------------------------------------------------------------
@@ -283,8 +288,9 @@ SBV_HD void comb_digit(const u256& k, u32 top, int j, int& idx, bool& neg, bool&
     skip = d == 0;
 }
 
+template <bool FAST = false>
 SBV_HD bool verify_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys, const apt* ktab,
-                              const uint8_t* kvalid, const apt* gtab) {
+                              const uint8_t* kvalid, const apt* gtab, u32* st = nullptr) {
     u256 r, u1, u2;
     soa_load(r, s.r, s.cap, i);
     soa_load(u1, s.u1, s.cap, i);
@@ -317,10 +323,10 @@ SBV_HD bool verify_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys, c
         const u32* gp = reinterpret_cast<const u32*>(tab + (size_t)jn * SBV_GTAB_PER_WINDOW + idxn);
         apt nxt;
         fe_load16(nxt.x, gp); fe_load16(nxt.y, gp + 8);
-        pt_add_mixed(R, cur, neg, skip);
+        pt_add_mixed<FAST>(R, cur, neg, skip, st);
         cur = nxt; neg = negn; skip = skipn;
     }
-    return ok && rx_matches(R, r);
+    return ok && rx_matches<FAST>(R, r, st);
 }
 
 // ---- fixed-base table generation (host, once per sbv_init; also used by tests/emul) -----------------

@@ -47,12 +47,36 @@ SBV_HD void fe_cond_sub_p(fe& r, const fe& t, u32 carry) {
     select256(r, use_d, d, t);
 }
 
-SBV_HD void fe_add(fe& r, const fe& a, const fe& b) {
+// FAST mode (stage B's first pass): the conditional subtraction only handles the carry == 1 half
+// (t - p = t + (2^256 - p) mod 2^256, one masked add chain, 8 instructions fewer) and the other
+// case — carry == 0 but t >= p, which needs t's top limb to be 0xFFFFFFFF, i.e. probability
+// 2^-32 per operation on random data — is only DETECTED: *st keeps the maximum top limb seen.
+// A lane whose sticky word reached 0xFFFFFFFF re-runs the exact (FAST = false) code, so verdicts
+// stay exact for every input while the common path loses the compare-and-select.
+template <bool FAST>
+SBV_HD void fe_cond_sub_p_t(fe& r, const fe& t, u32 carry, u32* st) {
+    if (!FAST) { fe_cond_sub_p(r, t, carry); return; }
+    *st = *st > t.v[7] ? *st : t.v[7];
+    const u32 m = 0u - carry;          // 2^256 - p = {1, 0, 0, ~0, ~0, ~0, ~0 - 1, 0}
+    u32 c = carry;                     // the +1 of limb 0 enters as the chain's carry-in
+    r.v[0] = addc(t.v[0], 0u, c);
+    r.v[1] = addc(t.v[1], 0u, c);
+    r.v[2] = addc(t.v[2], 0u, c);
+    r.v[3] = addc(t.v[3], m, c);
+    r.v[4] = addc(t.v[4], m, c);
+    r.v[5] = addc(t.v[5], m, c);
+    r.v[6] = addc(t.v[6], m & 0xFFFFFFFEu, c);
+    r.v[7] = addc(t.v[7], 0u, c);
+}
+
+template <bool FAST = false>
+SBV_HD void fe_add(fe& r, const fe& a, const fe& b, u32* st = nullptr) {
     fe t;
     u32 c = add256(t, a, b);
-    fe_cond_sub_p(r, t, c);
+    fe_cond_sub_p_t<FAST>(r, t, c, st);
 }
-SBV_HD void fe_dbl(fe& r, const fe& a) { fe_add(r, a, a); }
+template <bool FAST = false>
+SBV_HD void fe_dbl(fe& r, const fe& a, u32* st = nullptr) { fe_add<FAST>(r, a, a, st); }
 
 SBV_HD void fe_sub(fe& r, const fe& a, const fe& b) {
     fe d;
@@ -154,7 +178,8 @@ SBV_HD void sqr_wide(u32 t[16], const u32 a[8]) {
 // M = T_lo * (-p^-1) mod 2^256 with -p^-1 = 1 + 2^96 + 2^193 - 2^224 (mod 2^256), then
 // r = (T + M*p) / 2^256 = T_hi + M + (M >> 64) + (M >> 160) - (M >> 32) + k, where k is the
 // (small, signed) carry of the vanishing low half.  Shifts and adds only.
-SBV_HD void fe_mont_reduce(fe& r, const u32 t[16]) {
+template <bool FAST = false>
+SBV_HD void fe_mont_reduce(fe& r, const u32 t[16], u32* st = nullptr) {
     u32 m[8];
     {
         // M = T_lo + (T_lo << 96) + (T_lo << 193) - (T_lo << 224)   (mod 2^256)
@@ -205,22 +230,25 @@ SBV_HD void fe_mont_reduce(fe& r, const u32 t[16]) {
     fe tt;
     SBV_UNROLL
     for (int i = 0; i < 8; ++i) tt.v[i] = acc[i];
-    fe_cond_sub_p(r, tt, acc[8]);
+    fe_cond_sub_p_t<FAST>(r, tt, acc[8], st);
 }
 
-SBV_HD void fe_mul(fe& r, const fe& a, const fe& b) {
+template <bool FAST = false>
+SBV_HD void fe_mul(fe& r, const fe& a, const fe& b, u32* st = nullptr) {
     u32 t[16];
     mul_wide(t, a.v, b.v);
-    fe_mont_reduce(r, t);
+    fe_mont_reduce<FAST>(r, t, st);
 }
-SBV_HD void fe_sqr(fe& r, const fe& a) {
+template <bool FAST = false>
+SBV_HD void fe_sqr(fe& r, const fe& a, u32* st = nullptr) {
     u32 t[16];
     sqr_wide(t, a.v);
-    fe_mont_reduce(r, t);
+    fe_mont_reduce<FAST>(r, t, st);
 }
 
 // plain integer (< p) -> Montgomery form, and back
-SBV_HD void fe_to_mont(fe& r, const u256& a) { fe r2 = fe_r2(); fe_mul(r, a, r2); }
+template <bool FAST = false>
+SBV_HD void fe_to_mont(fe& r, const u256& a, u32* st = nullptr) { fe r2 = fe_r2(); fe_mul<FAST>(r, a, r2, st); }
 SBV_HD void fe_from_mont(u256& r, const fe& a) {
     u32 t[16];
     SBV_UNROLL

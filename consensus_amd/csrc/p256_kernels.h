@@ -12,11 +12,13 @@ namespace sbv {
 int prep_chunk_T(size_t n);
 hipError_t launch_p256_prep(const uint8_t* d_tuples, size_t n, const Scratch& s, hipStream_t stream, bool keyed = false);
 hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
-                                    const uint8_t* d_kvalid, const apt* d_gtab, uint8_t* d_bitmap, hipStream_t stream);
+                                    const uint8_t* d_kvalid, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
+                                    hipStream_t stream);
 // comb table (33 x 128 affine multiples) of a registered key; false if the key is not a valid curve point
 bool host_build_key_table(const uint8_t q[64], apt* out);
 #define SBV_KEYTAB_ENTRIES (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW)
-hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt* d_gtab, uint8_t* d_bitmap,
+// d_rerun: ceil(n/64) bytes of per-wavefront flags (fast pass -> exact pass)
+hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
                               hipStream_t stream);
 void host_build_gtable(apt* out);   // 33 x 128 affine multiples of G (one-time table setup)
 

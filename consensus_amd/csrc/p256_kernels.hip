@@ -7,7 +7,7 @@
 //                   ds_read_b32 column walk is bank-conflict free), then every lane reads
 //                   its own tuple's 40 dwords back from LDS.  Montgomery's trick runs along
 //                   the T slabs inside each lane: one Fermat inversion per T signatures.
-//   k_p256_verify : stage B.  256 lanes per workgroup; all inputs come from the limb-major
+//   k_p256_verify_fast : stage B.  256 lanes per workgroup; all inputs come from the limb-major
 //                   scratch (coalesced dword loads); the per-signature window table lives
 //                   in HBM scratch (1280 B / lane, written and read only by its lane); the
 //                   fixed-base table (270 KiB) is read-only and L2/L1 resident.  The accept
@@ -66,55 +66,79 @@ __global__ __launch_bounds__(kPrepLanes) void k_p256_prep_keyed(const uint8_t* _
     prep_body<24, false>(rsh, n, s, T);
 }
 
+// Stage B normally runs as ONE launch of the exact kernel.  An experimental two-launch mode
+// (env SBV_STAGEB_FAST=1) first runs a FAST kernel using the cheap conditional subtraction
+// (p256_fe.h: fe_cond_sub_p_t), records per wavefront whether any lane's sticky word fired, and lets
+// the exact kernel re-verify only those wavefronts.  MEASURED NEGATIVE RESULT (profiles/r01/
+// stageb_fast_ab.txt): 7 % fewer VALU instructions per doubling but 11 % MORE time for the generic
+// kernel — the masked add chain needs the reduction's final carry before its first limb, which
+// lengthens the dependent v_addc chain, and at 3 waves/SIMD the kernel is as much latency- as
+// issue-bound.  (+3.5 % for the registered-key kernel.)  Kept selectable for the next round.
+template <bool FAST>
+__device__ __forceinline__ void finish_wave(bool accept, bool need_exact, size_t i, size_t n, uint8_t* __restrict__ bitmap,
+                                            uint8_t* __restrict__ rerun) {
+    const unsigned long long m = __ballot(accept);
+    const int lane = threadIdx.x & 63;
+    const size_t wave_first = i - (size_t)lane;
+    if (lane < 8) {
+        const size_t byte = (wave_first >> 3) + (size_t)lane;
+        if (byte < ((n + 7) >> 3)) bitmap[byte] = (uint8_t)(m >> (8 * lane));
+    }
+    if (FAST) {
+        const unsigned long long need = __ballot(need_exact);
+        if (lane == 0) rerun[wave_first >> 6] = need != 0ull ? 1 : 0;
+    }
+}
+
 // Stage B, registered-key form: 66 mixed additions per lane from two combs (G and the key's).
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_keyed(Scratch s, size_t n,
-                                                                       const u32* __restrict__ slots, u32 nkeys,
-                                                                       const apt* __restrict__ ktab,
+template <bool FAST>
+__device__ __forceinline__ void verify_keyed_body(const Scratch& s, size_t n, const u32* __restrict__ slots, u32 nkeys,
+                                                  const apt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
+                                                  const apt* __restrict__ gtab, uint8_t* __restrict__ bitmap,
+                                                  uint8_t* __restrict__ rerun) {
+    const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (!FAST && rerun && !rerun[i >> 6]) return;        // wave-uniform: nothing fired in this wavefront
+    bool accept = false;
+    u32 sticky = 0;
+    if (i < n) accept = verify_lane_keyed<FAST>(s, i, slots[i], nkeys, ktab, kvalid, gtab, &sticky);
+    finish_wave<FAST>(accept, sticky == 0xFFFFFFFFu, i, n, bitmap, rerun);
+}
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_keyed_fast(Scratch s, size_t n, const u32* __restrict__ slots,
+                                                                       u32 nkeys, const apt* __restrict__ ktab,
                                                                        const uint8_t* __restrict__ kvalid,
                                                                        const apt* __restrict__ gtab,
-                                                                       uint8_t* __restrict__ bitmap) {
-    const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
-    bool accept = false;
-    if (i < n) accept = verify_lane_keyed(s, i, slots[i], nkeys, ktab, kvalid, gtab);
-    const unsigned long long m = __ballot(accept);
-    const int lane = threadIdx.x & 63;
-    const size_t wave_first = i - (size_t)lane;
-    if (lane < 8) {
-        const size_t byte = (wave_first >> 3) + (size_t)lane;
-        if (byte < ((n + 7) >> 3)) bitmap[byte] = (uint8_t)(m >> (8 * lane));
-    }
+                                                                       uint8_t* __restrict__ bitmap, uint8_t* __restrict__ rerun) {
+    verify_keyed_body<true>(s, n, slots, nkeys, ktab, kvalid, gtab, bitmap, rerun);
+}
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_keyed(Scratch s, size_t n, const u32* __restrict__ slots,
+                                                                             u32 nkeys, const apt* __restrict__ ktab,
+                                                                             const uint8_t* __restrict__ kvalid,
+                                                                             const apt* __restrict__ gtab,
+                                                                             uint8_t* __restrict__ bitmap,
+                                                                             uint8_t* __restrict__ rerun) {
+    verify_keyed_body<false>(s, n, slots, nkeys, ktab, kvalid, gtab, bitmap, rerun);
 }
 
-// The stage-B body; stamped out with different register budgets (waves per SIMD) so that the
-// occupancy / spill trade-off can be A/B-tested on hardware (env SBV_VERIFY_VARIANT, default 0).
-__device__ __forceinline__ void verify_body(const Scratch& s, size_t n, u32* __restrict__ qtab,
-                                            const apt* __restrict__ gtab, uint8_t* __restrict__ bitmap) {
+// Generic form (public key in the tuple): per-signature window table in HBM.
+template <bool FAST>
+__device__ __forceinline__ void verify_body(const Scratch& s, size_t n, u32* __restrict__ qtab, const apt* __restrict__ gtab,
+                                            uint8_t* __restrict__ bitmap, uint8_t* __restrict__ rerun) {
     const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (!FAST && rerun && !rerun[i >> 6]) return;        // wave-uniform
     bool accept = false;
-    if (i < n) accept = verify_lane(s, i, qtab + i * (size_t)(SBV_QTAB_ENTRIES * 40), gtab);
-    const unsigned long long m = __ballot(accept);
-    const int lane = threadIdx.x & 63;
-    const size_t wave_first = i - (size_t)lane;
-    if (lane < 8) {
-        const size_t byte = (wave_first >> 3) + (size_t)lane;
-        if (byte < ((n + 7) >> 3)) bitmap[byte] = (uint8_t)(m >> (8 * lane));
-    }
+    u32 sticky = 0;
+    if (i < n) accept = verify_lane<FAST>(s, i, qtab + i * (size_t)(SBV_QTAB_ENTRIES * 40), gtab, &sticky);
+    finish_wave<FAST>(accept, sticky == 0xFFFFFFFFu, i, n, bitmap, rerun);
 }
-
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_fast(Scratch s, size_t n, u32* __restrict__ qtab,
+                                                                 const apt* __restrict__ gtab, uint8_t* __restrict__ bitmap,
+                                                                 uint8_t* __restrict__ rerun) {
+    verify_body<true>(s, n, qtab, gtab, bitmap, rerun);
+}
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify(Scratch s, size_t n, u32* __restrict__ qtab,
-                                                                 const apt* __restrict__ gtab,
-                                                                 uint8_t* __restrict__ bitmap) {
-    verify_body(s, n, qtab, gtab, bitmap);
-}
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_w2(Scratch s, size_t n, u32* __restrict__ qtab,
                                                                        const apt* __restrict__ gtab,
-                                                                       uint8_t* __restrict__ bitmap) {
-    verify_body(s, n, qtab, gtab, bitmap);
-}
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 4) void k_p256_verify_w4(Scratch s, size_t n, u32* __restrict__ qtab,
-                                                                       const apt* __restrict__ gtab,
-                                                                       uint8_t* __restrict__ bitmap) {
-    verify_body(s, n, qtab, gtab, bitmap);
+                                                                       uint8_t* __restrict__ bitmap, uint8_t* __restrict__ rerun) {
+    verify_body<false>(s, n, qtab, gtab, bitmap, rerun);
 }
 
 int prep_chunk_T(size_t n) {
@@ -135,26 +159,47 @@ hipError_t launch_p256_prep(const uint8_t* d_tuples, size_t n, const Scratch& s,
     return hipGetLastError();
 }
 
+// test hook: SBV_FORCE_EXACT=1 marks every wavefront for the exact pass, so the GPU tests can run the
+// code that real data reaches with probability 2^-32 per field operation
+static bool force_exact() {
+    static const bool v = [] { const char* e = getenv("SBV_FORCE_EXACT"); return e && e[0] == '1'; }();
+    return v;
+}
+
+// SBV_STAGEB_FAST=1 selects the experimental fast+exact two-launch mode (default: exact only)
+static bool two_pass() {
+    static const bool v = [] { const char* e = getenv("SBV_STAGEB_FAST"); return e && e[0] == '1'; }();
+    return v;
+}
+
 hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
-                                    const uint8_t* d_kvalid, const apt* d_gtab, uint8_t* d_bitmap, hipStream_t stream) {
+                                    const uint8_t* d_kvalid, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
+                                    hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned grid = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
+    uint8_t* rr = nullptr;                 // nullptr = the exact kernel verifies every wavefront
+    if (two_pass()) {
+        hipLaunchKernelGGL(k_p256_verify_keyed_fast, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab,
+                           d_kvalid, d_gtab, d_bitmap, d_rerun);
+        if (force_exact()) (void)hipMemsetAsync(d_rerun, 1, (n + 63) / 64, stream);
+        rr = d_rerun;
+    }
     hipLaunchKernelGGL(k_p256_verify_keyed, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab,
-                       d_kvalid, d_gtab, d_bitmap);
+                       d_kvalid, d_gtab, d_bitmap, rr);
     return hipGetLastError();
 }
 
-hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt* d_gtab, uint8_t* d_bitmap,
+hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
                               hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned grid = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
-    static const int variant = [] { const char* e = getenv("SBV_VERIFY_VARIANT"); return e ? atoi(e) : 0; }();
-    if (variant == 2)
-        hipLaunchKernelGGL(k_p256_verify_w2, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gtab, d_bitmap);
-    else if (variant == 4)
-        hipLaunchKernelGGL(k_p256_verify_w4, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gtab, d_bitmap);
-    else
-        hipLaunchKernelGGL(k_p256_verify, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gtab, d_bitmap);
+    uint8_t* rr = nullptr;
+    if (two_pass()) {
+        hipLaunchKernelGGL(k_p256_verify_fast, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gtab, d_bitmap, d_rerun);
+        if (force_exact()) (void)hipMemsetAsync(d_rerun, 1, (n + 63) / 64, stream);
+        rr = d_rerun;
+    }
+    hipLaunchKernelGGL(k_p256_verify, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gtab, d_bitmap, rr);
     return hipGetLastError();
 }
 

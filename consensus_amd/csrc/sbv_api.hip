@@ -35,6 +35,7 @@ struct Context {
     u32* d_qtab = nullptr;
     sbv::apt* d_gtab = nullptr;
     uint8_t* d_bitmap = nullptr;
+    uint8_t* d_rerun = nullptr;         // per-wavefront flags between the fast and the exact stage-B pass
     uint8_t* h_bitmap = nullptr;        // pinned
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -77,6 +78,8 @@ void free_buffers(Context& c) {
     if (c.h_bitmap) (void)hipHostFree(c.h_bitmap);
     if (c.d_slots) (void)hipFree(c.d_slots);
     c.d_slots = nullptr;
+    if (c.d_rerun) (void)hipFree(c.d_rerun);
+    c.d_rerun = nullptr;
     c.d_tuples = c.d_scratch = c.d_bitmap = c.h_bitmap = nullptr;
     c.d_qtab = nullptr;
     c.cap = 0;
@@ -93,6 +96,7 @@ int ensure_capacity(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_qtab, want * (size_t)(SBV_QTAB_ENTRIES * 160)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_bitmap, want / 8));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_slots, want * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_rerun, want / 64));
     HIP_TRY(SBV_ENOMEM, hipHostMalloc(&c.h_bitmap, want / 8, hipHostMallocDefault));
     c.cap = want;
     return SBV_OK;
@@ -119,7 +123,7 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
     const sbv::Scratch s = scratch_view(c);
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_tuples, n, s, stream));
     if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
-    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify(s, n, c.d_qtab, c.d_gtab, d_bitmap, stream));
+    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify(s, n, c.d_qtab, c.d_gtab, d_bitmap, c.d_rerun, stream));
     return SBV_OK;
 }
 
@@ -128,7 +132,7 @@ int enqueue_keyed(Context& c, const uint8_t* d_rsh, const u32* d_slots, size_t n
     const sbv::Scratch s = scratch_view(c);
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_rsh, n, s, stream, true));
     if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
-    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_keyed(s, n, d_slots, (u32)c.nkeys, c.d_ktab, c.d_kvalid, c.d_gtab, d_bitmap, stream));
+    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_keyed(s, n, d_slots, (u32)c.nkeys, c.d_ktab, c.d_kvalid, c.d_gtab, d_bitmap, c.d_rerun, stream));
     return SBV_OK;
 }
 

@@ -14,6 +14,7 @@
 
 using namespace sbv;
 
+static unsigned long g_sticky_reruns = 0, g_fast_mismatches = 0;
 static apt* g_gtab = nullptr;
 static const apt* gtab() {
     if (!g_gtab) {
@@ -49,10 +50,22 @@ void sbve_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap, in
         for (int t = 0; t < block; ++t) prep_chunk<true>(hw, n, s, b * per_block + t, (size_t)block, T);
     memset(bitmap, 0, (n + 7) / 8);
     u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB_ENTRIES * 40 * 4);
-    for (size_t i = 0; i < n; ++i)
-        if (verify_lane(s, i, qtab, gtab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+    for (size_t i = 0; i < n; ++i) {
+        // exactly the kernel's two-pass scheme: fast pass, exact re-run when the sticky word fired
+        u32 sticky = 0;
+        bool acc = verify_lane<true>(s, i, qtab, gtab(), &sticky);
+        const bool exact = verify_lane<false>(s, i, qtab, gtab());
+        if (sticky == 0xFFFFFFFFu) { ++g_sticky_reruns; acc = exact; }
+        else if (acc != exact) ++g_fast_mismatches;      // must never happen: the test asserts it stays 0
+        if (acc) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+    }
     free(qtab);
 }
+unsigned long sbve_sticky_reruns() { return g_sticky_reruns; }
+unsigned long sbve_fast_mismatches() { return g_fast_mismatches; }
+// fast conditional subtraction, standalone: returns the sticky word
+u32 sbve_fe_add_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_add<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
+u32 sbve_fe_mul_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_mul<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 
 // registered-key form: rsh = n x 96 B (r|s|hash), slots[i] indexes keys (nkeys x 64 B, Qx|Qy)
 void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n, const uint8_t* keys, u32 nkeys,

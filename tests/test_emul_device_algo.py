@@ -191,3 +191,30 @@ def test_registered_key_form_matches_generic_verdicts(emul, oracle, golden_vecto
     emul.sbve_p256_verify_batch_keyed(rsh[:96 * 4], arr2, 4, b"".join(keys), len(keys), bm2, 64, 1)
     assert _bitmap_list(bm2.raw, 4) == [False, False, want[0] if slots[0] == slots[2] else got[2], False] or True
     assert not _bitmap_list(bm2.raw, 4)[0] and not _bitmap_list(bm2.raw, 4)[1] and not _bitmap_list(bm2.raw, 4)[3]
+
+
+def test_fast_conditional_subtraction_is_exact_or_flags(emul):
+    """FAST mode: either the result equals the exact one, or the sticky word is 0xFFFFFFFF."""
+    emul.sbve_fe_add_fast.restype = ctypes.c_uint32
+    emul.sbve_fe_mul_fast.restype = ctypes.c_uint32
+    rng = random.Random(77)
+    rinv = pow(R, -1, P)
+    vals = edge_values(P) + [P - 1 - i for i in range(5)] + [rng.randrange(P) for _ in range(300)]
+    out = (ctypes.c_uint32 * 8)()
+    flagged = 0
+    for i, a in enumerate(vals):
+        for b in (vals[(i * 7 + 3) % len(vals)], 1, P - a if a else 0, (P - a + 1) % P):
+            st = emul.sbve_fe_add_fast(limbs(a), limbs(b), out)
+            if val(out) != (a + b) % P:
+                assert st == 0xFFFFFFFF and a + b >= P and a + b < R, (hex(a), hex(b))
+                flagged += 1
+            st = emul.sbve_fe_mul_fast(limbs(a), limbs(b), out)
+            if val(out) != a * b * rinv % P:
+                assert st == 0xFFFFFFFF
+    assert flagged > 0          # a + b == p .. 2^256-1 is exactly the case the sticky word exists for
+
+
+def test_two_pass_scheme_never_disagrees_with_exact(emul):
+    emul.sbve_fast_mismatches.restype = ctypes.c_ulong
+    emul.sbve_sticky_reruns.restype = ctypes.c_ulong
+    assert emul.sbve_fast_mismatches() == 0     # accumulated over every batch this module emulated

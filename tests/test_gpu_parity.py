@@ -211,3 +211,31 @@ def test_registered_key_full_batch_2_20(gpu):
     tm = gpu.last_timing()
     print(f"\n[2^20 keyed] prep {tm.prep_us:.0f} us  verify {tm.verify_us:.0f} us -> {n / (tm.prep_us + tm.verify_us):.1f} M verifies/s (kernels)")
     gpu.clear_keys()
+
+
+def test_exact_pass_forced(golden_vectors):
+    """Experimental two-launch stage B (SBV_STAGEB_FAST=1): fast kernel, then the exact kernel on flagged
+    wavefronts; SBV_FORCE_EXACT=1 flags all of them.  Verdicts must equal the default single-launch mode."""
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import consensus_amd as sbv, synth
+sbv.init(0)
+vs = [v for v in json.load(open("tests/golden/p256_vectors.json"))["vectors"] if v["kind"] == "tuple"]
+blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+got = sbv.bitmap_to_list(sbv.verify_batch(blob), len(vs))
+assert got == [v["accept"] for v in vs]
+t, valid = synth.gen_batch(0x77, 5000, 16, 4, cache=False)
+assert sbv.verify_batch(t.tobytes(), 5000) == valid.tobytes()
+keys = sorted(set(bytes(t[i * 160 + 96:i * 160 + 160]) for i in range(5000)))
+reg = dict(zip(keys, sbv.register_keys(keys)))
+rsh = b"".join(bytes(t[i * 160:i * 160 + 96]) for i in range(5000))
+assert sbv.verify_batch_keyed(rsh, [reg[bytes(t[i * 160 + 96:i * 160 + 160])] for i in range(5000)], 5000) == valid.tobytes()
+print("forced-exact ok")
+'''
+    env = dict(os.environ, SBV_FORCE_EXACT="1", SBV_STAGEB_FAST="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "forced-exact ok" in out.stdout, out.stdout + out.stderr

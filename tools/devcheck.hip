@@ -198,7 +198,8 @@ static int pipeline_test(const char* path) {
     for (size_t i = 0; i < n; ++i) if (verify_lane(s, i, qtp, gt.data())) hbm[i >> 3] |= (uint8_t)(1u << (i & 7));
     size_t hacc = 0; for (size_t i = 0; i < n; ++i) hacc += (hbm[i >> 3] >> (i & 7)) & 1;
     // device
-    uint8_t *d_t, *d_s, *d_b; u32* d_q; apt* d_g;
+    uint8_t *d_t, *d_s, *d_b, *d_rr; u32* d_q; apt* d_g;
+    CHECK(hipMalloc(&d_rr, cap / 64 + 64));
     CHECK(hipMalloc(&d_t, cap * 160)); CHECK(hipMalloc(&d_s, cap * 193)); CHECK(hipMalloc(&d_q, cap * 1280));
     CHECK(hipMalloc(&d_b, cap / 8)); CHECK(hipMalloc(&d_g, gt.size() * sizeof(apt)));
     CHECK(hipMemcpy(d_t, tuples.data(), n * 160, hipMemcpyHostToDevice));
@@ -232,7 +233,7 @@ static int pipeline_test(const char* path) {
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) { CHECK(hipMemcpy(d_s, hs.data(), cap * 192, hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_s + cap * 192, hok.data(), cap, hipMemcpyHostToDevice)); }
         CHECK(hipMemset(d_b, 0, cap / 8));
-        CHECK(launch_p256_verify(ds, n, d_q, d_g, d_b, 0));
+        CHECK(launch_p256_verify(ds, n, d_q, d_g, d_b, d_rr, 0));
         CHECK(hipDeviceSynchronize());
         std::vector<uint8_t> dbm((n + 7) / 8);
         CHECK(hipMemcpy(dbm.data(), d_b, (n + 7) / 8, hipMemcpyDeviceToHost));
