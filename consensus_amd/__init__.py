@@ -83,6 +83,8 @@ def load() -> ctypes.CDLL:
     lib.sbv_ed25519_verify_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     lib.sbv_ed25519_make_tuples.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
                                             ctypes.c_size_t, ctypes.c_char_p]
+    lib.sbv_p256_verify_msgs_keyed.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p,
+                                               ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.sbv_last_timing.argtypes = [ctypes.POINTER(Timing)]
     lib.sbv_profile_enable.argtypes = [ctypes.c_int]
     lib.sbv_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
@@ -192,6 +194,22 @@ def ed25519_verify_batch(tuples: bytes, n: Optional[int] = None) -> bytes:
 
 def ed25519_verify_batch_dev(d_tuples_ptr: int, n: int, d_bitmap_ptr: int, stream: int = 0) -> None:
     _check(load().sbv_ed25519_verify_batch_dev(d_tuples_ptr, n, d_bitmap_ptr, stream))
+
+
+def verify_msgs_keyed(msgs, sigs_der, slots) -> bytes:
+    """Device front end: SHA-256(msg) + strict DER parse on the GPU, then registered-key verification."""
+    n = len(msgs)
+    mo = (ctypes.c_uint64 * (n + 1))()
+    so = (ctypes.c_uint64 * (n + 1))()
+    a = b = 0
+    for i in range(n):
+        mo[i], so[i] = a, b
+        a += len(msgs[i]); b += len(sigs_der[i])
+    mo[n], so[n] = a, b
+    arr = (ctypes.c_uint32 * max(1, n))(*slots)
+    out = ctypes.create_string_buffer(max(1, (n + 7) // 8))
+    _check(load().sbv_p256_verify_msgs_keyed(b"".join(msgs), mo, b"".join(sigs_der), so, arr, n, out))
+    return out.raw[:(n + 7) // 8]
 
 
 def parse_der(sig: bytes) -> Optional[bytes]:

@@ -14,6 +14,8 @@ hipError_t launch_p256_prep(const uint8_t* d_tuples, size_t n, const Scratch& s,
 hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
                                     const uint8_t* d_kvalid, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
                                     hipStream_t stream);
+hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const uint8_t* d_sigs, const u64* d_soff, size_t n,
+                               u32* d_rsh, hipStream_t stream);
 // comb table (33 x 128 affine multiples) of a registered key; false if the key is not a valid curve point
 bool host_build_key_table(const uint8_t q[64], apt* out);
 #define SBV_KEYTAB_ENTRIES (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW)

@@ -19,6 +19,7 @@
 
 #include "p256_core.h"
 #include "p256_kernels.h"
+#include "sha256_dev.h"
 
 namespace sbv {
 
@@ -139,6 +140,28 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify(Scratch s, siz
                                                                        const apt* __restrict__ gtab,
                                                                        uint8_t* __restrict__ bitmap, uint8_t* __restrict__ rerun) {
     verify_body<false>(s, n, qtab, gtab, bitmap, rerun);
+}
+
+// Message front end: lane i hashes message i (SHA-256) and parses DER signature i,
+// emitting the 96-byte r|s|hash record the registered-key stage A consumes.  Input is variable length,
+// so lanes read their own byte ranges (offset tables); the 96-byte records are written back contiguous.
+__global__ __launch_bounds__(256) void k_msg_frontend(const uint8_t* __restrict__ msgs, const u64* __restrict__ moff,
+                                                      const uint8_t* __restrict__ sigs, const u64* __restrict__ soff,
+                                                      size_t n, u32* __restrict__ rsh) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 m0 = moff[i], m1 = moff[i + 1], s0 = soff[i], s1 = soff[i + 1];
+    u32 rec[24];
+    msg_frontend_lane(msgs + m0, (size_t)(m1 - m0), sigs + s0, (size_t)(s1 - s0), rec);
+#pragma unroll
+    for (int k = 0; k < 24; ++k) rsh[i * 24 + k] = rec[k];
+}
+
+hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const uint8_t* d_sigs, const u64* d_soff, size_t n,
+                               u32* d_rsh, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_msg_frontend, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_msgs, d_moff, d_sigs, d_soff, n, d_rsh);
+    return hipGetLastError();
 }
 
 int prep_chunk_T(size_t n) {

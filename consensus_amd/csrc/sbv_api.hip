@@ -42,6 +42,10 @@ struct Context {
     hipEvent_t busy = nullptr;          // completion of the last launch that used the scratch
     bool busy_valid = false;
     sbv_timing timing{};
+    // message front end staging (grown on demand)
+    uint8_t* d_msgs = nullptr; size_t msgs_cap = 0;
+    uint8_t* d_sigs = nullptr; size_t sigs_cap = 0;
+    uint64_t* d_moff = nullptr; uint64_t* d_soff = nullptr; size_t off_cap = 0;
     sbv::aniels* d_btab = nullptr;      // Ed25519 base-point comb, built on first use
     // registered keys
     sbv::apt* d_ktab = nullptr;
@@ -154,6 +158,11 @@ int ensure_key_capacity(Context& c, size_t want) {
     }
     if (c.d_btab) (void)hipFree(c.d_btab);
     c.d_btab = nullptr;
+    if (c.d_msgs) (void)hipFree(c.d_msgs);
+    if (c.d_sigs) (void)hipFree(c.d_sigs);
+    if (c.d_moff) (void)hipFree(c.d_moff);
+    if (c.d_soff) (void)hipFree(c.d_soff);
+    c.d_msgs = c.d_sigs = nullptr; c.d_moff = c.d_soff = nullptr; c.msgs_cap = c.sigs_cap = c.off_cap = 0;
     if (c.d_ktab) (void)hipFree(c.d_ktab);
     if (c.d_kvalid) (void)hipFree(c.d_kvalid);
     c.d_ktab = nt;
@@ -220,6 +229,11 @@ extern "C" int sbv_shutdown(void) {
     c.d_gtab = nullptr;
     if (c.d_btab) (void)hipFree(c.d_btab);
     c.d_btab = nullptr;
+    if (c.d_msgs) (void)hipFree(c.d_msgs);
+    if (c.d_sigs) (void)hipFree(c.d_sigs);
+    if (c.d_moff) (void)hipFree(c.d_moff);
+    if (c.d_soff) (void)hipFree(c.d_soff);
+    c.d_msgs = c.d_sigs = nullptr; c.d_moff = c.d_soff = nullptr; c.msgs_cap = c.sigs_cap = c.off_cap = 0;
     if (c.d_ktab) (void)hipFree(c.d_ktab);
     if (c.d_kvalid) (void)hipFree(c.d_kvalid);
     c.d_ktab = nullptr; c.d_kvalid = nullptr; c.key_cap = c.nkeys = 0;
@@ -524,6 +538,69 @@ extern "C" int sbv_ed25519_verify_batch(const uint8_t* tuples, size_t n, uint8_t
         tm.verify_us += 1e3 * ms_between(c.ev[1], c.ev[3]);
         tm.d2h_us += 1e3 * ms_between(c.ev[3], c.ev[4]);
     }
+    c.busy_valid = false;
+    tm.total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    c.timing = tm;
+    return SBV_OK;
+}
+
+namespace {
+template <typename T>
+int grow(T*& ptr, size_t& cap, size_t want_elems) {
+    if (want_elems <= cap) return SBV_OK;
+    size_t ncap = cap ? cap : 4096;
+    while (ncap < want_elems) ncap *= 2;
+    T* np = nullptr;
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&np, ncap * sizeof(T)));
+    if (ptr) { HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize()); (void)hipFree(ptr); }
+    ptr = np;
+    cap = ncap;
+    return SBV_OK;
+}
+}  // namespace
+
+extern "C" int sbv_p256_verify_msgs_keyed(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* sigs,
+                                          const uint64_t* sig_offsets, const uint32_t* slots, size_t n, uint8_t* accept_bitmap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (n == 0) return SBV_OK;
+    if (!msg_offsets || !sig_offsets || !slots || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
+    if (c.nkeys == 0) { g_err = "no keys registered"; return SBV_EINVAL; }
+    if (n > kMaxChunk) { g_err = "batch larger than 2^21: split it"; return SBV_EINVAL; }
+    const size_t mbytes = (size_t)msg_offsets[n], sbytes = (size_t)sig_offsets[n];
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    int rc = ensure_capacity(c, n);
+    if (rc != SBV_OK) return rc;
+    size_t oc1 = c.off_cap, oc2 = c.off_cap;
+    if ((rc = grow(c.d_msgs, c.msgs_cap, mbytes + 16)) != SBV_OK) return rc;
+    if ((rc = grow(c.d_sigs, c.sigs_cap, sbytes + 16)) != SBV_OK) return rc;
+    if ((rc = grow(c.d_moff, oc1, n + 1)) != SBV_OK) return rc;
+    if ((rc = grow(c.d_soff, oc2, n + 1)) != SBV_OK) return rc;
+    c.off_cap = oc1 < oc2 ? oc1 : oc2;
+    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(c.stream, c.busy, 0));
+    sbv_timing tm{};
+    tm.n = n;
+    HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[0], c.stream));
+    if (mbytes) HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_msgs, msgs, mbytes, hipMemcpyHostToDevice, c.stream));
+    if (sbytes) HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_sigs, sigs, sbytes, hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_moff, msg_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_soff, sig_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_slots, slots, n * sizeof(u32), hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
+    HIP_TRY(SBV_EDEVICE, sbv::launch_msg_frontend(c.d_msgs, c.d_moff, c.d_sigs, c.d_soff, n, reinterpret_cast<u32*>(c.d_tuples), c.stream));
+    rc = enqueue_keyed(c, c.d_tuples, c.d_slots, n, c.d_bitmap, c.stream, c.ev[2]);
+    if (rc != SBV_OK) return rc;
+    HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
+    HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.h_bitmap, c.d_bitmap, (n + 7) / 8, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[4], c.stream));
+    HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(c.stream));
+    memcpy(accept_bitmap, c.h_bitmap, (n + 7) / 8);
+    tm.h2d_us = 1e3 * ms_between(c.ev[0], c.ev[1]);
+    tm.prep_us = 1e3 * ms_between(c.ev[1], c.ev[2]);       // front end + stage A
+    tm.verify_us = 1e3 * ms_between(c.ev[2], c.ev[3]);
+    tm.d2h_us = 1e3 * ms_between(c.ev[3], c.ev[4]);
     c.busy_valid = false;
     tm.total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     c.timing = tm;

@@ -52,6 +52,12 @@ class SbvBackend : public Backend {
         if (rc_ != SBV_OK) return rc_;
         return sbv_p256_verify_batch_keyed(rsh, slots, n, bitmap);
     }
+    int verify_msgs_keyed(const uint8_t* msgs, const uint64_t* moff, const uint8_t* sigs, const uint64_t* soff,
+                          const uint32_t* slots, size_t n, uint8_t* bitmap) override {
+        if (rc_ != SBV_OK) return rc_;
+        if (n > ((size_t)1 << 21)) return -2;          // the front end takes one chunk; larger batches use tuples
+        return sbv_p256_verify_msgs_keyed(msgs, moff, sigs, soff, slots, n, bitmap);
+    }
  private:
     int rc_;
 };
@@ -313,7 +319,7 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
                                          std::vector<uint8_t>* out) {
     const size_t n = sigs.size();
     if (props.size() != n) return Status::Invalid("size mismatch");
-    std::vector<uint8_t> tuples(n * 160, 0), bitmap((n + 7) / 8, 0), pre(n, 1);
+    std::vector<uint8_t> bitmap((n + 7) / 8, 0), pre(n, 1);
     std::vector<uint32_t> slots(n, 0);
     std::atomic<int> unkeyed(0);
     std::map<uint64_t, bytes> keys;                 // snapshot: the workers must not contend on mu_
@@ -323,34 +329,62 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
         keys = consenters_;
         key_slots = consenter_slot_;
     }
+    // pass 1 (host, parallel): signer known? message bound to its proposal?  No hashing of messages here.
     parallel_chunks(n, [&](size_t lo, size_t hi) {
         const Proposal* last = nullptr;
         bytes last_digest;
         for (size_t i = lo; i < hi; ++i) {
-            bytes binding;
             if (props[i] != last) { last = props[i]; last_digest = proposal_digest_raw(*last); }
-            auto it = keys.find(sigs[i].id);
-            if (it == keys.end() || !consenter_msg_split(sigs[i].msg, &binding, nullptr) || binding != last_digest) {
-                pre[i] = 0;             // tuple stays all-zero: rejected by the range check as well
-                continue;
-            }
-            make_tuple((const uint8_t*)it->second.data(), sigs[i].msg, sigs[i].value, &tuples[i * 160]);
+            const bytes& m = sigs[i].msg;
+            const auto it = keys.find(sigs[i].id);
+            const bool bound = m.size() >= 40 && m.compare(0, 4, "SBV1") == 0 && m.compare(4, 32, last_digest) == 0 &&
+                               consenter_msg_split(m, nullptr, nullptr);
+            if (it == keys.end() || !bound) { pre[i] = 0; continue; }
             const auto ks = key_slots.find(sigs[i].id);
             const long slot = ks == key_slots.end() ? -1 : ks->second;
             if (slot < 0) unkeyed.store(1); else slots[i] = (uint32_t)slot;
         }
     });
-    if (n) {
-        int rc;
-        if (!unkeyed.load()) {          // every signer registered with the backend: r|s|hash + slot, no doublings
+    int rc = -2;
+    if (n && !unkeyed.load()) {
+        // device front end: the host only lays the bytes out; SHA-256 and DER parsing run on the GPU.
+        // Pre-rejected entries get an empty signature (DER failure -> r = s = 0 -> reject).
+        std::vector<uint64_t> moff(n + 1), soff(n + 1);
+        uint64_t a = 0, b = 0;
+        for (size_t i = 0; i < n; ++i) {
+            moff[i] = a; soff[i] = b;
+            a += sigs[i].msg.size();
+            b += pre[i] ? sigs[i].value.size() : 0;
+        }
+        moff[n] = a; soff[n] = b;
+        std::vector<uint8_t> mbuf(a ? a : 1), sbuf(b ? b : 1);
+        parallel_chunks(n, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                memcpy(&mbuf[moff[i]], sigs[i].msg.data(), sigs[i].msg.size());
+                if (pre[i]) memcpy(&sbuf[soff[i]], sigs[i].value.data(), sigs[i].value.size());
+            }
+        });
+        rc = co_.backend().verify_msgs_keyed(mbuf.data(), moff.data(), sbuf.data(), soff.data(), slots.data(), n, bitmap.data());
+    }
+    if (n && rc == -2) {
+        // backend without the front end (or unregistered signers): build tuples on the host
+        std::vector<uint8_t> tuples(n * 160, 0);
+        parallel_chunks(n, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                if (!pre[i]) continue;             // tuple stays all-zero: rejected by the range check
+                make_tuple((const uint8_t*)keys.find(sigs[i].id)->second.data(), sigs[i].msg, sigs[i].value, &tuples[i * 160]);
+            }
+        });
+        if (!unkeyed.load()) {
             std::vector<uint8_t> rsh(n * 96);
             parallel_chunks(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) memcpy(&rsh[i * 96], &tuples[i * 160], 96); });
             rc = co_.submit_many_keyed(rsh.data(), slots.data(), n, bitmap.data());
+            if (rc == -2) rc = co_.submit_many(tuples.data(), n, bitmap.data());
         } else {
             rc = co_.submit_many(tuples.data(), n, bitmap.data());
         }
-        if (rc != 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());
     }
+    if (n && rc != 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());
     out->assign(n, 0);
     for (size_t i = 0; i < n; ++i) (*out)[i] = pre[i] && ((bitmap[i >> 3] >> (i & 7)) & 1);
     return Status::Ok();

@@ -48,6 +48,12 @@ class Backend {
     virtual int verify_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap) {
         (void)rsh; (void)slots; (void)n; (void)bitmap; return -2;
     }
+    // Optional device front end (sbv_p256_verify_msgs_keyed): raw messages + DER signatures + slots.
+    // Returns -2 when unsupported.
+    virtual int verify_msgs_keyed(const uint8_t* msgs, const uint64_t* moff, const uint8_t* sigs, const uint64_t* soff,
+                                  const uint32_t* slots, size_t n, uint8_t* bitmap) {
+        (void)msgs; (void)moff; (void)sigs; (void)soff; (void)slots; (void)n; (void)bitmap; return -2;
+    }
 };
 std::shared_ptr<Backend> make_sbv_backend(int device);     // sbv_init(device) + sbv_p256_verify_batch
 typedef int (*backend_fn)(const uint8_t* tuples, size_t n, uint8_t* bitmap, void* user);

@@ -87,6 +87,14 @@ int sbv_p256_clear_keys(void);
 int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* accept_bitmap);
 int sbv_p256_verify_batch_keyed_dev(const void* d_rsh, const void* d_slots, size_t n, void* d_bitmap, void* hip_stream);
 
+/* Message front end on the device: SHA-256 of each message and the strict DER
+ * parse of each signature run as a kernel in front of the registered-key verification, so the host
+ * only concatenates bytes.  msg i = msgs[msg_offsets[i] .. msg_offsets[i+1]), signature i (ASN.1 DER,
+ * types.Signature.Value) = sigs[sig_offsets[i] .. sig_offsets[i+1]), signer = slots[i].
+ * Equivalent to crypto/ecdsa.VerifyASN1(key[slots[i]], sha256(msg i), sig i) for every i. */
+int sbv_p256_verify_msgs_keyed(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* sigs,
+                               const uint64_t* sig_offsets, const uint32_t* slots, size_t n, uint8_t* accept_bitmap);
+
 /* ---- Ed25519 variant (BASELINE.json configs[4]) ----------------------------------------------------
  * Semantics of Go crypto/ed25519.Verify(pk, msg, sig) (crypto/internal/edwards25519): S canonical,
  * A decoded with Go's leniency (non-canonical y accepted, no small-order rejection), cofactorless

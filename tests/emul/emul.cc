@@ -11,6 +11,7 @@
 
 #include "../../consensus_amd/csrc/p256_core.h"
 #include "../../consensus_amd/csrc/ed25519_core.h"
+#include "../../consensus_amd/csrc/sha256_dev.h"
 
 using namespace sbv;
 
@@ -93,6 +94,13 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
     memset(bitmap, 0, (n + 7) / 8);
     for (size_t i = 0; i < n; ++i)
         if (verify_lane_keyed(s, i, slots[i], nkeys, ktab.data(), kvalid.data(), gtab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+}
+
+// device message front end (SHA-256 + strict DER) emulated: -> 96-byte r|s|hash record
+void sbve_msg_frontend(const uint8_t* msg, size_t mlen, const uint8_t* der, size_t dlen, uint8_t out96[96]) {
+    u32 w[24];
+    msg_frontend_lane(msg, mlen, der, dlen, w);
+    memcpy(out96, w, 96);
 }
 
 // ---- Ed25519 -----------------------------------------------------------------------------------------

@@ -218,3 +218,35 @@ def test_two_pass_scheme_never_disagrees_with_exact(emul):
     emul.sbve_fast_mismatches.restype = ctypes.c_ulong
     emul.sbve_sticky_reruns.restype = ctypes.c_ulong
     assert emul.sbve_fast_mismatches() == 0     # accumulated over every batch this module emulated
+
+
+def test_device_message_frontend_sha256_and_der(emul, golden_vectors):
+    """SHA-256 + strict DER as per-lane device code vs hashlib and the twin's parser."""
+    import hashlib
+    emul.sbve_msg_frontend.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    rng = random.Random(256)
+    sigs = [bytes.fromhex(v["sig"]) for v in golden_vectors if v["kind"] == "asn1"]
+    base = [s for s in sigs if ec.parse_der_sig(s) is not None]
+    for _ in range(1500):
+        b = bytearray(rng.choice(base))
+        op = rng.randrange(4)
+        if op == 0 and b:
+            b[rng.randrange(len(b))] = rng.randrange(256)
+        elif op == 1 and b:
+            del b[rng.randrange(len(b))]
+        elif op == 2:
+            b.insert(rng.randrange(len(b) + 1), rng.randrange(256))
+        else:
+            b = b[:rng.randrange(len(b) + 1)]
+        sigs.append(bytes(b))
+    out = ctypes.create_string_buffer(96)
+    for i, sig in enumerate(sigs):
+        mlen = [0, 1, 55, 56, 63, 64, 65, 119, 120, 200, 1000][i % 11]
+        msg = bytes(rng.randrange(256) for _ in range(mlen))
+        emul.sbve_msg_frontend(msg, mlen, sig, len(sig), out)
+        assert out.raw[64:96] == hashlib.sha256(msg).digest(), mlen
+        want = ec.parse_der_sig(sig)
+        if want is None or len(want[0]) > 32 or len(want[1]) > 32:
+            assert out.raw[:64] == bytes(64), sig.hex()
+        else:
+            assert out.raw[:64] == want[0].rjust(32, b"\0") + want[1].rjust(32, b"\0"), sig.hex()
