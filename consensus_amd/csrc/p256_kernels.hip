@@ -136,7 +136,10 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_fast(Scratch s
                                                                  uint8_t* __restrict__ rerun) {
     verify_body<true>(s, n, qtab, gtab, bitmap, rerun);
 }
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify(Scratch s, size_t n, u32* __restrict__ qtab,
+#ifndef SBV_LB_WAVES
+#define SBV_LB_WAVES 1
+#endif
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_LB_WAVES) void k_p256_verify(Scratch s, size_t n, u32* __restrict__ qtab,
                                                                        const apt* __restrict__ gtab,
                                                                        uint8_t* __restrict__ bitmap, uint8_t* __restrict__ rerun) {
     verify_body<false>(s, n, qtab, gtab, bitmap, rerun);

@@ -49,6 +49,17 @@ SBV_HD void pt_dbl(jpt& r, const jpt& p, u32* st = nullptr) {
     fe_sub(r.Y, t1, t2);                 // Y3 = alpha (4 beta - X3) - 8 gamma^2
 }
 
+// The P == Q fallback.  With SBV_NOINLINE_FALLBACK the (never taken on honest data) doubling is an
+// out-of-line call instead of an inlined copy inside every addition: smaller code, lower register
+// pressure in the additions (experiment knob; see profiles/).
+#if defined(SBV_NOINLINE_FALLBACK) && defined(__HIP_DEVICE_COMPILE__)
+template <bool FAST>
+__device__ __noinline__ void pt_dbl_cold(jpt& r, const jpt& p, u32* st) { pt_dbl<FAST>(r, p, st); }
+#define SBV_PT_DBL_COLD(F, r, p, st) pt_dbl_cold<F>(r, p, st)
+#else
+#define SBV_PT_DBL_COLD(F, r, p, st) pt_dbl<F>(r, p, st)
+#endif
+
 // R += (q.x, q.y) with y negated when `neg`; no-op when `skip` (window digit 0).
 template <bool FAST = false>
 SBV_HD void pt_add_mixed(jpt& R, const apt& q, bool neg, bool skip, u32* st = nullptr) {
@@ -75,7 +86,7 @@ SBV_HD void pt_add_mixed(jpt& R, const apt& q, bool neg, bool skip, u32* st = nu
     fe_mul<FAST>(v, R.Y, hhh, st);
     fe_sub(g.Y, t, v);                   // Y3 = r (X1 H^2 - X3) - Y1 H^3
     fe_mul<FAST>(g.Z, R.Z, h, st);                 // Z3 = Z1 H   (0 when P == -Q: infinity, as it must be)
-    if (same) pt_dbl<FAST>(g, R, st);
+    if (same) SBV_PT_DBL_COLD(FAST, g, R, st);
     const fe one = fe_one();
     const bool take_q = p_inf;
     SBV_UNROLL
@@ -119,7 +130,7 @@ SBV_HD void pt_add_qent(jpt& R, const qent& q, bool neg, bool skip, u32* st = nu
     fe_sub(g.Y, t, v);
     fe_mul<FAST>(t, R.Z, q.Z, st);
     fe_mul<FAST>(g.Z, t, h, st);
-    if (same) pt_dbl<FAST>(g, R, st);
+    if (same) SBV_PT_DBL_COLD(FAST, g, R, st);
     const bool take_q = p_inf;
     SBV_UNROLL
     for (int i = 0; i < 8; ++i) {
