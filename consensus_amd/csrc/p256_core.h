@@ -125,6 +125,16 @@ SBV_HD void prep_chunk(TupleWords words, size_t n, const Scratch& sc_, size_t fi
 #define SBV_GTAB_WINDOWS 33
 #define SBV_GTAB_PER_WINDOW 128
 
+#define SBV_G16_WINDOWS 17
+#define SBV_G16_PER_WINDOW 32768
+SBV_HD void comb16_digit(const u256& k, u32 top, int j, int& idx, bool& neg, bool& skip) {
+    if (j == 16) { idx = 0; neg = false; skip = top == 0; return; }
+    const int d = (int)((k.v[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu) - 32768;
+    const int ad = d < 0 ? -d : d;
+    idx = ad == 0 ? 0 : ad - 1;
+    neg = d < 0;
+    skip = d == 0;
+}
 struct alignas(16) vec4 { u32 x, y, z, w; };
 
 SBV_HD void fe_store16(u32* dst, const fe& a) {
@@ -190,12 +200,12 @@ SBV_HD bool rx_matches(const jpt& R, const u256& r, u32* st = nullptr) {
 }
 
 // Returns accept (true) / reject for lane `i`.  `qtab` = this lane's private table space
-// (SBV_QTAB_ENTRIES * 40 dwords, 16-byte aligned), `gtab` = 33 x 128 affine multiples of G:
-// gtab[j * 128 + (k-1)] = k * 2^(8j) * G.
+// (SBV_QTAB_ENTRIES * 40 dwords, 16-byte aligned), `g16` = 17 x 32768 affine multiples of G:
+// g16[j * 32768 + (k-1)] = k * 2^(16j) * G.
 // FAST = true is the first pass (see fe_cond_sub_p_t): *st must start at 0 and the caller re-runs
 // FAST = false for lanes whose sticky word came back 0xFFFFFFFF.
 template <bool FAST = false>
-SBV_HD bool verify_lane(const Scratch& s, size_t i, u32* qtab, const apt* gtab, u32* st = nullptr) {
+SBV_HD bool verify_lane(const Scratch& s, size_t i, u32* qtab, const apt* g16, u32* st = nullptr) {
     u256 r, u1, u2, qx, qy;
     soa_load(r, s.r, s.cap, i);
     soa_load(u1, s.u1, s.cap, i);
@@ -225,7 +235,7 @@ SBV_HD bool verify_lane(const Scratch& s, size_t i, u32* qtab, const apt* gtab, 
     // signed-window recoding: u + 0x88..8 has nibbles d+8, d in [-8,7]; bit 256 is a final +1 digit
     u256 k2, k1;
     const u32 top2 = add_const_limbs(k2, u2, 0x88888888u);
-    const u32 top1 = add_const_limbs(k1, u1, 0x80808080u);
+    const u32 top1 = add_const_limbs(k1, u1, 0x80008000u);
 
     jpt R;
     {
@@ -251,23 +261,27 @@ SBV_HD bool verify_lane(const Scratch& s, size_t i, u32* qtab, const apt* gtab, 
         qent_load(e, qtab + idx * 40);
         pt_add_qent<FAST>(R, e, d < 0, d == 0, st);
     }
-    // fixed-base part: 32 signed 8-bit windows + the carry window
-    for (int j = 0; j < 32; ++j) {
-        const int d = (int)((k1.v[j >> 2] >> ((j & 3) * 8)) & 255u) - 128;
-        const int ad = d < 0 ? -d : d;
-        const int idx = ad == 0 ? 0 : ad - 1;
-        apt g;
-        const u32* gp = reinterpret_cast<const u32*>(gtab + (size_t)j * SBV_GTAB_PER_WINDOW + idx);
-        fe_load16(g.x, gp);
-        fe_load16(g.y, gp + 8);
-        pt_add_mixed<FAST>(R, g, d < 0, d == 0, st);
-    }
+    // fixed-base part: 16 signed 16-bit comb windows + the carry window (17 mixed additions), with the
+    // next window's entry prefetched while the current addition runs
     {
-        apt g;
-        const u32* gp = reinterpret_cast<const u32*>(gtab + (size_t)32 * SBV_GTAB_PER_WINDOW);
-        fe_load16(g.x, gp);
-        fe_load16(g.y, gp + 8);
-        pt_add_mixed<FAST>(R, g, false, top1 == 0, st);
+        apt cur;
+        int idx; bool neg, skip;
+        comb16_digit(k1, top1, 0, idx, neg, skip);
+        {
+            const u32* gp = reinterpret_cast<const u32*>(g16 + idx);
+            fe_load16(cur.x, gp); fe_load16(cur.y, gp + 8);
+        }
+        SBV_NOUNROLL
+        for (int j = 0; j < SBV_G16_WINDOWS; ++j) {
+            const int jn = j + 1 < SBV_G16_WINDOWS ? j + 1 : SBV_G16_WINDOWS - 1;
+            int idxn; bool negn, skipn;
+            comb16_digit(k1, top1, jn, idxn, negn, skipn);
+            const u32* gp = reinterpret_cast<const u32*>(g16 + (size_t)jn * SBV_G16_PER_WINDOW + idxn);
+            apt nxt;
+            fe_load16(nxt.x, gp); fe_load16(nxt.y, gp + 8);
+            pt_add_mixed<FAST>(R, cur, neg, skip, st);
+            cur = nxt; neg = negn; skip = skipn;
+        }
     }
 
     return ok && rx_matches<FAST>(R, r, st);
@@ -290,7 +304,7 @@ SBV_HD void comb_digit(const u256& k, u32 top, int j, int& idx, bool& neg, bool&
 
 template <bool FAST = false>
 SBV_HD bool verify_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys, const apt* ktab,
-                              const uint8_t* kvalid, const apt* gtab, u32* st = nullptr) {
+                              const uint8_t* kvalid, const apt* g16, u32* st = nullptr) {
     u256 r, u1, u2;
     soa_load(r, s.r, s.cap, i);
     soa_load(u1, s.u1, s.cap, i);
@@ -300,27 +314,32 @@ SBV_HD bool verify_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys, c
     ok = ok && kvalid[slot] != 0;
     const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
     u256 k1, k2;
-    const u32 top1 = add_const_limbs(k1, u1, 0x80808080u);
+    const u32 top1 = add_const_limbs(k1, u1, 0x80008000u);
     const u32 top2 = add_const_limbs(k2, u2, 0x80808080u);
     jpt R;
     pt_set_inf(R);
-    // one rolled loop over 66 (table, window) steps: a single mixed-add body in the instruction stream
+    // one rolled loop over 17 (G, 16-bit comb) + 33 (Q, 8-bit comb) steps: a single mixed-add body in
+    // the instruction stream; the next step's entry is prefetched while this step's addition runs
+    constexpr int kSteps = SBV_G16_WINDOWS + SBV_GTAB_WINDOWS;
+    auto locate = [&](int t, int& idx, bool& neg, bool& skip) -> const apt* {
+        if (t < SBV_G16_WINDOWS) {
+            comb16_digit(k1, top1, t, idx, neg, skip);
+            return g16 + (size_t)t * SBV_G16_PER_WINDOW + idx;
+        }
+        comb_digit(k2, top2, t - SBV_G16_WINDOWS, idx, neg, skip);
+        return qtab + (size_t)(t - SBV_G16_WINDOWS) * SBV_GTAB_PER_WINDOW + idx;
+    };
     apt cur;
     int idx; bool neg, skip;
-    comb_digit(k1, top1, 0, idx, neg, skip);
     {
-        const u32* gp = reinterpret_cast<const u32*>(gtab + idx);
+        const u32* gp = reinterpret_cast<const u32*>(locate(0, idx, neg, skip));
         fe_load16(cur.x, gp); fe_load16(cur.y, gp + 8);
     }
     SBV_NOUNROLL
-    for (int t = 0; t < 66; ++t) {
-        // software prefetch of the next step's table entry while this step's addition runs
-        const int tn = t + 1 < 66 ? t + 1 : 65;
-        const int jn = tn >> 1;
+    for (int t = 0; t < kSteps; ++t) {
+        const int tn = t + 1 < kSteps ? t + 1 : kSteps - 1;
         int idxn; bool negn, skipn;
-        if (tn & 1) comb_digit(k2, top2, jn, idxn, negn, skipn); else comb_digit(k1, top1, jn, idxn, negn, skipn);
-        const apt* tab = (tn & 1) ? qtab : gtab;
-        const u32* gp = reinterpret_cast<const u32*>(tab + (size_t)jn * SBV_GTAB_PER_WINDOW + idxn);
+        const u32* gp = reinterpret_cast<const u32*>(locate(tn, idxn, negn, skipn));
         apt nxt;
         fe_load16(nxt.x, gp); fe_load16(nxt.y, gp + 8);
         pt_add_mixed<FAST>(R, cur, neg, skip, st);
@@ -347,41 +366,46 @@ inline bool key_is_valid(const u256& px, const u256& py) {
     fe_to_mont(y, py);
     return pt_on_curve(x, y);
 }
-inline void build_comb_table(const u256& px, const u256& py, apt* out) {
+// General form: `windows` windows of `per_window` = 2^(wbits-1) entries, out[j*per_window + (k-1)] =
+// k * 2^(wbits*j) * P.  One window is independent of the others once its base is known.
+inline void comb_window(const apt& base, int per_window, apt* out_row) {
+    jpt* row = new jpt[per_window];
+    fe* pre = new fe[per_window];
+    jpt t;
+    t.X = base.x; t.Y = base.y; t.Z = fe_one();
+    row[0] = t;
+    pt_dbl(t, t);
+    row[1] = t;
+    for (int k = 3; k <= per_window; ++k) {
+        pt_add_mixed(t, base, false, false);
+        row[k - 1] = t;
+    }
+    fe acc = fe_one();                          // batch-invert the Z's (Montgomery's trick)
+    for (int k = 0; k < per_window; ++k) { pre[k] = acc; fe_mul(acc, acc, row[k].Z); }
+    fe inv;
+    fe_inv(inv, acc);
+    for (int k = per_window - 1; k >= 0; --k) {
+        fe zi, zi2, zi3;
+        fe_mul(zi, inv, pre[k]);
+        fe_mul(inv, inv, row[k].Z);
+        fe_sqr(zi2, zi);
+        fe_mul(zi3, zi2, zi);
+        fe_mul(out_row[k].x, row[k].X, zi2);
+        fe_mul(out_row[k].y, row[k].Y, zi3);
+    }
+    delete[] row;
+    delete[] pre;
+}
+// bases[j] = 2^(wbits*j) * P, affine
+inline void comb_bases(const u256& px, const u256& py, int wbits, int windows, apt* bases) {
     apt base;
     fe_to_mont(base.x, px);
     fe_to_mont(base.y, py);
-    jpt* row = new jpt[SBV_GTAB_PER_WINDOW];
-    fe* pre = new fe[SBV_GTAB_PER_WINDOW];
-    for (int j = 0; j < SBV_GTAB_WINDOWS; ++j) {
-        jpt t;
-        t.X = base.x; t.Y = base.y; t.Z = fe_one();
-        row[0] = t;
-        pt_dbl(t, t);
-        row[1] = t;
-        for (int k = 3; k <= SBV_GTAB_PER_WINDOW; ++k) {
-            pt_add_mixed(t, base, false, false);
-            row[k - 1] = t;
-        }
-        // batch-invert the Z's (Montgomery's trick)
-        fe acc = fe_one();
-        for (int k = 0; k < SBV_GTAB_PER_WINDOW; ++k) { pre[k] = acc; fe_mul(acc, acc, row[k].Z); }
-        fe inv;
-        fe_inv(inv, acc);
-        for (int k = SBV_GTAB_PER_WINDOW - 1; k >= 0; --k) {
-            fe zi, zi2, zi3;
-            fe_mul(zi, inv, pre[k]);
-            fe_mul(inv, inv, row[k].Z);
-            fe_sqr(zi2, zi);
-            fe_mul(zi3, zi2, zi);
-            apt a;
-            fe_mul(a.x, row[k].X, zi2);
-            fe_mul(a.y, row[k].Y, zi3);
-            out[(size_t)j * SBV_GTAB_PER_WINDOW + k] = a;
-        }
-        // next base = 2^8 * base = 2 * (128 * base)
-        jpt nb = row[SBV_GTAB_PER_WINDOW - 1];
-        pt_dbl(nb, nb);
+    for (int j = 0; j < windows; ++j) {
+        bases[j] = base;
+        jpt nb;
+        nb.X = base.x; nb.Y = base.y; nb.Z = fe_one();
+        for (int i = 0; i < wbits; ++i) pt_dbl(nb, nb);
         fe zi, zi2, zi3;
         fe_inv(zi, nb.Z);
         fe_sqr(zi2, zi);
@@ -389,8 +413,24 @@ inline void build_comb_table(const u256& px, const u256& py, apt* out) {
         fe_mul(base.x, nb.X, zi2);
         fe_mul(base.y, nb.Y, zi3);
     }
-    delete[] row;
-    delete[] pre;
+}
+inline void build_comb_table(const u256& px, const u256& py, apt* out) {
+    apt bases[SBV_GTAB_WINDOWS];
+    comb_bases(px, py, 8, SBV_GTAB_WINDOWS, bases);
+    for (int j = 0; j < SBV_GTAB_WINDOWS; ++j) comb_window(bases[j], SBV_GTAB_PER_WINDOW, out + (size_t)j * SBV_GTAB_PER_WINDOW);
+}
+
+// ---- 16-bit comb for G (device verify kernels) ---------------------------------------------------------
+// u1*G is then 17 mixed additions instead of 33.  17 x 32768 x 64 B = 35.7 MB: far beyond LDS or one
+// XCD's L2 but nothing for HBM / the 256 MB Infinity Cache; the next window's entry is software-
+// prefetched while the current addition runs.
+// window j of the G16 table (j = 0..16), callable from several host threads
+inline void build_g16_window(int j, apt* out_row) {
+    const u256 gx = {{0xD898C296u, 0xF4A13945u, 0x2DEB33A0u, 0x77037D81u, 0x63A440F2u, 0xF8BCE6E5u, 0xE12C4247u, 0x6B17D1F2u}};
+    const u256 gy = {{0x37BF51F5u, 0xCBB64068u, 0x6B315ECEu, 0x2BCE3357u, 0x7C0F9E16u, 0x8EE7EB4Au, 0xFE1A7F9Bu, 0x4FE342E2u}};
+    apt bases[SBV_G16_WINDOWS];
+    comb_bases(gx, gy, 16, j + 1, bases);
+    comb_window(bases[j], SBV_G16_PER_WINDOW, out_row);
 }
 
 }  // namespace sbv

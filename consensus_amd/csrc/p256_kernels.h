@@ -22,6 +22,8 @@ bool host_build_key_table(const uint8_t q[64], apt* out);
 // d_rerun: ceil(n/64) bytes of per-wavefront flags (fast pass -> exact pass)
 hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
                               hipStream_t stream);
-void host_build_gtable(apt* out);   // 33 x 128 affine multiples of G (one-time table setup)
+void host_build_gtable(apt* out);   // 33 x 128 affine multiples of G (8-bit comb; host signer, key tables)
+void host_build_g16(apt* out);      // 17 x 32768 affine multiples of G (16-bit comb used by the verify kernels)
+#define SBV_G16_ENTRIES ((size_t)SBV_G16_WINDOWS * SBV_G16_PER_WINDOW)
 
 }  // namespace sbv

@@ -17,6 +17,9 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <thread>
+#include <vector>
+
 #include "p256_core.h"
 #include "p256_kernels.h"
 #include "sha256_dev.h"
@@ -230,6 +233,12 @@ hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt
 }
 
 void host_build_gtable(apt* out) { build_gtable(out); }
+
+void host_build_g16(apt* out) {
+    std::vector<std::thread> th;
+    for (int j = 0; j < SBV_G16_WINDOWS; ++j) th.emplace_back([j, out] { build_g16_window(j, out + (size_t)j * SBV_G16_PER_WINDOW); });
+    for (auto& t : th) t.join();
+}
 
 bool host_build_key_table(const uint8_t q[64], apt* out) {
     u256 x, y;

@@ -4,7 +4,7 @@
 //   tuples    cap * 160 B            staging for the host-pointer entry point (AoS, as received)
 //   scratch   6 x cap * 32 B + cap   limb-major r, u1, u2, Qx, Qy, sM + ok flags   (stage A -> B)
 //   qtab      cap * 1280 B           per-signature window tables k*Q, k = 1..8      (stage B)
-//   gtab      33 * 128 * 64 B        fixed-base table k * 2^(8j) * G                (read-only)
+//   gtab      17 * 32768 * 64 B      fixed-base 16-bit comb k * 2^(16j) * G (35.7 MB, read-only)
 //   bitmap    cap / 8 B
 // For the 2^20-tuple headline batch that is 0.17 + 0.20 + 1.34 GB: sized for 288 GB of HBM3E,
 // not for a cache.  There is no CPU verification path in this library.
@@ -207,9 +207,10 @@ extern "C" int sbv_init(int device) {
     for (auto& ev : c.ev) HIP_TRY(SBV_ENODEV, hipEventCreate(&ev));
     HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(&c.busy, hipEventDisableTiming));
     // fixed-base table: computed once on the host with the same field code, then resident in HBM
-    const size_t gcount = (size_t)SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW;
+    // (16-bit comb, 35.7 MB: u1*G is 17 mixed additions; built by 17 host threads in ~0.1 s)
+    const size_t gcount = SBV_G16_ENTRIES;
     std::vector<sbv::apt> h_gtab(gcount);
-    sbv::host_build_gtable(h_gtab.data());
+    sbv::host_build_g16(h_gtab.data());
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_gtab, gcount * sizeof(sbv::apt)));
     HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_gtab, h_gtab.data(), gcount * sizeof(sbv::apt), hipMemcpyHostToDevice));
     c.device = device;

@@ -7,6 +7,7 @@
 // libsbv.so, is never shipped and is not a fallback: the product fails loudly without a GPU.
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 
 #include "../../consensus_amd/csrc/p256_core.h"
@@ -17,12 +18,22 @@ using namespace sbv;
 
 static unsigned long g_sticky_reruns = 0, g_fast_mismatches = 0;
 static apt* g_gtab = nullptr;
-static const apt* gtab() {
+static const apt* gtab() {          // 8-bit comb (host signer / registered-key tables use this shape)
     if (!g_gtab) {
         g_gtab = (apt*)aligned_alloc(64, sizeof(apt) * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
         build_gtable(g_gtab);
     }
     return g_gtab;
+}
+static apt* g_g16 = nullptr;
+static const apt* g16tab() {        // 16-bit comb for G, as the verify kernels use
+    if (!g_g16) {
+        g_g16 = (apt*)aligned_alloc(64, sizeof(apt) * (size_t)SBV_G16_WINDOWS * SBV_G16_PER_WINDOW);
+        std::vector<std::thread> th;
+        for (int j = 0; j < SBV_G16_WINDOWS; ++j) th.emplace_back([j] { build_g16_window(j, g_g16 + (size_t)j * SBV_G16_PER_WINDOW); });
+        for (auto& t : th) t.join();
+    }
+    return g_g16;
 }
 
 struct HostWords {
@@ -54,8 +65,8 @@ void sbve_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap, in
     for (size_t i = 0; i < n; ++i) {
         // exactly the kernel's two-pass scheme: fast pass, exact re-run when the sticky word fired
         u32 sticky = 0;
-        bool acc = verify_lane<true>(s, i, qtab, gtab(), &sticky);
-        const bool exact = verify_lane<false>(s, i, qtab, gtab());
+        bool acc = verify_lane<true>(s, i, qtab, g16tab(), &sticky);
+        const bool exact = verify_lane<false>(s, i, qtab, g16tab());
         if (sticky == 0xFFFFFFFFu) { ++g_sticky_reruns; acc = exact; }
         else if (acc != exact) ++g_fast_mismatches;      // must never happen: the test asserts it stays 0
         if (acc) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
@@ -93,7 +104,7 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
     }
     memset(bitmap, 0, (n + 7) / 8);
     for (size_t i = 0; i < n; ++i)
-        if (verify_lane_keyed(s, i, slots[i], nkeys, ktab.data(), kvalid.data(), gtab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+        if (verify_lane_keyed(s, i, slots[i], nkeys, ktab.data(), kvalid.data(), g16tab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
 }
 
 // device message front end (SHA-256 + strict DER) emulated: -> 96-byte r|s|hash record
@@ -142,6 +153,7 @@ void sbve_mont_reduce(const u32* t16, u32* out) { fe z; fe_mont_reduce(z, t16); 
 void sbve_sc_mul(const u32* a, const u32* b, u32* out) { sc x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); sc_mul(z, x, y); memcpy(out, &z, 32); }
 void sbve_sc_inv(const u32* a, u32* out) { sc x, z; memcpy(&x, a, 32); sc_inv(z, x); memcpy(out, &z, 32); }
 // affine Montgomery-form G-table entry (j, k): 16 dwords
+void sbve_g16_entry(int j, int k, u32* out16) { memcpy(out16, &g16tab()[(size_t)j * SBV_G16_PER_WINDOW + (k - 1)], 64); }
 void sbve_gtab_entry(int j, int k, u32* out16) { memcpy(out16, &gtab()[(size_t)j * SBV_GTAB_PER_WINDOW + (k - 1)], 64); }
 
 }  // extern "C"

@@ -23,7 +23,7 @@ def emul():
     csrc = os.path.join(HERE, "..", "consensus_amd", "csrc")
     deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-misleading-indentation",
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-misleading-indentation",
                                src, "-o", so])
     lib = ctypes.CDLL(so)
     lib.sbve_p256_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
@@ -114,6 +114,16 @@ def test_gtable_entries(emul):
         y = val(out[8:16]) * rinv % P
         want = ec.pt_mul(k * (1 << (8 * j)) % N, ec.G)
         assert (x, y) == want, (j, k)
+
+
+def test_g16_table_entries(emul):
+    out = (ctypes.c_uint32 * 16)()
+    rinv = pow(R, -1, P)
+    for j, k in [(0, 1), (0, 2), (0, 32768), (1, 1), (7, 12345), (15, 32768), (16, 1)]:
+        emul.sbve_g16_entry(j, k, out)
+        x = val(out[0:8]) * rinv % P
+        y = val(out[8:16]) * rinv % P
+        assert (x, y) == ec.pt_mul(k * (1 << (16 * j)) % N, ec.G), (j, k)
 
 
 def _bitmap_list(bm, n):

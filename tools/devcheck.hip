@@ -190,8 +190,8 @@ static int pipeline_test(const char* path) {
     const size_t per_block = (size_t)64 * T, nblocks = (n + per_block - 1) / per_block;
     HostWords hw{tuples.data()};
     for (size_t b = 0; b < nblocks; ++b) for (int t = 0; t < 64; ++t) prep_chunk<true>(hw, n, s, b * per_block + t, 64, T);
-    std::vector<apt> gt((size_t)SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
-    host_build_gtable(gt.data());
+    std::vector<apt> gt(SBV_G16_ENTRIES);
+    host_build_g16(gt.data());
     std::vector<uint8_t> hbm((n + 7) / 8, 0);
     std::vector<u32> qt(SBV_QTAB_ENTRIES * 40 + 4);
     u32* qtp = (u32*)(((uintptr_t)qt.data() + 15) & ~(uintptr_t)15);
