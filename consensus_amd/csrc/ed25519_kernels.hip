@@ -21,7 +21,10 @@ struct EdLdsTuple {
     __device__ __forceinline__ u32 operator[](int i) const { return row[i]; }
 };
 
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_ed25519_verify(const uint8_t* __restrict__ tuples, size_t n,
+#ifndef SBV_ED_LB_WAVES
+#define SBV_ED_LB_WAVES 3   // measured: 168 VGPR + 26 spilled at 3 waves/SIMD beats 190 VGPR at 2 by 13 % (profiles/r01)
+#endif
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_LB_WAVES) void k_ed25519_verify(const uint8_t* __restrict__ tuples, size_t n,
                                                                     u32* __restrict__ qtab,
                                                                     const aniels* __restrict__ btab,
                                                                     uint8_t* __restrict__ bitmap) {

@@ -241,19 +241,26 @@ int sbvh_replay(void* h, int n_nodes, int K, int sequences, int decisions, int t
             }
             t_prev.push_back(now_us() - t0);
         }
-        // N-1 concurrent votes; done when Q-1 accepted (view.go:531)
-        std::atomic<int> accepted(0), failed(0);
+        // N-1 concurrent votes; done when Q-1 accepted (view.go:531).  The voter threads are parked on a
+        // start flag and released together: goroutines in View.processCommits start within microseconds of
+        // each other (view.go:537-541), OS thread creation would smear the burst over ~0.5 ms.
+        std::atomic<int> accepted(0), failed(0), ready(0);
+        std::atomic<bool> go(false);
         std::vector<std::thread> voters;
         double t_done = 0;
         std::mutex m;
-        t0 = now_us();
         for (int nd = 1; nd < n_nodes; ++nd)
             voters.emplace_back([&, nd] {
+                ready.fetch_add(1);
+                while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
                 bytes aux;
                 const Status r = V.VerifyConsenterSig(commits[(size_t)s][(size_t)nd], props[(size_t)s], &aux);
                 if (r.ok()) { if (accepted.fetch_add(1) + 1 == Q - 1) { std::lock_guard<std::mutex> lk(m); t_done = now_us(); } }
                 else failed.fetch_add(1);
             });
+        while (ready.load() < n_nodes - 1) std::this_thread::yield();
+        t0 = now_us();
+        go.store(true, std::memory_order_release);
         for (auto& t : voters) t.join();
         if (failed.load() || accepted.load() < Q - 1) { out->status = 1; return 1; }
         t_quorum.push_back(t_done - t0);

@@ -235,10 +235,25 @@ Status Verifier::VerifySignature(const Signature& s) {        // viewchanger.go:
     return verify_one(q, s.msg, s.value, slot);
 }
 
+bytes Verifier::digest_memo(const Proposal& p) {
+    {
+        std::lock_guard<std::mutex> lk(digest_mu_);
+        for (const DigestEntry& e : digest_cache_)
+            if (e.p.verification_sequence == p.verification_sequence && e.p.header == p.header && e.p.metadata == p.metadata &&
+                e.p.payload == p.payload)
+                return e.digest;
+    }
+    DigestEntry e{p, proposal_digest_raw(p)};
+    std::lock_guard<std::mutex> lk(digest_mu_);
+    if (digest_cache_.size() < 4) digest_cache_.push_back(e);
+    else { digest_cache_[digest_next_] = e; digest_next_ = (digest_next_ + 1) % 4; }
+    return e.digest;
+}
+
 Status Verifier::VerifyConsenterSig(const Signature& s, const Proposal& prop, bytes* aux) {   // view.go:631, 834
     bytes binding, a;
     if (!consenter_msg_split(s.msg, &binding, &a)) return Status::Invalid("malformed signature message");
-    if (binding != proposal_digest_raw(prop)) return Status::Invalid("signature message does not match proposal");
+    if (binding != digest_memo(prop)) return Status::Invalid("signature message does not match proposal");
     Status st = VerifySignature(s);
     if (!st.ok()) return st;
     if (aux) *aux = a;

@@ -43,5 +43,6 @@ def run(name, n_nodes, K, sequences, decisions, wait_us):
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 run("config1-shape: 4 nodes, K=100", 4, 100, 5, 0, 50)
 run("config3: 4 nodes, K=10000", 4, 10000 if not quick else 2000, 3, 0, 50)
-run("M2: 16 nodes commit-quorum latency", 16, 10, 7, 0, 50)
+run("M2: 16 nodes commit-quorum latency", 16, 10, 9, 0, 50)
+run("M2: 16 nodes commit-quorum latency (coalesce 200us)", 16, 10, 9, 0, 200)
 run("config4: 16 nodes, 50k decisions x 11 sigs", 16, 10, 1, 50000 if not quick else 5000, 50)
