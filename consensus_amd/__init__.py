@@ -85,6 +85,7 @@ def load() -> ctypes.CDLL:
                                             ctypes.c_size_t, ctypes.c_char_p]
     lib.sbv_p256_verify_msgs_keyed.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p,
                                                ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.sbv_p256_set_grouping.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32]
     lib.sbv_last_timing.argtypes = [ctypes.POINTER(Timing)]
     lib.sbv_profile_enable.argtypes = [ctypes.c_int]
     lib.sbv_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
@@ -210,6 +211,11 @@ def verify_msgs_keyed(msgs, sigs_der, slots) -> bytes:
     out = ctypes.create_string_buffer(max(1, (n + 7) // 8))
     _check(load().sbv_p256_verify_msgs_keyed(b"".join(msgs), mo, b"".join(sigs_der), so, arr, n, out))
     return out.raw[:(n + 7) // 8]
+
+
+def set_grouping(enabled: bool, min_batch: int = 0, min_count: int = 0, max_groups: int = 0) -> None:
+    """In-step grouping of generic batches by public key (0 keeps a value); see include/sbv.h."""
+    _check(load().sbv_p256_set_grouping(1 if enabled else 0, min_batch, min_count, max_groups))
 
 
 def parse_der(sig: bytes) -> Optional[bytes]:

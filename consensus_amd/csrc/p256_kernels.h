@@ -22,6 +22,19 @@ bool host_build_key_table(const uint8_t q[64], apt* out);
 // d_rerun: ceil(n/64) bytes of per-wavefront flags (fast pass -> exact pass)
 hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
                               hipStream_t stream);
+// device buffers of the in-step key grouping (p256_group.h); owned by the context
+struct GroupBuffers {
+    u32* ht = nullptr; u32 ht_mask = 0;
+    u32 *rep = nullptr, *cnt = nullptr, *slot_of = nullptr, *group_rep = nullptr, *counters = nullptr, *grp_idx = nullptr,
+        *ung_idx = nullptr, *slots = nullptr;
+    apt* bases = nullptr; apt* ktab = nullptr; uint8_t* kvalid = nullptr; u32* tmp = nullptr; uint8_t* acc = nullptr;
+    u32 max_groups = 0, min_count = 0;
+    size_t cap = 0;
+};
+// ev_fork must have been recorded on `stream` before stage A was enqueued
+hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b, u32* d_qtab,
+                                      const apt* d_g16, uint8_t* d_bitmap, hipStream_t stream, hipStream_t side,
+                                      hipEvent_t ev_fork, hipEvent_t ev_split, hipEvent_t ev_tables);
 void host_build_gtable(apt* out);   // 33 x 128 affine multiples of G (8-bit comb; host signer, key tables)
 void host_build_g16(apt* out);      // 17 x 32768 affine multiples of G (16-bit comb used by the verify kernels)
 #define SBV_G16_ENTRIES ((size_t)SBV_G16_WINDOWS * SBV_G16_PER_WINDOW)

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -38,10 +39,17 @@ struct Context {
     uint8_t* d_rerun = nullptr;         // per-wavefront flags between the fast and the exact stage-B pass
     uint8_t* h_bitmap = nullptr;        // pinned
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;         // grouping / table-building chain of the grouped stage B
+    hipEvent_t ev_fork = nullptr, ev_split = nullptr, ev_tables = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t busy = nullptr;          // completion of the last launch that used the scratch
     bool busy_valid = false;
     sbv_timing timing{};
+    // in-step key grouping (p256_group.h)
+    sbv::GroupBuffers grp;
+    bool group_enabled = true;
+    size_t group_min_batch = 131072;
+    u32 group_min_count = 64, group_max = 2048;
     // message front end staging (grown on demand)
     uint8_t* d_msgs = nullptr; size_t msgs_cap = 0;
     uint8_t* d_sigs = nullptr; size_t sigs_cap = 0;
@@ -121,12 +129,60 @@ sbv::Scratch scratch_view(const Context& c) {
     return s;
 }
 
+void free_group_buffers(Context& c) {
+    sbv::GroupBuffers& b = c.grp;
+    void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.bases, b.ktab, b.kvalid, b.tmp, b.acc};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    b = sbv::GroupBuffers();
+}
+
+int ensure_group_buffers(Context& c, size_t n) {
+    sbv::GroupBuffers& b = c.grp;
+    if (b.cap >= n && b.max_groups == c.group_max) { b.min_count = c.group_min_count; return SBV_OK; }
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    free_group_buffers(c);
+    const size_t cap = (n + 1023) & ~(size_t)1023;
+    size_t ht = 1024;
+    while (ht < 2 * cap) ht *= 2;
+    const size_t G = c.group_max;
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ht, ht * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.rep, cap * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.cnt, cap * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.slot_of, cap * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.group_rep, G * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.counters, 4 * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.grp_idx, cap * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ung_idx, cap * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.slots, cap * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.bases, G * SBV_GTAB_WINDOWS * sizeof(sbv::apt)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ktab, G * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, G));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tmp, G * SBV_GTAB_WINDOWS * (size_t)(SBV_GTAB_PER_WINDOW * 32) * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.acc, cap));
+    b.ht_mask = (u32)(ht - 1);
+    b.max_groups = (u32)G;
+    b.min_count = c.group_min_count;
+    b.cap = cap;
+    return SBV_OK;
+}
+
 // enqueue stage A + stage B for n <= cap tuples on `stream`
 int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream,
             hipEvent_t after_prep) {
     const sbv::Scratch s = scratch_view(c);
+    const bool grouped = c.group_enabled && n >= c.group_min_batch;
+    if (grouped) {
+        const int rc = ensure_group_buffers(c, n);
+        if (rc != SBV_OK) return rc;
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev_fork, stream));
+    }
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_tuples, n, s, stream));
     if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
+    if (grouped) {
+        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, d_bitmap, stream, c.side,
+                                                             c.ev_fork, c.ev_split, c.ev_tables));
+        return SBV_OK;
+    }
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify(s, n, c.d_qtab, c.d_gtab, d_bitmap, c.d_rerun, stream));
     return SBV_OK;
 }
@@ -204,6 +260,10 @@ extern "C" int sbv_init(int device) {
         return SBV_ENODEV;
     }
     HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+    HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+    HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(&c.ev_split, hipEventDisableTiming));
+    HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(&c.ev_tables, hipEventDisableTiming));
     for (auto& ev : c.ev) HIP_TRY(SBV_ENODEV, hipEventCreate(&ev));
     HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(&c.busy, hipEventDisableTiming));
     // fixed-base table: computed once on the host with the same field code, then resident in HBM
@@ -213,6 +273,7 @@ extern "C" int sbv_init(int device) {
     sbv::host_build_g16(h_gtab.data());
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_gtab, gcount * sizeof(sbv::apt)));
     HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_gtab, h_gtab.data(), gcount * sizeof(sbv::apt), hipMemcpyHostToDevice));
+    if (const char* e = getenv("SBV_GROUP")) c.group_enabled = e[0] != '0';
     c.device = device;
     c.ready = true;
     g_err.clear();
@@ -226,6 +287,7 @@ extern "C" int sbv_shutdown(void) {
     (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
     free_buffers(c);
+    free_group_buffers(c);
     if (c.d_gtab) (void)hipFree(c.d_gtab);
     c.d_gtab = nullptr;
     if (c.d_btab) (void)hipFree(c.d_btab);
@@ -245,6 +307,8 @@ extern "C" int sbv_shutdown(void) {
     c.prof_used = 0;
     if (c.busy) { (void)hipEventDestroy(c.busy); c.busy = nullptr; }
     if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
+    if (c.side) { (void)hipStreamDestroy(c.side); c.side = nullptr; }
+    for (hipEvent_t* ev : {&c.ev_fork, &c.ev_split, &c.ev_tables}) if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
     c.busy_valid = false;
     c.ready = false;
     c.device = -1;
@@ -605,6 +669,16 @@ extern "C" int sbv_p256_verify_msgs_keyed(const uint8_t* msgs, const uint64_t* m
     c.busy_valid = false;
     tm.total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     c.timing = tm;
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uint32_t max_groups) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    c.group_enabled = enabled != 0;
+    if (min_batch) c.group_min_batch = min_batch;
+    if (min_count) c.group_min_count = min_count;
+    if (max_groups) c.group_max = max_groups;
     return SBV_OK;
 }
 

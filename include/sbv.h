@@ -64,6 +64,14 @@ int sbv_device_count(void);
  * (viewchanger.go:598, 660, 718, 983, 1022, 1076). */
 int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap);
 
+/* In-step key grouping for the two generic entry points above (consensus_amd/csrc/p256_group.h): when a
+ * batch has at least `min_batch` tuples, tuples are grouped by public key on the device, keys used by
+ * at least `min_count` tuples of THIS batch (at most `max_groups` of them) get a comb table built inside
+ * the call and their signatures take the no-doubling kernel; everything else takes the generic kernel.
+ * Nothing is remembered between calls; verdicts are identical.  Defaults: enabled, 131072, 64, 2048
+ * (env SBV_GROUP=0 disables).  Passing 0 for a numeric argument keeps its current value. */
+int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uint32_t max_groups);
+
 /* Same, on device-resident buffers, asynchronous on `hip_stream` (a hipStream_t; NULL = the
  * default stream).  d_tuples: n*160 bytes, 16-byte aligned.  d_bitmap: ceil(n/8) bytes.
  * The caller synchronises the stream.  Used by bench.py / multi-GPU shards. */

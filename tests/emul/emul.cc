@@ -13,6 +13,7 @@
 #include "../../consensus_amd/csrc/p256_core.h"
 #include "../../consensus_amd/csrc/ed25519_core.h"
 #include "../../consensus_amd/csrc/sha256_dev.h"
+#include "../../consensus_amd/csrc/p256_group.h"
 
 using namespace sbv;
 
@@ -78,6 +79,52 @@ unsigned long sbve_fast_mismatches() { return g_fast_mismatches; }
 // fast conditional subtraction, standalone: returns the sticky word
 u32 sbve_fe_add_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_add<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 u32 sbve_fe_mul_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_mul<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
+
+// grouped form: generic tuples, keys grouped inside the call (p256_group.h), emulated sequentially.
+// stats_out[0..2] = groups, grouped tuples, ungrouped tuples.
+void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bitmap, u32 min_count, u32 max_groups,
+                                    u32 ht_bits, u32* stats_out) {
+    size_t cap = (n + 63) & ~(size_t)63;
+    if (cap == 0) cap = 64;
+    std::vector<u32> r(8 * cap), u1(8 * cap), u2(8 * cap), qx(8 * cap), qy(8 * cap), sm(8 * cap);
+    std::vector<uint8_t> ok(cap, 0);
+    Scratch s{r.data(), u1.data(), u2.data(), qx.data(), qy.data(), sm.data(), ok.data(), cap};
+    HostWords hw{tuples, 160};
+    const int T = 4;
+    const size_t per_block = (size_t)64 * T, nblocks = (n + per_block - 1) / per_block;
+    for (size_t b = 0; b < nblocks; ++b)
+        for (int t = 0; t < 64; ++t) prep_chunk<true>(hw, n, s, b * per_block + t, 64, T);
+    std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(max_groups ? max_groups : 1), counters(4, 0),
+        grp_idx(cap), ung_idx(cap), slots(cap);
+    GroupState g{ht.data(), (u32)(((size_t)1 << ht_bits) - 1), rep.data(), cnt.data(), slot_of.data(), group_rep.data(), counters.data(),
+                 grp_idx.data(), ung_idx.data(), slots.data(), max_groups, min_count};
+    for (size_t i = 0; i < n; ++i) group_insert_lane(tuples, i, g);
+    for (size_t i = 0; i < n; ++i) group_assign_lane(i, g);
+    for (size_t i = 0; i < n; ++i) group_split_lane(i, g);
+    const u32 ngroups = counters[0] < max_groups ? counters[0] : max_groups;
+    std::vector<apt> bases((size_t)(ngroups ? ngroups : 1) * SBV_GTAB_WINDOWS);
+    std::vector<apt> ktab((size_t)(ngroups ? ngroups : 1) * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
+    std::vector<uint8_t> kvalid(ngroups ? ngroups : 1, 0);
+    std::vector<u32> tmp(SBV_KEYTAB_TMP_DWORDS + 4);
+    u32* tmpa = (u32*)(((uintptr_t)tmp.data() + 15) & ~(uintptr_t)15);
+    for (u32 k = 0; k < ngroups; ++k) keytab_bases_lane(tuples, k, g, bases.data(), kvalid.data());
+    for (u32 k = 0; k < ngroups; ++k)
+        for (int j = 0; j < SBV_GTAB_WINDOWS; ++j)
+            keytab_window_lane(bases[(size_t)k * SBV_GTAB_WINDOWS + j], tmpa,
+                               &ktab[((size_t)k * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW]);
+    memset(bitmap, 0, (n + 7) / 8);
+    u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB_ENTRIES * 40 * 4);
+    for (u32 L = 0; L < counters[1]; ++L) {
+        const u32 t = grp_idx[L];
+        if (verify_lane_keyed(s, t, slots[t], ngroups, ktab.data(), kvalid.data(), g16tab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+    }
+    for (u32 L = 0; L < counters[2]; ++L) {
+        const u32 t = ung_idx[L];
+        if (verify_lane(s, t, qtab, g16tab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+    }
+    free(qtab);
+    if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; }
+}
 
 // registered-key form: rsh = n x 96 B (r|s|hash), slots[i] indexes keys (nkeys x 64 B, Qx|Qy)
 void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n, const uint8_t* keys, u32 nkeys,

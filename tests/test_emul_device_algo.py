@@ -260,3 +260,36 @@ def test_device_message_frontend_sha256_and_der(emul, golden_vectors):
             assert out.raw[:64] == bytes(64), sig.hex()
         else:
             assert out.raw[:64] == want[0].rjust(32, b"\0") + want[1].rjust(32, b"\0"), sig.hex()
+
+
+def test_grouped_by_key_inside_the_batch_matches_generic(emul, oracle, golden_vectors):
+    """p256_group.h: hash-grouping + per-batch key tables + registered-key kernel == generic verdicts,
+    including invalid keys that repeat, keys below the group threshold, more keys than table slots and
+    a hash table so small that every probe collides."""
+    emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+    n = 900
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0x6B, n, 7, 5, tup, exp, 4)
+    # repeat an invalid-key tuple (off curve) 40 times so that an INVALID key becomes a group
+    off = next(bytes.fromhex(v["tuple"]) for v in vs if v["name"] == "q_off_curve_y_plus_1")
+    allt = blob + tup.raw + off * 40
+    total = len(allt) // 160
+    want = [v["accept"] for v in vs] + _bitmap_list(exp.raw, n) + [False] * 40
+    stats = (ctypes.c_uint32 * 3)()
+    for min_count, max_groups, ht_bits in [(8, 64, 12), (1, 4096, 12), (8, 3, 12), (2, 64, 11), (10**6, 64, 12)]:
+        bm = ctypes.create_string_buffer((total + 7) // 8)
+        emul.sbve_p256_verify_batch_grouped(allt, total, bm, min_count, max_groups, ht_bits, stats)
+        got = _bitmap_list(bm.raw, total)
+        bad = [i for i in range(total) if got[i] != want[i]]
+        assert not bad, (min_count, max_groups, ht_bits, bad[:8])
+        assert stats[1] + stats[2] == total
+        if min_count == 8 and max_groups == 64:
+            assert stats[0] >= 8 and stats[1] > 800          # 7 signer keys + the repeated invalid key + reused golden keys
+        if max_groups == 3:
+            assert stats[0] == 3
+        if min_count == 10**6:
+            assert stats[0] == 0 and stats[2] == total

@@ -280,3 +280,52 @@ def test_device_message_frontend(gpu, oracle, golden_vectors):
     assert not bad, bad[:10]
     assert sum(want) > 500 and sum(want) < 2500
     gpu.clear_keys()
+
+
+def test_in_step_key_grouping_equals_generic(gpu, oracle, golden_vectors):
+    """sbv_p256_set_grouping: tuples grouped by key on the device, per-batch comb tables, registered-key kernel for
+    the grouped ones — verdicts must equal the plain generic kernel in every configuration."""
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+    n = 20000
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0x6B, n, 23, 5, tup, exp, os.cpu_count() or 1)
+    off = next(bytes.fromhex(v["tuple"]) for v in vs if v["name"] == "q_off_curve_y_plus_1")
+    allt = blob + tup.raw + off * 100
+    total = len(allt) // 160
+    want = [v["accept"] for v in vs] + sbv.bitmap_to_list(exp.raw, n) + [False] * 100
+    try:
+        gpu.set_grouping(False)
+        assert sbv.bitmap_to_list(gpu.verify_batch(allt, total), total) == want
+        for min_count, max_groups in [(8, 64), (1, 4096), (8, 3), (1000000, 64)]:
+            gpu.set_grouping(True, 1, min_count, max_groups)
+            got = sbv.bitmap_to_list(gpu.verify_batch(allt, total), total)
+            bad = [i for i in range(total) if got[i] != want[i]]
+            assert not bad, (min_count, max_groups, bad[:8])
+    finally:
+        gpu.set_grouping(True, 131072, 64, 2048)
+
+
+def test_grouped_vs_ungrouped_full_batch(gpu):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import numpy as np
+    import synth
+    n = 1 << 20
+    tuples, valid = synth.gen_batch(0x5B7F2026, n)
+    out = np.zeros(n // 8, dtype=np.uint8)
+    times = {}
+    try:
+        for mode in (True, False):
+            gpu.set_grouping(mode, 131072, 64, 2048)
+            out[:] = 0
+            gpu.verify_batch_ptr(tuples.ctypes.data, n, out.ctypes.data)
+            gpu.verify_batch_ptr(tuples.ctypes.data, n, out.ctypes.data)
+            assert (out == valid).all(), mode
+            tm = gpu.last_timing()
+            times[mode] = (tm.prep_us, tm.verify_us)
+    finally:
+        gpu.set_grouping(True, 131072, 64, 2048)
+    print(f"\n[2^20] grouped: prep {times[True][0]:.0f} us stageB {times[True][1]:.0f} us | ungrouped: prep {times[False][0]:.0f} us "
+          f"stageB {times[False][1]:.0f} us")
