@@ -121,8 +121,11 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    dominant_us = sbv.profile_read_dominant()
     prep_us, verify_us, launches = sbv.profile_read()
     sbv.profile_enable(False)
+    groups, n_grouped, n_ungrouped = sbv.last_group_stats()
+    was_grouped = (n_grouped + n_ungrouped) == n
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -200,13 +203,17 @@ def main():
     if rank == 0:
         total = n * world * args.steps
         value = total / elapsed
-        kern_s = (verify_us / max(1, launches)) * 1e-6
-        achieved = ALGO_BYTES_PER_VERIFY * n / kern_s / 1e9
+        # dominant kernel: k_verify_keyed_list over the grouped tuples when the batch was grouped by key,
+        # else k_p256_verify over all n; its units = the tuples that launch processed
+        kern_s = (dominant_us / max(1, launches)) * 1e-6
+        dom_units = n_grouped if was_grouped else n
+        dom_name = "k_verify_keyed_list" if was_grouped else "k_p256_verify"
+        achieved = ALGO_BYTES_PER_VERIFY * dom_units / kern_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")      # per-launch HBM bytes from a rocprofv3 --pmc run
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_p256_verify_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(dom_name + "_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -220,11 +227,14 @@ def main():
                        "parallelism": "shard-by-tuple" + (f" x{world} + RCCL all-gather of bitmaps" if world > 1 else "")},
             "bitmap_correct": ok,
             "kernel_us": {"k_p256_prep": prep_us / max(1, launches), "stage_b_all_kernels": verify_us / max(1, launches),
-                          "launches": launches},
+                          dom_name: dominant_us / max(1, launches), "launches": launches},
+            "key_grouping": {"enabled": was_grouped, "groups": groups, "tuples_registered_key_kernel": n_grouped,
+                             "tuples_generic_kernel": n_ungrouped,
+                             "note": "in-step grouping by public key (consensus_amd/csrc/p256_group.h); all of it is inside the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "stage B (grouping + per-batch key tables + k_verify_keyed_list + k_verify_generic_list)",
-                         "note": "algorithmic bytes = 160.125 B/verify x tuples per launch / avg stage-B time "
+                         "kernel": dom_name, "units_per_launch": dom_units,
+                         "note": "algorithmic bytes = 160.125 B/verify x tuples that launch processed / its avg duration "
                                  "(HIP events on the launch stream); the path is integer-ALU bound, see DESIGN.md"},
         }
         if ungrouped is not None:

@@ -90,6 +90,8 @@ def load() -> ctypes.CDLL:
     lib.sbv_profile_enable.argtypes = [ctypes.c_int]
     lib.sbv_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_uint64)]
+    lib.sbv_profile_read_dominant.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    lib.sbv_p256_last_group_stats.argtypes = [ctypes.POINTER(ctypes.c_uint32)]
     lib.sbv_last_error.restype = ctypes.c_char_p
     _lib = lib
     return lib
@@ -258,6 +260,20 @@ def profile_read():
     p, v, k = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint64()
     _check(load().sbv_profile_read(ctypes.byref(p), ctypes.byref(v), ctypes.byref(k)))
     return p.value, v.value, k.value
+
+
+def profile_read_dominant() -> float:
+    """Summed duration (us) of the dominant stage-B kernel since profiling was enabled; call before profile_read()."""
+    d = ctypes.c_double()
+    _check(load().sbv_profile_read_dominant(ctypes.byref(d)))
+    return d.value
+
+
+def last_group_stats():
+    """(key groups, tuples through the registered-key kernel, tuples through the generic kernel) of the last grouped batch."""
+    out = (ctypes.c_uint32 * 3)()
+    _check(load().sbv_p256_last_group_stats(out))
+    return out[0], out[1], out[2]
 
 
 def bitmap_to_list(bm: bytes, n: int):

@@ -145,25 +145,37 @@ SBV_HD void keytab_bases_lane(const uint8_t* tuples, u32 gidx, const GroupState&
     }
 }
 
-// One (key, window): row[k-1] = k * base, k = 1..128, affine.  `tmp` = private scratch of
-// 128 * (24 + 8) dwords (Jacobian points, then prefix products).
-SBV_HD void keytab_window_lane(const apt& base, u32* tmp, apt* row) {
-    constexpr int W = SBV_GTAB_PER_WINDOW;
-    u32* pts = tmp;                   // W * 24 dwords
-    u32* pre = tmp + W * 24;          // W * 8 dwords
+// One quarter of one (key, window): row[k-1] = k * base for k = part*32 + 1 .. part*32 + 32, affine.
+// Four lanes per window instead of one: the lane first reaches (part*32) * base with <= 7 doublings
+// and <= 2 additions, then walks its 32 entries; each lane normalises its own 32 points (Montgomery's
+// trick + one inversion).  `tmp` = private scratch of 32 * (24 + 8) dwords.
+#define SBV_KEYTAB_PARTS 4
+#define SBV_KEYTAB_PART_ENTRIES (SBV_GTAB_PER_WINDOW / SBV_KEYTAB_PARTS)
+#define SBV_KEYTAB_TMP_DWORDS (SBV_KEYTAB_PART_ENTRIES * 32)
+SBV_HD void keytab_window_lane(const apt& base, int part, u32* tmp, apt* row) {
+    constexpr int E = SBV_KEYTAB_PART_ENTRIES;
+    u32* pts = tmp;                   // E * 24 dwords
+    u32* pre = tmp + E * 24;          // E * 8 dwords
     jpt t;
-    t.X = base.x; t.Y = base.y; t.Z = fe_one();
+    pt_set_inf(t);
+    const int m = part * E;           // start multiple: 0, 32, 64, 96
+    SBV_NOUNROLL
+    for (int bit = 6; bit >= 0; --bit) {
+        pt_dbl(t, t);                                         // infinity stays infinity
+        pt_add_mixed(t, base, false, ((m >> bit) & 1) == 0);  // exact: handles t = infinity
+    }
     fe acc = fe_one();
-    for (int k = 0; k < W; ++k) {
-        if (k == 1) pt_dbl(t, t);
-        else if (k > 1) pt_add_mixed(t, base, false, false);
+    SBV_NOUNROLL
+    for (int k = 0; k < E; ++k) {
+        pt_add_mixed(t, base, false, false);                  // (m + k + 1) * base; never hits P == +-Q for a valid key
         fe_store16(pts + k * 24, t.X); fe_store16(pts + k * 24 + 8, t.Y); fe_store16(pts + k * 24 + 16, t.Z);
         fe_store16(pre + k * 8, acc);
         fe_mul(acc, acc, t.Z);
     }
     fe inv;
     fe_inv(inv, acc);
-    for (int k = W - 1; k >= 0; --k) {
+    SBV_NOUNROLL
+    for (int k = E - 1; k >= 0; --k) {
         fe X, Y, Z, pk, zi, zi2, zi3;
         fe_load16(X, pts + k * 24); fe_load16(Y, pts + k * 24 + 8); fe_load16(Z, pts + k * 24 + 16);
         fe_load16(pk, pre + k * 8);
@@ -174,10 +186,9 @@ SBV_HD void keytab_window_lane(const apt& base, u32* tmp, apt* row) {
         apt a;
         fe_mul(a.x, X, zi2);
         fe_mul(a.y, Y, zi3);
-        fe_store16(reinterpret_cast<u32*>(row + k), a.x);
-        fe_store16(reinterpret_cast<u32*>(row + k) + 8, a.y);
+        fe_store16(reinterpret_cast<u32*>(row + m + k), a.x);
+        fe_store16(reinterpret_cast<u32*>(row + m + k) + 8, a.y);
     }
 }
-#define SBV_KEYTAB_TMP_DWORDS (SBV_GTAB_PER_WINDOW * 32)
 
 }  // namespace sbv

@@ -3,7 +3,7 @@
 //
 //   k_group_insert / k_group_assign / k_group_split : one lane per tuple; global atomics only
 //   k_keytab_bases   : one lane per grouped key  (256 doublings: the latency floor of a fresh key)
-//   k_keytab_window  : one lane per (key, window): 127 mixed additions + Montgomery-trick normalisation,
+//   k_keytab_window  : four lanes per (key, window): 32 mixed additions + Montgomery-trick normalisation each,
 //                      Jacobian intermediates parked in a private 16 KiB strip of HBM
 //   k_verify_keyed_list / k_verify_generic_list : stage B over grp_idx / ung_idx, one accept BYTE per tuple
 //   k_pack_bitmap    : accept bytes -> LSB-first bitmap
@@ -63,10 +63,10 @@ __global__ __launch_bounds__(64) void k_keytab_bases(const uint8_t* __restrict__
 
 __global__ __launch_bounds__(64) void k_keytab_window(GroupState g, const apt* __restrict__ bases, u32* __restrict__ tmp,
                                                       apt* __restrict__ ktab) {
-    const u32 lane = blockIdx.x * 64 + threadIdx.x;          // = key * 33 + window
-    const u32 k = lane / SBV_GTAB_WINDOWS;
-    if (k >= group_count(g)) return;
-    keytab_window_lane(bases[lane], tmp + (size_t)lane * SBV_KEYTAB_TMP_DWORDS, ktab + (size_t)lane * SBV_GTAB_PER_WINDOW);
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;          // = (key * 33 + window) * 4 + part
+    const u32 kw = lane / SBV_KEYTAB_PARTS, part = lane % SBV_KEYTAB_PARTS;
+    if (kw / SBV_GTAB_WINDOWS >= group_count(g)) return;
+    keytab_window_lane(bases[kw], (int)part, tmp + (size_t)lane * SBV_KEYTAB_TMP_DWORDS, ktab + (size_t)kw * SBV_GTAB_PER_WINDOW);
 }
 
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_verify_keyed_list(Scratch s, GroupState g, const apt* __restrict__ ktab,
@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256) void k_pack_bitmap(const uint8_t* __restrict__
 //   side  : insert assign split | bases ------- windows ------|
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b,
                                       u32* d_qtab, const apt* d_g16, uint8_t* d_bitmap, hipStream_t stream, hipStream_t side,
-                                      hipEvent_t ev_fork, hipEvent_t ev_split, hipEvent_t ev_tables) {
+                                      hipEvent_t ev_fork, hipEvent_t ev_split, hipEvent_t ev_tables, hipEvent_t prof_k0,
+                                      hipEvent_t prof_k1) {
     if (n == 0) return hipSuccess;
     GroupState g;
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
@@ -126,13 +127,15 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
     hipLaunchKernelGGL(k_group_split, dim3(gn), dim3(256), 0, side, n, g);
     if ((e = hipEventRecord(ev_split, side)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_keytab_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, side, d_tuples, g, b.bases, b.kvalid);
-    hipLaunchKernelGGL(k_keytab_window, dim3((b.max_groups * SBV_GTAB_WINDOWS + 63) / 64), dim3(64), 0, side, g, b.bases, b.tmp, b.ktab);
+    hipLaunchKernelGGL(k_keytab_window, dim3((b.max_groups * SBV_GTAB_WINDOWS * SBV_KEYTAB_PARTS + 63) / 64), dim3(64), 0, side, g, b.bases, b.tmp, b.ktab);
     if ((e = hipEventRecord(ev_tables, side)) != hipSuccess) return e;
     const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
     if ((e = hipStreamWaitEvent(stream, ev_split, 0)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_verify_generic_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, d_qtab, d_g16, b.acc);
     if ((e = hipStreamWaitEvent(stream, ev_tables, 0)) != hipSuccess) return e;
+    if (prof_k0 && (e = hipEventRecord(prof_k0, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_verify_keyed_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, d_g16, b.acc);
+    if (prof_k1 && (e = hipEventRecord(prof_k1, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
     return hipGetLastError();
 }

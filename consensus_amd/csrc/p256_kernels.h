@@ -34,7 +34,8 @@ struct GroupBuffers {
 // ev_fork must have been recorded on `stream` before stage A was enqueued
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b, u32* d_qtab,
                                       const apt* d_g16, uint8_t* d_bitmap, hipStream_t stream, hipStream_t side,
-                                      hipEvent_t ev_fork, hipEvent_t ev_split, hipEvent_t ev_tables);
+                                      hipEvent_t ev_fork, hipEvent_t ev_split, hipEvent_t ev_tables,
+                                      hipEvent_t prof_k0 = nullptr, hipEvent_t prof_k1 = nullptr);
 void host_build_gtable(apt* out);   // 33 x 128 affine multiples of G (8-bit comb; host signer, key tables)
 void host_build_g16(apt* out);      // 17 x 32768 affine multiples of G (16-bit comb used by the verify kernels)
 #define SBV_G16_ENTRIES ((size_t)SBV_G16_WINDOWS * SBV_G16_PER_WINDOW)

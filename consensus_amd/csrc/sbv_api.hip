@@ -48,7 +48,7 @@ struct Context {
     // in-step key grouping (p256_group.h)
     sbv::GroupBuffers grp;
     bool group_enabled = true;
-    size_t group_min_batch = 131072;
+    size_t group_min_batch = 262144;    // below this the ~3.5 ms table-building latency costs more than it saves
     u32 group_min_count = 64, group_max = 2048;
     // message front end staging (grown on demand)
     uint8_t* d_msgs = nullptr; size_t msgs_cap = 0;
@@ -63,6 +63,8 @@ struct Context {
     std::unordered_map<std::string, u32> key_index;
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;   // triples: before prep, after prep, after verify
+    std::vector<hipEvent_t> prof_dom;      // pairs around the dominant kernel of grouped batches (nullptr pair = ungrouped)
+    size_t prof_dom_used = 0;
     size_t prof_used = 0;
 };
 
@@ -168,9 +170,10 @@ int ensure_group_buffers(Context& c, size_t n) {
 
 // enqueue stage A + stage B for n <= cap tuples on `stream`
 int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream,
-            hipEvent_t after_prep) {
+            hipEvent_t after_prep, hipEvent_t dom0 = nullptr, hipEvent_t dom1 = nullptr, bool* was_grouped = nullptr) {
     const sbv::Scratch s = scratch_view(c);
     const bool grouped = c.group_enabled && n >= c.group_min_batch;
+    if (was_grouped) *was_grouped = grouped;
     if (grouped) {
         const int rc = ensure_group_buffers(c, n);
         if (rc != SBV_OK) return rc;
@@ -180,10 +183,12 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
     if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
     if (grouped) {
         HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, d_bitmap, stream, c.side,
-                                                             c.ev_fork, c.ev_split, c.ev_tables));
+                                                             c.ev_fork, c.ev_split, c.ev_tables, dom0, dom1));
         return SBV_OK;
     }
+    if (dom0) HIP_TRY(SBV_EDEVICE, hipEventRecord(dom0, stream));      // ungrouped: the dominant kernel is all of stage B
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify(s, n, c.d_qtab, c.d_gtab, d_bitmap, c.d_rerun, stream));
+    if (dom1) HIP_TRY(SBV_EDEVICE, hipEventRecord(dom1, stream));
     return SBV_OK;
 }
 
@@ -304,6 +309,9 @@ extern "C" int sbv_shutdown(void) {
     for (auto& ev : c.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
     for (auto& ev : c.prof_events) (void)hipEventDestroy(ev);
     c.prof_events.clear();
+    for (auto& ev : c.prof_dom) (void)hipEventDestroy(ev);
+    c.prof_dom.clear();
+    c.prof_dom_used = 0;
     c.prof_used = 0;
     if (c.busy) { (void)hipEventDestroy(c.busy); c.busy = nullptr; }
     if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
@@ -348,8 +356,18 @@ extern "C" int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d
             end = c.prof_events[c.prof_used + 2];
             c.prof_used += 3;
         }
-        rc = enqueue(c, src + off * SBV_TUPLE_BYTES, m, dst + off / 8, stream, mid);
+        hipEvent_t d0 = nullptr, d1 = nullptr;
+        if (c.profiling) {
+            if (c.prof_dom_used + 2 > c.prof_dom.size())
+                for (int k = 0; k < 2; ++k) { hipEvent_t ev; HIP_TRY(SBV_EDEVICE, hipEventCreate(&ev)); c.prof_dom.push_back(ev); }
+            d0 = c.prof_dom[c.prof_dom_used];
+            d1 = c.prof_dom[c.prof_dom_used + 1];
+        }
+        bool was_grouped = false;
+        rc = enqueue(c, src + off * SBV_TUPLE_BYTES, m, dst + off / 8, stream, mid, d0, d1, &was_grouped);
         if (rc != SBV_OK) return rc;
+        (void)was_grouped;
+        if (c.profiling) c.prof_dom_used += 2;
         if (end) HIP_TRY(SBV_EDEVICE, hipEventRecord(end, stream));
     }
     HIP_TRY(SBV_EDEVICE, hipEventRecord(c.busy, stream));
@@ -685,6 +703,37 @@ extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min
 extern "C" int sbv_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_ctx.profiling = on != 0;
+    return SBV_OK;
+}
+
+extern "C" int sbv_profile_read_dominant(double* dominant_us) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) return SBV_ENOTINIT;
+    double d = 0;
+    for (size_t i = 0; i + 2 <= c.prof_dom_used; i += 2) {
+        HIP_TRY(SBV_EDEVICE, hipEventSynchronize(c.prof_dom[i + 1]));
+        d += 1e3 * ms_between(c.prof_dom[i], c.prof_dom[i + 1]);
+    }
+    if (dominant_us) *dominant_us = d;
+    c.prof_dom_used = 0;
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_last_group_stats(uint32_t out[3]) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) return SBV_ENOTINIT;
+    if (!out) return SBV_EINVAL;
+    out[0] = out[1] = out[2] = 0;
+    if (!c.grp.counters) return SBV_OK;
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    uint32_t h[4];
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(h, c.grp.counters, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = h[0] < c.grp.max_groups ? h[0] : c.grp.max_groups;
+    out[1] = h[1];
+    out[2] = h[2];
     return SBV_OK;
 }
 

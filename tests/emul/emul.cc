@@ -110,8 +110,9 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     for (u32 k = 0; k < ngroups; ++k) keytab_bases_lane(tuples, k, g, bases.data(), kvalid.data());
     for (u32 k = 0; k < ngroups; ++k)
         for (int j = 0; j < SBV_GTAB_WINDOWS; ++j)
-            keytab_window_lane(bases[(size_t)k * SBV_GTAB_WINDOWS + j], tmpa,
-                               &ktab[((size_t)k * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW]);
+            for (int part = 0; part < SBV_KEYTAB_PARTS; ++part)
+                keytab_window_lane(bases[(size_t)k * SBV_GTAB_WINDOWS + j], part, tmpa,
+                                   &ktab[((size_t)k * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW]);
     memset(bitmap, 0, (n + 7) / 8);
     u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB_ENTRIES * 40 * 4);
     for (u32 L = 0; L < counters[1]; ++L) {
