@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tuples", type=int, default=1 << 20, help="tuples per GPU (default: the headline 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--primary-only", action="store_true", help="skip the secondary legs (grouping off, registered keys): quick A/B runs")
     args = ap.parse_args()
 
     import numpy as np
@@ -124,8 +125,8 @@ def main():
     dominant_us = sbv.profile_read_dominant()
     prep_us, verify_us, launches = sbv.profile_read()
     sbv.profile_enable(False)
-    groups, n_grouped, n_ungrouped = sbv.last_group_stats()
-    was_grouped = (n_grouped + n_ungrouped) == n
+    groups, n_grouped, n_ungrouped, n_key_rejected = sbv.last_group_stats()
+    was_grouped = (n_grouped + n_ungrouped + n_key_rejected) == n
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -138,7 +139,7 @@ def main():
     # Secondary measurement (NOT part of `value`): the same batch with in-step key grouping switched off,
     # i.e. what a batch of 2^20 all-distinct keys costs (every tuple through the generic doubling kernel).
     ungrouped = None
-    if world == 1:
+    if world == 1 and not args.primary_only:
         try:
             sbv.set_grouping(False)
             sbv.verify_batch_dev(d_tuples.data_ptr(), n, d_bitmap.data_ptr(), stream.cuda_stream)
@@ -163,7 +164,7 @@ def main():
     # Secondary measurement (NOT part of `value`): the same signatures through the registered-key entry
     # (key slots instead of inline public keys: what VerifyConsenterSig / decision replay use).
     keyed = None
-    if world == 1:
+    if world == 1 and not args.primary_only:
         try:
             t2 = tuples.reshape(n, 160)
             keys, counts = np.unique(t2[:, 96:160], axis=0, return_counts=True)
@@ -203,11 +204,11 @@ def main():
     if rank == 0:
         total = n * world * args.steps
         value = total / elapsed
-        # dominant kernel: k_verify_keyed_list over the grouped tuples when the batch was grouped by key,
+        # dominant kernel: k_verify_keyed_q (the key-comb additions) over the grouped tuples when the batch was grouped by key,
         # else k_p256_verify over all n; its units = the tuples that launch processed
         kern_s = (dominant_us / max(1, launches)) * 1e-6
         dom_units = n_grouped if was_grouped else n
-        dom_name = "k_verify_keyed_list" if was_grouped else "k_p256_verify"
+        dom_name = "k_verify_keyed_q" if was_grouped else "k_p256_verify"
         achieved = ALGO_BYTES_PER_VERIFY * dom_units / kern_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")      # per-launch HBM bytes from a rocprofv3 --pmc run
@@ -229,7 +230,7 @@ def main():
             "kernel_us": {"k_p256_prep": prep_us / max(1, launches), "stage_b_all_kernels": verify_us / max(1, launches),
                           dom_name: dominant_us / max(1, launches), "launches": launches},
             "key_grouping": {"enabled": was_grouped, "groups": groups, "tuples_registered_key_kernel": n_grouped,
-                             "tuples_generic_kernel": n_ungrouped,
+                             "tuples_generic_kernel": n_ungrouped, "tuples_rejected_for_their_key": n_key_rejected,
                              "note": "in-step grouping by public key (consensus_amd/csrc/p256_group.h); all of it is inside the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

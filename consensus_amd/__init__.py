@@ -270,10 +270,11 @@ def profile_read_dominant() -> float:
 
 
 def last_group_stats():
-    """(key groups, tuples through the registered-key kernel, tuples through the generic kernel) of the last grouped batch."""
-    out = (ctypes.c_uint32 * 3)()
+    """(key groups, tuples through the per-batch key tables, tuples through the generic kernel, ungrouped tuples
+    rejected for their public key alone) of the last grouped batch."""
+    out = (ctypes.c_uint32 * 4)()
     _check(load().sbv_p256_last_group_stats(out))
-    return out[0], out[1], out[2]
+    return out[0], out[1], out[2], out[3]
 
 
 def bitmap_to_list(bm: bytes, n: int):

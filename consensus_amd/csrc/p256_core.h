@@ -199,6 +199,53 @@ SBV_HD bool rx_matches(const jpt& R, const u256& r, u32* st = nullptr) {
     return match;
 }
 
+// ---- G phase (in-step grouping) ----------------------------------------------------------------------
+// u1*G does not depend on the public key, so the grouped step computes it for every tuple while the
+// per-batch key tables are still being built.  The Jacobian result is parked limb-major like Scratch:
+// word w (0..23 = X, Y, Z limbs) of tuple i at gacc[w * cap + i].
+SBV_HD void gacc_store(u32* gacc, size_t cap, size_t i, const jpt& R) {
+    SBV_UNROLL
+    for (int l = 0; l < 8; ++l) {
+        gacc[(size_t)l * cap + i] = R.X.v[l];
+        gacc[(size_t)(8 + l) * cap + i] = R.Y.v[l];
+        gacc[(size_t)(16 + l) * cap + i] = R.Z.v[l];
+    }
+}
+SBV_HD void gacc_load(jpt& R, const u32* gacc, size_t cap, size_t i) {
+    SBV_UNROLL
+    for (int l = 0; l < 8; ++l) {
+        R.X.v[l] = gacc[(size_t)l * cap + i];
+        R.Y.v[l] = gacc[(size_t)(8 + l) * cap + i];
+        R.Z.v[l] = gacc[(size_t)(16 + l) * cap + i];
+    }
+}
+SBV_HD void gphase_lane(const Scratch& s, size_t i, const apt* g16, u32* gacc) {
+    u256 u1, k1;
+    soa_load(u1, s.u1, s.cap, i);
+    const u32 top1 = add_const_limbs(k1, u1, 0x80008000u);
+    jpt R;
+    pt_set_inf(R);
+    apt cur;
+    int idx; bool neg, skip;
+    comb16_digit(k1, top1, 0, idx, neg, skip);
+    {
+        const u32* gp = reinterpret_cast<const u32*>(g16 + idx);
+        fe_load16(cur.x, gp); fe_load16(cur.y, gp + 8);
+    }
+    SBV_NOUNROLL
+    for (int j = 0; j < SBV_G16_WINDOWS; ++j) {
+        const int jn = j + 1 < SBV_G16_WINDOWS ? j + 1 : SBV_G16_WINDOWS - 1;
+        int idxn; bool negn, skipn;
+        comb16_digit(k1, top1, jn, idxn, negn, skipn);
+        const u32* gp = reinterpret_cast<const u32*>(g16 + (size_t)jn * SBV_G16_PER_WINDOW + idxn);
+        apt nxt;
+        fe_load16(nxt.x, gp); fe_load16(nxt.y, gp + 8);
+        pt_add_mixed(R, cur, neg, skip);
+        cur = nxt; neg = negn; skip = skipn;
+    }
+    gacc_store(gacc, s.cap, i, R);
+}
+
 // Returns accept (true) / reject for lane `i`.  `qtab` = this lane's private table space
 // (SBV_QTAB_ENTRIES * 40 dwords, 16-byte aligned), `g16` = 17 x 32768 affine multiples of G:
 // g16[j * 32768 + (k-1)] = k * 2^(16j) * G.
@@ -346,6 +393,44 @@ SBV_HD bool verify_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys, c
         cur = nxt; neg = negn; skip = skipn;
     }
     return ok && rx_matches<FAST>(R, r, st);
+}
+
+// Q phase of the grouped step: R (from gacc) += sum of key-comb windows [j0, j1) of u2*Q.  `last` -> the
+// verdict is returned; otherwise R goes back to gacc for the next chunk of windows and the return value
+// is meaningless.
+SBV_HD bool verify_lane_keyed_q(const Scratch& s, size_t i, u32 slot, u32 nkeys, const apt* ktab, const uint8_t* kvalid,
+                                u32* gacc, int j0, int j1, bool last) {
+    u256 u2, k2;
+    soa_load(u2, s.u2, s.cap, i);
+    bool ok = s.ok[i] != 0 && slot < nkeys;
+    if (slot >= nkeys) slot = 0;
+    ok = ok && kvalid[slot] != 0;
+    const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
+    const u32 top2 = add_const_limbs(k2, u2, 0x80808080u);
+    jpt R;
+    gacc_load(R, gacc, s.cap, i);
+    apt cur;
+    int idx; bool neg, skip;
+    comb_digit(k2, top2, j0, idx, neg, skip);
+    {
+        const u32* gp = reinterpret_cast<const u32*>(qtab + (size_t)j0 * SBV_GTAB_PER_WINDOW + idx);
+        fe_load16(cur.x, gp); fe_load16(cur.y, gp + 8);
+    }
+    SBV_NOUNROLL
+    for (int j = j0; j < j1; ++j) {
+        const int jn = j + 1 < j1 ? j + 1 : j1 - 1;
+        int idxn; bool negn, skipn;
+        comb_digit(k2, top2, jn, idxn, negn, skipn);
+        const u32* gp = reinterpret_cast<const u32*>(qtab + (size_t)jn * SBV_GTAB_PER_WINDOW + idxn);
+        apt nxt;
+        fe_load16(nxt.x, gp); fe_load16(nxt.y, gp + 8);
+        pt_add_mixed(R, cur, neg, skip);
+        cur = nxt; neg = negn; skip = skipn;
+    }
+    if (!last) { gacc_store(gacc, s.cap, i, R); return false; }
+    u256 r;
+    soa_load(r, s.r, s.cap, i);
+    return ok && rx_matches(R, r);
 }
 
 // ---- fixed-base table generation (host, once per sbv_init; also used by tests/emul) -----------------

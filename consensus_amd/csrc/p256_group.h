@@ -10,12 +10,19 @@
 //   group_insert   every tuple inserts its 64-byte key into an open-addressing hash table in HBM
 //                  (32-bit entries = representative tuple index + 1, claimed with atomicCAS; a hash
 //                  hit is only trusted after comparing all 64 key bytes, so collisions cost a probe,
-//                  never a wrong group) and counts itself on its representative
-//   group_assign   representatives with >= min_count users take a table slot (atomic counter)
-//   group_split    tuples are compacted into a "grouped" and an "ungrouped" index list
-//   keytab_bases   per grouped key: validate it (pointFromAffine rules), 2^(8j) * Q for j = 0..32
+//                  never a wrong group); a SAMPLE of the tuples (every 2^k-th) counts itself on its
+//                  representative — a million atomicAdds cost ~1 ms on MI355X, and the count only
+//                  decides whether a table is worth building, never a verdict
+//   group_assign   representatives with >= min_samples sampled users take a table slot (atomic counter)
+//   group_split    tuples are compacted into a "grouped" and an "ungrouped" index list; ungrouped tuples
+//                  with a key that pointFromAffine refuses are rejected on the spot
+//   keytab_bases   per grouped key: validate it (pointFromAffine rules), 2^(8j) * Q for j = 0..32, Jacobian
+//                  (no normalisation: the windows add them with the full Jacobian formula), in chunks
+//                  of windows so that table building and use can be pipelined
 //   keytab_window  per (key, window): the 128 affine multiples, Montgomery-trick normalised
-// then k_p256_verify_keyed runs over the grouped list and k_p256_verify over the ungrouped one.
+//   gphase         u1 * G for every tuple (p256_core.h), independent of all of the above
+// then the Q phase (verify_lane_keyed_q) runs over the grouped list and the generic stage B over the
+// ungrouped one.
 //
 // Shared host/device source (tests/emul runs the same functions sequentially).
 #pragma once
@@ -42,16 +49,53 @@ struct GroupState {
     u32* cnt;         // [n] users of a representative (zeroed before every batch)
     u32* slot_of;     // [n] table slot of a representative, or NONE
     u32* group_rep;   // [max_groups] representative tuple of slot g
-    u32* counters;    // [0] groups handed out, [1] grouped tuples, [2] ungrouped tuples (zeroed)
+    u32* counters;    // [0] groups handed out, [1] grouped tuples, [2] ungrouped tuples, [3] rejected for their key (zeroed)
     u32* grp_idx;     // [n] compacted grouped tuple indices
     u32* ung_idx;     // [n] compacted ungrouped tuple indices
     u32* slots;       // [n] table slot per tuple (grouped ones)
     u32 max_groups;
-    u32 min_count;
+    u32 min_count;    // requested threshold (users of a key in this batch)
+    u32 sample_mask;  // tuples with group_sampled(i, sample_mask) are counted
+    u32 min_samples;  // threshold on the sampled count
 };
+
+// Sampling rate for a threshold: exact counting for small thresholds (tests, tiny batches), otherwise
+// every 2^k-th tuple with at least 8 expected samples at the threshold.
+SBV_HD void group_set_threshold(GroupState& g, u32 min_count) {
+    u32 shift = 0;
+    while (shift < 6 && (min_count >> (shift + 1)) >= 8) ++shift;
+    g.min_count = min_count;
+    g.sample_mask = (1u << shift) - 1u;
+    const u32 ms = min_count >> shift;
+    g.min_samples = ms ? ms : 1u;
+}
+
+// Which tuples are counted: a multiplicative hash of the index, NOT its low bits — batches are often laid
+// out round-robin over the signers (tuple i signed by key i mod K), and `i & mask` would then count only
+// every 2^k-th KEY.  (An adversarial layout can still dodge the sample; that only costs its own batch the
+// table speed-up, never a verdict.)
+SBV_HD bool group_sampled(u32 i, u32 sample_mask) {
+    u32 h = i * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    return ((h >> 24) & sample_mask) == 0;
+}
 
 SBV_HD const u32* tuple_key_words(const uint8_t* tuples, size_t i) {
     return reinterpret_cast<const u32*>(tuples + i * 160 + 96);       // 16-byte aligned: 160 i + 96
+}
+
+// pointFromAffine's verdict on tuple idx's public key (coordinates < p, on the curve); x, y = the key in
+// Montgomery form (garbage when the verdict is false)
+SBV_HD bool tuple_key_load(const uint8_t* tuples, size_t idx, fe& x, fe& y) {
+    const u32* k = tuple_key_words(tuples, idx);
+    u256 qx, qy;
+    SBV_UNROLL
+    for (int l = 0; l < 8; ++l) { qx.v[l] = bswap32(k[7 - l]); qy.v[l] = bswap32(k[8 + 7 - l]); }
+    const fe p_ = fe_p();
+    fe_to_mont(x, qx);
+    fe_to_mont(y, qy);
+    return lt256(qx, p_) && lt256(qy, p_) && pt_on_curve(x, y);
 }
 
 SBV_HD void group_insert_lane(const uint8_t* tuples, size_t i, const GroupState& g) {
@@ -59,12 +103,16 @@ SBV_HD void group_insert_lane(const uint8_t* tuples, size_t i, const GroupState&
     u32 w[16];
     SBV_UNROLL
     for (int j = 0; j < 16; ++j) w[j] = k[j];
-    u32 h = w[0] * 0x9E3779B1u;
-    h = (h ^ (h >> 15)) + w[3] * 0x85EBCA77u;
-    h = (h ^ (h >> 13)) + w[7] * 0xC2B2AE3Du;
-    h = (h ^ (h >> 16)) + w[8] * 0x27D4EB2Fu;
-    h = (h ^ (h >> 15)) + w[12] * 0x165667B1u;
-    h = (h ^ (h >> 13)) + w[15] * 0x9E3779B1u;
+    // every key word goes into the hash: the batch's corrupted tuples are single-bit variants of the signers'
+    // keys, and a hash that skips words sends each variant down its original's probe chain (measured: ~30
+    // probes per wavefront, 1 ms per batch)
+    u32 h = 0x9E3779B1u;
+    SBV_UNROLL
+    for (int j = 0; j < 16; ++j) {
+        h = (h ^ w[j]) * 0x85EBCA77u;
+        h ^= h >> 15;
+    }
+    h *= 0xC2B2AE3Du;
     h ^= h >> 16;
     u32 slot = h & g.ht_mask;
     u32 mine = (u32)i;
@@ -80,100 +128,97 @@ SBV_HD void group_insert_lane(const uint8_t* tuples, size_t i, const GroupState&
         slot = (slot + 1) & g.ht_mask;
     }
     g.rep[i] = mine;
-    SBV_ATOMIC_ADD(&g.cnt[mine], 1u);
+    if (group_sampled((u32)i, g.sample_mask)) SBV_ATOMIC_ADD(&g.cnt[mine], 1u);
 }
 
 SBV_HD void group_assign_lane(size_t i, const GroupState& g) {
     u32 s = SBV_GROUP_NONE;
-    if (g.rep[i] == (u32)i && g.cnt[i] >= g.min_count) {
+    if (g.rep[i] == (u32)i && g.cnt[i] >= g.min_samples) {
         const u32 got = SBV_ATOMIC_ADD(&g.counters[0], 1u);
         if (got < g.max_groups) { s = got; g.group_rep[got] = (u32)i; }
     }
     g.slot_of[i] = s;
 }
 
-SBV_HD void group_split_lane(size_t i, const GroupState& g) {
+// Ungrouped tuples whose key pointFromAffine refuses are rejected here and never reach the generic
+// kernel (crypto/ecdsa returns false before any scalar multiplication, too): in a SIMT kernel an early
+// exit only pays when whole wavefronts take it, so the filter has to sit in front of the compaction.
+// counters[3] counts them (stats only).
+SBV_HD bool group_split_lane(const uint8_t* tuples, size_t i, const GroupState& g, uint8_t* acc) {
     const u32 s = g.slot_of[g.rep[i]];
     if (s == SBV_GROUP_NONE) {
+        fe x, y;
+        if (!tuple_key_load(tuples, i, x, y)) {
+            acc[i] = 0;
+            SBV_ATOMIC_ADD(&g.counters[3], 1u);
+            return false;
+        }
         g.ung_idx[SBV_ATOMIC_ADD(&g.counters[2], 1u)] = (u32)i;
     } else {
         g.slots[i] = s;
         g.grp_idx[SBV_ATOMIC_ADD(&g.counters[1], 1u)] = (u32)i;
     }
+    return true;
 }
 
 // ---- per-batch key tables ----------------------------------------------------------------------------
-// bases: [groups][33] affine 2^(8j) * Q (Montgomery form); valid[g] = pointFromAffine verdict.
-SBV_HD void keytab_bases_lane(const uint8_t* tuples, u32 gidx, const GroupState& g, apt* bases, uint8_t* valid) {
-    const u32* k = tuple_key_words(tuples, g.group_rep[gidx]);
-    u256 qx, qy;
-    SBV_UNROLL
-    for (int l = 0; l < 8; ++l) { qx.v[l] = bswap32(k[7 - l]); qy.v[l] = bswap32(k[8 + 7 - l]); }
-    const fe p_ = fe_p();
-    apt q;
-    fe_to_mont(q.x, qx);
-    fe_to_mont(q.y, qy);
-    const bool ok = lt256(qx, p_) && lt256(qy, p_) && pt_on_curve(q.x, q.y);
-    valid[gidx] = ok ? 1 : 0;
-    apt* out = bases + (size_t)gidx * SBV_GTAB_WINDOWS;
-    // Jacobian chain of doublings; the 33 bases are normalised together (one inversion).  The Jacobian
-    // bases are parked in the output rows' memory: X -> out[j].x, Y -> out[j].y, Z in a side array.
+// jbases: [groups][33] Jacobian 2^(8j) * Q with cached Z^2, Z^3 (qent layout, 40 dwords);
+// valid[g] = pointFromAffine verdict.  One call produces bases j_first..j_last; a call with j_first > 0
+// continues the doubling chain from base j_first - 1 left by the previous chunk.
+#define SBV_JBASE_DWORDS 40
+SBV_HD void keytab_bases_lane(const uint8_t* tuples, u32 gidx, const GroupState& g, u32* jbases, uint8_t* valid,
+                              int j_first, int j_last) {
+    u32* out = jbases + (size_t)gidx * (SBV_GTAB_WINDOWS * SBV_JBASE_DWORDS);
     jpt t;
-    t.X = q.x; t.Y = q.y; t.Z = fe_one();
-    fe zs[SBV_GTAB_WINDOWS];
-    fe pre[SBV_GTAB_WINDOWS];
-    fe acc = fe_one();
-    for (int j = 0; j < SBV_GTAB_WINDOWS; ++j) {
-        out[j].x = t.X; out[j].y = t.Y; zs[j] = t.Z;
-        pre[j] = acc;
-        fe_mul(acc, acc, t.Z);
-        if (j + 1 < SBV_GTAB_WINDOWS) {
+    if (j_first == 0) {
+        const bool ok = tuple_key_load(tuples, g.group_rep[gidx], t.X, t.Y);
+        t.Z = fe_one();
+        valid[gidx] = ok ? 1 : 0;        // an invalid key still gets a (garbage) table; it is never used
+    } else {
+        const u32* prev = out + (size_t)(j_first - 1) * SBV_JBASE_DWORDS;
+        fe_load16(t.X, prev); fe_load16(t.Y, prev + 8); fe_load16(t.Z, prev + 16);
+    }
+    SBV_NOUNROLL
+    for (int j = j_first; j <= j_last; ++j) {
+        if (j > 0) {
             SBV_NOUNROLL
             for (int d = 0; d < 8; ++d) pt_dbl(t, t);
         }
-    }
-    fe inv;
-    fe_inv(inv, acc);                  // garbage in, garbage out for an invalid key (never used: valid = 0)
-    for (int j = SBV_GTAB_WINDOWS - 1; j >= 0; --j) {
-        fe zi, zi2, zi3;
-        fe_mul(zi, inv, pre[j]);
-        fe_mul(inv, inv, zs[j]);
-        fe_sqr(zi2, zi);
-        fe_mul(zi3, zi2, zi);
-        fe_mul(out[j].x, out[j].x, zi2);
-        fe_mul(out[j].y, out[j].y, zi3);
+        qent_store(out + (size_t)j * SBV_JBASE_DWORDS, t);
     }
 }
 
-// One quarter of one (key, window): row[k-1] = k * base for k = part*32 + 1 .. part*32 + 32, affine.
-// Four lanes per window instead of one: the lane first reaches (part*32) * base with <= 7 doublings
-// and <= 2 additions, then walks its 32 entries; each lane normalises its own 32 points (Montgomery's
-// trick + one inversion).  `tmp` = private scratch of 32 * (24 + 8) dwords.
-#define SBV_KEYTAB_PARTS 4
-#define SBV_KEYTAB_PART_ENTRIES (SBV_GTAB_PER_WINDOW / SBV_KEYTAB_PARTS)
-#define SBV_KEYTAB_TMP_DWORDS (SBV_KEYTAB_PART_ENTRIES * 32)
-SBV_HD void keytab_window_lane(const apt& base, int part, u32* tmp, apt* row) {
-    constexpr int E = SBV_KEYTAB_PART_ENTRIES;
+// One part of one (key, window): row[k-1] = k * base for k = part*E + 1 .. part*E + E, affine.
+// Several lanes per window instead of one: the lane first reaches (part*E) * base with 7 doubling /
+// conditional-addition steps, then walks its E entries; each lane normalises its own E points
+// (Montgomery's trick + one inversion).  `tmp` = private scratch of E * (24 + 8) dwords.
+// Every addition is exact (the second entry of part 0 is base + base: the doubling branch).
+#define SBV_KEYTAB_PARTS_DEFAULT 4
+#define SBV_KEYTAB_TMP_DWORDS_PER_WINDOW (SBV_GTAB_PER_WINDOW * 32)
+SBV_HD void keytab_window_lane(const u32* jbase, int part, int parts, u32* tmp, apt* row) {
+    const int E = SBV_GTAB_PER_WINDOW / parts;     // parts is a power of two <= 16
     u32* pts = tmp;                   // E * 24 dwords
     u32* pre = tmp + E * 24;          // E * 8 dwords
+    qent base;
+    qent_load(base, jbase);
     jpt t;
     pt_set_inf(t);
-    const int m = part * E;           // start multiple: 0, 32, 64, 96
+    const int m = part * E;           // start multiple
     SBV_NOUNROLL
     for (int bit = 6; bit >= 0; --bit) {
-        pt_dbl(t, t);                                         // infinity stays infinity
-        pt_add_mixed(t, base, false, ((m >> bit) & 1) == 0);  // exact: handles t = infinity
+        pt_dbl(t, t);                                        // infinity stays infinity
+        pt_add_qent(t, base, false, ((m >> bit) & 1) == 0);  // exact: handles t = infinity
     }
     fe acc = fe_one();
     SBV_NOUNROLL
     for (int k = 0; k < E; ++k) {
-        pt_add_mixed(t, base, false, false);                  // (m + k + 1) * base; never hits P == +-Q for a valid key
+        pt_add_qent(t, base, false, false);                  // (m + k + 1) * base
         fe_store16(pts + k * 24, t.X); fe_store16(pts + k * 24 + 8, t.Y); fe_store16(pts + k * 24 + 16, t.Z);
         fe_store16(pre + k * 8, acc);
         fe_mul(acc, acc, t.Z);
     }
     fe inv;
-    fe_inv(inv, acc);
+    fe_inv(inv, acc);                 // garbage in, garbage out for an invalid key (never used: valid = 0)
     SBV_NOUNROLL
     for (int k = E - 1; k >= 0; --k) {
         fe X, Y, Z, pk, zi, zi2, zi3;

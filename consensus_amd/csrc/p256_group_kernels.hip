@@ -2,10 +2,11 @@
 // (p256_group.h) and for running stage B over the two compacted index lists.
 //
 //   k_group_insert / k_group_assign / k_group_split : one lane per tuple; global atomics only
-//   k_keytab_bases   : one lane per grouped key  (256 doublings: the latency floor of a fresh key)
-//   k_keytab_window  : four lanes per (key, window): 32 mixed additions + Montgomery-trick normalisation each,
-//                      Jacobian intermediates parked in a private 16 KiB strip of HBM
-//   k_verify_keyed_list / k_verify_generic_list : stage B over grp_idx / ung_idx, one accept BYTE per tuple
+//   k_keytab_bases   : one lane per grouped key  (256 doublings: the latency floor of a fresh key), in chunks of windows
+//   k_keytab_window  : a few lanes per (key, window): additions + Montgomery-trick normalisation each,
+//                      Jacobian intermediates parked in a private strip of HBM
+//   k_gphase_generic : u1*G for every tuple (independent of the keys) + the generic stage B over ung_idx
+//   k_verify_keyed_q : the key-comb additions over grp_idx; one accept BYTE per tuple from either kernel
 //   k_pack_bitmap    : accept bytes -> LSB-first bitmap
 // Launch sizes that depend on device-side counters use the upper bound; surplus lanes exit at once.
 #include <hip/hip_runtime.h>
@@ -23,25 +24,39 @@ __global__ __launch_bounds__(256) void k_group_assign(size_t n, GroupState g) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) group_assign_lane(i, g);
 }
-// Same result as group_split_lane, but with ONE atomic per wavefront and list instead of one per lane:
-// a million atomicAdds on two words serialise at ~11 ns each (11 ms per batch, measured); a ballot +
-// prefix popcount needs 2 x n/64 of them.
-__global__ __launch_bounds__(256) void k_group_split(size_t n, GroupState g) {
+// Same result as group_split_lane, but with ONE atomic per workgroup and list instead of one per lane:
+// atomicAdds on one word serialise at ~11 ns each on MI355X (a million of them: 11 ms per batch, measured);
+// ballots + prefix popcounts + a 4-entry LDS sum need 2 x n/256 of them.
+__global__ __launch_bounds__(256) void k_group_split(const uint8_t* __restrict__ tuples, size_t n, GroupState g, uint8_t* __restrict__ acc) {
+    __shared__ u32 sh_cnt[3][4];
+    __shared__ u32 sh_base[2];
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool active = i < n;
     u32 s = SBV_GROUP_NONE;
     if (active) s = g.slot_of[g.rep[i]];
-    const bool ung = active && s == SBV_GROUP_NONE;
+    bool ung = active && s == SBV_GROUP_NONE;
     const bool grp = active && s != SBV_GROUP_NONE;
-    const unsigned long long mu = __ballot(ung), mg = __ballot(grp);
-    const int lane = threadIdx.x & 63;
-    u32 base_u = 0, base_g = 0;
-    if (lane == 0) {
-        if (mu) base_u = atomicAdd(&g.counters[2], (u32)__popcll(mu));
-        if (mg) base_g = atomicAdd(&g.counters[1], (u32)__popcll(mg));
+    bool key_rejected = false;
+    if (ung) {                      // key filter of group_split_lane
+        fe x, y;
+        if (!tuple_key_load(tuples, i, x, y)) { acc[i] = 0; ung = false; key_rejected = true; }
     }
-    base_u = __shfl(base_u, 0, 64);
-    base_g = __shfl(base_g, 0, 64);
+    const unsigned long long mr = __ballot(key_rejected);
+    const unsigned long long mu = __ballot(ung), mg = __ballot(grp);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh_cnt[0][wave] = (u32)__popcll(mu); sh_cnt[1][wave] = (u32)__popcll(mg); sh_cnt[2][wave] = (u32)__popcll(mr); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 tu = sh_cnt[0][0] + sh_cnt[0][1] + sh_cnt[0][2] + sh_cnt[0][3];
+        const u32 tg = sh_cnt[1][0] + sh_cnt[1][1] + sh_cnt[1][2] + sh_cnt[1][3];
+        sh_base[0] = tu ? atomicAdd(&g.counters[2], tu) : 0u;
+        sh_base[1] = tg ? atomicAdd(&g.counters[1], tg) : 0u;
+        const u32 tr = sh_cnt[2][0] + sh_cnt[2][1] + sh_cnt[2][2] + sh_cnt[2][3];
+        if (tr) atomicAdd(&g.counters[3], tr);
+    }
+    __syncthreads();
+    u32 base_u = sh_base[0], base_g = sh_base[1];
+    for (int w = 0; w < wave; ++w) { base_u += sh_cnt[0][w]; base_g += sh_cnt[1][w]; }
     const unsigned long long below = (1ull << lane) - 1ull;
     if (ung) g.ung_idx[base_u + (u32)__popcll(mu & below)] = (u32)i;
     if (grp) {
@@ -55,35 +70,63 @@ __device__ __forceinline__ u32 group_count(const GroupState& g) {
     return c < g.max_groups ? c : g.max_groups;
 }
 
-__global__ __launch_bounds__(64) void k_keytab_bases(const uint8_t* __restrict__ tuples, GroupState g, apt* __restrict__ bases,
-                                                     uint8_t* __restrict__ valid) {
+__global__ __launch_bounds__(64) void k_keytab_bases(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jbases,
+                                                     uint8_t* __restrict__ valid, int j_first, int j_last) {
     const u32 k = blockIdx.x * 64 + threadIdx.x;
-    if (k < group_count(g)) keytab_bases_lane(tuples, k, g, bases, valid);
+    if (k < group_count(g)) keytab_bases_lane(tuples, k, g, jbases, valid, j_first, j_last);
 }
 
-__global__ __launch_bounds__(64) void k_keytab_window(GroupState g, const apt* __restrict__ bases, u32* __restrict__ tmp,
-                                                      apt* __restrict__ ktab) {
-    const u32 lane = blockIdx.x * 64 + threadIdx.x;          // = (key * 33 + window) * 4 + part
-    const u32 kw = lane / SBV_KEYTAB_PARTS, part = lane % SBV_KEYTAB_PARTS;
-    if (kw / SBV_GTAB_WINDOWS >= group_count(g)) return;
-    keytab_window_lane(bases[kw], (int)part, tmp + (size_t)lane * SBV_KEYTAB_TMP_DWORDS, ktab + (size_t)kw * SBV_GTAB_PER_WINDOW);
+// lanes = groups x j_count x parts
+__global__ __launch_bounds__(64) void k_keytab_window(GroupState g, const u32* __restrict__ jbases, u32* __restrict__ tmp,
+                                                      apt* __restrict__ ktab, int j_first, int j_count, int parts) {
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 part = lane % (u32)parts;
+    const u32 kw = lane / (u32)parts;
+    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
+    if (key >= group_count(g)) return;
+    const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
+    keytab_window_lane(jbases + w * SBV_JBASE_DWORDS, (int)part, parts,
+                       tmp + w * SBV_KEYTAB_TMP_DWORDS_PER_WINDOW + (size_t)part * (SBV_GTAB_PER_WINDOW / parts) * 32,
+                       ktab + w * SBV_GTAB_PER_WINDOW);
 }
 
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_verify_keyed_list(Scratch s, GroupState g, const apt* __restrict__ ktab,
-                                                                       const uint8_t* __restrict__ kvalid,
-                                                                       const apt* __restrict__ g16, uint8_t* __restrict__ acc) {
-    const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
-    if (L >= g.counters[1]) return;
-    const u32 t = g.grp_idx[L];
-    acc[t] = verify_lane_keyed<false>(s, t, g.slots[t], group_count(g), ktab, kvalid, g16) ? 1 : 0;
+// One launch, two jobs.  Blocks [0, generic_blocks): the generic stage B (doubling kernel) over the
+// ungrouped list — keys that repeat too rarely for a table; a 2.3 ms serial chain per lane on ~5 % of the
+// tuples, so it has to start as early as possible and run BESIDE the throughput work, at the same
+// 3 waves/SIMD register budget (on its own stream it ran at 234 VGPRs and squeezed the kernel it
+// overlapped down to one wave per SIMD).  Remaining blocks: u1 * G for every tuple of the batch.
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_gphase_generic(Scratch s, size_t n, GroupState g, u32* __restrict__ qtab,
+                                                                       const apt* __restrict__ g16, u32* __restrict__ gacc,
+                                                                       uint8_t* __restrict__ acc, unsigned generic_blocks) {
+    if (blockIdx.x < generic_blocks) {
+        const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+        if (L >= g.counters[2]) return;
+        const u32 t = g.ung_idx[L];
+        acc[t] = verify_lane<false>(s, t, qtab + (size_t)L * (SBV_QTAB_ENTRIES * 40), g16) ? 1 : 0;
+        return;
+    }
+    const size_t i = (size_t)(blockIdx.x - generic_blocks) * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (i < n) gphase_lane(s, i, g16, gacc);
 }
 
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_verify_generic_list(Scratch s, GroupState g, u32* __restrict__ qtab,
-                                                                         const apt* __restrict__ g16, uint8_t* __restrict__ acc) {
+// The generic stage B alone (own stream, when the process has hardware queues to spare)
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_verify_generic_list(Scratch s, GroupState g, u32* __restrict__ qtab,
+                                                                            const apt* __restrict__ g16, uint8_t* __restrict__ acc) {
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= g.counters[2]) return;
     const u32 t = g.ung_idx[L];
     acc[t] = verify_lane<false>(s, t, qtab + (size_t)L * (SBV_QTAB_ENTRIES * 40), g16) ? 1 : 0;
+}
+
+// Q phase over the grouped list: windows [j0, j1) of the per-batch key combs
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_verify_keyed_q(Scratch s, GroupState g, const apt* __restrict__ ktab,
+                                                                    const uint8_t* __restrict__ kvalid, u32* __restrict__ gacc,
+                                                                    uint8_t* __restrict__ acc, int j0, int j1, int last) {
+    const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (L >= g.counters[1]) return;
+    const u32 t = g.grp_idx[L];
+    const bool v = verify_lane_keyed_q(s, t, g.slots[t], group_count(g), ktab, kvalid, gacc, j0, j1, last != 0);
+    if (last) acc[t] = v ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_pack_bitmap(const uint8_t* __restrict__ acc, size_t n, uint8_t* __restrict__ bitmap) {
@@ -99,44 +142,78 @@ __global__ __launch_bounds__(256) void k_pack_bitmap(const uint8_t* __restrict__
 }
 
 // Enqueue stage B with in-step grouping.  Stage A (k_p256_prep) is already enqueued on `stream`.
-// Two streams: the grouping + table-building chain (low occupancy, latency-bound: 33 lanes per key)
-// runs on `side` concurrently with stage A and with the generic kernel over the ungrouped list; only
-// the registered-key kernel has to wait for the tables.
+// Three streams (a process gets 4 hardware queues by default; with a fourth stream for the generic kernel
+// the Q phase was serialised behind it, measured).  Only the G phase and the Q phase are throughput work;
+// everything else is a low-occupancy, latency-bound chain (one lane per key / a few lanes per window /
+// the rare ungrouped tuples), so the chains run beside each other and beside the throughput kernels:
 //
-//   stream: [prep] ........ wait(split) generic_list ....... wait(tables) keyed_list  pack
-//   side  : insert assign split | bases ------- windows ------|
+//   stream: [prep] wait(split) { generic stage B over the ungrouped list + G phase } wait(tables c) Q-phase chunk c ... pack
+//   side_a: insert assign | bases chunk 0 | bases chunk 1 | ...
+//   side_b:        wait(assign) split | wait(bases c) windows chunk c ...
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b,
-                                      u32* d_qtab, const apt* d_g16, uint8_t* d_bitmap, hipStream_t stream, hipStream_t side,
-                                      hipEvent_t ev_fork, hipEvent_t ev_split, hipEvent_t ev_tables, hipEvent_t prof_k0,
-                                      hipEvent_t prof_k1) {
+                                      u32* d_qtab, const apt* d_g16, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y,
+                                      hipEvent_t prof_k0, hipEvent_t prof_k1) {
     if (n == 0) return hipSuccess;
     GroupState g;
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
     g.counters = b.counters; g.grp_idx = b.grp_idx; g.ung_idx = b.ung_idx; g.slots = b.slots;
-    g.max_groups = b.max_groups; g.min_count = b.min_count;
+    g.max_groups = b.max_groups;
+    group_set_threshold(g, b.min_count);
+    const int chunks = y.chunks < 1 ? 1 : (y.chunks > SBV_GROUP_MAX_CHUNKS ? SBV_GROUP_MAX_CHUNKS : y.chunks);
+    int parts = SBV_KEYTAB_PARTS_DEFAULT;
+    if (y.parts == 2 || y.parts == 4 || y.parts == 8 || y.parts == 16) parts = y.parts;
     hipError_t e;
-    // `side` may not touch the group buffers before everything already enqueued on `stream` (the previous
-    // batch's readers of those buffers) has run; ev_fork was recorded by the caller BEFORE stage A.
-    if ((e = hipStreamWaitEvent(side, ev_fork, 0)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(b.ht, 0, ((size_t)b.ht_mask + 1) * sizeof(u32), side)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(b.cnt, 0, n * sizeof(u32), side)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(b.counters, 0, 4 * sizeof(u32), side)) != hipSuccess) return e;
+#define SBV_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
+    // The side streams may not touch the group buffers before everything already enqueued on `stream` (the
+    // previous batch's readers of those buffers) has run; ev_fork was recorded by the caller BEFORE stage A.
+    SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_fork, 0));
+    SBV_TRY(hipMemsetAsync(b.ht, 0, ((size_t)b.ht_mask + 1) * sizeof(u32), y.side_a));
+    SBV_TRY(hipMemsetAsync(b.cnt, 0, n * sizeof(u32), y.side_a));
+    SBV_TRY(hipMemsetAsync(b.counters, 0, 4 * sizeof(u32), y.side_a));
     const unsigned gn = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_group_insert, dim3(gn), dim3(256), 0, side, d_tuples, n, g);
-    hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, side, n, g);
-    hipLaunchKernelGGL(k_group_split, dim3(gn), dim3(256), 0, side, n, g);
-    if ((e = hipEventRecord(ev_split, side)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_keytab_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, side, d_tuples, g, b.bases, b.kvalid);
-    hipLaunchKernelGGL(k_keytab_window, dim3((b.max_groups * SBV_GTAB_WINDOWS * SBV_KEYTAB_PARTS + 63) / 64), dim3(64), 0, side, g, b.bases, b.tmp, b.ktab);
-    if ((e = hipEventRecord(ev_tables, side)) != hipSuccess) return e;
     const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
-    if ((e = hipStreamWaitEvent(stream, ev_split, 0)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_verify_generic_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, d_qtab, d_g16, b.acc);
-    if ((e = hipStreamWaitEvent(stream, ev_tables, 0)) != hipSuccess) return e;
-    if (prof_k0 && (e = hipEventRecord(prof_k0, stream)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_verify_keyed_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, d_g16, b.acc);
-    if (prof_k1 && (e = hipEventRecord(prof_k1, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
+    hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, n, g);
+    SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
+    // side_b: split
+    SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
+    hipLaunchKernelGGL(k_group_split, dim3(gn), dim3(256), 0, y.side_b, d_tuples, n, g, b.acc);
+    SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
+    // stream, right behind stage A: generic stage B over the ungrouped list + G phase for every tuple
+    if (y.side_c) {
+        SBV_TRY(hipEventRecord(y.ev_prep, stream));
+        SBV_TRY(hipStreamWaitEvent(y.side_c, y.ev_prep, 0));
+        SBV_TRY(hipStreamWaitEvent(y.side_c, y.ev_split, 0));
+        hipLaunchKernelGGL(k_verify_generic_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, y.side_c, s, g, d_qtab, d_g16, b.acc);
+        SBV_TRY(hipEventRecord(y.ev_generic, y.side_c));
+        hipLaunchKernelGGL(k_gphase_generic, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, b.gacc, b.acc, 0u);
+        SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
+    } else {
+        SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
+        hipLaunchKernelGGL(k_gphase_generic, dim3(2 * gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, b.gacc, b.acc, gv);
+    }
+    // chunks of windows: bases on side_a, tables on side_b, Q phase on stream
+    for (int c = 0; c < chunks; ++c) {
+        const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [j_first, j_end)
+        const int j_count = j_end - j_first;
+        hipLaunchKernelGGL(k_keytab_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jbases, b.kvalid,
+                           j_first, j_end - 1);
+        SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
+        SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[c], 0));
+        const size_t wl = (size_t)b.max_groups * j_count * parts;
+        hipLaunchKernelGGL(k_keytab_window, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.jbases, b.tmp, b.ktab,
+                           j_first, j_count, parts);
+        SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
+        SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
+        const bool last = c + 1 == chunks;
+        if (last && prof_k0) SBV_TRY(hipEventRecord(prof_k0, stream));
+        hipLaunchKernelGGL(k_verify_keyed_q, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.gacc, b.acc,
+                           j_first, j_end, last ? 1 : 0);
+        if (last && prof_k1) SBV_TRY(hipEventRecord(prof_k1, stream));
+    }
+    if (y.side_c) SBV_TRY(hipStreamWaitEvent(stream, y.ev_generic, 0));
     hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
+#undef SBV_TRY
     return hipGetLastError();
 }
 

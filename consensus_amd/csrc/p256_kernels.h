@@ -27,14 +27,29 @@ struct GroupBuffers {
     u32* ht = nullptr; u32 ht_mask = 0;
     u32 *rep = nullptr, *cnt = nullptr, *slot_of = nullptr, *group_rep = nullptr, *counters = nullptr, *grp_idx = nullptr,
         *ung_idx = nullptr, *slots = nullptr;
-    apt* bases = nullptr; apt* ktab = nullptr; uint8_t* kvalid = nullptr; u32* tmp = nullptr; uint8_t* acc = nullptr;
+    u32* jbases = nullptr;      // [max_groups][33] Jacobian window bases (40 dwords each)
+    apt* ktab = nullptr; uint8_t* kvalid = nullptr; u32* tmp = nullptr; uint8_t* acc = nullptr;
+    u32* gacc = nullptr;        // [24][scratch cap] u1*G per tuple, then the running sum of the Q phase
     u32 max_groups = 0, min_count = 0;
     size_t cap = 0;
+    size_t gacc_cap = 0;        // the scratch capacity gacc was sized for
 };
-// ev_fork must have been recorded on `stream` before stage A was enqueued
+// streams and events of the grouped step; owned by the context.  `chunks` (1..SBV_GROUP_MAX_CHUNKS) = how
+// many pieces the 33 key-comb windows are built and consumed in.
+#define SBV_GROUP_MAX_CHUNKS 4
+struct GroupSync {
+    hipStream_t side_a = nullptr;   // insert, assign, window bases
+    hipStream_t side_b = nullptr;   // split, window tables
+    hipStream_t side_c = nullptr;   // optional: generic stage B over the ungrouped list (nullptr: fused into the G-phase launch)
+    hipEvent_t ev_fork = nullptr, ev_assign = nullptr, ev_split = nullptr, ev_prep = nullptr, ev_generic = nullptr;
+    hipEvent_t ev_bases[SBV_GROUP_MAX_CHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
+    int chunks = 1;
+    int parts = 4;                  // lanes per (key, window) in k_keytab_window: 2, 4, 8 or 16
+};
+// ev_fork must have been recorded on `stream` before stage A was enqueued.  prof_k0/k1 (optional) bracket
+// the LAST Q-phase launch (the only one when chunks == 1).
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b, u32* d_qtab,
-                                      const apt* d_g16, uint8_t* d_bitmap, hipStream_t stream, hipStream_t side,
-                                      hipEvent_t ev_fork, hipEvent_t ev_split, hipEvent_t ev_tables,
+                                      const apt* d_g16, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y,
                                       hipEvent_t prof_k0 = nullptr, hipEvent_t prof_k1 = nullptr);
 void host_build_gtable(apt* out);   // 33 x 128 affine multiples of G (8-bit comb; host signer, key tables)
 void host_build_g16(apt* out);      // 17 x 32768 affine multiples of G (16-bit comb used by the verify kernels)

@@ -172,9 +172,10 @@ hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const u
 
 int prep_chunk_T(size_t n) {
     // small batches: one inversion per tuple (latency); large batches: amortise over 32
+    static const int cap = [] { const char* e = getenv("SBV_PREP_T"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? v : 32; }();
     size_t t = (n + 16383) / 16384;
     if (t < 1) t = 1;
-    if (t > 32) t = 32;
+    if (t > (size_t)cap) t = (size_t)cap;
     return (int)t;
 }
 

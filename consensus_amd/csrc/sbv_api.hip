@@ -39,8 +39,7 @@ struct Context {
     uint8_t* d_rerun = nullptr;         // per-wavefront flags between the fast and the exact stage-B pass
     uint8_t* h_bitmap = nullptr;        // pinned
     hipStream_t stream = nullptr;
-    hipStream_t side = nullptr;         // grouping / table-building chain of the grouped stage B
-    hipEvent_t ev_fork = nullptr, ev_split = nullptr, ev_tables = nullptr;
+    sbv::GroupSync gsync;               // side streams + events of the grouped stage B
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t busy = nullptr;          // completion of the last launch that used the scratch
     bool busy_valid = false;
@@ -131,16 +130,23 @@ sbv::Scratch scratch_view(const Context& c) {
     return s;
 }
 
+std::vector<hipEvent_t*> group_events(Context& c) {
+    sbv::GroupSync& y = c.gsync;
+    std::vector<hipEvent_t*> v = {&y.ev_fork, &y.ev_assign, &y.ev_split, &y.ev_prep, &y.ev_generic};
+    for (int i = 0; i < SBV_GROUP_MAX_CHUNKS; ++i) { v.push_back(&y.ev_bases[i]); v.push_back(&y.ev_tables[i]); }
+    return v;
+}
+
 void free_group_buffers(Context& c) {
     sbv::GroupBuffers& b = c.grp;
-    void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.bases, b.ktab, b.kvalid, b.tmp, b.acc};
+    void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.jbases, b.ktab, b.kvalid, b.tmp, b.acc, b.gacc};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     b = sbv::GroupBuffers();
 }
 
 int ensure_group_buffers(Context& c, size_t n) {
     sbv::GroupBuffers& b = c.grp;
-    if (b.cap >= n && b.max_groups == c.group_max) { b.min_count = c.group_min_count; return SBV_OK; }
+    if (b.cap >= n && b.max_groups == c.group_max && b.gacc_cap == c.cap) { b.min_count = c.group_min_count; return SBV_OK; }
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
     free_group_buffers(c);
     const size_t cap = (n + 1023) & ~(size_t)1023;
@@ -156,7 +162,8 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.grp_idx, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ung_idx, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.slots, cap * sizeof(u32)));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.bases, G * SBV_GTAB_WINDOWS * sizeof(sbv::apt)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jbases, G * SBV_GTAB_WINDOWS * (size_t)40 * sizeof(u32)));   // 40 dwords = one Jacobian base (p256_group.h)
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 24 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ktab, G * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, G));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tmp, G * SBV_GTAB_WINDOWS * (size_t)(SBV_GTAB_PER_WINDOW * 32) * sizeof(u32)));
@@ -165,6 +172,7 @@ int ensure_group_buffers(Context& c, size_t n) {
     b.max_groups = (u32)G;
     b.min_count = c.group_min_count;
     b.cap = cap;
+    b.gacc_cap = c.cap;
     return SBV_OK;
 }
 
@@ -177,13 +185,12 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
     if (grouped) {
         const int rc = ensure_group_buffers(c, n);
         if (rc != SBV_OK) return rc;
-        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev_fork, stream));
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
     }
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_tuples, n, s, stream));
     if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
     if (grouped) {
-        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, d_bitmap, stream, c.side,
-                                                             c.ev_fork, c.ev_split, c.ev_tables, dom0, dom1));
+        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, d_bitmap, stream, c.gsync, dom0, dom1));
         return SBV_OK;
     }
     if (dom0) HIP_TRY(SBV_EDEVICE, hipEventRecord(dom0, stream));      // ungrouped: the dominant kernel is all of stage B
@@ -265,10 +272,18 @@ extern "C" int sbv_init(int device) {
         return SBV_ENODEV;
     }
     HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
-    HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
-    HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(&c.ev_split, hipEventDisableTiming));
-    HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(&c.ev_tables, hipEventDisableTiming));
+    for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b})
+        HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    for (hipEvent_t* ev : group_events(c)) HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    c.gsync.chunks = 3;
+    if (const char* e = getenv("SBV_GROUP_CHUNKS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= SBV_GROUP_MAX_CHUNKS) c.gsync.chunks = v;
+    }
+    if (const char* e = getenv("SBV_GROUP_PARTS")) c.gsync.parts = atoi(e);
+    if (const char* e = getenv("SBV_GENERIC_STREAM")) {
+        if (e[0] == '1') HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.gsync.side_c, hipStreamNonBlocking));
+    }
     for (auto& ev : c.ev) HIP_TRY(SBV_ENODEV, hipEventCreate(&ev));
     HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(&c.busy, hipEventDisableTiming));
     // fixed-base table: computed once on the host with the same field code, then resident in HBM
@@ -315,8 +330,8 @@ extern "C" int sbv_shutdown(void) {
     c.prof_used = 0;
     if (c.busy) { (void)hipEventDestroy(c.busy); c.busy = nullptr; }
     if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
-    if (c.side) { (void)hipStreamDestroy(c.side); c.side = nullptr; }
-    for (hipEvent_t* ev : {&c.ev_fork, &c.ev_split, &c.ev_tables}) if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
+    for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b, &c.gsync.side_c}) if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
+    for (hipEvent_t* ev : group_events(c)) if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
     c.busy_valid = false;
     c.ready = false;
     c.device = -1;
@@ -720,12 +735,12 @@ extern "C" int sbv_profile_read_dominant(double* dominant_us) {
     return SBV_OK;
 }
 
-extern "C" int sbv_p256_last_group_stats(uint32_t out[3]) {
+extern "C" int sbv_p256_last_group_stats(uint32_t out[4]) {
     std::lock_guard<std::mutex> lk(g_mu);
     Context& c = g_ctx;
     if (!c.ready) return SBV_ENOTINIT;
     if (!out) return SBV_EINVAL;
-    out[0] = out[1] = out[2] = 0;
+    out[0] = out[1] = out[2] = out[3] = 0;
     if (!c.grp.counters) return SBV_OK;
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
@@ -734,6 +749,7 @@ extern "C" int sbv_p256_last_group_stats(uint32_t out[3]) {
     out[0] = h[0] < c.grp.max_groups ? h[0] : c.grp.max_groups;
     out[1] = h[1];
     out[2] = h[2];
+    out[3] = h[3];
     return SBV_OK;
 }
 

@@ -144,11 +144,13 @@ int sbv_last_timing(sbv_timing* out);
 int sbv_profile_enable(int on);
 int sbv_profile_read(double* prep_us, double* verify_us, uint64_t* launches);
 /* Same window as sbv_profile_read (call it BEFORE sbv_profile_read, which resets): summed duration of the
- * dominant stage-B kernel alone — k_verify_keyed_list when the batch was grouped, else all of stage B. */
+ * dominant stage-B kernel alone — k_verify_keyed_q (its last launch when the key-comb windows are consumed in
+ * chunks) when the batch was grouped, else all of stage B. */
 int sbv_profile_read_dominant(double* dominant_us);
-/* Device-side counters of the most recent grouped batch: out[0] = key groups, out[1] = tuples verified by
- * the registered-key kernel, out[2] = tuples verified by the generic kernel.  Synchronises the device. */
-int sbv_p256_last_group_stats(uint32_t out[3]);
+/* Device-side counters of the most recent grouped batch: out[0] = key groups, out[1] = tuples verified through
+ * the per-batch key tables, out[2] = tuples verified by the generic kernel, out[3] = ungrouped tuples rejected
+ * for their public key alone (pointFromAffine: coordinate >= p or off the curve).  Synchronises the device. */
+int sbv_p256_last_group_stats(uint32_t out[4]);
 
 /* Human-readable description of the last failure in this process ("" if none). */
 const char* sbv_last_error(void);

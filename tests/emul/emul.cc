@@ -80,8 +80,11 @@ unsigned long sbve_fast_mismatches() { return g_fast_mismatches; }
 u32 sbve_fe_add_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_add<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 u32 sbve_fe_mul_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_mul<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 
+static int g_group_chunks = 3, g_group_parts = 4;
+void sbve_set_group_chunks(int c) { g_group_chunks = c < 1 ? 1 : (c > 4 ? 4 : c); }
+void sbve_set_group_parts(int p) { if (p == 2 || p == 4 || p == 8 || p == 16) g_group_parts = p; }
 // grouped form: generic tuples, keys grouped inside the call (p256_group.h), emulated sequentially.
-// stats_out[0..2] = groups, grouped tuples, ungrouped tuples.
+// stats_out[0..3] = groups, grouped tuples, ungrouped tuples, ungrouped tuples rejected for their key.
 void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bitmap, u32 min_count, u32 max_groups,
                                     u32 ht_bits, u32* stats_out) {
     size_t cap = (n + 63) & ~(size_t)63;
@@ -96,35 +99,50 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
         for (int t = 0; t < 64; ++t) prep_chunk<true>(hw, n, s, b * per_block + t, 64, T);
     std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(max_groups ? max_groups : 1), counters(4, 0),
         grp_idx(cap), ung_idx(cap), slots(cap);
-    GroupState g{ht.data(), (u32)(((size_t)1 << ht_bits) - 1), rep.data(), cnt.data(), slot_of.data(), group_rep.data(), counters.data(),
-                 grp_idx.data(), ung_idx.data(), slots.data(), max_groups, min_count};
+    GroupState g{};
+    g.ht = ht.data(); g.ht_mask = (u32)(((size_t)1 << ht_bits) - 1); g.rep = rep.data(); g.cnt = cnt.data(); g.slot_of = slot_of.data();
+    g.group_rep = group_rep.data(); g.counters = counters.data(); g.grp_idx = grp_idx.data(); g.ung_idx = ung_idx.data();
+    g.slots = slots.data(); g.max_groups = max_groups;
+    group_set_threshold(g, min_count);
     for (size_t i = 0; i < n; ++i) group_insert_lane(tuples, i, g);
     for (size_t i = 0; i < n; ++i) group_assign_lane(i, g);
-    for (size_t i = 0; i < n; ++i) group_split_lane(i, g);
+    std::vector<uint8_t> accb(cap, 0xEE);
+    for (size_t i = 0; i < n; ++i) group_split_lane(tuples, i, g, accb.data());
     const u32 ngroups = counters[0] < max_groups ? counters[0] : max_groups;
-    std::vector<apt> bases((size_t)(ngroups ? ngroups : 1) * SBV_GTAB_WINDOWS);
-    std::vector<apt> ktab((size_t)(ngroups ? ngroups : 1) * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
-    std::vector<uint8_t> kvalid(ngroups ? ngroups : 1, 0);
-    std::vector<u32> tmp(SBV_KEYTAB_TMP_DWORDS + 4);
-    u32* tmpa = (u32*)(((uintptr_t)tmp.data() + 15) & ~(uintptr_t)15);
-    for (u32 k = 0; k < ngroups; ++k) keytab_bases_lane(tuples, k, g, bases.data(), kvalid.data());
-    for (u32 k = 0; k < ngroups; ++k)
-        for (int j = 0; j < SBV_GTAB_WINDOWS; ++j)
-            for (int part = 0; part < SBV_KEYTAB_PARTS; ++part)
-                keytab_window_lane(bases[(size_t)k * SBV_GTAB_WINDOWS + j], part, tmpa,
-                                   &ktab[((size_t)k * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW]);
+    // G phase for every tuple
+    std::vector<u32> gacc(24 * cap);
+    for (size_t i = 0; i < n; ++i) gphase_lane(s, i, g16tab(), gacc.data());
+    // key tables and the Q phase, in `chunks` pieces like the device pipeline
+    const size_t ng1 = ngroups ? ngroups : 1;
+    u32* jbases = (u32*)aligned_alloc(16, ng1 * SBV_GTAB_WINDOWS * SBV_JBASE_DWORDS * 4);
+    apt* ktab = (apt*)aligned_alloc(64, ng1 * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW * sizeof(apt));
+    std::vector<uint8_t> kvalid(ng1, 0);
+    u32* tmpa = (u32*)aligned_alloc(16, SBV_KEYTAB_TMP_DWORDS_PER_WINDOW * 4);
     memset(bitmap, 0, (n + 7) / 8);
-    u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB_ENTRIES * 40 * 4);
-    for (u32 L = 0; L < counters[1]; ++L) {
-        const u32 t = grp_idx[L];
-        if (verify_lane_keyed(s, t, slots[t], ngroups, ktab.data(), kvalid.data(), g16tab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+    const int chunks = g_group_chunks;
+    for (int c = 0; c < chunks; ++c) {
+        const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
+        for (u32 k = 0; k < ngroups; ++k) keytab_bases_lane(tuples, k, g, jbases, kvalid.data(), j_first, j_end - 1);
+        for (u32 k = 0; k < ngroups; ++k)
+            for (int j = j_first; j < j_end; ++j)
+                for (int part = 0; part < g_group_parts; ++part) {
+                    const size_t w = (size_t)k * SBV_GTAB_WINDOWS + j;
+                    keytab_window_lane(jbases + w * SBV_JBASE_DWORDS, part, g_group_parts, tmpa, ktab + w * SBV_GTAB_PER_WINDOW);
+                }
+        const bool last = c + 1 == chunks;
+        for (u32 L = 0; L < counters[1]; ++L) {
+            const u32 t = grp_idx[L];
+            const bool v = verify_lane_keyed_q(s, t, slots[t], ngroups, ktab, kvalid.data(), gacc.data(), j_first, j_end, last);
+            if (last && v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+        }
     }
+    u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB_ENTRIES * 40 * 4);
     for (u32 L = 0; L < counters[2]; ++L) {
         const u32 t = ung_idx[L];
         if (verify_lane(s, t, qtab, g16tab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
     }
-    free(qtab);
-    if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; }
+    free(qtab); free(tmpa); free(ktab); free(jbases);
+    if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }
 }
 
 // registered-key form: rsh = n x 96 B (r|s|hash), slots[i] indexes keys (nkeys x 64 B, Qx|Qy)

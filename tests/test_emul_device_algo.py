@@ -279,17 +279,26 @@ def test_grouped_by_key_inside_the_batch_matches_generic(emul, oracle, golden_ve
     allt = blob + tup.raw + off * 40
     total = len(allt) // 160
     want = [v["accept"] for v in vs] + _bitmap_list(exp.raw, n) + [False] * 40
-    stats = (ctypes.c_uint32 * 3)()
-    for min_count, max_groups, ht_bits in [(8, 64, 12), (1, 4096, 12), (8, 3, 12), (2, 64, 11), (10**6, 64, 12)]:
+    stats = (ctypes.c_uint32 * 4)()
+    # (threshold, table slots, hash bits, chunks of windows the tables are built and consumed in, lanes per window);
+    # threshold 64 exercises the sampled count (every 8th tuple), the small ones the exact count
+    for min_count, max_groups, ht_bits, chunks, parts in [(8, 64, 12, 3, 4), (8, 64, 12, 1, 8), (64, 64, 12, 4, 16), (1, 4096, 12, 2, 2),
+                                                          (8, 3, 12, 3, 4), (2, 64, 11, 3, 8), (10**6, 64, 12, 3, 4)]:
+        emul.sbve_set_group_chunks(chunks)
+        emul.sbve_set_group_parts(parts)
         bm = ctypes.create_string_buffer((total + 7) // 8)
         emul.sbve_p256_verify_batch_grouped(allt, total, bm, min_count, max_groups, ht_bits, stats)
         got = _bitmap_list(bm.raw, total)
         bad = [i for i in range(total) if got[i] != want[i]]
         assert not bad, (min_count, max_groups, ht_bits, bad[:8])
-        assert stats[1] + stats[2] == total
+        assert stats[1] + stats[2] + stats[3] == total
         if min_count == 8 and max_groups == 64:
             assert stats[0] >= 8 and stats[1] > 800          # 7 signer keys + the repeated invalid key + reused golden keys
         if max_groups == 3:
             assert stats[0] == 3
+        if min_count == 64:
+            assert 1 <= stats[0] <= 7 and stats[1] >= 100   # only the 7 signer keys (~128 uses each) can pass the sampled threshold
         if min_count == 10**6:
-            assert stats[0] == 0 and stats[2] == total
+            assert stats[0] == 0 and stats[2] + stats[3] == total and stats[3] >= 40    # the repeated off-curve key at least
+    emul.sbve_set_group_chunks(3)
+    emul.sbve_set_group_parts(4)
