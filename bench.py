@@ -122,7 +122,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    dominant_us = sbv.profile_read_dominant()
+    dominant_us, dominant_launches = sbv.profile_read_dominant()
     prep_us, verify_us, launches = sbv.profile_read()
     sbv.profile_enable(False)
     groups, n_grouped, n_ungrouped, n_key_rejected = sbv.last_group_stats()
@@ -204,12 +204,18 @@ def main():
     if rank == 0:
         total = n * world * args.steps
         value = total / elapsed
-        # dominant kernel: k_verify_keyed_q (the key-comb additions) over the grouped tuples when the batch was grouped by key,
-        # else k_p256_verify over all n; its units = the tuples that launch processed
-        kern_s = (dominant_us / max(1, launches)) * 1e-6
-        dom_units = n_grouped if was_grouped else n
-        dom_name = "k_verify_keyed_q" if was_grouped else "k_p256_verify"
-        achieved = ALGO_BYTES_PER_VERIFY * dom_units / kern_s / 1e9
+        # dominant kernel.  Grouped batch: k_verify_keyed_q, the key-comb additions over the grouped tuples; it is
+        # launched once per chunk of windows, and one launch executes 33/chunks of the 50 comb additions (17 for
+        # u1*G in k_gphase_generic + 33 for u2*Q) that make up a grouped tuple's stage B — it is charged that share
+        # of the tuple's 160.125 algorithmic bytes.  Ungrouped batch: k_p256_verify, all of stage B, all n tuples.
+        dom_launches_per_step = max(1, int(round(dominant_launches / max(1, launches))))
+        kern_s = (dominant_us / max(1, dominant_launches)) * 1e-6
+        if was_grouped:
+            dom_name, dom_units = "k_verify_keyed_q", n_grouped
+            share = (33.0 / dom_launches_per_step) / 50.0
+        else:
+            dom_name, dom_units, share = "k_p256_verify", n, 1.0
+        achieved = ALGO_BYTES_PER_VERIFY * dom_units * share / kern_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")      # per-launch HBM bytes from a rocprofv3 --pmc run
         if os.path.exists(tpath):
@@ -228,15 +234,17 @@ def main():
                        "parallelism": "shard-by-tuple" + (f" x{world} + RCCL all-gather of bitmaps" if world > 1 else "")},
             "bitmap_correct": ok,
             "kernel_us": {"k_p256_prep": prep_us / max(1, launches), "stage_b_all_kernels": verify_us / max(1, launches),
-                          dom_name: dominant_us / max(1, launches), "launches": launches},
+                          dom_name: dominant_us / max(1, dominant_launches), dom_name + "_launches_per_step": dom_launches_per_step,
+                          "launches": launches},
             "key_grouping": {"enabled": was_grouped, "groups": groups, "tuples_registered_key_kernel": n_grouped,
                              "tuples_generic_kernel": n_ungrouped, "tuples_rejected_for_their_key": n_key_rejected,
                              "note": "in-step grouping by public key (consensus_amd/csrc/p256_group.h); all of it is inside the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": dom_name, "units_per_launch": dom_units,
-                         "note": "algorithmic bytes = 160.125 B/verify x tuples that launch processed / its avg duration "
-                                 "(HIP events on the launch stream); the path is integer-ALU bound, see DESIGN.md"},
+                         "kernel": dom_name, "units_per_launch": dom_units, "share_of_a_tuples_stage_b_per_launch": share,
+                         "note": "algorithmic bytes = 160.125 B/verify x tuples that launch processed x the share of their "
+                                 "stage B it executes / its avg duration (HIP events on the launch stream); the path is "
+                                 "integer-ALU bound, see DESIGN.md"},
         }
         if ungrouped is not None:
             line["without_key_grouping"] = ungrouped

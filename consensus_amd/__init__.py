@@ -90,7 +90,7 @@ def load() -> ctypes.CDLL:
     lib.sbv_profile_enable.argtypes = [ctypes.c_int]
     lib.sbv_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                      ctypes.POINTER(ctypes.c_uint64)]
-    lib.sbv_profile_read_dominant.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    lib.sbv_profile_read_dominant.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)]
     lib.sbv_p256_last_group_stats.argtypes = [ctypes.POINTER(ctypes.c_uint32)]
     lib.sbv_last_error.restype = ctypes.c_char_p
     _lib = lib
@@ -262,11 +262,13 @@ def profile_read():
     return p.value, v.value, k.value
 
 
-def profile_read_dominant() -> float:
-    """Summed duration (us) of the dominant stage-B kernel since profiling was enabled; call before profile_read()."""
+def profile_read_dominant():
+    """(summed duration in us, number of launches) of the dominant stage-B kernel since profiling was enabled;
+    call before profile_read()."""
     d = ctypes.c_double()
-    _check(load().sbv_profile_read_dominant(ctypes.byref(d)))
-    return d.value
+    k = ctypes.c_uint64()
+    _check(load().sbv_profile_read_dominant(ctypes.byref(d), ctypes.byref(k)))
+    return d.value, k.value
 
 
 def last_group_stats():

@@ -8,8 +8,8 @@
 //
 //   stage A  prep_chunk   : range checks (bigmod SetBytes / IsZero, pointFromAffine's
 //                           coordinate < p), e = hash mod N (hashToNat), s^-1 by Montgomery's
-//                           trick over the thread's chunk of T tuples (one Fermat inversion
-//                           per T signatures), u1 = e*s^-1, u2 = r*s^-1.  Writes a limb-major
+//                           trick over the thread's chunk of T tuples (one inversion by division
+//                           steps, modinv30.h, per T signatures), u1 = e*s^-1, u2 = r*s^-1.  Writes a limb-major
 //                           (SoA) scratch so stage B's loads are coalesced.
 //   stage B  verify_lane  : on-curve check, R = u1*G + u2*Q with signed fixed windows
 //                           (4-bit for Q from a per-signature table, 8-bit comb for G from a
@@ -101,7 +101,7 @@ SBV_HD void prep_chunk(TupleWords words, size_t n, const Scratch& sc_, size_t fi
         }
     }
     sc inv;
-    sc_inv(inv, acc);                      // (prod s_k)^-1, Montgomery form
+    sc_inv_gcd(inv, acc);                  // (prod s_k)^-1, Montgomery form; division steps, not the 350-multiplication Fermat chain
     for (int k = T - 1; k >= 0; --k) {
         const size_t idx = first + (size_t)k * step;
         if (idx >= n) continue;

@@ -10,6 +10,7 @@
 // all because -p^-1 = 1 (mod 2^32) and p is a sum of four signed powers of 2^32.
 #pragma once
 #include "sbv_common.h"
+#include "modinv30.h"
 
 namespace sbv {
 
@@ -276,6 +277,16 @@ SBV_HD void fe_inv(fe& r, const fe& a) {
     for (int i = 0; i < 32; ++i) fe_sqr(t, t); fe_mul(t, t, x32);
     for (int i = 0; i < 30; ++i) fe_sqr(t, t); fe_mul(t, t, x30);
     fe_sqr(t, t); fe_sqr(t, t); fe_mul(r, t, a);           // 0 1
+}
+
+// The same inverse by division steps (modinv30.h): ~4x fewer instructions than the Fermat chain and no
+// long multiply dependency chain.  a = xR (Montgomery form, < p): the integer inverse is x^-1 R^-1, one
+// Montgomery multiplication by R^3 mod p brings it back to x^-1 R.  a = 0 -> 0, like fe_inv.
+SBV_HD void fe_inv_gcd(fe& r, const fe& a) {
+    const fe r3 = {{0x0000000Au, 0xFFFFFFFDu, 0xFFFFFFF7u, 0xFFFFFFEDu, 0xFFFFFFFCu, 0x00000005u, 0x00000001u, 0x00000018u}};
+    u256 t;
+    modinv30(t, a, modinfo30_p256());
+    fe_mul(r, t, r3);
 }
 
 }  // namespace sbv

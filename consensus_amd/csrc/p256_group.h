@@ -218,7 +218,7 @@ SBV_HD void keytab_window_lane(const u32* jbase, int part, int parts, u32* tmp, 
         fe_mul(acc, acc, t.Z);
     }
     fe inv;
-    fe_inv(inv, acc);                 // garbage in, garbage out for an invalid key (never used: valid = 0)
+    fe_inv_gcd(inv, acc);             // garbage in, garbage out for an invalid key (never used: valid = 0)
     SBV_NOUNROLL
     for (int k = E - 1; k >= 0; --k) {
         fe X, Y, Z, pk, zi, zi2, zi3;

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_pack_bitmap(const uint8_t* __restrict__
 //   side_b:        wait(assign) split | wait(bases c) windows chunk c ...
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b,
                                       u32* d_qtab, const apt* d_g16, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y,
-                                      hipEvent_t prof_k0, hipEvent_t prof_k1) {
+                                      hipEvent_t* prof, int* prof_pairs) {
     if (n == 0) return hipSuccess;
     GroupState g;
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
@@ -206,14 +206,15 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
         SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         const bool last = c + 1 == chunks;
-        if (last && prof_k0) SBV_TRY(hipEventRecord(prof_k0, stream));
+        if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
         hipLaunchKernelGGL(k_verify_keyed_q, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.gacc, b.acc,
                            j_first, j_end, last ? 1 : 0);
-        if (last && prof_k1) SBV_TRY(hipEventRecord(prof_k1, stream));
+        if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
     if (y.side_c) SBV_TRY(hipStreamWaitEvent(stream, y.ev_generic, 0));
     hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
 #undef SBV_TRY
+    if (prof && prof_pairs) *prof_pairs = chunks;
     return hipGetLastError();
 }
 

@@ -46,11 +46,11 @@ struct GroupSync {
     int chunks = 1;
     int parts = 4;                  // lanes per (key, window) in k_keytab_window: 2, 4, 8 or 16
 };
-// ev_fork must have been recorded on `stream` before stage A was enqueued.  prof_k0/k1 (optional) bracket
-// the LAST Q-phase launch (the only one when chunks == 1).
+// ev_fork must have been recorded on `stream` before stage A was enqueued.  prof (optional): 2 * chunks events,
+// a pair around every Q-phase launch; *prof_pairs = the number of pairs used.
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b, u32* d_qtab,
                                       const apt* d_g16, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y,
-                                      hipEvent_t prof_k0 = nullptr, hipEvent_t prof_k1 = nullptr);
+                                      hipEvent_t* prof = nullptr, int* prof_pairs = nullptr);
 void host_build_gtable(apt* out);   // 33 x 128 affine multiples of G (8-bit comb; host signer, key tables)
 void host_build_g16(apt* out);      // 17 x 32768 affine multiples of G (16-bit comb used by the verify kernels)
 #define SBV_G16_ENTRIES ((size_t)SBV_G16_WINDOWS * SBV_G16_PER_WINDOW)

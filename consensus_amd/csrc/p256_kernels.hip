@@ -171,9 +171,11 @@ hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const u
 }
 
 int prep_chunk_T(size_t n) {
-    // small batches: one inversion per tuple (latency); large batches: amortise over 32
-    static const int cap = [] { const char* e = getenv("SBV_PREP_T"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? v : 32; }();
-    size_t t = (n + 16383) / 16384;
+    // Tuples per lane for Montgomery's trick.  The inversion (division steps, ~40 multiplications' worth) is
+    // cheap enough that long chunks no longer pay: small batches take one inversion per tuple (shortest chain),
+    // large ones amortise it over up to 8 and still put >= 2 wavefronts on every SIMD.
+    static const int cap = [] { const char* e = getenv("SBV_PREP_T"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? v : 8; }();
+    size_t t = (n + 131071) / 131072;
     if (t < 1) t = 1;
     if (t > (size_t)cap) t = (size_t)cap;
     return (int)t;

@@ -5,6 +5,7 @@
 // This is <2% of the per-signature work once s^-1 is amortised by Montgomery's trick over a
 // thread's chunk of tuples (p256_core.h: prep_chunk), so it is written for clarity.
 #pragma once
+#include "modinv30.h"
 #include "sbv_common.h"
 
 namespace sbv {
@@ -90,6 +91,14 @@ SBV_HD void sc_inv(sc& r, const sc& a) {
         if ((low[i >> 5] >> (i & 31)) & 1u) sc_mul(t, t, a);
     }
     r = t;
+}
+
+// The same inverse by division steps (modinv30.h; see fe_inv_gcd): Montgomery form in and out, R^3 mod N.
+SBV_HD void sc_inv_gcd(sc& r, const sc& a) {
+    const sc r3 = {{0x0B65A624u, 0xAC8EBEC9u, 0x0C0555C9u, 0x111F28AEu, 0x6BA5E93Fu, 0x2543B924u, 0x6407BE65u, 0x503A54E7u}};
+    u256 t;
+    modinv30(t, a, modinfo30_p256_order());
+    sc_mul(r, t, r3);
 }
 
 }  // namespace sbv

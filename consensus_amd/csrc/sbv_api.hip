@@ -178,7 +178,7 @@ int ensure_group_buffers(Context& c, size_t n) {
 
 // enqueue stage A + stage B for n <= cap tuples on `stream`
 int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream,
-            hipEvent_t after_prep, hipEvent_t dom0 = nullptr, hipEvent_t dom1 = nullptr, bool* was_grouped = nullptr) {
+            hipEvent_t after_prep, hipEvent_t* dom = nullptr, int* dom_pairs = nullptr, bool* was_grouped = nullptr) {
     const sbv::Scratch s = scratch_view(c);
     const bool grouped = c.group_enabled && n >= c.group_min_batch;
     if (was_grouped) *was_grouped = grouped;
@@ -190,12 +190,12 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_tuples, n, s, stream));
     if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
     if (grouped) {
-        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, d_bitmap, stream, c.gsync, dom0, dom1));
+        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, d_bitmap, stream, c.gsync, dom, dom_pairs));
         return SBV_OK;
     }
-    if (dom0) HIP_TRY(SBV_EDEVICE, hipEventRecord(dom0, stream));      // ungrouped: the dominant kernel is all of stage B
+    if (dom) HIP_TRY(SBV_EDEVICE, hipEventRecord(dom[0], stream));     // ungrouped: the dominant kernel is all of stage B
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify(s, n, c.d_qtab, c.d_gtab, d_bitmap, c.d_rerun, stream));
-    if (dom1) HIP_TRY(SBV_EDEVICE, hipEventRecord(dom1, stream));
+    if (dom) { HIP_TRY(SBV_EDEVICE, hipEventRecord(dom[1], stream)); if (dom_pairs) *dom_pairs = 1; }
     return SBV_OK;
 }
 
@@ -275,7 +275,7 @@ extern "C" int sbv_init(int device) {
     for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b})
         HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
     for (hipEvent_t* ev : group_events(c)) HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(ev, hipEventDisableTiming));
-    c.gsync.chunks = 3;
+    c.gsync.chunks = 2;
     if (const char* e = getenv("SBV_GROUP_CHUNKS")) {
         const int v = atoi(e);
         if (v >= 1 && v <= SBV_GROUP_MAX_CHUNKS) c.gsync.chunks = v;
@@ -371,18 +371,22 @@ extern "C" int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d
             end = c.prof_events[c.prof_used + 2];
             c.prof_used += 3;
         }
-        hipEvent_t d0 = nullptr, d1 = nullptr;
+        // event pairs around every launch of the dominant kernel (one per chunk of windows when grouped)
+        hipEvent_t* dom = nullptr;
+        int dom_pairs = 0;
         if (c.profiling) {
-            if (c.prof_dom_used + 2 > c.prof_dom.size())
-                for (int k = 0; k < 2; ++k) { hipEvent_t ev; HIP_TRY(SBV_EDEVICE, hipEventCreate(&ev)); c.prof_dom.push_back(ev); }
-            d0 = c.prof_dom[c.prof_dom_used];
-            d1 = c.prof_dom[c.prof_dom_used + 1];
+            while (c.prof_dom_used + 2 * SBV_GROUP_MAX_CHUNKS > c.prof_dom.size()) {
+                hipEvent_t ev;
+                HIP_TRY(SBV_EDEVICE, hipEventCreate(&ev));
+                c.prof_dom.push_back(ev);
+            }
+            dom = c.prof_dom.data() + c.prof_dom_used;
         }
         bool was_grouped = false;
-        rc = enqueue(c, src + off * SBV_TUPLE_BYTES, m, dst + off / 8, stream, mid, d0, d1, &was_grouped);
+        rc = enqueue(c, src + off * SBV_TUPLE_BYTES, m, dst + off / 8, stream, mid, dom, &dom_pairs, &was_grouped);
         if (rc != SBV_OK) return rc;
         (void)was_grouped;
-        if (c.profiling) c.prof_dom_used += 2;
+        if (c.profiling) c.prof_dom_used += 2 * (size_t)dom_pairs;
         if (end) HIP_TRY(SBV_EDEVICE, hipEventRecord(end, stream));
     }
     HIP_TRY(SBV_EDEVICE, hipEventRecord(c.busy, stream));
@@ -721,7 +725,7 @@ extern "C" int sbv_profile_enable(int on) {
     return SBV_OK;
 }
 
-extern "C" int sbv_profile_read_dominant(double* dominant_us) {
+extern "C" int sbv_profile_read_dominant(double* dominant_us, uint64_t* dominant_launches) {
     std::lock_guard<std::mutex> lk(g_mu);
     Context& c = g_ctx;
     if (!c.ready) return SBV_ENOTINIT;
@@ -731,6 +735,7 @@ extern "C" int sbv_profile_read_dominant(double* dominant_us) {
         d += 1e3 * ms_between(c.prof_dom[i], c.prof_dom[i + 1]);
     }
     if (dominant_us) *dominant_us = d;
+    if (dominant_launches) *dominant_launches = c.prof_dom_used / 2;
     c.prof_dom_used = 0;
     return SBV_OK;
 }

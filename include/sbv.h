@@ -143,10 +143,10 @@ int sbv_last_timing(sbv_timing* out);
  * number of stage-B launches since the previous read. */
 int sbv_profile_enable(int on);
 int sbv_profile_read(double* prep_us, double* verify_us, uint64_t* launches);
-/* Same window as sbv_profile_read (call it BEFORE sbv_profile_read, which resets): summed duration of the
- * dominant stage-B kernel alone — k_verify_keyed_q (its last launch when the key-comb windows are consumed in
- * chunks) when the batch was grouped, else all of stage B. */
-int sbv_profile_read_dominant(double* dominant_us);
+/* Same window as sbv_profile_read (call it BEFORE sbv_profile_read, which resets): summed duration and number
+ * of launches of the dominant stage-B kernel alone — k_verify_keyed_q (one launch per chunk of key-comb windows)
+ * when the batch was grouped, else k_p256_verify. */
+int sbv_profile_read_dominant(double* dominant_us, uint64_t* dominant_launches);
 /* Device-side counters of the most recent grouped batch: out[0] = key groups, out[1] = tuples verified through
  * the per-batch key tables, out[2] = tuples verified by the generic kernel, out[3] = ungrouped tuples rejected
  * for their public key alone (pointFromAffine: coordinate >= p or off the curve).  Synchronises the device. */

@@ -218,6 +218,14 @@ void sbve_sqr_wide(const u32* a, u32* out16) { sqr_wide(out16, a); }
 void sbve_mont_reduce(const u32* t16, u32* out) { fe z; fe_mont_reduce(z, t16); memcpy(out, &z, 32); }
 void sbve_sc_mul(const u32* a, const u32* b, u32* out) { sc x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); sc_mul(z, x, y); memcpy(out, &z, 32); }
 void sbve_sc_inv(const u32* a, u32* out) { sc x, z; memcpy(&x, a, 32); sc_inv(z, x); memcpy(out, &z, 32); }
+// division-step inversions (modinv30.h): Montgomery in/out wrappers and the plain-integer core (which: 0 = p, 1 = N, 2 = 2^255-19)
+void sbve_fe_inv_gcd(const u32* a, u32* out) { fe x, z; memcpy(&x, a, 32); fe_inv_gcd(z, x); memcpy(out, &z, 32); }
+void sbve_sc_inv_gcd(const u32* a, u32* out) { sc x, z; memcpy(&x, a, 32); sc_inv_gcd(z, x); memcpy(out, &z, 32); }
+void sbve_modinv30(int which, const u32* a, u32* out) {
+    u256 x, z; memcpy(&x, a, 32);
+    modinv30(z, x, which == 0 ? modinfo30_p256() : which == 1 ? modinfo30_p256_order() : modinfo30_25519());
+    memcpy(out, &z, 32);
+}
 // affine Montgomery-form G-table entry (j, k): 16 dwords
 void sbve_g16_entry(int j, int k, u32* out16) { memcpy(out16, &g16tab()[(size_t)j * SBV_G16_PER_WINDOW + (k - 1)], 64); }
 void sbve_gtab_entry(int j, int k, u32* out16) { memcpy(out16, &gtab()[(size_t)j * SBV_GTAB_PER_WINDOW + (k - 1)], 64); }

@@ -105,6 +105,28 @@ def test_fe_inv_and_sc_ops_match_bigint(emul):
         assert val(out) == pow(x, -1, N) * R % N
 
 
+def test_division_step_inversion_matches_bigint(emul):
+    """modinv30.h (Bernstein-Yang division steps, 20 x 30) on the three moduli of the library, edge values included,
+    and the Montgomery-domain wrappers against the Fermat chains they replace."""
+    rng = random.Random(14)
+    out = (ctypes.c_uint32 * 8)()
+    for which, m in ((0, P), (1, N), (2, 2**255 - 19)):
+        edge = [0, 1, 2, 3, m - 1, m - 2, (m + 1) // 2, (m - 1) // 2, 2**255 % m, 2**128, 2**30, 2**30 - 1, 2**60 + 1, m // 3,
+                2**256 % m, (2**256 - 1) % m]
+        for a in edge + [rng.randrange(m) for _ in range(400)] + [rng.randrange(2**k) for k in (8, 31, 61, 200) for _ in range(10)]:
+            emul.sbve_modinv30(which, limbs(a), out)
+            assert val(out) == (pow(a, -1, m) if a else 0), (which, hex(a))
+    out2 = (ctypes.c_uint32 * 8)()
+    for a in [0, 1, 2, P - 1, R % P] + [rng.randrange(P) for _ in range(60)]:
+        emul.sbve_fe_inv_gcd(limbs(a), out)
+        emul.sbve_fe_inv(limbs(a), out2)
+        assert val(out) == val(out2), hex(a)
+    for a in [0, 1, 2, N - 1, R % N] + [rng.randrange(N) for _ in range(60)]:
+        emul.sbve_sc_inv_gcd(limbs(a), out)
+        emul.sbve_sc_inv(limbs(a), out2)
+        assert val(out) == val(out2), hex(a)
+
+
 def test_gtable_entries(emul):
     out = (ctypes.c_uint32 * 16)()
     rinv = pow(R, -1, P)

@@ -18,9 +18,9 @@ using namespace sbv;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
-enum { OP_MULW, OP_SQRW, OP_RED, OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_SCMUL, OP_SCINV, OP_DBL, OP_ADDM, OP_ADDQ, OP_ONCURVE, OP_REDDBG, OP_ED_MUL, OP_ED_SQR, OP_ED_ADD, OP_ED_SUB, OP_ED_FREEZE, OP_ED_INV, OP_ED_DBL, OP_ED_ADDP, OP_ED_DECOMP, OP_COUNT };
+enum { OP_MULW, OP_SQRW, OP_RED, OP_MUL, OP_SQR, OP_ADD, OP_SUB, OP_SCMUL, OP_SCINV, OP_SCINVG, OP_FEINVG, OP_DBL, OP_ADDM, OP_ADDQ, OP_ONCURVE, OP_REDDBG, OP_ED_MUL, OP_ED_SQR, OP_ED_ADD, OP_ED_SUB, OP_ED_FREEZE, OP_ED_INV, OP_ED_DBL, OP_ED_ADDP, OP_ED_DECOMP, OP_COUNT };
 static const char* kNames[OP_COUNT] = {"mul_wide", "sqr_wide", "fe_mont_reduce", "fe_mul", "fe_sqr", "fe_add", "fe_sub",
-                                       "sc_mul", "sc_inv", "pt_dbl", "pt_add_mixed", "pt_add_qent", "pt_on_curve", "reduce_debug_taps", "fe25_mul", "fe25_sqr", "fe25_add", "fe25_sub", "fe25_freeze", "fe25_inv", "ed_dbl", "ed_add_pniels", "ed_decompress"};
+                                       "sc_mul", "sc_inv", "sc_inv_gcd (division steps)", "fe_inv_gcd (division steps)", "pt_dbl", "pt_add_mixed", "pt_add_qent", "pt_on_curve", "reduce_debug_taps", "fe25_mul", "fe25_sqr", "fe25_add", "fe25_sub", "fe25_freeze", "fe25_inv", "ed_dbl", "ed_add_pniels", "ed_decompress"};
 constexpr int IN_WORDS = 64, OUT_WORDS = 32;
 
 // fe_mont_reduce with taps: out[0..7] = M, out[8] = k+1, out[9..17] = acc after T_hi+M,
@@ -73,6 +73,8 @@ __host__ __device__ inline void run_op(int op, const u32* in, u32* out) {
         case OP_SUB: { fe r; fe_sub(r, a, b); memcpy(out, &r, 32); break; }
         case OP_SCMUL: { sc r; sc_mul(r, a, b); memcpy(out, &r, 32); break; }
         case OP_SCINV: { sc r; sc_inv(r, a); memcpy(out, &r, 32); break; }
+        case OP_SCINVG: { sc r; sc_inv_gcd(r, a); memcpy(out, &r, 32); break; }
+        case OP_FEINVG: { fe r; fe_inv_gcd(r, a); memcpy(out, &r, 32); break; }
         case OP_DBL: { jpt p{a, b, c}, r; pt_dbl(r, p); memcpy(out, &r, 96); break; }
         case OP_ADDM: { jpt p{a, b, c}; apt q{d, e}; pt_add_mixed(p, q, (in[40] & 1) != 0, (in[40] & 2) != 0); memcpy(out, &p, 96); break; }
         case OP_ADDQ: { jpt p{a, b, c}; qent q; memcpy(&q, in + 24, 160); pt_add_qent(p, q, (in[0] & 1) != 0, false); memcpy(out, &p, 96); break; }
@@ -132,7 +134,7 @@ static int unit_tests() {
                 w[k] = mode == 0 ? r : mode == 1 ? ((r & 1) ? 0xFFFFFFFFu : 0u) : mode == 2 ? (r | 0xFFFF0000u) : (r & 0xFFFFu);
             }
             if (op != OP_MULW && op != OP_SQRW && op < OP_ED_MUL) {
-                const u32* mod = (op == OP_SCMUL || op == OP_SCINV) ? nn.v : p.v;
+                const u32* mod = (op == OP_SCMUL || op == OP_SCINV || op == OP_SCINVG) ? nn.v : p.v;
                 for (int f = 0; f < 8; ++f) reduce_mod(w + 8 * f, mod);
                 if (op == OP_RED || op == OP_REDDBG) reduce_mod(w + 8, p.v);       // T < p * 2^256
             }

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"; cd "$ROOT"; export TMPDIR=/tmp
 ( timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "group" > "$OUT/pytest_group.log" 2>&1; echo "rc=$?" >> "$OUT/pytest_group.log" ); tail -3 "$OUT/pytest_group.log"
-for cfg in "2 4 32 0 4" "1 4 32 0 4" "3 4 32 0 4" "2 8 32 0 4" "2 4 16 0 4"; do
+for cfg in "2 4 8" "3 4 8" "2 8 8" "2 4 4" "2 4 16" "1 4 8"; do
   set -- $cfg
   ( SBV_GROUP_CHUNKS=$1 SBV_GROUP_PARTS=$2 SBV_PREP_T=${3:-32} SBV_GENERIC_STREAM=${4:-0} GPU_MAX_HW_QUEUES=${5:-4} timeout 120 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --primary-only > "$OUT/bench_c$1_p$2_t${3:-32}_g${4:-0}_q${5:-4}.log" 2>&1; echo "rc=$?" >> "$OUT/bench_c$1_p$2_t${3:-32}_g${4:-0}_q${5:-4}.log" )
   python - "$OUT/bench_c$1_p$2_t${3:-32}_g${4:-0}_q${5:-4}.log" "$1" "$2/T${3:-32}/gs${4:-0}/hwq${5:-4}" <<'PY'
