@@ -395,6 +395,53 @@ SBV_HD bool verify_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys, c
     return ok && rx_matches<FAST>(R, r, st);
 }
 
+// ---- registered-key form, several lanes per signature (latency form) ----------------------------------
+// A quorum-sized micro-batch (BASELINE.json's second metric: N = 16 -> 15 concurrent VerifyConsenterSig) puts
+// one wavefront on a 256-CU GPU, and a lane's chain of 50 dependent additions is what the caller waits for.
+// With no doublings in the registered-key form the 50 comb terms are independent, so SBV_COOP_LANES lanes
+// each sum every SBV_COOP_LANES-th term (7 or 6 additions) and the partial sums are combined by a butterfly
+// of exact Jacobian additions across the lanes (3 levels): ~10 additions deep instead of 50.
+#define SBV_COOP_LANES 8
+SBV_HD void pt_add_jac(jpt& R, const jpt& Q) {           // exact, either operand may be the point at infinity
+    qent e;
+    e.X = Q.X; e.Y = Q.Y; e.Z = Q.Z;
+    fe_sqr(e.ZZ, Q.Z);
+    fe_mul(e.ZZZ, e.ZZ, Q.Z);
+    pt_add_qent(R, e, false, pt_is_inf(Q));
+}
+// R = sum of the comb terms t = sub, sub + LANES, ... < 50 of u1*G + u2*Q (key comb `qtab` of the tuple's slot)
+SBV_HD void keyed_partial_lane(jpt& R, const u256& u1, const u256& u2, const apt* qtab, const apt* g16, int sub) {
+    u256 k1, k2;
+    const u32 top1 = add_const_limbs(k1, u1, 0x80008000u);
+    const u32 top2 = add_const_limbs(k2, u2, 0x80808080u);
+    pt_set_inf(R);
+    constexpr int kSteps = SBV_G16_WINDOWS + SBV_GTAB_WINDOWS;
+    auto locate = [&](int t, int& idx, bool& neg, bool& skip) -> const apt* {
+        if (t < SBV_G16_WINDOWS) {
+            comb16_digit(k1, top1, t, idx, neg, skip);
+            return g16 + (size_t)t * SBV_G16_PER_WINDOW + idx;
+        }
+        comb_digit(k2, top2, t - SBV_G16_WINDOWS, idx, neg, skip);
+        return qtab + (size_t)(t - SBV_G16_WINDOWS) * SBV_GTAB_PER_WINDOW + idx;
+    };
+    apt cur;
+    int idx; bool neg, skip;
+    {
+        const u32* gp = reinterpret_cast<const u32*>(locate(sub, idx, neg, skip));
+        fe_load16(cur.x, gp); fe_load16(cur.y, gp + 8);
+    }
+    SBV_NOUNROLL
+    for (int t = sub; t < kSteps; t += SBV_COOP_LANES) {
+        const int tn = t + SBV_COOP_LANES < kSteps ? t + SBV_COOP_LANES : t;
+        int idxn; bool negn, skipn;
+        const u32* gp = reinterpret_cast<const u32*>(locate(tn, idxn, negn, skipn));
+        apt nxt;
+        fe_load16(nxt.x, gp); fe_load16(nxt.y, gp + 8);
+        pt_add_mixed(R, cur, neg, skip);
+        cur = nxt; neg = negn; skip = skipn;
+    }
+}
+
 // Q phase of the grouped step: R (from gacc) += sum of key-comb windows [j0, j1) of u2*Q.  `last` -> the
 // verdict is returned; otherwise R goes back to gacc for the next chunk of windows and the return value
 // is meaningless.

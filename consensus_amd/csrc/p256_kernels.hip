@@ -123,6 +123,56 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_keyed(Scratch 
     verify_keyed_body<false>(s, n, slots, nkeys, ktab, kvalid, gtab, bitmap, rerun);
 }
 
+// Registered-key form, SBV_COOP_LANES lanes per signature (p256_core.h): the latency kernel for small batches.
+// A wavefront holds 8 signatures = exactly one byte of the bitmap.
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_keyed_coop(Scratch s, size_t n, const u32* __restrict__ slots,
+                                                                            u32 nkeys, const apt* __restrict__ ktab,
+                                                                            const uint8_t* __restrict__ kvalid,
+                                                                            const apt* __restrict__ g16, uint8_t* __restrict__ bitmap) {
+    const size_t lane_g = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    const size_t i = lane_g / SBV_COOP_LANES;
+    const int sub = (int)(lane_g % SBV_COOP_LANES);
+    const bool active = i < n;
+    jpt R;
+    pt_set_inf(R);
+    bool ok = false;
+    if (active) {
+        u32 slot = slots[i];
+        ok = s.ok[i] != 0 && slot < nkeys;
+        if (slot >= nkeys) slot = 0;
+        ok = ok && kvalid[slot] != 0;
+        u256 u1, u2;
+        soa_load(u1, s.u1, s.cap, i);
+        soa_load(u2, s.u2, s.cap, i);
+        keyed_partial_lane(R, u1, u2, ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW), g16, sub);
+    }
+    // butterfly: after log2(lanes) exchanges every lane of the group holds the whole sum
+    SBV_NOUNROLL
+    for (int off = SBV_COOP_LANES / 2; off >= 1; off >>= 1) {
+        jpt P;
+        SBV_UNROLL
+        for (int l = 0; l < 8; ++l) {
+            P.X.v[l] = __shfl_xor(R.X.v[l], off, 64);
+            P.Y.v[l] = __shfl_xor(R.Y.v[l], off, 64);
+            P.Z.v[l] = __shfl_xor(R.Z.v[l], off, 64);
+        }
+        pt_add_jac(R, P);
+    }
+    bool accept = false;
+    if (active && sub == 0) {
+        u256 r;
+        soa_load(r, s.r, s.cap, i);
+        accept = ok && rx_matches(R, r);
+    }
+    const unsigned long long m = __ballot(accept);          // bits 0, 8, ..., 56
+    if ((threadIdx.x & 63) == 0 && active) {                // lane 0 is sub 0 of the wavefront's first signature
+        u32 byte = 0;
+        SBV_UNROLL
+        for (int g = 0; g < 8; ++g) byte |= (u32)((m >> (8 * g)) & 1ull) << g;
+        bitmap[i >> 3] = (uint8_t)byte;
+    }
+}
+
 // Generic form (public key in the tuple): per-signature window table in HBM.
 template <bool FAST>
 __device__ __forceinline__ void verify_body(const Scratch& s, size_t n, u32* __restrict__ qtab, const apt* __restrict__ gtab,
@@ -204,10 +254,23 @@ static bool two_pass() {
     return v;
 }
 
+// Batches up to this size take the lanes-per-signature kernel: 8192 x 8 lanes = one wavefront on every SIMD.
+// SBV_COOP_MAX=0 switches it off.
+static size_t coop_max_batch() {
+    static const size_t v = [] { const char* e = getenv("SBV_COOP_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)8192; }();
+    return v;
+}
+
 hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
                                     const uint8_t* d_kvalid, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
                                     hipStream_t stream) {
     if (n == 0) return hipSuccess;
+    if (n <= coop_max_batch() && !two_pass()) {      // small batch: latency matters, lanes are plentiful
+        const size_t lanes = n * SBV_COOP_LANES;
+        hipLaunchKernelGGL(k_p256_verify_keyed_coop, dim3((unsigned)((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK)),
+                           dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab, d_kvalid, d_gtab, d_bitmap);
+        return hipGetLastError();
+    }
     const unsigned grid = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
     uint8_t* rr = nullptr;                 // nullptr = the exact kernel verifies every wavefront
     if (two_pass()) {

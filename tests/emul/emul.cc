@@ -145,6 +145,8 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }
 }
 
+static bool g_keyed_coop = false;
+static unsigned long g_coop_disagreements = 0;
 // registered-key form: rsh = n x 96 B (r|s|hash), slots[i] indexes keys (nkeys x 64 B, Qx|Qy)
 void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n, const uint8_t* keys, u32 nkeys,
                                   uint8_t* bitmap, int block, int T) {
@@ -169,9 +171,36 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
         if (kvalid[k]) build_comb_table(x, y, &ktab[per_key * k]);
     }
     memset(bitmap, 0, (n + 7) / 8);
-    for (size_t i = 0; i < n; ++i)
-        if (verify_lane_keyed(s, i, slots[i], nkeys, ktab.data(), kvalid.data(), g16tab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+    for (size_t i = 0; i < n; ++i) {
+        bool accept;
+        if (!g_keyed_coop) {
+            accept = verify_lane_keyed(s, i, slots[i], nkeys, ktab.data(), kvalid.data(), g16tab());
+        } else {
+            // k_p256_verify_keyed_coop: SBV_COOP_LANES partial sums, xor-butterfly of exact Jacobian additions
+            u32 slot = slots[i];
+            bool okk = s.ok[i] != 0 && slot < nkeys;
+            if (slot >= nkeys) slot = 0;
+            okk = okk && kvalid[slot] != 0;
+            u256 a, b, rr;
+            soa_load(a, s.u1, s.cap, i);
+            soa_load(b, s.u2, s.cap, i);
+            soa_load(rr, s.r, s.cap, i);
+            jpt part[SBV_COOP_LANES];
+            for (int sub = 0; sub < SBV_COOP_LANES; ++sub) keyed_partial_lane(part[sub], a, b, &ktab[per_key * slot], g16tab(), sub);
+            for (int off = SBV_COOP_LANES / 2; off >= 1; off >>= 1) {
+                jpt nxt[SBV_COOP_LANES];
+                for (int sub = 0; sub < SBV_COOP_LANES; ++sub) { nxt[sub] = part[sub]; pt_add_jac(nxt[sub], part[sub ^ off]); }
+                for (int sub = 0; sub < SBV_COOP_LANES; ++sub) part[sub] = nxt[sub];
+            }
+            accept = okk && rx_matches(part[0], rr);
+            for (int sub = 1; sub < SBV_COOP_LANES; ++sub)           // every lane of the group must hold the same point
+                if ((okk && rx_matches(part[sub], rr)) != accept) g_coop_disagreements++;
+        }
+        if (accept) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+    }
 }
+void sbve_set_keyed_coop(int on) { g_keyed_coop = on != 0; }
+unsigned long sbve_coop_disagreements() { return g_coop_disagreements; }
 
 // device message front end (SHA-256 + strict DER) emulated: -> 96-byte r|s|hash record
 void sbve_msg_frontend(const uint8_t* msg, size_t mlen, const uint8_t* der, size_t dlen, uint8_t out96[96]) {

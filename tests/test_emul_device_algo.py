@@ -223,6 +223,19 @@ def test_registered_key_form_matches_generic_verdicts(emul, oracle, golden_vecto
     emul.sbve_p256_verify_batch_keyed(rsh[:96 * 4], arr2, 4, b"".join(keys), len(keys), bm2, 64, 1)
     assert _bitmap_list(bm2.raw, 4) == [False, False, want[0] if slots[0] == slots[2] else got[2], False] or True
     assert not _bitmap_list(bm2.raw, 4)[0] and not _bitmap_list(bm2.raw, 4)[1] and not _bitmap_list(bm2.raw, 4)[3]
+    # the latency form (k_p256_verify_keyed_coop: 8 lanes per signature, butterfly of exact Jacobian additions) gives
+    # the same verdicts, and every lane of a group ends with the same point (incl. u1*G == +-u2*Q, R == infinity vectors)
+    emul.sbve_coop_disagreements.restype = ctypes.c_ulong
+    emul.sbve_set_keyed_coop(1)
+    try:
+        bm3 = ctypes.create_string_buffer((total + 7) // 8)
+        emul.sbve_p256_verify_batch_keyed(rsh, arr, total, b"".join(keys), len(keys), bm3, 64, 1)
+        got3 = _bitmap_list(bm3.raw, total)
+        bad = [i for i in range(total) if got3[i] != want[i]]
+        assert not bad, bad[:10]
+        assert emul.sbve_coop_disagreements() == 0
+    finally:
+        emul.sbve_set_keyed_coop(0)
 
 
 def test_fast_conditional_subtraction_is_exact_or_flags(emul):
