@@ -44,10 +44,11 @@ void parallel_for(size_t n, int threads, const std::function<void(size_t)>& fn) 
 
 extern "C" {
 
-// backend_kind 0: libsbv.so on `device`; 1: callback (tests inject a stand-in, like mocks.VerifierMock)
+// backend_kind 0: libsbv.so on `device`; 1: callback (tests inject a stand-in, like mocks.VerifierMock);
+// 2: callback + a host-side key registry (stand-in for the registered-key form)
 void* sbvh_verifier_new(int backend_kind, int device, backend_fn fn, void* user, size_t coalesce_max, int coalesce_wait_us, int cache) {
     VHandle* h = new VHandle;
-    h->be = backend_kind == 0 ? make_sbv_backend(device) : make_callback_backend(fn, user);
+    h->be = backend_kind == 0 ? make_sbv_backend(device) : make_callback_backend(fn, user, backend_kind == 2);
     VerifierOptions o;
     o.coalesce_max = coalesce_max;
     o.coalesce_wait = std::chrono::microseconds(coalesce_wait_us);
@@ -56,6 +57,7 @@ void* sbvh_verifier_new(int backend_kind, int device, backend_fn fn, void* user,
     return h;
 }
 void sbvh_verifier_free(void* h) { delete (VHandle*)h; }
+uint64_t sbvh_backend_keyed_batches(void* h) { return ((VHandle*)h)->be->keyed_batches(); }
 void sbvh_register_consenter(void* h, uint64_t id, const uint8_t q[64]) { ((VHandle*)h)->v->RegisterConsenter(id, q); }
 void sbvh_register_client(void* h, const char* client, const uint8_t q[64]) { ((VHandle*)h)->v->RegisterClient(client, q); }
 void sbvh_set_verification_sequence(void* h, uint64_t s) { ((VHandle*)h)->v->SetVerificationSequence(s); }

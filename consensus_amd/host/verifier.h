@@ -45,6 +45,7 @@ class Backend {
     // register_key returns a slot >= 0, or -1 when the backend has no key registry (then callers
     // use verify() with the key carried in the tuple).
     virtual long register_key(const uint8_t q[64]) { (void)q; return -1; }
+    virtual uint64_t keyed_batches() { return 0; }      // test hook: how many verify_keyed batches ran
     virtual int verify_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap) {
         (void)rsh; (void)slots; (void)n; (void)bitmap; return -2;
     }
@@ -57,7 +58,7 @@ class Backend {
 };
 std::shared_ptr<Backend> make_sbv_backend(int device);     // sbv_init(device) + sbv_p256_verify_batch
 typedef int (*backend_fn)(const uint8_t* tuples, size_t n, uint8_t* bitmap, void* user);
-std::shared_ptr<Backend> make_callback_backend(backend_fn fn, void* user);
+std::shared_ptr<Backend> make_callback_backend(backend_fn fn, void* user, bool with_key_registry = false);
 
 struct CoalescerStats {
     uint64_t calls = 0;        // single-signature submissions
@@ -129,12 +130,13 @@ class Verifier {
 
  private:
     bool consenter_key(uint64_t id, uint8_t q[64], long* slot = nullptr);
-    bool client_key(const std::string& id, uint8_t q[64]);
+    bool client_key(const std::string& id, uint8_t q[64], long* slot = nullptr);
     void make_tuple(const uint8_t q[64], const bytes& msg, const bytes& sig_der, uint8_t out[160]);
     Status verify_one(const uint8_t q[64], const bytes& msg, const bytes& sig, long slot = -1);
     std::mutex mu_;
     std::map<uint64_t, bytes> consenters_;
     std::map<uint64_t, long> consenter_slot_;
+    std::map<std::string, long> client_slot_;       // backend key slot per client, -1 without a registry
     std::map<std::string, bytes> clients_;
     uint64_t seq_ = 0;
     VerifierOptions opt_;

@@ -30,7 +30,7 @@ def lib():
 class Harness:
     """A Verifier wired to a stand-in backend + N consenter signers + clients."""
 
-    def __init__(self, lib, oracle, n_nodes=4, fail_rc=0, wait_us=2000, cache=0):
+    def __init__(self, lib, oracle, n_nodes=4, fail_rc=0, wait_us=2000, cache=0, backend_kind=1):
         self.lib, self.batches, self.fail_rc = lib, [], fail_rc
 
         def backend(tuples, n, bitmap, _user):
@@ -41,7 +41,7 @@ class Harness:
             return 0
 
         self._cb = hostlib.BACKEND_FN(backend)          # keep alive
-        self.v = lib.sbvh_verifier_new(1, 0, self._cb, None, 4096, wait_us, cache)
+        self.v = lib.sbvh_verifier_new(backend_kind, 0, self._cb, None, 4096, wait_us, cache)
         self.nodes = []
         for i in range(n_nodes):
             s = lib.sbvh_signer_new(i + 1, hashlib.sha256(b"node%d" % i).digest())
@@ -225,6 +225,31 @@ def test_verify_proposal_batches_all_request_signatures(hx):
     assert hx.verify_proposal((prop[0], b"h", b"m", 7))[0] == INVALID        # verification sequence mismatch
     assert hx.verify_proposal((prop[0][:-1], b"h", b"m", 0))[0] == INVALID   # malformed payload
     assert hx.verify_proposal((hostlib.payload_encode([]), b"h", b"m", 0)) == (OK, [])
+
+
+def test_registered_client_and_consenter_keys_take_the_keyed_backend_path(lib, oracle):
+    """With a backend that has a key registry (libsbv: sbv_p256_register_keys), RegisterClient / RegisterConsenter take
+    key slots and VerifyProposal, VerifyRequest and VerifyConsenterSig ship r|s|hash + slot instead of full tuples;
+    verdicts and batching are unchanged."""
+    lib.sbvh_backend_keyed_batches.restype = ctypes.c_uint64
+    lib.sbvh_backend_keyed_batches.argtypes = [ctypes.c_void_p]
+    hx = Harness(lib, oracle, backend_kind=2, wait_us=10)
+    try:
+        reqs = [hx.request("alice%d" % (i % 3), "r%d" % i, payload=bytes([i])) for i in range(100)]
+        prop = (hostlib.payload_encode(reqs), b"h", b"m", 0)
+        hx.batches.clear()
+        st, infos = hx.verify_proposal(prop)
+        assert st == OK and len(infos) == 100 and hx.batches == [100]
+        assert lib.sbvh_backend_keyed_batches(hx.v) == 1
+        reqs[41] = hx.request("alice2", "r41", corrupt=True)
+        assert hx.verify_proposal((hostlib.payload_encode(reqs), b"h", b"m", 0))[0] == INVALID
+        assert hx.verify_request(hx.request("alice1", "solo"))[0] == OK
+        assert hx.verify_request(hx.request("alice1", "solo2", corrupt=True))[0] == INVALID
+        sig = hx.sign_proposal(2, prop, b"aux")
+        assert hx.verify_consenter_sig(sig, prop)[0] == OK
+        assert lib.sbvh_backend_keyed_batches(hx.v) >= 5
+    finally:
+        hx.close()
 
 
 def test_device_fault_is_unavailable_never_invalid(lib, oracle):
