@@ -254,10 +254,11 @@ static bool two_pass() {
     return v;
 }
 
-// Batches up to this size take the lanes-per-signature kernel: 8192 x 8 lanes = one wavefront on every SIMD.
+// Batches up to this size take the lanes-per-signature kernel: 32768 x 8 lanes = 4 wavefronts per SIMD, still
+// latency-bound (12 additions deep against 50 for the one-lane kernel at half a wavefront per SIMD).
 // SBV_COOP_MAX=0 switches it off.
 static size_t coop_max_batch() {
-    static const size_t v = [] { const char* e = getenv("SBV_COOP_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)8192; }();
+    static const size_t v = [] { const char* e = getenv("SBV_COOP_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)32768; }();
     return v;
 }
 

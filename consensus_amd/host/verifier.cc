@@ -1,5 +1,7 @@
 #include "verifier.h"
 
+#include <functional>
+
 #include <string.h>
 
 #include <atomic>
@@ -14,23 +16,96 @@ namespace sbvhost {
 namespace {
 // Host-side tuple preparation (SHA-256 of Msg, DER parse, digest binding) is ~1 us per signature
 // per core; for 10^4..10^6-signature batches it must not run on one thread or it — not the GPU —
-// bounds the batch.  Plain fork-join over hardware threads.
+// bounds the batch.  Fork-join over a persistent pool: creating threads per call costs
+// more than preparing a 10 000-request proposal does.
+class WorkerPool {
+ public:
+    static WorkerPool& get() { static WorkerPool p; return p; }
+    size_t size() const { return workers_.size(); }
+    // runs fn(k) for k = 0..jobs-1 on the pool and on the calling thread; returns when all are done
+    void run(size_t jobs, const std::function<void(size_t)>& fn) {
+        if (jobs == 0) return;
+        std::unique_lock<std::mutex> call(call_mu_);          // one fork-join at a time
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn; jobs_ = jobs; next_ = 0; pending_ = jobs; ++epoch_;
+        }
+        cv_work_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+ private:
+    WorkerPool() {
+        size_t n = std::thread::hardware_concurrency();
+        if (n == 0) n = 1;
+        if (n > 32) n = 32;
+        for (size_t i = 0; i + 1 < n; ++i) workers_.emplace_back([this] { loop(); });
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_work_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    void drain() {
+        for (;;) {
+            size_t k;
+            const std::function<void(size_t)>* fn;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!fn_ || next_ >= jobs_) return;
+                k = next_++;
+                fn = fn_;
+            }
+            (*fn)(k);
+            bool last;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                last = --pending_ == 0;
+            }
+            if (last) cv_done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_work_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+                if (stop_) return;
+                seen = epoch_;
+            }
+            drain();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_, call_mu_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t jobs_ = 0, next_ = 0, pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+};
+
 template <typename F>
 void parallel_chunks(size_t n, F fn) {
-    const size_t min_per_thread = 2048;
-    size_t threads = std::thread::hardware_concurrency();
-    if (threads == 0) threads = 1;
-    if (threads > 64) threads = 64;
-    if (n / min_per_thread < threads) threads = n / min_per_thread;
-    if (threads <= 1) { fn(0, n); return; }
-    std::vector<std::thread> th;
-    const size_t per = (n + threads - 1) / threads;
-    for (size_t t = 0; t < threads; ++t) {
-        const size_t lo = t * per, hi = lo + per < n ? lo + per : n;
-        if (lo >= hi) break;
-        th.emplace_back([=, &fn] { fn(lo, hi); });
-    }
-    for (auto& t : th) t.join();
+    const size_t min_per_job = 256;
+    WorkerPool& pool = WorkerPool::get();
+    size_t jobs = n / min_per_job;
+    const size_t max_jobs = 4 * (pool.size() + 1);
+    if (jobs > max_jobs) jobs = max_jobs;
+    if (jobs <= 1) { fn(0, n); return; }
+    const size_t per = (n + jobs - 1) / jobs;
+    const std::function<void(size_t)> job = [&](size_t k) {
+        const size_t lo = k * per, hi = lo + per < n ? lo + per : n;
+        if (lo < hi) fn(lo, hi);
+    };
+    pool.run(jobs, job);
 }
 }  // namespace
 

@@ -162,7 +162,7 @@ def test_registered_key_form_equals_generic_verdicts(gpu, oracle, golden_vectors
     gpu.clear_keys()
     vs = [v for v in golden_vectors if v["kind"] == "tuple"]
     blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
-    n = 9000                                    # > 8192 in total: the one-lane-per-signature kernel
+    n = 34000                                   # > 32768 in total: the one-lane-per-signature kernel
     tup = ctypes.create_string_buffer(160 * n)
     exp = ctypes.create_string_buffer((n + 7) // 8)
     oracle.sbvo_gen_batch(0x4B45, n, 37, 3, tup, exp, os.cpu_count() or 1)
@@ -177,9 +177,9 @@ def test_registered_key_form_equals_generic_verdicts(gpu, oracle, golden_vectors
     bad = [i for i in range(total) if got[i] != want[i]]
     assert not bad, bad[:10]
     assert got == sbv.bitmap_to_list(gpu.verify_batch(allt, total), total)
-    # batches <= 8192 take the latency kernel (8 lanes per signature, k_p256_verify_keyed_coop): the golden vectors
+    # batches <= 32768 take the latency kernel (8 lanes per signature, k_p256_verify_keyed_coop): the golden vectors
     # (first in the blob) and every ragged size around the 8-signatures-per-wavefront granularity
-    for m in (1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, len(vs), len(vs) + 777, 5000, 8192):
+    for m in (1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, len(vs), len(vs) + 777, 5000, 8192, 32768):
         gotm = sbv.bitmap_to_list(gpu.verify_batch_keyed(rsh[:96 * m], [reg[s] for s in slots[:m]], m), m)
         badm = [i for i in range(m) if gotm[i] != want[i]]
         assert not badm, (m, badm[:10])
