@@ -119,6 +119,31 @@ def test_full_batch_2_20_bitmap_equals_generator_and_checksum(gpu, oracle):
           f"d2h {t.d2h_us:.0f} us  -> {n / (t.prep_us + t.verify_us) :.2f} M verifies/s (kernels)")
 
 
+def test_batches_larger_than_one_launch_are_chunked(gpu):
+    """More tuples than one launch holds (2^21): both entries walk the batch in chunks, each chunk grouped by key on
+    its own; a chunk boundary that is not a multiple of 64 tuples away from the end must not disturb the bitmap."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import numpy as np
+    import torch
+    import synth
+    base_n = 1 << 20
+    tuples, valid = synth.gen_batch(0x5B7F2026, base_n)
+    n = (1 << 21) + (1 << 19) + 37
+    reps = -(-n // base_n)
+    big = np.tile(tuples.reshape(base_n, 160), (reps, 1))[:n].copy()
+    bits = np.tile(np.unpackbits(valid, bitorder="little")[:base_n], reps)[:n]
+    want = np.packbits(bits, bitorder="little")
+    out = np.zeros((n + 7) // 8, dtype=np.uint8)
+    gpu.verify_batch_ptr(big.ctypes.data, n, out.ctypes.data)
+    assert (out == want).all()
+    d_t = torch.from_numpy(big.reshape(-1)).cuda()
+    d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
+    gpu.verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (d_b.cpu().numpy() == want).all()
+
+
 def test_device_pointer_entry_with_torch(gpu, oracle):
     import torch
     n = 10000

@@ -17,6 +17,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hostlib  # noqa: E402
 
 lib = hostlib.load()
+
+
+class Timing(ctypes.Structure):          # include/sbv.h: sbv_timing
+    _fields_ = [("h2d_us", ctypes.c_double), ("prep_us", ctypes.c_double), ("verify_us", ctypes.c_double),
+                ("d2h_us", ctypes.c_double), ("total_us", ctypes.c_double), ("n", ctypes.c_uint64)]
+
+
+# libsbv.so is already in the process (libsbv_host.so links it): same handle, same context
+libsbv = ctypes.CDLL(os.path.join(ROOT, "consensus_amd", "libsbv.so"))
 cb = hostlib.BACKEND_FN(lambda *a: -1)
 threads = min(128, os.cpu_count() or 8)
 
@@ -25,6 +34,14 @@ def run(name, n_nodes, K, sequences, decisions, wait_us):
     v = lib.sbvh_verifier_new(0, 0, cb, None, 1 << 20, wait_us, 0)
     res = hostlib.ReplayResult()
     rc = lib.sbvh_replay(v, n_nodes, K, sequences, decisions, threads, ctypes.byref(res))
+    last = None
+    try:                        # device-side split of the LAST backend call of this configuration
+        tm = Timing()
+        if libsbv.sbv_last_timing(ctypes.byref(tm)) == 0:
+            last = {"n": tm.n, "h2d_us": tm.h2d_us, "prep_us": tm.prep_us, "verify_us": tm.verify_us, "d2h_us": tm.d2h_us,
+                    "total_us": tm.total_us}
+    except Exception as e:      # noqa: BLE001 - diagnostics only
+        last = {"error": repr(e)}
     lib.sbvh_verifier_free(v)
     q, f = ctypes.c_int(), ctypes.c_int()
     lib.sbvh_compute_quorum(n_nodes, ctypes.byref(q), ctypes.byref(f))
@@ -36,7 +53,7 @@ def run(name, n_nodes, K, sequences, decisions, wait_us):
            "batch_sigs_per_s": res.batch_tuples / (res.batch_total_us * 1e-6) if res.batch_total_us else None,
            "amortised_us_per_decision": res.batch_total_us / decisions if decisions else None,
            "proposals_with_quorum": res.proposals_with_quorum, "backend_batches": res.backend_batches,
-           "max_backend_batch": res.max_backend_batch, "setup_s": res.setup_s}
+           "max_backend_batch": res.max_backend_batch, "setup_s": res.setup_s, "last_backend_call": last}
     print(json.dumps(out), flush=True)
 
 
