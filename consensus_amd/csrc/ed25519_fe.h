@@ -137,6 +137,14 @@ SBV_HD void fe25_inv(fe25& out, const fe25& z) {
 }
 
 // 32 little-endian bytes given as 8 little-endian dwords -> field element (bit 255 cleared by the caller)
+// The same inverse by division steps (modinv30.h): the input is frozen to [0, p) first; plain integers, so
+// no domain conversion.  0 -> 0, like z^(p-2).
+SBV_HD void fe25_inv_gcd(fe25& out, const fe25& z) {
+    fe25 t;
+    fe25_freeze(t, z);
+    modinv30(out, t, modinfo30_25519());
+}
+
 SBV_HD void fe25_from_words(fe25& r, const u32 w[8]) {
     SBV_UNROLL
     for (int i = 0; i < 8; ++i) r.v[i] = w[i];

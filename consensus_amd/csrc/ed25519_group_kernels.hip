@@ -1,0 +1,138 @@
+// ed25519_group_kernels.hip — the grouped step of the Ed25519 variant (ed25519_group.h), same stream layout
+// as the P-256 one (p256_group_kernels.hip):
+//
+//   stream: wait(split) { one-lane kernel over the ungrouped list + [S]B for every tuple } wait(tables c) Q-phase chunk c ... pack
+//   side_a: insert assign | bases chunk 0 | bases chunk 1 | ...
+//   side_b:        wait(assign) split | wait(bases c) windows chunk c ...
+//
+// No stage A here (Ed25519 has no scalar inversion), so the G phase starts at once.
+#include <hip/hip_runtime.h>
+
+#include "ed25519_group.h"
+#include "ed25519_kernels.h"
+#include "group_kernels_common.h"
+#include "p256_kernels.h"
+
+namespace sbv {
+
+__global__ __launch_bounds__(256) void k_ed_group_insert(const uint8_t* __restrict__ tuples, size_t n, GroupState g) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ed_group_insert_lane(tuples, i, g);
+}
+
+// Same result as ed_group_split_lane (compaction: group_split_emit)
+__global__ __launch_bounds__(256) void k_ed_group_split(const uint8_t* __restrict__ tuples, size_t n, GroupState g,
+                                                        uint8_t* __restrict__ acc) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool active = i < n;
+    u32 s = SBV_GROUP_NONE;
+    if (active) s = g.slot_of[g.rep[i]];
+    bool ung = active && s == SBV_GROUP_NONE;
+    const bool grp = active && s != SBV_GROUP_NONE;
+    bool key_rejected = false;
+    if (ung) {
+        ept A;
+        if (!ed_tuple_key_load(tuples, i, A)) { acc[i] = 0; ung = false; key_rejected = true; }
+    }
+    group_split_emit(i, s, ung, grp, key_rejected, g);
+}
+
+__global__ __launch_bounds__(64) void k_ed_keytab_bases(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jbases,
+                                                        uint8_t* __restrict__ valid, int j_first, int j_last) {
+    const u32 k = blockIdx.x * 64 + threadIdx.x;
+    if (k < group_count(g)) ed_keytab_bases_lane(tuples, k, g, jbases, valid, j_first, j_last);
+}
+
+// lanes = groups x j_count x parts
+__global__ __launch_bounds__(64) void k_ed_keytab_window(GroupState g, const u32* __restrict__ jbases, u32* __restrict__ tmp,
+                                                         aniels* __restrict__ ktab, int j_first, int j_count, int parts) {
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 part = lane % (u32)parts;
+    const u32 kw = lane / (u32)parts;
+    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
+    if (key >= group_count(g)) return;
+    const size_t w = (size_t)key * SBV_ED_KEY_WINDOWS + j;
+    ed_keytab_window_lane(jbases + w * SBV_ED_JBASE_DWORDS, (int)part, parts,
+                          tmp + w * (SBV_ED_KEY_PER_WINDOW * 32) + (size_t)part * (SBV_ED_KEY_PER_WINDOW / parts) * 32,
+                          ktab + w * SBV_ED_KEY_PER_WINDOW);
+}
+
+// Blocks [0, generic_blocks): the one-lane kernel (ed25519_verify_lane) over the ungrouped list, at the same
+// 3 waves/SIMD budget; remaining blocks: [S]B for every tuple of the batch.
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_ed_gphase_generic(const uint8_t* __restrict__ tuples, size_t n, GroupState g,
+                                                                          u32* __restrict__ qtab, const aniels* __restrict__ btab,
+                                                                          u32* __restrict__ gacc, size_t cap, uint8_t* __restrict__ okb,
+                                                                          uint8_t* __restrict__ acc, unsigned generic_blocks) {
+    if (blockIdx.x < generic_blocks) {
+        const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+        if (L >= g.counters[2]) return;
+        const u32 t = g.ung_idx[L];
+        acc[t] = ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab + (size_t)L * (SBV_ED_QTAB_ENTRIES * 32), btab) ? 1 : 0;
+        return;
+    }
+    const size_t i = (size_t)(blockIdx.x - generic_blocks) * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (i < n) ed_gphase_lane(tuples, i, btab, gacc, cap, okb);
+}
+
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_ed_qphase(const uint8_t* __restrict__ tuples, GroupState g,
+                                                                  const aniels* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
+                                                                  u32* __restrict__ gacc, size_t cap, const uint8_t* __restrict__ okb,
+                                                                  uint8_t* __restrict__ acc, int j0, int j1, int last) {
+    const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (L >= g.counters[1]) return;
+    const u32 t = g.grp_idx[L];
+    const bool v = ed_qphase_lane(tuples, t, g.slots[t], group_count(g), ktab, kvalid, gacc, cap, okb, j0, j1, last != 0);
+    if (last) acc[t] = v ? 1 : 0;
+}
+
+hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, const GroupBuffers& b, const EdGroupBuffers& eb,
+                                         u32* d_qtab, const aniels* d_btab, uint8_t* d_bitmap, hipStream_t stream,
+                                         const GroupSync& y) {
+    if (n == 0) return hipSuccess;
+    GroupState g;
+    g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
+    g.counters = b.counters; g.grp_idx = b.grp_idx; g.ung_idx = b.ung_idx; g.slots = b.slots;
+    g.max_groups = b.max_groups;
+    group_set_threshold(g, b.min_count);
+    const int chunks = y.chunks < 1 ? 1 : (y.chunks > SBV_GROUP_MAX_CHUNKS ? SBV_GROUP_MAX_CHUNKS : y.chunks);
+    int parts = SBV_KEYTAB_PARTS_DEFAULT;
+    if (y.parts == 2 || y.parts == 4 || y.parts == 8 || y.parts == 16) parts = y.parts;
+    hipError_t e;
+#define SBV_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
+    // ev_fork was recorded by the caller on `stream` before anything of this batch (see the P-256 launcher)
+    SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_fork, 0));
+    SBV_TRY(hipMemsetAsync(b.ht, 0, ((size_t)b.ht_mask + 1) * sizeof(u32), y.side_a));
+    SBV_TRY(hipMemsetAsync(b.cnt, 0, n * sizeof(u32), y.side_a));
+    SBV_TRY(hipMemsetAsync(b.counters, 0, 4 * sizeof(u32), y.side_a));
+    const unsigned gn = (unsigned)((n + 255) / 256);
+    const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
+    hipLaunchKernelGGL(k_ed_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
+    hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, n, g);
+    SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
+    SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
+    hipLaunchKernelGGL(k_ed_group_split, dim3(gn), dim3(256), 0, y.side_b, d_tuples, n, g, b.acc);
+    SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
+    SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
+    hipLaunchKernelGGL(k_ed_gphase_generic, dim3(2 * gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, n, g, d_qtab, d_btab, b.gacc,
+                       b.gacc_cap, eb.okb, b.acc, gv);
+    for (int c = 0; c < chunks; ++c) {
+        const int j_first = SBV_ED_KEY_WINDOWS * c / chunks, j_end = SBV_ED_KEY_WINDOWS * (c + 1) / chunks;
+        const int j_count = j_end - j_first;
+        hipLaunchKernelGGL(k_ed_keytab_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jbases, b.kvalid,
+                           j_first, j_end - 1);
+        SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
+        SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[c], 0));
+        const size_t wl = (size_t)b.max_groups * j_count * parts;
+        hipLaunchKernelGGL(k_ed_keytab_window, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.jbases, b.tmp, eb.ktab,
+                           j_first, j_count, parts);
+        SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
+        SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
+        hipLaunchKernelGGL(k_ed_qphase, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, b.kvalid, b.gacc, b.gacc_cap,
+                           eb.okb, b.acc, j_first, j_end, c + 1 == chunks ? 1 : 0);
+    }
+    hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
+#undef SBV_TRY
+    return hipGetLastError();
+}
+
+}  // namespace sbv

@@ -98,17 +98,20 @@ SBV_HD bool tuple_key_load(const uint8_t* tuples, size_t idx, fe& x, fe& y) {
     return lt256(qx, p_) && lt256(qy, p_) && pt_on_curve(x, y);
 }
 
-SBV_HD void group_insert_lane(const uint8_t* tuples, size_t i, const GroupState& g) {
-    const u32* k = tuple_key_words(tuples, i);
-    u32 w[16];
+// Key location of a tuple format: STRIDE bytes per tuple, key = WORDS dwords at byte OFF (16-byte aligned).
+// P-256: 160 / 96 / 16 (Qx|Qy); Ed25519: 128 / 64 / 8 (A_enc).
+template <int STRIDE, int OFF, int WORDS>
+SBV_HD void group_insert_lane_t(const uint8_t* tuples, size_t i, const GroupState& g) {
+    const u32* k = reinterpret_cast<const u32*>(tuples + i * STRIDE + OFF);
+    u32 w[WORDS];
     SBV_UNROLL
-    for (int j = 0; j < 16; ++j) w[j] = k[j];
+    for (int j = 0; j < WORDS; ++j) w[j] = k[j];
     // every key word goes into the hash: the batch's corrupted tuples are single-bit variants of the signers'
     // keys, and a hash that skips words sends each variant down its original's probe chain (measured: ~30
     // probes per wavefront, 1 ms per batch)
     u32 h = 0x9E3779B1u;
     SBV_UNROLL
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < WORDS; ++j) {
         h = (h ^ w[j]) * 0x85EBCA77u;
         h ^= h >> 15;
     }
@@ -120,16 +123,17 @@ SBV_HD void group_insert_lane(const uint8_t* tuples, size_t i, const GroupState&
         u32 v = g.ht[slot];
         if (v == 0) v = SBV_ATOMIC_CAS(&g.ht[slot], 0u, (u32)i + 1u);
         if (v == 0) break;                                   // claimed: this tuple represents its key
-        const u32* o = tuple_key_words(tuples, v - 1);
+        const u32* o = reinterpret_cast<const u32*>(tuples + (size_t)(v - 1) * STRIDE + OFF);
         u32 diff = 0;
         SBV_UNROLL
-        for (int j = 0; j < 16; ++j) diff |= o[j] ^ w[j];
+        for (int j = 0; j < WORDS; ++j) diff |= o[j] ^ w[j];
         if (diff == 0) { mine = v - 1; break; }
         slot = (slot + 1) & g.ht_mask;
     }
     g.rep[i] = mine;
     if (group_sampled((u32)i, g.sample_mask)) SBV_ATOMIC_ADD(&g.cnt[mine], 1u);
 }
+SBV_HD void group_insert_lane(const uint8_t* tuples, size_t i, const GroupState& g) { group_insert_lane_t<160, 96, 16>(tuples, i, g); }
 
 SBV_HD void group_assign_lane(size_t i, const GroupState& g) {
     u32 s = SBV_GROUP_NONE;

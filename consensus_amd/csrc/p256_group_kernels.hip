@@ -11,7 +11,7 @@
 // Launch sizes that depend on device-side counters use the upper bound; surplus lanes exit at once.
 #include <hip/hip_runtime.h>
 
-#include "p256_group.h"
+#include "group_kernels_common.h"
 #include "p256_kernels.h"
 
 namespace sbv {
@@ -20,16 +20,8 @@ __global__ __launch_bounds__(256) void k_group_insert(const uint8_t* __restrict_
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) group_insert_lane(tuples, i, g);
 }
-__global__ __launch_bounds__(256) void k_group_assign(size_t n, GroupState g) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) group_assign_lane(i, g);
-}
-// Same result as group_split_lane, but with ONE atomic per workgroup and list instead of one per lane:
-// atomicAdds on one word serialise at ~11 ns each on MI355X (a million of them: 11 ms per batch, measured);
-// ballots + prefix popcounts + a 4-entry LDS sum need 2 x n/256 of them.
+// Same result as group_split_lane (compaction: group_split_emit)
 __global__ __launch_bounds__(256) void k_group_split(const uint8_t* __restrict__ tuples, size_t n, GroupState g, uint8_t* __restrict__ acc) {
-    __shared__ u32 sh_cnt[3][4];
-    __shared__ u32 sh_base[2];
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool active = i < n;
     u32 s = SBV_GROUP_NONE;
@@ -41,33 +33,7 @@ __global__ __launch_bounds__(256) void k_group_split(const uint8_t* __restrict__
         fe x, y;
         if (!tuple_key_load(tuples, i, x, y)) { acc[i] = 0; ung = false; key_rejected = true; }
     }
-    const unsigned long long mr = __ballot(key_rejected);
-    const unsigned long long mu = __ballot(ung), mg = __ballot(grp);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) { sh_cnt[0][wave] = (u32)__popcll(mu); sh_cnt[1][wave] = (u32)__popcll(mg); sh_cnt[2][wave] = (u32)__popcll(mr); }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const u32 tu = sh_cnt[0][0] + sh_cnt[0][1] + sh_cnt[0][2] + sh_cnt[0][3];
-        const u32 tg = sh_cnt[1][0] + sh_cnt[1][1] + sh_cnt[1][2] + sh_cnt[1][3];
-        sh_base[0] = tu ? atomicAdd(&g.counters[2], tu) : 0u;
-        sh_base[1] = tg ? atomicAdd(&g.counters[1], tg) : 0u;
-        const u32 tr = sh_cnt[2][0] + sh_cnt[2][1] + sh_cnt[2][2] + sh_cnt[2][3];
-        if (tr) atomicAdd(&g.counters[3], tr);
-    }
-    __syncthreads();
-    u32 base_u = sh_base[0], base_g = sh_base[1];
-    for (int w = 0; w < wave; ++w) { base_u += sh_cnt[0][w]; base_g += sh_cnt[1][w]; }
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (ung) g.ung_idx[base_u + (u32)__popcll(mu & below)] = (u32)i;
-    if (grp) {
-        g.slots[i] = s;
-        g.grp_idx[base_g + (u32)__popcll(mg & below)] = (u32)i;
-    }
-}
-
-__device__ __forceinline__ u32 group_count(const GroupState& g) {
-    const u32 c = g.counters[0];
-    return c < g.max_groups ? c : g.max_groups;
+    group_split_emit(i, s, ung, grp, key_rejected, g);
 }
 
 __global__ __launch_bounds__(64) void k_keytab_bases(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jbases,
@@ -127,18 +93,6 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_verify_keyed_q(Scratch 
     const u32 t = g.grp_idx[L];
     const bool v = verify_lane_keyed_q(s, t, g.slots[t], group_count(g), ktab, kvalid, gacc, j0, j1, last != 0);
     if (last) acc[t] = v ? 1 : 0;
-}
-
-__global__ __launch_bounds__(256) void k_pack_bitmap(const uint8_t* __restrict__ acc, size_t n, uint8_t* __restrict__ bitmap) {
-    const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;           // bitmap byte
-    if (b >= ((n + 7) >> 3)) return;
-    u32 v = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const size_t i = b * 8 + k;
-        if (i < n && acc[i]) v |= 1u << k;
-    }
-    bitmap[b] = (uint8_t)v;
 }
 
 // Enqueue stage B with in-step grouping.  Stage A (k_p256_prep) is already enqueued on `stream`.

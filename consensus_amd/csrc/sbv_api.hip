@@ -46,6 +46,7 @@ struct Context {
     sbv_timing timing{};
     // in-step key grouping (p256_group.h)
     sbv::GroupBuffers grp;
+    sbv::EdGroupBuffers edgrp;          // Ed25519 grouped step: per-batch combs of -A (the rest is shared with grp)
     bool group_enabled = true;
     size_t group_min_batch = 262144;    // below this the ~3.5 ms table-building latency costs more than it saves
     u32 group_min_count = 64, group_max = 2048;
@@ -142,6 +143,9 @@ void free_group_buffers(Context& c) {
     void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.jbases, b.ktab, b.kvalid, b.tmp, b.acc, b.gacc};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     b = sbv::GroupBuffers();
+    if (c.edgrp.ktab) (void)hipFree(c.edgrp.ktab);
+    if (c.edgrp.okb) (void)hipFree(c.edgrp.okb);
+    c.edgrp = sbv::EdGroupBuffers();
 }
 
 int ensure_group_buffers(Context& c, size_t n) {
@@ -163,7 +167,7 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ung_idx, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.slots, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jbases, G * SBV_GTAB_WINDOWS * (size_t)40 * sizeof(u32)));   // 40 dwords = one Jacobian base (p256_group.h)
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 24 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 32 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride; 24 words (P-256) or 32 (Ed25519) per tuple
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ktab, G * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, G));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tmp, G * SBV_GTAB_WINDOWS * (size_t)(SBV_GTAB_PER_WINDOW * 32) * sizeof(u32)));
@@ -173,6 +177,35 @@ int ensure_group_buffers(Context& c, size_t n) {
     b.min_count = c.group_min_count;
     b.cap = cap;
     b.gacc_cap = c.cap;
+    return SBV_OK;
+}
+
+int ensure_ed_group_buffers(Context& c, size_t n) {
+    int rc = ensure_group_buffers(c, n);
+    if (rc != SBV_OK) return rc;
+    sbv::EdGroupBuffers& e = c.edgrp;
+    if (e.cap >= c.grp.cap && e.max_groups == c.grp.max_groups) return SBV_OK;
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    if (e.ktab) (void)hipFree(e.ktab);
+    if (e.okb) (void)hipFree(e.okb);
+    e = sbv::EdGroupBuffers();
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&e.ktab, (size_t)c.grp.max_groups * SBV_ED_BTAB_ENTRIES * sizeof(sbv::aniels)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&e.okb, c.grp.cap));
+    e.cap = c.grp.cap;
+    e.max_groups = c.grp.max_groups;
+    return SBV_OK;
+}
+
+// one chunk (n <= cap) of Ed25519 tuples on `stream`: grouped step or the one-lane kernel
+int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream) {
+    if (c.group_enabled && n >= c.group_min_batch) {
+        const int rc = ensure_ed_group_buffers(c, n);
+        if (rc != SBV_OK) return rc;
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
+        HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify_grouped(d_tuples, n, c.grp, c.edgrp, c.d_qtab, c.d_btab, d_bitmap, stream, c.gsync));
+        return SBV_OK;
+    }
+    HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify(d_tuples, n, c.d_qtab, c.d_btab, d_bitmap, stream));
     return SBV_OK;
 }
 
@@ -603,7 +636,7 @@ extern "C" int sbv_ed25519_verify_batch_dev(const void* d_tuples, size_t n, void
             end = c.prof_events[c.prof_used + 2];
             c.prof_used += 3;
         }
-        HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify(src + off * 128, m, c.d_qtab, c.d_btab, dst + off / 8, stream));
+        if ((rc = enqueue_ed25519(c, src + off * 128, m, dst + off / 8, stream)) != SBV_OK) return rc;
         if (end) HIP_TRY(SBV_EDEVICE, hipEventRecord(end, stream));
     }
     HIP_TRY(SBV_EDEVICE, hipEventRecord(c.busy, stream));
@@ -630,7 +663,7 @@ extern "C" int sbv_ed25519_verify_batch(const uint8_t* tuples, size_t n, uint8_t
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[0], c.stream));
         HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_tuples, tuples + off * 128, m * 128, hipMemcpyHostToDevice, c.stream));
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
-        HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify(c.d_tuples, m, c.d_qtab, c.d_btab, c.d_bitmap, c.stream));
+        if ((rc = enqueue_ed25519(c, c.d_tuples, m, c.d_bitmap, c.stream)) != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
         HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.h_bitmap, c.d_bitmap, (m + 7) / 8, hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[4], c.stream));

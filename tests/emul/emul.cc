@@ -12,6 +12,7 @@
 
 #include "../../consensus_amd/csrc/p256_core.h"
 #include "../../consensus_amd/csrc/ed25519_core.h"
+#include "../../consensus_amd/csrc/ed25519_group.h"
 #include "../../consensus_amd/csrc/sha256_dev.h"
 #include "../../consensus_amd/csrc/p256_group.h"
 
@@ -229,6 +230,59 @@ void sbve_ed25519_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap)
         if (ed25519_verify_lane(EdWords{tuples + 128 * i}, qtab, btab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
     free(qtab);
 }
+// grouped form (ed25519_group.h), emulated sequentially with the device pipeline's chunking.
+// stats_out[0..3] = groups, grouped tuples, ungrouped tuples, ungrouped tuples rejected for their key.
+void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8_t* bitmap, u32 min_count, u32 max_groups,
+                                       u32 ht_bits, int chunks, int parts, u32* stats_out) {
+    size_t cap = (n + 63) & ~(size_t)63;
+    if (cap == 0) cap = 64;
+    uint8_t* tuples = (uint8_t*)aligned_alloc(16, cap * 128);           // the kernels read 16-byte vectors
+    memcpy(tuples, tuples_in, n * 128);
+    std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(max_groups ? max_groups : 1), counters(4, 0),
+        grp_idx(cap), ung_idx(cap), slots(cap);
+    GroupState g{};
+    g.ht = ht.data(); g.ht_mask = (u32)(((size_t)1 << ht_bits) - 1); g.rep = rep.data(); g.cnt = cnt.data(); g.slot_of = slot_of.data();
+    g.group_rep = group_rep.data(); g.counters = counters.data(); g.grp_idx = grp_idx.data(); g.ung_idx = ung_idx.data();
+    g.slots = slots.data(); g.max_groups = max_groups;
+    group_set_threshold(g, min_count);
+    std::vector<uint8_t> accb(cap, 0xEE), okb(cap, 0);
+    for (size_t i = 0; i < n; ++i) ed_group_insert_lane(tuples, i, g);
+    for (size_t i = 0; i < n; ++i) group_assign_lane(i, g);
+    for (size_t i = 0; i < n; ++i) ed_group_split_lane(tuples, i, g, accb.data());
+    const u32 ngroups = counters[0] < max_groups ? counters[0] : max_groups;
+    std::vector<u32> gacc(32 * cap);
+    for (size_t i = 0; i < n; ++i) ed_gphase_lane(tuples, i, btab(), gacc.data(), cap, okb.data());
+    const size_t ng1 = ngroups ? ngroups : 1;
+    u32* jbases = (u32*)aligned_alloc(16, ng1 * SBV_ED_KEY_WINDOWS * SBV_ED_JBASE_DWORDS * 4);
+    aniels* ktab = (aniels*)aligned_alloc(64, ng1 * SBV_ED_KEYTAB_ENTRIES * sizeof(aniels));
+    std::vector<uint8_t> kvalid(ng1, 0);
+    u32* tmpa = (u32*)aligned_alloc(16, SBV_ED_KEY_PER_WINDOW * 32 * 4);
+    memset(bitmap, 0, (n + 7) / 8);
+    for (int c = 0; c < chunks; ++c) {
+        const int j_first = SBV_ED_KEY_WINDOWS * c / chunks, j_end = SBV_ED_KEY_WINDOWS * (c + 1) / chunks;
+        for (u32 k = 0; k < ngroups; ++k) ed_keytab_bases_lane(tuples, k, g, jbases, kvalid.data(), j_first, j_end - 1);
+        for (u32 k = 0; k < ngroups; ++k)
+            for (int j = j_first; j < j_end; ++j)
+                for (int part = 0; part < parts; ++part) {
+                    const size_t w = (size_t)k * SBV_ED_KEY_WINDOWS + j;
+                    ed_keytab_window_lane(jbases + w * SBV_ED_JBASE_DWORDS, part, parts, tmpa, ktab + w * SBV_ED_KEY_PER_WINDOW);
+                }
+        const bool last = c + 1 == chunks;
+        for (u32 L = 0; L < counters[1]; ++L) {
+            const u32 t = grp_idx[L];
+            const bool v = ed_qphase_lane(tuples, t, slots[t], ngroups, ktab, kvalid.data(), gacc.data(), cap, okb.data(), j_first, j_end, last);
+            if (last && v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+        }
+    }
+    u32* qtab = (u32*)aligned_alloc(16, SBV_ED_QTAB_ENTRIES * 32 * 4);
+    for (u32 L = 0; L < counters[2]; ++L) {
+        const u32 t = ung_idx[L];
+        if (ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab, btab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+    }
+    free(qtab); free(tmpa); free(ktab); free(jbases); free(tuples);
+    if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }
+}
+void sbve_fe25_inv_gcd(const u32* a, u32* out) { fe25 x, z; memcpy(&x, a, 32); fe25_inv_gcd(z, x); memcpy(out, &z, 32); }
 void sbve_fe25_mul(const u32* a, const u32* b, u32* out) { fe25 x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe25_mul(z, x, y); memcpy(out, &z, 32); }
 void sbve_fe25_sqr(const u32* a, u32* out) { fe25 x, z; memcpy(&x, a, 32); fe25_sqr(z, x); memcpy(out, &z, 32); }
 void sbve_fe25_add(const u32* a, const u32* b, u32* out) { fe25 x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe25_add(z, x, y); memcpy(out, &z, 32); }

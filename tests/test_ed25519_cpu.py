@@ -85,3 +85,46 @@ def test_device_algorithm_on_golden_vectors_and_random_batch(emul, oracle, ed_ve
     emul.sbve_ed25519_verify_batch(tup.raw, m, bm)
     assert bm.raw == exp.raw
     assert sum(_bits(exp.raw, m)) == m - m // 3
+
+
+def test_grouped_by_key_inside_the_batch_matches_plain_kernel(emul, oracle, ed_vectors):
+    """ed25519_group.h: hash grouping by A + per-batch combs of -A + [S]B / [k](-A) phases == the one-lane verdicts,
+    on the golden vectors (non-canonical and small-order keys, S >= L, ...), a seeded batch, an undecompressable key
+    that repeats, and across chunk counts / lanes per window / thresholds (sampled and exact counts)."""
+    emul.sbve_ed25519_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32,
+                                                       ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    oracle.sbvo_ed25519_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int]
+    blob = _tuples(ed_vectors)
+    m = 900
+    tup = ctypes.create_string_buffer(128 * m)
+    exp = ctypes.create_string_buffer((m + 7) // 8)
+    oracle.sbvo_ed25519_gen_batch(0xED25, m, 7, 5, tup, exp, 4)
+    # a key that is not a point (y = 2: x^2 = 3 / (4d + 1) is a non-residue?) -- find one, then repeat it 40 times
+    bad_key = None
+    for y in range(2, 60):
+        cand = y.to_bytes(32, "little")
+        if ed.decompress(cand) is None:
+            bad_key = cand
+            break
+    assert bad_key is not None
+    t0 = bytearray(tup.raw[:128])
+    t0[64:96] = bad_key
+    allt = blob + tup.raw + bytes(t0) * 40
+    total = len(allt) // 128
+    want = [v["accept"] for v in ed_vectors] + _bits(exp.raw, m) + [False] * 40
+    stats = (ctypes.c_uint32 * 4)()
+    for min_count, max_groups, ht_bits, chunks, parts in [(8, 64, 12, 2, 4), (8, 64, 12, 1, 8), (64, 64, 12, 4, 16), (1, 4096, 12, 3, 2),
+                                                          (8, 3, 12, 2, 4), (2, 64, 11, 2, 4), (10**6, 64, 12, 2, 4)]:
+        bm = ctypes.create_string_buffer((total + 7) // 8)
+        emul.sbve_ed25519_verify_batch_grouped(allt, total, bm, min_count, max_groups, ht_bits, chunks, parts, stats)
+        got = _bits(bm.raw, total)
+        bad = [i for i in range(total) if got[i] != want[i]]
+        assert not bad, (min_count, max_groups, ht_bits, chunks, parts, bad[:8])
+        assert stats[1] + stats[2] + stats[3] == total
+        if min_count == 8 and max_groups == 64:
+            assert stats[0] >= 8 and stats[1] > 800
+        if max_groups == 3:
+            assert stats[0] == 3
+        if min_count == 10**6:
+            assert stats[0] == 0 and stats[3] >= 40

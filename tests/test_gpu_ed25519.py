@@ -68,3 +68,48 @@ def test_full_batch_2_20(gpu, oracle):
     tm = gpu.last_timing()
     print(f"\n[ed25519 2^20] h2d {tm.h2d_us:.0f} us  verify {tm.verify_us:.0f} us -> {n / tm.verify_us:.1f} M verifies/s (kernel); "
           f"roofline: {128.125 * n / (tm.verify_us * 1e-6) / 1e9:.2f} GB/s algorithmic of 8000")
+
+
+def test_in_step_key_grouping_equals_plain_kernel(gpu, oracle):
+    """ed25519_group.h through the C-ABI: grouping by A, per-batch combs of -A, [S]B / [k](-A) phases — verdicts must
+    equal the one-lane kernel's on the golden vectors (small-order / non-canonical keys, S >= L), a seeded batch and a
+    key that is not a point repeated 40 times, in every configuration of thresholds and table slots."""
+    vs = json.load(open(os.path.join(GOLDEN, "ed25519_vectors.json")))["vectors"]
+    blob = b"".join(ed.pack_tuple(bytes.fromhex(v["pk"]), bytes.fromhex(v["msg"]), bytes.fromhex(v["sig"])) for v in vs)
+    m = 3000
+    tup, exp = _gen(oracle, 0xED25, m, 9, 5)
+    bad_key = next(y.to_bytes(32, "little") for y in range(2, 60) if ed.decompress(y.to_bytes(32, "little")) is None)
+    t0 = bytearray(tup.raw[:128]); t0[64:96] = bad_key
+    allt = blob + tup.raw + bytes(t0) * 40
+    total = len(allt) // 128
+    want = [v["accept"] for v in vs] + sbv.bitmap_to_list(exp.raw, m) + [False] * 40
+    try:
+        gpu.set_grouping(False)
+        plain = sbv.bitmap_to_list(gpu.ed25519_verify_batch(allt, total), total)
+        assert plain == want
+        for min_count, max_groups in [(8, 64), (1, 4096), (8, 3), (64, 64), (1000000, 64)]:
+            gpu.set_grouping(True, 1, min_count, max_groups)
+            got = sbv.bitmap_to_list(gpu.ed25519_verify_batch(allt, total), total)
+            bad = [i for i in range(total) if got[i] != want[i]]
+            assert not bad, (min_count, max_groups, bad[:8])
+    finally:
+        gpu.set_grouping(True, 131072, 64, 2048)
+
+
+def test_grouped_vs_plain_full_batch(gpu, oracle):
+    """2^20 signatures, 1024 keys: the grouped step (default at this size) and the one-lane kernel give the generator's
+    verdicts; prints both kernel times."""
+    n = 1 << 20
+    tup, exp = _gen(oracle, 0x5B7F2026, n, 1024, 8)
+    times = {}
+    try:
+        for mode in (True, False):
+            gpu.set_grouping(mode, 131072, 64, 2048)
+            got = ctypes.create_string_buffer(n // 8)
+            sbv._check(sbv.load().sbv_ed25519_verify_batch(ctypes.addressof(tup), n, ctypes.addressof(got)))
+            assert got.raw == exp.raw, mode
+            times[mode] = gpu.last_timing().verify_us
+    finally:
+        gpu.set_grouping(True, 131072, 64, 2048)
+    print(f"\n[ed25519 2^20] grouped {times[True]:.0f} us ({n / times[True]:.1f} M/s) | one lane per signature {times[False]:.0f} us "
+          f"({n / times[False]:.1f} M/s)")
