@@ -7,7 +7,7 @@
 // exceptional cases.  Grouping state, sampling, slot assignment: GroupState / group_assign_lane of
 // p256_group.h; the key is the 32-byte A_enc at byte 64 of the 128-byte tuple R | S | A | k.
 //
-//   ed_group_split      compaction; ungrouped tuples whose A is not a point are rejected on the spot
+//   ed_group_split      compaction only (no key filter: see below)
 //   ed_keytab_bases     per grouped key: decompress, negate, 2^(8j) * (-A), j = 0..31 (extended coordinates)
 //   ed_keytab_window    per (key, window, part): the affine-Niels multiples, Montgomery-trick normalised
 //   ed_gphase           [S]B for every tuple + the S < L, k < L checks
@@ -38,15 +38,13 @@ SBV_HD bool ed_tuple_key_load(const uint8_t* tuples, size_t idx, ept& A) {
     return ed_decompress(A, pk);
 }
 
-SBV_HD bool ed_group_split_lane(const uint8_t* tuples, size_t i, const GroupState& g, uint8_t* acc) {
+// Unlike the P-256 split there is no key filter here: decompressing A is a ~270-multiplication square root, and
+// because nearly every wavefront holds at least one ungrouped lane the filter made the split cost as much as the
+// whole [S]B phase (1.1 ms, measured) — while about half of all random 32-byte strings ARE points, so it could
+// not empty the ungrouped list anyway.  Undecompressable keys are rejected by the one-lane kernel.
+SBV_HD bool ed_group_split_lane(size_t i, const GroupState& g) {
     const u32 s = g.slot_of[g.rep[i]];
     if (s == SBV_GROUP_NONE) {
-        ept A;
-        if (!ed_tuple_key_load(tuples, i, A)) {
-            acc[i] = 0;
-            SBV_ATOMIC_ADD(&g.counters[3], 1u);
-            return false;
-        }
         g.ung_idx[SBV_ATOMIC_ADD(&g.counters[2], 1u)] = (u32)i;
     } else {
         g.slots[i] = s;

@@ -1,11 +1,13 @@
 // ed25519_group_kernels.hip — the grouped step of the Ed25519 variant (ed25519_group.h), same stream layout
 // as the P-256 one (p256_group_kernels.hip):
 //
-//   stream: wait(split) { one-lane kernel over the ungrouped list + [S]B for every tuple } wait(tables c) Q-phase chunk c ... pack
-//   side_a: insert assign | bases chunk 0 | bases chunk 1 | ...
+//   stream: [S]B for every tuple ........ wait(split, tables c) Q-phase chunk c ... wait(generic) pack
+//   side_a: insert assign | bases chunk 0 | bases chunk 1 | ... | wait(split) one-lane kernel over the ungrouped list
 //   side_b:        wait(assign) split | wait(bases c) windows chunk c ...
 //
-// No stage A here (Ed25519 has no scalar inversion), so the G phase starts at once.
+// No stage A here (Ed25519 has no scalar inversion), so the G phase starts at once.  Unlike P-256 the ungrouped
+// list is never empty on the headline-shaped batch (half of all corrupted keys still decompress), so its 2.5 ms
+// chain runs on side_a where it gates only the final pack.
 #include <hip/hip_runtime.h>
 
 #include "ed25519_group.h"
@@ -21,20 +23,12 @@ __global__ __launch_bounds__(256) void k_ed_group_insert(const uint8_t* __restri
 }
 
 // Same result as ed_group_split_lane (compaction: group_split_emit)
-__global__ __launch_bounds__(256) void k_ed_group_split(const uint8_t* __restrict__ tuples, size_t n, GroupState g,
-                                                        uint8_t* __restrict__ acc) {
+__global__ __launch_bounds__(256) void k_ed_group_split(size_t n, GroupState g) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool active = i < n;
     u32 s = SBV_GROUP_NONE;
     if (active) s = g.slot_of[g.rep[i]];
-    bool ung = active && s == SBV_GROUP_NONE;
-    const bool grp = active && s != SBV_GROUP_NONE;
-    bool key_rejected = false;
-    if (ung) {
-        ept A;
-        if (!ed_tuple_key_load(tuples, i, A)) { acc[i] = 0; ung = false; key_rejected = true; }
-    }
-    group_split_emit(i, s, ung, grp, key_rejected, g);
+    group_split_emit(i, s, active && s == SBV_GROUP_NONE, active && s != SBV_GROUP_NONE, false, g);
 }
 
 __global__ __launch_bounds__(64) void k_ed_keytab_bases(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jbases,
@@ -57,20 +51,22 @@ __global__ __launch_bounds__(64) void k_ed_keytab_window(GroupState g, const u32
                           ktab + w * SBV_ED_KEY_PER_WINDOW);
 }
 
-// Blocks [0, generic_blocks): the one-lane kernel (ed25519_verify_lane) over the ungrouped list, at the same
-// 3 waves/SIMD budget; remaining blocks: [S]B for every tuple of the batch.
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_ed_gphase_generic(const uint8_t* __restrict__ tuples, size_t n, GroupState g,
-                                                                          u32* __restrict__ qtab, const aniels* __restrict__ btab,
-                                                                          u32* __restrict__ gacc, size_t cap, uint8_t* __restrict__ okb,
-                                                                          uint8_t* __restrict__ acc, unsigned generic_blocks) {
-    if (blockIdx.x < generic_blocks) {
-        const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
-        if (L >= g.counters[2]) return;
-        const u32 t = g.ung_idx[L];
-        acc[t] = ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab + (size_t)L * (SBV_ED_QTAB_ENTRIES * 32), btab) ? 1 : 0;
-        return;
-    }
-    const size_t i = (size_t)(blockIdx.x - generic_blocks) * SBV_VERIFY_BLOCK + threadIdx.x;
+// The one-lane kernel (ed25519_verify_lane) over the ungrouped list, at the 3 waves/SIMD budget of the throughput
+// kernels it runs beside.  A ~2.5 ms serial chain per lane: it goes on side_a behind the last bases so that it
+// gates nothing but the final pack.
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_ed_generic_list(const uint8_t* __restrict__ tuples, GroupState g,
+                                                                        u32* __restrict__ qtab, const aniels* __restrict__ btab,
+                                                                        uint8_t* __restrict__ acc) {
+    const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (L >= g.counters[2]) return;
+    const u32 t = g.ung_idx[L];
+    acc[t] = ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab + (size_t)L * (SBV_ED_QTAB_ENTRIES * 32), btab) ? 1 : 0;
+}
+
+// [S]B for every tuple of the batch
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_ed_gphase(const uint8_t* __restrict__ tuples, size_t n, const aniels* __restrict__ btab,
+                                                                  u32* __restrict__ gacc, size_t cap, uint8_t* __restrict__ okb) {
+    const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (i < n) ed_gphase_lane(tuples, i, btab, gacc, cap, okb);
 }
 
@@ -110,11 +106,11 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, n, g);
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
-    hipLaunchKernelGGL(k_ed_group_split, dim3(gn), dim3(256), 0, y.side_b, d_tuples, n, g, b.acc);
+    hipLaunchKernelGGL(k_ed_group_split, dim3(gn), dim3(256), 0, y.side_b, n, g);
     SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
+    // stream: the G phase needs nothing but the tuples
+    hipLaunchKernelGGL(k_ed_gphase, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, n, d_btab, b.gacc, b.gacc_cap, eb.okb);
     SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
-    hipLaunchKernelGGL(k_ed_gphase_generic, dim3(2 * gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, n, g, d_qtab, d_btab, b.gacc,
-                       b.gacc_cap, eb.okb, b.acc, gv);
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_ED_KEY_WINDOWS * c / chunks, j_end = SBV_ED_KEY_WINDOWS * (c + 1) / chunks;
         const int j_count = j_end - j_first;
@@ -130,6 +126,11 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
         hipLaunchKernelGGL(k_ed_qphase, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, b.kvalid, b.gacc, b.gacc_cap,
                            eb.okb, b.acc, j_first, j_end, c + 1 == chunks ? 1 : 0);
     }
+    // side_a, behind the last bases: the ungrouped list
+    SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_split, 0));
+    hipLaunchKernelGGL(k_ed_generic_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, d_tuples, g, d_qtab, d_btab, b.acc);
+    SBV_TRY(hipEventRecord(y.ev_generic, y.side_a));
+    SBV_TRY(hipStreamWaitEvent(stream, y.ev_generic, 0));
     hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
 #undef SBV_TRY
     return hipGetLastError();

@@ -248,7 +248,7 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     std::vector<uint8_t> accb(cap, 0xEE), okb(cap, 0);
     for (size_t i = 0; i < n; ++i) ed_group_insert_lane(tuples, i, g);
     for (size_t i = 0; i < n; ++i) group_assign_lane(i, g);
-    for (size_t i = 0; i < n; ++i) ed_group_split_lane(tuples, i, g, accb.data());
+    for (size_t i = 0; i < n; ++i) ed_group_split_lane(i, g);
     const u32 ngroups = counters[0] < max_groups ? counters[0] : max_groups;
     std::vector<u32> gacc(32 * cap);
     for (size_t i = 0; i < n; ++i) ed_gphase_lane(tuples, i, btab(), gacc.data(), cap, okb.data());
