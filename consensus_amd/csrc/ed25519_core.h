@@ -8,8 +8,8 @@
 //
 // Twisted Edwards a = -1 with d non-square: the unified addition is COMPLETE, so unlike P-256
 // there are no exceptional cases to route.  Extended coordinates (X:Y:Z:T); [k](-A) by 64 signed
-// 4-bit windows from a per-signature table of projective-Niels points in HBM, [S]B by 32 signed
-// 8-bit comb windows of affine-Niels points (393 KiB, L2 resident).  One inversion per lane to
+// 4-bit windows from a per-signature table of projective-Niels points in HBM, [S]B by 16 signed
+// 16-bit comb windows of affine-Niels points (50 MB, HBM / Infinity Cache resident).  One inversion per lane to
 // re-encode R (the comparison is byte-wise by specification).
 #pragma once
 #include "ed25519_fe.h"
@@ -22,8 +22,11 @@ struct pniels { fe25 YpX, YmX, Z, T2d; };   // 128 bytes
 struct aniels { fe25 ypx, ymx, xy2d; };     // 96 bytes
 
 #define SBV_ED_QTAB_ENTRIES 8
-#define SBV_ED_BTAB_WINDOWS 32
-#define SBV_ED_BTAB_PER_WINDOW 128
+// 16-bit comb of B: [S]B is 16 additions (an 8-bit comb needs 32).  16 x 32768 x 96 B = 50 MB: nothing for HBM / the
+// 256 MB Infinity Cache (same trade as the P-256 G16 table).
+#define SBV_ED_B16_WINDOWS 16
+#define SBV_ED_B16_PER_WINDOW 32768
+#define SBV_ED_B16_ENTRIES ((size_t)SBV_ED_B16_WINDOWS * SBV_ED_B16_PER_WINDOW)
 
 SBV_HD void ed_set_ident(ept& p) { p.X = fe25_zero(); p.Y = fe25_one(); p.Z = fe25_one(); p.T = fe25_zero(); }
 
@@ -152,9 +155,24 @@ SBV_HD void pn_load(pniels& p, const u32* src) {
     fe_load16(p.YpX, src); fe_load16(p.YmX, src + 8); fe_load16(p.Z, src + 16); fe_load16(p.T2d, src + 24);
 }
 
+// R += [S]B from the 16-bit comb b16[j * 32768 + (k-1)] = k * 2^(16j) * B; S < 2^253, so S + 0x8000...8000 does not
+// carry out of 256 bits and its 16-bit digits minus 32768 are the signed digits.
+SBV_HD void ed_add_sB(ept& R, const u256& S, const aniels* b16) {
+    u256 ss;
+    (void)add_const_limbs(ss, S, 0x80008000u);
+    SBV_NOUNROLL
+    for (int j = 0; j < SBV_ED_B16_WINDOWS; ++j) {
+        const int d = (int)((ss.v[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu) - 32768;
+        const int ad = d < 0 ? -d : d;
+        const u32* bp = reinterpret_cast<const u32*>(b16 + (size_t)j * SBV_ED_B16_PER_WINDOW + (ad == 0 ? 0 : ad - 1));
+        aniels e;
+        fe_load16(e.ypx, bp); fe_load16(e.ymx, bp + 8); fe_load16(e.xy2d, bp + 16);
+        ed_add_aniels(R, e, d < 0, d == 0);
+    }
+}
+
 // One tuple -> accept?  `w` indexes the tuple's 32 little-endian dwords, `qtab` = 8 x 32 dwords of
-// private table space (16-byte aligned), `btab` = 32 x 128 affine-Niels multiples of B:
-// btab[j*128 + (k-1)] = k * 2^(8j) * B.
+// private table space (16-byte aligned), `btab` = the 16-bit comb of B (ed_add_sB).
 template <typename Words>
 SBV_HD bool ed25519_verify_lane(Words w, u32* qtab, const aniels* btab) {
     u32 renc[8], pk[8];
@@ -184,9 +202,8 @@ SBV_HD bool ed25519_verify_lane(Words w, u32* qtab, const aniels* btab) {
         }
     }
     // signed windows: k < 2^253 so k + 0x88..8 and S + 0x80..80 do not carry out of 256 bits
-    u256 kk, ss;
+    u256 kk;
     (void)add_const_limbs(kk, k, 0x88888888u);
-    (void)add_const_limbs(ss, S, 0x80808080u);
     ept R;
     ed_set_ident(R);
     for (int win = 63; win >= 0; --win) {
@@ -198,14 +215,7 @@ SBV_HD bool ed25519_verify_lane(Words w, u32* qtab, const aniels* btab) {
         pn_load(e, qtab + (ad == 0 ? 0 : ad - 1) * 32);
         ed_add_pniels(R, e, d < 0, d == 0);
     }
-    for (int j = 0; j < SBV_ED_BTAB_WINDOWS; ++j) {
-        const int d = (int)((ss.v[j >> 2] >> ((j & 3) * 8)) & 255u) - 128;
-        const int ad = d < 0 ? -d : d;
-        const u32* bp = reinterpret_cast<const u32*>(btab + (size_t)j * SBV_ED_BTAB_PER_WINDOW + (ad == 0 ? 0 : ad - 1));
-        aniels e;
-        fe_load16(e.ypx, bp); fe_load16(e.ymx, bp + 8); fe_load16(e.xy2d, bp + 16);
-        ed_add_aniels(R, e, d < 0, d == 0);
-    }
+    ed_add_sB(R, S, btab);
     // encode(R) == R_enc, byte for byte
     fe25 zi, x, y;
     fe25_inv(zi, R.Z);
@@ -220,39 +230,42 @@ SBV_HD bool ed25519_verify_lane(Words w, u32* qtab, const aniels* btab) {
 }
 
 // ---- base-point comb (host, once per init; also tests/emul) --------------------------------------------
-inline void build_ed_btable(aniels* out) {
+// window j (0..15) of the 16-bit comb, callable from several host threads
+inline void build_ed_b16_window(int j, aniels* out_row) {
     const fe25 bx = {{0x8F25D51Au, 0xC9562D60u, 0x9525A7B2u, 0x692CC760u, 0xFDD6DC5Cu, 0xC0A4E231u, 0xCD6E53FEu, 0x216936D3u}};
     const fe25 by = {{0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u}};
     const fe25 d2 = fe25_2d();
     ept base;
     base.X = bx; base.Y = by; base.Z = fe25_one(); fe25_mul(base.T, bx, by);
-    for (int j = 0; j < SBV_ED_BTAB_WINDOWS; ++j) {
-        pniels bn;
-        ed_to_pniels(bn, base);
-        ept t = base;
-        for (int kx = 1; kx <= SBV_ED_BTAB_PER_WINDOW; ++kx) {
-            if (kx > 1) ed_add_pniels(t, bn, false, false);
-            fe25 zi, x, y;
-            fe25_inv(zi, t.Z);
-            fe25_mul(x, t.X, zi);
-            fe25_mul(y, t.Y, zi);
-            aniels a;
-            fe25_add(a.ypx, y, x);
-            fe25_sub(a.ymx, y, x);
-            fe25_mul(a.xy2d, x, y);
-            fe25_mul(a.xy2d, a.xy2d, d2);
-            out[(size_t)j * SBV_ED_BTAB_PER_WINDOW + (kx - 1)] = a;
-        }
-        // next base = 2^8 * base = 2 * (128 * base)
-        ept nb;
-        ed_dbl(nb, t);
-        fe25 zi;
-        fe25_inv(zi, nb.Z);
-        fe25_mul(base.X, nb.X, zi);
-        fe25_mul(base.Y, nb.Y, zi);
-        base.Z = fe25_one();
-        fe25_mul(base.T, base.X, base.Y);
+    for (int i = 0; i < 16 * j; ++i) ed_dbl(base, base);          // 2^(16j) * B, projective
+    pniels bn;
+    ed_to_pniels(bn, base);
+    const int n = SBV_ED_B16_PER_WINDOW;
+    fe25* X = new fe25[n]; fe25* Y = new fe25[n]; fe25* Z = new fe25[n]; fe25* pre = new fe25[n];
+    ept t = base;
+    fe25 acc = fe25_one();
+    for (int k = 0; k < n; ++k) {                                  // (k+1) * base, Z's multiplied up for Montgomery's trick
+        if (k > 0) ed_add_pniels(t, bn, false, false);
+        X[k] = t.X; Y[k] = t.Y; Z[k] = t.Z;
+        pre[k] = acc;
+        fe25_mul(acc, acc, t.Z);
     }
+    fe25 inv;
+    fe25_inv(inv, acc);
+    for (int k = n - 1; k >= 0; --k) {
+        fe25 zi, x, y;
+        fe25_mul(zi, inv, pre[k]);
+        fe25_mul(inv, inv, Z[k]);
+        fe25_mul(x, X[k], zi);
+        fe25_mul(y, Y[k], zi);
+        aniels a;
+        fe25_add(a.ypx, y, x);
+        fe25_sub(a.ymx, y, x);
+        fe25_mul(a.xy2d, x, y);
+        fe25_mul(a.xy2d, a.xy2d, d2);
+        out_row[k] = a;
+    }
+    delete[] X; delete[] Y; delete[] Z; delete[] pre;
 }
 
 }  // namespace sbv

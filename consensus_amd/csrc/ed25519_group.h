@@ -154,7 +154,7 @@ SBV_HD void ed_gacc_load(ept& R, const u32* gacc, size_t cap, size_t i) {
     }
 }
 
-// [S]B for tuple i -> gacc; okb[i] = S < L and k < L (SetCanonicalBytes(S); a reduced k is always < L)
+// [S]B (16-bit comb `btab`) for tuple i -> gacc; okb[i] = S < L and k < L (SetCanonicalBytes(S); a reduced k is always < L)
 SBV_HD void ed_gphase_lane(const uint8_t* tuples, size_t i, const aniels* btab, u32* gacc, size_t cap, uint8_t* okb) {
     const u32* w = ed_tuple_words(tuples, i);
     u256 S, k;
@@ -162,19 +162,9 @@ SBV_HD void ed_gphase_lane(const uint8_t* tuples, size_t i, const aniels* btab, 
     for (int j = 0; j < 8; ++j) { S.v[j] = w[8 + j]; k.v[j] = w[24 + j]; }
     const u256 L = ed_L();
     okb[i] = (lt256(S, L) && lt256(k, L)) ? 1 : 0;
-    u256 ss;
-    (void)add_const_limbs(ss, S, 0x80808080u);
     ept R;
     ed_set_ident(R);
-    SBV_NOUNROLL
-    for (int j = 0; j < SBV_ED_BTAB_WINDOWS; ++j) {
-        const int d = (int)((ss.v[j >> 2] >> ((j & 3) * 8)) & 255u) - 128;
-        const int ad = d < 0 ? -d : d;
-        const u32* bp = reinterpret_cast<const u32*>(btab + (size_t)j * SBV_ED_BTAB_PER_WINDOW + (ad == 0 ? 0 : ad - 1));
-        aniels e;
-        fe_load16(e.ypx, bp); fe_load16(e.ymx, bp + 8); fe_load16(e.xy2d, bp + 16);
-        ed_add_aniels(R, e, d < 0, d == 0);
-    }
+    ed_add_sB(R, S, btab);
     ed_gacc_store(gacc, cap, i, R);
 }
 

@@ -19,6 +19,6 @@ struct EdGroupBuffers {
 hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, const GroupBuffers& b, const EdGroupBuffers& eb,
                                          u32* d_qtab, const aniels* d_btab, uint8_t* d_bitmap, hipStream_t stream,
                                          const GroupSync& y);
-void host_build_ed_btable(aniels* out);   // 32 x 128 affine-Niels multiples of B (one-time setup)
-#define SBV_ED_BTAB_ENTRIES (SBV_ED_BTAB_WINDOWS * SBV_ED_BTAB_PER_WINDOW)
+#define SBV_ED_KEYTAB_ENTRIES_PER_KEY 4096   // 32 windows x 128 entries (ed25519_group.h)
+void host_build_ed_b16(aniels* out);      // 16 x 32768 affine-Niels multiples of B: the comb the device kernels use
 }  // namespace sbv

@@ -4,10 +4,13 @@
 // tile of tuples is contiguous in HBM: it is fetched with coalesced 16-byte loads into LDS
 // (33-dword row pitch -> conflict-free per-lane ds_read_b32) and each lane then reads its own row.
 // [k](-A): 64 signed 4-bit windows from a per-signature projective-Niels table kept in HBM
-// (1 KiB per lane); [S]B: 32 signed 8-bit comb windows from a 393 KiB affine-Niels table (L2
-// resident).  Complete unified addition, no exceptional cases; one field inversion per lane to
+// (1 KiB per lane); [S]B: 16 signed 16-bit comb windows from a 50 MB affine-Niels table (HBM /
+// Infinity Cache resident).  Complete unified addition, no exceptional cases; one field inversion per lane to
 // re-encode R for the byte-wise comparison Go performs.  No scalar inversion -> no stage A.
 #include <hip/hip_runtime.h>
+
+#include <thread>
+#include <vector>
 
 #include "ed25519_core.h"
 #include "p256_kernels.h"
@@ -62,6 +65,10 @@ hipError_t launch_ed25519_verify(const uint8_t* d_tuples, size_t n, u32* d_qtab,
     return hipGetLastError();
 }
 
-void host_build_ed_btable(aniels* out) { build_ed_btable(out); }
+void host_build_ed_b16(aniels* out) {
+    std::vector<std::thread> th;
+    for (int j = 0; j < SBV_ED_B16_WINDOWS; ++j) th.emplace_back([j, out] { build_ed_b16_window(j, out + (size_t)j * SBV_ED_B16_PER_WINDOW); });
+    for (auto& t : th) t.join();
+}
 
 }  // namespace sbv

@@ -214,8 +214,10 @@ void sbve_msg_frontend(const uint8_t* msg, size_t mlen, const uint8_t* der, size
 static aniels* g_btab = nullptr;
 static const aniels* btab() {
     if (!g_btab) {
-        g_btab = (aniels*)aligned_alloc(64, sizeof(aniels) * SBV_ED_BTAB_WINDOWS * SBV_ED_BTAB_PER_WINDOW);
-        build_ed_btable(g_btab);
+        g_btab = (aniels*)aligned_alloc(64, sizeof(aniels) * SBV_ED_B16_ENTRIES);
+        std::vector<std::thread> th;
+        for (int j = 0; j < SBV_ED_B16_WINDOWS; ++j) th.emplace_back([j] { build_ed_b16_window(j, g_btab + (size_t)j * SBV_ED_B16_PER_WINDOW); });
+        for (auto& t : th) t.join();
     }
     return g_btab;
 }
