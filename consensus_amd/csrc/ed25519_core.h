@@ -218,7 +218,7 @@ SBV_HD bool ed25519_verify_lane(Words w, u32* qtab, const aniels* btab) {
     ed_add_sB(R, S, btab);
     // encode(R) == R_enc, byte for byte
     fe25 zi, x, y;
-    fe25_inv(zi, R.Z);
+    fe25_inv_gcd(zi, R.Z);            // division steps (modinv30.h): ~4x cheaper than the z^(p-2) chain
     fe25_mul(x, R.X, zi);
     fe25_mul(y, R.Y, zi);
     fe25_freeze(y, y);

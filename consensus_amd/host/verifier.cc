@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/sbv.h"
+#include "ed25519_host.h"
 #include "p256_host.h"
 
 namespace sbvhost {
@@ -127,6 +128,10 @@ class SbvBackend : public Backend {
         if (rc_ != SBV_OK) return rc_;
         return sbv_p256_verify_batch_keyed(rsh, slots, n, bitmap);
     }
+    int verify_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap) override {
+        if (rc_ != SBV_OK) return rc_;
+        return sbv_ed25519_verify_batch(tuples128, n, bitmap);
+    }
     int verify_msgs_keyed(const uint8_t* msgs, const uint64_t* moff, const uint8_t* sigs, const uint64_t* soff,
                           const uint32_t* slots, size_t n, uint8_t* bitmap) override {
         if (rc_ != SBV_OK) return rc_;
@@ -164,6 +169,8 @@ class CallbackBackend : public Backend {
         return fn_(tuples.data(), n, bitmap, user_);
     }
     uint64_t keyed_batches() override { std::lock_guard<std::mutex> lk(mu_); return keyed_batches_; }
+    // the stand-in knows which scheme its test runs: the same callback receives the 128-byte tuples
+    int verify_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap) override { return fn_(tuples128, n, bitmap, user_); }
  private:
     backend_fn fn_;
     void* user_;
@@ -191,10 +198,11 @@ Coalescer::~Coalescer() {
     th_.join();
 }
 
-int Coalescer::submit(const uint8_t tuple[160], long slot) {
+int Coalescer::submit(const uint8_t tuple[160], long slot, bool ed25519) {
     Job j;
-    memcpy(j.tuple, tuple, 160);
+    memcpy(j.tuple, tuple, ed25519 ? 128 : 160);
     j.slot = slot;
+    j.ed25519 = ed25519;
     std::unique_lock<std::mutex> lk(mu_);
     q_.push_back(&j);
     ++st_.calls;
@@ -210,6 +218,15 @@ int Coalescer::submit_many(const uint8_t* tuples, size_t n, uint8_t* bitmap) {
         if (n > st_.max_batch) st_.max_batch = n;
     }
     return be_->verify(tuples, n, bitmap);      // the backend serialises device work itself
+}
+
+int Coalescer::submit_many_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap) {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        ++st_.batches;
+        if (n > st_.max_batch) st_.max_batch = n;
+    }
+    return be_->verify_ed25519(tuples128, n, bitmap);
 }
 
 int Coalescer::submit_many_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap) {
@@ -249,7 +266,11 @@ void Coalescer::run() {
         bool all_keyed = true;
         for (size_t i = 0; i < n; ++i) all_keyed = all_keyed && batch[i]->slot >= 0;
         int rc;
-        if (all_keyed) {                 // the commit-vote burst: every signer is a registered consenter
+        if (batch[0]->ed25519) {         // Ed25519 Verifier: 128-byte tuples
+            tuples.resize(n * 128);
+            for (size_t i = 0; i < n; ++i) memcpy(&tuples[i * 128], batch[i]->tuple, 128);
+            rc = be_->verify_ed25519(tuples.data(), n, bitmap.data());
+        } else if (all_keyed) {          // the commit-vote burst: every signer is a registered consenter
             tuples.resize(n * 96);
             std::vector<uint32_t> slots(n);
             for (size_t i = 0; i < n; ++i) { memcpy(&tuples[i * 96], batch[i]->tuple, 96); slots[i] = (uint32_t)batch[i]->slot; }
@@ -274,19 +295,23 @@ void Coalescer::run() {
 Verifier::Verifier(std::shared_ptr<Backend> be, const VerifierOptions& opt)
     : opt_(opt), co_(be, opt.coalesce_max, opt.coalesce_wait) {}
 
-void Verifier::RegisterConsenter(uint64_t id, const uint8_t q[64]) {
-    const long slot = co_.backend().register_key(q);     // -1: backend without a key registry
+void Verifier::RegisterConsenter(uint64_t id, const uint8_t* q) {
+    const long slot = ed() ? -1 : co_.backend().register_key(q);     // -1: no key registry (or Ed25519: grouped per batch)
+    bytes key((const char*)q, key_bytes());
+    key.resize(64, '\0');
     std::lock_guard<std::mutex> lk(mu_);
-    consenters_[id] = bytes((const char*)q, 64);
+    consenters_[id] = key;
     consenter_slot_[id] = slot;
 }
 // Clients are a registry too (the application hands their keys to the Verifier), so their keys take the same
 // registered-key slots as the consenters': VerifyRequest / VerifyProposal then run 50 table additions per
 // signature instead of the 256-doubling chain of a key the device has never seen.
-void Verifier::RegisterClient(const std::string& client_id, const uint8_t q[64]) {
-    const long slot = co_.backend().register_key(q);     // -1: backend without a key registry
+void Verifier::RegisterClient(const std::string& client_id, const uint8_t* q) {
+    const long slot = ed() ? -1 : co_.backend().register_key(q);     // -1: no key registry (or Ed25519: grouped per batch)
+    bytes key((const char*)q, key_bytes());
+    key.resize(64, '\0');
     std::lock_guard<std::mutex> lk(mu_);
-    clients_[client_id] = bytes((const char*)q, 64);
+    clients_[client_id] = key;
     client_slot_[client_id] = slot;
 }
 void Verifier::SetVerificationSequence(uint64_t s) { std::lock_guard<std::mutex> lk(mu_); seq_ = s; }
@@ -320,6 +345,19 @@ void Verifier::make_tuple(const uint8_t q[64], const bytes& msg, const bytes& si
     memcpy(out + 96, q, 64);
 }
 
+// R|S|A|k.  A signature that is not exactly 64 bytes becomes S = 2^256 - 1 >= L, which the kernel rejects — the verdict
+// crypto/ed25519.Verify gives for a wrong length, without a second code path.
+void Verifier::make_tuple_ed25519(const uint8_t a_enc[32], const bytes& msg, const bytes& sig, uint8_t out[128]) {
+    if (sig.size() != 64) {
+        memset(out, 0xFF, 128);
+        memcpy(out + 64, a_enc, 32);
+        return;
+    }
+    memcpy(out, sig.data(), 64);
+    memcpy(out + 64, a_enc, 32);
+    ed25519_hram((const uint8_t*)sig.data(), a_enc, msg.data(), msg.size(), out + 96);
+}
+
 Status Verifier::verify_one(const uint8_t q[64], const bytes& msg, const bytes& sig, long slot) {
     std::string key;
     if (opt_.cache_verified) {
@@ -331,8 +369,9 @@ Status Verifier::verify_one(const uint8_t q[64], const bytes& msg, const bytes& 
         if (it != cache_.end()) return it->second ? Status::Ok() : Status::Invalid("invalid signature (cached)");
     }
     uint8_t t[160];
-    make_tuple(q, msg, sig, t);
-    const int r = co_.submit(t, slot);
+    if (ed()) make_tuple_ed25519(q, msg, sig, t);
+    else make_tuple(q, msg, sig, t);
+    const int r = co_.submit(t, ed() ? -1 : slot, ed());
     if (r < 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());
     if (opt_.cache_verified) {
         std::lock_guard<std::mutex> lk(cache_mu_);
@@ -413,7 +452,8 @@ Status Verifier::VerifyProposal(const Proposal& p, std::vector<RequestInfo>* req
     if (!payload_split(p.payload, &reqs)) return Status::Invalid("malformed proposal payload");
     if ((uint64_t)p.verification_sequence != VerificationSequence()) return Status::Invalid("verification sequence mismatch");
     const size_t n = reqs.size();
-    std::vector<uint8_t> tuples(n * 160), bitmap((n + 7) / 8, 0);
+    const size_t tb = ed() ? 128 : 160;              // tuple bytes of the scheme
+    std::vector<uint8_t> tuples(n * tb), bitmap((n + 7) / 8, 0);
     std::vector<RequestInfo> infos(n);
     std::atomic<int> bad(0);            // 1 = malformed request, 2 = unknown client
     std::map<std::string, bytes> clients;           // snapshot: the workers must not contend on mu_
@@ -432,7 +472,8 @@ Status Verifier::VerifyProposal(const Proposal& p, std::vector<RequestInfo>* req
             auto it = clients.find(r.client_id);
             if (it == clients.end()) { bad.store(2); return; }
             const uint8_t* q = (const uint8_t*)it->second.data();
-            make_tuple(q, r.signed_part, r.sig, &tuples[i * 160]);
+            if (ed()) make_tuple_ed25519(q, r.signed_part, r.sig, &tuples[i * tb]);
+            else make_tuple(q, r.signed_part, r.sig, &tuples[i * tb]);
             const auto st = client_slots.find(r.client_id);
             if (st == client_slots.end() || st->second < 0) unkeyed.store(1);
             else slots[i] = (uint32_t)st->second;
@@ -444,7 +485,9 @@ Status Verifier::VerifyProposal(const Proposal& p, std::vector<RequestInfo>* req
     if (bad.load() == 2) return Status::Invalid("unknown client in proposal");
     if (n) {
         int rc;
-        if (!unkeyed.load()) {
+        if (ed()) {
+            rc = co_.submit_many_ed25519(tuples.data(), n, bitmap.data());
+        } else if (!unkeyed.load()) {
             std::vector<uint8_t> rsh(n * 96);       // r|s|hash; the key comes from the client's slot
             for (size_t i = 0; i < n; ++i) memcpy(&rsh[i * 96], &tuples[i * 160], 96);
             rc = co_.submit_many_keyed(rsh.data(), slots.data(), n, bitmap.data());
@@ -491,7 +534,16 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
         }
     });
     int rc = -2;
-    if (n && !unkeyed.load()) {
+    if (n && ed()) {
+        // Ed25519: k = SHA-512(R | A | msg) mod L on the host workers, one batch of 128-byte tuples
+        std::vector<uint8_t> tuples(n * 128, 0xFF);       // pre-rejected entries keep S = 2^256 - 1 >= L: rejected
+        parallel_chunks(n, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i)
+                if (pre[i]) make_tuple_ed25519((const uint8_t*)keys.find(sigs[i].id)->second.data(), sigs[i].msg, sigs[i].value, &tuples[i * 128]);
+        });
+        rc = co_.submit_many_ed25519(tuples.data(), n, bitmap.data());
+        if (rc == -2) return Status::Unavailable("backend has no Ed25519 entry");
+    } else if (n && !unkeyed.load()) {
         // device front end: the host only lays the bytes out; SHA-256 and DER parsing run on the GPU.
         // Pre-rejected entries get an empty signature (DER failure -> r = s = 0 -> reject).
         std::vector<uint64_t> moff(n + 1), soff(n + 1);
@@ -511,7 +563,7 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
         });
         rc = co_.backend().verify_msgs_keyed(mbuf.data(), moff.data(), sbuf.data(), soff.data(), slots.data(), n, bitmap.data());
     }
-    if (n && rc == -2) {
+    if (n && rc == -2 && !ed()) {
         // backend without the front end (or unregistered signers): build tuples on the host
         std::vector<uint8_t> tuples(n * 160, 0);
         parallel_chunks(n, [&](size_t lo, size_t hi) {
@@ -536,12 +588,18 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
 }
 
 // ---- signer --------------------------------------------------------------------------------------
-Signer::Signer(uint64_t id, const uint8_t private_key[32]) : id_(id) {
+Signer::Signer(uint64_t id, const uint8_t private_key[32], Scheme scheme) : id_(id), scheme_(scheme) {
     memcpy(d_, private_key, 32);
     memset(q_, 0, 64);
-    pubkey_from_private(d_, q_);
+    if (scheme_ == Scheme::ED25519) ed25519_public_key(d_, q_);
+    else pubkey_from_private(d_, q_);
 }
 bytes Signer::Sign(const bytes& msg) {
+    if (scheme_ == Scheme::ED25519) {
+        uint8_t sig[64];
+        ed25519_sign(d_, msg.data(), msg.size(), sig);
+        return bytes((const char*)sig, 64);
+    }
     uint8_t h[32], rs[64];
     sha256(msg.data(), msg.size(), h);
     if (!sign_rfc6979(d_, h, rs)) return bytes();

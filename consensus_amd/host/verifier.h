@@ -46,6 +46,8 @@ class Backend {
     // use verify() with the key carried in the tuple).
     virtual long register_key(const uint8_t q[64]) { (void)q; return -1; }
     virtual uint64_t keyed_batches() { return 0; }      // test hook: how many verify_keyed batches ran
+    // Ed25519 variant (include/sbv.h: sbv_ed25519_verify_batch): n tuples of 128 bytes R|S|A|k.  -2 when unsupported.
+    virtual int verify_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap) { (void)tuples128; (void)n; (void)bitmap; return -2; }
     virtual int verify_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap) {
         (void)rsh; (void)slots; (void)n; (void)bitmap; return -2;
     }
@@ -76,14 +78,16 @@ class Coalescer {
     ~Coalescer();
     // 1 = accept, 0 = reject, <0 = backend error
     // slot >= 0: the signer's key is registered with the backend (tuple[96..160) is then ignored)
-    int submit(const uint8_t tuple[160], long slot = -1);
+    // ed25519 = true: `tuple` holds a 128-byte R|S|A|k tuple instead (one Verifier = one scheme, so a burst never mixes)
+    int submit(const uint8_t tuple[160], long slot = -1, bool ed25519 = false);
+    int submit_many_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap);
     int submit_many(const uint8_t* tuples, size_t n, uint8_t* bitmap);
     int submit_many_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap);
     Backend& backend() { return *be_; }
     CoalescerStats stats();
 
  private:
-    struct Job { uint8_t tuple[160]; long slot = -1; int result = -100; bool done = false; };
+    struct Job { uint8_t tuple[160]; long slot = -1; bool ed25519 = false; int result = -100; bool done = false; };
     void run();
     std::shared_ptr<Backend> be_;
     size_t max_batch_;
@@ -96,7 +100,13 @@ class Coalescer {
     std::thread th_;
 };
 
+// Signature scheme of a Verifier / Signer pair.  P256: ECDSA over SHA-256, DER signatures, 64-byte Qx|Qy keys (Go
+// crypto/ecdsa.VerifyASN1).  ED25519: the BASELINE.json configs[4] variant — 64-byte R|S signatures, 32-byte keys
+// (Go crypto/ed25519.Verify); registered-key slots do not apply (the device groups by key inside each batch).
+enum class Scheme { P256 = 0, ED25519 = 1 };
+
 struct VerifierOptions {
+    Scheme scheme = Scheme::P256;
     size_t coalesce_max = 4096;
     std::chrono::microseconds coalesce_wait{50};
     bool cache_verified = true;     // commit sigs of sequence s reappear at s+1 (view.go:376, 630)
@@ -106,9 +116,10 @@ class Verifier {
  public:
     Verifier(std::shared_ptr<Backend> be, const VerifierOptions& opt = VerifierOptions());
 
-    // key registry (id -> affine public key Qx|Qy); the kernel re-validates every key
-    void RegisterConsenter(uint64_t id, const uint8_t q[64]);
-    void RegisterClient(const std::string& client_id, const uint8_t q[64]);
+    // key registry (id -> public key: 64 bytes Qx|Qy, or the first 32 bytes = A_enc under Scheme::ED25519); the kernel
+    // re-validates every key
+    void RegisterConsenter(uint64_t id, const uint8_t* q);
+    void RegisterClient(const std::string& client_id, const uint8_t* q);
     void SetVerificationSequence(uint64_t s);
 
     // ---- api.Verifier ---------------------------------------------------------------------------
@@ -132,6 +143,9 @@ class Verifier {
     bool consenter_key(uint64_t id, uint8_t q[64], long* slot = nullptr);
     bool client_key(const std::string& id, uint8_t q[64], long* slot = nullptr);
     void make_tuple(const uint8_t q[64], const bytes& msg, const bytes& sig_der, uint8_t out[160]);
+    static void make_tuple_ed25519(const uint8_t a_enc[32], const bytes& msg, const bytes& sig, uint8_t out[128]);
+    bool ed() const { return opt_.scheme == Scheme::ED25519; }
+    size_t key_bytes() const { return ed() ? 32 : 64; }
     Status verify_one(const uint8_t q[64], const bytes& msg, const bytes& sig, long slot = -1);
     std::mutex mu_;
     std::map<uint64_t, bytes> consenters_;
@@ -157,14 +171,16 @@ class Verifier {
 // api.Signer for one node (pkg/api/dependencies.go:46-52)
 class Signer {
  public:
-    Signer(uint64_t id, const uint8_t private_key[32]);
+    // private_key: the P-256 scalar d, or the RFC 8032 seed under Scheme::ED25519
+    Signer(uint64_t id, const uint8_t private_key[32], Scheme scheme = Scheme::P256);
     uint64_t id() const { return id_; }
-    const uint8_t* public_key() const { return q_; }
-    bytes Sign(const bytes& msg);                                           // DER over SHA-256(msg)
+    const uint8_t* public_key() const { return q_; }                        // 64 bytes Qx|Qy, or 32 bytes A_enc (+ 32 zero bytes)
+    bytes Sign(const bytes& msg);                                           // DER over SHA-256(msg), or the 64-byte Ed25519 R|S
     Signature SignProposal(const Proposal& proposal, const bytes& auxiliary_input);
 
  private:
     uint64_t id_;
+    Scheme scheme_;
     uint8_t d_[32], q_[64];
 };
 

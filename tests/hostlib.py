@@ -27,6 +27,10 @@ def load():
     V, S = ctypes.c_void_p, ctypes.c_size_t
     lib.sbvh_verifier_new.restype = V
     lib.sbvh_verifier_new.argtypes = [ctypes.c_int, ctypes.c_int, BACKEND_FN, V, S, ctypes.c_int, ctypes.c_int]
+    lib.sbvh_verifier_new_scheme.restype = V
+    lib.sbvh_verifier_new_scheme.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, BACKEND_FN, V, S, ctypes.c_int, ctypes.c_int]
+    lib.sbvh_signer_new_scheme.restype = V
+    lib.sbvh_signer_new_scheme.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p]
     lib.sbvh_verifier_free.argtypes = [V]
     lib.sbvh_register_consenter.argtypes = [V, ctypes.c_uint64, ctypes.c_char_p]
     lib.sbvh_register_client.argtypes = [V, ctypes.c_char_p, ctypes.c_char_p]

@@ -30,28 +30,32 @@ def lib():
 class Harness:
     """A Verifier wired to a stand-in backend + N consenter signers + clients."""
 
-    def __init__(self, lib, oracle, n_nodes=4, fail_rc=0, wait_us=2000, cache=0, backend_kind=1):
+    def __init__(self, lib, oracle, n_nodes=4, fail_rc=0, wait_us=2000, cache=0, backend_kind=1, scheme=0):
         self.lib, self.batches, self.fail_rc = lib, [], fail_rc
+        ED = scheme == 1
 
         def backend(tuples, n, bitmap, _user):
             self.batches.append(n)
             if self.fail_rc:
                 return self.fail_rc
-            oracle.sbvo_p256_verify_batch(tuples, n, bitmap, 1)
+            if ED:
+                oracle.sbvo_ed25519_verify_batch(tuples, n, bitmap, 1)       # 128-byte R|S|A|k tuples
+            else:
+                oracle.sbvo_p256_verify_batch(tuples, n, bitmap, 1)
             return 0
 
         self._cb = hostlib.BACKEND_FN(backend)          # keep alive
-        self.v = lib.sbvh_verifier_new(backend_kind, 0, self._cb, None, 4096, wait_us, cache)
+        self.v = lib.sbvh_verifier_new_scheme(scheme, backend_kind, 0, self._cb, None, 4096, wait_us, cache)
         self.nodes = []
         for i in range(n_nodes):
-            s = lib.sbvh_signer_new(i + 1, hashlib.sha256(b"node%d" % i).digest())
+            s = lib.sbvh_signer_new_scheme(scheme, i + 1, hashlib.sha256(b"node%d" % i).digest())
             q = ctypes.create_string_buffer(64)
             lib.sbvh_signer_public_key(s, q)
             lib.sbvh_register_consenter(self.v, i + 1, q.raw)
             self.nodes.append(s)
         self.clients = {}
         for i in range(3):
-            s = lib.sbvh_signer_new(0, hashlib.sha256(b"client%d" % i).digest())
+            s = lib.sbvh_signer_new_scheme(scheme, 0, hashlib.sha256(b"client%d" % i).digest())
             q = ctypes.create_string_buffer(64)
             lib.sbvh_signer_public_key(s, q)
             lib.sbvh_register_client(self.v, b"alice%d" % i, q.raw)
@@ -248,6 +252,67 @@ def test_registered_client_and_consenter_keys_take_the_keyed_backend_path(lib, o
         sig = hx.sign_proposal(2, prop, b"aux")
         assert hx.verify_consenter_sig(sig, prop)[0] == OK
         assert lib.sbvh_backend_keyed_batches(hx.v) >= 5
+    finally:
+        hx.close()
+
+
+def test_ed25519_verifier_variant(lib, oracle):
+    """BASELINE.json configs[4] at the seam: the same api.Verifier / api.Signer pair with Scheme::ED25519 — RFC 8032
+    signer (byte-identical to the oracle's and to RFC 8032 §7.1 test 1-3 keys), 64-byte signatures, 128-byte R|S|A|k
+    tuples, one backend batch per proposal / per commit-vote burst, wrong-length signatures rejected."""
+    import json, os
+    vs = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ed25519_vectors.json")))["vectors"]
+    oracle.sbvo_ed25519_public_key.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    oracle.sbvo_ed25519_sign.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    oracle.sbvo_ed25519_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+    # RFC 8032 §7.1 test 1: seed -> public key and signature of the empty message
+    seed = bytes.fromhex("9d61b19deffd5a60ba844af492ec2cc44449c5697b326919703bac031cae7f60")
+    s = lib.sbvh_signer_new_scheme(1, 7, seed)
+    q = ctypes.create_string_buffer(64)
+    lib.sbvh_signer_public_key(s, q)
+    assert q.raw[:32].hex() == next(v["pk"] for v in vs if v["name"] == "rfc8032_test1")
+    out = ctypes.create_string_buffer(80)
+    assert lib.sbvh_sign(s, b"", 0, out, 80) == 64
+    assert out.raw[:64].hex() == next(v["sig"] for v in vs if v["name"] == "rfc8032_test1")
+    # ... and byte-identical to the oracle's signer on other seeds / messages
+    for i in range(6):
+        sd = hashlib.sha256(b"edseed%d" % i).digest()
+        msg = bytes(range(i * 37 % 200))
+        si = lib.sbvh_signer_new_scheme(1, 1, sd)
+        lib.sbvh_signer_public_key(si, q)
+        pk, sig = ctypes.create_string_buffer(32), ctypes.create_string_buffer(64)
+        oracle.sbvo_ed25519_public_key(sd, pk)
+        oracle.sbvo_ed25519_sign(sd, msg, len(msg), sig)
+        assert q.raw[:32] == pk.raw
+        assert lib.sbvh_sign(si, msg, len(msg), out, 80) == 64 and out.raw[:64] == sig.raw
+        lib.sbvh_signer_free(si)
+    lib.sbvh_signer_free(s)
+    hx = Harness(lib, oracle, scheme=1, wait_us=2000)
+    try:
+        reqs = [hx.request("alice%d" % (i % 3), "r%d" % i, payload=bytes([i])) for i in range(100)]
+        prop = (hostlib.payload_encode(reqs), b"h", b"m", 0)
+        hx.batches.clear()
+        st, infos = hx.verify_proposal(prop)
+        assert st == OK and len(infos) == 100 and hx.batches == [100]
+        reqs[13] = hx.request("alice1", "r13", corrupt=True)
+        assert hx.verify_proposal((hostlib.payload_encode(reqs), b"h", b"m", 0))[0] == INVALID
+        assert hx.verify_request(hx.request("alice2", "solo"))[0] == OK
+        assert hx.verify_request(hx.request("alice2", "solo2", corrupt=True))[0] == INVALID
+        # commit votes: good, tampered value, truncated value (wrong length -> reject, not an error)
+        sid, val, msg = hx.sign_proposal(1, prop, b"aux")
+        assert len(val) == 64
+        assert hx.verify_consenter_sig((sid, val, msg), prop) == (OK, b"aux")
+        assert hx.verify_consenter_sig((sid, val[:-1] + bytes([val[-1] ^ 1]), msg), prop)[0] == INVALID
+        assert hx.verify_consenter_sig((sid, val[:63], msg), prop)[0] == INVALID
+        assert hx.verify_consenter_sig((sid + 1, val, msg), prop)[0] == INVALID      # another node's key
+        # concurrent votes of all nodes coalesce into one backend batch
+        import threading
+        hx.batches.clear()
+        sigs = [hx.sign_proposal(i, prop, b"") for i in range(4)]
+        res = [None] * 4
+        th = [threading.Thread(target=lambda i=i: res.__setitem__(i, hx.verify_consenter_sig(sigs[i], prop)[0])) for i in range(4)]
+        [t.start() for t in th]; [t.join() for t in th]
+        assert res == [OK] * 4 and sum(hx.batches) == 4 and len(hx.batches) <= 2
     finally:
         hx.close()
 
