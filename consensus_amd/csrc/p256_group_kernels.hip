@@ -71,6 +71,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_gphase_generic(Scratch 
         acc[t] = verify_lane<false>(s, t, qtab + (size_t)L * (SBV_QTAB_ENTRIES * 40), g16) ? 1 : 0;
         return;
     }
+    if (group_count(g) == 0) return;            // no key repeats often enough (e.g. all-distinct keys): nothing will read gacc
     const size_t i = (size_t)(blockIdx.x - generic_blocks) * SBV_VERIFY_BLOCK + threadIdx.x;
     if (i < n) gphase_lane(s, i, g16, gacc);
 }
