@@ -554,14 +554,16 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
             b += pre[i] ? sigs[i].value.size() : 0;
         }
         moff[n] = a; soff[n] = b;
-        std::vector<uint8_t> mbuf(a ? a : 1), sbuf(b ? b : 1);
+        // uninitialised staging: zero-filling ~150 B per signature on one thread cost more than the GPU's share of a
+        // 550 000-signature replay; the workers touch (and page in) their own slices
+        std::unique_ptr<uint8_t[]> mbuf(new uint8_t[a ? a : 1]), sbuf(new uint8_t[b ? b : 1]);
         parallel_chunks(n, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i) {
                 memcpy(&mbuf[moff[i]], sigs[i].msg.data(), sigs[i].msg.size());
                 if (pre[i]) memcpy(&sbuf[soff[i]], sigs[i].value.data(), sigs[i].value.size());
             }
         });
-        rc = co_.backend().verify_msgs_keyed(mbuf.data(), moff.data(), sbuf.data(), soff.data(), slots.data(), n, bitmap.data());
+        rc = co_.backend().verify_msgs_keyed(mbuf.get(), moff.data(), sbuf.get(), soff.data(), slots.data(), n, bitmap.data());
     }
     if (n && rc == -2 && !ed()) {
         // backend without the front end (or unregistered signers): build tuples on the host
