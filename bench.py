@@ -36,7 +36,19 @@ def cpu_baseline(tuples, n, gpu_bitmap):
     is reported beside it as the closer proxy for Go's nistec assembly.  This is the ONLY place
     bench.py touches oracle/ — as the thing timed for the baseline and as a parity check of the
     sample, never as the measured product."""
-    cores = os.cpu_count() or 1
+    visible = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = visible
+    quota = None                        # cgroup v2 CPU quota of the container, in CPUs (None = unlimited / unknown)
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(visible, affinity, int(quota + 0.999) if quota else visible))     # threads actually used
     lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsbv_oracle.so"))
     lib.sbvo_p256_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
     probe = min(n, 256)
@@ -51,7 +63,8 @@ def cpu_baseline(tuples, n, gpu_bitmap):
     parity = out.raw[:sample // 8] == bytes(gpu_bitmap[:sample // 8])
     res = {"value": sample / dt, "unit": "verifies/s", "cores": cores, "kind": "port",
            "sample": f"first {sample} tuples of the same batch, oracle/p256_oracle.c on {cores} threads, {dt:.2f} s",
-           "parity_with_gpu_on_sample": parity}
+           "parity_with_gpu_on_sample": parity, "one_thread_value": per_thread,
+           "host": {"cpus_visible": visible, "affinity": affinity, "cgroup_cpu_quota": quota}}
     ssl_path = os.path.join(ROOT, "oracle", "libsbv_openssl.so")
     if os.path.exists(ssl_path):
         ssl = ctypes.CDLL(ssl_path)
