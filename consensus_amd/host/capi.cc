@@ -170,6 +170,7 @@ struct sbvh_replay_result {
     uint64_t backend_batches;
     uint64_t max_backend_batch;
     int status;                  // 0 ok, 2 backend unavailable, 1 unexpected reject
+    double batch_first_us;       // config 4: the first (cold) call — device staging buffers are allocated inside it
 };
 
 static double median(std::vector<double> v) {
@@ -288,8 +289,14 @@ int sbvh_replay(void* h, int n_nodes, int K, int sequences, int decisions, int t
         std::vector<const Proposal*> pp(dsigs.size());
         for (size_t i = 0; i < dsigs.size(); ++i) pp[i] = &dprops[i / Q];
         std::vector<uint8_t> ok;
-        const double t0 = now_us();
-        const Status st = V.VerifyConsenterSigBatch(dsigs, pp, &ok);
+        // a replaying node streams batch after batch: the first call pays for the device staging buffers once, the
+        // second is the steady state that is reported
+        double t0 = now_us();
+        Status st = V.VerifyConsenterSigBatch(dsigs, pp, &ok);
+        out->batch_first_us = now_us() - t0;
+        if (!st.ok()) { out->status = st.code; return out->status; }
+        t0 = now_us();
+        st = V.VerifyConsenterSigBatch(dsigs, pp, &ok);
         out->batch_total_us = now_us() - t0;
         if (!st.ok()) { out->status = st.code; return out->status; }
         out->batch_tuples = dsigs.size();

@@ -168,6 +168,25 @@ class CallbackBackend : public Backend {
         }
         return fn_(tuples.data(), n, bitmap, user_);
     }
+    // stand-in for the device front end (sbv_p256_verify_msgs_keyed): SHA-256 + strict DER on the host, then the callback
+    int verify_msgs_keyed(const uint8_t* msgs, const uint64_t* moff, const uint8_t* sigs, const uint64_t* soff,
+                          const uint32_t* slots, size_t n, uint8_t* bitmap) override {
+        if (!registry_) return -2;
+        std::vector<uint8_t> tuples(n * 160, 0);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            ++keyed_batches_;
+            for (size_t i = 0; i < n; ++i)
+                if (slots[i] < keys_.size()) memcpy(&tuples[i * 160 + 96], keys_[slots[i]].data(), 64);
+        }
+        parallel_chunks(n, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i) {
+                sbv_p256_parse_der(sigs + soff[i], (size_t)(soff[i + 1] - soff[i]), &tuples[i * 160]);   // failure leaves r = s = 0
+                sha256(msgs + moff[i], (size_t)(moff[i + 1] - moff[i]), &tuples[i * 160 + 64]);
+            }
+        });
+        return fn_(tuples.data(), n, bitmap, user_);
+    }
     uint64_t keyed_batches() override { std::lock_guard<std::mutex> lk(mu_); return keyed_batches_; }
     // the stand-in knows which scheme its test runs: the same callback receives the 128-byte tuples
     int verify_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap) override { return fn_(tuples128, n, bitmap, user_); }

@@ -14,7 +14,7 @@ class ReplayResult(ctypes.Structure):
     _fields_ = [("setup_s", ctypes.c_double), ("verify_proposal_us", ctypes.c_double), ("prev_commits_us", ctypes.c_double),
                 ("commit_quorum_us", ctypes.c_double), ("batch_total_us", ctypes.c_double), ("batch_tuples", ctypes.c_uint64),
                 ("proposals_with_quorum", ctypes.c_uint64), ("backend_batches", ctypes.c_uint64),
-                ("max_backend_batch", ctypes.c_uint64), ("status", ctypes.c_int)]
+                ("max_backend_batch", ctypes.c_uint64), ("status", ctypes.c_int), ("batch_first_us", ctypes.c_double)]
 
 
 def load():

@@ -359,13 +359,17 @@ def test_product_backend_without_gpu_is_unavailable(lib):
         lib.sbvh_verifier_free(v)
 
 
-def test_replay_driver_runs_the_reference_call_pattern(lib, oracle):
-    hx = Harness(lib, oracle, wait_us=500)
+@pytest.mark.parametrize("backend_kind", [1, 2])
+def test_replay_driver_runs_the_reference_call_pattern(lib, oracle, backend_kind):
+    """backend_kind 2 = a backend with a key registry and a message front end (as libsbv has): the decision-replay batch
+    then goes through the raw-messages path (verify_msgs_keyed) instead of host-built tuples."""
+    hx = Harness(lib, oracle, wait_us=500, backend_kind=backend_kind)
     try:
         res = hostlib.ReplayResult()
         rc = lib.sbvh_replay(hx.v, 4, 20, 3, 6, 4, ctypes.byref(res))
         assert rc == 0 and res.status == 0
         assert res.batch_tuples == 6 * 3 and res.proposals_with_quorum == 6
         assert res.max_backend_batch >= 20
+        assert res.batch_first_us > 0 and res.batch_total_us > 0
     finally:
         hx.close()

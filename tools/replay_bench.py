@@ -50,6 +50,7 @@ def run(name, n_nodes, K, sequences, decisions, wait_us):
            "verify_proposal_us": res.verify_proposal_us, "verify_proposal_sigs_per_s": K / (res.verify_proposal_us * 1e-6) if res.verify_proposal_us else None,
            "prev_commits_serial_us": res.prev_commits_us, "commit_quorum_latency_us": res.commit_quorum_us,
            "decisions": decisions, "batch_tuples": res.batch_tuples, "batch_total_us": res.batch_total_us,
+           "batch_first_call_us": res.batch_first_us,
            "batch_sigs_per_s": res.batch_tuples / (res.batch_total_us * 1e-6) if res.batch_total_us else None,
            "amortised_us_per_decision": res.batch_total_us / decisions if decisions else None,
            "proposals_with_quorum": res.proposals_with_quorum, "backend_batches": res.backend_batches,
