@@ -81,6 +81,8 @@ def load() -> ctypes.CDLL:
                                                     ctypes.c_void_p]
     lib.sbv_ed25519_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.sbv_ed25519_verify_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    lib.sbv_ed25519_verify_msgs.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
+                                            ctypes.c_size_t, ctypes.c_char_p]
     lib.sbv_ed25519_make_tuples.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
                                             ctypes.c_size_t, ctypes.c_char_p]
     lib.sbv_p256_verify_msgs_keyed.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p,
@@ -184,6 +186,20 @@ def ed25519_make_tuples(sigs, pks, msgs) -> bytes:
     out = ctypes.create_string_buffer(max(1, 128 * n))
     _check(load().sbv_ed25519_make_tuples(b"".join(sigs), b"".join(pks), b"".join(msgs), offs, n, out))
     return out.raw[:128 * n]
+
+
+def ed25519_verify_msgs(sigs, pks, msgs) -> bytes:
+    """(64-byte sig, 32-byte pk, message) triples -> accept bitmap; SHA-512 and the reduction mod L run on the device."""
+    n = len(sigs)
+    offs = (ctypes.c_uint64 * (n + 1))()
+    acc = 0
+    for i, m in enumerate(msgs):
+        offs[i] = acc
+        acc += len(m)
+    offs[n] = acc
+    out = ctypes.create_string_buffer(max(1, (n + 7) // 8))
+    _check(load().sbv_ed25519_verify_msgs(b"".join(sigs), b"".join(pks), b"".join(msgs), offs, n, out))
+    return out.raw[:(n + 7) // 8]
 
 
 def ed25519_verify_batch(tuples: bytes, n: Optional[int] = None) -> bytes:

@@ -19,6 +19,9 @@ struct EdGroupBuffers {
 hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, const GroupBuffers& b, const EdGroupBuffers& eb,
                                          u32* d_qtab, const aniels* d_btab, uint8_t* d_bitmap, hipStream_t stream,
                                          const GroupSync& y);
+// message front end: raw signatures / keys / messages -> 128-byte tuples on the device (sha512_dev.h)
+hipError_t launch_ed_msg_frontend(const uint8_t* d_sigs, const uint8_t* d_pks, const uint8_t* d_msgs, const u64* d_moff, size_t n,
+                                  u32* d_tuples, hipStream_t stream);
 #define SBV_ED_KEYTAB_ENTRIES_PER_KEY 4096   // 32 windows x 128 entries (ed25519_group.h)
 void host_build_ed_b16(aniels* out);      // 16 x 32768 affine-Niels multiples of B: the comb the device kernels use
 }  // namespace sbv

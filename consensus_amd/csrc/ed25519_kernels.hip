@@ -14,6 +14,7 @@
 
 #include "ed25519_core.h"
 #include "p256_kernels.h"
+#include "sha512_dev.h"
 
 namespace sbv {
 
@@ -62,6 +63,27 @@ hipError_t launch_ed25519_verify(const uint8_t* d_tuples, size_t n, u32* d_qtab,
     if (n == 0) return hipSuccess;
     const unsigned grid = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
     hipLaunchKernelGGL(k_ed25519_verify, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, n, d_qtab, d_btab, d_bitmap);
+    return hipGetLastError();
+}
+
+// Message front end (sha512_dev.h): one signature per lane, k = SHA-512(R | A | M) mod L, writes the 128-byte tuples
+// the verify kernels take.  sigs = n x 64 bytes, pks = n x 32 bytes, message i = msgs[moff[i] .. moff[i+1]).
+__global__ __launch_bounds__(256) void k_ed_msg_frontend(const uint8_t* __restrict__ sigs, const uint8_t* __restrict__ pks,
+                                                         const uint8_t* __restrict__ msgs, const u64* __restrict__ moff, size_t n,
+                                                         u32* __restrict__ tuples) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 m0 = moff[i], m1 = moff[i + 1];
+    u32 rec[32];
+    ed_msg_frontend_lane(sigs + i * 64, pks + i * 32, msgs + m0, (size_t)(m1 - m0), rec);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) tuples[i * 32 + k] = rec[k];
+}
+
+hipError_t launch_ed_msg_frontend(const uint8_t* d_sigs, const uint8_t* d_pks, const uint8_t* d_msgs, const u64* d_moff, size_t n,
+                                  u32* d_tuples, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_ed_msg_frontend, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_sigs, d_pks, d_msgs, d_moff, n, d_tuples);
     return hipGetLastError();
 }
 

@@ -53,7 +53,7 @@ struct Context {
     // message front end staging (grown on demand)
     uint8_t* d_msgs = nullptr; size_t msgs_cap = 0;
     uint8_t* d_sigs = nullptr; size_t sigs_cap = 0;
-    uint64_t* d_moff = nullptr; uint64_t* d_soff = nullptr; size_t off_cap = 0;
+    uint64_t* d_moff = nullptr; uint64_t* d_soff = nullptr; size_t moff_cap = 0, soff_cap = 0;
     sbv::aniels* d_btab = nullptr;      // Ed25519 base-point comb, built on first use
     // registered keys
     sbv::apt* d_ktab = nullptr;
@@ -263,7 +263,7 @@ int ensure_key_capacity(Context& c, size_t want) {
     if (c.d_sigs) (void)hipFree(c.d_sigs);
     if (c.d_moff) (void)hipFree(c.d_moff);
     if (c.d_soff) (void)hipFree(c.d_soff);
-    c.d_msgs = c.d_sigs = nullptr; c.d_moff = c.d_soff = nullptr; c.msgs_cap = c.sigs_cap = c.off_cap = 0;
+    c.d_msgs = c.d_sigs = nullptr; c.d_moff = c.d_soff = nullptr; c.msgs_cap = c.sigs_cap = c.moff_cap = c.soff_cap = 0;
     if (c.d_ktab) (void)hipFree(c.d_ktab);
     if (c.d_kvalid) (void)hipFree(c.d_kvalid);
     c.d_ktab = nt;
@@ -349,7 +349,7 @@ extern "C" int sbv_shutdown(void) {
     if (c.d_sigs) (void)hipFree(c.d_sigs);
     if (c.d_moff) (void)hipFree(c.d_moff);
     if (c.d_soff) (void)hipFree(c.d_soff);
-    c.d_msgs = c.d_sigs = nullptr; c.d_moff = c.d_soff = nullptr; c.msgs_cap = c.sigs_cap = c.off_cap = 0;
+    c.d_msgs = c.d_sigs = nullptr; c.d_moff = c.d_soff = nullptr; c.msgs_cap = c.sigs_cap = c.moff_cap = c.soff_cap = 0;
     if (c.d_ktab) (void)hipFree(c.d_ktab);
     if (c.d_kvalid) (void)hipFree(c.d_kvalid);
     c.d_ktab = nullptr; c.d_kvalid = nullptr; c.key_cap = c.nkeys = 0;
@@ -708,12 +708,10 @@ extern "C" int sbv_p256_verify_msgs_keyed(const uint8_t* msgs, const uint64_t* m
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
     int rc = ensure_capacity(c, n);
     if (rc != SBV_OK) return rc;
-    size_t oc1 = c.off_cap, oc2 = c.off_cap;
     if ((rc = grow(c.d_msgs, c.msgs_cap, mbytes + 16)) != SBV_OK) return rc;
     if ((rc = grow(c.d_sigs, c.sigs_cap, sbytes + 16)) != SBV_OK) return rc;
-    if ((rc = grow(c.d_moff, oc1, n + 1)) != SBV_OK) return rc;
-    if ((rc = grow(c.d_soff, oc2, n + 1)) != SBV_OK) return rc;
-    c.off_cap = oc1 < oc2 ? oc1 : oc2;
+    if ((rc = grow(c.d_moff, c.moff_cap, n + 1)) != SBV_OK) return rc;
+    if ((rc = grow(c.d_soff, c.soff_cap, n + 1)) != SBV_OK) return rc;
     if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(c.stream, c.busy, 0));
     sbv_timing tm{};
     tm.n = n;
@@ -734,6 +732,52 @@ extern "C" int sbv_p256_verify_msgs_keyed(const uint8_t* msgs, const uint64_t* m
     memcpy(accept_bitmap, c.h_bitmap, (n + 7) / 8);
     tm.h2d_us = 1e3 * ms_between(c.ev[0], c.ev[1]);
     tm.prep_us = 1e3 * ms_between(c.ev[1], c.ev[2]);       // front end + stage A
+    tm.verify_us = 1e3 * ms_between(c.ev[2], c.ev[3]);
+    tm.d2h_us = 1e3 * ms_between(c.ev[3], c.ev[4]);
+    c.busy_valid = false;
+    tm.total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    c.timing = tm;
+    return SBV_OK;
+}
+
+extern "C" int sbv_ed25519_verify_msgs(const uint8_t* sigs, const uint8_t* pks, const uint8_t* msgs, const uint64_t* msg_offsets,
+                                       size_t n, uint8_t* accept_bitmap) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (n == 0) return SBV_OK;
+    if (!sigs || !pks || !msg_offsets || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
+    if (n > kMaxChunk) { g_err = "batch larger than 2^21: split it"; return SBV_EINVAL; }
+    const size_t mbytes = (size_t)msg_offsets[n];
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    int rc = ensure_capacity(c, n);
+    if (rc != SBV_OK) return rc;
+    if ((rc = ensure_ed_table(c)) != SBV_OK) return rc;
+    // staging: messages in d_msgs, signatures (64 B each) followed by keys (32 B each) in d_sigs, offsets in d_moff
+    if ((rc = grow(c.d_msgs, c.msgs_cap, mbytes + 16)) != SBV_OK) return rc;
+    if ((rc = grow(c.d_sigs, c.sigs_cap, n * 96 + 16)) != SBV_OK) return rc;
+    if ((rc = grow(c.d_moff, c.moff_cap, n + 1)) != SBV_OK) return rc;
+    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(c.stream, c.busy, 0));
+    sbv_timing tm{};
+    tm.n = n;
+    HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[0], c.stream));
+    if (mbytes) HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_msgs, msgs, mbytes, hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_sigs, sigs, n * 64, hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_sigs + n * 64, pks, n * 32, hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_moff, msg_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
+    HIP_TRY(SBV_EDEVICE, sbv::launch_ed_msg_frontend(c.d_sigs, c.d_sigs + n * 64, c.d_msgs, c.d_moff, n,
+                                                     reinterpret_cast<u32*>(c.d_tuples), c.stream));
+    HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[2], c.stream));
+    if ((rc = enqueue_ed25519(c, c.d_tuples, n, c.d_bitmap, c.stream)) != SBV_OK) return rc;
+    HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
+    HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.h_bitmap, c.d_bitmap, (n + 7) / 8, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[4], c.stream));
+    HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(c.stream));
+    memcpy(accept_bitmap, c.h_bitmap, (n + 7) / 8);
+    tm.h2d_us = 1e3 * ms_between(c.ev[0], c.ev[1]);
+    tm.prep_us = 1e3 * ms_between(c.ev[1], c.ev[2]);       // the front end
     tm.verify_us = 1e3 * ms_between(c.ev[2], c.ev[3]);
     tm.d2h_us = 1e3 * ms_between(c.ev[3], c.ev[4]);
     c.busy_valid = false;

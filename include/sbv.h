@@ -108,14 +108,20 @@ int sbv_p256_verify_msgs_keyed(const uint8_t* msgs, const uint64_t* msg_offsets,
  * A decoded with Go's leniency (non-canonical y accepted, no small-order rejection), cofactorless
  * [S]B = R + [k]A checked by re-encoding R byte-wise.
  * Tuple, 128 bytes little-endian as on the wire:  R (32) | S (32) | public key (32) | k (32), where
- * k = SHA-512(R || pk || msg) mod L is produced by sbv_ed25519_hram_batch (host).  A tuple with
- * k >= L or S >= L is rejected.  len(sig) != 64 is the caller's reject (encode as all-zero R, S = L). */
+ * k = SHA-512(R || pk || msg) mod L is produced by sbv_ed25519_make_tuples (host) or, for the raw-message
+ * entry sbv_ed25519_verify_msgs, on the device.  A tuple with k >= L or S >= L is rejected.  len(sig) != 64 is
+ * the caller's reject (encode S = 2^256 - 1). */
 #define SBV_ED25519_TUPLE_BYTES 128
 int sbv_ed25519_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap);
 int sbv_ed25519_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, void* hip_stream);
 /* Builds the tuples: sigs n x 64, pks n x 32, msgs packed (offsets[i]..offsets[i+1]) -> tuples n x 128. */
 int sbv_ed25519_make_tuples(const uint8_t* sigs, const uint8_t* pks, const uint8_t* msgs, const uint64_t* offsets,
                             size_t n, uint8_t* tuples_out);
+/* Raw-message entry: the same inputs as sbv_ed25519_make_tuples, hashed on the device (SHA-512 + reduction mod L per
+ * lane, consensus_amd/csrc/sha512_dev.h) and verified in the same call; n <= 2^21.  What a Verifier's
+ * VerifyProposal / decision replay hands over when signatures are Ed25519 (internal/bft/view.go:555). */
+int sbv_ed25519_verify_msgs(const uint8_t* sigs, const uint8_t* pks, const uint8_t* msgs, const uint64_t* msg_offsets,
+                            size_t n, uint8_t* accept_bitmap);
 
 /* Strict DER parse of an ECDSA-Sig-Value with Go x/crypto/cryptobyte rules
  * (crypto/ecdsa.parseSignature): out = r | s, 32 bytes each, big-endian, zero padded.

@@ -13,6 +13,7 @@
 #include "../../consensus_amd/csrc/p256_core.h"
 #include "../../consensus_amd/csrc/ed25519_core.h"
 #include "../../consensus_amd/csrc/ed25519_group.h"
+#include "../../consensus_amd/csrc/sha512_dev.h"
 #include "../../consensus_amd/csrc/sha256_dev.h"
 #include "../../consensus_amd/csrc/p256_group.h"
 
@@ -283,6 +284,13 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     }
     free(qtab); free(tmpa); free(ktab); free(jbases); free(tuples);
     if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }
+}
+// Ed25519 message front end (sha512_dev.h): 512-bit little-endian x -> x mod L; sig | pk | msg -> 128-byte tuple
+void sbve_mod_l_512(const u32* x16, u32* out8) { mod_l_512(x16, out8); }
+void sbve_ed_msg_frontend(const uint8_t* sig64, const uint8_t* a32, const uint8_t* msg, size_t mlen, uint8_t out128[128]) {
+    u32 w[32];
+    ed_msg_frontend_lane(sig64, a32, msg, mlen, w);
+    memcpy(out128, w, 128);
 }
 void sbve_fe25_inv_gcd(const u32* a, u32* out) { fe25 x, z; memcpy(&x, a, 32); fe25_inv_gcd(z, x); memcpy(out, &z, 32); }
 void sbve_fe25_mul(const u32* a, const u32* b, u32* out) { fe25 x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe25_mul(z, x, y); memcpy(out, &z, 32); }

@@ -128,3 +128,27 @@ def test_grouped_by_key_inside_the_batch_matches_plain_kernel(emul, oracle, ed_v
             assert stats[0] == 3
         if min_count == 10**6:
             assert stats[0] == 0 and stats[2] == total
+
+
+def test_device_message_front_end_sha512_and_mod_l(emul):
+    """sha512_dev.h: the 512-bit reduction mod L against big ints (edge values: 0, L-1, L, 2L, 2^252 multiples, 2^512-1)
+    and the whole lane — SHA-512(R|A|M) mod L — against hashlib for message lengths around the block boundaries."""
+    import hashlib
+    rng = random.Random(99)
+    L = ed.L
+    out = (ctypes.c_uint32 * 8)()
+    edge = [0, 1, L - 1, L, L + 1, 2 * L, 2**252, 2**252 - 1, 2**253, 2**256 - 1, 2**256, 2**511, 2**512 - 1, (2**512 - 1) // L * L,
+            (2**512 - 1) // L * L - 1, L << 160, (L << 160) - 1, L << 64, 2**385, 2**414 - 1]
+    for x in edge + [rng.getrandbits(512) for _ in range(400)] + [rng.getrandbits(k) for k in (253, 260, 300, 386, 450) for _ in range(20)]:
+        arr = (ctypes.c_uint32 * 16)(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(16)])
+        emul.sbve_mod_l_512(arr, out)
+        assert val(out) == x % L, hex(x)
+    emul.sbve_ed_msg_frontend.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    t = ctypes.create_string_buffer(128)
+    for mlen in [0, 1, 31, 46, 47, 48, 63, 64, 111, 112, 113, 127, 128, 129, 175, 176, 300, 1000]:
+        sig = bytes(rng.getrandbits(8) for _ in range(64))
+        pk = bytes(rng.getrandbits(8) for _ in range(32))
+        msg = bytes(rng.getrandbits(8) for _ in range(mlen))
+        emul.sbve_ed_msg_frontend(sig, pk, msg, mlen, t)
+        k = int.from_bytes(hashlib.sha512(sig[:32] + pk + msg).digest(), "little") % L
+        assert t.raw == sig + pk + k.to_bytes(32, "little"), mlen

@@ -113,3 +113,33 @@ def test_grouped_vs_plain_full_batch(gpu, oracle):
         gpu.set_grouping(True, 131072, 64, 2048)
     print(f"\n[ed25519 2^20] grouped {times[True]:.0f} us ({n / times[True]:.1f} M/s) | one lane per signature {times[False]:.0f} us "
           f"({n / times[False]:.1f} M/s)")
+
+
+def test_device_message_front_end_equals_host_tuple_builder(gpu, oracle):
+    """sbv_ed25519_verify_msgs (SHA-512 + mod L on the device, sha512_dev.h) == sbv_ed25519_make_tuples + verify_batch on the
+    golden vectors and on signed messages of every length around the SHA-512 block boundaries, some tampered."""
+    import random
+    vs = json.load(open(os.path.join(GOLDEN, "ed25519_vectors.json")))["vectors"]
+    sigs = [bytes.fromhex(v["sig"]) for v in vs]
+    pks = [bytes.fromhex(v["pk"]) for v in vs]
+    msgs = [bytes.fromhex(v["msg"]) for v in vs]
+    keep = [i for i, s in enumerate(sigs) if len(s) == 64]           # wrong-length signatures are the caller's reject
+    sigs, pks, msgs = [sigs[i] for i in keep], [pks[i] for i in keep], [msgs[i] for i in keep]
+    want = [vs[i]["accept"] for i in keep]
+    rng = random.Random(512)
+    oracle.sbvo_ed25519_public_key.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    oracle.sbvo_ed25519_sign.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    for j, mlen in enumerate([0, 1, 46, 47, 48, 63, 64, 65, 111, 112, 113, 127, 128, 129, 175, 176, 177, 500, 3000]):
+        seed = bytes([j]) * 32
+        pk, sig = ctypes.create_string_buffer(32), ctypes.create_string_buffer(64)
+        msg = bytes(rng.getrandbits(8) for _ in range(mlen))
+        oracle.sbvo_ed25519_public_key(seed, pk)
+        oracle.sbvo_ed25519_sign(seed, msg, mlen, sig)
+        sigs.append(sig.raw); pks.append(pk.raw); msgs.append(msg); want.append(True)
+        if mlen:
+            bad = bytearray(msg); bad[mlen // 2] ^= 1
+            sigs.append(sig.raw); pks.append(pk.raw); msgs.append(bytes(bad)); want.append(False)
+    n = len(sigs)
+    got = sbv.bitmap_to_list(gpu.ed25519_verify_msgs(sigs, pks, msgs), n)
+    via_tuples = sbv.bitmap_to_list(gpu.ed25519_verify_batch(gpu.ed25519_make_tuples(sigs, pks, msgs), n), n)
+    assert got == via_tuples == want
