@@ -2,6 +2,8 @@
 
 #include <functional>
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -526,6 +528,11 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
                                          std::vector<uint8_t>* out) {
     const size_t n = sigs.size();
     if (props.size() != n) return Status::Invalid("size mismatch");
+    // SBVH_TRACE=1: phase times of this call on stderr (host pass / byte layout / backend / total)
+    static const bool trace = [] { const char* e = getenv("SBVH_TRACE"); return e && e[0] == '1'; }();
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = trace ? now() : 0;
+    double t_pass1 = 0, t_layout = 0, t_backend = 0;
     std::vector<uint8_t> bitmap((n + 7) / 8, 0), pre(n, 1);
     std::vector<uint32_t> slots(n, 0);
     std::atomic<int> unkeyed(0);
@@ -552,6 +559,7 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
             if (slot < 0) unkeyed.store(1); else slots[i] = (uint32_t)slot;
         }
     });
+    if (trace) t_pass1 = now();
     int rc = -2;
     if (n && ed()) {
         // Ed25519: k = SHA-512(R | A | msg) mod L on the host workers, one batch of 128-byte tuples
@@ -582,7 +590,9 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
                 if (pre[i]) memcpy(&sbuf[soff[i]], sigs[i].value.data(), sigs[i].value.size());
             }
         });
+        if (trace) t_layout = now();
         rc = co_.backend().verify_msgs_keyed(mbuf.get(), moff.data(), sbuf.get(), soff.data(), slots.data(), n, bitmap.data());
+        if (trace) t_backend = now();
     }
     if (n && rc == -2 && !ed()) {
         // backend without the front end (or unregistered signers): build tuples on the host
@@ -605,6 +615,9 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
     if (n && rc != 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());
     out->assign(n, 0);
     for (size_t i = 0; i < n; ++i) (*out)[i] = pre[i] && ((bitmap[i >> 3] >> (i & 7)) & 1);
+    if (trace)
+        fprintf(stderr, "[sbvh trace] VerifyConsenterSigBatch n=%zu: host pass %.0f us, layout %.0f us, backend %.0f us, total %.0f us\n", n,
+                t_pass1 - t_start, t_layout ? t_layout - t_pass1 : 0.0, t_backend ? t_backend - t_layout : 0.0, now() - t_start);
     return Status::Ok();
 }
 
