@@ -786,6 +786,23 @@ extern "C" int sbv_ed25519_verify_msgs(const uint8_t* sigs, const uint8_t* pks, 
     return SBV_OK;
 }
 
+extern "C" void* sbv_host_alloc(size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Context& c = g_ctx;
+    if (!c.ready || bytes == 0) return nullptr;
+    if (hipSetDevice(c.device) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        g_err = "hipHostMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void sbv_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uint32_t max_groups) {
     std::lock_guard<std::mutex> lk(g_mu);
     Context& c = g_ctx;

@@ -134,6 +134,8 @@ class SbvBackend : public Backend {
         if (rc_ != SBV_OK) return rc_;
         return sbv_ed25519_verify_batch(tuples128, n, bitmap);
     }
+    void* host_alloc(size_t bytes) override { return rc_ == SBV_OK ? sbv_host_alloc(bytes) : nullptr; }
+    void host_free(void* p) override { sbv_host_free(p); }
     int verify_msgs_keyed(const uint8_t* msgs, const uint64_t* moff, const uint8_t* sigs, const uint64_t* soff,
                           const uint32_t* slots, size_t n, uint8_t* bitmap) override {
         if (rc_ != SBV_OK) return rc_;
@@ -315,6 +317,31 @@ void Coalescer::run() {
 // ---- verifier ------------------------------------------------------------------------------------
 Verifier::Verifier(std::shared_ptr<Backend> be, const VerifierOptions& opt)
     : opt_(opt), co_(be, opt.coalesce_max, opt.coalesce_wait) {}
+
+Verifier::~Verifier() {
+    for (Staging* s : {&st_msgs_, &st_sigs_, &st_moff_, &st_soff_, &st_slots_}) staging_release(*s);
+}
+
+void Verifier::staging_release(Staging& s) {
+    if (s.p) {
+        if (s.pinned) co_.backend().host_free(s.p);
+        else free(s.p);
+    }
+    s = Staging();
+}
+
+void* Verifier::staging(Staging& s, size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    if (s.cap >= bytes) return s.p;
+    staging_release(s);
+    size_t cap = 4096;
+    while (cap < bytes) cap *= 2;
+    s.p = co_.backend().host_alloc(cap);
+    s.pinned = s.p != nullptr;
+    if (!s.p) s.p = malloc(cap);
+    s.cap = s.p ? cap : 0;
+    return s.p;
+}
 
 void Verifier::RegisterConsenter(uint64_t id, const uint8_t* q) {
     const long slot = ed() ? -1 : co_.backend().register_key(q);     // -1: no key registry (or Ed25519: grouped per batch)
@@ -573,7 +600,13 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
     } else if (n && !unkeyed.load()) {
         // device front end: the host only lays the bytes out; SHA-256 and DER parsing run on the GPU.
         // Pre-rejected entries get an empty signature (DER failure -> r = s = 0 -> reject).
-        std::vector<uint64_t> moff(n + 1), soff(n + 1);
+        // All five arrays live in grow-only staging memory, page-locked when the backend has it (sbv_host_alloc):
+        // nothing is zero-filled, the workers write their own slices, and the H2D copies are plain DMA.
+        std::lock_guard<std::mutex> staging_lock(staging_mu_);
+        uint64_t* moff = (uint64_t*)staging(st_moff_, (n + 1) * sizeof(uint64_t));
+        uint64_t* soff = (uint64_t*)staging(st_soff_, (n + 1) * sizeof(uint64_t));
+        uint32_t* dslots = (uint32_t*)staging(st_slots_, n * sizeof(uint32_t));
+        if (!moff || !soff || !dslots) return Status::Unavailable("out of host memory");
         uint64_t a = 0, b = 0;
         for (size_t i = 0; i < n; ++i) {
             moff[i] = a; soff[i] = b;
@@ -581,17 +614,18 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
             b += pre[i] ? sigs[i].value.size() : 0;
         }
         moff[n] = a; soff[n] = b;
-        // uninitialised staging: zero-filling ~150 B per signature on one thread cost more than the GPU's share of a
-        // 550 000-signature replay; the workers touch (and page in) their own slices
-        std::unique_ptr<uint8_t[]> mbuf(new uint8_t[a ? a : 1]), sbuf(new uint8_t[b ? b : 1]);
+        uint8_t* mbuf = (uint8_t*)staging(st_msgs_, a);
+        uint8_t* sbuf = (uint8_t*)staging(st_sigs_, b);
+        if (!mbuf || !sbuf) return Status::Unavailable("out of host memory");
         parallel_chunks(n, [&](size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; ++i) {
-                memcpy(&mbuf[moff[i]], sigs[i].msg.data(), sigs[i].msg.size());
-                if (pre[i]) memcpy(&sbuf[soff[i]], sigs[i].value.data(), sigs[i].value.size());
+                memcpy(mbuf + moff[i], sigs[i].msg.data(), sigs[i].msg.size());
+                if (pre[i]) memcpy(sbuf + soff[i], sigs[i].value.data(), sigs[i].value.size());
+                dslots[i] = slots[i];
             }
         });
         if (trace) t_layout = now();
-        rc = co_.backend().verify_msgs_keyed(mbuf.get(), moff.data(), sbuf.get(), soff.data(), slots.data(), n, bitmap.data());
+        rc = co_.backend().verify_msgs_keyed(mbuf, moff, sbuf, soff, dslots, n, bitmap.data());
         if (trace) t_backend = now();
     }
     if (n && rc == -2 && !ed()) {

@@ -46,6 +46,9 @@ class Backend {
     // use verify() with the key carried in the tuple).
     virtual long register_key(const uint8_t q[64]) { (void)q; return -1; }
     virtual uint64_t keyed_batches() { return 0; }      // test hook: how many verify_keyed batches ran
+    // Page-locked staging memory (include/sbv.h: sbv_host_alloc); nullptr = none available, the caller uses the heap
+    virtual void* host_alloc(size_t bytes) { (void)bytes; return nullptr; }
+    virtual void host_free(void* p) { (void)p; }
     // Ed25519 variant (include/sbv.h: sbv_ed25519_verify_batch): n tuples of 128 bytes R|S|A|k.  -2 when unsupported.
     virtual int verify_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap) { (void)tuples128; (void)n; (void)bitmap; return -2; }
     virtual int verify_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap) {
@@ -115,6 +118,7 @@ struct VerifierOptions {
 class Verifier {
  public:
     Verifier(std::shared_ptr<Backend> be, const VerifierOptions& opt = VerifierOptions());
+    ~Verifier();
 
     // key registry (id -> public key: 64 bytes Qx|Qy, or the first 32 bytes = A_enc under Scheme::ED25519); the kernel
     // re-validates every key
@@ -161,6 +165,15 @@ class Verifier {
     // sequence (view.go:435, 443, 524) and every VerifyConsenterSig must bind its message to it; for a
     // 10k-request proposal that is ~4 ms of CPU per call.  Exact: an entry only
     // hits after a full field-by-field comparison.
+    // Grow-only staging arrays of the raw-messages batch path, page-locked when the backend offers it: handing
+    // pageable memory to a ~100 MB batch costs more in the runtime's pinning than the kernels take.
+    struct Staging {
+        void* p = nullptr; size_t cap = 0; bool pinned = false;
+    };
+    void* staging(Staging& s, size_t bytes);
+    void staging_release(Staging& s);
+    std::mutex staging_mu_;
+    Staging st_msgs_, st_sigs_, st_moff_, st_soff_, st_slots_;
     bytes digest_memo(const Proposal& p);
     struct DigestEntry { Proposal p; bytes digest; };
     std::mutex digest_mu_;

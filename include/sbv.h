@@ -158,6 +158,13 @@ int sbv_profile_read_dominant(double* dominant_us, uint64_t* dominant_launches);
  * for their public key alone (pointFromAffine: coordinate >= p or off the curve).  Synchronises the device. */
 int sbv_p256_last_group_stats(uint32_t out[4]);
 
+/* Page-locked host memory for the host-pointer entries.  Handing pageable memory to a 100 MB batch makes the HIP
+ * runtime pin (or bounce) it inside the call — measured at 25 ms for a 550 000-signature replay batch whose kernels
+ * take 5 ms.  A caller that lays its batch out in sbv_host_alloc memory gets a plain DMA.  NULL on failure (or
+ * before sbv_init); sbv_host_free accepts NULL. */
+void* sbv_host_alloc(size_t bytes);
+void sbv_host_free(void* p);
+
 /* Human-readable description of the last failure in this process ("" if none). */
 const char* sbv_last_error(void);
 
