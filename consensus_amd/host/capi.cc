@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "p256_host.h"
+#include "ed25519_host.h"
 #include "verifier.h"
 
 using namespace sbvhost;
@@ -157,6 +158,64 @@ void sbvh_proposal_digest(const void* payload, size_t pl, const void* header, si
     memcpy(hex_out, d.c_str(), 65);
 }
 void sbvh_compute_quorum(uint64_t n, int* q, int* f) { compute_quorum(n, q, f); }
+
+// ---- synthetic Ed25519 traffic (tools/bench_ed25519.py) --------------------------------------------------
+// nkeys RFC 8032 keys from seeds SHA-512("sbv-ed-key" | seed | i)[0..32), tuple i = signature by key i % nkeys over a
+// 32-byte counter message; every invalid_every-th tuple has one pseudo-random bit flipped in sig | pk (k is recomputed
+// from the flipped bytes, as a verifier would).  Derivations are byte-identical to oracle/ed25519_oracle.c's generator
+// so the two cross-check (tests/test_datagen.py); expect = 1 for untouched tuples, 0 for flipped ones.
+void sbvh_ed25519_gen_batch(uint32_t seed, size_t n, size_t nkeys, unsigned invalid_every, uint8_t* tuples, uint8_t* expect,
+                            int threads) {
+    std::vector<uint8_t> seeds(32 * nkeys), pks(32 * nkeys);
+    for (size_t i = 0; i < nkeys; ++i) {
+        uint8_t lbl[24], h[64];
+        memcpy(lbl, "sbv-ed-key", 10);
+        lbl[10] = (uint8_t)(seed >> 24); lbl[11] = (uint8_t)(seed >> 16); lbl[12] = (uint8_t)(seed >> 8); lbl[13] = (uint8_t)seed;
+        for (int b = 0; b < 8; ++b) lbl[14 + b] = (uint8_t)((uint64_t)i >> (56 - 8 * b));
+        sha512(lbl, 22, h);
+        memcpy(&seeds[32 * i], h, 32);
+        ed25519_public_key(&seeds[32 * i], &pks[32 * i]);
+    }
+    if (expect) memset(expect, 0, (n + 7) / 8);
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    const size_t per = ((n + threads - 1) / threads + 7) & ~(size_t)7;      // whole bitmap bytes per thread
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) {
+        const size_t lo = (size_t)t * per, hi = lo + per < n ? lo + per : n;
+        if (lo >= n) break;
+        th.emplace_back([=, &seeds, &pks] {
+            for (size_t i = lo; i < hi; ++i) {
+                uint8_t msg[32], sig[64], pk[32];
+                memset(msg, 0, 32);
+                memcpy(msg, "sbv-ed-msg", 10);
+                msg[12] = (uint8_t)(seed >> 24); msg[13] = (uint8_t)(seed >> 16); msg[14] = (uint8_t)(seed >> 8); msg[15] = (uint8_t)seed;
+                for (int b = 0; b < 8; ++b) msg[24 + b] = (uint8_t)((uint64_t)i >> (56 - 8 * b));
+                const size_t key = i % nkeys;
+                ed25519_sign(&seeds[32 * key], msg, 32, sig);
+                memcpy(pk, &pks[32 * key], 32);
+                bool valid = true;
+                if (invalid_every && (i % invalid_every) == invalid_every - 1) {
+                    uint8_t lbl[24], sel[64];
+                    memcpy(lbl, "sbv-ed-flip", 11);
+                    for (int b = 0; b < 8; ++b) lbl[11 + b] = (uint8_t)((uint64_t)i >> (56 - 8 * b));
+                    lbl[19] = (uint8_t)(seed >> 24); lbl[20] = (uint8_t)(seed >> 16); lbl[21] = (uint8_t)(seed >> 8); lbl[22] = (uint8_t)seed;
+                    sha512(lbl, 23, sel);
+                    const unsigned bit = (((unsigned)sel[0] << 8) | sel[1]) % 768u;      // 96 bytes: sig | pk
+                    if (bit < 512) sig[bit >> 3] ^= (uint8_t)(1u << (bit & 7));
+                    else pk[(bit - 512) >> 3] ^= (uint8_t)(1u << (bit & 7));
+                    valid = false;
+                }
+                uint8_t* t128 = tuples + 128 * i;
+                memcpy(t128, sig, 64);
+                memcpy(t128 + 64, pk, 32);
+                ed25519_hram(sig, pk, msg, 32, t128 + 96);
+                if (expect && valid) expect[i >> 3] |= (uint8_t)(1u << (i & 7));
+            }
+        });
+    }
+    for (auto& x : th) x.join();
+}
 
 // ---- replay: the reference's call pattern at the seam -------------------------------------------------
 struct sbvh_replay_result {

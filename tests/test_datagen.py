@@ -22,3 +22,21 @@ def test_openssl_datagen_equals_oracle_generator(oracle):
     bm = ctypes.create_string_buffer((n + 7) // 8)
     oracle.sbvo_p256_verify_batch(tup, n, bm, 4)
     assert bm.raw == exp.raw
+
+
+def test_host_ed25519_generator_equals_oracle_generator(oracle):
+    """tools/bench_ed25519.py's batch comes from the host library's RFC 8032 signer (consensus_amd/host/ed25519_host.cc,
+    the api.Signer half of the product); the oracle has its own signer.  Same seed -> byte-identical tuples (which pins
+    both signers, both SHA-512s and both mod-L reductions against each other on thousands of signatures), and the host
+    generator's "corrupted => invalid" flags agree with the oracle's verdicts."""
+    import hostlib
+    h = hostlib.load()
+    oracle.sbvo_ed25519_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int]
+    n = 4000
+    t1, e1 = ctypes.create_string_buffer(128 * n), ctypes.create_string_buffer((n + 7) // 8)
+    t2, e2 = ctypes.create_string_buffer(128 * n), ctypes.create_string_buffer((n + 7) // 8)
+    h.sbvh_ed25519_gen_batch(0x5B7F2026, n, 37, 8, ctypes.addressof(t1), ctypes.addressof(e1), 4)
+    oracle.sbvo_ed25519_gen_batch(0x5B7F2026, n, 37, 8, t2, e2, 4)
+    assert t1.raw == t2.raw
+    assert e1.raw == e2.raw

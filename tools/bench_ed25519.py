@@ -22,12 +22,13 @@ cache = f"/tmp/sbv_ed_batch_{n}.npz"
 if os.path.exists(cache):
     z = np.load(cache); tuples, expect = z["tuples"], z["expect"]
 else:
-    # synthetic signatures come from the oracle's RFC 8032 signer (test-infrastructure use: data only)
-    o = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsbv_oracle.so"))
-    o.sbvo_ed25519_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p,
-                                         ctypes.c_void_p, ctypes.c_int]
+    # synthetic signatures come from the host library's RFC 8032 signer (consensus_amd/host/ed25519_host.cc: the
+    # api.Signer half of the product; cross-checked byte for byte against the oracle's generator in tests/test_datagen.py)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hostlib  # noqa: E402
+    h = hostlib.load()
     tuples = np.zeros(n * 128, dtype=np.uint8); expect = np.zeros((n + 7) // 8, dtype=np.uint8)
-    o.sbvo_ed25519_gen_batch(0x5B7F2026, n, 1024, 8, tuples.ctypes.data, expect.ctypes.data, os.cpu_count() or 1)
+    h.sbvh_ed25519_gen_batch(0x5B7F2026, n, 1024, 8, tuples.ctypes.data, expect.ctypes.data, os.cpu_count() or 1)
     np.savez(cache, tuples=tuples, expect=expect)
 d_t = torch.from_numpy(tuples).cuda()
 d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
