@@ -337,3 +337,31 @@ def test_grouped_by_key_inside_the_batch_matches_generic(emul, oracle, golden_ve
             assert stats[0] == 0 and stats[2] + stats[3] == total and stats[3] >= 40    # the repeated off-curve key at least
     emul.sbve_set_group_chunks(3)
     emul.sbve_set_group_parts(4)
+
+
+def test_grouped_verdicts_do_not_depend_on_tuple_order(emul, oracle, golden_vectors):
+    """Size-independent property of the grouped step: which tuple represents a key, which slot a key gets and where a
+    tuple lands in the index lists all depend on the order of the batch — the verdicts must not.  A shuffled batch gives
+    the shuffled bitmap, and verifying twice gives the same answer (nothing is carried from call to call)."""
+    emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    n = 600
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0x0DDE, n, 5, 4, tup, exp, 4)
+    tuples = [bytes.fromhex(v["tuple"]) for v in vs] + [tup.raw[160 * i:160 * i + 160] for i in range(n)]
+    want = [v["accept"] for v in vs] + _bitmap_list(exp.raw, n)
+    total = len(tuples)
+    rng = random.Random(4242)
+    stats = (ctypes.c_uint32 * 4)()
+    for trial in range(3):
+        perm = list(range(total))
+        if trial:
+            rng.shuffle(perm)
+        blob = b"".join(tuples[p] for p in perm)
+        for _ in range(2):                                   # idempotence
+            bm = ctypes.create_string_buffer((total + 7) // 8)
+            emul.sbve_p256_verify_batch_grouped(blob, total, bm, 8, 64, 12, stats)
+            got = _bitmap_list(bm.raw, total)
+            assert got == [want[p] for p in perm], trial
