@@ -373,3 +373,42 @@ def test_replay_driver_runs_the_reference_call_pattern(lib, oracle, backend_kind
         assert res.batch_first_us > 0 and res.batch_total_us > 0
     finally:
         hx.close()
+
+
+@pytest.mark.parametrize("backend_kind", [1, 2])
+def test_concurrent_mixed_calls_are_safe_and_correct(lib, oracle, backend_kind):
+    """The reference calls its Verifier from several goroutines at once (view.go:537-541 commit votes, controller.go:239
+    leader requests, pool pruning): proposals, single requests and commit votes from 8 threads at a time must all get
+    the right verdict — coalescer, worker pool, staging arrays and key maps under contention."""
+    import threading
+    hx = Harness(lib, oracle, wait_us=200, backend_kind=backend_kind)
+    try:
+        reqs = [hx.request("alice%d" % (i % 3), "c%d" % i, payload=bytes([i])) for i in range(40)]
+        good = (hostlib.payload_encode(reqs), b"h", b"m", 0)
+        bad_reqs = list(reqs)
+        bad_reqs[7] = hx.request("alice1", "c7", corrupt=True)
+        bad = (hostlib.payload_encode(bad_reqs), b"h", b"m", 0)
+        votes = [hx.sign_proposal(i, good, b"aux%d" % i) for i in range(4)]
+        wrong = [(sid, val, msg) for (sid, val, msg) in (hx.sign_proposal(i, bad, b"") for i in range(4))]     # bound to `bad`, not `good`
+        errors = []
+
+        def worker(k):
+            try:
+                for it in range(6):
+                    j = (k + it) % 4
+                    if hx.verify_proposal(good)[0] != OK: errors.append(("proposal good", k, it))
+                    if hx.verify_proposal(bad)[0] != INVALID: errors.append(("proposal bad", k, it))
+                    if hx.verify_consenter_sig(votes[j], good) != (OK, b"aux%d" % j): errors.append(("vote", k, it))
+                    if hx.verify_consenter_sig(wrong[j], good)[0] != INVALID: errors.append(("vote wrong proposal", k, it))
+                    if hx.verify_request(reqs[(k * 5 + it) % 40])[0] != OK: errors.append(("request", k, it))
+                    if hx.verify_request(bad_reqs[7])[0] != INVALID: errors.append(("request bad", k, it))
+            except Exception as e:      # noqa: BLE001
+                errors.append(("exception", k, repr(e)))
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+        [t.start() for t in th]
+        [t.join(timeout=120) for t in th]
+        assert not any(t.is_alive() for t in th), "deadlock"
+        assert not errors, errors[:5]
+    finally:
+        hx.close()
