@@ -86,3 +86,17 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
     with pytest.raises(sbv.SbvError) as ei:
         sbv.verify_batch(bytes(160), 1)
     assert ei.value.code == -5                      # SBV_ENOTINIT
+    # every other compute entry refuses too, and the staging allocator hands out nothing
+    import ctypes
+    lib = sbv.load()
+    out = ctypes.create_string_buffer(8)
+    offs = (ctypes.c_uint64 * 2)(0, 3)
+    assert lib.sbv_ed25519_verify_batch(bytes(128), 1, out) == -5
+    assert lib.sbv_ed25519_verify_msgs(bytes(64), bytes(32), b"abc", offs, 1, out) == -5
+    slot = (ctypes.c_uint32 * 1)()
+    assert lib.sbv_p256_register_keys(bytes(64), 1, slot) == -5
+    lib.sbv_host_alloc.restype = ctypes.c_void_p
+    lib.sbv_host_alloc.argtypes = [ctypes.c_size_t]
+    assert lib.sbv_host_alloc(4096) is None
+    lib.sbv_host_free.argtypes = [ctypes.c_void_p]
+    lib.sbv_host_free(None)
