@@ -141,8 +141,9 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
         SBV_TRY(hipStreamWaitEvent(y.side_c, y.ev_split, 0));
         hipLaunchKernelGGL(k_verify_generic_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, y.side_c, s, g, d_qtab, d_g16, b.acc);
         SBV_TRY(hipEventRecord(y.ev_generic, y.side_c));
-        hipLaunchKernelGGL(k_gphase_generic, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, b.gacc, b.acc, 0u);
+        // the G phase reads counters[0] (group_count): it may not start before side_a's memset / insert / assign
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
+        hipLaunchKernelGGL(k_gphase_generic, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, b.gacc, b.acc, 0u);
     } else {
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
         hipLaunchKernelGGL(k_gphase_generic, dim3(2 * gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, b.gacc, b.acc, gv);

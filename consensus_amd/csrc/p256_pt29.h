@@ -1,0 +1,150 @@
+// p256_pt29.h — P-256 group law over the carry-free field of p256_fe29.h.
+//
+// Accumulators of the comb phases (u1*G from the 16-bit comb of G, u2*Q from a key's 8-bit comb) are held
+// in XYZZ coordinates (X, Y, ZZ, ZZZ) with x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2 [Explicit-Formulas Database,
+// "xyzz" for short Weierstrass curves]: adding an affine table point is 8M + 2S (madd-2008-s) against 8M + 3S
+// for Jacobian coordinates, the two leading products (U2, S2) do not wait for a Z^2 -> Z^3 chain, and the
+// final check R.x == r needs ZZ only.  Infinity is an explicit per-lane flag: coordinates are residues that
+// are not kept canonical, so "ZZ == 0" would be a comparison mod p, not a register test.
+//
+// Every routine is EXACT for every input, like p256_pt.h: crypto/ecdsa's verdict on u1*G == +-u2*Q
+//  depends on it.  The exceptional cases of an addition (P == Q -> doubling, P == -Q ->
+// infinity) are detected by f29_maybe_zero(U2 - X1), three instructions, and resolved in a branch that
+// honest data never takes.
+#pragma once
+#include "p256_fe29.h"
+#include "p256_pt.h"
+#include "p256_sc.h"
+
+namespace sbv {
+
+struct xyzz { fe29 X, Y, ZZ, ZZZ; bool inf; };
+struct apt29 { fe29 x, y; };           // affine; limbs tight (unpacked from canonical storage)
+
+// f29_norm plus a value reduction by the multiple of p the top limb indicates: any |value| < 16 p with limbs
+// |v[i]| < 2^31  ->  value in (-2^229, 2^256 + 2^229), limbs 0..7 within (-2^25 - 8, 2^29 + 2^25 + 8).
+// p = 2^256 - 2^224 + 2^192 + 2^96 - 1 touches five limbs: bits 256 / 224 / 192 / 96 / 0 are bit 24 of limb 8,
+// 21 of limb 7, 18 of limb 6, 9 of limb 3, 0 of limb 0.
+SBV_HD void f29_norm_red(fe29& r, const fe29& a) {
+    f29_norm(r, a);
+    const i32 q = r.v[8] >> 24;                 // floor(value / 2^256), |q| <= 16
+    r.v[8] -= q << 24;
+    r.v[7] += q << 21;
+    r.v[6] -= q << 18;
+    r.v[3] -= q << 9;
+    r.v[0] += q;
+}
+
+SBV_HD void pt29_set_inf(xyzz& R) {
+    R.X = f29_zero(); R.Y = f29_zero(); R.ZZ = f29_zero(); R.ZZZ = f29_zero();
+    R.inf = true;
+}
+
+// 2 * (x, y) for an affine point (never infinity: finite points of a prime-order curve have y != 0)
+SBV_HD void pt29_mdbl(xyzz& R, const fe29& x, const fe29& y) {
+    fe29 U, V, W, S, M, t, X3, Y3;
+    f29_add(U, y, y);
+    f29_norm(U, U);
+    f29_sqr(V, U);
+    f29_mul(W, U, V);
+    f29_mul(S, x, V);
+    f29_sqr(t, x);
+    const fe29 one = f29_one();
+    f29_sub(t, t, one);                         // x^2 - 1   (a = -3: M = 3 x^2 + a)
+    f29_add(M, t, t);
+    f29_add(M, M, t);
+    f29_norm(M, M);
+    f29_sqr(t, M);
+    f29_sub(t, t, S);
+    f29_sub(X3, t, S);                          // X3 = M^2 - 2 S
+    f29_norm_red(R.X, X3);
+    f29_sub(t, S, R.X);
+    f29_mul(t, M, t);
+    f29_mul(Y3, W, y);
+    f29_sub(Y3, t, Y3);                         // Y3 = M (S - X3) - W y
+    f29_norm_red(R.Y, Y3);
+    R.ZZ = V;
+    R.ZZZ = W;
+    R.inf = false;
+}
+
+// R += (q.x, neg ? -q.y : q.y).  R.X, R.Y as left by this function (or pt29_mdbl / a load of stored
+// coordinates): value-reduced; ZZ, ZZZ tight.
+SBV_HD void pt29_madd(xyzz& R, const apt29& q, bool neg) {
+    if (R.inf) {
+        R.X = q.x;
+        f29_cneg(R.Y, q.y, neg);
+        R.ZZ = f29_one();
+        R.ZZZ = f29_one();
+        R.inf = false;
+        return;
+    }
+    fe29 U2, S2, P, Rr, PP, PPP, Q, t, X3, Y3;
+    f29_mul(U2, q.x, R.ZZ);
+    f29_mul(S2, q.y, R.ZZZ);
+    f29_sub(P, U2, R.X);
+    f29_cneg(S2, S2, neg);
+    f29_sub(Rr, S2, R.Y);
+    if (f29_maybe_zero(P)) {                    // random data: probability 2^-24 per lane
+        if (f29_is_zero_slow(P)) {
+            if (f29_is_zero(Rr)) {              // P == Q
+                fe29 qy;
+                f29_cneg(qy, q.y, neg);
+                pt29_mdbl(R, q.x, qy);
+            } else {
+                pt29_set_inf(R);                // P == -Q
+            }
+            return;
+        }
+    }
+    f29_sqr(PP, P);
+    f29_mul(PPP, P, PP);
+    f29_mul(Q, R.X, PP);
+    f29_sqr(t, Rr);
+    f29_sub(t, t, PPP);
+    f29_sub(t, t, Q);
+    f29_sub(X3, t, Q);                          // X3 = R^2 - PPP - 2 Q
+    f29_norm_red(X3, X3);
+    f29_sub(t, Q, X3);
+    f29_mul(t, Rr, t);
+    f29_mul(Y3, R.Y, PPP);
+    f29_sub(Y3, t, Y3);                         // Y3 = R (Q - X3) - Y1 PPP
+    f29_norm_red(R.Y, Y3);
+    R.X = X3;
+    f29_mul(R.ZZ, R.ZZ, PP);
+    f29_mul(R.ZZZ, R.ZZZ, PPP);
+}
+
+// R.x mod N == r  <=>  R != infinity and (X == r ZZ  or  (r + N < p and X == (r + N) ZZ))  (mod p); r < N plain.
+SBV_HD bool pt29_rx_matches(const xyzz& R, const u256& r) {
+    if (R.inf) return false;
+    fe29 rM, t;
+    f29_from_plain(rM, r);
+    f29_mul(t, rM, R.ZZ);
+    f29_sub(t, t, R.X);
+    bool match = f29_is_zero(t);
+    const sc n_ = sc_n();
+    const fe p_ = fe_p();
+    u256 rn;
+    const u32 carry = add256(rn, r, n_);
+    if (carry == 0 && lt256(rn, p_)) {          // only for r < p - N ~ 2^128: essentially never
+        f29_from_plain(rM, rn);
+        f29_mul(t, rM, R.ZZ);
+        f29_sub(t, t, R.X);
+        match = match || f29_is_zero(t);
+    }
+    return match;
+}
+
+// table entry (64 bytes: x | y, each the canonical 8-word residue of this domain) -> affine point
+SBV_HD void apt29_load(apt29& q, const u32* src) {
+    struct alignas(16) q4 { u32 x, y, z, w; };
+    const q4* s = reinterpret_cast<const q4*>(src);
+    const q4 a = s[0], b = s[1], c = s[2], d = s[3];
+    const u32 wx[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const u32 wy[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    f29_unpack(q.x, wx);
+    f29_unpack(q.y, wy);
+}
+
+}  // namespace sbv

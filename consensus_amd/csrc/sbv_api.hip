@@ -70,7 +70,9 @@ struct Context {
 
 Context g_ctx;
 std::mutex g_mu;
-std::string g_err;
+// Error text of the calling thread's last failing call: thread_local, so sbv_last_error() never races with another
+// thread's failure (the host Verifier calls it from many threads at once exactly when the device is faulting).
+thread_local std::string g_err;
 
 int fail(int code, const char* what, hipError_t e) {
     g_err = std::string(what) + ": " + hipGetErrorString(e);
@@ -417,7 +419,10 @@ extern "C" int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d
         }
         bool was_grouped = false;
         rc = enqueue(c, src + off * SBV_TUPLE_BYTES, m, dst + off / 8, stream, mid, dom, &dom_pairs, &was_grouped);
-        if (rc != SBV_OK) return rc;
+        if (rc != SBV_OK) {          // part of the step may be enqueued: later users of the scratch must still wait for it
+            if (hipEventRecord(c.busy, stream) == hipSuccess) c.busy_valid = true;
+            return rc;
+        }
         (void)was_grouped;
         if (c.profiling) c.prof_dom_used += 2 * (size_t)dom_pairs;
         if (end) HIP_TRY(SBV_EDEVICE, hipEventRecord(end, stream));
@@ -471,23 +476,25 @@ extern "C" int sbv_p256_register_keys(const uint8_t* keys, size_t m, uint32_t* s
     if (m == 0) return SBV_OK;
     if (!keys || !slots_out) { g_err = "null pointer"; return SBV_EINVAL; }
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
-    // de-duplicate, assign slots
+    // de-duplicate, assign slots.  The index is only extended AFTER both uploads succeeded: an entry left behind by a
+    // failed call would hand its slot number to the next fresh key, and the first key's ID would then resolve to another
+    // signer's comb.
     std::vector<size_t> fresh;                      // indices into keys[] that need a table
+    std::unordered_map<std::string, u32> pending;
     for (size_t i = 0; i < m; ++i) {
         const std::string k((const char*)keys + 64 * i, 64);
         auto it = c.key_index.find(k);
-        if (it == c.key_index.end()) {
-            const u32 slot = (u32)(c.nkeys + fresh.size());
-            c.key_index.emplace(k, slot);
-            fresh.push_back(i);
-            slots_out[i] = slot;
-        } else {
-            slots_out[i] = it->second;
-        }
+        if (it != c.key_index.end()) { slots_out[i] = it->second; continue; }
+        auto pt = pending.find(k);
+        if (pt != pending.end()) { slots_out[i] = pt->second; continue; }
+        const u32 slot = (u32)(c.nkeys + fresh.size());
+        pending.emplace(k, slot);
+        fresh.push_back(i);
+        slots_out[i] = slot;
     }
     if (fresh.empty()) return SBV_OK;
     int rc = ensure_key_capacity(c, c.nkeys + fresh.size());
-    if (rc != SBV_OK) { for (size_t i : fresh) c.key_index.erase(std::string((const char*)keys + 64 * i, 64)); return rc; }
+    if (rc != SBV_OK) return rc;
     // tables are built on the host (one-time setup, same field code as the kernels), in parallel
     std::vector<sbv::apt> tabs(fresh.size() * (size_t)SBV_KEYTAB_ENTRIES);
     std::vector<uint8_t> valid(fresh.size(), 0);
@@ -507,6 +514,7 @@ extern "C" int sbv_p256_register_keys(const uint8_t* keys, size_t m, uint32_t* s
     HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_ktab + c.nkeys * (size_t)SBV_KEYTAB_ENTRIES, tabs.data(), tabs.size() * sizeof(sbv::apt),
                                    hipMemcpyHostToDevice));
     HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_kvalid + c.nkeys, valid.data(), valid.size(), hipMemcpyHostToDevice));
+    for (auto& kv : pending) c.key_index.emplace(kv.first, kv.second);
     c.nkeys += fresh.size();
     return SBV_OK;
 }
@@ -554,7 +562,10 @@ extern "C" int sbv_p256_verify_batch_keyed_dev(const void* d_rsh, const void* d_
             c.prof_used += 3;
         }
         rc = enqueue_keyed(c, src + off * 96, sl + off, m, dst + off / 8, stream, mid);
-        if (rc != SBV_OK) return rc;
+        if (rc != SBV_OK) {
+            if (hipEventRecord(c.busy, stream) == hipSuccess) c.busy_valid = true;
+            return rc;
+        }
         if (end) HIP_TRY(SBV_EDEVICE, hipEventRecord(end, stream));
     }
     HIP_TRY(SBV_EDEVICE, hipEventRecord(c.busy, stream));
@@ -636,7 +647,10 @@ extern "C" int sbv_ed25519_verify_batch_dev(const void* d_tuples, size_t n, void
             end = c.prof_events[c.prof_used + 2];
             c.prof_used += 3;
         }
-        if ((rc = enqueue_ed25519(c, src + off * 128, m, dst + off / 8, stream)) != SBV_OK) return rc;
+        if ((rc = enqueue_ed25519(c, src + off * 128, m, dst + off / 8, stream)) != SBV_OK) {
+            if (hipEventRecord(c.busy, stream) == hipSuccess) c.busy_valid = true;
+            return rc;
+        }
         if (end) HIP_TRY(SBV_EDEVICE, hipEventRecord(end, stream));
     }
     HIP_TRY(SBV_EDEVICE, hipEventRecord(c.busy, stream));
@@ -703,7 +717,12 @@ extern "C" int sbv_p256_verify_msgs_keyed(const uint8_t* msgs, const uint64_t* m
     if (!msg_offsets || !sig_offsets || !slots || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
     if (c.nkeys == 0) { g_err = "no keys registered"; return SBV_EINVAL; }
     if (n > kMaxChunk) { g_err = "batch larger than 2^21: split it"; return SBV_EINVAL; }
+    // the device dereferences the offset tables: they must start at 0 and never decrease
+    if (msg_offsets[0] != 0 || sig_offsets[0] != 0) { g_err = "offset tables must start at 0"; return SBV_EINVAL; }
+    for (size_t i = 0; i < n; ++i)
+        if (msg_offsets[i + 1] < msg_offsets[i] || sig_offsets[i + 1] < sig_offsets[i]) { g_err = "offset table is not monotone"; return SBV_EINVAL; }
     const size_t mbytes = (size_t)msg_offsets[n], sbytes = (size_t)sig_offsets[n];
+    if ((mbytes && !msgs) || (sbytes && !sigs)) { g_err = "null pointer"; return SBV_EINVAL; }
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
     int rc = ensure_capacity(c, n);
@@ -748,7 +767,11 @@ extern "C" int sbv_ed25519_verify_msgs(const uint8_t* sigs, const uint8_t* pks, 
     if (n == 0) return SBV_OK;
     if (!sigs || !pks || !msg_offsets || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
     if (n > kMaxChunk) { g_err = "batch larger than 2^21: split it"; return SBV_EINVAL; }
+    if (msg_offsets[0] != 0) { g_err = "offset tables must start at 0"; return SBV_EINVAL; }
+    for (size_t i = 0; i < n; ++i)
+        if (msg_offsets[i + 1] < msg_offsets[i]) { g_err = "offset table is not monotone"; return SBV_EINVAL; }
     const size_t mbytes = (size_t)msg_offsets[n];
+    if (mbytes && !msgs) { g_err = "null pointer"; return SBV_EINVAL; }
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
     int rc = ensure_capacity(c, n);
@@ -877,6 +900,6 @@ extern "C" int sbv_last_timing(sbv_timing* out) {
 }
 
 extern "C" const char* sbv_last_error(void) {
-    // the string is only replaced under g_mu; callers read it right after a failing call
+    // per-thread: valid until this thread's next failing libsbv call
     return g_err.c_str();
 }

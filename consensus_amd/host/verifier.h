@@ -151,6 +151,7 @@ class Verifier {
     bool ed() const { return opt_.scheme == Scheme::ED25519; }
     size_t key_bytes() const { return ed() ? 32 : 64; }
     Status verify_one(const uint8_t q[64], const bytes& msg, const bytes& sig, long slot = -1);
+    std::string cache_key(const uint8_t q[64], const bytes& msg, const bytes& sig) const;
     std::mutex mu_;
     std::map<uint64_t, bytes> consenters_;
     std::map<uint64_t, long> consenter_slot_;
@@ -175,7 +176,8 @@ class Verifier {
     std::mutex staging_mu_;
     Staging st_msgs_, st_sigs_, st_moff_, st_soff_, st_slots_;
     bytes digest_memo(const Proposal& p);
-    struct DigestEntry { Proposal p; bytes digest; };
+    struct DigestSlot { std::mutex mu; std::condition_variable cv; bool ready = false; bytes digest; };
+    struct DigestEntry { Proposal p; std::shared_ptr<DigestSlot> slot; };
     std::mutex digest_mu_;
     std::vector<DigestEntry> digest_cache_;
     size_t digest_next_ = 0;

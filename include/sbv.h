@@ -68,7 +68,7 @@ int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitma
  * batch has at least `min_batch` tuples, tuples are grouped by public key on the device, keys used by
  * at least `min_count` tuples of THIS batch (at most `max_groups` of them) get a comb table built inside
  * the call and their signatures take the no-doubling kernel; everything else takes the generic kernel.
- * Nothing is remembered between calls; verdicts are identical.  Defaults: enabled, 131072, 64, 2048
+ * Nothing is remembered between calls; verdicts are identical.  Defaults: enabled, 262144, 64, 2048
  * (env SBV_GROUP=0 disables).  Passing 0 for a numeric argument keeps its current value. */
 int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uint32_t max_groups);
 
@@ -81,7 +81,7 @@ int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, vo
  * SmartBFT's consenter set (and an application's client set) is a registry: types.Signature.ID
  * selects the key (pkg/types/types.go:25-29), it is not carried per signature.  Registering a key
  * builds a fixed-base comb for it (33 x 128 affine multiples, 270 KiB of HBM per key) once, after
- * which a verification against that key needs NO point doublings: R = u1*G + u2*Q is 66 mixed
+ * which a verification against that key needs NO point doublings: R = u1*G + u2*Q is 17 + 33 = 50 mixed
  * additions (~4.7x fewer field multiplications than the generic form).  Verdicts are identical to
  * the generic entry points: a key that crypto/ecdsa would refuse (coordinate >= p, off curve) still
  * gets a slot, flagged invalid, and every signature against it is rejected.

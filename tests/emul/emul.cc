@@ -16,6 +16,7 @@
 #include "../../consensus_amd/csrc/sha512_dev.h"
 #include "../../consensus_amd/csrc/sha256_dev.h"
 #include "../../consensus_amd/csrc/p256_group.h"
+#include "../../consensus_amd/csrc/p256_pt29.h"
 
 using namespace sbv;
 
@@ -322,5 +323,39 @@ void sbve_modinv30(int which, const u32* a, u32* out) {
 // affine Montgomery-form G-table entry (j, k): 16 dwords
 void sbve_g16_entry(int j, int k, u32* out16) { memcpy(out16, &g16tab()[(size_t)j * SBV_G16_PER_WINDOW + (k - 1)], 64); }
 void sbve_gtab_entry(int j, int k, u32* out16) { memcpy(out16, &gtab()[(size_t)j * SBV_GTAB_PER_WINDOW + (k - 1)], 64); }
+
+// ---- carry-free field (p256_fe29.h) and XYZZ point layer (p256_pt29.h): raw signed 29-bit limbs in / out ----------
+void sbve_f29_mul(const i32* a, const i32* b, i32* out) { fe29 x, y, z; memcpy(&x, a, 36); memcpy(&y, b, 36); f29_mul(z, x, y); memcpy(out, &z, 36); }
+void sbve_f29_sqr(const i32* a, i32* out) { fe29 x, z; memcpy(&x, a, 36); f29_sqr(z, x); memcpy(out, &z, 36); }
+void sbve_f29_canon(const i32* a, i32* out) { fe29 x, z; memcpy(&x, a, 36); f29_canon(z, x); memcpy(out, &z, 36); }
+void sbve_f29_norm(const i32* a, i32* out) { fe29 x, z; memcpy(&x, a, 36); f29_norm(z, x); memcpy(out, &z, 36); }
+void sbve_f29_norm_red(const i32* a, i32* out) { fe29 x, z; memcpy(&x, a, 36); f29_norm_red(z, x); memcpy(out, &z, 36); }
+int sbve_f29_is_zero(const i32* a) { fe29 x; memcpy(&x, a, 36); return f29_is_zero(x) ? 1 : 0; }
+int sbve_f29_maybe_zero(const i32* a) { fe29 x; memcpy(&x, a, 36); return f29_maybe_zero(x) ? 1 : 0; }
+void sbve_f29_unpack(const u32* w, i32* out) { fe29 z; f29_unpack(z, w); memcpy(out, &z, 36); }
+void sbve_f29_pack(const i32* c, u32* w) { fe29 x; memcpy(&x, c, 36); f29_pack(w, x); }
+void sbve_f29_from_fe(const u32* w, i32* out) { fe x; memcpy(&x, w, 32); fe29 z; f29_from_fe(z, x); memcpy(out, &z, 36); }
+void sbve_f29_to_fe(const i32* a, u32* w) { fe29 x; memcpy(&x, a, 36); fe z; f29_to_fe(z, x); memcpy(w, &z, 32); }
+void sbve_f29_from_plain(const u32* w, i32* out) { u256 x; memcpy(&x, w, 32); fe29 z; f29_from_plain(z, x); memcpy(out, &z, 36); }
+// sum of n affine points given as stored table entries (16 words each: canonical x | y of the R = 2^261 domain), each
+// optionally negated; out = X, Y, ZZ, ZZZ (36 limbs); returns the infinity flag
+int sbve_pt29_sum(const u32* entries, const uint8_t* negs, size_t n, i32* out) {
+    xyzz R;
+    pt29_set_inf(R);
+    for (size_t i = 0; i < n; ++i) {
+        apt29 q;
+        apt29_load(q, entries + 16 * i);
+        pt29_madd(R, q, negs[i] != 0);
+    }
+    memcpy(out, &R.X, 36); memcpy(out + 9, &R.Y, 36); memcpy(out + 18, &R.ZZ, 36); memcpy(out + 27, &R.ZZZ, 36);
+    return R.inf ? 1 : 0;
+}
+int sbve_pt29_rx_matches(const i32* xyzz36, int inf, const u32* r) {
+    xyzz R;
+    memcpy(&R.X, xyzz36, 36); memcpy(&R.Y, xyzz36 + 9, 36); memcpy(&R.ZZ, xyzz36 + 18, 36); memcpy(&R.ZZZ, xyzz36 + 27, 36);
+    R.inf = inf != 0;
+    u256 rr; memcpy(&rr, r, 32);
+    return pt29_rx_matches(R, rr) ? 1 : 0;
+}
 
 }  // extern "C"

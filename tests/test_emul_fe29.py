@@ -1,0 +1,203 @@
+"""CPU tier: the carry-free field (consensus_amd/csrc/p256_fe29.h: 9 signed 29-bit limbs, R = 2^261) and the XYZZ
+point layer (p256_pt29.h), compiled by g++ into tests/emul and diffed against Python big integers — including the
+worst cases the documented limb / value bounds allow (the i64 column accumulators must not overflow there) and the
+exceptional cases of the addition (P == Q, P == -Q, infinity)."""
+import ctypes
+import random
+
+import pytest
+
+import p256_py as ec
+from test_emul_device_algo import emul  # noqa: F401  (fixture: builds tests/emul/libsbv_emul.so)
+
+P = ec.P
+R = 1 << 261
+RINV = pow(R, -1, P)
+M29 = (1 << 29) - 1
+I32x9 = ctypes.c_int32 * 9
+
+
+def L(limbs):
+    return I32x9(*limbs)
+
+
+def val(arr):
+    return sum(int(v) << (29 * i) for i, v in enumerate(arr))
+
+
+def tight(x):
+    """canonical limbs of 0 <= x < 2^261"""
+    return [(x >> (29 * i)) & M29 for i in range(9)]
+
+
+def words(x):
+    return (ctypes.c_uint32 * 8)(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+
+
+def wval(arr):
+    return sum(int(v) << (32 * i) for i, v in enumerate(arr))
+
+
+def random_loose(rng, spread):
+    """a value given by limbs uniformly in (-spread, spread); the value itself is what the limbs say"""
+    return [rng.randrange(-spread + 1, spread) for _ in range(8)] + [rng.randrange(-(1 << 24), 1 << 25)]
+
+
+def check_tight(out, lo, hi):
+    v = val(out)
+    assert all(0 <= int(out[i]) < (1 << 29) for i in range(8)), list(out)
+    assert lo < v < hi, hex(v)
+    return v
+
+
+def test_f29_mul_sqr_match_bigint_within_contract(emul):
+    rng = random.Random(29)
+    out = I32x9()
+    cases = []
+    edge = [0, 1, P - 1, P, 2 * P, (1 << 256) - 1, R % P, (1 << 232) - 1, M29, M29 << 29]
+    for a in edge:
+        for b in edge:
+            cases.append((tight(a), tight(b)))
+    for _ in range(300):
+        cases.append((tight(rng.randrange(2 * P)), tight(rng.randrange(2 * P))))
+    # differences / sums of two tight values, the loosest operands the point formulas multiply directly
+    for _ in range(300):
+        cases.append((random_loose(rng, 1 << 29), random_loose(rng, 1 << 29)))
+    # worst-case limb magnitudes of the contract: every limb at +-(2^29 + 2^25) (value-reduced coordinates)
+    big = (1 << 29) + (1 << 25)
+    for sa in (1, -1):
+        for sb in (1, -1):
+            cases.append(([sa * big] * 8 + [sa * (1 << 24)], [sb * big] * 8 + [sb * (1 << 24)]))
+            cases.append(([sa * big] * 8 + [sa * (1 << 24)], [sb * (1 << 29)] * 8 + [-sb * (1 << 24)]))
+    for a, b in cases:
+        A, B = val(a), val(b)
+        if abs(A) * abs(B) > 16 * P * P:
+            continue
+        emul.sbve_f29_mul(L(a), L(b), out)
+        v = check_tight(out, -P // 2 - 1, 3 * P // 2 + 1)
+        assert (v - A * B * RINV) % P == 0, (a, b)
+        assert A * B <= v * R < A * B + P * R or (A * B // R) <= v <= (A * B // R) + P + 1
+        if abs(A) * abs(A) <= 16 * P * P:
+            emul.sbve_f29_sqr(L(a), out)
+            v = check_tight(out, -1, 3 * P // 2 + 1)
+            assert (v - A * A * RINV) % P == 0, a
+
+
+def test_f29_canon_norm_pack_roundtrip(emul):
+    rng = random.Random(30)
+    out = I32x9()
+    w = (ctypes.c_uint32 * 8)()
+    for _ in range(500):
+        a = random_loose(rng, 1 << 31)
+        a[8] = rng.randrange(-(1 << 27), 1 << 27)
+        A = val(a)
+        assert abs(A) < 16 * P
+        emul.sbve_f29_canon(L(a), out)
+        assert list(out) == tight(A % P), a
+        emul.sbve_f29_pack(out, w)
+        assert wval(w) == A % P
+        emul.sbve_f29_unpack(w, out)
+        assert list(out) == tight(A % P)
+        emul.sbve_f29_norm(L(a), out)
+        assert val(out) == A and all(-8 < int(out[i]) < (1 << 29) + 8 for i in range(8))
+        emul.sbve_f29_norm_red(L(a), out)
+        v = val(out)
+        assert (v - A) % P == 0 and -(1 << 229) < v < (1 << 256) + (1 << 229)
+        assert all(-(1 << 25) - 8 < int(out[i]) < (1 << 29) + (1 << 25) + 8 for i in range(8))
+    for x in (0, 1, P - 1, (1 << 256) - 1, 0xFFFFFFFF00000000FFFFFFFF00000000FFFFFFFF00000000FFFFFFFF00000000):
+        emul.sbve_f29_unpack(words(x), out)
+        assert val(out) == x and list(out) == tight(x)
+
+
+def test_f29_zero_tests_see_every_multiple_of_p(emul):
+    rng = random.Random(31)
+    for k in range(-16, 17):
+        for _ in range(4):
+            # k * p spread over loose limbs: add a random limb-wise "zero" (borrow between neighbours)
+            limbs = tight(k * P) if k >= 0 else [-v for v in tight(-k * P)]
+            for i in range(8):
+                d = rng.randrange(-3, 4)
+                limbs[i] += d << 29
+                limbs[i + 1] -= d
+            assert val(limbs) == k * P
+            assert emul.sbve_f29_maybe_zero(L(limbs)) == 1
+            assert emul.sbve_f29_is_zero(L(limbs)) == 1
+            limbs[rng.randrange(8)] += 1 + rng.randrange(5)
+            assert emul.sbve_f29_is_zero(L(limbs)) == 0
+    hits = 0
+    for _ in range(2000):
+        hits += emul.sbve_f29_maybe_zero(L(tight(rng.randrange(P))))
+    assert hits == 0          # the filter passes 2^-24 of random values
+
+
+def test_f29_domain_changes(emul):
+    rng = random.Random(32)
+    out = I32x9()
+    w = (ctypes.c_uint32 * 8)()
+    for x in [0, 1, P - 1] + [rng.randrange(P) for _ in range(100)]:
+        X32 = x * (1 << 256) % P                      # the 8 x 32 Montgomery form of p256_fe.h
+        emul.sbve_f29_from_fe(words(X32), out)
+        assert (val(out) - x * R) % P == 0
+        emul.sbve_f29_to_fe(out, w)
+        assert wval(w) == X32
+        emul.sbve_f29_from_plain(words(x), out)
+        assert (val(out) - x * R) % P == 0
+
+
+def entry(pt):
+    x, y = pt
+    e = (ctypes.c_uint32 * 16)()
+    for i in range(8):
+        e[i] = ((x * R % P) >> (32 * i)) & 0xFFFFFFFF
+        e[8 + i] = ((y * R % P) >> (32 * i)) & 0xFFFFFFFF
+    return list(e)
+
+
+def run_sum(emul, pts, negs):
+    n = len(pts)
+    ent = (ctypes.c_uint32 * (16 * n))(*[w for p in pts for w in entry(p)])
+    ng = (ctypes.c_uint8 * n)(*[1 if v else 0 for v in negs])
+    out = (ctypes.c_int32 * 36)()
+    inf = emul.sbve_pt29_sum(ent, ng, n, out)
+    X, Y, ZZ, ZZZ = (val(out[9 * k:9 * k + 9]) for k in range(4))
+    if inf:
+        return None, out, inf
+    assert ZZ % P != 0
+    assert pow(ZZ, 3, P) == pow(ZZZ, 2, P) * R % P    # ZZ = zz R, ZZZ = zzz R with zz^3 == zzz^2
+    x = X * pow(ZZ, -1, P) % P
+    y = Y * pow(ZZZ, -1, P) % P
+    return (x, y), out, inf
+
+
+def test_pt29_madd_chain_matches_affine_sum_including_exceptional_cases(emul):
+    rng = random.Random(33)
+    G = (ec.GX, ec.GY)
+    base = [ec.pt_mul(rng.randrange(1, ec.N), G) for _ in range(12)]
+    for trial in range(40):
+        k = rng.randrange(1, 9)
+        pts = [rng.choice(base) for _ in range(k)]
+        negs = [rng.random() < 0.4 for _ in range(k)]
+        shape = trial % 5
+        if shape == 1 and k >= 2:
+            pts[1], negs[1] = pts[0], negs[0]                     # P + P: the doubling branch
+        if shape == 2 and k >= 2:
+            pts[1], negs[1] = pts[0], not negs[0]                 # P - P: infinity, then the chain restarts from it
+        if shape == 3 and k >= 3:
+            s = ec.pt_add(pts[0] if not negs[0] else ec.pt_neg(pts[0]), pts[1] if not negs[1] else ec.pt_neg(pts[1]))
+            if s is not None:
+                pts[2], negs[2] = s, True                         # (A + B) - (A + B): infinity through a projective accumulator
+        if shape == 4 and k >= 3:
+            s = ec.pt_add(pts[0] if not negs[0] else ec.pt_neg(pts[0]), pts[1] if not negs[1] else ec.pt_neg(pts[1]))
+            if s is not None:
+                pts[2], negs[2] = s, False                        # (A + B) + (A + B): doubling with ZZ != 1
+        want = None
+        for p_, n_ in zip(pts, negs):
+            want = ec.pt_add(want, ec.pt_neg(p_) if n_ else p_)
+        got, out, inf = run_sum(emul, pts, negs)
+        assert got == want, (trial, shape)
+        if want is not None:
+            r = want[0] % ec.N
+            assert emul.sbve_pt29_rx_matches(out, inf, words(r)) == 1
+            assert emul.sbve_pt29_rx_matches(out, inf, words((r + 1) % ec.N)) == 0
+        else:
+            assert emul.sbve_pt29_rx_matches(out, inf, words(1)) == 0
