@@ -26,6 +26,12 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 ALGO_BYTES_PER_VERIFY = 160.125          # 5 x 32 B in + 1 bit out
 HBM_PEAK_GBPS = 8000.0                   # /opt/skills/guides/MI355X_MICROARCH.md (spec)
 SEED = 0x5B7F2026
+# Integer-multiply roofline (SURVEY.md §8d "int_mul_issue_fraction"): measured peak of v_mad_u64_u32 / v_mad_i64_i32 on
+# MI355X (profiles/r01/microbench.jsonl, 8 waves/SIMD) and the multiply-accumulates one mixed addition of the comb
+# phases executes (p256_pt29.h pt29_madd: 8 field multiplications x 149 + 2 squarings x 113, counted in the gfx950
+# ISA of k_verify_keyed_q — DESIGN.md §4.6).
+PEAK_LANE_MADS_PER_S = 33.8e12
+MADS_PER_MIXED_ADD = 8 * 149 + 2 * 113
 
 
 def cpu_baseline(tuples, n, gpu_bitmap):
@@ -76,6 +82,134 @@ def cpu_baseline(tuples, n, gpu_bitmap):
         res["openssl_value"] = s2 / dt2
         res["openssl_parity_with_gpu_on_sample"] = out.raw[:s2 // 8] == bytes(gpu_bitmap[:s2 // 8])
     return res
+
+def leg_all_valid(sbv, synth, torch, n, steps, stream):
+    """The same batch shape with every signature valid ("also report all-valid")."""
+    import numpy as np
+    tuples, valid = synth.gen_batch(SEED + 0x100, n, 1024, 0)
+    d_t = torch.from_numpy(tuples).cuda()
+    d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
+    sbv.verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sbv.verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "verifies/s", "ms_per_step": 1e3 * dt / steps,
+            "bitmap_correct": bool((d_b.cpu().numpy() == valid).all() and (valid == 0xFF).all())}
+
+
+def leg_end_to_end(sbv, tuples, valid, n, steps):
+    """PCIe-inclusive rate of the host-pointer entry sbv_p256_verify_batch (what a cgo caller uses): tuples in host memory
+    when the clock starts, bitmap in host memory when it stops.  Never `value` (inputs there are resident in HBM)."""
+    import numpy as np
+    out = {}
+    got = np.zeros((n + 7) // 8, dtype=np.uint8)
+    for kind in ("pinned", "pageable"):
+        ptr = 0
+        try:
+            if kind == "pinned":
+                ptr = sbv.host_alloc(n * 160)
+                if not ptr:
+                    out[kind] = {"error": "sbv_host_alloc failed"}
+                    continue
+                ctypes.memmove(ptr, tuples.ctypes.data, n * 160)
+                src = ptr
+            else:
+                src = tuples.ctypes.data
+            sbv.verify_batch_ptr(src, n, got.ctypes.data)          # warm-up (staging buffers)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sbv.verify_batch_ptr(src, n, got.ctypes.data)
+            dt = time.perf_counter() - t0
+            tm = sbv.last_timing()
+            out[kind] = {"value": n * steps / dt, "unit": "verifies/s", "ms_per_call": 1e3 * dt / steps,
+                         "bitmap_correct": bool((got == valid).all()),
+                         "last_call_us": {"h2d": tm.h2d_us, "prep": tm.prep_us, "stage_b": tm.verify_us, "d2h": tm.d2h_us, "total": tm.total_us}}
+        except Exception as e:      # noqa: BLE001 - a secondary leg must not take the headline down
+            out[kind] = {"error": repr(e)}
+        finally:
+            if ptr:
+                sbv.host_free(ptr)
+    return out
+
+
+def leg_ed25519(sbv, torch, n, steps, stream):
+    """BASELINE.json configs[4]: 2^20 Ed25519 signatures, 1024 keys, 7/8 valid, R|S|A|k tuples resident in HBM."""
+    import numpy as np
+    cache = f"/tmp/sbv_ed_batch_{n}.npz"
+    if os.path.exists(cache):
+        z = np.load(cache)
+        tuples, expect = z["tuples"], z["expect"]
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import hostlib
+        h = hostlib.load()
+        tuples = np.zeros(n * 128, dtype=np.uint8)
+        expect = np.zeros((n + 7) // 8, dtype=np.uint8)
+        h.sbvh_ed25519_gen_batch(SEED, n, 1024, 8, tuples.ctypes.data, expect.ctypes.data, os.cpu_count() or 1)
+        try:
+            np.savez(cache, tuples=tuples, expect=expect)
+        except Exception:
+            pass
+    d_t = torch.from_numpy(tuples).cuda()
+    d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
+    sbv.ed25519_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sbv.ed25519_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "Ed25519 verifies/sec at batch=1M (configs[4])", "value": n * steps / dt, "unit": "verifies/s",
+            "ms_per_step": 1e3 * dt / steps, "bitmap_correct": bool((d_b.cpu().numpy() == expect).all()),
+            "algorithmic_GBps": 128.125 * n * steps / dt / 1e9}
+
+
+def leg_m2(tuples, n):
+    """BASELINE.json's second metric — commit-quorum latency at N = 16 (Q = 11): wall time from "15 commit signatures in
+    host memory" to ">= 10 accepted" (SURVEY.md §8d M2).  (a) gpu: the 15 concurrent VerifyConsenterSig calls of
+    View.processCommits (view.go:537-541) coalesced into one micro-batch through the C++ api.Verifier mirror; (b) cpu: the
+    same 15 verifications on 15 host threads (OpenSSL ECDSA_do_verify and the oracle port — proxies for stock crypto/ecdsa
+    goroutines); (c) hybrid: what a Verifier with the Go adapter's gpuMin route picks for a quorum-sized batch."""
+    out = {}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import hostlib
+        lib = hostlib.load()
+        cb = hostlib.BACKEND_FN(lambda *a: -1)
+        v = lib.sbvh_verifier_new(0, 0, cb, None, 1 << 20, 50, 0)
+        res = hostlib.ReplayResult()
+        rc = lib.sbvh_replay(v, 16, 10, 15, 0, min(64, os.cpu_count() or 8), ctypes.byref(res))
+        lib.sbvh_verifier_free(v)
+        out["gpu"] = res.commit_quorum_us if rc == 0 and res.status == 0 else None
+        out["gpu_note"] = "median over 15 sequences, coalescer window 50 us included, registered consenter keys, 8-lanes-per-signature kernel"
+    except Exception as e:      # noqa: BLE001
+        out["gpu_error"] = repr(e)
+    import numpy as np
+    valid15 = np.ascontiguousarray(tuples[:15 * 160])            # 15 signatures of the headline batch (mostly valid)
+    bm = ctypes.create_string_buffer(8)
+    for name, so, fn in (("cpu_15_threads_openssl", "libsbv_openssl.so", "sbvssl_p256_verify_batch"),
+                         ("cpu_15_threads_oracle_port", "libsbv_oracle.so", "sbvo_p256_verify_batch")):
+        path = os.path.join(ROOT, "oracle", so)
+        if not os.path.exists(path):
+            continue
+        f = getattr(ctypes.CDLL(path), fn)
+        f.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+        ts = []
+        for _ in range(25):
+            t0 = time.perf_counter()
+            f(valid15.ctypes.data, 15, bm, 15)
+            ts.append(1e6 * (time.perf_counter() - t0))
+        out[name] = sorted(ts)[len(ts) // 2]
+    cpu = out.get("cpu_15_threads_openssl") or out.get("cpu_15_threads_oracle_port")
+    if cpu is not None and out.get("gpu") is not None:
+        out["hybrid"] = min(cpu, out["gpu"])
+        out["hybrid_note"] = ("a lone P-256 verification is a serial chain: quorum-sized batches are faster on host cores; the Go "
+                              "adapter routes batches below gpuMin to crypto/ecdsa and proposals / replay to the GPU (INTEGRATION.md)")
+    out["unit"] = "us"
+    return out
 
 
 def main():
@@ -207,6 +341,16 @@ def main():
                 sbv.clear_keys()
         except Exception as e:  # the headline number must not depend on the secondary leg
             keyed = {"error": repr(e)}
+    extra = {}
+    if world == 1 and not args.primary_only:
+        for name, fn in (("all_valid", lambda: leg_all_valid(sbv, synth, torch, n, max(2, args.steps // 2), stream)),
+                         ("end_to_end", lambda: leg_end_to_end(sbv, tuples, valid, n, max(2, args.steps // 2))),
+                         ("ed25519", lambda: leg_ed25519(sbv, torch, n, max(2, args.steps // 2), stream)),
+                         ("m2_commit_quorum_us", lambda: leg_m2(tuples, n))):
+            try:
+                extra[name] = fn()
+            except Exception as e:      # noqa: BLE001 - the headline number must not depend on a secondary leg
+                extra[name] = {"error": repr(e)}
     if world > 1:
         flag = torch.tensor([1 if ok else 0], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -259,6 +403,15 @@ def main():
                                  "stage B it executes / its avg duration (HIP events on the launch stream); the path is "
                                  "integer-ALU bound, see DESIGN.md"},
         }
+        # share of the integer-multiply pipe's measured peak that the dominant kernel sustains
+        if was_grouped:
+            adds_per_launch = 33.0 / dom_launches_per_step
+            mads_per_s = dom_units * adds_per_launch * MADS_PER_MIXED_ADD / kern_s
+            line["int_mul_issue_fraction"] = {"value": mads_per_s / PEAK_LANE_MADS_PER_S, "lane_mads_per_s": mads_per_s,
+                                              "peak_lane_mads_per_s": PEAK_LANE_MADS_PER_S, "kernel": dom_name,
+                                              "mads_per_mixed_addition": MADS_PER_MIXED_ADD,
+                                              "note": "v_mad_i64_i32 / v_mad_u64_u32 issued per second by the dominant kernel / the microbenchmarked peak"}
+        line.update(extra)
         if ungrouped is not None:
             line["without_key_grouping"] = ungrouped
         if keyed is not None:

@@ -13,7 +13,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsbv.so")
+LIB_PATH = os.environ.get("SBV_LIB") or os.path.join(_HERE, "libsbv.so")      # SBV_LIB: A/B builds of the same ABI (tools/)
 TUPLE_BYTES = 160
 
 SBV_OK = 0
@@ -259,6 +259,20 @@ def sha256_batch(msgs) -> bytes:
     out = ctypes.create_string_buffer(32 * max(1, len(msgs)))
     _check(load().sbv_sha256_batch(blob, offs, len(msgs), out))
     return out.raw[:32 * len(msgs)]
+
+
+def host_alloc(nbytes: int) -> int:
+    """Page-locked host memory for the host-pointer entries (sbv_host_alloc); returns the address, 0 on failure."""
+    lib = load()
+    lib.sbv_host_alloc.restype = ctypes.c_void_p
+    lib.sbv_host_alloc.argtypes = [ctypes.c_size_t]
+    return lib.sbv_host_alloc(nbytes) or 0
+
+
+def host_free(ptr: int) -> None:
+    lib = load()
+    lib.sbv_host_free.argtypes = [ctypes.c_void_p]
+    lib.sbv_host_free(ptr)
 
 
 def last_timing() -> Timing:

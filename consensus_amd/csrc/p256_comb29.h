@@ -1,0 +1,161 @@
+// p256_comb29.h — the comb phases of stage B over the carry-free field (p256_fe29.h, p256_pt29.h):
+//
+//   gphase29_lane        R = u1 * G from the 16-bit comb of G (17 mixed additions), parked in gacc
+//   qphase29_lane        R += windows [j0, j1) of u2 * Q from a key's 8-bit comb; the last chunk checks R.x == r
+//   verify29_lane_keyed  both for a registered key in one pass (50 mixed additions, no doublings)
+//
+// Same verdicts as verify_lane / verify_lane_keyed of p256_core.h (every addition exact), the arithmetic that
+// crypto/ecdsa.VerifyASN1 performs per signature behind the reference's api.Verifier (pkg/api/dependencies.go:54-71).
+// Tables hold affine points as 64-byte entries x | y, each coordinate the canonical 8-word residue of the
+// R = 2^261 Montgomery domain (f29_store_canon); the accumulator is XYZZ, parked between launches as 36 raw limbs
+// per tuple, limb-major (word w of tuple i at gacc[w * cap + i]); infinity is parked as ZZ = 0 in every limb.
+#pragma once
+#include "p256_core.h"
+#include "p256_pt29.h"
+
+namespace sbv {
+
+#define SBV_GACC29_WORDS 36
+
+SBV_HD void gacc29_store(u32* gacc, size_t cap, size_t i, const xyzz& R) {
+    SBV_UNROLL
+    for (int l = 0; l < 9; ++l) {
+        gacc[(size_t)l * cap + i] = (u32)R.X.v[l];
+        gacc[(size_t)(9 + l) * cap + i] = (u32)R.Y.v[l];
+        gacc[(size_t)(18 + l) * cap + i] = R.inf ? 0u : (u32)R.ZZ.v[l];
+        gacc[(size_t)(27 + l) * cap + i] = (u32)R.ZZZ.v[l];
+    }
+}
+SBV_HD void gacc29_load(xyzz& R, const u32* gacc, size_t cap, size_t i) {
+    SBV_UNROLL
+    for (int l = 0; l < 9; ++l) {
+        R.X.v[l] = (i32)gacc[(size_t)l * cap + i];
+        R.Y.v[l] = (i32)gacc[(size_t)(9 + l) * cap + i];
+        R.ZZ.v[l] = (i32)gacc[(size_t)(18 + l) * cap + i];
+        R.ZZZ.v[l] = (i32)gacc[(size_t)(27 + l) * cap + i];
+    }
+    R.inf = f29_limbs_all_zero(R.ZZ);       // a finite point has ZZ != 0 (mod p), so never the all-zero limbs
+}
+
+// A table entry as fetched (16 words): held in registers while the previous addition runs, unpacked at use.
+struct alignas(16) raw_apt { u32 w[16]; };
+SBV_HD void raw_apt_load(raw_apt& e, const apt* p) {
+    struct alignas(16) q4 { u32 x, y, z, w; };
+    const q4* s = reinterpret_cast<const q4*>(p);
+    const q4 a = s[0], b = s[1], c = s[2], d = s[3];
+    e.w[0] = a.x; e.w[1] = a.y; e.w[2] = a.z; e.w[3] = a.w; e.w[4] = b.x; e.w[5] = b.y; e.w[6] = b.z; e.w[7] = b.w;
+    e.w[8] = c.x; e.w[9] = c.y; e.w[10] = c.z; e.w[11] = c.w; e.w[12] = d.x; e.w[13] = d.y; e.w[14] = d.z; e.w[15] = d.w;
+}
+SBV_HD void raw_apt_unpack(apt29& q, const raw_apt& e) {
+    f29_unpack(q.x, e.w);
+    f29_unpack(q.y, e.w + 8);
+}
+
+// R = u1 * G.  g16r[j * 32768 + (k-1)] = k * 2^(16 j) * G, j = 0..16 (R = 2^261 domain).
+SBV_HD void gphase29_point(xyzz& R, const u256& u1, const apt* g16r) {
+    u256 k1;
+    const u32 top1 = add_const_limbs(k1, u1, 0x80008000u);
+    pt29_set_inf(R);
+    int idx; bool neg, skip;
+    comb16_digit(k1, top1, 0, idx, neg, skip);
+    raw_apt cur;
+    raw_apt_load(cur, g16r + idx);
+    SBV_NOUNROLL
+    for (int j = 0; j < SBV_G16_WINDOWS; ++j) {
+        const int jn = j + 1 < SBV_G16_WINDOWS ? j + 1 : SBV_G16_WINDOWS - 1;
+        int idxn; bool negn, skipn;
+        comb16_digit(k1, top1, jn, idxn, negn, skipn);
+        raw_apt nxt;
+        raw_apt_load(nxt, g16r + (size_t)jn * SBV_G16_PER_WINDOW + idxn);
+        if (!skip) {
+            apt29 q;
+            raw_apt_unpack(q, cur);
+            pt29_madd(R, q, neg);
+        }
+        cur = nxt; neg = negn; skip = skipn;
+    }
+}
+SBV_HD void gphase29_lane(const Scratch& s, size_t i, const apt* g16r, u32* gacc) {
+    u256 u1;
+    soa_load(u1, s.u1, s.cap, i);
+    xyzz R;
+    gphase29_point(R, u1, g16r);
+    gacc29_store(gacc, s.cap, i, R);
+}
+
+// R += sum of windows [j0, j1) of u2 * Q; qtab[j * 128 + (k-1)] = k * 2^(8 j) * Q, j = 0..32
+SBV_HD void qphase29_point(xyzz& R, const u256& u2, const apt* qtab, int j0, int j1) {
+    u256 k2;
+    const u32 top2 = add_const_limbs(k2, u2, 0x80808080u);
+    int idx; bool neg, skip;
+    comb_digit(k2, top2, j0, idx, neg, skip);
+    raw_apt cur;
+    raw_apt_load(cur, qtab + (size_t)j0 * SBV_GTAB_PER_WINDOW + idx);
+    SBV_NOUNROLL
+    for (int j = j0; j < j1; ++j) {
+        const int jn = j + 1 < j1 ? j + 1 : j1 - 1;
+        int idxn; bool negn, skipn;
+        comb_digit(k2, top2, jn, idxn, negn, skipn);
+        raw_apt nxt;
+        raw_apt_load(nxt, qtab + (size_t)jn * SBV_GTAB_PER_WINDOW + idxn);
+        if (!skip) {
+            apt29 q;
+            raw_apt_unpack(q, cur);
+            pt29_madd(R, q, neg);
+        }
+        cur = nxt; neg = negn; skip = skipn;
+    }
+}
+// Q phase of the grouped step.  `last` -> the verdict is returned; otherwise R goes back to gacc for the next chunk
+// of windows and the return value is meaningless.
+SBV_HD bool qphase29_lane(const Scratch& s, size_t i, u32 slot, u32 nkeys, const apt* ktab, const uint8_t* kvalid,
+                          u32* gacc, int j0, int j1, bool last) {
+    u256 u2;
+    soa_load(u2, s.u2, s.cap, i);
+    bool ok = s.ok[i] != 0 && slot < nkeys;
+    if (slot >= nkeys) slot = 0;
+    ok = ok && kvalid[slot] != 0;
+    const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
+    xyzz R;
+    gacc29_load(R, gacc, s.cap, i);
+    qphase29_point(R, u2, qtab, j0, j1);
+    if (!last) { gacc29_store(gacc, s.cap, i, R); return false; }
+    u256 r;
+    soa_load(r, s.r, s.cap, i);
+    return ok && pt29_rx_matches(R, r);
+}
+
+// registered key: u1 * G + u2 * Q in one pass
+SBV_HD bool verify29_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys, const apt* ktab, const uint8_t* kvalid,
+                                const apt* g16r) {
+    u256 r, u1, u2;
+    soa_load(r, s.r, s.cap, i);
+    soa_load(u1, s.u1, s.cap, i);
+    soa_load(u2, s.u2, s.cap, i);
+    bool ok = s.ok[i] != 0 && slot < nkeys;
+    if (slot >= nkeys) slot = 0;
+    ok = ok && kvalid[slot] != 0;
+    const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
+    xyzz R;
+    gphase29_point(R, u1, g16r);
+    qphase29_point(R, u2, qtab, 0, SBV_GTAB_WINDOWS);
+    return ok && pt29_rx_matches(R, r);
+}
+
+// ---- table conversion: entries of the 8 x 32 Montgomery domain (R = 2^256, p256_core.h generators) -> R = 2^261 ----
+SBV_HD void apt_to_r261(apt& out, const apt& in) {
+    fe29 x, y;
+    f29_from_fe(x, in.x);
+    f29_from_fe(y, in.y);
+    f29_store_canon(out.x.v, x);
+    f29_store_canon(out.y.v, y);
+}
+// the same on 8 x 32 arithmetic only (used inside the 8 x 32 table-building kernels): x * 2^5 mod p
+SBV_HD void fe_mul32(fe& r, const fe& a) {
+    fe t = a;
+    SBV_UNROLL
+    for (int i = 0; i < 5; ++i) fe_dbl(t, t);
+    r = t;
+}
+
+}  // namespace sbv

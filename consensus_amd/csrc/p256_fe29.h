@@ -16,6 +16,7 @@
 // Contracts (checked by tests/emul against big integers, including the worst cases the bounds allow):
 //   f29_mul(r, a, b): needs  sum_i |a.v[i]| * |b.v[k-i]| < 2^62 for every column k  and  |A| * |B| <= 16 p^2;
 //                     returns tight r with value in (A*B/R, A*B/R + p)  — so within (-p/2, 3p/2).
+//   f29_sqr(r, a):    the same, and |a.v[i]| < 2^30 (the cross terms use 2 * a.v[j] as a 32-bit operand).
 //   In practice: a tight value, or the sum / difference of two tight values, may be multiplied by another
 //   such value directly; anything looser goes through f29_norm() first.
 // Comparisons mod p go through f29_is_zero() (a three-instruction filter on the low limb, then the exact
@@ -98,7 +99,38 @@ SBV_HD void f29_reduce(fe29& r, i64 c[17]) {
     r.v[8] = (i32)(c[16] >> 29);           // |value| < 2p: the top limb fits easily
 }
 
+// Contract checks for the CPU test tier (tests/emul is compiled with -DSBV_F29_CHECK): every multiplication any
+// emulated code path executes asserts the operand bounds it relies on, so a formula that feeds it looser limbs than
+// analysed fails loudly in the container instead of wrapping silently on the GPU.
+#if defined(SBV_F29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+}  // namespace sbv
+#include <stdio.h>
+#include <stdlib.h>
+namespace sbv {
+inline void f29_check_operands(const fe29& a, const fe29& b, bool squaring) {
+    for (int k = 0; k < 17; ++k) {
+        unsigned __int128 col = 0;
+        for (int i = 0; i < 9; ++i) {
+            const int j = k - i;
+            if (j < 0 || j > 8) continue;
+            const i64 x = a.v[i], y = b.v[j];
+            col += (unsigned __int128)(u64)(x < 0 ? -x : x) * (u64)(y < 0 ? -y : y);
+        }
+        if (col >= ((unsigned __int128)1 << 62)) { fprintf(stderr, "f29: column %d would exceed 2^62\n", k); abort(); }
+    }
+    const i64 ta = a.v[8] < 0 ? -(i64)a.v[8] : a.v[8], tb = b.v[8] < 0 ? -(i64)b.v[8] : b.v[8];
+    if ((unsigned __int128)(ta + 1) * (unsigned __int128)(tb + 1) > ((unsigned __int128)1 << 52)) { fprintf(stderr, "f29: |A||B| may exceed 16 p^2\n"); abort(); }
+    if (squaring)
+        for (int i = 0; i < 9; ++i)
+            if (a.v[i] >= (1 << 30) || a.v[i] <= -(1 << 30)) { fprintf(stderr, "f29_sqr: limb %d needs |v| < 2^30 (it is doubled)\n", i); abort(); }
+}
+#define SBV_F29_CHECK_OPERANDS(a, b, sq) f29_check_operands(a, b, sq)
+#else
+#define SBV_F29_CHECK_OPERANDS(a, b, sq) ((void)0)
+#endif
+
 SBV_HD void f29_mul(fe29& r, const fe29& a, const fe29& b) {
+    SBV_F29_CHECK_OPERANDS(a, b, false);
     i64 c[17];
     SBV_UNROLL
     for (int k = 0; k < 17; ++k) c[k] = 0;
@@ -112,6 +144,7 @@ SBV_HD void f29_mul(fe29& r, const fe29& a, const fe29& b) {
 
 // 45 multiplies: the cross terms use 2 * a[j] (one full-rate shift each)
 SBV_HD void f29_sqr(fe29& r, const fe29& a) {
+    SBV_F29_CHECK_OPERANDS(a, a, true);
     i64 c[17];
     i32 d[9];
     SBV_UNROLL

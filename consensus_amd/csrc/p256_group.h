@@ -19,14 +19,16 @@
 //   keytab_bases   per grouped key: validate it (pointFromAffine rules), 2^(8j) * Q for j = 0..32, Jacobian
 //                  (no normalisation: the windows add them with the full Jacobian formula), in chunks
 //                  of windows so that table building and use can be pipelined
-//   keytab_window  per (key, window): the 128 affine multiples, Montgomery-trick normalised
+//   keytab_window  per (key, window): the 128 affine multiples, Montgomery-trick normalised, stored for the carry-free
+//                  field of the Q phase (R = 2^261 domain)
 //   gphase         u1 * G for every tuple (p256_core.h), independent of all of the above
-// then the Q phase (verify_lane_keyed_q) runs over the grouped list and the generic stage B over the
+// then the Q phase (qphase29_lane, p256_comb29.h) runs over the grouped list and the generic stage B over the
 // ungrouped one.
 //
 // Shared host/device source (tests/emul runs the same functions sequentially).
 #pragma once
 #include "p256_core.h"
+#include "p256_comb29.h"
 
 namespace sbv {
 
@@ -235,6 +237,9 @@ SBV_HD void keytab_window_lane(const u32* jbase, int part, int parts, u32* tmp, 
         apt a;
         fe_mul(a.x, X, zi2);
         fe_mul(a.y, Y, zi3);
+        // the Q phase runs on the carry-free field (p256_comb29.h): its tables hold x * 2^261, this kernel computes x * 2^256
+        fe_mul32(a.x, a.x);
+        fe_mul32(a.y, a.y);
         fe_store16(reinterpret_cast<u32*>(row + m + k), a.x);
         fe_store16(reinterpret_cast<u32*>(row + m + k) + 8, a.y);
     }

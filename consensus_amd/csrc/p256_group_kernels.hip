@@ -14,6 +14,14 @@
 #include "group_kernels_common.h"
 #include "p256_kernels.h"
 
+// waves per SIMD the comb kernels of the carry-free field are compiled for: the mixed addition keeps ~160 live registers
+// (XYZZ accumulator 36, two table entries in flight 32, 17 64-bit columns 34, temporaries); at 3 waves (168 VGPRs) hipcc
+// spills ~60 dwords per lane in the Q phase, at 2 waves nothing, and tools/febench measures the addition chain no slower
+// at 2 waves than at 3 (the arithmetic has no carry chains to hide).
+#ifndef SBV_COMB29_WAVES
+#define SBV_COMB29_WAVES 2
+#endif
+
 namespace sbv {
 
 __global__ __launch_bounds__(256) void k_group_insert(const uint8_t* __restrict__ tuples, size_t n, GroupState g) {
@@ -61,9 +69,10 @@ __global__ __launch_bounds__(64) void k_keytab_window(GroupState g, const u32* _
 // tuples, so it has to start as early as possible and run BESIDE the throughput work, at the same
 // 3 waves/SIMD register budget (on its own stream it ran at 234 VGPRs and squeezed the kernel it
 // overlapped down to one wave per SIMD).  Remaining blocks: u1 * G for every tuple of the batch.
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_gphase_generic(Scratch s, size_t n, GroupState g, u32* __restrict__ qtab,
-                                                                       const apt* __restrict__ g16, u32* __restrict__ gacc,
-                                                                       uint8_t* __restrict__ acc, unsigned generic_blocks) {
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_gphase_generic(Scratch s, size_t n, GroupState g, u32* __restrict__ qtab,
+                                                                       const apt* __restrict__ g16, const apt* __restrict__ g16r,
+                                                                       u32* __restrict__ gacc, uint8_t* __restrict__ acc,
+                                                                       unsigned generic_blocks) {
     if (blockIdx.x < generic_blocks) {
         const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
         if (L >= g.counters[2]) return;
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_gphase_generic(Scratch 
     }
     if (group_count(g) == 0) return;            // no key repeats often enough (e.g. all-distinct keys): nothing will read gacc
     const size_t i = (size_t)(blockIdx.x - generic_blocks) * SBV_VERIFY_BLOCK + threadIdx.x;
-    if (i < n) gphase_lane(s, i, g16, gacc);
+    if (i < n) gphase29_lane(s, i, g16r, gacc);
 }
 
 // The generic stage B alone (own stream, when the process has hardware queues to spare)
@@ -86,13 +95,13 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_verify_generic_list(Scr
 }
 
 // Q phase over the grouped list: windows [j0, j1) of the per-batch key combs
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_verify_keyed_q(Scratch s, GroupState g, const apt* __restrict__ ktab,
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_verify_keyed_q(Scratch s, GroupState g, const apt* __restrict__ ktab,
                                                                     const uint8_t* __restrict__ kvalid, u32* __restrict__ gacc,
                                                                     uint8_t* __restrict__ acc, int j0, int j1, int last) {
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= g.counters[1]) return;
     const u32 t = g.grp_idx[L];
-    const bool v = verify_lane_keyed_q(s, t, g.slots[t], group_count(g), ktab, kvalid, gacc, j0, j1, last != 0);
+    const bool v = qphase29_lane(s, t, g.slots[t], group_count(g), ktab, kvalid, gacc, j0, j1, last != 0);
     if (last) acc[t] = v ? 1 : 0;
 }
 
@@ -106,8 +115,8 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_verify_keyed_q(Scratch 
 //   side_a: insert assign | bases chunk 0 | bases chunk 1 | ...
 //   side_b:        wait(assign) split | wait(bases c) windows chunk c ...
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b,
-                                      u32* d_qtab, const apt* d_g16, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y,
-                                      hipEvent_t* prof, int* prof_pairs) {
+                                      u32* d_qtab, const apt* d_g16, const apt* d_g16r, uint8_t* d_bitmap, hipStream_t stream,
+                                      const GroupSync& y, hipEvent_t* prof, int* prof_pairs) {
     if (n == 0) return hipSuccess;
     GroupState g;
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
@@ -143,10 +152,10 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
         SBV_TRY(hipEventRecord(y.ev_generic, y.side_c));
         // the G phase reads counters[0] (group_count): it may not start before side_a's memset / insert / assign
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
-        hipLaunchKernelGGL(k_gphase_generic, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, b.gacc, b.acc, 0u);
+        hipLaunchKernelGGL(k_gphase_generic, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, 0u);
     } else {
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
-        hipLaunchKernelGGL(k_gphase_generic, dim3(2 * gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, b.gacc, b.acc, gv);
+        hipLaunchKernelGGL(k_gphase_generic, dim3(2 * gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, gv);
     }
     // chunks of windows: bases on side_a, tables on side_b, Q phase on stream
     for (int c = 0; c < chunks; ++c) {

@@ -29,7 +29,7 @@ struct GroupBuffers {
         *ung_idx = nullptr, *slots = nullptr;
     u32* jbases = nullptr;      // [max_groups][33] Jacobian window bases (40 dwords each)
     apt* ktab = nullptr; uint8_t* kvalid = nullptr; u32* tmp = nullptr; uint8_t* acc = nullptr;
-    u32* gacc = nullptr;        // [24][scratch cap] u1*G per tuple, then the running sum of the Q phase
+    u32* gacc = nullptr;        // [36][scratch cap] u1*G per tuple (XYZZ, 9-limb coordinates), then the running sum of the Q phase
     u32 max_groups = 0, min_count = 0;
     size_t cap = 0;
     size_t gacc_cap = 0;        // the scratch capacity gacc was sized for
@@ -48,9 +48,11 @@ struct GroupSync {
 };
 // ev_fork must have been recorded on `stream` before stage A was enqueued.  prof (optional): 2 * chunks events,
 // a pair around every Q-phase launch; *prof_pairs = the number of pairs used.
+// d_g16: 16-bit comb of G in the 8 x 32 Montgomery domain (generic kernel); d_g16r: the same points for the carry-free field
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b, u32* d_qtab,
-                                      const apt* d_g16, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y,
+                                      const apt* d_g16, const apt* d_g16r, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y,
                                       hipEvent_t* prof = nullptr, int* prof_pairs = nullptr);
+void host_convert_table_r261(const apt* in, apt* out, size_t count);   // 8 x 32 Montgomery entries -> R = 2^261 domain (host threads)
 void host_build_gtable(apt* out);   // 33 x 128 affine multiples of G (8-bit comb; host signer, key tables)
 void host_build_g16(apt* out);      // 17 x 32768 affine multiples of G (16-bit comb used by the verify kernels)
 #define SBV_G16_ENTRIES ((size_t)SBV_G16_WINDOWS * SBV_G16_PER_WINDOW)

@@ -22,6 +22,7 @@
 
 #include "p256_core.h"
 #include "p256_kernels.h"
+#include "p256_comb29.h"
 #include "sha256_dev.h"
 
 namespace sbv {
@@ -305,6 +306,18 @@ void host_build_g16(apt* out) {
     std::vector<std::thread> th;
     for (int j = 0; j < SBV_G16_WINDOWS; ++j) th.emplace_back([j, out] { build_g16_window(j, out + (size_t)j * SBV_G16_PER_WINDOW); });
     for (auto& t : th) t.join();
+}
+
+void host_convert_table_r261(const apt* in, apt* out, size_t count) {
+    size_t nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 32) nt = 32;
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t)
+        th.emplace_back([=] {
+            for (size_t k = count * t / nt; k < count * (t + 1) / nt; ++k) apt_to_r261(out[k], in[k]);
+        });
+    for (auto& x : th) x.join();
 }
 
 bool host_build_key_table(const uint8_t q[64], apt* out) {

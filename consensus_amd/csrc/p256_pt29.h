@@ -85,6 +85,7 @@ SBV_HD void pt29_madd(xyzz& R, const apt29& q, bool neg) {
     f29_sub(P, U2, R.X);
     f29_cneg(S2, S2, neg);
     f29_sub(Rr, S2, R.Y);
+    f29_norm(Rr, Rr);                           // -S2 - Y1 reaches -2^30 per limb: too loose for the squaring below
     if (f29_maybe_zero(P)) {                    // random data: probability 2^-24 per lane
         if (f29_is_zero_slow(P)) {
             if (f29_is_zero(Rr)) {              // P == Q

@@ -35,6 +35,7 @@ struct Context {
     uint8_t* d_scratch = nullptr;
     u32* d_qtab = nullptr;
     sbv::apt* d_gtab = nullptr;
+    sbv::apt* d_g16r = nullptr;          // the same comb of G for the carry-free field (R = 2^261 domain)
     uint8_t* d_bitmap = nullptr;
     uint8_t* d_rerun = nullptr;         // per-wavefront flags between the fast and the exact stage-B pass
     uint8_t* h_bitmap = nullptr;        // pinned
@@ -169,7 +170,7 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ung_idx, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.slots, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jbases, G * SBV_GTAB_WINDOWS * (size_t)40 * sizeof(u32)));   // 40 dwords = one Jacobian base (p256_group.h)
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 32 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride; 24 words (P-256) or 32 (Ed25519) per tuple
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 36 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride; 36 words (P-256: XYZZ, 9-limb coordinates) or 32 (Ed25519) per tuple
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ktab, G * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, G));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tmp, G * SBV_GTAB_WINDOWS * (size_t)(SBV_GTAB_PER_WINDOW * 32) * sizeof(u32)));
@@ -225,7 +226,7 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_tuples, n, s, stream));
     if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
     if (grouped) {
-        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, d_bitmap, stream, c.gsync, dom, dom_pairs));
+        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, c.d_g16r, d_bitmap, stream, c.gsync, dom, dom_pairs));
         return SBV_OK;
     }
     if (dom) HIP_TRY(SBV_EDEVICE, hipEventRecord(dom[0], stream));     // ungrouped: the dominant kernel is all of stage B
@@ -328,6 +329,12 @@ extern "C" int sbv_init(int device) {
     sbv::host_build_g16(h_gtab.data());
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_gtab, gcount * sizeof(sbv::apt)));
     HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_gtab, h_gtab.data(), gcount * sizeof(sbv::apt), hipMemcpyHostToDevice));
+    {
+        std::vector<sbv::apt> h_g16r(gcount);
+        sbv::host_convert_table_r261(h_gtab.data(), h_g16r.data(), gcount);
+        HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_g16r, gcount * sizeof(sbv::apt)));
+        HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_g16r, h_g16r.data(), gcount * sizeof(sbv::apt), hipMemcpyHostToDevice));
+    }
     if (const char* e = getenv("SBV_GROUP")) c.group_enabled = e[0] != '0';
     c.device = device;
     c.ready = true;
@@ -345,6 +352,8 @@ extern "C" int sbv_shutdown(void) {
     free_group_buffers(c);
     if (c.d_gtab) (void)hipFree(c.d_gtab);
     c.d_gtab = nullptr;
+    if (c.d_g16r) (void)hipFree(c.d_g16r);
+    c.d_g16r = nullptr;
     if (c.d_btab) (void)hipFree(c.d_btab);
     c.d_btab = nullptr;
     if (c.d_msgs) (void)hipFree(c.d_msgs);

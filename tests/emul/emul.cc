@@ -40,6 +40,20 @@ static const apt* g16tab() {        // 16-bit comb for G, as the verify kernels 
     return g_g16;
 }
 
+static apt* g_g16r = nullptr;
+static const apt* g16rtab() {       // the same comb in the R = 2^261 domain (carry-free field)
+    if (!g_g16r) {
+        const apt* src = g16tab();
+        const size_t count = (size_t)SBV_G16_WINDOWS * SBV_G16_PER_WINDOW;
+        g_g16r = (apt*)aligned_alloc(64, sizeof(apt) * count);
+        std::vector<std::thread> th;
+        for (int t = 0; t < 8; ++t)
+            th.emplace_back([=] { for (size_t k = count * t / 8; k < count * (t + 1) / 8; ++k) apt_to_r261(g_g16r[k], src[k]); });
+        for (auto& t : th) t.join();
+    }
+    return g_g16r;
+}
+
 struct HostWords {
     const uint8_t* tuples;
     size_t stride = 160;
@@ -113,8 +127,8 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     for (size_t i = 0; i < n; ++i) group_split_lane(tuples, i, g, accb.data());
     const u32 ngroups = counters[0] < max_groups ? counters[0] : max_groups;
     // G phase for every tuple
-    std::vector<u32> gacc(24 * cap);
-    for (size_t i = 0; i < n; ++i) gphase_lane(s, i, g16tab(), gacc.data());
+    std::vector<u32> gacc(SBV_GACC29_WORDS * cap);
+    for (size_t i = 0; i < n; ++i) gphase29_lane(s, i, g16rtab(), gacc.data());
     // key tables and the Q phase, in `chunks` pieces like the device pipeline
     const size_t ng1 = ngroups ? ngroups : 1;
     u32* jbases = (u32*)aligned_alloc(16, ng1 * SBV_GTAB_WINDOWS * SBV_JBASE_DWORDS * 4);
@@ -135,7 +149,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
         const bool last = c + 1 == chunks;
         for (u32 L = 0; L < counters[1]; ++L) {
             const u32 t = grp_idx[L];
-            const bool v = verify_lane_keyed_q(s, t, slots[t], ngroups, ktab, kvalid.data(), gacc.data(), j_first, j_end, last);
+            const bool v = qphase29_lane(s, t, slots[t], ngroups, ktab, kvalid.data(), gacc.data(), j_first, j_end, last);
             if (last && v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
         }
     }

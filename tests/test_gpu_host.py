@@ -92,3 +92,87 @@ def test_ed25519_scheme_through_the_gpu(lib):
         assert lib.sbvh_verify_proposal(v, p, len(p), b"h", 1, b"m", 1, 0, info, 1 << 16, ctypes.byref(ln), ctypes.byref(cnt)) == INVALID
     finally:
         lib.sbvh_verifier_free(v)
+
+
+class _Seam:
+    """Verifier over the real backend + 3 registered clients, for the leader / pool call sites."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.v = _new(lib)
+        self.clients = {}
+        q = ctypes.create_string_buffer(64)
+        for i in range(3):
+            s = lib.sbvh_signer_new(0, hashlib.sha256(b"gpu-client%d" % i).digest())
+            lib.sbvh_signer_public_key(s, q)
+            lib.sbvh_register_client(self.v, b"bob%d" % i, q.raw)
+            self.clients["bob%d" % i] = s
+
+    def request(self, client, rid, corrupt=False, payload=b"tx"):
+        u = hostlib.request_unsigned(client, rid, payload)
+        out = ctypes.create_string_buffer(80)
+        k = self.lib.sbvh_sign(self.clients[client], u, len(u), out, 80)
+        sig = bytearray(out.raw[:k])
+        if corrupt:
+            sig[-1] ^= 1
+        return hostlib.request_encode(u, bytes(sig))
+
+    def verify_request(self, raw):
+        out = ctypes.create_string_buffer(1024)
+        n = ctypes.c_size_t()
+        st = self.lib.sbvh_verify_request(self.v, raw, len(raw), out, 1024, ctypes.byref(n))
+        return st, (hostlib.split_infos(out.raw[:n.value]) or [None])[0]
+
+
+def test_leader_verify_request_on_gpu(lib):
+    """Controller.HandleRequest -> VerifyRequest (internal/bft/controller.go:233-246): one signature per call on an
+    arbitrary goroutine; an error means the request is not pooled (controller_test.go:548)."""
+    sx = _Seam(lib)
+    try:
+        good = sx.request("bob0", "req-1")
+        assert sx.verify_request(good) == (OK, ("bob0", "req-1"))
+        assert sx.verify_request(sx.request("bob1", "req-2", corrupt=True))[0] == INVALID
+        stranger = hostlib.request_encode(hostlib.request_unsigned("mallory", "x", b""), b"\x30\x00")
+        assert sx.verify_request(stranger)[0] == INVALID
+        assert sx.verify_request(good[:-3])[0] == INVALID
+        assert sx.verify_request(b"")[0] == INVALID
+    finally:
+        lib.sbvh_verifier_free(sx.v)
+
+
+def test_pool_prune_pattern_on_gpu(lib):
+    """Controller.MaybePruneRevokedRequests -> Pool.Prune (controller.go:733-746, requestpool.go:335-371): every pooled request
+    (RequestPoolSize = 400, pkg/types/config.go:98) is re-verified one call at a time; exactly the rejects leave the pool
+    (requestpool_test.go:264)."""
+    sx = _Seam(lib)
+    try:
+        pool = [sx.request("bob%d" % (i % 3), "r%d" % i, corrupt=(i % 7 == 3)) for i in range(400)]
+        kept = [r for r in pool if sx.verify_request(r)[0] == OK]
+        assert kept == [r for i, r in enumerate(pool) if i % 7 != 3]
+    finally:
+        lib.sbvh_verifier_free(sx.v)
+
+
+def test_config2_verify_proposal_k_10000_on_gpu(lib):
+    """BASELINE.json configs[2] at the seam: 4 nodes, one K = 10 000-request proposal per sequence through VerifyProposal
+    (view.go:553-559) as ONE device batch, then the commit path; the replay driver signs the traffic itself."""
+    v = _new(lib)
+    try:
+        res = hostlib.ReplayResult()
+        assert lib.sbvh_replay(v, 4, 10000, 2, 0, 16, ctypes.byref(res)) == 0
+        assert res.status == 0
+        assert res.max_backend_batch >= 10000
+    finally:
+        lib.sbvh_verifier_free(v)
+
+
+def test_config3_decision_replay_50000_x_11_on_gpu(lib):
+    """BASELINE.json configs[3] at the seam: 16 nodes (f = 5, Q = 11), 50 000 decisions x 11 consenter signatures through
+    VerifyConsenterSigBatch; every proposal must reach its quorum."""
+    v = _new(lib)
+    try:
+        res = hostlib.ReplayResult()
+        assert lib.sbvh_replay(v, 16, 10, 1, 50000, 16, ctypes.byref(res)) == 0
+        assert res.status == 0 and res.batch_tuples == 550000 and res.proposals_with_quorum == 50000
+    finally:
+        lib.sbvh_verifier_free(v)
