@@ -14,8 +14,9 @@
 //   "tight"   limbs 0..7 in [0, 2^29), limb 8 small and signed           (what f29_mul / f29_sqr return)
 //   "loose"   any limbs with |v[i]| < 2^31 after a few additions / subtractions of tight values
 // Contracts (checked by tests/emul against big integers, including the worst cases the bounds allow):
-//   f29_mul(r, a, b): needs  sum_i |a.v[i]| * |b.v[k-i]| < 2^62 for every column k  and  |A| * |B| <= 16 p^2;
-//                     returns tight r with value in (A*B/R, A*B/R + p)  — so within (-p/2, 3p/2).
+//   f29_mul(r, a, b): needs  sum_i |a.v[i]| * |b.v[k-i]| < 3 * 2^60 for every column k  and  |A| * |B| <= 64 p^2;
+//                     returns tight r with value in (A*B/R, A*B/R + p): within (-p/2, 3p/2) for |A||B| <= 16 p^2 (the
+//                     comb phases), within (-2p, 3p) in general (R = 32 * 2^256).
 //   f29_sqr(r, a):    the same, and |a.v[i]| < 2^30 (the cross terms use 2 * a.v[j] as a 32-bit operand).
 //   In practice: a tight value, or the sum / difference of two tight values, may be multiplied by another
 //   such value directly; anything looser goes through f29_norm() first.
@@ -44,6 +45,7 @@ SBV_HD fe29 f29_r2() { fe29 r = {{0x00000C00, 0x00000000, 0x1FFF0000, 0x1FDFFFFF
 SBV_HD fe29 f29_b() { fe29 r = {{0x1897BBFB, 0x1CDF6229, 0x018486C4, 0x01732821, 0x1DAD59E0, 0x0ABF7212, 0x1A06D110, 0x17721D20, 0x008600C3}}; return r; }
 SBV_HD fe29 f29_c266() { fe29 r = {{0x00000400, 0x00000000, 0x00000000, 0x1FF80000, 0x1FFFFFFF, 0x1FFFFFFF, 0x0FFFFFFF, 0x1FFFFFFF, 0x00000003}}; return r; }
 SBV_HD fe29 f29_c256() { fe29 r = {{0x00000001, 0x00000000, 0x00000000, 0x1FFFFE00, 0x1FFFFFFF, 0x1FFFFFFF, 0x1FFBFFFF, 0x001FFFFF, 0x00000000}}; return r; }
+SBV_HD fe29 f29_r3() { fe29 r = {{0x00050000, 0x1FF40000, 0x1EFFFFFF, 0x0DFFFFFF, 0x07FFFFFF, 0x1FFFFFFF, 0x0000000B, 0x00000010, 0x00000C00}}; return r; }   // R^3 mod p
 SBV_HD fe29 f29_zero() { fe29 r = {{0, 0, 0, 0, 0, 0, 0, 0, 0}}; return r; }
 
 // ---- the multiply-accumulate primitive ---------------------------------------------------------------
@@ -116,10 +118,10 @@ inline void f29_check_operands(const fe29& a, const fe29& b, bool squaring) {
             const i64 x = a.v[i], y = b.v[j];
             col += (unsigned __int128)(u64)(x < 0 ? -x : x) * (u64)(y < 0 ? -y : y);
         }
-        if (col >= ((unsigned __int128)1 << 62)) { fprintf(stderr, "f29: column %d would exceed 2^62\n", k); abort(); }
+        if (col >= ((unsigned __int128)3 << 60)) { fprintf(stderr, "f29: column %d would exceed 3 * 2^60 (two such products may share one set of i64 columns)\n", k); abort(); }
     }
     const i64 ta = a.v[8] < 0 ? -(i64)a.v[8] : a.v[8], tb = b.v[8] < 0 ? -(i64)b.v[8] : b.v[8];
-    if ((unsigned __int128)(ta + 1) * (unsigned __int128)(tb + 1) > ((unsigned __int128)1 << 52)) { fprintf(stderr, "f29: |A||B| may exceed 16 p^2\n"); abort(); }
+    if ((unsigned __int128)(ta + 1) * (unsigned __int128)(tb + 1) > ((unsigned __int128)1 << 54)) { fprintf(stderr, "f29: |A||B| may exceed 64 p^2\n"); abort(); }
     if (squaring)
         for (int i = 0; i < 9; ++i)
             if (a.v[i] >= (1 << 30) || a.v[i] <= -(1 << 30)) { fprintf(stderr, "f29_sqr: limb %d needs |v| < 2^30 (it is doubled)\n", i); abort(); }
@@ -158,6 +160,96 @@ SBV_HD void f29_sqr(fe29& r, const fe29& a) {
         for (int j = i + 1; j < 9; ++j) c[i + j] = f29_mad(a.v[i], d[j], c[i + j]);
     }
     f29_reduce(r, c);
+}
+
+// ---- column-level interface for the hot comb path: several products into ONE reduction ------------------------------
+// The reduction is almost half of a multiplication (59 - 68 of its ~145 multiply-accumulates), so the mixed addition
+// forms  X3 = Rr^2 - (PPP + 2 Q)  and  Y3 = Rr (Q - X3) - Y1 PPP  in the column domain and reduces each once:
+// a second product accumulates into the same 17 columns (negated through its first operand), and an already-reduced
+// value V enters as V * 2^261, i.e. limb i into column 9 + i.
+struct f29_cols { i64 c[17]; };
+SBV_HD void f29_cols_zero(f29_cols& t) {
+    SBV_UNROLL
+    for (int k = 0; k < 17; ++k) t.c[k] = 0;
+}
+SBV_HD void f29_cols_mul(f29_cols& t, const fe29& a, const fe29& b) {
+    SBV_F29_CHECK_OPERANDS(a, b, false);
+    SBV_UNROLL
+    for (int i = 0; i < 9; ++i) {
+        SBV_UNROLL
+        for (int j = 0; j < 9; ++j) t.c[i + j] = f29_mad(a.v[i], b.v[j], t.c[i + j]);
+    }
+}
+SBV_HD void f29_cols_sqr(f29_cols& t, const fe29& a) {
+    SBV_F29_CHECK_OPERANDS(a, a, true);
+    i32 d[9];
+    SBV_UNROLL
+    for (int i = 0; i < 9; ++i) d[i] = a.v[i] * 2;
+    SBV_UNROLL
+    for (int i = 0; i < 9; ++i) {
+        t.c[2 * i] = f29_mad(a.v[i], a.v[i], t.c[2 * i]);
+        SBV_UNROLL
+        for (int j = i + 1; j < 9; ++j) t.c[i + j] = f29_mad(a.v[i], d[j], t.c[i + j]);
+    }
+}
+// t -= v * 2^261   (|v.v[i]| < 2^31)
+SBV_HD void f29_cols_sub_val(f29_cols& t, const fe29& v) {
+    const i32 km1 = f29_opaque(-1);
+    SBV_UNROLL
+    for (int i = 0; i < 8; ++i) t.c[9 + i] = f29_mad(v.v[i], km1, t.c[9 + i]);
+    t.c[16] = f29_mad(v.v[8], f29_opaque(-(1 << 29)), t.c[16]);           // limb 8 sits one limb above column 16
+}
+// The reduction with 32-bit multipliers: step k clears the low 32 bits of column k (m = the signed low word), so the
+// carry is just (hi + sign) * 8 — one multiply-accumulate instead of two and no masking.  The price is a wider result:
+// sum m_k 2^(29 k) reaches +-2^263, so r lies within +-(4.01 p + |T| / R) instead of (T/R, T/R + p); callers that keep
+// values across iterations follow it with f29_red_q().  Limbs 0..7 of r are exact 29-bit limbs as in f29_reduce.
+SBV_HD void f29_reduce_x(fe29& r, f29_cols& t) {
+    const f29_consts K = f29_load_consts();
+    i64* c = t.c;
+    SBV_UNROLL
+    for (int k = 0; k < 9; ++k) {
+        const u32 lo = (u32)c[k];
+        const i32 hi = (i32)(c[k] >> 32);
+        const i32 m = (i32)lo;
+        const i32 cy = hi + (i32)(lo >> 31);
+        c[k + 1] = f29_mad(cy, K.k8, c[k + 1]);
+        c[k + 3] = f29_mad(m, K.k9, c[k + 3]);
+        c[k + 6] = f29_mad(m, K.k18, c[k + 6]);
+        c[k + 7] = f29_mad(m, K.k21n, c[k + 7]);
+        c[k + 8] = f29_mad(m, K.k24, c[k + 8]);
+    }
+    SBV_UNROLL
+    for (int j = 9; j < 16; ++j) {
+        const u32 lo = (u32)c[j];
+        const i32 hi = (i32)(c[j] >> 32);
+        r.v[j - 9] = (i32)(lo & SBV_M29);
+        c[j + 1] = f29_mad(hi, K.k8, c[j + 1]);
+        c[j + 1] = f29_madu(lo >> 29, K.k1, c[j + 1]);
+    }
+    r.v[7] = (i32)((u32)c[16] & SBV_M29);
+    r.v[8] = (i32)(c[16] >> 29);
+}
+SBV_HD void f29_mulx(fe29& r, const fe29& a, const fe29& b) {
+    f29_cols t;
+    f29_cols_zero(t);
+    f29_cols_mul(t, a, b);
+    f29_reduce_x(r, t);
+}
+SBV_HD void f29_sqrx(fe29& r, const fe29& a) {
+    f29_cols t;
+    f29_cols_zero(t);
+    f29_cols_sqr(t, a);
+    f29_reduce_x(r, t);
+}
+// value reduction of a tight element by the multiple of p its top limb indicates: |value| < 64 p  ->  value in
+// (-2^231, 2^256 + 2^231), limbs 0..7 within 2^27 of [0, 2^29)
+SBV_HD void f29_red_q(fe29& r) {
+    const i32 q = r.v[8] >> 24;
+    r.v[8] -= q << 24;
+    r.v[7] += q << 21;
+    r.v[6] -= q << 18;
+    r.v[3] -= q << 9;
+    r.v[0] += q;
 }
 
 // ---- additions: limb-wise, no carries, no reduction ------------------------------------------------------
@@ -293,6 +385,18 @@ SBV_HD void f29_to_fe(fe& X, const fe29& a) {
     f29_canon(c, t);
     f29_pack(X.v, c);
 }
+// a^-1 (Montgomery domain in and out) by division steps on the canonical 256-bit integer (modinv30.h): the plain
+// inverse of a R is a^-1 R^-1, one multiplication by R^3 brings it back to a^-1 R.  a = 0 (mod p) -> 0.
+SBV_HD void f29_inv(fe29& r, const fe29& a) {
+    fe29 c, t;
+    f29_canon(c, a);
+    u256 x, y;
+    f29_pack(x.v, c);
+    modinv30(y, x, modinfo30_p256());
+    f29_unpack(t, y.v);
+    f29_mul(r, t, f29_r3());
+}
+
 // x * 2^261 -> canonical 8-word value of the SAME domain (table / scratch storage: unpack gives it back)
 SBV_HD void f29_store_canon(u32 w[8], const fe29& a) {
     fe29 c;

@@ -13,6 +13,7 @@
 
 #include "group_kernels_common.h"
 #include "p256_kernels.h"
+#include "p256_keytab29.h"
 
 // waves per SIMD the comb kernels of the carry-free field are compiled for: the mixed addition keeps ~160 live registers
 // (XYZZ accumulator 36, two table entries in flight 32, 17 64-bit columns 34, temporaries); at 3 waves (168 VGPRs) hipcc
@@ -44,24 +45,41 @@ __global__ __launch_bounds__(256) void k_group_split(const uint8_t* __restrict__
     group_split_emit(i, s, ung, grp, key_rejected, g);
 }
 
-__global__ __launch_bounds__(64) void k_keytab_bases(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jbases,
-                                                     uint8_t* __restrict__ valid, int j_first, int j_last) {
+// ---- per-batch key tables on the carry-free field (p256_keytab29.h) -----------------------------------------------------
+// tmp layout (u32 words): [0, G * BASES_TMP) private strips of the bases kernel; behind it one strip of
+// SBV_KT29_WINDOW_TMP words per (key, window), shared by the rows and the fill kernel (same stream, never concurrent).
+#define SBV_KT29_WINDOW_TMP (7 * SBV_KT29_FILL_TMP_WORDS)
+__global__ __launch_bounds__(64) void k_keytab29_bases(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jstate,
+                                                       apt* __restrict__ bases, u32* __restrict__ tmp, uint8_t* __restrict__ valid,
+                                                       int j_first, int j_last) {
     const u32 k = blockIdx.x * 64 + threadIdx.x;
-    if (k < group_count(g)) keytab_bases_lane(tuples, k, g, jbases, valid, j_first, j_last);
+    if (k < group_count(g)) keytab29_bases_lane(tuples, k, g, jstate, bases, tmp + (size_t)k * SBV_KT29_BASES_TMP_WORDS, valid, j_first, j_last);
 }
-
-// lanes = groups x j_count x parts
-__global__ __launch_bounds__(64) void k_keytab_window(GroupState g, const u32* __restrict__ jbases, u32* __restrict__ tmp,
-                                                      apt* __restrict__ ktab, int j_first, int j_count, int parts) {
+// lanes = groups x j_count x 2
+__global__ __launch_bounds__(64) void k_keytab29_rows(GroupState g, const apt* __restrict__ bases, u32* __restrict__ tmp,
+                                                      apt* __restrict__ ktab, int j_first, int j_count) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;
-    const u32 part = lane % (u32)parts;
-    const u32 kw = lane / (u32)parts;
+    const u32 which = lane & 1u, kw = lane >> 1;
     const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
     if (key >= group_count(g)) return;
     const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
-    keytab_window_lane(jbases + w * SBV_JBASE_DWORDS, (int)part, parts,
-                       tmp + w * SBV_KEYTAB_TMP_DWORDS_PER_WINDOW + (size_t)part * (SBV_GTAB_PER_WINDOW / parts) * 32,
-                       ktab + w * SBV_GTAB_PER_WINDOW);
+    u32* t = tmp + (size_t)g.max_groups * SBV_KT29_BASES_TMP_WORDS + w * SBV_KT29_WINDOW_TMP + (size_t)which * SBV_KT29_ROWS_TMP_WORDS;
+    keytab29_rows_lane(bases + w * SBV_KT29_POINTS_PER_WINDOW, (int)which, j == SBV_GTAB_WINDOWS - 1, t, ktab + w * SBV_GTAB_PER_WINDOW);
+}
+// lanes = groups x j_count x lanes_per_window, each lane rows_per_lane of the 7 rows 16 a + b, a = 1..7
+__global__ __launch_bounds__(64) void k_keytab29_fill(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab, int j_first,
+                                                      int j_count, int rows_per_lane, int lanes_per_window) {
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 r = lane % (u32)lanes_per_window, kw = lane / (u32)lanes_per_window;
+    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
+    if (key >= group_count(g) || j == SBV_GTAB_WINDOWS - 1) return;
+    const int a_first = 1 + (int)r * rows_per_lane;
+    int a_last = a_first + rows_per_lane - 1;
+    if (a_last > 7) a_last = 7;
+    if (a_first > 7) return;
+    const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
+    u32* t = tmp + (size_t)g.max_groups * SBV_KT29_BASES_TMP_WORDS + w * SBV_KT29_WINDOW_TMP + (size_t)r * SBV_KT29_FILL_TMP_WORDS;
+    keytab29_fill_lane(a_first, a_last, t, ktab + w * SBV_GTAB_PER_WINDOW);
 }
 
 // One launch, two jobs.  Blocks [0, generic_blocks): the generic stage B (doubling kernel) over the
@@ -72,7 +90,7 @@ __global__ __launch_bounds__(64) void k_keytab_window(GroupState g, const u32* _
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_gphase_generic(Scratch s, size_t n, GroupState g, u32* __restrict__ qtab,
                                                                        const apt* __restrict__ g16, const apt* __restrict__ g16r,
                                                                        u32* __restrict__ gacc, uint8_t* __restrict__ acc,
-                                                                       unsigned generic_blocks) {
+                                                                       unsigned generic_blocks, size_t first, size_t end) {
     if (blockIdx.x < generic_blocks) {
         const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
         if (L >= g.counters[2]) return;
@@ -81,8 +99,8 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_gphase_g
         return;
     }
     if (group_count(g) == 0) return;            // no key repeats often enough (e.g. all-distinct keys): nothing will read gacc
-    const size_t i = (size_t)(blockIdx.x - generic_blocks) * SBV_VERIFY_BLOCK + threadIdx.x;
-    if (i < n) gphase29_lane(s, i, g16r, gacc);
+    const size_t i = first + (size_t)(blockIdx.x - generic_blocks) * SBV_VERIFY_BLOCK + threadIdx.x;      // this launch: tuples [first, end)
+    if (i < end) gphase29_lane(s, i, g16r, gacc);
 }
 
 // The generic stage B alone (own stream, when the process has hardware queues to spare)
@@ -116,7 +134,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_verify_k
 //   side_b:        wait(assign) split | wait(bases c) windows chunk c ...
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b,
                                       u32* d_qtab, const apt* d_g16, const apt* d_g16r, uint8_t* d_bitmap, hipStream_t stream,
-                                      const GroupSync& y, hipEvent_t* prof, int* prof_pairs) {
+                                      const GroupSync& y, hipEvent_t after_prep, hipEvent_t* prof, int* prof_pairs) {
     if (n == 0) return hipSuccess;
     GroupState g;
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
@@ -124,8 +142,8 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
     g.max_groups = b.max_groups;
     group_set_threshold(g, b.min_count);
     const int chunks = y.chunks < 1 ? 1 : (y.chunks > SBV_GROUP_MAX_CHUNKS ? SBV_GROUP_MAX_CHUNKS : y.chunks);
-    int parts = SBV_KEYTAB_PARTS_DEFAULT;
-    if (y.parts == 2 || y.parts == 4 || y.parts == 8 || y.parts == 16) parts = y.parts;
+    int rows_per_lane = 1;                         // rows of 16 entries one lane of the fill kernel builds (1, 2, 4 or 7)
+    if (y.parts == 1 || y.parts == 2 || y.parts == 4 || y.parts == 7) rows_per_lane = y.parts;
     hipError_t e;
 #define SBV_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
     // The side streams may not touch the group buffers before everything already enqueued on `stream` (the
@@ -139,11 +157,28 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
     hipLaunchKernelGGL(k_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
     hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, n, g);
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
+    // Stage A and the G phase, pipelined in slices of the batch: stage A is a low-occupancy chain (one inversion per
+    // thread), and while it ran alone at the head of the step most of the GPU idled for ~0.35 ms.  Slice 0 is prepared on
+    // `stream`, the others on side_b; the G phase of slice k starts as soon as slice k is prepared.  The generic kernel
+    // over the ungrouped list may touch any tuple, so it rides in the last slice's launch.
+    const size_t pbt = prep_block_tuples(n);
+    const unsigned pblocks = (unsigned)((n + pbt - 1) / pbt);
+    int slices = y.slices < 1 ? 1 : (y.slices > SBV_GROUP_MAX_SLICES ? SBV_GROUP_MAX_SLICES : y.slices);
+    if (y.side_c) slices = 1;
+    if ((unsigned)slices > pblocks) slices = (int)pblocks;
+    // the later slices go to side_b, which has nothing to do until the groups are assigned (a fifth stream would not get a
+    // hardware queue of its own: a process has four, and an aliased queue serialised the whole step — measured)
+    if (slices > 1) SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_fork, 0));
+    for (int k = 0; k < slices; ++k) {
+        const unsigned lo = (unsigned)((size_t)pblocks * k / slices), hi = (unsigned)((size_t)pblocks * (k + 1) / slices);
+        hipStream_t ps = k == 0 ? stream : y.side_b;
+        SBV_TRY(launch_p256_prep_blocks(d_tuples, n, s, ps, lo, hi));
+        if (k > 0) SBV_TRY(hipEventRecord(y.ev_slice[k], y.side_b));
+    }
     // side_b: split
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
     hipLaunchKernelGGL(k_group_split, dim3(gn), dim3(256), 0, y.side_b, d_tuples, n, g, b.acc);
     SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
-    // stream, right behind stage A: generic stage B over the ungrouped list + G phase for every tuple
     if (y.side_c) {
         SBV_TRY(hipEventRecord(y.ev_prep, stream));
         SBV_TRY(hipStreamWaitEvent(y.side_c, y.ev_prep, 0));
@@ -152,22 +187,42 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
         SBV_TRY(hipEventRecord(y.ev_generic, y.side_c));
         // the G phase reads counters[0] (group_count): it may not start before side_a's memset / insert / assign
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
-        hipLaunchKernelGGL(k_gphase_generic, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, 0u);
+        if (after_prep) SBV_TRY(hipEventRecord(after_prep, stream));
+        hipLaunchKernelGGL(k_gphase_generic, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, 0u,
+                           (size_t)0, n);
     } else {
-        SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
-        hipLaunchKernelGGL(k_gphase_generic, dim3(2 * gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, gv);
+        SBV_TRY(hipStreamWaitEvent(stream, y.ev_assign, 0));          // group_count() is final after the assignment
+        for (int k = 0; k < slices; ++k) {
+            const size_t first = (size_t)pblocks * k / slices * pbt;
+            size_t end = (size_t)pblocks * (k + 1) / slices * pbt;
+            if (end > n) end = n;
+            const bool last_slice = k + 1 == slices;
+            if (k > 0) SBV_TRY(hipStreamWaitEvent(stream, y.ev_slice[k], 0));
+            unsigned gen_blocks = 0;
+            if (last_slice) {
+                SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));  // the ungrouped list
+                if (after_prep) SBV_TRY(hipEventRecord(after_prep, stream));
+                gen_blocks = gv;
+            }
+            const unsigned gb = (unsigned)((end - first + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
+            hipLaunchKernelGGL(k_gphase_generic, dim3(gen_blocks + gb), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, d_g16r,
+                               b.gacc, b.acc, gen_blocks, first, end);
+        }
     }
     // chunks of windows: bases on side_a, tables on side_b, Q phase on stream
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [j_first, j_end)
         const int j_count = j_end - j_first;
-        hipLaunchKernelGGL(k_keytab_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jbases, b.kvalid,
-                           j_first, j_end - 1);
+        hipLaunchKernelGGL(k_keytab29_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases, b.tmp,
+                           b.kvalid, j_first, j_end - 1);
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
         SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[c], 0));
-        const size_t wl = (size_t)b.max_groups * j_count * parts;
-        hipLaunchKernelGGL(k_keytab_window, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.jbases, b.tmp, b.ktab,
-                           j_first, j_count, parts);
+        const size_t wl = (size_t)b.max_groups * j_count * 2;
+        hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.bases, b.tmp, b.ktab, j_first, j_count);
+        const int lpw = (7 + rows_per_lane - 1) / rows_per_lane;
+        const size_t fl = (size_t)b.max_groups * j_count * lpw;
+        hipLaunchKernelGGL(k_keytab29_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, y.side_b, g, b.tmp, b.ktab, j_first, j_count,
+                           rows_per_lane, lpw);
         SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         const bool last = c + 1 == chunks;

@@ -11,6 +11,8 @@ namespace sbv {
 
 int prep_chunk_T(size_t n);
 hipError_t launch_p256_prep(const uint8_t* d_tuples, size_t n, const Scratch& s, hipStream_t stream, bool keyed = false);
+size_t prep_block_tuples(size_t n);
+hipError_t launch_p256_prep_blocks(const uint8_t* d_tuples, size_t n, const Scratch& s, hipStream_t stream, unsigned block_lo, unsigned block_hi);
 hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
                                     const uint8_t* d_kvalid, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
                                     hipStream_t stream);
@@ -27,7 +29,9 @@ struct GroupBuffers {
     u32* ht = nullptr; u32 ht_mask = 0;
     u32 *rep = nullptr, *cnt = nullptr, *slot_of = nullptr, *group_rep = nullptr, *counters = nullptr, *grp_idx = nullptr,
         *ung_idx = nullptr, *slots = nullptr;
-    u32* jbases = nullptr;      // [max_groups][33] Jacobian window bases (40 dwords each)
+    u32* jbases = nullptr;      // (Ed25519 grouped step) [max_groups][33] window bases
+    apt* bases = nullptr;       // [max_groups][33][2] affine B_j = 2^(8j) Q and 16 B_j (p256_keytab29.h)
+    u32* jstate = nullptr;      // [max_groups][27] the doubling chain between chunks of windows
     apt* ktab = nullptr; uint8_t* kvalid = nullptr; u32* tmp = nullptr; uint8_t* acc = nullptr;
     u32* gacc = nullptr;        // [36][scratch cap] u1*G per tuple (XYZZ, 9-limb coordinates), then the running sum of the Q phase
     u32 max_groups = 0, min_count = 0;
@@ -37,21 +41,25 @@ struct GroupBuffers {
 // streams and events of the grouped step; owned by the context.  `chunks` (1..SBV_GROUP_MAX_CHUNKS) = how
 // many pieces the 33 key-comb windows are built and consumed in.
 #define SBV_GROUP_MAX_CHUNKS 4
+#define SBV_GROUP_MAX_SLICES 8
 struct GroupSync {
     hipStream_t side_a = nullptr;   // insert, assign, window bases
     hipStream_t side_b = nullptr;   // split, window tables
     hipStream_t side_c = nullptr;   // optional: generic stage B over the ungrouped list (nullptr: fused into the G-phase launch)
+    hipEvent_t ev_slice[SBV_GROUP_MAX_SLICES] = {};
+    int slices = 1;                 // pieces stage A + G phase are pipelined in (1..SBV_GROUP_MAX_SLICES); slices > 0 run on side_b
     hipEvent_t ev_fork = nullptr, ev_assign = nullptr, ev_split = nullptr, ev_prep = nullptr, ev_generic = nullptr;
     hipEvent_t ev_bases[SBV_GROUP_MAX_CHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
     int chunks = 1;
-    int parts = 4;                  // lanes per (key, window) in k_keytab_window: 2, 4, 8 or 16
+    int parts = 1;                  // P-256: rows of 16 entries per lane of k_keytab29_fill (1, 2, 4, 7); Ed25519: lanes per (key, window)
 };
-// ev_fork must have been recorded on `stream` before stage A was enqueued.  prof (optional): 2 * chunks events,
-// a pair around every Q-phase launch; *prof_pairs = the number of pairs used.
+// Enqueues stage A AND stage B of a grouped batch.  ev_fork must have been recorded on `stream` first.  after_prep
+// (optional) is recorded on `stream` once every slice of stage A is ordered before it.  prof (optional): 2 * chunks
+// events, a pair around every Q-phase launch; *prof_pairs = the number of pairs used.
 // d_g16: 16-bit comb of G in the 8 x 32 Montgomery domain (generic kernel); d_g16r: the same points for the carry-free field
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b, u32* d_qtab,
                                       const apt* d_g16, const apt* d_g16r, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y,
-                                      hipEvent_t* prof = nullptr, int* prof_pairs = nullptr);
+                                      hipEvent_t after_prep = nullptr, hipEvent_t* prof = nullptr, int* prof_pairs = nullptr);
 void host_convert_table_r261(const apt* in, apt* out, size_t count);   // 8 x 32 Montgomery entries -> R = 2^261 domain (host threads)
 void host_build_gtable(apt* out);   // 33 x 128 affine multiples of G (8-bit comb; host signer, key tables)
 void host_build_g16(apt* out);      // 17 x 32768 affine multiples of G (16-bit comb used by the verify kernels)

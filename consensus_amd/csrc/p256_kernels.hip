@@ -37,11 +37,11 @@ struct LdsTuple {
 
 // TD = dwords per input tuple: 40 (r|s|hash|Qx|Qy) or 24 (r|s|hash, registered-key form).
 template <int TD, bool HAS_Q>
-__device__ __forceinline__ void prep_body(const uint8_t* __restrict__ tuples, size_t n, const Scratch& s, int T) {
+__device__ __forceinline__ void prep_body(const uint8_t* __restrict__ tuples, size_t n, const Scratch& s, int T, unsigned block_off) {
     constexpr int kPitch = TD + 1;                 // odd -> conflict-free per-lane ds_read_b32 walk
     constexpr int kVec = TD / 4;                   // 16-byte elements per tuple
     __shared__ u32 lds[kPrepLanes * kPitch];
-    const size_t block_first = (size_t)blockIdx.x * kPrepLanes * (size_t)T;
+    const size_t block_first = ((size_t)blockIdx.x + block_off) * kPrepLanes * (size_t)T;
     const int lane = threadIdx.x;
     auto words = [&](int k, size_t) -> LdsTuple {
         const size_t slab = block_first + (size_t)k * kPrepLanes;      // first tuple of the slab
@@ -62,13 +62,15 @@ __device__ __forceinline__ void prep_body(const uint8_t* __restrict__ tuples, si
     prep_chunk<HAS_Q>(words, n, s, block_first + (size_t)lane, (size_t)kPrepLanes, T);
 }
 
+// block_off: the launch covers workgroups [block_off, block_off + gridDim.x) of the batch — the grouped step runs stage A in
+// slices so that the G phase of the first slice starts while the later slices are still being prepared.
 __global__ __launch_bounds__(kPrepLanes) void k_p256_prep(const uint8_t* __restrict__ tuples, size_t n,
-                                                          Scratch s, int T) {
-    prep_body<40, true>(tuples, n, s, T);
+                                                          Scratch s, int T, unsigned block_off) {
+    prep_body<40, true>(tuples, n, s, T, block_off);
 }
 __global__ __launch_bounds__(kPrepLanes) void k_p256_prep_keyed(const uint8_t* __restrict__ rsh, size_t n,
                                                                 Scratch s, int T) {
-    prep_body<24, false>(rsh, n, s, T);
+    prep_body<24, false>(rsh, n, s, T, 0u);
 }
 
 // Stage B normally runs as ONE launch of the exact kernel.  An experimental two-launch mode
@@ -238,7 +240,15 @@ hipError_t launch_p256_prep(const uint8_t* d_tuples, size_t n, const Scratch& s,
     const size_t per_block = (size_t)kPrepLanes * T;
     const unsigned grid = (unsigned)((n + per_block - 1) / per_block);
     if (keyed) hipLaunchKernelGGL(k_p256_prep_keyed, dim3(grid), dim3(kPrepLanes), 0, stream, d_tuples, n, s, T);
-    else hipLaunchKernelGGL(k_p256_prep, dim3(grid), dim3(kPrepLanes), 0, stream, d_tuples, n, s, T);
+    else hipLaunchKernelGGL(k_p256_prep, dim3(grid), dim3(kPrepLanes), 0, stream, d_tuples, n, s, T, 0u);
+    return hipGetLastError();
+}
+// workgroups [block_lo, block_hi) of stage A for the generic tuple form; prep_blocks() = how many there are, each
+// covering prep_block_tuples() consecutive tuples
+size_t prep_block_tuples(size_t n) { return (size_t)kPrepLanes * prep_chunk_T(n); }
+hipError_t launch_p256_prep_blocks(const uint8_t* d_tuples, size_t n, const Scratch& s, hipStream_t stream, unsigned block_lo, unsigned block_hi) {
+    if (n == 0 || block_hi <= block_lo) return hipSuccess;
+    hipLaunchKernelGGL(k_p256_prep, dim3(block_hi - block_lo), dim3(kPrepLanes), 0, stream, d_tuples, n, s, prep_chunk_T(n), block_lo);
     return hipGetLastError();
 }
 

@@ -69,7 +69,7 @@ SBV_HD void pt29_mdbl(xyzz& R, const fe29& x, const fe29& y) {
 }
 
 // R += (q.x, neg ? -q.y : q.y).  R.X, R.Y as left by this function (or pt29_mdbl / a load of stored
-// coordinates): value-reduced; ZZ, ZZZ tight.
+// coordinates): value-reduced; ZZ, ZZZ tight with |value| < 5 p.
 SBV_HD void pt29_madd(xyzz& R, const apt29& q, bool neg) {
     if (R.inf) {
         R.X = q.x;
@@ -79,9 +79,12 @@ SBV_HD void pt29_madd(xyzz& R, const apt29& q, bool neg) {
         R.inf = false;
         return;
     }
-    fe29 U2, S2, P, Rr, PP, PPP, Q, t, X3, Y3;
-    f29_mul(U2, q.x, R.ZZ);
-    f29_mul(S2, q.y, R.ZZZ);
+    // Hot path: the 32-bit-multiplier reduction (f29_reduce_x) and two fused reductions.  Bounds (units of p):
+    // X1, Y1 in (-0.01, 1.01) after f29_red_q; every product |A||B| <= 28, so every reduced value lies within +-4.9;
+    // P, Rr within +-5.3 (the zero filter covers +-16); X3 before f29_red_q within +-19, Y3 within +-5.
+    fe29 U2, S2, P, Rr, PP, PPP, Q, t, V;
+    f29_mulx(U2, q.x, R.ZZ);
+    f29_mulx(S2, q.y, R.ZZZ);
     f29_sub(P, U2, R.X);
     f29_cneg(S2, S2, neg);
     f29_sub(Rr, S2, R.Y);
@@ -98,22 +101,28 @@ SBV_HD void pt29_madd(xyzz& R, const apt29& q, bool neg) {
             return;
         }
     }
-    f29_sqr(PP, P);
-    f29_mul(PPP, P, PP);
-    f29_mul(Q, R.X, PP);
-    f29_sqr(t, Rr);
-    f29_sub(t, t, PPP);
-    f29_sub(t, t, Q);
-    f29_sub(X3, t, Q);                          // X3 = R^2 - PPP - 2 Q
-    f29_norm_red(X3, X3);
+    f29_sqrx(PP, P);
+    f29_mulx(PPP, P, PP);
+    f29_mulx(Q, R.X, PP);
+    f29_cols c;
+    f29_cols_zero(c);
+    f29_cols_sqr(c, Rr);
+    f29_add(V, PPP, Q);
+    f29_add(V, V, Q);
+    f29_cols_sub_val(c, V);
+    fe29 X3;
+    f29_reduce_x(X3, c);                        // X3 = Rr^2 - PPP - 2 Q, one reduction
+    f29_red_q(X3);
     f29_sub(t, Q, X3);
-    f29_mul(t, Rr, t);
-    f29_mul(Y3, R.Y, PPP);
-    f29_sub(Y3, t, Y3);                         // Y3 = R (Q - X3) - Y1 PPP
-    f29_norm_red(R.Y, Y3);
+    f29_neg(V, R.Y);
+    f29_cols_zero(c);
+    f29_cols_mul(c, Rr, t);
+    f29_cols_mul(c, V, PPP);
+    f29_reduce_x(R.Y, c);                       // Y3 = Rr (Q - X3) - Y1 PPP, one reduction
+    f29_red_q(R.Y);
     R.X = X3;
-    f29_mul(R.ZZ, R.ZZ, PP);
-    f29_mul(R.ZZZ, R.ZZZ, PPP);
+    f29_mulx(R.ZZ, R.ZZ, PP);
+    f29_mulx(R.ZZZ, R.ZZZ, PPP);
 }
 
 // R.x mod N == r  <=>  R != infinity and (X == r ZZ  or  (r + N < p and X == (r + N) ZZ))  (mod p); r < N plain.
@@ -135,6 +144,63 @@ SBV_HD bool pt29_rx_matches(const xyzz& R, const u256& r) {
         match = match || f29_is_zero(t);
     }
     return match;
+}
+
+// ---- Jacobian doubling (the 256-doubling chain that turns a fresh public key into its comb bases) --------------------
+// dbl-2001-b for a = -3: 3M + 5S.  X, Y, Z in / out: value-reduced (f29_norm_red).  Z = 0 (mod p) stays 0 (mod p).
+struct jpt29 { fe29 X, Y, Z; };
+SBV_HD void pt29_dbl_jac(jpt29& R) {
+    fe29 delta, gamma, beta, alpha, t1, t2, g2;
+    f29_sqr(delta, R.Z);
+    f29_sqr(gamma, R.Y);
+    f29_mul(beta, R.X, gamma);
+    f29_sub(t1, R.X, delta);
+    f29_add(t2, R.X, delta);
+    f29_norm(t2, t2);
+    f29_mul(alpha, t1, t2);
+    f29_add(t1, alpha, alpha);
+    f29_add(alpha, alpha, t1);                  // alpha = 3 (X - delta)(X + delta): limbs < 3 * 2^29
+    f29_norm(alpha, alpha);
+    f29_add(t1, R.Y, R.Z);
+    f29_norm(t1, t1);
+    f29_sqr(t1, t1);
+    f29_sub(t1, t1, gamma);
+    f29_sub(t1, t1, delta);
+    f29_norm_red(R.Z, t1);                      // Z3 = (Y + Z)^2 - gamma - delta
+    f29_add(t1, beta, beta);
+    f29_add(t1, t1, t1);
+    f29_norm(beta, t1);                         // 4 beta
+    f29_sqr(t1, alpha);
+    f29_sub(t1, t1, beta);
+    f29_sub(t1, t1, beta);
+    f29_norm_red(R.X, t1);                      // X3 = alpha^2 - 8 beta
+    f29_sub(t1, beta, R.X);
+    f29_mul(t1, alpha, t1);
+    f29_sqr(g2, gamma);
+    f29_add(t2, g2, g2);
+    f29_add(t2, t2, t2);
+    f29_norm(t2, t2);                           // 4 gamma^2
+    f29_sub(t1, t1, t2);
+    f29_sub(t1, t1, t2);
+    f29_norm_red(R.Y, t1);                      // Y3 = alpha (4 beta - X3) - 8 gamma^2
+}
+
+// affine + affine -> affine given the inverse of (x2 - x1):  lambda = (y2 - y1) / (x2 - x1),
+// x3 = lambda^2 - x1 - x2, y3 = lambda (x1 - x3) - y1.  2M + 1S.  Only for x1 != x2 (distinct small multiples of a
+// point of prime order — the table builder's case).  Inputs tight / canonical; outputs value-reduced.
+SBV_HD void apt29_add_with_inverse(apt29& r, const apt29& a, const apt29& b, const fe29& dinv) {
+    fe29 t, lam, x3;
+    f29_sub(t, b.y, a.y);
+    f29_mul(lam, t, dinv);
+    f29_sqr(t, lam);
+    f29_sub(t, t, a.x);
+    f29_sub(t, t, b.x);
+    f29_norm_red(x3, t);
+    f29_sub(t, a.x, x3);
+    f29_mul(t, lam, t);
+    f29_sub(t, t, a.y);
+    f29_norm_red(r.y, t);
+    r.x = x3;
 }
 
 // table entry (64 bytes: x | y, each the canonical 8-word residue of this domain) -> affine point

@@ -138,12 +138,13 @@ std::vector<hipEvent_t*> group_events(Context& c) {
     sbv::GroupSync& y = c.gsync;
     std::vector<hipEvent_t*> v = {&y.ev_fork, &y.ev_assign, &y.ev_split, &y.ev_prep, &y.ev_generic};
     for (int i = 0; i < SBV_GROUP_MAX_CHUNKS; ++i) { v.push_back(&y.ev_bases[i]); v.push_back(&y.ev_tables[i]); }
+    for (int i = 0; i < SBV_GROUP_MAX_SLICES; ++i) v.push_back(&y.ev_slice[i]);
     return v;
 }
 
 void free_group_buffers(Context& c) {
     sbv::GroupBuffers& b = c.grp;
-    void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.jbases, b.ktab, b.kvalid, b.tmp, b.acc, b.gacc};
+    void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.jbases, b.bases, b.jstate, b.ktab, b.kvalid, b.tmp, b.acc, b.gacc};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     b = sbv::GroupBuffers();
     if (c.edgrp.ktab) (void)hipFree(c.edgrp.ktab);
@@ -170,6 +171,8 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ung_idx, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.slots, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jbases, G * SBV_GTAB_WINDOWS * (size_t)40 * sizeof(u32)));   // 40 dwords = one Jacobian base (p256_group.h)
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.bases, G * SBV_GTAB_WINDOWS * (size_t)2 * sizeof(sbv::apt)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jstate, G * (size_t)27 * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 36 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride; 36 words (P-256: XYZZ, 9-limb coordinates) or 32 (Ed25519) per tuple
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ktab, G * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, G));
@@ -223,12 +226,13 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
         if (rc != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
     }
-    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_tuples, n, s, stream));
-    if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
-    if (grouped) {
-        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, c.d_g16r, d_bitmap, stream, c.gsync, dom, dom_pairs));
+    if (grouped) {           // stage A is enqueued by the grouped launcher, in slices pipelined with the G phase
+        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, c.d_g16r, d_bitmap, stream, c.gsync,
+                                                             after_prep, dom, dom_pairs));
         return SBV_OK;
     }
+    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_tuples, n, s, stream));
+    if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
     if (dom) HIP_TRY(SBV_EDEVICE, hipEventRecord(dom[0], stream));     // ungrouped: the dominant kernel is all of stage B
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify(s, n, c.d_qtab, c.d_gtab, d_bitmap, c.d_rerun, stream));
     if (dom) { HIP_TRY(SBV_EDEVICE, hipEventRecord(dom[1], stream)); if (dom_pairs) *dom_pairs = 1; }
@@ -317,6 +321,7 @@ extern "C" int sbv_init(int device) {
         if (v >= 1 && v <= SBV_GROUP_MAX_CHUNKS) c.gsync.chunks = v;
     }
     if (const char* e = getenv("SBV_GROUP_PARTS")) c.gsync.parts = atoi(e);
+    if (const char* e = getenv("SBV_GROUP_SLICES")) c.gsync.slices = atoi(e);
     if (const char* e = getenv("SBV_GENERIC_STREAM")) {
         if (e[0] == '1') HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.gsync.side_c, hipStreamNonBlocking));
     }

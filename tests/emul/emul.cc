@@ -17,6 +17,7 @@
 #include "../../consensus_amd/csrc/sha256_dev.h"
 #include "../../consensus_amd/csrc/p256_group.h"
 #include "../../consensus_amd/csrc/p256_pt29.h"
+#include "../../consensus_amd/csrc/p256_keytab29.h"
 
 using namespace sbv;
 
@@ -131,21 +132,26 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     for (size_t i = 0; i < n; ++i) gphase29_lane(s, i, g16rtab(), gacc.data());
     // key tables and the Q phase, in `chunks` pieces like the device pipeline
     const size_t ng1 = ngroups ? ngroups : 1;
-    u32* jbases = (u32*)aligned_alloc(16, ng1 * SBV_GTAB_WINDOWS * SBV_JBASE_DWORDS * 4);
+    apt* bases = (apt*)aligned_alloc(64, ng1 * SBV_GTAB_WINDOWS * SBV_KT29_POINTS_PER_WINDOW * sizeof(apt));
+    std::vector<u32> jstate(ng1 * SBV_KT29_STATE_WORDS);
     apt* ktab = (apt*)aligned_alloc(64, ng1 * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW * sizeof(apt));
+    memset(ktab, 0xA5, ng1 * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW * sizeof(apt));      // an entry nobody wrote must not look like a point
     std::vector<uint8_t> kvalid(ng1, 0);
-    u32* tmpa = (u32*)aligned_alloc(16, SBV_KEYTAB_TMP_DWORDS_PER_WINDOW * 4);
+    std::vector<u32> tmpa(SBV_KT29_BASES_TMP_WORDS + 7 * SBV_KT29_FILL_TMP_WORDS);
     memset(bitmap, 0, (n + 7) / 8);
     const int chunks = g_group_chunks;
+    const int rpl = g_group_parts == 2 ? 2 : (g_group_parts == 4 ? 4 : (g_group_parts == 16 ? 7 : 1));   // rows per lane of the fill kernel
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
-        for (u32 k = 0; k < ngroups; ++k) keytab_bases_lane(tuples, k, g, jbases, kvalid.data(), j_first, j_end - 1);
+        for (u32 k = 0; k < ngroups; ++k) keytab29_bases_lane(tuples, k, g, jstate.data(), bases, tmpa.data(), kvalid.data(), j_first, j_end - 1);
         for (u32 k = 0; k < ngroups; ++k)
-            for (int j = j_first; j < j_end; ++j)
-                for (int part = 0; part < g_group_parts; ++part) {
-                    const size_t w = (size_t)k * SBV_GTAB_WINDOWS + j;
-                    keytab_window_lane(jbases + w * SBV_JBASE_DWORDS, part, g_group_parts, tmpa, ktab + w * SBV_GTAB_PER_WINDOW);
-                }
+            for (int j = j_first; j < j_end; ++j) {
+                const size_t w = (size_t)k * SBV_GTAB_WINDOWS + j;
+                for (int which = 0; which < 2; ++which)
+                    keytab29_rows_lane(bases + w * SBV_KT29_POINTS_PER_WINDOW, which, j == SBV_GTAB_WINDOWS - 1, tmpa.data(), ktab + w * SBV_GTAB_PER_WINDOW);
+                if (j == SBV_GTAB_WINDOWS - 1) continue;
+                for (int a = 1; a <= 7; a += rpl) keytab29_fill_lane(a, a + rpl - 1 > 7 ? 7 : a + rpl - 1, tmpa.data(), ktab + w * SBV_GTAB_PER_WINDOW);
+            }
         const bool last = c + 1 == chunks;
         for (u32 L = 0; L < counters[1]; ++L) {
             const u32 t = grp_idx[L];
@@ -158,7 +164,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
         const u32 t = ung_idx[L];
         if (verify_lane(s, t, qtab, g16tab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
     }
-    free(qtab); free(tmpa); free(ktab); free(jbases);
+    free(qtab); free(ktab); free(bases);
     if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }
 }
 
@@ -341,6 +347,20 @@ void sbve_gtab_entry(int j, int k, u32* out16) { memcpy(out16, &gtab()[(size_t)j
 // ---- carry-free field (p256_fe29.h) and XYZZ point layer (p256_pt29.h): raw signed 29-bit limbs in / out ----------
 void sbve_f29_mul(const i32* a, const i32* b, i32* out) { fe29 x, y, z; memcpy(&x, a, 36); memcpy(&y, b, 36); f29_mul(z, x, y); memcpy(out, &z, 36); }
 void sbve_f29_sqr(const i32* a, i32* out) { fe29 x, z; memcpy(&x, a, 36); f29_sqr(z, x); memcpy(out, &z, 36); }
+// hot-path forms: 32-bit-multiplier reduction, fused a*b - c*d, fused a^2 - v
+void sbve_f29_mulx(const i32* a, const i32* b, i32* out) { fe29 x, y, z; memcpy(&x, a, 36); memcpy(&y, b, 36); f29_mulx(z, x, y); memcpy(out, &z, 36); }
+void sbve_f29_sqrx(const i32* a, i32* out) { fe29 x, z; memcpy(&x, a, 36); f29_sqrx(z, x); memcpy(out, &z, 36); }
+void sbve_f29_mul_sub_mul(const i32* a, const i32* b, const i32* c, const i32* d, i32* out) {
+    fe29 x, y, u, v, z; memcpy(&x, a, 36); memcpy(&y, b, 36); memcpy(&u, c, 36); memcpy(&v, d, 36);
+    fe29 nu; f29_neg(nu, u);
+    f29_cols t; f29_cols_zero(t); f29_cols_mul(t, x, y); f29_cols_mul(t, nu, v); f29_reduce_x(z, t); f29_red_q(z);
+    memcpy(out, &z, 36);
+}
+void sbve_f29_sqr_sub_val(const i32* a, const i32* v, i32* out) {
+    fe29 x, w, z; memcpy(&x, a, 36); memcpy(&w, v, 36);
+    f29_cols t; f29_cols_zero(t); f29_cols_sqr(t, x); f29_cols_sub_val(t, w); f29_reduce_x(z, t); f29_red_q(z);
+    memcpy(out, &z, 36);
+}
 void sbve_f29_canon(const i32* a, i32* out) { fe29 x, z; memcpy(&x, a, 36); f29_canon(z, x); memcpy(out, &z, 36); }
 void sbve_f29_norm(const i32* a, i32* out) { fe29 x, z; memcpy(&x, a, 36); f29_norm(z, x); memcpy(out, &z, 36); }
 void sbve_f29_norm_red(const i32* a, i32* out) { fe29 x, z; memcpy(&x, a, 36); f29_norm_red(z, x); memcpy(out, &z, 36); }

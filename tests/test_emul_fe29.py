@@ -83,6 +83,44 @@ def test_f29_mul_sqr_match_bigint_within_contract(emul):
             assert (v - A * A * RINV) % P == 0, a
 
 
+def test_f29_hot_path_forms_match_bigint(emul):
+    """f29_mulx / f29_sqrx (32-bit-multiplier reduction: value within +-(4.01 p + |AB|/R), exact 29-bit limbs) and the two
+    fused reductions of the mixed addition: a*b - c*d and a^2 - v, value-reduced by f29_red_q."""
+    rng = random.Random(34)
+    out = I32x9()
+    big = (1 << 29) + (1 << 26)
+
+    def operand(kind):
+        if kind == 0:
+            return tight(rng.randrange(5 * P))
+        if kind == 1:
+            return [-v for v in tight(rng.randrange(5 * P))]
+        if kind == 2:
+            return random_loose(rng, 1 << 29)
+        s_ = rng.choice((1, -1))
+        return [s_ * big] * 8 + [s_ * rng.randrange(1 << 26)]
+
+    for trial in range(400):
+        a, b, c, d = (operand(rng.randrange(4)) for _ in range(4))
+        A, B, C, D = val(a), val(b), val(c), val(d)
+        emul.sbve_f29_mulx(L(a), L(b), out)
+        v = val(out)
+        assert all(0 <= int(out[i]) < (1 << 29) for i in range(8))
+        assert (v * R - A * B) % P == 0 and abs(v * R - A * B) <= 4.01 * P * R
+        if all(abs(x) < (1 << 30) for x in a):
+            emul.sbve_f29_sqrx(L(a), out)
+            v = val(out)
+            assert (v * R - A * A) % P == 0 and abs(v * R - A * A) <= 4.01 * P * R
+            w = [x + y for x, y in zip(tight(rng.randrange(5 * P)), tight(rng.randrange(9 * P)))]       # PPP + 2 Q, loose
+            emul.sbve_f29_sqr_sub_val(L(a), L(w), out)
+            v = val(out)
+            assert (v * R - (A * A - val(w) * R)) % P == 0 and -(1 << 231) < v < (1 << 256) + (1 << 231)
+        emul.sbve_f29_mul_sub_mul(L(a), L(b), L(c), L(d), out)
+        v = val(out)
+        assert (v * R - (A * B - C * D)) % P == 0 and -(1 << 231) < v < (1 << 256) + (1 << 231)
+        assert all(-(1 << 27) < int(out[i]) < (1 << 29) + (1 << 27) for i in range(8))
+
+
 def test_f29_canon_norm_pack_roundtrip(emul):
     rng = random.Random(30)
     out = I32x9()
