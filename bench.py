@@ -135,6 +135,24 @@ def leg_end_to_end(sbv, tuples, valid, n, steps):
     return out
 
 
+def leg_sharded(sbv, tuples, valid, n, steps):
+    """The native multi-device entry sbv_p256_verify_batch_sharded (one process drives every GPU of the node; RCCL all-gather
+    of the bitmap shards when the batch is split).  On a one-GPU box it degenerates to one shard on one device; the N-GPU
+    scaling curve comes from the driver's `--gpus N` runs (one rank per GPU)."""
+    import numpy as np
+    ndev = sbv.init_all()
+    got = np.zeros((n + 7) // 8, dtype=np.uint8)
+    info = sbv.verify_batch_sharded(tuples.ctypes.data, n, got.ctypes.data)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        info = sbv.verify_batch_sharded(tuples.ctypes.data, n, got.ctypes.data)
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "verifies/s", "devices": ndev, "shards": info.shards,
+            "mode": {0: "one device", 1: "RCCL all-gather", 2: "per-device D2H"}.get(info.mode, info.mode),
+            "bitmap_correct": bool((got == valid).all()),
+            "last_call_us": {"h2d": info.h2d_us, "kernels": info.kernels_us, "gather": info.gather_us, "total": info.total_us}}
+
+
 def leg_ed25519(sbv, torch, n, steps, stream):
     """BASELINE.json configs[4]: 2^20 Ed25519 signatures, 1024 keys, 7/8 valid, R|S|A|k tuples resident in HBM."""
     import numpy as np
@@ -203,11 +221,20 @@ def leg_m2(tuples, n):
             f(valid15.ctypes.data, 15, bm, 15)
             ts.append(1e6 * (time.perf_counter() - t0))
         out[name] = sorted(ts)[len(ts) // 2]
+        ts1 = []
+        for _ in range(25):
+            t0 = time.perf_counter()
+            f(valid15.ctypes.data, 1, bm, 1)
+            ts1.append(1e6 * (time.perf_counter() - t0))
+        out[name.replace("cpu_15_threads", "cpu_one_verify")] = sorted(ts1)[len(ts1) // 2]
     cpu = out.get("cpu_15_threads_openssl") or out.get("cpu_15_threads_oracle_port")
     if cpu is not None and out.get("gpu") is not None:
         out["hybrid"] = min(cpu, out["gpu"])
         out["hybrid_note"] = ("a lone P-256 verification is a serial chain: quorum-sized batches are faster on host cores; the Go "
                               "adapter routes batches below gpuMin to crypto/ecdsa and proposals / replay to the GPU (INTEGRATION.md)")
+    out["cpu_note"] = ("cpu_15_threads_* spawn 15 pthreads per measurement (the checker libraries have no thread pool), so they "
+                       "carry ~0.3-0.5 ms of thread start-up; cpu_one_verify_* is one verification on one core = what 15 already "
+                       "running goroutines on 15 free cores would need")
     out["unit"] = "us"
     return out
 
@@ -345,6 +372,7 @@ def main():
     if world == 1 and not args.primary_only:
         for name, fn in (("all_valid", lambda: leg_all_valid(sbv, synth, torch, n, max(2, args.steps // 2), stream)),
                          ("end_to_end", lambda: leg_end_to_end(sbv, tuples, valid, n, max(2, args.steps // 2))),
+                         ("sharded_entry", lambda: leg_sharded(sbv, tuples, valid, n, max(2, args.steps // 2))),
                          ("ed25519", lambda: leg_ed25519(sbv, torch, n, max(2, args.steps // 2), stream)),
                          ("m2_commit_quorum_us", lambda: leg_m2(tuples, n))):
             try:

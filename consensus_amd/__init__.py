@@ -275,6 +275,45 @@ def host_free(ptr: int) -> None:
     lib.sbv_host_free(ptr)
 
 
+class ShardInfo(ctypes.Structure):
+    _fields_ = [("devices", ctypes.c_int), ("shards", ctypes.c_int), ("mode", ctypes.c_int), ("tuples_per_shard", ctypes.c_size_t),
+                ("h2d_us", ctypes.c_double), ("kernels_us", ctypes.c_double), ("gather_us", ctypes.c_double), ("total_us", ctypes.c_double)]
+
+
+def init_all() -> int:
+    """Initialise every visible gfx950 device (sbv_init_all); returns how many."""
+    n = load().sbv_init_all()
+    if n < 0:
+        _check(n)
+    return n
+
+
+def shard_plan(n: int, devices: int, group: int = 0, min_per_device: int = 0):
+    """The pure split of sbv_p256_verify_batch_sharded: list of shard start indices + [n]."""
+    lib = load()
+    lib.sbv_shard_plan.restype = ctypes.c_size_t
+    lib.sbv_shard_plan.argtypes = [ctypes.c_size_t, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    first = (ctypes.c_size_t * 17)()
+    k = lib.sbv_shard_plan(n, devices, group, min_per_device, first)
+    return [first[i] for i in range(k + 1)]
+
+
+def verify_batch_sharded(host_ptr: int, n: int, out_ptr: int, group: int = 0, quorum: int = 0, quorum_out_ptr: int = 0) -> ShardInfo:
+    """sbv_p256_verify_batch_sharded on raw pointers (numpy / ctypes buffers)."""
+    lib = load()
+    lib.sbv_p256_verify_batch_sharded.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.POINTER(ShardInfo)]
+    info = ShardInfo()
+    _check(lib.sbv_p256_verify_batch_sharded(host_ptr, n, group, quorum, out_ptr, quorum_out_ptr or None, ctypes.byref(info)))
+    return info
+
+
+def verify_batch_on(device: int, host_ptr: int, n: int, out_ptr: int) -> None:
+    lib = load()
+    lib.sbv_p256_verify_batch_on.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    _check(lib.sbv_p256_verify_batch_on(device, host_ptr, n, out_ptr))
+
+
 def last_timing() -> Timing:
     t = Timing()
     _check(load().sbv_last_timing(ctypes.byref(t)))

@@ -10,9 +10,14 @@
 // not for a cache.  There is no CPU verification path in this library.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -27,7 +32,17 @@ namespace {
 
 using sbv::u32;
 
+// staging of the pipelined host-pointer entry (sbv_p256_verify_batch): two of them, so that one call's upload overlaps
+// another's kernels
+struct StageSlot {
+    uint8_t* d_tuples = nullptr; uint8_t* d_bitmap = nullptr; uint8_t* h_bitmap = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // H2D start / end, stage A end, stage B end, D2H end
+    bool used = false;
+};
+
 struct Context {
+    std::mutex mu;                      // held for the whole of every call that touches this device's buffers
     bool ready = false;
     int device = -1;
     size_t cap = 0;
@@ -40,6 +55,9 @@ struct Context {
     uint8_t* d_rerun = nullptr;         // per-wavefront flags between the fast and the exact stage-B pass
     uint8_t* h_bitmap = nullptr;        // pinned
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // H2D of the pipelined host-pointer entry
+    StageSlot stage[2];
+    std::condition_variable slot_cv;
     sbv::GroupSync gsync;               // side streams + events of the grouped stage B
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t busy = nullptr;          // completion of the last launch that used the scratch
@@ -69,8 +87,25 @@ struct Context {
     size_t prof_used = 0;
 };
 
-Context g_ctx;
-std::mutex g_mu;
+// One Context per device.  A replica process of the reference injects ONE Verifier (pkg/consensus/consensus.go:35, 107) and
+// that process drives every GPU of the node: sbv_init(d) creates device d's context (the first one becomes the default that
+// the single-device entry points use), sbv_init_all() creates one per visible gfx950 device, and the sharded / _on entries
+// address them.  Contexts are never freed (a thread may still hold a pointer while another shuts down): sbv_shutdown tears
+// the device resources down and marks them not ready.
+constexpr int kMaxDevices = 16;
+std::unique_ptr<Context> g_ctxs[kMaxDevices];
+Context g_null;                      // stand-in before sbv_init: ready == false
+Context* g_def = nullptr;
+std::mutex g_mu;                     // the registry above, init / shutdown, and the RCCL communicators
+Context* default_ctx() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_def ? g_def : &g_null;
+}
+// every single-device entry point: lock the default context for the duration of the call
+#define SBV_ENTER(c)                                  \
+    Context* cp_ = default_ctx();                     \
+    std::lock_guard<std::mutex> lk(cp_->mu);          \
+    Context& c = *cp_
 // Error text of the calling thread's last failing call: thread_local, so sbv_last_error() never races with another
 // thread's failure (the host Verifier calls it from many threads at once exactly when the device is faulting).
 thread_local std::string g_err;
@@ -293,10 +328,20 @@ extern "C" int sbv_device_count(void) {
     return n;
 }
 
-extern "C" int sbv_init(int device) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
-    if (c.ready) return c.device == device ? SBV_OK : SBV_EINVAL;
+namespace {
+// The G combs are the same for every device: built once per process on the host, uploaded to each device.
+std::vector<sbv::apt> g_h_gtab, g_h_g16r;
+std::once_flag g_tables_once;
+void build_host_tables() {
+    g_h_gtab.resize(SBV_G16_ENTRIES);
+    sbv::host_build_g16(g_h_gtab.data());                 // 16-bit comb, 35.7 MB, 17 host threads
+    g_h_g16r.resize(SBV_G16_ENTRIES);
+    sbv::host_convert_table_r261(g_h_gtab.data(), g_h_g16r.data(), SBV_G16_ENTRIES);
+}
+
+// c.mu held by the caller
+int init_context(Context& c, int device) {
+    if (c.ready) return SBV_OK;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -312,6 +357,7 @@ extern "C" int sbv_init(int device) {
         return SBV_ENODEV;
     }
     HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
     for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b})
         HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
     for (hipEvent_t* ev : group_events(c)) HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(ev, hipEventDisableTiming));
@@ -330,16 +376,11 @@ extern "C" int sbv_init(int device) {
     // fixed-base table: computed once on the host with the same field code, then resident in HBM
     // (16-bit comb, 35.7 MB: u1*G is 17 mixed additions; built by 17 host threads in ~0.1 s)
     const size_t gcount = SBV_G16_ENTRIES;
-    std::vector<sbv::apt> h_gtab(gcount);
-    sbv::host_build_g16(h_gtab.data());
+    std::call_once(g_tables_once, build_host_tables);
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_gtab, gcount * sizeof(sbv::apt)));
-    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_gtab, h_gtab.data(), gcount * sizeof(sbv::apt), hipMemcpyHostToDevice));
-    {
-        std::vector<sbv::apt> h_g16r(gcount);
-        sbv::host_convert_table_r261(h_gtab.data(), h_g16r.data(), gcount);
-        HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_g16r, gcount * sizeof(sbv::apt)));
-        HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_g16r, h_g16r.data(), gcount * sizeof(sbv::apt), hipMemcpyHostToDevice));
-    }
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_gtab, g_h_gtab.data(), gcount * sizeof(sbv::apt), hipMemcpyHostToDevice));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_g16r, gcount * sizeof(sbv::apt)));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_g16r, g_h_g16r.data(), gcount * sizeof(sbv::apt), hipMemcpyHostToDevice));
     if (const char* e = getenv("SBV_GROUP")) c.group_enabled = e[0] != '0';
     c.device = device;
     c.ready = true;
@@ -347,14 +388,50 @@ extern "C" int sbv_init(int device) {
     return SBV_OK;
 }
 
-extern "C" int sbv_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+Context* context_of(int device, bool create) {          // g_mu held by the caller
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    if (!g_ctxs[device] && create) g_ctxs[device].reset(new Context());
+    return g_ctxs[device].get();
+}
+}  // namespace
+
+extern "C" int sbv_init(int device) {
+    Context* c;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        c = context_of(device, true);
+        if (!c) { g_err = "device index out of range"; return SBV_EINVAL; }
+    }
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        rc = init_context(*c, device);
+    }
+    if (rc == SBV_OK) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_def) g_def = c;                          // the first initialised device is the default of the single-device entries
+    }
+    return rc;
+}
+
+namespace {
+void rccl_teardown();
+// c.mu held by the caller
+struct ShardBuffers { uint8_t* d_gather = nullptr; size_t gather_cap = 0; uint8_t* d_q = nullptr; size_t q_cap = 0; };
+ShardBuffers g_shard[kMaxDevices];      // per-device gather slot buffers of the sharded entry
+
+int shutdown_context(Context& c) {
     if (!c.ready) return SBV_OK;
     (void)hipSetDevice(c.device);
     (void)hipDeviceSynchronize();
     free_buffers(c);
     free_group_buffers(c);
+    if (c.device >= 0 && c.device < kMaxDevices) {
+        ShardBuffers& sb = g_shard[c.device];
+        if (sb.d_gather) (void)hipFree(sb.d_gather);
+        if (sb.d_q) (void)hipFree(sb.d_q);
+        sb = ShardBuffers();
+    }
     if (c.d_gtab) (void)hipFree(c.d_gtab);
     c.d_gtab = nullptr;
     if (c.d_g16r) (void)hipFree(c.d_g16r);
@@ -379,6 +456,14 @@ extern "C" int sbv_shutdown(void) {
     c.prof_used = 0;
     if (c.busy) { (void)hipEventDestroy(c.busy); c.busy = nullptr; }
     if (c.stream) { (void)hipStreamDestroy(c.stream); c.stream = nullptr; }
+    if (c.copy_stream) { (void)hipStreamDestroy(c.copy_stream); c.copy_stream = nullptr; }
+    for (StageSlot& sl : c.stage) {
+        if (sl.d_tuples) (void)hipFree(sl.d_tuples);
+        if (sl.d_bitmap) (void)hipFree(sl.d_bitmap);
+        if (sl.h_bitmap) (void)hipHostFree(sl.h_bitmap);
+        for (auto& ev : sl.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+        sl = StageSlot();
+    }
     for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b, &c.gsync.side_c}) if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
     for (hipEvent_t* ev : group_events(c)) if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
     c.busy_valid = false;
@@ -386,10 +471,22 @@ extern "C" int sbv_shutdown(void) {
     c.device = -1;
     return SBV_OK;
 }
+}  // namespace
+
+extern "C" int sbv_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    rccl_teardown();
+    for (auto& up : g_ctxs) {
+        if (!up) continue;
+        std::lock_guard<std::mutex> lkc(up->mu);
+        (void)shutdown_context(*up);
+    }
+    g_def = nullptr;
+    return SBV_OK;
+}
 
 extern "C" int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, void* hip_stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
     if (n == 0) return SBV_OK;
     if (!d_tuples || !d_bitmap || (reinterpret_cast<uintptr_t>(d_tuples) & 15)) {
@@ -446,46 +543,143 @@ extern "C" int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d
     return SBV_OK;
 }
 
+// The host-pointer entry a cgo caller uses, pipelined: two staging slots (device tuples + bitmap + page-locked bitmap) and a
+// copy stream.  A call enqueues H2D (copy stream) -> stage A + B (c.stream, after the copy's event) -> D2H, records the
+// slot's completion event and RELEASES the context lock before it waits — so the next caller (another goroutine's cgo
+// thread, or this call's next chunk) uploads its tuples while these kernels run.  Kernels of all calls are ordered on
+// c.stream, so the single-flight scratch and group buffers need no further care.
+namespace {
+struct Outstanding { int slot; size_t off, m; };
+
+int collect_slot(Context& c, const Outstanding& o, uint8_t* accept_bitmap, sbv_timing& tm) {
+    StageSlot& sl = c.stage[o.slot];
+    const hipError_t e = hipEventSynchronize(sl.ev[4]);
+    int rc = SBV_OK;
+    if (e == hipSuccess) {
+        memcpy(accept_bitmap + o.off / 8, sl.h_bitmap, (o.m + 7) / 8);
+        tm.h2d_us += 1e3 * ms_between(sl.ev[0], sl.ev[1]);
+        tm.prep_us += 1e3 * ms_between(sl.ev[1], sl.ev[2]);
+        tm.verify_us += 1e3 * ms_between(sl.ev[2], sl.ev[3]);
+        tm.d2h_us += 1e3 * ms_between(sl.ev[3], sl.ev[4]);
+    } else {
+        rc = fail(SBV_EDEVICE, "hipEventSynchronize(slot)", e);
+    }
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        sl.used = false;
+    }
+    c.slot_cv.notify_all();
+    return rc;
+}
+
+int grow_slot(Context& c, StageSlot& sl, size_t m) {
+    if (!sl.ev[0]) for (auto& ev : sl.ev) HIP_TRY(SBV_EDEVICE, hipEventCreate(&ev));
+    const size_t want = (m + 1023) & ~(size_t)1023;
+    if (want <= sl.cap) return SBV_OK;
+    if (sl.d_tuples) (void)hipFree(sl.d_tuples);
+    if (sl.d_bitmap) (void)hipFree(sl.d_bitmap);
+    if (sl.h_bitmap) (void)hipHostFree(sl.h_bitmap);
+    sl.d_tuples = sl.d_bitmap = sl.h_bitmap = nullptr; sl.cap = 0;
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&sl.d_tuples, want * SBV_TUPLE_BYTES));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&sl.d_bitmap, want / 8));
+    HIP_TRY(SBV_ENOMEM, hipHostMalloc(&sl.h_bitmap, want / 8, hipHostMallocDefault));
+    sl.cap = want;
+    (void)c;
+    return SBV_OK;
+}
+}  // namespace
+
 extern "C" int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
-    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
-    if (n == 0) return SBV_OK;
+    Context* cp = default_ctx();
+    Context& c = *cp;
+    if (n == 0) { std::lock_guard<std::mutex> lk(c.mu); if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; } return SBV_OK; }
     if (!tuples || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
     const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
-    int rc = ensure_capacity(c, n < kMaxChunk ? n : kMaxChunk);
-    if (rc != SBV_OK) return rc;
-    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(c.stream, c.busy, 0));
     sbv_timing tm{};
     tm.n = n;
-    for (size_t off = 0; off < n; off += kMaxChunk) {
+    std::vector<Outstanding> out;           // at most two
+    int rc = SBV_OK;
+    for (size_t off = 0; off < n && rc == SBV_OK; off += kMaxChunk) {
         const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
-        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[0], c.stream));
-        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_tuples, tuples + off * SBV_TUPLE_BYTES, m * SBV_TUPLE_BYTES,
-                                            hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
-        rc = enqueue(c, c.d_tuples, m, c.d_bitmap, c.stream, c.ev[2]);
-        if (rc != SBV_OK) return rc;
-        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
-        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.h_bitmap, c.d_bitmap, (m + 7) / 8, hipMemcpyDeviceToHost, c.stream));
-        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[4], c.stream));
-        HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(c.stream));
-        memcpy(accept_bitmap + off / 8, c.h_bitmap, (m + 7) / 8);
-        tm.h2d_us += 1e3 * ms_between(c.ev[0], c.ev[1]);
-        tm.prep_us += 1e3 * ms_between(c.ev[1], c.ev[2]);
-        tm.verify_us += 1e3 * ms_between(c.ev[2], c.ev[3]);
-        tm.d2h_us += 1e3 * ms_between(c.ev[3], c.ev[4]);
+        std::unique_lock<std::mutex> lk(c.mu);
+        if (!c.ready) { g_err = "sbv_init has not succeeded"; rc = SBV_ENOTINIT; break; }
+        // a slot: never wait for one while holding one (two multi-chunk callers would deadlock) — collect first
+        while (c.stage[0].used && c.stage[1].used) {
+            if (!out.empty()) {
+                const Outstanding o = out.front();
+                out.erase(out.begin());
+                lk.unlock();
+                rc = collect_slot(c, o, accept_bitmap, tm);
+                lk.lock();
+                if (rc != SBV_OK) break;
+            } else {
+                c.slot_cv.wait(lk);
+            }
+        }
+        if (rc != SBV_OK) break;
+        if (hipSetDevice(c.device) != hipSuccess) { g_err = "hipSetDevice failed"; rc = SBV_EDEVICE; break; }
+        if (((m + 1023) & ~(size_t)1023) > c.cap) {           // growing the scratch frees buffers in-flight work may use: drain first
+            while (c.stage[0].used || c.stage[1].used) {
+                if (!out.empty()) {
+                    const Outstanding o = out.front();
+                    out.erase(out.begin());
+                    lk.unlock();
+                    rc = collect_slot(c, o, accept_bitmap, tm);
+                    lk.lock();
+                    if (rc != SBV_OK) break;
+                } else {
+                    c.slot_cv.wait(lk);
+                }
+            }
+            if (rc != SBV_OK) break;
+            if ((rc = ensure_capacity(c, m)) != SBV_OK) break;
+        }
+        const int s = c.stage[0].used ? 1 : 0;
+        StageSlot& sl = c.stage[s];
+        if ((rc = grow_slot(c, sl, m)) != SBV_OK) break;
+        sl.used = true;
+        hipError_t e = hipSuccess;
+        auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+        step(hipEventRecord(sl.ev[0], c.copy_stream));
+        step(hipMemcpyAsync(sl.d_tuples, tuples + off * SBV_TUPLE_BYTES, m * SBV_TUPLE_BYTES, hipMemcpyHostToDevice, c.copy_stream));
+        step(hipEventRecord(sl.ev[1], c.copy_stream));
+        step(hipStreamWaitEvent(c.stream, sl.ev[1], 0));
+        if (c.busy_valid) step(hipStreamWaitEvent(c.stream, c.busy, 0));
+        if (e == hipSuccess) rc = enqueue(c, sl.d_tuples, m, sl.d_bitmap, c.stream, sl.ev[2]);
+        step(hipEventRecord(sl.ev[3], c.stream));
+        step(hipMemcpyAsync(sl.h_bitmap, sl.d_bitmap, (m + 7) / 8, hipMemcpyDeviceToHost, c.stream));
+        step(hipEventRecord(sl.ev[4], c.stream));
+        if (hipEventRecord(c.busy, c.stream) == hipSuccess) c.busy_valid = true;
+        if (e != hipSuccess && rc == SBV_OK) rc = fail(SBV_EDEVICE, "enqueue of a staged chunk", e);
+        if (rc != SBV_OK) {                  // whatever was enqueued must drain before the slot is reused
+            (void)hipStreamSynchronize(c.copy_stream);
+            (void)hipStreamSynchronize(c.stream);
+            sl.used = false;
+            lk.unlock();
+            c.slot_cv.notify_all();
+            break;
+        }
+        lk.unlock();
+        out.push_back({s, off, m});
+        if (out.size() == 2) {
+            const Outstanding o = out.front();
+            out.erase(out.begin());
+            rc = collect_slot(c, o, accept_bitmap, tm);
+        }
     }
-    c.busy_valid = false;   // stream is idle
+    for (const Outstanding& o : out) {       // also on error: the slots must come back
+        const int r2 = collect_slot(c, o, accept_bitmap, tm);
+        if (rc == SBV_OK) rc = r2;
+    }
+    if (rc != SBV_OK) return rc;
     tm.total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    std::lock_guard<std::mutex> lk(c.mu);
     c.timing = tm;
     return SBV_OK;
 }
 
 extern "C" int sbv_p256_register_keys(const uint8_t* keys, size_t m, uint32_t* slots_out) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
     if (m == 0) return SBV_OK;
     if (!keys || !slots_out) { g_err = "null pointer"; return SBV_EINVAL; }
@@ -534,13 +728,12 @@ extern "C" int sbv_p256_register_keys(const uint8_t* keys, size_t m, uint32_t* s
 }
 
 extern "C" int sbv_p256_key_count(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    return g_ctx.ready ? (int)g_ctx.nkeys : SBV_ENOTINIT;
+    SBV_ENTER(c);
+    return c.ready ? (int)c.nkeys : SBV_ENOTINIT;
 }
 
 extern "C" int sbv_p256_clear_keys(void) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready) return SBV_ENOTINIT;
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
@@ -550,8 +743,7 @@ extern "C" int sbv_p256_clear_keys(void) {
 }
 
 extern "C" int sbv_p256_verify_batch_keyed_dev(const void* d_rsh, const void* d_slots, size_t n, void* d_bitmap, void* hip_stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
     if (n == 0) return SBV_OK;
     if (!d_rsh || !d_slots || !d_bitmap || (reinterpret_cast<uintptr_t>(d_rsh) & 15)) { g_err = "null or misaligned device pointer"; return SBV_EINVAL; }
@@ -588,8 +780,7 @@ extern "C" int sbv_p256_verify_batch_keyed_dev(const void* d_rsh, const void* d_
 }
 
 extern "C" int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* accept_bitmap) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
     if (n == 0) return SBV_OK;
     if (!rsh || !slots || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
@@ -637,8 +828,7 @@ int ensure_ed_table(Context& c) {
 }  // namespace
 
 extern "C" int sbv_ed25519_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, void* hip_stream) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
     if (n == 0) return SBV_OK;
     if (!d_tuples || !d_bitmap || (reinterpret_cast<uintptr_t>(d_tuples) & 15)) { g_err = "null or misaligned device pointer"; return SBV_EINVAL; }
@@ -673,8 +863,7 @@ extern "C" int sbv_ed25519_verify_batch_dev(const void* d_tuples, size_t n, void
 }
 
 extern "C" int sbv_ed25519_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
     if (n == 0) return SBV_OK;
     if (!tuples || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
@@ -724,8 +913,7 @@ int grow(T*& ptr, size_t& cap, size_t want_elems) {
 
 extern "C" int sbv_p256_verify_msgs_keyed(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* sigs,
                                           const uint64_t* sig_offsets, const uint32_t* slots, size_t n, uint8_t* accept_bitmap) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
     if (n == 0) return SBV_OK;
     if (!msg_offsets || !sig_offsets || !slots || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
@@ -775,8 +963,7 @@ extern "C" int sbv_p256_verify_msgs_keyed(const uint8_t* msgs, const uint64_t* m
 
 extern "C" int sbv_ed25519_verify_msgs(const uint8_t* sigs, const uint8_t* pks, const uint8_t* msgs, const uint64_t* msg_offsets,
                                        size_t n, uint8_t* accept_bitmap) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
     if (n == 0) return SBV_OK;
     if (!sigs || !pks || !msg_offsets || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
@@ -824,8 +1011,7 @@ extern "C" int sbv_ed25519_verify_msgs(const uint8_t* sigs, const uint8_t* pks, 
 }
 
 extern "C" void* sbv_host_alloc(size_t bytes) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready || bytes == 0) return nullptr;
     if (hipSetDevice(c.device) != hipSuccess) return nullptr;
     void* p = nullptr;
@@ -841,8 +1027,7 @@ extern "C" void sbv_host_free(void* p) {
 }
 
 extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uint32_t max_groups) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     c.group_enabled = enabled != 0;
     if (min_batch) c.group_min_batch = min_batch;
     if (min_count) c.group_min_count = min_count;
@@ -851,14 +1036,13 @@ extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min
 }
 
 extern "C" int sbv_profile_enable(int on) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_ctx.profiling = on != 0;
+    SBV_ENTER(c);
+    c.profiling = on != 0;
     return SBV_OK;
 }
 
 extern "C" int sbv_profile_read_dominant(double* dominant_us, uint64_t* dominant_launches) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready) return SBV_ENOTINIT;
     double d = 0;
     for (size_t i = 0; i + 2 <= c.prof_dom_used; i += 2) {
@@ -872,8 +1056,7 @@ extern "C" int sbv_profile_read_dominant(double* dominant_us, uint64_t* dominant
 }
 
 extern "C" int sbv_p256_last_group_stats(uint32_t out[4]) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready) return SBV_ENOTINIT;
     if (!out) return SBV_EINVAL;
     out[0] = out[1] = out[2] = out[3] = 0;
@@ -890,8 +1073,7 @@ extern "C" int sbv_p256_last_group_stats(uint32_t out[4]) {
 }
 
 extern "C" int sbv_profile_read(double* prep_us, double* verify_us, uint64_t* launches) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Context& c = g_ctx;
+    SBV_ENTER(c);
     if (!c.ready) return SBV_ENOTINIT;
     double p = 0, v = 0;
     for (size_t i = 0; i + 3 <= c.prof_used; i += 3) {
@@ -907,9 +1089,326 @@ extern "C" int sbv_profile_read(double* prep_us, double* verify_us, uint64_t* la
 }
 
 extern "C" int sbv_last_timing(sbv_timing* out) {
-    std::lock_guard<std::mutex> lk(g_mu);
     if (!out) return SBV_EINVAL;
-    *out = g_ctx.timing;
+    SBV_ENTER(c);
+    *out = c.timing;
+    return SBV_OK;
+}
+
+// =====================================================================================================================
+// All GPUs of the node behind one process (BASELINE.json north_star: "sharded across the 8 GPUs of one node
+// with an RCCL all-gather of the per-lane accept/reject bitmap over xGMI only when a batch outgrows one GPU").
+//
+//   * tuples are independent: a batch is split into contiguous shards, one per device, each a multiple of the granule
+//     lcm(512, 8 * group) tuples — whole bitmap bytes per device and, for consenter-signature batches (group = signatures
+//     per proposal, e.g. 11 at N = 16), whole proposals, so the device can also emit the per-proposal quorum bit;
+//   * every device gets its shard over its own PCIe link from its own host thread, verifies it with the same grouped step
+//     as the single-device entry and leaves its bitmap shard in its slot of a device-resident gather buffer;
+//   * when more than one device took part, ONE in-place ncclAllGather (uint8, shard bytes per rank) over the per-device
+//     streams leaves the full bitmap on every device and a single D2H returns it; RCCL is resolved with dlopen the first
+//     time it is needed, so single-GPU deployments never load it;
+//   * a batch below min_per_device * 2 tuples is not split: it goes whole to one device, round-robin ("replicas", no
+//     collective at all).
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::vector<void*> comms;          // one communicator per initialised device, in g_devs order
+    bool ready = false;
+} g_rccl;
+std::vector<int> g_devs;               // devices initialised by sbv_init_all, ascending
+std::atomic<unsigned> g_rr{0};         // round-robin cursor of the replica route
+size_t g_shard_min = (size_t)1 << 18;  // tuples per device below which a batch is not split
+
+void rccl_teardown() {                 // g_mu held
+    if (g_rccl.ready) for (void* cm : g_rccl.comms) if (cm) (void)g_rccl.CommDestroy(cm);
+    g_rccl.comms.clear();
+    g_rccl.ready = false;
+    g_devs.clear();
+}
+
+// g_mu held.  Failure is not fatal: the sharded entry then gathers the shards through the host.
+bool rccl_setup() {
+    if (g_rccl.ready) return true;
+    if (!g_rccl.handle) {
+        g_rccl.handle = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!g_rccl.handle) g_rccl.handle = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!g_rccl.handle) return false;
+        g_rccl.CommInitAll = reinterpret_cast<int (*)(void**, int, const int*)>(dlsym(g_rccl.handle, "ncclCommInitAll"));
+        g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(g_rccl.handle, "ncclCommDestroy"));
+        g_rccl.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(g_rccl.handle, "ncclAllGather"));
+        g_rccl.GroupStart = reinterpret_cast<int (*)()>(dlsym(g_rccl.handle, "ncclGroupStart"));
+        g_rccl.GroupEnd = reinterpret_cast<int (*)()>(dlsym(g_rccl.handle, "ncclGroupEnd"));
+        g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(g_rccl.handle, "ncclGetErrorString"));
+    }
+    if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GroupStart || !g_rccl.GroupEnd) return false;
+    g_rccl.comms.assign(g_devs.size(), nullptr);
+    if (g_rccl.CommInitAll(g_rccl.comms.data(), (int)g_devs.size(), g_devs.data()) != 0) { g_rccl.comms.clear(); return false; }
+    g_rccl.ready = true;
+    return true;
+}
+
+size_t gcd_sz(size_t a, size_t b) { while (b) { const size_t t = a % b; a = b; b = t; } return a; }
+size_t shard_granule(size_t group) {
+    const size_t g8 = 8 * (group ? group : 1);
+    return 512 / gcd_sz(512, g8) * g8;            // lcm(512, 8 * group)
+}
+
+// per proposal: at least `quorum` accepted signatures by DISTINCT public keys (>= Q distinct signers:
+// internal/bft/viewchanger.go:681-727; Q from internal/bft/util.go:183-187).  One lane per proposal; bits LSB-first.
+__global__ __launch_bounds__(256) void k_quorum_bits(const uint8_t* __restrict__ tuples, const uint8_t* __restrict__ bitmap,
+                                                     size_t nprops, u32 group, u32 quorum, uint8_t* __restrict__ qbitmap) {
+    const size_t pidx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    bool decided = false;
+    if (pidx < nprops) {
+        const size_t first = pidx * group;
+        u32 count = 0;
+        for (u32 i = 0; i < group; ++i) {
+            const size_t t = first + i;
+            if (!((bitmap[t >> 3] >> (t & 7)) & 1u)) continue;
+            const uint4* ki = reinterpret_cast<const uint4*>(tuples + t * SBV_TUPLE_BYTES + 96);
+            bool dup = false;
+            for (u32 j = 0; j < i && !dup; ++j) {
+                const size_t u = first + j;
+                if (!((bitmap[u >> 3] >> (u & 7)) & 1u)) continue;
+                const uint4* kj = reinterpret_cast<const uint4*>(tuples + u * SBV_TUPLE_BYTES + 96);
+                bool same = true;
+                for (int w = 0; w < 4; ++w) {
+                    const uint4 a = ki[w], b = kj[w];
+                    same = same && a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w;
+                }
+                dup = same;
+            }
+            if (!dup) ++count;
+        }
+        decided = count >= quorum;
+    }
+    const unsigned long long m = __ballot(decided);
+    const int lane = threadIdx.x & 63;
+    const size_t wave_first = pidx - (size_t)lane;
+    if (lane < 8) {
+        const size_t byte = (wave_first >> 3) + (size_t)lane;
+        if (byte < ((nprops + 7) >> 3)) qbitmap[byte] = (uint8_t)(m >> (8 * lane));
+    }
+}
+
+// One device's share of a sharded call; c.mu held.  Chunks of at most kMaxChunk tuples (a multiple of the granule):
+// H2D into the staging buffer, stage A + B with the bitmap written straight into this device's slot of the gather buffer,
+// the quorum bits of the chunk, then the stream is drained before the staging buffer is reused.
+int verify_shard(Context& c, const uint8_t* h_tuples, size_t m, size_t group, u32 quorum, uint8_t* d_slot, uint8_t* d_qslot,
+                 double* h2d_us, double* kern_us) {
+    if (!c.ready) { g_err = "device not initialised"; return SBV_ENOTINIT; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    const size_t gran = shard_granule(group);
+    size_t chunk = kMaxChunk / gran * gran;
+    if (chunk == 0) { g_err = "group too large"; return SBV_EINVAL; }
+    int rc = ensure_capacity(c, m < chunk ? m : chunk);
+    if (rc != SBV_OK) return rc;
+    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(c.stream, c.busy, 0));
+    for (size_t off = 0; off < m; off += chunk) {
+        const size_t k = m - off < chunk ? m - off : chunk;
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[0], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_tuples, h_tuples + off * SBV_TUPLE_BYTES, k * SBV_TUPLE_BYTES, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
+        rc = enqueue(c, c.d_tuples, k, d_slot + off / 8, c.stream, nullptr);
+        if (rc != SBV_OK) return rc;
+        if (d_qslot && group > 0 && quorum > 0) {
+            const size_t props = k / group;                 // k is a multiple of group except for a ragged tail, which gets no bit
+            if (props)
+                hipLaunchKernelGGL(k_quorum_bits, dim3((unsigned)((props + 255) / 256)), dim3(256), 0, c.stream, c.d_tuples, d_slot + off / 8,
+                                   props, (u32)group, quorum, d_qslot + (off / group) / 8);
+        }
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(c.stream));
+        if (h2d_us) *h2d_us += 1e3 * ms_between(c.ev[0], c.ev[1]);
+        if (kern_us) *kern_us += 1e3 * ms_between(c.ev[1], c.ev[3]);
+    }
+    c.busy_valid = false;
+    return SBV_OK;
+}
+
+int grow_bytes(uint8_t*& ptr, size_t& cap, size_t want) {
+    if (want <= cap) return SBV_OK;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr; cap = 0;
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&ptr, want));
+    cap = want;
+    return SBV_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sbv_shard_plan(size_t n, int devices, size_t group, size_t min_per_device, size_t* first) {
+    // first[0..shards] = tuple index where each shard starts (first[shards] = n); returns the number of shards (>= 1)
+    if (devices < 1) devices = 1;
+    if (devices > kMaxDevices) devices = kMaxDevices;
+    if (min_per_device == 0) min_per_device = g_shard_min;
+    const size_t gran = shard_granule(group);
+    size_t shards = 1;
+    if (devices > 1 && n >= 2 * min_per_device) {
+        shards = n / min_per_device;
+        if (shards > (size_t)devices) shards = (size_t)devices;
+    }
+    size_t per = ((n + shards - 1) / shards + gran - 1) / gran * gran;
+    if (per == 0) per = gran;
+    shards = (n + per - 1) / per;
+    if (shards == 0) shards = 1;
+    if (first) {
+        for (size_t k = 0; k <= shards; ++k) { const size_t f = k * per; first[k] = f < n ? f : n; }
+    }
+    return shards;
+}
+
+extern "C" int sbv_init_all(void) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_err = "no HIP device visible (libsbv has no CPU fallback)";
+        return SBV_ENODEV;
+    }
+    if (ndev > kMaxDevices) ndev = kMaxDevices;
+    std::vector<int> devs;
+    for (int d = 0; d < ndev; ++d) {
+        const int rc = sbv_init(d);
+        if (rc == SBV_OK) devs.push_back(d);
+        else if (devs.empty() && d == ndev - 1) return rc;       // not a single usable device
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_devs != devs) {
+        rccl_teardown();
+        g_devs = devs;
+    }
+    if (const char* e = getenv("SBV_SHARD_MIN")) { const long v = atol(e); if (v > 0) g_shard_min = (size_t)v; }
+    const char* force = getenv("SBV_RCCL");
+    if (g_devs.size() > 1 || (force && force[0] == '1')) (void)rccl_setup();     // failure -> host-side gather
+    return (int)g_devs.size();
+}
+
+extern "C" int sbv_initialised_devices(int* out, int max) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int k = 0;
+    for (int d = 0; d < kMaxDevices; ++d) {
+        if (!g_ctxs[d] || !g_ctxs[d]->ready) continue;
+        if (out && k < max) out[k] = d;
+        ++k;
+    }
+    return k;
+}
+
+extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, size_t group, uint32_t quorum, uint8_t* accept_bitmap,
+                                             uint8_t* quorum_bitmap, sbv_shard_info* info) {
+    if (info) memset(info, 0, sizeof *info);
+    if (n == 0) return SBV_OK;
+    if (!tuples || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
+    if (quorum_bitmap && (group == 0 || quorum == 0 || quorum > group || group > 64)) { g_err = "quorum bits need 0 < quorum <= group <= 64"; return SBV_EINVAL; }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<int> devs;
+    bool use_rccl;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        devs = g_devs;
+        if (devs.empty() && g_def) devs.push_back(g_def->device);     // sbv_init only: one device
+        use_rccl = g_rccl.ready;
+    }
+    if (devs.empty()) { g_err = "sbv_init_all / sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    size_t first[kMaxDevices + 1];
+    const size_t shards = sbv_shard_plan(n, (int)devs.size(), group, 0, first);
+    const size_t per = shards > 1 ? first[1] - first[0] : ((n + shard_granule(group) - 1) / shard_granule(group) * shard_granule(group));
+    const size_t sb = per / 8;                                          // bitmap bytes per shard slot
+    const size_t qb = group ? (per / group + 7) / 8 : 0;                // quorum bytes per shard slot
+    // which device takes which shard: all of them in order, or one picked round-robin for an unsplit batch
+    std::vector<int> use(shards);
+    if (shards == 1) use[0] = devs[g_rr.fetch_add(1) % devs.size()];
+    else for (size_t k = 0; k < shards; ++k) use[k] = devs[k];
+    const bool gather = shards > 1 && use_rccl && shards == devs.size();
+    const bool forced_single = shards == 1 && use_rccl && devs.size() == 1;   // SBV_RCCL=1 on a one-GPU box: exercise the collective with one rank
+    std::vector<int> rcs(shards, SBV_OK);
+    std::vector<std::string> errs(shards);
+    std::vector<double> h2d(shards, 0.0), kern(shards, 0.0);
+    auto work = [&](size_t k) {
+        Context* c;
+        { std::lock_guard<std::mutex> lk(g_mu); c = g_ctxs[use[k]].get(); }
+        std::lock_guard<std::mutex> lkc(c->mu);
+        ShardBuffers& sbuf = g_shard[use[k]];
+        int rc = SBV_OK;
+        if (hipSetDevice(c->device) != hipSuccess) rc = SBV_EDEVICE;
+        if (rc == SBV_OK) rc = grow_bytes(sbuf.d_gather, sbuf.gather_cap, sb * shards + 64);
+        if (rc == SBV_OK && quorum_bitmap) rc = grow_bytes(sbuf.d_q, sbuf.q_cap, qb + 64);
+        if (rc == SBV_OK)
+            rc = verify_shard(*c, tuples + first[k] * SBV_TUPLE_BYTES, first[k + 1] - first[k], group, quorum, sbuf.d_gather + k * sb,
+                              quorum_bitmap ? sbuf.d_q : nullptr, &h2d[k], &kern[k]);
+        if (rc == SBV_OK && quorum_bitmap) {
+            const size_t props = (first[k + 1] - first[k]) / group;
+            if (props && hipMemcpy(quorum_bitmap + (first[k] / group) / 8, sbuf.d_q, (props + 7) / 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SBV_EDEVICE;
+        }
+        if (rc == SBV_OK && !gather && !forced_single) {         // no collective: this shard's bitmap goes straight to the host
+            const size_t bytes = (first[k + 1] - first[k] + 7) / 8;
+            if (hipMemcpy(accept_bitmap + first[k] / 8, sbuf.d_gather + k * sb, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = SBV_EDEVICE;
+        }
+        rcs[k] = rc;
+        if (rc != SBV_OK) errs[k] = g_err;
+    };
+    if (shards == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < shards; ++k) th.emplace_back(work, k);
+        for (auto& t : th) t.join();
+    }
+    for (size_t k = 0; k < shards; ++k)
+        if (rcs[k] != SBV_OK) { g_err = "device " + std::to_string(use[k]) + ": " + errs[k]; return rcs[k]; }
+    const auto t1 = std::chrono::steady_clock::now();
+    double gather_us = 0;
+    if (gather || forced_single) {
+        std::lock_guard<std::mutex> lk(g_mu);                    // the communicators
+        bool ok = g_rccl.ready && g_rccl.GroupStart() == 0;
+        for (size_t k = 0; ok && k < shards; ++k) {
+            size_t rank = 0;
+            while (rank < g_devs.size() && g_devs[rank] != use[k]) ++rank;
+            ok = rank < g_devs.size() && hipSetDevice(use[k]) == hipSuccess;
+            ShardBuffers& sbuf = g_shard[use[k]];
+            if (ok) ok = g_rccl.AllGather(sbuf.d_gather + k * sb, sbuf.d_gather, sb, /*ncclUint8*/ 1, g_rccl.comms[rank], g_ctxs[use[k]]->stream) == 0;
+        }
+        if (ok) ok = g_rccl.GroupEnd() == 0;
+        if (ok) ok = hipSetDevice(use[0]) == hipSuccess &&
+                     hipMemcpyAsync(accept_bitmap, g_shard[use[0]].d_gather, (n + 7) / 8, hipMemcpyDeviceToHost, g_ctxs[use[0]]->stream) == hipSuccess &&
+                     hipStreamSynchronize(g_ctxs[use[0]]->stream) == hipSuccess;
+        for (size_t k = 1; ok && k < shards; ++k) ok = hipSetDevice(use[k]) == hipSuccess && hipStreamSynchronize(g_ctxs[use[k]]->stream) == hipSuccess;
+        if (!ok) { g_err = "RCCL all-gather of the bitmap shards failed"; return SBV_EDEVICE; }
+        gather_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+    }
+    if (info) {
+        info->devices = (int)devs.size();
+        info->shards = (int)shards;
+        info->mode = (gather || forced_single) ? 1 : (shards > 1 ? 2 : 0);
+        info->tuples_per_shard = per;
+        for (size_t k = 0; k < shards; ++k) { if (h2d[k] > info->h2d_us) info->h2d_us = h2d[k]; if (kern[k] > info->kernels_us) info->kernels_us = kern[k]; }
+        info->gather_us = gather_us;
+        info->total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_verify_batch_on(int device, const uint8_t* tuples, size_t n, uint8_t* accept_bitmap) {
+    if (n == 0) return SBV_OK;
+    if (!tuples || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
+    Context* c;
+    { std::lock_guard<std::mutex> lk(g_mu); c = context_of(device, false); }
+    if (!c) { g_err = "device not initialised"; return SBV_ENOTINIT; }
+    std::lock_guard<std::mutex> lkc(c->mu);
+    ShardBuffers& sbuf = g_shard[device];
+    if (!c->ready) { g_err = "device not initialised"; return SBV_ENOTINIT; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c->device));
+    const size_t bytes = (n + 7) / 8;
+    int rc = grow_bytes(sbuf.d_gather, sbuf.gather_cap, bytes + 64);
+    if (rc != SBV_OK) return rc;
+    rc = verify_shard(*c, tuples, n, 0, 0, sbuf.d_gather, nullptr, nullptr, nullptr);
+    if (rc != SBV_OK) return rc;
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(accept_bitmap, sbuf.d_gather, bytes, hipMemcpyDeviceToHost));
     return SBV_OK;
 }
 

@@ -1,0 +1,31 @@
+// Package gpuverifier implements SmartBFT's api.Verifier, api.Signer and api.RequestInspector
+// (pkg/api/dependencies.go:46-83) with ECDSA P-256 signatures, verifying them in batches on AMD MI355X GPUs through
+// libsbv.so (C-ABI: include/sbv.h of the consensus_amd repository).
+//
+// Drop this directory into the SmartBFT tree as pkg/gpuverifier.  Two build flavours:
+//
+//	go test ./pkg/gpuverifier/                      pure Go: every batch is verified with crypto/ecdsa (cpuBackend).
+//	                                                This is also the route a GPU build takes for batches below GPUMin
+//	                                                and whenever the device reports a fault.
+//	go test -tags sbvgpu ./pkg/gpuverifier/         cgo: batches of >= GPUMin signatures go to libsbv.so
+//	  CGO_CFLAGS=-I<consensus_amd>/include  CGO_LDFLAGS="-L<consensus_amd>/consensus_amd -lsbv"
+//
+// What the package does above the C-ABI (all of it is exercised by verifier_test.go without a GPU):
+//
+//   - wire formats for signed client requests and consenter signature messages (the reference defines none:
+//     examples/naive_chain/chain.go:41-58 has unsigned transactions) — formats.go;
+//   - a key registry: types.Signature.ID selects the consenter key, Request.ClientID the client key;
+//   - a coalescer: the <= N-1 goroutines of View.processCommits (internal/bft/view.go:537-541) each call
+//     VerifyConsenterSig with one signature; they are merged into one backend batch;
+//   - VerifyProposal ships all K request signatures of a proposal as ONE batch (internal/bft/view.go:553-559);
+//   - a verified-signature cache with an injective key (commit signatures of sequence s come back as
+//     prev_commit_signatures at s+1: internal/bft/view.go:376, 630);
+//   - Proposal.Digest() computed once per proposal, also for concurrent first callers.
+//
+// A device fault is never reported as an invalid signature: VerifyProposal returning an error deposes the leader
+// (internal/bft/view.go:387-392), so on any backend error the batch is re-verified with crypto/ecdsa.
+//
+// This code was written without a Go toolchain at hand (the build image of consensus_amd has none); the C++ mirror
+// consensus_amd/host/verifier.{h,cc} has the same structure, is compiled and tested there, and is the executable
+// specification of what follows.
+package gpuverifier

@@ -1,0 +1,404 @@
+package gpuverifier
+
+import (
+	"crypto/ecdsa"
+	"crypto/sha256"
+	"encoding/binary"
+	"errors"
+	"sync"
+	"time"
+
+	bft "github.com/hyperledger-labs/SmartBFT/pkg/types"
+)
+
+// Options tune the adapter.
+type Options struct {
+	// GPUMin: batches with fewer signatures are verified with crypto/ecdsa on the calling goroutines' cores.  A lone
+	// P-256 verification is a serial chain; a GPU wins from a few hundred signatures in flight (a 15-signature commit
+	// quorum takes ~0.3 ms on the device against ~0.1 ms on 15 cores).  0 = always use the backend.
+	GPUMin int
+	// CoalesceWait / CoalesceMax: how long the dispatcher waits for further single-signature calls and how many it ships
+	// at once.
+	CoalesceWait time.Duration
+	CoalesceMax  int
+	// CacheVerified keeps verdicts of single-signature calls (commit signatures of sequence s reappear at s+1).
+	CacheVerified bool
+}
+
+// DefaultOptions are sized for a node with a GPU backend.
+var DefaultOptions = Options{GPUMin: 256, CoalesceWait: 50 * time.Microsecond, CoalesceMax: 4096, CacheVerified: true}
+
+type job struct {
+	item Item
+	done chan bool
+}
+
+// Verifier implements api.Verifier and api.RequestInspector.
+type Verifier struct {
+	opt     Options
+	backend Backend
+	cpu     cpuBackend
+	jobs    chan *job
+	stop    chan struct{}
+	wg      sync.WaitGroup
+
+	mu         sync.RWMutex
+	consenters map[uint64]regKey
+	clients    map[string]regKey
+	seq        uint64
+
+	cacheMu sync.Mutex
+	cache   map[[32]byte]bool
+
+	digestMu sync.Mutex
+	digests  []*digestSlot
+}
+
+type regKey struct {
+	pub  *ecdsa.PublicKey
+	slot int32
+}
+
+type digestSlot struct {
+	p     bft.Proposal
+	once  sync.Once
+	value [32]byte
+}
+
+// New creates a Verifier over the given backend (NewDeviceBackend(), or nil for crypto/ecdsa only).
+func New(backend Backend, opt Options) *Verifier {
+	if backend == nil {
+		backend = cpuBackend{}
+	}
+	if opt.CoalesceMax <= 0 {
+		opt.CoalesceMax = 4096
+	}
+	v := &Verifier{opt: opt, backend: backend, jobs: make(chan *job, 4096), stop: make(chan struct{}),
+		consenters: map[uint64]regKey{}, clients: map[string]regKey{}, cache: map[[32]byte]bool{}}
+	v.wg.Add(1)
+	go v.dispatch()
+	return v
+}
+
+// Close stops the dispatcher and releases the backend.
+func (v *Verifier) Close() {
+	close(v.stop)
+	v.wg.Wait()
+	v.backend.Close()
+}
+
+// RegisterConsenter / RegisterClient: the key registry (types.Signature.ID and Request.ClientID select the key).
+func (v *Verifier) RegisterConsenter(id uint64, pub *ecdsa.PublicKey) {
+	slot := v.backend.RegisterKey(pub)
+	v.mu.Lock()
+	v.consenters[id] = regKey{pub, slot}
+	v.mu.Unlock()
+}
+
+func (v *Verifier) RegisterClient(clientID string, pub *ecdsa.PublicKey) {
+	slot := v.backend.RegisterKey(pub)
+	v.mu.Lock()
+	v.clients[clientID] = regKey{pub, slot}
+	v.mu.Unlock()
+}
+
+// SetVerificationSequence is called by the application when its verification rules change (epoch / config update).
+func (v *Verifier) SetVerificationSequence(s uint64) {
+	v.mu.Lock()
+	v.seq = s
+	v.mu.Unlock()
+}
+
+func (v *Verifier) consenter(id uint64) (regKey, bool) {
+	v.mu.RLock()
+	defer v.mu.RUnlock()
+	k, ok := v.consenters[id]
+	return k, ok
+}
+
+func (v *Verifier) client(id string) (regKey, bool) {
+	v.mu.RLock()
+	defer v.mu.RUnlock()
+	k, ok := v.clients[id]
+	return k, ok
+}
+
+// verifyBatch judges every item: the backend for batches of at least GPUMin, crypto/ecdsa otherwise — and crypto/ecdsa
+// again whenever the backend fails, so that a device fault can never look like an invalid signature.
+func (v *Verifier) verifyBatch(items []Item) []bool {
+	if len(items) >= v.opt.GPUMin {
+		if ok, err := v.backend.Verify(items); err == nil && len(ok) == len(items) {
+			return ok
+		}
+	}
+	ok, _ := v.cpu.Verify(items)
+	return ok
+}
+
+// dispatch merges concurrent single-signature calls into one batch: it takes the first pending job, waits up to
+// CoalesceWait for more (the <= N-1 goroutines of View.processCommits arrive within microseconds of each other,
+// internal/bft/view.go:537-541) and ships them together.
+func (v *Verifier) dispatch() {
+	defer v.wg.Done()
+	for {
+		var first *job
+		select {
+		case <-v.stop:
+			return
+		case first = <-v.jobs:
+		}
+		batch := []*job{first}
+		timer := time.NewTimer(v.opt.CoalesceWait)
+	collect:
+		for len(batch) < v.opt.CoalesceMax {
+			select {
+			case j := <-v.jobs:
+				batch = append(batch, j)
+			case <-timer.C:
+				break collect
+			}
+		}
+		timer.Stop()
+		items := make([]Item, len(batch))
+		for i, j := range batch {
+			items[i] = j.item
+		}
+		ok := v.verifyBatch(items)
+		for i, j := range batch {
+			j.done <- ok[i]
+		}
+	}
+}
+
+// cacheKey must be injective in (key, signature, message): both variable-length fields are length-prefixed.  With a plain
+// concatenation a verified (sig, msg) would vouch for (sig + msg[:k], msg[k:]) — a message nobody signed.
+func cacheKey(pub *ecdsa.PublicKey, msg, sig []byte) [32]byte {
+	h := sha256.New()
+	var kb [64]byte
+	pub.X.FillBytes(kb[:32])
+	pub.Y.FillBytes(kb[32:])
+	h.Write(kb[:])
+	var l [8]byte
+	binary.LittleEndian.PutUint64(l[:], uint64(len(sig)))
+	h.Write(l[:])
+	h.Write(sig)
+	binary.LittleEndian.PutUint64(l[:], uint64(len(msg)))
+	h.Write(l[:])
+	h.Write(msg)
+	var out [32]byte
+	copy(out[:], h.Sum(nil))
+	return out
+}
+
+func (v *Verifier) verifyOne(k regKey, msg, sig []byte) bool {
+	var key [32]byte
+	if v.opt.CacheVerified {
+		key = cacheKey(k.pub, msg, sig)
+		v.cacheMu.Lock()
+		ok, hit := v.cache[key]
+		v.cacheMu.Unlock()
+		if hit {
+			return ok
+		}
+	}
+	j := &job{item: Item{Pub: k.pub, Slot: k.slot, Msg: msg, Sig: sig}, done: make(chan bool, 1)}
+	v.jobs <- j
+	ok := <-j.done
+	if v.opt.CacheVerified {
+		v.cacheMu.Lock()
+		if len(v.cache) > 1<<20 {
+			v.cache = map[[32]byte]bool{}
+		}
+		v.cache[key] = ok
+		v.cacheMu.Unlock()
+	}
+	return ok
+}
+
+// digest returns SHA-256 of the proposal's ASN.1 form, computed once per proposal even when the first callers arrive
+// together (the reference recomputes it three times per sequence: internal/bft/view.go:435, 443, 524).
+func (v *Verifier) digest(p bft.Proposal) [32]byte {
+	v.digestMu.Lock()
+	var s *digestSlot
+	for _, d := range v.digests {
+		if d.p.VerificationSequence == p.VerificationSequence && string(d.p.Header) == string(p.Header) &&
+			string(d.p.Metadata) == string(p.Metadata) && string(d.p.Payload) == string(p.Payload) {
+			s = d
+			break
+		}
+	}
+	if s == nil {
+		s = &digestSlot{p: p}
+		if len(v.digests) >= 4 {
+			v.digests = v.digests[1:]
+		}
+		v.digests = append(v.digests, s)
+	}
+	v.digestMu.Unlock()
+	s.once.Do(func() { s.value = proposalDigestRaw(p) })
+	return s.value
+}
+
+// ---- api.Verifier ------------------------------------------------------------------------------------------------------
+
+var (
+	errInvalidSig = errors.New("invalid signature")
+	errUnknown    = errors.New("unknown signer")
+)
+
+// VerifySignature: internal/bft/viewchanger.go:598, 660, 983, 1022, 1076.
+func (v *Verifier) VerifySignature(s bft.Signature) error {
+	k, ok := v.consenter(s.ID)
+	if !ok {
+		return errUnknown
+	}
+	if !v.verifyOne(k, s.Msg, s.Value) {
+		return errInvalidSig
+	}
+	return nil
+}
+
+// VerifyConsenterSig: internal/bft/view.go:631, 834; internal/bft/viewchanger.go:681-727.
+func (v *Verifier) VerifyConsenterSig(s bft.Signature, prop bft.Proposal) ([]byte, error) {
+	bound, aux, ok := ConsenterMsgSplit(s.Msg)
+	if !ok {
+		return nil, errors.New("malformed signature message")
+	}
+	if bound != v.digest(prop) {
+		return nil, errors.New("signature message does not match proposal")
+	}
+	if err := v.VerifySignature(s); err != nil {
+		return nil, err
+	}
+	return aux, nil
+}
+
+// AuxiliaryData: internal/bft/view.go:1029, 1071 — no verification.
+func (v *Verifier) AuxiliaryData(msg []byte) []byte {
+	_, aux, _ := ConsenterMsgSplit(msg)
+	return aux
+}
+
+// RequestID implements api.RequestInspector (internal/bft/requestpool.go:192).
+func (v *Verifier) RequestID(raw []byte) bft.RequestInfo {
+	r, err := ParseRequest(raw)
+	if err != nil {
+		return bft.RequestInfo{}
+	}
+	return bft.RequestInfo{ClientID: r.ClientID, ID: r.ID}
+}
+
+// VerifyRequest: internal/bft/controller.go:233-246 (leader, before pooling) and :733-746 (Pool.Prune).
+func (v *Verifier) VerifyRequest(raw []byte) (bft.RequestInfo, error) {
+	r, err := ParseRequest(raw)
+	if err != nil {
+		return bft.RequestInfo{}, err
+	}
+	k, ok := v.client(r.ClientID)
+	if !ok {
+		return bft.RequestInfo{}, errors.New("unknown client")
+	}
+	if !v.verifyOne(k, r.Signed, r.Sig) {
+		return bft.RequestInfo{}, errors.New("invalid request signature")
+	}
+	return bft.RequestInfo{ClientID: r.ClientID, ID: r.ID}, nil
+}
+
+func (v *Verifier) parseProposal(p bft.Proposal) ([]*Request, []bft.RequestInfo, error) {
+	raws, err := PayloadSplit(p.Payload)
+	if err != nil {
+		return nil, nil, err
+	}
+	reqs := make([]*Request, len(raws))
+	infos := make([]bft.RequestInfo, len(raws))
+	for i, raw := range raws {
+		r, err := ParseRequest(raw)
+		if err != nil {
+			return nil, nil, err
+		}
+		reqs[i] = r
+		infos[i] = bft.RequestInfo{ClientID: r.ClientID, ID: r.ID}
+	}
+	return reqs, infos, nil
+}
+
+// VerifyProposal: internal/bft/view.go:553-559 — all K request signatures as ONE batch.
+func (v *Verifier) VerifyProposal(p bft.Proposal) ([]bft.RequestInfo, error) {
+	v.mu.RLock()
+	seq := v.seq
+	v.mu.RUnlock()
+	if uint64(p.VerificationSequence) != seq {
+		return nil, errors.New("verification sequence mismatch")
+	}
+	reqs, infos, err := v.parseProposal(p)
+	if err != nil {
+		return nil, err
+	}
+	items := make([]Item, len(reqs))
+	for i, r := range reqs {
+		k, ok := v.client(r.ClientID)
+		if !ok {
+			return nil, errors.New("unknown client")
+		}
+		items[i] = Item{Pub: k.pub, Slot: k.slot, Msg: r.Signed, Sig: r.Sig}
+	}
+	for _, ok := range v.verifyBatch(items) {
+		if !ok {
+			return nil, errors.New("invalid request signature in proposal")
+		}
+	}
+	return infos, nil
+}
+
+// RequestsFromProposal: internal/bft/view.go:395, 419; internal/bft/controller.go:892-898 — parsing only, and the same
+// list VerifyProposal returns (the pool evicts delivered requests by it).
+func (v *Verifier) RequestsFromProposal(p bft.Proposal) []bft.RequestInfo {
+	_, infos, err := v.parseProposal(p)
+	if err != nil {
+		return nil
+	}
+	return infos
+}
+
+// VerificationSequence: internal/bft/view.go:614-618.
+func (v *Verifier) VerificationSequence() uint64 {
+	v.mu.RLock()
+	defer v.mu.RUnlock()
+	return v.seq
+}
+
+// VerifyDecisions is the batch form for a Synchronizer that replays decisions (pkg/types/types.go:31-34): every
+// signature of every decision in one backend call; decided[i] reports whether decision i carries at least quorum valid
+// signatures by distinct consenters.
+func (v *Verifier) VerifyDecisions(decisions []bft.Decision, quorum int) (decided []bool) {
+	var items []Item
+	type ref struct{ d int; id uint64 }
+	var refs []ref
+	for di, d := range decisions {
+		dg := v.digest(d.Proposal)
+		for _, s := range d.Signatures {
+			bound, _, ok := ConsenterMsgSplit(s.Msg)
+			k, known := v.consenter(s.ID)
+			if !ok || !known || bound != dg {
+				continue
+			}
+			items = append(items, Item{Pub: k.pub, Slot: k.slot, Msg: s.Msg, Sig: s.Value})
+			refs = append(refs, ref{di, s.ID})
+		}
+	}
+	ok := v.verifyBatch(items)
+	seen := make([]map[uint64]bool, len(decisions))
+	for i, r := range refs {
+		if ok[i] {
+			if seen[r.d] == nil {
+				seen[r.d] = map[uint64]bool{}
+			}
+			seen[r.d][r.id] = true
+		}
+	}
+	decided = make([]bool, len(decisions))
+	for i := range decisions {
+		decided[i] = len(seen[i]) >= quorum
+	}
+	return decided
+}

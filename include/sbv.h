@@ -165,7 +165,40 @@ int sbv_p256_last_group_stats(uint32_t out[4]);
 void* sbv_host_alloc(size_t bytes);
 void sbv_host_free(void* p);
 
-/* Human-readable description of the last failure in this process ("" if none). */
+/* ---- every GPU of the node behind one process ---------------------------------------------------------------------
+ * The reference injects ONE Verifier into a replica process (pkg/consensus/consensus.go:35, 107); that process drives all
+ * the GPUs of its node.  sbv_init(d) may be called for several devices (the first one stays the default of the
+ * single-device entry points above); sbv_init_all() initialises every visible gfx950 device and returns how many.
+ *
+ * sbv_p256_verify_batch_sharded splits a host batch into contiguous shards, one per device (BASELINE.json: "client-request
+ * signatures queued in the RequestPool and the 2f+1 consenter Commit signatures collected per proposal are sharded across
+ * the 8 GPUs of one node"), each a multiple of lcm(512, 8 * group) tuples: whole bitmap bytes per device and — with
+ * group = signatures per proposal (11 at N = 16: internal/bft/util.go:183-187) — whole proposals, so that each device
+ * also emits the per-proposal quorum bit (>= quorum accepted signatures by DISTINCT keys, the rule of
+ * internal/bft/viewchanger.go:681-727).  When more than one device took part, one in-place ncclAllGather of the bitmap
+ * shards (RCCL over xGMI, uint8, per-device streams) leaves the full bitmap on every device and one D2H returns it; a
+ * batch smaller than 2 x 2^18 tuples is NOT split — it goes whole to one device, round-robin, with no collective.
+ *   group = 0: plain tuples.  quorum_bitmap may be NULL; otherwise ceil((n / group) / 8) bytes, bit p = proposal p.
+ *   info (optional) reports what was done.  sbv_shard_plan is the pure split (testable without a GPU):
+ *   first[0..shards], returns shards.  sbv_p256_verify_batch_on runs a whole batch on one chosen device. */
+typedef struct sbv_shard_info {
+    int devices;              /* devices available to the call                              */
+    int shards;               /* shards the batch was split into (1 = not split)            */
+    int mode;                 /* 0 = one device, 1 = RCCL all-gather, 2 = per-device D2H    */
+    size_t tuples_per_shard;
+    double h2d_us;            /* slowest device                                              */
+    double kernels_us;        /* slowest device: stage A + B (+ quorum bits)                 */
+    double gather_us;         /* all-gather + final D2H                                      */
+    double total_us;
+} sbv_shard_info;
+int sbv_init_all(void);
+int sbv_initialised_devices(int* out, int max);
+size_t sbv_shard_plan(size_t n, int devices, size_t group, size_t min_per_device, size_t* first);
+int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, size_t group, uint32_t quorum, uint8_t* accept_bitmap,
+                                  uint8_t* quorum_bitmap, sbv_shard_info* info);
+int sbv_p256_verify_batch_on(int device, const uint8_t* tuples, size_t n, uint8_t* accept_bitmap);
+
+/* Human-readable description of the calling thread's last failing call ("" if none). */
 const char* sbv_last_error(void);
 
 #ifdef __cplusplus

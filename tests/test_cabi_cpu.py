@@ -100,3 +100,42 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
     assert lib.sbv_host_alloc(4096) is None
     lib.sbv_host_free.argtypes = [ctypes.c_void_p]
     lib.sbv_host_free(None)
+    # the multi-device entries refuse the same way
+    with pytest.raises(sbv.SbvError) as ei:
+        sbv.init_all()
+    assert ei.value.code == -1
+    with pytest.raises(sbv.SbvError) as ei:
+        sbv.verify_batch_sharded(ctypes.addressof(ctypes.create_string_buffer(160 * 8)), 8, ctypes.addressof(out))
+    assert ei.value.code == -5
+    with pytest.raises(sbv.SbvError) as ei:
+        sbv.verify_batch_on(0, ctypes.addressof(ctypes.create_string_buffer(160 * 8)), 8, ctypes.addressof(out))
+    assert ei.value.code == -5
+
+
+def test_shard_plan_split_logic():
+    """The pure split of sbv_p256_verify_batch_sharded: contiguous shards, each a multiple of
+    lcm(512, 8 * group) tuples — whole bitmap bytes and whole proposals per device — and no split at all below
+    2 x min_per_device tuples ("only when a batch outgrows one GPU")."""
+    n = 1 << 20
+    # plain tuples, 8 devices: 2^17 each... below the default per-device minimum of 2^18 -> 4 shards of 2^18
+    assert sbv.shard_plan(n, 8) == [0, 1 << 18, 2 << 18, 3 << 18, 1 << 20]
+    assert sbv.shard_plan(8 * n, 8) == [k * n for k in range(9)]                      # weak scaling: 2^20 per device
+    assert sbv.shard_plan(n, 1) == [0, n]
+    assert sbv.shard_plan(100000, 8) == [0, 100000]                                   # small batch: one device (replica routing)
+    assert sbv.shard_plan((1 << 19) - 1, 8) == [0, (1 << 19) - 1]
+    assert sbv.shard_plan(1 << 19, 8) == [0, 1 << 18, 1 << 19]
+    # configs[3]: 50 000 proposals x 11 signatures over 8 devices, split BY PROPOSAL
+    P, Q = 50000, 11
+    plan = sbv.shard_plan(P * Q, 8, group=Q, min_per_device=1 << 16)
+    assert plan[0] == 0 and plan[-1] == P * Q and len(plan) == 9
+    gran = 5632                                                                       # lcm(512, 8 * 11)
+    for a, b in zip(plan, plan[1:]):
+        assert a < b
+    for f in plan[1:-1]:
+        assert f % gran == 0 and f % Q == 0 and (f // Q) % 8 == 0                     # whole proposals, whole quorum-bitmap bytes
+    sizes = {b - a for a, b in zip(plan[:-2], plan[1:-1])}
+    assert len(sizes) == 1                                                            # equal shards (the all-gather needs equal counts)
+    # ragged: the last shard is shorter, never empty, and the shards cover the batch exactly
+    for n2, dev, grp in [(1000003, 8, 0), (550001, 8, 11), (2 ** 21 + 5, 3, 7), (600000, 2, 0)]:
+        pl = sbv.shard_plan(n2, dev, group=grp, min_per_device=1 << 16)
+        assert pl[0] == 0 and pl[-1] == n2 and all(a < b for a, b in zip(pl, pl[1:])) and len(pl) - 1 <= dev

@@ -134,3 +134,58 @@ def test_config3_550000_consenter_signatures_and_quorum(gpu, oracle, openssl_che
     decided_cpu = sum(1 for p in range(P) if sum(want[p * Q:(p + 1) * Q]) >= Q - 1)
     assert decided_gpu == decided_cpu
     assert 0 < decided_gpu < P                        # the mix really contains proposals that miss quorum
+
+
+def test_sharded_entry_world_of_one_with_rccl_and_quorum_bits(oracle):
+    """The native multi-GPU entry on the box we have (one GPU): sbv_init_all finds 1 device; with SBV_RCCL=1 the bitmap
+    still travels through ncclAllGather (one rank), so the collective code path is exercised; the per-proposal quorum
+    bits (>= Q - 1 = 10 accepted signatures by distinct keys) are computed on the device.  Eight-GPU behaviour is the
+    driver's to measure."""
+    os.environ["SBV_RCCL"] = "1"
+    os.environ["SBV_SHARD_MIN"] = str(1 << 16)
+    try:
+        sbv.shutdown()
+        ndev = sbv.init_all()
+        assert ndev >= 1
+        P, Q = 30000, 11
+        n = P * Q
+        tup, exp = _gen(oracle, 0xC4, n, 16, 8)
+        got = ctypes.create_string_buffer((n + 7) // 8)
+        qb = ctypes.create_string_buffer((P + 7) // 8)
+        info = sbv.verify_batch_sharded(ctypes.addressof(tup), n, ctypes.addressof(got), group=Q, quorum=Q - 1,
+                                        quorum_out_ptr=ctypes.addressof(qb))
+        assert got.raw == exp, _diff(got.raw, exp)
+        assert info.devices == ndev and info.shards >= 1
+        assert info.mode == 1                                        # the RCCL all-gather ran (world size = devices used)
+        bits = sbv.bitmap_to_list(exp, n)
+        raw = tup.raw
+        want_q = []
+        for p in range(P):
+            keys = {raw[160 * i + 96:160 * i + 160] for i in range(p * Q, (p + 1) * Q) if bits[i]}
+            want_q.append(len(keys) >= Q - 1)
+        assert sbv.bitmap_to_list(qb.raw, P) == want_q
+        assert 0 < sum(want_q) < P
+        # duplicate signers must not count twice: proposal 0 becomes ten copies of ONE valid signature + one more signer
+        i0 = next(i for i in range(Q) if bits[i])
+        dup = bytearray(raw[:160 * Q])
+        for j in range(Q - 1):
+            dup[160 * j:160 * (j + 1)] = raw[160 * i0:160 * (i0 + 1)]
+        t2 = ctypes.create_string_buffer(bytes(dup) + raw[160 * Q:160 * 5632 * 2])
+        n2 = len(t2.raw) // 160 // Q * Q
+        g2 = ctypes.create_string_buffer((n2 + 7) // 8)
+        q2 = ctypes.create_string_buffer((n2 // Q + 7) // 8)
+        sbv.verify_batch_sharded(ctypes.addressof(t2), n2, ctypes.addressof(g2), group=Q, quorum=Q - 1, quorum_out_ptr=ctypes.addressof(q2))
+        assert sbv.bitmap_to_list(g2.raw, Q)[:Q - 1] == [True] * (Q - 1)      # ten accepted signatures ...
+        assert sbv.bitmap_to_list(q2.raw, 1) == [False]                        # ... by one signer: no quorum
+        # replica routing of a small batch, and the explicit-device entry
+        m = 4096
+        small = ctypes.create_string_buffer(m // 8)
+        info = sbv.verify_batch_sharded(ctypes.addressof(tup), m, ctypes.addressof(small))
+        assert small.raw == exp[:m // 8] and info.shards == 1
+        on = ctypes.create_string_buffer(m // 8)
+        sbv.verify_batch_on(0, ctypes.addressof(tup), m, ctypes.addressof(on))
+        assert on.raw == exp[:m // 8]
+    finally:
+        os.environ.pop("SBV_RCCL", None)
+        os.environ.pop("SBV_SHARD_MIN", None)
+        sbv.shutdown()

@@ -360,3 +360,35 @@ def test_grouped_vs_ungrouped_full_batch(gpu):
         gpu.set_grouping(True, 131072, 64, 2048)
     print(f"\n[2^20] grouped: prep {times[True][0]:.0f} us stageB {times[True][1]:.0f} us | ungrouped: prep {times[False][0]:.0f} us "
           f"stageB {times[False][1]:.0f} us")
+
+
+def test_concurrent_host_pointer_calls_are_pipelined_and_correct(gpu, oracle):
+    """The host-pointer entry keeps two staging slots and releases the context lock while it waits, so concurrent callers
+    (the reference calls the Verifier from several goroutines: view.go:539-541, controller.go:239) overlap one call's
+    upload with another's kernels.  Four threads, different batches and sizes (one of them larger than a launch), many
+    rounds: every bitmap must be its own batch's."""
+    import threading
+    sizes = [300000, 4097, 70000, (1 << 21) + 777]
+    batches = []
+    for k, n in enumerate(sizes):
+        tup = ctypes.create_string_buffer(160 * n)
+        exp = ctypes.create_string_buffer((n + 7) // 8)
+        oracle.sbvo_gen_batch(0xD00 + k, n, 50 + k, 5, tup, exp, os.cpu_count() or 1)
+        batches.append((tup, exp.raw[:(n + 7) // 8], n))
+    errors = []
+
+    def worker(k):
+        tup, exp, n = batches[k]
+        got = ctypes.create_string_buffer((n + 7) // 8)
+        for _ in range(4 if n > 1000000 else 12):
+            gpu.verify_batch_ptr(ctypes.addressof(tup), n, ctypes.addressof(got))
+            if got.raw != exp:
+                errors.append((k, n))
+                return
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(len(sizes))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
