@@ -1,6 +1,6 @@
 // p256_comb29.h — the comb phases of stage B over the carry-free field (p256_fe29.h, p256_pt29.h):
 //
-//   gphase29_lane        R = u1 * G from the 16-bit comb of G (17 mixed additions), parked in gacc
+//   gphase29_lane        R = u1 * G from the comb of G (13 mixed additions with 20-bit windows, 17 with 16-bit), parked in gacc
 //   qphase29_lane        R += windows [j0, j1) of u2 * Q from a key's 8-bit comb; the last chunk checks R.x == r
 //   verify29_lane_keyed  both for a registered key in one pass (50 mixed additions, no doublings)
 //
@@ -51,22 +51,63 @@ SBV_HD void raw_apt_unpack(apt29& q, const raw_apt& e) {
     f29_unpack(q.y, e.w + 8);
 }
 
-// R = u1 * G.  g16r[j * 32768 + (k-1)] = k * 2^(16 j) * G, j = 0..16 (R = 2^261 domain).
-SBV_HD void gphase29_point(xyzz& R, const u256& u1, const apt* g16r) {
-    u256 k1;
-    const u32 top1 = add_const_limbs(k1, u1, 0x80008000u);
-    pt29_set_inf(R);
-    int idx; bool neg, skip;
-    comb16_digit(k1, top1, 0, idx, neg, skip);
-    raw_apt cur;
-    raw_apt_load(cur, g16r + idx);
+// The fixed-base comb of G for the carry-free kernels: `bits`-wide signed windows, windows = ceil(257 / bits) rows of
+// 2^(bits-1) entries, tab[(j << (bits-1)) + (m-1)] = m * 2^(bits j) * G (R = 2^261 domain).  u1 * G is `windows` mixed
+// additions: 17 for the 16-bit comb (35.7 MB), 13 for the 20-bit comb (436 MB) — the table is static, HBM is 288 GB,
+// and a random 64-byte gather per addition is prefetched one addition ahead, so wider windows only cost memory.
+struct gcomb { const apt* tab; int bits; int windows; };
+SBV_HD gcomb gcomb_make(const apt* tab, int bits) { gcomb g = {tab, bits, (257 + bits - 1) / bits}; return g; }
+SBV_HD size_t gcomb_entries(int bits) { return (size_t)((257 + bits - 1) / bits) << (bits - 1); }
+struct u288 { u32 v[9]; };
+// k = u + sum_j 2^(bits j + bits - 1): window j of k, minus 2^(bits-1), is the signed digit (no carry chain between digits)
+SBV_HD void gcomb_recode(u288& k, const u256& u, int bits, int windows) {
+    u32 off[9];
+    SBV_UNROLL
+    for (int w = 0; w < 9; ++w) off[w] = 0;
     SBV_NOUNROLL
-    for (int j = 0; j < SBV_G16_WINDOWS; ++j) {
-        const int jn = j + 1 < SBV_G16_WINDOWS ? j + 1 : SBV_G16_WINDOWS - 1;
-        int idxn; bool negn, skipn;
-        comb16_digit(k1, top1, jn, idxn, negn, skipn);
+    for (int j = 0; j < windows; ++j) {
+        const int pos = bits * j + bits - 1;
+        SBV_UNROLL
+        for (int w = 0; w < 9; ++w) off[w] |= (pos >> 5) == w ? (1u << (pos & 31)) : 0u;
+    }
+    u32 c = 0;
+    SBV_UNROLL
+    for (int w = 0; w < 8; ++w) k.v[w] = addc(u.v[w], off[w], c);
+    k.v[8] = off[8] + c;
+}
+SBV_HD void gcomb_digit(const u288& k, int bits, int j, u32& idx, bool& neg, bool& skip) {
+    const int pos = bits * j, word = pos >> 5, sh = pos & 31;
+    u32 lo = 0, hi = 0;
+    SBV_UNROLL
+    for (int w = 0; w < 9; ++w) {
+        lo = word == w ? k.v[w] : lo;
+        hi = word + 1 == w ? k.v[w] : hi;
+    }
+    const u64 two = ((u64)hi << 32) | lo;
+    const u32 win = (u32)(two >> sh) & ((1u << bits) - 1u);
+    const i32 d = (i32)win - (i32)(1u << (bits - 1));
+    const i32 ad = d < 0 ? -d : d;
+    idx = ad == 0 ? 0u : (u32)ad - 1u;
+    neg = d < 0;
+    skip = d == 0;
+}
+
+// R = u1 * G
+SBV_HD void gphase29_point(xyzz& R, const u256& u1, const gcomb& gc) {
+    u288 k1;
+    gcomb_recode(k1, u1, gc.bits, gc.windows);
+    pt29_set_inf(R);
+    u32 idx; bool neg, skip;
+    gcomb_digit(k1, gc.bits, 0, idx, neg, skip);
+    raw_apt cur;
+    raw_apt_load(cur, gc.tab + idx);
+    SBV_NOUNROLL
+    for (int j = 0; j < gc.windows; ++j) {
+        const int jn = j + 1 < gc.windows ? j + 1 : gc.windows - 1;
+        u32 idxn; bool negn, skipn;
+        gcomb_digit(k1, gc.bits, jn, idxn, negn, skipn);
         raw_apt nxt;
-        raw_apt_load(nxt, g16r + (size_t)jn * SBV_G16_PER_WINDOW + idxn);
+        raw_apt_load(nxt, gc.tab + ((size_t)jn << (gc.bits - 1)) + idxn);
         if (!skip) {
             apt29 q;
             raw_apt_unpack(q, cur);
@@ -75,11 +116,11 @@ SBV_HD void gphase29_point(xyzz& R, const u256& u1, const apt* g16r) {
         cur = nxt; neg = negn; skip = skipn;
     }
 }
-SBV_HD void gphase29_lane(const Scratch& s, size_t i, const apt* g16r, u32* gacc) {
+SBV_HD void gphase29_lane(const Scratch& s, size_t i, const gcomb& gc, u32* gacc) {
     u256 u1;
     soa_load(u1, s.u1, s.cap, i);
     xyzz R;
-    gphase29_point(R, u1, g16r);
+    gphase29_point(R, u1, gc);
     gacc29_store(gacc, s.cap, i, R);
 }
 
@@ -127,7 +168,7 @@ SBV_HD bool qphase29_lane(const Scratch& s, size_t i, u32 slot, u32 nkeys, const
 
 // registered key: u1 * G + u2 * Q in one pass
 SBV_HD bool verify29_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys, const apt* ktab, const uint8_t* kvalid,
-                                const apt* g16r) {
+                                const gcomb& gc) {
     u256 r, u1, u2;
     soa_load(r, s.r, s.cap, i);
     soa_load(u1, s.u1, s.cap, i);
@@ -137,9 +178,47 @@ SBV_HD bool verify29_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys,
     ok = ok && kvalid[slot] != 0;
     const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
     xyzz R;
-    gphase29_point(R, u1, g16r);
+    gphase29_point(R, u1, gc);
     qphase29_point(R, u2, qtab, 0, SBV_GTAB_WINDOWS);
     return ok && pt29_rx_matches(R, r);
+}
+
+// ---- registered-key form, several lanes per signature (the latency form, BASELINE.json's second metric) -------------------
+// The 50 comb terms of u1 * G + u2 * Q are independent, so SBV_COOP_LANES lanes each sum every SBV_COOP_LANES-th term and
+// the partial sums meet in a butterfly of exact XYZZ additions (pt29_add): ~10 additions deep instead of 50.
+SBV_HD void keyed29_partial_lane(xyzz& R, const u256& u1, const u256& u2, const apt* qtab, const gcomb& gc, int sub) {
+    u288 k1;
+    gcomb_recode(k1, u1, gc.bits, gc.windows);
+    u256 k2;
+    const u32 top2 = add_const_limbs(k2, u2, 0x80808080u);
+    pt29_set_inf(R);
+    const int kSteps = gc.windows + SBV_GTAB_WINDOWS;
+    auto locate = [&](int t, bool& neg, bool& skip) -> const apt* {
+        if (t < gc.windows) {
+            u32 idx;
+            gcomb_digit(k1, gc.bits, t, idx, neg, skip);
+            return gc.tab + ((size_t)t << (gc.bits - 1)) + idx;
+        }
+        int idx;
+        comb_digit(k2, top2, t - gc.windows, idx, neg, skip);
+        return qtab + (size_t)(t - gc.windows) * SBV_GTAB_PER_WINDOW + idx;
+    };
+    bool neg, skip;
+    raw_apt cur;
+    raw_apt_load(cur, locate(sub, neg, skip));
+    SBV_NOUNROLL
+    for (int t = sub; t < kSteps; t += SBV_COOP_LANES) {
+        const int tn = t + SBV_COOP_LANES < kSteps ? t + SBV_COOP_LANES : t;
+        bool negn, skipn;
+        raw_apt nxt;
+        raw_apt_load(nxt, locate(tn, negn, skipn));
+        if (!skip) {
+            apt29 q;
+            raw_apt_unpack(q, cur);
+            pt29_madd(R, q, neg);
+        }
+        cur = nxt; neg = negn; skip = skipn;
+    }
 }
 
 // ---- table conversion: entries of the 8 x 32 Montgomery domain (R = 2^256, p256_core.h generators) -> R = 2^261 ----

@@ -22,6 +22,7 @@
 #include "p256_fe.h"
 #include "p256_pt.h"
 #include "p256_sc.h"
+#include "p256_sc29.h"
 
 namespace sbv {
 
@@ -117,6 +118,76 @@ SBV_HD void prep_chunk(TupleWords words, size_t n, const Scratch& sc_, size_t fi
         sc_mul(u2, w, r);
         soa_store(sc_.u1, sc_.cap, idx, u1);
         soa_store(sc_.u2, sc_.cap, idx, u2);
+    }
+}
+
+// The same stage A on the carry-free representation (p256_sc29.h): identical results (u1, u2, r, ok, keys in the
+// scratch), identical thread -> tuple mapping and Montgomery's trick along the thread's chunk, but every product is
+// 81 independent multiply-accumulates instead of a CIOS loop of dependent carry chains.  Prefix products and s*R are
+// parked between the two passes as canonical 256-bit words in the scratch planes stage B overwrites anyway.
+template <bool HAS_Q, typename TupleWords>
+SBV_HD void prep_chunk29(TupleWords words, size_t n, const Scratch& sc_, size_t first, size_t step, int T) {
+    const sc n_ = sc_n();
+    const fe p_ = fe_p();
+    const fe29 one = s29_one();
+    fe29 acc = one;
+    for (int k = 0; k < T; ++k) {
+        const size_t idx = first + (size_t)k * step;
+        auto w = words(k, idx);
+        if (idx < n) {
+            u256 r, s, e, qx, qy;
+            tuple_field(r, w, 0);
+            tuple_field(s, w, 1);
+            tuple_field(e, w, 2);
+            bool ok = !is_zero256(r) && lt256(r, n_) && !is_zero256(s) && lt256(s, n_);
+            if (HAS_Q) {
+                tuple_field(qx, w, 3);
+                tuple_field(qy, w, 4);
+                ok = ok && lt256(qx, p_) && lt256(qy, p_);
+            }
+            sc_cond_sub_n(e, e, 0);            // hashToNat: e < 2^256 < 2N, one conditional subtraction
+            fe29 sL, sM;
+            f29_unpack(sL, s.v);               // garbage if s >= N (still a bounded operand), replaced below
+            s29_mul(sM, sL, s29_r2());
+            f29_select(sM, ok, sM, one);       // keep the product chain invertible
+            u256 tw;
+            s29_store_canon(tw, acc);          // exclusive prefix product
+            soa_store(sc_.u1, sc_.cap, idx, tw);
+            s29_store_canon(tw, sM);
+            soa_store(sc_.sm, sc_.cap, idx, tw);
+            soa_store(sc_.u2, sc_.cap, idx, e);
+            soa_store(sc_.r, sc_.cap, idx, r);
+            if (HAS_Q) {
+                soa_store(sc_.qx, sc_.cap, idx, qx);
+                soa_store(sc_.qy, sc_.cap, idx, qy);
+            }
+            sc_.ok[idx] = ok ? 1 : 0;
+            s29_mul(acc, acc, sM);
+        }
+    }
+    fe29 inv;
+    s29_inv(inv, acc);                          // (prod s_k)^-1, Montgomery form
+    for (int k = T - 1; k >= 0; --k) {
+        const size_t idx = first + (size_t)k * step;
+        if (idx >= n) continue;
+        u256 tw, e, r;
+        fe29 pre, sM, w, eL, rL, u;
+        soa_load(tw, sc_.u1, sc_.cap, idx);
+        f29_unpack(pre, tw.v);
+        soa_load(tw, sc_.sm, sc_.cap, idx);
+        f29_unpack(sM, tw.v);
+        soa_load(e, sc_.u2, sc_.cap, idx);
+        soa_load(r, sc_.r, sc_.cap, idx);
+        f29_unpack(eL, e.v);
+        f29_unpack(rL, r.v);
+        s29_mul(w, inv, pre);                  // s_k^-1 (Montgomery)
+        s29_mul(inv, inv, sM);                 // drop s_k from the running inverse
+        s29_mul(u, w, eL);                     // Montgomery(w) * plain(e) = plain(e * w)
+        s29_store_canon(tw, u);
+        soa_store(sc_.u1, sc_.cap, idx, tw);
+        s29_mul(u, w, rL);
+        s29_store_canon(tw, u);
+        soa_store(sc_.u2, sc_.cap, idx, tw);
     }
 }
 
@@ -563,6 +634,16 @@ inline void build_g16_window(int j, apt* out_row) {
     apt bases[SBV_G16_WINDOWS];
     comb_bases(gx, gy, 16, j + 1, bases);
     comb_window(bases[j], SBV_G16_PER_WINDOW, out_row);
+}
+
+// window j of the `bits`-wide comb of G (8 x 32 Montgomery domain; converted for the carry-free kernels by apt_to_r261)
+inline void build_gcomb_window(int bits, int j, apt* out_row) {
+    const u256 gx = {{0xD898C296u, 0xF4A13945u, 0x2DEB33A0u, 0x77037D81u, 0x63A440F2u, 0xF8BCE6E5u, 0xE12C4247u, 0x6B17D1F2u}};
+    const u256 gy = {{0x37BF51F5u, 0xCBB64068u, 0x6B315ECEu, 0x2BCE3357u, 0x7C0F9E16u, 0x8EE7EB4Au, 0xFE1A7F9Bu, 0x4FE342E2u}};
+    apt* bases = new apt[j + 1];
+    comb_bases(gx, gy, bits, j + 1, bases);
+    comb_window(bases[j], 1 << (bits - 1), out_row);
+    delete[] bases;
 }
 
 }  // namespace sbv

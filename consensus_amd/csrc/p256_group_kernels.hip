@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64) void k_keytab29_fill(GroupState g, u32* __restr
 // 3 waves/SIMD register budget (on its own stream it ran at 234 VGPRs and squeezed the kernel it
 // overlapped down to one wave per SIMD).  Remaining blocks: u1 * G for every tuple of the batch.
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_gphase_generic(Scratch s, size_t n, GroupState g, u32* __restrict__ qtab,
-                                                                       const apt* __restrict__ g16, const apt* __restrict__ g16r,
+                                                                       const apt* __restrict__ g16, gcomb g16r,
                                                                        u32* __restrict__ gacc, uint8_t* __restrict__ acc,
                                                                        unsigned generic_blocks, size_t first, size_t end) {
     if (blockIdx.x < generic_blocks) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_verify_k
 //   side_a: insert assign | bases chunk 0 | bases chunk 1 | ...
 //   side_b:        wait(assign) split | wait(bases c) windows chunk c ...
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b,
-                                      u32* d_qtab, const apt* d_g16, const apt* d_g16r, uint8_t* d_bitmap, hipStream_t stream,
+                                      u32* d_qtab, const apt* d_g16, const gcomb& d_g16r, uint8_t* d_bitmap, hipStream_t stream,
                                       const GroupSync& y, hipEvent_t after_prep, hipEvent_t* prof, int* prof_pairs) {
     if (n == 0) return hipSuccess;
     GroupState g;

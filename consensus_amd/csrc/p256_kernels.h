@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "p256_core.h"
+#include "p256_comb29.h"
 
 #define SBV_TUPLE_BYTES 160
 #define SBV_VERIFY_BLOCK 256
@@ -14,11 +15,12 @@ hipError_t launch_p256_prep(const uint8_t* d_tuples, size_t n, const Scratch& s,
 size_t prep_block_tuples(size_t n);
 hipError_t launch_p256_prep_blocks(const uint8_t* d_tuples, size_t n, const Scratch& s, hipStream_t stream, unsigned block_lo, unsigned block_hi);
 hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
-                                    const uint8_t* d_kvalid, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
+                                    const uint8_t* d_kvalid, const gcomb& d_gcomb, uint8_t* d_bitmap, uint8_t* d_rerun,
                                     hipStream_t stream);
+void host_build_gcomb(int bits, apt* out);   // `bits`-wide comb of G, 8 x 32 Montgomery domain: gcomb_entries(bits) entries
 hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const uint8_t* d_sigs, const u64* d_soff, size_t n,
                                u32* d_rsh, hipStream_t stream);
-// comb table (33 x 128 affine multiples) of a registered key; false if the key is not a valid curve point
+// comb table (33 x 128 affine multiples, R = 2^261 domain) of a registered key; false if the key is not a valid curve point
 bool host_build_key_table(const uint8_t q[64], apt* out);
 #define SBV_KEYTAB_ENTRIES (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW)
 // d_rerun: ceil(n/64) bytes of per-wavefront flags (fast pass -> exact pass)
@@ -58,7 +60,7 @@ struct GroupSync {
 // events, a pair around every Q-phase launch; *prof_pairs = the number of pairs used.
 // d_g16: 16-bit comb of G in the 8 x 32 Montgomery domain (generic kernel); d_g16r: the same points for the carry-free field
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b, u32* d_qtab,
-                                      const apt* d_g16, const apt* d_g16r, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y,
+                                      const apt* d_g16, const gcomb& d_g16r, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y,
                                       hipEvent_t after_prep = nullptr, hipEvent_t* prof = nullptr, int* prof_pairs = nullptr);
 void host_convert_table_r261(const apt* in, apt* out, size_t count);   // 8 x 32 Montgomery entries -> R = 2^261 domain (host threads)
 void host_build_gtable(apt* out);   // 33 x 128 affine multiples of G (8-bit comb; host signer, key tables)

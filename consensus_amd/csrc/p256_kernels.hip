@@ -59,7 +59,7 @@ __device__ __forceinline__ void prep_body(const uint8_t* __restrict__ tuples, si
         __syncthreads();
         return LdsTuple{lds + lane * kPitch};
     };
-    prep_chunk<HAS_Q>(words, n, s, block_first + (size_t)lane, (size_t)kPrepLanes, T);
+    prep_chunk29<HAS_Q>(words, n, s, block_first + (size_t)lane, (size_t)kPrepLanes, T);
 }
 
 // block_off: the launch covers workgroups [block_off, block_off + gridDim.x) of the batch — the grouped step runs stage A in
@@ -97,47 +97,30 @@ __device__ __forceinline__ void finish_wave(bool accept, bool need_exact, size_t
     }
 }
 
-// Stage B, registered-key form: 66 mixed additions per lane from two combs (G and the key's).
-template <bool FAST>
-__device__ __forceinline__ void verify_keyed_body(const Scratch& s, size_t n, const u32* __restrict__ slots, u32 nkeys,
-                                                  const apt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
-                                                  const apt* __restrict__ gtab, uint8_t* __restrict__ bitmap,
-                                                  uint8_t* __restrict__ rerun) {
+// Stage B, registered-key form: 17 + 33 mixed additions per lane from two combs (G and the key's), on the carry-free
+// field (p256_comb29.h); both tables in the R = 2^261 domain.
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed(Scratch s, size_t n, const u32* __restrict__ slots,
+                                                                          u32 nkeys, const apt* __restrict__ ktab,
+                                                                          const uint8_t* __restrict__ kvalid,
+                                                                          gcomb g16r, uint8_t* __restrict__ bitmap) {
     const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
-    if (!FAST && rerun && !rerun[i >> 6]) return;        // wave-uniform: nothing fired in this wavefront
     bool accept = false;
-    u32 sticky = 0;
-    if (i < n) accept = verify_lane_keyed<FAST>(s, i, slots[i], nkeys, ktab, kvalid, gtab, &sticky);
-    finish_wave<FAST>(accept, sticky == 0xFFFFFFFFu, i, n, bitmap, rerun);
-}
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_keyed_fast(Scratch s, size_t n, const u32* __restrict__ slots,
-                                                                       u32 nkeys, const apt* __restrict__ ktab,
-                                                                       const uint8_t* __restrict__ kvalid,
-                                                                       const apt* __restrict__ gtab,
-                                                                       uint8_t* __restrict__ bitmap, uint8_t* __restrict__ rerun) {
-    verify_keyed_body<true>(s, n, slots, nkeys, ktab, kvalid, gtab, bitmap, rerun);
-}
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_keyed(Scratch s, size_t n, const u32* __restrict__ slots,
-                                                                             u32 nkeys, const apt* __restrict__ ktab,
-                                                                             const uint8_t* __restrict__ kvalid,
-                                                                             const apt* __restrict__ gtab,
-                                                                             uint8_t* __restrict__ bitmap,
-                                                                             uint8_t* __restrict__ rerun) {
-    verify_keyed_body<false>(s, n, slots, nkeys, ktab, kvalid, gtab, bitmap, rerun);
+    if (i < n) accept = verify29_lane_keyed(s, i, slots[i], nkeys, ktab, kvalid, g16r);
+    finish_wave<false>(accept, false, i, n, bitmap, nullptr);
 }
 
 // Registered-key form, SBV_COOP_LANES lanes per signature (p256_core.h): the latency kernel for small batches.
 // A wavefront holds 8 signatures = exactly one byte of the bitmap.
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_keyed_coop(Scratch s, size_t n, const u32* __restrict__ slots,
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_coop(Scratch s, size_t n, const u32* __restrict__ slots,
                                                                             u32 nkeys, const apt* __restrict__ ktab,
                                                                             const uint8_t* __restrict__ kvalid,
-                                                                            const apt* __restrict__ g16, uint8_t* __restrict__ bitmap) {
+                                                                            gcomb g16, uint8_t* __restrict__ bitmap) {
     const size_t lane_g = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     const size_t i = lane_g / SBV_COOP_LANES;
     const int sub = (int)(lane_g % SBV_COOP_LANES);
     const bool active = i < n;
-    jpt R;
-    pt_set_inf(R);
+    xyzz R;
+    pt29_set_inf(R);
     bool ok = false;
     if (active) {
         u32 slot = slots[i];
@@ -147,25 +130,27 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_keyed_coop(Scr
         u256 u1, u2;
         soa_load(u1, s.u1, s.cap, i);
         soa_load(u2, s.u2, s.cap, i);
-        keyed_partial_lane(R, u1, u2, ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW), g16, sub);
+        keyed29_partial_lane(R, u1, u2, ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW), g16, sub);
     }
     // butterfly: after log2(lanes) exchanges every lane of the group holds the whole sum
     SBV_NOUNROLL
     for (int off = SBV_COOP_LANES / 2; off >= 1; off >>= 1) {
-        jpt P;
+        xyzz P;
         SBV_UNROLL
-        for (int l = 0; l < 8; ++l) {
+        for (int l = 0; l < 9; ++l) {
             P.X.v[l] = __shfl_xor(R.X.v[l], off, 64);
             P.Y.v[l] = __shfl_xor(R.Y.v[l], off, 64);
-            P.Z.v[l] = __shfl_xor(R.Z.v[l], off, 64);
+            P.ZZ.v[l] = __shfl_xor(R.ZZ.v[l], off, 64);
+            P.ZZZ.v[l] = __shfl_xor(R.ZZZ.v[l], off, 64);
         }
-        pt_add_jac(R, P);
+        P.inf = __shfl_xor(R.inf ? 1 : 0, off, 64) != 0;
+        pt29_add(R, P);
     }
     bool accept = false;
     if (active && sub == 0) {
         u256 r;
         soa_load(r, s.r, s.cap, i);
-        accept = ok && rx_matches(R, r);
+        accept = ok && pt29_rx_matches(R, r);
     }
     const unsigned long long m = __ballot(accept);          // bits 0, 8, ..., 56
     if ((threadIdx.x & 63) == 0 && active) {                // lane 0 is sub 0 of the wavefront's first signature
@@ -274,25 +259,18 @@ static size_t coop_max_batch() {
 }
 
 hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
-                                    const uint8_t* d_kvalid, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
+                                    const uint8_t* d_kvalid, const gcomb& d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
                                     hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    if (n <= coop_max_batch() && !two_pass()) {      // small batch: latency matters, lanes are plentiful
+    if (n <= coop_max_batch()) {      // small batch: latency matters, lanes are plentiful
         const size_t lanes = n * SBV_COOP_LANES;
         hipLaunchKernelGGL(k_p256_verify_keyed_coop, dim3((unsigned)((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK)),
                            dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab, d_kvalid, d_gtab, d_bitmap);
         return hipGetLastError();
     }
     const unsigned grid = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
-    uint8_t* rr = nullptr;                 // nullptr = the exact kernel verifies every wavefront
-    if (two_pass()) {
-        hipLaunchKernelGGL(k_p256_verify_keyed_fast, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab,
-                           d_kvalid, d_gtab, d_bitmap, d_rerun);
-        if (force_exact()) (void)hipMemsetAsync(d_rerun, 1, (n + 63) / 64, stream);
-        rr = d_rerun;
-    }
-    hipLaunchKernelGGL(k_p256_verify_keyed, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab,
-                       d_kvalid, d_gtab, d_bitmap, rr);
+    (void)d_rerun;
+    hipLaunchKernelGGL(k_p256_verify_keyed, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab, d_kvalid, d_gtab, d_bitmap);
     return hipGetLastError();
 }
 
@@ -312,6 +290,13 @@ hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt
 
 void host_build_gtable(apt* out) { build_gtable(out); }
 
+void host_build_gcomb(int bits, apt* out) {
+    const int windows = (257 + bits - 1) / bits;
+    std::vector<std::thread> th;
+    for (int j = 0; j < windows; ++j) th.emplace_back([=] { build_gcomb_window(bits, j, out + ((size_t)j << (bits - 1))); });
+    for (auto& t : th) t.join();
+}
+
 void host_build_g16(apt* out) {
     std::vector<std::thread> th;
     for (int j = 0; j < SBV_G16_WINDOWS; ++j) th.emplace_back([j, out] { build_g16_window(j, out + (size_t)j * SBV_G16_PER_WINDOW); });
@@ -330,12 +315,14 @@ void host_convert_table_r261(const apt* in, apt* out, size_t count) {
     for (auto& x : th) x.join();
 }
 
+// comb of a registered key for the carry-free kernels (R = 2^261 domain)
 bool host_build_key_table(const uint8_t q[64], apt* out) {
     u256 x, y;
     from_be32(x, q);
     from_be32(y, q + 32);
     if (!key_is_valid(x, y)) return false;
     build_comb_table(x, y, out);
+    for (size_t k = 0; k < (size_t)SBV_KEYTAB_ENTRIES; ++k) { apt t; apt_to_r261(t, out[k]); out[k] = t; }
     return true;
 }
 

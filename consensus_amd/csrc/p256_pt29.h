@@ -125,6 +125,83 @@ SBV_HD void pt29_madd(xyzz& R, const apt29& q, bool neg) {
     f29_mulx(R.ZZZ, R.ZZZ, PPP);
 }
 
+// ---- general XYZZ doubling and addition (the lanes-per-signature butterfly of the latency kernel) ------------------------
+// dbl-2008-s-1 with a = -3: M = 3 (X - ZZ)(X + ZZ).  R finite or infinity (infinity stays infinity).
+SBV_HD void pt29_dbl(xyzz& R) {
+    if (R.inf) return;
+    fe29 U, V, W, S, M, t1, t2, X3, Y3;
+    f29_add(U, R.Y, R.Y);
+    f29_norm(U, U);
+    f29_sqr(V, U);
+    f29_mul(W, U, V);
+    f29_mul(S, R.X, V);
+    f29_sub(t1, R.X, R.ZZ);
+    f29_add(t2, R.X, R.ZZ);
+    f29_norm(t2, t2);
+    f29_mul(M, t1, t2);
+    f29_add(t1, M, M);
+    f29_add(M, M, t1);
+    f29_norm(M, M);
+    f29_sqr(t1, M);
+    f29_sub(t1, t1, S);
+    f29_sub(t1, t1, S);
+    f29_norm_red(X3, t1);                       // X3 = M^2 - 2 S
+    f29_sub(t1, S, X3);
+    f29_mul(t1, M, t1);
+    f29_mul(Y3, W, R.Y);
+    f29_sub(Y3, t1, Y3);
+    f29_norm_red(R.Y, Y3);                      // Y3 = M (S - X3) - W Y1
+    R.X = X3;
+    f29_mul(R.ZZ, V, R.ZZ);
+    f29_mul(R.ZZZ, W, R.ZZZ);
+}
+// R += Q, both XYZZ (add-2008-s, 12M + 2S), exact for every input: either operand may be infinity, R == Q doubles,
+// R == -Q gives infinity.  Coordinates as the comb phases leave them (X, Y value-reduced; ZZ, ZZZ within +-5 p).
+SBV_HD void pt29_add(xyzz& R, const xyzz& Q) {
+    if (Q.inf) return;
+    if (R.inf) { R = Q; return; }
+    fe29 U1, U2, S1, S2, P, Rr, PP, PPP, Qv, t, V;
+    f29_mulx(U1, R.X, Q.ZZ);
+    f29_mulx(U2, Q.X, R.ZZ);
+    f29_mulx(S1, R.Y, Q.ZZZ);
+    f29_mulx(S2, Q.Y, R.ZZZ);
+    f29_sub(P, U2, U1);
+    f29_norm_red(P, P);                         // +-8.4 p -> [0, p): keeps |A||B| of the products below in range
+    f29_sub(Rr, S2, S1);
+    f29_norm_red(Rr, Rr);
+    if (f29_maybe_zero(P)) {
+        if (f29_is_zero_slow(P)) {
+            if (f29_is_zero(Rr)) pt29_dbl(R);
+            else pt29_set_inf(R);
+            return;
+        }
+    }
+    f29_sqrx(PP, P);
+    f29_mulx(PPP, P, PP);
+    f29_mulx(Qv, U1, PP);
+    f29_cols c;
+    f29_cols_zero(c);
+    f29_cols_sqr(c, Rr);
+    f29_add(V, PPP, Qv);
+    f29_add(V, V, Qv);
+    f29_cols_sub_val(c, V);
+    fe29 X3;
+    f29_reduce_x(X3, c);
+    f29_red_q(X3);
+    f29_sub(t, Qv, X3);
+    f29_neg(V, S1);
+    f29_cols_zero(c);
+    f29_cols_mul(c, Rr, t);
+    f29_cols_mul(c, V, PPP);
+    f29_reduce_x(R.Y, c);
+    f29_red_q(R.Y);
+    R.X = X3;
+    f29_mulx(t, R.ZZ, Q.ZZ);
+    f29_mulx(R.ZZ, t, PP);
+    f29_mulx(t, R.ZZZ, Q.ZZZ);
+    f29_mulx(R.ZZZ, t, PPP);
+}
+
 // R.x mod N == r  <=>  R != infinity and (X == r ZZ  or  (r + N < p and X == (r + N) ZZ))  (mod p); r < N plain.
 SBV_HD bool pt29_rx_matches(const xyzz& R, const u256& r) {
     if (R.inf) return false;

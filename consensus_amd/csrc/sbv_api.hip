@@ -50,7 +50,8 @@ struct Context {
     uint8_t* d_scratch = nullptr;
     u32* d_qtab = nullptr;
     sbv::apt* d_gtab = nullptr;
-    sbv::apt* d_g16r = nullptr;          // the same comb of G for the carry-free field (R = 2^261 domain)
+    sbv::apt* d_g16r = nullptr;          // the comb of G for the carry-free kernels (R = 2^261 domain, g_bits-wide windows)
+    int g_bits = 16;
     uint8_t* d_bitmap = nullptr;
     uint8_t* d_rerun = nullptr;         // per-wavefront flags between the fast and the exact stage-B pass
     uint8_t* h_bitmap = nullptr;        // pinned
@@ -262,7 +263,7 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
     }
     if (grouped) {           // stage A is enqueued by the grouped launcher, in slices pipelined with the G phase
-        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, c.d_g16r, d_bitmap, stream, c.gsync,
+        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, sbv::gcomb_make(c.d_g16r, c.g_bits), d_bitmap, stream, c.gsync,
                                                              after_prep, dom, dom_pairs));
         return SBV_OK;
     }
@@ -279,7 +280,7 @@ int enqueue_keyed(Context& c, const uint8_t* d_rsh, const u32* d_slots, size_t n
     const sbv::Scratch s = scratch_view(c);
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_rsh, n, s, stream, true));
     if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
-    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_keyed(s, n, d_slots, (u32)c.nkeys, c.d_ktab, c.d_kvalid, c.d_gtab, d_bitmap, c.d_rerun, stream));
+    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_keyed(s, n, d_slots, (u32)c.nkeys, c.d_ktab, c.d_kvalid, sbv::gcomb_make(c.d_g16r, c.g_bits), d_bitmap, c.d_rerun, stream));
     return SBV_OK;
 }
 
@@ -331,12 +332,21 @@ extern "C" int sbv_device_count(void) {
 namespace {
 // The G combs are the same for every device: built once per process on the host, uploaded to each device.
 std::vector<sbv::apt> g_h_gtab, g_h_g16r;
+int g_gbits = 20;                     // window width of the carry-free kernels' comb of G (SBV_G_BITS: 12..22)
 std::once_flag g_tables_once;
 void build_host_tables() {
+    if (const char* e = getenv("SBV_G_BITS")) { const int v = atoi(e); if (v >= 12 && v <= 22) g_gbits = v; }
     g_h_gtab.resize(SBV_G16_ENTRIES);
-    sbv::host_build_g16(g_h_gtab.data());                 // 16-bit comb, 35.7 MB, 17 host threads
-    g_h_g16r.resize(SBV_G16_ENTRIES);
-    sbv::host_convert_table_r261(g_h_gtab.data(), g_h_g16r.data(), SBV_G16_ENTRIES);
+    sbv::host_build_g16(g_h_gtab.data());                 // 16-bit comb for the generic kernel, 35.7 MB, 17 host threads
+    const size_t cnt = sbv::gcomb_entries(g_gbits);
+    g_h_g16r.resize(cnt);
+    if (g_gbits == 16) {
+        sbv::host_convert_table_r261(g_h_gtab.data(), g_h_g16r.data(), cnt);
+    } else {                                              // 20 bits: 13 x 2^19 entries = 436 MB, built once per process
+        std::vector<sbv::apt> tmp(cnt);
+        sbv::host_build_gcomb(g_gbits, tmp.data());
+        sbv::host_convert_table_r261(tmp.data(), g_h_g16r.data(), cnt);
+    }
 }
 
 // c.mu held by the caller
@@ -357,7 +367,6 @@ int init_context(Context& c, int device) {
         return SBV_ENODEV;
     }
     HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking));
     for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b})
         HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
     for (hipEvent_t* ev : group_events(c)) HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(ev, hipEventDisableTiming));
@@ -379,8 +388,9 @@ int init_context(Context& c, int device) {
     std::call_once(g_tables_once, build_host_tables);
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_gtab, gcount * sizeof(sbv::apt)));
     HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_gtab, g_h_gtab.data(), gcount * sizeof(sbv::apt), hipMemcpyHostToDevice));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_g16r, gcount * sizeof(sbv::apt)));
-    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_g16r, g_h_g16r.data(), gcount * sizeof(sbv::apt), hipMemcpyHostToDevice));
+    c.g_bits = g_gbits;
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_g16r, g_h_g16r.size() * sizeof(sbv::apt)));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_g16r, g_h_g16r.data(), g_h_g16r.size() * sizeof(sbv::apt), hipMemcpyHostToDevice));
     if (const char* e = getenv("SBV_GROUP")) c.group_enabled = e[0] != '0';
     c.device = device;
     c.ready = true;
@@ -634,6 +644,10 @@ extern "C" int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* a
             if (rc != SBV_OK) break;
             if ((rc = ensure_capacity(c, m)) != SBV_OK) break;
         }
+        // The copy stream is created on first use: a process gets four hardware queues, and a fifth stream created at
+        // sbv_init aliased one of the grouped step's side streams — the table kernels then queued behind the G phase
+        // (measured: 3.9 -> 4.6 ms per 2^20 batch through the device-pointer entry, which never copies).
+        if (!c.copy_stream && hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = SBV_EDEVICE; break; }
         const int s = c.stage[0].used ? 1 : 0;
         StageSlot& sl = c.stage[s];
         if ((rc = grow_slot(c, sl, m)) != SBV_OK) break;

@@ -158,6 +158,19 @@ void sbvh_proposal_digest(const void* payload, size_t pl, const void* header, si
     memcpy(hex_out, d.c_str(), 65);
 }
 void sbvh_compute_quorum(uint64_t n, int* q, int* f) { compute_quorum(n, q, f); }
+// CommitSignaturesDigest over n signatures given as parallel arrays; returns 32 (digest written) or 0 (empty list -> nil)
+size_t sbvh_commit_signatures_digest(const uint64_t* ids, const void* const* values, const size_t* value_lens, const void* const* msgs,
+                                     const size_t* msg_lens, size_t n, uint8_t out32[32]) {
+    std::vector<Signature> sigs(n);
+    for (size_t i = 0; i < n; ++i) {
+        sigs[i].id = ids[i];
+        sigs[i].value.assign((const char*)values[i], value_lens[i]);
+        sigs[i].msg.assign((const char*)msgs[i], msg_lens[i]);
+    }
+    const bytes d = commit_signatures_digest(sigs);
+    if (d.size() == 32) memcpy(out32, d.data(), 32);
+    return d.size();
+}
 
 // ---- synthetic Ed25519 traffic (tools/bench_ed25519.py) --------------------------------------------------
 // nkeys RFC 8032 keys from seeds SHA-512("sbv-ed-key" | seed | i)[0..32), tuple i = signature by key i % nkeys over a

@@ -61,6 +61,34 @@ std::string proposal_digest(const Proposal& p) {
     return hex;
 }
 
+// CommitSignaturesDigest (internal/bft/util.go:564-595): asn1.Marshal(IntDoubleBytes{A: []IntDoubleByte{A int64; B, C []byte}})
+// = SEQUENCE { SEQUENCE OF SEQUENCE { INTEGER signer, OCTET STRING value, OCTET STRING msg } }, then SHA-256.
+// Go returns nil for an empty list; so does this (empty string).
+bytes asn1_marshal_commit_signatures(const std::vector<Signature>& sigs) {
+    bytes list;
+    for (const Signature& s : sigs) {
+        bytes item;
+        der_int64(item, (int64_t)s.id);
+        der_octets(item, s.value);
+        der_octets(item, s.msg);
+        list.push_back(0x30);
+        der_len(list, item.size());
+        list += item;
+    }
+    bytes inner;
+    inner.push_back(0x30);
+    der_len(inner, list.size());
+    inner += list;
+    bytes out;
+    out.push_back(0x30);
+    der_len(out, inner.size());
+    return out + inner;
+}
+bytes commit_signatures_digest(const std::vector<Signature>& sigs) {
+    if (sigs.empty()) return bytes();
+    return sha256(asn1_marshal_commit_signatures(sigs));
+}
+
 bytes request_unsigned(const std::string& client_id, const std::string& id, const bytes& payload) {
     bytes o;
     put_u16(o, client_id.size()); o += client_id;

@@ -33,6 +33,12 @@ bytes asn1_marshal_proposal(const Proposal& p);     // Go asn1.Marshal(Proposal{
 bytes proposal_digest_raw(const Proposal& p);       // 32-byte SHA-256 of the above
 std::string proposal_digest(const Proposal& p);     // hex, == Proposal.Digest()
 
+// CommitSignaturesDigest (internal/bft/util.go:564-595): SHA-256 over Go's asn1.Marshal of the signature list
+// (IntDoubleBytes); 32 raw bytes, or empty for an empty list (Go returns nil).  It is what a ViewData's
+// last-decision signatures are summarised to in the view-change path.
+bytes asn1_marshal_commit_signatures(const std::vector<Signature>& sigs);
+bytes commit_signatures_digest(const std::vector<Signature>& sigs);
+
 // ---- client request:  u16 len|ClientID  u16 len|ID  u32 len|payload  u16 len|sig  (big-endian lengths)
 struct Request {
     std::string client_id, id;

@@ -41,18 +41,26 @@ static const apt* g16tab() {        // 16-bit comb for G, as the verify kernels 
     return g_g16;
 }
 
-static apt* g_g16r = nullptr;
-static const apt* g16rtab() {       // the same comb in the R = 2^261 domain (carry-free field)
-    if (!g_g16r) {
-        const apt* src = g16tab();
-        const size_t count = (size_t)SBV_G16_WINDOWS * SBV_G16_PER_WINDOW;
-        g_g16r = (apt*)aligned_alloc(64, sizeof(apt) * count);
+static apt* g_gc_tab = nullptr;
+static int g_gc_bits = 16;
+// the comb of G for the carry-free kernels (R = 2^261 domain); sbve_set_gcomb_bits picks the window width
+static gcomb g16rtab() {
+    if (!g_gc_tab) {
+        const size_t count = gcomb_entries(g_gc_bits);
+        g_gc_tab = (apt*)aligned_alloc(64, sizeof(apt) * count);
+        apt* tmp = (apt*)aligned_alloc(64, sizeof(apt) * count);
+        const int windows = (257 + g_gc_bits - 1) / g_gc_bits, bits = g_gc_bits;
         std::vector<std::thread> th;
-        for (int t = 0; t < 8; ++t)
-            th.emplace_back([=] { for (size_t k = count * t / 8; k < count * (t + 1) / 8; ++k) apt_to_r261(g_g16r[k], src[k]); });
+        for (int j = 0; j < windows; ++j) th.emplace_back([=] { build_gcomb_window(bits, j, tmp + ((size_t)j << (bits - 1))); });
         for (auto& t : th) t.join();
+        th.clear();
+        apt* dst = g_gc_tab;
+        for (int t = 0; t < 8; ++t)
+            th.emplace_back([=] { for (size_t k = count * t / 8; k < count * (t + 1) / 8; ++k) apt_to_r261(dst[k], tmp[k]); });
+        for (auto& t : th) t.join();
+        free(tmp);
     }
-    return g_g16r;
+    return gcomb_make(g_gc_tab, g_gc_bits);
 }
 
 struct HostWords {
@@ -67,6 +75,8 @@ struct HostWords {
 
 extern "C" {
 
+void sbve_set_gcomb_bits(int bits) { if (bits != g_gc_bits) { free(g_gc_tab); g_gc_tab = nullptr; g_gc_bits = bits; } }
+
 // block = threads per emulated workgroup, T = tuples per thread (chunk for Montgomery's trick)
 void sbve_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap, int block, int T) {
     size_t cap = (n + 63) & ~(size_t)63;
@@ -78,7 +88,7 @@ void sbve_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap, in
     const size_t nblocks = (n + per_block - 1) / per_block;
     HostWords hw{tuples, 160};
     for (size_t b = 0; b < nblocks; ++b)
-        for (int t = 0; t < block; ++t) prep_chunk<true>(hw, n, s, b * per_block + t, (size_t)block, T);
+        for (int t = 0; t < block; ++t) prep_chunk29<true>(hw, n, s, b * per_block + t, (size_t)block, T);
     memset(bitmap, 0, (n + 7) / 8);
     u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB_ENTRIES * 40 * 4);
     for (size_t i = 0; i < n; ++i) {
@@ -114,7 +124,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     const int T = 4;
     const size_t per_block = (size_t)64 * T, nblocks = (n + per_block - 1) / per_block;
     for (size_t b = 0; b < nblocks; ++b)
-        for (int t = 0; t < 64; ++t) prep_chunk<true>(hw, n, s, b * per_block + t, 64, T);
+        for (int t = 0; t < 64; ++t) prep_chunk29<true>(hw, n, s, b * per_block + t, 64, T);
     std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(max_groups ? max_groups : 1), counters(4, 0),
         grp_idx(cap), ung_idx(cap), slots(cap);
     GroupState g{};
@@ -182,7 +192,7 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
     const size_t nblocks = (n + per_block - 1) / per_block;
     HostWords hw{rsh, 96};
     for (size_t b = 0; b < nblocks; ++b)
-        for (int t = 0; t < block; ++t) prep_chunk<false>(hw, n, s, b * per_block + t, (size_t)block, T);
+        for (int t = 0; t < block; ++t) prep_chunk29<false>(hw, n, s, b * per_block + t, (size_t)block, T);
     const size_t per_key = (size_t)SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW;
     std::vector<apt> ktab(per_key * (nkeys ? nkeys : 1));
     std::vector<uint8_t> kvalid(nkeys ? nkeys : 1, 0);
@@ -191,15 +201,18 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
         from_be32(x, keys + 64 * k);
         from_be32(y, keys + 64 * k + 32);
         kvalid[k] = key_is_valid(x, y) ? 1 : 0;
-        if (kvalid[k]) build_comb_table(x, y, &ktab[per_key * k]);
+        if (kvalid[k]) {
+            build_comb_table(x, y, &ktab[per_key * k]);
+            for (size_t e = 0; e < per_key; ++e) { apt t; apt_to_r261(t, ktab[per_key * k + e]); ktab[per_key * k + e] = t; }
+        }
     }
     memset(bitmap, 0, (n + 7) / 8);
     for (size_t i = 0; i < n; ++i) {
         bool accept;
         if (!g_keyed_coop) {
-            accept = verify_lane_keyed(s, i, slots[i], nkeys, ktab.data(), kvalid.data(), g16tab());
+            accept = verify29_lane_keyed(s, i, slots[i], nkeys, ktab.data(), kvalid.data(), g16rtab());
         } else {
-            // k_p256_verify_keyed_coop: SBV_COOP_LANES partial sums, xor-butterfly of exact Jacobian additions
+            // k_p256_verify_keyed_coop: SBV_COOP_LANES partial sums, xor-butterfly of exact XYZZ additions
             u32 slot = slots[i];
             bool okk = s.ok[i] != 0 && slot < nkeys;
             if (slot >= nkeys) slot = 0;
@@ -208,16 +221,16 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
             soa_load(a, s.u1, s.cap, i);
             soa_load(b, s.u2, s.cap, i);
             soa_load(rr, s.r, s.cap, i);
-            jpt part[SBV_COOP_LANES];
-            for (int sub = 0; sub < SBV_COOP_LANES; ++sub) keyed_partial_lane(part[sub], a, b, &ktab[per_key * slot], g16tab(), sub);
+            xyzz part[SBV_COOP_LANES];
+            for (int sub = 0; sub < SBV_COOP_LANES; ++sub) keyed29_partial_lane(part[sub], a, b, &ktab[per_key * slot], g16rtab(), sub);
             for (int off = SBV_COOP_LANES / 2; off >= 1; off >>= 1) {
-                jpt nxt[SBV_COOP_LANES];
-                for (int sub = 0; sub < SBV_COOP_LANES; ++sub) { nxt[sub] = part[sub]; pt_add_jac(nxt[sub], part[sub ^ off]); }
+                xyzz nxt[SBV_COOP_LANES];
+                for (int sub = 0; sub < SBV_COOP_LANES; ++sub) { nxt[sub] = part[sub]; pt29_add(nxt[sub], part[sub ^ off]); }
                 for (int sub = 0; sub < SBV_COOP_LANES; ++sub) part[sub] = nxt[sub];
             }
-            accept = okk && rx_matches(part[0], rr);
+            accept = okk && pt29_rx_matches(part[0], rr);
             for (int sub = 1; sub < SBV_COOP_LANES; ++sub)           // every lane of the group must hold the same point
-                if ((okk && rx_matches(part[sub], rr)) != accept) g_coop_disagreements++;
+                if ((okk && pt29_rx_matches(part[sub], rr)) != accept) g_coop_disagreements++;
         }
         if (accept) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
     }
@@ -330,6 +343,10 @@ void sbve_fe_inv(const u32* a, u32* out) { fe x, z; memcpy(&x, a, 32); fe_inv(z,
 void sbve_mul_wide(const u32* a, const u32* b, u32* out16) { mul_wide(out16, a, b); }
 void sbve_sqr_wide(const u32* a, u32* out16) { sqr_wide(out16, a); }
 void sbve_mont_reduce(const u32* t16, u32* out) { fe z; fe_mont_reduce(z, t16); memcpy(out, &z, 32); }
+// scalar field on the carry-free representation (p256_sc29.h): raw limbs in / out
+void sbve_s29_mul(const i32* a, const i32* b, i32* out) { fe29 x, y, z; memcpy(&x, a, 36); memcpy(&y, b, 36); s29_mul(z, x, y); memcpy(out, &z, 36); }
+void sbve_s29_canon(const i32* a, i32* out) { fe29 x, z; memcpy(&x, a, 36); s29_canon(z, x); memcpy(out, &z, 36); }
+void sbve_s29_inv(const i32* a, i32* out) { fe29 x, z; memcpy(&x, a, 36); s29_inv(z, x); memcpy(out, &z, 36); }
 void sbve_sc_mul(const u32* a, const u32* b, u32* out) { sc x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); sc_mul(z, x, y); memcpy(out, &z, 32); }
 void sbve_sc_inv(const u32* a, u32* out) { sc x, z; memcpy(&x, a, 32); sc_inv(z, x); memcpy(out, &z, 32); }
 // division-step inversions (modinv30.h): Montgomery in/out wrappers and the plain-integer core (which: 0 = p, 1 = N, 2 = 2^255-19)

@@ -365,3 +365,31 @@ def test_grouped_verdicts_do_not_depend_on_tuple_order(emul, oracle, golden_vect
             emul.sbve_p256_verify_batch_grouped(blob, total, bm, 8, 64, 12, stats)
             got = _bitmap_list(bm.raw, total)
             assert got == [want[p] for p in perm], trial
+
+
+@pytest.mark.parametrize("bits", [10, 13, 18])
+def test_g_comb_window_width_does_not_change_verdicts(emul, oracle, golden_vectors, bits):
+    """The comb of G used by the carry-free kernels has a configurable window width (20 bits on the device: 13 additions
+    instead of 17).  Windows that do not align with 32-bit words (13, 18) and many short windows (10) must give the same
+    verdicts as the 16-bit table on the golden vectors (grouped path, every key grouped) and on a registered-key batch."""
+    emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+    n = 300
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0x6C + bits, n, 5, 4, tup, exp, 4)
+    allt = blob + tup.raw
+    total = len(allt) // 160
+    want = [v["accept"] for v in vs] + _bitmap_list(exp.raw, n)
+    emul.sbve_set_gcomb_bits(bits)
+    try:
+        bm = ctypes.create_string_buffer((total + 7) // 8)
+        stats = (ctypes.c_uint32 * 4)()
+        emul.sbve_p256_verify_batch_grouped(allt, total, bm, 1, 4096, 12, stats)
+        got = _bitmap_list(bm.raw, total)
+        bad = [i for i in range(total) if got[i] != want[i]]
+        assert not bad, (bits, bad[:8])
+    finally:
+        emul.sbve_set_gcomb_bits(16)

@@ -239,3 +239,26 @@ def test_pt29_madd_chain_matches_affine_sum_including_exceptional_cases(emul):
             assert emul.sbve_pt29_rx_matches(out, inf, words((r + 1) % ec.N)) == 0
         else:
             assert emul.sbve_pt29_rx_matches(out, inf, words(1)) == 0
+
+
+def test_s29_scalar_field_matches_bigint(emul):
+    """p256_sc29.h: Montgomery multiplication mod the group order N with R = 2^261, canonical form, inversion."""
+    N = ec.N
+    rng = random.Random(35)
+    out = I32x9()
+    rinv = pow(R, -1, N)
+    vals = [0, 1, N - 1, N, (1 << 256) - 1, R % N, (R * R) % N] + [rng.randrange(1 << 256) for _ in range(200)]
+    for i, a in enumerate(vals):
+        for b in (vals[(7 * i + 3) % len(vals)], vals[(13 * i + 5) % len(vals)]):
+            emul.sbve_s29_mul(L(tight(a)), L(tight(b)), out)
+            v = val(out)
+            assert all(0 <= int(out[k]) < (1 << 29) for k in range(8))
+            assert (v - a * b * rinv) % N == 0 and a * b // R <= v <= a * b // R + N + 1
+            emul.sbve_s29_canon(out, out)
+            assert val(out) == a * b * rinv % N
+    for a in [1, 2, N - 1] + [rng.randrange(1, N) for _ in range(40)]:
+        aM = a * R % N
+        emul.sbve_s29_inv(L(tight(aM)), out)
+        assert (val(out) - pow(a, -1, N) * R) % N == 0
+    emul.sbve_s29_inv(L(tight(0)), out)
+    assert val(out) % N == 0

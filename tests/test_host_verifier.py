@@ -456,3 +456,50 @@ def test_concurrent_first_callers_share_one_proposal_digest(hx):
     assert [r[1] for r in results] == [b"aux%d" % i for i in range(4)]
     other = (prop[0], b"hdr2", b"md", 0)
     assert hx.verify_consenter_sig(sigs[0], other)[0] == INVALID          # bound to the proposal it was signed for
+
+
+def test_commit_signatures_digest_matches_go_asn1(lib):
+    """f2: CommitSignaturesDigest (internal/bft/util.go:564-595) = SHA-256(asn1.Marshal(IntDoubleBytes{[]IntDoubleByte{A int64; B, C
+    []byte}})), restated independently here with struct.pack-level DER: SEQUENCE{SEQUENCE OF SEQUENCE{INTEGER, OCTET STRING,
+    OCTET STRING}}; an empty list gives nil."""
+    lib.sbvh_commit_signatures_digest.restype = ctypes.c_size_t
+    lib.sbvh_commit_signatures_digest.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t),
+                                                  ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_size_t, ctypes.c_char_p]
+
+    def der_int(v):
+        for n in range(1, 10):
+            try:
+                b = v.to_bytes(n, "big", signed=True)
+                break
+            except OverflowError:
+                continue
+        return b"\x02" + hostlib._der_len(len(b)) + b
+
+    def octets(b):
+        return b"\x04" + hostlib._der_len(len(b)) + b
+
+    def go_digest(sigs):
+        if not sigs:
+            return None
+        items = b"".join(b"\x30" + hostlib._der_len(len(body)) + body
+                         for body in (der_int(i) + octets(v) + octets(m) for i, v, m in sigs))
+        inner = b"\x30" + hostlib._der_len(len(items)) + items
+        return hashlib.sha256(b"\x30" + hostlib._der_len(len(inner)) + inner).digest()
+
+    cases = [[], [(1, b"v", b"m")], [(0, b"", b"")], [(127, b"a" * 70, b"b" * 200), (128, b"c" * 127, b"d" * 128), (255, b"", b"x")],
+             [(2 ** 40 + 3, bytes(range(256)) * 3, b"\x00" * 1000), (2 ** 63 - 1, b"\xff", b"\x80")],
+             [(i, bytes([i]) * i, bytes([255 - i]) * (3 * i)) for i in range(1, 60)]]
+    for sigs in cases:
+        n = len(sigs)
+        ids = (ctypes.c_uint64 * max(1, n))(*[s[0] for s in sigs])
+        vals = (ctypes.c_char_p * max(1, n))(*[s[1] for s in sigs])
+        vlen = (ctypes.c_size_t * max(1, n))(*[len(s[1]) for s in sigs])
+        msgs = (ctypes.c_char_p * max(1, n))(*[s[2] for s in sigs])
+        mlen = (ctypes.c_size_t * max(1, n))(*[len(s[2]) for s in sigs])
+        out = ctypes.create_string_buffer(32)
+        k = lib.sbvh_commit_signatures_digest(ids, vals, vlen, msgs, mlen, n, out)
+        want = go_digest(sigs)
+        if want is None:
+            assert k == 0
+        else:
+            assert k == 32 and out.raw == want, sigs[:1]
