@@ -236,6 +236,20 @@ def set_grouping(enabled: bool, min_batch: int = 0, min_count: int = 0, max_grou
     _check(load().sbv_p256_set_grouping(1 if enabled else 0, min_batch, min_count, max_groups))
 
 
+def key_cache(enabled: bool, capacity: int = 0) -> None:
+    """sbv_p256_key_cache: the persistent key-table cache of the grouped step (off also empties it)."""
+    lib = load()
+    lib.sbv_p256_key_cache.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    _check(lib.sbv_p256_key_cache(1 if enabled else 0, capacity))
+
+
+def key_cache_stats():
+    """(cached keys, groups of the last grouped batch that hit, that missed, capacity)"""
+    out = (ctypes.c_uint32 * 4)()
+    _check(load().sbv_p256_key_cache_stats(out))
+    return out[0], out[1], out[2], out[3]
+
+
 def parse_der(sig: bytes) -> Optional[bytes]:
     """Strict DER -> r|s (64 bytes), or None when Go's parseSignature would fail."""
     out = ctypes.create_string_buffer(64)

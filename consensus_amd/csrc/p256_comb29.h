@@ -92,11 +92,11 @@ SBV_HD void gcomb_digit(const u288& k, int bits, int j, u32& idx, bool& neg, boo
     skip = d == 0;
 }
 
-// R = u1 * G
-SBV_HD void gphase29_point(xyzz& R, const u256& u1, const gcomb& gc) {
+// R = u1 * G   (add_to_R: R += u1 * G)
+SBV_HD void gphase29_point(xyzz& R, const u256& u1, const gcomb& gc, bool add_to_R = false) {
     u288 k1;
     gcomb_recode(k1, u1, gc.bits, gc.windows);
-    pt29_set_inf(R);
+    if (!add_to_R) pt29_set_inf(R);
     u32 idx; bool neg, skip;
     gcomb_digit(k1, gc.bits, 0, idx, neg, skip);
     raw_apt cur;
@@ -181,6 +181,108 @@ SBV_HD bool verify29_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys,
     gphase29_point(R, u1, gc);
     qphase29_point(R, u2, qtab, 0, SBV_GTAB_WINDOWS);
     return ok && pt29_rx_matches(R, r);
+}
+
+// ---- generic form: the public key travels in the tuple and is seen once (no table worth building per batch) ---------------
+// u2 * Q with 64 signed 4-bit windows over a per-signature table of the AFFINE multiples 1..8 of Q (chain of 7 exact mixed
+// additions, one inversion per lane to normalise them: 64-byte entries instead of 160-byte Jacobian ones, 4.6 KB of table
+// traffic per signature instead of 10 KB), a Jacobian accumulator (4 doublings of 3M + 5S and one mixed addition per
+// window, fused reductions), then + u1 * G from the comb of G.  qtab: this lane's 8 x 16 words.
+#define SBV_QTAB29_WORDS (8 * 16 + 7 * 45 + 5)        // table + raw chain records, rounded to 448 words = 1792 bytes
+SBV_HD bool verify29_lane_generic(const Scratch& s, size_t i, u32* qtab, const gcomb& gc) {
+    u256 r, u1, u2, qx, qy;
+    soa_load(r, s.r, s.cap, i);
+    soa_load(u1, s.u1, s.cap, i);
+    soa_load(u2, s.u2, s.cap, i);
+    soa_load(qx, s.qx, s.cap, i);
+    soa_load(qy, s.qy, s.cap, i);
+    bool ok = s.ok[i] != 0;
+    apt29 Q;
+    f29_from_plain(Q.x, qx);
+    f29_from_plain(Q.y, qy);
+    {   // pointFromAffine: y^2 == x^3 - 3x + b
+        fe29 lhs, t, rhs;
+        f29_sqr(lhs, Q.y);
+        f29_sqr(t, Q.x);
+        f29_mul(rhs, t, Q.x);
+        f29_sub(rhs, rhs, Q.x);
+        f29_sub(rhs, rhs, Q.x);
+        f29_sub(rhs, rhs, Q.x);
+        f29_add(rhs, rhs, f29_b());
+        f29_sub(t, lhs, rhs);
+        ok = ok && f29_is_zero(t);
+    }
+    // table k * Q, k = 1..8: XYZZ chain, parked raw behind the table in the lane's strip, normalised with one inversion
+    {
+        u32 w[16];
+        f29_store_canon(w, Q.x); f29_store_canon(w + 8, Q.y);
+        SBV_UNROLL
+        for (int l = 0; l < 16; ++l) qtab[l] = w[l];
+        u32* raw = qtab + 8 * 16;               // 7 records of 45 words: X, Y, ZZ, ZZZ, prefix product
+        xyzz T;
+        T.X = Q.x; T.Y = Q.y; T.ZZ = f29_one(); T.ZZZ = f29_one(); T.inf = false;
+        fe29 acc = f29_one();
+        SBV_NOUNROLL
+        for (int k = 0; k < 7; ++k) {
+            pt29_madd(T, Q, false);             // k = 0 is Q + Q: the doubling branch
+            u32* rec = raw + k * 45;
+            SBV_UNROLL
+            for (int l = 0; l < 9; ++l) {
+                rec[l] = (u32)T.X.v[l]; rec[9 + l] = (u32)T.Y.v[l]; rec[18 + l] = (u32)T.ZZ.v[l]; rec[27 + l] = (u32)T.ZZZ.v[l];
+                rec[36 + l] = (u32)acc.v[l];
+            }
+            f29_mul(acc, acc, T.ZZZ);
+        }
+        fe29 inv;
+        f29_inv(inv, acc);                      // an off-curve "point" may give 0 here: garbage entries, ok is already false
+        SBV_NOUNROLL
+        for (int k = 6; k >= 0; --k) {
+            const u32* rec = raw + k * 45;
+            fe29 X, Y, ZZ, ZZZ, pre, i3, wv, w2;
+            SBV_UNROLL
+            for (int l = 0; l < 9; ++l) {
+                X.v[l] = (i32)rec[l]; Y.v[l] = (i32)rec[9 + l]; ZZ.v[l] = (i32)rec[18 + l]; ZZZ.v[l] = (i32)rec[27 + l];
+                pre.v[l] = (i32)rec[36 + l];
+            }
+            f29_mul(i3, inv, pre);
+            f29_mul(inv, inv, ZZZ);
+            f29_mul(wv, ZZ, i3);
+            f29_sqr(w2, wv);
+            apt29 a;
+            f29_mul(a.x, X, w2);
+            f29_mul(a.y, Y, i3);
+            f29_store_canon(w, a.x); f29_store_canon(w + 8, a.y);
+            SBV_UNROLL
+            for (int l = 0; l < 16; ++l) qtab[(k + 1) * 16 + l] = w[l];
+        }
+    }
+    // signed-window recoding: u2 + 0x88..8 has nibbles d + 8, d in [-8, 7]; bit 256 is a final +1 digit
+    u256 k2;
+    const u32 top2 = add_const_limbs(k2, u2, 0x88888888u);
+    jpt29f R;
+    R.X = Q.x; R.Y = Q.y; R.Z = f29_one();
+    R.inf = top2 == 0;
+    SBV_NOUNROLL
+    for (int w = 63; w >= 0; --w) {
+        if (!R.inf) {
+            SBV_NOUNROLL
+            for (int t = 0; t < 4; ++t) pt29_dbl_jacx(R);
+        }
+        const int d = (int)((k2.v[w >> 3] >> ((w & 7) * 4)) & 15u) - 8;
+        if (d != 0) {
+            const int ad = d < 0 ? -d : d;
+            apt29 e;
+            apt29_load(e, qtab + (ad - 1) * 16);
+            pt29_madd_jacx(R, e, d < 0);
+        }
+    }
+    xyzz S;
+    S.inf = R.inf;
+    S.X = R.X; S.Y = R.Y;
+    f29_sqrx(S.ZZ, R.Z);
+    f29_mulx(S.ZZZ, R.Z, S.ZZ);
+    gphase29_point(S, u1, gc, true);
+    return ok && pt29_rx_matches(S, r);
 }
 
 // ---- registered-key form, several lanes per signature (the latency form, BASELINE.json's second metric) -------------------

@@ -167,6 +167,69 @@ SBV_HD bool group_split_lane(const uint8_t* tuples, size_t i, const GroupState& 
     return true;
 }
 
+// ---- persistent key-table cache (across batches) -----------------------------------------------------------------------
+// A key's comb is a pure function of its 64 bytes, and signer sets are stable for whole epochs (consenters:
+// pkg/types/types.go:25-29; reconfiguration: pkg/consensus/consensus.go:185-252), so the tables a batch builds are kept:
+// table slots [0, cap) of the comb pool are owned by the cache, slots [cap, cap + max_groups) are the per-batch area used
+// when the cache is off or full.  After the groups of a batch are assigned, every group looks its key up (open addressing,
+// entries = slot + 1, a hit only after comparing all 16 key words); a miss takes a fresh slot and the group is "cold":
+// only cold groups run the table-building kernels.  Verdicts cannot depend on the cache: a slot is keyed by the exact key
+// bytes and holds exactly what the batch would have built.  tslot[g] = table slot of group g, cold[g] = build it now.
+struct KeyCache {
+    u32* ht;          // ht_mask + 1 entries
+    u32 ht_mask;
+    u32* keys;        // [cap][16] key words of the cached slots
+    u32* count;       // [0] slots handed out (may overshoot cap), [1] hits, [2] misses of the current batch
+    u32 cap;
+    u32 enabled;
+};
+SBV_HD u32 key_hash16(const u32 w[16]) {
+    u32 h = 0x9E3779B1u;
+    SBV_UNROLL
+    for (int j = 0; j < 16; ++j) {
+        h = (h ^ w[j]) * 0x85EBCA77u;
+        h ^= h >> 15;
+    }
+    h *= 0xC2B2AE3Du;
+    return h ^ (h >> 16);
+}
+// read-only phase: slot of a cached key, or NONE
+SBV_HD u32 key_cache_lookup(const KeyCache& kc, const u32 w[16]) {
+    u32 p = key_hash16(w) & kc.ht_mask;
+    for (u32 probes = 0; probes <= kc.ht_mask; ++probes) {
+        const u32 v = kc.ht[p];
+        if (v == 0) return SBV_GROUP_NONE;
+        const u32* o = kc.keys + (size_t)(v - 1) * 16;
+        u32 diff = 0;
+        SBV_UNROLL
+        for (int j = 0; j < 16; ++j) diff |= o[j] ^ w[j];
+        if (diff == 0) return v - 1;
+        p = (p + 1) & kc.ht_mask;
+    }
+    return SBV_GROUP_NONE;
+}
+// insert phase (keys of one batch are distinct, and none of them was found by the lookup phase): a fresh slot, or NONE
+// when the cache is full
+SBV_HD u32 key_cache_insert(const KeyCache& kc, const u32 w[16]) {
+    if (kc.count[0] >= kc.cap) return SBV_GROUP_NONE;      // full (the counter is monotone: a stale read only delays this)
+    const u32 slot = SBV_ATOMIC_ADD(&kc.count[0], 1u);
+    if (slot >= kc.cap) return SBV_GROUP_NONE;
+    u32* o = kc.keys + (size_t)slot * 16;
+    SBV_UNROLL
+    for (int j = 0; j < 16; ++j) o[j] = w[j];
+    u32 p = key_hash16(w) & kc.ht_mask;
+    for (u32 probes = 0; probes <= kc.ht_mask; ++probes) {
+        if (SBV_ATOMIC_CAS(&kc.ht[p], 0u, slot + 1u) == 0u) break;
+        p = (p + 1) & kc.ht_mask;
+    }
+    return slot;
+}
+SBV_HD void key_cache_group_key(const uint8_t* tuples, const GroupState& g, u32 gidx, u32 w[16]) {
+    const u32* k = tuple_key_words(tuples, g.group_rep[gidx]);
+    SBV_UNROLL
+    for (int j = 0; j < 16; ++j) w[j] = k[j];
+}
+
 // ---- per-batch key tables ----------------------------------------------------------------------------
 // jbases: [groups][33] Jacobian 2^(8j) * Q with cached Z^2, Z^3 (qent layout, 40 dwords);
 // valid[g] = pointFromAffine verdict.  One call produces bases j_first..j_last; a call with j_first > 0

@@ -49,37 +49,74 @@ __global__ __launch_bounds__(256) void k_group_split(const uint8_t* __restrict__
 // tmp layout (u32 words): [0, G * BASES_TMP) private strips of the bases kernel; behind it one strip of
 // SBV_KT29_WINDOW_TMP words per (key, window), shared by the rows and the fill kernel (same stream, never concurrent).
 #define SBV_KT29_WINDOW_TMP (7 * SBV_KT29_FILL_TMP_WORDS)
+// One workgroup: every group of the batch finds its table slot (p256_group.h: persistent key-table cache).  Phase 1 looks
+// the keys up (read-only: everything in the table was inserted by earlier batches, i.e. earlier kernels); phase 2 inserts
+// the misses (atomics only; the keys of one batch are distinct, so nobody needs to read what a neighbour just wrote).
+__global__ __launch_bounds__(1024) void k_key_cache_assign(const uint8_t* __restrict__ tuples, GroupState g, KeyCache kc,
+                                                           u32* __restrict__ tslot, uint8_t* __restrict__ cold) {
+    const u32 groups = group_count(g);
+    if (threadIdx.x < 2) kc.count[1 + threadIdx.x] = 0;
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < groups; k += 1024) {
+        u32 slot = SBV_GROUP_NONE;
+        if (kc.enabled) {
+            u32 w[16];
+            key_cache_group_key(tuples, g, k, w);
+            slot = key_cache_lookup(kc, w);
+        }
+        tslot[k] = slot;
+        cold[k] = slot == SBV_GROUP_NONE ? 1 : 0;
+        if (kc.enabled) atomicAdd(&kc.count[slot == SBV_GROUP_NONE ? 2 : 1], 1u);
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < groups; k += 1024) {
+        if (tslot[k] != SBV_GROUP_NONE) continue;
+        u32 slot = SBV_GROUP_NONE;
+        if (kc.enabled) {
+            u32 w[16];
+            key_cache_group_key(tuples, g, k, w);
+            slot = key_cache_insert(kc, w);
+        }
+        tslot[k] = slot == SBV_GROUP_NONE ? kc.cap + k : slot;       // cache off or full: the per-batch area
+    }
+}
+
 __global__ __launch_bounds__(64) void k_keytab29_bases(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jstate,
                                                        apt* __restrict__ bases, u32* __restrict__ tmp, uint8_t* __restrict__ valid,
+                                                       const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
                                                        int j_first, int j_last) {
     const u32 k = blockIdx.x * 64 + threadIdx.x;
-    if (k < group_count(g)) keytab29_bases_lane(tuples, k, g, jstate, bases, tmp + (size_t)k * SBV_KT29_BASES_TMP_WORDS, valid, j_first, j_last);
+    if (k >= group_count(g) || !cold[k]) return;
+    keytab29_bases_lane(tuples, k, g, jstate, bases, tmp + (size_t)k * SBV_KT29_BASES_TMP_WORDS, valid + tslot[k], j_first, j_last);
 }
 // lanes = groups x j_count x 2
 __global__ __launch_bounds__(64) void k_keytab29_rows(GroupState g, const apt* __restrict__ bases, u32* __restrict__ tmp,
-                                                      apt* __restrict__ ktab, int j_first, int j_count) {
+                                                      apt* __restrict__ ktab, const u32* __restrict__ tslot,
+                                                      const uint8_t* __restrict__ cold, int j_first, int j_count) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;
     const u32 which = lane & 1u, kw = lane >> 1;
     const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
-    if (key >= group_count(g)) return;
+    if (key >= group_count(g) || !cold[key]) return;
     const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
     u32* t = tmp + (size_t)g.max_groups * SBV_KT29_BASES_TMP_WORDS + w * SBV_KT29_WINDOW_TMP + (size_t)which * SBV_KT29_ROWS_TMP_WORDS;
-    keytab29_rows_lane(bases + w * SBV_KT29_POINTS_PER_WINDOW, (int)which, j == SBV_GTAB_WINDOWS - 1, t, ktab + w * SBV_GTAB_PER_WINDOW);
+    keytab29_rows_lane(bases + w * SBV_KT29_POINTS_PER_WINDOW, (int)which, j == SBV_GTAB_WINDOWS - 1, t,
+                       ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
 }
 // lanes = groups x j_count x lanes_per_window, each lane rows_per_lane of the 7 rows 16 a + b, a = 1..7
-__global__ __launch_bounds__(64) void k_keytab29_fill(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab, int j_first,
+__global__ __launch_bounds__(64) void k_keytab29_fill(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab,
+                                                      const u32* __restrict__ tslot, const uint8_t* __restrict__ cold, int j_first,
                                                       int j_count, int rows_per_lane, int lanes_per_window) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;
     const u32 r = lane % (u32)lanes_per_window, kw = lane / (u32)lanes_per_window;
     const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
-    if (key >= group_count(g) || j == SBV_GTAB_WINDOWS - 1) return;
+    if (key >= group_count(g) || j == SBV_GTAB_WINDOWS - 1 || !cold[key]) return;
     const int a_first = 1 + (int)r * rows_per_lane;
     int a_last = a_first + rows_per_lane - 1;
     if (a_last > 7) a_last = 7;
     if (a_first > 7) return;
     const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
     u32* t = tmp + (size_t)g.max_groups * SBV_KT29_BASES_TMP_WORDS + w * SBV_KT29_WINDOW_TMP + (size_t)r * SBV_KT29_FILL_TMP_WORDS;
-    keytab29_fill_lane(a_first, a_last, t, ktab + w * SBV_GTAB_PER_WINDOW);
+    keytab29_fill_lane(a_first, a_last, t, ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
 }
 
 // One launch, two jobs.  Blocks [0, generic_blocks): the generic stage B (doubling kernel) over the
@@ -95,7 +132,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_gphase_g
         const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
         if (L >= g.counters[2]) return;
         const u32 t = g.ung_idx[L];
-        acc[t] = verify_lane<false>(s, t, qtab + (size_t)L * (SBV_QTAB_ENTRIES * 40), g16) ? 1 : 0;
+        acc[t] = verify29_lane_generic(s, t, qtab + (size_t)L * SBV_QTAB29_WORDS, g16r) ? 1 : 0;
         return;
     }
     if (group_count(g) == 0) return;            // no key repeats often enough (e.g. all-distinct keys): nothing will read gacc
@@ -104,22 +141,25 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_gphase_g
 }
 
 // The generic stage B alone (own stream, when the process has hardware queues to spare)
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_verify_generic_list(Scratch s, GroupState g, u32* __restrict__ qtab,
-                                                                            const apt* __restrict__ g16, uint8_t* __restrict__ acc) {
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_verify_generic_list(Scratch s, GroupState g, u32* __restrict__ qtab,
+                                                                            gcomb g16r, uint8_t* __restrict__ acc) {
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= g.counters[2]) return;
     const u32 t = g.ung_idx[L];
-    acc[t] = verify_lane<false>(s, t, qtab + (size_t)L * (SBV_QTAB_ENTRIES * 40), g16) ? 1 : 0;
+    acc[t] = verify29_lane_generic(s, t, qtab + (size_t)L * SBV_QTAB29_WORDS, g16r) ? 1 : 0;
 }
 
 // Q phase over the grouped list: windows [j0, j1) of the per-batch key combs
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_verify_keyed_q(Scratch s, GroupState g, const apt* __restrict__ ktab,
-                                                                    const uint8_t* __restrict__ kvalid, u32* __restrict__ gacc,
+                                                                    const uint8_t* __restrict__ kvalid, const u32* __restrict__ tslot,
+                                                                    u32 table_slots, u32* __restrict__ gacc,
                                                                     uint8_t* __restrict__ acc, int j0, int j1, int last) {
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= g.counters[1]) return;
     const u32 t = g.grp_idx[L];
-    const bool v = qphase29_lane(s, t, g.slots[t], group_count(g), ktab, kvalid, gacc, j0, j1, last != 0);
+    const u32 grp = g.slots[t];                                        // group of this tuple -> its table slot (cache or per-batch area)
+    const u32 ts = grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE;
+    const bool v = qphase29_lane(s, t, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
     if (last) acc[t] = v ? 1 : 0;
 }
 
@@ -157,6 +197,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
     hipLaunchKernelGGL(k_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
     hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, n, g);
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
+    hipLaunchKernelGGL(k_key_cache_assign, dim3(1), dim3(1024), 0, y.side_a, d_tuples, g, b.kc, b.tslot, b.cold);
     // Stage A and the G phase, pipelined in slices of the batch: stage A is a low-occupancy chain (one inversion per
     // thread), and while it ran alone at the head of the step most of the GPU idled for ~0.35 ms.  Slice 0 is prepared on
     // `stream`, the others on side_b; the G phase of slice k starts as soon as slice k is prepared.  The generic kernel
@@ -183,7 +224,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
         SBV_TRY(hipEventRecord(y.ev_prep, stream));
         SBV_TRY(hipStreamWaitEvent(y.side_c, y.ev_prep, 0));
         SBV_TRY(hipStreamWaitEvent(y.side_c, y.ev_split, 0));
-        hipLaunchKernelGGL(k_verify_generic_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, y.side_c, s, g, d_qtab, d_g16, b.acc);
+        hipLaunchKernelGGL(k_verify_generic_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, y.side_c, s, g, d_qtab, d_g16r, b.acc);
         SBV_TRY(hipEventRecord(y.ev_generic, y.side_c));
         // the G phase reads counters[0] (group_count): it may not start before side_a's memset / insert / assign
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
@@ -214,20 +255,20 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [j_first, j_end)
         const int j_count = j_end - j_first;
         hipLaunchKernelGGL(k_keytab29_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases, b.tmp,
-                           b.kvalid, j_first, j_end - 1);
+                           b.kvalid, b.tslot, b.cold, j_first, j_end - 1);
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
         SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[c], 0));
         const size_t wl = (size_t)b.max_groups * j_count * 2;
-        hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.bases, b.tmp, b.ktab, j_first, j_count);
+        hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
         const int lpw = (7 + rows_per_lane - 1) / rows_per_lane;
         const size_t fl = (size_t)b.max_groups * j_count * lpw;
-        hipLaunchKernelGGL(k_keytab29_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, y.side_b, g, b.tmp, b.ktab, j_first, j_count,
+        hipLaunchKernelGGL(k_keytab29_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, y.side_b, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count,
                            rows_per_lane, lpw);
         SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         const bool last = c + 1 == chunks;
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
-        hipLaunchKernelGGL(k_verify_keyed_q, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.gacc, b.acc,
+        hipLaunchKernelGGL(k_verify_keyed_q, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.kc.cap + b.max_groups, b.gacc, b.acc,
                            j_first, j_end, last ? 1 : 0);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }

@@ -4,6 +4,7 @@
 
 #include "p256_core.h"
 #include "p256_comb29.h"
+#include "p256_group.h"
 
 #define SBV_TUPLE_BYTES 160
 #define SBV_VERIFY_BLOCK 256
@@ -24,7 +25,7 @@ hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const u
 bool host_build_key_table(const uint8_t q[64], apt* out);
 #define SBV_KEYTAB_ENTRIES (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW)
 // d_rerun: ceil(n/64) bytes of per-wavefront flags (fast pass -> exact pass)
-hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
+hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const gcomb& d_gcomb, uint8_t* d_bitmap, uint8_t* d_rerun,
                               hipStream_t stream);
 // device buffers of the in-step key grouping (p256_group.h); owned by the context
 struct GroupBuffers {
@@ -35,6 +36,9 @@ struct GroupBuffers {
     apt* bases = nullptr;       // [max_groups][33][2] affine B_j = 2^(8j) Q and 16 B_j (p256_keytab29.h)
     u32* jstate = nullptr;      // [max_groups][27] the doubling chain between chunks of windows
     apt* ktab = nullptr; uint8_t* kvalid = nullptr; u32* tmp = nullptr; uint8_t* acc = nullptr;
+    KeyCache kc = {};           // persistent key-table cache: slots [0, kc.cap) of ktab / kvalid; [kc.cap, kc.cap + max_groups) = per batch
+    u32* tslot = nullptr;       // [max_groups] table slot of each group of the current batch
+    uint8_t* cold = nullptr;    // [max_groups] 1 = the group's tables are built in this batch
     u32* gacc = nullptr;        // [36][scratch cap] u1*G per tuple (XYZZ, 9-limb coordinates), then the running sum of the Q phase
     u32 max_groups = 0, min_count = 0;
     size_t cap = 0;

@@ -161,29 +161,14 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_coop(
     }
 }
 
-// Generic form (public key in the tuple): per-signature window table in HBM.
-template <bool FAST>
-__device__ __forceinline__ void verify_body(const Scratch& s, size_t n, u32* __restrict__ qtab, const apt* __restrict__ gtab,
-                                            uint8_t* __restrict__ bitmap, uint8_t* __restrict__ rerun) {
+// Generic form (public key in the tuple), carry-free field: per-signature AFFINE window table in HBM (p256_comb29.h:
+// verify29_lane_generic), Jacobian accumulator with fused reductions.  qtab: SBV_QTAB29_WORDS words per lane.
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify(Scratch s, size_t n, u32* __restrict__ qtab, gcomb gc,
+                                                                      uint8_t* __restrict__ bitmap) {
     const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
-    if (!FAST && rerun && !rerun[i >> 6]) return;        // wave-uniform
     bool accept = false;
-    u32 sticky = 0;
-    if (i < n) accept = verify_lane<FAST>(s, i, qtab + i * (size_t)(SBV_QTAB_ENTRIES * 40), gtab, &sticky);
-    finish_wave<FAST>(accept, sticky == 0xFFFFFFFFu, i, n, bitmap, rerun);
-}
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK) void k_p256_verify_fast(Scratch s, size_t n, u32* __restrict__ qtab,
-                                                                 const apt* __restrict__ gtab, uint8_t* __restrict__ bitmap,
-                                                                 uint8_t* __restrict__ rerun) {
-    verify_body<true>(s, n, qtab, gtab, bitmap, rerun);
-}
-#ifndef SBV_LB_WAVES
-#define SBV_LB_WAVES 1
-#endif
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_LB_WAVES) void k_p256_verify(Scratch s, size_t n, u32* __restrict__ qtab,
-                                                                       const apt* __restrict__ gtab,
-                                                                       uint8_t* __restrict__ bitmap, uint8_t* __restrict__ rerun) {
-    verify_body<false>(s, n, qtab, gtab, bitmap, rerun);
+    if (i < n) accept = verify29_lane_generic(s, i, qtab + i * (size_t)SBV_QTAB29_WORDS, gc);
+    finish_wave<false>(accept, false, i, n, bitmap, nullptr);
 }
 
 // Message front end: lane i hashes message i (SHA-256) and parses DER signature i,
@@ -274,17 +259,12 @@ hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slo
     return hipGetLastError();
 }
 
-hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const apt* d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
+hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const gcomb& d_gcomb, uint8_t* d_bitmap, uint8_t* d_rerun,
                               hipStream_t stream) {
     if (n == 0) return hipSuccess;
+    (void)d_rerun;
     const unsigned grid = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
-    uint8_t* rr = nullptr;
-    if (two_pass()) {
-        hipLaunchKernelGGL(k_p256_verify_fast, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gtab, d_bitmap, d_rerun);
-        if (force_exact()) (void)hipMemsetAsync(d_rerun, 1, (n + 63) / 64, stream);
-        rr = d_rerun;
-    }
-    hipLaunchKernelGGL(k_p256_verify, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gtab, d_bitmap, rr);
+    hipLaunchKernelGGL(k_p256_verify, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_qtab, d_gcomb, d_bitmap);
     return hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ SBV_HD void apt29_store_canon(apt* dst, const apt29& a) {
 // ---- bases -------------------------------------------------------------------------------------------------------------
 // bases[(gidx * 33 + j) * 2 + {0, 1}] = B_j, 16 B_j (affine, canonical).  jstate[gidx * 27 ..]: the chain between chunks
 // (16 B_{j_last} after a chunk).  tmp: SBV_KT29_BASES_TMP_WORDS private words.
+// valid: the byte of this key's TABLE SLOT (written by the first chunk)
 SBV_HD void keytab29_bases_lane(const uint8_t* tuples, u32 gidx, const GroupState& g, u32* jstate, apt* bases, u32* tmp,
                                 uint8_t* valid, int j_first, int j_last) {
     jpt29 t;
@@ -57,7 +58,7 @@ SBV_HD void keytab29_bases_lane(const uint8_t* tuples, u32 gidx, const GroupStat
     if (j_first == 0) {
         fe x, y;
         const bool ok = tuple_key_load(tuples, g.group_rep[gidx], x, y);
-        valid[gidx] = ok ? 1 : 0;
+        *valid = ok ? 1 : 0;
         f29_from_fe(t.X, x);
         f29_from_fe(t.Y, y);
         t.Z = f29_one();

@@ -262,6 +262,108 @@ SBV_HD void pt29_dbl_jac(jpt29& R) {
     f29_norm_red(R.Y, t1);                      // Y3 = alpha (4 beta - X3) - 8 gamma^2
 }
 
+// The same doubling for the per-signature chain of the all-distinct-keys kernel (256 of them per signature): the
+// 32-bit-multiplier reduction and fused reductions for X3 and Y3 (p256_fe29.h, column-level interface).  `inf` stays.
+// Bounds (units of p): X, Y value-reduced, Z within +-5; alpha within +-13 before its product is formed, every
+// |A||B| <= 64.
+struct jpt29f { fe29 X, Y, Z; bool inf; };
+SBV_HD void pt29_dbl_jacx(jpt29f& R) {
+    fe29 delta, gamma, beta, alpha, t1, t2, g2, V;
+    f29_sqrx(delta, R.Z);
+    f29_sqrx(gamma, R.Y);
+    f29_mulx(beta, R.X, gamma);
+    f29_sub(t1, R.X, delta);
+    f29_add(t2, R.X, delta);
+    f29_norm(t2, t2);
+    f29_mulx(alpha, t1, t2);
+    f29_red_q(alpha);
+    f29_add(t1, alpha, alpha);
+    f29_add(alpha, alpha, t1);                  // alpha = 3 (X - delta)(X + delta), value within (0, 3.1)
+    f29_norm(alpha, alpha);
+    f29_add(t1, R.Y, R.Z);
+    f29_norm(t1, t1);
+    f29_cols c;
+    f29_cols_zero(c);
+    f29_cols_sqr(c, t1);
+    f29_add(V, gamma, delta);
+    f29_cols_sub_val(c, V);
+    f29_reduce_x(R.Z, c);                       // Z3 = (Y + Z)^2 - gamma - delta
+    f29_red_q(R.Z);
+    f29_add(t1, beta, beta);
+    f29_add(t1, t1, t1);
+    f29_norm(beta, t1);
+    f29_red_q(beta);                            // 4 beta, value-reduced
+    f29_cols_zero(c);
+    f29_cols_sqr(c, alpha);
+    f29_add(V, beta, beta);
+    f29_cols_sub_val(c, V);
+    f29_reduce_x(R.X, c);                       // X3 = alpha^2 - 8 beta
+    f29_red_q(R.X);
+    f29_sub(t1, beta, R.X);
+    f29_sqrx(g2, gamma);
+    f29_red_q(g2);
+    f29_add(t2, g2, g2);
+    f29_norm(t2, t2);
+    f29_add(V, t2, t2);                         // 4 gamma^2 (limbs < 2^30 + 16)
+    f29_cols_zero(c);
+    f29_cols_mul(c, alpha, t1);
+    f29_cols_sub_val(c, V);
+    f29_cols_sub_val(c, V);
+    f29_reduce_x(R.Y, c);                       // Y3 = alpha (4 beta - X3) - 8 gamma^2
+    f29_red_q(R.Y);
+}
+
+// R += (q.x, +-q.y) for a Jacobian accumulator (madd-2007-bl shape: 8M + 3S), exact like pt29_madd.
+SBV_HD void pt29_madd_jacx(jpt29f& R, const apt29& q, bool neg) {
+    if (R.inf) {
+        R.X = q.x;
+        f29_cneg(R.Y, q.y, neg);
+        R.Z = f29_one();
+        R.inf = false;
+        return;
+    }
+    fe29 zz, U2, S2, H, Rr, HH, HHH, Vv, t, W;
+    f29_sqrx(zz, R.Z);
+    f29_mulx(U2, q.x, zz);
+    f29_mulx(t, R.Z, zz);
+    f29_mulx(S2, q.y, t);
+    f29_sub(H, U2, R.X);
+    f29_cneg(S2, S2, neg);
+    f29_sub(Rr, S2, R.Y);
+    f29_norm(Rr, Rr);
+    if (f29_maybe_zero(H)) {
+        if (f29_is_zero_slow(H)) {
+            if (f29_is_zero(Rr)) {              // P == Q: the doubling of the accumulator itself
+                pt29_dbl_jacx(R);
+            } else {
+                R.X = f29_zero(); R.Y = f29_zero(); R.Z = f29_zero(); R.inf = true;
+            }
+            return;
+        }
+    }
+    f29_sqrx(HH, H);
+    f29_mulx(HHH, H, HH);
+    f29_mulx(Vv, R.X, HH);
+    f29_cols c;
+    f29_cols_zero(c);
+    f29_cols_sqr(c, Rr);
+    f29_add(W, HHH, Vv);
+    f29_add(W, W, Vv);
+    f29_cols_sub_val(c, W);
+    fe29 X3;
+    f29_reduce_x(X3, c);
+    f29_red_q(X3);
+    f29_sub(t, Vv, X3);
+    f29_neg(W, R.Y);
+    f29_cols_zero(c);
+    f29_cols_mul(c, Rr, t);
+    f29_cols_mul(c, W, HHH);
+    f29_reduce_x(R.Y, c);
+    f29_red_q(R.Y);
+    R.X = X3;
+    f29_mulx(R.Z, R.Z, H);
+}
+
 // affine + affine -> affine given the inverse of (x2 - x1):  lambda = (y2 - y1) / (x2 - x1),
 // x3 = lambda^2 - x1 - x2, y3 = lambda (x1 - x3) - y1.  2M + 1S.  Only for x1 != x2 (distinct small multiples of a
 // point of prime order — the table builder's case).  Inputs tight / canonical; outputs value-reduced.

@@ -70,6 +70,8 @@ struct Context {
     bool group_enabled = true;
     size_t group_min_batch = 262144;    // below this the ~3.5 ms table-building latency costs more than it saves
     u32 group_min_count = 64, group_max = 2048;
+    bool kc_enabled = true;             // persistent key-table cache (p256_group.h)
+    u32 kc_cap = 4096;                  // cached keys (270 KiB of HBM each)
     // message front end staging (grown on demand)
     uint8_t* d_msgs = nullptr; size_t msgs_cap = 0;
     uint8_t* d_sigs = nullptr; size_t sigs_cap = 0;
@@ -146,7 +148,7 @@ int ensure_capacity(Context& c, size_t n) {
     free_buffers(c);
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_tuples, want * SBV_TUPLE_BYTES));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_scratch, want * (6 * 32 + 1)));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_qtab, want * (size_t)(SBV_QTAB_ENTRIES * 160)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_qtab, want * (size_t)SBV_QTAB29_WORDS * sizeof(u32)));      // per-lane strip of the generic kernel (Ed25519: 8 x 128 B fits)
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_bitmap, want / 8));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_slots, want * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_rerun, want / 64));
@@ -180,7 +182,8 @@ std::vector<hipEvent_t*> group_events(Context& c) {
 
 void free_group_buffers(Context& c) {
     sbv::GroupBuffers& b = c.grp;
-    void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.jbases, b.bases, b.jstate, b.ktab, b.kvalid, b.tmp, b.acc, b.gacc};
+    void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.jbases, b.bases, b.jstate, b.ktab, b.kvalid, b.tmp, b.acc, b.gacc,
+                    b.tslot, b.cold, b.kc.ht, b.kc.keys, b.kc.count};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     b = sbv::GroupBuffers();
     if (c.edgrp.ktab) (void)hipFree(c.edgrp.ktab);
@@ -190,7 +193,11 @@ void free_group_buffers(Context& c) {
 
 int ensure_group_buffers(Context& c, size_t n) {
     sbv::GroupBuffers& b = c.grp;
-    if (b.cap >= n && b.max_groups == c.group_max && b.gacc_cap == c.cap) { b.min_count = c.group_min_count; return SBV_OK; }
+    if (b.cap >= n && b.max_groups == c.group_max && b.gacc_cap == c.cap && b.kc.cap == c.kc_cap) {
+        b.min_count = c.group_min_count;
+        b.kc.enabled = c.kc_enabled ? 1u : 0u;
+        return SBV_OK;
+    }
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
     free_group_buffers(c);
     const size_t cap = (n + 1023) & ~(size_t)1023;
@@ -210,8 +217,22 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.bases, G * SBV_GTAB_WINDOWS * (size_t)2 * sizeof(sbv::apt)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jstate, G * (size_t)27 * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 36 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride; 36 words (P-256: XYZZ, 9-limb coordinates) or 32 (Ed25519) per tuple
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ktab, G * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, G));
+    // comb pool: slots [0, kc_cap) belong to the persistent key-table cache, [kc_cap, kc_cap + G) are rebuilt per batch
+    const size_t K = c.kc_cap;
+    size_t kht = 1024;
+    while (kht < 4 * (K ? K : 1)) kht *= 2;
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ktab, (K + G) * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, K + G));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tslot, G * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.cold, G));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kc.ht, kht * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kc.keys, (K ? K : 1) * 16 * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kc.count, 4 * sizeof(u32)));
+    HIP_TRY(SBV_EDEVICE, hipMemset(b.kc.ht, 0, kht * sizeof(u32)));
+    HIP_TRY(SBV_EDEVICE, hipMemset(b.kc.count, 0, 4 * sizeof(u32)));
+    b.kc.ht_mask = (u32)(kht - 1);
+    b.kc.cap = (u32)K;
+    b.kc.enabled = c.kc_enabled ? 1u : 0u;
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tmp, G * SBV_GTAB_WINDOWS * (size_t)(SBV_GTAB_PER_WINDOW * 32) * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.acc, cap));
     b.ht_mask = (u32)(ht - 1);
@@ -270,7 +291,7 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_tuples, n, s, stream));
     if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
     if (dom) HIP_TRY(SBV_EDEVICE, hipEventRecord(dom[0], stream));     // ungrouped: the dominant kernel is all of stage B
-    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify(s, n, c.d_qtab, c.d_gtab, d_bitmap, c.d_rerun, stream));
+    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify(s, n, c.d_qtab, sbv::gcomb_make(c.d_g16r, c.g_bits), d_bitmap, c.d_rerun, stream));
     if (dom) { HIP_TRY(SBV_EDEVICE, hipEventRecord(dom[1], stream)); if (dom_pairs) *dom_pairs = 1; }
     return SBV_OK;
 }
@@ -1046,6 +1067,39 @@ extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min
     if (min_batch) c.group_min_batch = min_batch;
     if (min_count) c.group_min_count = min_count;
     if (max_groups) c.group_max = max_groups;
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_key_cache(int enabled, uint32_t capacity) {
+    SBV_ENTER(c);
+    c.kc_enabled = enabled != 0;
+    if (capacity) c.kc_cap = capacity;          // a new capacity takes effect (and empties the cache) at the next grouped batch
+    if (c.ready && c.grp.kc.ht) {
+        HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+        HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+        c.grp.kc.enabled = c.kc_enabled ? 1u : 0u;
+        if (!c.kc_enabled) {                     // switching it off forgets everything: the next "on" starts cold
+            HIP_TRY(SBV_EDEVICE, hipMemset(c.grp.kc.ht, 0, ((size_t)c.grp.kc.ht_mask + 1) * sizeof(u32)));
+            HIP_TRY(SBV_EDEVICE, hipMemset(c.grp.kc.count, 0, 4 * sizeof(u32)));
+        }
+    }
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_key_cache_stats(uint32_t out[4]) {
+    SBV_ENTER(c);
+    if (!c.ready) return SBV_ENOTINIT;
+    if (!out) return SBV_EINVAL;
+    out[0] = out[1] = out[2] = 0;
+    out[3] = c.kc_cap;
+    if (!c.grp.kc.count) return SBV_OK;
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    uint32_t h[3];
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(h, c.grp.kc.count, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = h[0] < c.grp.kc.cap ? h[0] : c.grp.kc.cap;
+    out[1] = h[1];
+    out[2] = h[2];
     return SBV_OK;
 }
 

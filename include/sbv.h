@@ -72,6 +72,17 @@ int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitma
  * (env SBV_GROUP=0 disables).  Passing 0 for a numeric argument keeps its current value. */
 int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uint32_t max_groups);
 
+/* Persistent key-table cache.  The comb a grouped batch builds for a key is a pure function of the key's 64 bytes, and
+ * SmartBFT's signer sets are stable for whole epochs (pkg/types/types.go:25-29; reconfiguration:
+ * pkg/consensus/consensus.go:185-252), so the tables are kept in HBM (270 KiB per key) and later batches only build the
+ * tables of keys they have not met: a "warm" batch skips the doubling chains and the table kernels altogether.  Verdicts
+ * cannot depend on it (a slot is found by comparing all 64 key bytes and holds exactly what the batch would have built).
+ * enabled: default 1; switching it off also empties it.  capacity: keys kept (default 4096; 0 = unchanged); when full,
+ * further keys are simply rebuilt per batch.  stats: out[0] = cached keys, out[1] / out[2] = groups of the last grouped
+ * batch that hit / missed, out[3] = capacity.  bench.py measures its headline with the cache OFF (every step cold). */
+int sbv_p256_key_cache(int enabled, uint32_t capacity);
+int sbv_p256_key_cache_stats(uint32_t out[4]);
+
 /* Same, on device-resident buffers, asynchronous on `hip_stream` (a hipStream_t; NULL = the
  * default stream).  d_tuples: n*160 bytes, 16-byte aligned.  d_bitmap: ceil(n/8) bytes.
  * The caller synchronises the stream.  Used by bench.py / multi-GPU shards. */

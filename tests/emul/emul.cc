@@ -90,9 +90,27 @@ void sbve_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap, in
     for (size_t b = 0; b < nblocks; ++b)
         for (int t = 0; t < block; ++t) prep_chunk29<true>(hw, n, s, b * per_block + t, (size_t)block, T);
     memset(bitmap, 0, (n + 7) / 8);
+    u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB29_WORDS * 4);
+    for (size_t i = 0; i < n; ++i)
+        if (verify29_lane_generic(s, i, qtab, g16rtab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+    free(qtab);
+}
+// the 8 x 32 generic lane (p256_core.h: verify_lane, fast + exact passes) kept as a second implementation to diff against
+void sbve_p256_verify_batch_v0(const uint8_t* tuples, size_t n, uint8_t* bitmap, int block, int T) {
+    size_t cap = (n + 63) & ~(size_t)63;
+    if (cap == 0) cap = 64;
+    std::vector<u32> r(8 * cap), u1(8 * cap), u2(8 * cap), qx(8 * cap), qy(8 * cap), sm(8 * cap);
+    std::vector<uint8_t> ok(cap, 0);
+    Scratch s{r.data(), u1.data(), u2.data(), qx.data(), qy.data(), sm.data(), ok.data(), cap};
+    const size_t per_block = (size_t)block * T;
+    const size_t nblocks = (n + per_block - 1) / per_block;
+    HostWords hw{tuples, 160};
+    for (size_t b = 0; b < nblocks; ++b)
+        for (int t = 0; t < block; ++t) prep_chunk<true>(hw, n, s, b * per_block + t, (size_t)block, T);
+    memset(bitmap, 0, (n + 7) / 8);
     u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB_ENTRIES * 40 * 4);
     for (size_t i = 0; i < n; ++i) {
-        // exactly the kernel's two-pass scheme: fast pass, exact re-run when the sticky word fired
+        // exactly the old kernel's two-pass scheme: fast pass, exact re-run when the sticky word fired
         u32 sticky = 0;
         bool acc = verify_lane<true>(s, i, qtab, g16tab(), &sticky);
         const bool exact = verify_lane<false>(s, i, qtab, g16tab());
@@ -109,6 +127,22 @@ u32 sbve_fe_add_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(
 u32 sbve_fe_mul_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_mul<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 
 static int g_group_chunks = 3, g_group_parts = 4;
+// persistent key-table cache of the emulated grouped step (sbve_key_cache resets it)
+static KeyCache g_kc = {};
+static apt* g_kc_ktab = nullptr;
+static std::vector<uint8_t> g_kc_valid;
+static std::vector<u32> g_kc_ht, g_kc_keys, g_kc_count;
+void sbve_key_cache(int enabled, u32 cap) {
+    free(g_kc_ktab);
+    g_kc_ktab = nullptr;
+    size_t ht = 16;
+    while (ht < 4 * (size_t)(cap ? cap : 1)) ht *= 2;
+    g_kc_ht.assign(ht, 0); g_kc_keys.assign((size_t)(cap ? cap : 1) * 16, 0); g_kc_count.assign(4, 0); g_kc_valid.assign(cap ? cap : 1, 0);
+    if (cap) g_kc_ktab = (apt*)aligned_alloc(64, (size_t)cap * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW * sizeof(apt));
+    g_kc.ht = g_kc_ht.data(); g_kc.ht_mask = (u32)(ht - 1); g_kc.keys = g_kc_keys.data(); g_kc.count = g_kc_count.data();
+    g_kc.cap = cap; g_kc.enabled = enabled && cap ? 1u : 0u;
+}
+void sbve_key_cache_stats(u32 out[3]) { out[0] = g_kc.count ? g_kc_count[0] : 0; out[1] = g_kc.count ? g_kc_count[1] : 0; out[2] = g_kc.count ? g_kc_count[2] : 0; }
 void sbve_set_group_chunks(int c) { g_group_chunks = c < 1 ? 1 : (c > 4 ? 4 : c); }
 void sbve_set_group_parts(int p) { if (p == 2 || p == 4 || p == 8 || p == 16) g_group_parts = p; }
 // grouped form: generic tuples, keys grouped inside the call (p256_group.h), emulated sequentially.
@@ -144,35 +178,61 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     const size_t ng1 = ngroups ? ngroups : 1;
     apt* bases = (apt*)aligned_alloc(64, ng1 * SBV_GTAB_WINDOWS * SBV_KT29_POINTS_PER_WINDOW * sizeof(apt));
     std::vector<u32> jstate(ng1 * SBV_KT29_STATE_WORDS);
-    apt* ktab = (apt*)aligned_alloc(64, ng1 * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW * sizeof(apt));
-    memset(ktab, 0xA5, ng1 * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW * sizeof(apt));      // an entry nobody wrote must not look like a point
+    const size_t per_key = (size_t)SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW;
+    apt* ktab = (apt*)aligned_alloc(64, ng1 * per_key * sizeof(apt));                     // the per-batch area
+    memset(ktab, 0xA5, ng1 * per_key * sizeof(apt));      // an entry nobody wrote must not look like a point
     std::vector<uint8_t> kvalid(ng1, 0);
     std::vector<u32> tmpa(SBV_KT29_BASES_TMP_WORDS + 7 * SBV_KT29_FILL_TMP_WORDS);
+    // persistent key-table cache (p256_group.h): the two phases of k_key_cache_assign, sequentially
+    std::vector<u32> tslot(ng1, SBV_GROUP_NONE);
+    std::vector<uint8_t> cold(ng1, 1);
+    KeyCache kc = g_kc;
+    if (kc.enabled) kc.count[1] = kc.count[2] = 0;
+    for (u32 k = 0; k < ngroups; ++k) {
+        u32 w[16];
+        key_cache_group_key(tuples, g, k, w);
+        tslot[k] = kc.enabled ? key_cache_lookup(kc, w) : SBV_GROUP_NONE;
+        cold[k] = tslot[k] == SBV_GROUP_NONE ? 1 : 0;
+        if (kc.enabled) kc.count[cold[k] ? 2 : 1]++;
+    }
+    for (u32 k = 0; k < ngroups; ++k) {
+        if (tslot[k] != SBV_GROUP_NONE) continue;
+        u32 w[16];
+        key_cache_group_key(tuples, g, k, w);
+        const u32 slot = kc.enabled ? key_cache_insert(kc, w) : SBV_GROUP_NONE;
+        tslot[k] = slot == SBV_GROUP_NONE ? kc.cap + k : slot;
+    }
+    auto table_of = [&](u32 k) -> apt* { return tslot[k] < kc.cap ? g_kc_ktab + (size_t)tslot[k] * per_key : ktab + (size_t)k * per_key; };
+    auto valid_of = [&](u32 k) -> uint8_t* { return tslot[k] < kc.cap ? &g_kc_valid[tslot[k]] : &kvalid[k]; };
     memset(bitmap, 0, (n + 7) / 8);
     const int chunks = g_group_chunks;
     const int rpl = g_group_parts == 2 ? 2 : (g_group_parts == 4 ? 4 : (g_group_parts == 16 ? 7 : 1));   // rows per lane of the fill kernel
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
-        for (u32 k = 0; k < ngroups; ++k) keytab29_bases_lane(tuples, k, g, jstate.data(), bases, tmpa.data(), kvalid.data(), j_first, j_end - 1);
         for (u32 k = 0; k < ngroups; ++k)
-            for (int j = j_first; j < j_end; ++j) {
+            if (cold[k]) keytab29_bases_lane(tuples, k, g, jstate.data(), bases, tmpa.data(), valid_of(k), j_first, j_end - 1);
+        for (u32 k = 0; k < ngroups; ++k)
+            for (int j = j_first; j < j_end && cold[k]; ++j) {
                 const size_t w = (size_t)k * SBV_GTAB_WINDOWS + j;
+                apt* row = table_of(k) + (size_t)j * SBV_GTAB_PER_WINDOW;
                 for (int which = 0; which < 2; ++which)
-                    keytab29_rows_lane(bases + w * SBV_KT29_POINTS_PER_WINDOW, which, j == SBV_GTAB_WINDOWS - 1, tmpa.data(), ktab + w * SBV_GTAB_PER_WINDOW);
+                    keytab29_rows_lane(bases + w * SBV_KT29_POINTS_PER_WINDOW, which, j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
                 if (j == SBV_GTAB_WINDOWS - 1) continue;
-                for (int a = 1; a <= 7; a += rpl) keytab29_fill_lane(a, a + rpl - 1 > 7 ? 7 : a + rpl - 1, tmpa.data(), ktab + w * SBV_GTAB_PER_WINDOW);
+                for (int a = 1; a <= 7; a += rpl) keytab29_fill_lane(a, a + rpl - 1 > 7 ? 7 : a + rpl - 1, tmpa.data(), row);
             }
         const bool last = c + 1 == chunks;
         for (u32 L = 0; L < counters[1]; ++L) {
             const u32 t = grp_idx[L];
-            const bool v = qphase29_lane(s, t, slots[t], ngroups, ktab, kvalid.data(), gacc.data(), j_first, j_end, last);
+            const u32 grp = slots[t];
+            const bool v = grp < ngroups ? qphase29_lane(s, t, 0, 1, table_of(grp), valid_of(grp), gacc.data(), j_first, j_end, last)
+                                         : qphase29_lane(s, t, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc.data(), j_first, j_end, last);
             if (last && v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
         }
     }
-    u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB_ENTRIES * 40 * 4);
+    u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB29_WORDS * 4);
     for (u32 L = 0; L < counters[2]; ++L) {
         const u32 t = ung_idx[L];
-        if (verify_lane(s, t, qtab, g16tab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+        if (verify29_lane_generic(s, t, qtab, g16rtab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
     }
     free(qtab); free(ktab); free(bases);
     if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }

@@ -393,3 +393,51 @@ def test_g_comb_window_width_does_not_change_verdicts(emul, oracle, golden_vecto
         assert not bad, (bits, bad[:8])
     finally:
         emul.sbve_set_gcomb_bits(16)
+
+
+def test_persistent_key_table_cache_never_changes_verdicts(emul, oracle, golden_vectors):
+    """The persistent key-table cache of the grouped step (p256_group.h): batch 1 builds and keeps the tables, batch 2 (other
+    signatures, same keys + new keys + an invalid key that repeats) hits for the old keys, a cache too small for all keys
+    overflows into the per-batch area, and a key that was cached as INVALID stays rejected.  Verdicts always equal the
+    oracle's."""
+    emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    emul.sbve_key_cache.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    off = next(bytes.fromhex(v["tuple"]) for v in vs if v["name"] == "q_off_curve_y_plus_1")
+    stats = (ctypes.c_uint32 * 4)()
+    cstats = (ctypes.c_uint32 * 3)()
+
+    def batch(seed, n, nkeys):
+        tup = ctypes.create_string_buffer(160 * n)
+        exp = ctypes.create_string_buffer((n + 7) // 8)
+        oracle.sbvo_gen_batch(seed, n, nkeys, 5, tup, exp, 4)
+        return tup.raw, _bitmap_list(exp.raw, n)
+
+    def run(blob, want):
+        total = len(blob) // 160
+        bm = ctypes.create_string_buffer((total + 7) // 8)
+        emul.sbve_p256_verify_batch_grouped(blob, total, bm, 8, 64, 12, stats)
+        got = _bitmap_list(bm.raw, total)
+        assert got == want, [i for i in range(total) if got[i] != want[i]][:8]
+        emul.sbve_key_cache_stats(cstats)
+        return cstats[0], cstats[1], cstats[2]
+
+    try:
+        emul.sbve_key_cache(1, 16)
+        a, wa = batch(0x91, 400, 6)                       # keys of seed 0x91
+        entries, hits, misses = run(a + off * 20, wa + [False] * 20)
+        assert hits == 0 and misses == 7 and entries == 7             # 6 signer keys + the repeated invalid key
+        b, wb = batch(0x91, 500, 6)                       # same seed -> same keys; generator's signatures differ with n
+        entries, hits, misses = run(b + off * 20, wb + [False] * 20)
+        assert hits == 7 and misses == 0 and entries == 7             # everything warm, the invalid key still rejected
+        c, wc = batch(0x92, 600, 12)                      # 12 new keys: 7 + 12 > 16 -> three of them overflow per batch
+        entries, hits, misses = run(c + a, wc + wa)
+        assert hits == 6 and misses == 12 and entries == 16
+        entries, hits, misses = run(c + a, wc + wa)       # again: the 9 that fitted are warm now, 3 stay cold every time
+        assert hits == 6 + 9 and misses == 3 and entries == 16
+        emul.sbve_key_cache(0, 16)                        # off: same verdicts, nothing cached
+        entries, hits, misses = run(c + a, wc + wa)
+        assert hits == 0 and misses == 0
+    finally:
+        emul.sbve_key_cache(0, 0)

@@ -392,3 +392,44 @@ def test_concurrent_host_pointer_calls_are_pipelined_and_correct(gpu, oracle):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+def test_persistent_key_table_cache_on_gpu(gpu, oracle):
+    """sbv_p256_key_cache: batch 1 builds the tables, batch 2 (other signatures of the same 300 keys) is all hits, a
+    capacity smaller than the key set overflows into the per-batch area; verdicts always equal the oracle's, cache on or off."""
+    n = 1 << 18
+
+    def batch(seed, nkeys):
+        tup = ctypes.create_string_buffer(160 * n)
+        exp = ctypes.create_string_buffer(n // 8)
+        oracle.sbvo_gen_batch(seed, n, nkeys, 7, tup, exp, os.cpu_count() or 1)
+        return tup, exp.raw
+
+    def run(tup, exp):
+        got = ctypes.create_string_buffer(n // 8)
+        gpu.verify_batch_ptr(ctypes.addressof(tup), n, ctypes.addressof(got))
+        assert got.raw == exp
+        return gpu.key_cache_stats()
+
+    a, ea = batch(0xE1, 300)
+    b, eb = batch(0xE1, 300)          # same seed: same keys; different corruption pattern? (same n -> identical) so use another too
+    c, ec = batch(0xE2, 300)
+    try:
+        gpu.key_cache(False)
+        gpu.key_cache(True, 4096)
+        entries, hits, misses, cap = run(a, ea)
+        assert hits == 0 and misses >= 300 and entries == misses and cap == 4096
+        first = entries
+        entries, hits, misses, cap = run(b, eb)
+        assert misses == 0 and hits == first and entries == first
+        entries, hits, misses, cap = run(c, ec)
+        assert hits == 0 and misses >= 300 and entries == first + misses
+        gpu.key_cache(False)
+        gpu.key_cache(True, 256)      # smaller than one batch's key set: the overflow is rebuilt per batch
+        entries, hits, misses, cap = run(a, ea)
+        assert entries == 256 and cap == 256
+        entries, hits, misses, cap = run(a, ea)
+        assert hits == 256 and misses == first - 256
+    finally:
+        gpu.key_cache(False)
+        gpu.key_cache(True, 4096)
