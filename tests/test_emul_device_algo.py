@@ -441,3 +441,25 @@ def test_persistent_key_table_cache_never_changes_verdicts(emul, oracle, golden_
         assert hits == 0 and misses == 0
     finally:
         emul.sbve_key_cache(0, 0)
+
+
+def test_two_field_representations_agree(emul, oracle, golden_vectors):
+    """The kernels run on the carry-free field (p256_fe29.h ...); the earlier 8 x 32-bit-limb lanes (p256_core.h: prep_chunk,
+    verify_lane with its fast / exact passes) are kept as a second, independently written implementation of the same
+    per-signature algorithm: both must give the oracle's verdicts on the golden vectors and on a seeded batch."""
+    emul.sbve_p256_verify_batch_v0.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+    n = 500
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0x7A, n, 9, 3, tup, exp, 4)
+    allt = blob + tup.raw
+    total = len(allt) // 160
+    want = [v["accept"] for v in vs] + _bitmap_list(exp.raw, n)
+    a = ctypes.create_string_buffer((total + 7) // 8)
+    b = ctypes.create_string_buffer((total + 7) // 8)
+    emul.sbve_p256_verify_batch(allt, total, a, 64, 4)
+    emul.sbve_p256_verify_batch_v0(allt, total, b, 64, 4)
+    assert _bitmap_list(a.raw, total) == want
+    assert _bitmap_list(b.raw, total) == want
