@@ -116,9 +116,16 @@ void parallel_chunks(size_t n, F fn) {
 namespace {
 class SbvBackend : public Backend {
  public:
-    explicit SbvBackend(int device) { rc_ = sbv_init(device); }
+    // device >= 0: that GPU.  device < 0: every GPU of the node (sbv_init_all): generic batches go through the sharded
+    // entry (split over the devices above 2 x 2^18 tuples, otherwise one device round-robin); registered keys and the
+    // message front end stay on the first device.
+    explicit SbvBackend(int device) : all_(device < 0) {
+        if (all_) { const int n = sbv_init_all(); rc_ = n > 0 ? SBV_OK : (n < 0 ? n : SBV_ENODEV); }
+        else rc_ = sbv_init(device);
+    }
     int verify(const uint8_t* tuples, size_t n, uint8_t* bitmap) override {
         if (rc_ != SBV_OK) return rc_;                 // no device: every batch is UNAVAILABLE, never a CPU guess
+        if (all_) return sbv_p256_verify_batch_sharded(tuples, n, 0, 0, bitmap, nullptr, nullptr);
         return sbv_p256_verify_batch(tuples, n, bitmap);
     }
     long register_key(const uint8_t q[64]) override {
@@ -143,6 +150,7 @@ class SbvBackend : public Backend {
         return sbv_p256_verify_msgs_keyed(msgs, moff, sigs, soff, slots, n, bitmap);
     }
  private:
+    bool all_;
     int rc_;
 };
 class CallbackBackend : public Backend {

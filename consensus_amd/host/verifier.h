@@ -61,7 +61,7 @@ class Backend {
         (void)msgs; (void)moff; (void)sigs; (void)soff; (void)slots; (void)n; (void)bitmap; return -2;
     }
 };
-std::shared_ptr<Backend> make_sbv_backend(int device);     // sbv_init(device) + sbv_p256_verify_batch
+std::shared_ptr<Backend> make_sbv_backend(int device);     // device >= 0: sbv_init(device); device < 0: sbv_init_all() + the sharded entry
 typedef int (*backend_fn)(const uint8_t* tuples, size_t n, uint8_t* bitmap, void* user);
 std::shared_ptr<Backend> make_callback_backend(backend_fn fn, void* user, bool with_key_registry = false);
 

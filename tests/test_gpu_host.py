@@ -176,3 +176,16 @@ def test_config3_decision_replay_50000_x_11_on_gpu(lib):
         assert res.status == 0 and res.batch_tuples == 550000 and res.proposals_with_quorum == 50000
     finally:
         lib.sbvh_verifier_free(v)
+
+
+def test_host_verifier_over_all_gpus_of_the_node(lib):
+    """Backend device = -1: sbv_init_all + sbv_p256_verify_batch_sharded behind the same api.Verifier (one Verifier per
+    replica process drives every GPU of its node: pkg/consensus/consensus.go:35).  On this box that is one GPU."""
+    cb = hostlib.BACKEND_FN(lambda *a: -1)
+    v = lib.sbvh_verifier_new(0, -1, cb, None, 4096, 200, 0)
+    try:
+        res = hostlib.ReplayResult()
+        assert lib.sbvh_replay(v, 4, 2000, 2, 20, 16, ctypes.byref(res)) == 0
+        assert res.status == 0 and res.proposals_with_quorum == 20 and res.max_backend_batch >= 2000
+    finally:
+        lib.sbvh_verifier_free(v)
