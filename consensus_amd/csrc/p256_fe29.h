@@ -37,6 +37,8 @@ typedef int64_t i64;
 struct fe29 { i32 v[9]; };
 
 #define SBV_M29 0x1FFFFFFFu
+// x * 2^n for a possibly negative x (a left shift of a negative value is undefined before C++20; the unsigned detour is not)
+SBV_HD i32 f29_shl(i32 x, int n) { return (i32)((u32)x << n); }
 
 // p, R mod p, R^2 mod p, b*R mod p, 2^266 mod p (8x32 Montgomery form -> this domain), 2^256 mod p (back)
 SBV_HD fe29 f29_p() { fe29 r = {{0x1FFFFFFF, 0x1FFFFFFF, 0x1FFFFFFF, 0x000001FF, 0x00000000, 0x00000000, 0x00040000, 0x1FE00000, 0x00FFFFFF}}; return r; }
@@ -245,10 +247,10 @@ SBV_HD void f29_sqrx(fe29& r, const fe29& a) {
 // (-2^231, 2^256 + 2^231), limbs 0..7 within 2^27 of [0, 2^29)
 SBV_HD void f29_red_q(fe29& r) {
     const i32 q = r.v[8] >> 24;
-    r.v[8] -= q << 24;
-    r.v[7] += q << 21;
-    r.v[6] -= q << 18;
-    r.v[3] -= q << 9;
+    r.v[8] -= f29_shl(q, 24);
+    r.v[7] += f29_shl(q, 21);
+    r.v[6] -= f29_shl(q, 18);
+    r.v[3] -= f29_shl(q, 9);
     r.v[0] += q;
 }
 
@@ -291,37 +293,37 @@ SBV_HD void f29_norm(fe29& r, const fe29& a) {
 // any value in (-16p, 16p), limbs |v[i]| < 2^31  ->  the representative in [0, p), exact 29-bit limbs
 SBV_HD void f29_canon(fe29& r, const fe29& a) {
     const fe29 P = f29_p();
-    i32 v[9];
+    i64 v[9];                                        // 64-bit working limbs: a 2^31 - 1 limb plus a carry must not wrap
     SBV_UNROLL
     for (int i = 0; i < 9; ++i) v[i] = a.v[i];
     SBV_UNROLL
-    for (int i = 0; i < 8; ++i) { v[i + 1] += v[i] >> 29; v[i] &= (i32)SBV_M29; }
+    for (int i = 0; i < 8; ++i) { v[i + 1] += v[i] >> 29; v[i] &= (i64)SBV_M29; }
     // q = floor(value / 2^256) is within one of floor(value / p): subtract q * p, then fix up by at most one p each way
-    const i32 q = v[8] >> 24;                         // |q| <= 16; p = 2^256 - 2^224 + 2^192 + 2^96 - 1 limb by limb
-    v[8] -= q << 24; v[7] += q << 21; v[6] -= q << 18; v[3] -= q << 9; v[0] += q;
+    const i64 q = v[8] >> 24;                         // |q| <= 16; p = 2^256 - 2^224 + 2^192 + 2^96 - 1 limb by limb
+    v[8] -= q * (1 << 24); v[7] += q * (1 << 21); v[6] -= q * (1 << 18); v[3] -= q * (1 << 9); v[0] += q;
     SBV_UNROLL
-    for (int i = 0; i < 8; ++i) { v[i + 1] += v[i] >> 29; v[i] &= (i32)SBV_M29; }
+    for (int i = 0; i < 8; ++i) { v[i + 1] += v[i] >> 29; v[i] &= (i64)SBV_M29; }
     SBV_NOUNROLL
     for (int pass = 0; pass < 2; ++pass) {
-        const i32 neg = v[8] >> 31;                    // -1 when negative: add p
+        const i64 neg = v[8] >> 63;                   // -1 when negative: add p
         SBV_UNROLL
-        for (int i = 0; i < 9; ++i) v[i] += neg & P.v[i];
+        for (int i = 0; i < 9; ++i) v[i] += neg & (i64)P.v[i];
         SBV_UNROLL
-        for (int i = 0; i < 8; ++i) { v[i + 1] += v[i] >> 29; v[i] &= (i32)SBV_M29; }
+        for (int i = 0; i < 8; ++i) { v[i + 1] += v[i] >> 29; v[i] &= (i64)SBV_M29; }
     }
     SBV_NOUNROLL
     for (int pass = 0; pass < 2; ++pass) {
-        i32 t[9];
+        i64 t[9];
         SBV_UNROLL
         for (int i = 0; i < 9; ++i) t[i] = v[i] - P.v[i];
         SBV_UNROLL
-        for (int i = 0; i < 8; ++i) { t[i + 1] += t[i] >> 29; t[i] &= (i32)SBV_M29; }
+        for (int i = 0; i < 8; ++i) { t[i + 1] += t[i] >> 29; t[i] &= (i64)SBV_M29; }
         const bool ge = t[8] >= 0;                      // value >= p
         SBV_UNROLL
         for (int i = 0; i < 9; ++i) v[i] = ge ? t[i] : v[i];
     }
     SBV_UNROLL
-    for (int i = 0; i < 9; ++i) r.v[i] = v[i];
+    for (int i = 0; i < 9; ++i) r.v[i] = (i32)v[i];
 }
 // value == 0 (mod p) for |value| < 16 p.  A multiple k*p with |k| <= 16 has low limb -k mod 2^29 (limb 0 receives
 // no carry, so it IS the value mod 2^29): everything else is rejected by three instructions.

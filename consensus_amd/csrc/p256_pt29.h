@@ -28,10 +28,10 @@ struct apt29 { fe29 x, y; };           // affine; limbs tight (unpacked from can
 SBV_HD void f29_norm_red(fe29& r, const fe29& a) {
     f29_norm(r, a);
     const i32 q = r.v[8] >> 24;                 // floor(value / 2^256), |q| <= 16
-    r.v[8] -= q << 24;
-    r.v[7] += q << 21;
-    r.v[6] -= q << 18;
-    r.v[3] -= q << 9;
+    r.v[8] -= f29_shl(q, 24);
+    r.v[7] += f29_shl(q, 21);
+    r.v[6] -= f29_shl(q, 18);
+    r.v[3] -= f29_shl(q, 9);
     r.v[0] += q;
 }
 

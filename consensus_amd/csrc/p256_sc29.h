@@ -56,32 +56,32 @@ SBV_HD void s29_mul(fe29& r, const fe29& a, const fe29& b) {
 // any value in (-2N, 3N) with limbs |v[i]| < 2^31  ->  the representative in [0, N), exact limbs
 SBV_HD void s29_canon(fe29& r, const fe29& a) {
     const fe29 N = s29_n();
-    i32 v[9];
+    i64 v[9];
     SBV_UNROLL
     for (int i = 0; i < 9; ++i) v[i] = a.v[i];
     SBV_UNROLL
-    for (int i = 0; i < 8; ++i) { v[i + 1] += v[i] >> 29; v[i] &= (i32)SBV_M29; }
+    for (int i = 0; i < 8; ++i) { v[i + 1] += v[i] >> 29; v[i] &= (i64)SBV_M29; }
     SBV_NOUNROLL
     for (int pass = 0; pass < 2; ++pass) {
-        const i32 neg = v[8] >> 31;
+        const i64 neg = v[8] >> 63;
         SBV_UNROLL
-        for (int i = 0; i < 9; ++i) v[i] += neg & N.v[i];
+        for (int i = 0; i < 9; ++i) v[i] += neg & (i64)N.v[i];
         SBV_UNROLL
-        for (int i = 0; i < 8; ++i) { v[i + 1] += v[i] >> 29; v[i] &= (i32)SBV_M29; }
+        for (int i = 0; i < 8; ++i) { v[i + 1] += v[i] >> 29; v[i] &= (i64)SBV_M29; }
     }
     SBV_NOUNROLL
     for (int pass = 0; pass < 2; ++pass) {
-        i32 t[9];
+        i64 t[9];
         SBV_UNROLL
         for (int i = 0; i < 9; ++i) t[i] = v[i] - N.v[i];
         SBV_UNROLL
-        for (int i = 0; i < 8; ++i) { t[i + 1] += t[i] >> 29; t[i] &= (i32)SBV_M29; }
+        for (int i = 0; i < 8; ++i) { t[i + 1] += t[i] >> 29; t[i] &= (i64)SBV_M29; }
         const bool ge = t[8] >= 0;
         SBV_UNROLL
         for (int i = 0; i < 9; ++i) v[i] = ge ? t[i] : v[i];
     }
     SBV_UNROLL
-    for (int i = 0; i < 9; ++i) r.v[i] = v[i];
+    for (int i = 0; i < 9; ++i) r.v[i] = (i32)v[i];
 }
 // canonical 256-bit words of a residue (the value itself, whatever domain it is in)
 SBV_HD void s29_store_canon(u256& w, const fe29& a) {

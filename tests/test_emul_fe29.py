@@ -154,7 +154,7 @@ def test_f29_zero_tests_see_every_multiple_of_p(emul):
             # k * p spread over loose limbs: add a random limb-wise "zero" (borrow between neighbours)
             limbs = tight(k * P) if k >= 0 else [-v for v in tight(-k * P)]
             for i in range(8):
-                d = rng.randrange(-3, 4)
+                d = rng.randrange(-2, 3)                     # keeps every limb inside int32
                 limbs[i] += d << 29
                 limbs[i + 1] -= d
             assert val(limbs) == k * P

@@ -202,10 +202,15 @@ static int pipeline_test(const char* path) {
     // device
     uint8_t *d_t, *d_s, *d_b, *d_rr; u32* d_q; apt* d_g;
     CHECK(hipMalloc(&d_rr, cap / 64 + 64));
-    CHECK(hipMalloc(&d_t, cap * 160)); CHECK(hipMalloc(&d_s, cap * 193)); CHECK(hipMalloc(&d_q, cap * 1280));
-    CHECK(hipMalloc(&d_b, cap / 8)); CHECK(hipMalloc(&d_g, gt.size() * sizeof(apt)));
+    CHECK(hipMalloc(&d_t, cap * 160)); CHECK(hipMalloc(&d_s, cap * 193)); CHECK(hipMalloc(&d_q, cap * (size_t)SBV_QTAB29_WORDS * 4));
+    // the device kernels take the G comb in the carry-free field's domain (R = 2^261); the host side above is the 8 x 32 form
+    const int gbits = 16;
+    std::vector<apt> gc(gcomb_entries(gbits)), gc261(gcomb_entries(gbits));
+    host_build_gcomb(gbits, gc.data());
+    host_convert_table_r261(gc.data(), gc261.data(), gc.size());
+    CHECK(hipMalloc(&d_b, cap / 8)); CHECK(hipMalloc(&d_g, gc261.size() * sizeof(apt)));
     CHECK(hipMemcpy(d_t, tuples.data(), n * 160, hipMemcpyHostToDevice));
-    CHECK(hipMemcpy(d_g, gt.data(), gt.size() * sizeof(apt), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_g, gc261.data(), gc261.size() * sizeof(apt), hipMemcpyHostToDevice));
     CHECK(hipMemset(d_s, 0, cap * 193)); CHECK(hipMemset(d_b, 0, cap / 8));
     u32* base = (u32*)d_s;
     Scratch ds{base, base + cap * 8, base + cap * 16, base + cap * 24, base + cap * 32, base + cap * 40, d_s + cap * 192, cap};
@@ -235,7 +240,7 @@ static int pipeline_test(const char* path) {
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) { CHECK(hipMemcpy(d_s, hs.data(), cap * 192, hipMemcpyHostToDevice)); CHECK(hipMemcpy(d_s + cap * 192, hok.data(), cap, hipMemcpyHostToDevice)); }
         CHECK(hipMemset(d_b, 0, cap / 8));
-        CHECK(launch_p256_verify(ds, n, d_q, d_g, d_b, d_rr, 0));
+        CHECK(launch_p256_verify(ds, n, d_q, gcomb_make(d_g, gbits), d_b, d_rr, 0));
         CHECK(hipDeviceSynchronize());
         std::vector<uint8_t> dbm((n + 7) / 8);
         CHECK(hipMemcpy(dbm.data(), d_b, (n + 7) / 8, hipMemcpyDeviceToHost));
