@@ -283,6 +283,7 @@ def main():
     ap.add_argument("--tuples", type=int, default=1 << 20, help="tuples per GPU (default: the headline 2^20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--primary-only", action="store_true", help="skip the secondary legs (grouping off, registered keys): quick A/B runs")
+    ap.add_argument("--warm-leg", action="store_true", help="with --primary-only: still run the warm-key-cache leg")
     args = ap.parse_args()
 
     import numpy as np
@@ -417,6 +418,8 @@ def main():
                 extra[name] = fn()
             except Exception as e:      # noqa: BLE001 - the headline number must not depend on a secondary leg
                 extra[name] = {"error": repr(e)}
+    if world == 1 and args.primary_only and args.warm_leg:
+        extra["warm_key_cache"] = leg_warm_cache(sbv, torch, d_tuples, d_bitmap, valid, n, max(2, args.steps // 2), stream)
     if world > 1:
         flag = torch.tensor([1 if ok else 0], device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)

@@ -81,12 +81,24 @@ __global__ __launch_bounds__(1024) void k_key_cache_assign(const uint8_t* __rest
     }
 }
 
+// The table kernels are a few hundred lanes of latency-bound chains on the critical path of the step, sharing SIMDs with
+// the throughput kernels (G phase, Q phase, stage A): raise their wave priority so the arbiter issues them first.
+#ifndef SBV_TABLE_PRIO
+#define SBV_TABLE_PRIO 0
+#endif
+static __device__ __forceinline__ void table_prio() {
+#if SBV_TABLE_PRIO > 0
+    __builtin_amdgcn_s_setprio(SBV_TABLE_PRIO);
+#endif
+}
+
 __global__ __launch_bounds__(64) void k_keytab29_bases(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jstate,
                                                        apt* __restrict__ bases, u32* __restrict__ tmp, uint8_t* __restrict__ valid,
                                                        const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
                                                        int j_first, int j_last) {
     const u32 k = blockIdx.x * 64 + threadIdx.x;
     if (k >= group_count(g) || !cold[k]) return;
+    table_prio();
     keytab29_bases_lane(tuples, k, g, jstate, bases, tmp + (size_t)k * SBV_KT29_BASES_TMP_WORDS, valid + tslot[k], j_first, j_last);
 }
 // lanes = groups x j_count x 2
@@ -97,6 +109,7 @@ __global__ __launch_bounds__(64) void k_keytab29_rows(GroupState g, const apt* _
     const u32 which = lane & 1u, kw = lane >> 1;
     const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
     if (key >= group_count(g) || !cold[key]) return;
+    table_prio();
     const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
     u32* t = tmp + (size_t)g.max_groups * SBV_KT29_BASES_TMP_WORDS + w * SBV_KT29_WINDOW_TMP + (size_t)which * SBV_KT29_ROWS_TMP_WORDS;
     keytab29_rows_lane(bases + w * SBV_KT29_POINTS_PER_WINDOW, (int)which, j == SBV_GTAB_WINDOWS - 1, t,
@@ -114,6 +127,7 @@ __global__ __launch_bounds__(64) void k_keytab29_fill(GroupState g, u32* __restr
     int a_last = a_first + rows_per_lane - 1;
     if (a_last > 7) a_last = 7;
     if (a_first > 7) return;
+    table_prio();
     const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
     u32* t = tmp + (size_t)g.max_groups * SBV_KT29_BASES_TMP_WORDS + w * SBV_KT29_WINDOW_TMP + (size_t)r * SBV_KT29_FILL_TMP_WORDS;
     keytab29_fill_lane(a_first, a_last, t, ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);

@@ -11,6 +11,7 @@
 
 #include "p256_host.h"
 #include "ed25519_host.h"
+#include "chain_emul.h"
 #include "verifier.h"
 
 using namespace sbvhost;
@@ -381,6 +382,32 @@ int sbvh_replay(void* h, int n_nodes, int K, int sequences, int decisions, int t
     const CoalescerStats cs = V.stats();
     out->backend_batches = cs.batches;
     out->max_backend_batch = cs.max_batch;
+    return 0;
+}
+
+// SURVEY.md §8 a12 (chain_emul.cc): handles[i] = node i+1's Verifier.  ledgers: n_nodes x blocks x 32 bytes (Proposal.Digest()
+// of each delivered block, in order), ledger_len[n_nodes] = blocks delivered, signer_masks[n_nodes x blocks] = bit (id-1) per
+// signature handed to Deliver, counters[3] = rejected proposals, dropped votes, backend-unavailable answers.
+int sbvh_chain_emulate(void* const* handles, int n_nodes, int blocks, int batch_size, int byzantine_node, int bad_request_block,
+                       uint8_t* ledgers, uint32_t* ledger_len, uint64_t* signer_masks, uint64_t* counters) {
+    std::vector<Verifier*> vs;
+    for (int i = 0; i < n_nodes; ++i) vs.push_back(((VHandle*)handles[i])->v.get());
+    ChainEmulOptions opt;
+    opt.blocks = blocks; opt.batch_size = batch_size; opt.byzantine_node = byzantine_node; opt.bad_request_block = bad_request_block;
+    ChainEmulResult res;
+    const int rc = chain_emulate(vs, opt, &res);
+    counters[0] = res.rejected_proposals; counters[1] = res.dropped_votes; counters[2] = res.unavailable;
+    if (rc != 0) return rc;
+    memset(ledgers, 0, (size_t)n_nodes * blocks * 32);
+    for (int i = 0; i < n_nodes; ++i) {
+        ledger_len[i] = (uint32_t)res.ledgers[(size_t)i].size();
+        for (size_t b = 0; b < res.ledgers[(size_t)i].size(); ++b) {
+            memcpy(ledgers + ((size_t)i * blocks + b) * 32, res.ledgers[(size_t)i][b].data(), 32);
+            uint64_t m = 0;
+            for (uint64_t id : res.signers[(size_t)i][b]) m |= 1ull << (id - 1);
+            signer_masks[(size_t)i * blocks + b] = m;
+        }
+    }
     return 0;
 }
 

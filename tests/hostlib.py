@@ -8,6 +8,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BACKEND_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p)
 OK, INVALID, UNAVAILABLE = 0, 1, 2
+V = ctypes.c_void_p
 
 
 class ReplayResult(ctypes.Structure):
@@ -67,6 +68,9 @@ def load():
     lib.sbvh_pubkey.argtypes = [ctypes.c_char_p] * 2
     lib.sbvh_proposal_digest.argtypes = [ctypes.c_char_p, S, ctypes.c_char_p, S, ctypes.c_char_p, S, ctypes.c_int64, ctypes.c_char_p]
     lib.sbvh_compute_quorum.argtypes = [ctypes.c_uint64, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    lib.sbvh_chain_emulate.argtypes = [ctypes.POINTER(V), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64),
+                                       ctypes.POINTER(ctypes.c_uint64)]
     lib.sbvh_replay.argtypes = [V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ReplayResult)]
     return lib
 
@@ -117,3 +121,24 @@ def consenter_msg(payload, header, metadata, vseq, aux: bytes) -> bytes:
 def split_infos(raw: bytes):
     parts = raw.split(b"\0")[:-1]
     return [(parts[i].decode(), parts[i + 1].decode()) for i in range(0, len(parts), 2)]
+
+
+class ChainRun:
+    """One run of the chain emulation (consensus_amd/host/chain_emul.cc) over n_nodes Verifiers made by
+    `make_verifier()`; ledgers[node] = list of 32-byte block digests, signers[node][block] = set of signer ids."""
+
+    def __init__(self, lib, make_verifier, n_nodes=4, blocks=9, batch_size=1, byzantine_node=0, bad_request_block=0):
+        hs = [make_verifier() for _ in range(n_nodes)]
+        try:
+            arr = (V * n_nodes)(*hs)
+            led = ctypes.create_string_buffer(n_nodes * max(1, blocks) * 32)
+            lens = (ctypes.c_uint32 * n_nodes)()
+            masks = (ctypes.c_uint64 * (n_nodes * max(1, blocks)))()
+            cnt = (ctypes.c_uint64 * 3)()
+            self.rc = lib.sbvh_chain_emulate(arr, n_nodes, blocks, batch_size, byzantine_node, bad_request_block, led, lens, masks, cnt)
+            self.rejected_proposals, self.dropped_votes, self.unavailable = int(cnt[0]), int(cnt[1]), int(cnt[2])
+            self.ledgers = [[led.raw[(i * blocks + b) * 32:(i * blocks + b + 1) * 32] for b in range(lens[i])] for i in range(n_nodes)]
+            self.signers = [[{k + 1 for k in range(64) if masks[i * blocks + b] >> k & 1} for b in range(lens[i])] for i in range(n_nodes)]
+        finally:
+            for h in hs:
+                lib.sbvh_verifier_free(h)

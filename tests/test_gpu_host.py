@@ -189,3 +189,48 @@ def test_host_verifier_over_all_gpus_of_the_node(lib):
         assert res.status == 0 and res.proposals_with_quorum == 20 and res.max_backend_batch >= 2000
     finally:
         lib.sbvh_verifier_free(v)
+
+
+def _noop_factory(lib, keep):
+    def backend(_tuples, n, bitmap, _user):
+        ctypes.memset(bitmap, 0xFF, (n + 7) // 8)
+        return 0
+    cb = hostlib.BACKEND_FN(backend)
+    keep.append(cb)
+    return lambda: lib.sbvh_verifier_new(1, 0, cb, None, 4096, 200, 1)
+
+
+def test_chain_over_the_gpu_delivers_the_same_blocks_as_a_noop_verifier_run(lib):
+    """SURVEY.md §8 a12: the Verifier traffic of the reference's 4-node chain test (examples/naive_chain/chain_test.go:71-98;
+    consensus_amd/host/chain_emul.cc), every node with its own Verifier over libsbv.so, against the same run over no-op
+    Verifiers (examples/naive_chain/node.go:64-100): same blocks, same order, same signature sets at every node."""
+    keep = []
+    cb = hostlib.BACKEND_FN(lambda *a: -1)
+    gpu = lambda: lib.sbvh_verifier_new(0, 0, cb, None, 4096, 200, 1)       # noqa: E731
+    real = hostlib.ChainRun(lib, gpu, n_nodes=4, blocks=9, batch_size=1)
+    ref = hostlib.ChainRun(lib, _noop_factory(lib, keep), n_nodes=4, blocks=9, batch_size=1)
+    assert real.rc == 0 and real.unavailable == 0
+    assert all(len(l) == 9 for l in real.ledgers) and all(l == real.ledgers[0] for l in real.ledgers)
+    assert real.ledgers == ref.ledgers and real.signers == ref.signers
+    assert real.rejected_proposals == 0 and real.dropped_votes == 0
+    # larger cluster, batched blocks
+    real = hostlib.ChainRun(lib, gpu, n_nodes=10, blocks=5, batch_size=100)
+    ref = hostlib.ChainRun(lib, _noop_factory(lib, keep), n_nodes=10, blocks=5, batch_size=100)
+    assert real.rc == 0 and real.ledgers == ref.ledgers and real.signers == ref.signers
+    assert all(len(l) == 5 for l in real.ledgers) and all(len(s) == 7 for node in real.signers for s in node)
+
+
+def test_chain_faults_are_caught_by_the_gpu_verifier(lib):
+    """view_test.go:466 TestBadCommit / view.go:387-392 through the chain emulation: a commit vote signed with the wrong key and a
+    client request with a forged signature are well-formed — only the curve arithmetic on the device can reject them."""
+    keep = []
+    cb = hostlib.BACKEND_FN(lambda *a: -1)
+    gpu = lambda: lib.sbvh_verifier_new(0, 0, cb, None, 4096, 200, 1)       # noqa: E731
+    real = hostlib.ChainRun(lib, gpu, blocks=5, byzantine_node=2)
+    ref = hostlib.ChainRun(lib, _noop_factory(lib, keep), blocks=5, byzantine_node=2)
+    assert real.rc == 0 and all(len(l) == 5 for l in real.ledgers)
+    assert real.dropped_votes == 15 and ref.dropped_votes == 0
+    assert all(2 not in s for node in (0, 2, 3) for s in real.signers[node])
+    assert any(2 in s for s in ref.signers[0])
+    real = hostlib.ChainRun(lib, gpu, blocks=4, batch_size=3, bad_request_block=2)
+    assert real.rejected_proposals == 1 and all(len(l) == 3 for l in real.ledgers)
