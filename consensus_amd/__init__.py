@@ -243,6 +243,27 @@ def key_cache(enabled: bool, capacity: int = 0) -> None:
     _check(lib.sbv_p256_key_cache(1 if enabled else 0, capacity))
 
 
+def sign_batch(keys: bytes, digests: bytes, key_index=None):
+    """sbv_p256_sign_batch: RFC 6979 ECDSA P-256 signatures (r | s, 64 bytes each) of n 32-byte digests under the 32-byte private
+    scalars in `keys` (key_index[i], default i % n_keys).  Returns (sigs, ok) with ok[i] = 1 per produced signature."""
+    lib = load()
+    n, nk = len(digests) // 32, len(keys) // 32
+    lib.sbv_p256_sign_batch.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t,
+                                        ctypes.c_char_p, ctypes.c_char_p]
+    sigs, ok = ctypes.create_string_buffer(64 * n), ctypes.create_string_buffer(max(1, n))
+    idx = None if key_index is None else (ctypes.c_uint32 * n)(*key_index)
+    _check(lib.sbv_p256_sign_batch(keys, nk, idx, digests, n, sigs, ok))
+    return sigs.raw, ok.raw[:n]
+
+
+def sign_batch_dev(d_keys_ptr: int, n_keys: int, d_index_ptr: int, d_digests_ptr: int, n: int, d_sigs_ptr: int, d_ok_ptr: int,
+                   stream: int = 0) -> None:
+    lib = load()
+    lib.sbv_p256_sign_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    _check(lib.sbv_p256_sign_batch_dev(d_keys_ptr, n_keys, d_index_ptr or None, d_digests_ptr, n, d_sigs_ptr, d_ok_ptr, stream or None))
+
+
 def key_cache_stats():
     """(cached keys, groups of the last grouped batch that hit, that missed, capacity)"""
     out = (ctypes.c_uint32 * 4)()

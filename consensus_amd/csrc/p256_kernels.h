@@ -27,6 +27,9 @@ bool host_build_key_table(const uint8_t q[64], apt* out);
 // d_rerun: ceil(n/64) bytes of per-wavefront flags (fast pass -> exact pass)
 hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const gcomb& d_gcomb, uint8_t* d_bitmap, uint8_t* d_rerun,
                               hipStream_t stream);
+// batch signing (p256_sign.h): keys n_keys x 32 B, key_index n x u32 or nullptr (i % n_keys), digests n x 32 B -> sigs n x 64 B (r | s), ok n B
+hipError_t launch_p256_sign(const uint8_t* d_keys, u32 n_keys, const u32* d_key_index, const uint8_t* d_digests, size_t n,
+                            const gcomb& d_gcomb, uint8_t* d_sigs, uint8_t* d_ok, hipStream_t stream);
 // device buffers of the in-step key grouping (p256_group.h); owned by the context
 struct GroupBuffers {
     u32* ht = nullptr; u32 ht_mask = 0;

@@ -22,6 +22,7 @@
 
 #include "p256_core.h"
 #include "p256_kernels.h"
+#include "p256_sign.h"
 #include "p256_comb29.h"
 #include "sha256_dev.h"
 
@@ -169,6 +170,37 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify(Scratch s, 
     bool accept = false;
     if (i < n) accept = verify29_lane_generic(s, i, qtab + i * (size_t)SBV_QTAB29_WORDS, gc);
     finish_wave<false>(accept, false, i, n, bitmap, nullptr);
+}
+
+// Batch signing (p256_sign.h): lane i signs digest i with private key key_index[i] (or i % n_keys).
+// keys / digests / sigs are byte strings as on the wire (big-endian 32-byte integers); ok[i] = 1 when a signature was produced.
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_sign(const u32* __restrict__ keys, u32 n_keys, const u32* __restrict__ key_index,
+                                                                    const u32* __restrict__ digests, size_t n, gcomb gc,
+                                                                    u32* __restrict__ sigs, uint8_t* __restrict__ ok) {
+    const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    u32 kidx = key_index ? key_index[i] : (u32)(i % n_keys);
+    const bool known = kidx < n_keys;
+    if (!known) kidx = 0;
+    u32 d[8], h[8], rs[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        d[k] = __builtin_bswap32(keys[(size_t)kidx * 8 + k]);
+        h[k] = __builtin_bswap32(digests[i * 8 + k]);
+    }
+    const bool good = sign29_lane(d, h, gc, rs) && known;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sigs[i * 16 + k] = good ? __builtin_bswap32(rs[k]) : 0u;
+    ok[i] = good ? 1 : 0;
+}
+
+hipError_t launch_p256_sign(const uint8_t* d_keys, u32 n_keys, const u32* d_key_index, const uint8_t* d_digests, size_t n,
+                            const gcomb& d_gcomb, uint8_t* d_sigs, uint8_t* d_ok, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_p256_sign, dim3((unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK)), dim3(SBV_VERIFY_BLOCK), 0, stream,
+                       reinterpret_cast<const u32*>(d_keys), n_keys, d_key_index, reinterpret_cast<const u32*>(d_digests), n, d_gcomb,
+                       reinterpret_cast<u32*>(d_sigs), d_ok);
+    return hipGetLastError();
 }
 
 // Message front end: lane i hashes message i (SHA-256) and parses DER signature i,

@@ -1045,6 +1045,62 @@ extern "C" int sbv_ed25519_verify_msgs(const uint8_t* sigs, const uint8_t* pks, 
     return SBV_OK;
 }
 
+// ---- batch signing (p256_sign.h) ----------------------------------------------------------------------
+extern "C" int sbv_p256_sign_batch_dev(const void* d_keys, uint32_t n_keys, const void* d_key_index, const void* d_digests, size_t n,
+                                       void* d_sigs, void* d_ok, void* hip_stream) {
+    SBV_ENTER(c);
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (n == 0) return SBV_OK;
+    if (!d_keys || !d_digests || !d_sigs || !d_ok || n_keys == 0) { g_err = "null pointer or no keys"; return SBV_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(d_keys) | reinterpret_cast<uintptr_t>(d_digests) | reinterpret_cast<uintptr_t>(d_sigs) |
+         reinterpret_cast<uintptr_t>(d_key_index)) & 3) {
+        g_err = "misaligned device pointer";
+        return SBV_EINVAL;
+    }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_sign(static_cast<const uint8_t*>(d_keys), n_keys, static_cast<const u32*>(d_key_index),
+                                               static_cast<const uint8_t*>(d_digests), n, sbv::gcomb_make(c.d_g16r, c.g_bits),
+                                               static_cast<uint8_t*>(d_sigs), static_cast<uint8_t*>(d_ok),
+                                               static_cast<hipStream_t>(hip_stream)));
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_sign_batch(const uint8_t* keys, uint32_t n_keys, const uint32_t* key_index, const uint8_t* digests, size_t n,
+                                   uint8_t* sigs, uint8_t* ok) {
+    SBV_ENTER(c);
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (n == 0) return SBV_OK;
+    if (!keys || !digests || !sigs || !ok || n_keys == 0) { g_err = "null pointer or no keys"; return SBV_EINVAL; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    // not a hot path: buffers of the call's own size, released before returning (private keys do not linger in a pool)
+    uint8_t *d_keys = nullptr, *d_dig = nullptr, *d_sig = nullptr, *d_ok = nullptr;
+    u32* d_idx = nullptr;
+    int rc = SBV_OK;
+    auto fail = [&](int code, hipError_t e) { if (e != hipSuccess && rc == SBV_OK) { g_err = hipGetErrorString(e); rc = code; } return e != hipSuccess; };
+    do {
+        if (fail(SBV_ENOMEM, hipMalloc(&d_keys, (size_t)n_keys * 32))) break;
+        if (fail(SBV_ENOMEM, hipMalloc(&d_dig, n * 32))) break;
+        if (fail(SBV_ENOMEM, hipMalloc(&d_sig, n * 64))) break;
+        if (fail(SBV_ENOMEM, hipMalloc(&d_ok, n))) break;
+        if (key_index && fail(SBV_ENOMEM, hipMalloc(&d_idx, n * sizeof(u32)))) break;
+        if (fail(SBV_EDEVICE, hipMemcpyAsync(d_keys, keys, (size_t)n_keys * 32, hipMemcpyHostToDevice, c.stream))) break;
+        if (fail(SBV_EDEVICE, hipMemcpyAsync(d_dig, digests, n * 32, hipMemcpyHostToDevice, c.stream))) break;
+        if (key_index && fail(SBV_EDEVICE, hipMemcpyAsync(d_idx, key_index, n * sizeof(u32), hipMemcpyHostToDevice, c.stream))) break;
+        if (fail(SBV_EDEVICE, sbv::launch_p256_sign(d_keys, n_keys, d_idx, d_dig, n, sbv::gcomb_make(c.d_g16r, c.g_bits), d_sig, d_ok, c.stream))) break;
+        if (fail(SBV_EDEVICE, hipMemcpyAsync(sigs, d_sig, n * 64, hipMemcpyDeviceToHost, c.stream))) break;
+        if (fail(SBV_EDEVICE, hipMemcpyAsync(ok, d_ok, n, hipMemcpyDeviceToHost, c.stream))) break;
+        if (fail(SBV_EDEVICE, hipStreamSynchronize(c.stream))) break;
+        (void)hipMemsetAsync(d_keys, 0, (size_t)n_keys * 32, c.stream);
+        (void)hipStreamSynchronize(c.stream);
+    } while (false);
+    if (d_keys) (void)hipFree(d_keys);
+    if (d_dig) (void)hipFree(d_dig);
+    if (d_sig) (void)hipFree(d_sig);
+    if (d_ok) (void)hipFree(d_ok);
+    if (d_idx) (void)hipFree(d_idx);
+    return rc;
+}
+
 extern "C" void* sbv_host_alloc(size_t bytes) {
     SBV_ENTER(c);
     if (!c.ready || bytes == 0) return nullptr;

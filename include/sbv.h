@@ -106,6 +106,18 @@ int sbv_p256_clear_keys(void);
 int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* accept_bitmap);
 int sbv_p256_verify_batch_keyed_dev(const void* d_rsh, const void* d_slots, size_t n, void* d_bitmap, void* hip_stream);
 
+/* Batch signing: the batch form of api.Signer.Sign / SignProposal (pkg/api/dependencies.go:46-52;
+ * examples and tests sign with crypto/ecdsa over SHA-256).  Signature i = ECDSA-P256(key[key_index[i]], digests[i]) with the
+ * deterministic nonce of RFC 6979 (HMAC-SHA256), bit-identical to consensus_amd/host's Signer; key_index == NULL means key
+ * i % n_keys.  keys: n_keys x 32 bytes (private scalar, big-endian); digests: n x 32 bytes (SHA-256 of the message);
+ * sigs: n x 64 bytes r | s (big-endian; DER-encode for types.Signature.Value); ok[i] = 0 when key i is not in [1, N-1] or the
+ * index is out of range (sigs[i] is then all zero).  NOT constant-time (secret-indexed table lookups in HBM): for test
+ * traffic and trusted single-tenant hosts, see consensus_amd/csrc/p256_sign.h. */
+int sbv_p256_sign_batch(const uint8_t* keys, uint32_t n_keys, const uint32_t* key_index, const uint8_t* digests, size_t n,
+                        uint8_t* sigs, uint8_t* ok);
+int sbv_p256_sign_batch_dev(const void* d_keys, uint32_t n_keys, const void* d_key_index, const void* d_digests, size_t n,
+                            void* d_sigs, void* d_ok, void* hip_stream);
+
 /* Message front end on the device: SHA-256 of each message and the strict DER
  * parse of each signature run as a kernel in front of the registered-key verification, so the host
  * only concatenates bytes.  msg i = msgs[msg_offsets[i] .. msg_offsets[i+1]), signature i (ASN.1 DER,

@@ -18,6 +18,7 @@
 #include "../../consensus_amd/csrc/p256_group.h"
 #include "../../consensus_amd/csrc/p256_pt29.h"
 #include "../../consensus_amd/csrc/p256_keytab29.h"
+#include "../../consensus_amd/csrc/p256_sign.h"
 
 using namespace sbv;
 
@@ -467,6 +468,31 @@ int sbve_pt29_rx_matches(const i32* xyzz36, int inf, const u32* r) {
     R.inf = inf != 0;
     u256 rr; memcpy(&rr, r, 32);
     return pt29_rx_matches(R, rr) ? 1 : 0;
+}
+
+// batch signing (p256_sign.h) lane by lane: the source the k_p256_sign kernel runs
+void sbve_p256_sign_batch(const uint8_t* keys, uint32_t n_keys, const uint32_t* key_index, const uint8_t* digests, size_t n,
+                          uint8_t* sigs, uint8_t* ok) {
+    const gcomb gc = g16rtab();
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t kidx = key_index ? key_index[i] : (uint32_t)(i % n_keys);
+        const bool known = kidx < n_keys;
+        if (!known) kidx = 0;
+        u32 d[8], h[8], rs[16];
+        for (int k = 0; k < 8; ++k) {
+            const uint8_t* a = keys + (size_t)kidx * 32 + 4 * k;
+            const uint8_t* b = digests + i * 32 + 4 * k;
+            d[k] = ((u32)a[0] << 24) | ((u32)a[1] << 16) | ((u32)a[2] << 8) | a[3];
+            h[k] = ((u32)b[0] << 24) | ((u32)b[1] << 16) | ((u32)b[2] << 8) | b[3];
+        }
+        const bool good = sign29_lane(d, h, gc, rs) && known;
+        for (int k = 0; k < 16; ++k) {
+            const u32 w = good ? rs[k] : 0u;
+            sigs[i * 64 + 4 * k] = (uint8_t)(w >> 24); sigs[i * 64 + 4 * k + 1] = (uint8_t)(w >> 16);
+            sigs[i * 64 + 4 * k + 2] = (uint8_t)(w >> 8); sigs[i * 64 + 4 * k + 3] = (uint8_t)w;
+        }
+        ok[i] = good ? 1 : 0;
+    }
 }
 
 }  // extern "C"

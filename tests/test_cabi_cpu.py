@@ -139,3 +139,9 @@ def test_shard_plan_split_logic():
     for n2, dev, grp in [(1000003, 8, 0), (550001, 8, 11), (2 ** 21 + 5, 3, 7), (600000, 2, 0)]:
         pl = sbv.shard_plan(n2, dev, group=grp, min_per_device=1 << 16)
         assert pl[0] == 0 and pl[-1] == n2 and all(a < b for a, b in zip(pl, pl[1:])) and len(pl) - 1 <= dev
+
+
+def test_signing_refuses_without_a_gpu():
+    with pytest.raises(sbv.SbvError) as ei:
+        sbv.sign_batch((1).to_bytes(32, "big"), bytes(32))
+    assert ei.value.code == -5
