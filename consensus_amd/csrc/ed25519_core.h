@@ -17,9 +17,11 @@
 
 namespace sbv {
 
-struct ept { fe25 X, Y, Z, T; };
-struct pniels { fe25 YpX, YmX, Z, T2d; };   // 128 bytes
-struct aniels { fe25 ypx, ymx, xy2d; };     // 96 bytes
+struct ept { fe25 X, Y, Z, T; };            // coordinates tight (ed25519_fe.h) between operations
+struct pniels { fe25 YpX, YmX, Z, T2d; };   // in registers; parked as 4 x 10 raw limbs (per-lane scratch)
+struct aniels_r { fe25 ypx, ymx, xy2d; };   // in registers
+struct aniels { u256 ypx, ymx, xy2d; };     // table entry: 96 bytes, canonical residues (the comb of B: 50 MB, cache resident)
+#define SBV_ED_PT_WORDS 40                  // an extended or projective-Niels point as raw limbs
 
 #define SBV_ED_QTAB_ENTRIES 8
 // 16-bit comb of B: [S]B is 16 additions (an 8-bit comb needs 32).  16 x 32768 x 96 B = 50 MB: nothing for HBM / the
@@ -43,17 +45,19 @@ SBV_HD void ed_dbl(ept& r, const ept& p) {
     fe25_sub(g, yy, xx);
     fe25_sub(e, xy2, h);
     fe25_sub(f, zz2, g);
-    fe25_mul(r.X, e, f);
+    // limb bounds in units of "tight": h, g <= 2, e <= 3, f <= 4; the second operand of fe25_mul takes <= 3
+    fe25_mul(r.X, f, e);
     fe25_mul(r.Y, h, g);
-    fe25_mul(r.Z, g, f);
+    fe25_mul(r.Z, f, g);
     fe25_mul(r.T, e, h);
 }
 
 // R += (+-)q for a projective-Niels q; no-op when skip   (8M)
 SBV_HD void ed_add_pniels(ept& R, const pniels& q, bool neg, bool skip) {
+    if (skip) return;                  // a zero digit: rare, so a branch, not 40 selects
     fe25 a, b, c, d, e, f, g, h, ypx, ymx, t2d;
-    select256(ypx, neg, q.YmX, q.YpX);
-    select256(ymx, neg, q.YpX, q.YmX);
+    fe25_select(ypx, neg, q.YmX, q.YpX);
+    fe25_select(ymx, neg, q.YpX, q.YmX);
     fe25_cneg(t2d, q.T2d, neg);
     fe25_sub(a, R.Y, R.X);
     fe25_mul(a, a, ymx);
@@ -62,25 +66,23 @@ SBV_HD void ed_add_pniels(ept& R, const pniels& q, bool neg, bool skip) {
     fe25_mul(c, R.T, t2d);
     fe25_mul(d, R.Z, q.Z);
     fe25_add(d, d, d);
-    fe25_sub(e, b, a);
+    fe25_sub(e, b, a);                 // bounds: a, b, c tight; d, e, h <= 2; f, g <= 3
     fe25_sub(f, d, c);
     fe25_add(g, d, c);
     fe25_add(h, b, a);
     ept n;
-    fe25_mul(n.X, e, f);
+    fe25_mul(n.X, f, e);
     fe25_mul(n.Y, g, h);
     fe25_mul(n.Z, f, g);
     fe25_mul(n.T, e, h);
-    select256(R.X, skip, R.X, n.X);
-    select256(R.Y, skip, R.Y, n.Y);
-    select256(R.Z, skip, R.Z, n.Z);
-    select256(R.T, skip, R.T, n.T);
+    R = n;
 }
-// R += (+-)q for an affine-Niels q (Z2 = 1); no-op when skip   (7M)
-SBV_HD void ed_add_aniels(ept& R, const aniels& q, bool neg, bool skip) {
+// R += (+-)q for an affine-Niels q (Z2 = 1); no-op when skip   (7M).  q's limbs come from a table: [0, 2^w) = 2x tight.
+SBV_HD void ed_add_aniels(ept& R, const aniels_r& q, bool neg, bool skip) {
+    if (skip) return;                  // a zero digit: rare, so a branch, not 40 selects
     fe25 a, b, c, d, e, f, g, h, ypx, ymx, t2d;
-    select256(ypx, neg, q.ymx, q.ypx);
-    select256(ymx, neg, q.ypx, q.ymx);
+    fe25_select(ypx, neg, q.ymx, q.ypx);
+    fe25_select(ymx, neg, q.ypx, q.ymx);
     fe25_cneg(t2d, q.xy2d, neg);
     fe25_sub(a, R.Y, R.X);
     fe25_mul(a, a, ymx);
@@ -93,14 +95,39 @@ SBV_HD void ed_add_aniels(ept& R, const aniels& q, bool neg, bool skip) {
     fe25_add(g, d, c);
     fe25_add(h, b, a);
     ept n;
-    fe25_mul(n.X, e, f);
+    fe25_mul(n.X, f, e);
     fe25_mul(n.Y, g, h);
     fe25_mul(n.Z, f, g);
     fe25_mul(n.T, e, h);
-    select256(R.X, skip, R.X, n.X);
-    select256(R.Y, skip, R.Y, n.Y);
-    select256(R.Z, skip, R.Z, n.Z);
-    select256(R.T, skip, R.T, n.T);
+    R = n;
+}
+SBV_HD void aniels_load(aniels_r& e, const aniels* p) {
+    const u32* bp = reinterpret_cast<const u32*>(p);
+    fe25_load_packed(e.ypx, bp); fe25_load_packed(e.ymx, bp + 8); fe25_load_packed(e.xy2d, bp + 16);
+}
+// Tried and dropped (profiles/r02/ed25519_ab_r02.txt): 64-byte (y + x, y - x) entries for the per-batch key combs with
+// 2 d x y recomputed as (d / 2)((y + x)^2 - (y - x)^2).  The comb phases are bound by VALU issue, not by their gathers
+// (SQ_INSTS_VALU / SQ_BUSY_CYCLES is the same 7.5 as in the P-256 comb kernel), so the extra 1M + 2S cost 8 % and
+// the smaller table bought nothing.
+
+// A table entry as fetched (24 words): held in registers while the previous addition runs, unpacked at use — the comb
+// loops fetch one addition ahead, otherwise every addition waits out a random 96-byte gather (measured: the additions ran
+// at ~14 k cycles per wavefront against ~6 k of issued instructions).
+struct raw_aniels { u256 ypx, ymx, xy2d; };
+SBV_HD void raw_u256_load(u256& o, const f25_q4* s) {
+    const f25_q4 lo = s[0], hi = s[1];
+    o.v[0] = lo.x; o.v[1] = lo.y; o.v[2] = lo.z; o.v[3] = lo.w; o.v[4] = hi.x; o.v[5] = hi.y; o.v[6] = hi.z; o.v[7] = hi.w;
+}
+SBV_HD void raw_aniels_load(raw_aniels& e, const aniels* p) {
+    const f25_q4* s = reinterpret_cast<const f25_q4*>(p);
+    raw_u256_load(e.ypx, s); raw_u256_load(e.ymx, s + 2); raw_u256_load(e.xy2d, s + 4);
+}
+SBV_HD void raw_aniels_unpack(aniels_r& q, const raw_aniels& e) {
+    fe25_from_words(q.ypx, e.ypx.v); fe25_from_words(q.ymx, e.ymx.v); fe25_from_words(q.xy2d, e.xy2d.v);
+}
+SBV_HD void aniels_store(aniels* p, const aniels_r& e) {
+    u32* bp = reinterpret_cast<u32*>(p);
+    fe25_store_packed(bp, e.ypx); fe25_store_packed(bp + 8, e.ymx); fe25_store_packed(bp + 16, e.xy2d);
 }
 SBV_HD void ed_to_pniels(pniels& o, const ept& p) {
     const fe25 d2 = fe25_2d();
@@ -113,10 +140,9 @@ SBV_HD void ed_to_pniels(pniels& o, const ept& p) {
 // edwards25519.Point.SetBytes: `w` = the 8 little-endian dwords of the encoding.  false = not a point.
 SBV_HD bool ed_decompress(ept& A, const u32 w[8]) {
     fe25 y, y2, u, v, v3, v7, t, rr, check, nu, nui;
-    SBV_UNROLL
-    for (int i = 0; i < 8; ++i) y.v[i] = w[i];
+    fe25_from_words(y, w);                       // bit 255 is the sign; a non-canonical y (>= p) is accepted as y mod p
+    fe25_carry(y, y);                            // unsigned limbs -> tight: A.Y feeds sums that must stay within the contracts
     const bool sign = (w[7] >> 31) != 0;
-    y.v[7] &= 0x7FFFFFFFu;                       // non-canonical y (>= p) is accepted as y mod p
     const fe25 one = fe25_one(), dd = fe25_d(), sm1 = fe25_sqrtm1();
     fe25_sqr(y2, y);
     fe25_sub(u, y2, one);
@@ -135,7 +161,7 @@ SBV_HD bool ed_decompress(ept& A, const u32 w[8]) {
     const bool correct = fe25_eq(check, u), flipped = fe25_eq(check, nu), flipped_i = fe25_eq(check, nui);
     fe25 rp;
     fe25_mul(rp, rr, sm1);
-    select256(rr, flipped || flipped_i, rp, rr);
+    fe25_select(rr, flipped || flipped_i, rp, rr);
     fe25_cneg(rr, rr, fe25_is_negative(rr));     // Absolute(): the even root
     fe25_cneg(rr, rr, sign);                     // "-0" stays 0 and is accepted, as in Go
     A.X = rr;
@@ -149,10 +175,20 @@ SBV_HD bool ed_decompress(ept& A, const u32 w[8]) {
 SBV_HD u256 ed_L() { u256 r = {{0x5CF5D3EDu, 0x5812631Au, 0xA2F79CD6u, 0x14DEF9DEu, 0x00000000u, 0x00000000u, 0x00000000u, 0x10000000u}}; return r; }
 
 SBV_HD void pn_store(u32* dst, const pniels& p) {
-    fe_store16(dst, p.YpX); fe_store16(dst + 8, p.YmX); fe_store16(dst + 16, p.Z); fe_store16(dst + 24, p.T2d);
+    fe25_store_raw(dst, p.YpX); fe25_store_raw(dst + 10, p.YmX); fe25_store_raw(dst + 20, p.Z); fe25_store_raw(dst + 30, p.T2d);
 }
 SBV_HD void pn_load(pniels& p, const u32* src) {
-    fe_load16(p.YpX, src); fe_load16(p.YmX, src + 8); fe_load16(p.Z, src + 16); fe_load16(p.T2d, src + 24);
+    fe25_load_raw(p.YpX, src); fe25_load_raw(p.YmX, src + 10); fe25_load_raw(p.Z, src + 20); fe25_load_raw(p.T2d, src + 30);
+}
+
+// k.v[idx] without indexing the array by a run-time value: a dynamically indexed private array goes to scratch, and a
+// scratch access inside the comb loops makes every iteration wait for ALL outstanding vector-memory operations — including the
+// table entry fetched one addition ahead (vmcnt is in-order), which cost more than the additions themselves.
+SBV_HD u32 ed_word_at(const u256& k, int idx) {
+    u32 w = 0;
+    SBV_UNROLL
+    for (int l = 0; l < 8; ++l) w = idx == l ? k.v[l] : w;
+    return w;
 }
 
 // R += [S]B from the 16-bit comb b16[j * 32768 + (k-1)] = k * 2^(16j) * B; S < 2^253, so S + 0x8000...8000 does not
@@ -160,15 +196,36 @@ SBV_HD void pn_load(pniels& p, const u32* src) {
 SBV_HD void ed_add_sB(ept& R, const u256& S, const aniels* b16) {
     u256 ss;
     (void)add_const_limbs(ss, S, 0x80008000u);
+    int d = (int)(ss.v[0] & 0xFFFFu) - 32768;
+    raw_aniels cur;
+    raw_aniels_load(cur, b16 + ((d < 0 ? -d : d) == 0 ? 0 : (d < 0 ? -d : d) - 1));
     SBV_NOUNROLL
     for (int j = 0; j < SBV_ED_B16_WINDOWS; ++j) {
-        const int d = (int)((ss.v[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu) - 32768;
-        const int ad = d < 0 ? -d : d;
-        const u32* bp = reinterpret_cast<const u32*>(b16 + (size_t)j * SBV_ED_B16_PER_WINDOW + (ad == 0 ? 0 : ad - 1));
-        aniels e;
-        fe_load16(e.ypx, bp); fe_load16(e.ymx, bp + 8); fe_load16(e.xy2d, bp + 16);
+        const int jn = j + 1 < SBV_ED_B16_WINDOWS ? j + 1 : j;
+        const int dn = (int)((ed_word_at(ss, jn >> 1) >> ((jn & 1) * 16)) & 0xFFFFu) - 32768;
+        const int adn = dn < 0 ? -dn : dn;
+        raw_aniels nxt;
+        raw_aniels_load(nxt, b16 + (size_t)jn * SBV_ED_B16_PER_WINDOW + (adn == 0 ? 0 : adn - 1));
+        aniels_r e;
+        raw_aniels_unpack(e, cur);
         ed_add_aniels(R, e, d < 0, d == 0);
+        cur = nxt; d = dn;
     }
+}
+
+// encode(R) == renc (8 little-endian dwords), byte for byte
+SBV_HD bool ed_encoding_matches(const ept& R, const u32* renc) {
+    fe25 zi, x, y;
+    fe25_inv_gcd(zi, R.Z);            // division steps (modinv30.h): ~4x cheaper than the z^(p-2) chain
+    fe25_mul(x, R.X, zi);
+    fe25_mul(y, R.Y, zi);
+    u256 yw;
+    fe25_freeze(yw, y);
+    yw.v[7] |= (fe25_is_negative(x) ? 1u : 0u) << 31;
+    u32 diff = 0;
+    SBV_UNROLL
+    for (int j = 0; j < 8; ++j) diff |= yw.v[j] ^ renc[j];
+    return diff == 0;
 }
 
 // One tuple -> accept?  `w` indexes the tuple's 32 little-endian dwords, `qtab` = 8 x 32 dwords of
@@ -194,11 +251,11 @@ SBV_HD bool ed25519_verify_lane(Words w, u32* qtab, const aniels* btab) {
         ept t;
         ed_dbl(t, nA);
         ed_to_pniels(cur, t);
-        pn_store(qtab + 32, cur);
+        pn_store(qtab + SBV_ED_PT_WORDS, cur);
         for (int i = 3; i <= SBV_ED_QTAB_ENTRIES; ++i) {
             ed_add_pniels(t, one, false, false);
             ed_to_pniels(cur, t);
-            pn_store(qtab + (i - 1) * 32, cur);
+            pn_store(qtab + (i - 1) * SBV_ED_PT_WORDS, cur);
         }
     }
     // signed windows: k < 2^253 so k + 0x88..8 and S + 0x80..80 do not carry out of 256 bits
@@ -209,31 +266,25 @@ SBV_HD bool ed25519_verify_lane(Words w, u32* qtab, const aniels* btab) {
     for (int win = 63; win >= 0; --win) {
         SBV_NOUNROLL
         for (int t = 0; t < 4; ++t) ed_dbl(R, R);
-        const int d = (int)((kk.v[win >> 3] >> ((win & 7) * 4)) & 15u) - 8;
+        const int d = (int)((ed_word_at(kk, win >> 3) >> ((win & 7) * 4)) & 15u) - 8;
         const int ad = d < 0 ? -d : d;
         pniels e;
-        pn_load(e, qtab + (ad == 0 ? 0 : ad - 1) * 32);
+        pn_load(e, qtab + (ad == 0 ? 0 : ad - 1) * SBV_ED_PT_WORDS);
         ed_add_pniels(R, e, d < 0, d == 0);
     }
     ed_add_sB(R, S, btab);
     // encode(R) == R_enc, byte for byte
-    fe25 zi, x, y;
-    fe25_inv_gcd(zi, R.Z);            // division steps (modinv30.h): ~4x cheaper than the z^(p-2) chain
-    fe25_mul(x, R.X, zi);
-    fe25_mul(y, R.Y, zi);
-    fe25_freeze(y, y);
-    y.v[7] |= (fe25_is_negative(x) ? 1u : 0u) << 31;
-    u32 diff = 0;
-    SBV_UNROLL
-    for (int i = 0; i < 8; ++i) diff |= y.v[i] ^ renc[i];
-    return ok && diff == 0;
+    return ok && ed_encoding_matches(R, renc);
 }
 
 // ---- base-point comb (host, once per init; also tests/emul) --------------------------------------------
 // window j (0..15) of the 16-bit comb, callable from several host threads
 inline void build_ed_b16_window(int j, aniels* out_row) {
-    const fe25 bx = {{0x8F25D51Au, 0xC9562D60u, 0x9525A7B2u, 0x692CC760u, 0xFDD6DC5Cu, 0xC0A4E231u, 0xCD6E53FEu, 0x216936D3u}};
-    const fe25 by = {{0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u}};
+    const u32 bxw[8] = {0x8F25D51Au, 0xC9562D60u, 0x9525A7B2u, 0x692CC760u, 0xFDD6DC5Cu, 0xC0A4E231u, 0xCD6E53FEu, 0x216936D3u};
+    const u32 byw[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};
+    fe25 bx, by;
+    fe25_from_words(bx, bxw); fe25_carry(bx, bx);
+    fe25_from_words(by, byw); fe25_carry(by, by);
     const fe25 d2 = fe25_2d();
     ept base;
     base.X = bx; base.Y = by; base.Z = fe25_one(); fe25_mul(base.T, bx, by);
@@ -258,12 +309,12 @@ inline void build_ed_b16_window(int j, aniels* out_row) {
         fe25_mul(inv, inv, Z[k]);
         fe25_mul(x, X[k], zi);
         fe25_mul(y, Y[k], zi);
-        aniels a;
+        aniels_r a;
         fe25_add(a.ypx, y, x);
         fe25_sub(a.ymx, y, x);
         fe25_mul(a.xy2d, x, y);
         fe25_mul(a.xy2d, a.xy2d, d2);
-        out_row[k] = a;
+        aniels_store(out_row + k, a);
     }
     delete[] X; delete[] Y; delete[] Z; delete[] pre;
 }

@@ -23,7 +23,7 @@ namespace sbv {
 #define SBV_ED_KEY_WINDOWS 32              // k < L < 2^253: 32 signed 8-bit digits
 #define SBV_ED_KEY_PER_WINDOW 128
 #define SBV_ED_KEYTAB_ENTRIES (SBV_ED_KEY_WINDOWS * SBV_ED_KEY_PER_WINDOW)
-#define SBV_ED_JBASE_DWORDS 32             // one extended point
+#define SBV_ED_JBASE_DWORDS SBV_ED_PT_WORDS   // one extended point, raw limbs
 
 SBV_HD const u32* ed_tuple_words(const uint8_t* tuples, size_t i) { return reinterpret_cast<const u32*>(tuples + i * 128); }
 
@@ -54,10 +54,10 @@ SBV_HD bool ed_group_split_lane(size_t i, const GroupState& g) {
 }
 
 SBV_HD void ept_store(u32* dst, const ept& p) {
-    fe_store16(dst, p.X); fe_store16(dst + 8, p.Y); fe_store16(dst + 16, p.Z); fe_store16(dst + 24, p.T);
+    fe25_store_raw(dst, p.X); fe25_store_raw(dst + 10, p.Y); fe25_store_raw(dst + 20, p.Z); fe25_store_raw(dst + 30, p.T);
 }
 SBV_HD void ept_load(ept& p, const u32* src) {
-    fe_load16(p.X, src); fe_load16(p.Y, src + 8); fe_load16(p.Z, src + 16); fe_load16(p.T, src + 24);
+    fe25_load_raw(p.X, src); fe25_load_raw(p.Y, src + 10); fe25_load_raw(p.Z, src + 20); fe25_load_raw(p.T, src + 30);
 }
 
 // jbases: [groups][32] extended points 2^(8j) * (-A); valid[g] = the key decompressed.  One call produces
@@ -87,11 +87,12 @@ SBV_HD void ed_keytab_bases_lane(const uint8_t* tuples, u32 gidx, const GroupSta
 }
 
 // One part of one (key, window): row[k-1] = k * base for k = part*E + 1 .. part*E + E as affine-Niels points.
-// `tmp` = private scratch of E * (24 + 8) dwords (X, Y, Z and the running product of the Zs).
+// `tmp` = private scratch of E * SBV_ED_WINDOW_TMP_WORDS dwords (X, Y, Z and the running product of the Zs, raw limbs).
+#define SBV_ED_WINDOW_TMP_WORDS 40
 SBV_HD void ed_keytab_window_lane(const u32* jbase, int part, int parts, u32* tmp, aniels* row) {
     const int E = SBV_ED_KEY_PER_WINDOW / parts;      // parts is a power of two <= 16
-    u32* pts = tmp;                   // E * 24 dwords
-    u32* pre = tmp + E * 24;          // E * 8 dwords
+    u32* pts = tmp;                   // E * 30 dwords
+    u32* pre = tmp + E * 30;          // E * 10 dwords
     ept b;
     ept_load(b, jbase);
     pniels base;
@@ -108,8 +109,8 @@ SBV_HD void ed_keytab_window_lane(const u32* jbase, int part, int parts, u32* tm
     SBV_NOUNROLL
     for (int k = 0; k < E; ++k) {
         ed_add_pniels(t, base, false, false);                 // (m + k + 1) * base
-        fe_store16(pts + k * 24, t.X); fe_store16(pts + k * 24 + 8, t.Y); fe_store16(pts + k * 24 + 16, t.Z);
-        fe_store16(pre + k * 8, acc);
+        fe25_store_raw(pts + k * 30, t.X); fe25_store_raw(pts + k * 30 + 10, t.Y); fe25_store_raw(pts + k * 30 + 20, t.Z);
+        fe25_store_raw(pre + k * 10, acc);
         fe25_mul(acc, acc, t.Z);
     }
     fe25 inv;
@@ -118,39 +119,39 @@ SBV_HD void ed_keytab_window_lane(const u32* jbase, int part, int parts, u32* tm
     SBV_NOUNROLL
     for (int k = E - 1; k >= 0; --k) {
         fe25 X, Y, Z, pk, zi, x, y;
-        fe_load16(X, pts + k * 24); fe_load16(Y, pts + k * 24 + 8); fe_load16(Z, pts + k * 24 + 16);
-        fe_load16(pk, pre + k * 8);
+        fe25_load_raw(X, pts + k * 30); fe25_load_raw(Y, pts + k * 30 + 10); fe25_load_raw(Z, pts + k * 30 + 20);
+        fe25_load_raw(pk, pre + k * 10);
         fe25_mul(zi, inv, pk);
         fe25_mul(inv, inv, Z);
         fe25_mul(x, X, zi);
         fe25_mul(y, Y, zi);
-        aniels a;
+        aniels_r a;
         fe25_add(a.ypx, y, x);
         fe25_sub(a.ymx, y, x);
         fe25_mul(a.xy2d, x, y);
         fe25_mul(a.xy2d, a.xy2d, d2);
-        u32* dst = reinterpret_cast<u32*>(row + m + k);
-        fe_store16(dst, a.ypx); fe_store16(dst + 8, a.ymx); fe_store16(dst + 16, a.xy2d);
+        aniels_store(row + m + k, a);
     }
 }
 
-// gacc: 32 words per tuple (X, Y, Z, T limbs), limb-major: word w of tuple i at gacc[w * cap + i]
+// gacc: SBV_ED_GACC_WORDS words per tuple (X, Y, Z, T raw limbs), limb-major: word w of tuple i at gacc[w * cap + i]
+#define SBV_ED_GACC_WORDS 40
 SBV_HD void ed_gacc_store(u32* gacc, size_t cap, size_t i, const ept& R) {
     SBV_UNROLL
-    for (int l = 0; l < 8; ++l) {
-        gacc[(size_t)l * cap + i] = R.X.v[l];
-        gacc[(size_t)(8 + l) * cap + i] = R.Y.v[l];
-        gacc[(size_t)(16 + l) * cap + i] = R.Z.v[l];
-        gacc[(size_t)(24 + l) * cap + i] = R.T.v[l];
+    for (int l = 0; l < 10; ++l) {
+        gacc[(size_t)l * cap + i] = (u32)R.X.v[l];
+        gacc[(size_t)(10 + l) * cap + i] = (u32)R.Y.v[l];
+        gacc[(size_t)(20 + l) * cap + i] = (u32)R.Z.v[l];
+        gacc[(size_t)(30 + l) * cap + i] = (u32)R.T.v[l];
     }
 }
 SBV_HD void ed_gacc_load(ept& R, const u32* gacc, size_t cap, size_t i) {
     SBV_UNROLL
-    for (int l = 0; l < 8; ++l) {
-        R.X.v[l] = gacc[(size_t)l * cap + i];
-        R.Y.v[l] = gacc[(size_t)(8 + l) * cap + i];
-        R.Z.v[l] = gacc[(size_t)(16 + l) * cap + i];
-        R.T.v[l] = gacc[(size_t)(24 + l) * cap + i];
+    for (int l = 0; l < 10; ++l) {
+        R.X.v[l] = (i32)gacc[(size_t)l * cap + i];
+        R.Y.v[l] = (i32)gacc[(size_t)(10 + l) * cap + i];
+        R.Z.v[l] = (i32)gacc[(size_t)(20 + l) * cap + i];
+        R.T.v[l] = (i32)gacc[(size_t)(30 + l) * cap + i];
     }
 }
 
@@ -168,20 +169,6 @@ SBV_HD void ed_gphase_lane(const uint8_t* tuples, size_t i, const aniels* btab, 
     ed_gacc_store(gacc, cap, i, R);
 }
 
-// encode(R) == R_enc (the tuple's first 8 dwords), byte for byte
-SBV_HD bool ed_encoding_matches(const ept& R, const u32* renc) {
-    fe25 zi, x, y;
-    fe25_inv_gcd(zi, R.Z);
-    fe25_mul(x, R.X, zi);
-    fe25_mul(y, R.Y, zi);
-    fe25_freeze(y, y);
-    y.v[7] |= (fe25_is_negative(x) ? 1u : 0u) << 31;
-    u32 diff = 0;
-    SBV_UNROLL
-    for (int j = 0; j < 8; ++j) diff |= y.v[j] ^ renc[j];
-    return diff == 0;
-}
-
 // R (from gacc) += windows [j0, j1) of [k](-A) from the key's comb.  `last` -> the verdict is returned; otherwise
 // R goes back to gacc and the return value is meaningless.
 SBV_HD bool ed_qphase_lane(const uint8_t* tuples, size_t i, u32 slot, u32 nkeys, const aniels* ktab, const uint8_t* kvalid,
@@ -195,16 +182,22 @@ SBV_HD bool ed_qphase_lane(const uint8_t* tuples, size_t i, u32 slot, u32 nkeys,
     ok = ok && kvalid[slot] != 0;
     const aniels* tab = ktab + (size_t)slot * SBV_ED_KEYTAB_ENTRIES;
     (void)add_const_limbs(kk, k, 0x80808080u);       // k >= L was rejected above; k < 2^253 cannot carry out
+    int d = (int)((ed_word_at(kk, j0 >> 2) >> ((j0 & 3) * 8)) & 255u) - 128;
+    raw_aniels cur;
+    raw_aniels_load(cur, tab + (size_t)j0 * SBV_ED_KEY_PER_WINDOW + ((d < 0 ? -d : d) == 0 ? 0 : (d < 0 ? -d : d) - 1));
     ept R;
     ed_gacc_load(R, gacc, cap, i);
     SBV_NOUNROLL
     for (int j = j0; j < j1; ++j) {
-        const int d = (int)((kk.v[j >> 2] >> ((j & 3) * 8)) & 255u) - 128;
-        const int ad = d < 0 ? -d : d;
-        const u32* bp = reinterpret_cast<const u32*>(tab + (size_t)j * SBV_ED_KEY_PER_WINDOW + (ad == 0 ? 0 : ad - 1));
-        aniels e;
-        fe_load16(e.ypx, bp); fe_load16(e.ymx, bp + 8); fe_load16(e.xy2d, bp + 16);
+        const int jn = j + 1 < j1 ? j + 1 : j;                     // the entry of the next window is fetched while this addition runs
+        const int dn = (int)((ed_word_at(kk, jn >> 2) >> ((jn & 3) * 8)) & 255u) - 128;
+        const int adn = dn < 0 ? -dn : dn;
+        raw_aniels nxt;
+        raw_aniels_load(nxt, tab + (size_t)jn * SBV_ED_KEY_PER_WINDOW + (adn == 0 ? 0 : adn - 1));
+        aniels_r e;
+        raw_aniels_unpack(e, cur);
         ed_add_aniels(R, e, d < 0, d == 0);
+        cur = nxt; d = dn;
     }
     if (!last) { ed_gacc_store(gacc, cap, i, R); return false; }
     u32 renc[8];

@@ -17,6 +17,10 @@
 
 namespace sbv {
 
+#ifndef SBV_ED_GROUP_WAVES
+#define SBV_ED_GROUP_WAVES 2      // waves/SIMD the comb kernels are compiled for: 234 VGPRs and no scratch at 2; 168 + 268 B of spills at 3, same speed (profiles/r02/ed25519_ab_r02.txt)
+#endif
+
 __global__ __launch_bounds__(256) void k_ed_group_insert(const uint8_t* __restrict__ tuples, size_t n, GroupState g) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) ed_group_insert_lane(tuples, i, g);
@@ -47,30 +51,30 @@ __global__ __launch_bounds__(64) void k_ed_keytab_window(GroupState g, const u32
     if (key >= group_count(g)) return;
     const size_t w = (size_t)key * SBV_ED_KEY_WINDOWS + j;
     ed_keytab_window_lane(jbases + w * SBV_ED_JBASE_DWORDS, (int)part, parts,
-                          tmp + w * (SBV_ED_KEY_PER_WINDOW * 32) + (size_t)part * (SBV_ED_KEY_PER_WINDOW / parts) * 32,
+                          tmp + w * (size_t)(SBV_ED_KEY_PER_WINDOW * SBV_ED_WINDOW_TMP_WORDS) + (size_t)part * (SBV_ED_KEY_PER_WINDOW / parts) * SBV_ED_WINDOW_TMP_WORDS,
                           ktab + w * SBV_ED_KEY_PER_WINDOW);
 }
 
 // The one-lane kernel (ed25519_verify_lane) over the ungrouped list, at the 3 waves/SIMD budget of the throughput
 // kernels it runs beside.  A ~2.5 ms serial chain per lane: it goes on side_a behind the last bases so that it
 // gates nothing but the final pack.
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_ed_generic_list(const uint8_t* __restrict__ tuples, GroupState g,
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_generic_list(const uint8_t* __restrict__ tuples, GroupState g,
                                                                         u32* __restrict__ qtab, const aniels* __restrict__ btab,
                                                                         uint8_t* __restrict__ acc) {
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= g.counters[2]) return;
     const u32 t = g.ung_idx[L];
-    acc[t] = ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab + (size_t)L * (SBV_ED_QTAB_ENTRIES * 32), btab) ? 1 : 0;
+    acc[t] = ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab + (size_t)L * (SBV_ED_QTAB_ENTRIES * SBV_ED_PT_WORDS), btab) ? 1 : 0;
 }
 
 // [S]B for every tuple of the batch
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_ed_gphase(const uint8_t* __restrict__ tuples, size_t n, const aniels* __restrict__ btab,
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_gphase(const uint8_t* __restrict__ tuples, size_t n, const aniels* __restrict__ btab,
                                                                   u32* __restrict__ gacc, size_t cap, uint8_t* __restrict__ okb) {
     const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (i < n) ed_gphase_lane(tuples, i, btab, gacc, cap, okb);
 }
 
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_ed_qphase(const uint8_t* __restrict__ tuples, GroupState g,
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_qphase(const uint8_t* __restrict__ tuples, GroupState g,
                                                                   const aniels* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
                                                                   u32* __restrict__ gacc, size_t cap, const uint8_t* __restrict__ okb,
                                                                   uint8_t* __restrict__ acc, int j0, int j1, int last) {

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_LB_WAVES) void k_ed25519_v
     __syncthreads();
     const size_t i = tile + (size_t)tid;
     bool accept = false;
-    if (i < n) accept = ed25519_verify_lane(EdLdsTuple{lds + tid * kEdPitch}, qtab + i * (size_t)(SBV_ED_QTAB_ENTRIES * 32), btab);
+    if (i < n) accept = ed25519_verify_lane(EdLdsTuple{lds + tid * kEdPitch}, qtab + i * (size_t)(SBV_ED_QTAB_ENTRIES * SBV_ED_PT_WORDS), btab);
     const unsigned long long m = __ballot(accept);
     const int lane = tid & 63;
     const size_t wave_first = i - (size_t)lane;

@@ -216,7 +216,7 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jbases, G * SBV_GTAB_WINDOWS * (size_t)40 * sizeof(u32)));   // 40 dwords = one Jacobian base (p256_group.h)
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.bases, G * SBV_GTAB_WINDOWS * (size_t)2 * sizeof(sbv::apt)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jstate, G * (size_t)27 * sizeof(u32)));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 36 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride; 36 words (P-256: XYZZ, 9-limb coordinates) or 32 (Ed25519) per tuple
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 40 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride; 36 words (P-256: XYZZ, 9-limb coordinates) or 40 (Ed25519: extended, 10-limb coordinates) per tuple
     // comb pool: slots [0, kc_cap) belong to the persistent key-table cache, [kc_cap, kc_cap + G) are rebuilt per batch
     const size_t K = c.kc_cap;
     size_t kht = 1024;
@@ -233,7 +233,7 @@ int ensure_group_buffers(Context& c, size_t n) {
     b.kc.ht_mask = (u32)(kht - 1);
     b.kc.cap = (u32)K;
     b.kc.enabled = c.kc_enabled ? 1u : 0u;
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tmp, G * SBV_GTAB_WINDOWS * (size_t)(SBV_GTAB_PER_WINDOW * 32) * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tmp, G * SBV_GTAB_WINDOWS * (size_t)(SBV_GTAB_PER_WINDOW * 40) * sizeof(u32)));     // Ed25519: 128 x 40 raw limbs per (key, window)
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.acc, cap));
     b.ht_mask = (u32)(ht - 1);
     b.max_groups = (u32)G;

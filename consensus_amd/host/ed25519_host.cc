@@ -142,8 +142,11 @@ void muladd_mod_l(const uint64_t a[4], const uint64_t b[4], const uint64_t c[4],
 
 // ---- [s]B and point encoding -------------------------------------------------------------------------
 void scalar_mult_base(const uint8_t s[32], uint8_t enc[32]) {
-    const fe25 bx = {{0x8F25D51Au, 0xC9562D60u, 0x9525A7B2u, 0x692CC760u, 0xFDD6DC5Cu, 0xC0A4E231u, 0xCD6E53FEu, 0x216936D3u}};
-    const fe25 by = {{0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u}};
+    const uint32_t bxw[8] = {0x8F25D51Au, 0xC9562D60u, 0x9525A7B2u, 0x692CC760u, 0xFDD6DC5Cu, 0xC0A4E231u, 0xCD6E53FEu, 0x216936D3u};
+    const uint32_t byw[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};
+    fe25 bx, by;
+    sbv::fe25_from_words(bx, bxw); sbv::fe25_carry(bx, bx);
+    sbv::fe25_from_words(by, byw); sbv::fe25_carry(by, by);
     ept base;
     base.X = bx; base.Y = by; base.Z = sbv::fe25_one(); sbv::fe25_mul(base.T, bx, by);
     pniels bn;
@@ -158,10 +161,11 @@ void scalar_mult_base(const uint8_t s[32], uint8_t enc[32]) {
     sbv::fe25_inv(zi, r.Z);
     sbv::fe25_mul(x, r.X, zi);
     sbv::fe25_mul(y, r.Y, zi);
-    sbv::fe25_freeze(y, y);
-    y.v[7] |= (sbv::fe25_is_negative(x) ? 1u : 0u) << 31;
+    sbv::u256 yw;
+    sbv::fe25_freeze(yw, y);
+    yw.v[7] |= (sbv::fe25_is_negative(x) ? 1u : 0u) << 31;
     for (int i = 0; i < 8; ++i)
-        for (int b = 0; b < 4; ++b) enc[4 * i + b] = (uint8_t)(y.v[i] >> (8 * b));
+        for (int b = 0; b < 4; ++b) enc[4 * i + b] = (uint8_t)(yw.v[i] >> (8 * b));
 }
 void expand(const uint8_t seed[32], uint8_t a[32], uint8_t prefix[32]) {
     uint8_t h[64];

@@ -323,7 +323,7 @@ struct EdWords {
 };
 void sbve_ed25519_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap) {
     memset(bitmap, 0, (n + 7) / 8);
-    u32* qtab = (u32*)aligned_alloc(16, SBV_ED_QTAB_ENTRIES * 32 * 4);
+    u32* qtab = (u32*)aligned_alloc(16, SBV_ED_QTAB_ENTRIES * SBV_ED_PT_WORDS * 4);
     for (size_t i = 0; i < n; ++i)
         if (ed25519_verify_lane(EdWords{tuples + 128 * i}, qtab, btab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
     free(qtab);
@@ -348,13 +348,13 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     for (size_t i = 0; i < n; ++i) group_assign_lane(i, g);
     for (size_t i = 0; i < n; ++i) ed_group_split_lane(i, g);
     const u32 ngroups = counters[0] < max_groups ? counters[0] : max_groups;
-    std::vector<u32> gacc(32 * cap);
+    std::vector<u32> gacc(SBV_ED_GACC_WORDS * cap);
     for (size_t i = 0; i < n; ++i) ed_gphase_lane(tuples, i, btab(), gacc.data(), cap, okb.data());
     const size_t ng1 = ngroups ? ngroups : 1;
     u32* jbases = (u32*)aligned_alloc(16, ng1 * SBV_ED_KEY_WINDOWS * SBV_ED_JBASE_DWORDS * 4);
     aniels* ktab = (aniels*)aligned_alloc(64, ng1 * SBV_ED_KEYTAB_ENTRIES * sizeof(aniels));
     std::vector<uint8_t> kvalid(ng1, 0);
-    u32* tmpa = (u32*)aligned_alloc(16, SBV_ED_KEY_PER_WINDOW * 32 * 4);
+    u32* tmpa = (u32*)aligned_alloc(16, SBV_ED_KEY_PER_WINDOW * SBV_ED_WINDOW_TMP_WORDS * 4);
     memset(bitmap, 0, (n + 7) / 8);
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_ED_KEY_WINDOWS * c / chunks, j_end = SBV_ED_KEY_WINDOWS * (c + 1) / chunks;
@@ -372,7 +372,7 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
             if (last && v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
         }
     }
-    u32* qtab = (u32*)aligned_alloc(16, SBV_ED_QTAB_ENTRIES * 32 * 4);
+    u32* qtab = (u32*)aligned_alloc(16, SBV_ED_QTAB_ENTRIES * SBV_ED_PT_WORDS * 4);
     for (u32 L = 0; L < counters[2]; ++L) {
         const u32 t = ung_idx[L];
         if (ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab, btab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
@@ -387,13 +387,16 @@ void sbve_ed_msg_frontend(const uint8_t* sig64, const uint8_t* a32, const uint8_
     ed_msg_frontend_lane(sig64, a32, msg, mlen, w);
     memcpy(out128, w, 128);
 }
-void sbve_fe25_inv_gcd(const u32* a, u32* out) { fe25 x, z; memcpy(&x, a, 32); fe25_inv_gcd(z, x); memcpy(out, &z, 32); }
-void sbve_fe25_mul(const u32* a, const u32* b, u32* out) { fe25 x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe25_mul(z, x, y); memcpy(out, &z, 32); }
-void sbve_fe25_sqr(const u32* a, u32* out) { fe25 x, z; memcpy(&x, a, 32); fe25_sqr(z, x); memcpy(out, &z, 32); }
-void sbve_fe25_add(const u32* a, const u32* b, u32* out) { fe25 x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe25_add(z, x, y); memcpy(out, &z, 32); }
-void sbve_fe25_sub(const u32* a, const u32* b, u32* out) { fe25 x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe25_sub(z, x, y); memcpy(out, &z, 32); }
-void sbve_fe25_inv(const u32* a, u32* out) { fe25 x, z; memcpy(&x, a, 32); fe25_inv(z, x); memcpy(out, &z, 32); }
-void sbve_fe25_freeze(const u32* a, u32* out) { fe25 x, z; memcpy(&x, a, 32); fe25_freeze(z, x); memcpy(out, &z, 32); }
+// carry-free GF(2^255-19) (ed25519_fe.h): ten raw signed limbs in and out; freeze -> 8 canonical words
+static fe25 f25in(const int32_t* a) { fe25 x; memcpy(&x, a, 40); return x; }
+void sbve_fe25_mul(const int32_t* a, const int32_t* b, int32_t* out) { fe25 z; fe25_mul(z, f25in(a), f25in(b)); memcpy(out, &z, 40); }
+void sbve_fe25_sqr(const int32_t* a, int32_t* out) { fe25 z; fe25_sqr(z, f25in(a)); memcpy(out, &z, 40); }
+void sbve_fe25_carry(const int32_t* a, int32_t* out) { fe25 z; fe25_carry(z, f25in(a)); memcpy(out, &z, 40); }
+void sbve_fe25_inv(const int32_t* a, int32_t* out) { fe25 z; fe25_inv(z, f25in(a)); memcpy(out, &z, 40); }
+void sbve_fe25_inv_gcd(const int32_t* a, int32_t* out) { fe25 z; fe25_inv_gcd(z, f25in(a)); memcpy(out, &z, 40); }
+void sbve_fe25_freeze(const int32_t* a, u32* out8) { u256 w; fe25_freeze(w, f25in(a)); memcpy(out8, &w, 32); }
+void sbve_fe25_from_words(const u32* w8, int32_t* out) { fe25 z; fe25_from_words(z, w8); memcpy(out, &z, 40); }
+void sbve_fe25_consts(int32_t* out30) { fe25 d = fe25_d(), d2 = fe25_2d(), s = fe25_sqrtm1(); memcpy(out30, &d, 40); memcpy(out30 + 10, &d2, 40); memcpy(out30 + 20, &s, 40); }
 
 // ---- unit hooks (plain little-endian limb arrays) ---------------------------------------------------
 void sbve_fe_mul(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe_mul(z, x, y); memcpy(out, &z, 32); }

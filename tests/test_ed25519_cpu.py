@@ -41,24 +41,71 @@ def test_oracle_matches_vectors_and_openssl(oracle, openssl_check, ed_vectors):
     assert n_ssl >= 40
 
 
+POS = [(51 * i + 1) // 2 for i in range(10)]                 # limb i sits at bit ceil(25.5 i)
+WID = [25 if i & 1 else 26 for i in range(10)]
+
+
+def fval(limbs10):
+    return sum(int(v) << POS[i] for i, v in enumerate(limbs10))
+
+
+def flimbs(vals):
+    return (ctypes.c_int32 * 10)(*vals)
+
+
+def tight(out):
+    return all(abs(int(out[i])) <= (1 << (WID[i] - 1)) + (1 << 19) for i in range(10))
+
+
+def rand_limbs(rng, mult, corner=False):
+    """limbs up to mult x tight (tight = 2^(w-1)), signed; corner: every limb at +- the bound"""
+    out = []
+    for i in range(10):
+        b = mult * (1 << (WID[i] - 1))
+        out.append(rng.choice((-b, b)) if corner else rng.randint(-b, b))
+    return out
+
+
 def test_fe25_ops_match_bigint(emul):
+    """consensus_amd/csrc/ed25519_fe.h (10 signed limbs, radix 2^25.5) against Python integers, at and inside the operand contracts
+    (the emulator build aborts on a contract violation: -DSBV_F25_CHECK)."""
     rng = random.Random(25519)
-    R = 1 << 256
-    vals = [0, 1, 2, 19, P - 1, P, P + 1, 2 * P - 1, 2 * P, 2 * P + 37, R - 1, R - 38, R - 39, 2**255 - 1, 2**255, 2**255 + 18,
-            2**32 - 1, 2**224, (1 << 256) - (1 << 224)] + [rng.randrange(R) for _ in range(300)]
-    out = (ctypes.c_uint32 * 8)()
-    for i, a in enumerate(vals):
-        b = vals[(i * 7 + 3) % len(vals)]
-        emul.sbve_fe25_mul(limbs(a), limbs(b), out); assert val(out) % P == a * b % P and val(out) < R
-        emul.sbve_fe25_sqr(limbs(a), out); assert val(out) % P == a * a % P
-        emul.sbve_fe25_add(limbs(a), limbs(b), out); assert val(out) % P == (a + b) % P
-        emul.sbve_fe25_sub(limbs(a), limbs(b), out); assert val(out) % P == (a - b) % P
-        emul.sbve_fe25_freeze(limbs(a), out); assert val(out) == a % P
-    for a in [1, 2, P - 1, R - 1] + [rng.randrange(1, R) for _ in range(10)]:
-        if a % P == 0:
+    out = (ctypes.c_int32 * 10)()
+    w8 = (ctypes.c_uint32 * 8)()
+    for it in range(400):
+        corner = it < 40
+        a, b, c = rand_limbs(rng, 8, corner), rand_limbs(rng, 3, corner), rand_limbs(rng, 3, corner)
+        emul.sbve_fe25_mul(flimbs(a), flimbs(b), out)
+        assert fval(out) % P == fval(a) * fval(b) % P and tight(out)
+        emul.sbve_fe25_sqr(flimbs(c), out)
+        assert fval(out) % P == fval(c) ** 2 % P and tight(out)
+        emul.sbve_fe25_carry(flimbs(a), out)
+        assert fval(out) % P == fval(a) % P and tight(out)
+        emul.sbve_fe25_freeze(flimbs(a), w8)
+        assert val(w8) == fval(a) % P
+    # values around the modulus, through words -> limbs -> freeze
+    for x in [0, 1, 18, 19, P - 1, P, P + 1, 2**255 - 1, 2**255 - 20, 2**254, (1 << 255) - (1 << 230)] + [rng.randrange(1 << 255) for _ in range(100)]:
+        emul.sbve_fe25_from_words(limbs(x), out)
+        assert fval(out) == x and all(0 <= int(out[i]) < (1 << WID[i]) for i in range(10))
+        emul.sbve_fe25_freeze(out, w8)
+        assert val(w8) == x % P
+        neg = flimbs([-int(v) for v in out])
+        emul.sbve_fe25_freeze(neg, w8)
+        assert val(w8) == (-x) % P
+    for x in [1, 2, P - 1, 2**255 - 1] + [rng.randrange(1, 1 << 255) for _ in range(10)]:
+        if x % P == 0:
             continue
-        emul.sbve_fe25_inv(limbs(a), out)
-        assert val(out) % P == pow(a % P, -1, P)
+        emul.sbve_fe25_from_words(limbs(x), out)
+        t = (ctypes.c_int32 * 10)()
+        emul.sbve_fe25_carry(out, t)
+        emul.sbve_fe25_inv(t, out)
+        assert fval(out) % P == pow(x % P, -1, P)
+        emul.sbve_fe25_inv_gcd(t, out)
+        assert fval(out) % P == pow(x % P, -1, P)
+    consts = (ctypes.c_int32 * 30)()
+    emul.sbve_fe25_consts(consts)
+    d = (-121665 * pow(121666, -1, P)) % P
+    assert fval(consts[0:10]) == d and fval(consts[10:20]) == 2 * d % P and fval(consts[20:30]) == pow(2, (P - 1) // 4, P)
 
 
 def test_device_algorithm_on_golden_vectors_and_random_batch(emul, oracle, ed_vectors):
