@@ -83,20 +83,31 @@ __host__ __device__ inline void run_op(int op, const u32* in, u32* out) {
     }
 }
 
+// Ed25519 field / point operations on the carry-free field (ed25519_fe.h): inputs are 255-bit words cut into limbs and
+// carried to the tight form, outputs are frozen back to canonical words so that host and device compare bit for bit.
+__host__ __device__ inline void ed_in(fe25& r, const u32* w) { fe25 t; fe25_from_words(t, w); fe25_carry(r, t); }
+__host__ __device__ inline void ed_out(u32* out, const fe25& a) { u256 w; fe25_freeze(w, a); memcpy(out, &w, 32); }
 __host__ __device__ inline void run_op_ed(int op, const u32* in, u32* out) {
     for (int i = 0; i < OUT_WORDS; ++i) out[i] = 0;
-    fe a, b, c, d;
-    memcpy(&a, in, 32); memcpy(&b, in + 8, 32); memcpy(&c, in + 16, 32); memcpy(&d, in + 24, 32);
+    fe25 a, b, c, d;
+    ed_in(a, in); ed_in(b, in + 8); ed_in(c, in + 16); ed_in(d, in + 24);
     switch (op) {
-        case OP_ED_MUL: { fe25 r; fe25_mul(r, a, b); memcpy(out, &r, 32); break; }
-        case OP_ED_SQR: { fe25 r; fe25_sqr(r, a); memcpy(out, &r, 32); break; }
-        case OP_ED_ADD: { fe25 r; fe25_add(r, a, b); memcpy(out, &r, 32); break; }
-        case OP_ED_SUB: { fe25 r; fe25_sub(r, a, b); memcpy(out, &r, 32); break; }
-        case OP_ED_FREEZE: { fe25 r; fe25_freeze(r, a); memcpy(out, &r, 32); break; }
-        case OP_ED_INV: { fe25 r; fe25_inv(r, a); memcpy(out, &r, 32); break; }
-        case OP_ED_DBL: { ept p{a, b, c, d}, r; ed_dbl(r, p); memcpy(out, &r, 128); break; }
-        case OP_ED_ADDP: { ept p{a, b, c, d}; pniels q; memcpy(&q, in + 32, 128); ed_add_pniels(p, q, (in[0] & 1) != 0, (in[1] & 3) == 0); memcpy(out, &p, 128); break; }
-        case OP_ED_DECOMP: { ept p; const bool ok = ed_decompress(p, in); memcpy(out, &p, 96); out[31] = ok ? 1u : 0u; break; }
+        case OP_ED_MUL: { fe25 r; fe25_mul(r, a, b); ed_out(out, r); break; }
+        case OP_ED_SQR: { fe25 r; fe25_sqr(r, a); ed_out(out, r); break; }
+        case OP_ED_ADD: { fe25 r; fe25_add(r, a, b); ed_out(out, r); break; }
+        case OP_ED_SUB: { fe25 r; fe25_sub(r, a, b); ed_out(out, r); break; }
+        case OP_ED_FREEZE: { ed_out(out, a); break; }
+        case OP_ED_INV: { fe25 r; fe25_inv(r, a); ed_out(out, r); break; }
+        case OP_ED_DBL: { ept p{a, b, c, d}, r; ed_dbl(r, p); ed_out(out, r.X); ed_out(out + 8, r.Y); ed_out(out + 16, r.Z); ed_out(out + 24, r.T); break; }
+        case OP_ED_ADDP: {
+            ept p{a, b, c, d};
+            pniels q;
+            ed_in(q.YpX, in + 32); ed_in(q.YmX, in + 40); ed_in(q.Z, in + 48); ed_in(q.T2d, in + 56);
+            ed_add_pniels(p, q, (in[0] & 1) != 0, (in[1] & 3) == 0);
+            ed_out(out, p.X); ed_out(out + 8, p.Y); ed_out(out + 16, p.Z); ed_out(out + 24, p.T);
+            break;
+        }
+        case OP_ED_DECOMP: { ept p; const bool ok = ed_decompress(p, in); ed_out(out, p.X); ed_out(out + 8, p.Y); ed_out(out + 16, p.Z); out[31] = ok ? 1u : 0u; break; }
     }
 }
 
