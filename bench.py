@@ -28,10 +28,11 @@ HBM_PEAK_GBPS = 8000.0                   # /opt/skills/guides/MI355X_MICROARCH.m
 SEED = 0x5B7F2026
 # Integer-multiply roofline (SURVEY.md §8d "int_mul_issue_fraction"): measured peak of v_mad_u64_u32 / v_mad_i64_i32 on
 # MI355X (profiles/r01/microbench.jsonl, 8 waves/SIMD) and the multiply-accumulates one mixed addition of the comb
-# phases executes (p256_pt29.h pt29_madd: 8 field multiplications x 149 + 2 squarings x 113, counted in the gfx950
-# ISA of k_verify_keyed_q — DESIGN.md §4.6).
+# phases executes on its hot path (p256_pt29.h pt29_madd after the fused reductions: 8 products x 81 + 2 squares x 45 = 738
+# product multiply-accumulates, 9 reductions x 59 = 531, 9 for the zero filter — DESIGN.md §4.8; the static ISA mix of the
+# kernel is in profiles/r02/isa_stats_r02.txt).  Round 2's earlier runs used the pre-fusion count 1418 and reported 0.64-0.66.
 PEAK_LANE_MADS_PER_S = 33.8e12
-MADS_PER_MIXED_ADD = 8 * 149 + 2 * 113
+MADS_PER_MIXED_ADD = 738 + 531 + 9
 
 
 def cpu_baseline(tuples, n, gpu_bitmap):
