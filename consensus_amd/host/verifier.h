@@ -11,6 +11,7 @@
 // crypto/ecdsa — this C++ mirror has no CPU verifier on purpose and surfaces the condition instead
 // of ever turning it into INVALID.
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -88,9 +89,12 @@ class Coalescer {
     int submit_many_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap);
     Backend& backend() { return *be_; }
     CoalescerStats stats();
+    // How many submissions a burst is expected to bring (N-1 commit votes: view.go:537-541); the dispatcher ships as soon as
+    // that many are queued instead of sitting out the window.  0 = unknown.
+    void set_burst_hint(size_t n) { burst_hint_.store(n, std::memory_order_relaxed); }
 
  private:
-    struct Job { uint8_t tuple[160]; long slot = -1; bool ed25519 = false; int result = -100; bool done = false; };
+    struct Job { uint8_t tuple[160]; long slot = -1; bool ed25519 = false; int result = -100; std::atomic<bool> done{false}; };
     void run();
     std::shared_ptr<Backend> be_;
     size_t max_batch_;
@@ -98,6 +102,8 @@ class Coalescer {
     std::mutex mu_;
     std::condition_variable cv_job_, cv_done_;
     std::deque<Job*> q_;
+    std::atomic<size_t> qn_{0};            // q_.size(), readable without the lock by the spinning dispatcher
+    std::atomic<size_t> burst_hint_{0};
     bool stop_ = false;
     CoalescerStats st_;
     std::thread th_;
