@@ -53,6 +53,14 @@ SBV_HD bool ed_group_split_lane(size_t i, const GroupState& g) {
     return true;
 }
 
+// key-sorted step: classification only; the ungrouped list is built directly (no key check on this curve, see above), the
+// grouped one by the counting sort of p256_group.h
+SBV_HD void ed_group_classify_lane(size_t i, const GroupState& g) {
+    const u32 s = g.slot_of[g.rep[i]];
+    g.slots[i] = s;
+    if (s == SBV_GROUP_NONE) g.ung_idx[SBV_ATOMIC_ADD(&g.counters[2], 1u)] = (u32)i;
+}
+
 SBV_HD void ept_store(u32* dst, const ept& p) {
     fe25_store_raw(dst, p.X); fe25_store_raw(dst + 10, p.Y); fe25_store_raw(dst + 20, p.Z); fe25_store_raw(dst + 30, p.T);
 }
@@ -155,8 +163,29 @@ SBV_HD void ed_gacc_load(ept& R, const u32* gacc, size_t cap, size_t i) {
     }
 }
 
+// Tuple-major twin (key-sorted step): the 40 words of tuple i are contiguous (160 bytes, ten 16-byte vectors).  The G phase
+// runs in tuple order before the grouping is known, the Q phase in key order: with one record per tuple either order costs
+// two cache lines per visit.
+struct alignas(16) ed_q4 { u32 x, y, z, w; };
+SBV_HD void ed_gacc_store_tm(u32* gacc, size_t i, const ept& R) {
+    u32 w[40];
+    SBV_UNROLL
+    for (int l = 0; l < 10; ++l) { w[l] = (u32)R.X.v[l]; w[10 + l] = (u32)R.Y.v[l]; w[20 + l] = (u32)R.Z.v[l]; w[30 + l] = (u32)R.T.v[l]; }
+    ed_q4* d = reinterpret_cast<ed_q4*>(gacc + i * SBV_ED_GACC_WORDS);
+    SBV_UNROLL
+    for (int q = 0; q < 10; ++q) { const ed_q4 v = {w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]}; d[q] = v; }
+}
+SBV_HD void ed_gacc_load_tm(ept& R, const u32* gacc, size_t i) {
+    u32 w[40];
+    const ed_q4* s = reinterpret_cast<const ed_q4*>(gacc + i * SBV_ED_GACC_WORDS);
+    SBV_UNROLL
+    for (int q = 0; q < 10; ++q) { const ed_q4 v = s[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+    SBV_UNROLL
+    for (int l = 0; l < 10; ++l) { R.X.v[l] = (i32)w[l]; R.Y.v[l] = (i32)w[10 + l]; R.Z.v[l] = (i32)w[20 + l]; R.T.v[l] = (i32)w[30 + l]; }
+}
+
 // [S]B (16-bit comb `btab`) for tuple i -> gacc; okb[i] = S < L and k < L (SetCanonicalBytes(S); a reduced k is always < L)
-SBV_HD void ed_gphase_lane(const uint8_t* tuples, size_t i, const aniels* btab, u32* gacc, size_t cap, uint8_t* okb) {
+SBV_HD void ed_gphase_lane(const uint8_t* tuples, size_t i, const aniels* btab, u32* gacc, size_t cap, uint8_t* okb, bool tuple_major = false) {
     const u32* w = ed_tuple_words(tuples, i);
     u256 S, k;
     SBV_UNROLL
@@ -166,18 +195,19 @@ SBV_HD void ed_gphase_lane(const uint8_t* tuples, size_t i, const aniels* btab, 
     ept R;
     ed_set_ident(R);
     ed_add_sB(R, S, btab);
-    ed_gacc_store(gacc, cap, i, R);
+    if (tuple_major) ed_gacc_store_tm(gacc, i, R);
+    else ed_gacc_store(gacc, cap, i, R);
 }
 
 // R (from gacc) += windows [j0, j1) of [k](-A) from the key's comb.  `last` -> the verdict is returned; otherwise
 // R goes back to gacc and the return value is meaningless.
 SBV_HD bool ed_qphase_lane(const uint8_t* tuples, size_t i, u32 slot, u32 nkeys, const aniels* ktab, const uint8_t* kvalid,
-                           u32* gacc, size_t cap, const uint8_t* okb, int j0, int j1, bool last) {
+                           u32* gacc, size_t cap, const uint8_t* okb, int j0, int j1, bool last, bool tuple_major = false) {
     const u32* w = ed_tuple_words(tuples, i);
     u256 k, kk;
     SBV_UNROLL
     for (int j = 0; j < 8; ++j) k.v[j] = w[24 + j];
-    bool ok = okb[i] != 0 && slot < nkeys;
+    bool ok = (!last || okb[i] != 0) && slot < nkeys;          // the range verdict of the G phase only matters to the final answer
     if (slot >= nkeys) slot = 0;
     ok = ok && kvalid[slot] != 0;
     const aniels* tab = ktab + (size_t)slot * SBV_ED_KEYTAB_ENTRIES;
@@ -186,7 +216,8 @@ SBV_HD bool ed_qphase_lane(const uint8_t* tuples, size_t i, u32 slot, u32 nkeys,
     raw_aniels cur;
     raw_aniels_load(cur, tab + (size_t)j0 * SBV_ED_KEY_PER_WINDOW + ((d < 0 ? -d : d) == 0 ? 0 : (d < 0 ? -d : d) - 1));
     ept R;
-    ed_gacc_load(R, gacc, cap, i);
+    if (tuple_major) ed_gacc_load_tm(R, gacc, i);
+    else ed_gacc_load(R, gacc, cap, i);
     SBV_NOUNROLL
     for (int j = j0; j < j1; ++j) {
         const int jn = j + 1 < j1 ? j + 1 : j;                     // the entry of the next window is fetched while this addition runs
@@ -199,7 +230,11 @@ SBV_HD bool ed_qphase_lane(const uint8_t* tuples, size_t i, u32 slot, u32 nkeys,
         ed_add_aniels(R, e, d < 0, d == 0);
         cur = nxt; d = dn;
     }
-    if (!last) { ed_gacc_store(gacc, cap, i, R); return false; }
+    if (!last) {
+        if (tuple_major) ed_gacc_store_tm(gacc, i, R);
+        else ed_gacc_store(gacc, cap, i, R);
+        return false;
+    }
     u32 renc[8];
     SBV_UNROLL
     for (int j = 0; j < 8; ++j) renc[j] = w[j];

@@ -69,15 +69,28 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_gen
 
 // [S]B for every tuple of the batch
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_gphase(const uint8_t* __restrict__ tuples, size_t n, const aniels* __restrict__ btab,
-                                                                  u32* __restrict__ gacc, size_t cap, uint8_t* __restrict__ okb) {
+                                                                  u32* __restrict__ gacc, size_t cap, uint8_t* __restrict__ okb, int tuple_major) {
     const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
-    if (i < n) ed_gphase_lane(tuples, i, btab, gacc, cap, okb);
+    if (i < n) ed_gphase_lane(tuples, i, btab, gacc, cap, okb, tuple_major != 0);
 }
 
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_qphase(const uint8_t* __restrict__ tuples, GroupState g,
                                                                   const aniels* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
                                                                   u32* __restrict__ gacc, size_t cap, const uint8_t* __restrict__ okb,
                                                                   uint8_t* __restrict__ acc, int j0, int j1, int last) {
+    if (g.sorted) {
+        // key-sorted list, XCD-aware block order (see k_verify_keyed_q): block b takes logical block (b % 8) * per + b / 8
+        const u32 lanes = g.counters[1];
+        const u32 per = ((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK + 7) >> 3;
+        const u32 local = blockIdx.x >> 3;
+        if (local >= per) return;
+        const u32 L = ((blockIdx.x & 7u) * per + local) * SBV_VERIFY_BLOCK + threadIdx.x;
+        if (L >= lanes) return;
+        const u32 t = g.grp_idx[L];
+        const bool v = ed_qphase_lane(tuples, t, g.grp_of[L], group_count(g), ktab, kvalid, gacc, cap, okb, j0, j1, last != 0, true);
+        if (last) acc[t] = v ? 1 : 0;
+        return;
+    }
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= g.counters[1]) return;
     const u32 t = g.grp_idx[L];
@@ -93,6 +106,11 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
     g.counters = b.counters; g.grp_idx = b.grp_idx; g.ung_idx = b.ung_idx; g.slots = b.slots;
     g.max_groups = b.max_groups;
+    g.gcount = b.gcount; g.gcursor = b.gcount ? b.gcount + b.max_groups : nullptr; g.grp_of = b.grp_of; g.ung_cand = nullptr;
+    // key-sorted grouped list (p256_group.h): the Q phase walks runs of equal keys; the accumulator is tuple-major so that the
+    // G phase can still start at once, in tuple order
+    const size_t sort_lds = (size_t)b.max_groups * sizeof(u32);
+    g.sorted = y.sorted && b.gcount && b.grp_of && sort_lds <= 64 * 1024 ? 1u : 0u;
     group_set_threshold(g, b.min_count);
     const int chunks = y.chunks < 1 ? 1 : (y.chunks > SBV_GROUP_MAX_CHUNKS ? SBV_GROUP_MAX_CHUNKS : y.chunks);
     int parts = SBV_KEYTAB_PARTS_DEFAULT;
@@ -103,17 +121,26 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_fork, 0));
     SBV_TRY(hipMemsetAsync(b.ht, 0, ((size_t)b.ht_mask + 1) * sizeof(u32), y.side_a));
     SBV_TRY(hipMemsetAsync(b.cnt, 0, n * sizeof(u32), y.side_a));
-    SBV_TRY(hipMemsetAsync(b.counters, 0, 4 * sizeof(u32), y.side_a));
+    SBV_TRY(hipMemsetAsync(b.counters, 0, SBV_GROUP_COUNTERS * sizeof(u32), y.side_a));
+    if (g.sorted) SBV_TRY(hipMemsetAsync(b.gcount, 0, (size_t)b.max_groups * sizeof(u32), y.side_a));
     const unsigned gn = (unsigned)((n + 255) / 256);
     const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
     hipLaunchKernelGGL(k_ed_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
     hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, n, g);
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
-    hipLaunchKernelGGL(k_ed_group_split, dim3(gn), dim3(256), 0, y.side_b, n, g);
+    if (g.sorted) {
+        const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
+        hipLaunchKernelGGL(k_group_classify, dim3(gn), dim3(256), 0, y.side_b, n, g, b.ung_idx, b.counters + 2);
+        hipLaunchKernelGGL(k_group_sort_count, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
+        hipLaunchKernelGGL(k_group_sort_scan, dim3(1), dim3(1024), 0, y.side_b, g);
+        hipLaunchKernelGGL(k_group_sort_scatter, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
+    } else {
+        hipLaunchKernelGGL(k_ed_group_split, dim3(gn), dim3(256), 0, y.side_b, n, g);
+    }
     SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
     // stream: the G phase needs nothing but the tuples
-    hipLaunchKernelGGL(k_ed_gphase, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, n, d_btab, b.gacc, b.gacc_cap, eb.okb);
+    hipLaunchKernelGGL(k_ed_gphase, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, n, d_btab, b.gacc, b.gacc_cap, eb.okb, (int)g.sorted);
     SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_ED_KEY_WINDOWS * c / chunks, j_end = SBV_ED_KEY_WINDOWS * (c + 1) / chunks;
@@ -127,7 +154,7 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
                            j_first, j_count, parts);
         SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
-        hipLaunchKernelGGL(k_ed_qphase, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, b.kvalid, b.gacc, b.gacc_cap,
+        hipLaunchKernelGGL(k_ed_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, b.kvalid, b.gacc, b.gacc_cap,
                            eb.okb, b.acc, j_first, j_end, c + 1 == chunks ? 1 : 0);
     }
     // side_a, behind the last bases: the ungrouped list

@@ -43,7 +43,7 @@ __device__ __forceinline__ void group_split_emit(size_t i, u32 s, bool ung, bool
         const u32 tg = sh_cnt[1][0] + sh_cnt[1][1] + sh_cnt[1][2] + sh_cnt[1][3];
         const u32 tr = sh_cnt[2][0] + sh_cnt[2][1] + sh_cnt[2][2] + sh_cnt[2][3];
         sh_base[0] = tu ? atomicAdd(&g.counters[2], tu) : 0u;
-        sh_base[1] = tg ? atomicAdd(&g.counters[1], tg) : 0u;
+        sh_base[1] = tg && !g.sorted ? atomicAdd(&g.counters[1], tg) : 0u;      // sorted: the counting sort owns counters[1] and grp_idx
         if (tr) atomicAdd(&g.counters[3], tr);
     }
     __syncthreads();
@@ -51,9 +51,121 @@ __device__ __forceinline__ void group_split_emit(size_t i, u32 s, bool ung, bool
     for (int w = 0; w < wave; ++w) { base_u += sh_cnt[0][w]; base_g += sh_cnt[1][w]; }
     const unsigned long long below = (1ull << lane) - 1ull;
     if (ung) g.ung_idx[base_u + (u32)__popcll(mu & below)] = (u32)i;
+    if (ung || rejected) g.slots[i] = SBV_GROUP_NONE;
     if (grp) {
         g.slots[i] = s;
-        g.grp_idx[base_g + (u32)__popcll(mg & below)] = (u32)i;
+        if (!g.sorted) g.grp_idx[base_g + (u32)__popcll(mg & below)] = (u32)i;
+    }
+}
+
+// Compaction of one class with one atomicAdd per workgroup (256 lanes): returns this lane's position in the list, valid
+// where `mine` is set.
+__device__ __forceinline__ u32 group_compact_pos(bool mine, u32* counter) {
+    __shared__ u32 cp_cnt[4];
+    __shared__ u32 cp_base;
+    const unsigned long long m = __ballot(mine);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) cp_cnt[wave] = (u32)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u32 t = cp_cnt[0] + cp_cnt[1] + cp_cnt[2] + cp_cnt[3];
+        cp_base = t ? atomicAdd(counter, t) : 0u;
+    }
+    __syncthreads();
+    u32 base = cp_base;
+    for (int w = 0; w < wave; ++w) base += cp_cnt[w];
+    return base + (u32)__popcll(m & ((1ull << lane) - 1ull));
+}
+// key-sorted step, pass 1 (group_classify_lane): the group of every tuple; ungrouped tuples become candidates
+// (P-256: list = ung_cand, counter = counters[4]; Ed25519 has no key check in front of the one-lane kernel: ung_idx, counters[2])
+static __global__ __launch_bounds__(256) void k_group_classify(size_t n, GroupState g, u32* __restrict__ list, u32* __restrict__ counter) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool active = i < n;
+    u32 s = SBV_GROUP_NONE;
+    if (active) { s = g.slot_of[g.rep[i]]; g.slots[i] = s; }
+    const bool cand = active && s == SBV_GROUP_NONE;
+    const u32 pos = group_compact_pos(cand, counter);
+    if (cand) list[pos] = (u32)i;
+}
+
+// ---- key-sorted grouped list (p256_group.h: group_sort_*) ----------------------------------------------------------------
+// One workgroup of 1024 lanes per SBV_SORT_TILE tuples; dynamic LDS = one u32 per group.  A tile sees each of ~1000 keys a
+// handful of times, so the LDS histogram turns a million global atomics on ~1000 hot words into groups x tiles of them.
+#define SBV_SORT_PER_LANE 8
+#define SBV_SORT_TILE (1024 * SBV_SORT_PER_LANE)
+static __global__ __launch_bounds__(1024) void k_group_sort_count(size_t n, GroupState g) {
+    extern __shared__ u32 sort_lh[];
+    const u32 groups = group_count(g);
+    if (groups == 0) return;
+    for (u32 k = threadIdx.x; k < groups; k += 1024) sort_lh[k] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SBV_SORT_TILE;
+#pragma unroll
+    for (int q = 0; q < SBV_SORT_PER_LANE; ++q) {
+        const size_t i = base + (size_t)q * 1024 + threadIdx.x;
+        if (i < n) {
+            const u32 s = g.slots[i];
+            if (s < groups) atomicAdd(&sort_lh[s], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < groups; k += 1024) {
+        const u32 c = sort_lh[k];
+        if (c) atomicAdd(&g.gcount[k], c);
+    }
+}
+// one workgroup: exclusive scan of the group counts
+static __global__ __launch_bounds__(1024) void k_group_sort_scan(GroupState g) {
+    __shared__ u32 part[1024];
+    const u32 groups = group_count(g);
+    const u32 per = (groups + 1023) / 1024;
+    const u32 lo = threadIdx.x * per;
+    u32 hi = lo + per;
+    if (hi > groups) hi = groups;
+    u32 sum = 0;
+    for (u32 k = lo; k < hi; ++k) sum += g.gcount[k];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024; d <<= 1) {            // Hillis-Steele inclusive scan
+        const u32 v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    u32 run = part[threadIdx.x] - sum;
+    for (u32 k = lo; k < hi; ++k) { g.gcursor[k] = run; run += g.gcount[k]; }
+    if (threadIdx.x == 1023) g.counters[1] = part[1023];
+}
+static __global__ __launch_bounds__(1024) void k_group_sort_scatter(size_t n, GroupState g) {
+    extern __shared__ u32 sort_lh[];
+    const u32 groups = group_count(g);
+    if (groups == 0) return;
+    for (u32 k = threadIdx.x; k < groups; k += 1024) sort_lh[k] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SBV_SORT_TILE;
+    u32 grp[SBV_SORT_PER_LANE], rank[SBV_SORT_PER_LANE];
+#pragma unroll
+    for (int q = 0; q < SBV_SORT_PER_LANE; ++q) {
+        const size_t i = base + (size_t)q * 1024 + threadIdx.x;
+        grp[q] = SBV_GROUP_NONE;
+        rank[q] = 0;
+        if (i < n) {
+            const u32 s = g.slots[i];
+            if (s < groups) { grp[q] = s; rank[q] = atomicAdd(&sort_lh[s], 1u); }
+        }
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < groups; k += 1024) {
+        const u32 c = sort_lh[k];
+        if (c) sort_lh[k] = atomicAdd(&g.gcursor[k], c);      // the tile's piece of group k's run
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SBV_SORT_PER_LANE; ++q) {
+        if (grp[q] == SBV_GROUP_NONE) continue;
+        const u32 L = sort_lh[grp[q]] + rank[q];
+        g.grp_idx[L] = (u32)(base + (size_t)q * 1024 + threadIdx.x);
+        g.grp_of[L] = grp[q];
     }
 }
 

@@ -124,6 +124,16 @@ SBV_HD void gphase29_lane(const Scratch& s, size_t i, const gcomb& gc, u32* gacc
     gacc29_store(gacc, s.cap, i, R);
 }
 
+// Key-sorted grouped step: lane L of the sorted list handles tuple t; scalars come from t's record (Scratch::rec), the
+// accumulator lives at the lane's own position L, so that the lanes of a wavefront (all of one key) stay coalesced.
+SBV_HD void gphase29_lane_sorted(const Scratch& s, size_t t, size_t L, const gcomb& gc, u32* gacc) {
+    u256 u1;
+    rec_load256(u1, s.rec, t, SBV_REC_U1);
+    xyzz R;
+    gphase29_point(R, u1, gc);
+    gacc29_store(gacc, s.cap, L, R);
+}
+
 // R += sum of windows [j0, j1) of u2 * Q; qtab[j * 128 + (k-1)] = k * 2^(8 j) * Q, j = 0..32
 SBV_HD void qphase29_point(xyzz& R, const u256& u2, const apt* qtab, int j0, int j1) {
     u256 k2;
@@ -163,6 +173,24 @@ SBV_HD bool qphase29_lane(const Scratch& s, size_t i, u32 slot, u32 nkeys, const
     if (!last) { gacc29_store(gacc, s.cap, i, R); return false; }
     u256 r;
     soa_load(r, s.r, s.cap, i);
+    return ok && pt29_rx_matches(R, r);
+}
+
+SBV_HD bool qphase29_lane_sorted(const Scratch& s, size_t t, size_t L, u32 slot, u32 nkeys, const apt* ktab, const uint8_t* kvalid,
+                                 u32* gacc, int j0, int j1, bool last) {
+    u256 u2;
+    rec_load256(u2, s.rec, t, SBV_REC_U2);
+    bool ok = slot < nkeys;
+    if (slot >= nkeys) slot = 0;
+    ok = ok && kvalid[slot] != 0;
+    const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
+    xyzz R;
+    gacc29_load(R, gacc, s.cap, L);
+    qphase29_point(R, u2, qtab, j0, j1);
+    if (!last) { gacc29_store(gacc, s.cap, L, R); return false; }
+    u256 r;
+    rec_load256(r, s.rec, t, SBV_REC_R);
+    ok = ok && s.rec[t * SBV_REC_WORDS + SBV_REC_OK] != 0;
     return ok && pt29_rx_matches(R, r);
 }
 

@@ -38,7 +38,24 @@ struct Scratch {
     u32* sm;     // temp: s in Montgomery form (stage A only)
     uint8_t* ok; // 1 = passed the range checks
     size_t cap;
+    u32* rec = nullptr;   // optional: one 128-byte record per tuple (rec_* below), written by stage A beside the limb-major planes
 };
+
+// Tuple-major twin of (u1, u2, r, ok): SBV_REC_WORDS dwords per tuple = u1[8] | u2[8] | r[8] | ok | pad.  The key-sorted
+// grouped step (p256_group.h) visits tuples in key order, i.e. in random tuple order: from the limb-major planes one
+// u256 would touch 8 cache lines, from its record one.
+#define SBV_REC_WORDS 32
+#define SBV_REC_U1 0
+#define SBV_REC_U2 8
+#define SBV_REC_R 16
+#define SBV_REC_OK 24
+struct alignas(16) rec_q4 { u32 x, y, z, w; };
+SBV_HD void rec_store256(u32* rec, size_t i, int off, const u32 v[8]) {
+    rec_q4* d = reinterpret_cast<rec_q4*>(rec + i * SBV_REC_WORDS + off);
+    const rec_q4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+    d[0] = lo;
+    d[1] = hi;
+}
 
 SBV_HD void soa_store(u32* base, size_t cap, size_t i, const u256& v) {
     SBV_UNROLL
@@ -47,6 +64,11 @@ SBV_HD void soa_store(u32* base, size_t cap, size_t i, const u256& v) {
 SBV_HD void soa_load(u256& v, const u32* base, size_t cap, size_t i) {
     SBV_UNROLL
     for (int l = 0; l < 8; ++l) v.v[l] = base[(size_t)l * cap + i];
+}
+SBV_HD void rec_load256(u256& v, const u32* rec, size_t i, int off) {
+    const rec_q4* s = reinterpret_cast<const rec_q4*>(rec + i * SBV_REC_WORDS + off);
+    const rec_q4 lo = s[0], hi = s[1];
+    v.v[0] = lo.x; v.v[1] = lo.y; v.v[2] = lo.z; v.v[3] = lo.w; v.v[4] = hi.x; v.v[5] = hi.y; v.v[6] = hi.z; v.v[7] = hi.w;
 }
 
 // field f (0..4 = r, s, hash, Qx, Qy) of a tuple given as 40 packed big-endian dwords
@@ -185,9 +207,15 @@ SBV_HD void prep_chunk29(TupleWords words, size_t n, const Scratch& sc_, size_t 
         s29_mul(u, w, eL);                     // Montgomery(w) * plain(e) = plain(e * w)
         s29_store_canon(tw, u);
         soa_store(sc_.u1, sc_.cap, idx, tw);
+        if (sc_.rec) rec_store256(sc_.rec, idx, SBV_REC_U1, tw.v);
         s29_mul(u, w, rL);
         s29_store_canon(tw, u);
         soa_store(sc_.u2, sc_.cap, idx, tw);
+        if (sc_.rec) {
+            rec_store256(sc_.rec, idx, SBV_REC_U2, tw.v);
+            rec_store256(sc_.rec, idx, SBV_REC_R, r.v);
+            sc_.rec[idx * SBV_REC_WORDS + SBV_REC_OK] = sc_.ok[idx];
+        }
     }
 }
 

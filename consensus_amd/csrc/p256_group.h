@@ -43,6 +43,7 @@ SBV_HD u32 host_add(u32* p, u32 v) { const u32 old = *p; *p = old + v; return ol
 #endif
 
 #define SBV_GROUP_NONE 0xFFFFFFFFu
+#define SBV_GROUP_COUNTERS 8
 
 struct GroupState {
     u32* ht;          // hash table, ht_mask + 1 entries, zeroed before every batch
@@ -51,10 +52,15 @@ struct GroupState {
     u32* cnt;         // [n] users of a representative (zeroed before every batch)
     u32* slot_of;     // [n] table slot of a representative, or NONE
     u32* group_rep;   // [max_groups] representative tuple of slot g
-    u32* counters;    // [0] groups handed out, [1] grouped tuples, [2] ungrouped tuples, [3] rejected for their key (zeroed)
+    u32* counters;    // [0] groups handed out, [1] grouped tuples, [2] ungrouped tuples, [3] rejected for their key, [4] ungrouped candidates (SBV_GROUP_COUNTERS words, zeroed)
     u32* grp_idx;     // [n] compacted grouped tuple indices
     u32* ung_idx;     // [n] compacted ungrouped tuple indices
-    u32* slots;       // [n] table slot per tuple (grouped ones)
+    u32* slots;       // [n] group of every tuple (SBV_GROUP_NONE for the ungrouped and rejected ones)
+    u32* gcount;      // [max_groups] exact number of tuples of each group (key-sorted list only; zeroed before every batch)
+    u32* gcursor;     // [max_groups] next free position of each group's run in grp_idx
+    u32* grp_of;      // [n] group of lane L of the key-sorted list (= slots[grp_idx[L]])
+    u32* ung_cand;    // [n] key-sorted step: ungrouped tuples before their keys are checked (group_classify_lane)
+    u32 sorted;       // 1: grp_idx is built by the counting sort below (runs of equal keys), 0: by the split's compaction
     u32 max_groups;
     u32 min_count;    // requested threshold (users of a key in this batch)
     u32 sample_mask;  // tuples with group_sampled(i, sample_mask) are counted
@@ -153,6 +159,7 @@ SBV_HD void group_assign_lane(size_t i, const GroupState& g) {
 SBV_HD bool group_split_lane(const uint8_t* tuples, size_t i, const GroupState& g, uint8_t* acc) {
     const u32 s = g.slot_of[g.rep[i]];
     if (s == SBV_GROUP_NONE) {
+        g.slots[i] = SBV_GROUP_NONE;
         fe x, y;
         if (!tuple_key_load(tuples, i, x, y)) {
             acc[i] = 0;
@@ -162,9 +169,57 @@ SBV_HD bool group_split_lane(const uint8_t* tuples, size_t i, const GroupState& 
         g.ung_idx[SBV_ATOMIC_ADD(&g.counters[2], 1u)] = (u32)i;
     } else {
         g.slots[i] = s;
-        g.grp_idx[SBV_ATOMIC_ADD(&g.counters[1], 1u)] = (u32)i;
+        if (!g.sorted) g.grp_idx[SBV_ATOMIC_ADD(&g.counters[1], 1u)] = (u32)i;
     }
     return true;
+}
+
+// The key-sorted step splits in two passes: every tuple is classified (its group, or a candidate for the ungrouped list), then
+// only the candidates — a few per cent of a batch, compacted, so whole wavefronts do the same thing — have their keys checked.
+// (In one pass nearly every wavefront holds a few ungrouped lanes and pays the curve equation for all 64: 0.15 ms at 2^20, on
+// the path to the G phase.)  Same lists, counters and verdicts as group_split_lane.
+SBV_HD void group_classify_lane(size_t i, const GroupState& g) {
+    const u32 s = g.slot_of[g.rep[i]];
+    g.slots[i] = s;
+    if (s == SBV_GROUP_NONE) g.ung_cand[SBV_ATOMIC_ADD(&g.counters[4], 1u)] = (u32)i;
+}
+SBV_HD bool group_keycheck_lane(const uint8_t* tuples, size_t L, const GroupState& g, uint8_t* acc) {
+    const u32 i = g.ung_cand[L];
+    fe x, y;
+    if (!tuple_key_load(tuples, i, x, y)) {
+        acc[i] = 0;
+        SBV_ATOMIC_ADD(&g.counters[3], 1u);
+        return false;
+    }
+    g.ung_idx[SBV_ATOMIC_ADD(&g.counters[2], 1u)] = i;
+    return true;
+}
+
+// ---- key-sorted grouped list -------------------------------------------------------------------------------------------
+// The Q phase gathers one 64-byte table entry per addition from its key's comb (33 rows of 8 KB).  With the grouped list in
+// tuple order the 64 lanes of a wavefront belong to 64 different keys and every gather is a fresh line from HBM (measured:
+// 2.2 GB per launch for 0.05 GB of algorithmic bytes).  A counting sort by group — exact per-group counts, exclusive scan,
+// scatter — makes runs of equal keys: a wavefront reads ONE key's rows, a key's ~n/keys tuples sit in neighbouring
+// workgroups, and with the XCD-aware block order of the Q phase a key's rows are fetched into one L2 once.  The order inside
+// a run is arbitrary (atomics) and irrelevant: verdicts are written by tuple index.
+//   count    gcount[group of tuple i] += 1                      (device: LDS histogram per workgroup, then global atomics)
+//   scan     gcursor[k] = sum of gcount[< k]; counters[1] = total
+//   scatter  L = gcursor[group]++; grp_idx[L] = i; grp_of[L] = group
+SBV_HD void group_sort_count_lane(size_t i, const GroupState& g) {
+    const u32 s = g.slots[i];
+    if (s != SBV_GROUP_NONE) SBV_ATOMIC_ADD(&g.gcount[s], 1u);
+}
+SBV_HD void group_sort_scan_seq(const GroupState& g, u32 groups) {
+    u32 run = 0;
+    for (u32 k = 0; k < groups; ++k) { g.gcursor[k] = run; run += g.gcount[k]; }
+    g.counters[1] = run;
+}
+SBV_HD void group_sort_scatter_lane(size_t i, const GroupState& g) {
+    const u32 s = g.slots[i];
+    if (s == SBV_GROUP_NONE) return;
+    const u32 L = SBV_ATOMIC_ADD(&g.gcursor[s], 1u);
+    g.grp_idx[L] = (u32)i;
+    g.grp_of[L] = s;
 }
 
 // ---- persistent key-table cache (across batches) -----------------------------------------------------------------------

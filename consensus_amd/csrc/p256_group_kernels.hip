@@ -45,40 +45,63 @@ __global__ __launch_bounds__(256) void k_group_split(const uint8_t* __restrict__
     group_split_emit(i, s, ung, grp, key_rejected, g);
 }
 
+// key-sorted step, pass 2 (group_keycheck_lane): pointFromAffine on the compacted candidates -> ung_idx, or rejected
+__global__ __launch_bounds__(256) void k_group_keycheck(const uint8_t* __restrict__ tuples, GroupState g, uint8_t* __restrict__ acc) {
+    const u32 L = blockIdx.x * 256 + threadIdx.x;
+    const u32 cands = g.counters[4];
+    if (blockIdx.x * 256u >= cands) return;            // whole workgroup idle (uniform: the barriers below are not reached by anyone)
+    const bool active = L < cands;
+    u32 i = 0;
+    bool ok = false;
+    if (active) {
+        i = g.ung_cand[L];
+        fe x, y;
+        ok = tuple_key_load(tuples, i, x, y);
+        if (!ok) acc[i] = 0;
+    }
+    const unsigned long long mr = __ballot(active && !ok);
+    if ((threadIdx.x & 63) == 0 && mr) atomicAdd(&g.counters[3], (u32)__popcll(mr));
+    const u32 pos = group_compact_pos(active && ok, &g.counters[2]);
+    if (active && ok) g.ung_idx[pos] = i;
+}
+
 // ---- per-batch key tables on the carry-free field (p256_keytab29.h) -----------------------------------------------------
 // tmp layout (u32 words): [0, G * BASES_TMP) private strips of the bases kernel; behind it one strip of
 // SBV_KT29_WINDOW_TMP words per (key, window), shared by the rows and the fill kernel (same stream, never concurrent).
 #define SBV_KT29_WINDOW_TMP (7 * SBV_KT29_FILL_TMP_WORDS)
-// One workgroup: every group of the batch finds its table slot (p256_group.h: persistent key-table cache).  Phase 1 looks
-// the keys up (read-only: everything in the table was inserted by earlier batches, i.e. earlier kernels); phase 2 inserts
-// the misses (atomics only; the keys of one batch are distinct, so nobody needs to read what a neighbour just wrote).
-__global__ __launch_bounds__(1024) void k_key_cache_assign(const uint8_t* __restrict__ tuples, GroupState g, KeyCache kc,
-                                                           u32* __restrict__ tslot, uint8_t* __restrict__ cold) {
-    const u32 groups = group_count(g);
-    if (threadIdx.x < 2) kc.count[1 + threadIdx.x] = 0;
-    __syncthreads();
-    for (u32 k = threadIdx.x; k < groups; k += 1024) {
-        u32 slot = SBV_GROUP_NONE;
-        if (kc.enabled) {
-            u32 w[16];
-            key_cache_group_key(tuples, g, k, w);
-            slot = key_cache_lookup(kc, w);
-        }
-        tslot[k] = slot;
-        cold[k] = slot == SBV_GROUP_NONE ? 1 : 0;
-        if (kc.enabled) atomicAdd(&kc.count[slot == SBV_GROUP_NONE ? 2 : 1], 1u);
+// Every group of the batch finds its table slot (p256_group.h: persistent key-table cache), in two small launches of
+// 64-lane workgroups.  k_key_cache_lookup is read-only: everything in the table was inserted by earlier batches, i.e. by
+// earlier kernels; k_key_cache_insert places the misses (atomics only; the keys of one batch are distinct, so nobody needs
+// to read what a neighbour just wrote).  (One 1024-lane workgroup did both with a barrier in between; it had to wait ~130 us
+// for a whole CU to drain while stage A and the split kernel filled the device, at the head of the table-building chain.)
+__global__ __launch_bounds__(64) void k_key_cache_lookup(const uint8_t* __restrict__ tuples, GroupState g, KeyCache kc,
+                                                         u32* __restrict__ tslot, uint8_t* __restrict__ cold) {
+    const u32 k = blockIdx.x * 64 + threadIdx.x;
+    if (k == 0) { kc.count[1] = 0; kc.count[2] = 0; }       // hits / misses of this batch: counted by k_key_cache_insert
+    if (k >= group_count(g)) return;
+    u32 slot = SBV_GROUP_NONE;
+    if (kc.enabled) {
+        u32 w[16];
+        key_cache_group_key(tuples, g, k, w);
+        slot = key_cache_lookup(kc, w);
     }
-    __syncthreads();
-    for (u32 k = threadIdx.x; k < groups; k += 1024) {
-        if (tslot[k] != SBV_GROUP_NONE) continue;
-        u32 slot = SBV_GROUP_NONE;
-        if (kc.enabled) {
-            u32 w[16];
-            key_cache_group_key(tuples, g, k, w);
-            slot = key_cache_insert(kc, w);
-        }
-        tslot[k] = slot == SBV_GROUP_NONE ? kc.cap + k : slot;       // cache off or full: the per-batch area
+    tslot[k] = slot;
+    cold[k] = slot == SBV_GROUP_NONE ? 1 : 0;
+}
+__global__ __launch_bounds__(64) void k_key_cache_insert(const uint8_t* __restrict__ tuples, GroupState g, KeyCache kc,
+                                                         u32* __restrict__ tslot) {
+    const u32 k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= group_count(g)) return;
+    const bool miss = tslot[k] == SBV_GROUP_NONE;
+    if (kc.enabled) atomicAdd(&kc.count[miss ? 2 : 1], 1u);
+    if (!miss) return;
+    u32 slot = SBV_GROUP_NONE;
+    if (kc.enabled) {
+        u32 w[16];
+        key_cache_group_key(tuples, g, k, w);
+        slot = key_cache_insert(kc, w);
     }
+    tslot[k] = slot == SBV_GROUP_NONE ? kc.cap + k : slot;       // cache off or full: the per-batch area
 }
 
 // The table kernels are a few hundred lanes of latency-bound chains on the critical path of the step, sharing SIMDs with
@@ -151,6 +174,10 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_gphase_g
     }
     if (group_count(g) == 0) return;            // no key repeats often enough (e.g. all-distinct keys): nothing will read gacc
     const size_t i = first + (size_t)(blockIdx.x - generic_blocks) * SBV_VERIFY_BLOCK + threadIdx.x;      // this launch: tuples [first, end)
+    if (g.sorted) {                             // lanes of the key-sorted list: only grouped tuples, accumulator parked at the lane's position
+        if (i < g.counters[1]) gphase29_lane_sorted(s, g.grp_idx[i], i, g16r, gacc);
+        return;
+    }
     if (i < end) gphase29_lane(s, i, g16r, gacc);
 }
 
@@ -168,6 +195,24 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_verify_k
                                                                     const uint8_t* __restrict__ kvalid, const u32* __restrict__ tslot,
                                                                     u32 table_slots, u32* __restrict__ gacc,
                                                                     uint8_t* __restrict__ acc, int j0, int j1, int last) {
+    if (g.sorted) {
+        // Key-sorted list: consecutive blocks hold consecutive keys.  The dispatcher deals workgroups round-robin over the
+        // 8 XCDs (block b -> XCD b % 8, MI355X_MICROARCH.md "Workgroup dispatch"; a speed assumption only), so block b takes
+        // logical block (b % 8) * per + b / 8: every XCD walks its own contiguous eighth of the list and a key's comb rows are
+        // fetched into ONE L2.  `per` comes from the live lane count, not the launch's upper bound, so the eighths are even.
+        const u32 lanes = g.counters[1];
+        const u32 per = ((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK + 7) >> 3;
+        const u32 local = blockIdx.x >> 3;
+        if (local >= per) return;
+        const u32 L = ((blockIdx.x & 7u) * per + local) * SBV_VERIFY_BLOCK + threadIdx.x;
+        if (L >= lanes) return;
+        const u32 t = g.grp_idx[L];
+        const u32 grp = g.grp_of[L];
+        const u32 ts = grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE;
+        const bool v = qphase29_lane_sorted(s, t, L, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
+        if (last) acc[t] = v ? 1 : 0;
+        return;
+    }
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= g.counters[1]) return;
     const u32 t = g.grp_idx[L];
@@ -194,6 +239,10 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
     g.counters = b.counters; g.grp_idx = b.grp_idx; g.ung_idx = b.ung_idx; g.slots = b.slots;
     g.max_groups = b.max_groups;
+    g.gcount = b.gcount; g.gcursor = b.gcount ? b.gcount + b.max_groups : nullptr; g.grp_of = b.grp_of; g.ung_cand = b.ung_cand;
+    // key-sorted grouped list: needs the per-tuple records of stage A, one LDS word per group, and an unsliced G phase
+    const size_t sort_lds = (size_t)b.max_groups * sizeof(u32);
+    g.sorted = y.sorted && s.rec && b.gcount && b.grp_of && b.ung_cand && sort_lds <= 64 * 1024 && !y.side_c && y.slices <= 1 ? 1u : 0u;
     group_set_threshold(g, b.min_count);
     const int chunks = y.chunks < 1 ? 1 : (y.chunks > SBV_GROUP_MAX_CHUNKS ? SBV_GROUP_MAX_CHUNKS : y.chunks);
     int rows_per_lane = 1;                         // rows of 16 entries one lane of the fill kernel builds (1, 2, 4 or 7)
@@ -205,13 +254,15 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
     SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_fork, 0));
     SBV_TRY(hipMemsetAsync(b.ht, 0, ((size_t)b.ht_mask + 1) * sizeof(u32), y.side_a));
     SBV_TRY(hipMemsetAsync(b.cnt, 0, n * sizeof(u32), y.side_a));
-    SBV_TRY(hipMemsetAsync(b.counters, 0, 4 * sizeof(u32), y.side_a));
+    SBV_TRY(hipMemsetAsync(b.counters, 0, SBV_GROUP_COUNTERS * sizeof(u32), y.side_a));
+    if (g.sorted) SBV_TRY(hipMemsetAsync(b.gcount, 0, (size_t)b.max_groups * sizeof(u32), y.side_a));
     const unsigned gn = (unsigned)((n + 255) / 256);
     const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
     hipLaunchKernelGGL(k_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
     hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, n, g);
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
-    hipLaunchKernelGGL(k_key_cache_assign, dim3(1), dim3(1024), 0, y.side_a, d_tuples, g, b.kc, b.tslot, b.cold);
+    hipLaunchKernelGGL(k_key_cache_lookup, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.kc, b.tslot, b.cold);
+    hipLaunchKernelGGL(k_key_cache_insert, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.kc, b.tslot);
     // Stage A and the G phase, pipelined in slices of the batch: stage A is a low-occupancy chain (one inversion per
     // thread), and while it ran alone at the head of the step most of the GPU idled for ~0.35 ms.  Slice 0 is prepared on
     // `stream`, the others on side_b; the G phase of slice k starts as soon as slice k is prepared.  The generic kernel
@@ -232,7 +283,16 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
     }
     // side_b: split
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
-    hipLaunchKernelGGL(k_group_split, dim3(gn), dim3(256), 0, y.side_b, d_tuples, n, g, b.acc);
+    if (!g.sorted) hipLaunchKernelGGL(k_group_split, dim3(gn), dim3(256), 0, y.side_b, d_tuples, n, g, b.acc);
+    if (g.sorted) {             // classify, check the ungrouped candidates' keys, counting sort of the grouped tuples by key;
+                                // ev_split then also stands for "the sorted list is final"
+        hipLaunchKernelGGL(k_group_classify, dim3(gn), dim3(256), 0, y.side_b, n, g, b.ung_cand, b.counters + 4);
+        hipLaunchKernelGGL(k_group_keycheck, dim3(gn), dim3(256), 0, y.side_b, d_tuples, g, b.acc);
+        const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
+        hipLaunchKernelGGL(k_group_sort_count, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
+        hipLaunchKernelGGL(k_group_sort_scan, dim3(1), dim3(1024), 0, y.side_b, g);
+        hipLaunchKernelGGL(k_group_sort_scatter, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
+    }
     SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
     if (y.side_c) {
         SBV_TRY(hipEventRecord(y.ev_prep, stream));
@@ -282,7 +342,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         const bool last = c + 1 == chunks;
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
-        hipLaunchKernelGGL(k_verify_keyed_q, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.kc.cap + b.max_groups, b.gacc, b.acc,
+        hipLaunchKernelGGL(k_verify_keyed_q, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.kc.cap + b.max_groups, b.gacc, b.acc,
                            j_first, j_end, last ? 1 : 0);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }

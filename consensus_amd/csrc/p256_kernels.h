@@ -43,6 +43,10 @@ struct GroupBuffers {
     u32* tslot = nullptr;       // [max_groups] table slot of each group of the current batch
     uint8_t* cold = nullptr;    // [max_groups] 1 = the group's tables are built in this batch
     u32* gacc = nullptr;        // [36][scratch cap] u1*G per tuple (XYZZ, 9-limb coordinates), then the running sum of the Q phase
+    u32* gcount = nullptr;      // [2][max_groups] key-sorted list: exact group sizes, then the scatter cursors (p256_group.h)
+    u32* grp_of = nullptr;      // [cap] group of lane L of the key-sorted list
+    u32* ung_cand = nullptr;    // [cap] key-sorted step: ungrouped candidates before the key check
+    u32* rec = nullptr;         // [scratch cap][SBV_REC_WORDS] stage A's per-tuple records (Scratch::rec) for the key-sorted list
     u32 max_groups = 0, min_count = 0;
     size_t cap = 0;
     size_t gacc_cap = 0;        // the scratch capacity gacc was sized for
@@ -60,6 +64,7 @@ struct GroupSync {
     hipEvent_t ev_fork = nullptr, ev_assign = nullptr, ev_split = nullptr, ev_prep = nullptr, ev_generic = nullptr;
     hipEvent_t ev_bases[SBV_GROUP_MAX_CHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
     int chunks = 1;
+    int sorted = 1;                 // P-256: key-sorted grouped list + XCD-aware Q phase (SBV_GROUP_SORT=0: the split's compaction order)
     int parts = 1;                  // P-256: rows of 16 entries per lane of k_keytab29_fill (1, 2, 4, 7); Ed25519: lanes per (key, window)
 };
 // Enqueues stage A AND stage B of a grouped batch.  ev_fork must have been recorded on `stream` first.  after_prep

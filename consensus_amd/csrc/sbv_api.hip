@@ -183,7 +183,7 @@ std::vector<hipEvent_t*> group_events(Context& c) {
 void free_group_buffers(Context& c) {
     sbv::GroupBuffers& b = c.grp;
     void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.jbases, b.bases, b.jstate, b.ktab, b.kvalid, b.tmp, b.acc, b.gacc,
-                    b.tslot, b.cold, b.kc.ht, b.kc.keys, b.kc.count};
+                    b.gcount, b.grp_of, b.ung_cand, b.rec, b.tslot, b.cold, b.kc.ht, b.kc.keys, b.kc.count};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     b = sbv::GroupBuffers();
     if (c.edgrp.ktab) (void)hipFree(c.edgrp.ktab);
@@ -209,10 +209,14 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.cnt, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.slot_of, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.group_rep, G * sizeof(u32)));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.counters, 4 * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.counters, SBV_GROUP_COUNTERS * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.grp_idx, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ung_idx, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.slots, cap * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gcount, 2 * G * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.grp_of, cap * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ung_cand, cap * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.rec, c.cap * (size_t)SBV_REC_WORDS * sizeof(u32)));    // indexed like the scratch planes
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jbases, G * SBV_GTAB_WINDOWS * (size_t)40 * sizeof(u32)));   // 40 dwords = one Jacobian base (p256_group.h)
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.bases, G * SBV_GTAB_WINDOWS * (size_t)2 * sizeof(sbv::apt)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jstate, G * (size_t)27 * sizeof(u32)));
@@ -284,7 +288,9 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
     }
     if (grouped) {           // stage A is enqueued by the grouped launcher, in slices pipelined with the G phase
-        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, s, n, c.grp, c.d_qtab, c.d_gtab, sbv::gcomb_make(c.d_g16r, c.g_bits), d_bitmap, stream, c.gsync,
+        sbv::Scratch sg = s;
+        sg.rec = c.gsync.sorted ? c.grp.rec : nullptr;      // stage A also writes the per-tuple records the key-sorted list reads
+        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, sg, n, c.grp, c.d_qtab, c.d_gtab, sbv::gcomb_make(c.d_g16r, c.g_bits), d_bitmap, stream, c.gsync,
                                                              after_prep, dom, dom_pairs));
         return SBV_OK;
     }
@@ -388,8 +394,18 @@ int init_context(Context& c, int device) {
         return SBV_ENODEV;
     }
     HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b})
-        HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    {
+        // The side streams carry the table-building chains: few lanes, long dependent chains, and the Q phase waits for them.
+        // SBV_SIDE_PRIO=1 asks for the highest queue priority so that their workgroups are placed ahead of the throughput
+        // kernels' (default 0: measured).
+        int lo = 0, hi = 0;
+        const char* e = getenv("SBV_SIDE_PRIO");
+        const bool prio = e && e[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo;
+        for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b}) {
+            if (prio) HIP_TRY(SBV_ENODEV, hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi));
+            else HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+        }
+    }
     for (hipEvent_t* ev : group_events(c)) HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(ev, hipEventDisableTiming));
     c.gsync.chunks = 2;
     if (const char* e = getenv("SBV_GROUP_CHUNKS")) {
@@ -398,6 +414,7 @@ int init_context(Context& c, int device) {
     }
     if (const char* e = getenv("SBV_GROUP_PARTS")) c.gsync.parts = atoi(e);
     if (const char* e = getenv("SBV_GROUP_SLICES")) c.gsync.slices = atoi(e);
+    if (const char* e = getenv("SBV_GROUP_SORT")) c.gsync.sorted = atoi(e) != 0;
     if (const char* e = getenv("SBV_GENERIC_STREAM")) {
         if (e[0] == '1') HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.gsync.side_c, hipStreamNonBlocking));
     }

@@ -127,7 +127,10 @@ unsigned long sbve_fast_mismatches() { return g_fast_mismatches; }
 u32 sbve_fe_add_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_add<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 u32 sbve_fe_mul_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_mul<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 
-static int g_group_chunks = 3, g_group_parts = 4;
+static int g_group_chunks = 3, g_group_parts = 4, g_group_sort = 1;
+void sbve_set_group_sort(int on) { g_group_sort = on ? 1 : 0; }
+static unsigned long g_sort_violations = 0;
+unsigned long sbve_group_sort_violations() { return g_sort_violations; }
 // persistent key-table cache of the emulated grouped step (sbve_key_cache resets it)
 static KeyCache g_kc = {};
 static apt* g_kc_ktab = nullptr;
@@ -155,14 +158,19 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     std::vector<u32> r(8 * cap), u1(8 * cap), u2(8 * cap), qx(8 * cap), qy(8 * cap), sm(8 * cap);
     std::vector<uint8_t> ok(cap, 0);
     Scratch s{r.data(), u1.data(), u2.data(), qx.data(), qy.data(), sm.data(), ok.data(), cap};
+    std::vector<u32> rec(g_group_sort ? cap * SBV_REC_WORDS + 4 : 4, 0xDEADBEEFu);
+    u32* rec_al = rec.data();
+    while ((uintptr_t)rec_al & 15) ++rec_al;
+    if (g_group_sort) s.rec = rec_al;
     HostWords hw{tuples, 160};
     const int T = 4;
     const size_t per_block = (size_t)64 * T, nblocks = (n + per_block - 1) / per_block;
     for (size_t b = 0; b < nblocks; ++b)
         for (int t = 0; t < 64; ++t) prep_chunk29<true>(hw, n, s, b * per_block + t, 64, T);
-    std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(max_groups ? max_groups : 1), counters(4, 0),
-        grp_idx(cap), ung_idx(cap), slots(cap);
+    std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(max_groups ? max_groups : 1), counters(SBV_GROUP_COUNTERS, 0), ung_cand(cap),
+        grp_idx(cap, 0xFFFFFFFFu), ung_idx(cap), slots(cap), gcount(2 * (size_t)(max_groups ? max_groups : 1), 0), grp_of(cap, 0xFFFFFFFFu);
     GroupState g{};
+    g.gcount = gcount.data(); g.gcursor = gcount.data() + (max_groups ? max_groups : 1); g.grp_of = grp_of.data(); g.ung_cand = ung_cand.data(); g.sorted = (u32)g_group_sort;
     g.ht = ht.data(); g.ht_mask = (u32)(((size_t)1 << ht_bits) - 1); g.rep = rep.data(); g.cnt = cnt.data(); g.slot_of = slot_of.data();
     g.group_rep = group_rep.data(); g.counters = counters.data(); g.grp_idx = grp_idx.data(); g.ung_idx = ung_idx.data();
     g.slots = slots.data(); g.max_groups = max_groups;
@@ -170,11 +178,35 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     for (size_t i = 0; i < n; ++i) group_insert_lane(tuples, i, g);
     for (size_t i = 0; i < n; ++i) group_assign_lane(i, g);
     std::vector<uint8_t> accb(cap, 0xEE);
-    for (size_t i = 0; i < n; ++i) group_split_lane(tuples, i, g, accb.data());
+    if (g.sorted) {                      // two passes (k_group_classify, k_group_keycheck); candidates visited backwards, the order is free
+        for (size_t i = 0; i < n; ++i) group_classify_lane(i, g);
+        for (size_t L = counters[4]; L-- > 0;) group_keycheck_lane(tuples, L, g, accb.data());
+    } else {
+        for (size_t i = 0; i < n; ++i) group_split_lane(tuples, i, g, accb.data());
+    }
     const u32 ngroups = counters[0] < max_groups ? counters[0] : max_groups;
-    // G phase for every tuple
+    if (g.sorted) {                      // counting sort of the grouped tuples by key (k_group_sort_count / _scan / _scatter)
+        for (size_t i = 0; i < n; ++i) group_sort_count_lane(i, g);
+        group_sort_scan_seq(g, ngroups);
+        // the device scatters tile by tile in any order: walk the tuples backwards so that the emulated order differs from
+        // both the tuple order and the device's — verdicts may not depend on it
+        for (size_t i = n; i-- > 0;) group_sort_scatter_lane(i, g);
+        // invariants of the sorted list (the test reads the violation counter): a permutation of exactly the grouped tuples,
+        // non-decreasing groups, grp_of consistent with the per-tuple group
+        size_t grouped = 0;
+        for (size_t i = 0; i < n; ++i) grouped += slots[i] != SBV_GROUP_NONE;
+        if (grouped != counters[1]) ++g_sort_violations;
+        std::vector<uint8_t> seen(cap, 0);
+        for (u32 L = 0; L < counters[1]; ++L) {
+            const u32 t = grp_idx[L];
+            if (t >= n || seen[t] || slots[t] != grp_of[L] || (L && grp_of[L - 1] > grp_of[L])) { ++g_sort_violations; continue; }
+            seen[t] = 1;
+        }
+    }
+    // G phase: for every tuple, or (key-sorted list) for the grouped ones at their sorted position
     std::vector<u32> gacc(SBV_GACC29_WORDS * cap);
-    for (size_t i = 0; i < n; ++i) gphase29_lane(s, i, g16rtab(), gacc.data());
+    if (g.sorted) for (u32 L = 0; L < counters[1]; ++L) gphase29_lane_sorted(s, grp_idx[L], L, g16rtab(), gacc.data());
+    else for (size_t i = 0; i < n; ++i) gphase29_lane(s, i, g16rtab(), gacc.data());
     // key tables and the Q phase, in `chunks` pieces like the device pipeline
     const size_t ng1 = ngroups ? ngroups : 1;
     apt* bases = (apt*)aligned_alloc(64, ng1 * SBV_GTAB_WINDOWS * SBV_KT29_POINTS_PER_WINDOW * sizeof(apt));
@@ -224,9 +256,12 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
         const bool last = c + 1 == chunks;
         for (u32 L = 0; L < counters[1]; ++L) {
             const u32 t = grp_idx[L];
-            const u32 grp = slots[t];
-            const bool v = grp < ngroups ? qphase29_lane(s, t, 0, 1, table_of(grp), valid_of(grp), gacc.data(), j_first, j_end, last)
-                                         : qphase29_lane(s, t, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc.data(), j_first, j_end, last);
+            const u32 grp = g.sorted ? grp_of[L] : slots[t];
+            bool v;
+            if (g.sorted) v = grp < ngroups ? qphase29_lane_sorted(s, t, L, 0, 1, table_of(grp), valid_of(grp), gacc.data(), j_first, j_end, last)
+                                            : qphase29_lane_sorted(s, t, L, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc.data(), j_first, j_end, last);
+            else v = grp < ngroups ? qphase29_lane(s, t, 0, 1, table_of(grp), valid_of(grp), gacc.data(), j_first, j_end, last)
+                                   : qphase29_lane(s, t, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc.data(), j_first, j_end, last);
             if (last && v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
         }
     }
@@ -336,9 +371,10 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     if (cap == 0) cap = 64;
     uint8_t* tuples = (uint8_t*)aligned_alloc(16, cap * 128);           // the kernels read 16-byte vectors
     memcpy(tuples, tuples_in, n * 128);
-    std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(max_groups ? max_groups : 1), counters(4, 0),
-        grp_idx(cap), ung_idx(cap), slots(cap);
+    std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(max_groups ? max_groups : 1), counters(SBV_GROUP_COUNTERS, 0),
+        grp_idx(cap, 0xFFFFFFFFu), ung_idx(cap), slots(cap), gcount(2 * (size_t)(max_groups ? max_groups : 1), 0), grp_of(cap, 0xFFFFFFFFu);
     GroupState g{};
+    g.gcount = gcount.data(); g.gcursor = gcount.data() + (max_groups ? max_groups : 1); g.grp_of = grp_of.data(); g.sorted = (u32)g_group_sort;
     g.ht = ht.data(); g.ht_mask = (u32)(((size_t)1 << ht_bits) - 1); g.rep = rep.data(); g.cnt = cnt.data(); g.slot_of = slot_of.data();
     g.group_rep = group_rep.data(); g.counters = counters.data(); g.grp_idx = grp_idx.data(); g.ung_idx = ung_idx.data();
     g.slots = slots.data(); g.max_groups = max_groups;
@@ -346,10 +382,20 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     std::vector<uint8_t> accb(cap, 0xEE), okb(cap, 0);
     for (size_t i = 0; i < n; ++i) ed_group_insert_lane(tuples, i, g);
     for (size_t i = 0; i < n; ++i) group_assign_lane(i, g);
-    for (size_t i = 0; i < n; ++i) ed_group_split_lane(i, g);
     const u32 ngroups = counters[0] < max_groups ? counters[0] : max_groups;
-    std::vector<u32> gacc(SBV_ED_GACC_WORDS * cap);
-    for (size_t i = 0; i < n; ++i) ed_gphase_lane(tuples, i, btab(), gacc.data(), cap, okb.data());
+    if (g.sorted) {                      // key-sorted list: classify, then the counting sort of p256_group.h (scatter walked backwards)
+        for (size_t i = 0; i < n; ++i) ed_group_classify_lane(i, g);
+        for (size_t i = 0; i < n; ++i) group_sort_count_lane(i, g);
+        group_sort_scan_seq(g, ngroups);
+        for (size_t i = n; i-- > 0;) group_sort_scatter_lane(i, g);
+        for (u32 L = 0; L < counters[1]; ++L)
+            if (grp_idx[L] >= n || slots[grp_idx[L]] != grp_of[L] || (L && grp_of[L - 1] > grp_of[L])) ++g_sort_violations;
+    } else {
+        for (size_t i = 0; i < n; ++i) ed_group_split_lane(i, g);
+    }
+    const bool tm = g.sorted != 0;       // tuple-major accumulator records
+    u32* gacc = (u32*)aligned_alloc(16, (size_t)SBV_ED_GACC_WORDS * cap * 4);
+    for (size_t i = 0; i < n; ++i) ed_gphase_lane(tuples, i, btab(), gacc, cap, okb.data(), tm);
     const size_t ng1 = ngroups ? ngroups : 1;
     u32* jbases = (u32*)aligned_alloc(16, ng1 * SBV_ED_KEY_WINDOWS * SBV_ED_JBASE_DWORDS * 4);
     aniels* ktab = (aniels*)aligned_alloc(64, ng1 * SBV_ED_KEYTAB_ENTRIES * sizeof(aniels));
@@ -368,7 +414,7 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
         const bool last = c + 1 == chunks;
         for (u32 L = 0; L < counters[1]; ++L) {
             const u32 t = grp_idx[L];
-            const bool v = ed_qphase_lane(tuples, t, slots[t], ngroups, ktab, kvalid.data(), gacc.data(), cap, okb.data(), j_first, j_end, last);
+            const bool v = ed_qphase_lane(tuples, t, g.sorted ? grp_of[L] : slots[t], ngroups, ktab, kvalid.data(), gacc, cap, okb.data(), j_first, j_end, last, tm);
             if (last && v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
         }
     }
@@ -377,7 +423,7 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
         const u32 t = ung_idx[L];
         if (ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab, btab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
     }
-    free(qtab); free(tmpa); free(ktab); free(jbases); free(tuples);
+    free(qtab); free(tmpa); free(ktab); free(jbases); free(tuples); free(gacc);
     if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }
 }
 // Ed25519 message front end (sha512_dev.h): 512-bit little-endian x -> x mod L; sig | pk | msg -> 128-byte tuple

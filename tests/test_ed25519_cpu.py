@@ -161,10 +161,19 @@ def test_grouped_by_key_inside_the_batch_matches_plain_kernel(emul, oracle, ed_v
     total = len(allt) // 128
     want = [v["accept"] for v in ed_vectors] + _bits(exp.raw, m) + [False] * 40
     stats = (ctypes.c_uint32 * 4)()
+    emul.sbve_group_sort_violations.restype = ctypes.c_ulong
+    violations = emul.sbve_group_sort_violations()
     for min_count, max_groups, ht_bits, chunks, parts in [(8, 64, 12, 2, 4), (8, 64, 12, 1, 8), (64, 64, 12, 4, 16), (1, 4096, 12, 3, 2),
                                                           (8, 3, 12, 2, 4), (2, 64, 11, 2, 4), (10**6, 64, 12, 2, 4)]:
-        bm = ctypes.create_string_buffer((total + 7) // 8)
-        emul.sbve_ed25519_verify_batch_grouped(allt, total, bm, min_count, max_groups, ht_bits, chunks, parts, stats)
+        # the key-sorted grouped list (tuple-major accumulator records, runs of equal keys) and the split's compaction order
+        res = []
+        for sort in (0, 1):
+            emul.sbve_set_group_sort(sort)
+            bm = ctypes.create_string_buffer((total + 7) // 8)
+            emul.sbve_ed25519_verify_batch_grouped(allt, total, bm, min_count, max_groups, ht_bits, chunks, parts, stats)
+            res.append((bm.raw, tuple(stats)))
+        assert res[0] == res[1], (min_count, max_groups, ht_bits, chunks, parts)
+        assert emul.sbve_group_sort_violations() == violations
         got = _bits(bm.raw, total)
         bad = [i for i in range(total) if got[i] != want[i]]
         assert not bad, (min_count, max_groups, ht_bits, chunks, parts, bad[:8])

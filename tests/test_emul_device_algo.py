@@ -339,6 +339,39 @@ def test_grouped_by_key_inside_the_batch_matches_generic(emul, oracle, golden_ve
     emul.sbve_set_group_parts(4)
 
 
+def test_key_sorted_grouped_list_equals_compaction_order(emul, oracle, golden_vectors):
+    """The key-sorted grouped list (p256_group.h: group_sort_*, per-tuple records of stage A, accumulators parked at the
+    sorted position) gives the verdicts of the split's compaction order, and the list it builds is a permutation of exactly
+    the grouped tuples in runs of equal keys."""
+    emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    emul.sbve_group_sort_violations.restype = ctypes.c_ulong
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    n = 700
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0x50E7, n, 9, 6, tup, exp, 4)
+    off = next(bytes.fromhex(v["tuple"]) for v in vs if v["name"] == "q_off_curve_y_plus_1")
+    allt = b"".join(bytes.fromhex(v["tuple"]) for v in vs) + tup.raw + off * 20
+    total = len(allt) // 160
+    want = [v["accept"] for v in vs] + _bitmap_list(exp.raw, n) + [False] * 20
+    stats = (ctypes.c_uint32 * 4)()
+    before = emul.sbve_group_sort_violations()
+    for min_count, max_groups, chunks in [(4, 64, 2), (1, 4096, 3), (4, 5, 1), (10**6, 64, 2)]:
+        emul.sbve_set_group_chunks(chunks)
+        res = []
+        for sort in (1, 0):
+            emul.sbve_set_group_sort(sort)
+            bm = ctypes.create_string_buffer((total + 7) // 8)
+            emul.sbve_p256_verify_batch_grouped(allt, total, bm, min_count, max_groups, 12, stats)
+            res.append((bm.raw, tuple(stats)))
+        assert res[0] == res[1], (min_count, max_groups)
+        assert _bitmap_list(res[0][0], total) == want, (min_count, max_groups)
+    emul.sbve_set_group_sort(1)
+    emul.sbve_set_group_chunks(3)
+    assert emul.sbve_group_sort_violations() == before
+
+
 def test_grouped_verdicts_do_not_depend_on_tuple_order(emul, oracle, golden_vectors):
     """Size-independent property of the grouped step: which tuple represents a key, which slot a key gets and where a
     tuple lands in the index lists all depend on the order of the batch — the verdicts must not.  A shuffled batch gives
