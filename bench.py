@@ -465,7 +465,8 @@ def main():
                           "launches": launches},
             "key_grouping": {"enabled": was_grouped, "groups": groups, "tuples_registered_key_kernel": n_grouped,
                              "tuples_generic_kernel": n_ungrouped, "tuples_rejected_for_their_key": n_key_rejected,
-                             "note": "in-step grouping by public key (consensus_amd/csrc/p256_group.h); all of it is inside the timed region"},
+                             "key_sorted_list": os.environ.get("SBV_GROUP_SORT", "1") != "0",
+                             "note": "in-step grouping by public key and counting sort of the grouped tuples by key (consensus_amd/csrc/p256_group.h); all of it is inside the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": dom_name, "units_per_launch": dom_units, "share_of_a_tuples_stage_b_per_launch": share,

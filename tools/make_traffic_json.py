@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from a rocprofv3 PMC summary (tools/gpu_profile_r02.sh / gpu_r02aa.sh write summary.json):
+per-launch HBM bytes of every kernel = 2 x FETCH_SIZE KiB (gfx950 tallies 128-byte requests as 64, MI355X_MICROARCH.md) +
+WRITE_SIZE KiB.  bench.py reads <kernel>_hbm_bytes_per_launch for roofline.traffic.
+usage: make_traffic_json.py <summary.json> <tag> [note]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+summary = json.load(open(sys.argv[1]))
+tag = sys.argv[2]
+out = {
+    "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing besides --kernel-trace in its own pass) over "
+              f"`python bench.py --steps 5 --warmup 2 --no-cpu-baseline --primary-only`, run {tag}; summary: profiles/r02/rocprof_summary_{tag}.json",
+    "method": "FETCH_SIZE and WRITE_SIZE are KiB; FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950 tallies 128-B "
+              "requests as 64 B); the guide calibrates that factor on wide coalesced reads only - the comb phases read 64-byte table "
+              "entries as four 16-byte loads per lane, so for them the doubled figure is an upper bound; WRITE_SIZE as is.  Per launch = "
+              "mean over the dispatches of the profiled run.",
+    "launch": "2^20 tuples",
+}
+for k, c in sorted(summary.get("pmc", {}).items()):
+    f = c.get("FETCH_SIZE", {}).get("mean")
+    w = c.get("WRITE_SIZE", {}).get("mean")
+    if f is None or w is None:
+        continue
+    out[k + "_fetch_kib_raw"] = f
+    out[k + "_write_kib_raw"] = w
+    out[k + "_hbm_bytes_per_launch"] = int(round((2 * f + w) * 1024))
+if len(sys.argv) > 3:
+    out["note"] = sys.argv[3]
+json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k.endswith("_hbm_bytes_per_launch")}, indent=1))
