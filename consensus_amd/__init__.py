@@ -81,6 +81,8 @@ def load() -> ctypes.CDLL:
                                                     ctypes.c_void_p]
     lib.sbv_ed25519_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.sbv_ed25519_verify_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    lib.sbv_secp256k1_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.sbv_secp256k1_verify_batch_dev.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
     lib.sbv_ed25519_verify_msgs.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
                                             ctypes.c_size_t, ctypes.c_char_p]
     lib.sbv_ed25519_make_tuples.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
@@ -213,6 +215,20 @@ def ed25519_verify_batch(tuples: bytes, n: Optional[int] = None) -> bytes:
 
 def ed25519_verify_batch_dev(d_tuples_ptr: int, n: int, d_bitmap_ptr: int, stream: int = 0) -> None:
     _check(load().sbv_ed25519_verify_batch_dev(d_tuples_ptr, n, d_bitmap_ptr, stream))
+
+
+def secp256k1_verify_batch(tuples: bytes, n: Optional[int] = None) -> bytes:
+    """ECDSA over secp256k1 on 160-byte tuples r | s | hash | Qx | Qy (include/sbv.h); returns the accept bitmap."""
+    if n is None:
+        n = len(tuples) // 160
+    out = ctypes.create_string_buffer(max(1, (n + 7) // 8))
+    buf = (ctypes.c_char * len(tuples)).from_buffer_copy(tuples) if n else None
+    _check(load().sbv_secp256k1_verify_batch(buf, n, out))
+    return out.raw[:(n + 7) // 8]
+
+
+def secp256k1_verify_batch_dev(d_tuples_ptr: int, n: int, d_bitmap_ptr: int, stream: int = 0) -> None:
+    _check(load().sbv_secp256k1_verify_batch_dev(d_tuples_ptr, n, d_bitmap_ptr, stream))
 
 
 def verify_msgs_keyed(msgs, sigs_der, slots) -> bytes:

@@ -79,4 +79,12 @@ void host_build_gtable(apt* out);   // 33 x 128 affine multiples of G (8-bit com
 void host_build_g16(apt* out);      // 17 x 32768 affine multiples of G (16-bit comb used by the verify kernels)
 #define SBV_G16_ENTRIES ((size_t)SBV_G16_WINDOWS * SBV_G16_PER_WINDOW)
 
+// secp256k1 variant (k256_kernels.hip): stage A + stage B for n generic tuples; d_qtab = the per-lane strips of the P-256 generic
+// kernel (SBV_QTAB29_WORDS words per lane); d_gtab = the 17 x 32768-entry comb of G built by host_build_k256_gtable
+struct kapt;
+hipError_t launch_k256_verify(const uint8_t* d_tuples, size_t n, const Scratch& s, u32* d_qtab, const kapt* d_gtab, uint8_t* d_bitmap,
+                              hipStream_t stream);
+void host_build_k256_gtable(kapt* out);
+#define SBV_K256_GTABLE_ENTRIES ((size_t)17 * 32768)
+
 }  // namespace sbv

@@ -27,6 +27,7 @@
 #include "../../include/sbv.h"
 #include "ed25519_kernels.h"
 #include "p256_kernels.h"
+#include "k256_core.h"
 
 namespace {
 
@@ -77,6 +78,7 @@ struct Context {
     uint8_t* d_sigs = nullptr; size_t sigs_cap = 0;
     uint64_t* d_moff = nullptr; uint64_t* d_soff = nullptr; size_t moff_cap = 0, soff_cap = 0;
     sbv::aniels* d_btab = nullptr;      // Ed25519 base-point comb, built on first use
+    sbv::kapt* d_k256_gtab = nullptr;   // secp256k1 comb of G (17 x 32768 entries), built on first use
     // registered keys
     sbv::apt* d_ktab = nullptr;
     uint8_t* d_kvalid = nullptr;
@@ -329,6 +331,8 @@ int ensure_key_capacity(Context& c, size_t want) {
     }
     if (c.d_btab) (void)hipFree(c.d_btab);
     c.d_btab = nullptr;
+    if (c.d_k256_gtab) (void)hipFree(c.d_k256_gtab);
+    c.d_k256_gtab = nullptr;
     if (c.d_msgs) (void)hipFree(c.d_msgs);
     if (c.d_sigs) (void)hipFree(c.d_sigs);
     if (c.d_moff) (void)hipFree(c.d_moff);
@@ -486,6 +490,8 @@ int shutdown_context(Context& c) {
     c.d_g16r = nullptr;
     if (c.d_btab) (void)hipFree(c.d_btab);
     c.d_btab = nullptr;
+    if (c.d_k256_gtab) (void)hipFree(c.d_k256_gtab);
+    c.d_k256_gtab = nullptr;
     if (c.d_msgs) (void)hipFree(c.d_msgs);
     if (c.d_sigs) (void)hipFree(c.d_sigs);
     if (c.d_moff) (void)hipFree(c.d_moff);
@@ -933,6 +939,81 @@ extern "C" int sbv_ed25519_verify_batch(const uint8_t* tuples, size_t n, uint8_t
         HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_tuples, tuples + off * 128, m * 128, hipMemcpyHostToDevice, c.stream));
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
         if ((rc = enqueue_ed25519(c, c.d_tuples, m, c.d_bitmap, c.stream)) != SBV_OK) return rc;
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.h_bitmap, c.d_bitmap, (m + 7) / 8, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[4], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(c.stream));
+        memcpy(accept_bitmap + off / 8, c.h_bitmap, (m + 7) / 8);
+        tm.h2d_us += 1e3 * ms_between(c.ev[0], c.ev[1]);
+        tm.verify_us += 1e3 * ms_between(c.ev[1], c.ev[3]);
+        tm.d2h_us += 1e3 * ms_between(c.ev[3], c.ev[4]);
+    }
+    c.busy_valid = false;
+    tm.total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    c.timing = tm;
+    return SBV_OK;
+}
+
+// ---- secp256k1 variant ("other curves") ------------------------------------------------------
+namespace {
+std::vector<sbv::kapt> g_h_k256_gtab;           // built once per process, uploaded to each context on its first secp256k1 call
+std::once_flag g_k256_once;
+int ensure_k256_table(Context& c) {
+    if (c.d_k256_gtab) return SBV_OK;
+    std::call_once(g_k256_once, [] {
+        g_h_k256_gtab.resize(SBV_K256_GTABLE_ENTRIES);
+        sbv::host_build_k256_gtable(g_h_k256_gtab.data());     // 17 host threads, a fraction of a second
+    });
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_k256_gtab, g_h_k256_gtab.size() * sizeof(sbv::kapt)));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_k256_gtab, g_h_k256_gtab.data(), g_h_k256_gtab.size() * sizeof(sbv::kapt), hipMemcpyHostToDevice));
+    return SBV_OK;
+}
+}  // namespace
+
+extern "C" int sbv_secp256k1_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, void* hip_stream) {
+    SBV_ENTER(c);
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (n == 0) return SBV_OK;
+    if (!d_tuples || !d_bitmap || (reinterpret_cast<uintptr_t>(d_tuples) & 15)) { g_err = "null or misaligned device pointer"; return SBV_EINVAL; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    int rc = ensure_capacity(c, n < kMaxChunk ? n : kMaxChunk);
+    if (rc != SBV_OK) return rc;
+    if ((rc = ensure_k256_table(c)) != SBV_OK) return rc;
+    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(stream, c.busy, 0));
+    const uint8_t* src = static_cast<const uint8_t*>(d_tuples);
+    uint8_t* dst = static_cast<uint8_t*>(d_bitmap);
+    const sbv::Scratch s = scratch_view(c);
+    hipError_t e = hipSuccess;
+    for (size_t off = 0; off < n && e == hipSuccess; off += kMaxChunk) {
+        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        e = sbv::launch_k256_verify(src + off * 160, m, s, c.d_qtab, c.d_k256_gtab, dst + off / 8, stream);
+    }
+    if (hipEventRecord(c.busy, stream) == hipSuccess) c.busy_valid = true;       // the scratch stays ordered behind whatever was enqueued
+    HIP_TRY(SBV_EDEVICE, e);
+    return SBV_OK;
+}
+
+extern "C" int sbv_secp256k1_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap) {
+    SBV_ENTER(c);
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (n == 0) return SBV_OK;
+    if (!tuples || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    int rc = ensure_capacity(c, n < kMaxChunk ? n : kMaxChunk);
+    if (rc != SBV_OK) return rc;
+    if ((rc = ensure_k256_table(c)) != SBV_OK) return rc;
+    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(c.stream, c.busy, 0));
+    const sbv::Scratch s = scratch_view(c);
+    sbv_timing tm{};
+    tm.n = n;
+    for (size_t off = 0; off < n; off += kMaxChunk) {
+        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[0], c.stream));
+        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_tuples, tuples + off * 160, m * 160, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
+        HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify(c.d_tuples, m, s, c.d_qtab, c.d_k256_gtab, c.d_bitmap, c.stream));
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
         HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.h_bitmap, c.d_bitmap, (m + 7) / 8, hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[4], c.stream));

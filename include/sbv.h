@@ -126,6 +126,15 @@ int sbv_p256_sign_batch_dev(const void* d_keys, uint32_t n_keys, const void* d_k
 int sbv_p256_verify_msgs_keyed(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* sigs,
                                const uint64_t* sig_offsets, const uint32_t* slots, size_t n, uint8_t* accept_bitmap);
 
+/* ---- secp256k1 variant ("other curves": api.Verifier / api.Signer are curve-agnostic,
+ * pkg/api/dependencies.go:46-71) --------------------------------------------------------------------------------------
+ * The same 160-byte tuples r | s | hash | Qx | Qy and the same rules as sbv_p256_verify_batch (1 <= r, s <= n - 1, key
+ * coordinates < p and on the curve, hash = leftmost 32 bytes reduced mod n, R = infinity rejected, accept iff
+ * R.x mod n == r; no low-S rule at this layer) over y^2 = x^3 + 7, p = 2^256 - 2^32 - 977.  One lane per signature
+ * (consensus_amd/csrc/k256_core.h); the 35.7 MB comb of G is built on the first call of a process. */
+int sbv_secp256k1_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap);
+int sbv_secp256k1_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, void* hip_stream);
+
 /* ---- Ed25519 variant (BASELINE.json configs[4]) ----------------------------------------------------
  * Semantics of Go crypto/ed25519.Verify(pk, msg, sig) (crypto/internal/edwards25519): S canonical,
  * A decoded with Go's leniency (non-canonical y accepted, no small-order rejection), cofactorless

@@ -31,14 +31,34 @@ int sbvssl_p256_verify_tuple(const uint8_t t[160]) {
     return ok;
 }
 
-typedef struct { const uint8_t *tuples; size_t lo, hi; uint8_t *bitmap; } job_t;
+/* the same on secp256k1 (the "other curves" variant: oracle/secp256k1_oracle.c) */
+int sbvssl_k256_verify_tuple(const uint8_t t[160]) {
+    int ok = 0;
+    EC_KEY *key = EC_KEY_new_by_curve_name(NID_secp256k1);
+    BIGNUM *x = BN_bin2bn(t + 96, 32, NULL), *y = BN_bin2bn(t + 128, 32, NULL);
+    BIGNUM *r = BN_bin2bn(t, 32, NULL), *s = BN_bin2bn(t + 32, 32, NULL);
+    ECDSA_SIG *sig = ECDSA_SIG_new();
+    if (key && x && y && r && s && sig && EC_KEY_set_public_key_affine_coordinates(key, x, y) == 1) {
+        ECDSA_SIG_set0(sig, r, s); r = s = NULL;
+        ok = ECDSA_do_verify(t + 64, 32, sig, key) == 1;
+    }
+    BN_free(x); BN_free(y); BN_free(r); BN_free(s);
+    ECDSA_SIG_free(sig); EC_KEY_free(key);
+    return ok;
+}
+
+typedef struct { const uint8_t *tuples; size_t lo, hi; uint8_t *bitmap; int k256; } job_t;
 static void *worker(void *arg) {
     job_t *j = (job_t *)arg;
     for (size_t i = j->lo; i < j->hi; ++i)
-        if (sbvssl_p256_verify_tuple(j->tuples + 160 * i)) j->bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+        if (j->k256 ? sbvssl_k256_verify_tuple(j->tuples + 160 * i) : sbvssl_p256_verify_tuple(j->tuples + 160 * i))
+            j->bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
     return NULL;
 }
-void sbvssl_p256_verify_batch(const uint8_t *tuples, size_t n, uint8_t *bitmap, int threads) {
+static void verify_batch_curve(const uint8_t *tuples, size_t n, uint8_t *bitmap, int threads, int k256);
+void sbvssl_p256_verify_batch(const uint8_t *tuples, size_t n, uint8_t *bitmap, int threads) { verify_batch_curve(tuples, n, bitmap, threads, 0); }
+void sbvssl_k256_verify_batch(const uint8_t *tuples, size_t n, uint8_t *bitmap, int threads) { verify_batch_curve(tuples, n, bitmap, threads, 1); }
+static void verify_batch_curve(const uint8_t *tuples, size_t n, uint8_t *bitmap, int threads, int k256) {
     memset(bitmap, 0, (n + 7) / 8);
     if (threads < 1) threads = 1;
     if (threads > 256) threads = 256;
@@ -47,7 +67,7 @@ void sbvssl_p256_verify_batch(const uint8_t *tuples, size_t n, uint8_t *bitmap, 
     int started = 0;
     for (int t = 0; t < threads; ++t) {
         size_t lo = (size_t)t * per, hi = lo + per; if (lo >= n) break; if (hi > n) hi = n;
-        jobs[t] = (job_t){tuples, lo, hi, bitmap};
+        jobs[t] = (job_t){tuples, lo, hi, bitmap, k256};
         pthread_create(&th[t], NULL, worker, &jobs[t]); ++started;
     }
     for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);

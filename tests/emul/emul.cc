@@ -6,6 +6,7 @@
 // the device algorithm against the oracle and the golden vectors.  It is NOT part of
 // libsbv.so, is never shipped and is not a fallback: the product fails loudly without a GPU.
 #include <stdlib.h>
+#include <algorithm>
 #include <string.h>
 #include <thread>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "../../consensus_amd/csrc/p256_pt29.h"
 #include "../../consensus_amd/csrc/p256_keytab29.h"
 #include "../../consensus_amd/csrc/p256_sign.h"
+#include "../../consensus_amd/csrc/k256_core.h"
 
 using namespace sbv;
 
@@ -443,6 +445,89 @@ void sbve_fe25_inv_gcd(const int32_t* a, int32_t* out) { fe25 z; fe25_inv_gcd(z,
 void sbve_fe25_freeze(const int32_t* a, u32* out8) { u256 w; fe25_freeze(w, f25in(a)); memcpy(out8, &w, 32); }
 void sbve_fe25_from_words(const u32* w8, int32_t* out) { fe25 z; fe25_from_words(z, w8); memcpy(out, &z, 40); }
 void sbve_fe25_consts(int32_t* out30) { fe25 d = fe25_d(), d2 = fe25_2d(), s = fe25_sqrtm1(); memcpy(out30, &d, 40); memcpy(out30 + 10, &d2, 40); memcpy(out30 + 20, &s, 40); }
+
+// ---- secp256k1 (k256_fe.h, k256_sc.h, k256_core.h) ---------------------------------------------------------------------
+static kapt* g_k256_gtab = nullptr;
+static const kapt* k256_gtab() {
+    if (!g_k256_gtab) {
+        g_k256_gtab = (kapt*)aligned_alloc(64, sizeof(kapt) * SBV_K256_G_ENTRIES);
+        std::vector<std::thread> th;
+        for (int j = 0; j < SBV_K256_G_WINDOWS; ++j)
+            th.emplace_back([j] { k256_build_g_window(j, g_k256_gtab + (size_t)j * SBV_K256_G_PER_WINDOW, SBV_K256_G_PER_WINDOW); });
+        for (auto& t : th) t.join();
+    }
+    return g_k256_gtab;
+}
+static kfe kfe_in(const u32* w8) { u256 w; memcpy(&w, w8, 32); kfe r; kfe_from_words(r, w); return r; }
+static void kfe_out(u32* w8, const kfe& a) { u256 w; kfe_to_words(w, a); memcpy(w8, &w, 32); }
+// op: 0 mul, 1 sqr, 2 add, 3 sub, 4 inv, 5 a*3 - b*8 (kfe_lin), 6 neg; words in (any 256-bit value), canonical words out
+void sbve_kfe_op(int op, const u32* a, const u32* b, u32* out) {
+    const kfe x = kfe_in(a), y = kfe_in(b);
+    kfe z = kfe_zero();
+    if (op == 0) kfe_mul(z, x, y);
+    else if (op == 1) kfe_sqr(z, x);
+    else if (op == 2) kfe_add(z, x, y);
+    else if (op == 3) kfe_sub(z, x, y);
+    else if (op == 4) kfe_inv(z, x);
+    else if (op == 5) kfe_lin(z, x, 3, y, 8);
+    else if (op == 6) kfe_cneg(z, x, true);
+    kfe_out(out, z);
+}
+// a chain of operations on unnormalised intermediates: ((a - b) * (a + b) - a^2 + b^2) must be 0, and is_zero must say so
+int sbve_kfe_chain_is_zero(const u32* a, const u32* b) {
+    const kfe x = kfe_in(a), y = kfe_in(b);
+    kfe d, s2, p, xx, yy, t;
+    kfe_sub(d, x, y); kfe_add(s2, x, y); kfe_mul(p, d, s2); kfe_sqr(xx, x); kfe_sqr(yy, y);
+    kfe_sub(t, p, xx); kfe_add(t, t, yy);
+    return kfe_is_zero(t) ? 1 : 0;
+}
+void sbve_ksc_mul(const u32* a, const u32* b, u32* out) { u256 x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); ksc_mul(z, x, y); memcpy(out, &z, 32); }
+void sbve_ksc_inv(const u32* a, u32* out) { u256 x, z; memcpy(&x, a, 32); ksc_inv(z, x); memcpy(out, &z, 32); }
+void sbve_ksc_reduce512(const u32* x16, u32* out) { u256 z; ksc_reduce512(z, x16); memcpy(out, &z, 32); }
+// entry (window j, multiple m) of the comb of G as 16 words x | y
+void sbve_k256_g_entry(int j, int m, u32* out16) { memcpy(out16, k256_gtab() + (size_t)j * SBV_K256_G_PER_WINDOW + (m - 1), 64); }
+// k * (x, y) + l * G on the device point layer (double-and-add with kpt_dbl / kpt_madd): affine words out, returns 0 for infinity
+int sbve_k256_mul2(const u32* k8, const u32* x8, const u32* y8, const u32* l8, u32* out16) {
+    const kfe x = kfe_in(x8), y = kfe_in(y8);
+    kfe gx, gy;
+    kfe_from_words(gx, k256_gx_words());
+    kfe_from_words(gy, k256_gy_words());
+    kjpt R;
+    kpt_set_inf(R);
+    for (int bit = 255; bit >= 0; --bit) {
+        kpt_dbl(R, R);
+        kpt_madd(R, R, x, y, false, ((k8[bit >> 5] >> (bit & 31)) & 1) == 0);
+        kpt_madd(R, R, gx, gy, false, ((l8[bit >> 5] >> (bit & 31)) & 1) == 0);
+    }
+    if (R.inf) return 0;
+    kfe zi, zi2, zi3, ax, ay;
+    kfe_inv(zi, R.Z); kfe_sqr(zi2, zi); kfe_mul(zi3, zi2, zi); kfe_mul(ax, R.X, zi2); kfe_mul(ay, R.Y, zi3);
+    kfe_out(out16, ax); kfe_out(out16 + 8, ay);
+    return 1;
+}
+// the whole path: stage A (k256_prep_lane) + stage B (k256_verify_lane), lane by lane
+void sbve_k256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap) {
+    size_t cap = (n + 63) & ~(size_t)63;
+    if (cap == 0) cap = 64;
+    std::vector<u32> r(8 * cap), u1(8 * cap), u2(8 * cap), qx(8 * cap), qy(8 * cap), sm(8 * cap);
+    std::vector<uint8_t> ok(cap, 0);
+    Scratch s{r.data(), u1.data(), u2.data(), qx.data(), qy.data(), sm.data(), ok.data(), cap};
+    HostWords hw{tuples, 160};
+    for (size_t i = 0; i < n; ++i) k256_prep_lane(hw(0, i), i, s);
+    memset(bitmap, 0, (n + 7) / 8);
+    const kapt* gt = k256_gtab();
+    const unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            u32* qtab = (u32*)aligned_alloc(16, SBV_K256_QTAB_WORDS * 4);
+            const size_t lo = (n * t / nt) & ~(size_t)7, hi = t + 1 == nt ? n : (n * (t + 1) / nt) & ~(size_t)7;     // whole bitmap bytes per thread
+            for (size_t i = lo; i < hi; ++i)
+                if (k256_verify_lane(s, i, qtab, gt)) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+            free(qtab);
+        });
+    for (auto& t : th) t.join();
+}
 
 // ---- unit hooks (plain little-endian limb arrays) ---------------------------------------------------
 void sbve_fe_mul(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe_mul(z, x, y); memcpy(out, &z, 32); }

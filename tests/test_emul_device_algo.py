@@ -23,7 +23,7 @@ def emul():
     csrc = os.path.join(HERE, "..", "consensus_amd", "csrc")
     deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-misleading-indentation", "-DSBV_F29_CHECK", "-DSBV_F25_CHECK",
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-misleading-indentation", "-DSBV_F29_CHECK", "-DSBV_F25_CHECK", "-DSBV_K256_CHECK",
                                src, "-o", so])
     lib = ctypes.CDLL(so)
     lib.sbve_p256_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]

@@ -1,0 +1,175 @@
+"""CPU tier for the secp256k1 variant: the oracle against its pins (golden vectors from the Python
+twin, OpenSSL NID_secp256k1), and the device algorithm (consensus_amd/csrc/k256_*.h compiled by g++ into tests/emul, with
+the field's contract checks on) against big ints, the golden vectors and the oracle."""
+import ctypes
+import json
+import os
+import random
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+import k256_py as ec  # noqa: E402
+from test_emul_device_algo import emul  # noqa: E402,F401  (fixture: builds tests/emul/libsbv_emul.so)
+
+P, N = ec.P, ec.N
+
+
+@pytest.fixture(scope="module")
+def k256_vectors():
+    with open(os.path.join(HERE, "golden", "k256_vectors.json")) as f:
+        return json.load(f)["vectors"]
+
+
+@pytest.fixture(scope="module")
+def koracle(oracle):
+    oracle.sbvo_k256_verify_tuple.argtypes = [ctypes.c_char_p]
+    oracle.sbvo_k256_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+    oracle.sbvo_k256_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_int]
+    oracle.sbvo_k256_pubkey.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    oracle.sbvo_k256_sign.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    return oracle
+
+
+def words(x):
+    return (ctypes.c_uint32 * 8)(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(8)])
+
+
+def val(arr, n=8):
+    return sum(int(arr[i]) << (32 * i) for i in range(n))
+
+
+def bits(bm, n):
+    return [bool((bm[i >> 3] >> (i & 7)) & 1) for i in range(n)]
+
+
+def edge_values(m):
+    return [0, 1, 2, m - 1, m - 2, (m - 1) // 2, 2**32 - 1, 2**32, 2**64 - 1, 2**128 - 1, 2**255 % m, (2**256 - 1) % m, 2**256 - 1,
+            m, m + 1, 977, 2**32 + 977, 2**29 - 1, 2**232, 2**232 - 1, 2**261 % m,
+            0xFFFFFFFF00000000FFFFFFFF00000000FFFFFFFF00000000FFFFFFFF00000000, 0x1FFFFFFF << 203]
+
+
+# ---- the oracle against its pins ------------------------------------------------------------------------------------
+def test_oracle_matches_the_golden_vectors(koracle, k256_vectors):
+    for v in k256_vectors:
+        assert bool(koracle.sbvo_k256_verify_tuple(bytes.fromhex(v["tuple"]))) == v["accept"], v["name"]
+
+
+def test_golden_vectors_are_what_the_python_twin_says(k256_vectors):
+    for v in k256_vectors[::3]:
+        assert ec.verify_tuple(bytes.fromhex(v["tuple"])) == v["accept"], v["name"]
+    assert sum(v["accept"] for v in k256_vectors) >= 50 and sum(not v["accept"] for v in k256_vectors) >= 50
+
+
+def test_openssl_agrees_on_the_golden_vectors_and_a_seeded_batch(koracle, openssl_check, k256_vectors):
+    openssl_check.sbvssl_k256_verify_tuple.argtypes = [ctypes.c_char_p]
+    openssl_check.sbvssl_k256_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+    for v in k256_vectors:
+        assert bool(openssl_check.sbvssl_k256_verify_tuple(bytes.fromhex(v["tuple"]))) == v["accept"], v["name"]
+    n = 4096
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer(n // 8)
+    koracle.sbvo_k256_gen_batch(0x6B32, n, 37, 4, tup, exp, 8)
+    got = ctypes.create_string_buffer(n // 8)
+    openssl_check.sbvssl_k256_verify_batch(tup, n, got, 8)
+    assert got.raw == exp.raw
+    assert sum(bits(exp.raw, n)) == n - n // 4
+
+
+def test_oracle_signer_and_keys_match_the_python_twin(koracle):
+    rng = random.Random(5)
+    for _ in range(6):
+        d, k = rng.randrange(1, N), rng.randrange(1, N)
+        h = rng.randbytes(32)
+        q = ctypes.create_string_buffer(64)
+        koracle.sbvo_k256_pubkey(d.to_bytes(32, "big"), q)
+        Q = ec.pt_mul(d, ec.G)
+        assert q.raw == Q[0].to_bytes(32, "big") + Q[1].to_bytes(32, "big")
+        rs = ctypes.create_string_buffer(64)
+        assert koracle.sbvo_k256_sign(d.to_bytes(32, "big"), k.to_bytes(32, "big"), h, rs) == 0
+        r, s = ec.sign(d, k, h)
+        assert rs.raw == r.to_bytes(32, "big") + s.to_bytes(32, "big")
+
+
+# ---- the device arithmetic against big ints ------------------------------------------------------------------------------
+def test_field_operations_match_bigint(emul):
+    rng = random.Random(11)
+    vals = edge_values(P) + [rng.randrange(2**256) for _ in range(60)]
+    out = (ctypes.c_uint32 * 8)()
+    for a in vals:
+        emul.sbve_kfe_op(1, words(a), words(0), out)
+        assert val(out) == a * a % P
+        emul.sbve_kfe_op(4, words(a), words(0), out)
+        assert val(out) == (pow(a, -1, P) if a % P else 0)
+        emul.sbve_kfe_op(6, words(a), words(0), out)
+        assert val(out) == -a % P
+        for b in vals[::5] + [a]:
+            for op, want in [(0, a * b % P), (2, (a + b) % P), (3, (a - b) % P), (5, (3 * a - 8 * b) % P)]:
+                emul.sbve_kfe_op(op, words(a), words(b), out)
+                assert val(out) == want, (op, hex(a), hex(b))
+            assert emul.sbve_kfe_chain_is_zero(words(a), words(b)) == 1
+
+
+def test_scalar_operations_match_bigint(emul):
+    rng = random.Random(12)
+    vals = [v % N for v in edge_values(N)] + [rng.randrange(N) for _ in range(60)]
+    out = (ctypes.c_uint32 * 8)()
+    for a in vals:
+        emul.sbve_ksc_inv(words(a), out)
+        assert val(out) == (pow(a, -1, N) if a else 0)
+        for b in vals[::4]:
+            emul.sbve_ksc_mul(words(a), words(b), out)
+            assert val(out) == a * b % N
+    for x in [0, 1, N, N - 1, 2**256, 2**512 - 1, (N - 1) * (N - 1), 2**511, 2**385 - 1] + [rng.randrange(2**512) for _ in range(200)]:
+        x16 = (ctypes.c_uint32 * 16)(*[(x >> (32 * i)) & 0xFFFFFFFF for i in range(16)])
+        emul.sbve_ksc_reduce512(x16, out)
+        assert val(out) == x % N, hex(x)
+
+
+def test_point_layer_and_comb_of_G_match_the_python_twin(emul):
+    rng = random.Random(13)
+    out = (ctypes.c_uint32 * 16)()
+    for j, m in [(0, 1), (0, 2), (0, 32768), (1, 1), (7, 12345), (16, 1), (16, 32768), (15, 32767)]:
+        emul.sbve_k256_g_entry(j, m, out)
+        want = ec.pt_mul(m * 2**(16 * j) % N, ec.G)
+        assert (val(out), val(out[8:])) == want, (j, m)
+    Q = ec.pt_mul(rng.randrange(1, N), ec.G)
+    cases = [(rng.randrange(N), rng.randrange(N)) for _ in range(6)] + [(0, 0), (1, 0), (0, 1), (2, 0), (N - 1, 0), (5, N - 5 * 1)]
+    for k, l in cases:
+        ok = emul.sbve_k256_mul2(words(k), words(Q[0]), words(Q[1]), words(l), out)
+        want = ec.pt_add(ec.pt_mul(k, Q), ec.pt_mul(l, ec.G))
+        assert (ok == 0) == (want is None)
+        if want is not None:
+            assert (val(out), val(out[8:])) == want, (k, l)
+    # k Q + l G with Q = G: every addition of G onto a multiple of G, including G + G and G + (-G)
+    for k, l in [(1, 1), (1, N - 1), (3, N - 3), (2, 2), (N - 2, 1)]:
+        ok = emul.sbve_k256_mul2(words(k), words(ec.GX), words(ec.GY), words(l), out)
+        want = ec.pt_mul((k + l) % N, ec.G)
+        assert (ok == 0) == (want is None)
+        if want is not None:
+            assert (val(out), val(out[8:])) == want
+
+
+# ---- the whole device path, emulated ----------------------------------------------------------------------------------------
+def test_emulated_device_path_on_the_golden_vectors(emul, k256_vectors):
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in k256_vectors)
+    n = len(k256_vectors)
+    bm = ctypes.create_string_buffer((n + 7) // 8)
+    emul.sbve_k256_verify_batch(blob, ctypes.c_size_t(n), bm)
+    got = bits(bm.raw, n)
+    bad = [v["name"] for v, g in zip(k256_vectors, got) if g != v["accept"]]
+    assert not bad, bad
+
+
+def test_emulated_device_path_equals_the_oracle_on_a_seeded_batch(emul, koracle):
+    n = 1536
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer(n // 8)
+    koracle.sbvo_k256_gen_batch(0xC0DE, n, 11, 3, tup, exp, 8)
+    bm = ctypes.create_string_buffer(n // 8)
+    emul.sbve_k256_verify_batch(tup.raw, ctypes.c_size_t(n), bm)
+    assert bm.raw == exp.raw
+    assert sum(bits(exp.raw, n)) == n - n // 3

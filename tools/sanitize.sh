@@ -15,7 +15,7 @@ restore() {
   cp /tmp/libsbv_host.so.keep consensus_amd/libsbv_host.so
 }
 trap restore EXIT
-g++ $SAN -std=c++17 -fPIC -shared -pthread -Wno-misleading-indentation -DSBV_F29_CHECK -DSBV_F25_CHECK tests/emul/emul.cc -o tests/emul/libsbv_emul.so
+g++ $SAN -std=c++17 -fPIC -shared -pthread -Wno-misleading-indentation -DSBV_F29_CHECK -DSBV_F25_CHECK -DSBV_K256_CHECK tests/emul/emul.cc -o tests/emul/libsbv_emul.so
 ( cd consensus_amd/host && g++ $SAN -std=c++17 -fPIC -Wall -Wno-misleading-indentation -pthread -shared p256_host.cc ed25519_host.cc \
     formats.cc verifier.cc chain_emul.cc capi.cc -o ../libsbv_host.so -L.. -lsbv -Wl,-rpath,'$ORIGIN' )
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$PRE" python -m pytest tests/test_emul_device_algo.py tests/test_emul_fe29.py tests/test_ed25519_cpu.py \
