@@ -6,7 +6,7 @@
 //   stage A  k256_prep_lane     range checks (1 <= r, s < n; Qx, Qy < p), e = hash mod n, w = s^-1 mod n (division steps),
 //                               u1 = e w, u2 = r w  -> the limb-major scratch planes of p256_core.h
 //   stage B  k256_verify_lane   Q on the curve; the 8 affine multiples of Q (Jacobian chain, one inversion); u2 * Q with 64 signed
-//                               4-bit windows (4 doublings of 2M + 5S and one mixed addition each); + u1 * G from a signed 16-bit
+//                               4-bit windows (4 doublings of 3M + 4S and one mixed addition of 8M + 3S each); + u1 * G from a signed 16-bit
 //                               comb of G (17 mixed additions, 17 x 32768 affine entries = 35.7 MB, built once per process);
 //                               accept iff R != infinity and R.x = r (mod n), tested without an inversion: X = r Z^2 or
 //                               X = (r + n) Z^2 when r + n < p
@@ -40,66 +40,69 @@ SBV_HD bool k256_on_curve(const kfe& x, const kfe& y) {
     return kfe_equal(l, rr);
 }
 
-// 2P, a = 0: 2M + 5S.  No point of order two exists (the group order is prime), so Y = 0 never happens on the curve.
+// 2P, a = 0.  3M + 4S and five carries: with near-full-rate 64-bit multiply-accumulates a carry pass costs about as much as a
+// squaring, so X Y^2 is one more product instead of ((X + Y^2)^2 - X^2 - Y^4) / 2 with its three carried additions.
+// No point of order two exists (the group order is prime), so Y = 0 never happens on the curve.
 SBV_HD void kpt_dbl(kjpt& r, const kjpt& p) {
-    kfe A, B, C, D, E, F, t;
+    kfe A, B, C, XB, E, F, Z3, t;
     kfe_sqr(A, p.X);
     kfe_sqr(B, p.Y);
     kfe_sqr(C, B);
-    kfe_add(t, p.X, B);
-    kfe_sqr(t, t);
-    kfe_sub(t, t, A);
-    kfe_sub(t, t, C);
-    kfe_mul_small(D, t, 2);                       // D = 2 ((X + B)^2 - A - C) = 4 X Y^2
-    kfe_mul_small(E, A, 3);
+    kfe_mul(XB, p.X, B);                          // X Y^2
+    kfe_scale(E, A, 3);
     kfe_sqr(F, E);
-    kfe Z3;
     kfe_mul(Z3, p.Y, p.Z);
-    kfe_mul_small(Z3, Z3, 2);
-    kfe_lin(r.X, F, 1, D, 2);                     // X3 = F - 2 D
-    kfe_sub(t, D, r.X);
+    kfe_scale(Z3, Z3, 2);
+    kfe_lin(r.X, F, 1, XB, 8);                    // X3 = E^2 - 8 X Y^2
+    kfe_lin(t, XB, 4, r.X, 1);                    // 4 X Y^2 - X3
     kfe_mul(t, E, t);
-    kfe_lin(r.Y, t, 1, C, 8);                     // Y3 = E (D - X3) - 8 C
+    kfe_lin(r.Y, t, 1, C, 8);                     // Y3 = E (4 X Y^2 - X3) - 8 Y^4
     r.Z = Z3;
     r.inf = p.inf;
 }
 
-// r = p + (x2, y2) (affine, not infinity; `neg` adds (x2, -y2); `skip` adds nothing).  8M + 3S, exact in every case.
+// r = p + (x2, y2) (affine, reduced, not infinity; `neg` adds (x2, -y2); `skip` adds nothing).  8M + 3S and two carries: the
+// differences H, R and V - X3 go into their products uncarried.  Exact in every case: P + P and P + (-P) are detected on the
+// uncarried H (a 3-in-2^29 filter on its low limb, then the exact test) and resolved after the fact, so the common path stays
+// branch-free.
 SBV_HD void kpt_madd(kjpt& r, const kjpt& p, const kfe& x2, const kfe& y2in, bool neg, bool skip) {
     kfe y2;
-    kfe_cneg(y2, y2in, neg);
+    kfe_cneg_nc(y2, y2in, neg);
     kfe Z1Z1, U2, S2, H, Rr, HH, HHH, V, t;
     kfe_sqr(Z1Z1, p.Z);
     kfe_mul(U2, x2, Z1Z1);
     kfe_mul(S2, p.Z, Z1Z1);
     kfe_mul(S2, y2, S2);
-    kfe_sub(H, U2, p.X);
-    kfe_sub(Rr, S2, p.Y);
-    const bool h0 = kfe_is_zero(H), r0 = kfe_is_zero(Rr);
+    kfe_sub_nc(H, U2, p.X);
+    kfe_sub_nc(Rr, S2, p.Y);
     kfe_sqr(HH, H);
     kfe_mul(HHH, H, HH);
     kfe_mul(V, p.X, HH);
     kjpt s;
     kfe_sqr(t, Rr);
-    kfe_sub(t, t, HHH);
-    kfe_lin(s.X, t, 1, V, 2);
-    kfe_sub(t, V, s.X);
+    kfe_lin3(s.X, t, HHH, 1, V, 2);               // X3 = R^2 - H^3 - 2 V
+    kfe_sub_nc(t, V, s.X);
     kfe_mul(t, Rr, t);
     kfe m;
     kfe_mul(m, p.Y, HHH);
-    kfe_sub(s.Y, t, m);
+    kfe_sub(s.Y, t, m);                           // Y3 = R (V - X3) - Y1 H^3
     kfe_mul(s.Z, p.Z, H);
     s.inf = false;
-    // the exceptional cases, resolved after the fact so that the common path stays branch-free
-    const bool same = !p.inf && h0 && r0;         // p == (x2, y2): the result is 2 (x2, y2)
-    const bool opp = !p.inf && h0 && !r0;         // p == -(x2, y2): infinity
-    if (same) {
-        kjpt a;
-        a.X = x2; a.Y = y2; a.Z = kfe_one(); a.inf = false;
-        kpt_dbl(s, a);
+    if (kfe_diff_maybe_zero(H) && !p.inf) {       // rare: decide exactly
+        kfe hc, rc;
+        kfe_carry32(hc, H);
+        if (kfe_is_zero(hc)) {
+            kfe_carry32(rc, Rr);
+            if (kfe_is_zero(rc)) {                // p == (x2, y2): the result is 2 (x2, y2)
+                kjpt a;
+                a.X = x2; kfe_carry32(a.Y, y2); a.Z = kfe_one(); a.inf = false;
+                kpt_dbl(s, a);
+            } else {                              // p == -(x2, y2)
+                kpt_set_inf(s);
+            }
+        }
     }
-    if (opp) kpt_set_inf(s);
-    if (p.inf) { s.X = x2; s.Y = y2; s.Z = kfe_one(); s.inf = false; }
+    if (p.inf) { s.X = x2; kfe_carry32(s.Y, y2); s.Z = kfe_one(); s.inf = false; }
     if (skip) s = p;
     r = s;
 }

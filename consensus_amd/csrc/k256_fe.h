@@ -7,9 +7,14 @@
 //     2^261 = 32 * 2^256 = 32 * (2^32 + 977) = 2^37 + 31264  (mod p)  ->  limb k + 9 adds 31264 to limb k and 256 to limb k + 1
 //     2^256 = 2^32 + 977                                      (mod p)  ->  bit 24 of limb 8 upwards adds 977 to limb 0 and 8 to limb 1
 //
-// Contract ("reduced"): every function here returns limbs 0..7 in [0, 2^29) and limb 8 in [-2^20, 2^24 + 2^20]; the value is
-// then in (-2^253, 2^256 + 2^253), so it is congruent to 0 iff it IS 0 or p (kfe_is_zero tests exactly that).  Every
-// function accepts reduced operands.  SBV_K256_CHECK (emulator builds) turns the contract into assertions.
+// Contract.  "Reduced": limbs 0..7 in [0, 2^29), limb 8 in [-2^20, 2^24 + 2^20]; the value is then in (-2^253, 2^256 + 2^253),
+// so it is congruent to 0 iff it IS 0 or p (kfe_is_zero tests exactly that).  Everything that carries (kfe_mul, kfe_sqr,
+// kfe_add, kfe_sub, kfe_lin*, kfe_scale, kfe_carry*) returns reduced values.  The *_nc forms (no carry) return the limb-wise
+// sum or difference: signed limbs, not reduced, good as operands of ONE multiplication and nothing else.  A product's 17
+// columns are sums of nine 64-bit terms, so kfe_mul / kfe_sqr require 9 * max|a_i| * max|b_j| < 2^62.9: reduced x reduced,
+// difference x difference (|limb| < 2^29), or (3 x reduced) x reduced.  SBV_K256_CHECK (emulator builds) turns both rules
+// into assertions.  On gfx950 a 64-bit multiply-accumulate issues almost as fast as a 32-bit add, so what the point formulas
+// save is carries, not products (k256_core.h).
 //
 // Shared host/device source (tests/emul compiles it with g++).
 #pragma once
@@ -65,16 +70,57 @@ SBV_HD void kfe_carry64(kfe& r, i64 t[9]) {
     kfe_check(r, "kfe_carry64");
 }
 
-SBV_HD void kfe_add(kfe& r, const kfe& a, const kfe& b) {
-    i64 t[9];
+// the same on 32-bit limbs (|t[i]| < 2^31 - 2^26): for sums and differences of a few reduced values
+SBV_HD void kfe_carry32(kfe& r, const kfe& a) {
+    i32 t[9];
     SBV_UNROLL
-    for (int i = 0; i < 9; ++i) t[i] = (i64)a.v[i] + b.v[i];
-    kfe_carry64(r, t);
+    for (int i = 0; i < 9; ++i) t[i] = a.v[i];
+    SBV_UNROLL
+    for (int i = 0; i < 8; ++i) { t[i + 1] += t[i] >> 29; t[i] &= SBV_KM29; }
+    const i32 top = t[8] >> 24;
+    t[8] &= 0xFFFFFF;
+    t[0] += 977 * top;
+    t[1] += 8 * top;
+    SBV_UNROLL
+    for (int i = 0; i < 8; ++i) { t[i + 1] += t[i] >> 29; t[i] &= SBV_KM29; }
+    SBV_UNROLL
+    for (int i = 0; i < 9; ++i) r.v[i] = t[i];
+    kfe_check(r, "kfe_carry32");
+}
+SBV_HD void kfe_add_nc(kfe& r, const kfe& a, const kfe& b) {
+    SBV_UNROLL
+    for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] + b.v[i];
+}
+SBV_HD void kfe_sub_nc(kfe& r, const kfe& a, const kfe& b) {
+    SBV_UNROLL
+    for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] - b.v[i];
+}
+SBV_HD void kfe_cneg_nc(kfe& r, const kfe& a, bool neg) {
+    SBV_UNROLL
+    for (int i = 0; i < 9; ++i) r.v[i] = neg ? -a.v[i] : a.v[i];
+}
+SBV_HD void kfe_add(kfe& r, const kfe& a, const kfe& b) {
+    kfe t;
+    kfe_add_nc(t, a, b);
+    kfe_carry32(r, t);
 }
 SBV_HD void kfe_sub(kfe& r, const kfe& a, const kfe& b) {
+    kfe t;
+    kfe_sub_nc(t, a, b);
+    kfe_carry32(r, t);
+}
+// r = a * k for k = 2, 3 (32-bit)
+SBV_HD void kfe_scale(kfe& r, const kfe& a, int k) {
+    kfe t;
+    SBV_UNROLL
+    for (int i = 0; i < 9; ++i) t.v[i] = a.v[i] * k;
+    kfe_carry32(r, t);
+}
+// r = a - b * kb - c * kc for small non-negative constants (64-bit)
+SBV_HD void kfe_lin3(kfe& r, const kfe& a, const kfe& b, int kb, const kfe& c, int kc) {
     i64 t[9];
     SBV_UNROLL
-    for (int i = 0; i < 9; ++i) t[i] = (i64)a.v[i] - b.v[i];
+    for (int i = 0; i < 9; ++i) t[i] = (i64)a.v[i] - (i64)b.v[i] * kb - (i64)c.v[i] * kc;
     kfe_carry64(r, t);
 }
 // r = a * k - b * m for small non-negative constants (k, m <= 16)
@@ -124,9 +170,22 @@ SBV_HD void kfe_reduce(kfe& r, i64 c[17]) {
     kfe_carry64(r, t);
 }
 
+SBV_HD void kfe_check_product(const kfe& a, const kfe& b, const char* where) {
+#if defined(SBV_K256_CHECK)
+    i64 ma = 0, mb = 0;
+    for (int i = 0; i < 9; ++i) {
+        const i64 x = a.v[i] < 0 ? -(i64)a.v[i] : (i64)a.v[i], y = b.v[i] < 0 ? -(i64)b.v[i] : (i64)b.v[i];
+        if (x > ma) ma = x;
+        if (y > mb) mb = y;
+    }
+    const long double bound = 9.0L * (long double)ma * (long double)mb;
+    if (bound >= 8.6e18L) { fprintf(stderr, "k256_fe product bound violated in %s: 9 * %lld * %lld\n", where, (long long)ma, (long long)mb); abort(); }
+#else
+    (void)a; (void)b; (void)where;
+#endif
+}
 SBV_HD void kfe_mul(kfe& r, const kfe& a, const kfe& b) {
-    kfe_check(a, "kfe_mul a");
-    kfe_check(b, "kfe_mul b");
+    kfe_check_product(a, b, "kfe_mul");
     i64 c[17];
     SBV_UNROLL
     for (int k = 0; k < 17; ++k) c[k] = 0;
@@ -138,7 +197,7 @@ SBV_HD void kfe_mul(kfe& r, const kfe& a, const kfe& b) {
     kfe_reduce(r, c);
 }
 SBV_HD void kfe_sqr(kfe& r, const kfe& a) {
-    kfe_check(a, "kfe_sqr");
+    kfe_check_product(a, a, "kfe_sqr");
     i64 c[17];
     SBV_UNROLL
     for (int k = 0; k < 17; ++k) c[k] = 0;
@@ -186,17 +245,16 @@ SBV_HD void kfe_to_words(u256& w, const kfe& a) {
     SBV_UNROLL
     for (int k = 0; k < 8; ++k) w.v[k] = x[k];
 }
-// any 256-bit integer (not necessarily < p) -> reduced limbs of the same residue
+// any 256-bit integer (not necessarily < p) -> reduced limbs of the same residue: the nine bit fields ARE reduced limbs
 SBV_HD void kfe_from_words(kfe& r, const u256& w) {
-    i64 t[9];
     SBV_UNROLL
     for (int i = 0; i < 9; ++i) {
         const int bit = 29 * i, wd = bit >> 5, sh = bit & 31;
-        u64 v = (u64)w.v[wd] >> sh;
-        if (sh > 3 && wd + 1 < 8) v |= (u64)w.v[wd + 1] << (32 - sh);
-        t[i] = (i64)(v & (i == 8 ? 0xFFFFFFu : (u32)SBV_KM29));
+        u32 v = w.v[wd] >> sh;
+        if (sh > 3 && wd + 1 < 8) v |= w.v[wd + 1] << (32 - sh);
+        r.v[i] = (i32)(v & (i == 8 ? 0xFFFFFFu : (u32)SBV_KM29));
     }
-    kfe_carry64(r, t);
+    kfe_check(r, "kfe_from_words");
 }
 
 // exact zero test of a reduced value: the value is 0 or p
@@ -211,6 +269,12 @@ SBV_HD bool kfe_is_zero_slow(const kfe& a) {
 SBV_HD bool kfe_is_zero(const kfe& a) {
     kfe_check(a, "kfe_is_zero");
     return kfe_maybe_zero(a) && kfe_is_zero_slow(a);
+}
+// d = a - b (kfe_sub_nc of two reduced values): false means d is certainly not 0 mod p.  |d| < 1.25 * 2^256, so d = 0 mod p
+// iff d is 0, p or -p, whose low 29 bits are 0, p mod 2^29 and 2^29 - p mod 2^29 = 977.
+SBV_HD bool kfe_diff_maybe_zero(const kfe& d) {
+    const i32 lo = d.v[0] & SBV_KM29;
+    return lo == 0 || lo == SBV_K_P0 || lo == 977;
 }
 SBV_HD bool kfe_equal(const kfe& a, const kfe& b) {
     kfe d;
