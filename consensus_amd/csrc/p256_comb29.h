@@ -135,9 +135,26 @@ SBV_HD void gphase29_lane_sorted(const Scratch& s, size_t t, size_t L, const gco
 }
 
 // R += sum of windows [j0, j1) of u2 * Q; qtab[j * 128 + (k-1)] = k * 2^(8 j) * Q, j = 0..32
-SBV_HD void qphase29_point(xyzz& R, const u256& u2, const apt* qtab, int j0, int j1) {
+// Window 32 holds the carry of the signed recoding (digit 0 or 1).  For a uniformly random u2 it is 1 about half the time, so
+// every wavefront paid a 33rd addition.  u2 * Q = (n - u2) * (-Q) (Q has order n), so a scalar with its top bit set is replaced
+// by n - u2 < 2^255 with every digit's sign flipped: the carry then needs a top byte of 0x7F (0.4 % of the lanes), and the loop
+// bound becomes wave-uniform — a wavefront runs window 32 only if one of its lanes carries (22 % of the wavefronts).
+SBV_HD bool wave_any(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __any(x) != 0;
+#else
+    return x;
+#endif
+}
+SBV_HD void qphase29_point(xyzz& R, const u256& u2in, const apt* qtab, int j0, int j1) {
+    const bool flip = (u2in.v[7] >> 31) != 0;
+    u256 u2, nmu;
+    (void)sub256(nmu, sc_n(), u2in);                  // u2in < n always (stage A reduces it); garbage for an out-of-range lane, whose verdict is already false
+    select256(u2, flip, nmu, u2in);
     u256 k2;
     const u32 top2 = add_const_limbs(k2, u2, 0x80808080u);
+    if (j1 == SBV_GTAB_WINDOWS && !wave_any(top2 != 0)) j1 = SBV_GTAB_WINDOWS - 1;
+    if (j0 >= j1) return;
     int idx; bool neg, skip;
     comb_digit(k2, top2, j0, idx, neg, skip);
     raw_apt cur;
@@ -152,7 +169,7 @@ SBV_HD void qphase29_point(xyzz& R, const u256& u2, const apt* qtab, int j0, int
         if (!skip) {
             apt29 q;
             raw_apt_unpack(q, cur);
-            pt29_madd(R, q, neg);
+            pt29_madd(R, q, neg != flip);
         }
         cur = nxt; neg = negn; skip = skipn;
     }

@@ -238,6 +238,48 @@ def test_registered_key_form_matches_generic_verdicts(emul, oracle, golden_vecto
         emul.sbve_set_keyed_coop(0)
 
 
+def test_key_comb_scalars_around_the_sign_flip_and_the_carry_window(emul, oracle):
+    """qphase29_point replaces a scalar with its top bit set by n - u2 (all digit signs flipped) so that the carry window of
+    the signed recoding is almost never needed.  Forged signatures with chosen u2 walk the edges: 2^255 and its neighbours,
+    n - 1, the exact carry threshold 0x7F7F...7F80 on both sides, through the registered-key form and the grouped step."""
+    rng = random.Random(0xF11B)
+    d = rng.randrange(1, N)
+    Q = ec.pt_mul(d, ec.G)
+    thr = int.from_bytes(b"\x7f" * 31 + b"\x80", "big")                  # u2 + 0x8080...80 carries out iff u2 >= thr
+    u2s = [1, 2, 127, 128, 129, 2**255 - 1, 2**255, 2**255 + 1, N - 1, N - 2, thr, thr - 1, thr + 1, N - thr, N - thr + 1, N - thr - 1,
+           2**254, 2**255 - 2**247, (N - 1) // 2, (N + 1) // 2, 0x80 << 248, (0x7F << 248) | ((1 << 248) - 1)]
+    u2s = [u % N for u in u2s if u % N] + [rng.randrange(1, N) for _ in range(20)]
+    tuples = []
+    for u2 in u2s:
+        u1 = rng.randrange(0, N)
+        Rp = ec.pt_add(ec.pt_mul(u1, ec.G), ec.pt_mul(u2, Q))
+        r = Rp[0] % N
+        s_ = r * pow(u2, -1, N) % N
+        e = u1 * s_ % N
+        tuples.append(r.to_bytes(32, "big") + s_.to_bytes(32, "big") + e.to_bytes(32, "big") + Q[0].to_bytes(32, "big") + Q[1].to_bytes(32, "big"))
+        bad = bytearray(tuples[-1]); bad[70] ^= 4                            # same u2 (r and s untouched), wrong hash
+        tuples.append(bytes(bad))
+    blob = b"".join(tuples)
+    total = len(tuples)
+    want = [bool(oracle.sbvo_p256_verify_tuple(t)) for t in tuples]
+    assert want == [True, False] * (total // 2)
+    rsh, slots, keys = split_keyed(blob)
+    arr = (ctypes.c_uint32 * total)(*slots)
+    bm = ctypes.create_string_buffer((total + 7) // 8)
+    emul.sbve_p256_verify_batch_keyed(rsh, arr, total, b"".join(keys), len(keys), bm, 64, 4)
+    assert _bitmap_list(bm.raw, total) == want
+    emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    stats = (ctypes.c_uint32 * 4)()
+    for chunks in (1, 2, 3):
+        emul.sbve_set_group_chunks(chunks)
+        bm = ctypes.create_string_buffer((total + 7) // 8)
+        emul.sbve_p256_verify_batch_grouped(blob, total, bm, 2, 16, 10, stats)
+        assert _bitmap_list(bm.raw, total) == want, chunks
+        assert stats[1] == total
+    emul.sbve_set_group_chunks(3)
+
+
 def test_fast_conditional_subtraction_is_exact_or_flags(emul):
     """FAST mode: either the result equals the exact one, or the sticky word is 0xFFFFFFFF."""
     emul.sbve_fe_add_fast.restype = ctypes.c_uint32
