@@ -55,7 +55,7 @@ SBV_HD void kfe_check(const kfe& a, const char* where) {
 #endif
 }
 
-// Limbs as 64-bit values (|t[i]| < 2^56) -> reduced.  Two carry passes around the fold of everything from bit 256 up.
+// Limbs as 64-bit values (|t[i]| < 2^63 - 2^35) -> reduced.  Two carry passes around the fold of everything from bit 256 up.
 SBV_HD void kfe_carry64(kfe& r, i64 t[9]) {
     SBV_UNROLL
     for (int i = 0; i < 8; ++i) { t[i + 1] += t[i] >> 29; t[i] &= SBV_KM29; }
@@ -147,27 +147,27 @@ SBV_HD void kfe_select(kfe& r, bool c, const kfe& a, const kfe& b) {
     for (int i = 0; i < 9; ++i) r.v[i] = c ? a.v[i] : b.v[i];
 }
 
-// 17 product columns -> reduced.  |c[k]| < 2^62 (nine products of reduced limbs).
+// 17 product columns -> reduced.  |c[k]| < 2^62.9 (kfe_check_product).  The high columns are NOT carried through one another
+// (a 16-step chain of 64-bit shifts and adds): each is split on its own into its low 29 bits and the rest, position 9 + k
+// then holds lo(c[9+k]) + hi(c[8+k]) < 2^35, and that folds into positions k and k + 1.  One carry pass pair (kfe_carry64)
+// at the end does all the propagation.
 SBV_HD void kfe_reduce(kfe& r, i64 c[17]) {
-    // columns -> 29-bit limbs l[0..16] and the final carry l17 (bits 493 and up; < 2^22)
-    i64 l17;
+    i64 h[9];                                   // positions 9..17
+    i64 prev_hi = 0;
     SBV_UNROLL
-    for (int k = 0; k < 16; ++k) { c[k + 1] += c[k] >> 29; c[k] &= SBV_KM29; }
-    l17 = c[16] >> 29;
-    c[16] &= SBV_KM29;
-    // fold limbs 9..17: limb 9 + k goes to limbs k and k + 1
+    for (int k = 0; k < 8; ++k) {
+        const i64 hi = c[9 + k] >> 29;
+        h[k] = (c[9 + k] & SBV_KM29) + prev_hi;
+        prev_hi = hi;
+    }
+    h[8] = prev_hi;                             // |h[8]| < 2^34
     i64 t[9];
     SBV_UNROLL
-    for (int k = 0; k < 9; ++k) {
-        const i64 hk = k < 8 ? c[9 + k] : l17;
-        const i64 hk1 = k == 0 ? 0 : c[9 + k - 1];
-        t[k] = c[k] + 31264 * hk + 256 * hk1;
-    }
-    // limb 9 of the folded value (256 * l17) is another multiple of 2^261
-    const i64 t9 = 256 * l17;
+    for (int k = 0; k < 9; ++k) t[k] = c[k] + 31264 * h[k] + (k == 0 ? 0 : 256 * h[k - 1]);
+    const i64 t9 = 256 * h[8];                  // position 9 once more; |t9| < 2^42
     t[0] += 31264 * t9;
     t[1] += 256 * t9;
-    kfe_carry64(r, t);
+    kfe_carry64(r, t);                          // |t[k]| < 2^62.9 + 2^57: the carries added on the way stay below 2^63
 }
 
 SBV_HD void kfe_check_product(const kfe& a, const kfe& b, const char* where) {

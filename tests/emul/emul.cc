@@ -473,6 +473,14 @@ void sbve_kfe_op(int op, const u32* a, const u32* b, u32* out) {
     else if (op == 6) kfe_cneg(z, x, true);
     kfe_out(out, z);
 }
+// raw limbs in (any signed 32-bit values that satisfy the product bound), canonical words of a * b (or a^2 when b is null) out:
+// the extremes of the operand contract, which kfe_in can never produce
+void sbve_kfe_mul_raw(const int32_t* a9, const int32_t* b9, u32* out) {
+    kfe x, y, z;
+    memcpy(&x, a9, 36);
+    if (b9) { memcpy(&y, b9, 36); kfe_mul(z, x, y); } else kfe_sqr(z, x);
+    kfe_out(out, z);
+}
 // a chain of operations on unnormalised intermediates: ((a - b) * (a + b) - a^2 + b^2) must be 0, and is_zero must say so
 int sbve_kfe_chain_is_zero(const u32* a, const u32* b) {
     const kfe x = kfe_in(a), y = kfe_in(b);

@@ -113,6 +113,31 @@ def test_field_operations_match_bigint(emul):
             assert emul.sbve_kfe_chain_is_zero(words(a), words(b)) == 1
 
 
+def test_field_products_at_the_extremes_of_the_operand_contract(emul):
+    """kfe_mul / kfe_sqr on raw limb patterns up to the product bound 9 * max|a| * max|b| < 2^62.9: all limbs at +-(2^29 - 1)
+    (uncarried differences), one operand at 3 x reduced, alternating signs, large top limbs — against big ints.  The emulator
+    build asserts the bound itself; the 64-bit intermediates of the reduction must not wrap below it."""
+    rng = random.Random(14)
+    M = 2**29 - 1
+    out = (ctypes.c_uint32 * 8)()
+
+    def value(l):
+        return sum(v << (29 * i) for i, v in enumerate(l))
+
+    pats = [[M] * 8 + [2**24 + 2**20], [-M] * 8 + [-(2**24 + 2**20)], [M, -M] * 4 + [2**24], [-M, M] * 4 + [-(2**20)],
+            [0] * 8 + [2**24 + 2**20], [M] * 9, [-M] * 9, [1] + [0] * 8, [0] * 9]
+    pats += [[rng.randrange(-M, M + 1) for _ in range(8)] + [rng.randrange(-(2**24), 2**24)] for _ in range(40)]
+    wide = [[3 * M] * 8 + [3 * 2**24], [-3 * M, 3 * M] * 4 + [2**25]]          # 3 x reduced against a reduced / difference operand
+    for a in pats:
+        arr_a = (ctypes.c_int32 * 9)(*a)
+        emul.sbve_kfe_mul_raw(arr_a, None, out)
+        assert val(out) == value(a) ** 2 % P, a
+        for b in pats[::3] + wide:
+            arr_b = (ctypes.c_int32 * 9)(*b)
+            emul.sbve_kfe_mul_raw(arr_a, arr_b, out)
+            assert val(out) == value(a) * value(b) % P, (a, b)
+
+
 def test_scalar_operations_match_bigint(emul):
     rng = random.Random(12)
     vals = [v % N for v in edge_values(N)] + [rng.randrange(N) for _ in range(60)]
