@@ -48,13 +48,13 @@ extern "C" {
 
 // backend_kind 0: libsbv.so on `device`; 1: callback (tests inject a stand-in, like mocks.VerifierMock);
 // 2: callback + a host-side key registry (stand-in for the registered-key form)
-// scheme 0 = ECDSA P-256, 1 = Ed25519 (BASELINE.json configs[4]); everything else as sbvh_verifier_new
+// scheme 0 = ECDSA P-256, 1 = Ed25519 (BASELINE.json configs[4]), 2 = ECDSA secp256k1; everything else as sbvh_verifier_new
 void* sbvh_verifier_new_scheme(int scheme, int backend_kind, int device, backend_fn fn, void* user, size_t coalesce_max,
                                int coalesce_wait_us, int cache) {
     VHandle* h = new VHandle;
     h->be = backend_kind == 0 ? make_sbv_backend(device) : make_callback_backend(fn, user, backend_kind == 2);
     VerifierOptions o;
-    o.scheme = scheme == 1 ? Scheme::ED25519 : Scheme::P256;
+    o.scheme = scheme == 1 ? Scheme::ED25519 : (scheme == 2 ? Scheme::SECP256K1 : Scheme::P256);
     o.coalesce_max = coalesce_max;
     o.coalesce_wait = std::chrono::microseconds(coalesce_wait_us);
     o.cache_verified = cache != 0;
@@ -135,7 +135,7 @@ void sbvh_stats(void* h, uint64_t* calls, uint64_t* batches, uint64_t* max_batch
 
 // ---- signer ----------------------------------------------------------------------------------------
 void* sbvh_signer_new(uint64_t id, const uint8_t sk[32]) { return new Signer(id, sk); }
-void* sbvh_signer_new_scheme(int scheme, uint64_t id, const uint8_t sk[32]) { return new Signer(id, sk, scheme == 1 ? Scheme::ED25519 : Scheme::P256); }
+void* sbvh_signer_new_scheme(int scheme, uint64_t id, const uint8_t sk[32]) { return new Signer(id, sk, scheme == 1 ? Scheme::ED25519 : (scheme == 2 ? Scheme::SECP256K1 : Scheme::P256)); }
 void sbvh_signer_free(void* s) { delete (Signer*)s; }
 void sbvh_signer_public_key(void* s, uint8_t q[64]) { memcpy(q, ((Signer*)s)->public_key(), 64); }
 size_t sbvh_sign(void* s, const void* msg, size_t n, void* out, size_t cap) { return put(((Signer*)s)->Sign(B(msg, n)), out, cap); }

@@ -52,6 +52,8 @@ class Backend {
     virtual void host_free(void* p) { (void)p; }
     // Ed25519 variant (include/sbv.h: sbv_ed25519_verify_batch): n tuples of 128 bytes R|S|A|k.  -2 when unsupported.
     virtual int verify_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap) { (void)tuples128; (void)n; (void)bitmap; return -2; }
+    // secp256k1 variant (include/sbv.h: sbv_secp256k1_verify_batch): n tuples of 160 bytes, same layout as verify().  -2 when unsupported.
+    virtual int verify_k256(const uint8_t* tuples, size_t n, uint8_t* bitmap) { (void)tuples; (void)n; (void)bitmap; return -2; }
     virtual int verify_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap) {
         (void)rsh; (void)slots; (void)n; (void)bitmap; return -2;
     }
@@ -83,8 +85,9 @@ class Coalescer {
     // 1 = accept, 0 = reject, <0 = backend error
     // slot >= 0: the signer's key is registered with the backend (tuple[96..160) is then ignored)
     // ed25519 = true: `tuple` holds a 128-byte R|S|A|k tuple instead (one Verifier = one scheme, so a burst never mixes)
-    int submit(const uint8_t tuple[160], long slot = -1, bool ed25519 = false);
+    int submit(const uint8_t tuple[160], long slot = -1, bool ed25519 = false, bool k256 = false);
     int submit_many_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap);
+    int submit_many_k256(const uint8_t* tuples, size_t n, uint8_t* bitmap);
     int submit_many(const uint8_t* tuples, size_t n, uint8_t* bitmap);
     int submit_many_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap);
     Backend& backend() { return *be_; }
@@ -94,7 +97,7 @@ class Coalescer {
     void set_burst_hint(size_t n) { burst_hint_.store(n, std::memory_order_relaxed); }
 
  private:
-    struct Job { uint8_t tuple[160]; long slot = -1; bool ed25519 = false; int result = -100; std::atomic<bool> done{false}; };
+    struct Job { uint8_t tuple[160]; long slot = -1; bool ed25519 = false; bool k256 = false; int result = -100; std::atomic<bool> done{false}; };
     void run();
     std::shared_ptr<Backend> be_;
     size_t max_batch_;
@@ -112,7 +115,9 @@ class Coalescer {
 // Signature scheme of a Verifier / Signer pair.  P256: ECDSA over SHA-256, DER signatures, 64-byte Qx|Qy keys (Go
 // crypto/ecdsa.VerifyASN1).  ED25519: the BASELINE.json configs[4] variant — 64-byte R|S signatures, 32-byte keys
 // (Go crypto/ed25519.Verify); registered-key slots do not apply (the device groups by key inside each batch).
-enum class Scheme { P256 = 0, ED25519 = 1 };
+// SECP256K1: ECDSA over SHA-256 with DER signatures and 64-byte keys exactly like P256, on the other curve
+// (include/sbv.h: sbv_secp256k1_verify_batch); no registered-key slots yet (every tuple carries its key).
+enum class Scheme { P256 = 0, ED25519 = 1, SECP256K1 = 2 };
 
 struct VerifierOptions {
     Scheme scheme = Scheme::P256;
@@ -155,6 +160,7 @@ class Verifier {
     void make_tuple(const uint8_t q[64], const bytes& msg, const bytes& sig_der, uint8_t out[160]);
     static void make_tuple_ed25519(const uint8_t a_enc[32], const bytes& msg, const bytes& sig, uint8_t out[128]);
     bool ed() const { return opt_.scheme == Scheme::ED25519; }
+    bool k256() const { return opt_.scheme == Scheme::SECP256K1; }
     size_t key_bytes() const { return ed() ? 32 : 64; }
     Status verify_one(const uint8_t q[64], const bytes& msg, const bytes& sig, long slot = -1);
     std::string cache_key(const uint8_t q[64], const bytes& msg, const bytes& sig) const;
@@ -192,7 +198,7 @@ class Verifier {
 // api.Signer for one node (pkg/api/dependencies.go:46-52)
 class Signer {
  public:
-    // private_key: the P-256 scalar d, or the RFC 8032 seed under Scheme::ED25519
+    // private_key: the P-256 / secp256k1 scalar d, or the RFC 8032 seed under Scheme::ED25519
     Signer(uint64_t id, const uint8_t private_key[32], Scheme scheme = Scheme::P256);
     uint64_t id() const { return id_; }
     const uint8_t* public_key() const { return q_; }                        // 64 bytes Qx|Qy, or 32 bytes A_enc (+ 32 zero bytes)

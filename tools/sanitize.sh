@@ -16,7 +16,7 @@ restore() {
 }
 trap restore EXIT
 g++ $SAN -std=c++17 -fPIC -shared -pthread -Wno-misleading-indentation -DSBV_F29_CHECK -DSBV_F25_CHECK -DSBV_K256_CHECK tests/emul/emul.cc -o tests/emul/libsbv_emul.so
-( cd consensus_amd/host && g++ $SAN -std=c++17 -fPIC -Wall -Wno-misleading-indentation -pthread -shared p256_host.cc ed25519_host.cc \
+( cd consensus_amd/host && g++ $SAN -std=c++17 -fPIC -Wall -Wno-misleading-indentation -pthread -shared p256_host.cc ed25519_host.cc k256_host.cc \
     formats.cc verifier.cc chain_emul.cc capi.cc -o ../libsbv_host.so -L.. -lsbv -Wl,-rpath,'$ORIGIN' )
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$PRE" python -m pytest tests/test_emul_device_algo.py tests/test_emul_fe29.py tests/test_ed25519_cpu.py \
     tests/test_host_verifier.py tests/test_datagen.py tests/test_emul_sign.py tests/test_chain_emul.py tests/test_k256_cpu.py -q
