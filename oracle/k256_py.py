@@ -5,7 +5,8 @@ module; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 
 Parity status: **parity unpinned by the reference** (see secp256k1_oracle.c's header: the reference holds no signature
 arithmetic, and this curve is not in Go's standard library).  Restates SEC 1 v2.0 §4.1.4 with the SEC 2 v2.0 §2.4.1
-parameters and the input rules of the P-256 twin (oracle/p256_py.py); pinned against OpenSSL's NID_secp256k1.
+parameters and the input rules of the P-256 twin (oracle/p256_py.py); pinned against the community RFC 6979 secp256k1
+known answers (tests/golden/rfc6979_k256.json) and OpenSSL's NID_secp256k1.
 
 Deliberately simple: affine arithmetic with modular inverses, one function per step.
 """

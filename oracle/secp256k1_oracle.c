@@ -11,8 +11,10 @@
  * api.Signer, pkg/api/dependencies.go:46-71).  This file restates the *published* algorithm — SEC 1 v2.0 §4.1.4 with
  * SEC 2 v2.0 §2.4.1 parameters, and the same input rules as the P-256 oracle (p256_oracle.c: 1 <= r, s <= n - 1, public
  * key coordinates < p and on the curve, hash = leftmost 32 bytes reduced mod n, exact group law, R = infinity rejected,
- * accept iff R.x mod n == r) — and is pinned against OpenSSL 3.0 ECDSA_do_verify with NID_secp256k1
- * (oracle/openssl_check.c, tests/test_k256_cpu.py) and a Python big-int twin (oracle/k256_py.py).
+ * accept iff R.x mod n == r) — and is pinned against (i) the community RFC 6979 secp256k1 known answers
+ * (tests/golden/rfc6979_k256.json: d, message, nonce, signature; the signer below reproduces r and s from the published
+ * nonce, the verifier accepts them), (ii) OpenSSL 3.0 ECDSA_do_verify with NID_secp256k1 (oracle/openssl_check.c,
+ * tests/test_k256_cpu.py) on every vector class and on whole seeded batches, (iii) a Python big-int twin (oracle/k256_py.py).
  *
  * Deliberately simple: 4 x 64-bit words, plain (non-Montgomery) residues, the pseudo-Mersenne folds 2^256 = 2^32 + 977
  * (mod p) and 2^256 = c (mod n), Fermat inversions, Jacobian double-and-add.  It shares no arithmetic with the device code

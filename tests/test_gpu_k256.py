@@ -43,6 +43,24 @@ def test_golden_vectors(gpu):
     assert not bad, bad
 
 
+def test_external_known_answers_rfc6979_secp256k1(gpu):
+    """tests/golden/rfc6979_k256.json (community RFC 6979 secp256k1 vectors): the published (r, s) and (r, n - s) verify under
+    d * G and not under a neighbouring key."""
+    import hashlib
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import k256_py as kc
+    tuples, want = [], []
+    for v in json.load(open(os.path.join(GOLDEN, "rfc6979_k256.json")))["vectors"]:
+        h = hashlib.sha256(v["msg"].encode()).digest()
+        r, s_low = int(v["sig"][:64], 16), int(v["sig"][64:], 16)
+        Q = kc.pt_mul(int(v["d"], 16), kc.G)
+        for s_ in (s_low, kc.N - s_low):
+            tuples.append(kc.make_tuple(r, s_, h, Q)); want.append(True)
+            tuples.append(kc.make_tuple(r, s_, h, kc.pt_add(Q, kc.pt_mul(2, kc.G)))); want.append(False)
+    assert sbv.bitmap_to_list(gpu.secp256k1_verify_batch(b"".join(tuples)), len(tuples)) == want
+
+
 @pytest.mark.parametrize("n", [0, 1, 7, 63, 64, 65, 257, 1000, 20000])
 def test_ragged_sizes_match_oracle(gpu, koracle, n):
     tup, exp = _gen(koracle, 0x6B00 + n, n, 13, 3)

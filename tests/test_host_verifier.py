@@ -467,6 +467,21 @@ def test_secp256k1_verifier_variant(lib, oracle):
         assert out.raw[:n2] != der
         lib.sbvh_signer_free(sp)
         lib.sbvh_signer_free(si)
+    # external known answers (tests/golden/rfc6979_k256.json): the host signer derives the published nonce, hence r, and s up
+    # to the vectors' low-S normalisation; public keys as derived by the big-int twin
+    import json
+    for v in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rfc6979_k256.json")))["vectors"]:
+        si = lib.sbvh_signer_new_scheme(2, 1, bytes.fromhex(v["d"]))
+        lib.sbvh_signer_public_key(si, q)
+        Qk = kc.pt_mul(int(v["d"], 16), kc.G)
+        assert q.raw == Qk[0].to_bytes(32, "big") + Qk[1].to_bytes(32, "big")
+        msg = v["msg"].encode()
+        n = lib.sbvh_sign(si, msg, len(msg), out, 80)
+        der = out.raw[:n]
+        rl = der[3]; r = int.from_bytes(der[4:4 + rl], "big")
+        sl = der[5 + rl]; s_ = int.from_bytes(der[6 + rl:6 + rl + sl], "big")
+        assert r == int(v["sig"][:64], 16) and min(s_, kc.N - s_) == int(v["sig"][64:], 16)
+        lib.sbvh_signer_free(si)
     hx = Harness(lib, oracle, scheme=2, wait_us=2000)
     try:
         reqs = [hx.request("alice%d" % (i % 3), "r%d" % i, payload=bytes([i])) for i in range(100)]

@@ -94,6 +94,40 @@ def test_oracle_signer_and_keys_match_the_python_twin(koracle):
         assert rs.raw == r.to_bytes(32, "big") + s.to_bytes(32, "big")
 
 
+def test_external_known_answers_rfc6979_secp256k1(koracle, openssl_check, emul, k256_vectors):
+    """The one pin that comes from outside this repository: the community RFC 6979 secp256k1 vectors (tests/golden/
+    rfc6979_k256.json: provenance there).  The oracle's signer reproduces r and s (up to the vectors' low-S normalisation)
+    from d and the published nonce; the oracle, its Python twin, OpenSSL and the emulated device path accept both the published
+    (r, s) and (r, n - s), and reject them under a neighbouring key."""
+    import hashlib
+    kats = json.load(open(os.path.join(HERE, "golden", "rfc6979_k256.json")))["vectors"]
+    openssl_check.sbvssl_k256_verify_tuple.argtypes = [ctypes.c_char_p]
+    tuples, want = [], []
+    for v in kats:
+        d, k = bytes.fromhex(v["d"]), bytes.fromhex(v["k"])
+        h = hashlib.sha256(v["msg"].encode()).digest()
+        r, s_low = int(v["sig"][:64], 16), int(v["sig"][64:], 16)
+        rs = ctypes.create_string_buffer(64)
+        assert koracle.sbvo_k256_sign(d, k, h, rs) == 0
+        s_raw = int.from_bytes(rs.raw[32:], "big")
+        assert int.from_bytes(rs.raw[:32], "big") == r and min(s_raw, N - s_raw) == s_low and (s_raw != s_low) == v["s_was_high"]
+        assert ec.sign(int(v["d"], 16), int(v["k"], 16), h) == (r, s_raw)
+        q = ctypes.create_string_buffer(64)
+        koracle.sbvo_k256_pubkey(d, q)
+        Q = ec.pt_mul(int(v["d"], 16), ec.G)
+        assert q.raw == Q[0].to_bytes(32, "big") + Q[1].to_bytes(32, "big")
+        Q2 = ec.pt_add(Q, ec.pt_mul(2, ec.G))           # d = n - 1 makes Q = -G: Q + G would be infinity
+        for s_ in (s_low, N - s_low):
+            tuples.append(ec.make_tuple(r, s_, h, Q)); want.append(True)
+            tuples.append(ec.make_tuple(r, s_, h, Q2)); want.append(False)
+    for t, w in zip(tuples, want):
+        assert bool(koracle.sbvo_k256_verify_tuple(t)) == w and ec.verify_tuple(t) == w
+        assert bool(openssl_check.sbvssl_k256_verify_tuple(t)) == w
+    bm = ctypes.create_string_buffer((len(tuples) + 7) // 8)
+    emul.sbve_k256_verify_batch(b"".join(tuples), ctypes.c_size_t(len(tuples)), bm)
+    assert bits(bm.raw, len(tuples)) == want
+
+
 # ---- the device arithmetic against big ints ------------------------------------------------------------------------------
 def test_field_operations_match_bigint(emul):
     rng = random.Random(11)
