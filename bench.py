@@ -222,6 +222,39 @@ def leg_ed25519(sbv, torch, n, steps, stream):
             "algorithmic_GBps": 128.125 * n * steps / dt / 1e9}
 
 
+def leg_secp256k1(sbv, torch, n, steps, stream):
+    """The "other curves" variant: n secp256k1 signatures, 1024 keys, 7/8 valid, 160-byte tuples resident in
+    HBM, one lane per signature (no grouped step for this curve yet).  Signatures come from the host library's RFC 6979 signer."""
+    import numpy as np
+    cache = f"/tmp/sbv_k256_batch_{n}.npz"
+    if os.path.exists(cache):
+        z = np.load(cache)
+        tuples, expect = z["tuples"], z["expect"]
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import hostlib
+        h = hostlib.load()
+        tuples = np.zeros(n * 160, dtype=np.uint8)
+        expect = np.zeros((n + 7) // 8, dtype=np.uint8)
+        h.sbvh_k256_gen_batch(SEED, n, 1024, 8, tuples.ctypes.data, expect.ctypes.data, os.cpu_count() or 1)
+        try:
+            np.savez(cache, tuples=tuples, expect=expect)
+        except Exception:
+            pass
+    d_t = torch.from_numpy(tuples).cuda()
+    d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
+    sbv.secp256k1_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sbv.secp256k1_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "ECDSA secp256k1 verifies/sec, one lane per signature", "value": n * steps / dt, "unit": "verifies/s", "tuples": n,
+            "ms_per_step": 1e3 * dt / steps, "bitmap_correct": bool((d_b.cpu().numpy() == expect).all()),
+            "algorithmic_GBps": 160.125 * n * steps / dt / 1e9}
+
+
 def leg_m2(tuples, n):
     """BASELINE.json's second metric — commit-quorum latency at N = 16 (Q = 11): wall time from "15 commit signatures in
     host memory" to ">= 10 accepted" (SURVEY.md §8d M2).  (a) gpu: the 15 concurrent VerifyConsenterSig calls of
@@ -414,6 +447,7 @@ def main():
                          ("end_to_end", lambda: leg_end_to_end(sbv, tuples, valid, n, max(2, args.steps // 2))),
                          ("sharded_entry", lambda: leg_sharded(sbv, tuples, valid, n, max(2, args.steps // 2))),
                          ("ed25519", lambda: leg_ed25519(sbv, torch, n, max(2, args.steps // 2), stream)),
+                         ("secp256k1", lambda: leg_secp256k1(sbv, torch, min(n, 1 << 18), max(2, args.steps // 2), stream)),
                          ("m2_commit_quorum_us", lambda: leg_m2(tuples, n))):
             try:
                 extra[name] = fn()

@@ -260,13 +260,14 @@ SBV_HD bool k256_verify_lane(const Scratch& s, size_t i, u32* qtab, const kapt* 
 
 // ---- the comb of G, built on the host (or by the emulator): one call per window ------------------------------------------------
 // row[m - 1] = m * 2^(16 j) * G, m = 1..count: a Jacobian chain normalised in chunks with Montgomery's trick
-SBV_HD void k256_build_g_window(int j, kapt* row, int count) {
+// (bits = window width: 16 for the device comb; the host signer uses an 8-bit comb of the same shape)
+SBV_HD void k256_build_g_window_bits(int bits, int j, kapt* row, int count) {
     kjpt B;
     kfe_from_words(B.X, k256_gx_words());
     kfe_from_words(B.Y, k256_gy_words());
     B.Z = kfe_one();
     B.inf = false;
-    for (int d = 0; d < 16 * j; ++d) kpt_dbl(B, B);
+    for (int d = 0; d < bits * j; ++d) kpt_dbl(B, B);
     kfe bx, by;
     {   // base -> affine
         kfe zi, zi2, zi3;
@@ -304,5 +305,6 @@ SBV_HD void k256_build_g_window(int j, kapt* row, int count) {
         }
     }
 }
+SBV_HD void k256_build_g_window(int j, kapt* row, int count) { k256_build_g_window_bits(16, j, row, count); }
 
 }  // namespace sbv

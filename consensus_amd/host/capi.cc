@@ -11,6 +11,7 @@
 
 #include "p256_host.h"
 #include "ed25519_host.h"
+#include "k256_host.h"
 #include "chain_emul.h"
 #include "verifier.h"
 
@@ -224,6 +225,64 @@ void sbvh_ed25519_gen_batch(uint32_t seed, size_t n, size_t nkeys, unsigned inva
                 memcpy(t128, sig, 64);
                 memcpy(t128 + 64, pk, 32);
                 ed25519_hram(sig, pk, msg, 32, t128 + 96);
+                if (expect && valid) expect[i >> 3] |= (uint8_t)(1u << (i & 7));
+            }
+        });
+    }
+    for (auto& x : th) x.join();
+}
+
+// Synthetic secp256k1 batch for bench.py / tools (160-byte tuples r | s | hash | Qx | Qy): nkeys key pairs from the host Signer's
+// key derivation, tuple i = RFC 6979 signature by key i % nkeys over SHA-256 of a 32-byte counter message; every
+// invalid_every-th tuple has one pseudo-random bit of its 1280 flipped.  expect = 1 for untouched tuples, 0 for flipped ones
+// (a single flipped bit of a valid ECDSA tuple is accepted with probability ~2^-128; tests/test_datagen.py checks the whole
+// batch against the oracle).
+void sbvh_k256_gen_batch(uint32_t seed, size_t n, size_t nkeys, unsigned invalid_every, uint8_t* tuples, uint8_t* expect, int threads) {
+    std::vector<uint8_t> sks(32 * nkeys), pks(64 * nkeys);
+    for (size_t i = 0; i < nkeys; ++i) {
+        uint8_t lbl[24];
+        memcpy(lbl, "sbv-k256-key", 12);
+        lbl[12] = (uint8_t)(seed >> 24); lbl[13] = (uint8_t)(seed >> 16); lbl[14] = (uint8_t)(seed >> 8); lbl[15] = (uint8_t)seed;
+        for (int b = 0; b < 8; ++b) lbl[16 + b] = (uint8_t)((uint64_t)i >> (56 - 8 * b));
+        for (uint8_t ctr = 0;; ++ctr) {          // a SHA-256 output is a valid scalar except with probability 2^-128
+            lbl[11] = (uint8_t)('y' + ctr);
+            sha256(lbl, 24, &sks[32 * i]);
+            if (k256_pubkey_from_private(&sks[32 * i], &pks[64 * i])) break;
+        }
+    }
+    if (expect) memset(expect, 0, (n + 7) / 8);
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    const size_t per = ((n + threads - 1) / threads + 7) & ~(size_t)7;      // whole bitmap bytes per thread
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) {
+        const size_t lo = (size_t)t * per, hi = lo + per < n ? lo + per : n;
+        if (lo >= n) break;
+        th.emplace_back([=, &sks, &pks] {
+            for (size_t i = lo; i < hi; ++i) {
+                uint8_t msg[32], h[32], rs[64];
+                memset(msg, 0, 32);
+                memcpy(msg, "sbv-k256-msg", 12);
+                msg[12] = (uint8_t)(seed >> 24); msg[13] = (uint8_t)(seed >> 16); msg[14] = (uint8_t)(seed >> 8); msg[15] = (uint8_t)seed;
+                for (int b = 0; b < 8; ++b) msg[24 + b] = (uint8_t)((uint64_t)i >> (56 - 8 * b));
+                sha256(msg, 32, h);
+                const size_t key = i % nkeys;
+                k256_sign_rfc6979(&sks[32 * key], h, rs);
+                uint8_t* t160 = tuples + 160 * i;
+                memcpy(t160, rs, 64);
+                memcpy(t160 + 64, h, 32);
+                memcpy(t160 + 96, &pks[64 * key], 64);
+                bool valid = true;
+                if (invalid_every && (i % invalid_every) == invalid_every - 1) {
+                    uint8_t lbl[24], sel[32];
+                    memcpy(lbl, "sbv-k256-flip", 13);
+                    for (int b = 0; b < 8; ++b) lbl[13 + b] = (uint8_t)((uint64_t)i >> (56 - 8 * b));
+                    lbl[21] = (uint8_t)(seed >> 16); lbl[22] = (uint8_t)(seed >> 8); lbl[23] = (uint8_t)seed;
+                    sha256(lbl, 24, sel);
+                    const unsigned bit = (((unsigned)sel[0] << 8) | sel[1]) % 1280u;
+                    t160[bit >> 3] ^= (uint8_t)(1u << (bit & 7));
+                    valid = false;
+                }
                 if (expect && valid) expect[i >> 3] |= (uint8_t)(1u << (i & 7));
             }
         });

@@ -5,6 +5,9 @@
 
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "../csrc/k256_core.h"
 #include "p256_host.h"
 
@@ -22,16 +25,30 @@ void to_be32(uint8_t out[32], const u256& v) {
 }
 bool valid_scalar(const u256& d) { return !is_zero256(d) && lt256(d, k256_n_words()); }
 
-// affine k * G, k in [1, n - 1]: plain double-and-add on the device's point layer (every addition exact)
+// 8-bit signed comb of G for the signer: 33 windows x 128 entries (270 KB), built once
+const kapt* gtable8() {
+    static std::vector<kapt> tab;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        tab.resize((size_t)33 * 128);
+        for (int j = 0; j < 33; ++j) k256_build_g_window_bits(8, j, tab.data() + (size_t)j * 128, j == 32 ? 1 : 128);
+    });
+    return tab.data();
+}
+
+// affine k * G, k in [1, n - 1]: 33 exact mixed additions from the comb (k + 0x80..80: byte j minus 128 is the digit of window j)
 void base_mul_affine(const u256& k, u256& x, u256& y) {
-    kfe gx, gy;
-    kfe_from_words(gx, k256_gx_words());
-    kfe_from_words(gy, k256_gy_words());
+    const kapt* gt = gtable8();
+    u256 kk;
+    const u32 top = add_const_limbs(kk, k, 0x80808080u);
     kjpt R;
     kpt_set_inf(R);
-    for (int bit = 255; bit >= 0; --bit) {
-        kpt_dbl(R, R);
-        kpt_madd(R, R, gx, gy, false, ((k.v[bit >> 5] >> (bit & 31)) & 1) == 0);
+    for (int j = 0; j < 33; ++j) {
+        int idx; bool neg, skip;
+        comb_digit(kk, top, j, idx, neg, skip);
+        kfe ex, ey;
+        kapt_load(ex, ey, gt + (size_t)j * 128 + idx);
+        kpt_madd(R, R, ex, ey, neg, skip);
     }
     kfe zi, zi2, zi3, ax, ay;
     kfe_inv(zi, R.Z);

@@ -34,6 +34,8 @@ def load():
     lib.sbvh_signer_new_scheme.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p]
     lib.sbvh_ed25519_gen_batch.argtypes = [ctypes.c_uint32, S, S, ctypes.c_uint, V, V, ctypes.c_int]
     lib.sbvh_ed25519_gen_batch.restype = None
+    lib.sbvh_k256_gen_batch.argtypes = [ctypes.c_uint32, S, S, ctypes.c_uint, V, V, ctypes.c_int]
+    lib.sbvh_k256_gen_batch.restype = None
     lib.sbvh_verifier_free.argtypes = [V]
     lib.sbvh_register_consenter.argtypes = [V, ctypes.c_uint64, ctypes.c_char_p]
     lib.sbvh_register_client.argtypes = [V, ctypes.c_char_p, ctypes.c_char_p]
