@@ -433,3 +433,30 @@ def test_persistent_key_table_cache_on_gpu(gpu, oracle):
     finally:
         gpu.key_cache(False)
         gpu.key_cache(True, 4096)
+
+
+def test_key_sorted_list_and_compaction_order_give_the_same_bitmap():
+    """The grouped step with the key-sorted list (default) and with the split's compaction order (SBV_GROUP_SORT=0, the
+    first half of round 2's pipeline) on the same 2^18-tuple batch: both equal the generator's verdicts.  The switch is
+    read at sbv_init, hence the child processes."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import consensus_amd as sbv, synth
+sbv.init(0)
+sbv.key_cache(False)
+n = 1 << 18
+t, valid = synth.gen_batch(0x50E7ED, n, 256, 8)
+for _ in range(2):
+    assert sbv.verify_batch(t.tobytes(), n) == valid.tobytes()
+groups, grouped, ungrouped, rejected = sbv.last_group_stats()
+assert 250 <= groups <= 256 and grouped + ungrouped + rejected == n and grouped > n * 9 // 10
+print("sorted=%s ok" % os.environ.get("SBV_GROUP_SORT", "1"))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sort in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SBV_GROUP_SORT=sort), capture_output=True, text=True,
+                             timeout=300, cwd=root)
+        assert out.returncode == 0 and "sorted=%s ok" % sort in out.stdout, out.stdout + out.stderr
