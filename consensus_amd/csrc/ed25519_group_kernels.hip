@@ -126,7 +126,7 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     const unsigned gn = (unsigned)((n + 255) / 256);
     const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
     hipLaunchKernelGGL(k_ed_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
-    hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, n, g);
+    hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g, KeyCache{});
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
     if (g.sorted) {

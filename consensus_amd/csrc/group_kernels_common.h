@@ -12,9 +12,11 @@ __device__ __forceinline__ u32 group_count(const GroupState& g) {
     return c < g.max_groups ? c : g.max_groups;
 }
 
-static __global__ __launch_bounds__(256) void k_group_assign(size_t n, GroupState g) {
+// kc: the persistent key-table cache (P-256; kc.enabled = 0 for Ed25519 and when the cache is off): cached keys are grouped
+// whatever their count in this batch
+static __global__ __launch_bounds__(256) void k_group_assign(const uint8_t* __restrict__ tuples, size_t n, GroupState g, KeyCache kc) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) group_assign_lane(i, g);
+    if (i < n) group_assign_lane(tuples, i, g, kc);
 }
 
 static __global__ __launch_bounds__(256) void k_pack_bitmap(const uint8_t* __restrict__ acc, size_t n, uint8_t* __restrict__ bitmap) {

@@ -153,6 +153,10 @@ SBV_HD void prep_chunk29(TupleWords words, size_t n, const Scratch& sc_, size_t 
     const fe p_ = fe_p();
     const fe29 one = s29_one();
     fe29 acc = one;
+    // With per-tuple records (Scratch::rec: the key-sorted grouped step) NOTHING goes to the limb-major planes: every reader of
+    // that step takes u1 | u2 | r | ok from the record and the public key from the tuple itself, and the values parked between
+    // the two passes live in the record too (197 bytes written per tuple instead of 384).
+    const bool rec_only = sc_.rec != nullptr;
     for (int k = 0; k < T; ++k) {
         const size_t idx = first + (size_t)k * step;
         auto w = words(k, idx);
@@ -174,14 +178,22 @@ SBV_HD void prep_chunk29(TupleWords words, size_t n, const Scratch& sc_, size_t 
             f29_select(sM, ok, sM, one);       // keep the product chain invertible
             u256 tw;
             s29_store_canon(tw, acc);          // exclusive prefix product
-            soa_store(sc_.u1, sc_.cap, idx, tw);
-            s29_store_canon(tw, sM);
-            soa_store(sc_.sm, sc_.cap, idx, tw);
-            soa_store(sc_.u2, sc_.cap, idx, e);
-            soa_store(sc_.r, sc_.cap, idx, r);
-            if (HAS_Q) {
-                soa_store(sc_.qx, sc_.cap, idx, qx);
-                soa_store(sc_.qy, sc_.cap, idx, qy);
+            if (rec_only) {                    // parked in the tuple's own record: prefix | e | r | s (Montgomery)
+                rec_store256(sc_.rec, idx, SBV_REC_U1, tw.v);
+                s29_store_canon(tw, sM);
+                rec_store256(sc_.rec, idx, SBV_REC_OK, tw.v);
+                rec_store256(sc_.rec, idx, SBV_REC_U2, e.v);
+                rec_store256(sc_.rec, idx, SBV_REC_R, r.v);
+            } else {
+                soa_store(sc_.u1, sc_.cap, idx, tw);
+                s29_store_canon(tw, sM);
+                soa_store(sc_.sm, sc_.cap, idx, tw);
+                soa_store(sc_.u2, sc_.cap, idx, e);
+                soa_store(sc_.r, sc_.cap, idx, r);
+                if (HAS_Q) {
+                    soa_store(sc_.qx, sc_.cap, idx, qx);
+                    soa_store(sc_.qy, sc_.cap, idx, qy);
+                }
             }
             sc_.ok[idx] = ok ? 1 : 0;
             s29_mul(acc, acc, sM);
@@ -194,27 +206,36 @@ SBV_HD void prep_chunk29(TupleWords words, size_t n, const Scratch& sc_, size_t 
         if (idx >= n) continue;
         u256 tw, e, r;
         fe29 pre, sM, w, eL, rL, u;
-        soa_load(tw, sc_.u1, sc_.cap, idx);
-        f29_unpack(pre, tw.v);
-        soa_load(tw, sc_.sm, sc_.cap, idx);
-        f29_unpack(sM, tw.v);
-        soa_load(e, sc_.u2, sc_.cap, idx);
-        soa_load(r, sc_.r, sc_.cap, idx);
+        if (rec_only) {
+            rec_load256(tw, sc_.rec, idx, SBV_REC_U1);
+            f29_unpack(pre, tw.v);
+            rec_load256(tw, sc_.rec, idx, SBV_REC_OK);
+            f29_unpack(sM, tw.v);
+            rec_load256(e, sc_.rec, idx, SBV_REC_U2);
+            rec_load256(r, sc_.rec, idx, SBV_REC_R);
+        } else {
+            soa_load(tw, sc_.u1, sc_.cap, idx);
+            f29_unpack(pre, tw.v);
+            soa_load(tw, sc_.sm, sc_.cap, idx);
+            f29_unpack(sM, tw.v);
+            soa_load(e, sc_.u2, sc_.cap, idx);
+            soa_load(r, sc_.r, sc_.cap, idx);
+        }
         f29_unpack(eL, e.v);
         f29_unpack(rL, r.v);
         s29_mul(w, inv, pre);                  // s_k^-1 (Montgomery)
         s29_mul(inv, inv, sM);                 // drop s_k from the running inverse
         s29_mul(u, w, eL);                     // Montgomery(w) * plain(e) = plain(e * w)
         s29_store_canon(tw, u);
-        soa_store(sc_.u1, sc_.cap, idx, tw);
-        if (sc_.rec) rec_store256(sc_.rec, idx, SBV_REC_U1, tw.v);
+        if (rec_only) rec_store256(sc_.rec, idx, SBV_REC_U1, tw.v);
+        else soa_store(sc_.u1, sc_.cap, idx, tw);
         s29_mul(u, w, rL);
         s29_store_canon(tw, u);
-        soa_store(sc_.u2, sc_.cap, idx, tw);
-        if (sc_.rec) {
+        if (rec_only) {                        // r is already in its place
             rec_store256(sc_.rec, idx, SBV_REC_U2, tw.v);
-            rec_store256(sc_.rec, idx, SBV_REC_R, r.v);
             sc_.rec[idx * SBV_REC_WORDS + SBV_REC_OK] = sc_.ok[idx];
+        } else {
+            soa_store(sc_.u2, sc_.cap, idx, tw);
         }
     }
 }

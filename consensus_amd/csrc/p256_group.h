@@ -143,15 +143,6 @@ SBV_HD void group_insert_lane_t(const uint8_t* tuples, size_t i, const GroupStat
 }
 SBV_HD void group_insert_lane(const uint8_t* tuples, size_t i, const GroupState& g) { group_insert_lane_t<160, 96, 16>(tuples, i, g); }
 
-SBV_HD void group_assign_lane(size_t i, const GroupState& g) {
-    u32 s = SBV_GROUP_NONE;
-    if (g.rep[i] == (u32)i && g.cnt[i] >= g.min_samples) {
-        const u32 got = SBV_ATOMIC_ADD(&g.counters[0], 1u);
-        if (got < g.max_groups) { s = got; g.group_rep[got] = (u32)i; }
-    }
-    g.slot_of[i] = s;
-}
-
 // Ungrouped tuples whose key pointFromAffine refuses are rejected here and never reach the generic
 // kernel (crypto/ecdsa returns false before any scalar multiplication, too): in a SIMT kernel an early
 // exit only pays when whole wavefronts take it, so the filter has to sit in front of the compaction.
@@ -279,6 +270,34 @@ SBV_HD u32 key_cache_insert(const KeyCache& kc, const u32 w[16]) {
     }
     return slot;
 }
+// A representative takes a table slot when its key is used often enough in THIS batch — or when the persistent cache already
+// holds its comb (kc.enabled; P-256 only), however few of its signatures the batch carries: a warm key costs nothing to
+// "build", so even a batch of a few thousand tuples then runs the comb phases instead of 256 doublings per signature.
+// The lookup is read-only (everything in the cache was inserted by earlier batches) and runs for the representatives below
+// the threshold only.
+SBV_HD void group_assign_lane(const uint8_t* tuples, size_t i, const GroupState& g, const KeyCache& kc) {
+    u32 s = SBV_GROUP_NONE;
+    if (g.rep[i] == (u32)i) {
+        bool take = g.cnt[i] >= g.min_samples;
+        if (!take && kc.enabled) {
+            u32 w[16];
+            const u32* k = tuple_key_words(tuples, i);
+            SBV_UNROLL
+            for (int j = 0; j < 16; ++j) w[j] = k[j];
+            take = key_cache_lookup(kc, w) != SBV_GROUP_NONE;
+        }
+        if (take) {
+            const u32 got = SBV_ATOMIC_ADD(&g.counters[0], 1u);
+            if (got < g.max_groups) { s = got; g.group_rep[got] = (u32)i; }
+        }
+    }
+    g.slot_of[i] = s;
+}
+SBV_HD void group_assign_lane(size_t i, const GroupState& g) {
+    KeyCache off = {};
+    group_assign_lane(nullptr, i, g, off);
+}
+
 SBV_HD void key_cache_group_key(const uint8_t* tuples, const GroupState& g, u32 gidx, u32 w[16]) {
     const u32* k = tuple_key_words(tuples, g.group_rep[gidx]);
     SBV_UNROLL

@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void k_group_keycheck(const uint8_t* __restric
 }
 
 // ---- per-batch key tables on the carry-free field (p256_keytab29.h) -----------------------------------------------------
-// tmp layout (u32 words): [0, G * BASES_TMP) private strips of the bases kernel; behind it one strip of
-// SBV_KT29_WINDOW_TMP words per (key, window), shared by the rows and the fill kernel (same stream, never concurrent).
+// tmp layout (u32 words): one strip of SBV_KT29_WINDOW_TMP words per (key, window), shared by the rows and the fill kernel
+// (same stream, never concurrent).
 #define SBV_KT29_WINDOW_TMP (7 * SBV_KT29_FILL_TMP_WORDS)
 // Every group of the batch finds its table slot (p256_group.h: persistent key-table cache), in two small launches of
 // 64-lane workgroups.  k_key_cache_lookup is read-only: everything in the table was inserted by earlier batches, i.e. by
@@ -115,27 +115,49 @@ static __device__ __forceinline__ void table_prio() {
 #endif
 }
 
-__global__ __launch_bounds__(64) void k_keytab29_bases(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jstate,
-                                                       apt* __restrict__ bases, u32* __restrict__ tmp, uint8_t* __restrict__ valid,
+// Exchange policy of the chain on the device: one lane of a quad; a value of lane `src` of the quad reaches all four lanes
+// by DPP quad_perm (v_mov_b32_dpp, a full-rate register move; control = the source lane in all four 2-bit fields).
+struct keychain_quad_dev {
+    static const int N = 1;
+    kchain s[1];
+    int r;
+    __device__ __forceinline__ int role(int) const { return r; }
+    __device__ __forceinline__ void bcast(fe29 out[1], const fe29 in[1], int src) const {
+        SBV_UNROLL
+        for (int l = 0; l < 9; ++l) {
+            const int v = in[0].v[l];
+            out[0].v[l] = src == 0 ? __builtin_amdgcn_mov_dpp(v, 0x00, 0xF, 0xF, true)
+                        : src == 1 ? __builtin_amdgcn_mov_dpp(v, 0x55, 0xF, 0xF, true)
+                                   : __builtin_amdgcn_mov_dpp(v, 0xAA, 0xF, 0xF, true);
+        }
+    }
+};
+// lanes = groups x 4 (p256_keytab29.h: keychain29_run); a quad lives or exits as a whole
+__global__ __launch_bounds__(64) void k_keytab29_chain(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jstate,
+                                                       u32* __restrict__ bases, uint8_t* __restrict__ valid,
                                                        const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
                                                        int j_first, int j_last) {
-    const u32 k = blockIdx.x * 64 + threadIdx.x;
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 k = lane >> 2;
     if (k >= group_count(g) || !cold[k]) return;
     table_prio();
-    keytab29_bases_lane(tuples, k, g, jstate, bases, tmp + (size_t)k * SBV_KT29_BASES_TMP_WORDS, valid + tslot[k], j_first, j_last);
+    keychain_quad_dev q;
+    q.r = (int)(lane & 3u);
+    keychain29_run(q, tuples, k, g, jstate, bases, valid + tslot[k], j_first, j_last);
 }
 // lanes = groups x j_count x 2
-__global__ __launch_bounds__(64) void k_keytab29_rows(GroupState g, const apt* __restrict__ bases, u32* __restrict__ tmp,
+__global__ __launch_bounds__(64, 2) void k_keytab29_rows(GroupState g, const u32* __restrict__ bases, u32* __restrict__ tmp,
                                                       apt* __restrict__ ktab, const u32* __restrict__ tslot,
                                                       const uint8_t* __restrict__ cold, int j_first, int j_count) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;
     const u32 which = lane & 1u, kw = lane >> 1;
     const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
     if (key >= group_count(g) || !cold[key]) return;
+    if (which == 1 && j == SBV_GTAB_WINDOWS - 1) return;          // the top window has no giants
     table_prio();
     const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
-    u32* t = tmp + (size_t)g.max_groups * SBV_KT29_BASES_TMP_WORDS + w * SBV_KT29_WINDOW_TMP + (size_t)which * SBV_KT29_ROWS_TMP_WORDS;
-    keytab29_rows_lane(bases + w * SBV_KT29_POINTS_PER_WINDOW, (int)which, j == SBV_GTAB_WINDOWS - 1, t,
+    u32* t = tmp + w * SBV_KT29_WINDOW_TMP + (size_t)which * SBV_KT29_ROWS_TMP_WORDS;
+    keytab29_rows_lane(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), (int)which, j == SBV_GTAB_WINDOWS - 1, t,
                        ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
 }
 // lanes = groups x j_count x lanes_per_window, each lane rows_per_lane of the 7 rows 16 a + b, a = 1..7
@@ -152,7 +174,7 @@ __global__ __launch_bounds__(64) void k_keytab29_fill(GroupState g, u32* __restr
     if (a_first > 7) return;
     table_prio();
     const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
-    u32* t = tmp + (size_t)g.max_groups * SBV_KT29_BASES_TMP_WORDS + w * SBV_KT29_WINDOW_TMP + (size_t)r * SBV_KT29_FILL_TMP_WORDS;
+    u32* t = tmp + w * SBV_KT29_WINDOW_TMP + (size_t)r * SBV_KT29_FILL_TMP_WORDS;
     keytab29_fill_lane(a_first, a_last, t, ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
 }
 
@@ -161,7 +183,7 @@ __global__ __launch_bounds__(64) void k_keytab29_fill(GroupState g, u32* __restr
 // tuples, so it has to start as early as possible and run BESIDE the throughput work, at the same
 // 3 waves/SIMD register budget (on its own stream it ran at 234 VGPRs and squeezed the kernel it
 // overlapped down to one wave per SIMD).  Remaining blocks: u1 * G for every tuple of the batch.
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_gphase_generic(Scratch s, size_t n, GroupState g, u32* __restrict__ qtab,
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_gphase_generic(const uint8_t* __restrict__ tuples, Scratch s, size_t n, GroupState g, u32* __restrict__ qtab,
                                                                        const apt* __restrict__ g16, gcomb g16r,
                                                                        u32* __restrict__ gacc, uint8_t* __restrict__ acc,
                                                                        unsigned generic_blocks, size_t first, size_t end) {
@@ -169,7 +191,9 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_gphase_g
         const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
         if (L >= g.counters[2]) return;
         const u32 t = g.ung_idx[L];
-        acc[t] = verify29_lane_generic(s, t, qtab + (size_t)L * SBV_QTAB29_WORDS, g16r) ? 1 : 0;
+        const bool v = s.rec ? verify29_lane_generic_rec(s, tuples, t, qtab + (size_t)L * SBV_QTAB29_WORDS, g16r)
+                             : verify29_lane_generic(s, t, qtab + (size_t)L * SBV_QTAB29_WORDS, g16r);
+        acc[t] = v ? 1 : 0;
         return;
     }
     if (group_count(g) == 0) return;            // no key repeats often enough (e.g. all-distinct keys): nothing will read gacc
@@ -231,7 +255,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_verify_k
 //   stream: [prep] wait(split) { generic stage B over the ungrouped list + G phase } wait(tables c) Q-phase chunk c ... pack
 //   side_a: insert assign | bases chunk 0 | bases chunk 1 | ...
 //   side_b:        wait(assign) split | wait(bases c) windows chunk c ...
-hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b,
+hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_in, size_t n, const GroupBuffers& b,
                                       u32* d_qtab, const apt* d_g16, const gcomb& d_g16r, uint8_t* d_bitmap, hipStream_t stream,
                                       const GroupSync& y, hipEvent_t after_prep, hipEvent_t* prof, int* prof_pairs) {
     if (n == 0) return hipSuccess;
@@ -242,7 +266,10 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
     g.gcount = b.gcount; g.gcursor = b.gcount ? b.gcount + b.max_groups : nullptr; g.grp_of = b.grp_of; g.ung_cand = b.ung_cand;
     // key-sorted grouped list: needs the per-tuple records of stage A, one LDS word per group, and an unsliced G phase
     const size_t sort_lds = (size_t)b.max_groups * sizeof(u32);
-    g.sorted = y.sorted && s.rec && b.gcount && b.grp_of && b.ung_cand && sort_lds <= 64 * 1024 && !y.side_c && y.slices <= 1 ? 1u : 0u;
+    g.sorted = y.sorted && s_in.rec && b.gcount && b.grp_of && b.ung_cand && sort_lds <= 64 * 1024 && !y.side_c && y.slices <= 1 ? 1u : 0u;
+    // Stage A writes EITHER the per-tuple records (key-sorted step: every reader takes them) OR the limb-major planes
+    Scratch s = s_in;
+    if (!g.sorted) s.rec = nullptr;
     group_set_threshold(g, b.min_count);
     const int chunks = y.chunks < 1 ? 1 : (y.chunks > SBV_GROUP_MAX_CHUNKS ? SBV_GROUP_MAX_CHUNKS : y.chunks);
     int rows_per_lane = 1;                         // rows of 16 entries one lane of the fill kernel builds (1, 2, 4 or 7)
@@ -259,7 +286,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
     const unsigned gn = (unsigned)((n + 255) / 256);
     const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
     hipLaunchKernelGGL(k_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
-    hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, n, g);
+    hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g, b.kc);
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
     hipLaunchKernelGGL(k_key_cache_lookup, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.kc, b.tslot, b.cold);
     hipLaunchKernelGGL(k_key_cache_insert, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.kc, b.tslot);
@@ -303,7 +330,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
         // the G phase reads counters[0] (group_count): it may not start before side_a's memset / insert / assign
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
         if (after_prep) SBV_TRY(hipEventRecord(after_prep, stream));
-        hipLaunchKernelGGL(k_gphase_generic, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, 0u,
+        hipLaunchKernelGGL(k_gphase_generic, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, 0u,
                            (size_t)0, n);
     } else {
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_assign, 0));          // group_count() is final after the assignment
@@ -320,7 +347,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
                 gen_blocks = gv;
             }
             const unsigned gb = (unsigned)((end - first + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
-            hipLaunchKernelGGL(k_gphase_generic, dim3(gen_blocks + gb), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, g, d_qtab, d_g16, d_g16r,
+            hipLaunchKernelGGL(k_gphase_generic, dim3(gen_blocks + gb), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r,
                                b.gacc, b.acc, gen_blocks, first, end);
         }
     }
@@ -328,7 +355,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s,
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [j_first, j_end)
         const int j_count = j_end - j_first;
-        hipLaunchKernelGGL(k_keytab29_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases, b.tmp,
+        hipLaunchKernelGGL(k_keytab29_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases,
                            b.kvalid, b.tslot, b.cold, j_first, j_end - 1);
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
         SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[c], 0));

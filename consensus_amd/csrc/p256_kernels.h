@@ -36,7 +36,7 @@ struct GroupBuffers {
     u32 *rep = nullptr, *cnt = nullptr, *slot_of = nullptr, *group_rep = nullptr, *counters = nullptr, *grp_idx = nullptr,
         *ung_idx = nullptr, *slots = nullptr;
     u32* jbases = nullptr;      // (Ed25519 grouped step) [max_groups][33] window bases
-    apt* bases = nullptr;       // [max_groups][33][2] affine B_j = 2^(8j) Q and 16 B_j (p256_keytab29.h)
+    u32* bases = nullptr;       // [max_groups][33][2] chain records of 36 words: B_j = 2^(8j) Q and 16 B_j, modified Jacobian (p256_keytab29.h)
     u32* jstate = nullptr;      // [max_groups][27] the doubling chain between chunks of windows
     apt* ktab = nullptr; uint8_t* kvalid = nullptr; u32* tmp = nullptr; uint8_t* acc = nullptr;
     KeyCache kc = {};           // persistent key-table cache: slots [0, kc.cap) of ktab / kvalid; [kc.cap, kc.cap + max_groups) = per batch

@@ -24,8 +24,6 @@
 namespace sbv {
 
 #define SBV_KT29_POINTS_PER_WINDOW 2                       // bases buffer: B_j and 16 B_j
-#define SBV_KT29_STATE_WORDS 27                            // running Jacobian point between chunks (X, Y, Z limbs)
-#define SBV_KT29_BASES_TMP_WORDS (66 * 36)                 // per key: up to 66 recorded points x (X, Y, Z, prefix product)
 #define SBV_KT29_ROWS_TMP_WORDS (15 * 45)                  // per lane of the rows kernel: 15 points x (X, Y, ZZ, ZZZ, prefix)
 #define SBV_KT29_FILL_TMP_WORDS (15 * 4 * 9)               // per lane of the fill kernel: up to 4 rows x 15 prefix products
 
@@ -47,92 +45,255 @@ SBV_HD void apt29_store_canon(apt* dst, const apt29& a) {
     for (int k = 0; k < 4; ++k) { q4 v = {w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]}; d[k] = v; }
 }
 
-// ---- bases -------------------------------------------------------------------------------------------------------------
-// bases[(gidx * 33 + j) * 2 + {0, 1}] = B_j, 16 B_j (affine, canonical).  jstate[gidx * 27 ..]: the chain between chunks
-// (16 B_{j_last} after a chunk).  tmp: SBV_KT29_BASES_TMP_WORDS private words.
-// valid: the byte of this key's TABLE SLOT (written by the first chunk)
-SBV_HD void keytab29_bases_lane(const uint8_t* tuples, u32 gidx, const GroupState& g, u32* jstate, apt* bases, u32* tmp,
-                                uint8_t* valid, int j_first, int j_last) {
-    jpt29 t;
+// ---- chain -------------------------------------------------------------------------------------------------------------
+// The doubling chain 2^(8j) Q is the one serial dependency of a fresh key: 256 doublings, nothing to overlap inside one lane.
+// FOUR lanes (one quad) share a key and split every doubling at the level of the group-law formula, in modified Jacobian
+// coordinates (X : Y : Z : T = a Z^4; Cohen-Miyaji-Ono), whose 4M + 4S doubling is only THREE products deep:
+//   level 1   XX = X^2            | YY = Y^2           | YZ = Y Z
+//   level 2   AA = A^2, A = 2 YY  | XA = X A           | MM = M^2, M = 3 XX + T
+//   level 3   M (S - X3) - U      | U T                                 with S = 2 XA, U = 2 AA, X3 = MM - 2 S
+//   X3, Y3 = level 3 left, Z3 = 2 YZ, T3 = 2 U T
+// Every lane holds the whole state; at each level lane r of the quad runs product r (lane 3 repeats lane 2's: the wavefront is
+// SIMD, an idle lane costs the same), and the results travel by DPP quad_perm broadcasts — full-rate register moves, no LDS.
+// One doubling is 3 x (81 + 59) multiply-accumulates per lane instead of the 3M + 5S = 8 products of pt29_dbl_jac in a row.
+// The level functions below are plain per-lane code; keychain29_dbl<QX> strings them together through an exchange policy:
+// on the device QX is one lane + DPP (p256_group_kernels.hip), in tests/emul it is four lanes stepped in lockstep.
+//
+// Bounds (units of p; "vr" = value-reduced as f29_red_q / f29_norm_red leave a value: within (-0.01, 1.01), limbs 0..7
+// within 2^27 of [0, 2^29)): state X, Y, Z, T vr.  Level 1 products of two vr values, reduced with the 32-bit multiplier:
+// within +-4.1, then f29_red_q -> vr.  A = 2 YY <= 2.02, M = 3 XX + T <= 4.04 (both re-normalised limb-wise), so
+// |A||B| <= 16.4 at level 2 and AA, XA, MM lie within +-4.6 with exact 29-bit limbs 0..7.  X3 = MM - 4 XA within +-23
+// -> f29_norm_red -> vr.  Level 3: M (S - X3) with |S - X3| <= 10.2: |A||B| <= 41.3 (the contract allows 64), minus
+// U = 2 AA (+-9.2) in the column domain: within +-15 -> f29_red_q -> vr; U T: |A||B| <= 9.3.  tests/emul runs all of it
+// under SBV_F29_CHECK.
+struct kchain { fe29 X, Y, Z, T; };
+#define SBV_KT29_REC_WORDS 36                              // one recorded point: X, Y, Z, T raw limbs
+#define SBV_KT29_STATE_WORDS 36                            // the running point between chunks
+
+SBV_HD void f29_pick(fe29& r, bool c, const fe29& a, const fe29& b) { f29_select(r, c, a, b); }
+
+// level 1: role 0 -> X X, role 1 -> Y Y, roles 2, 3 -> Y Z
+SBV_HD void keychain29_l1(fe29& P1, const kchain& s, int role) {
+    fe29 a, b, t;
+    f29_pick(a, role == 0, s.X, s.Y);
+    f29_pick(t, role == 1, s.Y, s.Z);
+    f29_pick(b, role == 0, s.X, t);
+    f29_mulx(P1, a, b);
+    f29_red_q(P1);
+}
+// after the exchange every lane holds XX, YY, YZ (vr).  M and Z3 are the same in every lane.
+SBV_HD void keychain29_l2(fe29& P2, fe29& M, fe29& Z3, const kchain& s, const fe29& XX, const fe29& YY, const fe29& YZ, int role) {
+    fe29 A, t, a, b;
+    f29_add(A, YY, YY);
+    f29_norm(A, A);                               // A = 2 YY
+    f29_add(t, XX, XX);
+    f29_add(t, t, XX);
+    f29_norm(t, t);
+    f29_add(t, t, s.T);
+    f29_norm(M, t);                               // M = 3 XX + T
+    f29_add(t, YZ, YZ);
+    f29_norm_red(Z3, t);                          // Z3 = 2 Y Z
+    f29_pick(t, role == 1, s.X, M);
+    f29_pick(a, role == 0, A, t);                 // A | X | M
+    f29_pick(b, role < 2, A, M);                  // A | A | M
+    f29_mulx(P2, a, b);
+}
+// after the exchange every lane holds AA, XA, MM (reduce_x outputs: limbs 0..7 exact).  X3 is the same in every lane.
+// P3: role 0 (and 2, 3) -> Y3 = M (S - X3) - U, role 1 -> U T (T3 = 2 U T).
+SBV_HD void keychain29_l3(fe29& P3, fe29& X3, const kchain& s, const fe29& M, const fe29& AA, const fe29& XA, const fe29& MM, int role) {
+    fe29 S, U, t, a, b, V;
+    f29_add(S, XA, XA);                           // S = 2 XA, limbs < 2^30
+    f29_sub(t, MM, S);
+    f29_sub(t, t, S);                             // limbs within (-2^31, 2^29)
+    f29_norm_red(X3, t);                          // X3 = MM - 2 S
+    f29_add(U, AA, AA);
+    f29_norm(U, U);                               // U = 2 AA
+    f29_sub(t, S, X3);
+    f29_norm(t, t);
+    f29_pick(a, role == 1, U, M);
+    f29_pick(b, role == 1, s.T, t);
+    f29_pick(V, role == 1, f29_zero(), U);
+    f29_cols c;
+    f29_cols_zero(c);
+    f29_cols_mul(c, a, b);
+    f29_cols_sub_val(c, V);
+    f29_reduce_x(P3, c);
+    f29_red_q(P3);
+}
+// Y3r = level 3 of lane 0, UTr = level 3 of lane 1
+SBV_HD void keychain29_finish(kchain& s, const fe29& X3, const fe29& Z3, const fe29& Y3r, const fe29& UTr) {
+    fe29 t;
+    s.X = X3;
+    s.Y = Y3r;
+    s.Z = Z3;
+    f29_add(t, UTr, UTr);
+    f29_norm_red(s.T, t);
+}
+
+// Exchange policy of the emulator and the unit tests: the four lanes of a quad stepped in lockstep.
+struct keychain_quad_host {
+    static const int N = 4;
+    kchain s[4];
+    int role(int i) const { return i; }
+    void bcast(fe29 out[4], const fe29 in[4], int src) const { for (int i = 0; i < 4; ++i) out[i] = in[src]; }
+};
+// One doubling of the quad's point.  QX: N lanes in q.s[0..N), role(i) in 0..3, bcast(out, in, src) = every lane's copy of
+// lane src's value.
+template <class QX>
+SBV_HD void keychain29_dbl(QX& q) {
+    fe29 P[QX::N], XX[QX::N], YY[QX::N], YZ[QX::N], M[QX::N], Z3[QX::N], X3[QX::N];
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) keychain29_l1(P[i], q.s[i], q.role(i));
+    q.bcast(XX, P, 0); q.bcast(YY, P, 1); q.bcast(YZ, P, 2);
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) keychain29_l2(P[i], M[i], Z3[i], q.s[i], XX[i], YY[i], YZ[i], q.role(i));
+    q.bcast(XX, P, 0); q.bcast(YY, P, 1); q.bcast(YZ, P, 2);        // AA, XA, MM
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) keychain29_l3(P[i], X3[i], q.s[i], M[i], XX[i], YY[i], YZ[i], q.role(i));
+    q.bcast(XX, P, 0); q.bcast(YY, P, 1);                             // Y3, U T
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) keychain29_finish(q.s[i], X3[i], Z3[i], XX[i], YY[i]);
+}
+
+// pointFromAffine's verdict on tuple idx's key, on the carry-free field: coordinates < p, y^2 = x^3 - 3x + b.
+// x, y: the key in the R = 2^261 domain, tight (garbage when the verdict is false).
+SBV_HD bool key29_load(const uint8_t* tuples, size_t idx, fe29& x, fe29& y) {
+    const u32* k = tuple_key_words(tuples, idx);
+    u256 qx, qy;
+    SBV_UNROLL
+    for (int l = 0; l < 8; ++l) { qx.v[l] = bswap32(k[7 - l]); qy.v[l] = bswap32(k[8 + 7 - l]); }
+    const fe p_ = fe_p();
+    f29_from_plain(x, qx);
+    f29_from_plain(y, qy);
+    fe29 lhs, t, rhs;
+    f29_sqr(lhs, y);
+    f29_sqr(t, x);
+    f29_mul(rhs, t, x);
+    f29_sub(rhs, rhs, x);
+    f29_sub(rhs, rhs, x);
+    f29_sub(rhs, rhs, x);
+    f29_add(rhs, rhs, f29_b());
+    f29_sub(t, lhs, rhs);
+    return lt256(qx, p_) && lt256(qy, p_) && f29_is_zero(t);
+}
+// the chain's first point: (x : y : 1 : -3)
+SBV_HD void keychain29_start(kchain& s, const fe29& x, const fe29& y) {
+    fe29 t;
+    s.X = x; s.Y = y; s.Z = f29_one();
+    f29_add(t, s.Z, s.Z);
+    f29_add(t, t, s.Z);
+    f29_neg(t, t);
+    f29_norm_red(s.T, t);
+}
+SBV_HD void kchain_store(u32* dst, const kchain& s) {
+    f29_store_raw(dst, s.X); f29_store_raw(dst + 9, s.Y); f29_store_raw(dst + 18, s.Z); f29_store_raw(dst + 27, s.T);
+}
+SBV_HD void kchain_load(kchain& s, const u32* src) {
+    f29_load_raw(s.X, src); f29_load_raw(s.Y, src + 9); f29_load_raw(s.Z, src + 18); f29_load_raw(s.T, src + 27);
+}
+// coordinate `role` of the state (each lane of a quad stores one of the four)
+SBV_HD void kchain_store_part(u32* dst, const kchain& s, int role) {
+    fe29 a, b, c;
+    f29_pick(a, role == 0, s.X, s.Y);
+    f29_pick(b, role == 2, s.Z, s.T);
+    f29_pick(c, role < 2, a, b);
+    f29_store_raw(dst + 9 * role, c);
+}
+
+// The whole chain of one chunk for one quad.  bases: [(gidx * 33 + j) * 2 + {0, 1}] records of SBV_KT29_REC_WORDS words =
+// B_j = 2^(8j) Q and 16 B_j as the chain left them (modified Jacobian, NOT normalised: the rows kernel works on the
+// isomorphic curve where the point is affine).  jstate[gidx]: the running point between chunks.  valid: the byte of this
+// key's TABLE SLOT (written with the first chunk).
+template <class QX>
+SBV_HD void keychain29_run(QX& q, const uint8_t* tuples, u32 gidx, const GroupState& g, u32* jstate, u32* bases, uint8_t* valid,
+                           int j_first, int j_last) {
     u32* st = jstate + (size_t)gidx * SBV_KT29_STATE_WORDS;
     if (j_first == 0) {
-        fe x, y;
-        const bool ok = tuple_key_load(tuples, g.group_rep[gidx], x, y);
-        *valid = ok ? 1 : 0;
-        f29_from_fe(t.X, x);
-        f29_from_fe(t.Y, y);
-        t.Z = f29_one();
+        fe29 x, y;
+        const bool ok = key29_load(tuples, g.group_rep[gidx], x, y);
+        SBV_UNROLL
+        for (int i = 0; i < QX::N; ++i) {
+            if (q.role(i) == 0) *valid = ok ? 1 : 0;
+            keychain29_start(q.s[i], x, y);
+        }
     } else {
-        f29_load_raw(t.X, st); f29_load_raw(t.Y, st + 9); f29_load_raw(t.Z, st + 18);
+        SBV_UNROLL
+        for (int i = 0; i < QX::N; ++i) kchain_load(q.s[i], st);
     }
-    fe29 acc = f29_one();
-    int cnt = 0;
     SBV_NOUNROLL
     for (int j = j_first; j <= j_last; ++j) {
         SBV_NOUNROLL
         for (int half = 0; half < 2; ++half) {
             if (j > 0 || half > 0) {
                 SBV_NOUNROLL
-                for (int d = 0; d < 4; ++d) pt29_dbl_jac(t);
+                for (int d = 0; d < 4; ++d) keychain29_dbl(q);
             }
-            u32* rec = tmp + cnt * 36;
-            f29_store_raw(rec, t.X); f29_store_raw(rec + 9, t.Y); f29_store_raw(rec + 18, t.Z); f29_store_raw(rec + 27, acc);
-            f29_mul(acc, acc, t.Z);
-            ++cnt;
+            u32* rec = bases + (((size_t)gidx * SBV_GTAB_WINDOWS + j) * SBV_KT29_POINTS_PER_WINDOW + half) * SBV_KT29_REC_WORDS;
+            SBV_UNROLL
+            for (int i = 0; i < QX::N; ++i) kchain_store_part(rec, q.s[i], q.role(i));
+            if (j == SBV_GTAB_WINDOWS - 1) break;           // the top window has the single entry B_32
         }
     }
-    f29_store_raw(st, t.X); f29_store_raw(st + 9, t.Y); f29_store_raw(st + 18, t.Z);
-    fe29 inv;
-    f29_inv(inv, acc);
-    apt* out = bases + ((size_t)gidx * SBV_GTAB_WINDOWS + j_first) * SBV_KT29_POINTS_PER_WINDOW;
-    SBV_NOUNROLL
-    for (int k = cnt - 1; k >= 0; --k) {
-        const u32* rec = tmp + k * 36;
-        fe29 X, Y, Z, pre, zi, zi2, zi3;
-        f29_load_raw(X, rec); f29_load_raw(Y, rec + 9); f29_load_raw(Z, rec + 18); f29_load_raw(pre, rec + 27);
-        f29_mul(zi, inv, pre);
-        f29_mul(inv, inv, Z);
-        f29_sqr(zi2, zi);
-        f29_mul(zi3, zi2, zi);
-        apt29 a;
-        f29_mul(a.x, X, zi2);
-        f29_mul(a.y, Y, zi3);
-        apt29_store_canon(out + k, a);
-    }
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) kchain_store_part(st, q.s[i], q.role(i));
 }
 
 // ---- rows ----------------------------------------------------------------------------------------------------------------
 // which = 0: babies b * B, b = 1..16 -> row[b - 1];  which = 1: giants 16 a * B, a = 2..8 -> row[16 a - 1].
-// base2 = &bases[(key * 33 + j) * 2]; row = the window's 128 entries; tmp: SBV_KT29_ROWS_TMP_WORDS private words.
-// top_window (j == 32): only entry 1 exists (the comb's carry digit is 0 or 1).
-SBV_HD void keytab29_rows_lane(const apt* base2, int which, bool top_window, u32* tmp, apt* row) {
+// base2 = the window's two chain records (B and 16 B, modified Jacobian); row = the window's 128 entries;
+// tmp: SBV_KT29_ROWS_TMP_WORDS private words.  top_window (j == 32): only entry 1 exists (the carry digit is 0 or 1).
+//
+// The base point (X : Y : Z) is never normalised on its own.  (x, y) -> (x Z^2, y Z^3) maps P-256 onto the curve
+// y^2 = x^3 - 3 Z^4 x + b Z^6, where the base is the AFFINE point (X, Y): the multiples are chains of mixed additions there
+// (the addition formulas do not depend on the curve's coefficients; the one doubling takes a4 = T = -3 Z^4 from the chain),
+// and a multiple (X' : Y' : ZZ' : ZZZ') maps back as x = X' / (ZZ' Z^2), y = Y' / (ZZZ' Z^3).  Z joins the lane's ONE
+// inversion (Montgomery's trick over Z and the ZZZ' of the chain).
+SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32* tmp, apt* row) {
+    kchain B;
+    kchain_load(B, base2 + which * SBV_KT29_REC_WORDS);
+    const int n = top_window ? 0 : (which == 0 ? 15 : 7);                 // points of the chain beyond its first
     apt29 step;
-    apt29_load(step, reinterpret_cast<const u32*>(base2 + which));        // B or 16 B
-    if (which == 0) apt29_store_canon(row, step);                         // entry 1 = B itself
-    if (top_window) return;
-    const int n = which == 0 ? 15 : 7;                                    // points of the chain beyond its first
+    step.x = B.X; step.y = B.Y;
     xyzz R;
-    R.X = step.x; R.Y = step.y; R.ZZ = f29_one(); R.ZZZ = f29_one(); R.inf = false;
     fe29 acc = f29_one();
+    if (n > 0) {                                // 2 * base: the chain's only doubling; its ZZZ' opens the running product
+        pt29_mdbl_a(R, B.X, B.Y, B.T);
+        f29_store_raw(tmp, R.X); f29_store_raw(tmp + 9, R.Y); f29_store_raw(tmp + 18, R.ZZ); f29_store_raw(tmp + 27, R.ZZZ);
+        f29_store_raw(tmp + 36, acc);
+        acc = R.ZZZ;
+    }
     SBV_NOUNROLL
-    for (int k = 0; k < n; ++k) {
+    for (int k = 1; k < n; ++k) {
         pt29_madd(R, step, false);
         u32* rec = tmp + k * 45;
         f29_store_raw(rec, R.X); f29_store_raw(rec + 9, R.Y); f29_store_raw(rec + 18, R.ZZ); f29_store_raw(rec + 27, R.ZZZ);
         f29_store_raw(rec + 36, acc);
         f29_mul(acc, acc, R.ZZZ);
     }
-    fe29 inv;
-    f29_inv(inv, acc);
+    fe29 all, inv, zi, zi2, zi3;
+    f29_mul(all, acc, B.Z);
+    f29_inv(inv, all);
+    f29_mul(zi, inv, acc);                      // 1 / Z
+    f29_mul(inv, inv, B.Z);                     // 1 / prod ZZZ'
+    f29_sqr(zi2, zi);
+    f29_mul(zi3, zi2, zi);
+    if (which == 0) {                           // entry 1 = B itself
+        apt29 a;
+        f29_mul(a.x, B.X, zi2);
+        f29_mul(a.y, B.Y, zi3);
+        apt29_store_canon(row, a);
+    }
     SBV_NOUNROLL
     for (int k = n - 1; k >= 0; --k) {
         const u32* rec = tmp + k * 45;
         fe29 X, Y, ZZ, ZZZ, pre, i3, w, w2;
         f29_load_raw(X, rec); f29_load_raw(Y, rec + 9); f29_load_raw(ZZ, rec + 18); f29_load_raw(ZZZ, rec + 27); f29_load_raw(pre, rec + 36);
-        f29_mul(i3, inv, pre);                  // 1 / ZZZ
+        f29_mul(i3, inv, pre);                  // 1 / ZZZ'
         f29_mul(inv, inv, ZZZ);
-        f29_mul(w, ZZ, i3);                     // ZZ / ZZZ = 1 / Z
-        f29_sqr(w2, w);                         // 1 / ZZ
+        f29_mul(w, ZZ, i3);                     // ZZ' / ZZZ'
+        f29_sqr(w2, w);                         // 1 / ZZ'
+        f29_mul(w2, w2, zi2);                   // 1 / (ZZ' Z^2)
+        f29_mul(i3, i3, zi3);                   // 1 / (ZZZ' Z^3)
         apt29 a;
         f29_mul(a.x, X, w2);
         f29_mul(a.y, Y, i3);

@@ -68,6 +68,36 @@ SBV_HD void pt29_mdbl(xyzz& R, const fe29& x, const fe29& y) {
     R.inf = false;
 }
 
+// 2 * (x, y) on the curve y^2 = x^3 + a4 x + b' for ANY a4 (mdbl-2008-s-1: the formulas never use b').  The table builder
+// doubles a Jacobian point (X : Y : Z) of P-256 as the affine point (X, Y) of the isomorphic curve with a4 = -3 Z^4
+// (p256_keytab29.h).  x, y, a4 value-reduced (f29_norm_red / f29_red_q); outputs as pt29_mdbl's.
+SBV_HD void pt29_mdbl_a(xyzz& R, const fe29& x, const fe29& y, const fe29& a4) {
+    fe29 U, V, W, S, M, t, X3, Y3;
+    f29_add(U, y, y);
+    f29_norm(U, U);
+    f29_sqr(V, U);
+    f29_mul(W, U, V);
+    f29_mul(S, x, V);
+    f29_sqr(t, x);
+    f29_add(M, t, t);
+    f29_add(M, M, t);
+    f29_add(M, M, a4);                          // M = 3 x^2 + a4, value within +-5.6 p
+    f29_norm(M, M);
+    f29_sqr(t, M);
+    f29_sub(t, t, S);
+    f29_sub(X3, t, S);                          // X3 = M^2 - 2 S
+    f29_norm_red(R.X, X3);
+    f29_sub(t, S, R.X);
+    f29_norm(t, t);
+    f29_mul(t, M, t);
+    f29_mul(Y3, W, y);
+    f29_sub(Y3, t, Y3);                         // Y3 = M (S - X3) - W y
+    f29_norm_red(R.Y, Y3);
+    R.ZZ = V;
+    R.ZZZ = W;
+    R.inf = false;
+}
+
 // R += (q.x, neg ? -q.y : q.y).  R.X, R.Y as left by this function (or pt29_mdbl / a load of stored
 // coordinates): value-reduced; ZZ, ZZZ tight with |value| < 5 p.
 SBV_HD void pt29_madd(xyzz& R, const apt29& q, bool neg) {

@@ -69,7 +69,10 @@ struct Context {
     sbv::GroupBuffers grp;
     sbv::EdGroupBuffers edgrp;          // Ed25519 grouped step: per-batch combs of -A (the rest is shared with grp)
     bool group_enabled = true;
-    size_t group_min_batch = 262144;    // below this the ~3.5 ms table-building latency costs more than it saves
+    // Batches from this size on take the grouped step.  It used to be 2^18 (the table-building latency of a cold batch);
+    // since cached keys are grouped whatever their count (p256_group.h: group_assign_lane) and cold rare keys fall through to
+    // the doubling kernel inside the same step, a small batch loses nothing by it and a warm one skips the 256 doublings.
+    size_t group_min_batch = 4096;
     u32 group_min_count = 64, group_max = 2048;
     bool kc_enabled = true;             // persistent key-table cache (p256_group.h)
     u32 kc_cap = 4096;                  // cached keys (270 KiB of HBM each)
@@ -98,6 +101,15 @@ struct Context {
 // address them.  Contexts are never freed (a thread may still hold a pointer while another shuts down): sbv_shutdown tears
 // the device resources down and marks them not ready.
 constexpr int kMaxDevices = 16;
+// Process-wide settings (sbv_p256_set_grouping / sbv_p256_key_cache / sbv_profile_enable): remembered here, copied into every
+// context when it is initialised and applied to every live context when they change — a setter called before sbv_init is not
+// lost, and after sbv_init_all it configures ALL devices, not just the default one.  Guarded by g_set_mu (a leaf lock).
+struct Settings {
+    bool group_enabled = true; size_t group_min_batch = 4096; u32 group_min_count = 64, group_max = 2048;
+    bool kc_enabled = true; u32 kc_cap = 4096;
+    bool profiling = false;
+} g_settings;
+std::mutex g_set_mu;
 std::unique_ptr<Context> g_ctxs[kMaxDevices];
 Context g_null;                      // stand-in before sbv_init: ready == false
 Context* g_def = nullptr;
@@ -220,8 +232,8 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ung_cand, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.rec, c.cap * (size_t)SBV_REC_WORDS * sizeof(u32)));    // indexed like the scratch planes
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jbases, G * SBV_GTAB_WINDOWS * (size_t)40 * sizeof(u32)));   // 40 dwords = one Jacobian base (p256_group.h)
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.bases, G * SBV_GTAB_WINDOWS * (size_t)2 * sizeof(sbv::apt)));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jstate, G * (size_t)27 * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.bases, G * SBV_GTAB_WINDOWS * (size_t)(2 * 36) * sizeof(u32)));       // SBV_KT29_REC_WORDS per recorded point
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jstate, G * (size_t)36 * sizeof(u32)));                                  // SBV_KT29_STATE_WORDS
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 40 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride; 36 words (P-256: XYZZ, 9-limb coordinates) or 40 (Ed25519: extended, 10-limb coordinates) per tuple
     // comb pool: slots [0, kc_cap) belong to the persistent key-table cache, [kc_cap, kc_cap + G) are rebuilt per batch
     const size_t K = c.kc_cap;
@@ -292,8 +304,18 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
     if (grouped) {           // stage A is enqueued by the grouped launcher, in slices pipelined with the G phase
         sbv::Scratch sg = s;
         sg.rec = c.gsync.sorted ? c.grp.rec : nullptr;      // stage A also writes the per-tuple records the key-sorted list reads
-        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_grouped(d_tuples, sg, n, c.grp, c.d_qtab, c.d_gtab, sbv::gcomb_make(c.d_g16r, c.g_bits), d_bitmap, stream, c.gsync,
-                                                             after_prep, dom, dom_pairs));
+        const hipError_t ge = sbv::launch_p256_verify_grouped(d_tuples, sg, n, c.grp, c.d_qtab, c.d_gtab, sbv::gcomb_make(c.d_g16r, c.g_bits), d_bitmap, stream, c.gsync,
+                                                              after_prep, dom, dom_pairs);
+        if (ge != hipSuccess) {
+            // k_key_cache_insert publishes a slot before its tables are built: a step that failed half-way may leave slots
+            // whose combs never were.  Forget the whole cache (best effort, after draining what did get enqueued).
+            (void)hipDeviceSynchronize();
+            if (c.grp.kc.ht) {
+                (void)hipMemset(c.grp.kc.ht, 0, ((size_t)c.grp.kc.ht_mask + 1) * sizeof(u32));
+                (void)hipMemset(c.grp.kc.count, 0, 4 * sizeof(u32));
+            }
+            return fail(SBV_EDEVICE, "launch_p256_verify_grouped", ge);
+        }
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_tuples, n, s, stream));
@@ -433,7 +455,15 @@ int init_context(Context& c, int device) {
     c.g_bits = g_gbits;
     HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_g16r, g_h_g16r.size() * sizeof(sbv::apt)));
     HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_g16r, g_h_g16r.data(), g_h_g16r.size() * sizeof(sbv::apt), hipMemcpyHostToDevice));
+    {
+        std::lock_guard<std::mutex> lk(g_set_mu);
+        c.group_enabled = g_settings.group_enabled; c.group_min_batch = g_settings.group_min_batch;
+        c.group_min_count = g_settings.group_min_count; c.group_max = g_settings.group_max;
+        c.kc_enabled = g_settings.kc_enabled; c.kc_cap = g_settings.kc_cap;
+        c.profiling = g_settings.profiling;
+    }
     if (const char* e = getenv("SBV_GROUP")) c.group_enabled = e[0] != '0';
+    if (const char* e = getenv("SBV_GROUP_MIN_BATCH")) { const long v = atol(e); if (v > 0) c.group_min_batch = (size_t)v; }
     c.device = device;
     c.ready = true;
     g_err.clear();
@@ -469,8 +499,14 @@ extern "C" int sbv_init(int device) {
 namespace {
 void rccl_teardown();
 // c.mu held by the caller
-struct ShardBuffers { uint8_t* d_gather = nullptr; size_t gather_cap = 0; uint8_t* d_q = nullptr; size_t q_cap = 0; };
-ShardBuffers g_shard[kMaxDevices];      // per-device gather slot buffers of the sharded entry
+// Per-device bitmap buffers of the multi-device entries.  d_gather / d_q belong to the ONE multi-shard call in flight
+// (g_sharded_mu is held from its first worker to its final copy: the all-gather reads every device's d_gather after the
+// workers dropped their context locks).  d_on serves the calls that stay on one device (sbv_p256_verify_batch_on and the
+// replica route of the sharded entry) and is only touched under that device's context lock.
+struct ShardBuffers { uint8_t* d_gather = nullptr; size_t gather_cap = 0; uint8_t* d_q = nullptr; size_t q_cap = 0;
+                      uint8_t* d_on = nullptr; size_t on_cap = 0; uint8_t* d_onq = nullptr; size_t onq_cap = 0; };
+ShardBuffers g_shard[kMaxDevices];
+std::mutex g_sharded_mu;
 
 int shutdown_context(Context& c) {
     if (!c.ready) return SBV_OK;
@@ -482,6 +518,8 @@ int shutdown_context(Context& c) {
         ShardBuffers& sb = g_shard[c.device];
         if (sb.d_gather) (void)hipFree(sb.d_gather);
         if (sb.d_q) (void)hipFree(sb.d_q);
+        if (sb.d_on) (void)hipFree(sb.d_on);
+        if (sb.d_onq) (void)hipFree(sb.d_onq);
         sb = ShardBuffers();
     }
     if (c.d_gtab) (void)hipFree(c.d_gtab);
@@ -1215,29 +1253,60 @@ extern "C" void sbv_host_free(void* p) {
     if (p) (void)hipHostFree(p);
 }
 
+namespace {
+// every initialised context, for the process-wide setters
+std::vector<Context*> live_contexts() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::vector<Context*> v;
+    for (auto& up : g_ctxs) if (up) v.push_back(up.get());
+    return v;
+}
+}  // namespace
+
 extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uint32_t max_groups) {
-    SBV_ENTER(c);
-    c.group_enabled = enabled != 0;
-    if (min_batch) c.group_min_batch = min_batch;
-    if (min_count) c.group_min_count = min_count;
-    if (max_groups) c.group_max = max_groups;
+    Settings st;
+    {
+        std::lock_guard<std::mutex> lk(g_set_mu);
+        g_settings.group_enabled = enabled != 0;
+        if (min_batch) g_settings.group_min_batch = min_batch;
+        if (min_count) g_settings.group_min_count = min_count;
+        if (max_groups) g_settings.group_max = max_groups;
+        st = g_settings;
+    }
+    for (Context* cp : live_contexts()) {
+        std::lock_guard<std::mutex> lk(cp->mu);
+        cp->group_enabled = st.group_enabled; cp->group_min_batch = st.group_min_batch;
+        cp->group_min_count = st.group_min_count; cp->group_max = st.group_max;
+    }
     return SBV_OK;
 }
 
 extern "C" int sbv_p256_key_cache(int enabled, uint32_t capacity) {
-    SBV_ENTER(c);
-    c.kc_enabled = enabled != 0;
-    if (capacity) c.kc_cap = capacity;          // a new capacity takes effect (and empties the cache) at the next grouped batch
-    if (c.ready && c.grp.kc.ht) {
-        HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
-        HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
-        c.grp.kc.enabled = c.kc_enabled ? 1u : 0u;
-        if (!c.kc_enabled) {                     // switching it off forgets everything: the next "on" starts cold
-            HIP_TRY(SBV_EDEVICE, hipMemset(c.grp.kc.ht, 0, ((size_t)c.grp.kc.ht_mask + 1) * sizeof(u32)));
-            HIP_TRY(SBV_EDEVICE, hipMemset(c.grp.kc.count, 0, 4 * sizeof(u32)));
+    Settings st;
+    {
+        std::lock_guard<std::mutex> lk(g_set_mu);
+        g_settings.kc_enabled = enabled != 0;
+        if (capacity) g_settings.kc_cap = capacity;
+        st = g_settings;
+    }
+    int rc = SBV_OK;
+    for (Context* cp : live_contexts()) {
+        std::lock_guard<std::mutex> lk(cp->mu);
+        Context& c = *cp;
+        c.kc_enabled = st.kc_enabled;
+        c.kc_cap = st.kc_cap;                       // a new capacity takes effect (and empties the cache) at the next grouped batch
+        if (c.ready && c.grp.kc.ht) {
+            hipError_t e = hipSetDevice(c.device);
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            c.grp.kc.enabled = c.kc_enabled ? 1u : 0u;
+            if (e == hipSuccess && !c.kc_enabled) {  // switching it off forgets everything: the next "on" starts cold
+                e = hipMemset(c.grp.kc.ht, 0, ((size_t)c.grp.kc.ht_mask + 1) * sizeof(u32));
+                if (e == hipSuccess) e = hipMemset(c.grp.kc.count, 0, 4 * sizeof(u32));
+            }
+            if (e != hipSuccess) rc = fail(SBV_EDEVICE, "sbv_p256_key_cache", e);
         }
     }
-    return SBV_OK;
+    return rc;
 }
 
 extern "C" int sbv_p256_key_cache_stats(uint32_t out[4]) {
@@ -1258,8 +1327,14 @@ extern "C" int sbv_p256_key_cache_stats(uint32_t out[4]) {
 }
 
 extern "C" int sbv_profile_enable(int on) {
-    SBV_ENTER(c);
-    c.profiling = on != 0;
+    {
+        std::lock_guard<std::mutex> lk(g_set_mu);
+        g_settings.profiling = on != 0;
+    }
+    for (Context* cp : live_contexts()) {
+        std::lock_guard<std::mutex> lk(cp->mu);
+        cp->profiling = on != 0;
+    }
     return SBV_OK;
 }
 
@@ -1552,25 +1627,34 @@ extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, si
     std::vector<int> rcs(shards, SBV_OK);
     std::vector<std::string> errs(shards);
     std::vector<double> h2d(shards, 0.0), kern(shards, 0.0);
+    // A call that spans devices owns every device's gather buffer until its final copy; a call that stays on one device
+    // (replica route) uses that device's private buffer under its context lock and runs beside other replicas.
+    const bool multi = shards > 1 || forced_single;
+    std::unique_lock<std::mutex> sharded_lk(g_sharded_mu, std::defer_lock);
+    if (multi) sharded_lk.lock();
     auto work = [&](size_t k) {
         Context* c;
         { std::lock_guard<std::mutex> lk(g_mu); c = g_ctxs[use[k]].get(); }
         std::lock_guard<std::mutex> lkc(c->mu);
         ShardBuffers& sbuf = g_shard[use[k]];
+        uint8_t*& d_bits = multi ? sbuf.d_gather : sbuf.d_on;
+        size_t& bits_cap = multi ? sbuf.gather_cap : sbuf.on_cap;
+        uint8_t*& d_qb = multi ? sbuf.d_q : sbuf.d_onq;
+        size_t& qb_cap = multi ? sbuf.q_cap : sbuf.onq_cap;
         int rc = SBV_OK;
         if (hipSetDevice(c->device) != hipSuccess) rc = SBV_EDEVICE;
-        if (rc == SBV_OK) rc = grow_bytes(sbuf.d_gather, sbuf.gather_cap, sb * shards + 64);
-        if (rc == SBV_OK && quorum_bitmap) rc = grow_bytes(sbuf.d_q, sbuf.q_cap, qb + 64);
+        if (rc == SBV_OK) rc = grow_bytes(d_bits, bits_cap, sb * shards + 64);
+        if (rc == SBV_OK && quorum_bitmap) rc = grow_bytes(d_qb, qb_cap, qb + 64);
         if (rc == SBV_OK)
-            rc = verify_shard(*c, tuples + first[k] * SBV_TUPLE_BYTES, first[k + 1] - first[k], group, quorum, sbuf.d_gather + k * sb,
-                              quorum_bitmap ? sbuf.d_q : nullptr, &h2d[k], &kern[k]);
+            rc = verify_shard(*c, tuples + first[k] * SBV_TUPLE_BYTES, first[k + 1] - first[k], group, quorum, d_bits + k * sb,
+                              quorum_bitmap ? d_qb : nullptr, &h2d[k], &kern[k]);
         if (rc == SBV_OK && quorum_bitmap) {
             const size_t props = (first[k + 1] - first[k]) / group;
-            if (props && hipMemcpy(quorum_bitmap + (first[k] / group) / 8, sbuf.d_q, (props + 7) / 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SBV_EDEVICE;
+            if (props && hipMemcpy(quorum_bitmap + (first[k] / group) / 8, d_qb, (props + 7) / 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SBV_EDEVICE;
         }
         if (rc == SBV_OK && !gather && !forced_single) {         // no collective: this shard's bitmap goes straight to the host
             const size_t bytes = (first[k + 1] - first[k] + 7) / 8;
-            if (hipMemcpy(accept_bitmap + first[k] / 8, sbuf.d_gather + k * sb, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = SBV_EDEVICE;
+            if (hipMemcpy(accept_bitmap + first[k] / 8, d_bits + k * sb, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = SBV_EDEVICE;
         }
         rcs[k] = rc;
         if (rc != SBV_OK) errs[k] = g_err;
@@ -1626,11 +1710,11 @@ extern "C" int sbv_p256_verify_batch_on(int device, const uint8_t* tuples, size_
     if (!c->ready) { g_err = "device not initialised"; return SBV_ENOTINIT; }
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c->device));
     const size_t bytes = (n + 7) / 8;
-    int rc = grow_bytes(sbuf.d_gather, sbuf.gather_cap, bytes + 64);
+    int rc = grow_bytes(sbuf.d_on, sbuf.on_cap, bytes + 64);
     if (rc != SBV_OK) return rc;
-    rc = verify_shard(*c, tuples, n, 0, 0, sbuf.d_gather, nullptr, nullptr, nullptr);
+    rc = verify_shard(*c, tuples, n, 0, 0, sbuf.d_on, nullptr, nullptr, nullptr);
     if (rc != SBV_OK) return rc;
-    HIP_TRY(SBV_EDEVICE, hipMemcpy(accept_bitmap, sbuf.d_gather, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(accept_bitmap, sbuf.d_on, bytes, hipMemcpyDeviceToHost));
     return SBV_OK;
 }
 

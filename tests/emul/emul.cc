@@ -169,6 +169,9 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     const size_t per_block = (size_t)64 * T, nblocks = (n + per_block - 1) / per_block;
     for (size_t b = 0; b < nblocks; ++b)
         for (int t = 0; t < 64; ++t) prep_chunk29<true>(hw, n, s, b * per_block + t, 64, T);
+    if (g_group_sort) {                  // nothing may read the limb-major planes in the key-sorted step: make a stray read visible
+        for (auto* v : {&r, &u1, &u2, &qx, &qy, &sm}) std::fill(v->begin(), v->end(), 0xDBDBDBDBu);
+    }
     std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(max_groups ? max_groups : 1), counters(SBV_GROUP_COUNTERS, 0), ung_cand(cap),
         grp_idx(cap, 0xFFFFFFFFu), ung_idx(cap), slots(cap), gcount(2 * (size_t)(max_groups ? max_groups : 1), 0), grp_of(cap, 0xFFFFFFFFu);
     GroupState g{};
@@ -178,7 +181,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     g.slots = slots.data(); g.max_groups = max_groups;
     group_set_threshold(g, min_count);
     for (size_t i = 0; i < n; ++i) group_insert_lane(tuples, i, g);
-    for (size_t i = 0; i < n; ++i) group_assign_lane(i, g);
+    for (size_t i = 0; i < n; ++i) group_assign_lane(tuples, i, g, g_kc);      // cached keys are grouped whatever their count
     std::vector<uint8_t> accb(cap, 0xEE);
     if (g.sorted) {                      // two passes (k_group_classify, k_group_keycheck); candidates visited backwards, the order is free
         for (size_t i = 0; i < n; ++i) group_classify_lane(i, g);
@@ -211,13 +214,14 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     else for (size_t i = 0; i < n; ++i) gphase29_lane(s, i, g16rtab(), gacc.data());
     // key tables and the Q phase, in `chunks` pieces like the device pipeline
     const size_t ng1 = ngroups ? ngroups : 1;
-    apt* bases = (apt*)aligned_alloc(64, ng1 * SBV_GTAB_WINDOWS * SBV_KT29_POINTS_PER_WINDOW * sizeof(apt));
+    u32* bases = (u32*)aligned_alloc(64, ng1 * SBV_GTAB_WINDOWS * SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS * sizeof(u32));
+    memset(bases, 0xA5, ng1 * SBV_GTAB_WINDOWS * SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS * sizeof(u32));
     std::vector<u32> jstate(ng1 * SBV_KT29_STATE_WORDS);
     const size_t per_key = (size_t)SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW;
     apt* ktab = (apt*)aligned_alloc(64, ng1 * per_key * sizeof(apt));                     // the per-batch area
     memset(ktab, 0xA5, ng1 * per_key * sizeof(apt));      // an entry nobody wrote must not look like a point
     std::vector<uint8_t> kvalid(ng1, 0);
-    std::vector<u32> tmpa(SBV_KT29_BASES_TMP_WORDS + 7 * SBV_KT29_FILL_TMP_WORDS);
+    std::vector<u32> tmpa(7 * SBV_KT29_FILL_TMP_WORDS);
     // persistent key-table cache (p256_group.h): the two phases of k_key_cache_assign, sequentially
     std::vector<u32> tslot(ng1, SBV_GROUP_NONE);
     std::vector<uint8_t> cold(ng1, 1);
@@ -245,13 +249,18 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
         for (u32 k = 0; k < ngroups; ++k)
-            if (cold[k]) keytab29_bases_lane(tuples, k, g, jstate.data(), bases, tmpa.data(), valid_of(k), j_first, j_end - 1);
+            if (cold[k]) {               // k_keytab29_chain: the four lanes of the key's quad in lockstep
+                keychain_quad_host q;
+                keychain29_run(q, tuples, k, g, jstate.data(), bases, valid_of(k), j_first, j_end - 1);
+            }
         for (u32 k = 0; k < ngroups; ++k)
             for (int j = j_first; j < j_end && cold[k]; ++j) {
                 const size_t w = (size_t)k * SBV_GTAB_WINDOWS + j;
                 apt* row = table_of(k) + (size_t)j * SBV_GTAB_PER_WINDOW;
-                for (int which = 0; which < 2; ++which)
-                    keytab29_rows_lane(bases + w * SBV_KT29_POINTS_PER_WINDOW, which, j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
+                for (int which = 0; which < 2; ++which) {
+                    if (which == 1 && j == SBV_GTAB_WINDOWS - 1) continue;
+                    keytab29_rows_lane(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), which, j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
+                }
                 if (j == SBV_GTAB_WINDOWS - 1) continue;
                 for (int a = 1; a <= 7; a += rpl) keytab29_fill_lane(a, a + rpl - 1 > 7 ? 7 : a + rpl - 1, tmpa.data(), row);
             }
@@ -270,10 +279,41 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB29_WORDS * 4);
     for (u32 L = 0; L < counters[2]; ++L) {
         const u32 t = ung_idx[L];
-        if (verify29_lane_generic(s, t, qtab, g16rtab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+        const bool v = s.rec ? verify29_lane_generic_rec(s, tuples, t, qtab, g16rtab()) : verify29_lane_generic(s, t, qtab, g16rtab());
+        if (v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
     }
     free(qtab); free(ktab); free(bases);
     if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }
+}
+
+// n doublings of the affine point (x, y) (plain words) through the quad-cooperative chain of the table builder
+// (p256_keytab29.h: keychain29_dbl, four lanes in lockstep) -> affine plain x, y.  Returns 0 when the four lanes disagree or
+// the carried T differs from -3 Z^4, 1 otherwise.
+int sbve_keychain_dbl(const u32* x8, const u32* y8, int n, u32* outx, u32* outy) {
+    u256 px, py;
+    memcpy(&px, x8, 32); memcpy(&py, y8, 32);
+    fe29 x, y;
+    f29_from_plain(x, px);
+    f29_from_plain(y, py);
+    keychain_quad_host q;
+    for (int i = 0; i < 4; ++i) keychain29_start(q.s[i], x, y);
+    for (int d = 0; d < n; ++d) keychain29_dbl(q);
+    int ok = 1;
+    for (int i = 1; i < 4; ++i) ok &= memcmp(&q.s[i], &q.s[0], sizeof(kchain)) == 0;
+    const kchain& s = q.s[0];
+    fe29 z2, z4, t, zi, zi2, zi3, ax, ay, one1 = f29_zero();
+    one1.v[0] = 1;
+    f29_sqr(z2, s.Z); f29_sqr(z4, z2);
+    f29_add(t, z4, z4); f29_add(t, t, z4); f29_add(t, t, s.T);      // 3 Z^4 + T == 0 ?
+    ok &= f29_is_zero(t) ? 1 : 0;
+    f29_inv(zi, s.Z);
+    f29_sqr(zi2, zi); f29_mul(zi3, zi2, zi);
+    f29_mul(ax, s.X, zi2); f29_mul(ay, s.Y, zi3);
+    f29_mul(ax, ax, one1); f29_mul(ay, ay, one1);                   // out of the Montgomery domain
+    fe29 c;
+    f29_canon(c, ax); f29_pack(outx, c);
+    f29_canon(c, ay); f29_pack(outy, c);
+    return ok;
 }
 
 static bool g_keyed_coop = false;

@@ -511,9 +511,17 @@ def test_persistent_key_table_cache_never_changes_verdicts(emul, oracle, golden_
         assert hits == 6 and misses == 12 and entries == 16
         entries, hits, misses = run(c + a, wc + wa)       # again: the 9 that fitted are warm now, 3 stay cold every time
         assert hits == 6 + 9 and misses == 3 and entries == 16
+        # a cached key is grouped however few of its signatures a batch carries (group_assign_lane): a batch of 30 tuples, far
+        # below the threshold of 8 per key, still takes the comb path for the 6 + 9 keys that are warm
+        d, wd = batch(0x91, 30, 6)
+        entries, hits, misses = run(d, wd)
+        assert hits >= 4 and misses == 0 and entries == 16, (hits, misses)
+        assert stats[1] >= 20 and stats[2] == 0 and stats[1] + stats[3] == 30, list(stats)   # grouped (or key refused): nobody on the doubling kernel
         emul.sbve_key_cache(0, 16)                        # off: same verdicts, nothing cached
         entries, hits, misses = run(c + a, wc + wa)
         assert hits == 0 and misses == 0
+        entries, hits, misses = run(d, wd)                # cache off: the small batch is all-generic again, same verdicts
+        assert stats[1] == 0 and stats[2] >= 20 and stats[2] + stats[3] == 30, list(stats)
     finally:
         emul.sbve_key_cache(0, 0)
 

@@ -241,6 +241,21 @@ def test_pt29_madd_chain_matches_affine_sum_including_exceptional_cases(emul):
             assert emul.sbve_pt29_rx_matches(out, inf, words(1)) == 0
 
 
+def test_quad_cooperative_doubling_chain_matches_bigint(emul):
+    """p256_keytab29.h: the table builder's doubling chain — four lanes per key, modified Jacobian coordinates, one product
+    level per lane (keychain29_dbl) — against 2^n * P from Python big integers; the emulated lanes must agree with one
+    another and the carried T must stay -3 Z^4.  Runs under SBV_F29_CHECK: every product asserts its operand bounds."""
+    rng = random.Random(77)
+    G = (ec.GX, ec.GY)
+    emul.sbve_keychain_dbl.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    pts = [G, ec.pt_mul(ec.N - 1, G), ec.pt_mul(2, G)] + [ec.pt_mul(rng.randrange(1, ec.N), G) for _ in range(10)]
+    ox, oy = (ctypes.c_uint32 * 8)(), (ctypes.c_uint32 * 8)()
+    for i, pt in enumerate(pts):
+        for n in (0, 1, 2, 3, 4, 8, 33, 256) if i < 4 else (rng.randrange(1, 64), 128):
+            assert emul.sbve_keychain_dbl(words(pt[0]), words(pt[1]), n, ox, oy) == 1, (i, n)
+            assert (wval(ox), wval(oy)) == ec.pt_mul(pow(2, n, ec.N), pt), (i, n)
+
+
 def test_s29_scalar_field_matches_bigint(emul):
     """p256_sc29.h: Montgomery multiplication mod the group order N with R = 2^261, canonical form, inversion."""
     N = ec.N
