@@ -255,13 +255,23 @@ SBV_HD void f29_red_q(fe29& r) {
 }
 
 // ---- additions: limb-wise, no carries, no reduction ------------------------------------------------------
+// (CPU test tier: a limb that leaves the i32 range aborts — the sums are formed without any carry, so a formula that stacks
+// one loose value too many wraps silently on the GPU; tests/emul is how that is caught.)
+#if defined(SBV_F29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+inline void f29_check_limb(i64 v, const char* what) {
+    if (v > 2147483647LL || v < -2147483647LL - 1) { fprintf(stderr, "f29: a limb of %s leaves the 32-bit range\n", what); abort(); }
+}
+#define SBV_F29_CHECK_LIMB(v, what) f29_check_limb(v, what)
+#else
+#define SBV_F29_CHECK_LIMB(v, what) ((void)0)
+#endif
 SBV_HD void f29_add(fe29& r, const fe29& a, const fe29& b) {
     SBV_UNROLL
-    for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] + b.v[i];
+    for (int i = 0; i < 9; ++i) { SBV_F29_CHECK_LIMB((i64)a.v[i] + (i64)b.v[i], "a sum"); r.v[i] = a.v[i] + b.v[i]; }
 }
 SBV_HD void f29_sub(fe29& r, const fe29& a, const fe29& b) {
     SBV_UNROLL
-    for (int i = 0; i < 9; ++i) r.v[i] = a.v[i] - b.v[i];
+    for (int i = 0; i < 9; ++i) { SBV_F29_CHECK_LIMB((i64)a.v[i] - (i64)b.v[i], "a difference"); r.v[i] = a.v[i] - b.v[i]; }
 }
 SBV_HD void f29_neg(fe29& r, const fe29& a) {
     SBV_UNROLL

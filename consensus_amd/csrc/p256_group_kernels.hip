@@ -351,26 +351,37 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
                                b.gacc, b.acc, gen_blocks, first, end);
         }
     }
-    // chunks of windows: bases on side_a, tables on side_b, Q phase on stream
+    // Chunks of windows: the chain on side_a, rows + fill on side_b, the Q phase on stream.  The tables are BUILT in finer
+    // pieces than they are consumed in (y.tsub pieces per Q-phase chunk): rows + fill of one piece run beside the chain of
+    // the next, so what is left after the chain's last doubling is the tail of a quarter of the windows, not of a half
+    // (it is what bounds a cold batch of 2^18: profiles/r03).  The Q phase keeps its two launches (every launch is one round
+    // trip of the accumulators).
+    int tsub = y.tsub < 1 ? 1 : y.tsub;
+    while (chunks * tsub > SBV_GROUP_MAX_TCHUNKS) --tsub;
     for (int c = 0; c < chunks; ++c) {
-        const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [j_first, j_end)
-        const int j_count = j_end - j_first;
-        hipLaunchKernelGGL(k_keytab29_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases,
-                           b.kvalid, b.tslot, b.cold, j_first, j_end - 1);
-        SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
-        SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[c], 0));
-        const size_t wl = (size_t)b.max_groups * j_count * 2;
-        hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
-        const int lpw = (7 + rows_per_lane - 1) / rows_per_lane;
-        const size_t fl = (size_t)b.max_groups * j_count * lpw;
-        hipLaunchKernelGGL(k_keytab29_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, y.side_b, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count,
-                           rows_per_lane, lpw);
+        const int q_first = SBV_GTAB_WINDOWS * c / chunks, q_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [q_first, q_end)
+        for (int t = 0; t < tsub; ++t) {
+            const int j_first = q_first + (q_end - q_first) * t / tsub, j_end = q_first + (q_end - q_first) * (t + 1) / tsub;
+            const int j_count = j_end - j_first;
+            if (j_count <= 0) continue;
+            const int tc = c * tsub + t;
+            hipLaunchKernelGGL(k_keytab29_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases,
+                               b.kvalid, b.tslot, b.cold, j_first, j_end - 1);
+            SBV_TRY(hipEventRecord(y.ev_bases[tc], y.side_a));
+            SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[tc], 0));
+            const size_t wl = (size_t)b.max_groups * j_count * 2;
+            hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
+            const int lpw = (7 + rows_per_lane - 1) / rows_per_lane;
+            const size_t fl = (size_t)b.max_groups * j_count * lpw;
+            hipLaunchKernelGGL(k_keytab29_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, y.side_b, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count,
+                               rows_per_lane, lpw);
+        }
         SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         const bool last = c + 1 == chunks;
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
         hipLaunchKernelGGL(k_verify_keyed_q, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.kc.cap + b.max_groups, b.gacc, b.acc,
-                           j_first, j_end, last ? 1 : 0);
+                           q_first, q_end, last ? 1 : 0);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
     if (y.side_c) SBV_TRY(hipStreamWaitEvent(stream, y.ev_generic, 0));

@@ -54,6 +54,7 @@ struct GroupBuffers {
 // streams and events of the grouped step; owned by the context.  `chunks` (1..SBV_GROUP_MAX_CHUNKS) = how
 // many pieces the 33 key-comb windows are built and consumed in.
 #define SBV_GROUP_MAX_CHUNKS 4
+#define SBV_GROUP_MAX_TCHUNKS 8      // pieces the key tables are built in: chunks x tsub
 #define SBV_GROUP_MAX_SLICES 8
 struct GroupSync {
     hipStream_t side_a = nullptr;   // insert, assign, window bases
@@ -62,8 +63,9 @@ struct GroupSync {
     hipEvent_t ev_slice[SBV_GROUP_MAX_SLICES] = {};
     int slices = 1;                 // pieces stage A + G phase are pipelined in (1..SBV_GROUP_MAX_SLICES); slices > 0 run on side_b
     hipEvent_t ev_fork = nullptr, ev_assign = nullptr, ev_split = nullptr, ev_prep = nullptr, ev_generic = nullptr;
-    hipEvent_t ev_bases[SBV_GROUP_MAX_CHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
+    hipEvent_t ev_bases[SBV_GROUP_MAX_TCHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
     int chunks = 1;
+    int tsub = 2;                   // P-256: table-building pieces per Q-phase chunk (SBV_GROUP_TSUB)
     int sorted = 1;                 // P-256: key-sorted grouped list + XCD-aware Q phase (SBV_GROUP_SORT=0: the split's compaction order)
     int parts = 1;                  // P-256: rows of 16 entries per lane of k_keytab29_fill (1, 2, 4, 7); Ed25519: lanes per (key, window)
 };

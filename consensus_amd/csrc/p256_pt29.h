@@ -81,6 +81,7 @@ SBV_HD void pt29_mdbl_a(xyzz& R, const fe29& x, const fe29& y, const fe29& a4) {
     f29_sqr(t, x);
     f29_add(M, t, t);
     f29_add(M, M, t);
+    f29_norm(M, M);                             // 3 x^2 alone reaches 3 * 2^29 per limb: one more loose limb would wrap the i32
     f29_add(M, M, a4);                          // M = 3 x^2 + a4, value within +-5.6 p
     f29_norm(M, M);
     f29_sqr(t, M);

@@ -69,10 +69,14 @@ struct Context {
     sbv::GroupBuffers grp;
     sbv::EdGroupBuffers edgrp;          // Ed25519 grouped step: per-batch combs of -A (the rest is shared with grp)
     bool group_enabled = true;
-    // Batches from this size on take the grouped step.  It used to be 2^18 (the table-building latency of a cold batch);
-    // since cached keys are grouped whatever their count (p256_group.h: group_assign_lane) and cold rare keys fall through to
-    // the doubling kernel inside the same step, a small batch loses nothing by it and a warm one skips the 256 doublings.
-    size_t group_min_batch = 4096;
+    // Batches from this size on take the grouped step.  With the key-table cache ON (the default) that is nearly every batch:
+    // cached keys are grouped whatever their count (p256_group.h: group_assign_lane), so a warm batch of a few thousand
+    // tuples runs the comb phases (2^12: 0.34 ms against 1.25 ms through the doubling kernel, profiles/r03/
+    // sweep_sizes_r03a.jsonl) and a cold one leaves its tables behind for the next.  With the cache OFF nothing outlives
+    // the call, and below ~2^17 tuples building tables costs more latency (~2 ms) than the doubling kernel takes (1.3-1.5 ms):
+    // group_min_batch_cold applies then.  sbv_p256_set_grouping(min_batch != 0) sets both.
+    size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17;
+    size_t group_min_batch_ed = (size_t)1 << 18;     // Ed25519 keeps no tables between batches: its cold crossover (round 2)
     u32 group_min_count = 64, group_max = 2048;
     bool kc_enabled = true;             // persistent key-table cache (p256_group.h)
     u32 kc_cap = 4096;                  // cached keys (270 KiB of HBM each)
@@ -105,7 +109,7 @@ constexpr int kMaxDevices = 16;
 // context when it is initialised and applied to every live context when they change — a setter called before sbv_init is not
 // lost, and after sbv_init_all it configures ALL devices, not just the default one.  Guarded by g_set_mu (a leaf lock).
 struct Settings {
-    bool group_enabled = true; size_t group_min_batch = 4096; u32 group_min_count = 64, group_max = 2048;
+    bool group_enabled = true; size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17, group_min_batch_ed = (size_t)1 << 18; u32 group_min_count = 64, group_max = 2048;
     bool kc_enabled = true; u32 kc_cap = 4096;
     bool profiling = false;
 } g_settings;
@@ -189,7 +193,8 @@ sbv::Scratch scratch_view(const Context& c) {
 std::vector<hipEvent_t*> group_events(Context& c) {
     sbv::GroupSync& y = c.gsync;
     std::vector<hipEvent_t*> v = {&y.ev_fork, &y.ev_assign, &y.ev_split, &y.ev_prep, &y.ev_generic};
-    for (int i = 0; i < SBV_GROUP_MAX_CHUNKS; ++i) { v.push_back(&y.ev_bases[i]); v.push_back(&y.ev_tables[i]); }
+    for (int i = 0; i < SBV_GROUP_MAX_TCHUNKS; ++i) v.push_back(&y.ev_bases[i]);
+    for (int i = 0; i < SBV_GROUP_MAX_CHUNKS; ++i) v.push_back(&y.ev_tables[i]);
     for (int i = 0; i < SBV_GROUP_MAX_SLICES; ++i) v.push_back(&y.ev_slice[i]);
     return v;
 }
@@ -279,7 +284,7 @@ int ensure_ed_group_buffers(Context& c, size_t n) {
 
 // one chunk (n <= cap) of Ed25519 tuples on `stream`: grouped step or the one-lane kernel
 int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream) {
-    if (c.group_enabled && n >= c.group_min_batch) {
+    if (c.group_enabled && n >= c.group_min_batch_ed) {
         const int rc = ensure_ed_group_buffers(c, n);
         if (rc != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
@@ -294,7 +299,7 @@ int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bi
 int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream,
             hipEvent_t after_prep, hipEvent_t* dom = nullptr, int* dom_pairs = nullptr, bool* was_grouped = nullptr) {
     const sbv::Scratch s = scratch_view(c);
-    const bool grouped = c.group_enabled && n >= c.group_min_batch;
+    const bool grouped = c.group_enabled && n >= (c.kc_enabled ? c.group_min_batch : c.group_min_batch_cold);
     if (was_grouped) *was_grouped = grouped;
     if (grouped) {
         const int rc = ensure_group_buffers(c, n);
@@ -438,6 +443,7 @@ int init_context(Context& c, int device) {
         const int v = atoi(e);
         if (v >= 1 && v <= SBV_GROUP_MAX_CHUNKS) c.gsync.chunks = v;
     }
+    if (const char* e = getenv("SBV_GROUP_TSUB")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.tsub = v; }
     if (const char* e = getenv("SBV_GROUP_PARTS")) c.gsync.parts = atoi(e);
     if (const char* e = getenv("SBV_GROUP_SLICES")) c.gsync.slices = atoi(e);
     if (const char* e = getenv("SBV_GROUP_SORT")) c.gsync.sorted = atoi(e) != 0;
@@ -458,12 +464,13 @@ int init_context(Context& c, int device) {
     {
         std::lock_guard<std::mutex> lk(g_set_mu);
         c.group_enabled = g_settings.group_enabled; c.group_min_batch = g_settings.group_min_batch;
+        c.group_min_batch_cold = g_settings.group_min_batch_cold; c.group_min_batch_ed = g_settings.group_min_batch_ed;
         c.group_min_count = g_settings.group_min_count; c.group_max = g_settings.group_max;
         c.kc_enabled = g_settings.kc_enabled; c.kc_cap = g_settings.kc_cap;
         c.profiling = g_settings.profiling;
     }
     if (const char* e = getenv("SBV_GROUP")) c.group_enabled = e[0] != '0';
-    if (const char* e = getenv("SBV_GROUP_MIN_BATCH")) { const long v = atol(e); if (v > 0) c.group_min_batch = (size_t)v; }
+    if (const char* e = getenv("SBV_GROUP_MIN_BATCH")) { const long v = atol(e); if (v > 0) c.group_min_batch = c.group_min_batch_cold = c.group_min_batch_ed = (size_t)v; }
     c.device = device;
     c.ready = true;
     g_err.clear();
@@ -1268,14 +1275,14 @@ extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min
     {
         std::lock_guard<std::mutex> lk(g_set_mu);
         g_settings.group_enabled = enabled != 0;
-        if (min_batch) g_settings.group_min_batch = min_batch;
+        if (min_batch) g_settings.group_min_batch = g_settings.group_min_batch_cold = g_settings.group_min_batch_ed = min_batch;
         if (min_count) g_settings.group_min_count = min_count;
         if (max_groups) g_settings.group_max = max_groups;
         st = g_settings;
     }
     for (Context* cp : live_contexts()) {
         std::lock_guard<std::mutex> lk(cp->mu);
-        cp->group_enabled = st.group_enabled; cp->group_min_batch = st.group_min_batch;
+        cp->group_enabled = st.group_enabled; cp->group_min_batch = st.group_min_batch; cp->group_min_batch_cold = st.group_min_batch_cold; cp->group_min_batch_ed = st.group_min_batch_ed;
         cp->group_min_count = st.group_min_count; cp->group_max = st.group_max;
     }
     return SBV_OK;

@@ -316,6 +316,35 @@ int sbve_keychain_dbl(const u32* x8, const u32* y8, int n, u32* outx, u32* outy)
     return ok;
 }
 
+// The whole per-batch table of ONE key as the grouped step builds it (k_keytab29_chain -> k_keytab29_rows -> k_keytab29_fill,
+// in `chunks` pieces): table = 33 x 128 entries of 16 words (x | y canonical words of the R = 2^261 domain).  key64 = Qx | Qy
+// big-endian.  Returns the key's pointFromAffine verdict.
+int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
+    std::vector<uint8_t> tup(160, 0);
+    memcpy(tup.data() + 96, key64, 64);
+    u32 rep0 = 0, counters[SBV_GROUP_COUNTERS] = {1};
+    GroupState g{};
+    g.group_rep = &rep0; g.counters = counters; g.max_groups = 1;
+    std::vector<u32> bases((size_t)SBV_GTAB_WINDOWS * SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS, 0xA5A5A5A5u), jstate(SBV_KT29_STATE_WORDS), tmpa(7 * SBV_KT29_FILL_TMP_WORDS);
+    uint8_t valid = 0xEE;
+    apt* ktab = reinterpret_cast<apt*>(table);
+    for (int c = 0; c < chunks; ++c) {
+        const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
+        keychain_quad_host q;
+        keychain29_run(q, tup.data(), 0, g, jstate.data(), bases.data(), &valid, j_first, j_end - 1);
+        for (int j = j_first; j < j_end; ++j) {
+            apt* row = ktab + (size_t)j * SBV_GTAB_PER_WINDOW;
+            for (int which = 0; which < 2; ++which) {
+                if (which == 1 && j == SBV_GTAB_WINDOWS - 1) continue;
+                keytab29_rows_lane(bases.data() + (size_t)j * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), which, j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
+            }
+            if (j == SBV_GTAB_WINDOWS - 1) continue;
+            for (int a = 1; a <= 7; ++a) keytab29_fill_lane(a, a, tmpa.data(), row);
+        }
+    }
+    return valid;
+}
+
 static bool g_keyed_coop = false;
 static unsigned long g_coop_disagreements = 0;
 // registered-key form: rsh = n x 96 B (r|s|hash), slots[i] indexes keys (nkeys x 64 B, Qx|Qy)

@@ -256,6 +256,29 @@ def test_quad_cooperative_doubling_chain_matches_bigint(emul):
             assert (wval(ox), wval(oy)) == ec.pt_mul(pow(2, n, ec.N), pt), (i, n)
 
 
+def test_key_table_of_the_key_that_wrapped_a_limb(emul):
+    """Regression (round 3, found by the GPU tier): for this key the giants lane of window 8 doubles a point whose x^2 has a
+    limb within 2^19 of 2^29 while the matching limb of a4 = -3 Z^4 sits above 2^29 — 3 x^2 + a4 formed without an
+    intermediate f29_norm wrapped the i32 and 97 of the key's 4097 table entries came out wrong.  The whole table
+    (k_keytab29_chain -> rows -> fill as the grouped step runs them) against k * 2^(8j) * Q from Python big integers."""
+    emul.sbve_keytab_build.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
+    key = bytes.fromhex("682f6f1f118445cb0a09ef3dc8e5c202fb3d60460e82f513d07bd5fece567f52"
+                        "cec0e52c50735a5480607398a6880d494a83013fa269b1442a36466fe2fcfee1")
+    q = (int.from_bytes(key[:32], "big"), int.from_bytes(key[32:], "big"))
+    tab = (ctypes.c_uint32 * (33 * 128 * 16))()
+    for chunks in (2, 3):
+        assert emul.sbve_keytab_build(key, chunks, tab) == 1
+        for j in (0, 7, 8, 9, 31, 32):
+            base = ec.pt_mul(pow(2, 8 * j, ec.N), q)
+            for m_ in ((1,) if j == 32 else (1, 2, 15, 16, 17, 31, 32, 33, 48, 100, 127, 128)):
+                e = tab[(j * 128 + m_ - 1) * 16:(j * 128 + m_) * 16]
+                want = ec.pt_mul(m_, base)
+                assert (wval(e[:8]), wval(e[8:])) == (want[0] * R % P, want[1] * R % P), (chunks, j, m_)
+    off = bytearray(key)
+    off[63] ^= 1
+    assert emul.sbve_keytab_build(bytes(off), 2, tab) == 0          # pointFromAffine refuses it (key29_load)
+
+
 def test_s29_scalar_field_matches_bigint(emul):
     """p256_sc29.h: Montgomery multiplication mod the group order N with R = 2^261, canonical form, inversion."""
     N = ec.N
