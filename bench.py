@@ -32,6 +32,10 @@ SEED = 0x5B7F2026
 # product multiply-accumulates, 9 reductions x 59 = 531, 9 for the zero filter — DESIGN.md §4.8; the static ISA mix of the
 # kernel is in profiles/r02/isa_stats_r02.txt).  Round 2's earlier runs used the pre-fusion count 1418 and reported 0.64-0.66.
 PEAK_LANE_MADS_PER_S = 33.8e12
+# comb additions of one grouped tuple's stage B: 13 for u1*G (20-bit comb of G, k_gphase_generic) + 32 key-comb windows and the
+# carry window in the 22 % of wavefronts that need it (p256_comb29.h: qphase29_point) = 32.22 for u2*Q (k_verify_keyed_q)
+G_ADDS_PER_TUPLE = 13.0
+Q_ADDS_PER_TUPLE = 32.22
 MADS_PER_MIXED_ADD = 738 + 531 + 9
 
 
@@ -255,6 +259,124 @@ def leg_secp256k1(sbv, torch, n, steps, stream):
             "algorithmic_GBps": 160.125 * n * steps / dt / 1e9}
 
 
+def leg_proposals():
+    """BASELINE.json configs[2] at its stated size: VerifyProposal of a K = 10 000-request proposal (4 nodes, f = 1) through
+    the C++ api.Verifier mirror (internal/bft/view.go:553-559 is the call site), host pointers in, verdict out — (a) client
+    keys registered on the device (comb slots, raw-messages front end), (b) client keys NOT registered: generic tuples with the
+    key inline, grouped by key inside the batch, tables kept by the key cache between proposals.  Median of 3 proposals."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hostlib
+    lib = hostlib.load()
+    cb = hostlib.BACKEND_FN(lambda *a: -1)
+    out = {"K": 10000, "n_nodes": 4, "unit": "us"}
+    for label, on_device in (("registered_client_keys", 1), ("unregistered_client_keys", 0)):
+        v = lib.sbvh_verifier_new(0, 0, cb, None, 1 << 20, 50, 0)
+        lib.sbvh_set_device_client_keys(v, on_device)
+        res = hostlib.ReplayResult()
+        rc = lib.sbvh_replay(v, 4, 10000, 3, 0, min(64, os.cpu_count() or 8), ctypes.byref(res))
+        lib.sbvh_verifier_free(v)
+        out[label] = {"verify_proposal_us": res.verify_proposal_us, "request_sigs_per_s": 10000 / (res.verify_proposal_us * 1e-6) if res.verify_proposal_us else None,
+                      "prev_commits_serial_us": res.prev_commits_us, "commit_quorum_us": res.commit_quorum_us} if rc == 0 and res.status == 0 else {"error": f"rc {rc} status {res.status}"}
+    return out
+
+
+def leg_replay_550k(sbv, synth):
+    """BASELINE.json configs[3] at its stated size: 50 000 proposals x 11 consenter signatures (N = 16: f = 5, Q = 11,
+    internal/bft/util.go:183-187) as ONE call of the native multi-device entry with group = 11, quorum = 10 (the Q - 1 votes a
+    replica needs besides its own: view.go:531) — host pointers in, accept bitmap + per-proposal quorum bits out (>= 10
+    accepted signatures by distinct keys, viewchanger.go:681-727).  16 signer keys, 1/8 of the signatures corrupted.  The
+    quorum bits are checked against bits recomputed from the oracle's verdicts on the first 10 000 proposals, the accept
+    bitmap against the generator's expectation on all 550 000."""
+    import numpy as np
+    group, quorum, props = 11, 10, 50000
+    n = group * props
+    tuples, valid = synth.gen_batch(SEED + 0x300, n, 16, 8)
+    got = np.zeros((n + 7) // 8, dtype=np.uint8)
+    qgot = np.zeros((props + 7) // 8, dtype=np.uint8)
+    sbv.init_all()
+    sbv.key_cache(True)          # a replaying replica sees the same 16 consenters proposal after proposal
+    try:
+        info = sbv.verify_batch_sharded(tuples.ctypes.data, n, got.ctypes.data, group, quorum, qgot.ctypes.data)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            info = sbv.verify_batch_sharded(tuples.ctypes.data, n, got.ctypes.data, group, quorum, qgot.ctypes.data)
+            ts.append(time.perf_counter() - t0)
+    finally:
+        sbv.key_cache(False)
+    dt = sorted(ts)[1]
+    bits = np.unpackbits(got, bitorder="little")[:n].reshape(props, group)
+    qbits = np.unpackbits(qgot, bitorder="little")[:props]
+    # independent statement of the rule on the generator's expectation (keys are distinct inside a proposal: tuple j is signed
+    # by key j % 16 and 11 consecutive tuples never repeat one; a corrupted key cannot verify)
+    want_bits = np.unpackbits(valid, bitorder="little")[:n].reshape(props, group)
+    want_q = (want_bits.sum(axis=1) >= quorum).astype(np.uint8)
+    sample_props = 10000
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsbv_oracle.so"))
+    lib.sbvo_p256_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+    ob = np.zeros((sample_props * group + 7) // 8, dtype=np.uint8)
+    lib.sbvo_p256_verify_batch(tuples.ctypes.data, sample_props * group, ob.ctypes.data, os.cpu_count() or 1)
+    oq = (np.unpackbits(ob, bitorder="little")[:sample_props * group].reshape(sample_props, group).sum(axis=1) >= quorum).astype(np.uint8)
+    return {"proposals": props, "signatures": n, "group": group, "quorum": quorum, "sigs_per_s": n / dt, "ms_per_call": 1e3 * dt,
+            "proposals_with_quorum": int(qbits.sum()), "accept_bitmap_correct": bool((bits == want_bits).all()),
+            "quorum_bits_equal_generator_rule": bool((qbits == want_q).all()),
+            "quorum_bits_equal_oracle_on_first_10000_proposals": bool((qbits[:sample_props] == oq).all()),
+            "devices": info.devices, "shards": info.shards,
+            "last_call_us": {"h2d": info.h2d_us, "kernels": info.kernels_us, "gather": info.gather_us, "total": info.total_us},
+            "note": "PCIe-inclusive (88 MB of tuples from host memory per call); key-table cache warm as for a replaying replica"}
+
+
+def leg_front_end(sbv, tuples, valid, n_all):
+    """SURVEY §8f row 1 measured end to end: raw messages + DER signatures + key slots in HOST memory -> accept bitmap in host
+    memory through sbv_p256_verify_msgs_keyed (SHA-256 and the strict DER parse run on the device).  2^18 signatures of the
+    headline batch: message j is rebuilt from the generator's rule, (r, s) re-encoded as DER; a tuple whose corruption hit the
+    hash gets a flipped message bit instead, one whose corruption hit the key keeps its signature but has no slot."""
+    import hashlib
+    import numpy as np
+    n = min(n_all, 1 << 18)
+    t2 = tuples.reshape(n_all, 160)[:n]
+    keys, counts = np.unique(tuples.reshape(n_all, 160)[:, 96:160], axis=0, return_counts=True)
+    keys = keys[counts >= 64]
+    sbv.clear_keys()
+    slots_of = dict(zip((bytes(k) for k in keys), sbv.register_keys([bytes(k) for k in keys])))
+    slots = [slots_of.get(bytes(k), 0xFFFFFFFF) for k in t2[:, 96:160]]
+    seed = SEED
+    msgs, sigs = [], []
+
+    def der_int(b):
+        b = b.lstrip(b"\0") or b"\0"
+        if b[0] & 0x80:
+            b = b"\0" + b
+        return b"\x02" + bytes([len(b)]) + b
+
+    vbits = np.unpackbits(valid, bitorder="little")
+    for j in range(n):
+        m = bytearray(32)
+        m[0:7] = b"sbv-msg"
+        m[8:12] = seed.to_bytes(4, "big")
+        m[24:32] = j.to_bytes(8, "big")
+        row = t2[j].tobytes()
+        if not vbits[j] and hashlib.sha256(bytes(m)).digest() != row[64:96]:
+            m[16] ^= 1                      # the generator flipped a bit of the hash: any other message does
+        body = der_int(row[0:32]) + der_int(row[32:64])
+        msgs.append(bytes(m))
+        sigs.append(b"\x30" + bytes([len(body)]) + body)
+    got = sbv.verify_msgs_keyed(msgs, sigs, slots)           # warm-up (staging buffers) and the verdicts
+    ok = bytes(got) == bytes(valid[:n // 8])
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        sbv.verify_msgs_keyed(msgs, sigs, slots)
+        ts.append(time.perf_counter() - t0)
+    tm = sbv.last_timing()
+    sbv.clear_keys()
+    dt = sorted(ts)[1]
+    return {"messages": n, "msgs_per_s": n / dt, "ms_per_call": 1e3 * dt, "bitmap_correct": ok,
+            "device_us": {"h2d": tm.h2d_us, "front_end_and_stage_a": tm.prep_us, "stage_b": tm.verify_us, "d2h": tm.d2h_us, "total": tm.total_us},
+            "msgs_per_s_device_side": n / (tm.total_us * 1e-6) if tm.total_us else None,
+            "note": "ms_per_call includes the Python binding's own packing of 2^18 byte strings; device_us is the library's split of the last call"}
+
+
 def leg_m2(tuples, n):
     """BASELINE.json's second metric — commit-quorum latency at N = 16 (Q = 11): wall time from "15 commit signatures in
     host memory" to ">= 10 accepted" (SURVEY.md §8d M2).  (a) gpu: the 15 concurrent VerifyConsenterSig calls of
@@ -297,11 +419,15 @@ def leg_m2(tuples, n):
             f(valid15.ctypes.data, 1, bm, 1)
             ts1.append(1e6 * (time.perf_counter() - t0))
         out[name.replace("cpu_15_threads", "cpu_one_verify")] = sorted(ts1)[len(ts1) // 2]
-    cpu = out.get("cpu_15_threads_openssl") or out.get("cpu_15_threads_oracle_port")
-    if cpu is not None and out.get("gpu") is not None:
-        out["hybrid"] = min(cpu, out["gpu"])
-        out["hybrid_note"] = ("a lone P-256 verification is a serial chain: quorum-sized batches are faster on host cores; the Go "
-                              "adapter routes batches below gpuMin to crypto/ecdsa and proposals / replay to the GPU (INTEGRATION.md)")
+    one = out.get("cpu_one_verify_openssl") or out.get("cpu_one_verify_oracle_port")
+    if one is not None and out.get("gpu") is not None:
+        # What a Verifier that may use either pays for the quorum: 15 goroutines on 15 free cores finish in ONE verification's
+        # time; the Go adapter's GPUMin decides which side a burst goes to (go/gpuverifier/verifier.go), and for a burst of 15 it
+        # is whichever of the two numbers is smaller on the box at hand.
+        out["hybrid"] = min(one, out["gpu"])
+        out["hybrid_route"] = "cpu" if one <= out["gpu"] else "gpu"
+        out["hybrid_note"] = ("min(one CPU verification = 15 running goroutines on 15 free cores, GPU micro-batch); the 15-pthread-spawn "
+                              "figures are not used for it (they are dominated by thread start-up)")
     out["cpu_note"] = ("cpu_15_threads_* spawn 15 pthreads per measurement (the checker libraries have no thread pool), so they "
                        "carry ~0.3-0.5 ms of thread start-up; cpu_one_verify_* is one verification on one core = what 15 already "
                        "running goroutines on 15 free cores would need")
@@ -448,7 +574,10 @@ def main():
                          ("sharded_entry", lambda: leg_sharded(sbv, tuples, valid, n, max(2, args.steps // 2))),
                          ("ed25519", lambda: leg_ed25519(sbv, torch, n, max(2, args.steps // 2), stream)),
                          ("secp256k1", lambda: leg_secp256k1(sbv, torch, min(n, 1 << 18), max(2, args.steps // 2), stream)),
-                         ("m2_commit_quorum_us", lambda: leg_m2(tuples, n))):
+                         ("m2_commit_quorum_us", lambda: leg_m2(tuples, n)),
+                         ("verify_proposal_k10000_us", leg_proposals),
+                         ("replay_550k", lambda: leg_replay_550k(sbv, synth)),
+                         ("front_end_msgs_per_s", lambda: leg_front_end(sbv, tuples, valid, n))):
             try:
                 extra[name] = fn()
             except Exception as e:      # noqa: BLE001 - the headline number must not depend on a secondary leg
@@ -466,14 +595,14 @@ def main():
         total = n * world * args.steps
         value = total / elapsed
         # dominant kernel.  Grouped batch: k_verify_keyed_q, the key-comb additions over the grouped tuples; it is
-        # launched once per chunk of windows, and one launch executes 33/chunks of the 50 comb additions (17 for
-        # u1*G in k_gphase_generic + 33 for u2*Q) that make up a grouped tuple's stage B — it is charged that share
+        # launched once per chunk of windows, and one launch executes 32.22/chunks of the 45.22 comb additions (13 for
+        # u1*G in k_gphase_generic + 32.22 for u2*Q) that make up a grouped tuple's stage B — it is charged that share
         # of the tuple's 160.125 algorithmic bytes.  Ungrouped batch: k_p256_verify, all of stage B, all n tuples.
         dom_launches_per_step = max(1, int(round(dominant_launches / max(1, launches))))
         kern_s = (dominant_us / max(1, dominant_launches)) * 1e-6
         if was_grouped:
             dom_name, dom_units = "k_verify_keyed_q", n_grouped
-            share = (33.0 / dom_launches_per_step) / 50.0
+            share = (Q_ADDS_PER_TUPLE / dom_launches_per_step) / (G_ADDS_PER_TUPLE + Q_ADDS_PER_TUPLE)
         else:
             dom_name, dom_units, share = "k_p256_verify", n, 1.0
         achieved = ALGO_BYTES_PER_VERIFY * dom_units * share / kern_s / 1e9
@@ -512,7 +641,7 @@ def main():
         if was_grouped:
             # 32 windows for every tuple + the carry window in the wavefronts that need it: 1 - (1 - 0.0039)^64 = 22 % for
             # uniform scalars (p256_comb29.h: qphase29_point)
-            adds_per_launch = 32.22 / dom_launches_per_step
+            adds_per_launch = Q_ADDS_PER_TUPLE / dom_launches_per_step
             mads_per_s = dom_units * adds_per_launch * MADS_PER_MIXED_ADD / kern_s
             line["int_mul_issue_fraction"] = {"value": mads_per_s / PEAK_LANE_MADS_PER_S, "lane_mads_per_s": mads_per_s,
                                               "peak_lane_mads_per_s": PEAK_LANE_MADS_PER_S, "kernel": dom_name,

@@ -351,11 +351,11 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
                                b.gacc, b.acc, gen_blocks, first, end);
         }
     }
-    // Chunks of windows: the chain on side_a, rows + fill on side_b, the Q phase on stream.  The tables are BUILT in finer
-    // pieces than they are consumed in (y.tsub pieces per Q-phase chunk): rows + fill of one piece run beside the chain of
-    // the next, so what is left after the chain's last doubling is the tail of a quarter of the windows, not of a half
-    // (it is what bounds a cold batch of 2^18: profiles/r03).  The Q phase keeps its two launches (every launch is one round
-    // trip of the accumulators).
+    // Chunks of windows: the chain on side_a, rows + fill on side_b, the Q phase on stream.  The tables CAN be built in finer
+    // pieces than they are consumed in (y.tsub pieces per Q-phase chunk, SBV_GROUP_TSUB) so that rows + fill of one piece run
+    // beside the chain of the next.  Measured and rejected as a default (profiles/r03/ab_tsub_parts_chunks_prio_r03c.jsonl):
+    // 2^20 cold 3.37-3.46 ms with one piece, 3.60-3.76 with two, 3.97-4.27 with three (2^18: 1.95-2.15 / 2.2-2.4 / 2.7-3.1) —
+    // every extra launch behind a cross-stream event costs more than the overlap buys.
     int tsub = y.tsub < 1 ? 1 : y.tsub;
     while (chunks * tsub > SBV_GROUP_MAX_TCHUNKS) --tsub;
     for (int c = 0; c < chunks; ++c) {

@@ -65,7 +65,7 @@ struct GroupSync {
     hipEvent_t ev_fork = nullptr, ev_assign = nullptr, ev_split = nullptr, ev_prep = nullptr, ev_generic = nullptr;
     hipEvent_t ev_bases[SBV_GROUP_MAX_TCHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
     int chunks = 1;
-    int tsub = 2;                   // P-256: table-building pieces per Q-phase chunk (SBV_GROUP_TSUB)
+    int tsub = 1;                   // P-256: table-building pieces per Q-phase chunk (SBV_GROUP_TSUB; measured: 1 is best, every extra launch + cross-stream wait costs more than the overlap buys — profiles/r03/ab_tsub_parts_chunks_prio_r03c.jsonl)
     int sorted = 1;                 // P-256: key-sorted grouped list + XCD-aware Q phase (SBV_GROUP_SORT=0: the split's compaction order)
     int parts = 1;                  // P-256: rows of 16 entries per lane of k_keytab29_fill (1, 2, 4, 7); Ed25519: lanes per (key, window)
 };

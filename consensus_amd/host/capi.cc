@@ -76,6 +76,8 @@ void sbvh_verifier_free(void* h) { delete (VHandle*)h; }
 uint64_t sbvh_backend_keyed_batches(void* h) { return ((VHandle*)h)->be->keyed_batches(); }
 void sbvh_register_consenter(void* h, uint64_t id, const uint8_t q[64]) { ((VHandle*)h)->v->RegisterConsenter(id, q); }
 void sbvh_register_client(void* h, const char* client, const uint8_t q[64]) { ((VHandle*)h)->v->RegisterClient(client, q); }
+// 0: clients registered from now on get no comb slot on the device (their request signatures go as generic tuples)
+void sbvh_set_device_client_keys(void* h, int on) { ((VHandle*)h)->v->SetDeviceClientKeys(on != 0); }
 void sbvh_set_verification_sequence(void* h, uint64_t s) { ((VHandle*)h)->v->SetVerificationSequence(s); }
 uint64_t sbvh_verification_sequence(void* h) { return ((VHandle*)h)->v->VerificationSequence(); }
 

@@ -427,7 +427,9 @@ void Verifier::RegisterConsenter(uint64_t id, const uint8_t* q) {
 // registered-key slots as the consenters': VerifyRequest / VerifyProposal then run 50 table additions per
 // signature instead of the 256-doubling chain of a key the device has never seen.
 void Verifier::RegisterClient(const std::string& client_id, const uint8_t* q) {
-    const long slot = ed() || k256() ? -1 : co_.backend().register_key(q);     // -1: no key registry (Ed25519: grouped per batch; secp256k1: no combs yet)
+    bool on_device;
+    { std::lock_guard<std::mutex> lk(mu_); on_device = opt_.device_client_keys; }
+    const long slot = ed() || k256() || !on_device ? -1 : co_.backend().register_key(q);     // -1: no key registry (Ed25519: grouped per batch; secp256k1: no combs yet)
     bytes key((const char*)q, key_bytes());
     key.resize(64, '\0');
     std::lock_guard<std::mutex> lk(mu_);

@@ -124,6 +124,10 @@ struct VerifierOptions {
     size_t coalesce_max = 4096;
     std::chrono::microseconds coalesce_wait{50};
     bool cache_verified = true;     // commit sigs of sequence s reappear at s+1 (view.go:376, 630)
+    // false: client keys are NOT given comb slots on the device; request signatures then travel as generic tuples with the
+    // key inline and the device groups them by key inside each batch (what an open client population gets: a replica
+    // cannot pre-register keys it has never seen).  Consenter keys are always registered.
+    bool device_client_keys = true;
 };
 
 class Verifier {
@@ -136,6 +140,7 @@ class Verifier {
     void RegisterConsenter(uint64_t id, const uint8_t* q);
     void RegisterClient(const std::string& client_id, const uint8_t* q);
     void SetVerificationSequence(uint64_t s);
+    void SetDeviceClientKeys(bool on) { std::lock_guard<std::mutex> lk(mu_); opt_.device_client_keys = on; }     // applies to clients registered afterwards
 
     // ---- api.Verifier ---------------------------------------------------------------------------
     Status VerifyProposal(const Proposal& proposal, std::vector<RequestInfo>* requests);

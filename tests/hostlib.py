@@ -40,6 +40,7 @@ def load():
     lib.sbvh_register_consenter.argtypes = [V, ctypes.c_uint64, ctypes.c_char_p]
     lib.sbvh_register_client.argtypes = [V, ctypes.c_char_p, ctypes.c_char_p]
     lib.sbvh_set_verification_sequence.argtypes = [V, ctypes.c_uint64]
+    lib.sbvh_set_device_client_keys.argtypes = [V, ctypes.c_int]
     lib.sbvh_verification_sequence.restype = ctypes.c_uint64
     lib.sbvh_verification_sequence.argtypes = [V]
     lib.sbvh_verify_signature.argtypes = [V, ctypes.c_uint64, ctypes.c_char_p, S, ctypes.c_char_p, S]

@@ -1,0 +1,170 @@
+"""GPU tier (`-m gpu`): the edge classes AT FULL SCALE.  The golden vectors (range edges, e = 0 / e >= N,
+keys off the curve / >= p / (0,0), Q = +-G, u1*G = +-u2*Q, R.x in [N, p), hash lengths, …) used to ride in batches of ~20 k
+tuples: three sort tiles, one launch.  Here every P-256 tuple vector is replicated 64 times — so that its key repeats often
+enough to take the table path — and spliced at pseudo-random positions into
+
+  * the 2^20 headline batch (128 sort tiles, all eight XCD eighths of the key-sorted Q phase), and
+  * a 2^21 + 2^19 + 37 batch (chunked at kMaxChunk = 2^21: the vectors land in both launches and in the ragged tail),
+
+with the key-table cache off, warm (second pass over the same batch) and overflowing (capacity 256 < 1024 signer keys).
+Every spliced verdict must equal the vector's pinned one and the oracle's, the rest of the bitmap the generator's (which the
+whole-batch oracle / OpenSSL tests of test_gpu_configs.py pin).  The Ed25519 and secp256k1 sets get the same treatment in
+their own 2^20 batches."""
+import ctypes
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import consensus_amd as sbv
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+THREADS = os.cpu_count() or 1
+COPIES = 64
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    sbv.init(0)
+    yield sbv
+    sbv.set_grouping(True, 0, 64, 0)
+    sbv.key_cache(True, 4096)
+
+
+def _splice(base, expect_bits, vectors, tuple_bytes, seed):
+    """base: uint8[n * tuple_bytes] (copied), expect_bits: uint8[n] 0/1 (copied); every vector (blob, accept) is written COPIES
+    times at positions drawn without replacement -> (batch, expected bits, positions per vector)."""
+    n = len(expect_bits)
+    batch = base.copy().reshape(n, tuple_bytes)
+    want = expect_bits.copy()
+    rng = random.Random(seed)
+    pos = rng.sample(range(n), COPIES * len(vectors))
+    where = []
+    for k, (blob, accept) in enumerate(vectors):
+        p = pos[k * COPIES:(k + 1) * COPIES]
+        batch[p] = np.frombuffer(blob, dtype=np.uint8)
+        want[p] = 1 if accept else 0
+        where.append(p)
+    return batch.reshape(-1), want, where
+
+
+def _report(got_bits, want_bits, where, names):
+    bad = np.nonzero(got_bits != want_bits)[0]
+    if len(bad) == 0:
+        return None
+    spliced = {p: names[k] for k, ps in enumerate(where) for p in ps}
+    return [(int(i), spliced.get(int(i), "base batch"), int(want_bits[i])) for i in bad[:12]], len(bad)
+
+
+def _bits(bitmap_bytes, n):
+    return np.unpackbits(np.frombuffer(bitmap_bytes, dtype=np.uint8), bitorder="little")[:n]
+
+
+def _p256_vectors():
+    vs = [v for v in json.load(open(os.path.join(GOLDEN, "p256_vectors.json")))["vectors"] if v["kind"] == "tuple"]
+    return vs, [(bytes.fromhex(v["tuple"]), v["accept"]) for v in vs]
+
+
+def _run_ptr(gpu, batch, n):
+    got = np.zeros((n + 7) // 8, dtype=np.uint8)
+    gpu.verify_batch_ptr(batch.ctypes.data, n, got.ctypes.data)
+    return _bits(got.tobytes(), n)
+
+
+def test_p256_edge_vectors_spliced_into_the_headline_batch_cache_off_warm_overflowing(gpu, oracle):
+    import synth
+    n = 1 << 20
+    tuples, valid = synth.gen_batch(0x5B7F2026, n)
+    vs, vecs = _p256_vectors()
+    batch, want, where = _splice(tuples, _bits(valid.tobytes(), n), vecs, 160, 0xED6E)
+    # the oracle's own opinion on every spliced tuple (the pinned `accept` values are its verdicts on the vectors; this guards the splice itself)
+    for k in range(0, len(vecs), 17):
+        assert oracle.sbvo_p256_verify_tuple(batch[160 * where[k][0]:160 * where[k][0] + 160].tobytes()) == (1 if vecs[k][1] else 0)
+    names = [v["name"] for v in vs]
+    gpu.set_grouping(True, 0, 32, 0)          # 64 copies clear a threshold of 32 with the sampled count to spare
+    try:
+        for label, setup in (("cache off", lambda: gpu.key_cache(False)),
+                             ("cache cold then warm", lambda: gpu.key_cache(True, 4096)),
+                             ("cache overflowing", lambda: (gpu.key_cache(False), gpu.key_cache(True, 256)))):
+            setup()
+            for rnd in range(2):
+                got = _run_ptr(gpu, batch, n)
+                assert _report(got, want, where, names) is None, (label, rnd, _report(got, want, where, names))
+            groups, grouped, generic, rejected = gpu.last_group_stats()
+            assert groups >= 1024 and grouped > 900000, (label, groups, grouped, generic, rejected)
+        # the all-distinct-keys kernel on the same spliced batch
+        gpu.key_cache(False)
+        gpu.set_grouping(False)
+        got = _run_ptr(gpu, batch, n)
+        assert _report(got, want, where, names) is None, ("grouping off", _report(got, want, where, names))
+    finally:
+        gpu.set_grouping(True, 0, 64, 0)
+        gpu.key_cache(True, 4096)
+
+
+def test_p256_edge_vectors_spliced_into_a_chunked_ragged_batch(gpu):
+    import synth
+    n1 = 1 << 20
+    tuples, valid = synth.gen_batch(0x5B7F2026, n1)
+    n = (1 << 21) + (1 << 19) + 37                         # two launches (2^21 + the rest) and a ragged tail
+    base = np.concatenate([tuples, tuples, tuples[:160 * (n - 2 * n1)]])
+    b1 = _bits(valid.tobytes(), n1)
+    bits = np.concatenate([b1, b1, b1[:n - 2 * n1]])
+    vs, vecs = _p256_vectors()
+    batch, want, where = _splice(base, bits, vecs, 160, 0xC4A6)
+    in_tail = sum(1 for ps in where for p in ps if p >= (1 << 21))
+    assert in_tail > 1000                                  # the second launch got its share of edge tuples
+    names = [v["name"] for v in vs]
+    gpu.set_grouping(True, 0, 32, 0)
+    try:
+        for label, setup in (("cache off", lambda: gpu.key_cache(False)), ("cache on, capacity 256", lambda: gpu.key_cache(True, 256)),
+                             ("cache on", lambda: (gpu.key_cache(False), gpu.key_cache(True, 4096)))):
+            setup()
+            for rnd in range(2):
+                got = _run_ptr(gpu, batch, n)
+                assert _report(got, want, where, names) is None, (label, rnd, _report(got, want, where, names))
+    finally:
+        gpu.set_grouping(True, 0, 64, 0)
+        gpu.key_cache(True, 4096)
+
+
+def test_ed25519_edge_vectors_spliced_into_2_20(gpu, oracle):
+    import ed25519_py as ed
+    oracle.sbvo_ed25519_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int]
+    n = 1 << 20
+    tup = np.zeros(128 * n, dtype=np.uint8)
+    exp = np.zeros(n // 8, dtype=np.uint8)
+    oracle.sbvo_ed25519_gen_batch(0x5B7F2026, n, 1024, 8, tup.ctypes.data, exp.ctypes.data, THREADS)
+    vs = json.load(open(os.path.join(GOLDEN, "ed25519_vectors.json")))["vectors"]
+    vecs = [(ed.pack_tuple(bytes.fromhex(v["pk"]), bytes.fromhex(v["msg"]), bytes.fromhex(v["sig"])), v["accept"]) for v in vs]
+    batch, want, where = _splice(tup, _bits(exp.tobytes(), n), vecs, 128, 0xED25)
+    names = [v["name"] for v in vs]
+    for grouping in (True, False):
+        gpu.set_grouping(grouping, 0, 32 if grouping else 0, 0)
+        try:
+            got = np.zeros(n // 8, dtype=np.uint8)
+            sbv._check(sbv.load().sbv_ed25519_verify_batch(ctypes.c_void_p(batch.ctypes.data), n, ctypes.c_void_p(got.ctypes.data)))
+            rep = _report(_bits(got.tobytes(), n), want, where, names)
+            assert rep is None, (grouping, rep)
+        finally:
+            gpu.set_grouping(True, 0, 64, 0)
+
+
+def test_secp256k1_edge_vectors_spliced_into_2_20(gpu, oracle):
+    oracle.sbvo_k256_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_int]
+    n = 1 << 20
+    tup = np.zeros(160 * n, dtype=np.uint8)
+    exp = np.zeros(n // 8, dtype=np.uint8)
+    oracle.sbvo_k256_gen_batch(0x5B7F2026, n, 1024, 8, tup.ctypes.data, exp.ctypes.data, THREADS)
+    vs = json.load(open(os.path.join(GOLDEN, "k256_vectors.json")))["vectors"]
+    vecs = [(bytes.fromhex(v["tuple"]), v["accept"]) for v in vs]
+    batch, want, where = _splice(tup, _bits(exp.tobytes(), n), vecs, 160, 0x256C1)
+    got = np.zeros(n // 8, dtype=np.uint8)
+    sbv._check(sbv.load().sbv_secp256k1_verify_batch(ctypes.c_void_p(batch.ctypes.data), n, ctypes.c_void_p(got.ctypes.data)))
+    rep = _report(_bits(got.tobytes(), n), want, where, [v["name"] for v in vs])
+    assert rep is None, rep
