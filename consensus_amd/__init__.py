@@ -371,8 +371,9 @@ def last_timing() -> Timing:
     return t
 
 
-def profile_enable(on: bool) -> None:
-    _check(load().sbv_profile_enable(1 if on else 0))
+def profile_enable(on) -> None:
+    """True / 1: step triples + dominant-kernel pairs; 2: dominant-kernel pairs only; False / 0: off."""
+    _check(load().sbv_profile_enable(2 if on == 2 else (1 if on else 0)))
 
 
 def profile_read():

@@ -92,7 +92,7 @@ struct Context {
     u32* d_slots = nullptr;             // staging for the host-pointer keyed entry (cap entries)
     size_t key_cap = 0, nkeys = 0;
     std::unordered_map<std::string, u32> key_index;
-    bool profiling = false;
+    int profiling = 0;                     // 0 off, 1 = step triples + dominant-kernel pairs, 2 = dominant-kernel pairs only
     std::vector<hipEvent_t> prof_events;   // triples: before prep, after prep, after verify
     std::vector<hipEvent_t> prof_dom;      // pairs around the dominant kernel of grouped batches (nullptr pair = ungrouped)
     size_t prof_dom_used = 0;
@@ -111,7 +111,7 @@ constexpr int kMaxDevices = 16;
 struct Settings {
     bool group_enabled = true; size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17, group_min_batch_ed = (size_t)1 << 18; u32 group_min_count = 64, group_max = 2048;
     bool kc_enabled = true; u32 kc_cap = 4096;
-    bool profiling = false;
+    int profiling = 0;
 } g_settings;
 std::mutex g_set_mu;
 std::unique_ptr<Context> g_ctxs[kMaxDevices];
@@ -603,7 +603,7 @@ extern "C" int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d
     for (size_t off = 0; off < n; off += kMaxChunk) {       // kMaxChunk is a multiple of 8
         const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
         hipEvent_t mid = nullptr, end = nullptr;
-        if (c.profiling) {
+        if (c.profiling == 1) {
             if (c.prof_used + 3 > c.prof_events.size()) {
                 for (int k = 0; k < 3; ++k) {
                     hipEvent_t ev;
@@ -1334,13 +1334,14 @@ extern "C" int sbv_p256_key_cache_stats(uint32_t out[4]) {
 }
 
 extern "C" int sbv_profile_enable(int on) {
+    const int level = on == 2 ? 2 : (on != 0 ? 1 : 0);
     {
         std::lock_guard<std::mutex> lk(g_set_mu);
-        g_settings.profiling = on != 0;
+        g_settings.profiling = level;
     }
     for (Context* cp : live_contexts()) {
         std::lock_guard<std::mutex> lk(cp->mu);
-        cp->profiling = on != 0;
+        cp->profiling = level;
     }
     return SBV_OK;
 }

@@ -14,13 +14,23 @@
 //
 //   - wire formats for signed client requests and consenter signature messages (the reference defines none:
 //     examples/naive_chain/chain.go:41-58 has unsigned transactions) — formats.go;
-//   - a key registry: types.Signature.ID selects the consenter key, Request.ClientID the client key;
-//   - a coalescer: the <= N-1 goroutines of View.processCommits (internal/bft/view.go:537-541) each call
-//     VerifyConsenterSig with one signature; they are merged into one backend batch;
+//   - a key registry: types.Signature.ID selects the consenter key, Request.ClientID the client key; P-256 keys are also
+//     registered with the device (Backend.RegisterKey -> sbv_p256_register_keys) and keep their comb slot;
+//   - routing inside the device backend (backend_cgo.go), the same four routes as the C++ mirror's SbvBackend: every
+//     item slotted -> raw messages + DER + slots (sbv_p256_verify_msgs_keyed: SHA-256 and DER on the device) or, for
+//     small batches, r|s|hash records + slots (sbv_p256_verify_batch_keyed); otherwise generic tuples over all GPUs of
+//     the node (sbv_p256_verify_batch_sharded); Options.Scheme selects Ed25519 (sbv_ed25519_verify_msgs) or secp256k1
+//     (sbv_secp256k1_verify_batch);
+//   - a coalescer for backends that take bursts: the <= N-1 goroutines of View.processCommits
+//     (internal/bft/view.go:537-541) each call VerifyConsenterSig with one signature; they are merged into one backend
+//     batch by a dispatcher that polls (spin, then yield — no timer) until the expected burst of N-1 is in, a quiet
+//     period passes or the window closes.  With the default GPUMin (32) a burst of a 16-node cluster never reaches the
+//     device and every vote is verified on its own goroutine's core instead;
 //   - VerifyProposal ships all K request signatures of a proposal as ONE batch (internal/bft/view.go:553-559);
 //   - a verified-signature cache with an injective key (commit signatures of sequence s come back as
 //     prev_commit_signatures at s+1: internal/bft/view.go:376, 630);
-//   - Proposal.Digest() computed once per proposal, also for concurrent first callers.
+//   - Proposal.Digest() computed once per proposal, also for concurrent first callers;
+//   - Signer.SignBatch: the batch form of api.Signer.Sign over sbv_p256_sign_batch (load generators, replay tools).
 //
 // A device fault is never reported as an invalid signature: VerifyProposal returning an error deposes the leader
 // (internal/bft/view.go:387-392), so on any backend error the batch is re-verified with crypto/ecdsa.

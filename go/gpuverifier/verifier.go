@@ -5,28 +5,36 @@ import (
 	"crypto/sha256"
 	"encoding/binary"
 	"errors"
+	"runtime"
 	"sync"
+	"sync/atomic"
 	"time"
 
 	bft "github.com/hyperledger-labs/SmartBFT/pkg/types"
 )
 
-// Options tune the adapter.
+// Options tune the adapter.  Counterpart of consensus_amd/host/verifier.h: struct VerifierOptions.
 type Options struct {
-	// GPUMin: batches with fewer signatures are verified with crypto/ecdsa on the calling goroutines' cores.  A lone
-	// P-256 verification is a serial chain; a GPU wins from a few hundred signatures in flight (a 15-signature commit
-	// quorum takes ~0.3 ms on the device against ~0.1 ms on 15 cores).  0 = always use the backend.
+	// Scheme: SchemeP256 (default), SchemeEd25519 or SchemeSecp256k1.  One Verifier = one scheme.
+	Scheme Scheme
+	// GPUMin: batches with fewer signatures are verified with the standard library on the calling goroutines' cores.
+	// Through the registered-key route a K = 100 proposal takes 0.27 ms on the device (16 cores need ~0.6 ms), a burst of
+	// 15 commit votes ~0.2 ms (15 idle cores: ~0.1 ms) — DESIGN.md section 5.  The default sends everything from 32
+	// signatures on to the device; 0 = always use the backend.
 	GPUMin int
-	// CoalesceWait / CoalesceMax: how long the dispatcher waits for further single-signature calls and how many it ships
-	// at once.
+	// CoalesceWait / CoalesceMax: the longest the dispatcher holds the first single-signature call back while it waits
+	// for the rest of a burst, and how many calls it ships at once.
 	CoalesceWait time.Duration
 	CoalesceMax  int
 	// CacheVerified keeps verdicts of single-signature calls (commit signatures of sequence s reappear at s+1).
 	CacheVerified bool
+	// DeviceClientKeys: register client keys with the device (comb slots) as consenter keys always are.  Switch it off
+	// for an open client population: request signatures then carry their key inline and the device groups them per batch.
+	DeviceClientKeys bool
 }
 
 // DefaultOptions are sized for a node with a GPU backend.
-var DefaultOptions = Options{GPUMin: 256, CoalesceWait: 50 * time.Microsecond, CoalesceMax: 4096, CacheVerified: true}
+var DefaultOptions = Options{GPUMin: 32, CoalesceWait: 50 * time.Microsecond, CoalesceMax: 4096, CacheVerified: true, DeviceClientKeys: true}
 
 type job struct {
 	item Item
@@ -41,6 +49,7 @@ type Verifier struct {
 	jobs    chan *job
 	stop    chan struct{}
 	wg      sync.WaitGroup
+	burst   int32 // expected size of a burst of single-signature calls: N - 1 commit votes (internal/bft/view.go:537-541); 0 = unknown
 
 	mu         sync.RWMutex
 	consenters map[uint64]regKey
@@ -55,7 +64,8 @@ type Verifier struct {
 }
 
 type regKey struct {
-	pub  *ecdsa.PublicKey
+	pub  *ecdsa.PublicKey // SchemeP256
+	raw  []byte           // the key bytes: Qx|Qy (P-256, secp256k1) or the 32-byte Ed25519 key
 	slot int32
 }
 
@@ -88,19 +98,61 @@ func (v *Verifier) Close() {
 }
 
 // RegisterConsenter / RegisterClient: the key registry (types.Signature.ID and Request.ClientID select the key).
+// P-256 keys are also given to the backend (RegisterKey -> sbv_p256_register_keys): a verification against a registered
+// key runs 46 comb additions and no doublings, and the batch can take the raw-messages route (SHA-256 and DER on the device).
 func (v *Verifier) RegisterConsenter(id uint64, pub *ecdsa.PublicKey) {
-	slot := v.backend.RegisterKey(pub)
+	k := regKey{pub: pub, raw: p256Raw(pub), slot: -1}
+	if v.opt.Scheme == SchemeP256 {
+		k.slot = v.backend.RegisterKey(pub)
+	}
 	v.mu.Lock()
-	v.consenters[id] = regKey{pub, slot}
+	v.consenters[id] = k
+	n := len(v.consenters)
 	v.mu.Unlock()
+	if n > 1 {
+		atomic.StoreInt32(&v.burst, int32(n-1))
+	}
 }
 
 func (v *Verifier) RegisterClient(clientID string, pub *ecdsa.PublicKey) {
-	slot := v.backend.RegisterKey(pub)
+	k := regKey{pub: pub, raw: p256Raw(pub), slot: -1}
+	if v.opt.Scheme == SchemeP256 && v.opt.DeviceClientKeys {
+		k.slot = v.backend.RegisterKey(pub)
+	}
 	v.mu.Lock()
-	v.clients[clientID] = regKey{pub, slot}
+	v.clients[clientID] = k
 	v.mu.Unlock()
 }
+
+// RegisterConsenterRaw / RegisterClientRaw: the registry for SchemeEd25519 (32-byte keys) and SchemeSecp256k1 (64 bytes
+// Qx|Qy big-endian); no device slots for these schemes (the device groups by key inside each batch).
+func (v *Verifier) RegisterConsenterRaw(id uint64, key []byte) {
+	v.mu.Lock()
+	v.consenters[id] = regKey{raw: append([]byte(nil), key...), slot: -1}
+	n := len(v.consenters)
+	v.mu.Unlock()
+	if n > 1 {
+		atomic.StoreInt32(&v.burst, int32(n-1))
+	}
+}
+
+func (v *Verifier) RegisterClientRaw(clientID string, key []byte) {
+	v.mu.Lock()
+	v.clients[clientID] = regKey{raw: append([]byte(nil), key...), slot: -1}
+	v.mu.Unlock()
+}
+
+func p256Raw(pub *ecdsa.PublicKey) []byte {
+	if pub == nil || pub.X == nil || pub.Y == nil || pub.X.Sign() < 0 || pub.Y.Sign() < 0 || pub.X.BitLen() > 256 || pub.Y.BitLen() > 256 {
+		return nil
+	}
+	kb := make([]byte, 64)
+	pub.X.FillBytes(kb[:32])
+	pub.Y.FillBytes(kb[32:])
+	return kb
+}
+
+func (k regKey) item(msg, sig []byte) Item { return Item{Pub: k.pub, Key: k.raw, Slot: k.slot, Msg: msg, Sig: sig} }
 
 // SetVerificationSequence is called by the application when its verification rules change (epoch / config update).
 func (v *Verifier) SetVerificationSequence(s uint64) {
@@ -123,21 +175,36 @@ func (v *Verifier) client(id string) (regKey, bool) {
 	return k, ok
 }
 
-// verifyBatch judges every item: the backend for batches of at least GPUMin, crypto/ecdsa otherwise — and crypto/ecdsa
-// again whenever the backend fails, so that a device fault can never look like an invalid signature.
+// verifyBatch judges every item: the backend for batches of at least GPUMin, the standard library otherwise — and the
+// standard library again whenever the backend fails, so that a device fault can never look like an invalid signature.
+// (secp256k1 has no standard-library verifier: when neither side can judge, ok is nil and the callers report
+// "could not verify", never "invalid".)
 func (v *Verifier) verifyBatch(items []Item) []bool {
 	if len(items) >= v.opt.GPUMin {
-		if ok, err := v.backend.Verify(items); err == nil && len(ok) == len(items) {
+		if ok, err := v.backend.Verify(v.opt.Scheme, items); err == nil && len(ok) == len(items) {
 			return ok
 		}
 	}
-	ok, _ := v.cpu.Verify(items)
+	ok, err := v.cpu.Verify(v.opt.Scheme, items)
+	if err != nil {
+		if ok2, err2 := v.backend.Verify(v.opt.Scheme, items); err2 == nil && len(ok2) == len(items) {
+			return ok2
+		}
+		return nil
+	}
 	return ok
 }
 
-// dispatch merges concurrent single-signature calls into one batch: it takes the first pending job, waits up to
-// CoalesceWait for more (the <= N-1 goroutines of View.processCommits arrive within microseconds of each other,
-// internal/bft/view.go:537-541) and ships them together.
+// dispatch merges concurrent single-signature calls into one batch: it takes the first pending job and polls the queue —
+// spin, then yield; no timer: Go's timers fire 50-100 us late at this scale, which is the whole budget — until
+//
+//	the expected burst is in (N - 1 votes: the goroutines of View.processCommits arrive within microseconds of one
+//	another, internal/bft/view.go:537-541), or
+//	nothing has arrived for a quiet period of CoalesceWait / 4 (a lone call — VerifyRequest from HandleRequest, the serial
+//	loop of verifyPrevCommitSignatures, internal/bft/view.go:630-644 — is not held back for the whole window), or
+//	CoalesceWait has passed since the first job, or CoalesceMax jobs are queued.
+//
+// Counterpart of consensus_amd/host/verifier.cc: Coalescer::run.
 func (v *Verifier) dispatch() {
 	defer v.wg.Done()
 	for {
@@ -148,37 +215,47 @@ func (v *Verifier) dispatch() {
 		case first = <-v.jobs:
 		}
 		batch := []*job{first}
-		timer := time.NewTimer(v.opt.CoalesceWait)
+		start := time.Now()
+		lastArrival := start
+		quiet := v.opt.CoalesceWait / 4
+		hint := int(atomic.LoadInt32(&v.burst))
 	collect:
 		for len(batch) < v.opt.CoalesceMax {
 			select {
 			case j := <-v.jobs:
 				batch = append(batch, j)
-			case <-timer.C:
+				lastArrival = time.Now()
+				continue
+			default:
+			}
+			if hint > 0 && len(batch) >= hint {
 				break collect
 			}
+			now := time.Now()
+			if now.Sub(start) >= v.opt.CoalesceWait || now.Sub(lastArrival) >= quiet {
+				break collect
+			}
+			runtime.Gosched()
 		}
-		timer.Stop()
 		items := make([]Item, len(batch))
 		for i, j := range batch {
 			items[i] = j.item
 		}
 		ok := v.verifyBatch(items)
 		for i, j := range batch {
-			j.done <- ok[i]
+			j.done <- ok != nil && ok[i]
 		}
 	}
 }
 
 // cacheKey must be injective in (key, signature, message): both variable-length fields are length-prefixed.  With a plain
 // concatenation a verified (sig, msg) would vouch for (sig + msg[:k], msg[k:]) — a message nobody signed.
-func cacheKey(pub *ecdsa.PublicKey, msg, sig []byte) [32]byte {
+func cacheKey(key, msg, sig []byte) [32]byte {
 	h := sha256.New()
-	var kb [64]byte
-	pub.X.FillBytes(kb[:32])
-	pub.Y.FillBytes(kb[32:])
-	h.Write(kb[:])
 	var l [8]byte
+	binary.LittleEndian.PutUint64(l[:], uint64(len(key)))
+	h.Write(l[:])
+	h.Write(key)
 	binary.LittleEndian.PutUint64(l[:], uint64(len(sig)))
 	h.Write(l[:])
 	h.Write(sig)
@@ -193,7 +270,7 @@ func cacheKey(pub *ecdsa.PublicKey, msg, sig []byte) [32]byte {
 func (v *Verifier) verifyOne(k regKey, msg, sig []byte) bool {
 	var key [32]byte
 	if v.opt.CacheVerified {
-		key = cacheKey(k.pub, msg, sig)
+		key = cacheKey(k.raw, msg, sig)
 		v.cacheMu.Lock()
 		ok, hit := v.cache[key]
 		v.cacheMu.Unlock()
@@ -201,9 +278,20 @@ func (v *Verifier) verifyOne(k regKey, msg, sig []byte) bool {
 			return ok
 		}
 	}
-	j := &job{item: Item{Pub: k.pub, Slot: k.slot, Msg: msg, Sig: sig}, done: make(chan bool, 1)}
-	v.jobs <- j
-	ok := <-j.done
+	var ok bool
+	if hint := int(atomic.LoadInt32(&v.burst)); v.opt.GPUMin > 1 && hint < v.opt.GPUMin {
+		// A burst of single-signature calls can never reach GPUMin (it is at most N - 1 votes): verify right here, on the
+		// calling goroutine's core — the reference's goroutines already are the parallelism (internal/bft/view.go:537-541).
+		verdict := v.verifyBatch([]Item{k.item(msg, sig)})
+		if verdict == nil {
+			return false // nobody could judge (secp256k1 without a device): an error for the caller, and nothing to remember
+		}
+		ok = verdict[0]
+	} else {
+		j := &job{item: k.item(msg, sig), done: make(chan bool, 1)}
+		v.jobs <- j
+		ok = <-j.done
+	}
 	if v.opt.CacheVerified {
 		v.cacheMu.Lock()
 		if len(v.cache) > 1<<20 {
@@ -340,9 +428,13 @@ func (v *Verifier) VerifyProposal(p bft.Proposal) ([]bft.RequestInfo, error) {
 		if !ok {
 			return nil, errors.New("unknown client")
 		}
-		items[i] = Item{Pub: k.pub, Slot: k.slot, Msg: r.Signed, Sig: r.Sig}
+		items[i] = k.item(r.Signed, r.Sig)
 	}
-	for _, ok := range v.verifyBatch(items) {
+	verdicts := v.verifyBatch(items)
+	if verdicts == nil && len(items) > 0 {
+		return nil, errors.New("could not verify the proposal's request signatures (no backend for this scheme)")
+	}
+	for _, ok := range verdicts {
 		if !ok {
 			return nil, errors.New("invalid request signature in proposal")
 		}
@@ -382,14 +474,14 @@ func (v *Verifier) VerifyDecisions(decisions []bft.Decision, quorum int) (decide
 			if !ok || !known || bound != dg {
 				continue
 			}
-			items = append(items, Item{Pub: k.pub, Slot: k.slot, Msg: s.Msg, Sig: s.Value})
+			items = append(items, k.item(s.Msg, s.Value))
 			refs = append(refs, ref{di, s.ID})
 		}
 	}
 	ok := v.verifyBatch(items)
 	seen := make([]map[uint64]bool, len(decisions))
 	for i, r := range refs {
-		if ok[i] {
+		if ok != nil && ok[i] {
 			if seen[r.d] == nil {
 				seen[r.d] = map[uint64]bool{}
 			}

@@ -1,9 +1,12 @@
 package gpuverifier
 
 import (
+	"bytes"
 	"crypto/ecdsa"
+	"crypto/ed25519"
 	"crypto/elliptic"
 	"crypto/rand"
+	"errors"
 	"fmt"
 	"sync"
 	"testing"
@@ -176,5 +179,316 @@ func TestVerifyDecisionsQuorum(t *testing.T) {
 	got := h.v.VerifyDecisions(ds, 11)
 	for d := range ds {
 		assert.Equal(t, !(d%5 == 0 || d%7 == 3), got[d], "decision %d", d)
+	}
+}
+
+// ---- the registered-key ("keyed") route ---------------------------------------------------------------------------------
+// recordingBackend stands below the seam the way mocks.VerifierMock stands above it in the reference's tests
+// (internal/bft/mocks/verifier_mock.go): it hands out key slots like sbv_p256_register_keys, records which route a batch
+// would take in backend_cgo.go (every item slotted -> the keyed entries; otherwise generic tuples) and judges with
+// crypto/ecdsa — resolving the key FROM THE SLOT when there is one, as the device does, so a wrong slot is a wrong verdict.
+type recordingBackend struct {
+	mu       sync.Mutex
+	keys     []*ecdsa.PublicKey
+	keyed    int // batches in which every item had a slot
+	generic  int
+	sizes    []int
+	failNext bool
+}
+
+func (b *recordingBackend) RegisterKey(pub *ecdsa.PublicKey) int32 {
+	b.mu.Lock()
+	defer b.mu.Unlock()
+	for i, k := range b.keys {
+		if k.X.Cmp(pub.X) == 0 && k.Y.Cmp(pub.Y) == 0 {
+			return int32(i)
+		}
+	}
+	b.keys = append(b.keys, pub)
+	return int32(len(b.keys) - 1)
+}
+
+func (b *recordingBackend) Verify(scheme Scheme, items []Item) ([]bool, error) {
+	b.mu.Lock()
+	defer b.mu.Unlock()
+	if b.failNext {
+		b.failNext = false
+		return nil, errors.New("device fault")
+	}
+	all := true
+	for _, it := range items {
+		all = all && it.Slot >= 0
+	}
+	if all {
+		b.keyed++
+	} else {
+		b.generic++
+	}
+	b.sizes = append(b.sizes, len(items))
+	resolved := make([]Item, len(items))
+	for i, it := range items {
+		resolved[i] = it
+		if it.Slot >= 0 {
+			resolved[i].Pub = nil
+			if int(it.Slot) < len(b.keys) {
+				resolved[i].Pub = b.keys[it.Slot]
+			}
+		}
+	}
+	return cpuBackend{}.Verify(scheme, resolved)
+}
+
+func (b *recordingBackend) SignBatch([][32]byte, []uint32, [][32]byte) ([][64]byte, []bool, error) {
+	return nil, nil, ErrNoBatchSigner
+}
+func (b *recordingBackend) Close() {}
+
+func newKeyedHarness(t *testing.T, n int, opt Options) (*harness, *recordingBackend) {
+	be := &recordingBackend{}
+	h := &harness{v: New(be, opt), clients: map[string]*ecdsa.PrivateKey{}}
+	for i := 1; i <= n; i++ {
+		k, _ := ecdsa.GenerateKey(elliptic.P256(), rand.Reader)
+		h.nodes = append(h.nodes, &Signer{ID: uint64(i), Key: k})
+		h.v.RegisterConsenter(uint64(i), &k.PublicKey)
+	}
+	for i := 0; i < 3; i++ {
+		k, _ := ecdsa.GenerateKey(elliptic.P256(), rand.Reader)
+		id := fmt.Sprintf("alice%d", i)
+		h.clients[id] = k
+		h.v.RegisterClient(id, &k.PublicKey)
+	}
+	return h, be
+}
+
+// TestBadCommit mirrors internal/bft/view_test.go:466 below the seam: there the VerifierMock answers every
+// VerifyConsenterSig with an error and the view must log "Couldn't verify 2's signature"; here the commit signatures are
+// real — one bound to a wrong digest, one with a damaged signature value — and the Verifier must be the one to refuse
+// them, through the registered-key route.
+func TestBadCommit(t *testing.T) {
+	opt := DefaultOptions
+	opt.GPUMin = 0
+	h, be := newKeyedHarness(t, 4, opt)
+	defer h.v.Close()
+	prop := bft.Proposal{Payload: PayloadEncode(nil), Header: []byte("h"), Metadata: []byte("m"), VerificationSequence: 0}
+	wrong := prop
+	wrong.Metadata = []byte("another proposal")
+	commitWrongDigest := h.nodes[0].SignProposal(wrong, nil)
+	_, err := h.v.VerifyConsenterSig(*commitWrongDigest, prop)
+	assert.Error(t, err) // "Got wrong digest"
+	commit2 := h.nodes[1].SignProposal(prop, nil)
+	commit2.Value[len(commit2.Value)-1] ^= 0x40
+	_, err = h.v.VerifyConsenterSig(*commit2, prop)
+	assert.Error(t, err) // "Couldn't verify 2's signature"
+	good := h.nodes[2].SignProposal(prop, nil)
+	_, err = h.v.VerifyConsenterSig(*good, prop)
+	assert.NoError(t, err)
+	stolen := *good
+	stolen.ID = 4 // node 3's signature presented as node 4's: the slot decides the key
+	_, err = h.v.VerifyConsenterSig(stolen, prop)
+	assert.Error(t, err)
+	assert.True(t, be.keyed >= 3 && be.generic == 0, "consenter signatures must take the keyed route: %d keyed, %d generic", be.keyed, be.generic)
+}
+
+// TestNormalPath mirrors internal/bft/view_test.go:533: one view taken through pre-prepare, prepare and commit to a
+// decision, twice — the Verifier traffic of a follower: VerifyProposal (view.go:555), the previous sequence's commit
+// signatures one by one (view.go:630-644), then N - 1 concurrent commit votes of which Q - 1 suffice (view.go:531-541).
+func TestNormalPath(t *testing.T) {
+	opt := DefaultOptions
+	opt.GPUMin = 0
+	h, be := newKeyedHarness(t, 4, opt)
+	defer h.v.Close()
+	var prev []*bft.Signature
+	var prevProp bft.Proposal
+	for seq := 0; seq < 2; seq++ {
+		var reqs [][]byte
+		for i := 0; i < 10; i++ {
+			reqs = append(reqs, h.request(fmt.Sprintf("alice%d", i%3), fmt.Sprintf("s%d-r%d", seq, i), false))
+		}
+		prop := bft.Proposal{Payload: PayloadEncode(reqs), Header: []byte{byte(seq)}, Metadata: []byte("md")}
+		infos, err := h.v.VerifyProposal(prop)
+		assert.NoError(t, err)
+		assert.Len(t, infos, 10)
+		for _, s := range prev { // verifyPrevCommitSignatures
+			_, err := h.v.VerifyConsenterSig(*s, prevProp)
+			assert.NoError(t, err)
+		}
+		var wg sync.WaitGroup
+		sigs := make([]*bft.Signature, 3)
+		errs := make([]error, 3)
+		for i := 0; i < 3; i++ { // nodes 2, 3, 4 vote; this node is 1
+			sigs[i] = h.nodes[i+1].SignProposal(prop, []byte("prepares"))
+			wg.Add(1)
+			go func(i int) {
+				defer wg.Done()
+				_, errs[i] = h.v.VerifyConsenterSig(*sigs[i], prop)
+			}(i)
+		}
+		wg.Wait()
+		for _, e := range errs {
+			assert.NoError(t, e)
+		}
+		prev, prevProp = sigs[:2], prop // Q - 1 = 2 signatures travel with the next pre-prepare
+	}
+	assert.Equal(t, 0, be.generic, "every key of this run is registered: nothing may take the generic route")
+	assert.True(t, be.keyed >= 4)
+	maxBatch := 0
+	for _, n := range be.sizes {
+		if n > maxBatch {
+			maxBatch = n
+		}
+	}
+	assert.Equal(t, 10, maxBatch, "the proposal's request signatures go as ONE batch")
+}
+
+// TestControllerLeaderRequestHandling mirrors internal/bft/controller_test.go:548 ("bad request" / "good request"): the
+// leader verifies a forwarded request before pooling it (controller.go:233-246); VerifyRequest's error is what keeps an
+// unauthorized request out of the pool.
+func TestControllerLeaderRequestHandling(t *testing.T) {
+	opt := DefaultOptions
+	opt.GPUMin = 0
+	h, be := newKeyedHarness(t, 4, opt)
+	defer h.v.Close()
+	for _, tc := range []struct {
+		description   string
+		req           []byte
+		shouldEnqueue bool
+	}{
+		{"bad request: damaged signature", h.request("alice0", "r1", true), false},
+		{"bad request: unauthorized user", SignRequest("mallory", "r2", []byte("tx"), h.clients["alice0"]), false},
+		{"bad request: someone else's key", SignRequest("alice1", "r3", []byte("tx"), h.clients["alice0"]), false},
+		{"good request", h.request("alice2", "r4", false), true},
+	} {
+		t.Run(tc.description, func(t *testing.T) {
+			info, err := h.v.VerifyRequest(tc.req)
+			if tc.shouldEnqueue {
+				assert.NoError(t, err)
+				assert.Equal(t, h.v.RequestID(tc.req), info)
+			} else {
+				assert.Error(t, err)
+			}
+		})
+	}
+	assert.Equal(t, 0, be.generic)
+}
+
+// TestReqPoolPrune mirrors internal/bft/requestpool_test.go:264: Pool.Prune keeps exactly the requests its predicate
+// accepts (requestpool.go:335-371); the predicate the Controller passes is VerifyRequest (controller.go:742-745).  Here a
+// client's key is revoked (re-registered with another key, as after a configuration change): its pooled requests go, the
+// others stay.
+func TestReqPoolPrune(t *testing.T) {
+	opt := DefaultOptions
+	opt.GPUMin = 0
+	h, _ := newKeyedHarness(t, 4, opt)
+	defer h.v.Close()
+	byteReq1 := h.request("alice0", "1", false)
+	byteReq2 := h.request("alice1", "2", false)
+	pool := [][]byte{byteReq1, byteReq2}
+	prune := func() [][]byte {
+		var kept [][]byte
+		for _, r := range pool {
+			if _, err := h.v.VerifyRequest(r); err == nil {
+				kept = append(kept, r)
+			}
+		}
+		return kept
+	}
+	assert.Len(t, prune(), 2)
+	fresh, _ := ecdsa.GenerateKey(elliptic.P256(), rand.Reader)
+	h.v.RegisterClient("alice0", &fresh.PublicKey) // revoked
+	kept := prune()
+	assert.Len(t, kept, 1)
+	assert.True(t, bytes.Equal(byteReq2, kept[0]))
+}
+
+// A device fault must never look like an invalid signature (internal/bft/view.go:387-392: a rejected proposal deposes the
+// leader): the batch is judged again by crypto/ecdsa.
+func TestDeviceFaultFallsBackToCPU(t *testing.T) {
+	opt := DefaultOptions
+	opt.GPUMin = 0
+	h, be := newKeyedHarness(t, 4, opt)
+	defer h.v.Close()
+	var reqs [][]byte
+	for i := 0; i < 40; i++ {
+		reqs = append(reqs, h.request(fmt.Sprintf("alice%d", i%3), fmt.Sprintf("r%d", i), false))
+	}
+	be.mu.Lock()
+	be.failNext = true
+	be.mu.Unlock()
+	_, err := h.v.VerifyProposal(bft.Proposal{Payload: PayloadEncode(reqs), Header: []byte("h"), Metadata: []byte("m")})
+	assert.NoError(t, err)
+}
+
+// With the default GPUMin a burst of N - 1 = 15 commit votes never reaches the device: each vote is verified on its own
+// goroutine's core; a K = 100 proposal does go to the backend, slotted.
+func TestDefaultRouting(t *testing.T) {
+	h, be := newKeyedHarness(t, 16, DefaultOptions)
+	defer h.v.Close()
+	prop := bft.Proposal{Payload: PayloadEncode(nil), Header: []byte("h"), Metadata: []byte("m")}
+	var wg sync.WaitGroup
+	for i := 0; i < 15; i++ {
+		wg.Add(1)
+		go func(i int) {
+			defer wg.Done()
+			_, err := h.v.VerifyConsenterSig(*h.nodes[i+1].SignProposal(prop, nil), prop)
+			assert.NoError(t, err)
+		}(i)
+	}
+	wg.Wait()
+	assert.Equal(t, 0, be.keyed+be.generic)
+	var reqs [][]byte
+	for i := 0; i < 100; i++ {
+		reqs = append(reqs, h.request(fmt.Sprintf("alice%d", i%3), fmt.Sprintf("r%d", i), false))
+	}
+	_, err := h.v.VerifyProposal(bft.Proposal{Payload: PayloadEncode(reqs), Header: []byte("h"), Metadata: []byte("m")})
+	assert.NoError(t, err)
+	assert.Equal(t, 1, be.keyed)
+	assert.Equal(t, 0, be.generic)
+}
+
+// Unregistered client keys (Options.DeviceClientKeys = false): request signatures travel as generic tuples.
+func TestOpenClientPopulationTakesTheGenericRoute(t *testing.T) {
+	opt := DefaultOptions
+	opt.GPUMin = 0
+	opt.DeviceClientKeys = false
+	h, be := newKeyedHarness(t, 4, opt)
+	defer h.v.Close()
+	_, err := h.v.VerifyRequest(h.request("alice0", "r", false))
+	assert.NoError(t, err)
+	assert.Equal(t, 1, be.generic)
+	assert.Equal(t, 0, be.keyed)
+}
+
+// SchemeEd25519: the same seam over crypto/ed25519 (BASELINE.json configs[4]).
+func TestEd25519Scheme(t *testing.T) {
+	opt := DefaultOptions
+	opt.Scheme = SchemeEd25519
+	v := New(nil, opt)
+	defer v.Close()
+	pub, priv, _ := ed25519.GenerateKey(rand.Reader)
+	v.RegisterConsenterRaw(1, pub)
+	msg := []byte("view data")
+	sig := ed25519.Sign(priv, msg)
+	assert.NoError(t, v.VerifySignature(bft.Signature{ID: 1, Value: sig, Msg: msg}))
+	assert.Error(t, v.VerifySignature(bft.Signature{ID: 1, Value: sig, Msg: append(msg, 'x')}))
+	assert.Error(t, v.VerifySignature(bft.Signature{ID: 1, Value: sig[:63], Msg: msg}))
+}
+
+// SchemeSecp256k1 without a device: nobody can judge, and that is reported as an error, never as a verdict.
+func TestSecp256k1WithoutDeviceCannotJudge(t *testing.T) {
+	opt := DefaultOptions
+	opt.Scheme = SchemeSecp256k1
+	v := New(nil, opt)
+	defer v.Close()
+	v.RegisterConsenterRaw(1, make([]byte, 64))
+	assert.Error(t, v.VerifySignature(bft.Signature{ID: 1, Value: []byte{0x30, 0x06, 2, 1, 1, 2, 1, 1}, Msg: []byte("m")}))
+}
+
+func TestSignBatchFallsBackToSign(t *testing.T) {
+	h, be := newKeyedHarness(t, 4, DefaultOptions)
+	defer h.v.Close()
+	msgs := [][]byte{[]byte("a"), []byte("b"), []byte("c")}
+	sigs := h.nodes[0].SignBatch(be, msgs)
+	for i, m := range msgs {
+		assert.NoError(t, h.v.VerifySignature(bft.Signature{ID: 1, Value: sigs[i], Msg: m}))
 	}
 }

@@ -178,7 +178,11 @@ int sbv_last_timing(sbv_timing* out);
 /* Per-kernel timing of the device-pointer entry (bench.py's roofline leg).  While enabled,
  * every sbv_p256_verify_batch_dev call records HIP events around its two kernels ON THE
  * CALLER'S STREAM; sbv_profile_read waits for them and returns the sums (microseconds) and the
- * number of stage-B launches since the previous read. */
+ * number of stage-B launches since the previous read.
+ * on = 1: an event triple per call (before stage A, after stage A, after stage B) AND a pair around every launch of the
+ * dominant kernel; on = 2: the dominant-kernel pairs only (what bench.py keeps inside its timed region: every recorded event
+ * is a packet between two kernels of the step); on = 0: off.  Process-wide: applies to every initialised device and to
+ * devices initialised later. */
 int sbv_profile_enable(int on);
 int sbv_profile_read(double* prep_us, double* verify_us, uint64_t* launches);
 /* Same window as sbv_profile_read (call it BEFORE sbv_profile_read, which resets): summed duration and number
