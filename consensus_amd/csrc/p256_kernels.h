@@ -18,6 +18,12 @@ hipError_t launch_p256_prep_blocks(const uint8_t* d_tuples, size_t n, const Scra
 hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
                                     const uint8_t* d_kvalid, const gcomb& d_gcomb, uint8_t* d_bitmap, uint8_t* d_rerun,
                                     hipStream_t stream);
+// latency form of small registered-key batches in one launch (p256_kernels.hip: k_p256_verify_keyed_small).  d_in: the device
+// view of a page-locked buffer holding n x 96 bytes r|s|hash and, at byte SBV_SMALL_MAX * 96, n u32 key slots; d_out: one
+// verdict byte per signature; d_done: system-scope counter, += 1 per signature when its verdict is visible.
+#define SBV_SMALL_MAX 64
+hipError_t launch_p256_verify_keyed_small(const void* d_in, size_t n, u32 nkeys, const apt* d_ktab, const uint8_t* d_kvalid, const gcomb& d_gcomb,
+                                          uint8_t* d_out, u32* d_done, hipStream_t stream);
 void host_build_gcomb(int bits, apt* out);   // `bits`-wide comb of G, 8 x 32 Montgomery domain: gcomb_entries(bits) entries
 hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const uint8_t* d_sigs, const u64* d_soff, size_t n,
                                u32* d_rsh, hipStream_t stream);

@@ -162,6 +162,79 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_coop(
     }
 }
 
+// The latency form in ONE launch (n <= SBV_SMALL_MAX: a commit quorum, a handful of serial single verifications): stage A
+// of a signature runs in lane 0 of its 8-lane group straight from the caller's page-locked input (mapped into the device's
+// address space: no staging copy, no scratch round trip), u1 / u2 / r reach the other lanes by shuffles, the 46 comb terms
+// and the butterfly are those of k_p256_verify_keyed_coop, and the verdict is written as one byte per signature into mapped
+// host memory followed by a system-scope counter the host polls — no copy back, no stream synchronisation on the way out.
+// in: n x 96 bytes r | s | hash (big-endian), then at byte SBV_SMALL_MAX * 96 the n key slots.
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_small(const u32* __restrict__ in, u32 n, u32 nkeys,
+                                                                              const apt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
+                                                                              gcomb g16, uint8_t* __restrict__ out, u32* __restrict__ done) {
+    const u32 lane_g = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    const u32 i = lane_g / SBV_COOP_LANES;
+    const int sub = (int)(lane_g % SBV_COOP_LANES);
+    const bool active = i < n;
+    u256 r, u1, u2;
+    SBV_UNROLL
+    for (int l = 0; l < 8; ++l) { r.v[l] = 0; u1.v[l] = 0; u2.v[l] = 0; }
+    u32 okw = 0, slot = 0;
+    if (active && sub == 0) {
+        const u32* t = in + (size_t)i * 24;
+        u256 s, h;
+        tuple_field(r, t, 0);
+        tuple_field(s, t, 1);
+        tuple_field(h, t, 2);
+        okw = stage_a_single(r, s, h, u1, u2) ? 1u : 0u;
+        slot = in[SBV_SMALL_MAX * 24 + i];
+    }
+    const int leader = (int)(threadIdx.x & 63u) & ~(SBV_COOP_LANES - 1);
+    SBV_UNROLL
+    for (int l = 0; l < 8; ++l) {
+        r.v[l] = (u32)__shfl((int)r.v[l], leader, 64);
+        u1.v[l] = (u32)__shfl((int)u1.v[l], leader, 64);
+        u2.v[l] = (u32)__shfl((int)u2.v[l], leader, 64);
+    }
+    okw = (u32)__shfl((int)okw, leader, 64);
+    slot = (u32)__shfl((int)slot, leader, 64);
+    xyzz R;
+    pt29_set_inf(R);
+    bool ok = false;
+    if (active) {
+        ok = okw != 0 && slot < nkeys;
+        if (slot >= nkeys) slot = 0;
+        ok = ok && kvalid[slot] != 0;
+        keyed29_partial_lane(R, u1, u2, ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW), g16, sub);
+    }
+    SBV_NOUNROLL
+    for (int off = SBV_COOP_LANES / 2; off >= 1; off >>= 1) {
+        xyzz P;
+        SBV_UNROLL
+        for (int l = 0; l < 9; ++l) {
+            P.X.v[l] = __shfl_xor(R.X.v[l], off, 64);
+            P.Y.v[l] = __shfl_xor(R.Y.v[l], off, 64);
+            P.ZZ.v[l] = __shfl_xor(R.ZZ.v[l], off, 64);
+            P.ZZZ.v[l] = __shfl_xor(R.ZZZ.v[l], off, 64);
+        }
+        P.inf = __shfl_xor(R.inf ? 1 : 0, off, 64) != 0;
+        pt29_add(R, P);
+    }
+    if (active && sub == 0) {
+        out[i] = ok && pt29_rx_matches(R, r) ? 1 : 0;
+        __threadfence_system();
+        __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_p256_verify_keyed_small(const void* d_in, size_t n, u32 nkeys, const apt* d_ktab, const uint8_t* d_kvalid, const gcomb& d_gtab,
+                                          uint8_t* d_out, u32* d_done, hipStream_t stream) {
+    if (n == 0 || n > SBV_SMALL_MAX) return hipErrorInvalidValue;
+    const size_t lanes = n * SBV_COOP_LANES;
+    hipLaunchKernelGGL(k_p256_verify_keyed_small, dim3((unsigned)((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK)), dim3(SBV_VERIFY_BLOCK), 0, stream,
+                       static_cast<const u32*>(d_in), (u32)n, nkeys, d_ktab, d_kvalid, d_gtab, d_out, d_done);
+    return hipGetLastError();
+}
+
 // Generic form (public key in the tuple), carry-free field: per-signature AFFINE window table in HBM (p256_comb29.h:
 // verify29_lane_generic), Jacobian accumulator with fused reductions.  qtab: SBV_QTAB29_WORDS words per lane.
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify(Scratch s, size_t n, u32* __restrict__ qtab, gcomb gc,

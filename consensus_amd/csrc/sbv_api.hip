@@ -86,6 +86,11 @@ struct Context {
     uint64_t* d_moff = nullptr; uint64_t* d_soff = nullptr; size_t moff_cap = 0, soff_cap = 0;
     sbv::aniels* d_btab = nullptr;      // Ed25519 base-point comb, built on first use
     sbv::kapt* d_k256_gtab = nullptr;   // secp256k1 comb of G (17 x 32768 entries), built on first use
+    // latency form of small registered-key batches (k_p256_verify_keyed_small): page-locked buffers mapped into the device's
+    // address space — input records + slots, one verdict byte per signature + the completion counter the host polls
+    uint8_t* h_small_in = nullptr; void* d_small_in = nullptr;
+    uint8_t* h_small_out = nullptr; void* d_small_out = nullptr;
+    bool small_enabled = true;
     // registered keys
     sbv::apt* d_ktab = nullptr;
     uint8_t* d_kvalid = nullptr;
@@ -469,6 +474,7 @@ int init_context(Context& c, int device) {
         c.kc_enabled = g_settings.kc_enabled; c.kc_cap = g_settings.kc_cap;
         c.profiling = g_settings.profiling;
     }
+    if (const char* e = getenv("SBV_SMALL")) c.small_enabled = e[0] != '0';
     if (const char* e = getenv("SBV_GROUP")) c.group_enabled = e[0] != '0';
     if (const char* e = getenv("SBV_GROUP_MIN_BATCH")) { const long v = atol(e); if (v > 0) c.group_min_batch = c.group_min_batch_cold = c.group_min_batch_ed = (size_t)v; }
     c.device = device;
@@ -546,6 +552,9 @@ int shutdown_context(Context& c) {
     if (c.d_kvalid) (void)hipFree(c.d_kvalid);
     c.d_ktab = nullptr; c.d_kvalid = nullptr; c.key_cap = c.nkeys = 0;
     c.key_index.clear();
+    if (c.h_small_in) (void)hipHostFree(c.h_small_in);
+    if (c.h_small_out) (void)hipHostFree(c.h_small_out);
+    c.h_small_in = c.h_small_out = nullptr; c.d_small_in = c.d_small_out = nullptr;
     for (auto& ev : c.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
     for (auto& ev : c.prof_events) (void)hipEventDestroy(ev);
     c.prof_events.clear();
@@ -890,6 +899,43 @@ extern "C" int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* s
     if (c.nkeys == 0) { g_err = "no keys registered"; return SBV_EINVAL; }
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    if (n <= SBV_SMALL_MAX && c.small_enabled) {
+        // The latency form: ONE launch, no staging copies.  The records go into a page-locked buffer the kernel reads over
+        // PCIe, every verdict comes back as a byte in mapped host memory, and this thread polls the completion counter
+        // instead of sleeping in a stream synchronisation (a commit quorum: 15 signatures, internal/bft/view.go:531-541).
+        if (!c.h_small_in) {
+            HIP_TRY(SBV_ENOMEM, hipHostMalloc(&c.h_small_in, SBV_SMALL_MAX * (96 + 4), hipHostMallocMapped));
+            HIP_TRY(SBV_ENOMEM, hipHostMalloc(&c.h_small_out, SBV_SMALL_MAX + 64, hipHostMallocMapped));
+            HIP_TRY(SBV_EDEVICE, hipHostGetDevicePointer(&c.d_small_in, c.h_small_in, 0));
+            HIP_TRY(SBV_EDEVICE, hipHostGetDevicePointer(&c.d_small_out, c.h_small_out, 0));
+        }
+        memcpy(c.h_small_in, rsh, n * 96);
+        memcpy(c.h_small_in + SBV_SMALL_MAX * 96, slots, n * sizeof(u32));
+        volatile u32* done = reinterpret_cast<volatile u32*>(c.h_small_out + SBV_SMALL_MAX);
+        *done = 0;
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_keyed_small(c.d_small_in, n, (u32)c.nkeys, c.d_ktab, c.d_kvalid, sbv::gcomb_make(c.d_g16r, c.g_bits),
+                                                               static_cast<uint8_t*>(c.d_small_out),
+                                                               reinterpret_cast<u32*>(static_cast<uint8_t*>(c.d_small_out) + SBV_SMALL_MAX), c.stream));
+        const auto give_up = t0 + std::chrono::milliseconds(5);
+        while (*done < (u32)n) {
+            if (std::chrono::steady_clock::now() > give_up) break;     // slow box / fault: let the runtime tell which
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (*done < (u32)n) HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(c.stream));
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        if (*done < (u32)n) { g_err = "the small-batch kernel did not report completion"; return SBV_EDEVICE; }
+        memset(accept_bitmap, 0, (n + 7) / 8);
+        for (size_t i = 0; i < n; ++i) if (c.h_small_out[i]) accept_bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
+        sbv_timing tm{};
+        tm.n = n;
+        tm.total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        tm.verify_us = tm.total_us;
+        c.timing = tm;
+        return SBV_OK;
+    }
     int rc = ensure_capacity(c, n < kMaxChunk ? n : kMaxChunk);
     if (rc != SBV_OK) return rc;
     if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(c.stream, c.busy, 0));

@@ -247,7 +247,7 @@ Coalescer::~Coalescer() {
     th_.join();
 }
 
-int Coalescer::submit(const uint8_t tuple[160], long slot, bool ed25519, bool k256) {
+int Coalescer::submit(const uint8_t tuple[160], long slot, bool ed25519, bool k256, std::string* err) {
     Job j;
     memcpy(j.tuple, tuple, ed25519 ? 128 : 160);
     j.slot = slot;
@@ -271,6 +271,7 @@ int Coalescer::submit(const uint8_t tuple[160], long slot, bool ed25519, bool k2
         }
         cpu_relax();
     }
+    if (err && j.result < 0) *err = j.err;
     return j.result;
 }
 
@@ -326,8 +327,11 @@ void Coalescer::run() {
             // First job is here: give concurrent callers a short window to join the batch.  The window is tens of
             // microseconds — below the kernel's timer slack, so a timed condition-variable wait would oversleep it by a
             // multiple; the dispatcher polls the queue length instead and leaves early when the expected burst is complete
-            // or — only while no burst size is known — nothing new has arrived for a quarter of the window (a burst of
-            // goroutines that start a few microseconds apart must not be cut into several serial round trips).
+            // or nothing new has arrived for a quiet period: a quarter of the window while no burst size is known, half of it
+            // when one is (the votes of a burst arrive a few microseconds apart and must not be cut into several serial round
+            // trips; but a LONE call — VerifyRequest from HandleRequest, the serial verifyPrevCommitSignatures loop of
+            // internal/bft/view.go:630-644, a view-change VerifySignature — must not sit out the whole window with this thread
+            // spinning either: at N = 16 that was 15 x 50 us per sequence).
             const auto t_first = std::chrono::steady_clock::now();
             const auto deadline = t_first + max_wait_;
             const auto quiet = max_wait_ / 4;
@@ -340,7 +344,7 @@ void Coalescer::run() {
                 const size_t hint = burst_hint_.load(std::memory_order_relaxed);
                 if (have >= max_batch_ || (hint && have >= hint) || now >= deadline) break;
                 if (have != seen) { seen = have; last = now; }
-                else if (!hint && now - last >= quiet) break;      // with a known burst size the window is waited out for it
+                else if (now - last >= (hint ? 2 * quiet : quiet)) break;
                 cpu_relax();
             }
             lk.lock();
@@ -373,11 +377,13 @@ void Coalescer::run() {
             for (size_t i = 0; i < n; ++i) memcpy(&tuples[i * 160], batch[i]->tuple, 160);
             rc = be_->verify(tuples.data(), n, bitmap.data());
         }
+        const std::string err_text = rc != 0 ? std::string(sbv_last_error()) : std::string();     // this thread made the failing call
         {
             std::lock_guard<std::mutex> lk(mu_);
             for (size_t i = 0; i < n; ++i) {
                 Job* job = batch[i];        // not touched after done: the submitter's stack frame may be gone
                 job->result = rc != 0 ? (rc < 0 ? rc : -1) : ((bitmap[i >> 3] >> (i & 7)) & 1);
+                if (rc != 0) job->err = err_text;
                 job->done.store(true, std::memory_order_release);
             }
         }
@@ -512,8 +518,9 @@ Status Verifier::verify_one(const uint8_t q[64], const bytes& msg, const bytes& 
     uint8_t t[160];
     if (ed()) make_tuple_ed25519(q, msg, sig, t);
     else make_tuple(q, msg, sig, t);
-    const int r = co_.submit(t, ed() || k256() ? -1 : slot, ed(), k256());
-    if (r < 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());
+    std::string err;
+    const int r = co_.submit(t, ed() || k256() ? -1 : slot, ed(), k256(), &err);
+    if (r < 0) return Status::Unavailable("backend error: " + err);
     if (opt_.cache_verified) {
         std::lock_guard<std::mutex> lk(cache_mu_);
         if (cache_.size() > (1u << 20)) cache_.clear();

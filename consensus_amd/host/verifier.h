@@ -85,7 +85,9 @@ class Coalescer {
     // 1 = accept, 0 = reject, <0 = backend error
     // slot >= 0: the signer's key is registered with the backend (tuple[96..160) is then ignored)
     // ed25519 = true: `tuple` holds a 128-byte R|S|A|k tuple instead (one Verifier = one scheme, so a burst never mixes)
-    int submit(const uint8_t tuple[160], long slot = -1, bool ed25519 = false, bool k256 = false);
+    // err (optional): on a backend error, the library's error text as the DISPATCHER thread saw it (sbv_last_error() is per
+    // thread, and the failing call ran there, not on the submitter)
+    int submit(const uint8_t tuple[160], long slot = -1, bool ed25519 = false, bool k256 = false, std::string* err = nullptr);
     int submit_many_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap);
     int submit_many_k256(const uint8_t* tuples, size_t n, uint8_t* bitmap);
     int submit_many(const uint8_t* tuples, size_t n, uint8_t* bitmap);
@@ -97,7 +99,7 @@ class Coalescer {
     void set_burst_hint(size_t n) { burst_hint_.store(n, std::memory_order_relaxed); }
 
  private:
-    struct Job { uint8_t tuple[160]; long slot = -1; bool ed25519 = false; bool k256 = false; int result = -100; std::atomic<bool> done{false}; };
+    struct Job { uint8_t tuple[160]; long slot = -1; bool ed25519 = false; bool k256 = false; int result = -100; std::string err; std::atomic<bool> done{false}; };
     void run();
     std::shared_ptr<Backend> be_;
     size_t max_batch_;

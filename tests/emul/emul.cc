@@ -345,8 +345,8 @@ int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
     return valid;
 }
 
-static bool g_keyed_coop = false;
-static unsigned long g_coop_disagreements = 0;
+static bool g_keyed_coop = false, g_keyed_small = false;
+static unsigned long g_coop_disagreements = 0, g_small_disagreements = 0;
 // registered-key form: rsh = n x 96 B (r|s|hash), slots[i] indexes keys (nkeys x 64 B, Qx|Qy)
 void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n, const uint8_t* keys, u32 nkeys,
                                   uint8_t* bitmap, int block, int T) {
@@ -388,6 +388,15 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
             soa_load(a, s.u1, s.cap, i);
             soa_load(b, s.u2, s.cap, i);
             soa_load(rr, s.r, s.cap, i);
+            if (g_keyed_small) {       // k_p256_verify_keyed_small: stage A of the one signature in registers, straight from the record
+                u256 sv, hv, a2, b2;
+                HostWords::W w{rsh + 96 * i};
+                tuple_field(rr, w, 0); tuple_field(sv, w, 1); tuple_field(hv, w, 2);
+                const bool ok1 = stage_a_single(rr, sv, hv, a2, b2);
+                if (ok1 != (s.ok[i] != 0) || (ok1 && (!eq256(a, a2) || !eq256(b, b2)))) g_small_disagreements++;
+                a = a2; b = b2;
+                okk = ok1 && slots[i] < nkeys && kvalid[slot] != 0;
+            }
             xyzz part[SBV_COOP_LANES];
             for (int sub = 0; sub < SBV_COOP_LANES; ++sub) keyed29_partial_lane(part[sub], a, b, &ktab[per_key * slot], g16rtab(), sub);
             for (int off = SBV_COOP_LANES / 2; off >= 1; off >>= 1) {
@@ -402,7 +411,8 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
         if (accept) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
     }
 }
-void sbve_set_keyed_coop(int on) { g_keyed_coop = on != 0; }
+void sbve_set_keyed_coop(int on) { g_keyed_coop = on != 0; g_keyed_small = on == 2; }       // 2: the one-launch latency form (stage A in registers)
+unsigned long sbve_small_disagreements() { return g_small_disagreements; }
 unsigned long sbve_coop_disagreements() { return g_coop_disagreements; }
 
 // device message front end (SHA-256 + strict DER) emulated: -> 96-byte r|s|hash record
