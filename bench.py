@@ -377,6 +377,77 @@ def leg_front_end(sbv, tuples, valid, n_all):
             "note": "ms_per_call includes the Python binding's own packing of 2^18 byte strings; device_us is the library's split of the last call"}
 
 
+def leg_projected_strong_scaling(sbv, torch, d_tuples, valid, n, stream, base_ms):
+    """PROJECTION, not a measurement of several GPUs: the one visible GPU runs, one after another, what each of G devices
+    would run for the SAME 2^20 batch, device-resident, key cache off (cold), and max over the parts stands for the step
+    time of a G-GPU node.  Two partitions: `by_key` (sbv_p256_verify_batch_dev_part: device g verifies the tuples of the
+    keys that hash to it — K / G tables, n / G tuples) and `contiguous` (device g verifies tuples [g n / G, (g+1) n / G) —
+    all K tables on every device: the round-2 design).  Not included: PCIe (every device of the by-key form receives the
+    whole batch; of the contiguous form 1 / G of it), the bitmap exchange (128 KiB: one all-reduce / all-gather), clock and
+    HBM contention between devices (none: they are separate packages)."""
+    import numpy as np
+    want = np.unpackbits(valid, bitorder="little")[:n]
+    out = {"base_ms_one_gpu_cold": base_ms, "label": "projection from one GPU running the parts sequentially", "partitions": {}}
+    words = (n + 31) // 32
+    d_full = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
+
+    def one_gpu_warm_ms():
+        sbv.key_cache(True)
+        try:
+            ts = []
+            for rep in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                sbv.verify_batch_dev(d_tuples.data_ptr(), n, d_full.data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            return 1e3 * sorted(ts[1:])[1]
+        finally:
+            sbv.key_cache(False)
+    warm_base = one_gpu_warm_ms()
+    out["base_ms_one_gpu_warm"] = warm_base
+    for G in (2, 4, 8):
+        row = {}
+        for label, warm, base in (("by_key", False, base_ms), ("by_key_warm_key_cache", True, warm_base)):
+            acc = np.zeros(n, dtype=np.uint8)
+            t_key = []
+            sbv.key_cache(warm)
+            try:
+                for g in range(G):
+                    d_w = torch.zeros(words, dtype=torch.int32, device="cuda")
+                    ts = []
+                    for rep in range(4):               # rep 0 warms allocations (and, with the cache on, this part's tables)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        sbv.verify_batch_dev_part(d_tuples.data_ptr(), n, g, G, d_w.data_ptr(), stream.cuda_stream)
+                        torch.cuda.synchronize()
+                        ts.append(time.perf_counter() - t0)
+                    t_key.append(sorted(ts[1:])[1])
+                    acc |= np.unpackbits(d_w.cpu().numpy().view(np.uint8), bitorder="little")[:n]
+            finally:
+                sbv.key_cache(False)
+            row[label] = {"max_part_ms": 1e3 * max(t_key), "mean_part_ms": 1e3 * sum(t_key) / G, "bitmap_correct": bool((acc == want).all()),
+                          "projected_speedup": base / (1e3 * max(t_key))}
+        per = (n // G + 511) // 512 * 512
+        t_con = []
+        ok = True
+        for g in range(G):
+            lo, hi = g * per, min(n, (g + 1) * per)
+            d_b = torch.zeros((hi - lo + 7) // 8, dtype=torch.uint8, device="cuda")
+            ts = []
+            for rep in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                sbv.verify_batch_dev(d_tuples.data_ptr() + 160 * lo, hi - lo, d_b.data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            t_con.append(sorted(ts[1:])[1])
+            ok = ok and bool((np.unpackbits(d_b.cpu().numpy(), bitorder="little")[:hi - lo] == want[lo:hi]).all())
+        row["contiguous"] = {"max_part_ms": 1e3 * max(t_con), "bitmap_correct": ok, "projected_speedup": base_ms / (1e3 * max(t_con))}
+        out["partitions"][f"G={G}"] = row
+    return out
+
+
 def leg_m2(tuples, n):
     """BASELINE.json's second metric — commit-quorum latency at N = 16 (Q = 11): wall time from "15 commit signatures in
     host memory" to ">= 10 accepted" (SURVEY.md §8d M2).  (a) gpu: the 15 concurrent VerifyConsenterSig calls of
@@ -590,6 +661,7 @@ def main():
                          ("sharded_entry", lambda: leg_sharded(sbv, tuples, valid, n, max(2, args.steps // 2))),
                          ("ed25519", lambda: leg_ed25519(sbv, torch, n, max(2, args.steps // 2), stream)),
                          ("secp256k1", lambda: leg_secp256k1(sbv, torch, min(n, 1 << 18), max(2, args.steps // 2), stream)),
+                         ("projected_strong_scaling", lambda: leg_projected_strong_scaling(sbv, torch, d_tuples, valid, n, stream, 1e3 * elapsed / args.steps)),
                          ("m2_commit_quorum_us", lambda: leg_m2(tuples, n)),
                          ("verify_proposal_k10000_us", leg_proposals),
                          ("replay_550k", lambda: leg_replay_550k(sbv, synth)),

@@ -359,6 +359,25 @@ def verify_batch_sharded(host_ptr: int, n: int, out_ptr: int, group: int = 0, qu
     return info
 
 
+def shard_mode(by_key: bool, parts: int = 0) -> None:
+    """sbv_shard_mode: how the sharded entry partitions a batch that spans devices (contiguous ranges / by key hash); parts = 0
+    means one part per device, more parts than devices run one after another on their device."""
+    lib = load()
+    lib.sbv_shard_mode.argtypes = [ctypes.c_int, ctypes.c_uint]
+    _check(lib.sbv_shard_mode(1 if by_key else 0, parts))
+
+
+def verify_batch_dev_part(d_tuples_ptr: int, n: int, part: int, parts: int, d_bitmap_words_ptr: int, stream: int = 0) -> int:
+    """sbv_p256_verify_batch_dev_part: part `part` of `parts` (by key hash) of n device-resident tuples; the bitmap (ceil(n/32)
+    words) receives that part's verdict bits.  Returns how many tuples the part held."""
+    lib = load()
+    lib.sbv_p256_verify_batch_dev_part.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                                   ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    members = ctypes.c_size_t(0)
+    _check(lib.sbv_p256_verify_batch_dev_part(d_tuples_ptr, n, part, parts, d_bitmap_words_ptr, stream, ctypes.byref(members)))
+    return members.value
+
+
 def verify_batch_on(device: int, host_ptr: int, n: int, out_ptr: int) -> None:
     lib = load()
     lib.sbv_p256_verify_batch_on.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]

@@ -145,7 +145,7 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_ED_KEY_WINDOWS * c / chunks, j_end = SBV_ED_KEY_WINDOWS * (c + 1) / chunks;
         const int j_count = j_end - j_first;
-        hipLaunchKernelGGL(k_ed_keytab_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jbases, b.kvalid,
+        hipLaunchKernelGGL(k_ed_keytab_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jbases, eb.kvalid,
                            j_first, j_end - 1);
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
         SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[c], 0));
@@ -154,7 +154,7 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
                            j_first, j_count, parts);
         SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
-        hipLaunchKernelGGL(k_ed_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, b.kvalid, b.gacc, b.gacc_cap,
+        hipLaunchKernelGGL(k_ed_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.gacc, b.gacc_cap,
                            eb.okb, b.acc, j_first, j_end, c + 1 == chunks ? 1 : 0);
     }
     // side_a, behind the last bases: the ungrouped list

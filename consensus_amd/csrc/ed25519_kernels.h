@@ -11,10 +11,13 @@ hipError_t launch_ed25519_verify(const uint8_t* d_tuples, size_t n, u32* d_qtab,
 struct EdGroupBuffers {
     aniels* ktab = nullptr;       // [max_groups][32 x 128] per-batch combs of -A
     uint8_t* okb = nullptr;       // [cap] S < L && k < L
+    uint8_t* kvalid = nullptr;    // [max_groups] 1 = the group's key decompressed.  NOT GroupBuffers::kvalid: bytes [0, kc.cap) of
+                                  // that array belong to the P-256 key-table cache and outlive the batch — an Ed25519 batch writing
+                                  // its own group verdicts there invalidated cached P-256 keys (found in round 3 by test order)
     size_t cap = 0;
     u32 max_groups = 0;
 };
-// Grouped step (ed25519_group.h).  `b` supplies the grouping arrays, jbases, tmp, kvalid, acc and gacc (32 words per
+// Grouped step (ed25519_group.h).  `b` supplies the grouping arrays, jbases, tmp, acc and gacc (32 words per
 // tuple, stride b.gacc_cap); ev_fork of `y` must have been recorded on `stream` before the call.
 hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, const GroupBuffers& b, const EdGroupBuffers& eb,
                                          u32* d_qtab, const aniels* d_btab, uint8_t* d_bitmap, hipStream_t stream,

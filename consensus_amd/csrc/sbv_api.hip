@@ -212,6 +212,7 @@ void free_group_buffers(Context& c) {
     b = sbv::GroupBuffers();
     if (c.edgrp.ktab) (void)hipFree(c.edgrp.ktab);
     if (c.edgrp.okb) (void)hipFree(c.edgrp.okb);
+    if (c.edgrp.kvalid) (void)hipFree(c.edgrp.kvalid);
     c.edgrp = sbv::EdGroupBuffers();
 }
 
@@ -279,9 +280,11 @@ int ensure_ed_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
     if (e.ktab) (void)hipFree(e.ktab);
     if (e.okb) (void)hipFree(e.okb);
+    if (e.kvalid) (void)hipFree(e.kvalid);
     e = sbv::EdGroupBuffers();
     HIP_TRY(SBV_ENOMEM, hipMalloc(&e.ktab, (size_t)c.grp.max_groups * SBV_ED_KEYTAB_ENTRIES_PER_KEY * sizeof(sbv::aniels)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&e.okb, c.grp.cap));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&e.kvalid, c.grp.max_groups));
     e.cap = c.grp.cap;
     e.max_groups = c.grp.max_groups;
     return SBV_OK;
@@ -301,10 +304,12 @@ int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bi
 }
 
 // enqueue stage A + stage B for n <= cap tuples on `stream`
+// decide_n: the batch size the grouped / one-lane decision is taken on (0 = n).  A key-affine part holds 1 / G of a batch's
+// tuples but each of its keys as often as the whole batch does: it groups whenever the whole batch would.
 int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream,
-            hipEvent_t after_prep, hipEvent_t* dom = nullptr, int* dom_pairs = nullptr, bool* was_grouped = nullptr) {
+            hipEvent_t after_prep, hipEvent_t* dom = nullptr, int* dom_pairs = nullptr, bool* was_grouped = nullptr, size_t decide_n = 0) {
     const sbv::Scratch s = scratch_view(c);
-    const bool grouped = c.group_enabled && n >= (c.kc_enabled ? c.group_min_batch : c.group_min_batch_cold);
+    const bool grouped = c.group_enabled && (decide_n ? decide_n : n) >= (c.kc_enabled ? c.group_min_batch : c.group_min_batch_cold);
     if (was_grouped) *was_grouped = grouped;
     if (grouped) {
         const int rc = ensure_group_buffers(c, n);
@@ -517,9 +522,13 @@ void rccl_teardown();
 // workers dropped their context locks).  d_on serves the calls that stay on one device (sbv_p256_verify_batch_on and the
 // replica route of the sharded entry) and is only touched under that device's context lock.
 struct ShardBuffers { uint8_t* d_gather = nullptr; size_t gather_cap = 0; uint8_t* d_q = nullptr; size_t q_cap = 0;
-                      uint8_t* d_on = nullptr; size_t on_cap = 0; uint8_t* d_onq = nullptr; size_t onq_cap = 0; };
+                      uint8_t* d_on = nullptr; size_t on_cap = 0; uint8_t* d_onq = nullptr; size_t onq_cap = 0;
+                      uint8_t* d_full = nullptr; size_t full_cap = 0; };       // key-affine mode: the whole batch on every device
 ShardBuffers g_shard[kMaxDevices];
 std::mutex g_sharded_mu;
+// staging of the key-affine partition (part_enqueue below), per device, under that device's context lock
+struct PartBuffers { uint8_t* d_dense = nullptr; u32* d_idx = nullptr; u32* d_count = nullptr; uint8_t* d_bits = nullptr; u32* h_count = nullptr; size_t cap = 0; };
+PartBuffers g_part[kMaxDevices];
 
 int shutdown_context(Context& c) {
     if (!c.ready) return SBV_OK;
@@ -533,7 +542,15 @@ int shutdown_context(Context& c) {
         if (sb.d_q) (void)hipFree(sb.d_q);
         if (sb.d_on) (void)hipFree(sb.d_on);
         if (sb.d_onq) (void)hipFree(sb.d_onq);
+        if (sb.d_full) (void)hipFree(sb.d_full);
         sb = ShardBuffers();
+        PartBuffers& pb = g_part[c.device];
+        if (pb.d_dense) (void)hipFree(pb.d_dense);
+        if (pb.d_idx) (void)hipFree(pb.d_idx);
+        if (pb.d_bits) (void)hipFree(pb.d_bits);
+        if (pb.d_count) (void)hipFree(pb.d_count);
+        if (pb.h_count) (void)hipHostFree(pb.h_count);
+        pb = PartBuffers();
     }
     if (c.d_gtab) (void)hipFree(c.d_gtab);
     c.d_gtab = nullptr;
@@ -1467,6 +1484,7 @@ struct RcclApi {
     int (*CommInitAll)(void**, int, const int*) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;     // key-affine partition: OR of disjoint bitmaps = their byte sum
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -1476,6 +1494,12 @@ struct RcclApi {
 std::vector<int> g_devs;               // devices initialised by sbv_init_all, ascending
 std::atomic<unsigned> g_rr{0};         // round-robin cursor of the replica route
 size_t g_shard_min = (size_t)1 << 18;  // tuples per device below which a batch is not split
+// How a batch that spans devices is partitioned: 0 = contiguous ranges of tuples (every device sees every key), 1 = by a
+// hash of the public key (device g builds the tables of its keys only; every device receives the whole batch).
+// g_shard_parts: parts of the key-affine partition; 0 = one per device.  More parts than devices run one after another on
+// their device (that is how one GPU rehearses an 8-GPU partition: tests, bench.py's projection leg).
+std::atomic<int> g_shard_mode{0};
+std::atomic<unsigned> g_shard_parts{0};
 
 void rccl_teardown() {                 // g_mu held
     if (g_rccl.ready) for (void* cm : g_rccl.comms) if (cm) (void)g_rccl.CommDestroy(cm);
@@ -1494,6 +1518,7 @@ bool rccl_setup() {
         g_rccl.CommInitAll = reinterpret_cast<int (*)(void**, int, const int*)>(dlsym(g_rccl.handle, "ncclCommInitAll"));
         g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(g_rccl.handle, "ncclCommDestroy"));
         g_rccl.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(g_rccl.handle, "ncclAllGather"));
+        g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(g_rccl.handle, "ncclAllReduce"));
         g_rccl.GroupStart = reinterpret_cast<int (*)()>(dlsym(g_rccl.handle, "ncclGroupStart"));
         g_rccl.GroupEnd = reinterpret_cast<int (*)()>(dlsym(g_rccl.handle, "ncclGroupEnd"));
         g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(g_rccl.handle, "ncclGetErrorString"));
@@ -1547,6 +1572,101 @@ __global__ __launch_bounds__(256) void k_quorum_bits(const uint8_t* __restrict__
         const size_t byte = (wave_first >> 3) + (size_t)lane;
         if (byte < ((nprops + 7) >> 3)) qbitmap[byte] = (uint8_t)(m >> (8 * lane));
     }
+}
+
+// ---- key-affine partition ---------------------------------------------------------------------------------
+// A contiguous split hands every device tuples of EVERY signer, so every device builds every key's tables: the one part of
+// a cold step that does not shrink with the shard.  Partitioning by a hash of the public key instead gives device g the
+// tuples of "its" keys only — K / G tables and n / G tuples.  Part g of G of a device-resident batch:
+//   k_part_select   membership by key hash, compaction of the member indices (one atomic per wavefront)
+//   k_part_gather   the member tuples copied into a dense staging batch (16 bytes per lane, coalesced)
+//   [the ordinary step on the dense batch]
+//   k_part_scatter  dense verdict bit j -> bit idx[j] of the caller's bitmap (zeroed first; atomicOr on 32-bit words)
+// The hash is NOT the grouping hash table's slot hash (its low bits would then be constant per device and every key would
+// land in 1 / G of the table).
+__device__ __forceinline__ u32 part_of_key(const uint8_t* tuples, size_t i, u32 parts) {
+    const u32* k = reinterpret_cast<const u32*>(tuples + i * SBV_TUPLE_BYTES + 96);
+    u32 h = 0x2545F491u;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { h = (h ^ k[j]) * 0x9E3779B1u; h ^= h >> 13; }
+    h *= 0x85EBCA77u;
+    return (h >> 11) % parts;
+}
+__global__ __launch_bounds__(256) void k_part_select(const uint8_t* __restrict__ tuples, size_t n, u32 part, u32 parts,
+                                                     u32* __restrict__ idx, u32* __restrict__ count) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool mine = i < n && part_of_key(tuples, i, parts) == part;
+    const unsigned long long m = __ballot(mine);
+    const int lane = threadIdx.x & 63;
+    u32 base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, (u32)__popcll(m));
+    base = (u32)__shfl((int)base, 0, 64);
+    if (mine) idx[base + (u32)__popcll(m & ((1ull << lane) - 1ull))] = (u32)i;
+}
+__global__ __launch_bounds__(256) void k_part_gather(const uint8_t* __restrict__ tuples, const u32* __restrict__ idx, size_t members,
+                                                     uint8_t* __restrict__ dense) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;            // 16-byte element of the dense batch
+    const size_t j = e / 10, part = e - j * 10;
+    if (j >= members) return;
+    reinterpret_cast<uint4*>(dense)[e] = reinterpret_cast<const uint4*>(tuples + (size_t)idx[j] * SBV_TUPLE_BYTES)[part];
+}
+__global__ __launch_bounds__(256) void k_part_scatter(const uint8_t* __restrict__ dense_bitmap, const u32* __restrict__ idx, size_t members,
+                                                      u32* __restrict__ out_words) {
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= members) return;
+    if ((dense_bitmap[j >> 3] >> (j & 7)) & 1u) { const u32 i = idx[j]; atomicOr(&out_words[i >> 5], 1u << (i & 31)); }
+}
+
+
+int ensure_part_buffers(Context& c, PartBuffers& pb, size_t n) {
+    const size_t want = (n + 1023) & ~(size_t)1023;
+    if (want <= pb.cap) return SBV_OK;
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    if (pb.d_dense) (void)hipFree(pb.d_dense);
+    if (pb.d_idx) (void)hipFree(pb.d_idx);
+    if (pb.d_bits) (void)hipFree(pb.d_bits);
+    pb.d_dense = nullptr; pb.d_idx = nullptr; pb.d_bits = nullptr; pb.cap = 0;
+    if (!pb.d_count) HIP_TRY(SBV_ENOMEM, hipMalloc(&pb.d_count, 64));
+    if (!pb.h_count) HIP_TRY(SBV_ENOMEM, hipHostMalloc(&pb.h_count, 64, hipHostMallocDefault));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&pb.d_dense, want * SBV_TUPLE_BYTES));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&pb.d_idx, want * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&pb.d_bits, want / 8 + 64));
+    pb.cap = want;
+    (void)c;
+    return SBV_OK;
+}
+
+// Part `part` of `parts` of n device-resident tuples on `stream`; c.mu held.  d_out_words: ceil(n / 32) words, receives the
+// verdict bits of this part's tuples (every other bit 0).  One host round trip (the member count sizes the launches).
+int part_enqueue(Context& c, const uint8_t* d_tuples, size_t n, u32 part, u32 parts, u32* d_out_words, hipStream_t stream, size_t* members_out,
+                 bool zero_first = true) {
+    PartBuffers& pb = g_part[c.device];
+    if (zero_first) HIP_TRY(SBV_EDEVICE, hipMemsetAsync(d_out_words, 0, ((n + 31) / 32) * sizeof(u32), stream));
+    size_t total = 0;
+    for (size_t off = 0; off < n; off += kMaxChunk) {                  // kMaxChunk is a multiple of 32
+        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+        int rc = ensure_part_buffers(c, pb, m);
+        if (rc != SBV_OK) return rc;
+        const uint8_t* src = d_tuples + off * SBV_TUPLE_BYTES;
+        HIP_TRY(SBV_EDEVICE, hipMemsetAsync(pb.d_count, 0, sizeof(u32), stream));
+        hipLaunchKernelGGL(k_part_select, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, src, m, part, parts, pb.d_idx, pb.d_count);
+        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(pb.h_count, pb.d_count, sizeof(u32), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(stream));
+        const size_t members = *pb.h_count;
+        total += members;
+        if (members == 0) continue;
+        hipLaunchKernelGGL(k_part_gather, dim3((unsigned)((members * 10 + 255) / 256)), dim3(256), 0, stream, src, pb.d_idx, members, pb.d_dense);
+        if ((rc = ensure_capacity(c, members)) != SBV_OK) return rc;
+        if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(stream, c.busy, 0));
+        rc = enqueue(c, pb.d_dense, members, pb.d_bits, stream, nullptr, nullptr, nullptr, nullptr, n);
+        if (hipEventRecord(c.busy, stream) == hipSuccess) c.busy_valid = true;
+        if (rc != SBV_OK) return rc;
+        hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((members + 255) / 256)), dim3(256), 0, stream, pb.d_bits, pb.d_idx, members, d_out_words + off / 32);
+        HIP_TRY(SBV_EDEVICE, hipGetLastError());
+        if (off + kMaxChunk < n) HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(stream));       // the staging buffers are reused by the next chunk
+    }
+    if (members_out) *members_out = total;
+    return SBV_OK;
 }
 
 // One device's share of a sharded call; c.mu held.  Chunks of at most kMaxChunk tuples (a multiple of the granule):
@@ -1635,6 +1755,8 @@ extern "C" int sbv_init_all(void) {
         g_devs = devs;
     }
     if (const char* e = getenv("SBV_SHARD_MIN")) { const long v = atol(e); if (v > 0) g_shard_min = (size_t)v; }
+    if (const char* e = getenv("SBV_SHARD_MODE")) g_shard_mode.store(strcmp(e, "keys") == 0 ? 1 : 0);
+    if (const char* e = getenv("SBV_SHARD_PARTS")) { const long v = atol(e); if (v >= 0 && v <= 64) g_shard_parts.store((unsigned)v); }
     const char* force = getenv("SBV_RCCL");
     if (g_devs.size() > 1 || (force && force[0] == '1')) (void)rccl_setup();     // failure -> host-side gather
     return (int)g_devs.size();
@@ -1650,6 +1772,116 @@ extern "C" int sbv_initialised_devices(int* out, int max) {
     }
     return k;
 }
+
+extern "C" int sbv_shard_mode(int by_key, unsigned parts) {
+    g_shard_mode.store(by_key ? 1 : 0);
+    g_shard_parts.store(parts > 64 ? 64u : parts);
+    return SBV_OK;
+}
+
+namespace {
+// The key-affine form of the sharded entry: every participating device receives the whole batch over its own PCIe link,
+// verifies the tuples of its parts (part p runs on device p % devices) and leaves their verdict bits in a full-size bitmap
+// of its own; the bitmaps have disjoint bits, so their OR is their byte-wise SUM: one in-place ncclAllReduce(sum, uint8)
+// when RCCL is up, an OR on the host otherwise.  The per-proposal quorum bits need all of a proposal's verdicts, which now
+// live on different devices: they are computed on the first device from the combined bitmap.
+int sharded_by_key(const uint8_t* tuples, size_t n, size_t group, u32 quorum, uint8_t* accept_bitmap, uint8_t* quorum_bitmap,
+                   sbv_shard_info* info, const std::vector<int>& devs, unsigned parts, bool use_rccl) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t ndev = devs.size() < parts ? devs.size() : parts;
+    const size_t words = (n + 31) / 32, bytes = (n + 7) / 8;
+    std::vector<int> rcs(ndev, SBV_OK);
+    std::vector<std::string> errs(ndev);
+    std::vector<double> h2d(ndev, 0.0), kern(ndev, 0.0);
+    std::vector<std::vector<uint8_t>> host_bits(use_rccl ? 0 : ndev);
+    std::unique_lock<std::mutex> sharded_lk(g_sharded_mu);
+    auto work = [&](size_t d) {
+        Context* c;
+        { std::lock_guard<std::mutex> lk(g_mu); c = g_ctxs[devs[d]].get(); }
+        std::lock_guard<std::mutex> lkc(c->mu);
+        ShardBuffers& sbuf = g_shard[devs[d]];
+        int rc = SBV_OK;
+        auto step = [&](hipError_t e, const char* what) { if (rc == SBV_OK && e != hipSuccess) rc = fail(SBV_EDEVICE, what, e); };
+        if (!c->ready) { g_err = "device not initialised"; rc = SBV_ENOTINIT; }
+        if (rc == SBV_OK) step(hipSetDevice(c->device), "hipSetDevice");
+        if (rc == SBV_OK) rc = grow_bytes(sbuf.d_full, sbuf.full_cap, n * SBV_TUPLE_BYTES + 64);
+        if (rc == SBV_OK) rc = grow_bytes(sbuf.d_gather, sbuf.gather_cap, words * 4 + 64);
+        if (rc == SBV_OK) {
+            step(hipEventRecord(c->ev[0], c->stream), "hipEventRecord");
+            step(hipMemcpyAsync(sbuf.d_full, tuples, n * SBV_TUPLE_BYTES, hipMemcpyHostToDevice, c->stream), "H2D of the batch");
+            step(hipEventRecord(c->ev[1], c->stream), "hipEventRecord");
+            step(hipMemsetAsync(sbuf.d_gather, 0, words * 4, c->stream), "hipMemsetAsync");
+        }
+        for (unsigned p = (unsigned)d; rc == SBV_OK && p < parts; p += (unsigned)ndev)
+            rc = part_enqueue(*c, sbuf.d_full, n, p, parts, reinterpret_cast<u32*>(sbuf.d_gather), c->stream, nullptr, false);
+        if (rc == SBV_OK) {
+            step(hipEventRecord(c->ev[3], c->stream), "hipEventRecord");
+            if (!use_rccl) {
+                host_bits[d].resize(bytes);
+                step(hipMemcpyAsync(host_bits[d].data(), sbuf.d_gather, bytes, hipMemcpyDeviceToHost, c->stream), "D2H of a device's bitmap");
+            }
+            step(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+            if (rc == SBV_OK) { h2d[d] = 1e3 * ms_between(c->ev[0], c->ev[1]); kern[d] = 1e3 * ms_between(c->ev[1], c->ev[3]); }
+        }
+        rcs[d] = rc;
+        if (rc != SBV_OK) errs[d] = g_err;
+    };
+    if (ndev == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t d = 0; d < ndev; ++d) th.emplace_back(work, d);
+        for (auto& t : th) t.join();
+    }
+    for (size_t d = 0; d < ndev; ++d)
+        if (rcs[d] != SBV_OK) { g_err = "device " + std::to_string(devs[d]) + ": " + errs[d]; return rcs[d]; }
+    const auto t1 = std::chrono::steady_clock::now();
+    Context* c0;
+    { std::lock_guard<std::mutex> lk(g_mu); c0 = g_ctxs[devs[0]].get(); }
+    if (use_rccl) {
+        std::lock_guard<std::mutex> lk(g_mu);                    // the communicators
+        bool ok = g_rccl.ready && g_rccl.AllReduce && ndev == g_devs.size() && g_rccl.GroupStart() == 0;
+        for (size_t d = 0; ok && d < ndev; ++d) {
+            size_t rank = 0;
+            while (rank < g_devs.size() && g_devs[rank] != devs[d]) ++rank;
+            ok = rank < g_devs.size() && hipSetDevice(devs[d]) == hipSuccess;
+            ShardBuffers& sbuf = g_shard[devs[d]];
+            if (ok) ok = g_rccl.AllReduce(sbuf.d_gather, sbuf.d_gather, words * 4, /*ncclUint8*/ 1, /*ncclSum*/ 0, g_rccl.comms[rank], g_ctxs[devs[d]]->stream) == 0;
+        }
+        if (ok) ok = g_rccl.GroupEnd() == 0;
+        if (ok) ok = hipSetDevice(devs[0]) == hipSuccess &&
+                     hipMemcpyAsync(accept_bitmap, g_shard[devs[0]].d_gather, bytes, hipMemcpyDeviceToHost, c0->stream) == hipSuccess &&
+                     hipStreamSynchronize(c0->stream) == hipSuccess;
+        for (size_t d = 1; ok && d < ndev; ++d) ok = hipSetDevice(devs[d]) == hipSuccess && hipStreamSynchronize(g_ctxs[devs[d]]->stream) == hipSuccess;
+        if (!ok) { g_err = "RCCL all-reduce of the per-device bitmaps failed"; return SBV_EDEVICE; }
+    } else {
+        memcpy(accept_bitmap, host_bits[0].data(), bytes);
+        for (size_t d = 1; d < ndev; ++d)
+            for (size_t b = 0; b < bytes; ++b) accept_bitmap[b] |= host_bits[d][b];
+    }
+    if (quorum_bitmap && group > 0 && quorum > 0 && n / group > 0) {
+        std::lock_guard<std::mutex> lkc(c0->mu);
+        ShardBuffers& sbuf = g_shard[devs[0]];
+        const size_t props = n / group;
+        HIP_TRY(SBV_EDEVICE, hipSetDevice(c0->device));
+        int rc = grow_bytes(sbuf.d_q, sbuf.q_cap, (props + 7) / 8 + 64);
+        if (rc != SBV_OK) return rc;
+        if (!use_rccl) HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(sbuf.d_gather, accept_bitmap, bytes, hipMemcpyHostToDevice, c0->stream));
+        hipLaunchKernelGGL(k_quorum_bits, dim3((unsigned)((props + 255) / 256)), dim3(256), 0, c0->stream, sbuf.d_full, sbuf.d_gather, props, (u32)group, quorum, sbuf.d_q);
+        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(quorum_bitmap, sbuf.d_q, (props + 7) / 8, hipMemcpyDeviceToHost, c0->stream));
+        HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(c0->stream));
+    }
+    if (info) {
+        info->devices = (int)devs.size();
+        info->shards = (int)parts;
+        info->mode = use_rccl ? 3 : 4;
+        info->tuples_per_shard = (n + parts - 1) / parts;
+        for (size_t d = 0; d < ndev; ++d) { if (h2d[d] > info->h2d_us) info->h2d_us = h2d[d]; if (kern[d] > info->kernels_us) info->kernels_us = kern[d]; }
+        info->gather_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
+        info->total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return SBV_OK;
+}
+}  // namespace
 
 extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, size_t group, uint32_t quorum, uint8_t* accept_bitmap,
                                              uint8_t* quorum_bitmap, sbv_shard_info* info) {
@@ -1667,6 +1899,11 @@ extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, si
         use_rccl = g_rccl.ready;
     }
     if (devs.empty()) { g_err = "sbv_init_all / sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (g_shard_mode.load() == 1) {
+        unsigned parts = g_shard_parts.load();
+        if (parts == 0) parts = (unsigned)devs.size();
+        if (parts > 1 && n >= parts) return sharded_by_key(tuples, n, group, quorum, accept_bitmap, quorum_bitmap, info, devs, parts, use_rccl);
+    }
     size_t first[kMaxDevices + 1];
     const size_t shards = sbv_shard_plan(n, (int)devs.size(), group, 0, first);
     const size_t per = shards > 1 ? first[1] - first[0] : ((n + shard_granule(group) - 1) / shard_granule(group) * shard_granule(group));
@@ -1751,6 +1988,21 @@ extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, si
         info->total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     }
     return SBV_OK;
+}
+
+extern "C" int sbv_p256_verify_batch_dev_part(const void* d_tuples, size_t n, uint32_t part, uint32_t parts, void* d_bitmap_words,
+                                              void* hip_stream, size_t* part_tuples) {
+    SBV_ENTER(c);
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (part_tuples) *part_tuples = 0;
+    if (n == 0) return SBV_OK;
+    if (!d_tuples || !d_bitmap_words || (reinterpret_cast<uintptr_t>(d_tuples) & 15) || (reinterpret_cast<uintptr_t>(d_bitmap_words) & 3) ||
+        parts == 0 || part >= parts) {
+        g_err = "null / misaligned device pointer, or part >= parts";
+        return SBV_EINVAL;
+    }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    return part_enqueue(c, static_cast<const uint8_t*>(d_tuples), n, part, parts, static_cast<u32*>(d_bitmap_words), static_cast<hipStream_t>(hip_stream), part_tuples);
 }
 
 extern "C" int sbv_p256_verify_batch_on(int device, const uint8_t* tuples, size_t n, uint8_t* accept_bitmap) {

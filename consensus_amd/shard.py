@@ -55,3 +55,65 @@ def sharded_verify(tuples, n: int, verify_fn: Optional[Callable] = None, device:
     dist.all_gather_into_tensor(recv, send)
     # shards start at multiples of `granule` tuples = whole bytes, so concatenation is the bitmap
     return bytes(recv.cpu().numpy().tobytes())[:(n + 7) // 8]
+
+
+# ---- key-affine partition ------------------------------------------------------------------------------------------------
+# The contiguous split above hands every rank signatures of every signer, so every rank builds every key's comb tables — the
+# part of a cold step that does not shrink with the shard.  Partitioning by a hash of the public key
+# gives rank g the tuples of "its" keys only: K / G tables, n / G tuples.  The exchange step becomes an all-reduce of
+# full-size bitmaps with disjoint bits (OR = byte-wise sum) instead of an all-gather of shards.  The hash is the one
+# libsbv.so uses on the device (sbv_api.hip: part_of_key), restated in numpy; tests pin the two against each other.
+def key_parts(tuples, n: int, parts: int):
+    """part id (0 .. parts-1) of every tuple, from its 64 key bytes — numpy twin of the device's part_of_key."""
+    import numpy as np
+    t = np.frombuffer(tuples, dtype=np.uint8, count=n * TUPLE_BYTES).reshape(n, TUPLE_BYTES)
+    k = np.ascontiguousarray(t[:, 96:160]).view("<u4").astype(np.uint64)          # 16 little-endian words, as the device loads them
+    mask = np.uint64(0xFFFFFFFF)
+    h = np.full(n, 0x2545F491, dtype=np.uint64)
+    for j in range(16):
+        h = ((h ^ k[:, j]) * np.uint64(0x9E3779B1)) & mask
+        h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0x85EBCA77)) & mask
+    return ((h >> np.uint64(11)) % np.uint64(parts)).astype(np.int64)
+
+
+def quorum_bits(tuples, bitmap: bytes, n: int, group: int, quorum: int) -> bytes:
+    """Bit p = proposal p (tuples [p*group, (p+1)*group)) carries >= quorum accepted signatures by DISTINCT keys
+    (internal/bft/viewchanger.go:681-727); LSB-first like the accept bitmap.  A ragged tail gets no bit."""
+    import numpy as np
+    props = n // group
+    bits = np.unpackbits(np.frombuffer(bitmap, dtype=np.uint8), bitorder="little")[:props * group].reshape(props, group)
+    t = np.frombuffer(tuples, dtype=np.uint8, count=n * TUPLE_BYTES).reshape(n, TUPLE_BYTES)[:props * group, 96:160].reshape(props, group, 64)
+    out = np.zeros(props, dtype=np.uint8)
+    for p in range(props):
+        seen = {t[p, i].tobytes() for i in range(group) if bits[p, i]}
+        out[p] = 1 if len(seen) >= quorum else 0
+    return np.packbits(out, bitorder="little").tobytes()
+
+
+def sharded_verify_by_key(tuples, n: int, verify_fn: Optional[Callable] = None, group: int = 0, quorum: int = 0, device: str = "cpu"):
+    """Every rank passes the same (tuples, n); rank g verifies the tuples whose key hashes to part g.  Returns
+    (full accept bitmap, per-proposal quorum bitmap or None) on every rank."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if verify_fn is None:
+        import consensus_amd
+        verify_fn = consensus_amd.verify_batch
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    mine = np.nonzero(key_parts(tuples, n, world) == rank)[0] if world > 1 else np.arange(n)
+    t = np.frombuffer(tuples, dtype=np.uint8, count=n * TUPLE_BYTES).reshape(n, TUPLE_BYTES)
+    bits = np.zeros(n, dtype=np.uint8)
+    if len(mine):
+        local = verify_fn(np.ascontiguousarray(t[mine]).tobytes(), len(mine))
+        bits[mine] = np.unpackbits(np.frombuffer(bytes(local), dtype=np.uint8), bitorder="little")[:len(mine)]
+    packed = np.packbits(bits, bitorder="little")
+    if world > 1:
+        buf = torch.from_numpy(packed.copy()).to(device)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)           # disjoint bits: the sum IS the OR
+        packed = buf.cpu().numpy()
+    full = packed.tobytes()[:(n + 7) // 8]
+    q = quorum_bits(tuples, full, n, group, quorum) if group and quorum else None
+    return full, q

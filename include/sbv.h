@@ -220,7 +220,7 @@ void sbv_host_free(void* p);
 typedef struct sbv_shard_info {
     int devices;              /* devices available to the call                              */
     int shards;               /* shards the batch was split into (1 = not split)            */
-    int mode;                 /* 0 = one device, 1 = RCCL all-gather, 2 = per-device D2H    */
+    int mode;                 /* 0 = one device, 1 = RCCL all-gather, 2 = per-device D2H, 3 = key-affine + RCCL all-reduce, 4 = key-affine + host OR */
     size_t tuples_per_shard;
     double h2d_us;            /* slowest device                                              */
     double kernels_us;        /* slowest device: stage A + B (+ quorum bits)                 */
@@ -233,6 +233,22 @@ size_t sbv_shard_plan(size_t n, int devices, size_t group, size_t min_per_device
 int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, size_t group, uint32_t quorum, uint8_t* accept_bitmap,
                                   uint8_t* quorum_bitmap, sbv_shard_info* info);
 int sbv_p256_verify_batch_on(int device, const uint8_t* tuples, size_t n, uint8_t* accept_bitmap);
+/* Key-affine partition (the other way to spread a batch: by signer instead of by position).  A contiguous split hands every
+ * device signatures of every signer, so every device builds every key's tables — the part of a cold step that does not shrink
+ * with the shard.  With sbv_shard_mode(1, parts) the sharded entry partitions by a hash of the public key: part p (on device
+ * p % devices; parts = 0 means one per device, more parts than devices run one after another — how a single GPU rehearses an
+ * 8-GPU partition) verifies the tuples of "its" keys only.  Every participating device receives the WHOLE batch over its own
+ * PCIe link (the price of not bucketing on the host); the per-device bitmaps have disjoint bits and are combined with one
+ * in-place ncclAllReduce(sum, uint8) (info->mode 3) or an OR on the host (mode 4); quorum bits are computed on the first device
+ * from the combined bitmap.  Env: SBV_SHARD_MODE=keys, SBV_SHARD_PARTS=<n>.  Same verdicts as every other entry.
+ * sbv_p256_verify_batch_dev_part is the device-resident building block: part `part` of `parts` of n tuples already in HBM
+ * (default device), asynchronous on hip_stream except for ONE internal synchronisation (the member count sizes the launches);
+ * d_bitmap_words: ceil(n / 32) 32-bit words, 4-byte aligned, receives this part's verdict bits (all other bits 0);
+ * *part_tuples (optional) = how many tuples the part held.  Call sites: the same as sbv_p256_verify_batch_sharded
+ * (VerifyProposal's K request signatures, decision replay: internal/bft/view.go:553-559, controller.go:587-633). */
+int sbv_shard_mode(int by_key, unsigned parts);
+int sbv_p256_verify_batch_dev_part(const void* d_tuples, size_t n, uint32_t part, uint32_t parts, void* d_bitmap_words,
+                                   void* hip_stream, size_t* part_tuples);
 
 /* Human-readable description of the calling thread's last failing call ("" if none). */
 const char* sbv_last_error(void);

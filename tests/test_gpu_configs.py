@@ -189,3 +189,78 @@ def test_sharded_entry_world_of_one_with_rccl_and_quorum_bits(oracle):
         os.environ.pop("SBV_RCCL", None)
         os.environ.pop("SBV_SHARD_MIN", None)
         sbv.shutdown()
+
+
+# ---- key-affine partition: device g verifies the tuples of "its" keys only ------------------------------
+def test_key_affine_parts_are_disjoint_cover_the_batch_and_match_the_numpy_hash(gpu, oracle):
+    """sbv_p256_verify_batch_dev_part on a device-resident 2^18 batch (256 keys, 1/5 corrupted), parts = 1, 3, 8: each part's
+    bitmap has bits only at tuples whose key hashes to that part (consensus_amd/shard.py: key_parts is the numpy twin of the
+    device hash), the parts' member counts add up to n, their bitmaps are disjoint and their OR is the full verdict bitmap."""
+    import numpy as np
+    import torch
+    from consensus_amd import shard
+    sbv.init(0)                        # the test above shuts the library down
+    n = 1 << 18
+    tup, exp = _gen(oracle, 0xAFF1, n, 256, 5)
+    d_t = torch.frombuffer(tup, dtype=torch.uint8).cuda()
+    stream = torch.cuda.current_stream()
+    want = np.unpackbits(np.frombuffer(exp, dtype=np.uint8), bitorder="little")[:n]
+    for parts in (1, 3, 8):
+        ids = shard.key_parts(tup.raw, n, parts)
+        acc = np.zeros(n, dtype=np.uint8)
+        total = 0
+        for p in range(parts):
+            d_w = torch.full(((n + 31) // 32,), -1, dtype=torch.int32, device="cuda")        # the entry zeroes it itself
+            members = gpu.verify_batch_dev_part(d_t.data_ptr(), n, p, parts, d_w.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            bits = np.unpackbits(d_w.cpu().numpy().view(np.uint8), bitorder="little")[:n]
+            assert members == int((ids == p).sum()), (parts, p)
+            assert not bits[ids != p].any(), (parts, p)                 # nothing outside the part
+            assert (bits[ids == p] == want[ids == p]).all(), (parts, p)
+            assert not (acc & bits).any()
+            acc |= bits
+            total += members
+        assert total == n and (acc == want).all(), parts
+
+
+def test_sharded_entry_by_key_on_one_gpu_rehearses_an_8_way_partition(gpu, oracle, openssl_check):
+    """The key-affine mode of sbv_p256_verify_batch_sharded with 8 parts on the one visible GPU (parts run one after another):
+    550 000 consenter signatures = 50 000 proposals x 11 (configs[3]) with duplicated signers inside some proposals — accept
+    bitmap and per-proposal quorum bits equal the contiguous mode's, the oracle's and the rule restated in numpy."""
+    import numpy as np
+    from consensus_amd import shard
+    group, quorum, props = 11, 10, 50000
+    n = group * props
+    tup, exp = _gen(oracle, 0xAFF2, n, 16, 9)
+    raw = bytearray(tup.raw)
+    for p in range(0, props, 97):                        # every 97th proposal: signer of tuple 0 signs twice -> one distinct signer fewer
+        raw[160 * (p * group + 1) + 96:160 * (p * group + 1) + 160] = raw[160 * (p * group) + 96:160 * (p * group) + 160]
+        raw[160 * (p * group + 1):160 * (p * group + 1) + 96] = raw[160 * (p * group):160 * (p * group) + 96]
+    buf = ctypes.create_string_buffer(bytes(raw), len(raw))
+    a, b = _cpu_opinions(oracle, openssl_check, buf, n)
+    assert a == b
+    want_q = shard.quorum_bits(bytes(raw), a, n, group, quorum)
+    for rccl in (False, True):                 # host OR of the per-device bitmaps, then the in-place ncclAllReduce with a world of one
+        if rccl:
+            os.environ["SBV_RCCL"] = "1"
+        try:
+            sbv.shutdown()
+            gpu.init_all()
+            res = {}
+            for label, by_key in (("contiguous", False), ("by key, 8 parts", True)):
+                gpu.shard_mode(by_key, 8 if by_key else 0)
+                try:
+                    got = ctypes.create_string_buffer((n + 7) // 8)
+                    qb = ctypes.create_string_buffer((props + 7) // 8)
+                    info = gpu.verify_batch_sharded(ctypes.addressof(buf), n, ctypes.addressof(got), group, quorum, ctypes.addressof(qb))
+                    res[label] = (got.raw, qb.raw, info.mode, info.shards)
+                finally:
+                    gpu.shard_mode(False, 0)
+            assert res["contiguous"][0] == a[:(n + 7) // 8], _diff(res["contiguous"][0], a)
+            assert res["by key, 8 parts"][0] == res["contiguous"][0]
+            assert res["by key, 8 parts"][1] == res["contiguous"][1] == want_q
+            assert res["by key, 8 parts"][2] == (3 if rccl else 4) and res["by key, 8 parts"][3] == 8, res["by key, 8 parts"][2:]
+        finally:
+            os.environ.pop("SBV_RCCL", None)
+    sbv.shutdown()
+    sbv.init(0)

@@ -15,10 +15,14 @@ import json
 import os
 import random
 
+import sys
+
 import numpy as np
 import pytest
 
 import consensus_amd as sbv
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -168,3 +172,44 @@ def test_secp256k1_edge_vectors_spliced_into_2_20(gpu, oracle):
     sbv._check(sbv.load().sbv_secp256k1_verify_batch(ctypes.c_void_p(batch.ctypes.data), n, ctypes.c_void_p(got.ctypes.data)))
     rep = _report(_bits(got.tobytes(), n), want, where, [v["name"] for v in vs])
     assert rep is None, rep
+
+
+def test_ed25519_batches_leave_the_p256_key_cache_alone(gpu, oracle):
+    """Regression (round 3, found by test order): the Ed25519 grouped step wrote its per-batch group verdicts into the array whose
+    first bytes are the validity flags of the P-256 key-table cache, so an Ed25519 batch with a repeated undecodable key
+    switched cached P-256 signers to "invalid" and every later signature of theirs was rejected.  P-256 warm -> Ed25519 batch
+    with 64 copies of every golden vector (undecodable keys among them) -> the same P-256 batch, still warm, same verdicts."""
+    import ed25519_py as ed
+    oracle.sbvo_ed25519_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int]
+    n = 1 << 18
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer(n // 8)
+    oracle.sbvo_gen_batch(0x1CE, n, 300, 6, tup, exp, THREADS)
+    etup = np.zeros(128 * n, dtype=np.uint8)
+    eexp = np.zeros(n // 8, dtype=np.uint8)
+    oracle.sbvo_ed25519_gen_batch(0x1CF, n, 300, 6, etup.ctypes.data, eexp.ctypes.data, THREADS)
+    vs = json.load(open(os.path.join(GOLDEN, "ed25519_vectors.json")))["vectors"]
+    vecs = [(ed.pack_tuple(bytes.fromhex(v["pk"]), bytes.fromhex(v["msg"]), bytes.fromhex(v["sig"])), v["accept"]) for v in vs]
+    ebatch, ewant, ewhere = _splice(etup, _bits(eexp.tobytes(), n), vecs, 128, 0xED26)
+
+    def p256():
+        got = ctypes.create_string_buffer(n // 8)
+        gpu.verify_batch_ptr(ctypes.addressof(tup), n, ctypes.addressof(got))
+        return got.raw
+    gpu.key_cache(False)
+    gpu.key_cache(True, 4096)
+    gpu.set_grouping(True, 0, 32, 0)
+    try:
+        assert p256() == exp.raw
+        assert p256() == exp.raw
+        entries, hits, misses, cap = gpu.key_cache_stats()
+        assert hits >= 300 and misses == 0
+        got = np.zeros(n // 8, dtype=np.uint8)
+        sbv._check(sbv.load().sbv_ed25519_verify_batch(ctypes.c_void_p(ebatch.ctypes.data), n, ctypes.c_void_p(got.ctypes.data)))
+        assert _report(_bits(got.tobytes(), n), ewant, ewhere, [v["name"] for v in vs]) is None
+        assert p256() == exp.raw                       # still warm, still right
+        entries, hits, misses, cap = gpu.key_cache_stats()
+        assert hits >= 300 and misses == 0
+    finally:
+        gpu.set_grouping(True, 0, 64, 0)

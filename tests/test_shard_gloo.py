@@ -79,3 +79,62 @@ def test_world_size_2_gloo_gathers_full_bitmap(n):
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] for r in res), "gathered bitmap differs from the single-process result"
     assert all(r[2] for r in res), "a rank verified something other than exactly its shard"
+
+
+# ---- key-affine partition (consensus_amd/shard.py: sharded_verify_by_key) -------------------------------------------------
+def _worker_by_key(rank, world, port, n, group, quorum, out_q):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsbv_oracle.so"))
+    lib.sbvo_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    lib.sbvo_p256_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    lib.sbvo_gen_batch(0xC0DE, n, 16, 5, tup, exp, 1)
+    raw = bytearray(tup.raw)
+    raw[160 * 3 + 96:160 * 3 + 160] = raw[160 * 4 + 96:160 * 4 + 160]      # proposal 0: tuple 3 now carries tuple 4's key (its signature no longer verifies)
+    raw = bytes(raw)
+    want = ctypes.create_string_buffer((n + 7) // 8)
+    lib.sbvo_p256_verify_batch(raw, n, want, 1)
+    seen_keys = set()
+
+    def stand_in(tuples, m):
+        for i in range(m):
+            seen_keys.add(tuples[160 * i + 96:160 * i + 160])
+        bm = ctypes.create_string_buffer(max(1, (m + 7) // 8))
+        lib.sbvo_p256_verify_batch(tuples, m, bm, 1)
+        return bm.raw[:(m + 7) // 8]
+
+    full, q = shard.sharded_verify_by_key(raw, n, verify_fn=stand_in, group=group, quorum=quorum)
+    parts = shard.key_parts(raw, n, world)
+    mine_keys = {raw[160 * i + 96:160 * i + 160] for i in range(n) if parts[i] == rank}
+    # independent statement of the quorum rule
+    bits = [(want.raw[i >> 3] >> (i & 7)) & 1 for i in range(n)]
+    wq = []
+    for p in range(n // group):
+        keys = {raw[160 * i + 96:160 * i + 160] for i in range(p * group, (p + 1) * group) if bits[i]}
+        wq.append(1 if len(keys) >= quorum else 0)
+    got_q = [(q[p >> 3] >> (p & 7)) & 1 for p in range(n // group)]
+    out_q.put((rank, full == want.raw[:(n + 7) // 8], seen_keys == mine_keys, got_q == wq, int(np.bincount(parts, minlength=world)[rank])))
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_key_affine_partition_and_quorum_bits():
+    world, n, group, quorum = 2, 16 * 11 * 4 + 5, 11, 10
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_by_key, args=(r, world, port, n, group, quorum, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] for r in res), "combined bitmap differs from the single-process result"
+    assert all(r[2] for r in res), "a rank saw a key of the other rank's part: the partition is not key-affine"
+    assert all(r[3] for r in res), "per-proposal quorum bits differ from the rule"
+    assert sum(r[4] for r in res) == n and all(r[4] > 0 for r in res)
