@@ -11,7 +11,10 @@
 // 20 x 30 = 600 are run).  Constant time is not the point here (everything verified is public) —
 // uniform control flow across a wavefront is: every lane executes the same 600 steps.
 // Written from the paper's description; the limb layout (signed 30-bit limbs in 32-bit words, 64-bit
-// accumulators) is the natural one for v_mad_i64_i32.
+// accumulators) is the natural one for v_mad_i64_i32.  Prior art with the same shape — signed-30 limbs, a 2x2
+// transition matrix per 30 steps, divsteps / update_de / update_fg / normalize, the half-delta counter and the
+// 590 -> 600 step bound — is libsecp256k1's modinv32 (src/modinv32_impl.h, Pieter Wuille et al.), which also
+// documents the bound; this file owes its structure to that reading of the paper.
 //
 // Contract: modinv30(out, x, mi): x in [0, m), m odd, m < 2^256  ->  out = x^-1 mod m in [0, m);
 // x = 0 gives 0 (like x^(m-2)).  Plain integers, no Montgomery form; see fe_inv_gcd / sc_inv_gcd for

@@ -1,19 +1,22 @@
-// p256_kernels.hip — gfx950 kernels for batch ECDSA P-256 verification (one tuple per lane).
+// p256_kernels.hip — gfx950 kernels for batch ECDSA P-256 verification outside the grouped step
+// (the grouped step's kernels are in p256_group_kernels.hip).
 //
-//   k_p256_prep   : stage A.  One 64-lane workgroup (= one wavefront) walks T slabs of 64
-//                   tuples.  Each slab (64 x 160 B = 10 KiB, contiguous in HBM) is fetched
-//                   with coalesced 16-byte loads (global_load_dwordx4, lane l reads bytes
-//                   16*l..) into LDS with a 41-dword row pitch (41 is odd -> the per-lane
-//                   ds_read_b32 column walk is bank-conflict free), then every lane reads
-//                   its own tuple's 40 dwords back from LDS.  Montgomery's trick runs along
-//                   the T slabs inside each lane: one Fermat inversion per T signatures.
-//   k_p256_verify_fast : stage B.  256 lanes per workgroup; all inputs come from the limb-major
-//                   scratch (coalesced dword loads); the per-signature window table lives
-//                   in HBM scratch (1280 B / lane, written and read only by its lane); the
-//                   fixed-base table (270 KiB) is read-only and L2/L1 resident.  The accept
-//                   bits are gathered with a 64-wide ballot and written as bitmap bytes.
+//   k_p256_prep / _keyed  stage A.  One 64-lane workgroup (= one wavefront) walks T slabs of 64 tuples.  Each slab
+//                         (64 x 160 B = 10 KiB, contiguous in HBM) is fetched with coalesced 16-byte loads
+//                         (global_load_dwordx4, lane l reads bytes 16*l..) into LDS with a 41-dword row pitch (41 is odd ->
+//                         the per-lane ds_read_b32 column walk is bank-conflict free), then every lane reads its own tuple's
+//                         dwords back from LDS.  Montgomery's trick runs along the T slabs inside each lane: one
+//                         division-step inversion (modinv30.h) per T signatures, all products on the carry-free scalar
+//                         field (p256_sc29.h).
+//   k_p256_verify         stage B, generic form: one lane per signature, per-signature affine window table in HBM,
+//                         256 doublings on the carry-free field (p256_comb29.h: verify29_lane_generic).
+//   k_p256_verify_keyed   registered keys: 13 + 33 comb additions per lane, no doublings.
+//   k_p256_verify_keyed_coop   the same for batches <= 32768: 8 lanes per signature, butterfly of exact XYZZ additions.
+//   k_p256_verify_keyed_small  batches <= 64 in ONE launch: stage A in registers, records / verdicts in mapped host memory.
+//   k_p256_sign           batch signing (RFC 6979), k_msg_frontend: SHA-256 + strict DER in front of the keyed kernels.
+// The accept bits are gathered with a 64-wide ballot and written as bitmap bytes.
 //
-// No MFMA: this is 256-bit modular integer arithmetic (v_mad_u64_u32 + carry chains).
+// No MFMA: this is 256-bit modular integer arithmetic (v_mad_i64_i32 into 64-bit columns, p256_fe29.h).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -171,22 +174,40 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_coop(
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_small(const u32* __restrict__ in, u32 n, u32 nkeys,
                                                                               const apt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
                                                                               gcomb g16, uint8_t* __restrict__ out, u32* __restrict__ done) {
-    const u32 lane_g = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
-    const u32 i = lane_g / SBV_COOP_LANES;
-    const int sub = (int)(lane_g % SBV_COOP_LANES);
-    const bool active = i < n;
+    // The input lives in HOST memory: a lane-by-lane dword walk over it is one PCIe read per dword (measured: 64 signatures
+    // took 230 us that way, 15 took 128).  The workgroup's 32 records (3 KB) are fetched with 16-byte loads, one per lane —
+    // whole PCIe bursts — into LDS, and the verdicts leave as one 32-bit word per 4 signatures plus ONE counter update.
+    constexpr int kSigs = SBV_VERIFY_BLOCK / SBV_COOP_LANES;          // signatures per workgroup
+    __shared__ u32 rec[kSigs * 24];
+    __shared__ u32 slot_s[kSigs];
+    __shared__ u32 verdict_s[kSigs];
+    const u32 first = blockIdx.x * kSigs;
+    const u32 here = n - first < (u32)kSigs ? n - first : (u32)kSigs;   // signatures of this workgroup (the launch covers no empty one)
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)first * 24);
+        for (u32 e = threadIdx.x; e < here * 6; e += SBV_VERIFY_BLOCK) {
+            const uint4 v = src[e];
+            rec[4 * e] = v.x; rec[4 * e + 1] = v.y; rec[4 * e + 2] = v.z; rec[4 * e + 3] = v.w;
+        }
+        if (threadIdx.x < here) slot_s[threadIdx.x] = in[SBV_SMALL_MAX * 24 + first + threadIdx.x];
+        if (threadIdx.x < kSigs) verdict_s[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const u32 g = threadIdx.x / SBV_COOP_LANES;                        // signature of this lane inside the workgroup
+    const int sub = (int)(threadIdx.x % SBV_COOP_LANES);
+    const bool active = g < here;
     u256 r, u1, u2;
     SBV_UNROLL
     for (int l = 0; l < 8; ++l) { r.v[l] = 0; u1.v[l] = 0; u2.v[l] = 0; }
     u32 okw = 0, slot = 0;
     if (active && sub == 0) {
-        const u32* t = in + (size_t)i * 24;
+        const u32* t = rec + g * 24;
         u256 s, h;
         tuple_field(r, t, 0);
         tuple_field(s, t, 1);
         tuple_field(h, t, 2);
         okw = stage_a_single(r, s, h, u1, u2) ? 1u : 0u;
-        slot = in[SBV_SMALL_MAX * 24 + i];
+        slot = slot_s[g];
     }
     const int leader = (int)(threadIdx.x & 63u) & ~(SBV_COOP_LANES - 1);
     SBV_UNROLL
@@ -219,10 +240,18 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_small
         P.inf = __shfl_xor(R.inf ? 1 : 0, off, 64) != 0;
         pt29_add(R, P);
     }
-    if (active && sub == 0) {
-        out[i] = ok && pt29_rx_matches(R, r) ? 1 : 0;
+    if (active && sub == 0) verdict_s[g] = ok && pt29_rx_matches(R, r) ? 1u : 0u;
+    __syncthreads();
+    if (threadIdx.x < kSigs / 4) {                                     // 8 lanes, one 32-bit store each: 4 verdict bytes
+        const u32 w = verdict_s[4 * threadIdx.x] | (verdict_s[4 * threadIdx.x + 1] << 8) | (verdict_s[4 * threadIdx.x + 2] << 16) |
+                      (verdict_s[4 * threadIdx.x + 3] << 24);
+        reinterpret_cast<u32*>(out)[first / 4 + threadIdx.x] = w;       // first is a multiple of 32
+        __threadfence_system();                                          // visible to the host before the counter says so
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         __threadfence_system();
-        __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_fetch_add(done, here, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

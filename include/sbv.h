@@ -25,8 +25,11 @@
  *     1 = crypto/ecdsa.VerifyASN1 would return true.
  *   - there is NO CPU fallback inside the library: without a usable gfx950 device every
  *     compute entry point returns SBV_ENODEV.
- *   - all functions are thread-safe; device work is serialised internally (one context per
- *     process, selected device = sbv_init's argument).
+ *   - all functions are thread-safe.  There is one context per DEVICE (sbv_init(d) creates device d's; the first one
+ *     initialised is the default the single-device entry points use; sbv_init_all() creates one per visible gfx950 device and
+ *     the sharded / _on entries address them); device work is serialised per context.  The tuning setters
+ *     (sbv_p256_set_grouping, sbv_p256_key_cache, sbv_profile_enable, sbv_shard_mode) are process-wide: they apply to every
+ *     initialised device and to devices initialised later, also when called before sbv_init.
  */
 #ifndef SBV_H_
 #define SBV_H_
@@ -64,12 +67,15 @@ int sbv_device_count(void);
  * (viewchanger.go:598, 660, 718, 983, 1022, 1076). */
 int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap);
 
-/* In-step key grouping for the two generic entry points above (consensus_amd/csrc/p256_group.h): when a
- * batch has at least `min_batch` tuples, tuples are grouped by public key on the device, keys used by
- * at least `min_count` tuples of THIS batch (at most `max_groups` of them) get a comb table built inside
- * the call and their signatures take the no-doubling kernel; everything else takes the generic kernel.
- * Nothing is remembered between calls; verdicts are identical.  Defaults: enabled, 262144, 64, 2048
- * (env SBV_GROUP=0 disables).  Passing 0 for a numeric argument keeps its current value. */
+/* In-step key grouping for the generic entry points (consensus_amd/csrc/p256_group.h): tuples are grouped by public key on
+ * the device; keys used by at least `min_count` tuples of THIS batch — or already held by the key-table cache below, however
+ * few of their signatures the batch carries — (at most `max_groups` of them) get / reuse a comb table and their signatures
+ * take the no-doubling kernels; everything else takes the generic kernel inside the same step.  Verdicts are identical.
+ * `min_batch` = batches from this size on take the grouped step.  Defaults: enabled; min_batch 64 while the key-table cache is
+ * on (a warm batch of a few thousand tuples skips the 256 doublings per signature), 2^17 while it is off (nothing outlives the
+ * call then, and below ~2^17 building tables costs more latency than the doubling kernel takes); min_count 64; max_groups 2048.
+ * Passing a non-zero min_batch sets both thresholds; 0 for a numeric argument keeps its current value.  Env: SBV_GROUP=0
+ * disables, SBV_GROUP_MIN_BATCH=<n>.  What IS remembered between calls is the key-table cache. */
 int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uint32_t max_groups);
 
 /* Persistent key-table cache.  The comb a grouped batch builds for a key is a pure function of the key's 64 bytes, and
@@ -92,8 +98,10 @@ int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, vo
  * SmartBFT's consenter set (and an application's client set) is a registry: types.Signature.ID
  * selects the key (pkg/types/types.go:25-29), it is not carried per signature.  Registering a key
  * builds a fixed-base comb for it (33 x 128 affine multiples, 270 KiB of HBM per key) once, after
- * which a verification against that key needs NO point doublings: R = u1*G + u2*Q is 17 + 33 = 50 mixed
- * additions (~4.7x fewer field multiplications than the generic form).  Verdicts are identical to
+ * which a verification against that key needs NO point doublings: R = u1*G + u2*Q is 13 + 32.2 = 45.2 mixed
+ * additions on average (13 from the 20-bit comb of G, 32 key-comb windows + the rarely needed carry window; ~5x fewer field
+ * multiplications than the generic form).  Batches of at most 64 signatures take a one-launch latency form (stage A in
+ * registers, records and verdicts in mapped host memory), up to 32768 the 8-lanes-per-signature kernel.  Verdicts are identical to
  * the generic entry points: a key that crypto/ecdsa would refuse (coordinate >= p, off curve) still
  * gets a slot, flagged invalid, and every signature against it is rejected.
  *   keys: m x 64 bytes (Qx|Qy big-endian).  slots_out[i] = slot of keys[i] (equal keys share a slot). */

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Latency of the registered-key host entry for quorum-sized batches (n = 1, 15, 64): median wall time of sbv_p256_verify_batch_keyed
+over 300 calls, through ctypes.  SBV_SMALL=0 in the environment selects the staged path (copies + two launches) for the A/B."""
+import ctypes, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np
+import consensus_amd as sbv
+import synth
+sbv.init(0)
+tuples, valid = synth.gen_batch(0x5B7F2026, 1 << 16, 16, 8)
+t2 = tuples.reshape(-1, 160)
+keys = [bytes(t2[i, 96:160]) for i in range(16)]
+slots_of = dict(zip(keys, sbv.register_keys(keys)))
+lib = sbv.load()
+lib.sbv_p256_verify_batch_keyed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+out = {"small_path": os.environ.get("SBV_SMALL", "1") != "0"}
+for n in (1, 15, 64, 65):
+    rsh = np.ascontiguousarray(t2[:n, :96]).reshape(-1)
+    slots = np.array([slots_of.get(bytes(t2[i, 96:160]), 0xFFFFFFFF) for i in range(n)], dtype=np.uint32)
+    bm = np.zeros(16, dtype=np.uint8)
+    ts = []
+    for _ in range(300):
+        t0 = time.perf_counter()
+        rc = lib.sbv_p256_verify_batch_keyed(rsh.ctypes.data, slots.ctypes.data, n, bm.ctypes.data)
+        ts.append(time.perf_counter() - t0)
+        assert rc == 0
+    want = np.unpackbits(valid, bitorder="little")[:n]
+    got = np.unpackbits(bm, bitorder="little")[:n]
+    ts.sort()
+    out[f"n={n}"] = {"median_us": round(1e6 * ts[len(ts) // 2], 1), "p10_us": round(1e6 * ts[30], 1), "p90_us": round(1e6 * ts[270], 1), "correct": bool((got == want).all())}
+print(json.dumps(out))
