@@ -21,7 +21,10 @@ hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slo
 // latency form of small registered-key batches in one launch (p256_kernels.hip: k_p256_verify_keyed_small).  d_in: the device
 // view of a page-locked buffer holding n x 96 bytes r|s|hash and, at byte SBV_SMALL_MAX * 96, n u32 key slots; d_out: one
 // verdict byte per signature; d_done: system-scope counter, += 1 per signature when its verdict is visible.
-#define SBV_SMALL_MAX 64
+// One workgroup's worth: measured on MI355X (profiles/r03/latency_small_r03g.jsonl, kernel trace r03h) the one-launch form takes
+// 85-100 us for up to 32 signatures (the staged path: 48 us stage A + 49 us comb kernel + copies = 131 us per call), but with a
+// second workgroup its median doubles (180 us), so 33+ signatures keep the staged path.
+#define SBV_SMALL_MAX 32
 hipError_t launch_p256_verify_keyed_small(const void* d_in, size_t n, u32 nkeys, const apt* d_ktab, const uint8_t* d_kvalid, const gcomb& d_gcomb,
                                           uint8_t* d_out, u32* d_done, hipStream_t stream);
 void host_build_gcomb(int bits, apt* out);   // `bits`-wide comb of G, 8 x 32 Montgomery domain: gcomb_entries(bits) entries

@@ -942,6 +942,7 @@ extern "C" int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* s
 #endif
         }
         if (*done < (u32)n) HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(c.stream));
+        else (void)hipStreamQuery(c.stream);       // never blocks; lets the runtime retire the finished launch (this path never synchronises)
         std::atomic_thread_fence(std::memory_order_seq_cst);
         if (*done < (u32)n) { g_err = "the small-batch kernel did not report completion"; return SBV_EDEVICE; }
         memset(accept_bitmap, 0, (n + 7) / 8);

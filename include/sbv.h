@@ -100,7 +100,7 @@ int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, vo
  * builds a fixed-base comb for it (33 x 128 affine multiples, 270 KiB of HBM per key) once, after
  * which a verification against that key needs NO point doublings: R = u1*G + u2*Q is 13 + 32.2 = 45.2 mixed
  * additions on average (13 from the 20-bit comb of G, 32 key-comb windows + the rarely needed carry window; ~5x fewer field
- * multiplications than the generic form).  Batches of at most 64 signatures take a one-launch latency form (stage A in
+ * multiplications than the generic form).  Batches of at most 32 signatures take a one-launch latency form (stage A in
  * registers, records and verdicts in mapped host memory), up to 32768 the 8-lanes-per-signature kernel.  Verdicts are identical to
  * the generic entry points: a key that crypto/ecdsa would refuse (coordinate >= p, off curve) still
  * gets a slot, flagged invalid, and every signature against it is rejected.

@@ -12,7 +12,7 @@ summary = json.load(open(sys.argv[1]))
 tag = sys.argv[2]
 out = {
     "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no tracing besides --kernel-trace in its own pass) over "
-              f"`python bench.py --steps 5 --warmup 2 --no-cpu-baseline --primary-only`, run {tag}; summary: profiles/{"r03" if tag.startswith("r03") else "r02"}/rocprof_summary_{tag}.json",
+              f"`python bench.py --steps 5 --warmup 2 --no-cpu-baseline --primary-only`, run {tag}; summary: profiles/{tag[:3]}/rocprof_summary_{tag}.json",
     "method": "FETCH_SIZE and WRITE_SIZE are KiB; FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md (gfx950 tallies 128-B "
               "requests as 64 B); the guide calibrates that factor on wide coalesced reads only - the comb phases read 64-byte table "
               "entries as four 16-byte loads per lane, so for them the doubled figure is an upper bound; WRITE_SIZE as is.  Per launch = "
