@@ -167,6 +167,12 @@ SBV_HD void k256_prep_lane(WordPtr w, size_t i, const Scratch& sc_) {
     soa_store(sc_.qx, sc_.cap, i, qx);
     soa_store(sc_.qy, sc_.cap, i, qy);
     sc_.ok[i] = ok ? 1 : 0;
+    if (sc_.rec) {                              // grouped step (k256_group.h): the key-sorted list reads one record per tuple
+        rec_store256(sc_.rec, i, SBV_REC_U1, u1.v);
+        rec_store256(sc_.rec, i, SBV_REC_U2, u2.v);
+        rec_store256(sc_.rec, i, SBV_REC_R, r.v);
+        sc_.rec[i * SBV_REC_WORDS + SBV_REC_OK] = ok ? 1u : 0u;
+    }
 }
 
 // ---- stage B -----------------------------------------------------------------------------------------------------------

@@ -1,0 +1,184 @@
+// k256_group_kernels.hip — the grouped step for secp256k1 (k256_group.h): the P-256 step's three-stream pipeline with this
+// curve's kernels.  Grouping, classification, counting sort and the bitmap pack are the shared kernels of
+// group_kernels_common.h; stage A is k_k256_prep (one lane per signature, also writes the per-tuple records).
+//
+//   stream: [prep] wait(sort) { generic stage B over the ungrouped list + G phase } wait(tables c) Q-phase chunk c ... pack
+//   side_a: insert assign | chain chunk 0 | chain chunk 1
+//   side_b:        wait(assign) classify keycheck sort | wait(chain c) rows fill of chunk c
+//
+// No persistent key cache on this curve (k256_group.h says why): every grouped key's comb is built in the call, in the per-batch
+// area of the comb pool.
+#include <hip/hip_runtime.h>
+
+#include "group_kernels_common.h"
+#include "k256_group.h"
+#include "p256_kernels.h"
+
+namespace sbv {
+
+struct KGlobalTupleG {
+    const u32* p;
+    __device__ __forceinline__ u32 operator[](int i) const { return p[i]; }
+};
+__global__ __launch_bounds__(64) void k_k256_prep_rec(const uint8_t* __restrict__ tuples, size_t n, Scratch s) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    k256_prep_lane(KGlobalTupleG{reinterpret_cast<const u32*>(tuples + i * 160)}, i, s);
+}
+__global__ __launch_bounds__(256) void k_k256_group_insert(const uint8_t* __restrict__ tuples, size_t n, GroupState g) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) group_insert_lane(tuples, i, g);
+}
+__global__ __launch_bounds__(256) void k_k256_keycheck(const uint8_t* __restrict__ tuples, GroupState g, uint8_t* __restrict__ acc) {
+    const u32 L = blockIdx.x * 256 + threadIdx.x;
+    const u32 cands = g.counters[4];
+    if (blockIdx.x * 256u >= cands) return;
+    const bool active = L < cands;
+    u32 i = 0;
+    bool ok = false;
+    if (active) {
+        i = g.ung_cand[L];
+        kfe x, y;
+        ok = k256_key_load(tuples, i, x, y);
+        if (!ok) acc[i] = 0;
+    }
+    const unsigned long long mr = __ballot(active && !ok);
+    if ((threadIdx.x & 63) == 0 && mr) atomicAdd(&g.counters[3], (u32)__popcll(mr));
+    const u32 pos = group_compact_pos(active && ok, &g.counters[2]);
+    if (active && ok) g.ung_idx[pos] = i;
+}
+
+struct k256_quad_dev {
+    static const int N = 1;
+    kchain3 s[1];
+    int r;
+    __device__ __forceinline__ int role(int) const { return r; }
+    __device__ __forceinline__ void bcast(kfe out[1], const kfe in[1], int src) const {
+        SBV_UNROLL
+        for (int l = 0; l < 9; ++l) {
+            const int v = in[0].v[l];
+            out[0].v[l] = src == 0 ? __builtin_amdgcn_mov_dpp(v, 0x00, 0xF, 0xF, true)
+                        : src == 1 ? __builtin_amdgcn_mov_dpp(v, 0x55, 0xF, 0xF, true)
+                                   : __builtin_amdgcn_mov_dpp(v, 0xAA, 0xF, 0xF, true);
+        }
+    }
+};
+// lanes = groups x 4; table slot of group k = slot0 + k (the per-batch area of the comb pool)
+__global__ __launch_bounds__(64) void k_k256_chain(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jstate, u32* __restrict__ bases,
+                                                   uint8_t* __restrict__ valid, int j_first, int j_last) {
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 k = lane >> 2;
+    if (k >= group_count(g)) return;
+    k256_quad_dev q;
+    q.r = (int)(lane & 3u);
+    k256_chain_run(q, tuples, k, g, jstate, bases, valid + k, j_first, j_last);
+}
+__global__ __launch_bounds__(64, 2) void k_k256_rows(GroupState g, const u32* __restrict__ bases, u32* __restrict__ tmp, kapt* __restrict__ ktab,
+                                                     int j_first, int j_count) {
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 which = lane & 1u, kw = lane >> 1;
+    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
+    if (key >= group_count(g)) return;
+    if (which == 1 && j == SBV_GTAB_WINDOWS - 1) return;
+    const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
+    k256_rows_lane(bases + w * SBV_K256_BASES_STRIDE, (int)which, j == SBV_GTAB_WINDOWS - 1,
+                   tmp + w * SBV_K256_WINDOW_TMP + (size_t)which * SBV_K256_ROWS_TMP_WORDS, ktab + w * SBV_GTAB_PER_WINDOW);
+}
+// lanes = groups x j_count x 7
+__global__ __launch_bounds__(64) void k_k256_fill(GroupState g, u32* __restrict__ tmp, kapt* __restrict__ ktab, int j_first, int j_count) {
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 r = lane % 7u, kw = lane / 7u;
+    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
+    if (key >= group_count(g) || j == SBV_GTAB_WINDOWS - 1) return;
+    const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
+    k256_fill_lane(1 + (int)r, tmp + w * SBV_K256_WINDOW_TMP + (size_t)r * SBV_K256_FILL_TMP_WORDS, ktab + w * SBV_GTAB_PER_WINDOW);
+}
+
+// generic stage B over the ungrouped list (first blocks) + u1 * G over the key-sorted list
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_gphase_generic(Scratch s, GroupState g, u32* __restrict__ qtab, const kapt* __restrict__ gtab,
+                                                                           u32* __restrict__ gacc, uint8_t* __restrict__ acc, unsigned generic_blocks) {
+    if (blockIdx.x < generic_blocks) {
+        const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+        if (L >= g.counters[2]) return;
+        const u32 t = g.ung_idx[L];
+        acc[t] = k256_verify_lane(s, t, qtab + (size_t)L * SBV_QTAB29_WORDS, gtab) ? 1 : 0;
+        return;
+    }
+    if (group_count(g) == 0) return;
+    const size_t i = (size_t)(blockIdx.x - generic_blocks) * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (i < g.counters[1]) k256_gphase_lane_sorted(s, g.grp_idx[i], i, gtab, gacc);
+}
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_qphase(Scratch s, GroupState g, const kapt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
+                                                                   u32* __restrict__ gacc, uint8_t* __restrict__ acc, int j0, int j1, int last) {
+    // key-sorted list, XCD-aware block order (p256_group_kernels.hip: k_verify_keyed_q)
+    const u32 lanes = g.counters[1];
+    const u32 per = ((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK + 7) >> 3;
+    const u32 local = blockIdx.x >> 3;
+    if (local >= per) return;
+    const u32 L = ((blockIdx.x & 7u) * per + local) * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (L >= lanes) return;
+    const u32 t = g.grp_idx[L];
+    const u32 grp = g.grp_of[L];
+    const bool v = k256_qphase_lane_sorted(s, t, L, grp < group_count(g) ? grp : SBV_GROUP_NONE, group_count(g), ktab, kvalid, gacc, j0, j1, last != 0);
+    if (last) acc[t] = v ? 1 : 0;
+}
+
+// stage A + stage B of a grouped secp256k1 batch.  ev_fork must have been recorded on `stream` first.  The per-batch area of the
+// comb pool (b.ktab + kc.cap keys, b.kvalid + kc.cap) holds this batch's tables; group k uses slot k of it.
+hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_in, size_t n, const GroupBuffers& b, u32* d_qtab,
+                                      const kapt* d_gtab, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y) {
+    if (n == 0) return hipSuccess;
+    GroupState g;
+    g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
+    g.counters = b.counters; g.grp_idx = b.grp_idx; g.ung_idx = b.ung_idx; g.slots = b.slots; g.max_groups = b.max_groups;
+    g.gcount = b.gcount; g.gcursor = b.gcount + b.max_groups; g.grp_of = b.grp_of; g.ung_cand = b.ung_cand;
+    g.sorted = 1u;
+    group_set_threshold(g, b.min_count);
+    Scratch s = s_in;
+    s.rec = b.rec;
+    const size_t sort_lds = (size_t)b.max_groups * sizeof(u32);
+    kapt* ktab = reinterpret_cast<kapt*>(b.ktab) + (size_t)b.kc.cap * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
+    uint8_t* kvalid = b.kvalid + b.kc.cap;
+    hipError_t e;
+#define SBV_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
+    SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_fork, 0));
+    SBV_TRY(hipMemsetAsync(b.ht, 0, ((size_t)b.ht_mask + 1) * sizeof(u32), y.side_a));
+    SBV_TRY(hipMemsetAsync(b.cnt, 0, n * sizeof(u32), y.side_a));
+    SBV_TRY(hipMemsetAsync(b.counters, 0, SBV_GROUP_COUNTERS * sizeof(u32), y.side_a));
+    SBV_TRY(hipMemsetAsync(b.gcount, 0, (size_t)b.max_groups * sizeof(u32), y.side_a));
+    const unsigned gn = (unsigned)((n + 255) / 256);
+    const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
+    hipLaunchKernelGGL(k_k256_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
+    hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g, KeyCache{});
+    SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
+    hipLaunchKernelGGL(k_k256_prep_rec, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_tuples, n, s);
+    SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
+    hipLaunchKernelGGL(k_group_classify, dim3(gn), dim3(256), 0, y.side_b, n, g, b.ung_cand, b.counters + 4);
+    hipLaunchKernelGGL(k_k256_keycheck, dim3(gn), dim3(256), 0, y.side_b, d_tuples, g, b.acc);
+    const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
+    hipLaunchKernelGGL(k_group_sort_count, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
+    hipLaunchKernelGGL(k_group_sort_scan, dim3(1), dim3(1024), 0, y.side_b, g);
+    hipLaunchKernelGGL(k_group_sort_scatter, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
+    SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
+    SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
+    hipLaunchKernelGGL(k_k256_gphase_generic, dim3(2 * gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, d_qtab, d_gtab, b.gacc, b.acc, gv);
+    const int chunks = 2;
+    for (int c = 0; c < chunks; ++c) {
+        const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks, j_count = j_end - j_first;
+        hipLaunchKernelGGL(k_k256_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases, kvalid, j_first, j_end - 1);
+        SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
+        SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[c], 0));
+        const size_t wl = (size_t)b.max_groups * j_count * 2, fl = (size_t)b.max_groups * j_count * 7;
+        hipLaunchKernelGGL(k_k256_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.bases, b.tmp, ktab, j_first, j_count);
+        hipLaunchKernelGGL(k_k256_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, y.side_b, g, b.tmp, ktab, j_first, j_count);
+        SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
+        SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
+        hipLaunchKernelGGL(k_k256_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, ktab, kvalid, b.gacc, b.acc, j_first, j_end,
+                           c + 1 == chunks ? 1 : 0);
+    }
+    hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
+#undef SBV_TRY
+    return hipGetLastError();
+}
+
+}  // namespace sbv

@@ -96,6 +96,9 @@ struct kapt;
 hipError_t launch_k256_verify(const uint8_t* d_tuples, size_t n, const Scratch& s, u32* d_qtab, const kapt* d_gtab, uint8_t* d_bitmap,
                               hipStream_t stream);
 void host_build_k256_gtable(kapt* out);
+// grouped step on this curve (k256_group_kernels.hip): stage A + stage B; ev_fork recorded on `stream` by the caller
+hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b, u32* d_qtab,
+                                      const kapt* d_gtab, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y);
 #define SBV_K256_GTABLE_ENTRIES ((size_t)17 * 32768)
 
 }  // namespace sbv

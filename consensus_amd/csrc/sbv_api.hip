@@ -77,6 +77,7 @@ struct Context {
     // group_min_batch_cold applies then.  sbv_p256_set_grouping(min_batch != 0) sets both.
     size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17;
     size_t group_min_batch_ed = (size_t)1 << 18;     // Ed25519 keeps no tables between batches: its cold crossover (round 2)
+    size_t group_min_batch_k256 = (size_t)1 << 17;   // secp256k1: per-batch tables only (k256_group.h)
     u32 group_min_count = 64, group_max = 2048;
     bool kc_enabled = true;             // persistent key-table cache (p256_group.h)
     u32 kc_cap = 4096;                  // cached keys (270 KiB of HBM each)
@@ -114,7 +115,7 @@ constexpr int kMaxDevices = 16;
 // context when it is initialised and applied to every live context when they change — a setter called before sbv_init is not
 // lost, and after sbv_init_all it configures ALL devices, not just the default one.  Guarded by g_set_mu (a leaf lock).
 struct Settings {
-    bool group_enabled = true; size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17, group_min_batch_ed = (size_t)1 << 18; u32 group_min_count = 64, group_max = 2048;
+    bool group_enabled = true; size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17, group_min_batch_ed = (size_t)1 << 18, group_min_batch_k256 = (size_t)1 << 17; u32 group_min_count = 64, group_max = 2048;
     bool kc_enabled = true; u32 kc_cap = 4096;
     int profiling = 0;
 } g_settings;
@@ -474,14 +475,14 @@ int init_context(Context& c, int device) {
     {
         std::lock_guard<std::mutex> lk(g_set_mu);
         c.group_enabled = g_settings.group_enabled; c.group_min_batch = g_settings.group_min_batch;
-        c.group_min_batch_cold = g_settings.group_min_batch_cold; c.group_min_batch_ed = g_settings.group_min_batch_ed;
+        c.group_min_batch_cold = g_settings.group_min_batch_cold; c.group_min_batch_ed = g_settings.group_min_batch_ed; c.group_min_batch_k256 = g_settings.group_min_batch_k256;
         c.group_min_count = g_settings.group_min_count; c.group_max = g_settings.group_max;
         c.kc_enabled = g_settings.kc_enabled; c.kc_cap = g_settings.kc_cap;
         c.profiling = g_settings.profiling;
     }
     if (const char* e = getenv("SBV_SMALL")) c.small_enabled = e[0] != '0';
     if (const char* e = getenv("SBV_GROUP")) c.group_enabled = e[0] != '0';
-    if (const char* e = getenv("SBV_GROUP_MIN_BATCH")) { const long v = atol(e); if (v > 0) c.group_min_batch = c.group_min_batch_cold = c.group_min_batch_ed = (size_t)v; }
+    if (const char* e = getenv("SBV_GROUP_MIN_BATCH")) { const long v = atol(e); if (v > 0) c.group_min_batch = c.group_min_batch_cold = c.group_min_batch_ed = c.group_min_batch_k256 = (size_t)v; }
     c.device = device;
     c.ready = true;
     g_err.clear();
@@ -1079,6 +1080,22 @@ int ensure_k256_table(Context& c) {
 }
 }  // namespace
 
+namespace {
+// one chunk (m <= cap) of secp256k1 tuples on `stream`: the grouped step (k256_group_kernels.hip) or the one-lane kernel
+int enqueue_k256(Context& c, const uint8_t* d_tuples, size_t m, uint8_t* d_bitmap, hipStream_t stream) {
+    const sbv::Scratch s = scratch_view(c);
+    if (c.group_enabled && m >= c.group_min_batch_k256) {
+        const int rc = ensure_group_buffers(c, m);
+        if (rc != SBV_OK) return rc;
+        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
+        HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify_grouped(d_tuples, s, m, c.grp, c.d_qtab, c.d_k256_gtab, d_bitmap, stream, c.gsync));
+        return SBV_OK;
+    }
+    HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify(d_tuples, m, s, c.d_qtab, c.d_k256_gtab, d_bitmap, stream));
+    return SBV_OK;
+}
+}  // namespace
+
 extern "C" int sbv_secp256k1_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, void* hip_stream) {
     SBV_ENTER(c);
     if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
@@ -1092,15 +1109,12 @@ extern "C" int sbv_secp256k1_verify_batch_dev(const void* d_tuples, size_t n, vo
     if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(stream, c.busy, 0));
     const uint8_t* src = static_cast<const uint8_t*>(d_tuples);
     uint8_t* dst = static_cast<uint8_t*>(d_bitmap);
-    const sbv::Scratch s = scratch_view(c);
-    hipError_t e = hipSuccess;
-    for (size_t off = 0; off < n && e == hipSuccess; off += kMaxChunk) {
+    for (size_t off = 0; off < n && rc == SBV_OK; off += kMaxChunk) {
         const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
-        e = sbv::launch_k256_verify(src + off * 160, m, s, c.d_qtab, c.d_k256_gtab, dst + off / 8, stream);
+        rc = enqueue_k256(c, src + off * 160, m, dst + off / 8, stream);
     }
     if (hipEventRecord(c.busy, stream) == hipSuccess) c.busy_valid = true;       // the scratch stays ordered behind whatever was enqueued
-    HIP_TRY(SBV_EDEVICE, e);
-    return SBV_OK;
+    return rc;
 }
 
 extern "C" int sbv_secp256k1_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap) {
@@ -1114,7 +1128,6 @@ extern "C" int sbv_secp256k1_verify_batch(const uint8_t* tuples, size_t n, uint8
     if (rc != SBV_OK) return rc;
     if ((rc = ensure_k256_table(c)) != SBV_OK) return rc;
     if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(c.stream, c.busy, 0));
-    const sbv::Scratch s = scratch_view(c);
     sbv_timing tm{};
     tm.n = n;
     for (size_t off = 0; off < n; off += kMaxChunk) {
@@ -1122,7 +1135,7 @@ extern "C" int sbv_secp256k1_verify_batch(const uint8_t* tuples, size_t n, uint8
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[0], c.stream));
         HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_tuples, tuples + off * 160, m * 160, hipMemcpyHostToDevice, c.stream));
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
-        HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify(c.d_tuples, m, s, c.d_qtab, c.d_k256_gtab, c.d_bitmap, c.stream));
+        if ((rc = enqueue_k256(c, c.d_tuples, m, c.d_bitmap, c.stream)) != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
         HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.h_bitmap, c.d_bitmap, (m + 7) / 8, hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[4], c.stream));
@@ -1339,14 +1352,14 @@ extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min
     {
         std::lock_guard<std::mutex> lk(g_set_mu);
         g_settings.group_enabled = enabled != 0;
-        if (min_batch) g_settings.group_min_batch = g_settings.group_min_batch_cold = g_settings.group_min_batch_ed = min_batch;
+        if (min_batch) g_settings.group_min_batch = g_settings.group_min_batch_cold = g_settings.group_min_batch_ed = g_settings.group_min_batch_k256 = min_batch;
         if (min_count) g_settings.group_min_count = min_count;
         if (max_groups) g_settings.group_max = max_groups;
         st = g_settings;
     }
     for (Context* cp : live_contexts()) {
         std::lock_guard<std::mutex> lk(cp->mu);
-        cp->group_enabled = st.group_enabled; cp->group_min_batch = st.group_min_batch; cp->group_min_batch_cold = st.group_min_batch_cold; cp->group_min_batch_ed = st.group_min_batch_ed;
+        cp->group_enabled = st.group_enabled; cp->group_min_batch = st.group_min_batch; cp->group_min_batch_cold = st.group_min_batch_cold; cp->group_min_batch_ed = st.group_min_batch_ed; cp->group_min_batch_k256 = st.group_min_batch_k256;
         cp->group_min_count = st.group_min_count; cp->group_max = st.group_max;
     }
     return SBV_OK;

@@ -21,6 +21,7 @@
 #include "../../consensus_amd/csrc/p256_keytab29.h"
 #include "../../consensus_amd/csrc/p256_sign.h"
 #include "../../consensus_amd/csrc/k256_core.h"
+#include "../../consensus_amd/csrc/k256_group.h"
 
 using namespace sbv;
 
@@ -617,6 +618,79 @@ void sbve_k256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap) {
 }
 
 // ---- unit hooks (plain little-endian limb arrays) ---------------------------------------------------
+// secp256k1 grouped step (k256_group.h, k256_group_kernels.hip) emulated sequentially: stage A with records, grouping, key check
+// of the ungrouped candidates, counting sort, G phase over the sorted list, the per-batch combs (quad chain in lockstep, rows,
+// fill) and the Q phase in `chunks` pieces, the one-lane kernel over the ungrouped list.  stats_out as for the P-256 form.
+void sbve_k256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bitmap, u32 min_count, u32 max_groups, u32 ht_bits, int chunks,
+                                    u32* stats_out) {
+    size_t cap = (n + 63) & ~(size_t)63;
+    if (cap == 0) cap = 64;
+    std::vector<u32> r(8 * cap), u1(8 * cap), u2(8 * cap), qx(8 * cap), qy(8 * cap), sm(8 * cap), rec(cap * SBV_REC_WORDS + 4, 0xDEADBEEFu);
+    std::vector<uint8_t> ok(cap, 0);
+    Scratch s{r.data(), u1.data(), u2.data(), qx.data(), qy.data(), sm.data(), ok.data(), cap};
+    u32* rec_al = rec.data();
+    while ((uintptr_t)rec_al & 15) ++rec_al;
+    s.rec = rec_al;
+    HostWords hw{tuples, 160};
+    for (size_t i = 0; i < n; ++i) k256_prep_lane(hw(0, i), i, s);
+    const u32 G = max_groups ? max_groups : 1;
+    std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(G), counters(SBV_GROUP_COUNTERS, 0), ung_cand(cap),
+        grp_idx(cap, 0xFFFFFFFFu), ung_idx(cap), slots(cap), gcount(2 * (size_t)G, 0), grp_of(cap, 0xFFFFFFFFu);
+    GroupState g{};
+    g.gcount = gcount.data(); g.gcursor = gcount.data() + G; g.grp_of = grp_of.data(); g.ung_cand = ung_cand.data(); g.sorted = 1;
+    g.ht = ht.data(); g.ht_mask = (u32)(((size_t)1 << ht_bits) - 1); g.rep = rep.data(); g.cnt = cnt.data(); g.slot_of = slot_of.data();
+    g.group_rep = group_rep.data(); g.counters = counters.data(); g.grp_idx = grp_idx.data(); g.ung_idx = ung_idx.data();
+    g.slots = slots.data(); g.max_groups = max_groups;
+    group_set_threshold(g, min_count);
+    for (size_t i = 0; i < n; ++i) group_insert_lane(tuples, i, g);
+    for (size_t i = 0; i < n; ++i) group_assign_lane(i, g);
+    std::vector<uint8_t> accb(cap, 0xEE);
+    for (size_t i = 0; i < n; ++i) group_classify_lane(i, g);
+    for (size_t L = counters[4]; L-- > 0;) k256_keycheck_lane(tuples, L, g, accb.data());
+    const u32 ngroups = counters[0] < max_groups ? counters[0] : max_groups;
+    for (size_t i = 0; i < n; ++i) group_sort_count_lane(i, g);
+    group_sort_scan_seq(g, ngroups);
+    for (size_t i = n; i-- > 0;) group_sort_scatter_lane(i, g);
+    std::vector<u32> gacc((size_t)SBV_K256_GACC_WORDS * cap);
+    for (u32 L = 0; L < counters[1]; ++L) k256_gphase_lane_sorted(s, grp_idx[L], L, k256_gtab(), gacc.data());
+    const size_t ng1 = ngroups ? ngroups : 1, per_key = (size_t)SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW;
+    std::vector<u32> bases(ng1 * SBV_GTAB_WINDOWS * SBV_K256_BASES_STRIDE, 0xA5A5A5A5u), jstate(ng1 * SBV_K256_STATE_WORDS), tmpa(SBV_K256_WINDOW_TMP);
+    kapt* ktab = (kapt*)aligned_alloc(64, ng1 * per_key * sizeof(kapt));
+    memset(ktab, 0xA5, ng1 * per_key * sizeof(kapt));
+    std::vector<uint8_t> kvalid(ng1, 0);
+    memset(bitmap, 0, (n + 7) / 8);
+    for (int c = 0; c < chunks; ++c) {
+        const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
+        for (u32 k = 0; k < ngroups; ++k) {
+            k256_quad_host q;
+            k256_chain_run(q, tuples, k, g, jstate.data(), bases.data(), &kvalid[k], j_first, j_end - 1);
+            for (int j = j_first; j < j_end; ++j) {
+                const size_t w = (size_t)k * SBV_GTAB_WINDOWS + j;
+                kapt* row = ktab + w * SBV_GTAB_PER_WINDOW;
+                for (int which = 0; which < 2; ++which) {
+                    if (which == 1 && j == SBV_GTAB_WINDOWS - 1) continue;
+                    k256_rows_lane(bases.data() + w * SBV_K256_BASES_STRIDE, which, j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
+                }
+                if (j == SBV_GTAB_WINDOWS - 1) continue;
+                for (int a = 1; a <= 7; ++a) k256_fill_lane(a, tmpa.data(), row);
+            }
+        }
+        const bool last = c + 1 == chunks;
+        for (u32 L = 0; L < counters[1]; ++L) {
+            const u32 t = grp_idx[L], grp = grp_of[L];
+            const bool v = k256_qphase_lane_sorted(s, t, L, grp < ngroups ? grp : SBV_GROUP_NONE, ngroups, ktab, kvalid.data(), gacc.data(), j_first, j_end, last);
+            if (last && v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+        }
+    }
+    u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB29_WORDS * 4);
+    for (u32 L = 0; L < counters[2]; ++L) {
+        const u32 t = ung_idx[L];
+        if (k256_verify_lane(s, t, qtab, k256_gtab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+    }
+    free(qtab); free(ktab);
+    if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }
+}
+
 void sbve_fe_mul(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe_mul(z, x, y); memcpy(out, &z, 32); }
 void sbve_fe_sqr(const u32* a, u32* out) { fe x, z; memcpy(&x, a, 32); fe_sqr(z, x); memcpy(out, &z, 32); }
 void sbve_fe_add(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); fe_add(z, x, y); memcpy(out, &z, 32); }

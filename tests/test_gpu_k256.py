@@ -121,3 +121,26 @@ def test_full_batch_2_20_device_resident_vs_openssl(gpu, koracle, openssl_check)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"\nsecp256k1: 2^20 tuples in {1e3 * dt:.2f} ms = {n / dt / 1e6:.1f} M verifies/s")
+
+
+def test_grouped_step_equals_the_one_lane_kernel_and_openssl(gpu, koracle, openssl_check):
+    """The grouped step of this curve (k256_group.h: per-batch key combs, key-sorted Q phase) on 2^18 tuples with 300 keys and on a
+    ragged 2^17 + 777: verdicts equal OpenSSL's, the oracle's and the one-lane kernel's (grouping off); group statistics say
+    the comb path really ran."""
+    import numpy as np
+    openssl_check.sbvssl_k256_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+    for n, nkeys in ((1 << 18, 300), ((1 << 17) + 777, 40)):
+        tup, exp = _gen(koracle, 0x6B00 + nkeys, n, nkeys, 6)
+        ssl = ctypes.create_string_buffer((n + 7) // 8)
+        openssl_check.sbvssl_k256_verify_batch(tup, n, ssl, THREADS)
+        want = exp.raw[:(n + 7) // 8]
+        assert ssl.raw == want
+        got = gpu.secp256k1_verify_batch(tup.raw, n)
+        assert got == want, [i for i in range(len(want)) if got[i] != want[i]][:8]
+        groups, grouped, generic, rejected = gpu.last_group_stats()
+        assert groups == nkeys and grouped > n * 0.8 and grouped + generic + rejected == n, (groups, grouped, generic, rejected)
+        gpu.set_grouping(False)
+        try:
+            assert gpu.secp256k1_verify_batch(tup.raw, n) == want
+        finally:
+            gpu.set_grouping(True)

@@ -232,3 +232,35 @@ def test_emulated_device_path_equals_the_oracle_on_a_seeded_batch(emul, koracle)
     emul.sbve_k256_verify_batch(tup.raw, ctypes.c_size_t(n), bm)
     assert bm.raw == exp.raw
     assert sum(bits(exp.raw, n)) == n - n // 3
+
+
+def test_emulated_grouped_step_equals_the_oracle_and_the_one_lane_path(emul, koracle, k256_vectors):
+    """k256_group.h (per-batch key combs built by the quad chain / rows on the isomorphic curve / affine fill, G phase and Q
+    phase over the key-sorted list): the golden vectors replicated so that their keys take the table path, spliced into a seeded
+    batch, in 1, 2 and 3 chunks of windows — verdicts equal the oracle's and the pinned ones, with the field's contract checks
+    on; every key of the batch is grouped (threshold 2) except the corrupted ones."""
+    emul.sbve_k256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    n = 360
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    koracle.sbvo_k256_gen_batch(0x256B, n, 12, 5, tup, exp, 4)
+    blob = b"".join(bytes.fromhex(v["tuple"]) * 3 for v in k256_vectors)
+    allt = tup.raw + blob
+    total = len(allt) // 160
+    want = bits(exp.raw, n) + [v["accept"] for v in k256_vectors for _ in range(3)]
+    ob = ctypes.create_string_buffer((total + 7) // 8)
+    koracle.sbvo_k256_verify_batch(allt, total, ob, 4)
+    assert bits(ob.raw, total) == want
+    stats = (ctypes.c_uint32 * 4)()
+    for chunks in (2, 1, 3):
+        bm = ctypes.create_string_buffer((total + 7) // 8)
+        emul.sbve_k256_verify_batch_grouped(allt, total, bm, 2, 512, 12, chunks, stats)
+        got = bits(bm.raw, total)
+        bad = [i for i in range(total) if got[i] != want[i]]
+        assert not bad, (chunks, bad[:10])
+        assert stats[0] >= 12 and stats[1] > 300 and stats[1] + stats[2] + stats[3] == total, list(stats)
+    # threshold above every count: nothing is grouped, everything takes the one-lane kernel, same verdicts
+    bm = ctypes.create_string_buffer((total + 7) // 8)
+    emul.sbve_k256_verify_batch_grouped(allt, total, bm, 1000, 512, 12, 2, stats)
+    assert bits(bm.raw, total) == want and stats[0] == 0
