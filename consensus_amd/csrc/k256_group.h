@@ -252,12 +252,55 @@ SBV_HD void k256_rec_store(const Scratch& s, size_t i, const u256& u1, const u25
     s.rec[i * SBV_REC_WORDS + SBV_REC_OK] = ok ? 1u : 0u;
 }
 
-SBV_HD void k256_gphase_lane_sorted(const Scratch& s, size_t t, size_t L, const kapt* gtab, u32* gacc) {
+// A table entry as fetched (16 words): the next one is on its way while the current addition runs (the comb of G is 35.7 MB,
+// a key's comb 270 KB: a gather is an L2 / Infinity Cache / HBM round trip that one addition's worth of arithmetic hides).
+struct alignas(16) kraw { u32 w[16]; };
+SBV_HD void kraw_load(kraw& e, const kapt* p) {
+    struct alignas(16) q4 { u32 a, b, c, d; };
+    const q4* s = reinterpret_cast<const q4*>(p);
+    const q4 v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
+    e.w[0] = v0.a; e.w[1] = v0.b; e.w[2] = v0.c; e.w[3] = v0.d; e.w[4] = v1.a; e.w[5] = v1.b; e.w[6] = v1.c; e.w[7] = v1.d;
+    e.w[8] = v2.a; e.w[9] = v2.b; e.w[10] = v2.c; e.w[11] = v2.d; e.w[12] = v3.a; e.w[13] = v3.b; e.w[14] = v3.c; e.w[15] = v3.d;
+}
+SBV_HD void kraw_unpack(kfe& x, kfe& y, const kraw& e) {
+    u256 wx, wy;
+    SBV_UNROLL
+    for (int k = 0; k < 8; ++k) { wx.v[k] = e.w[k]; wy.v[k] = e.w[8 + k]; }
+    kfe_from_words(x, wx);
+    kfe_from_words(y, wy);
+}
+// The comb of G of the grouped step: `bits`-wide signed windows like the P-256 comb (p256_comb29.h: gcomb_recode / gcomb_digit):
+// tab[(j << (bits - 1)) + (m - 1)] = m * 2^(bits j) * G, windows = ceil(257 / bits).  16 bits = the one-lane kernel's table
+// (17 additions, 35.7 MB); 20 bits = 13 additions from 436 MB, built once per process on the host.
+struct kgcomb { const kapt* tab; int bits; int windows; };
+SBV_HD kgcomb kgcomb_make(const kapt* tab, int bits) { kgcomb g = {tab, bits, (257 + bits - 1) / bits}; return g; }
+// R += u1 * G, next entry prefetched
+SBV_HD void k256_gphase_point(kjpt& R, const u256& u1, const kgcomb& gc) {
+    u288 k1;
+    gcomb_recode(k1, u1, gc.bits, gc.windows);
+    u32 idx; bool neg, skip;
+    gcomb_digit(k1, gc.bits, 0, idx, neg, skip);
+    kraw cur;
+    kraw_load(cur, gc.tab + idx);
+    SBV_NOUNROLL
+    for (int j = 0; j < gc.windows; ++j) {
+        const int jn = j + 1 < gc.windows ? j + 1 : gc.windows - 1;
+        u32 idxn; bool negn, skipn;
+        gcomb_digit(k1, gc.bits, jn, idxn, negn, skipn);
+        kraw nxt;
+        kraw_load(nxt, gc.tab + ((size_t)jn << (gc.bits - 1)) + idxn);
+        kfe x, y;
+        kraw_unpack(x, y, cur);
+        kpt_madd(R, R, x, y, neg, skip);
+        cur = nxt; neg = negn; skip = skipn;
+    }
+}
+SBV_HD void k256_gphase_lane_sorted(const Scratch& s, size_t t, size_t L, const kgcomb& gc, u32* gacc) {
     u256 u1;
     rec_load256(u1, s.rec, t, SBV_REC_U1);
     kjpt R;
     kpt_set_inf(R);
-    k256_add_u1G(R, u1, gtab);
+    k256_gphase_point(R, u1, gc);
     k256_gacc_store(gacc, s.cap, L, R);
 }
 
@@ -287,13 +330,22 @@ SBV_HD void k256_qphase_point(kjpt& R, const u256& u2in, const kapt* qtab, int j
     u256 k2;
     const u32 top2 = add_const_limbs(k2, u2, 0x80808080u);
     if (j1 == SBV_GTAB_WINDOWS && !wave_any(top2 != 0)) j1 = SBV_GTAB_WINDOWS - 1;
+    if (j0 >= j1) return;
+    int idx; bool neg, skip;
+    comb_digit(k2, top2, j0, idx, neg, skip);
+    kraw cur;
+    kraw_load(cur, qtab + (size_t)j0 * SBV_GTAB_PER_WINDOW + idx);
     SBV_NOUNROLL
     for (int j = j0; j < j1; ++j) {
-        int idx; bool neg, skip;
-        comb_digit(k2, top2, j, idx, neg, skip);
+        const int jn = j + 1 < j1 ? j + 1 : j1 - 1;
+        int idxn; bool negn, skipn;
+        comb_digit(k2, top2, jn, idxn, negn, skipn);
+        kraw nxt;
+        kraw_load(nxt, qtab + (size_t)jn * SBV_GTAB_PER_WINDOW + idxn);
         kfe x, y;
-        kapt_load(x, y, qtab + (size_t)j * SBV_GTAB_PER_WINDOW + idx);
+        kraw_unpack(x, y, cur);
         kpt_madd(R, R, x, y, neg != flip, skip);
+        cur = nxt; neg = negn; skip = skipn;
     }
 }
 SBV_HD bool k256_qphase_lane_sorted(const Scratch& s, size_t t, size_t L, u32 slot, u32 nslots, const kapt* ktab, const uint8_t* kvalid,

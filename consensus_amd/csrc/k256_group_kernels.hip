@@ -10,6 +10,9 @@
 // area of the comb pool.
 #include <hip/hip_runtime.h>
 
+#include <thread>
+#include <vector>
+
 #include "group_kernels_common.h"
 #include "k256_group.h"
 #include "p256_kernels.h"
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(64) void k_k256_fill(GroupState g, u32* __restrict_
 
 // generic stage B over the ungrouped list (first blocks) + u1 * G over the key-sorted list
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_gphase_generic(Scratch s, GroupState g, u32* __restrict__ qtab, const kapt* __restrict__ gtab,
-                                                                           u32* __restrict__ gacc, uint8_t* __restrict__ acc, unsigned generic_blocks) {
+                                                                           kgcomb gc, u32* __restrict__ gacc, uint8_t* __restrict__ acc, unsigned generic_blocks) {
     if (blockIdx.x < generic_blocks) {
         const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
         if (L >= g.counters[2]) return;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_gphase_generic(Scr
     }
     if (group_count(g) == 0) return;
     const size_t i = (size_t)(blockIdx.x - generic_blocks) * SBV_VERIFY_BLOCK + threadIdx.x;
-    if (i < g.counters[1]) k256_gphase_lane_sorted(s, g.grp_idx[i], i, gtab, gacc);
+    if (i < g.counters[1]) k256_gphase_lane_sorted(s, g.grp_idx[i], i, gc, gacc);
 }
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_qphase(Scratch s, GroupState g, const kapt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
                                                                    u32* __restrict__ gacc, uint8_t* __restrict__ acc, int j0, int j1, int last) {
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_qphase(Scratch s, 
 // stage A + stage B of a grouped secp256k1 batch.  ev_fork must have been recorded on `stream` first.  The per-batch area of the
 // comb pool (b.ktab + kc.cap keys, b.kvalid + kc.cap) holds this batch's tables; group k uses slot k of it.
 hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_in, size_t n, const GroupBuffers& b, u32* d_qtab,
-                                      const kapt* d_gtab, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y) {
+                                      const kapt* d_gtab, const kapt* d_gcomb, int gcomb_bits, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y) {
     if (n == 0) return hipSuccess;
     GroupState g;
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
@@ -161,7 +164,7 @@ hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     hipLaunchKernelGGL(k_group_sort_scatter, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
     SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
     SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
-    hipLaunchKernelGGL(k_k256_gphase_generic, dim3(2 * gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, d_qtab, d_gtab, b.gacc, b.acc, gv);
+    hipLaunchKernelGGL(k_k256_gphase_generic, dim3(2 * gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, d_qtab, d_gtab, kgcomb_make(d_gcomb, gcomb_bits), b.gacc, b.acc, gv);
     const int chunks = 2;
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks, j_count = j_end - j_first;
@@ -181,4 +184,15 @@ hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     return hipGetLastError();
 }
 
+}  // namespace sbv
+
+namespace sbv {
+// the `bits`-wide comb of G for the grouped step, one host thread per window (k256_core.h: k256_build_g_window_bits)
+void host_build_k256_gcomb(int bits, kapt* out) {
+    const int windows = (257 + bits - 1) / bits;
+    std::vector<std::thread> th;
+    for (int j = 0; j < windows; ++j)
+        th.emplace_back([=] { k256_build_g_window_bits(bits, j, out + ((size_t)j << (bits - 1)), 1 << (bits - 1)); });
+    for (auto& t : th) t.join();
+}
 }  // namespace sbv

@@ -87,6 +87,8 @@ struct Context {
     uint64_t* d_moff = nullptr; uint64_t* d_soff = nullptr; size_t moff_cap = 0, soff_cap = 0;
     sbv::aniels* d_btab = nullptr;      // Ed25519 base-point comb, built on first use
     sbv::kapt* d_k256_gtab = nullptr;   // secp256k1 comb of G (17 x 32768 entries), built on first use
+    sbv::kapt* d_k256_gcomb = nullptr;  // the grouped step's wider comb of G (SBV_K256_G_BITS, default 20: 13 x 2^19 entries), built on first use
+    int k256_gbits = 16;
     // latency form of small registered-key batches (k_p256_verify_keyed_small): page-locked buffers mapped into the device's
     // address space — input records + slots, one verdict byte per signature + the completion counter the host polls
     uint8_t* h_small_in = nullptr; void* d_small_in = nullptr;
@@ -369,6 +371,7 @@ int ensure_key_capacity(Context& c, size_t want) {
     }
     if (c.d_btab) (void)hipFree(c.d_btab);
     c.d_btab = nullptr;
+    if (c.d_k256_gcomb == c.d_k256_gtab) c.d_k256_gcomb = nullptr;      // 16-bit configuration: the grouped step borrows this table
     if (c.d_k256_gtab) (void)hipFree(c.d_k256_gtab);
     c.d_k256_gtab = nullptr;
     if (c.d_msgs) (void)hipFree(c.d_msgs);
@@ -559,6 +562,8 @@ int shutdown_context(Context& c) {
     c.d_g16r = nullptr;
     if (c.d_btab) (void)hipFree(c.d_btab);
     c.d_btab = nullptr;
+    if (c.d_k256_gcomb && c.d_k256_gcomb != c.d_k256_gtab) (void)hipFree(c.d_k256_gcomb);
+    c.d_k256_gcomb = nullptr;
     if (c.d_k256_gtab) (void)hipFree(c.d_k256_gtab);
     c.d_k256_gtab = nullptr;
     if (c.d_msgs) (void)hipFree(c.d_msgs);
@@ -1068,6 +1073,23 @@ extern "C" int sbv_ed25519_verify_batch(const uint8_t* tuples, size_t n, uint8_t
 namespace {
 std::vector<sbv::kapt> g_h_k256_gtab;           // built once per process, uploaded to each context on its first secp256k1 call
 std::once_flag g_k256_once;
+std::vector<sbv::kapt> g_h_k256_gcomb;          // the grouped step's comb, built once per process
+int g_k256_gbits = 20;
+std::once_flag g_k256_gcomb_once;
+int ensure_k256_gcomb(Context& c) {
+    if (c.d_k256_gcomb) return SBV_OK;
+    std::call_once(g_k256_gcomb_once, [] {
+        if (const char* e = getenv("SBV_K256_G_BITS")) { const int v = atoi(e); if (v >= 12 && v <= 22) g_k256_gbits = v; }
+        if (g_k256_gbits == 16) return;                 // the one-lane kernel's table serves
+        g_h_k256_gcomb.resize((size_t)((257 + g_k256_gbits - 1) / g_k256_gbits) << (g_k256_gbits - 1));
+        sbv::host_build_k256_gcomb(g_k256_gbits, g_h_k256_gcomb.data());
+    });
+    c.k256_gbits = g_k256_gbits;
+    if (g_k256_gbits == 16) { c.d_k256_gcomb = c.d_k256_gtab; return SBV_OK; }
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_k256_gcomb, g_h_k256_gcomb.size() * sizeof(sbv::kapt)));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_k256_gcomb, g_h_k256_gcomb.data(), g_h_k256_gcomb.size() * sizeof(sbv::kapt), hipMemcpyHostToDevice));
+    return SBV_OK;
+}
 int ensure_k256_table(Context& c) {
     if (c.d_k256_gtab) return SBV_OK;
     std::call_once(g_k256_once, [] {
@@ -1085,10 +1107,11 @@ namespace {
 int enqueue_k256(Context& c, const uint8_t* d_tuples, size_t m, uint8_t* d_bitmap, hipStream_t stream) {
     const sbv::Scratch s = scratch_view(c);
     if (c.group_enabled && m >= c.group_min_batch_k256) {
-        const int rc = ensure_group_buffers(c, m);
+        int rc = ensure_group_buffers(c, m);
         if (rc != SBV_OK) return rc;
+        if ((rc = ensure_k256_gcomb(c)) != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
-        HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify_grouped(d_tuples, s, m, c.grp, c.d_qtab, c.d_k256_gtab, d_bitmap, stream, c.gsync));
+        HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify_grouped(d_tuples, s, m, c.grp, c.d_qtab, c.d_k256_gtab, c.d_k256_gcomb, c.k256_gbits, d_bitmap, stream, c.gsync));
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify(d_tuples, m, s, c.d_qtab, c.d_k256_gtab, d_bitmap, stream));

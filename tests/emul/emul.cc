@@ -618,6 +618,35 @@ void sbve_k256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap) {
 }
 
 // ---- unit hooks (plain little-endian limb arrays) ---------------------------------------------------
+// u1 * G through the grouped step's comb walk (k256_group.h: k256_gphase_point) with a `bits`-wide comb built here
+// (k256_build_g_window_bits, as the host builds the 20-bit one) -> affine x | y words; returns 0 for infinity
+int sbve_k256_gcomb_mul(const u32* u1w, int bits, u32* out16) {
+    static std::vector<kapt> tab;
+    static int tab_bits = 0;
+    const int windows = (257 + bits - 1) / bits;
+    if (tab_bits != bits) {
+        tab.assign((size_t)windows << (bits - 1), kapt{});
+        std::vector<std::thread> th;
+        for (int j = 0; j < windows; ++j) th.emplace_back([=] { k256_build_g_window_bits(bits, j, tab.data() + ((size_t)j << (bits - 1)), 1 << (bits - 1)); });
+        for (auto& t : th) t.join();
+        tab_bits = bits;
+    }
+    u256 u1;
+    memcpy(&u1, u1w, 32);
+    kjpt R;
+    kpt_set_inf(R);
+    k256_gphase_point(R, u1, kgcomb_make(tab.data(), bits));
+    if (R.inf) return 0;
+    kfe zi, zi2, zi3, x, y;
+    kfe_inv(zi, R.Z);
+    kfe_sqr(zi2, zi); kfe_mul(zi3, zi2, zi);
+    kfe_mul(x, R.X, zi2); kfe_mul(y, R.Y, zi3);
+    kapt e;
+    kapt_store(&e, x, y);
+    memcpy(out16, &e, 64);
+    return 1;
+}
+
 // secp256k1 grouped step (k256_group.h, k256_group_kernels.hip) emulated sequentially: stage A with records, grouping, key check
 // of the ungrouped candidates, counting sort, G phase over the sorted list, the per-batch combs (quad chain in lockstep, rows,
 // fill) and the Q phase in `chunks` pieces, the one-lane kernel over the ungrouped list.  stats_out as for the P-256 form.
@@ -652,7 +681,7 @@ void sbve_k256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     group_sort_scan_seq(g, ngroups);
     for (size_t i = n; i-- > 0;) group_sort_scatter_lane(i, g);
     std::vector<u32> gacc((size_t)SBV_K256_GACC_WORDS * cap);
-    for (u32 L = 0; L < counters[1]; ++L) k256_gphase_lane_sorted(s, grp_idx[L], L, k256_gtab(), gacc.data());
+    for (u32 L = 0; L < counters[1]; ++L) k256_gphase_lane_sorted(s, grp_idx[L], L, kgcomb_make(k256_gtab(), 16), gacc.data());
     const size_t ng1 = ngroups ? ngroups : 1, per_key = (size_t)SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW;
     std::vector<u32> bases(ng1 * SBV_GTAB_WINDOWS * SBV_K256_BASES_STRIDE, 0xA5A5A5A5u), jstate(ng1 * SBV_K256_STATE_WORDS), tmpa(SBV_K256_WINDOW_TMP);
     kapt* ktab = (kapt*)aligned_alloc(64, ng1 * per_key * sizeof(kapt));

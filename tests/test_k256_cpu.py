@@ -264,3 +264,21 @@ def test_emulated_grouped_step_equals_the_oracle_and_the_one_lane_path(emul, kor
     bm = ctypes.create_string_buffer((total + 7) // 8)
     emul.sbve_k256_verify_batch_grouped(allt, total, bm, 1000, 512, 12, 2, stats)
     assert bits(bm.raw, total) == want and stats[0] == 0
+
+
+def test_wide_comb_of_G_walk_matches_the_python_twin(emul):
+    """The grouped step's G phase walks a `bits`-wide signed comb (20 bits on the device: 13 additions from 436 MB); the same
+    recoding and table builder with 10-, 13- and 16-bit windows against u1 * G from big integers, edge scalars included."""
+    emul.sbve_k256_gcomb_mul.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    rng = random.Random(0x6C0)
+    scalars = [0, 1, 2, N - 1, N - 2, (1 << 255), (1 << 256) - 1 - (1 << 32), 0x8000800080008000800080008000800080008000800080008000800080008000 % N,
+               0x7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF7FFF] + [rng.randrange(N) for _ in range(24)]
+    out = (ctypes.c_uint32 * 16)()
+    for bits in (10, 13, 16):
+        for u in scalars:
+            got = emul.sbve_k256_gcomb_mul(words(u), bits, out)
+            want = ec.pt_mul(u % N, ec.G) if u % N else None
+            if want is None:
+                assert got == 0
+            else:
+                assert got == 1 and (val(out[:8]), val(out[8:])) == want, (bits, hex(u))
