@@ -409,6 +409,17 @@ SBV_HD void f29_inv(fe29& r, const fe29& a) {
     f29_mul(r, t, f29_r3());
 }
 
+// the same through the constant-time division steps (the signing kernel: Z of k G depends on the nonce)
+SBV_HD void f29_inv_ct(fe29& r, const fe29& a) {
+    fe29 c, t;
+    f29_canon(c, a);
+    u256 x, y;
+    f29_pack(x.v, c);
+    modinv30_ct(y, x, modinfo30_p256());
+    f29_unpack(t, y.v);
+    f29_mul(r, t, f29_r3());
+}
+
 // x * 2^261 -> canonical 8-word value of the SAME domain (table / scratch storage: unpack gives it back)
 SBV_HD void f29_store_canon(u32 w[8], const fe29& a) {
     fe29 c;

@@ -99,4 +99,14 @@ SBV_HD void s29_inv(fe29& r, const fe29& a) {
     s29_mul(r, t, s29_r3());
 }
 
+// constant-time form (the signing kernel inverts the secret nonce)
+SBV_HD void s29_inv_ct(fe29& r, const fe29& a) {
+    u256 x, y;
+    s29_store_canon(x, a);
+    modinv30_ct(y, x, modinfo30_p256_order());
+    fe29 t;
+    f29_unpack(t, y.v);
+    s29_mul(r, t, s29_r3());
+}
+
 }  // namespace sbv

@@ -112,7 +112,7 @@ SBV_HD bool sign29_with_nonce(const u256& d, const u256& k, const u256& e, const
     gphase29_point(R, k, gc);
     if (R.inf) return false;                       // cannot happen for 0 < k < N
     fe29 zi, xM, x1, one_plain = {{1, 0, 0, 0, 0, 0, 0, 0, 0}};
-    f29_inv(zi, R.ZZ);
+    f29_inv_ct(zi, R.ZZ);
     f29_mul(xM, R.X, zi);                          // affine x, Montgomery domain
     f29_mul(x1, xM, one_plain);                    // plain
     u256 x;
@@ -122,7 +122,7 @@ SBV_HD bool sign29_with_nonce(const u256& d, const u256& k, const u256& e, const
     fe29 kL, kM, kinv, rL, dL, dM, eL, t, sM;
     f29_unpack(kL, k.v);
     s29_mul(kM, kL, s29_r2());
-    s29_inv(kinv, kM);                             // k^-1 (Montgomery)
+    s29_inv_ct(kinv, kM);                          // k^-1 (Montgomery)
     f29_unpack(rL, r.v);
     f29_unpack(dL, d.v);
     f29_unpack(eL, e.v);

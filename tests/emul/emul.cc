@@ -647,6 +647,19 @@ int sbve_k256_gcomb_mul(const u32* u1w, int bits, u32* out16) {
     return 1;
 }
 
+// modinv30.h: the variable-time division steps against the constant-time ones and the modulus (0 = P-256 p, 1 = P-256 n,
+// 2 = 2^255 - 19, 3 = secp256k1 p, 4 = secp256k1 n); out_var / out_ct = x^-1 mod m; returns 1 when both agree
+int sbve_modinv30_both(const u32* x8, int which, u32* out_var, u32* out_ct) {
+    const modinfo30 mi = which == 0 ? modinfo30_p256() : which == 1 ? modinfo30_p256_order() : which == 2 ? modinfo30_25519()
+                       : which == 3 ? modinfo30_k256_p() : modinfo30_k256_n();
+    u256 x, a, b;
+    memcpy(&x, x8, 32);
+    modinv30(a, x, mi);
+    modinv30_ct(b, x, mi);
+    memcpy(out_var, &a, 32); memcpy(out_ct, &b, 32);
+    return memcmp(&a, &b, 32) == 0;
+}
+
 // secp256k1 grouped step (k256_group.h, k256_group_kernels.hip) emulated sequentially: stage A with records, grouping, key check
 // of the ungrouped candidates, counting sort, G phase over the sorted list, the per-batch combs (quad chain in lockstep, rows,
 // fill) and the Q phase in `chunks` pieces, the one-lane kernel over the ungrouped list.  stats_out as for the P-256 form.

@@ -556,3 +556,19 @@ def test_two_field_representations_agree(emul, oracle, golden_vectors):
     emul.sbve_p256_verify_batch_v0(allt, total, b, 64, 4)
     assert _bitmap_list(a.raw, total) == want
     assert _bitmap_list(b.raw, total) == want
+
+
+def test_variable_time_division_steps_equal_the_constant_time_ones_and_the_inverse(emul):
+    """modinv30.h: divsteps30_var takes a run of even g in one iteration and modinv30 stops when g is 0 — step for step the same
+    sequence as the branch-free form, so the two must agree bit for bit and both must be x^-1 mod m, for all five moduli of the
+    library (P-256 p and n, 2^255 - 19, secp256k1 p and n), on edge values and on random ones; 0 maps to 0."""
+    emul.sbve_modinv30_both.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    moduli = [P, N, 2**255 - 19, 2**256 - 2**32 - 977, 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141]
+    rng = random.Random(0x30)
+    a, b = (ctypes.c_uint32 * 8)(), (ctypes.c_uint32 * 8)()
+    for which, m in enumerate(moduli):
+        xs = [0, 1, 2, 3, m - 1, m - 2, (m - 1) // 2, (m + 1) // 2, 2**32, 2**64 - 1, 2**128, 2**255 % m, 2**30, 2**30 - 1, 2**60 + 1,
+              (1 << 200) - 1] + [rng.randrange(m) for _ in range(400)] + [rng.randrange(1, 1 << rng.randrange(1, 256)) % m for _ in range(200)]
+        for x in xs:
+            assert emul.sbve_modinv30_both(limbs(x), which, a, b) == 1, (which, hex(x))
+            assert val(a) == (pow(x, -1, m) if x else 0), (which, hex(x))
