@@ -178,6 +178,41 @@ __global__ __launch_bounds__(64) void k_keytab29_fill(GroupState g, u32* __restr
     keytab29_fill_lane(a_first, a_last, t, ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
 }
 
+// Wide forms (GroupSync::wide, default): one lane per entry of the fill step's inputs, and the 7 rows in `split` parts each.
+// lanes = groups x j_count x 24 (lane 23 of each window idles: 24 keeps a window inside one wavefront's 64-lane row pairs)
+__global__ __launch_bounds__(64, 3) void k_keytab29_entries(GroupState g, const u32* __restrict__ bases, apt* __restrict__ ktab,
+                                                         const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
+                                                         int j_first, int j_count) {
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 e = lane % 24u, kw = lane / 24u;
+    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
+    if (key >= group_count(g) || !cold[key] || e >= SBV_KT29_ENTRY_LANES) return;
+    table_prio();
+    const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
+    keytab29_entry_lane(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), (int)e, j == SBV_GTAB_WINDOWS - 1,
+                        ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
+}
+// lanes = groups x j_count x (7 x split); lane r of a window: row a = 1 + r / split, entries b of part r % split
+__global__ __launch_bounds__(64) void k_keytab29_fill_parts(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab,
+                                                            const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
+                                                            int j_first, int j_count, int split) {
+    const u32 lpw = 7u * (u32)split;
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 r = lane % lpw, kw = lane / lpw;
+    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
+    if (key >= group_count(g) || j == SBV_GTAB_WINDOWS - 1 || !cold[key]) return;
+    const int a = 1 + (int)(r / (u32)split), part = (int)(r % (u32)split);
+    const int per = (15 + split - 1) / split;
+    const int b_first = 1 + part * per;
+    int b_last = b_first + per - 1;
+    if (b_last > 15) b_last = 15;
+    if (b_first > 15) return;
+    table_prio();
+    const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
+    u32* t = tmp + w * SBV_KT29_WINDOW_TMP + (size_t)r * (15 * 9);
+    keytab29_fill_part_lane(a, b_first, b_last, t, ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
+}
+
 // One launch, two jobs.  Blocks [0, generic_blocks): the generic stage B (doubling kernel) over the
 // ungrouped list — keys that repeat too rarely for a table; a 2.3 ms serial chain per lane on ~5 % of the
 // tuples, so it has to start as early as possible and run BESIDE the throughput work, at the same
@@ -369,12 +404,21 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
                                b.kvalid, b.tslot, b.cold, j_first, j_end - 1);
             SBV_TRY(hipEventRecord(y.ev_bases[tc], y.side_a));
             SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[tc], 0));
-            const size_t wl = (size_t)b.max_groups * j_count * 2;
-            hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
-            const int lpw = (7 + rows_per_lane - 1) / rows_per_lane;
-            const size_t fl = (size_t)b.max_groups * j_count * lpw;
-            hipLaunchKernelGGL(k_keytab29_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, y.side_b, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count,
-                               rows_per_lane, lpw);
+            if (y.wide) {
+                const size_t wl = (size_t)b.max_groups * j_count * 24;
+                hipLaunchKernelGGL(k_keytab29_entries, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.bases, b.ktab, b.tslot, b.cold, j_first, j_count);
+                const int split = y.fsplit < 1 ? 1 : (y.fsplit > 4 ? 4 : y.fsplit);
+                const size_t fl = (size_t)b.max_groups * j_count * 7 * split;
+                hipLaunchKernelGGL(k_keytab29_fill_parts, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, y.side_b, g, b.tmp, b.ktab, b.tslot, b.cold, j_first,
+                                   j_count, split);
+            } else {
+                const size_t wl = (size_t)b.max_groups * j_count * 2;
+                hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
+                const int lpw = (7 + rows_per_lane - 1) / rows_per_lane;
+                const size_t fl = (size_t)b.max_groups * j_count * lpw;
+                hipLaunchKernelGGL(k_keytab29_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, y.side_b, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count,
+                                   rows_per_lane, lpw);
+            }
         }
         SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));

@@ -246,7 +246,7 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ung_cand, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.rec, c.cap * (size_t)SBV_REC_WORDS * sizeof(u32)));    // indexed like the scratch planes
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jbases, G * SBV_GTAB_WINDOWS * (size_t)40 * sizeof(u32)));   // 40 dwords = one Jacobian base (p256_group.h)
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.bases, G * SBV_GTAB_WINDOWS * (size_t)(2 * 36) * sizeof(u32)));       // SBV_KT29_REC_WORDS per recorded point
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.bases, G * SBV_GTAB_WINDOWS * (size_t)(8 * 36) * sizeof(u32)));       // p256_keytab29.h: SBV_KT29_POINTS_PER_WINDOW records of SBV_KT29_REC_WORDS
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jstate, G * (size_t)36 * sizeof(u32)));                                  // SBV_KT29_STATE_WORDS
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 40 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride; 36 words (P-256: XYZZ, 9-limb coordinates) or 40 (Ed25519: extended, 10-limb coordinates) per tuple
     // comb pool: slots [0, kc_cap) belong to the persistent key-table cache, [kc_cap, kc_cap + G) are rebuilt per batch
@@ -459,6 +459,8 @@ int init_context(Context& c, int device) {
     }
     if (const char* e = getenv("SBV_GROUP_TSUB")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.tsub = v; }
     if (const char* e = getenv("SBV_GROUP_PARTS")) c.gsync.parts = atoi(e);
+    if (const char* e = getenv("SBV_GROUP_WIDE")) c.gsync.wide = atoi(e) != 0;
+    if (const char* e = getenv("SBV_GROUP_FSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.fsplit = v; }
     if (const char* e = getenv("SBV_GROUP_SLICES")) c.gsync.slices = atoi(e);
     if (const char* e = getenv("SBV_GROUP_SORT")) c.gsync.sorted = atoi(e) != 0;
     if (const char* e = getenv("SBV_GENERIC_STREAM")) {

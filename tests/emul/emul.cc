@@ -130,7 +130,7 @@ unsigned long sbve_fast_mismatches() { return g_fast_mismatches; }
 u32 sbve_fe_add_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_add<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 u32 sbve_fe_mul_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_mul<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 
-static int g_group_chunks = 3, g_group_parts = 4, g_group_sort = 1;
+static int g_group_chunks = 3, g_group_parts = 4, g_group_sort = 1, g_group_wide = 1, g_group_fsplit = 3;
 void sbve_set_group_sort(int on) { g_group_sort = on ? 1 : 0; }
 static unsigned long g_sort_violations = 0;
 unsigned long sbve_group_sort_violations() { return g_sort_violations; }
@@ -151,6 +151,8 @@ void sbve_key_cache(int enabled, u32 cap) {
 }
 void sbve_key_cache_stats(u32 out[3]) { out[0] = g_kc.count ? g_kc_count[0] : 0; out[1] = g_kc.count ? g_kc_count[1] : 0; out[2] = g_kc.count ? g_kc_count[2] : 0; }
 void sbve_set_group_chunks(int c) { g_group_chunks = c < 1 ? 1 : (c > 4 ? 4 : c); }
+static void emul_window_rows_fill(const u32* recs, bool top, int rpl, u32* tmp, apt* row);
+void sbve_set_group_wide(int wide, int fsplit) { g_group_wide = wide != 0; if (fsplit >= 1 && fsplit <= 4) g_group_fsplit = fsplit; }
 void sbve_set_group_parts(int p) { if (p == 2 || p == 4 || p == 8 || p == 16) g_group_parts = p; }
 // grouped form: generic tuples, keys grouped inside the call (p256_group.h), emulated sequentially.
 // stats_out[0..3] = groups, grouped tuples, ungrouped tuples, ungrouped tuples rejected for their key.
@@ -258,12 +260,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             for (int j = j_first; j < j_end && cold[k]; ++j) {
                 const size_t w = (size_t)k * SBV_GTAB_WINDOWS + j;
                 apt* row = table_of(k) + (size_t)j * SBV_GTAB_PER_WINDOW;
-                for (int which = 0; which < 2; ++which) {
-                    if (which == 1 && j == SBV_GTAB_WINDOWS - 1) continue;
-                    keytab29_rows_lane(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), which, j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
-                }
-                if (j == SBV_GTAB_WINDOWS - 1) continue;
-                for (int a = 1; a <= 7; a += rpl) keytab29_fill_lane(a, a + rpl - 1 > 7 ? 7 : a + rpl - 1, tmpa.data(), row);
+                emul_window_rows_fill(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, rpl, tmpa.data(), row);
             }
         const bool last = c + 1 == chunks;
         for (u32 L = 0; L < counters[1]; ++L) {
@@ -285,6 +282,29 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     }
     free(qtab); free(ktab); free(bases);
     if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }
+}
+
+// rows + fill of one (key, window) the way the launcher's two forms do it (k_keytab29_entries + k_keytab29_fill_parts, or
+// k_keytab29_rows + k_keytab29_fill)
+static void emul_window_rows_fill(const u32* recs, bool top, int rpl, u32* tmp, apt* row) {
+    if (g_group_wide) {
+        for (int e = 0; e < SBV_KT29_ENTRY_LANES; ++e) keytab29_entry_lane(recs, e, top, row);
+        if (top) return;
+        const int split = g_group_fsplit, per = (15 + split - 1) / split;
+        for (int r = 0; r < 7 * split; ++r) {
+            const int a = 1 + r / split, b_first = 1 + (r % split) * per;
+            const int b_last = b_first + per - 1 > 15 ? 15 : b_first + per - 1;
+            if (b_first > 15) continue;
+            keytab29_fill_part_lane(a, b_first, b_last, tmp + (size_t)r * (15 * 9), row);
+        }
+        return;
+    }
+    for (int which = 0; which < 2; ++which) {
+        if (which == 1 && top) continue;
+        keytab29_rows_lane(recs, which, top, tmp, row);
+    }
+    if (top) return;
+    for (int a = 1; a <= 7; a += rpl) keytab29_fill_lane(a, a + rpl - 1 > 7 ? 7 : a + rpl - 1, tmp, row);
 }
 
 // n doublings of the affine point (x, y) (plain words) through the quad-cooperative chain of the table builder
@@ -335,12 +355,7 @@ int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
         keychain29_run(q, tup.data(), 0, g, jstate.data(), bases.data(), &valid, j_first, j_end - 1);
         for (int j = j_first; j < j_end; ++j) {
             apt* row = ktab + (size_t)j * SBV_GTAB_PER_WINDOW;
-            for (int which = 0; which < 2; ++which) {
-                if (which == 1 && j == SBV_GTAB_WINDOWS - 1) continue;
-                keytab29_rows_lane(bases.data() + (size_t)j * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), which, j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
-            }
-            if (j == SBV_GTAB_WINDOWS - 1) continue;
-            for (int a = 1; a <= 7; ++a) keytab29_fill_lane(a, a, tmpa.data(), row);
+            emul_window_rows_fill(bases.data() + (size_t)j * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, 1, tmpa.data(), row);
         }
     }
     return valid;
