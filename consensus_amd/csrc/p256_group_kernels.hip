@@ -136,14 +136,14 @@ struct keychain_quad_dev {
 __global__ __launch_bounds__(64) void k_keytab29_chain(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jstate,
                                                        u32* __restrict__ bases, uint8_t* __restrict__ valid,
                                                        const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
-                                                       int j_first, int j_last) {
+                                                       int j_first, int j_last, u32 rec_mask) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;
     const u32 k = lane >> 2;
     if (k >= group_count(g) || !cold[k]) return;
     table_prio();
     keychain_quad_dev q;
     q.r = (int)(lane & 3u);
-    keychain29_run(q, tuples, k, g, jstate, bases, valid + tslot[k], j_first, j_last);
+    keychain29_run(q, tuples, k, g, jstate, bases, valid + tslot[k], j_first, j_last, rec_mask);
 }
 // lanes = groups x j_count x 2
 __global__ __launch_bounds__(64, 2) void k_keytab29_rows(GroupState g, const u32* __restrict__ bases, u32* __restrict__ tmp,
@@ -401,7 +401,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
             if (j_count <= 0) continue;
             const int tc = c * tsub + t;
             hipLaunchKernelGGL(k_keytab29_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases,
-                               b.kvalid, b.tslot, b.cold, j_first, j_end - 1);
+                               b.kvalid, b.tslot, b.cold, j_first, j_end - 1, y.wide ? 0xFFu : 0x11u);
             SBV_TRY(hipEventRecord(y.ev_bases[tc], y.side_a));
             SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[tc], 0));
             if (y.wide) {

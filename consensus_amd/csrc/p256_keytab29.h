@@ -202,10 +202,11 @@ SBV_HD void kchain_store_part(u32* dst, const kchain& s, int role) {
 
 // The whole chain of one chunk for one quad.  bases: [(gidx * 33 + j) * 8 + d] records of SBV_KT29_REC_WORDS words =
 // 2^d B_j, B_j = 2^(8j) Q, as the chain left them (modified Jacobian, NOT normalised).  jstate[gidx]: the running point between
-// chunks (B of the next window).  valid: the byte of this key's TABLE SLOT (written with the first chunk).
+// chunks (B of the next window).  valid: the byte of this key's TABLE SLOT (written with the first chunk).  rec_mask: bit d =
+// record 2^d B_j (the chain-of-additions rows kernel reads d = 0 and 4 only: 0x11).
 template <class QX>
 SBV_HD void keychain29_run(QX& q, const uint8_t* tuples, u32 gidx, const GroupState& g, u32* jstate, u32* bases, uint8_t* valid,
-                           int j_first, int j_last) {
+                           int j_first, int j_last, u32 rec_mask = 0xFFu) {
     u32* st = jstate + (size_t)gidx * SBV_KT29_STATE_WORDS;
     if (j_first == 0) {
         fe29 x, y;
@@ -226,8 +227,10 @@ SBV_HD void keychain29_run(QX& q, const uint8_t* tuples, u32 gidx, const GroupSt
         SBV_NOUNROLL
         for (int d = 0; d < 8; ++d) {
             u32* rec = bases + (((size_t)gidx * SBV_GTAB_WINDOWS + j) * SBV_KT29_POINTS_PER_WINDOW + d) * SBV_KT29_REC_WORDS;
-            SBV_UNROLL
-            for (int i = 0; i < QX::N; ++i) kchain_store_part(rec, q.s[i], q.role(i));
+            if ((rec_mask >> d) & 1u) {
+                SBV_UNROLL
+                for (int i = 0; i < QX::N; ++i) kchain_store_part(rec, q.s[i], q.role(i));
+            }
             if (j == SBV_GTAB_WINDOWS - 1) break;           // the top window has the single entry B_32
             keychain29_dbl(q);
         }

@@ -446,8 +446,17 @@ int init_context(Context& c, int device) {
         int lo = 0, hi = 0;
         const char* e = getenv("SBV_SIDE_PRIO");
         const bool prio = e && e[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo;
+        // SBV_TABLE_CUS=N (experiment, default off): the side streams may only use N compute units (mask bits 0 .. N-1; the
+        // driver deals mask bits round-robin over the 8 XCDs).  A table wave of 122-256 VGPRs pushes a 256-VGPR G/Q-phase
+        // wave off its SIMD for its whole 0.3 ms life; the mask concentrates that on N CUs instead of all 256.
+        int table_cus = 0;
+        if (const char* m = getenv("SBV_TABLE_CUS")) table_cus = atoi(m);
         for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b}) {
-            if (prio) HIP_TRY(SBV_ENODEV, hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi));
+            if (table_cus > 0 && table_cus < prop.multiProcessorCount) {
+                std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0u);
+                for (int b = 0; b < table_cus; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
+                HIP_TRY(SBV_ENODEV, hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()));
+            } else if (prio) HIP_TRY(SBV_ENODEV, hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi));
             else HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
         }
     }

@@ -130,7 +130,7 @@ unsigned long sbve_fast_mismatches() { return g_fast_mismatches; }
 u32 sbve_fe_add_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_add<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 u32 sbve_fe_mul_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_mul<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 
-static int g_group_chunks = 3, g_group_parts = 4, g_group_sort = 1, g_group_wide = 1, g_group_fsplit = 3;
+static int g_group_chunks = 3, g_group_parts = 4, g_group_sort = 1, g_group_wide = 0, g_group_fsplit = 3;
 void sbve_set_group_sort(int on) { g_group_sort = on ? 1 : 0; }
 static unsigned long g_sort_violations = 0;
 unsigned long sbve_group_sort_violations() { return g_sort_violations; }
@@ -254,7 +254,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
         for (u32 k = 0; k < ngroups; ++k)
             if (cold[k]) {               // k_keytab29_chain: the four lanes of the key's quad in lockstep
                 keychain_quad_host q;
-                keychain29_run(q, tuples, k, g, jstate.data(), bases, valid_of(k), j_first, j_end - 1);
+                keychain29_run(q, tuples, k, g, jstate.data(), bases, valid_of(k), j_first, j_end - 1, g_group_wide ? 0xFFu : 0x11u);
             }
         for (u32 k = 0; k < ngroups; ++k)
             for (int j = j_first; j < j_end && cold[k]; ++j) {
@@ -352,7 +352,7 @@ int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
         keychain_quad_host q;
-        keychain29_run(q, tup.data(), 0, g, jstate.data(), bases.data(), &valid, j_first, j_end - 1);
+        keychain29_run(q, tup.data(), 0, g, jstate.data(), bases.data(), &valid, j_first, j_end - 1, g_group_wide ? 0xFFu : 0x11u);
         for (int j = j_first; j < j_end; ++j) {
             apt* row = ktab + (size_t)j * SBV_GTAB_PER_WINDOW;
             emul_window_rows_fill(bases.data() + (size_t)j * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, 1, tmpa.data(), row);

@@ -289,7 +289,7 @@ def test_key_comb_scalars_around_the_sign_flip_and_the_carry_window(emul, oracle
         assert _bitmap_list(bm.raw, total) == want, (chunks, wide)
         assert stats[1] == total
     emul.sbve_set_group_chunks(3)
-    emul.sbve_set_group_wide(1, 3)
+    emul.sbve_set_group_wide(0, 3)
 
 
 def test_fast_conditional_subtraction_is_exact_or_flags(emul):
@@ -392,7 +392,7 @@ def test_grouped_by_key_inside_the_batch_matches_generic(emul, oracle, golden_ve
             assert stats[0] == 0 and stats[2] + stats[3] == total and stats[3] >= 40    # the repeated off-curve key at least
     emul.sbve_set_group_chunks(3)
     emul.sbve_set_group_parts(4)
-    emul.sbve_set_group_wide(1, 3)
+    emul.sbve_set_group_wide(0, 3)
 
 
 def test_key_sorted_grouped_list_equals_compaction_order(emul, oracle, golden_vectors):

@@ -280,7 +280,7 @@ def test_key_table_of_the_key_that_wrapped_a_limb(emul):
                 e = tab[(j * 128 + m_ - 1) * 16:(j * 128 + m_) * 16]
                 want = ec.pt_mul(m_, base)
                 assert (wval(e[:8]), wval(e[8:])) == (want[0] * R % P, want[1] * R % P), (wide, fsplit, chunks, j, m_)
-    emul.sbve_set_group_wide(1, 3)
+    emul.sbve_set_group_wide(0, 3)
     off = bytearray(key)
     off[63] ^= 1
     assert emul.sbve_keytab_build(bytes(off), 2, tab) == 0          # pointFromAffine refuses it (key29_load)
