@@ -395,6 +395,8 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     while (chunks * tsub > SBV_GROUP_MAX_TCHUNKS) --tsub;
     for (int c = 0; c < chunks; ++c) {
         const int q_first = SBV_GTAB_WINDOWS * c / chunks, q_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [q_first, q_end)
+        const int ts = y.tstreams > 1 ? c % y.tstreams : 0;
+        hipStream_t tb = ts == 0 || !y.side_t[ts - 1] ? y.side_b : y.side_t[ts - 1];     // rows + fill of this chunk
         for (int t = 0; t < tsub; ++t) {
             const int j_first = q_first + (q_end - q_first) * t / tsub, j_end = q_first + (q_end - q_first) * (t + 1) / tsub;
             const int j_count = j_end - j_first;
@@ -403,24 +405,24 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
             hipLaunchKernelGGL(k_keytab29_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases,
                                b.kvalid, b.tslot, b.cold, j_first, j_end - 1, y.wide ? 0xFFu : 0x11u);
             SBV_TRY(hipEventRecord(y.ev_bases[tc], y.side_a));
-            SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[tc], 0));
+            SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[tc], 0));
             if (y.wide) {
                 const size_t wl = (size_t)b.max_groups * j_count * 24;
-                hipLaunchKernelGGL(k_keytab29_entries, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.bases, b.ktab, b.tslot, b.cold, j_first, j_count);
+                hipLaunchKernelGGL(k_keytab29_entries, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.ktab, b.tslot, b.cold, j_first, j_count);
                 const int split = y.fsplit < 1 ? 1 : (y.fsplit > 4 ? 4 : y.fsplit);
                 const size_t fl = (size_t)b.max_groups * j_count * 7 * split;
-                hipLaunchKernelGGL(k_keytab29_fill_parts, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, y.side_b, g, b.tmp, b.ktab, b.tslot, b.cold, j_first,
+                hipLaunchKernelGGL(k_keytab29_fill_parts, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, b.ktab, b.tslot, b.cold, j_first,
                                    j_count, split);
             } else {
                 const size_t wl = (size_t)b.max_groups * j_count * 2;
-                hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
+                hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
                 const int lpw = (7 + rows_per_lane - 1) / rows_per_lane;
                 const size_t fl = (size_t)b.max_groups * j_count * lpw;
-                hipLaunchKernelGGL(k_keytab29_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, y.side_b, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count,
+                hipLaunchKernelGGL(k_keytab29_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count,
                                    rows_per_lane, lpw);
             }
         }
-        SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
+        SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         const bool last = c + 1 == chunks;
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));

@@ -317,6 +317,13 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
     if (grouped) {
         const int rc = ensure_group_buffers(c, n);
         if (rc != SBV_OK) return rc;
+        // Below 2^18 tuples the step is latency: one straggling tuple in the one-lane doubling kernel (2.3 ms) outlasts the
+        // whole table pipeline (1.7 ms at 1024 cold keys).  A threshold of 64 uses, counted on every 8th tuple, loses 3 % of
+        // the keys of a 2^17 batch over 1024 signers (128 uses each, 16 +- 3.7 samples against 8) and the step went from 1.7
+        // to 2.2-2.5 ms (profiles/r03/sweep_sizes_r03a.jsonl: 2582 tuples on the one-lane path); 32 uses, counted on every
+        // 4th tuple (32 +- 4.9 samples against 8), loses none.  At full size the configured threshold stands: twice the
+        // counting atomics in k_group_insert, which is on the path to the G phase.
+        if (n < ((size_t)1 << 18) && c.grp.min_count > 32) c.grp.min_count = 32;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
     }
     if (grouped) {           // stage A is enqueued by the grouped launcher, in slices pipelined with the G phase
@@ -461,6 +468,11 @@ int init_context(Context& c, int device) {
         }
     }
     for (hipEvent_t* ev : group_events(c)) HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    {   // every knob back to its default: a context initialised again re-reads the environment
+        const sbv::GroupSync d;
+        c.gsync.tsub = d.tsub; c.gsync.parts = d.parts; c.gsync.wide = d.wide; c.gsync.fsplit = d.fsplit; c.gsync.slices = d.slices;
+        c.gsync.sorted = d.sorted; c.gsync.tstreams = d.tstreams;
+    }
     c.gsync.chunks = 2;
     if (const char* e = getenv("SBV_GROUP_CHUNKS")) {
         const int v = atoi(e);
@@ -468,6 +480,8 @@ int init_context(Context& c, int device) {
     }
     if (const char* e = getenv("SBV_GROUP_TSUB")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.tsub = v; }
     if (const char* e = getenv("SBV_GROUP_PARTS")) c.gsync.parts = atoi(e);
+    if (const char* e = getenv("SBV_GROUP_TSTREAMS")) { const int v = atoi(e); if (v >= 1 && v <= SBV_GROUP_MAX_CHUNKS) c.gsync.tstreams = v; }
+    for (int i = 0; i + 1 < c.gsync.tstreams; ++i) HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.gsync.side_t[i], hipStreamNonBlocking));
     if (const char* e = getenv("SBV_GROUP_WIDE")) c.gsync.wide = atoi(e) != 0;
     if (const char* e = getenv("SBV_GROUP_FSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.fsplit = v; }
     if (const char* e = getenv("SBV_GROUP_SLICES")) c.gsync.slices = atoi(e);
@@ -606,7 +620,8 @@ int shutdown_context(Context& c) {
         for (auto& ev : sl.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
         sl = StageSlot();
     }
-    for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b, &c.gsync.side_c}) if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
+    for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b, &c.gsync.side_c, &c.gsync.side_t[0], &c.gsync.side_t[1], &c.gsync.side_t[2]})
+        if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
     for (hipEvent_t* ev : group_events(c)) if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
     c.busy_valid = false;
     c.ready = false;
