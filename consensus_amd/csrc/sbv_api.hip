@@ -552,7 +552,8 @@ void rccl_teardown();
 // replica route of the sharded entry) and is only touched under that device's context lock.
 struct ShardBuffers { uint8_t* d_gather = nullptr; size_t gather_cap = 0; uint8_t* d_q = nullptr; size_t q_cap = 0;
                       uint8_t* d_on = nullptr; size_t on_cap = 0; uint8_t* d_onq = nullptr; size_t onq_cap = 0;
-                      uint8_t* d_full = nullptr; size_t full_cap = 0; };       // key-affine mode: the whole batch on every device
+                      uint8_t* d_full = nullptr; size_t full_cap = 0;          // key-affine mode: the whole batch on every device
+                      uint8_t* d_stage2 = nullptr; size_t stage2_cap = 0; };   // second upload slot of verify_shard (the first is Context::d_tuples)
 ShardBuffers g_shard[kMaxDevices];
 std::mutex g_sharded_mu;
 // staging of the key-affine partition (part_enqueue below), per device, under that device's context lock
@@ -572,6 +573,7 @@ int shutdown_context(Context& c) {
         if (sb.d_on) (void)hipFree(sb.d_on);
         if (sb.d_onq) (void)hipFree(sb.d_onq);
         if (sb.d_full) (void)hipFree(sb.d_full);
+        if (sb.d_stage2) (void)hipFree(sb.d_stage2);
         sb = ShardBuffers();
         PartBuffers& pb = g_part[c.device];
         if (pb.d_dense) (void)hipFree(pb.d_dense);
@@ -1557,6 +1559,7 @@ struct RcclApi {
 std::vector<int> g_devs;               // devices initialised by sbv_init_all, ascending
 std::atomic<unsigned> g_rr{0};         // round-robin cursor of the replica route
 size_t g_shard_min = (size_t)1 << 18;  // tuples per device below which a batch is not split
+size_t g_shard_piece = (size_t)1 << 18;  // verify_shard: tuples per upload piece when the key-table cache is on (SBV_SHARD_PIECE)
 // How a batch that spans devices is partitioned: 0 = contiguous ranges of tuples (every device sees every key), 1 = by a
 // hash of the public key (device g builds the tables of its keys only; every device receives the whole batch).
 // g_shard_parts: parts of the key-affine partition; 0 = one per device.  More parts than devices run one after another on
@@ -1732,41 +1735,6 @@ int part_enqueue(Context& c, const uint8_t* d_tuples, size_t n, u32 part, u32 pa
     return SBV_OK;
 }
 
-// One device's share of a sharded call; c.mu held.  Chunks of at most kMaxChunk tuples (a multiple of the granule):
-// H2D into the staging buffer, stage A + B with the bitmap written straight into this device's slot of the gather buffer,
-// the quorum bits of the chunk, then the stream is drained before the staging buffer is reused.
-int verify_shard(Context& c, const uint8_t* h_tuples, size_t m, size_t group, u32 quorum, uint8_t* d_slot, uint8_t* d_qslot,
-                 double* h2d_us, double* kern_us) {
-    if (!c.ready) { g_err = "device not initialised"; return SBV_ENOTINIT; }
-    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
-    const size_t gran = shard_granule(group);
-    size_t chunk = kMaxChunk / gran * gran;
-    if (chunk == 0) { g_err = "group too large"; return SBV_EINVAL; }
-    int rc = ensure_capacity(c, m < chunk ? m : chunk);
-    if (rc != SBV_OK) return rc;
-    if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(c.stream, c.busy, 0));
-    for (size_t off = 0; off < m; off += chunk) {
-        const size_t k = m - off < chunk ? m - off : chunk;
-        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[0], c.stream));
-        HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_tuples, h_tuples + off * SBV_TUPLE_BYTES, k * SBV_TUPLE_BYTES, hipMemcpyHostToDevice, c.stream));
-        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
-        rc = enqueue(c, c.d_tuples, k, d_slot + off / 8, c.stream, nullptr);
-        if (rc != SBV_OK) return rc;
-        if (d_qslot && group > 0 && quorum > 0) {
-            const size_t props = k / group;                 // k is a multiple of group except for a ragged tail, which gets no bit
-            if (props)
-                hipLaunchKernelGGL(k_quorum_bits, dim3((unsigned)((props + 255) / 256)), dim3(256), 0, c.stream, c.d_tuples, d_slot + off / 8,
-                                   props, (u32)group, quorum, d_qslot + (off / group) / 8);
-        }
-        HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
-        HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(c.stream));
-        if (h2d_us) *h2d_us += 1e3 * ms_between(c.ev[0], c.ev[1]);
-        if (kern_us) *kern_us += 1e3 * ms_between(c.ev[1], c.ev[3]);
-    }
-    c.busy_valid = false;
-    return SBV_OK;
-}
-
 int grow_bytes(uint8_t*& ptr, size_t& cap, size_t want) {
     if (want <= cap) return SBV_OK;
     if (ptr) (void)hipFree(ptr);
@@ -1775,6 +1743,78 @@ int grow_bytes(uint8_t*& ptr, size_t& cap, size_t want) {
     cap = want;
     return SBV_OK;
 }
+
+// One device's share of a sharded call; c.mu held.  Two upload slots and the copy stream: while the kernels of piece i run
+// on c.stream, the tuples of piece i + 1 are on their way over PCIe (168 MB per 2^20 tuples: 3.3 ms at 50 GB/s, as long as
+// the kernels themselves).  Pieces are 2^18 tuples (a multiple of the granule) when the key-table cache is on — the first
+// piece builds the signers' combs, the others find them (0.87 ms per piece, 1.7 ms for the first; one cold 2^20 step is
+// 3.45 ms) — and whole launches of up to kMaxChunk tuples when it is off (every cold piece would rebuild every table).
+// The bitmap is written straight into this device's slot of the gather buffer, the quorum bits of each piece behind it;
+// nothing waits on the host until the last piece is enqueued.  h2d_us: the copies' own durations, summed; kern_us: from the
+// end of the first copy to the end of the last kernel (waits for later copies included).
+int verify_shard(Context& c, const uint8_t* h_tuples, size_t m, size_t group, u32 quorum, uint8_t* d_slot, uint8_t* d_qslot,
+                 double* h2d_us, double* kern_us) {
+    if (!c.ready) { g_err = "device not initialised"; return SBV_ENOTINIT; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    const size_t gran = shard_granule(group);
+    const size_t want_piece = c.kc_enabled && c.group_enabled ? g_shard_piece : kMaxChunk;
+    size_t chunk = (want_piece < kMaxChunk ? want_piece : kMaxChunk) / gran * gran;
+    if (chunk == 0) chunk = kMaxChunk / gran * gran;
+    if (chunk == 0) { g_err = "group too large"; return SBV_EINVAL; }
+    const size_t pieces = (m + chunk - 1) / chunk;
+    int rc = ensure_capacity(c, m < chunk ? m : chunk);
+    if (rc != SBV_OK) return rc;
+    ShardBuffers& sbuf = g_shard[c.device];
+    if (pieces > 1) {
+        rc = grow_bytes(sbuf.d_stage2, sbuf.stage2_cap, chunk * SBV_TUPLE_BYTES);
+        if (rc != SBV_OK) return rc;
+        if (!c.copy_stream && hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking) != hipSuccess) { g_err = "hipStreamCreate failed"; return SBV_EDEVICE; }
+    }
+    hipStream_t up = pieces > 1 ? c.copy_stream : c.stream;
+    uint8_t* stage[2] = {c.d_tuples, pieces > 1 ? sbuf.d_stage2 : c.d_tuples};
+    // events: per piece copy start / copy end / kernels end (timing), destroyed before returning
+    std::vector<hipEvent_t> ev(3 * pieces, nullptr);
+    auto drop_events = [&] { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
+    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) { drop_events(); g_err = "hipEventCreate failed"; return SBV_EDEVICE; }
+    hipError_t he = hipSuccess;
+    auto step = [&](hipError_t r) { if (he == hipSuccess) he = r; };
+    if (c.busy_valid) {                        // an earlier pipelined call may still read c.d_tuples' neighbours on c.stream
+        step(hipStreamWaitEvent(c.stream, c.busy, 0));
+        if (pieces > 1) step(hipStreamWaitEvent(up, c.busy, 0));
+    }
+    size_t i = 0;
+    for (size_t off = 0; off < m && rc == SBV_OK && he == hipSuccess; off += chunk, ++i) {
+        const size_t k = m - off < chunk ? m - off : chunk;
+        uint8_t* d_in = stage[i & 1];
+        if (i >= 2) step(hipStreamWaitEvent(up, ev[3 * (i - 2) + 2], 0));       // the slot's previous kernels are done with it
+        step(hipEventRecord(ev[3 * i], up));
+        step(hipMemcpyAsync(d_in, h_tuples + off * SBV_TUPLE_BYTES, k * SBV_TUPLE_BYTES, hipMemcpyHostToDevice, up));
+        step(hipEventRecord(ev[3 * i + 1], up));
+        if (pieces > 1) step(hipStreamWaitEvent(c.stream, ev[3 * i + 1], 0));
+        if (he != hipSuccess) break;
+        rc = enqueue(c, d_in, k, d_slot + off / 8, c.stream, nullptr);
+        if (rc != SBV_OK) break;
+        if (d_qslot && group > 0 && quorum > 0) {
+            const size_t props = k / group;                 // k is a multiple of group except for a ragged tail, which gets no bit
+            if (props)
+                hipLaunchKernelGGL(k_quorum_bits, dim3((unsigned)((props + 255) / 256)), dim3(256), 0, c.stream, d_in, d_slot + off / 8,
+                                   props, (u32)group, quorum, d_qslot + (off / group) / 8);
+        }
+        step(hipEventRecord(ev[3 * i + 2], c.stream));
+    }
+    // drain in every case: the slots and the caller's host buffer must not be in use when this returns
+    if (pieces > 1) step(hipStreamSynchronize(up));
+    step(hipStreamSynchronize(c.stream));
+    if (rc == SBV_OK && he != hipSuccess) rc = fail(SBV_EDEVICE, "verify_shard", he);
+    if (rc == SBV_OK) {
+        if (h2d_us) for (size_t j = 0; j < pieces; ++j) *h2d_us += 1e3 * ms_between(ev[3 * j], ev[3 * j + 1]);
+        if (kern_us) *kern_us += 1e3 * ms_between(ev[1], ev[3 * (pieces - 1) + 2]);
+    }
+    drop_events();
+    c.busy_valid = false;
+    return rc;
+}
+
 
 }  // namespace
 
@@ -1818,6 +1858,7 @@ extern "C" int sbv_init_all(void) {
         g_devs = devs;
     }
     if (const char* e = getenv("SBV_SHARD_MIN")) { const long v = atol(e); if (v > 0) g_shard_min = (size_t)v; }
+    if (const char* e = getenv("SBV_SHARD_PIECE")) { const long v = atol(e); if (v >= 512) g_shard_piece = (size_t)v; }
     if (const char* e = getenv("SBV_SHARD_MODE")) g_shard_mode.store(strcmp(e, "keys") == 0 ? 1 : 0);
     if (const char* e = getenv("SBV_SHARD_PARTS")) { const long v = atol(e); if (v >= 0 && v <= 64) g_shard_parts.store((unsigned)v); }
     const char* force = getenv("SBV_RCCL");

@@ -222,6 +222,9 @@ void sbv_host_free(void* p);
  * internal/bft/viewchanger.go:681-727).  When more than one device took part, one in-place ncclAllGather of the bitmap
  * shards (RCCL over xGMI, uint8, per-device streams) leaves the full bitmap on every device and one D2H returns it; a
  * batch smaller than 2 x 2^18 tuples is NOT split — it goes whole to one device, round-robin, with no collective.
+ * Each device takes its shard in pieces through two upload slots: the host -> device copy of piece i + 1 runs on a copy stream
+ * beside the kernels of piece i (pieces of 2^18 tuples while the key-table cache is on — the first piece builds the signers'
+ * combs, the later ones find them — and whole launches when it is off; SBV_SHARD_PIECE overrides the size).
  *   group = 0: plain tuples.  quorum_bitmap may be NULL; otherwise ceil((n / group) / 8) bytes, bit p = proposal p.
  *   info (optional) reports what was done.  sbv_shard_plan is the pure split (testable without a GPU):
  *   first[0..shards], returns shards.  sbv_p256_verify_batch_on runs a whole batch on one chosen device. */
@@ -230,8 +233,9 @@ typedef struct sbv_shard_info {
     int shards;               /* shards the batch was split into (1 = not split)            */
     int mode;                 /* 0 = one device, 1 = RCCL all-gather, 2 = per-device D2H, 3 = key-affine + RCCL all-reduce, 4 = key-affine + host OR */
     size_t tuples_per_shard;
-    double h2d_us;            /* slowest device                                              */
-    double kernels_us;        /* slowest device: stage A + B (+ quorum bits)                 */
+    double h2d_us;            /* slowest device: the copies' own durations, summed over its pieces           */
+    double kernels_us;        /* slowest device: end of its first copy -> end of its last kernel (stage A + B,
+                                 quorum bits; waits for later copies included)                                */
     double gather_us;         /* all-gather + final D2H                                      */
     double total_us;
 } sbv_shard_info;

@@ -192,6 +192,43 @@ def test_sharded_entry_world_of_one_with_rccl_and_quorum_bits(oracle):
 
 
 # ---- key-affine partition: device g verifies the tuples of "its" keys only ------------------------------
+def test_sharded_entry_uploads_in_pieces_beside_the_kernels(oracle):
+    """verify_shard's two upload slots: with SBV_SHARD_PIECE = 16384 a 330 000-tuple call runs as 30 pieces of 11 264 tuples
+    (the granule of group = 11 is 5 632) alternating between the two slots, the copy of piece i + 1 on the copy stream while
+    piece i's kernels run; accept bitmap and quorum bits must equal the one-piece run's (key-table cache off: whole launches)
+    and the generator's.  Also through the explicit-device entry, whose pieces have no group."""
+    os.environ["SBV_SHARD_PIECE"] = "16384"
+    try:
+        sbv.shutdown()
+        assert sbv.init_all() >= 1
+        P, Q = 30000, 11
+        n = P * Q
+        tup, exp = _gen(oracle, 0xC7, n, 16, 8)
+        outs = []
+        for cache in (True, False, True):
+            sbv.key_cache(cache)
+            got = ctypes.create_string_buffer((n + 7) // 8)
+            qb = ctypes.create_string_buffer((P + 7) // 8)
+            info = sbv.verify_batch_sharded(ctypes.addressof(tup), n, ctypes.addressof(got), group=Q, quorum=Q - 1,
+                                            quorum_out_ptr=ctypes.addressof(qb))
+            assert got.raw == exp, (cache, _diff(got.raw, exp))
+            assert info.h2d_us > 0 and info.kernels_us > 0
+            outs.append(qb.raw)
+        assert outs[0] == outs[1] == outs[2]
+        bits = sbv.bitmap_to_list(exp, n)
+        raw = tup.raw
+        want_q = [len({raw[160 * i + 96:160 * i + 160] for i in range(p * Q, (p + 1) * Q) if bits[i]}) >= Q - 1 for p in range(P)]
+        assert sbv.bitmap_to_list(outs[0], P) == want_q
+        m = 100003                                    # ragged: 6 pieces of 16 384 and a tail of 1 699
+        on = ctypes.create_string_buffer((m + 7) // 8)
+        sbv.verify_batch_on(0, ctypes.addressof(tup), m, ctypes.addressof(on))
+        assert sbv.bitmap_to_list(on.raw, m) == bits[:m]
+    finally:
+        os.environ.pop("SBV_SHARD_PIECE", None)
+        sbv.key_cache(True)
+        sbv.shutdown()
+
+
 def test_key_affine_parts_are_disjoint_cover_the_batch_and_match_the_numpy_hash(gpu, oracle):
     """sbv_p256_verify_batch_dev_part on a device-resident 2^18 batch (256 keys, 1/5 corrupted), parts = 1, 3, 8: each part's
     bitmap has bits only at tuples whose key hashes to that part (consensus_amd/shard.py: key_parts is the numpy twin of the
