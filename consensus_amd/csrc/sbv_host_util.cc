@@ -89,10 +89,67 @@ void sha256_compress(uint32_t st[8], const uint8_t* blk) {
     for (int i = 0; i < 8; ++i) st[i] += v[i];
 }
 
+// The same compression function on the SHA extensions of x86-64 (sha256rnds2 = two rounds, sha256msg1 / msg2 = the message
+// schedule), chosen once at run time by CPUID; Go's crypto/sha256 — what the reference's applications hash with — does the
+// same.  State registers: ABEF / CDGH as the instructions want them.  ~6x the portable loop's throughput on a 64-byte block.
+#if defined(__x86_64__)
+}  // namespace (the intrinsics headers must not be included inside it)
+#include <cpuid.h>
+#include <immintrin.h>
+namespace {
+__attribute__((target("sha,sse4.1,ssse3"))) void sha256_compress_shani(uint32_t st[8], const uint8_t* blk) {
+    const __m128i mask = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);      // big-endian words
+    __m128i tmp = _mm_loadu_si128((const __m128i*)&st[0]);          // DCBA
+    __m128i s1 = _mm_loadu_si128((const __m128i*)&st[4]);           // HGFE
+    tmp = _mm_shuffle_epi32(tmp, 0xB1);                             // CDAB
+    s1 = _mm_shuffle_epi32(s1, 0x1B);                               // EFGH
+    __m128i s0 = _mm_alignr_epi8(tmp, s1, 8);                       // ABEF
+    s1 = _mm_blend_epi16(s1, tmp, 0xF0);                            // CDGH
+    const __m128i save0 = s0, save1 = s1;
+    __m128i m[4];
+    for (int i = 0; i < 16; ++i) {                                  // four rounds per step
+        if (i < 4) m[i] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(blk + 16 * i)), mask);
+        __m128i msg = _mm_add_epi32(m[i & 3], _mm_loadu_si128((const __m128i*)&kSha256K[4 * i]));
+        s1 = _mm_sha256rnds2_epu32(s1, s0, msg);
+        if (i >= 3 && i <= 14) {                                    // W[4(i+1) ..] = sigma1 part: needs W[.. - 7] and W[.. - 2]
+            const __m128i t = _mm_alignr_epi8(m[i & 3], m[(i - 1) & 3], 4);
+            m[(i + 1) & 3] = _mm_sha256msg2_epu32(_mm_add_epi32(m[(i + 1) & 3], t), m[i & 3]);
+        }
+        msg = _mm_shuffle_epi32(msg, 0x0E);
+        s0 = _mm_sha256rnds2_epu32(s0, s1, msg);
+        if (i >= 1 && i <= 12) m[(i - 1) & 3] = _mm_sha256msg1_epu32(m[(i - 1) & 3], m[i & 3]);   // sigma0 part of the word group after next
+    }
+    s0 = _mm_add_epi32(s0, save0);
+    s1 = _mm_add_epi32(s1, save1);
+    tmp = _mm_shuffle_epi32(s0, 0x1B);                              // FEBA
+    s1 = _mm_shuffle_epi32(s1, 0xB1);                               // DCHG
+    s0 = _mm_blend_epi16(tmp, s1, 0xF0);                            // DCBA
+    s1 = _mm_alignr_epi8(s1, tmp, 8);                               // HGFE
+    _mm_storeu_si128((__m128i*)&st[0], s0);
+    _mm_storeu_si128((__m128i*)&st[4], s1);
+}
+bool cpu_has_sha() {
+    unsigned a = 0, b = 0, c = 0, d = 0;
+    if (!__get_cpuid_count(7, 0, &a, &b, &c, &d)) return false;
+    const bool sha = (b >> 29) & 1u;
+    if (!__get_cpuid(1, &a, &b, &c, &d)) return false;
+    return sha && ((c >> 19) & 1u) && ((c >> 9) & 1u);              // + SSE4.1, SSSE3
+}
+#else
+void sha256_compress_shani(uint32_t st[8], const uint8_t* blk) { sha256_compress(st, blk); }
+bool cpu_has_sha() { return false; }
+#endif
+// SBV_SHA_PORTABLE=1 keeps the portable loop (tests compare the two)
+const bool g_sha_ext = [] { const char* e = getenv("SBV_SHA_PORTABLE"); return !(e && e[0] == '1') && cpu_has_sha(); }();
+inline void sha256_block(uint32_t st[8], const uint8_t* blk) {
+    if (g_sha_ext) sha256_compress_shani(st, blk);
+    else sha256_compress(st, blk);
+}
+
 void sha256(const uint8_t* msg, size_t len, uint8_t out[32]) {
     uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     size_t off = 0;
-    for (; off + 64 <= len; off += 64) sha256_compress(st, msg + off);
+    for (; off + 64 <= len; off += 64) sha256_block(st, msg + off);
     uint8_t pad[128] = {0};
     const size_t rem = len - off;
     memcpy(pad, msg + off, rem);
@@ -100,8 +157,8 @@ void sha256(const uint8_t* msg, size_t len, uint8_t out[32]) {
     const size_t total = rem < 56 ? 64 : 128;
     const uint64_t bits = (uint64_t)len * 8;
     for (int i = 0; i < 8; ++i) pad[total - 1 - i] = (uint8_t)(bits >> (8 * i));
-    sha256_compress(st, pad);
-    if (total == 128) sha256_compress(st, pad + 64);
+    sha256_block(st, pad);
+    if (total == 128) sha256_block(st, pad + 64);
     for (int i = 0; i < 8; ++i) {
         out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16);
         out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i];
@@ -214,6 +271,8 @@ extern "C" int sbv_p256_parse_der(const uint8_t* der, size_t len, uint8_t out_rs
     memcpy(out_rs, tmp, 64);
     return SBV_OK;
 }
+
+extern "C" int sbv_sha256_uses_cpu_extensions(void) { return g_sha_ext ? 1 : 0; }
 
 extern "C" int sbv_sha256_batch(const uint8_t* msgs, const uint64_t* offsets, size_t n, uint8_t* out_hashes) {
     if (n == 0) return SBV_OK;

@@ -162,6 +162,32 @@ void sbvh_proposal_digest(const void* payload, size_t pl, const void* header, si
     memcpy(hex_out, d.c_str(), 65);
 }
 void sbvh_compute_quorum(uint64_t n, int* q, int* f) { compute_quorum(n, q, f); }
+// Test hook: do the copy-free parsers (payload_split_views, request_parse_view: what VerifyProposal runs) accept exactly what
+// the copying ones accept, with the same fields?  1 = they agree on this payload, 0 = they differ.  *requests_ok (optional) =
+// how many requests both parsed.
+int sbvh_payload_parsers_agree(const void* payload, size_t pl, size_t* requests_ok) {
+    const bytes p = B(payload, pl);
+    std::vector<bytes> copies;
+    std::vector<std::pair<size_t, size_t>> views;
+    const bool a = payload_split(p, &copies), b = payload_split_views(p, &views);
+    if (requests_ok) *requests_ok = 0;
+    if (a != b) return 0;
+    if (!a) return 1;
+    if (copies.size() != views.size()) return 0;
+    for (size_t i = 0; i < copies.size(); ++i) {
+        if (p.compare(views[i].first, views[i].second, copies[i]) != 0) return 0;
+        Request r;
+        RequestView v;
+        const bool ra = request_parse(copies[i], &r), rb = request_parse_view(p, views[i].first, views[i].second, &v);
+        if (ra != rb) return 0;
+        if (!ra) continue;
+        if (p.compare(v.client_off, v.client_len, r.client_id) != 0 || p.compare(v.id_off, v.id_len, r.id) != 0 ||
+            p.compare(v.signed_off, v.signed_len, r.signed_part) != 0 || p.compare(v.sig_off, v.sig_len, r.sig) != 0)
+            return 0;
+        if (requests_ok) ++*requests_ok;
+    }
+    return 1;
+}
 // CommitSignaturesDigest over n signatures given as parallel arrays; returns 32 (digest written) or 0 (empty list -> nil)
 size_t sbvh_commit_signatures_digest(const uint64_t* ids, const void* const* values, const size_t* value_lens, const void* const* msgs,
                                      const size_t* msg_lens, size_t n, uint8_t out32[32]) {

@@ -114,6 +114,32 @@ bool request_parse(const bytes& raw, Request* out) {
     return true;
 }
 
+bool request_parse_view(const bytes& buf, size_t off, size_t len, RequestView* out) {
+    if (len > buf.size() || off > buf.size() - len) return false;
+    const uint8_t* b = (const uint8_t*)buf.data() + off;
+    size_t pos = 0;
+    auto u16 = [&](size_t& v) { if (pos + 2 > len) return false; v = ((size_t)b[pos] << 8) | b[pos + 1]; pos += 2; return true; };
+    auto u32 = [&](size_t& v) {
+        if (pos + 4 > len) return false;
+        v = ((size_t)b[pos] << 24) | ((size_t)b[pos + 1] << 16) | ((size_t)b[pos + 2] << 8) | b[pos + 3];
+        pos += 4; return true;
+    };
+    auto skip = [&](size_t n) { if (n > len - pos) return false; pos += n; return true; };
+    RequestView v;
+    size_t n = 0;
+    if (!u16(n)) return false;
+    v.client_off = off + pos; v.client_len = n;
+    if (!skip(n) || !u16(n)) return false;
+    v.id_off = off + pos; v.id_len = n;
+    if (!skip(n) || !u32(n) || !skip(n)) return false;
+    v.signed_off = off; v.signed_len = pos;
+    if (!u16(n)) return false;
+    v.sig_off = off + pos; v.sig_len = n;
+    if (!skip(n) || pos != len) return false;
+    *out = v;
+    return true;
+}
+
 bytes payload_encode(const std::vector<bytes>& requests) {
     bytes o;
     put_u32(o, requests.size());
@@ -130,6 +156,21 @@ bool payload_split(const bytes& payload, std::vector<bytes>* out) {
         size_t n = 0; bytes r;
         if (!get_u32(payload, pos, n) || !get_bytes(payload, pos, n, r)) return false;
         out->push_back(r);
+    }
+    return pos == payload.size();
+}
+
+bool payload_split_views(const bytes& payload, std::vector<std::pair<size_t, size_t>>* out) {
+    size_t pos = 0, count = 0;
+    if (!get_u32(payload, pos, count)) return false;
+    if (count > payload.size()) return false;
+    out->clear();
+    out->reserve(count);
+    for (size_t i = 0; i < count; ++i) {
+        size_t n = 0;
+        if (!get_u32(payload, pos, n) || n > payload.size() || pos > payload.size() - n) return false;
+        out->emplace_back(pos, n);
+        pos += n;
     }
     return pos == payload.size();
 }

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace sbvhost {
@@ -50,9 +51,20 @@ bytes request_unsigned(const std::string& client_id, const std::string& id, cons
 bytes request_encode(const bytes& unsigned_part, const bytes& sig_der);
 bool request_parse(const bytes& raw, Request* out);
 
+// The same parse without copies: offsets into the buffer the request lives in (a proposal's payload).  request_parse_view
+// accepts exactly what request_parse accepts.
+struct RequestView {
+    size_t client_off = 0, client_len = 0, id_off = 0, id_len = 0;
+    size_t signed_off = 0, signed_len = 0;      // everything before the signature length field
+    size_t sig_off = 0, sig_len = 0;
+};
+bool request_parse_view(const bytes& buf, size_t off, size_t len, RequestView* out);
+
 // ---- proposal payload:  u32 count  (u32 len | request)*
 bytes payload_encode(const std::vector<bytes>& requests);
 bool payload_split(const bytes& payload, std::vector<bytes>* out);
+// (offset, length) of every request inside `payload`; accepts exactly what payload_split accepts
+bool payload_split_views(const bytes& payload, std::vector<std::pair<size_t, size_t>>* out);
 
 // ---- consenter signature message:  "SBV1" | SHA-256(asn1(proposal)) | u32 len | aux
 bytes consenter_msg(const Proposal& p, const bytes& aux);

@@ -92,6 +92,9 @@ class Coalescer {
     int submit_many_k256(const uint8_t* tuples, size_t n, uint8_t* bitmap);
     int submit_many(const uint8_t* tuples, size_t n, uint8_t* bitmap);
     int submit_many_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap);
+    // raw messages + DER signatures + slots through the backend's front end (-2 when it has none)
+    int submit_many_msgs_keyed(const uint8_t* msgs, const uint64_t* moff, const uint8_t* sigs, const uint64_t* soff, const uint32_t* slots, size_t n,
+                               uint8_t* bitmap);
     Backend& backend() { return *be_; }
     CoalescerStats stats();
     // How many submissions a burst is expected to bring (N-1 commit votes: view.go:537-541); the dispatcher ships as soon as

@@ -169,8 +169,11 @@ int sbv_ed25519_verify_msgs(const uint8_t* sigs, const uint8_t* pks, const uint8
 int sbv_p256_parse_der(const uint8_t* der, size_t len, uint8_t out_rs[64]);
 
 /* SHA-256 of n messages packed back to back (offsets[i]..offsets[i+1]) -> n*32 bytes.
- * Host implementation used to build tuples (hash = SHA-256(Signature.Msg)). */
+ * Host implementation used to build tuples (hash = SHA-256(Signature.Msg)).  On x86-64 CPUs with the SHA extensions the
+ * compression function runs on them (as Go's crypto/sha256 does); sbv_sha256_uses_cpu_extensions() says which one is in use
+ * (SBV_SHA_PORTABLE=1 in the environment keeps the portable loop). */
 int sbv_sha256_batch(const uint8_t* msgs, const uint64_t* offsets, size_t n, uint8_t* out_hashes);
+int sbv_sha256_uses_cpu_extensions(void);
 
 typedef struct sbv_timing {
     double h2d_us;      /* host -> device copy of the tuples   (host-pointer entry only) */

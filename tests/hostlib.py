@@ -54,6 +54,7 @@ def load():
     lib.sbvh_request_id.argtypes = [V, ctypes.c_char_p, S, ctypes.c_char_p, S]
     lib.sbvh_verify_proposal.argtypes = [V, ctypes.c_char_p, S, ctypes.c_char_p, S, ctypes.c_char_p, S, ctypes.c_int64,
                                          ctypes.c_char_p, S, ctypes.POINTER(S), ctypes.POINTER(S)]
+    lib.sbvh_payload_parsers_agree.argtypes = [ctypes.c_char_p, S, ctypes.POINTER(S)]
     lib.sbvh_requests_from_proposal.restype = S
     lib.sbvh_requests_from_proposal.argtypes = [V, ctypes.c_char_p, S, ctypes.c_char_p, S, ctypes.POINTER(S)]
     lib.sbvh_stats.argtypes = [V, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]

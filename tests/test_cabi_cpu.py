@@ -71,6 +71,29 @@ def test_sha256_batch_matches_hashlib():
         assert out[32 * i:32 * i + 32] == hashlib.sha256(m).digest()
 
 
+def test_sha256_portable_loop_and_cpu_extension_path_agree():
+    """sbv_host_util.cc picks the compression function once per process (CPUID: SHA extensions).  Both choices, each in its own
+    process, against hashlib on every length 0..199 and a few long messages (1, 2 and many blocks, both padding cases)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, hashlib, random, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import consensus_amd as sbv\n"
+        "rng = random.Random(5)\n"
+        "msgs = [bytes(rng.randrange(256) for _ in range(n)) for n in list(range(200)) + [255, 256, 1000, 4096, 65537]]\n"
+        "out = sbv.sha256_batch(msgs)\n"
+        "assert all(out[32 * i:32 * i + 32] == hashlib.sha256(m).digest() for i, m in enumerate(msgs))\n"
+        "print(sbv.load().sbv_sha256_uses_cpu_extensions())\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    seen = set()
+    for portable in ("1", "0"):
+        env = dict(os.environ, SBV_SHA_PORTABLE=portable)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-800:]
+        seen.add((portable, r.stdout.strip()))
+    assert ("1", "0") in seen                       # the override really selects the portable loop
+
+
 def _has_gpu():
     try:
         return sbv.device_count() > 0

@@ -251,6 +251,41 @@ def test_verify_proposal_batches_all_request_signatures(hx):
     assert hx.verify_proposal((hostlib.payload_encode([]), b"h", b"m", 0)) == (OK, [])
 
 
+def test_copy_free_payload_parsers_accept_exactly_what_the_copying_ones_do(lib):
+    """VerifyProposal parses the requests where they lie in the payload (formats.h: payload_split_views,
+    request_parse_view).  Same language as payload_split / request_parse, same fields: well-formed payloads, every
+    truncation of one, single-byte mutations of its length fields, and random garbage."""
+    import random
+    import struct
+    rng = random.Random(0x5B7)
+    agree = lambda b: lib.sbvh_payload_parsers_agree(b, len(b), None)
+    ok = ctypes.c_size_t()
+    reqs = [hostlib.request_encode(hostlib.request_unsigned("client-%d" % i, "id%d" % i, bytes(rng.randrange(256) for _ in range(rng.randrange(40)))),
+                                   bytes(rng.randrange(256) for _ in range(rng.choice((0, 8, 70, 71, 72))))) for i in range(12)]
+    good = hostlib.payload_encode(reqs)
+    assert lib.sbvh_payload_parsers_agree(good, len(good), ctypes.byref(ok)) == 1 and ok.value == 12
+    empty = hostlib.payload_encode([])
+    assert lib.sbvh_payload_parsers_agree(empty, len(empty), ctypes.byref(ok)) == 1 and ok.value == 0
+    for cut in range(len(good)):
+        assert agree(good[:cut]) == 1, cut
+    for pos in range(min(len(good), 160)):
+        for val in (0, 1, 0x7F, 0x80, 0xFF):
+            m = bytearray(good)
+            m[pos] = val
+            assert agree(bytes(m)) == 1, (pos, val)
+    # a request whose inner lengths overrun its own frame but not the payload: must fail in both parsers
+    inner = bytearray(reqs[0])
+    inner[0:2] = struct.pack(">H", len(inner) + 5)
+    framed = hostlib.payload_encode([bytes(inner), reqs[1]])
+    assert lib.sbvh_payload_parsers_agree(framed, len(framed), ctypes.byref(ok)) == 1 and ok.value == 1
+    huge = struct.pack(">I", 0xFFFFFFFF) + b"\x00" * 8
+    assert agree(huge) == 1
+    for _ in range(300):
+        junk = bytes(rng.randrange(256) for _ in range(rng.randrange(64)))
+        assert agree(junk) == 1
+        assert agree(struct.pack(">I", rng.randrange(4)) + junk) == 1
+
+
 def test_registered_client_and_consenter_keys_take_the_keyed_backend_path(lib, oracle):
     """With a backend that has a key registry (libsbv: sbv_p256_register_keys), RegisterClient / RegisterConsenter take
     key slots and VerifyProposal, VerifyRequest and VerifyConsenterSig ship r|s|hash + slot instead of full tuples;
