@@ -395,8 +395,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     while (chunks * tsub > SBV_GROUP_MAX_TCHUNKS) --tsub;
     for (int c = 0; c < chunks; ++c) {
         const int q_first = SBV_GTAB_WINDOWS * c / chunks, q_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [q_first, q_end)
-        const int ts = y.tstreams > 1 ? c % y.tstreams : 0;
-        hipStream_t tb = ts == 0 || !y.side_t[ts - 1] ? y.side_b : y.side_t[ts - 1];     // rows + fill of this chunk
+        hipStream_t tb = y.tstreams > 1 && y.side_t && (c & 1) ? y.side_t : y.side_b;     // rows + fill of this chunk
         for (int t = 0; t < tsub; ++t) {
             const int j_first = q_first + (q_end - q_first) * t / tsub, j_end = q_first + (q_end - q_first) * (t + 1) / tsub;
             const int j_count = j_end - j_first;

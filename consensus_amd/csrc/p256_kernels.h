@@ -68,8 +68,8 @@ struct GroupBuffers {
 struct GroupSync {
     hipStream_t side_a = nullptr;   // insert, assign, window bases
     hipStream_t side_b = nullptr;   // split, window tables
-    hipStream_t side_t[SBV_GROUP_MAX_CHUNKS - 1] = {};   // P-256: rows + fill of chunk c run on {side_b, side_t[..]}[c % tstreams]
-    int tstreams = 2;               // SBV_GROUP_TSTREAMS (1..SBV_GROUP_MAX_CHUNKS): 1 = every chunk's rows + fill queue up on side_b.  2: rows of chunk 1 start when ITS chain ends, not when fill of chunk 0 does — cold 2^18 2.04 -> 1.70 ms, 2^17 2.54 -> 2.23, 2^20 unchanged (profiles/r03/ab_sched_r03m.jsonl)
+    hipStream_t side_t = nullptr;   // P-256: not owned — rows + fill of the odd chunks when tstreams = 2 (the context's own stream while the caller's runs the step)
+    int tstreams = 2;               // SBV_GROUP_TSTREAMS (1, 2): 1 = every chunk's rows + fill queue up on side_b.  2: rows of chunk 1 start when ITS chain ends, not when fill of chunk 0 does — cold 2^18 2.04 -> 1.70 ms, 2^17 2.54 -> 2.23, 2^20 unchanged (profiles/r03/ab_sched_r03m.jsonl)
     hipStream_t side_c = nullptr;   // optional: generic stage B over the ungrouped list (nullptr: fused into the G-phase launch)
     hipEvent_t ev_slice[SBV_GROUP_MAX_SLICES] = {};
     int slices = 1;                 // pieces stage A + G phase are pipelined in (1..SBV_GROUP_MAX_SLICES); slices > 0 run on side_b

@@ -329,7 +329,14 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
     if (grouped) {           // stage A is enqueued by the grouped launcher, in slices pipelined with the G phase
         sbv::Scratch sg = s;
         sg.rec = c.gsync.sorted ? c.grp.rec : nullptr;      // stage A also writes the per-tuple records the key-sorted list reads
-        const hipError_t ge = sbv::launch_p256_verify_grouped(d_tuples, sg, n, c.grp, c.d_qtab, c.d_gtab, sbv::gcomb_make(c.d_g16r, c.g_bits), d_bitmap, stream, c.gsync,
+        // The second table stream is NOT a stream of its own: a process gets four hardware queues and the fifth stream shares
+        // one with the first — here the caller's, so rows + fill of chunk 1 queued behind the first Q launch (2^20 cold 3.45 ->
+        // 3.75 ms, profiles/r03/timeline_r03o.txt).  When the caller brings its own stream (device-pointer entries) the
+        // context's stream is idle and takes the job; the host-pointer entries run on it themselves and keep one table stream.
+        sbv::GroupSync y = c.gsync;
+        if (y.tstreams > 1 && stream != c.stream) y.side_t = c.stream;
+        else y.tstreams = 1;
+        const hipError_t ge = sbv::launch_p256_verify_grouped(d_tuples, sg, n, c.grp, c.d_qtab, c.d_gtab, sbv::gcomb_make(c.d_g16r, c.g_bits), d_bitmap, stream, y,
                                                               after_prep, dom, dom_pairs);
         if (ge != hipSuccess) {
             // k_key_cache_insert publishes a slot before its tables are built: a step that failed half-way may leave slots
@@ -480,8 +487,7 @@ int init_context(Context& c, int device) {
     }
     if (const char* e = getenv("SBV_GROUP_TSUB")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.tsub = v; }
     if (const char* e = getenv("SBV_GROUP_PARTS")) c.gsync.parts = atoi(e);
-    if (const char* e = getenv("SBV_GROUP_TSTREAMS")) { const int v = atoi(e); if (v >= 1 && v <= SBV_GROUP_MAX_CHUNKS) c.gsync.tstreams = v; }
-    for (int i = 0; i + 1 < c.gsync.tstreams; ++i) HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.gsync.side_t[i], hipStreamNonBlocking));
+    if (const char* e = getenv("SBV_GROUP_TSTREAMS")) { const int v = atoi(e); if (v >= 1 && v <= 2) c.gsync.tstreams = v; }
     if (const char* e = getenv("SBV_GROUP_WIDE")) c.gsync.wide = atoi(e) != 0;
     if (const char* e = getenv("SBV_GROUP_FSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.fsplit = v; }
     if (const char* e = getenv("SBV_GROUP_SLICES")) c.gsync.slices = atoi(e);
@@ -622,8 +628,7 @@ int shutdown_context(Context& c) {
         for (auto& ev : sl.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
         sl = StageSlot();
     }
-    for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b, &c.gsync.side_c, &c.gsync.side_t[0], &c.gsync.side_t[1], &c.gsync.side_t[2]})
-        if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
+    for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b, &c.gsync.side_c}) if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
     for (hipEvent_t* ev : group_events(c)) if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
     c.busy_valid = false;
     c.ready = false;
