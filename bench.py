@@ -282,15 +282,21 @@ def leg_proposals():
     import hostlib
     lib = hostlib.load()
     cb = hostlib.BACKEND_FN(lambda *a: -1)
-    out = {"K": 10000, "n_nodes": 4, "unit": "us"}
-    for label, on_device in (("registered_client_keys", 1), ("unregistered_client_keys", 0)):
-        v = lib.sbvh_verifier_new(0, 0, cb, None, 1 << 20, 50, 0)
-        lib.sbvh_set_device_client_keys(v, on_device)
-        res = hostlib.ReplayResult()
-        rc = lib.sbvh_replay(v, 4, 10000, 3, 0, min(64, os.cpu_count() or 8), ctypes.byref(res))
-        lib.sbvh_verifier_free(v)
-        out[label] = {"verify_proposal_us": res.verify_proposal_us, "request_sigs_per_s": 10000 / (res.verify_proposal_us * 1e-6) if res.verify_proposal_us else None,
-                      "prev_commits_serial_us": res.prev_commits_us, "commit_quorum_us": res.commit_quorum_us} if rc == 0 and res.status == 0 else {"error": f"rc {rc} status {res.status}"}
+    import consensus_amd as sbv
+    out = {"K": 10000, "n_nodes": 4, "unit": "us", "note": "median of 3 proposals; the key-table cache is on, as in a running node (the library's default; "
+           "the headline leg switches it off to stay cold): the first proposal builds the 64 clients' combs, the later ones find them"}
+    sbv.key_cache(True)
+    try:
+        for label, on_device in (("registered_client_keys", 1), ("unregistered_client_keys", 0)):
+            v = lib.sbvh_verifier_new(0, 0, cb, None, 1 << 20, 50, 0)
+            lib.sbvh_set_device_client_keys(v, on_device)
+            res = hostlib.ReplayResult()
+            rc = lib.sbvh_replay(v, 4, 10000, 3, 0, min(64, os.cpu_count() or 8), ctypes.byref(res))
+            lib.sbvh_verifier_free(v)
+            out[label] = {"verify_proposal_us": res.verify_proposal_us, "request_sigs_per_s": 10000 / (res.verify_proposal_us * 1e-6) if res.verify_proposal_us else None,
+                          "prev_commits_serial_us": res.prev_commits_us, "commit_quorum_us": res.commit_quorum_us} if rc == 0 and res.status == 0 else {"error": f"rc {rc} status {res.status}"}
+    finally:
+        sbv.key_cache(False)
     return out
 
 

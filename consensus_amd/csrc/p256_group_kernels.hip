@@ -402,19 +402,24 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
             if (j_count <= 0) continue;
             const int tc = c * tsub + t;
             hipLaunchKernelGGL(k_keytab29_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases,
-                               b.kvalid, b.tslot, b.cold, j_first, j_end - 1, y.wide ? 0xFFu : 0x11u);
+                               b.kvalid, b.tslot, b.cold, j_first, j_end - 1, (y.wide & 1) ? 0xFFu : 0x11u);
             SBV_TRY(hipEventRecord(y.ev_bases[tc], y.side_a));
             SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[tc], 0));
-            if (y.wide) {
+            // rows: one lane per entry (wide & 1) or two chains of additions per window; fill: rows split over `fsplit` lanes
+            // (wide & 2) or whole rows per lane.  Both wide forms measured slower (kernels.h: GroupSync::wide).
+            if (y.wide & 1) {
                 const size_t wl = (size_t)b.max_groups * j_count * 24;
                 hipLaunchKernelGGL(k_keytab29_entries, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.ktab, b.tslot, b.cold, j_first, j_count);
+            } else {
+                const size_t wl = (size_t)b.max_groups * j_count * 2;
+                hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
+            }
+            if (y.wide & 2) {
                 const int split = y.fsplit < 1 ? 1 : (y.fsplit > 4 ? 4 : y.fsplit);
                 const size_t fl = (size_t)b.max_groups * j_count * 7 * split;
                 hipLaunchKernelGGL(k_keytab29_fill_parts, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, b.ktab, b.tslot, b.cold, j_first,
                                    j_count, split);
             } else {
-                const size_t wl = (size_t)b.max_groups * j_count * 2;
-                hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
                 const int lpw = (7 + rows_per_lane - 1) / rows_per_lane;
                 const size_t fl = (size_t)b.max_groups * j_count * lpw;
                 hipLaunchKernelGGL(k_keytab29_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count,

@@ -488,7 +488,7 @@ int init_context(Context& c, int device) {
     if (const char* e = getenv("SBV_GROUP_TSUB")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.tsub = v; }
     if (const char* e = getenv("SBV_GROUP_PARTS")) c.gsync.parts = atoi(e);
     if (const char* e = getenv("SBV_GROUP_TSTREAMS")) { const int v = atoi(e); if (v >= 1 && v <= 2) c.gsync.tstreams = v; }
-    if (const char* e = getenv("SBV_GROUP_WIDE")) c.gsync.wide = atoi(e) != 0;
+    if (const char* e = getenv("SBV_GROUP_WIDE")) c.gsync.wide = atoi(e) & 3;
     if (const char* e = getenv("SBV_GROUP_FSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.fsplit = v; }
     if (const char* e = getenv("SBV_GROUP_SLICES")) c.gsync.slices = atoi(e);
     if (const char* e = getenv("SBV_GROUP_SORT")) c.gsync.sorted = atoi(e) != 0;

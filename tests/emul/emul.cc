@@ -152,7 +152,8 @@ void sbve_key_cache(int enabled, u32 cap) {
 void sbve_key_cache_stats(u32 out[3]) { out[0] = g_kc.count ? g_kc_count[0] : 0; out[1] = g_kc.count ? g_kc_count[1] : 0; out[2] = g_kc.count ? g_kc_count[2] : 0; }
 void sbve_set_group_chunks(int c) { g_group_chunks = c < 1 ? 1 : (c > 4 ? 4 : c); }
 static void emul_window_rows_fill(const u32* recs, bool top, int rpl, u32* tmp, apt* row);
-void sbve_set_group_wide(int wide, int fsplit) { g_group_wide = wide != 0; if (fsplit >= 1 && fsplit <= 4) g_group_fsplit = fsplit; }
+void sbve_set_group_wide(int wide, int fsplit) { g_group_wide = wide & 3;   // bit 0: one lane per entry in the rows step, bit 1: fill rows split over fsplit lanes
+    if (fsplit >= 1 && fsplit <= 4) g_group_fsplit = fsplit; }
 void sbve_set_group_parts(int p) { if (p == 2 || p == 4 || p == 8 || p == 16) g_group_parts = p; }
 // grouped form: generic tuples, keys grouped inside the call (p256_group.h), emulated sequentially.
 // stats_out[0..3] = groups, grouped tuples, ungrouped tuples, ungrouped tuples rejected for their key.
@@ -254,7 +255,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
         for (u32 k = 0; k < ngroups; ++k)
             if (cold[k]) {               // k_keytab29_chain: the four lanes of the key's quad in lockstep
                 keychain_quad_host q;
-                keychain29_run(q, tuples, k, g, jstate.data(), bases, valid_of(k), j_first, j_end - 1, g_group_wide ? 0xFFu : 0x11u);
+                keychain29_run(q, tuples, k, g, jstate.data(), bases, valid_of(k), j_first, j_end - 1, (g_group_wide & 1) ? 0xFFu : 0x11u);
             }
         for (u32 k = 0; k < ngroups; ++k)
             for (int j = j_first; j < j_end && cold[k]; ++j) {
@@ -287,9 +288,16 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
 // rows + fill of one (key, window) the way the launcher's two forms do it (k_keytab29_entries + k_keytab29_fill_parts, or
 // k_keytab29_rows + k_keytab29_fill)
 static void emul_window_rows_fill(const u32* recs, bool top, int rpl, u32* tmp, apt* row) {
-    if (g_group_wide) {
+    if (g_group_wide & 1) {
         for (int e = 0; e < SBV_KT29_ENTRY_LANES; ++e) keytab29_entry_lane(recs, e, top, row);
-        if (top) return;
+    } else {
+        for (int which = 0; which < 2; ++which) {
+            if (which == 1 && top) continue;
+            keytab29_rows_lane(recs, which, top, tmp, row);
+        }
+    }
+    if (top) return;
+    if (g_group_wide & 2) {
         const int split = g_group_fsplit, per = (15 + split - 1) / split;
         for (int r = 0; r < 7 * split; ++r) {
             const int a = 1 + r / split, b_first = 1 + (r % split) * per;
@@ -299,11 +307,6 @@ static void emul_window_rows_fill(const u32* recs, bool top, int rpl, u32* tmp, 
         }
         return;
     }
-    for (int which = 0; which < 2; ++which) {
-        if (which == 1 && top) continue;
-        keytab29_rows_lane(recs, which, top, tmp, row);
-    }
-    if (top) return;
     for (int a = 1; a <= 7; a += rpl) keytab29_fill_lane(a, a + rpl - 1 > 7 ? 7 : a + rpl - 1, tmp, row);
 }
 
@@ -352,7 +355,7 @@ int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
         keychain_quad_host q;
-        keychain29_run(q, tup.data(), 0, g, jstate.data(), bases.data(), &valid, j_first, j_end - 1, g_group_wide ? 0xFFu : 0x11u);
+        keychain29_run(q, tup.data(), 0, g, jstate.data(), bases.data(), &valid, j_first, j_end - 1, (g_group_wide & 1) ? 0xFFu : 0x11u);
         for (int j = j_first; j < j_end; ++j) {
             apt* row = ktab + (size_t)j * SBV_GTAB_PER_WINDOW;
             emul_window_rows_fill(bases.data() + (size_t)j * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, 1, tmpa.data(), row);

@@ -281,7 +281,7 @@ def test_key_comb_scalars_around_the_sign_flip_and_the_carry_window(emul, oracle
     emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
                                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
     stats = (ctypes.c_uint32 * 4)()
-    for chunks, wide in ((1, 1), (2, 1), (3, 1), (3, 0)):
+    for chunks, wide in ((1, 3), (2, 1), (3, 2), (3, 0)):
         emul.sbve_set_group_chunks(chunks)
         emul.sbve_set_group_wide(wide, 3)
         bm = ctypes.create_string_buffer((total + 7) // 8)
@@ -375,7 +375,7 @@ def test_grouped_by_key_inside_the_batch_matches_generic(emul, oracle, golden_ve
                                                                           (8, 3, 12, 3, 4), (2, 64, 11, 3, 8), (10**6, 64, 12, 3, 4)]):
         emul.sbve_set_group_chunks(chunks)
         emul.sbve_set_group_parts(parts)
-        emul.sbve_set_group_wide(0 if ci in (1, 5) else 1, 1 + ci % 4)       # both table builders, every fill split
+        emul.sbve_set_group_wide(ci % 4, 1 + ci % 4)       # every combination of the table builders' forms, every fill split
         bm = ctypes.create_string_buffer((total + 7) // 8)
         emul.sbve_p256_verify_batch_grouped(allt, total, bm, min_count, max_groups, ht_bits, stats)
         got = _bitmap_list(bm.raw, total)

@@ -266,9 +266,9 @@ def test_key_table_of_the_key_that_wrapped_a_limb(emul):
                         "cec0e52c50735a5480607398a6880d494a83013fa269b1442a36466fe2fcfee1")
     q = (int.from_bytes(key[:32], "big"), int.from_bytes(key[32:], "big"))
     tab = (ctypes.c_uint32 * (33 * 128 * 16))()
-    # both forms of rows + fill: wide (one lane per entry from the chain's 8 records per window, fill rows in 1..4 parts) and the
-    # chains of additions (SBV_GROUP_WIDE=0)
-    for wide, fsplit, chunks in ((1, 3, 2), (1, 3, 3), (1, 1, 1), (1, 2, 3), (1, 4, 2), (0, 3, 2), (0, 3, 3)):
+    # every form of rows + fill: bit 0 of `wide` = one lane per entry from the chain's 8 records per window, bit 1 = fill rows in
+    # 1..4 parts; 0 = the chains of additions and whole rows (the default)
+    for wide, fsplit, chunks in ((3, 3, 2), (3, 3, 3), (3, 1, 1), (2, 2, 3), (2, 4, 2), (1, 3, 2), (0, 3, 2), (0, 3, 3)):
         emul.sbve_set_group_wide(wide, fsplit)
         for k in range(len(tab)):
             tab[k] = 0xA5A5A5A5
