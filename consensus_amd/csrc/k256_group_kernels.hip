@@ -170,11 +170,12 @@ hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks, j_count = j_end - j_first;
         hipLaunchKernelGGL(k_k256_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases, kvalid, j_first, j_end - 1);
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
-        SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[c], 0));
+        hipStream_t tb = y.tstreams > 1 && y.side_t && (c & 1) ? y.side_t : y.side_b;     // as the P-256 step: rows + fill of chunk 1 do not queue behind chunk 0's
+        SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[c], 0));
         const size_t wl = (size_t)b.max_groups * j_count * 2, fl = (size_t)b.max_groups * j_count * 7;
-        hipLaunchKernelGGL(k_k256_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.bases, b.tmp, ktab, j_first, j_count);
-        hipLaunchKernelGGL(k_k256_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, y.side_b, g, b.tmp, ktab, j_first, j_count);
-        SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
+        hipLaunchKernelGGL(k_k256_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.tmp, ktab, j_first, j_count);
+        hipLaunchKernelGGL(k_k256_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, ktab, j_first, j_count);
+        SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         hipLaunchKernelGGL(k_k256_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, ktab, kvalid, b.gacc, b.acc, j_first, j_end,
                            c + 1 == chunks ? 1 : 0);

@@ -1144,7 +1144,10 @@ int enqueue_k256(Context& c, const uint8_t* d_tuples, size_t m, uint8_t* d_bitma
         if (rc != SBV_OK) return rc;
         if ((rc = ensure_k256_gcomb(c)) != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
-        HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify_grouped(d_tuples, s, m, c.grp, c.d_qtab, c.d_k256_gtab, c.d_k256_gcomb, c.k256_gbits, d_bitmap, stream, c.gsync));
+        sbv::GroupSync y = c.gsync;                 // second table stream: the context's own, when the caller's runs the step (enqueue() says why)
+        if (y.tstreams > 1 && stream != c.stream) y.side_t = c.stream;
+        else y.tstreams = 1;
+        HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify_grouped(d_tuples, s, m, c.grp, c.d_qtab, c.d_k256_gtab, c.d_k256_gcomb, c.k256_gbits, d_bitmap, stream, y));
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify(d_tuples, m, s, c.d_qtab, c.d_k256_gtab, d_bitmap, stream));
