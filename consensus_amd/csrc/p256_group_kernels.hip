@@ -19,8 +19,19 @@
 // (XYZZ accumulator 36, two table entries in flight 32, 17 64-bit columns 34, temporaries); at 3 waves (168 VGPRs) hipcc
 // spills ~60 dwords per lane in the Q phase, at 2 waves nothing, and tools/febench measures the addition chain no slower
 // at 2 waves than at 3 (the arithmetic has no carry chains to hide).
+// The G phase of the key-sorted step also exists as a kernel of its own (k_gphase_sorted): without the one-lane kernel's code
+// in the same launch it needs 168 VGPRs and spills nothing at 3 waves per SIMD, and while the table kernels hold registers
+// beside it two of its waves still fit on a SIMD instead of one (2^20 cold 3.44 -> 3.35 ms, profiles/r03/ab_gphase_split_r03t.jsonl;
+// 4 waves: 77 spilled dwords, 3.78 ms).  The ungrouped list then needs a launch in front of it, which costs 0.05 ms of a
+// 0.9 ms step at 2^18: GroupSync::gsplit_min picks the form by batch size.
+#ifndef SBV_GPHASE_WAVES
+#define SBV_GPHASE_WAVES 3
+#endif
 #ifndef SBV_COMB29_WAVES
 #define SBV_COMB29_WAVES 2
+#endif
+#ifndef SBV_QPHASE_WAVES
+#define SBV_QPHASE_WAVES SBV_COMB29_WAVES
 #endif
 
 namespace sbv {
@@ -240,6 +251,12 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_gphase_g
     if (i < end) gphase29_lane(s, i, g16r, gacc);
 }
 
+// The G phase of the key-sorted step alone: lane L of the sorted list
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_GPHASE_WAVES) void k_gphase_sorted(Scratch s, GroupState g, gcomb g16r, u32* __restrict__ gacc) {
+    const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (i < g.counters[1]) gphase29_lane_sorted(s, g.grp_idx[i], i, g16r, gacc);
+}
+
 // The generic stage B alone (own stream, when the process has hardware queues to spare)
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_verify_generic_list(Scratch s, GroupState g, u32* __restrict__ qtab,
                                                                             gcomb g16r, uint8_t* __restrict__ acc) {
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_verify_generic_list(Scr
 }
 
 // Q phase over the grouped list: windows [j0, j1) of the per-batch key combs
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_verify_keyed_q(Scratch s, GroupState g, const apt* __restrict__ ktab,
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_keyed_q(Scratch s, GroupState g, const apt* __restrict__ ktab,
                                                                     const uint8_t* __restrict__ kvalid, const u32* __restrict__ tslot,
                                                                     u32 table_slots, u32* __restrict__ gacc,
                                                                     uint8_t* __restrict__ acc, int j0, int j1, int last) {
@@ -382,6 +399,12 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
                 gen_blocks = gv;
             }
             const unsigned gb = (unsigned)((end - first + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
+            if (g.sorted && slices == 1 && y.gsplit_min && n >= y.gsplit_min) {
+                hipLaunchKernelGGL(k_gphase_generic, dim3(gen_blocks), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc,
+                                   gen_blocks, first, end);
+                hipLaunchKernelGGL(k_gphase_sorted, dim3(gb), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, d_g16r, b.gacc);
+                continue;
+            }
             hipLaunchKernelGGL(k_gphase_generic, dim3(gen_blocks + gb), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r,
                                b.gacc, b.acc, gen_blocks, first, end);
         }
