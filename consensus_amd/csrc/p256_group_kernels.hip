@@ -157,7 +157,10 @@ __global__ __launch_bounds__(64) void k_keytab29_chain(const uint8_t* __restrict
     keychain29_run(q, tuples, k, g, jstate, bases, valid + tslot[k], j_first, j_last, rec_mask);
 }
 // lanes = groups x j_count x 2
-__global__ __launch_bounds__(64, 2) void k_keytab29_rows(GroupState g, const u32* __restrict__ bases, u32* __restrict__ tmp,
+#ifndef SBV_ROWS_WAVES
+#define SBV_ROWS_WAVES 2
+#endif
+__global__ __launch_bounds__(64, SBV_ROWS_WAVES) void k_keytab29_rows(GroupState g, const u32* __restrict__ bases, u32* __restrict__ tmp,
                                                       apt* __restrict__ ktab, const u32* __restrict__ tslot,
                                                       const uint8_t* __restrict__ cold, int j_first, int j_count) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;

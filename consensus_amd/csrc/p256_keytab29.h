@@ -271,17 +271,25 @@ SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32
         f29_store_raw(rec + 36, acc);
         f29_mul(acc, acc, R.ZZZ);
     }
-    fe29 all, inv, zi, zi2, zi3;
-    f29_mul(all, acc, B.Z);
+    // the base's coordinates are fetched again where they are needed instead of living in registers through the chain and the
+    // inversion (no spills at 2 waves per SIMD; compiled for 3 — 168 VGPRs, 88 spilled dwords — the step is no faster:
+    // profiles/r03/ab_rows_waves_r03v.jsonl)
+    const u32* brec = base2 + which * 4 * SBV_KT29_REC_WORDS;
+    fe29 all, inv, zi, zi2, zi3, bz;
+    f29_load_raw(bz, brec + 18);
+    f29_mul(all, acc, bz);
     f29_inv(inv, all);
     f29_mul(zi, inv, acc);                      // 1 / Z
-    f29_mul(inv, inv, B.Z);                     // 1 / prod ZZZ'
+    f29_load_raw(bz, brec + 18);
+    f29_mul(inv, inv, bz);                      // 1 / prod ZZZ'
     f29_sqr(zi2, zi);
     f29_mul(zi3, zi2, zi);
     if (which == 0) {                           // entry 1 = B itself
         apt29 a;
-        f29_mul(a.x, B.X, zi2);
-        f29_mul(a.y, B.Y, zi3);
+        fe29 bx, by;
+        f29_load_raw(bx, brec); f29_load_raw(by, brec + 9);
+        f29_mul(a.x, bx, zi2);
+        f29_mul(a.y, by, zi3);
         apt29_store_canon(row, a);
     }
     SBV_NOUNROLL
