@@ -311,6 +311,46 @@ def test_registered_client_and_consenter_keys_take_the_keyed_backend_path(lib, o
         hx.close()
 
 
+def test_proposal_mixing_slotted_and_unslotted_clients_goes_the_generic_way(lib, oracle):
+    """One client registered while device client keys are off has no comb slot: a proposal that carries one of its requests
+    cannot use the slots of the others — the whole batch ships as host-built tuples (SHA-256 + DER on the workers, keys
+    inline), in ONE backend call, with the same verdicts; unknown clients and malformed requests are refused before any
+    backend call, as view.go:553-559 expects from VerifyProposal."""
+    lib.sbvh_backend_keyed_batches.restype = ctypes.c_uint64
+    lib.sbvh_backend_keyed_batches.argtypes = [ctypes.c_void_p]
+    hx = Harness(lib, oracle, backend_kind=2, wait_us=10)
+    try:
+        lib.sbvh_set_device_client_keys(hx.v, 0)
+        s = lib.sbvh_signer_new_scheme(0, 0, hashlib.sha256(b"late-client").digest())
+        q = ctypes.create_string_buffer(64)
+        lib.sbvh_signer_public_key(s, q)
+        lib.sbvh_register_client(hx.v, b"bob", q.raw)
+        hx.clients["bob"] = s
+        reqs = [hx.request("alice%d" % (i % 3), "r%d" % i, payload=bytes([i])) for i in range(40)]
+        keyed_before = lib.sbvh_backend_keyed_batches(hx.v)
+        hx.batches.clear()
+        st, infos = hx.verify_proposal((hostlib.payload_encode(reqs), b"h", b"m", 0))
+        assert st == OK and len(infos) == 40 and hx.batches == [40]
+        assert lib.sbvh_backend_keyed_batches(hx.v) == keyed_before + 1          # every client slotted: the front end
+        reqs[17] = hx.request("bob", "r17", payload=b"x")
+        hx.batches.clear()
+        st, infos = hx.verify_proposal((hostlib.payload_encode(reqs), b"h", b"m", 0))
+        assert st == OK and infos[17] == ("bob", "r17") and hx.batches == [40]
+        assert lib.sbvh_backend_keyed_batches(hx.v) == keyed_before + 1          # ... one unslotted client: generic tuples
+        reqs[3] = hx.request("bob", "r3", corrupt=True)
+        assert hx.verify_proposal((hostlib.payload_encode(reqs), b"h", b"m", 0))[0] == INVALID
+        reqs[3] = hx.request("alice0", "r3")
+        hx.batches.clear()
+        u = hostlib.request_unsigned("mallory", "r9", b"tx")
+        reqs[9] = hostlib.request_encode(u, hx.sign(hx.clients["bob"], u))
+        assert hx.verify_proposal((hostlib.payload_encode(reqs), b"h", b"m", 0))[0] == INVALID     # unknown client
+        reqs[9] = reqs[8][:-1]
+        assert hx.verify_proposal((hostlib.payload_encode(reqs), b"h", b"m", 0))[0] == INVALID     # malformed request
+        assert hx.batches == []                                                   # neither reached the backend
+    finally:
+        hx.close()
+
+
 def test_ed25519_verifier_variant(lib, oracle):
     """BASELINE.json configs[4] at the seam: the same api.Verifier / api.Signer pair with Scheme::ED25519 — RFC 8032
     signer (byte-identical to the oracle's and to RFC 8032 §7.1 test 1-3 keys), 64-byte signatures, 128-byte R|S|A|k
