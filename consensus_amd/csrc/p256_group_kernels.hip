@@ -301,6 +301,54 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
     if (last) acc[t] = v ? 1 : 0;
 }
 
+// Latency form of the key-sorted step (GroupSync::coop_max, default off until it has been measured): SBV_COOP_LANES lanes per
+// grouped tuple, every lane sums every SBV_COOP_LANES-th of the 13 + 33 comb terms of u1 * G + u2 * Q from the comb of G and
+// the key's table (p256_comb29.h: keyed29_partial_lane, the registered-key latency kernel's lane) and the partial sums meet
+// in a butterfly of exact XYZZ additions: one launch ~10 additions deep instead of the G phase and two Q launches (45 deep).
+// For warm batches of a few thousand tuples, where every kernel of the step runs at the latency of one lane.
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_group_coop(Scratch s, GroupState g, const apt* __restrict__ ktab,
+                                                                    const uint8_t* __restrict__ kvalid, const u32* __restrict__ tslot,
+                                                                    u32 table_slots, gcomb g16r, uint8_t* __restrict__ acc) {
+    const size_t lane_g = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    const size_t L = lane_g / SBV_COOP_LANES;
+    const int sub = (int)(lane_g % SBV_COOP_LANES);
+    const bool active = L < g.counters[1];
+    xyzz R;
+    pt29_set_inf(R);
+    bool ok = false;
+    u32 t = 0;
+    if (active) {
+        t = g.grp_idx[L];
+        const u32 grp = g.grp_of[L];
+        u32 slot = grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE;
+        ok = slot < table_slots;
+        if (!ok) slot = 0;
+        ok = ok && kvalid[slot] != 0 && s.rec[(size_t)t * SBV_REC_WORDS + SBV_REC_OK] != 0;
+        u256 u1, u2;
+        rec_load256(u1, s.rec, t, SBV_REC_U1);
+        rec_load256(u2, s.rec, t, SBV_REC_U2);
+        keyed29_partial_lane(R, u1, u2, ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW), g16r, sub);
+    }
+    SBV_NOUNROLL
+    for (int off = SBV_COOP_LANES / 2; off >= 1; off >>= 1) {      // after log2(lanes) exchanges every lane of the group holds the whole sum
+        xyzz P;
+        SBV_UNROLL
+        for (int l = 0; l < 9; ++l) {
+            P.X.v[l] = __shfl_xor(R.X.v[l], off, 64);
+            P.Y.v[l] = __shfl_xor(R.Y.v[l], off, 64);
+            P.ZZ.v[l] = __shfl_xor(R.ZZ.v[l], off, 64);
+            P.ZZZ.v[l] = __shfl_xor(R.ZZZ.v[l], off, 64);
+        }
+        P.inf = __shfl_xor(R.inf ? 1 : 0, off, 64) != 0;
+        pt29_add(R, P);
+    }
+    if (active && sub == 0) {
+        u256 r;
+        rec_load256(r, s.rec, t, SBV_REC_R);
+        acc[t] = ok && pt29_rx_matches(R, r) ? 1 : 0;
+    }
+}
+
 // Enqueue stage B with in-step grouping.  Stage A (k_p256_prep) is already enqueued on `stream`.
 // Three streams (a process gets 4 hardware queues by default; with a fourth stream for the generic kernel
 // the Q phase was serialised behind it, measured).  Only the G phase and the Q phase are throughput work;
@@ -327,6 +375,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     if (!g.sorted) s.rec = nullptr;
     group_set_threshold(g, b.min_count);
     const int chunks = y.chunks < 1 ? 1 : (y.chunks > SBV_GROUP_MAX_CHUNKS ? SBV_GROUP_MAX_CHUNKS : y.chunks);
+    const bool coop = g.sorted && y.coop_max && n <= y.coop_max;      // k_group_coop instead of the G phase and the Q launches (sorted => unsliced)
     int rows_per_lane = 1;                         // rows of 16 entries one lane of the fill kernel builds (1, 2, 4 or 7)
     if (y.parts == 1 || y.parts == 2 || y.parts == 4 || y.parts == 7) rows_per_lane = y.parts;
     hipError_t e;
@@ -402,6 +451,11 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
                 gen_blocks = gv;
             }
             const unsigned gb = (unsigned)((end - first + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
+            if (coop) {          // the ungrouped list only: the coop launch below does the G phase's job too
+                hipLaunchKernelGGL(k_gphase_generic, dim3(gen_blocks), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc,
+                                   gen_blocks, first, end);
+                continue;
+            }
             if (g.sorted && slices == 1 && y.gsplit_min && n >= y.gsplit_min) {
                 hipLaunchKernelGGL(k_gphase_generic, dim3(gen_blocks), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc,
                                    gen_blocks, first, end);
@@ -455,6 +509,15 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         const bool last = c + 1 == chunks;
+        if (coop) {              // every table first, then the one launch
+            if (!last) continue;
+            if (prof) SBV_TRY(hipEventRecord(prof[0], stream));
+            const size_t lanes = n * SBV_COOP_LANES;
+            hipLaunchKernelGGL(k_group_coop, dim3((unsigned)((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK)), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab,
+                               b.kvalid, b.tslot, b.kc.cap + b.max_groups, d_g16r, b.acc);
+            if (prof) SBV_TRY(hipEventRecord(prof[1], stream));
+            continue;
+        }
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
         hipLaunchKernelGGL(k_verify_keyed_q, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.kc.cap + b.max_groups, b.gacc, b.acc,
                            q_first, q_end, last ? 1 : 0);
@@ -463,7 +526,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     if (y.side_c) SBV_TRY(hipStreamWaitEvent(stream, y.ev_generic, 0));
     hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
 #undef SBV_TRY
-    if (prof && prof_pairs) *prof_pairs = chunks;
+    if (prof && prof_pairs) *prof_pairs = coop ? 1 : chunks;
     return hipGetLastError();
 }
 

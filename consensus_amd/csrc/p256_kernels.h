@@ -78,6 +78,7 @@ struct GroupSync {
     int chunks = 1;
     int tsub = 1;                   // P-256: table-building pieces per Q-phase chunk (SBV_GROUP_TSUB; measured: 1 is best, every extra launch + cross-stream wait costs more than the overlap buys — profiles/r03/ab_tsub_parts_chunks_prio_r03c.jsonl)
     int sorted = 1;                 // P-256: key-sorted grouped list + XCD-aware Q phase (SBV_GROUP_SORT=0: the split's compaction order)
+    size_t coop_max = 0;            // P-256: batches up to this size finish in ONE launch of 8 lanes per grouped tuple (k_group_coop; SBV_GROUP_COOP_MAX).  0 = off: built and emulated in round 3, not yet measured on a GPU
     size_t gsplit_min = (size_t)1 << 19;   // P-256: batches from this size run the G phase as its own 3-waves-per-SIMD kernel (SBV_GPHASE_SPLIT_MIN; 0 = never)
     int wide = 0;                   // P-256, SBV_GROUP_WIDE: bit 0 = one lane per table entry in the rows step (k_keytab29_entries), bit 1 = fill rows split over fsplit lanes (k_keytab29_fill_parts); default 0 = two chains of additions per window + whole rows per lane (measured: profiles/r03/ab_wide_fresh_process_r03l.jsonl, ab_wide_bits_r03r.jsonl)
     int fsplit = 3;                 // P-256, wide: lanes per row of 15 entries in the fill step, 1..4 (SBV_GROUP_FSPLIT)

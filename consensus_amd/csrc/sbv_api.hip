@@ -478,7 +478,7 @@ int init_context(Context& c, int device) {
     {   // every knob back to its default: a context initialised again re-reads the environment
         const sbv::GroupSync d;
         c.gsync.tsub = d.tsub; c.gsync.parts = d.parts; c.gsync.wide = d.wide; c.gsync.fsplit = d.fsplit; c.gsync.slices = d.slices;
-        c.gsync.sorted = d.sorted; c.gsync.tstreams = d.tstreams; c.gsync.gsplit_min = d.gsplit_min;
+        c.gsync.sorted = d.sorted; c.gsync.tstreams = d.tstreams; c.gsync.gsplit_min = d.gsplit_min; c.gsync.coop_max = d.coop_max;
     }
     c.gsync.chunks = 2;
     if (const char* e = getenv("SBV_GROUP_CHUNKS")) {
@@ -489,6 +489,7 @@ int init_context(Context& c, int device) {
     if (const char* e = getenv("SBV_GROUP_PARTS")) c.gsync.parts = atoi(e);
     if (const char* e = getenv("SBV_GROUP_TSTREAMS")) { const int v = atoi(e); if (v >= 1 && v <= 2) c.gsync.tstreams = v; }
     if (const char* e = getenv("SBV_GPHASE_SPLIT_MIN")) c.gsync.gsplit_min = (size_t)strtoull(e, nullptr, 10);
+    if (const char* e = getenv("SBV_GROUP_COOP_MAX")) { const size_t v = (size_t)strtoull(e, nullptr, 10); c.gsync.coop_max = v > 32768 ? 32768 : v; }
     if (const char* e = getenv("SBV_GROUP_WIDE")) c.gsync.wide = atoi(e) & 3;
     if (const char* e = getenv("SBV_GROUP_FSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.fsplit = v; }
     if (const char* e = getenv("SBV_GROUP_SLICES")) c.gsync.slices = atoi(e);

@@ -130,7 +130,8 @@ unsigned long sbve_fast_mismatches() { return g_fast_mismatches; }
 u32 sbve_fe_add_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_add<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 u32 sbve_fe_mul_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_mul<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 
-static int g_group_chunks = 3, g_group_parts = 4, g_group_sort = 1, g_group_wide = 0, g_group_fsplit = 3;
+static unsigned long g_coop_disagreements = 0, g_small_disagreements = 0;     // lanes of a cooperating group that ended with different points / stage-A forms that disagreed
+static int g_group_chunks = 3, g_group_parts = 4, g_group_sort = 1, g_group_wide = 0, g_group_fsplit = 3, g_group_coop = 0;
 void sbve_set_group_sort(int on) { g_group_sort = on ? 1 : 0; }
 static unsigned long g_sort_violations = 0;
 unsigned long sbve_group_sort_violations() { return g_sort_violations; }
@@ -154,6 +155,7 @@ void sbve_set_group_chunks(int c) { g_group_chunks = c < 1 ? 1 : (c > 4 ? 4 : c)
 static void emul_window_rows_fill(const u32* recs, bool top, int rpl, u32* tmp, apt* row);
 void sbve_set_group_wide(int wide, int fsplit) { g_group_wide = wide & 3;   // bit 0: one lane per entry in the rows step, bit 1: fill rows split over fsplit lanes
     if (fsplit >= 1 && fsplit <= 4) g_group_fsplit = fsplit; }
+void sbve_set_group_coop(int on) { g_group_coop = on != 0; }     // k_group_coop instead of the G phase + Q launches (key-sorted step only)
 void sbve_set_group_parts(int p) { if (p == 2 || p == 4 || p == 8 || p == 16) g_group_parts = p; }
 // grouped form: generic tuples, keys grouped inside the call (p256_group.h), emulated sequentially.
 // stats_out[0..3] = groups, grouped tuples, ungrouped tuples, ungrouped tuples rejected for their key.
@@ -214,7 +216,8 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     }
     // G phase: for every tuple, or (key-sorted list) for the grouped ones at their sorted position
     std::vector<u32> gacc(SBV_GACC29_WORDS * cap);
-    if (g.sorted) for (u32 L = 0; L < counters[1]; ++L) gphase29_lane_sorted(s, grp_idx[L], L, g16rtab(), gacc.data());
+    if (g_group_coop && g.sorted) {}          // the coop launch below does the G phase's job too
+    else if (g.sorted) for (u32 L = 0; L < counters[1]; ++L) gphase29_lane_sorted(s, grp_idx[L], L, g16rtab(), gacc.data());
     else for (size_t i = 0; i < n; ++i) gphase29_lane(s, i, g16rtab(), gacc.data());
     // key tables and the Q phase, in `chunks` pieces like the device pipeline
     const size_t ng1 = ngroups ? ngroups : 1;
@@ -264,6 +267,36 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
                 emul_window_rows_fill(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, rpl, tmpa.data(), row);
             }
         const bool last = c + 1 == chunks;
+        if (g_group_coop && g.sorted) {
+            if (!last) continue;
+            // k_group_coop: SBV_COOP_LANES partial sums per grouped tuple (comb of G + the key's table), xor-butterfly of exact
+            // XYZZ additions; every lane of a group must end with the same point
+            for (u32 L = 0; L < counters[1]; ++L) {
+                const u32 t = grp_idx[L];
+                const u32 grp = grp_of[L];
+                const u32 table_slots = kc.cap + (u32)ng1;
+                u32 slot = grp < ngroups ? tslot[grp] : SBV_GROUP_NONE;
+                bool okk = slot < table_slots;
+                const apt* tab = okk ? table_of(grp) : ktab;
+                okk = okk && *valid_of(grp < ngroups ? grp : 0) != 0 && s.rec[(size_t)t * SBV_REC_WORDS + SBV_REC_OK] != 0;
+                u256 a, bb, rr;
+                rec_load256(a, s.rec, t, SBV_REC_U1);
+                rec_load256(bb, s.rec, t, SBV_REC_U2);
+                rec_load256(rr, s.rec, t, SBV_REC_R);
+                xyzz part[SBV_COOP_LANES];
+                for (int sub = 0; sub < SBV_COOP_LANES; ++sub) keyed29_partial_lane(part[sub], a, bb, tab, g16rtab(), sub);
+                for (int off = SBV_COOP_LANES / 2; off >= 1; off >>= 1) {
+                    xyzz nxt[SBV_COOP_LANES];
+                    for (int sub = 0; sub < SBV_COOP_LANES; ++sub) { nxt[sub] = part[sub]; pt29_add(nxt[sub], part[sub ^ off]); }
+                    for (int sub = 0; sub < SBV_COOP_LANES; ++sub) part[sub] = nxt[sub];
+                }
+                const bool v = okk && pt29_rx_matches(part[0], rr);
+                for (int sub = 1; sub < SBV_COOP_LANES; ++sub)
+                    if ((okk && pt29_rx_matches(part[sub], rr)) != v) g_coop_disagreements++;
+                if (v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+            }
+            continue;
+        }
         for (u32 L = 0; L < counters[1]; ++L) {
             const u32 t = grp_idx[L];
             const u32 grp = g.sorted ? grp_of[L] : slots[t];
@@ -365,7 +398,6 @@ int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
 }
 
 static bool g_keyed_coop = false, g_keyed_small = false;
-static unsigned long g_coop_disagreements = 0, g_small_disagreements = 0;
 // registered-key form: rsh = n x 96 B (r|s|hash), slots[i] indexes keys (nkeys x 64 B, Qx|Qy)
 void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n, const uint8_t* keys, u32 nkeys,
                                   uint8_t* bitmap, int block, int T) {

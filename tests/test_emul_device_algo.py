@@ -540,6 +540,49 @@ def test_persistent_key_table_cache_never_changes_verdicts(emul, oracle, golden_
         emul.sbve_key_cache(0, 0)
 
 
+def test_coop_form_of_the_grouped_step_equals_the_phased_one(emul, oracle, golden_vectors):
+    """k_group_coop (GroupSync::coop_max, off by default): eight lanes per grouped tuple sum the 13 + 33 comb terms of
+    u1 * G + u2 * Q and meet in a butterfly of exact additions, in ONE launch instead of the G phase and the Q launches.  The
+    whole step emulated both ways — golden vectors (u1 G = +-u2 Q, R.x in [N, p), off-curve keys ...), a seeded batch with a
+    repeated invalid key, cold tables in 1 / 2 / 3 chunks and warm ones from the key cache, groups capped at 3 so that some
+    tuples stay on the doubling kernel — must give the oracle's verdicts, identical statistics, and every lane of every group
+    must end with the same point."""
+    emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    emul.sbve_key_cache.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    emul.sbve_coop_disagreements.restype = ctypes.c_ulong
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    n = 500
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0xC00B, n, 7, 5, tup, exp, 4)
+    off = next(bytes.fromhex(v["tuple"]) for v in vs if v["name"] == "q_off_curve_y_plus_1")
+    allt = b"".join(bytes.fromhex(v["tuple"]) for v in vs) * 2 + tup.raw + off * 20
+    total = len(allt) // 160
+    want = [v["accept"] for v in vs] * 2 + _bitmap_list(exp.raw, n) + [False] * 20
+    stats = (ctypes.c_uint32 * 4)()
+    before = emul.sbve_coop_disagreements()
+    try:
+        for cache, min_count, max_groups, chunks in [(0, 2, 4096, 2), (0, 8, 64, 1), (0, 2, 3, 3), (1, 2, 4096, 2), (1, 2, 4096, 2)]:
+            emul.sbve_key_cache(cache, 512)
+            emul.sbve_set_group_chunks(chunks)
+            res = []
+            for coop in (1, 0):
+                emul.sbve_set_group_coop(coop)
+                bm = ctypes.create_string_buffer((total + 7) // 8)
+                emul.sbve_p256_verify_batch_grouped(allt, total, bm, min_count, max_groups, 12, stats)
+                res.append((_bitmap_list(bm.raw, total), tuple(stats)))
+            assert res[0][0] == want, (cache, min_count, max_groups, [i for i in range(total) if res[0][0][i] != want[i]][:8])
+            assert res[0] == res[1], (cache, min_count, max_groups)
+            if max_groups == 3:
+                assert res[0][1][0] == 3 and res[0][1][2] > 0           # three tables, the rest on the doubling kernel
+        assert emul.sbve_coop_disagreements() == before
+    finally:
+        emul.sbve_set_group_coop(0)
+        emul.sbve_set_group_chunks(3)
+        emul.sbve_key_cache(0, 0)
+
+
 def test_two_field_representations_agree(emul, oracle, golden_vectors):
     """The kernels run on the carry-free field (p256_fe29.h ...); the earlier 8 x 32-bit-limb lanes (p256_core.h: prep_chunk,
     verify_lane with its fast / exact passes) are kept as a second, independently written implementation of the same

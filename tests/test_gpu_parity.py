@@ -346,6 +346,45 @@ def test_in_step_key_grouping_equals_generic(gpu, oracle, golden_vectors):
         gpu.set_grouping(True, 131072, 64, 2048)
 
 
+@pytest.mark.skipif(os.environ.get("SBV_TEST_COOP") != "1", reason="k_group_coop is off by default until it has been measured: SBV_TEST_COOP=1 runs it")
+def test_coop_form_of_the_grouped_step_on_the_gpu(oracle, golden_vectors):
+    """SBV_GROUP_COOP_MAX: batches up to that size finish in one launch of eight lanes per grouped tuple (k_group_coop).  In a
+    child process (the knob is read when the context is created): golden vectors + a seeded batch + a repeated invalid key,
+    key cache cold and warm, thresholds that leave tuples on the doubling kernel; verdicts = the oracle's."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, json, os, sys\n"
+        "root = %r\n"
+        "sys.path.insert(0, root)\n"
+        "import consensus_amd as sbv\n"
+        "oracle = ctypes.CDLL(os.path.join(root, 'oracle', 'libsbv_oracle.so'))\n"
+        "oracle.sbvo_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]\n"
+        "vs = [v for v in json.load(open(os.path.join(root, 'tests', 'golden', 'p256_vectors.json')))['vectors'] if v['kind'] == 'tuple']\n"
+        "n = 6000\n"
+        "tup = ctypes.create_string_buffer(160 * n); exp = ctypes.create_string_buffer((n + 7) // 8)\n"
+        "oracle.sbvo_gen_batch(0xC00B, n, 23, 5, tup, exp, os.cpu_count() or 1)\n"
+        "off = next(bytes.fromhex(v['tuple']) for v in vs if v['name'] == 'q_off_curve_y_plus_1')\n"
+        "allt = b''.join(bytes.fromhex(v['tuple']) for v in vs) + tup.raw + off * 100\n"
+        "total = len(allt) // 160\n"
+        "want = [v['accept'] for v in vs] + sbv.bitmap_to_list(exp.raw, n) + [False] * 100\n"
+        "sbv.init(0)\n"
+        "for cache in (False, True, True):\n"
+        "    sbv.key_cache(cache)\n"
+        "    for min_count, max_groups in [(8, 64), (1, 4096), (8, 3)]:\n"
+        "        sbv.set_grouping(True, 1, min_count, max_groups)\n"
+        "        got = sbv.bitmap_to_list(sbv.verify_batch(allt, total), total)\n"
+        "        bad = [i for i in range(total) if got[i] != want[i]]\n"
+        "        assert not bad, (cache, min_count, max_groups, bad[:8])\n"
+        "print('ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    assert any(f.startswith("p256_vectors") for f in os.listdir(golden))
+    for coop in ("32768", "0"):
+        env = dict(os.environ, SBV_GROUP_COOP_MAX=coop)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (coop, r.stderr[-1500:])
+
+
 def test_grouped_vs_ungrouped_full_batch(gpu):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
