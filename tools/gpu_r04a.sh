@@ -1,0 +1,48 @@
+#!/bin/bash
+# round 4, first session (prepared at the end of round 3, when the GPU budget was spent): measure what round 3 left switched off.
+#   1. opt-in correctness: k_group_coop (SBV_TEST_COOP=1) and the key-affine part without the host round trip (SBV_PART_NOSYNC=1)
+#   2. warm small batches with and without the coop launch (fresh processes: the knob is read when the context is created)
+#   3. one Q chunk at 2^20 now that every table is ready when the G phase ends (SBV_GROUP_CHUNKS=1)
+#   4. the projection leg with SBV_PART_NOSYNC=1
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r04a
+mkdir -p "$OUT"; cd "$ROOT"; export TMPDIR=/tmp
+( SBV_TEST_COOP=1 timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -k coop_form > "$OUT/pytest_coop.log" 2>&1; echo "rc=$?" >> "$OUT/pytest_coop.log" ); tail -3 "$OUT/pytest_coop.log"
+( SBV_PART_NOSYNC=1 timeout 400 python -m pytest tests/test_gpu_configs.py -m gpu -q -k "key_affine or by_key" > "$OUT/pytest_part_nosync.log" 2>&1; echo "rc=$?" >> "$OUT/pytest_part_nosync.log" ); tail -3 "$OUT/pytest_part_nosync.log"
+for rep in 1 2; do for v in 0 32768; do
+  echo "# SBV_GROUP_COOP_MAX=$v rep $rep" >> "$OUT/coop.jsonl"
+  SBV_GROUP_COOP_MAX=$v timeout 100 python tools/sweep_sizes.py 10 12 13 14 15 >> "$OUT/coop.jsonl" 2>> "$OUT/coop.err"
+done; done
+python3 - "$OUT/coop.jsonl" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    if l.startswith("#"): print(l.strip()); continue
+    d = json.loads(l); print(d["log2_tuples"], "cold", d["cold"]["ms"], "warm", d["warm"]["ms"], d["cold"]["ok"], d["warm"]["ok"])
+PY
+( timeout 200 python tools/ab_env.py 19,20 default SBV_GROUP_CHUNKS=1 SBV_GROUP_CHUNKS=3 > "$OUT/ab_chunks.jsonl" 2> "$OUT/ab_chunks.err" ); cat "$OUT/ab_chunks.jsonl"
+for ns in 0 1; do
+( SBV_PART_NOSYNC=$ns timeout 300 python - > "$OUT/projection_nosync$ns.json" 2> "$OUT/projection_nosync$ns.err" <<'PY'
+import json, os, sys, time
+root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tools"))
+import torch
+import bench, synth
+import consensus_amd as sbv
+n = 1 << 20
+tuples, valid = synth.gen_batch(bench.SEED, n)
+sbv.init(0); sbv.key_cache(False)
+d_tuples = torch.from_numpy(tuples).cuda()
+stream = torch.cuda.current_stream()
+d_b = torch.zeros(n // 8, dtype=torch.uint8, device="cuda")
+for _ in range(3): sbv.verify_batch_dev(d_tuples.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(8): sbv.verify_batch_dev(d_tuples.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+torch.cuda.synchronize(); base = 1e3 * (time.perf_counter() - t0) / 8
+print(json.dumps(bench.leg_projected_strong_scaling(sbv, torch, d_tuples, valid, n, stream, base)))
+PY
+); python3 -c "
+import json
+d=json.load(open('$OUT/projection_nosync$ns.json'))
+print('nosync=$ns', {g: {k: round(x['projected_speedup'], 2) for k, x in v.items()} for g, v in d['partitions'].items()})"
+done
