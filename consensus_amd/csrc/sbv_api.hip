@@ -1837,7 +1837,7 @@ int verify_shard(Context& c, const uint8_t* h_tuples, size_t m, size_t group, u3
     for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) { drop_events(); g_err = "hipEventCreate failed"; return SBV_EDEVICE; }
     hipError_t he = hipSuccess;
     auto step = [&](hipError_t r) { if (he == hipSuccess) he = r; };
-    if (c.busy_valid) {                        // an earlier pipelined call may still read c.d_tuples' neighbours on c.stream
+    if (c.busy_valid) {                        // kernels of an earlier call (pipelined host entry, a key-affine part) may still be using the scratch and group buffers
         step(hipStreamWaitEvent(c.stream, c.busy, 0));
         if (pieces > 1) step(hipStreamWaitEvent(up, c.busy, 0));
     }
