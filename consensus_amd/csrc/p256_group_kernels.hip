@@ -474,7 +474,8 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     int tsub = y.tsub < 1 ? 1 : y.tsub;
     while (chunks * tsub > SBV_GROUP_MAX_TCHUNKS) --tsub;
     for (int c = 0; c < chunks; ++c) {
-        const int q_first = SBV_GTAB_WINDOWS * c / chunks, q_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [q_first, q_end)
+        int q_first = SBV_GTAB_WINDOWS * c / chunks, q_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [q_first, q_end)
+        if (chunks == 2 && y.chunk0 > 0 && y.chunk0 < SBV_GTAB_WINDOWS) { q_first = c == 0 ? 0 : y.chunk0; q_end = c == 0 ? y.chunk0 : SBV_GTAB_WINDOWS; }   // uneven split: a short first chunk has its tables ready when the G phase ends
         hipStream_t tb = y.tstreams > 1 && y.side_t && (c & 1) ? y.side_t : y.side_b;     // rows + fill of this chunk
         for (int t = 0; t < tsub; ++t) {
             const int j_first = q_first + (q_end - q_first) * t / tsub, j_end = q_first + (q_end - q_first) * (t + 1) / tsub;

@@ -76,6 +76,7 @@ struct GroupSync {
     hipEvent_t ev_fork = nullptr, ev_assign = nullptr, ev_split = nullptr, ev_prep = nullptr, ev_generic = nullptr;
     hipEvent_t ev_bases[SBV_GROUP_MAX_TCHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
     int chunks = 1;
+    int chunk0 = 0;                 // P-256, two chunks: windows in the FIRST one (SBV_GROUP_CHUNK0; 0 = 16, the even split).  Not yet measured: with the G phase as its own 3-wave kernel the first Q launch waits ~0.3 ms for the tables of an even first chunk (profiles/r03/timeline_r03u.txt)
     int tsub = 1;                   // P-256: table-building pieces per Q-phase chunk (SBV_GROUP_TSUB; measured: 1 is best, every extra launch + cross-stream wait costs more than the overlap buys — profiles/r03/ab_tsub_parts_chunks_prio_r03c.jsonl)
     int sorted = 1;                 // P-256: key-sorted grouped list + XCD-aware Q phase (SBV_GROUP_SORT=0: the split's compaction order)
     size_t coop_max = 0;            // P-256: batches up to this size finish in ONE launch of 8 lanes per grouped tuple (k_group_coop; SBV_GROUP_COOP_MAX).  0 = off: built and emulated in round 3, not yet measured on a GPU

@@ -131,7 +131,7 @@ u32 sbve_fe_add_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(
 u32 sbve_fe_mul_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_mul<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 
 static unsigned long g_coop_disagreements = 0, g_small_disagreements = 0;     // lanes of a cooperating group that ended with different points / stage-A forms that disagreed
-static int g_group_chunks = 3, g_group_parts = 4, g_group_sort = 1, g_group_wide = 0, g_group_fsplit = 3, g_group_coop = 0;
+static int g_group_chunks = 3, g_group_parts = 4, g_group_sort = 1, g_group_wide = 0, g_group_fsplit = 3, g_group_coop = 0, g_group_chunk0 = 0;
 void sbve_set_group_sort(int on) { g_group_sort = on ? 1 : 0; }
 static unsigned long g_sort_violations = 0;
 unsigned long sbve_group_sort_violations() { return g_sort_violations; }
@@ -155,6 +155,7 @@ void sbve_set_group_chunks(int c) { g_group_chunks = c < 1 ? 1 : (c > 4 ? 4 : c)
 static void emul_window_rows_fill(const u32* recs, bool top, int rpl, u32* tmp, apt* row);
 void sbve_set_group_wide(int wide, int fsplit) { g_group_wide = wide & 3;   // bit 0: one lane per entry in the rows step, bit 1: fill rows split over fsplit lanes
     if (fsplit >= 1 && fsplit <= 4) g_group_fsplit = fsplit; }
+void sbve_set_group_chunk0(int w) { g_group_chunk0 = w >= 1 && w <= 32 ? w : 0; }   // two chunks: windows in the first one (GroupSync::chunk0)
 void sbve_set_group_coop(int on) { g_group_coop = on != 0; }     // k_group_coop instead of the G phase + Q launches (key-sorted step only)
 void sbve_set_group_parts(int p) { if (p == 2 || p == 4 || p == 8 || p == 16) g_group_parts = p; }
 // grouped form: generic tuples, keys grouped inside the call (p256_group.h), emulated sequentially.
@@ -254,7 +255,8 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     const int chunks = g_group_chunks;
     const int rpl = g_group_parts == 2 ? 2 : (g_group_parts == 4 ? 4 : (g_group_parts == 16 ? 7 : 1));   // rows per lane of the fill kernel
     for (int c = 0; c < chunks; ++c) {
-        const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
+        int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
+        if (chunks == 2 && g_group_chunk0 > 0) { j_first = c == 0 ? 0 : g_group_chunk0; j_end = c == 0 ? g_group_chunk0 : SBV_GTAB_WINDOWS; }
         for (u32 k = 0; k < ngroups; ++k)
             if (cold[k]) {               // k_keytab29_chain: the four lanes of the key's quad in lockstep
                 keychain_quad_host q;

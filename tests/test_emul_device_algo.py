@@ -563,9 +563,10 @@ def test_coop_form_of_the_grouped_step_equals_the_phased_one(emul, oracle, golde
     stats = (ctypes.c_uint32 * 4)()
     before = emul.sbve_coop_disagreements()
     try:
-        for cache, min_count, max_groups, chunks in [(0, 2, 4096, 2), (0, 8, 64, 1), (0, 2, 3, 3), (1, 2, 4096, 2), (1, 2, 4096, 2)]:
+        for ci, (cache, min_count, max_groups, chunks) in enumerate([(0, 2, 4096, 2), (0, 8, 64, 1), (0, 2, 3, 3), (1, 2, 4096, 2), (1, 2, 4096, 2), (0, 2, 4096, 2)]):
             emul.sbve_key_cache(cache, 512)
             emul.sbve_set_group_chunks(chunks)
+            emul.sbve_set_group_chunk0(7 if ci == 5 else 0)         # an uneven split of the windows: 7 + 26 (GroupSync::chunk0)
             res = []
             for coop in (1, 0):
                 emul.sbve_set_group_coop(coop)
@@ -579,6 +580,7 @@ def test_coop_form_of_the_grouped_step_equals_the_phased_one(emul, oracle, golde
         assert emul.sbve_coop_disagreements() == before
     finally:
         emul.sbve_set_group_coop(0)
+        emul.sbve_set_group_chunk0(0)
         emul.sbve_set_group_chunks(3)
         emul.sbve_key_cache(0, 0)
 
