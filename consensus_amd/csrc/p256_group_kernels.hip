@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void k_keytab29_chain(const uint8_t* __restrict
 #endif
 __global__ __launch_bounds__(64, SBV_ROWS_WAVES) void k_keytab29_rows(GroupState g, const u32* __restrict__ bases, u32* __restrict__ tmp,
                                                       apt* __restrict__ ktab, const u32* __restrict__ tslot,
-                                                      const uint8_t* __restrict__ cold, int j_first, int j_count) {
+                                                      const uint8_t* __restrict__ cold, int j_first, int j_count, int babies) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;
     const u32 which = lane & 1u, kw = lane >> 1;
     const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(64, SBV_ROWS_WAVES) void k_keytab29_rows(GroupState
     const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
     u32* t = tmp + w * SBV_KT29_WINDOW_TMP + (size_t)which * SBV_KT29_ROWS_TMP_WORDS;
     keytab29_rows_lane(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), (int)which, j == SBV_GTAB_WINDOWS - 1, t,
-                       ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
+                       ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW, babies);
 }
 // lanes = groups x j_count x lanes_per_window, each lane rows_per_lane of the 7 rows 16 a + b, a = 1..7
 __global__ __launch_bounds__(64) void k_keytab29_fill(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab,
@@ -225,6 +225,20 @@ __global__ __launch_bounds__(64) void k_keytab29_fill_parts(GroupState g, u32* _
     const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
     u32* t = tmp + w * SBV_KT29_WINDOW_TMP + (size_t)r * (15 * 9);
     keytab29_fill_part_lane(a, b_first, b_last, t, ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
+}
+
+// Symmetric fill (GroupSync::wide bit 2): lanes = groups x j_count x 8, lane a - 1 of a window fills both sides of giant 16 a
+__global__ __launch_bounds__(64) void k_keytab29_fill_sym(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab,
+                                                          const u32* __restrict__ tslot, const uint8_t* __restrict__ cold, int j_first,
+                                                          int j_count) {
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 r = lane & 7u, kw = lane >> 3;
+    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
+    if (key >= group_count(g) || j == SBV_GTAB_WINDOWS - 1 || !cold[key]) return;
+    table_prio();
+    const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
+    keytab29_fill_sym_lane(1 + (int)r, tmp + w * SBV_KT29_WINDOW_TMP + (size_t)r * SBV_KT29_FILL_TMP_WORDS / 2,
+                           ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
 }
 
 // One launch, two jobs.  Blocks [0, generic_blocks): the generic stage B (doubling kernel) over the
@@ -493,9 +507,13 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
                 hipLaunchKernelGGL(k_keytab29_entries, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.ktab, b.tslot, b.cold, j_first, j_count);
             } else {
                 const size_t wl = (size_t)b.max_groups * j_count * 2;
-                hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
+                hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count,
+                                   (y.wide & 4) ? 8 : 16);
             }
-            if (y.wide & 2) {
+            if ((y.wide & 4) && !(y.wide & 1)) {          // symmetric fill: needs the chain-of-additions rows (babies 1..8, giants 16..128)
+                const size_t fl = (size_t)b.max_groups * j_count * 8;
+                hipLaunchKernelGGL(k_keytab29_fill_sym, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
+            } else if (y.wide & 2) {
                 const int split = y.fsplit < 1 ? 1 : (y.fsplit > 4 ? 4 : y.fsplit);
                 const size_t fl = (size_t)b.max_groups * j_count * 7 * split;
                 hipLaunchKernelGGL(k_keytab29_fill_parts, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, b.ktab, b.tslot, b.cold, j_first,

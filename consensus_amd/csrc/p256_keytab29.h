@@ -249,10 +249,10 @@ SBV_HD void keychain29_run(QX& q, const uint8_t* tuples, u32 gidx, const GroupSt
 // (the addition formulas do not depend on the curve's coefficients; the one doubling takes a4 = T = -3 Z^4 from the chain),
 // and a multiple (X' : Y' : ZZ' : ZZZ') maps back as x = X' / (ZZ' Z^2), y = Y' / (ZZZ' Z^3).  Z joins the lane's ONE
 // inversion (Montgomery's trick over Z and the ZZZ' of the chain).
-SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32* tmp, apt* row) {
+SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32* tmp, apt* row, int babies = 16) {
     kchain B;
     kchain_load(B, base2 + which * 4 * SBV_KT29_REC_WORDS);               // record 0 = B, record 4 = 16 B
-    const int n = top_window ? 0 : (which == 0 ? 15 : 7);                 // points of the chain beyond its first
+    const int n = top_window ? 0 : (which == 0 ? babies - 1 : 7);         // points of the chain beyond its first (babies = 8: the symmetric fill below)
     apt29 step;
     step.x = B.X; step.y = B.Y;
     xyzz R;
@@ -284,13 +284,13 @@ SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32
     f29_mul(inv, inv, bz);                      // 1 / prod ZZZ'
     f29_sqr(zi2, zi);
     f29_mul(zi3, zi2, zi);
-    if (which == 0) {                           // entry 1 = B itself
+    if (which == 0 || babies < 16) {            // entry 1 = B itself; with the short baby chain nobody else builds entry 16 = the giants' base
         apt29 a;
         fe29 bx, by;
         f29_load_raw(bx, brec); f29_load_raw(by, brec + 9);
         f29_mul(a.x, bx, zi2);
         f29_mul(a.y, by, zi3);
-        apt29_store_canon(row, a);
+        apt29_store_canon(row + (which == 0 ? 0 : 15), a);
     }
     SBV_NOUNROLL
     for (int k = n - 1; k >= 0; --k) {
@@ -399,6 +399,49 @@ SBV_HD void keytab29_fill_lane(int a_first, int a_last, u32* tmp, apt* row) {
             f29_mul(inv, inv, d);
             apt29_add_with_inverse(r, G, S, dinv);
             apt29_store_canon(row + 16 * a + b - 1, r);
+        }
+    }
+}
+
+// Symmetric form (GroupSync::wide bit 2): lane a = 1..8 fills BOTH sides of giant 16 a from babies 1..8 — 16 a + b (b = 1..7,
+// a <= 7) and 16 a - b (b = 1..8) share the inverse of x_b - x_16a, because -b B is (x_b, -y_b).  Eight denominators per lane
+// instead of fifteen, and the rows step only has to build babies 2..8 (7 additions instead of 15).  Entry 8 is a baby and is
+// not written again (a = 1, b = 8); entries 9..15 come from giant 16.  Lanes write disjoint entries and read only babies
+// 1..8 and their own giant, which the rows step wrote.  tmp: 8 x 9 words.
+SBV_HD void keytab29_fill_sym_lane(int a, u32* tmp, apt* row) {
+    apt29 G;
+    apt29_load(G, reinterpret_cast<const u32*>(row + 16 * a - 1));
+    fe29 acc = f29_one();
+    SBV_NOUNROLL
+    for (int b = 1; b <= 8; ++b) {
+        apt29 S;
+        apt29_load(S, reinterpret_cast<const u32*>(row + b - 1));
+        fe29 d;
+        f29_sub(d, S.x, G.x);
+        f29_store_raw(tmp + (b - 1) * 9, acc);
+        f29_mul(acc, acc, d);
+    }
+    fe29 inv;
+    f29_inv(inv, acc);
+    SBV_NOUNROLL
+    for (int b = 8; b >= 1; --b) {
+        apt29 S, r;
+        apt29_load(S, reinterpret_cast<const u32*>(row + b - 1));
+        fe29 d, pre, dinv;
+        f29_sub(d, S.x, G.x);
+        f29_load_raw(pre, tmp + (b - 1) * 9);
+        f29_mul(dinv, inv, pre);
+        f29_mul(inv, inv, d);
+        if (a <= 7 && b <= 7) {
+            apt29_add_with_inverse(r, G, S, dinv);
+            apt29_store_canon(row + 16 * a + b - 1, r);
+        }
+        if (!(a == 1 && b == 8)) {
+            fe29 ny;
+            f29_neg(ny, S.y);
+            S.y = ny;
+            apt29_add_with_inverse(r, G, S, dinv);
+            apt29_store_canon(row + 16 * a - b - 1, r);
         }
     }
 }

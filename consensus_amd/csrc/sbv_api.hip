@@ -491,7 +491,7 @@ int init_context(Context& c, int device) {
     if (const char* e = getenv("SBV_GROUP_TSTREAMS")) { const int v = atoi(e); if (v >= 1 && v <= 2) c.gsync.tstreams = v; }
     if (const char* e = getenv("SBV_GPHASE_SPLIT_MIN")) c.gsync.gsplit_min = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("SBV_GROUP_COOP_MAX")) { const size_t v = (size_t)strtoull(e, nullptr, 10); c.gsync.coop_max = v > 32768 ? 32768 : v; }
-    if (const char* e = getenv("SBV_GROUP_WIDE")) c.gsync.wide = atoi(e) & 3;
+    if (const char* e = getenv("SBV_GROUP_WIDE")) c.gsync.wide = atoi(e) & 7;
     if (const char* e = getenv("SBV_GROUP_FSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.fsplit = v; }
     if (const char* e = getenv("SBV_GROUP_SLICES")) c.gsync.slices = atoi(e);
     if (const char* e = getenv("SBV_GROUP_SORT")) c.gsync.sorted = atoi(e) != 0;

@@ -153,7 +153,7 @@ void sbve_key_cache(int enabled, u32 cap) {
 void sbve_key_cache_stats(u32 out[3]) { out[0] = g_kc.count ? g_kc_count[0] : 0; out[1] = g_kc.count ? g_kc_count[1] : 0; out[2] = g_kc.count ? g_kc_count[2] : 0; }
 void sbve_set_group_chunks(int c) { g_group_chunks = c < 1 ? 1 : (c > 4 ? 4 : c); }
 static void emul_window_rows_fill(const u32* recs, bool top, int rpl, u32* tmp, apt* row);
-void sbve_set_group_wide(int wide, int fsplit) { g_group_wide = wide & 3;   // bit 0: one lane per entry in the rows step, bit 1: fill rows split over fsplit lanes
+void sbve_set_group_wide(int wide, int fsplit) { g_group_wide = wide & 7;   // bit 0: one lane per entry in the rows step, bit 1: fill rows split over fsplit lanes
     if (fsplit >= 1 && fsplit <= 4) g_group_fsplit = fsplit; }
 void sbve_set_group_chunk0(int w) { g_group_chunk0 = w >= 1 && w <= 32 ? w : 0; }   // two chunks: windows in the first one (GroupSync::chunk0)
 void sbve_set_group_coop(int on) { g_group_coop = on != 0; }     // k_group_coop instead of the G phase + Q launches (key-sorted step only)
@@ -328,10 +328,14 @@ static void emul_window_rows_fill(const u32* recs, bool top, int rpl, u32* tmp, 
     } else {
         for (int which = 0; which < 2; ++which) {
             if (which == 1 && top) continue;
-            keytab29_rows_lane(recs, which, top, tmp, row);
+            keytab29_rows_lane(recs, which, top, tmp, row, (g_group_wide & 4) ? 8 : 16);
         }
     }
     if (top) return;
+    if ((g_group_wide & 4) && !(g_group_wide & 1)) {       // k_keytab29_fill_sym: lane a - 1 fills both sides of giant 16 a
+        for (int a = 8; a >= 1; --a) keytab29_fill_sym_lane(a, tmp + (size_t)(a - 1) * (SBV_KT29_FILL_TMP_WORDS / 2), row);
+        return;
+    }
     if (g_group_wide & 2) {
         const int split = g_group_fsplit, per = (15 + split - 1) / split;
         for (int r = 0; r < 7 * split; ++r) {

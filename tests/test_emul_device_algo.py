@@ -281,7 +281,7 @@ def test_key_comb_scalars_around_the_sign_flip_and_the_carry_window(emul, oracle
     emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
                                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
     stats = (ctypes.c_uint32 * 4)()
-    for chunks, wide in ((1, 3), (2, 1), (3, 2), (3, 0)):
+    for chunks, wide in ((1, 3), (2, 1), (3, 2), (2, 4), (3, 0)):
         emul.sbve_set_group_chunks(chunks)
         emul.sbve_set_group_wide(wide, 3)
         bm = ctypes.create_string_buffer((total + 7) // 8)

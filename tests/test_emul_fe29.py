@@ -267,8 +267,9 @@ def test_key_table_of_the_key_that_wrapped_a_limb(emul):
     q = (int.from_bytes(key[:32], "big"), int.from_bytes(key[32:], "big"))
     tab = (ctypes.c_uint32 * (33 * 128 * 16))()
     # every form of rows + fill: bit 0 of `wide` = one lane per entry from the chain's 8 records per window, bit 1 = fill rows in
-    # 1..4 parts; 0 = the chains of additions and whole rows (the default)
-    for wide, fsplit, chunks in ((3, 3, 2), (3, 3, 3), (3, 1, 1), (2, 2, 3), (2, 4, 2), (1, 3, 2), (0, 3, 2), (0, 3, 3)):
+    # 1..4 parts, bit 2 = the symmetric fill (babies 1..8 only, both sides of every giant from one inverse); 0 = the chains of
+    # additions and whole rows (the default)
+    for wide, fsplit, chunks in ((3, 3, 2), (3, 3, 3), (3, 1, 1), (2, 2, 3), (2, 4, 2), (1, 3, 2), (4, 3, 2), (4, 3, 3), (0, 3, 2), (0, 3, 3)):
         emul.sbve_set_group_wide(wide, fsplit)
         for k in range(len(tab)):
             tab[k] = 0xA5A5A5A5

@@ -4,6 +4,7 @@
 #   2. warm small batches with and without the coop launch (fresh processes: the knob is read when the context is created)
 #   3. the split of the 33 windows over the Q launches: a short first chunk (SBV_GROUP_CHUNK0: its tables are ready when the
 #      3-wave G phase ends — timeline_r03u.txt shows the first Q launch waiting 0.3 ms for an even one), 1 and 3 chunks
+#      and the symmetric fill (SBV_GROUP_WIDE=4: babies 1..8 only, both sides of every giant from one inverse)
 #   4. the projection leg with SBV_PART_NOSYNC=1
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -21,7 +22,7 @@ for l in open(sys.argv[1]):
     if l.startswith("#"): print(l.strip()); continue
     d = json.loads(l); print(d["log2_tuples"], "cold", d["cold"]["ms"], "warm", d["warm"]["ms"], d["cold"]["ok"], d["warm"]["ok"])
 PY
-( timeout 300 python tools/ab_env.py 18,19,20 default SBV_GROUP_CHUNK0=6 SBV_GROUP_CHUNK0=8 SBV_GROUP_CHUNK0=10 SBV_GROUP_CHUNK0=12 SBV_GROUP_CHUNKS=1 SBV_GROUP_CHUNKS=3 SBV_GPHASE_SPLIT_MIN=0 SBV_GPHASE_SPLIT_MIN=0,SBV_GROUP_CHUNK0=10 > "$OUT/ab_chunks.jsonl" 2> "$OUT/ab_chunks.err" ); cat "$OUT/ab_chunks.jsonl"
+( timeout 300 python tools/ab_env.py 18,19,20 default SBV_GROUP_CHUNK0=6 SBV_GROUP_CHUNK0=8 SBV_GROUP_CHUNK0=10 SBV_GROUP_CHUNK0=12 SBV_GROUP_WIDE=4 SBV_GROUP_WIDE=4,SBV_GROUP_CHUNK0=10 SBV_GROUP_CHUNKS=1 SBV_GROUP_CHUNKS=3 SBV_GPHASE_SPLIT_MIN=0 SBV_GPHASE_SPLIT_MIN=0,SBV_GROUP_CHUNK0=10 > "$OUT/ab_chunks.jsonl" 2> "$OUT/ab_chunks.err" ); cat "$OUT/ab_chunks.jsonl"
 for ns in 0 1; do
 ( SBV_PART_NOSYNC=$ns timeout 300 python - > "$OUT/projection_nosync$ns.json" 2> "$OUT/projection_nosync$ns.err" <<'PY'
 import json, os, sys, time
