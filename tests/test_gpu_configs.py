@@ -192,6 +192,49 @@ def test_sharded_entry_world_of_one_with_rccl_and_quorum_bits(oracle):
 
 
 # ---- key-affine partition: device g verifies the tuples of "its" keys only ------------------------------
+@pytest.mark.skipif(os.environ.get("SBV_TEST_STRESS") != "1", reason="first run belongs to the next round's GPU session (tools/gpu_r04a.sh): SBV_TEST_STRESS=1")
+def test_two_threads_in_the_sharded_entry_keep_their_own_bitmaps(oracle):
+    """the all-gather phase of a sharded call used to run without the device's lock, so a second caller
+    could overwrite (or free) the gather buffer in between.  One multi-shard call at a time now owns the gather buffers
+    (g_sharded_mu).  Two threads, different batches, SBV_RCCL=1 (world of one: every call takes the collective path), many
+    rounds: every call must return ITS batch's bitmap and quorum bits."""
+    import threading
+    os.environ["SBV_RCCL"] = "1"
+    os.environ["SBV_SHARD_MIN"] = str(1 << 14)
+    try:
+        sbv.shutdown()
+        assert sbv.init_all() >= 1
+        Q = 11
+        jobs = []
+        for seed, P in ((0xD1, 3000), (0xD2, 4500)):
+            n = P * Q
+            tup, exp = _gen(oracle, seed, n, 16, 8)
+            jobs.append((tup, exp, n, P))
+        errors = []
+
+        def worker(k):
+            tup, exp, n, P = jobs[k]
+            for _ in range(12):
+                got = ctypes.create_string_buffer((n + 7) // 8)
+                qb = ctypes.create_string_buffer((P + 7) // 8)
+                sbv.verify_batch_sharded(ctypes.addressof(tup), n, ctypes.addressof(got), group=Q, quorum=Q - 1, quorum_out_ptr=ctypes.addressof(qb))
+                if got.raw != exp:
+                    errors.append((k, _diff(got.raw, exp)))
+                    return
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in th), "a sharded call did not return"
+        assert not errors, errors[:2]
+    finally:
+        os.environ.pop("SBV_RCCL", None)
+        os.environ.pop("SBV_SHARD_MIN", None)
+        sbv.shutdown()
+
+
 def test_sharded_entry_uploads_in_pieces_beside_the_kernels(oracle):
     """verify_shard's two upload slots: with SBV_SHARD_PIECE = 16384 a 330 000-tuple call runs as 30 pieces of 11 264 tuples
     (the granule of group = 11 is 5 632) alternating between the two slots, the copy of piece i + 1 on the copy stream while

@@ -12,6 +12,7 @@ OUT=$ROOT/gpurun_out/r04a
 mkdir -p "$OUT"; cd "$ROOT"; export TMPDIR=/tmp
 ( SBV_TEST_COOP=1 timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -k coop_form > "$OUT/pytest_coop.log" 2>&1; echo "rc=$?" >> "$OUT/pytest_coop.log" ); tail -3 "$OUT/pytest_coop.log"
 ( SBV_PART_NOSYNC=1 timeout 400 python -m pytest tests/test_gpu_configs.py -m gpu -q -k "key_affine or by_key" > "$OUT/pytest_part_nosync.log" 2>&1; echo "rc=$?" >> "$OUT/pytest_part_nosync.log" ); tail -3 "$OUT/pytest_part_nosync.log"
+( SBV_TEST_STRESS=1 timeout 400 python -m pytest tests/test_gpu_configs.py -m gpu -q -k two_threads > "$OUT/pytest_stress.log" 2>&1; echo "rc=$?" >> "$OUT/pytest_stress.log" ); tail -3 "$OUT/pytest_stress.log"
 for rep in 1 2; do for v in 0 32768; do
   echo "# SBV_GROUP_COOP_MAX=$v rep $rep" >> "$OUT/coop.jsonl"
   SBV_GROUP_COOP_MAX=$v timeout 100 python tools/sweep_sizes.py 10 12 13 14 15 >> "$OUT/coop.jsonl" 2>> "$OUT/coop.err"
