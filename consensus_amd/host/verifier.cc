@@ -767,6 +767,7 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
     parallel_chunks(n, [&](size_t lo, size_t hi) {
         const Proposal* last = nullptr;
         bytes last_digest;
+        bool any_unkeyed = false;           // one store per chunk (VerifyProposal says why)
         for (size_t i = lo; i < hi; ++i) {
             if (props[i] != last) { last = props[i]; last_digest = proposal_digest_raw(*last); }
             const bytes& m = sigs[i].msg;
@@ -776,8 +777,9 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
             if (it == keys.end() || !bound) { pre[i] = 0; continue; }
             const auto ks = key_slots.find(sigs[i].id);
             const long slot = ks == key_slots.end() ? -1 : ks->second;
-            if (slot < 0) unkeyed.store(1); else slots[i] = (uint32_t)slot;
+            if (slot < 0) any_unkeyed = true; else slots[i] = (uint32_t)slot;
         }
+        if (any_unkeyed) unkeyed.store(1);
     });
     if (trace) t_pass1 = now();
     int rc = -2;
