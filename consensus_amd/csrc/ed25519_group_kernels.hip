@@ -148,11 +148,12 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
         hipLaunchKernelGGL(k_ed_keytab_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jbases, eb.kvalid,
                            j_first, j_end - 1);
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
-        SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_bases[c], 0));
+        hipStream_t tb = y.tstreams > 1 && y.side_t && (c & 1) ? y.side_t : y.side_b;     // side_t is set only on request (sbv_api.hip: SBV_ED_TSTREAMS)
+        SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[c], 0));
         const size_t wl = (size_t)b.max_groups * j_count * parts;
-        hipLaunchKernelGGL(k_ed_keytab_window, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, y.side_b, g, b.jbases, b.tmp, eb.ktab,
+        hipLaunchKernelGGL(k_ed_keytab_window, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.jbases, b.tmp, eb.ktab,
                            j_first, j_count, parts);
-        SBV_TRY(hipEventRecord(y.ev_tables[c], y.side_b));
+        SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         hipLaunchKernelGGL(k_ed_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.gacc, b.gacc_cap,
                            eb.okb, b.acc, j_first, j_end, c + 1 == chunks ? 1 : 0);

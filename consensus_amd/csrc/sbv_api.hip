@@ -299,7 +299,12 @@ int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bi
         const int rc = ensure_ed_group_buffers(c, n);
         if (rc != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
-        HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify_grouped(d_tuples, n, c.grp, c.edgrp, c.d_qtab, c.d_btab, d_bitmap, stream, c.gsync));
+        // SBV_ED_TSTREAMS=1 (not yet measured): the windows of the odd chunks on the context's idle stream, as the P-256 step
+        // does with its rows + fill (enqueue() says why it is not a stream of its own)
+        sbv::GroupSync y = c.gsync;
+        const char* et = getenv("SBV_ED_TSTREAMS");
+        if (et && et[0] == '1' && stream != c.stream) { y.tstreams = 2; y.side_t = c.stream; } else y.tstreams = 1;
+        HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify_grouped(d_tuples, n, c.grp, c.edgrp, c.d_qtab, c.d_btab, d_bitmap, stream, y));
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify(d_tuples, n, c.d_qtab, c.d_btab, d_bitmap, stream));

@@ -49,3 +49,17 @@ import json
 d=json.load(open('$OUT/projection_nosync$ns.json'))
 print('nosync=$ns', {g: {k: round(x['projected_speedup'], 2) for k, x in v.items()} for g, v in d['partitions'].items()})"
 done
+# 5. Ed25519 grouped step with the second table stream
+for rep in 1 2; do for v in 0 1; do
+  SBV_ED_TSTREAMS=$v timeout 200 python - >> "$OUT/ed_tstreams.jsonl" 2>> "$OUT/ed_tstreams.err" <<'PY'
+import json, os, sys
+root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tools"))
+import torch
+import bench
+import consensus_amd as sbv
+sbv.init(0)
+r = bench.leg_ed25519(sbv, torch, 1 << 20, 8, torch.cuda.current_stream())
+print(json.dumps({"SBV_ED_TSTREAMS": os.environ.get("SBV_ED_TSTREAMS"), "ms": r.get("ms_per_step"), "ok": r.get("bitmap_correct")}))
+PY
+done; done; cat "$OUT/ed_tstreams.jsonl"
