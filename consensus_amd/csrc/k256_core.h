@@ -175,6 +175,66 @@ SBV_HD void k256_prep_lane(WordPtr w, size_t i, const Scratch& sc_) {
     }
 }
 
+// Stage A of T tuples in one lane with ONE inversion (Montgomery's trick, as the P-256 slab kernel does): tuples
+// first + k * step, k = 0..T-1.  Same results in the same places as k256_prep_lane.  Between the two passes the exclusive
+// prefix product, s and e of a tuple are parked where its u1, its record's OK slot / the sm plane and its u2 will be.
+// words(idx) = the tuple's 40 dwords.  Four multiplications mod n and 1 / T of a division chain per signature instead of
+// two and a whole one.  (SBV_K256_PREP_T, off by default: not yet measured on a GPU.)
+template <typename WordsFn>
+SBV_HD void k256_prep_chunk(WordsFn words, size_t n, const Scratch& sc_, size_t first, size_t step, int T) {
+    const u256 n_ = k256_n_words(), p_ = k256_p_words();
+    u256 acc = {{1, 0, 0, 0, 0, 0, 0, 0}};
+    for (int k = 0; k < T; ++k) {
+        const size_t idx = first + (size_t)k * step;
+        if (idx >= n) continue;
+        auto w = words(idx);
+        u256 r, s, e, qx, qy;
+        tuple_field(r, w, 0);
+        tuple_field(s, w, 1);
+        tuple_field(e, w, 2);
+        tuple_field(qx, w, 3);
+        tuple_field(qy, w, 4);
+        const bool ok = !is_zero256(r) && lt256(r, n_) && !is_zero256(s) && lt256(s, n_) && lt256(qx, p_) && lt256(qy, p_);
+        ksc_cond_sub_n(e, e);                   // hashToNat: e < 2^256 < 2 n
+        u256 one = {{1, 0, 0, 0, 0, 0, 0, 0}}, sv;
+        select256(sv, ok, s, one);              // keep the product chain invertible
+        soa_store(sc_.u1, sc_.cap, idx, acc);   // exclusive prefix product
+        soa_store(sc_.sm, sc_.cap, idx, sv);
+        soa_store(sc_.u2, sc_.cap, idx, e);
+        soa_store(sc_.r, sc_.cap, idx, r);
+        soa_store(sc_.qx, sc_.cap, idx, qx);
+        soa_store(sc_.qy, sc_.cap, idx, qy);
+        sc_.ok[idx] = ok ? 1 : 0;
+        u256 t;
+        ksc_mul(t, acc, sv);
+        acc = t;
+    }
+    u256 inv;
+    ksc_inv(inv, acc);
+    for (int k = T - 1; k >= 0; --k) {
+        const size_t idx = first + (size_t)k * step;
+        if (idx >= n) continue;
+        u256 pre, sv, e, r, wv, u1, u2, t;
+        soa_load(pre, sc_.u1, sc_.cap, idx);
+        soa_load(sv, sc_.sm, sc_.cap, idx);
+        soa_load(e, sc_.u2, sc_.cap, idx);
+        soa_load(r, sc_.r, sc_.cap, idx);
+        ksc_mul(wv, inv, pre);                  // s_k^-1
+        ksc_mul(t, inv, sv);                    // drop s_k from the running inverse
+        inv = t;
+        ksc_mul(u1, e, wv);
+        ksc_mul(u2, r, wv);
+        soa_store(sc_.u1, sc_.cap, idx, u1);
+        soa_store(sc_.u2, sc_.cap, idx, u2);
+        if (sc_.rec) {
+            rec_store256(sc_.rec, idx, SBV_REC_U1, u1.v);
+            rec_store256(sc_.rec, idx, SBV_REC_U2, u2.v);
+            rec_store256(sc_.rec, idx, SBV_REC_R, r.v);
+            sc_.rec[idx * SBV_REC_WORDS + SBV_REC_OK] = sc_.ok[idx];
+        }
+    }
+}
+
 // ---- stage B -----------------------------------------------------------------------------------------------------------
 // qtab: this lane's strip of SBV_K256_QTAB_WORDS dwords (16-byte aligned): 8 affine entries, then 7 raw chain records
 #define SBV_K256_QTAB_WORDS (8 * 16 + 7 * 36 + 4)

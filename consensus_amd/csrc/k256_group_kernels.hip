@@ -28,6 +28,13 @@ __global__ __launch_bounds__(64) void k_k256_prep_rec(const uint8_t* __restrict_
     if (i >= n) return;
     k256_prep_lane(KGlobalTupleG{reinterpret_cast<const u32*>(tuples + i * 160)}, i, s);
 }
+// T tuples per lane, one inversion per lane (k256_core.h: k256_prep_chunk); workgroup b covers tuples [b * 64 T, (b + 1) * 64 T),
+// lane l of it tuples b * 64 T + l + 64 k: the lanes of a wavefront read 64 consecutive tuples in every pass
+__global__ __launch_bounds__(64) void k_k256_prep_chunk(const uint8_t* __restrict__ tuples, size_t n, Scratch s, int T) {
+    const size_t first = (size_t)blockIdx.x * 64 * (size_t)T + threadIdx.x;
+    auto words = [&](size_t idx) { return KGlobalTupleG{reinterpret_cast<const u32*>(tuples + idx * 160)}; };
+    k256_prep_chunk(words, n, s, first, (size_t)64, T);
+}
 __global__ __launch_bounds__(256) void k_k256_group_insert(const uint8_t* __restrict__ tuples, size_t n, GroupState g) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) group_insert_lane(tuples, i, g);
@@ -154,7 +161,12 @@ hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     hipLaunchKernelGGL(k_k256_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
     hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g, KeyCache{});
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
-    hipLaunchKernelGGL(k_k256_prep_rec, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_tuples, n, s);
+    if (y.k256_prep_t > 1) {
+        const size_t per_block = (size_t)64 * y.k256_prep_t;
+        hipLaunchKernelGGL(k_k256_prep_chunk, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(64), 0, stream, d_tuples, n, s, y.k256_prep_t);
+    } else {
+        hipLaunchKernelGGL(k_k256_prep_rec, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_tuples, n, s);
+    }
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
     hipLaunchKernelGGL(k_group_classify, dim3(gn), dim3(256), 0, y.side_b, n, g, b.ung_cand, b.counters + 4);
     hipLaunchKernelGGL(k_k256_keycheck, dim3(gn), dim3(256), 0, y.side_b, d_tuples, g, b.acc);

@@ -79,6 +79,7 @@ struct GroupSync {
     int chunk0 = 0;                 // P-256, two chunks: windows in the FIRST one (SBV_GROUP_CHUNK0; 0 = 16, the even split).  Not yet measured: with the G phase as its own 3-wave kernel the first Q launch waits ~0.3 ms for the tables of an even first chunk (profiles/r03/timeline_r03u.txt)
     int tsub = 1;                   // P-256: table-building pieces per Q-phase chunk (SBV_GROUP_TSUB; measured: 1 is best, every extra launch + cross-stream wait costs more than the overlap buys — profiles/r03/ab_tsub_parts_chunks_prio_r03c.jsonl)
     int sorted = 1;                 // P-256: key-sorted grouped list + XCD-aware Q phase (SBV_GROUP_SORT=0: the split's compaction order)
+    int k256_prep_t = 1;            // secp256k1 grouped step: tuples per inversion in stage A (SBV_K256_PREP_T, 1..8; 1 = one lane and one inversion per tuple).  Not yet measured
     size_t coop_max = 0;            // P-256: batches up to this size finish in ONE launch of 8 lanes per grouped tuple (k_group_coop; SBV_GROUP_COOP_MAX).  0 = off: built and emulated in round 3, not yet measured on a GPU
     size_t gsplit_min = (size_t)1 << 19;   // P-256: batches from this size run the G phase as its own 3-waves-per-SIMD kernel (SBV_GPHASE_SPLIT_MIN; 0 = never)
     int wide = 0;                   // P-256, SBV_GROUP_WIDE: bit 0 = one lane per table entry in the rows step (k_keytab29_entries), bit 1 = fill rows split over fsplit lanes (k_keytab29_fill_parts); default 0 = two chains of additions per window + whole rows per lane (measured: profiles/r03/ab_wide_fresh_process_r03l.jsonl, ab_wide_bits_r03r.jsonl)

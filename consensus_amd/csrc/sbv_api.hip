@@ -483,13 +483,14 @@ int init_context(Context& c, int device) {
     {   // every knob back to its default: a context initialised again re-reads the environment
         const sbv::GroupSync d;
         c.gsync.tsub = d.tsub; c.gsync.parts = d.parts; c.gsync.wide = d.wide; c.gsync.fsplit = d.fsplit; c.gsync.slices = d.slices;
-        c.gsync.sorted = d.sorted; c.gsync.tstreams = d.tstreams; c.gsync.gsplit_min = d.gsplit_min; c.gsync.coop_max = d.coop_max; c.gsync.chunk0 = d.chunk0;
+        c.gsync.sorted = d.sorted; c.gsync.tstreams = d.tstreams; c.gsync.gsplit_min = d.gsplit_min; c.gsync.coop_max = d.coop_max; c.gsync.chunk0 = d.chunk0; c.gsync.k256_prep_t = d.k256_prep_t;
     }
     c.gsync.chunks = 2;
     if (const char* e = getenv("SBV_GROUP_CHUNKS")) {
         const int v = atoi(e);
         if (v >= 1 && v <= SBV_GROUP_MAX_CHUNKS) c.gsync.chunks = v;
     }
+    if (const char* e = getenv("SBV_K256_PREP_T")) { const int v = atoi(e); if (v >= 1 && v <= 8) c.gsync.k256_prep_t = v; }
     if (const char* e = getenv("SBV_GROUP_CHUNK0")) { const int v = atoi(e); if (v >= 1 && v <= 32) c.gsync.chunk0 = v; }
     if (const char* e = getenv("SBV_GROUP_TSUB")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.tsub = v; }
     if (const char* e = getenv("SBV_GROUP_PARTS")) c.gsync.parts = atoi(e);

@@ -719,6 +719,8 @@ int sbve_modinv30_both(const u32* x8, int which, u32* out_var, u32* out_ct) {
 // secp256k1 grouped step (k256_group.h, k256_group_kernels.hip) emulated sequentially: stage A with records, grouping, key check
 // of the ungrouped candidates, counting sort, G phase over the sorted list, the per-batch combs (quad chain in lockstep, rows,
 // fill) and the Q phase in `chunks` pieces, the one-lane kernel over the ungrouped list.  stats_out as for the P-256 form.
+static int g_k256_prep_T = 1;
+void sbve_set_k256_prep_t(int t) { g_k256_prep_T = t >= 1 && t <= 8 ? t : 1; }   // GroupSync::k256_prep_t
 void sbve_k256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bitmap, u32 min_count, u32 max_groups, u32 ht_bits, int chunks,
                                     u32* stats_out) {
     size_t cap = (n + 63) & ~(size_t)63;
@@ -730,7 +732,14 @@ void sbve_k256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     while ((uintptr_t)rec_al & 15) ++rec_al;
     s.rec = rec_al;
     HostWords hw{tuples, 160};
-    for (size_t i = 0; i < n; ++i) k256_prep_lane(hw(0, i), i, s);
+    if (g_k256_prep_T > 1) {                    // k_k256_prep_chunk: workgroups of 64 lanes, T tuples per lane, one inversion per lane
+        const size_t per_block = (size_t)64 * g_k256_prep_T;
+        auto words = [&](size_t idx) { return hw(0, idx); };
+        for (size_t b = 0; b * per_block < n; ++b)
+            for (int t = 0; t < 64; ++t) k256_prep_chunk(words, n, s, b * per_block + t, (size_t)64, g_k256_prep_T);
+    } else {
+        for (size_t i = 0; i < n; ++i) k256_prep_lane(hw(0, i), i, s);
+    }
     const u32 G = max_groups ? max_groups : 1;
     std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(G), counters(SBV_GROUP_COUNTERS, 0), ung_cand(cap),
         grp_idx(cap, 0xFFFFFFFFu), ung_idx(cap), slots(cap), gcount(2 * (size_t)G, 0), grp_of(cap, 0xFFFFFFFFu);

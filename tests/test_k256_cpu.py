@@ -264,6 +264,18 @@ def test_emulated_grouped_step_equals_the_oracle_and_the_one_lane_path(emul, kor
     bm = ctypes.create_string_buffer((total + 7) // 8)
     emul.sbve_k256_verify_batch_grouped(allt, total, bm, 1000, 512, 12, 2, stats)
     assert bits(bm.raw, total) == want and stats[0] == 0
+    # stage A with T tuples per inversion (k256_prep_chunk, GroupSync::k256_prep_t): golden vectors with r, s out of range sit
+    # in the same product chains as valid ones; a ragged last workgroup (total is no multiple of 64 T)
+    try:
+        for T in (2, 4, 8):
+            emul.sbve_set_k256_prep_t(T)
+            bm = ctypes.create_string_buffer((total + 7) // 8)
+            emul.sbve_k256_verify_batch_grouped(allt, total, bm, 2, 512, 12, 2, stats)
+            got = bits(bm.raw, total)
+            bad = [i for i in range(total) if got[i] != want[i]]
+            assert not bad, (T, bad[:10])
+    finally:
+        emul.sbve_set_k256_prep_t(1)
 
 
 def test_wide_comb_of_G_walk_matches_the_python_twin(emul):

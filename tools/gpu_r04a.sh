@@ -63,3 +63,17 @@ r = bench.leg_ed25519(sbv, torch, 1 << 20, 8, torch.cuda.current_stream())
 print(json.dumps({"SBV_ED_TSTREAMS": os.environ.get("SBV_ED_TSTREAMS"), "ms": r.get("ms_per_step"), "ok": r.get("bitmap_correct")}))
 PY
 done; done; cat "$OUT/ed_tstreams.jsonl"
+# 6. secp256k1 grouped step: tuples per inversion in stage A
+for v in 1 4 8 1 4 8; do
+  SBV_K256_PREP_T=$v timeout 200 python - >> "$OUT/k256_prep_t.jsonl" 2>> "$OUT/k256_prep_t.err" <<'PY'
+import json, os, sys
+root = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tools"))
+import torch
+import bench
+import consensus_amd as sbv
+sbv.init(0)
+r = bench.leg_secp256k1(sbv, torch, 1 << 20, 8, torch.cuda.current_stream())
+print(json.dumps({"SBV_K256_PREP_T": os.environ.get("SBV_K256_PREP_T"), "ms": r.get("ms_per_step"), "ok": r.get("bitmap_correct")}))
+PY
+done; cat "$OUT/k256_prep_t.jsonl"
