@@ -174,9 +174,12 @@ func (b *gpuBackend) verifyP256(items []Item) ([]bool, error) {
 	for i := range items {
 		t := buf[i*tupleBytes : (i+1)*tupleBytes]
 		fillRSH(t, &items[i])
-		if items[i].Pub != nil {
-			k := keyBytes(items[i].Pub)
-			copy(t[96:160], k[:])
+		// Only the VALIDATED raw key (RegisterKey / p256Raw refuse nil or > 256-bit coordinates and leave Key empty) ever
+		// reaches the tuple: big.Int.FillBytes panics on an oversized coordinate, and this runs on the device goroutine.
+		// Without one the key field stays zero: (0, 0) is not on the curve, so the kernel rejects the signature, which is
+		// what crypto/ecdsa does with such a key.
+		if len(items[i].Key) == 64 {
+			copy(t[96:160], items[i].Key)
 		}
 	}
 	// all GPUs of the node; a batch that is not worth splitting goes whole to one device, round-robin

@@ -30,7 +30,7 @@
 //   - a verified-signature cache with an injective key (commit signatures of sequence s come back as
 //     prev_commit_signatures at s+1: internal/bft/view.go:376, 630);
 //   - Proposal.Digest() computed once per proposal, also for concurrent first callers;
-//   - Signer.SignBatch: the batch form of api.Signer.Sign over sbv_p256_sign_batch (load generators, replay tools).
+//   - LoadgenSigner.SignBatch (build tag sbv_loadgen only — the device signer is not constant-time): the batch form of api.Signer.Sign over sbv_p256_sign_batch (load generators, replay tools).
 //
 // A device fault is never reported as an invalid signature: VerifyProposal returning an error deposes the leader
 // (internal/bft/view.go:387-392), so on any backend error the batch is re-verified with crypto/ecdsa.

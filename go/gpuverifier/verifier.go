@@ -36,16 +36,26 @@ type Options struct {
 // DefaultOptions are sized for a node with a GPU backend.
 var DefaultOptions = Options{GPUMin: 32, CoalesceWait: 50 * time.Microsecond, CoalesceMax: 4096, CacheVerified: true, DeviceClientKeys: true}
 
+// verdict of one coalesced job: a batch nobody could judge (device fault with no CPU verifier for the scheme) is its own
+// state — it must reach the caller as an error and must never be cached as "invalid".
+type verdict uint8
+
+const (
+	verdictInvalid verdict = iota
+	verdictValid
+	verdictUnknown
+)
+
 type job struct {
 	item Item
-	done chan bool
+	done chan verdict
 }
 
 // Verifier implements api.Verifier and api.RequestInspector.
 type Verifier struct {
 	opt     Options
 	backend Backend
-	cpu     cpuBackend
+	cpu     Backend // the standard library (cpuBackend); an interface so that tests can take it away
 	jobs    chan *job
 	stop    chan struct{}
 	wg      sync.WaitGroup
@@ -83,7 +93,7 @@ func New(backend Backend, opt Options) *Verifier {
 	if opt.CoalesceMax <= 0 {
 		opt.CoalesceMax = 4096
 	}
-	v := &Verifier{opt: opt, backend: backend, jobs: make(chan *job, 4096), stop: make(chan struct{}),
+	v := &Verifier{opt: opt, backend: backend, cpu: cpuBackend{}, jobs: make(chan *job, 4096), stop: make(chan struct{}),
 		consenters: map[uint64]regKey{}, clients: map[string]regKey{}, cache: map[[32]byte]bool{}}
 	v.wg.Add(1)
 	go v.dispatch()
@@ -243,7 +253,14 @@ func (v *Verifier) dispatch() {
 		}
 		ok := v.verifyBatch(items)
 		for i, j := range batch {
-			j.done <- ok != nil && ok[i]
+			switch {
+			case ok == nil:
+				j.done <- verdictUnknown // nobody could judge: never a verdict, never cached (verifyOne)
+			case ok[i]:
+				j.done <- verdictValid
+			default:
+				j.done <- verdictInvalid
+			}
 		}
 	}
 }
@@ -288,9 +305,14 @@ func (v *Verifier) verifyOne(k regKey, msg, sig []byte) bool {
 		}
 		ok = verdict[0]
 	} else {
-		j := &job{item: k.item(msg, sig), done: make(chan bool, 1)}
+		j := &job{item: k.item(msg, sig), done: make(chan verdict, 1)}
 		v.jobs <- j
-		ok = <-j.done
+		switch <-j.done {
+		case verdictUnknown:
+			return false // as on the direct path: a device fault is an error for the caller and must not be remembered as "invalid"
+		case verdictValid:
+			ok = true
+		}
 	}
 	if v.opt.CacheVerified {
 		v.cacheMu.Lock()

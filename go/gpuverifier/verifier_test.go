@@ -194,6 +194,7 @@ type recordingBackend struct {
 	generic  int
 	sizes    []int
 	failNext bool
+	failAll  bool
 }
 
 func (b *recordingBackend) RegisterKey(pub *ecdsa.PublicKey) int32 {
@@ -211,7 +212,7 @@ func (b *recordingBackend) RegisterKey(pub *ecdsa.PublicKey) int32 {
 func (b *recordingBackend) Verify(scheme Scheme, items []Item) ([]bool, error) {
 	b.mu.Lock()
 	defer b.mu.Unlock()
-	if b.failNext {
+	if b.failNext || b.failAll {
 		b.failNext = false
 		return nil, errors.New("device fault")
 	}
@@ -483,12 +484,27 @@ func TestSecp256k1WithoutDeviceCannotJudge(t *testing.T) {
 	assert.Error(t, v.VerifySignature(bft.Signature{ID: 1, Value: []byte{0x30, 0x06, 2, 1, 1, 2, 1, 1}, Msg: []byte("m")}))
 }
 
-func TestSignBatchFallsBackToSign(t *testing.T) {
-	h, be := newKeyedHarness(t, 4, DefaultOptions)
+// A batch nobody could judge (here: every Verify fails, and the CPU side has no verifier for the scheme) must reach the
+// caller as an error WITHOUT being cached: the same signature verifies once the device is back.
+func TestCoalescedDeviceFaultIsNotCachedAsInvalid(t *testing.T) {
+	opt := DefaultOptions
+	opt.GPUMin = 1 // every single call goes through the dispatcher
+	opt.CacheVerified = true
+	h, be := newKeyedHarness(t, 4, opt)
 	defer h.v.Close()
-	msgs := [][]byte{[]byte("a"), []byte("b"), []byte("c")}
-	sigs := h.nodes[0].SignBatch(be, msgs)
-	for i, m := range msgs {
-		assert.NoError(t, h.v.VerifySignature(bft.Signature{ID: 1, Value: sigs[i], Msg: m}))
-	}
+	h.v.cpu = failingBackend{}
+	msg := []byte("view data")
+	sig := h.nodes[1].Sign(msg)
+	be.mu.Lock()
+	be.failAll = true
+	be.mu.Unlock()
+	assert.Error(t, h.v.VerifySignature(bft.Signature{ID: 2, Value: sig, Msg: msg}))
+	be.mu.Lock()
+	be.failAll = false
+	be.mu.Unlock()
+	assert.NoError(t, h.v.VerifySignature(bft.Signature{ID: 2, Value: sig, Msg: msg}))
 }
+
+type failingBackend struct{ cpuBackend } // RegisterKey, SignBatch, Close from the embedded value
+
+func (failingBackend) Verify(Scheme, []Item) ([]bool, error) { return nil, errors.New("no verifier") }

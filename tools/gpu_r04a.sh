@@ -77,3 +77,8 @@ r = bench.leg_secp256k1(sbv, torch, 1 << 20, 8, torch.cuda.current_stream())
 print(json.dumps({"SBV_K256_PREP_T": os.environ.get("SBV_K256_PREP_T"), "ms": r.get("ms_per_step"), "ok": r.get("bitmap_correct")}))
 PY
 done; cat "$OUT/k256_prep_t.jsonl"
+# 7. the one comb width of G that fits the 256 MiB Infinity Cache and was never run: 19 bits (14 additions, 218 MB) against 20
+for rep in 1 2; do for v in 20 19; do
+  echo "# SBV_G_BITS=$v rep $rep" >> "$OUT/gbits.jsonl"
+  SBV_G_BITS=$v timeout 200 python tools/ab_env.py 18,20 default >> "$OUT/gbits.jsonl" 2>> "$OUT/gbits.err"
+done; done; cat "$OUT/gbits.jsonl"
