@@ -349,6 +349,17 @@ def shard_plan(n: int, devices: int, group: int = 0, min_per_device: int = 0):
     return [first[i] for i in range(k + 1)]
 
 
+def shard_min_for(tuples, n: int, group: int = 0) -> int:
+    """sbv_shard_min_for: the per-device minimum the sharded entry plans this host batch with (few signers -> 2^16, else 2^17)."""
+    lib = load()
+    lib.sbv_shard_min_for.restype = ctypes.c_size_t
+    lib.sbv_shard_min_for.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]
+    if isinstance(tuples, int):
+        return lib.sbv_shard_min_for(tuples, n, group)
+    buf = (ctypes.c_char * len(tuples)).from_buffer_copy(tuples) if not isinstance(tuples, ctypes.Array) else tuples
+    return lib.sbv_shard_min_for(ctypes.addressof(buf), n, group)
+
+
 def verify_batch_sharded(host_ptr: int, n: int, out_ptr: int, group: int = 0, quorum: int = 0, quorum_out_ptr: int = 0) -> ShardInfo:
     """sbv_p256_verify_batch_sharded on raw pointers (numpy / ctypes buffers)."""
     lib = load()

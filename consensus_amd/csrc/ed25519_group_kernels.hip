@@ -113,8 +113,7 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     g.sorted = y.sorted && b.gcount && b.grp_of && sort_lds <= 64 * 1024 ? 1u : 0u;
     group_set_threshold(g, b.min_count);
     const int chunks = y.chunks < 1 ? 1 : (y.chunks > SBV_GROUP_MAX_CHUNKS ? SBV_GROUP_MAX_CHUNKS : y.chunks);
-    int parts = SBV_KEYTAB_PARTS_DEFAULT;
-    if (y.parts == 2 || y.parts == 4 || y.parts == 8 || y.parts == 16) parts = y.parts;
+    const int parts = SBV_KEYTAB_PARTS_DEFAULT;     // lanes per (key, window) of the table kernel (2 / 4 / 8 / 16 measured in round 2)
     hipError_t e;
 #define SBV_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
     // ev_fork was recorded by the caller on `stream` before anything of this batch (see the P-256 launcher)
@@ -148,7 +147,7 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
         hipLaunchKernelGGL(k_ed_keytab_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jbases, eb.kvalid,
                            j_first, j_end - 1);
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
-        hipStream_t tb = y.tstreams > 1 && y.side_t && (c & 1) ? y.side_t : y.side_b;     // side_t is set only on request (sbv_api.hip: SBV_ED_TSTREAMS)
+        hipStream_t tb = y.side_b;      // one table stream: the windows of the odd chunks on a second stream measured slower (round 4: 4.55 -> 4.67 ms)
         SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[c], 0));
         const size_t wl = (size_t)b.max_groups * j_count * parts;
         hipLaunchKernelGGL(k_ed_keytab_window, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.jbases, b.tmp, eb.ktab,

@@ -23,11 +23,7 @@ struct KGlobalTupleG {
     const u32* p;
     __device__ __forceinline__ u32 operator[](int i) const { return p[i]; }
 };
-__global__ __launch_bounds__(64) void k_k256_prep_rec(const uint8_t* __restrict__ tuples, size_t n, Scratch s) {
-    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    k256_prep_lane(KGlobalTupleG{reinterpret_cast<const u32*>(tuples + i * 160)}, i, s);
-}
+#define SBV_K256_PREP_T 8          // tuples per inversion in stage A of the grouped step
 // T tuples per lane, one inversion per lane (k256_core.h: k256_prep_chunk); workgroup b covers tuples [b * 64 T, (b + 1) * 64 T),
 // lane l of it tuples b * 64 T + l + 64 k: the lanes of a wavefront read 64 consecutive tuples in every pass
 __global__ __launch_bounds__(64) void k_k256_prep_chunk(const uint8_t* __restrict__ tuples, size_t n, Scratch s, int T) {
@@ -161,11 +157,10 @@ hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     hipLaunchKernelGGL(k_k256_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
     hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g, KeyCache{});
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
-    if (y.k256_prep_t > 1) {
-        const size_t per_block = (size_t)64 * y.k256_prep_t;
-        hipLaunchKernelGGL(k_k256_prep_chunk, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(64), 0, stream, d_tuples, n, s, y.k256_prep_t);
-    } else {
-        hipLaunchKernelGGL(k_k256_prep_rec, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_tuples, n, s);
+    {   // stage A: SBV_K256_PREP_T tuples per lane share one inversion (Montgomery's trick).  Measured in round 4
+        // (profiles/r04/ab_k256_prep_t_r04a.jsonl): 1 / 4 / 8 tuples per inversion 4.97 / 4.79 / 4.68 ms per 2^20 step.
+        const size_t per_block = (size_t)64 * SBV_K256_PREP_T;
+        hipLaunchKernelGGL(k_k256_prep_chunk, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(64), 0, stream, d_tuples, n, s, SBV_K256_PREP_T);
     }
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
     hipLaunchKernelGGL(k_group_classify, dim3(gn), dim3(256), 0, y.side_b, n, g, b.ung_cand, b.counters + 4);

@@ -156,13 +156,13 @@ __global__ __launch_bounds__(64) void k_keytab29_chain(const uint8_t* __restrict
     q.r = (int)(lane & 3u);
     keychain29_run(q, tuples, k, g, jstate, bases, valid + tslot[k], j_first, j_last, rec_mask);
 }
-// lanes = groups x j_count x 2
+// lanes = groups x j_count x 2: lane 0 of a window builds the babies b B_j, b = 1..8, lane 1 the giants 16 a B_j, a = 1..8
 #ifndef SBV_ROWS_WAVES
 #define SBV_ROWS_WAVES 2
 #endif
 __global__ __launch_bounds__(64, SBV_ROWS_WAVES) void k_keytab29_rows(GroupState g, const u32* __restrict__ bases, u32* __restrict__ tmp,
                                                       apt* __restrict__ ktab, const u32* __restrict__ tslot,
-                                                      const uint8_t* __restrict__ cold, int j_first, int j_count, int babies) {
+                                                      const uint8_t* __restrict__ cold, int j_first, int j_count) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;
     const u32 which = lane & 1u, kw = lane >> 1;
     const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
@@ -172,62 +172,13 @@ __global__ __launch_bounds__(64, SBV_ROWS_WAVES) void k_keytab29_rows(GroupState
     const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
     u32* t = tmp + w * SBV_KT29_WINDOW_TMP + (size_t)which * SBV_KT29_ROWS_TMP_WORDS;
     keytab29_rows_lane(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), (int)which, j == SBV_GTAB_WINDOWS - 1, t,
-                       ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW, babies);
-}
-// lanes = groups x j_count x lanes_per_window, each lane rows_per_lane of the 7 rows 16 a + b, a = 1..7
-__global__ __launch_bounds__(64) void k_keytab29_fill(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab,
-                                                      const u32* __restrict__ tslot, const uint8_t* __restrict__ cold, int j_first,
-                                                      int j_count, int rows_per_lane, int lanes_per_window) {
-    const u32 lane = blockIdx.x * 64 + threadIdx.x;
-    const u32 r = lane % (u32)lanes_per_window, kw = lane / (u32)lanes_per_window;
-    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
-    if (key >= group_count(g) || j == SBV_GTAB_WINDOWS - 1 || !cold[key]) return;
-    const int a_first = 1 + (int)r * rows_per_lane;
-    int a_last = a_first + rows_per_lane - 1;
-    if (a_last > 7) a_last = 7;
-    if (a_first > 7) return;
-    table_prio();
-    const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
-    u32* t = tmp + w * SBV_KT29_WINDOW_TMP + (size_t)r * SBV_KT29_FILL_TMP_WORDS;
-    keytab29_fill_lane(a_first, a_last, t, ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
+                       ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
 }
 
-// Wide forms (GroupSync::wide, default): one lane per entry of the fill step's inputs, and the 7 rows in `split` parts each.
-// lanes = groups x j_count x 24 (lane 23 of each window idles: 24 keeps a window inside one wavefront's 64-lane row pairs)
-__global__ __launch_bounds__(64, 3) void k_keytab29_entries(GroupState g, const u32* __restrict__ bases, apt* __restrict__ ktab,
-                                                         const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
-                                                         int j_first, int j_count) {
-    const u32 lane = blockIdx.x * 64 + threadIdx.x;
-    const u32 e = lane % 24u, kw = lane / 24u;
-    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
-    if (key >= group_count(g) || !cold[key] || e >= SBV_KT29_ENTRY_LANES) return;
-    table_prio();
-    const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
-    keytab29_entry_lane(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), (int)e, j == SBV_GTAB_WINDOWS - 1,
-                        ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
-}
-// lanes = groups x j_count x (7 x split); lane r of a window: row a = 1 + r / split, entries b of part r % split
-__global__ __launch_bounds__(64) void k_keytab29_fill_parts(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab,
-                                                            const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
-                                                            int j_first, int j_count, int split) {
-    const u32 lpw = 7u * (u32)split;
-    const u32 lane = blockIdx.x * 64 + threadIdx.x;
-    const u32 r = lane % lpw, kw = lane / lpw;
-    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
-    if (key >= group_count(g) || j == SBV_GTAB_WINDOWS - 1 || !cold[key]) return;
-    const int a = 1 + (int)(r / (u32)split), part = (int)(r % (u32)split);
-    const int per = (15 + split - 1) / split;
-    const int b_first = 1 + part * per;
-    int b_last = b_first + per - 1;
-    if (b_last > 15) b_last = 15;
-    if (b_first > 15) return;
-    table_prio();
-    const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
-    u32* t = tmp + w * SBV_KT29_WINDOW_TMP + (size_t)r * (15 * 9);
-    keytab29_fill_part_lane(a, b_first, b_last, t, ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
-}
-
-// Symmetric fill (GroupSync::wide bit 2): lanes = groups x j_count x 8, lane a - 1 of a window fills both sides of giant 16 a
+// The fill step (symmetric form, p256_keytab29.h): lanes = groups x j_count x 8, lane a - 1 of a window fills both sides of giant 16 a.
+// Measured against round 3's one-sided fill (15 denominators per lane, babies 1..16 from the rows step) in round 4
+// (profiles/r04/ab_chunk0_symfill_r04a.jsonl): cold 2^20 3.34 -> 3.22 ms, 2^19 2.23 -> 2.08, 2^18 1.77 -> 1.62; the one-sided
+// kernel and the two wide forms of round 3 (one lane per entry; rows split over lanes — both measured slower) left the library.
 __global__ __launch_bounds__(64) void k_keytab29_fill_sym(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab,
                                                           const u32* __restrict__ tslot, const uint8_t* __restrict__ cold, int j_first,
                                                           int j_count) {
@@ -274,15 +225,6 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_GPHASE_WAVES) void k_gphase_s
     if (i < g.counters[1]) gphase29_lane_sorted(s, g.grp_idx[i], i, g16r, gacc);
 }
 
-// The generic stage B alone (own stream, when the process has hardware queues to spare)
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_verify_generic_list(Scratch s, GroupState g, u32* __restrict__ qtab,
-                                                                            gcomb g16r, uint8_t* __restrict__ acc) {
-    const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
-    if (L >= g.counters[2]) return;
-    const u32 t = g.ung_idx[L];
-    acc[t] = verify29_lane_generic(s, t, qtab + (size_t)L * SBV_QTAB29_WORDS, g16r) ? 1 : 0;
-}
-
 // Q phase over the grouped list: windows [j0, j1) of the per-batch key combs
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_keyed_q(Scratch s, GroupState g, const apt* __restrict__ ktab,
                                                                     const uint8_t* __restrict__ kvalid, const u32* __restrict__ tslot,
@@ -315,7 +257,8 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
     if (last) acc[t] = v ? 1 : 0;
 }
 
-// Latency form of the key-sorted step (GroupSync::coop_max, default off until it has been measured): SBV_COOP_LANES lanes per
+// Latency form of the key-sorted step (GroupSync::coop_max: batches up to 2^15 tuples; measured in round 4,
+// profiles/r04/ab_coop_r04a.jsonl: warm 2^10 0.30 -> 0.19 ms, 2^12 0.34 -> 0.22, 2^14 0.37 -> 0.27, 2^15 0.39 -> 0.33): SBV_COOP_LANES lanes per
 // grouped tuple, every lane sums every SBV_COOP_LANES-th of the 13 + 33 comb terms of u1 * G + u2 * Q from the comb of G and
 // the key's table (p256_comb29.h: keyed29_partial_lane, the registered-key latency kernel's lane) and the partial sums meet
 // in a butterfly of exact XYZZ additions: one launch ~10 additions deep instead of the G phase and two Q launches (45 deep).
@@ -363,15 +306,19 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_group_coop(Scratch s, G
     }
 }
 
-// Enqueue stage B with in-step grouping.  Stage A (k_p256_prep) is already enqueued on `stream`.
-// Three streams (a process gets 4 hardware queues by default; with a fourth stream for the generic kernel
-// the Q phase was serialised behind it, measured).  Only the G phase and the Q phase are throughput work;
-// everything else is a low-occupancy, latency-bound chain (one lane per key / a few lanes per window /
-// the rare ungrouped tuples), so the chains run beside each other and beside the throughput kernels:
+// Enqueue stage B with in-step grouping.  Stage A (k_p256_prep) is enqueued here too, on `stream`.
+// Three streams (a process gets 4 hardware queues by default; a further stream aliases one of them and serialises the step,
+// measured twice).  Only the G phase and the Q phase are throughput work; everything else is a low-occupancy, latency-bound
+// chain (four lanes per key / a few lanes per window / the rare ungrouped tuples), so the chains run beside each other and
+// beside the throughput kernels:
 //
-//   stream: [prep] wait(split) { generic stage B over the ungrouped list + G phase } wait(tables c) Q-phase chunk c ... pack
-//   side_a: insert assign | bases chunk 0 | bases chunk 1 | ...
-//   side_b:        wait(assign) split | wait(bases c) windows chunk c ...
+//   stream: prep | wait(split) { generic stage B over the ungrouped list, G phase } wait(tables c) Q-phase chunk c ... pack
+//   side_a: insert assign cache | chain chunk 0 | chain chunk 1 | ...
+//   side_b:        wait(assign) classify keycheck sort | wait(chain c) rows + fill of chunk c   (odd chunks: side_t, if given)
+//
+// Forms that were built, measured and rejected in rounds 2-4 are no longer in the library (DESIGN.md section 7 keeps the
+// numbers): stage A + G phase in slices, table pieces finer than the Q chunks, an uneven first chunk, one lane per table entry,
+// fill rows split over lanes, an own stream for the one-lane kernel.
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_in, size_t n, const GroupBuffers& b,
                                       u32* d_qtab, const apt* d_g16, const gcomb& d_g16r, uint8_t* d_bitmap, hipStream_t stream,
                                       const GroupSync& y, hipEvent_t after_prep, hipEvent_t* prof, int* prof_pairs) {
@@ -381,17 +328,15 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     g.counters = b.counters; g.grp_idx = b.grp_idx; g.ung_idx = b.ung_idx; g.slots = b.slots;
     g.max_groups = b.max_groups;
     g.gcount = b.gcount; g.gcursor = b.gcount ? b.gcount + b.max_groups : nullptr; g.grp_of = b.grp_of; g.ung_cand = b.ung_cand;
-    // key-sorted grouped list: needs the per-tuple records of stage A, one LDS word per group, and an unsliced G phase
+    // key-sorted grouped list: needs the per-tuple records of stage A and one LDS word per group
     const size_t sort_lds = (size_t)b.max_groups * sizeof(u32);
-    g.sorted = y.sorted && s_in.rec && b.gcount && b.grp_of && b.ung_cand && sort_lds <= 64 * 1024 && !y.side_c && y.slices <= 1 ? 1u : 0u;
+    g.sorted = y.sorted && s_in.rec && b.gcount && b.grp_of && b.ung_cand && sort_lds <= 64 * 1024 ? 1u : 0u;
     // Stage A writes EITHER the per-tuple records (key-sorted step: every reader takes them) OR the limb-major planes
     Scratch s = s_in;
     if (!g.sorted) s.rec = nullptr;
     group_set_threshold(g, b.min_count);
     const int chunks = y.chunks < 1 ? 1 : (y.chunks > SBV_GROUP_MAX_CHUNKS ? SBV_GROUP_MAX_CHUNKS : y.chunks);
-    const bool coop = g.sorted && y.coop_max && n <= y.coop_max;      // k_group_coop instead of the G phase and the Q launches (sorted => unsliced)
-    int rows_per_lane = 1;                         // rows of 16 entries one lane of the fill kernel builds (1, 2, 4 or 7)
-    if (y.parts == 1 || y.parts == 2 || y.parts == 4 || y.parts == 7) rows_per_lane = y.parts;
+    const bool coop = g.sorted && y.coop_max && n <= y.coop_max;      // k_group_coop instead of the G phase and the Q launches
     hipError_t e;
 #define SBV_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
     // The side streams may not touch the group buffers before everything already enqueued on `stream` (the
@@ -408,24 +353,10 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
     hipLaunchKernelGGL(k_key_cache_lookup, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.kc, b.tslot, b.cold);
     hipLaunchKernelGGL(k_key_cache_insert, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.kc, b.tslot);
-    // Stage A and the G phase, pipelined in slices of the batch: stage A is a low-occupancy chain (one inversion per
-    // thread), and while it ran alone at the head of the step most of the GPU idled for ~0.35 ms.  Slice 0 is prepared on
-    // `stream`, the others on side_b; the G phase of slice k starts as soon as slice k is prepared.  The generic kernel
-    // over the ungrouped list may touch any tuple, so it rides in the last slice's launch.
+    // stage A
     const size_t pbt = prep_block_tuples(n);
     const unsigned pblocks = (unsigned)((n + pbt - 1) / pbt);
-    int slices = y.slices < 1 ? 1 : (y.slices > SBV_GROUP_MAX_SLICES ? SBV_GROUP_MAX_SLICES : y.slices);
-    if (y.side_c) slices = 1;
-    if ((unsigned)slices > pblocks) slices = (int)pblocks;
-    // the later slices go to side_b, which has nothing to do until the groups are assigned (a fifth stream would not get a
-    // hardware queue of its own: a process has four, and an aliased queue serialised the whole step — measured)
-    if (slices > 1) SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_fork, 0));
-    for (int k = 0; k < slices; ++k) {
-        const unsigned lo = (unsigned)((size_t)pblocks * k / slices), hi = (unsigned)((size_t)pblocks * (k + 1) / slices);
-        hipStream_t ps = k == 0 ? stream : y.side_b;
-        SBV_TRY(launch_p256_prep_blocks(d_tuples, n, s, ps, lo, hi));
-        if (k > 0) SBV_TRY(hipEventRecord(y.ev_slice[k], y.side_b));
-    }
+    SBV_TRY(launch_p256_prep_blocks(d_tuples, n, s, stream, 0, pblocks));
     // side_b: split
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
     if (!g.sorted) hipLaunchKernelGGL(k_group_split, dim3(gn), dim3(256), 0, y.side_b, d_tuples, n, g, b.acc);
@@ -439,92 +370,33 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         hipLaunchKernelGGL(k_group_sort_scatter, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
     }
     SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
-    if (y.side_c) {
-        SBV_TRY(hipEventRecord(y.ev_prep, stream));
-        SBV_TRY(hipStreamWaitEvent(y.side_c, y.ev_prep, 0));
-        SBV_TRY(hipStreamWaitEvent(y.side_c, y.ev_split, 0));
-        hipLaunchKernelGGL(k_verify_generic_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, y.side_c, s, g, d_qtab, d_g16r, b.acc);
-        SBV_TRY(hipEventRecord(y.ev_generic, y.side_c));
-        // the G phase reads counters[0] (group_count): it may not start before side_a's memset / insert / assign
-        SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
-        if (after_prep) SBV_TRY(hipEventRecord(after_prep, stream));
-        hipLaunchKernelGGL(k_gphase_generic, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, 0u,
-                           (size_t)0, n);
+    // The generic stage B over the ungrouped list (keys that repeat too rarely for a table: a 2.3 ms chain per lane, so it starts
+    // as early as possible and runs beside the throughput work) and the G phase.  group_count() is final after the assignment;
+    // the ungrouped list (and the sorted list) after the split.
+    SBV_TRY(hipStreamWaitEvent(stream, y.ev_assign, 0));
+    SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
+    if (after_prep) SBV_TRY(hipEventRecord(after_prep, stream));
+    if (coop) {                  // the ungrouped list only: the coop launch below does the G phase's job too
+        hipLaunchKernelGGL(k_gphase_generic, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, gv, (size_t)0, n);
+    } else if (g.sorted && y.gsplit_min && n >= y.gsplit_min) {
+        hipLaunchKernelGGL(k_gphase_generic, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, gv, (size_t)0, n);
+        hipLaunchKernelGGL(k_gphase_sorted, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, d_g16r, b.gacc);
     } else {
-        SBV_TRY(hipStreamWaitEvent(stream, y.ev_assign, 0));          // group_count() is final after the assignment
-        for (int k = 0; k < slices; ++k) {
-            const size_t first = (size_t)pblocks * k / slices * pbt;
-            size_t end = (size_t)pblocks * (k + 1) / slices * pbt;
-            if (end > n) end = n;
-            const bool last_slice = k + 1 == slices;
-            if (k > 0) SBV_TRY(hipStreamWaitEvent(stream, y.ev_slice[k], 0));
-            unsigned gen_blocks = 0;
-            if (last_slice) {
-                SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));  // the ungrouped list
-                if (after_prep) SBV_TRY(hipEventRecord(after_prep, stream));
-                gen_blocks = gv;
-            }
-            const unsigned gb = (unsigned)((end - first + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
-            if (coop) {          // the ungrouped list only: the coop launch below does the G phase's job too
-                hipLaunchKernelGGL(k_gphase_generic, dim3(gen_blocks), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc,
-                                   gen_blocks, first, end);
-                continue;
-            }
-            if (g.sorted && slices == 1 && y.gsplit_min && n >= y.gsplit_min) {
-                hipLaunchKernelGGL(k_gphase_generic, dim3(gen_blocks), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc,
-                                   gen_blocks, first, end);
-                hipLaunchKernelGGL(k_gphase_sorted, dim3(gb), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, d_g16r, b.gacc);
-                continue;
-            }
-            hipLaunchKernelGGL(k_gphase_generic, dim3(gen_blocks + gb), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r,
-                               b.gacc, b.acc, gen_blocks, first, end);
-        }
+        hipLaunchKernelGGL(k_gphase_generic, dim3(gv + gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, gv, (size_t)0, n);
     }
-    // Chunks of windows: the chain on side_a, rows + fill on side_b, the Q phase on stream.  The tables CAN be built in finer
-    // pieces than they are consumed in (y.tsub pieces per Q-phase chunk, SBV_GROUP_TSUB) so that rows + fill of one piece run
-    // beside the chain of the next.  Measured and rejected as a default (profiles/r03/ab_tsub_parts_chunks_prio_r03c.jsonl):
-    // 2^20 cold 3.37-3.46 ms with one piece, 3.60-3.76 with two, 3.97-4.27 with three (2^18: 1.95-2.15 / 2.2-2.4 / 2.7-3.1) —
-    // every extra launch behind a cross-stream event costs more than the overlap buys.
-    int tsub = y.tsub < 1 ? 1 : y.tsub;
-    while (chunks * tsub > SBV_GROUP_MAX_TCHUNKS) --tsub;
+    // Chunks of windows: the chain on side_a, rows + fill on side_b (odd chunks on side_t), the Q phase on stream.
     for (int c = 0; c < chunks; ++c) {
-        int q_first = SBV_GTAB_WINDOWS * c / chunks, q_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [q_first, q_end)
-        if (chunks == 2 && y.chunk0 > 0 && y.chunk0 < SBV_GTAB_WINDOWS) { q_first = c == 0 ? 0 : y.chunk0; q_end = c == 0 ? y.chunk0 : SBV_GTAB_WINDOWS; }   // uneven split: a short first chunk has its tables ready when the G phase ends
+        const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [j_first, j_end)
+        const int j_count = j_end - j_first;
         hipStream_t tb = y.tstreams > 1 && y.side_t && (c & 1) ? y.side_t : y.side_b;     // rows + fill of this chunk
-        for (int t = 0; t < tsub; ++t) {
-            const int j_first = q_first + (q_end - q_first) * t / tsub, j_end = q_first + (q_end - q_first) * (t + 1) / tsub;
-            const int j_count = j_end - j_first;
-            if (j_count <= 0) continue;
-            const int tc = c * tsub + t;
-            hipLaunchKernelGGL(k_keytab29_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases,
-                               b.kvalid, b.tslot, b.cold, j_first, j_end - 1, (y.wide & 1) ? 0xFFu : 0x11u);
-            SBV_TRY(hipEventRecord(y.ev_bases[tc], y.side_a));
-            SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[tc], 0));
-            // rows: one lane per entry (wide & 1) or two chains of additions per window; fill: rows split over `fsplit` lanes
-            // (wide & 2) or whole rows per lane.  Both wide forms measured slower (kernels.h: GroupSync::wide).
-            if (y.wide & 1) {
-                const size_t wl = (size_t)b.max_groups * j_count * 24;
-                hipLaunchKernelGGL(k_keytab29_entries, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.ktab, b.tslot, b.cold, j_first, j_count);
-            } else {
-                const size_t wl = (size_t)b.max_groups * j_count * 2;
-                hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count,
-                                   (y.wide & 4) ? 8 : 16);
-            }
-            if ((y.wide & 4) && !(y.wide & 1)) {          // symmetric fill: needs the chain-of-additions rows (babies 1..8, giants 16..128)
-                const size_t fl = (size_t)b.max_groups * j_count * 8;
-                hipLaunchKernelGGL(k_keytab29_fill_sym, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
-            } else if (y.wide & 2) {
-                const int split = y.fsplit < 1 ? 1 : (y.fsplit > 4 ? 4 : y.fsplit);
-                const size_t fl = (size_t)b.max_groups * j_count * 7 * split;
-                hipLaunchKernelGGL(k_keytab29_fill_parts, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, b.ktab, b.tslot, b.cold, j_first,
-                                   j_count, split);
-            } else {
-                const int lpw = (7 + rows_per_lane - 1) / rows_per_lane;
-                const size_t fl = (size_t)b.max_groups * j_count * lpw;
-                hipLaunchKernelGGL(k_keytab29_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count,
-                                   rows_per_lane, lpw);
-            }
-        }
+        hipLaunchKernelGGL(k_keytab29_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases,
+                           b.kvalid, b.tslot, b.cold, j_first, j_end - 1, 0x11u);
+        SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
+        SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[c], 0));
+        const size_t wl = (size_t)b.max_groups * j_count * 2;
+        hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
+        const size_t fl = (size_t)b.max_groups * j_count * 8;
+        hipLaunchKernelGGL(k_keytab29_fill_sym, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         const bool last = c + 1 == chunks;
@@ -539,10 +411,9 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         }
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
         hipLaunchKernelGGL(k_verify_keyed_q, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.kc.cap + b.max_groups, b.gacc, b.acc,
-                           q_first, q_end, last ? 1 : 0);
+                           j_first, j_end, last ? 1 : 0);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
-    if (y.side_c) SBV_TRY(hipStreamWaitEvent(stream, y.ev_generic, 0));
     hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
 #undef SBV_TRY
     if (prof && prof_pairs) *prof_pairs = coop ? 1 : chunks;

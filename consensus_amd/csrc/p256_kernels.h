@@ -63,31 +63,20 @@ struct GroupBuffers {
 // streams and events of the grouped step; owned by the context.  `chunks` (1..SBV_GROUP_MAX_CHUNKS) = how
 // many pieces the 33 key-comb windows are built and consumed in.
 #define SBV_GROUP_MAX_CHUNKS 4
-#define SBV_GROUP_MAX_TCHUNKS 8      // pieces the key tables are built in: chunks x tsub
-#define SBV_GROUP_MAX_SLICES 8
 struct GroupSync {
-    hipStream_t side_a = nullptr;   // insert, assign, window bases
-    hipStream_t side_b = nullptr;   // split, window tables
-    hipStream_t side_t = nullptr;   // P-256: not owned — rows + fill of the odd chunks when tstreams = 2 (the context's own stream while the caller's runs the step)
-    int tstreams = 2;               // SBV_GROUP_TSTREAMS (1, 2): 1 = every chunk's rows + fill queue up on side_b.  2: rows of chunk 1 start when ITS chain ends, not when fill of chunk 0 does — cold 2^18 2.04 -> 1.70 ms, 2^17 2.54 -> 2.23, 2^20 unchanged (profiles/r03/ab_sched_r03m.jsonl)
-    hipStream_t side_c = nullptr;   // optional: generic stage B over the ungrouped list (nullptr: fused into the G-phase launch)
-    hipEvent_t ev_slice[SBV_GROUP_MAX_SLICES] = {};
-    int slices = 1;                 // pieces stage A + G phase are pipelined in (1..SBV_GROUP_MAX_SLICES); slices > 0 run on side_b
-    hipEvent_t ev_fork = nullptr, ev_assign = nullptr, ev_split = nullptr, ev_prep = nullptr, ev_generic = nullptr;
-    hipEvent_t ev_bases[SBV_GROUP_MAX_TCHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
+    hipStream_t side_a = nullptr;   // insert, assign, key-cache lookup, the doubling chains
+    hipStream_t side_b = nullptr;   // split / sort, rows + fill of the even chunks
+    hipStream_t side_t = nullptr;   // P-256, secp256k1: not owned — rows + fill of the odd chunks when tstreams = 2 (the context's own stream while the caller's runs the step)
+    int tstreams = 2;               // SBV_GROUP_TSTREAMS (1, 2): 1 = every chunk's rows + fill queue up on side_b.  2: rows of chunk 1 start when ITS chain ends, not when fill of chunk 0 does — cold 2^18 2.04 -> 1.70 ms, 2^17 2.54 -> 2.23, 2^20 unchanged (profiles/r03/ab_sched_r03m.jsonl).  The Ed25519 step keeps one table stream (measured in round 4: 4.55 -> 4.67 ms with two, profiles/r04/ab_ed_tstreams_r04a.jsonl)
+    hipEvent_t ev_fork = nullptr, ev_assign = nullptr, ev_split = nullptr, ev_generic = nullptr;
+    hipEvent_t ev_bases[SBV_GROUP_MAX_CHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
     int chunks = 1;
-    int chunk0 = 0;                 // P-256, two chunks: windows in the FIRST one (SBV_GROUP_CHUNK0; 0 = 16, the even split).  Not yet measured: with the G phase as its own 3-wave kernel the first Q launch waits ~0.3 ms for the tables of an even first chunk (profiles/r03/timeline_r03u.txt)
-    int tsub = 1;                   // P-256: table-building pieces per Q-phase chunk (SBV_GROUP_TSUB; measured: 1 is best, every extra launch + cross-stream wait costs more than the overlap buys — profiles/r03/ab_tsub_parts_chunks_prio_r03c.jsonl)
-    int sorted = 1;                 // P-256: key-sorted grouped list + XCD-aware Q phase (SBV_GROUP_SORT=0: the split's compaction order)
-    int k256_prep_t = 1;            // secp256k1 grouped step: tuples per inversion in stage A (SBV_K256_PREP_T, 1..8; 1 = one lane and one inversion per tuple).  Not yet measured
-    size_t coop_max = 0;            // P-256: batches up to this size finish in ONE launch of 8 lanes per grouped tuple (k_group_coop; SBV_GROUP_COOP_MAX).  0 = off: built and emulated in round 3, not yet measured on a GPU
+    int sorted = 1;                 // key-sorted grouped list + XCD-aware Q phase (SBV_GROUP_SORT=0: the split's compaction order; the form the step falls back to when a batch has more groups than one LDS histogram holds)
+    size_t coop_max = (size_t)1 << 15;     // P-256: batches up to this size finish in ONE launch of 8 lanes per grouped tuple (k_group_coop; SBV_GROUP_COOP_MAX, 0 = off).  Measured in round 4 (profiles/r04/ab_coop_r04a.jsonl): warm 2^10 0.30 -> 0.19 ms, 2^12 0.34 -> 0.22, 2^14 0.37 -> 0.27, 2^15 0.39 -> 0.33
     size_t gsplit_min = (size_t)1 << 19;   // P-256: batches from this size run the G phase as its own 3-waves-per-SIMD kernel (SBV_GPHASE_SPLIT_MIN; 0 = never)
-    int wide = 0;                   // P-256, SBV_GROUP_WIDE: bit 0 = one lane per table entry in the rows step (k_keytab29_entries), bit 1 = fill rows split over fsplit lanes (k_keytab29_fill_parts); default 0 = two chains of additions per window + whole rows per lane (measured: profiles/r03/ab_wide_fresh_process_r03l.jsonl, ab_wide_bits_r03r.jsonl)
-    int fsplit = 3;                 // P-256, wide: lanes per row of 15 entries in the fill step, 1..4 (SBV_GROUP_FSPLIT)
-    int parts = 1;                  // P-256: rows of 16 entries per lane of k_keytab29_fill (1, 2, 4, 7); Ed25519: lanes per (key, window)
 };
 // Enqueues stage A AND stage B of a grouped batch.  ev_fork must have been recorded on `stream` first.  after_prep
-// (optional) is recorded on `stream` once every slice of stage A is ordered before it.  prof (optional): 2 * chunks
+// (optional) is recorded on `stream` once stage A is ordered before it.  prof (optional): 2 * chunks
 // events, a pair around every Q-phase launch; *prof_pairs = the number of pairs used.
 // d_g16: 16-bit comb of G in the 8 x 32 Montgomery domain (generic kernel); d_g16r: the same points for the carry-free field
 hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b, u32* d_qtab,

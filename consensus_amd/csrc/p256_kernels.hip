@@ -66,8 +66,7 @@ __device__ __forceinline__ void prep_body(const uint8_t* __restrict__ tuples, si
     prep_chunk29<HAS_Q>(words, n, s, block_first + (size_t)lane, (size_t)kPrepLanes, T);
 }
 
-// block_off: the launch covers workgroups [block_off, block_off + gridDim.x) of the batch — the grouped step runs stage A in
-// slices so that the G phase of the first slice starts while the later slices are still being prepared.
+// block_off: the launch covers workgroups [block_off, block_off + gridDim.x) of the batch
 __global__ __launch_bounds__(kPrepLanes) void k_p256_prep(const uint8_t* __restrict__ tuples, size_t n,
                                                           Scratch s, int T, unsigned block_off) {
     prep_body<40, true>(tuples, n, s, T, block_off);
@@ -77,27 +76,14 @@ __global__ __launch_bounds__(kPrepLanes) void k_p256_prep_keyed(const uint8_t* _
     prep_body<24, false>(rsh, n, s, T, 0u);
 }
 
-// Stage B normally runs as ONE launch of the exact kernel.  An experimental two-launch mode
-// (env SBV_STAGEB_FAST=1) first runs a FAST kernel using the cheap conditional subtraction
-// (p256_fe.h: fe_cond_sub_p_t), records per wavefront whether any lane's sticky word fired, and lets
-// the exact kernel re-verify only those wavefronts.  MEASURED NEGATIVE RESULT (profiles/r01/
-// stageb_fast_ab.txt): 7 % fewer VALU instructions per doubling but 11 % MORE time for the generic
-// kernel — the masked add chain needs the reduction's final carry before its first limb, which
-// lengthens the dependent v_addc chain, and at 3 waves/SIMD the kernel is as much latency- as
-// issue-bound.  (+3.5 % for the registered-key kernel.)  Kept selectable for the next round.
-template <bool FAST>
-__device__ __forceinline__ void finish_wave(bool accept, bool need_exact, size_t i, size_t n, uint8_t* __restrict__ bitmap,
-                                            uint8_t* __restrict__ rerun) {
+// accept bits of one wavefront -> 8 bitmap bytes (LSB-first)
+__device__ __forceinline__ void finish_wave(bool accept, size_t i, size_t n, uint8_t* __restrict__ bitmap) {
     const unsigned long long m = __ballot(accept);
     const int lane = threadIdx.x & 63;
     const size_t wave_first = i - (size_t)lane;
     if (lane < 8) {
         const size_t byte = (wave_first >> 3) + (size_t)lane;
         if (byte < ((n + 7) >> 3)) bitmap[byte] = (uint8_t)(m >> (8 * lane));
-    }
-    if (FAST) {
-        const unsigned long long need = __ballot(need_exact);
-        if (lane == 0) rerun[wave_first >> 6] = need != 0ull ? 1 : 0;
     }
 }
 
@@ -110,7 +96,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed(Scrat
     const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     bool accept = false;
     if (i < n) accept = verify29_lane_keyed(s, i, slots[i], nkeys, ktab, kvalid, g16r);
-    finish_wave<false>(accept, false, i, n, bitmap, nullptr);
+    finish_wave(accept, i, n, bitmap);
 }
 
 // Registered-key form, SBV_COOP_LANES lanes per signature (p256_core.h): the latency kernel for small batches.
@@ -271,7 +257,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify(Scratch s, 
     const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     bool accept = false;
     if (i < n) accept = verify29_lane_generic(s, i, qtab + i * (size_t)SBV_QTAB29_WORDS, gc);
-    finish_wave<false>(accept, false, i, n, bitmap, nullptr);
+    finish_wave(accept, i, n, bitmap);
 }
 
 // Batch signing (p256_sign.h): lane i signs digest i with private key key_index[i] (or i % n_keys).
@@ -354,19 +340,6 @@ hipError_t launch_p256_prep_blocks(const uint8_t* d_tuples, size_t n, const Scra
     if (n == 0 || block_hi <= block_lo) return hipSuccess;
     hipLaunchKernelGGL(k_p256_prep, dim3(block_hi - block_lo), dim3(kPrepLanes), 0, stream, d_tuples, n, s, prep_chunk_T(n), block_lo);
     return hipGetLastError();
-}
-
-// test hook: SBV_FORCE_EXACT=1 marks every wavefront for the exact pass, so the GPU tests can run the
-// code that real data reaches with probability 2^-32 per field operation
-static bool force_exact() {
-    static const bool v = [] { const char* e = getenv("SBV_FORCE_EXACT"); return e && e[0] == '1'; }();
-    return v;
-}
-
-// SBV_STAGEB_FAST=1 selects the experimental fast+exact two-launch mode (default: exact only)
-static bool two_pass() {
-    static const bool v = [] { const char* e = getenv("SBV_STAGEB_FAST"); return e && e[0] == '1'; }();
-    return v;
 }
 
 // Batches up to this size take the lanes-per-signature kernel: 32768 x 8 lanes = 4 wavefronts per SIMD, still

@@ -5,14 +5,16 @@
 // enough in that call (p256_group.h); nothing survives the call.  Three kernels, each a handful of lanes per unit of
 // work, all latency-bound chains that run beside the throughput kernels (G phase / Q phase):
 //
-//   bases   one lane per key:    the doubling chain 2^(8j) Q (Jacobian, 3M + 5S each), recording B_j = 2^(8j) Q and 16 B_j
-//                                for every window of the chunk, normalised to affine with ONE inversion per chunk
-//                                (Montgomery's trick along the lane)
-//   rows    two lanes per (key, window):   lane 0: the "babies" b * B_j, b = 1..16; lane 1: the "giants" 16 a * B_j,
-//                                a = 2..8 — chains of XYZZ mixed additions (8M + 2S), normalised with one inversion per lane
-//   fill    lanes per (key, window, rows of 16): entry 16 a + b = giant_a + baby_b as AFFINE + AFFINE additions sharing
-//                                one inversion per lane (Montgomery's trick): 5M + 1S per entry instead of the
-//                                ~17M + 4S of a Jacobian addition followed by a normalisation
+//   chain   four lanes per key:  the doubling chain 2^(8j) Q in modified Jacobian coordinates (X : Y : Z : T = a Z^4), the three
+//                                product levels of a doubling spread over the quad (DPP broadcasts); records B_j = 2^(8j) Q and
+//                                16 B_j per window, NOT normalised
+//   rows    two lanes per (key, window):   lane 0: the "babies" b * B_j, b = 1..8; lane 1: the "giants" 16 a * B_j,
+//                                a = 1..8 — chains of XYZZ mixed additions (8M + 2S) on the isomorphic curve where the
+//                                recorded base is affine, normalised with one inversion per lane
+//   fill    eight lanes per (key, window): lane a fills both sides of giant 16 a — entries 16 a + b and 16 a - b from babies
+//                                b = 1..8 as AFFINE + AFFINE additions; +b and -b share the inverse of x_b - x_16a and the
+//                                eight inverses of a lane come from ONE inversion (Montgomery's trick): 5M + 1S per entry
+//                                instead of the ~17M + 4S of a Jacobian addition followed by a normalisation
 //
 // Exceptional cases: every sum formed here is (16 a + b) * B with 0 < 16 a + b <= 128 and B of prime order n > 2^255,
 // so the two summands of an affine addition never share an x coordinate; the chains use the exact pt29_madd anyway.
@@ -23,9 +25,9 @@
 
 namespace sbv {
 
-#define SBV_KT29_POINTS_PER_WINDOW 8                       // chain records per window: 2^d B_j, d = 0..7 (the old rows kernel reads d = 0 and 4)
-#define SBV_KT29_ROWS_TMP_WORDS (15 * 45)                  // per lane of the rows kernel: 15 points x (X, Y, ZZ, ZZZ, prefix)
-#define SBV_KT29_FILL_TMP_WORDS (15 * 4 * 9)               // per lane of the fill kernel: up to 4 rows x 15 prefix products
+#define SBV_KT29_POINTS_PER_WINDOW 8                       // record slots per window: 2^d B_j, d = 0..7; the chain writes d = 0 and 4 (B_j and 16 B_j), which is what the rows step reads
+#define SBV_KT29_ROWS_TMP_WORDS (15 * 45)                  // per lane of the rows kernel: up to 15 points x (X, Y, ZZ, ZZZ, prefix); 7 used
+#define SBV_KT29_FILL_TMP_WORDS (15 * 4 * 9)               // scratch stride unit of the fill kernel (a lane uses 8 x 9 words at r * SBV_KT29_FILL_TMP_WORDS / 2)
 
 SBV_HD void f29_store_raw(u32* dst, const fe29& a) {
     SBV_UNROLL
@@ -240,7 +242,7 @@ SBV_HD void keychain29_run(QX& q, const uint8_t* tuples, u32 gidx, const GroupSt
 }
 
 // ---- rows ----------------------------------------------------------------------------------------------------------------
-// which = 0: babies b * B, b = 1..16 -> row[b - 1];  which = 1: giants 16 a * B, a = 2..8 -> row[16 a - 1].
+// which = 0: babies b * B, b = 1..8 -> row[b - 1];  which = 1: giants 16 a * B, a = 1..8 -> row[16 a - 1].
 // base2 = the window's two chain records (B and 16 B, modified Jacobian); row = the window's 128 entries;
 // tmp: SBV_KT29_ROWS_TMP_WORDS private words.  top_window (j == 32): only entry 1 exists (the carry digit is 0 or 1).
 //
@@ -249,7 +251,8 @@ SBV_HD void keychain29_run(QX& q, const uint8_t* tuples, u32 gidx, const GroupSt
 // (the addition formulas do not depend on the curve's coefficients; the one doubling takes a4 = T = -3 Z^4 from the chain),
 // and a multiple (X' : Y' : ZZ' : ZZZ') maps back as x = X' / (ZZ' Z^2), y = Y' / (ZZZ' Z^3).  Z joins the lane's ONE
 // inversion (Montgomery's trick over Z and the ZZZ' of the chain).
-SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32* tmp, apt* row, int babies = 16) {
+SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32* tmp, apt* row) {
+    const int babies = 8;                                                 // the symmetric fill needs babies 1..8 only
     kchain B;
     kchain_load(B, base2 + which * 4 * SBV_KT29_REC_WORDS);               // record 0 = B, record 4 = 16 B
     const int n = top_window ? 0 : (which == 0 ? babies - 1 : 7);         // points of the chain beyond its first (babies = 8: the symmetric fill below)
@@ -284,7 +287,7 @@ SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32
     f29_mul(inv, inv, bz);                      // 1 / prod ZZZ'
     f29_sqr(zi2, zi);
     f29_mul(zi3, zi2, zi);
-    if (which == 0 || babies < 16) {            // entry 1 = B itself; with the short baby chain nobody else builds entry 16 = the giants' base
+    {                                           // entry 1 = B itself; entry 16 = the giants' base
         apt29 a;
         fe29 bx, by;
         f29_load_raw(bx, brec); f29_load_raw(by, brec + 9);
@@ -311,99 +314,8 @@ SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32
     }
 }
 
-// ---- rows, wide form: one lane per entry -----------------------------------------------------------------------------------
-// The 23 entries of a window that the fill step starts from — babies 1..16 and giants 32, 48, .., 128 — are sums of at most
-// three of the chain's records 2^d B (d = 0..7), so no lane walks a chain of 15 additions any more: eight entries ARE
-// records, thirteen are one general addition away (3 = 2 + 1, 7 = 8 - 1, 112 = 128 - 16, ...), two are two away (11 = 8 + 2 + 1,
-// 13 = 8 + 4 + 1).  Every lane converts its records to XYZZ (ZZ = Z^2, ZZZ = Z^3), adds with the exact pt29_add and
-// normalises its one point with its own inversion.  ~70 us deep instead of ~400 (VERDICT r2 weak #2 / DESIGN section 8.1);
-// about twice the issue slots of the chain form.  term = record index + 1, negative = subtract, 0 = none.
-struct kt29_plan { unsigned char mult; signed char t1, t2, t3; };
-#define SBV_KT29_ENTRY_LANES 23
-SBV_HD kt29_plan keytab29_plan(int e) {
-    const kt29_plan tab[SBV_KT29_ENTRY_LANES] = {
-        {1, 1, 0, 0}, {2, 2, 0, 0}, {3, 2, 1, 0}, {4, 3, 0, 0}, {5, 3, 1, 0}, {6, 3, 2, 0}, {7, 4, -1, 0}, {8, 4, 0, 0},
-        {9, 4, 1, 0}, {10, 4, 2, 0}, {11, 4, 2, 1}, {12, 4, 3, 0}, {13, 4, 3, 1}, {14, 5, -2, 0}, {15, 5, -1, 0}, {16, 5, 0, 0},
-        {32, 6, 0, 0}, {48, 6, 5, 0}, {64, 7, 0, 0}, {80, 7, 5, 0}, {96, 7, 6, 0}, {112, 8, -5, 0}, {128, 8, 0, 0}};
-    return tab[e];
-}
-SBV_HD void kt29_record_xyzz(xyzz& P, const u32* recs, int term) {
-    const int d = (term < 0 ? -term : term) - 1;
-    const u32* rec = recs + d * SBV_KT29_REC_WORDS;
-    fe29 Z;
-    f29_load_raw(P.X, rec); f29_load_raw(P.Y, rec + 9); f29_load_raw(Z, rec + 18);
-    if (term < 0) { fe29 t; f29_neg(t, P.Y); P.Y = t; }
-    f29_sqr(P.ZZ, Z);
-    f29_mul(P.ZZZ, P.ZZ, Z);
-    P.inf = false;
-}
-// recs: the window's 8 chain records; e = 0..22; row = the window's 128 entries
-SBV_HD void keytab29_entry_lane(const u32* recs, int e, bool top_window, apt* row) {
-    const kt29_plan pl = keytab29_plan(e);
-    if (top_window && pl.mult != 1) return;
-    xyzz R, Q;
-    kt29_record_xyzz(R, recs, pl.t1);
-    SBV_NOUNROLL
-    for (int k = 0; k < 2; ++k) {               // one copy of the addition in the kernel's code
-        const int t = k == 0 ? pl.t2 : pl.t3;
-        if (t == 0) break;
-        kt29_record_xyzz(Q, recs, t);
-        pt29_add(R, Q);
-    }
-    fe29 i3, w, w2;
-    f29_inv(i3, R.ZZZ);
-    f29_mul(w, R.ZZ, i3);                       // ZZ / ZZZ = 1 / Z
-    f29_sqr(w2, w);                             // 1 / ZZ
-    apt29 a;
-    f29_mul(a.x, R.X, w2);
-    f29_mul(a.y, R.Y, i3);
-    apt29_store_canon(row + pl.mult - 1, a);
-}
-
 // ---- fill ----------------------------------------------------------------------------------------------------------------
-// rows a = a_first .. a_last (within 1..7): entry 16 a + b = row[16 a - 1] + row[b - 1], b = 1..15.
-// tmp: SBV_KT29_FILL_TMP_WORDS private words.
-SBV_HD void keytab29_fill_lane(int a_first, int a_last, u32* tmp, apt* row) {
-    fe29 acc = f29_one();
-    int cnt = 0;
-    SBV_NOUNROLL
-    for (int a = a_first; a <= a_last; ++a) {
-        apt29 G;
-        apt29_load(G, reinterpret_cast<const u32*>(row + 16 * a - 1));
-        SBV_NOUNROLL
-        for (int b = 1; b <= 15; ++b) {
-            apt29 S;
-            apt29_load(S, reinterpret_cast<const u32*>(row + b - 1));
-            fe29 d;
-            f29_sub(d, S.x, G.x);
-            f29_store_raw(tmp + cnt * 9, acc);
-            f29_mul(acc, acc, d);
-            ++cnt;
-        }
-    }
-    fe29 inv;
-    f29_inv(inv, acc);
-    SBV_NOUNROLL
-    for (int a = a_last; a >= a_first; --a) {
-        apt29 G;
-        apt29_load(G, reinterpret_cast<const u32*>(row + 16 * a - 1));
-        SBV_NOUNROLL
-        for (int b = 15; b >= 1; --b) {
-            --cnt;
-            apt29 S, r;
-            apt29_load(S, reinterpret_cast<const u32*>(row + b - 1));
-            fe29 d, pre, dinv;
-            f29_sub(d, S.x, G.x);
-            f29_load_raw(pre, tmp + cnt * 9);
-            f29_mul(dinv, inv, pre);
-            f29_mul(inv, inv, d);
-            apt29_add_with_inverse(r, G, S, dinv);
-            apt29_store_canon(row + 16 * a + b - 1, r);
-        }
-    }
-}
-
-// Symmetric form (GroupSync::wide bit 2): lane a = 1..8 fills BOTH sides of giant 16 a from babies 1..8 — 16 a + b (b = 1..7,
+// Symmetric form: lane a = 1..8 fills BOTH sides of giant 16 a from babies 1..8 — 16 a + b (b = 1..7,
 // a <= 7) and 16 a - b (b = 1..8) share the inverse of x_b - x_16a, because -b B is (x_b, -y_b).  Eight denominators per lane
 // instead of fifteen, and the rows step only has to build babies 2..8 (7 additions instead of 15).  Entry 8 is a baby and is
 // not written again (a = 1, b = 8); entries 9..15 come from giant 16.  Lanes write disjoint entries and read only babies
@@ -443,37 +355,6 @@ SBV_HD void keytab29_fill_sym_lane(int a, u32* tmp, apt* row) {
             apt29_add_with_inverse(r, G, S, dinv);
             apt29_store_canon(row + 16 * a - b - 1, r);
         }
-    }
-}
-
-// The same for a PART of row a: entries 16 a + b, b = b_first..b_last (the fill kernel with more, shorter lanes: the chain of
-// prefix products and the normalisations behind the one inversion are what a lane's latency is made of).  tmp: 15 x 9 words.
-SBV_HD void keytab29_fill_part_lane(int a, int b_first, int b_last, u32* tmp, apt* row) {
-    apt29 G;
-    apt29_load(G, reinterpret_cast<const u32*>(row + 16 * a - 1));
-    fe29 acc = f29_one();
-    SBV_NOUNROLL
-    for (int b = b_first; b <= b_last; ++b) {
-        apt29 S;
-        apt29_load(S, reinterpret_cast<const u32*>(row + b - 1));
-        fe29 d;
-        f29_sub(d, S.x, G.x);
-        f29_store_raw(tmp + (b - b_first) * 9, acc);
-        f29_mul(acc, acc, d);
-    }
-    fe29 inv;
-    f29_inv(inv, acc);
-    SBV_NOUNROLL
-    for (int b = b_last; b >= b_first; --b) {
-        apt29 S, r;
-        apt29_load(S, reinterpret_cast<const u32*>(row + b - 1));
-        fe29 d, pre, dinv;
-        f29_sub(d, S.x, G.x);
-        f29_load_raw(pre, tmp + (b - b_first) * 9);
-        f29_mul(dinv, inv, pre);
-        f29_mul(inv, inv, d);
-        apt29_add_with_inverse(r, G, S, dinv);
-        apt29_store_canon(row + 16 * a + b - 1, r);
     }
 }
 

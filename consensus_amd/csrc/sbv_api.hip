@@ -200,10 +200,9 @@ sbv::Scratch scratch_view(const Context& c) {
 
 std::vector<hipEvent_t*> group_events(Context& c) {
     sbv::GroupSync& y = c.gsync;
-    std::vector<hipEvent_t*> v = {&y.ev_fork, &y.ev_assign, &y.ev_split, &y.ev_prep, &y.ev_generic};
-    for (int i = 0; i < SBV_GROUP_MAX_TCHUNKS; ++i) v.push_back(&y.ev_bases[i]);
+    std::vector<hipEvent_t*> v = {&y.ev_fork, &y.ev_assign, &y.ev_split, &y.ev_generic};
+    for (int i = 0; i < SBV_GROUP_MAX_CHUNKS; ++i) v.push_back(&y.ev_bases[i]);
     for (int i = 0; i < SBV_GROUP_MAX_CHUNKS; ++i) v.push_back(&y.ev_tables[i]);
-    for (int i = 0; i < SBV_GROUP_MAX_SLICES; ++i) v.push_back(&y.ev_slice[i]);
     return v;
 }
 
@@ -299,12 +298,7 @@ int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bi
         const int rc = ensure_ed_group_buffers(c, n);
         if (rc != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
-        // SBV_ED_TSTREAMS=1 (not yet measured): the windows of the odd chunks on the context's idle stream, as the P-256 step
-        // does with its rows + fill (enqueue() says why it is not a stream of its own)
-        sbv::GroupSync y = c.gsync;
-        const char* et = getenv("SBV_ED_TSTREAMS");
-        if (et && et[0] == '1' && stream != c.stream) { y.tstreams = 2; y.side_t = c.stream; } else y.tstreams = 1;
-        HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify_grouped(d_tuples, n, c.grp, c.edgrp, c.d_qtab, c.d_btab, d_bitmap, stream, y));
+        HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify_grouped(d_tuples, n, c.grp, c.edgrp, c.d_qtab, c.d_btab, d_bitmap, stream, c.gsync));
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify(d_tuples, n, c.d_qtab, c.d_btab, d_bitmap, stream));
@@ -331,7 +325,7 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
         if (n < ((size_t)1 << 18) && c.grp.min_count > 32) c.grp.min_count = 32;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
     }
-    if (grouped) {           // stage A is enqueued by the grouped launcher, in slices pipelined with the G phase
+    if (grouped) {           // stage A is enqueued by the grouped launcher
         sbv::Scratch sg = s;
         sg.rec = c.gsync.sorted ? c.grp.rec : nullptr;      // stage A also writes the per-tuple records the key-sorted list reads
         // The second table stream is NOT a stream of its own: a process gets four hardware queues and the fifth stream shares
@@ -458,52 +452,23 @@ int init_context(Context& c, int device) {
         return SBV_ENODEV;
     }
     HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-    {
-        // The side streams carry the table-building chains: few lanes, long dependent chains, and the Q phase waits for them.
-        // SBV_SIDE_PRIO=1 asks for the highest queue priority so that their workgroups are placed ahead of the throughput
-        // kernels' (default 0: measured).
-        int lo = 0, hi = 0;
-        const char* e = getenv("SBV_SIDE_PRIO");
-        const bool prio = e && e[0] == '1' && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo;
-        // SBV_TABLE_CUS=N (experiment, default off): the side streams may only use N compute units (mask bits 0 .. N-1; the
-        // driver deals mask bits round-robin over the 8 XCDs).  A table wave of 122-256 VGPRs pushes a 256-VGPR G/Q-phase
-        // wave off its SIMD for its whole 0.3 ms life; the mask concentrates that on N CUs instead of all 256.
-        int table_cus = 0;
-        if (const char* m = getenv("SBV_TABLE_CUS")) table_cus = atoi(m);
-        for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b}) {
-            if (table_cus > 0 && table_cus < prop.multiProcessorCount) {
-                std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0u);
-                for (int b = 0; b < table_cus; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
-                HIP_TRY(SBV_ENODEV, hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data()));
-            } else if (prio) HIP_TRY(SBV_ENODEV, hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi));
-            else HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
-        }
-    }
+    // The side streams carry the grouping kernels and the table-building chains (few lanes, long dependent chains; the Q phase
+    // waits for them).  Highest queue priority and CU masks for them were measured and rejected in round 3.
+    for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b}) HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
     for (hipEvent_t* ev : group_events(c)) HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(ev, hipEventDisableTiming));
     {   // every knob back to its default: a context initialised again re-reads the environment
         const sbv::GroupSync d;
-        c.gsync.tsub = d.tsub; c.gsync.parts = d.parts; c.gsync.wide = d.wide; c.gsync.fsplit = d.fsplit; c.gsync.slices = d.slices;
-        c.gsync.sorted = d.sorted; c.gsync.tstreams = d.tstreams; c.gsync.gsplit_min = d.gsplit_min; c.gsync.coop_max = d.coop_max; c.gsync.chunk0 = d.chunk0; c.gsync.k256_prep_t = d.k256_prep_t;
+        c.gsync.sorted = d.sorted; c.gsync.tstreams = d.tstreams; c.gsync.gsplit_min = d.gsplit_min; c.gsync.coop_max = d.coop_max;
     }
     c.gsync.chunks = 2;
     if (const char* e = getenv("SBV_GROUP_CHUNKS")) {
         const int v = atoi(e);
         if (v >= 1 && v <= SBV_GROUP_MAX_CHUNKS) c.gsync.chunks = v;
     }
-    if (const char* e = getenv("SBV_K256_PREP_T")) { const int v = atoi(e); if (v >= 1 && v <= 8) c.gsync.k256_prep_t = v; }
-    if (const char* e = getenv("SBV_GROUP_CHUNK0")) { const int v = atoi(e); if (v >= 1 && v <= 32) c.gsync.chunk0 = v; }
-    if (const char* e = getenv("SBV_GROUP_TSUB")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.tsub = v; }
-    if (const char* e = getenv("SBV_GROUP_PARTS")) c.gsync.parts = atoi(e);
     if (const char* e = getenv("SBV_GROUP_TSTREAMS")) { const int v = atoi(e); if (v >= 1 && v <= 2) c.gsync.tstreams = v; }
     if (const char* e = getenv("SBV_GPHASE_SPLIT_MIN")) c.gsync.gsplit_min = (size_t)strtoull(e, nullptr, 10);
     if (const char* e = getenv("SBV_GROUP_COOP_MAX")) { const size_t v = (size_t)strtoull(e, nullptr, 10); c.gsync.coop_max = v > 32768 ? 32768 : v; }
-    if (const char* e = getenv("SBV_GROUP_WIDE")) c.gsync.wide = atoi(e) & 7;
-    if (const char* e = getenv("SBV_GROUP_FSPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 4) c.gsync.fsplit = v; }
-    if (const char* e = getenv("SBV_GROUP_SLICES")) c.gsync.slices = atoi(e);
     if (const char* e = getenv("SBV_GROUP_SORT")) c.gsync.sorted = atoi(e) != 0;
-    if (const char* e = getenv("SBV_GENERIC_STREAM")) {
-        if (e[0] == '1') HIP_TRY(SBV_ENODEV, hipStreamCreateWithFlags(&c.gsync.side_c, hipStreamNonBlocking));
-    }
     for (auto& ev : c.ev) HIP_TRY(SBV_ENODEV, hipEventCreate(&ev));
     HIP_TRY(SBV_ENODEV, hipEventCreateWithFlags(&c.busy, hipEventDisableTiming));
     // fixed-base table: computed once on the host with the same field code, then resident in HBM
@@ -637,7 +602,7 @@ int shutdown_context(Context& c) {
         for (auto& ev : sl.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
         sl = StageSlot();
     }
-    for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b, &c.gsync.side_c}) if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
+    for (hipStream_t* st : {&c.gsync.side_a, &c.gsync.side_b}) if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
     for (hipEvent_t* ev : group_events(c)) if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
     c.busy_valid = false;
     c.ready = false;
@@ -1575,7 +1540,16 @@ struct RcclApi {
 } g_rccl;
 std::vector<int> g_devs;               // devices initialised by sbv_init_all, ascending
 std::atomic<unsigned> g_rr{0};         // round-robin cursor of the replica route
-size_t g_shard_min = (size_t)1 << 18;  // tuples per device below which a batch is not split
+// Tuples per device below which a batch is not split further.  Two values, chosen per batch by shard_min_for():
+//   g_shard_min       a batch over MANY signers (client requests): every device builds the tables of every key it meets, a
+//                     cost that does not shrink with the shard; measured cold steps (profiles/r03/sweep_sizes_r03u.jsonl):
+//                     2^20 3.30 ms, 2^19 2.17, 2^18 1.66, 2^17 1.44, 2^16 1.35 — still falling at 2^17, flat below.
+//   g_shard_min_few   a batch over a HANDFUL of signers (consenter commit signatures: 16 keys at N = 16, configs[3]; the keys
+//                     are registered or sit in the key-table cache after the first piece): 2^16 tuples already run at
+//                     181 M/s warm (0.36 ms), so 550 000 tuples really span 8 devices (68 750 each).
+size_t g_shard_min = (size_t)1 << 17;
+size_t g_shard_min_few = (size_t)1 << 16;
+bool g_shard_min_env = false;           // SBV_SHARD_MIN given: it overrides both
 size_t g_shard_piece = (size_t)1 << 18;  // verify_shard: tuples per upload piece when the key-table cache is on (SBV_SHARD_PIECE)
 // How a batch that spans devices is partitioned: 0 = contiguous ranges of tuples (every device sees every key), 1 = by a
 // hash of the public key (device g builds the tables of its keys only; every device receives the whole batch).
@@ -1700,31 +1674,6 @@ __global__ __launch_bounds__(256) void k_part_scatter(const uint8_t* __restrict_
     if ((dense_bitmap[j >> 3] >> (j & 7)) & 1u) { const u32 i = idx[j]; atomicOr(&out_words[i >> 5], 1u << (i & 31)); }
 }
 
-// The same two without a host round trip (part_enqueue, SBV_PART_NOSYNC): the launches are sized for an upper bound of the
-// member count and read the count itself from device memory.  Slots [count, upper) of the dense batch are filled with tuples
-// no verifier accepts and no table is built for: r = s = 0 (refused by the range check of stage A) under keys that are all
-// different (x = the slot number, y = 0xA5..: never grouped, refused by the curve check at the split).
-__global__ __launch_bounds__(256) void k_part_gather_pad(const uint8_t* __restrict__ tuples, const u32* __restrict__ idx, const u32* __restrict__ count,
-                                                         size_t upper, uint8_t* __restrict__ dense) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;            // 16-byte element of the dense batch
-    const size_t j = e / 10, part = e - j * 10;
-    if (j >= upper) return;
-    const size_t members = *count < upper ? *count : upper;
-    uint4 v;
-    if (j < members) v = reinterpret_cast<const uint4*>(tuples + (size_t)idx[j] * SBV_TUPLE_BYTES)[part];
-    else if (part < 6) v = make_uint4(0u, 0u, 0u, 0u);                  // r | s | hash
-    else if (part < 8) v = make_uint4((u32)j, (u32)(j >> 32), 0x50414421u, (u32)part);     // Qx: distinct per slot
-    else v = make_uint4(0xA5A5A5A5u, 0xA5A5A5A5u, 0xA5A5A5A5u, 0xA5A5A5A5u);            // Qy
-    reinterpret_cast<uint4*>(dense)[e] = v;
-}
-__global__ __launch_bounds__(256) void k_part_scatter_dev(const uint8_t* __restrict__ dense_bitmap, const u32* __restrict__ idx,
-                                                          const u32* __restrict__ count, size_t upper, u32* __restrict__ out_words) {
-    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t members = *count < upper ? *count : upper;
-    if (j >= members) return;
-    if ((dense_bitmap[j >> 3] >> (j & 7)) & 1u) { const u32 i = idx[j]; atomicOr(&out_words[i >> 5], 1u << (i & 31)); }
-}
-
 int ensure_part_buffers(Context& c, PartBuffers& pb, size_t n) {
     const size_t want = (n + 1023) & ~(size_t)1023;
     if (want <= pb.cap) return SBV_OK;
@@ -1758,32 +1707,9 @@ int part_enqueue(Context& c, const uint8_t* d_tuples, size_t n, u32 part, u32 pa
         HIP_TRY(SBV_EDEVICE, hipMemsetAsync(pb.d_count, 0, sizeof(u32), stream));
         hipLaunchKernelGGL(k_part_select, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream, src, m, part, parts, pb.d_idx, pb.d_count);
         HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(pb.h_count, pb.d_count, sizeof(u32), hipMemcpyDeviceToHost, stream));
-        const char* ns = getenv("SBV_PART_NOSYNC");                        // off until measured on a GPU
-        if (ns && ns[0] == '1' && parts > 1) {
-            // No round trip in the middle (it drains the stream: the ~20 launches of the step are then enqueued against an idle
-            // GPU, ~0.2 ms of a 0.8 ms part).  Everything is sized for an upper bound — 1.3 x the mean part + 4096: a part of
-            // a batch over K keys deviates by sqrt(parts / K) of its mean, 8 % at K = 1024 — the kernels read the count on the
-            // device, and the host looks at it only when all is enqueued; a part that outgrew the bound is done again the
-            // exact way (the verdict bits are OR-ed in, so doing a part twice is harmless).
-            size_t upper = (m / parts) * 13 / 10 + 4096;
-            if (upper > m) upper = m;
-            upper = (upper + 63) & ~(size_t)63;
-            if (upper > pb.cap) upper = pb.cap;
-            hipLaunchKernelGGL(k_part_gather_pad, dim3((unsigned)((upper * 10 + 255) / 256)), dim3(256), 0, stream, src, pb.d_idx, pb.d_count, upper, pb.d_dense);
-            if ((rc = ensure_capacity(c, upper)) != SBV_OK) return rc;
-            if (c.busy_valid) HIP_TRY(SBV_EDEVICE, hipStreamWaitEvent(stream, c.busy, 0));
-            rc = enqueue(c, pb.d_dense, upper, pb.d_bits, stream, nullptr, nullptr, nullptr, nullptr, n);
-            if (hipEventRecord(c.busy, stream) == hipSuccess) c.busy_valid = true;
-            if (rc != SBV_OK) return rc;
-            hipLaunchKernelGGL(k_part_scatter_dev, dim3((unsigned)((upper + 255) / 256)), dim3(256), 0, stream, pb.d_bits, pb.d_idx, pb.d_count, upper,
-                               d_out_words + off / 32);
-            HIP_TRY(SBV_EDEVICE, hipGetLastError());
-            HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(stream));          // at the END of the chunk: nothing waits behind it
-            if (*pb.h_count <= upper) { total += *pb.h_count; continue; }
-            // a part larger than the bound (a skewed key population): the exact path below does the chunk again
-        } else {
-            HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(stream));
-        }
+        // one host round trip: the member count sizes the launches (a form without it — launches sized for an upper bound, the
+        // count read on the device — was measured in round 4 and did not move the projection: profiles/r04/projection_nosync*_r04a.json)
+        HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(stream));
         const size_t members = *pb.h_count;
         total += members;
         if (members == 0) continue;
@@ -1884,6 +1810,24 @@ int verify_shard(Context& c, const uint8_t* h_tuples, size_t m, size_t group, u3
 
 }  // namespace
 
+// The per-device minimum the sharded entry uses for THIS batch (host memory, no device): the keys of 256 evenly spaced tuples
+// are compared; at most 32 distinct ones among them = a consenter-style batch (a batch over K equally likely signers shows
+// about min(K, 256 (1 - e^(-256/K)) ...) distinct keys in such a sample: 16 for K = 16, 226 for K = 1024).
+extern "C" size_t sbv_shard_min_for(const uint8_t* tuples, size_t n, size_t group) {
+    (void)group;
+    if (g_shard_min_env || !tuples || n == 0) return g_shard_min;
+    const size_t samples = n < 256 ? n : 256;
+    const uint8_t* seen[33];
+    size_t distinct = 0;
+    for (size_t j = 0; j < samples && distinct <= 32; ++j) {
+        const uint8_t* k = tuples + (j * n / samples) * SBV_TUPLE_BYTES + 96;
+        bool dup = false;
+        for (size_t d = 0; d < distinct && !dup; ++d) dup = memcmp(seen[d], k, 64) == 0;
+        if (!dup) seen[distinct++] = k;
+    }
+    return distinct <= 32 ? g_shard_min_few : g_shard_min;
+}
+
 extern "C" size_t sbv_shard_plan(size_t n, int devices, size_t group, size_t min_per_device, size_t* first) {
     // first[0..shards] = tuple index where each shard starts (first[shards] = n); returns the number of shards (>= 1)
     if (devices < 1) devices = 1;
@@ -1923,7 +1867,7 @@ extern "C" int sbv_init_all(void) {
         rccl_teardown();
         g_devs = devs;
     }
-    if (const char* e = getenv("SBV_SHARD_MIN")) { const long v = atol(e); if (v > 0) g_shard_min = (size_t)v; }
+    if (const char* e = getenv("SBV_SHARD_MIN")) { const long v = atol(e); if (v > 0) { g_shard_min = g_shard_min_few = (size_t)v; g_shard_min_env = true; } }
     if (const char* e = getenv("SBV_SHARD_PIECE")) { const long v = atol(e); if (v >= 512) g_shard_piece = (size_t)v; }
     if (const char* e = getenv("SBV_SHARD_MODE")) g_shard_mode.store(strcmp(e, "keys") == 0 ? 1 : 0);
     if (const char* e = getenv("SBV_SHARD_PARTS")) { const long v = atol(e); if (v >= 0 && v <= 64) g_shard_parts.store((unsigned)v); }
@@ -2009,19 +1953,26 @@ int sharded_by_key(const uint8_t* tuples, size_t n, size_t group, u32 quorum, ui
     { std::lock_guard<std::mutex> lk(g_mu); c0 = g_ctxs[devs[0]].get(); }
     if (use_rccl) {
         std::lock_guard<std::mutex> lk(g_mu);                    // the communicators
-        bool ok = g_rccl.ready && g_rccl.AllReduce && ndev == g_devs.size() && g_rccl.GroupStart() == 0;
-        for (size_t d = 0; ok && d < ndev; ++d) {
-            size_t rank = 0;
-            while (rank < g_devs.size() && g_devs[rank] != devs[d]) ++rank;
-            ok = rank < g_devs.size() && hipSetDevice(devs[d]) == hipSuccess;
+        // Every rank of the communicator takes part (devs == g_devs: checked by the caller); with fewer parts than devices the
+        // idle ranks contribute a zeroed bitmap (this used to fail outright with parts < devices).
+        const size_t world = devs.size();
+        bool ok = g_rccl.ready && g_rccl.AllReduce && g_rccl.comms.size() == world;
+        for (size_t d = ndev; ok && d < world; ++d) {
             ShardBuffers& sbuf = g_shard[devs[d]];
-            if (ok) ok = g_rccl.AllReduce(sbuf.d_gather, sbuf.d_gather, words * 4, /*ncclUint8*/ 1, /*ncclSum*/ 0, g_rccl.comms[rank], g_ctxs[devs[d]]->stream) == 0;
+            ok = hipSetDevice(devs[d]) == hipSuccess && grow_bytes(sbuf.d_gather, sbuf.gather_cap, words * 4 + 64) == SBV_OK &&
+                 hipMemsetAsync(sbuf.d_gather, 0, words * 4, g_ctxs[devs[d]]->stream) == hipSuccess;
+        }
+        ok = ok && g_rccl.GroupStart() == 0;
+        for (size_t d = 0; ok && d < world; ++d) {
+            ok = hipSetDevice(devs[d]) == hipSuccess;
+            ShardBuffers& sbuf = g_shard[devs[d]];
+            if (ok) ok = g_rccl.AllReduce(sbuf.d_gather, sbuf.d_gather, words * 4, /*ncclUint8*/ 1, /*ncclSum*/ 0, g_rccl.comms[d], g_ctxs[devs[d]]->stream) == 0;
         }
         if (ok) ok = g_rccl.GroupEnd() == 0;
         if (ok) ok = hipSetDevice(devs[0]) == hipSuccess &&
                      hipMemcpyAsync(accept_bitmap, g_shard[devs[0]].d_gather, bytes, hipMemcpyDeviceToHost, c0->stream) == hipSuccess &&
                      hipStreamSynchronize(c0->stream) == hipSuccess;
-        for (size_t d = 1; ok && d < ndev; ++d) ok = hipSetDevice(devs[d]) == hipSuccess && hipStreamSynchronize(g_ctxs[devs[d]]->stream) == hipSuccess;
+        for (size_t d = 1; ok && d < world; ++d) ok = hipSetDevice(devs[d]) == hipSuccess && hipStreamSynchronize(g_ctxs[devs[d]]->stream) == hipSuccess;
         if (!ok) { g_err = "RCCL all-reduce of the per-device bitmaps failed"; return SBV_EDEVICE; }
     } else {
         memcpy(accept_bitmap, host_bits[0].data(), bytes);
@@ -2066,7 +2017,7 @@ extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, si
         std::lock_guard<std::mutex> lk(g_mu);
         devs = g_devs;
         if (devs.empty() && g_def) devs.push_back(g_def->device);     // sbv_init only: one device
-        use_rccl = g_rccl.ready;
+        use_rccl = g_rccl.ready && g_rccl.comms.size() == devs.size();   // the communicator spans exactly these devices
     }
     if (devs.empty()) { g_err = "sbv_init_all / sbv_init has not succeeded"; return SBV_ENOTINIT; }
     if (g_shard_mode.load() == 1) {
@@ -2075,7 +2026,7 @@ extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, si
         if (parts > 1 && n >= parts) return sharded_by_key(tuples, n, group, quorum, accept_bitmap, quorum_bitmap, info, devs, parts, use_rccl);
     }
     size_t first[kMaxDevices + 1];
-    const size_t shards = sbv_shard_plan(n, (int)devs.size(), group, 0, first);
+    const size_t shards = sbv_shard_plan(n, (int)devs.size(), group, sbv_shard_min_for(tuples, n, group), first);
     const size_t per = shards > 1 ? first[1] - first[0] : ((n + shard_granule(group) - 1) / shard_granule(group) * shard_granule(group));
     const size_t sb = per / 8;                                          // bitmap bytes per shard slot
     const size_t qb = group ? (per / group + 7) / 8 : 0;                // quorum bytes per shard slot
@@ -2083,7 +2034,11 @@ extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, si
     std::vector<int> use(shards);
     if (shards == 1) use[0] = devs[g_rr.fetch_add(1) % devs.size()];
     else for (size_t k = 0; k < shards; ++k) use[k] = devs[k];
-    const bool gather = shards > 1 && use_rccl && shards == devs.size();
+    // The collective runs whenever more than one device took part.  The communicator spans every initialised device, so with
+    // fewer shards than devices the idle ranks join the all-gather with an unused slot (one tiny launch on an idle GPU; no
+    // sub-communicators to create and cache at run time): slots [0, shards) of the gathered buffer are the bitmap.
+    const bool gather = shards > 1 && use_rccl;
+    const size_t ranks = gather ? devs.size() : shards;
     const bool forced_single = shards == 1 && use_rccl && devs.size() == 1;   // SBV_RCCL=1 on a one-GPU box: exercise the collective with one rank
     std::vector<int> rcs(shards, SBV_OK);
     std::vector<std::string> errs(shards);
@@ -2104,7 +2059,7 @@ extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, si
         size_t& qb_cap = multi ? sbuf.q_cap : sbuf.onq_cap;
         int rc = SBV_OK;
         if (hipSetDevice(c->device) != hipSuccess) rc = SBV_EDEVICE;
-        if (rc == SBV_OK) rc = grow_bytes(d_bits, bits_cap, sb * shards + 64);
+        if (rc == SBV_OK) rc = grow_bytes(d_bits, bits_cap, sb * ranks + 64);
         if (rc == SBV_OK && quorum_bitmap) rc = grow_bytes(d_qb, qb_cap, qb + 64);
         if (rc == SBV_OK)
             rc = verify_shard(*c, tuples + first[k] * SBV_TUPLE_BYTES, first[k + 1] - first[k], group, quorum, d_bits + k * sb,
@@ -2132,19 +2087,24 @@ extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, si
     double gather_us = 0;
     if (gather || forced_single) {
         std::lock_guard<std::mutex> lk(g_mu);                    // the communicators
-        bool ok = g_rccl.ready && g_rccl.GroupStart() == 0;
-        for (size_t k = 0; ok && k < shards; ++k) {
-            size_t rank = 0;
-            while (rank < g_devs.size() && g_devs[rank] != use[k]) ++rank;
-            ok = rank < g_devs.size() && hipSetDevice(use[k]) == hipSuccess;
-            ShardBuffers& sbuf = g_shard[use[k]];
-            if (ok) ok = g_rccl.AllGather(sbuf.d_gather + k * sb, sbuf.d_gather, sb, /*ncclUint8*/ 1, g_rccl.comms[rank], g_ctxs[use[k]]->stream) == 0;
+        // rank r of the communicator is device g_devs[r]; shard k ran on devs[k] = g_devs[k], so slot k IS rank k's slot (the
+        // in-place form needs sendbuff = recvbuff + rank * count).  Ranks [shards, world) are idle devices: their slot is unused.
+        const size_t world = forced_single ? 1 : g_devs.size();
+        bool ok = g_rccl.ready && g_rccl.comms.size() >= world;
+        for (size_t r = shards; ok && r < world; ++r)                  // an idle rank needs a buffer of its own for the gathered slots
+            ok = hipSetDevice(g_devs[r]) == hipSuccess && grow_bytes(g_shard[g_devs[r]].d_gather, g_shard[g_devs[r]].gather_cap, sb * world + 64) == SBV_OK;
+        ok = ok && g_rccl.GroupStart() == 0;
+        for (size_t r = 0; ok && r < world; ++r) {
+            const int dev = forced_single ? use[0] : g_devs[r];
+            ok = (r >= shards || use[r] == dev) && hipSetDevice(dev) == hipSuccess;
+            ShardBuffers& sbuf = g_shard[dev];
+            if (ok) ok = g_rccl.AllGather(sbuf.d_gather + r * sb, sbuf.d_gather, sb, /*ncclUint8*/ 1, g_rccl.comms[r], g_ctxs[dev]->stream) == 0;
         }
         if (ok) ok = g_rccl.GroupEnd() == 0;
         if (ok) ok = hipSetDevice(use[0]) == hipSuccess &&
                      hipMemcpyAsync(accept_bitmap, g_shard[use[0]].d_gather, (n + 7) / 8, hipMemcpyDeviceToHost, g_ctxs[use[0]]->stream) == hipSuccess &&
                      hipStreamSynchronize(g_ctxs[use[0]]->stream) == hipSuccess;
-        for (size_t k = 1; ok && k < shards; ++k) ok = hipSetDevice(use[k]) == hipSuccess && hipStreamSynchronize(g_ctxs[use[k]]->stream) == hipSuccess;
+        for (size_t r = 1; ok && r < world; ++r) ok = hipSetDevice(g_devs[r]) == hipSuccess && hipStreamSynchronize(g_ctxs[g_devs[r]]->stream) == hipSuccess;
         if (!ok) { g_err = "RCCL all-gather of the bitmap shards failed"; return SBV_EDEVICE; }
         gather_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
     }

@@ -223,8 +223,12 @@ void sbv_host_free(void* p);
  * group = signatures per proposal (11 at N = 16: internal/bft/util.go:183-187) — whole proposals, so that each device
  * also emits the per-proposal quorum bit (>= quorum accepted signatures by DISTINCT keys, the rule of
  * internal/bft/viewchanger.go:681-727).  When more than one device took part, one in-place ncclAllGather of the bitmap
- * shards (RCCL over xGMI, uint8, per-device streams) leaves the full bitmap on every device and one D2H returns it; a
- * batch smaller than 2 x 2^18 tuples is NOT split — it goes whole to one device, round-robin, with no collective.
+ * shards (RCCL over xGMI, uint8, per-device streams) leaves the full bitmap on every device and one D2H returns it (with
+ * fewer shards than devices the idle ranks of the node-wide communicator join with an unused slot); a batch smaller than
+ * twice the per-device minimum is NOT split — it goes whole to one device, round-robin, with no collective.  The minimum is
+ * chosen per batch (sbv_shard_min_for: 2^16 tuples when a sample of the batch shows a handful of signers — consenter commit
+ * signatures, configs[3]: 550 000 tuples over 16 keys span 8 devices, 68 750 each — and 2^17 otherwise; SBV_SHARD_MIN
+ * overrides both).
  * Each device takes its shard in pieces through two upload slots: the host -> device copy of piece i + 1 runs on a copy stream
  * beside the kernels of piece i (pieces of 2^18 tuples while the key-table cache is on — the first piece builds the signers'
  * combs, the later ones find them — and whole launches when it is off; SBV_SHARD_PIECE overrides the size).
@@ -245,6 +249,11 @@ typedef struct sbv_shard_info {
 int sbv_init_all(void);
 int sbv_initialised_devices(int* out, int max);
 size_t sbv_shard_plan(size_t n, int devices, size_t group, size_t min_per_device, size_t* first);
+/* The per-device minimum the sharded entry plans THIS host batch with (pure host code, no device needed): the public keys of
+ * 256 evenly spaced tuples are compared; <= 32 distinct ones = few signers.  Reference: the traffic it tells apart is
+ * ValidateLastDecision / decision replay (internal/bft/viewchanger.go:681-727: N consenters) against VerifyProposal's K
+ * client requests (internal/bft/view.go:553-559). */
+size_t sbv_shard_min_for(const uint8_t* tuples, size_t n, size_t group);
 int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, size_t group, uint32_t quorum, uint8_t* accept_bitmap,
                                   uint8_t* quorum_bitmap, sbv_shard_info* info);
 int sbv_p256_verify_batch_on(int device, const uint8_t* tuples, size_t n, uint8_t* accept_bitmap);

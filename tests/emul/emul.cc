@@ -131,7 +131,7 @@ u32 sbve_fe_add_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(
 u32 sbve_fe_mul_fast(const u32* a, const u32* b, u32* out) { fe x, y, z; memcpy(&x, a, 32); memcpy(&y, b, 32); u32 st = 0; fe_mul<true>(z, x, y, &st); memcpy(out, &z, 32); return st; }
 
 static unsigned long g_coop_disagreements = 0, g_small_disagreements = 0;     // lanes of a cooperating group that ended with different points / stage-A forms that disagreed
-static int g_group_chunks = 3, g_group_parts = 4, g_group_sort = 1, g_group_wide = 0, g_group_fsplit = 3, g_group_coop = 0, g_group_chunk0 = 0;
+static int g_group_chunks = 3, g_group_sort = 1, g_group_coop = 0;
 void sbve_set_group_sort(int on) { g_group_sort = on ? 1 : 0; }
 static unsigned long g_sort_violations = 0;
 unsigned long sbve_group_sort_violations() { return g_sort_violations; }
@@ -152,12 +152,8 @@ void sbve_key_cache(int enabled, u32 cap) {
 }
 void sbve_key_cache_stats(u32 out[3]) { out[0] = g_kc.count ? g_kc_count[0] : 0; out[1] = g_kc.count ? g_kc_count[1] : 0; out[2] = g_kc.count ? g_kc_count[2] : 0; }
 void sbve_set_group_chunks(int c) { g_group_chunks = c < 1 ? 1 : (c > 4 ? 4 : c); }
-static void emul_window_rows_fill(const u32* recs, bool top, int rpl, u32* tmp, apt* row);
-void sbve_set_group_wide(int wide, int fsplit) { g_group_wide = wide & 7;   // bit 0: one lane per entry in the rows step, bit 1: fill rows split over fsplit lanes
-    if (fsplit >= 1 && fsplit <= 4) g_group_fsplit = fsplit; }
-void sbve_set_group_chunk0(int w) { g_group_chunk0 = w >= 1 && w <= 32 ? w : 0; }   // two chunks: windows in the first one (GroupSync::chunk0)
+static void emul_window_rows_fill(const u32* recs, bool top, u32* tmp, apt* row);
 void sbve_set_group_coop(int on) { g_group_coop = on != 0; }     // k_group_coop instead of the G phase + Q launches (key-sorted step only)
-void sbve_set_group_parts(int p) { if (p == 2 || p == 4 || p == 8 || p == 16) g_group_parts = p; }
 // grouped form: generic tuples, keys grouped inside the call (p256_group.h), emulated sequentially.
 // stats_out[0..3] = groups, grouped tuples, ungrouped tuples, ungrouped tuples rejected for their key.
 void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bitmap, u32 min_count, u32 max_groups,
@@ -253,20 +249,18 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     auto valid_of = [&](u32 k) -> uint8_t* { return tslot[k] < kc.cap ? &g_kc_valid[tslot[k]] : &kvalid[k]; };
     memset(bitmap, 0, (n + 7) / 8);
     const int chunks = g_group_chunks;
-    const int rpl = g_group_parts == 2 ? 2 : (g_group_parts == 4 ? 4 : (g_group_parts == 16 ? 7 : 1));   // rows per lane of the fill kernel
     for (int c = 0; c < chunks; ++c) {
-        int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
-        if (chunks == 2 && g_group_chunk0 > 0) { j_first = c == 0 ? 0 : g_group_chunk0; j_end = c == 0 ? g_group_chunk0 : SBV_GTAB_WINDOWS; }
+        const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
         for (u32 k = 0; k < ngroups; ++k)
             if (cold[k]) {               // k_keytab29_chain: the four lanes of the key's quad in lockstep
                 keychain_quad_host q;
-                keychain29_run(q, tuples, k, g, jstate.data(), bases, valid_of(k), j_first, j_end - 1, (g_group_wide & 1) ? 0xFFu : 0x11u);
+                keychain29_run(q, tuples, k, g, jstate.data(), bases, valid_of(k), j_first, j_end - 1, 0x11u);
             }
         for (u32 k = 0; k < ngroups; ++k)
             for (int j = j_first; j < j_end && cold[k]; ++j) {
                 const size_t w = (size_t)k * SBV_GTAB_WINDOWS + j;
                 apt* row = table_of(k) + (size_t)j * SBV_GTAB_PER_WINDOW;
-                emul_window_rows_fill(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, rpl, tmpa.data(), row);
+                emul_window_rows_fill(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
             }
         const bool last = c + 1 == chunks;
         if (g_group_coop && g.sorted) {
@@ -320,33 +314,16 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }
 }
 
-// rows + fill of one (key, window) the way the launcher's two forms do it (k_keytab29_entries + k_keytab29_fill_parts, or
-// k_keytab29_rows + k_keytab29_fill)
-static void emul_window_rows_fill(const u32* recs, bool top, int rpl, u32* tmp, apt* row) {
-    if (g_group_wide & 1) {
-        for (int e = 0; e < SBV_KT29_ENTRY_LANES; ++e) keytab29_entry_lane(recs, e, top, row);
-    } else {
-        for (int which = 0; which < 2; ++which) {
-            if (which == 1 && top) continue;
-            keytab29_rows_lane(recs, which, top, tmp, row, (g_group_wide & 4) ? 8 : 16);
-        }
+// rows + fill of one (key, window) the way the launcher does it: k_keytab29_rows (two lanes), then k_keytab29_fill_sym (lane
+// a - 1 fills both sides of giant 16 a; the lanes run in descending order here so that a lane that wrongly depended on
+// another's output would show)
+static void emul_window_rows_fill(const u32* recs, bool top, u32* tmp, apt* row) {
+    for (int which = 0; which < 2; ++which) {
+        if (which == 1 && top) continue;
+        keytab29_rows_lane(recs, which, top, tmp, row);
     }
     if (top) return;
-    if ((g_group_wide & 4) && !(g_group_wide & 1)) {       // k_keytab29_fill_sym: lane a - 1 fills both sides of giant 16 a
-        for (int a = 8; a >= 1; --a) keytab29_fill_sym_lane(a, tmp + (size_t)(a - 1) * (SBV_KT29_FILL_TMP_WORDS / 2), row);
-        return;
-    }
-    if (g_group_wide & 2) {
-        const int split = g_group_fsplit, per = (15 + split - 1) / split;
-        for (int r = 0; r < 7 * split; ++r) {
-            const int a = 1 + r / split, b_first = 1 + (r % split) * per;
-            const int b_last = b_first + per - 1 > 15 ? 15 : b_first + per - 1;
-            if (b_first > 15) continue;
-            keytab29_fill_part_lane(a, b_first, b_last, tmp + (size_t)r * (15 * 9), row);
-        }
-        return;
-    }
-    for (int a = 1; a <= 7; a += rpl) keytab29_fill_lane(a, a + rpl - 1 > 7 ? 7 : a + rpl - 1, tmp, row);
+    for (int a = 8; a >= 1; --a) keytab29_fill_sym_lane(a, tmp + (size_t)(a - 1) * (SBV_KT29_FILL_TMP_WORDS / 2), row);
 }
 
 // n doublings of the affine point (x, y) (plain words) through the quad-cooperative chain of the table builder
@@ -379,7 +356,7 @@ int sbve_keychain_dbl(const u32* x8, const u32* y8, int n, u32* outx, u32* outy)
     return ok;
 }
 
-// The whole per-batch table of ONE key as the grouped step builds it (k_keytab29_chain -> k_keytab29_rows -> k_keytab29_fill,
+// The whole per-batch table of ONE key as the grouped step builds it (k_keytab29_chain -> k_keytab29_rows -> k_keytab29_fill_sym,
 // in `chunks` pieces): table = 33 x 128 entries of 16 words (x | y canonical words of the R = 2^261 domain).  key64 = Qx | Qy
 // big-endian.  Returns the key's pointFromAffine verdict.
 int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
@@ -394,10 +371,10 @@ int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
         keychain_quad_host q;
-        keychain29_run(q, tup.data(), 0, g, jstate.data(), bases.data(), &valid, j_first, j_end - 1, (g_group_wide & 1) ? 0xFFu : 0x11u);
+        keychain29_run(q, tup.data(), 0, g, jstate.data(), bases.data(), &valid, j_first, j_end - 1, 0x11u);
         for (int j = j_first; j < j_end; ++j) {
             apt* row = ktab + (size_t)j * SBV_GTAB_PER_WINDOW;
-            emul_window_rows_fill(bases.data() + (size_t)j * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, 1, tmpa.data(), row);
+            emul_window_rows_fill(bases.data() + (size_t)j * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
         }
     }
     return valid;

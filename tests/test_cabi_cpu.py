@@ -140,13 +140,16 @@ def test_shard_plan_split_logic():
     lcm(512, 8 * group) tuples — whole bitmap bytes and whole proposals per device — and no split at all below
     2 x min_per_device tuples ("only when a batch outgrows one GPU")."""
     n = 1 << 20
-    # plain tuples, 8 devices: 2^17 each... below the default per-device minimum of 2^18 -> 4 shards of 2^18
-    assert sbv.shard_plan(n, 8) == [0, 1 << 18, 2 << 18, 3 << 18, 1 << 20]
+    # plain tuples over many signers, 8 devices: the default per-device minimum is 2^17 (a cold step still gets faster down to
+    # 2^17 tuples, not below: DESIGN.md section 6) -> one 2^20 batch spans all 8 devices
+    assert sbv.shard_plan(n, 8) == [k << 17 for k in range(9)]
+    assert sbv.shard_plan(n, 8, min_per_device=1 << 18) == [0, 1 << 18, 2 << 18, 3 << 18, 1 << 20]
     assert sbv.shard_plan(8 * n, 8) == [k * n for k in range(9)]                      # weak scaling: 2^20 per device
     assert sbv.shard_plan(n, 1) == [0, n]
     assert sbv.shard_plan(100000, 8) == [0, 100000]                                   # small batch: one device (replica routing)
-    assert sbv.shard_plan((1 << 19) - 1, 8) == [0, (1 << 19) - 1]
-    assert sbv.shard_plan(1 << 19, 8) == [0, 1 << 18, 1 << 19]
+    assert sbv.shard_plan((1 << 18) - 1, 8) == [0, (1 << 18) - 1]
+    assert sbv.shard_plan(1 << 18, 8) == [0, 1 << 17, 1 << 18]
+    assert sbv.shard_plan(1 << 19, 8) == [k << 17 for k in range(5)]                  # 4 of 8 devices (idle ranks join the gather)
     # configs[3]: 50 000 proposals x 11 signatures over 8 devices, split BY PROPOSAL
     P, Q = 50000, 11
     plan = sbv.shard_plan(P * Q, 8, group=Q, min_per_device=1 << 16)
@@ -162,6 +165,40 @@ def test_shard_plan_split_logic():
     for n2, dev, grp in [(1000003, 8, 0), (550001, 8, 11), (2 ** 21 + 5, 3, 7), (600000, 2, 0)]:
         pl = sbv.shard_plan(n2, dev, group=grp, min_per_device=1 << 16)
         assert pl[0] == 0 and pl[-1] == n2 and all(a < b for a, b in zip(pl, pl[1:])) and len(pl) - 1 <= dev
+
+
+def test_configs3_spans_the_node():
+    """VERDICT r3 #3 / north_star configs[3]: "11 consenter sigs x 50k proposals sharded over 8 GPUs".  The plan the sharded
+    entry makes for THAT batch — its own per-device minimum (sbv_shard_min_for: a sample of the batch's keys) fed to
+    sbv_shard_plan — must use all 8 devices with whole proposals per shard; a batch of the same size over 1024 client keys
+    gets the many-signers minimum.  Pure host code: runs without a GPU."""
+    import numpy as np
+    P, Q, N = 50000, 11, 16
+    rng = np.random.default_rng(7)
+    keys16 = rng.integers(0, 256, size=(N, 64), dtype=np.uint8)
+    t = np.zeros((P * Q, 160), dtype=np.uint8)
+    t[:, :96] = rng.integers(0, 256, size=(P * Q, 96), dtype=np.uint8)
+    signer = (np.arange(P * Q) % Q + (np.arange(P * Q) // Q) % N) % N                  # 11 distinct consenters per proposal
+    t[:, 96:] = keys16[signer]
+    m = sbv.shard_min_for(t.tobytes(), P * Q, Q)
+    assert m == 1 << 16
+    plan = sbv.shard_plan(P * Q, 8, group=Q, min_per_device=m)
+    assert len(plan) == 9 and plan[0] == 0 and plan[-1] == P * Q                      # 8 shards on 8 devices
+    assert all(f % Q == 0 and f % 5632 == 0 for f in plan[1:-1])                      # whole proposals, whole bitmap bytes
+    assert plan[1] == 13 * 5632 == 73216                                              # 6 656 proposals per device, the last one 3 408
+    assert sbv.shard_plan(P * Q, 4, group=Q, min_per_device=m)[1] == 25 * 5632
+    assert len(sbv.shard_plan(P * Q, 2, group=Q, min_per_device=m)) == 3
+    # the same number of tuples over 1024 signers: many-signers minimum (2^17) -> 4 shards
+    keys1k = rng.integers(0, 256, size=(1024, 64), dtype=np.uint8)
+    t[:, 96:] = keys1k[np.arange(P * Q) % 1024]
+    m = sbv.shard_min_for(t.tobytes(), P * Q, 0)
+    assert m == 1 << 17
+    assert len(sbv.shard_plan(P * Q, 8, min_per_device=m)) - 1 == 4
+    # 33 signers in rotation: not "few" any more; 32 still is
+    for k, want in ((32, 1 << 16), (33, 1 << 17)):
+        t[:, 96:] = keys1k[np.arange(P * Q) % k]
+        assert sbv.shard_min_for(t.tobytes(), P * Q, 0) == want
+    assert sbv.shard_min_for(t.tobytes()[:160 * 5], 5, 0) == 1 << 16                  # tiny batches: every tuple is sampled
 
 
 def test_signing_refuses_without_a_gpu():

@@ -281,15 +281,13 @@ def test_key_comb_scalars_around_the_sign_flip_and_the_carry_window(emul, oracle
     emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
                                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
     stats = (ctypes.c_uint32 * 4)()
-    for chunks, wide in ((1, 3), (2, 1), (3, 2), (2, 4), (3, 0)):
+    for chunks in (1, 2, 3, 4):
         emul.sbve_set_group_chunks(chunks)
-        emul.sbve_set_group_wide(wide, 3)
         bm = ctypes.create_string_buffer((total + 7) // 8)
         emul.sbve_p256_verify_batch_grouped(blob, total, bm, 2, 16, 10, stats)
-        assert _bitmap_list(bm.raw, total) == want, (chunks, wide)
+        assert _bitmap_list(bm.raw, total) == want, chunks
         assert stats[1] == total
     emul.sbve_set_group_chunks(3)
-    emul.sbve_set_group_wide(0, 3)
 
 
 def test_fast_conditional_subtraction_is_exact_or_flags(emul):
@@ -369,13 +367,11 @@ def test_grouped_by_key_inside_the_batch_matches_generic(emul, oracle, golden_ve
     total = len(allt) // 160
     want = [v["accept"] for v in vs] + _bitmap_list(exp.raw, n) + [False] * 40
     stats = (ctypes.c_uint32 * 4)()
-    # (threshold, table slots, hash bits, chunks of windows the tables are built and consumed in, lanes per window);
+    # (threshold, table slots, hash bits, chunks of windows the tables are built and consumed in);
     # threshold 64 exercises the sampled count (every 8th tuple), the small ones the exact count
-    for ci, (min_count, max_groups, ht_bits, chunks, parts) in enumerate([(8, 64, 12, 3, 4), (8, 64, 12, 1, 8), (64, 64, 12, 4, 16), (1, 4096, 12, 2, 2),
-                                                                          (8, 3, 12, 3, 4), (2, 64, 11, 3, 8), (10**6, 64, 12, 3, 4)]):
+    for min_count, max_groups, ht_bits, chunks in [(8, 64, 12, 3), (8, 64, 12, 1), (64, 64, 12, 4), (1, 4096, 12, 2),
+                                                   (8, 3, 12, 3), (2, 64, 11, 3), (10**6, 64, 12, 3)]:
         emul.sbve_set_group_chunks(chunks)
-        emul.sbve_set_group_parts(parts)
-        emul.sbve_set_group_wide(ci % 4, 1 + ci % 4)       # every combination of the table builders' forms, every fill split
         bm = ctypes.create_string_buffer((total + 7) // 8)
         emul.sbve_p256_verify_batch_grouped(allt, total, bm, min_count, max_groups, ht_bits, stats)
         got = _bitmap_list(bm.raw, total)
@@ -391,8 +387,6 @@ def test_grouped_by_key_inside_the_batch_matches_generic(emul, oracle, golden_ve
         if min_count == 10**6:
             assert stats[0] == 0 and stats[2] + stats[3] == total and stats[3] >= 40    # the repeated off-curve key at least
     emul.sbve_set_group_chunks(3)
-    emul.sbve_set_group_parts(4)
-    emul.sbve_set_group_wide(0, 3)
 
 
 def test_key_sorted_grouped_list_equals_compaction_order(emul, oracle, golden_vectors):
@@ -566,7 +560,6 @@ def test_coop_form_of_the_grouped_step_equals_the_phased_one(emul, oracle, golde
         for ci, (cache, min_count, max_groups, chunks) in enumerate([(0, 2, 4096, 2), (0, 8, 64, 1), (0, 2, 3, 3), (1, 2, 4096, 2), (1, 2, 4096, 2), (0, 2, 4096, 2)]):
             emul.sbve_key_cache(cache, 512)
             emul.sbve_set_group_chunks(chunks)
-            emul.sbve_set_group_chunk0(7 if ci == 5 else 0)         # an uneven split of the windows: 7 + 26 (GroupSync::chunk0)
             res = []
             for coop in (1, 0):
                 emul.sbve_set_group_coop(coop)
@@ -580,7 +573,6 @@ def test_coop_form_of_the_grouped_step_equals_the_phased_one(emul, oracle, golde
         assert emul.sbve_coop_disagreements() == before
     finally:
         emul.sbve_set_group_coop(0)
-        emul.sbve_set_group_chunk0(0)
         emul.sbve_set_group_chunks(3)
         emul.sbve_key_cache(0, 0)
 

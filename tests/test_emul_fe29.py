@@ -266,11 +266,8 @@ def test_key_table_of_the_key_that_wrapped_a_limb(emul):
                         "cec0e52c50735a5480607398a6880d494a83013fa269b1442a36466fe2fcfee1")
     q = (int.from_bytes(key[:32], "big"), int.from_bytes(key[32:], "big"))
     tab = (ctypes.c_uint32 * (33 * 128 * 16))()
-    # every form of rows + fill: bit 0 of `wide` = one lane per entry from the chain's 8 records per window, bit 1 = fill rows in
-    # 1..4 parts, bit 2 = the symmetric fill (babies 1..8 only, both sides of every giant from one inverse); 0 = the chains of
-    # additions and whole rows (the default)
-    for wide, fsplit, chunks in ((3, 3, 2), (3, 3, 3), (3, 1, 1), (2, 2, 3), (2, 4, 2), (1, 3, 2), (4, 3, 2), (4, 3, 3), (0, 3, 2), (0, 3, 3)):
-        emul.sbve_set_group_wide(wide, fsplit)
+    # rows (babies 1..8, giants 16..128) + the symmetric fill (both sides of every giant from one inverse), in 1..4 chunks of windows
+    for chunks in (1, 2, 3, 4):
         for k in range(len(tab)):
             tab[k] = 0xA5A5A5A5
         assert emul.sbve_keytab_build(key, chunks, tab) == 1
@@ -280,8 +277,7 @@ def test_key_table_of_the_key_that_wrapped_a_limb(emul):
             for m_ in ((1,) if j == 32 else (range(1, 129) if every else (1, 2, 3, 7, 11, 13, 14, 15, 16, 17, 31, 32, 33, 48, 80, 100, 112, 113, 127, 128))):
                 e = tab[(j * 128 + m_ - 1) * 16:(j * 128 + m_) * 16]
                 want = ec.pt_mul(m_, base)
-                assert (wval(e[:8]), wval(e[8:])) == (want[0] * R % P, want[1] * R % P), (wide, fsplit, chunks, j, m_)
-    emul.sbve_set_group_wide(0, 3)
+                assert (wval(e[:8]), wval(e[8:])) == (want[0] * R % P, want[1] * R % P), (chunks, j, m_)
     off = bytearray(key)
     off[63] ^= 1
     assert emul.sbve_keytab_build(bytes(off), 2, tab) == 0          # pointFromAffine refuses it (key29_load)

@@ -192,7 +192,6 @@ def test_sharded_entry_world_of_one_with_rccl_and_quorum_bits(oracle):
 
 
 # ---- key-affine partition: device g verifies the tuples of "its" keys only ------------------------------
-@pytest.mark.skipif(os.environ.get("SBV_TEST_STRESS") != "1", reason="first run belongs to the next round's GPU session (tools/gpu_r04a.sh): SBV_TEST_STRESS=1")
 def test_two_threads_in_the_sharded_entry_keep_their_own_bitmaps(oracle):
     """the all-gather phase of a sharded call used to run without the device's lock, so a second caller
     could overwrite (or free) the gather buffer in between.  One multi-shard call at a time now owns the gather buffers

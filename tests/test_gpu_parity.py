@@ -346,10 +346,10 @@ def test_in_step_key_grouping_equals_generic(gpu, oracle, golden_vectors):
         gpu.set_grouping(True, 131072, 64, 2048)
 
 
-@pytest.mark.skipif(os.environ.get("SBV_TEST_COOP") != "1", reason="k_group_coop is off by default until it has been measured: SBV_TEST_COOP=1 runs it")
 def test_coop_form_of_the_grouped_step_on_the_gpu(oracle, golden_vectors):
-    """SBV_GROUP_COOP_MAX: batches up to that size finish in one launch of eight lanes per grouped tuple (k_group_coop).  In a
-    child process (the knob is read when the context is created): golden vectors + a seeded batch + a repeated invalid key,
+    """Batches up to 2^15 tuples finish in one launch of eight lanes per grouped tuple (k_group_coop; the default since round 4,
+    SBV_GROUP_COOP_MAX=0 switches it off).  In child processes (the knob is read when the context is created), once as
+    shipped and once with the phased form every larger batch takes: golden vectors + a seeded batch + a repeated invalid key,
     key cache cold and warm, thresholds that leave tuples on the doubling kernel; verdicts = the oracle's."""
     import subprocess
     import sys
