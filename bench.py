@@ -88,6 +88,68 @@ def cpu_baseline(tuples, n, gpu_bitmap):
         res["openssl_parity_with_gpu_on_sample"] = out.raw[:s2 // 8] == bytes(gpu_bitmap[:s2 // 8])
     return res
 
+def _host_cores():
+    visible = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = visible
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    return max(1, min(visible, affinity, int(quota + 0.999) if quota else visible))
+
+
+def cpu_baseline_variant(scheme, tuples, n, gpu_bitmap):
+    """CPU baseline of a variant scheme's leg: OpenSSL on this box's host cores over a bounded sample of the SAME
+    batch (about 2 s of wall clock), its bitmap compared with the device's on the sample.  kind "port": the reference's stock
+    verifier would be Go's crypto/ed25519 (absent: no Go toolchain); secp256k1 is not in Go's standard library at all.
+    oracle/ is touched here as the thing timed and as the checker only."""
+    ssl_path = os.path.join(ROOT, "oracle", "libsbv_openssl.so")
+    if not os.path.exists(ssl_path):
+        return {"error": "oracle/libsbv_openssl.so not built (libcrypto absent)"}
+    ssl = ctypes.CDLL(ssl_path)
+    cores = _host_cores()
+    if scheme == "ed25519":
+        ssl.sbvssl_ed25519_verify_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+        run = lambda m, out, th: ssl.sbvssl_ed25519_verify_gen_batch(SEED, tuples.ctypes.data, 0, m, out, th)   # noqa: E731
+        what = "EVP_DigestVerify(Ed25519) on (A, message, R|S) of"
+    else:
+        ssl.sbvssl_k256_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+        run = lambda m, out, th: ssl.sbvssl_k256_verify_batch(tuples.ctypes.data, m, out, th)                      # noqa: E731
+        what = "ECDSA_do_verify(NID_secp256k1) on"
+    out = ctypes.create_string_buffer(max(1, (n + 7) // 8))
+    probe = min(n, 64)
+    t0 = time.perf_counter()
+    run(probe, out, 1)
+    per_thread = probe / (time.perf_counter() - t0)
+    sample = int(min(n, max(512, per_thread * cores * 2.0))) & ~7
+    t0 = time.perf_counter()
+    run(sample, out, cores)
+    dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "verifies/s", "cores": cores, "kind": "port",
+            "sample": f"OpenSSL {what} the first {sample} tuples of the same batch, {cores} threads, {dt:.2f} s",
+            "parity_with_gpu_on_sample": out.raw[:sample // 8] == bytes(gpu_bitmap[:sample // 8]), "one_thread_value": per_thread}
+
+
+def variant_roofline(kernel, bytes_per_verify, lanes, share, dominant_us, dominant_launches):
+    """roofline object of a variant leg: the dominant kernel (its Q phase) is charged `share` of a tuple's algorithmic bytes per
+    launch — the comb additions one launch executes / all comb additions of a tuple's stage B — over its live lanes, divided by
+    its average launch duration (HIP-event pairs on the launch stream inside the leg's timed loop: sbv_profile_read_dominant)."""
+    if not dominant_launches:
+        return None
+    kern_s = dominant_us / dominant_launches * 1e-6
+    achieved = bytes_per_verify * lanes * share / kern_s / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "kernel": kernel, "avg_launch_us": dominant_us / dominant_launches, "launches": int(dominant_launches), "units_per_launch": int(lanes),
+            "share_of_a_tuples_stage_b_per_launch": share,
+            "note": "integer-ALU bound like the P-256 step (DESIGN.md 4.8); traffic: no PMC pass was run for this leg"}
+
+
 def leg_warm_cache(sbv, torch, d_tuples, d_bitmap, valid, n, steps, stream):
     """The same batch with the persistent key-table cache ON (the library's default): after the first call the 1024 keys'
     tables are resident, later calls skip the doubling chains and the table kernels.  Reported beside the headline, never
@@ -194,7 +256,7 @@ def leg_sharded(sbv, tuples, valid, n, steps):
             "last_call_us": {"h2d": info.h2d_us, "kernels": info.kernels_us, "gather": info.gather_us, "total": info.total_us}}
 
 
-def leg_ed25519(sbv, torch, n, steps, stream):
+def leg_ed25519(sbv, torch, n, steps, stream, cpu=False):
     """BASELINE.json configs[4]: 2^20 Ed25519 signatures, 1024 keys, 7/8 valid, R|S|A|k tuples resident in HBM."""
     import numpy as np
     cache = f"/tmp/sbv_ed_batch_{n}.npz"
@@ -216,17 +278,34 @@ def leg_ed25519(sbv, torch, n, steps, stream):
     d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
     sbv.ed25519_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
+    sbv.profile_read_dominant(); sbv.profile_read()
+    sbv.profile_enable(2)              # event pairs around the dominant kernel's launches only, on the launch stream
     t0 = time.perf_counter()
     for _ in range(steps):
         sbv.ed25519_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"metric": "Ed25519 verifies/sec at batch=1M (configs[4])", "value": n * steps / dt, "unit": "verifies/s",
-            "ms_per_step": 1e3 * dt / steps, "bitmap_correct": bool((d_b.cpu().numpy() == expect).all()),
-            "algorithmic_GBps": 128.125 * n * steps / dt / 1e9}
+    dom_us, dom_launches = sbv.profile_read_dominant()
+    sbv.profile_read()
+    sbv.profile_enable(False)
+    got = d_b.cpu().numpy()
+    out = {"metric": "Ed25519 verifies/sec at batch=1M (configs[4])", "value": n * steps / dt, "unit": "verifies/s",
+           "ms_per_step": 1e3 * dt / steps, "bitmap_correct": bool((got == expect).all()),
+           "algorithmic_GBps": 128.125 * n * steps / dt / 1e9}
+    # k_ed_qphase: one launch per chunk of the 32 key-comb windows; a tuple's stage B is 16 additions from the comb of B (G phase)
+    # + 32 from the key's comb, so a launch executes (32 / launches per step) / 48 of it.  Lanes = every tuple of the batch but
+    # the few whose key repeats too rarely to be grouped (1024 keys x 1024 uses: none).
+    per_step = max(1, int(round(dom_launches / max(1, steps))))
+    _, lanes, n_ung, n_rej = sbv.last_group_stats()
+    if lanes + n_ung + n_rej != n:
+        lanes = n
+    out["roofline"] = variant_roofline("k_ed_qphase", 128.125, lanes, (32.0 / per_step) / 48.0, dom_us, dom_launches)
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline_variant("ed25519", tuples, n, got)
+    return out
 
 
-def leg_secp256k1(sbv, torch, n, steps, stream):
+def leg_secp256k1(sbv, torch, n, steps, stream, cpu=False):
     """The "other curves" variant: n secp256k1 signatures, 1024 keys, 7/8 valid, 160-byte tuples resident in
     HBM, through the grouped step of this curve (k256_group.h: per-batch key combs, every step cold — there is no key cache
     for this curve); `one_lane` is the same batch with grouping off (256 doublings per signature).  Signatures come from the
@@ -251,14 +330,30 @@ def leg_secp256k1(sbv, torch, n, steps, stream):
     d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
     sbv.secp256k1_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
+    sbv.profile_read_dominant(); sbv.profile_read()
+    sbv.profile_enable(2)
     t0 = time.perf_counter()
     for _ in range(steps):
         sbv.secp256k1_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dom_us, dom_launches = sbv.profile_read_dominant()
+    sbv.profile_read()
+    sbv.profile_enable(False)
+    got = d_b.cpu().numpy()
     out = {"metric": "ECDSA secp256k1 verifies/sec at batch=1M (grouped step)", "value": n * steps / dt, "unit": "verifies/s", "tuples": n,
-           "ms_per_step": 1e3 * dt / steps, "bitmap_correct": bool((d_b.cpu().numpy() == expect).all()),
+           "ms_per_step": 1e3 * dt / steps, "bitmap_correct": bool((got == expect).all()),
            "algorithmic_GBps": 160.125 * n * steps / dt / 1e9}
+    # k_k256_qphase: two launches per step over the key-sorted list; the same accounting as the P-256 headline (13 additions from
+    # the 20-bit comb of G + 32.22 from the key's comb per tuple; the ~5 % of tuples with corrupted keys are not on the list)
+    per_step = max(1, int(round(dom_launches / max(1, steps))))
+    _, lanes, n_ung, n_rej = sbv.last_group_stats()       # the grouping counters are shared by the three schemes' grouped steps
+    if lanes + n_ung + n_rej != n:
+        lanes = n
+    out["roofline"] = variant_roofline("k_k256_qphase", 160.125, lanes, (Q_ADDS_PER_TUPLE / per_step) / (G_ADDS_PER_TUPLE + Q_ADDS_PER_TUPLE),
+                                       dom_us, dom_launches)
+    if cpu:
+        out["cpu_baseline"] = cpu_baseline_variant("secp256k1", tuples, n, got)
     sbv.set_grouping(False)
     try:
         sbv.secp256k1_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
@@ -679,8 +774,8 @@ def main():
                          ("all_valid", lambda: leg_all_valid(sbv, synth, torch, n, max(2, args.steps // 2), stream)),
                          ("end_to_end", lambda: leg_end_to_end(sbv, tuples, valid, n, max(2, args.steps // 2))),
                          ("sharded_entry", lambda: leg_sharded(sbv, tuples, valid, n, max(2, args.steps // 2))),
-                         ("ed25519", lambda: leg_ed25519(sbv, torch, n, max(2, args.steps // 2), stream)),
-                         ("secp256k1", lambda: leg_secp256k1(sbv, torch, n, max(2, args.steps // 2), stream)),
+                         ("ed25519", lambda: leg_ed25519(sbv, torch, n, max(2, args.steps // 2), stream, not args.no_cpu_baseline)),
+                         ("secp256k1", lambda: leg_secp256k1(sbv, torch, n, max(2, args.steps // 2), stream, not args.no_cpu_baseline)),
                          ("projected_strong_scaling", lambda: leg_projected_strong_scaling(sbv, torch, d_tuples, valid, n, stream, 1e3 * elapsed / args.steps)),
                          ("m2_commit_quorum_us", lambda: leg_m2(tuples, n)),
                          ("verify_proposal_k10000_us", leg_proposals),

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_qph
 
 hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, const GroupBuffers& b, const EdGroupBuffers& eb,
                                          u32* d_qtab, const aniels* d_btab, uint8_t* d_bitmap, hipStream_t stream,
-                                         const GroupSync& y) {
+                                         const GroupSync& y, hipEvent_t* prof, int* prof_pairs) {
     if (n == 0) return hipSuccess;
     GroupState g;
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
@@ -154,8 +154,10 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
                            j_first, j_count, parts);
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
+        if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
         hipLaunchKernelGGL(k_ed_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.gacc, b.gacc_cap,
                            eb.okb, b.acc, j_first, j_end, c + 1 == chunks ? 1 : 0);
+        if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
     // side_a, behind the last bases: the ungrouped list
     SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_split, 0));
@@ -164,6 +166,7 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     SBV_TRY(hipStreamWaitEvent(stream, y.ev_generic, 0));
     hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
 #undef SBV_TRY
+    if (prof && prof_pairs) *prof_pairs = chunks;
     return hipGetLastError();
 }
 

@@ -21,7 +21,7 @@ struct EdGroupBuffers {
 // tuple, stride b.gacc_cap); ev_fork of `y` must have been recorded on `stream` before the call.
 hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, const GroupBuffers& b, const EdGroupBuffers& eb,
                                          u32* d_qtab, const aniels* d_btab, uint8_t* d_bitmap, hipStream_t stream,
-                                         const GroupSync& y);
+                                         const GroupSync& y, hipEvent_t* prof = nullptr, int* prof_pairs = nullptr);   // prof: 2 * chunks events, a pair around every k_ed_qphase launch
 // message front end: raw signatures / keys / messages -> 128-byte tuples on the device (sha512_dev.h)
 hipError_t launch_ed_msg_frontend(const uint8_t* d_sigs, const uint8_t* d_pks, const uint8_t* d_msgs, const u64* d_moff, size_t n,
                                   u32* d_tuples, hipStream_t stream);

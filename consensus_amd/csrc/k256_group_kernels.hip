@@ -132,7 +132,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_qphase(Scratch s, 
 // stage A + stage B of a grouped secp256k1 batch.  ev_fork must have been recorded on `stream` first.  The per-batch area of the
 // comb pool (b.ktab + kc.cap keys, b.kvalid + kc.cap) holds this batch's tables; group k uses slot k of it.
 hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_in, size_t n, const GroupBuffers& b, u32* d_qtab,
-                                      const kapt* d_gtab, const kapt* d_gcomb, int gcomb_bits, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y) {
+                                      const kapt* d_gtab, const kapt* d_gcomb, int gcomb_bits, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y, hipEvent_t* prof, int* prof_pairs) {
     if (n == 0) return hipSuccess;
     GroupState g;
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
@@ -184,11 +184,14 @@ hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         hipLaunchKernelGGL(k_k256_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, ktab, j_first, j_count);
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
+        if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
         hipLaunchKernelGGL(k_k256_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, ktab, kvalid, b.gacc, b.acc, j_first, j_end,
                            c + 1 == chunks ? 1 : 0);
+        if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
     hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
 #undef SBV_TRY
+    if (prof && prof_pairs) *prof_pairs = chunks;
     return hipGetLastError();
 }
 

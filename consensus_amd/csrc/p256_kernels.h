@@ -96,7 +96,8 @@ void host_build_k256_gtable(kapt* out);
 // grouped step on this curve (k256_group_kernels.hip): stage A + stage B; ev_fork recorded on `stream` by the caller
 // d_gtab: the 16-bit comb (the generic lanes of the ungrouped list), d_gcomb: the `gcomb_bits`-wide comb of the G phase
 hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b, u32* d_qtab,
-                                      const kapt* d_gtab, const kapt* d_gcomb, int gcomb_bits, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y);
+                                      const kapt* d_gtab, const kapt* d_gcomb, int gcomb_bits, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y,
+                                      hipEvent_t* prof = nullptr, int* prof_pairs = nullptr);      // prof: 4 events, a pair around each of the two k_k256_qphase launches
 void host_build_k256_gcomb(int bits, kapt* out);     // ceil(257 / bits) << (bits - 1) entries
 #define SBV_K256_GTABLE_ENTRIES ((size_t)17 * 32768)
 

@@ -293,12 +293,12 @@ int ensure_ed_group_buffers(Context& c, size_t n) {
 }
 
 // one chunk (n <= cap) of Ed25519 tuples on `stream`: grouped step or the one-lane kernel
-int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream) {
+int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream, hipEvent_t* dom = nullptr, int* dom_pairs = nullptr) {
     if (c.group_enabled && n >= c.group_min_batch_ed) {
         const int rc = ensure_ed_group_buffers(c, n);
         if (rc != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
-        HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify_grouped(d_tuples, n, c.grp, c.edgrp, c.d_qtab, c.d_btab, d_bitmap, stream, c.gsync));
+        HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify_grouped(d_tuples, n, c.grp, c.edgrp, c.d_qtab, c.d_btab, d_bitmap, stream, c.gsync, dom, dom_pairs));
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify(d_tuples, n, c.d_qtab, c.d_btab, d_bitmap, stream));
@@ -1031,10 +1031,17 @@ extern "C" int sbv_ed25519_verify_batch_dev(const void* d_tuples, size_t n, void
             end = c.prof_events[c.prof_used + 2];
             c.prof_used += 3;
         }
-        if ((rc = enqueue_ed25519(c, src + off * 128, m, dst + off / 8, stream)) != SBV_OK) {
+        hipEvent_t* dom = nullptr;                // event pairs around the dominant kernel (k_ed_qphase, one launch per chunk of windows)
+        int dom_pairs = 0;
+        if (c.profiling) {
+            while (c.prof_dom_used + 2 * SBV_GROUP_MAX_CHUNKS > c.prof_dom.size()) { hipEvent_t ev; HIP_TRY(SBV_EDEVICE, hipEventCreate(&ev)); c.prof_dom.push_back(ev); }
+            dom = c.prof_dom.data() + c.prof_dom_used;
+        }
+        if ((rc = enqueue_ed25519(c, src + off * 128, m, dst + off / 8, stream, dom, &dom_pairs)) != SBV_OK) {
             if (hipEventRecord(c.busy, stream) == hipSuccess) c.busy_valid = true;
             return rc;
         }
+        if (c.profiling) c.prof_dom_used += 2 * (size_t)dom_pairs;
         if (end) HIP_TRY(SBV_EDEVICE, hipEventRecord(end, stream));
     }
     HIP_TRY(SBV_EDEVICE, hipEventRecord(c.busy, stream));
@@ -1111,7 +1118,7 @@ int ensure_k256_table(Context& c) {
 
 namespace {
 // one chunk (m <= cap) of secp256k1 tuples on `stream`: the grouped step (k256_group_kernels.hip) or the one-lane kernel
-int enqueue_k256(Context& c, const uint8_t* d_tuples, size_t m, uint8_t* d_bitmap, hipStream_t stream) {
+int enqueue_k256(Context& c, const uint8_t* d_tuples, size_t m, uint8_t* d_bitmap, hipStream_t stream, hipEvent_t* dom = nullptr, int* dom_pairs = nullptr) {
     const sbv::Scratch s = scratch_view(c);
     if (c.group_enabled && m >= c.group_min_batch_k256) {
         int rc = ensure_group_buffers(c, m);
@@ -1121,7 +1128,7 @@ int enqueue_k256(Context& c, const uint8_t* d_tuples, size_t m, uint8_t* d_bitma
         sbv::GroupSync y = c.gsync;                 // second table stream: the context's own, when the caller's runs the step (enqueue() says why)
         if (y.tstreams > 1 && stream != c.stream) y.side_t = c.stream;
         else y.tstreams = 1;
-        HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify_grouped(d_tuples, s, m, c.grp, c.d_qtab, c.d_k256_gtab, c.d_k256_gcomb, c.k256_gbits, d_bitmap, stream, y));
+        HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify_grouped(d_tuples, s, m, c.grp, c.d_qtab, c.d_k256_gtab, c.d_k256_gcomb, c.k256_gbits, d_bitmap, stream, y, dom, dom_pairs));
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify(d_tuples, m, s, c.d_qtab, c.d_k256_gtab, d_bitmap, stream));
@@ -1144,7 +1151,14 @@ extern "C" int sbv_secp256k1_verify_batch_dev(const void* d_tuples, size_t n, vo
     uint8_t* dst = static_cast<uint8_t*>(d_bitmap);
     for (size_t off = 0; off < n && rc == SBV_OK; off += kMaxChunk) {
         const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
-        rc = enqueue_k256(c, src + off * 160, m, dst + off / 8, stream);
+        hipEvent_t* dom = nullptr;                // event pairs around the dominant kernel (k_k256_qphase), read by sbv_profile_read_dominant
+        int dom_pairs = 0;
+        if (c.profiling) {
+            while (c.prof_dom_used + 2 * SBV_GROUP_MAX_CHUNKS > c.prof_dom.size()) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) { g_err = "hipEventCreate failed"; return SBV_EDEVICE; } c.prof_dom.push_back(ev); }
+            dom = c.prof_dom.data() + c.prof_dom_used;
+        }
+        rc = enqueue_k256(c, src + off * 160, m, dst + off / 8, stream, dom, &dom_pairs);
+        if (rc == SBV_OK && c.profiling) c.prof_dom_used += 2 * (size_t)dom_pairs;
     }
     if (hipEventRecord(c.busy, stream) == hipSuccess) c.busy_valid = true;       // the scratch stays ordered behind whatever was enqueued
     return rc;

@@ -95,6 +95,31 @@ int sbvh_verify_consenter_sig(void* h, uint64_t id, const void* value, size_t vl
     if (aux_len) *aux_len = st.ok() ? put(aux, aux_out, aux_cap) : 0;
     return st.code;
 }
+// Test hook for the per-object Proposal.Digest() memo (formats.h: ProposalDigestSlot): ONE Proposal object goes through
+// VerifyProposal and then VerifyConsenterSig, as internal/bft/view.go does with v.inFlightProposal (view.go:555, 834).
+// Returns VerifyProposal's code | VerifyConsenterSig's code << 8 | flags << 16; flags: 1 = VerifyProposal left a digest slot
+// on the object (the prefetch), 2 = the slot's digest equals a direct computation, 4 = the worker had released the caller's
+// object when VerifyProposal returned.
+int sbvh_test_proposal_then_vote(void* h, uint64_t id, const void* value, size_t vl, const void* msg, size_t ml,
+                                 const void* payload, size_t pl, const void* header, size_t hl, const void* meta, size_t mtl, int64_t vseq) {
+    Verifier& V = *((VHandle*)h)->v;
+    const Proposal p = make_prop(payload, pl, header, hl, meta, mtl, vseq);
+    std::vector<RequestInfo> infos;
+    const Status st1 = V.VerifyProposal(p, &infos);
+    int flags = 0;
+    std::shared_ptr<ProposalDigestSlot> slot = std::atomic_load(&p.digest_slot);
+    if (slot) {
+        flags |= 1;
+        std::unique_lock<std::mutex> lk(slot->mu);
+        if (slot->released) flags |= 4;
+        slot->cv.wait(lk, [&] { return slot->ready; });
+        if (slot->digest == proposal_digest_raw(p)) flags |= 2;
+    }
+    Signature s; s.id = id; s.value = B(value, vl); s.msg = B(msg, ml);
+    bytes aux;
+    const Status st2 = V.VerifyConsenterSig(s, p, &aux);
+    return (st1.code & 0xff) | ((st2.code & 0xff) << 8) | (flags << 16);
+}
 size_t sbvh_auxiliary_data(void* h, const void* msg, size_t ml, void* out, size_t cap) {
     return put(((VHandle*)h)->v->AuxiliaryData(B(msg, ml)), out, cap);
 }

@@ -8,6 +8,9 @@
 #pragma once
 #include <stdint.h>
 
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -16,9 +19,24 @@ namespace sbvhost {
 
 typedef std::string bytes;
 
+// Proposal.Digest() of one Proposal OBJECT, computed at most once (Verifier::digest_of / digest_prefetch).  The reference
+// recomputes it three times per sequence (internal/bft/view.go:435, 443, 524) and every VerifyConsenterSig must bind its
+// message to it; it passes the SAME proposal value to VerifyProposal (view.go:555) and, a round trip later, to every
+// VerifyConsenterSig of that sequence (view.go:834).  The memo therefore travels with the object — no table of proposals, no
+// payload comparison, no copy kept — as a lazily computed field does.  Contract: a Proposal is immutable once a Verifier has
+// seen it (as in the reference, where these are protobuf-decoded bytes nobody writes to); copies share the slot.
+struct ProposalDigestSlot {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool ready = false;       // digest is final
+    bool released = false;    // the worker no longer reads the caller's Proposal (it holds the marshalled bytes)
+    bytes digest;
+};
+
 struct Proposal {                 // pkg/types/types.go:18-23
     bytes payload, header, metadata;
     int64_t verification_sequence = 0;
+    mutable std::shared_ptr<ProposalDigestSlot> digest_slot;   // see ProposalDigestSlot; never part of the value
 };
 struct Signature {                // pkg/types/types.go:25-29
     uint64_t id = 0;

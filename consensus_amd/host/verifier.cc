@@ -407,6 +407,12 @@ Verifier::Verifier(std::shared_ptr<Backend> be, const VerifierOptions& opt)
     : opt_(opt), co_(be, opt.coalesce_max, opt.coalesce_wait) {}
 
 Verifier::~Verifier() {
+    {
+        std::lock_guard<std::mutex> lk(dw_mu_);
+        dw_stop_ = true;
+        dw_cv_.notify_all();
+    }
+    if (dw_thread_.joinable()) dw_thread_.join();       // drains the queue first: a queued job's slot must become ready
     for (Staging* s : {&st_msgs_, &st_sigs_, &st_moff_, &st_soff_, &st_slots_}) staging_release(*s);
 }
 
@@ -547,46 +553,67 @@ Status Verifier::VerifySignature(const Signature& s) {        // viewchanger.go:
     return verify_one(q, s.msg, s.value, slot);
 }
 
-// Proposal.Digest() once per proposal, also under concurrency: the <= N-1 goroutines of View.processCommits
-// (view.go:537-541) all ask for the digest of the same fresh proposal at the same moment.  The first caller
-// publishes a pending slot and computes; the others find the slot and wait for it instead of hashing the same
-// megabytes N-1 times (config 3: K = 10 000 requests, ~4 ms of SHA-256 per computation).
-bytes Verifier::digest_memo(const Proposal& p) {
-    std::shared_ptr<DigestSlot> slot;
-    bool mine = false;
-    {
-        std::lock_guard<std::mutex> lk(digest_mu_);
-        for (const DigestEntry& e : digest_cache_)
-            if (e.p.verification_sequence == p.verification_sequence && e.p.header == p.header && e.p.metadata == p.metadata &&
-                e.p.payload == p.payload) {
-                slot = e.slot;
-                break;
-            }
-        if (!slot) {
-            slot = std::make_shared<DigestSlot>();
-            mine = true;
-            DigestEntry e{p, slot};
-            if (digest_cache_.size() < 4) digest_cache_.push_back(std::move(e));
-            else { digest_cache_[digest_next_] = std::move(e); digest_next_ = (digest_next_ + 1) % 4; }
+// Proposal.Digest() once per Proposal object (formats.h: ProposalDigestSlot), also under concurrency: the <= N-1 goroutines
+// of View.processCommits (view.go:537-541) all ask for the digest of the same proposal at the same moment.  Whoever installs
+// the slot computes (or, from VerifyProposal, hands the computation to the worker); everybody else waits for `ready`.
+bytes Verifier::digest_of(const Proposal& p) {
+    std::shared_ptr<ProposalDigestSlot> slot = std::atomic_load(&p.digest_slot);
+    if (!slot) {
+        auto fresh = std::make_shared<ProposalDigestSlot>();
+        if (std::atomic_compare_exchange_strong(&p.digest_slot, &slot, fresh)) {
+            bytes d = proposal_digest_raw(p);
+            std::lock_guard<std::mutex> lk(fresh->mu);
+            fresh->digest = std::move(d);
+            fresh->ready = fresh->released = true;
+            fresh->cv.notify_all();
+            return fresh->digest;
         }
-    }
-    if (mine) {
-        bytes d = proposal_digest_raw(p);
-        std::lock_guard<std::mutex> lk(slot->mu);
-        slot->digest = std::move(d);
-        slot->ready = true;
-        slot->cv.notify_all();
-        return slot->digest;
     }
     std::unique_lock<std::mutex> lk(slot->mu);
     slot->cv.wait(lk, [&] { return slot->ready; });
     return slot->digest;
 }
 
+void Verifier::digest_prefetch(const Proposal& p, std::shared_ptr<ProposalDigestSlot>* slot_out) {
+    std::shared_ptr<ProposalDigestSlot> slot = std::atomic_load(&p.digest_slot);
+    if (slot) return;                                   // computed, or on its way
+    auto fresh = std::make_shared<ProposalDigestSlot>();
+    if (!std::atomic_compare_exchange_strong(&p.digest_slot, &slot, fresh)) return;
+    *slot_out = fresh;
+    std::lock_guard<std::mutex> lk(dw_mu_);
+    if (!dw_thread_.joinable()) dw_thread_ = std::thread([this] { digest_worker(); });
+    dw_jobs_.push_back(DigestJob{&p, fresh});
+    dw_cv_.notify_one();
+}
+
+void Verifier::digest_worker() {
+    for (;;) {
+        DigestJob job;
+        {
+            std::unique_lock<std::mutex> lk(dw_mu_);
+            dw_cv_.wait(lk, [&] { return dw_stop_ || !dw_jobs_.empty(); });
+            if (dw_jobs_.empty()) return;               // stop requested and nothing left
+            job = dw_jobs_.front();
+            dw_jobs_.erase(dw_jobs_.begin());
+        }
+        bytes m = asn1_marshal_proposal(*job.p);        // the only read of the caller's object
+        {
+            std::lock_guard<std::mutex> lk(job.slot->mu);
+            job.slot->released = true;
+            job.slot->cv.notify_all();
+        }
+        bytes d = sha256(m);
+        std::lock_guard<std::mutex> lk(job.slot->mu);
+        job.slot->digest = std::move(d);
+        job.slot->ready = true;
+        job.slot->cv.notify_all();
+    }
+}
+
 Status Verifier::VerifyConsenterSig(const Signature& s, const Proposal& prop, bytes* aux) {   // view.go:631, 834
     bytes binding, a;
     if (!consenter_msg_split(s.msg, &binding, &a)) return Status::Invalid("malformed signature message");
-    if (binding != digest_memo(prop)) return Status::Invalid("signature message does not match proposal");
+    if (binding != digest_of(prop)) return Status::Invalid("signature message does not match proposal");
     Status st = VerifySignature(s);
     if (!st.ok()) return st;
     if (aux) *aux = a;
@@ -639,6 +666,19 @@ Status Verifier::VerifyProposal(const Proposal& p, std::vector<RequestInfo>* req
     if (!payload_split_views(p.payload, &reqs)) return Status::Invalid("malformed proposal payload");
     if (trace) t_split = now();
     if ((uint64_t)p.verification_sequence != VerificationSequence()) return Status::Invalid("verification sequence mismatch");
+    // Proposal.Digest() starts NOW on the worker thread, beside everything below (and beside the prepare round that follows):
+    // the first commit vote of this proposal finds it ready instead of hashing 1.7 MB (view.go:524, 834).  This call does not
+    // return before the worker has stopped reading `p` (it marshals first — 0.1-0.2 ms — and hashes its own bytes).
+    std::shared_ptr<ProposalDigestSlot> prefetched;
+    digest_prefetch(p, &prefetched);
+    struct ReleaseWait {
+        std::shared_ptr<ProposalDigestSlot>& s;
+        ~ReleaseWait() {
+            if (!s) return;
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv.wait(lk, [&] { return s->released; });
+        }
+    } release_wait{prefetched};
     const size_t n = reqs.size();
     const size_t tb = ed() ? 128 : 160;              // tuple bytes of the scheme
     std::vector<uint8_t> bitmap((n + 7) / 8, 0);
@@ -769,7 +809,7 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
         bytes last_digest;
         bool any_unkeyed = false;           // one store per chunk (VerifyProposal says why)
         for (size_t i = lo; i < hi; ++i) {
-            if (props[i] != last) { last = props[i]; last_digest = proposal_digest_raw(*last); }
+            if (props[i] != last) { last = props[i]; last_digest = digest_of(*last); }
             const bytes& m = sigs[i].msg;
             const auto it = keys.find(sigs[i].id);
             const bool bound = m.size() >= 40 && m.compare(0, 4, "SBV1") == 0 && m.compare(4, 32, last_digest) == 0 &&

@@ -184,10 +184,6 @@ class Verifier {
     Coalescer co_;
     std::mutex cache_mu_;
     std::unordered_map<std::string, bool> cache_;
-    // Proposal.Digest() memo: the reference recomputes SHA-256 over the whole proposal three times per
-    // sequence (view.go:435, 443, 524) and every VerifyConsenterSig must bind its message to it; for a
-    // 10k-request proposal that is ~4 ms of CPU per call.  Exact: an entry only
-    // hits after a full field-by-field comparison.
     // Grow-only staging arrays of the raw-messages batch path, page-locked when the backend offers it: handing
     // pageable memory to a ~100 MB batch costs more in the runtime's pinning than the kernels take.
     struct Staging {
@@ -197,12 +193,21 @@ class Verifier {
     void staging_release(Staging& s);
     std::mutex staging_mu_;
     Staging st_msgs_, st_sigs_, st_moff_, st_soff_, st_slots_;
-    bytes digest_memo(const Proposal& p);
-    struct DigestSlot { std::mutex mu; std::condition_variable cv; bool ready = false; bytes digest; };
-    struct DigestEntry { Proposal p; std::shared_ptr<DigestSlot> slot; };
-    std::mutex digest_mu_;
-    std::vector<DigestEntry> digest_cache_;
-    size_t digest_next_ = 0;
+    // Proposal.Digest() once per Proposal object (formats.h: ProposalDigestSlot).  digest_of: the digest, computed here by the
+    // first caller (concurrent first callers wait for it instead of hashing the same megabytes N - 1 times) or awaited from the
+    // prefetch.  digest_prefetch: VerifyProposal hands ASN.1 + SHA-256 of the proposal to a worker thread, so that it runs
+    // beside the backend call and the prepare round (a K = 10 000 proposal is 1.7 MB: ~1.2 ms of marshalling + SHA-256 that the
+    // first commit vote used to pay); the worker reads the caller's object only until it holds the marshalled bytes, and
+    // VerifyProposal does not return before that (the caller may drop the proposal afterwards).
+    bytes digest_of(const Proposal& p);
+    void digest_prefetch(const Proposal& p, std::shared_ptr<ProposalDigestSlot>* slot_out);
+    void digest_worker();
+    struct DigestJob { const Proposal* p; std::shared_ptr<ProposalDigestSlot> slot; };
+    std::mutex dw_mu_;
+    std::condition_variable dw_cv_;
+    std::vector<DigestJob> dw_jobs_;
+    std::thread dw_thread_;
+    bool dw_stop_ = false;
 };
 
 // api.Signer for one node (pkg/api/dependencies.go:46-52)

@@ -197,7 +197,8 @@ int sbv_last_timing(sbv_timing* out);
 int sbv_profile_enable(int on);
 int sbv_profile_read(double* prep_us, double* verify_us, uint64_t* launches);
 /* Same window as sbv_profile_read (call it BEFORE sbv_profile_read, which resets): summed duration and number
- * of launches of the dominant stage-B kernel alone — k_verify_keyed_q (one launch per chunk of key-comb windows)
+ * of launches of the dominant stage-B kernel alone — k_verify_keyed_q (one launch per chunk of key-comb windows; k_ed_qphase /
+ * k_k256_qphase for the grouped steps of the device-pointer entries of the other two schemes)
  * when the batch was grouped, else k_p256_verify. */
 int sbv_profile_read_dominant(double* dominant_us, uint64_t* dominant_launches);
 /* Device-side counters of the most recent grouped batch: out[0] = key groups, out[1] = tuples verified through

@@ -86,3 +86,39 @@ int sbvssl_ed25519_verify(const uint8_t pk[32], const uint8_t *msg, size_t len, 
     EVP_MD_CTX_free(ctx); EVP_PKEY_free(key);
     return ok;
 }
+
+/* A whole synthetic Ed25519 batch (oracle/ed25519_oracle.c: sbvo_ed25519_gen_batch) through EVP_DigestVerify: tuple i is
+ * R|S|A|k (128 bytes); OpenSSL needs the message, which the generator derives from (seed, i) alone — "sbv-ed-msg", the seed
+ * at bytes 12..15, i big-endian at bytes 24..31 (egen_worker) — and takes A and R|S from the tuple, i.e. the bytes a verifier
+ * would see (the generator's bit flips are already in them; k is ignored: OpenSSL hashes R|A|M itself).  The flips are random
+ * single bits, which no two correct implementations judge differently (see the note above), so the bitmap must equal the
+ * oracle's and the device's on every tuple.  Used by tests/test_gpu_ed25519.py and as bench.py's Ed25519 CPU baseline. */
+typedef struct { uint32_t seed; const uint8_t *tuples; size_t first, lo, hi; uint8_t *bitmap; } edjob_t;
+static void *ed_worker(void *arg) {
+    edjob_t *j = (edjob_t *)arg;
+    for (size_t l = j->lo; l < j->hi; ++l) {                 /* l: index inside the slice; i: index in the generated batch */
+        const uint64_t i = (uint64_t)j->first + l;
+        uint8_t msg[32];
+        memset(msg, 0, 32); memcpy(msg, "sbv-ed-msg", 10);
+        msg[12] = (uint8_t)(j->seed >> 24); msg[13] = (uint8_t)(j->seed >> 16); msg[14] = (uint8_t)(j->seed >> 8); msg[15] = (uint8_t)j->seed;
+        for (int b = 0; b < 8; ++b) msg[24 + b] = (uint8_t)(i >> (56 - 8 * b));
+        const uint8_t *t = j->tuples + 128 * l;
+        if (sbvssl_ed25519_verify(t + 64, msg, 32, t)) j->bitmap[l >> 3] |= (uint8_t)(1u << (l & 7));
+    }
+    return NULL;
+}
+/* tuples = n tuples starting at tuple `first` of the batch generated from `seed` (the message depends on the global index) */
+void sbvssl_ed25519_verify_gen_batch(uint32_t seed, const uint8_t *tuples, size_t first, size_t n, uint8_t *bitmap, int threads) {
+    memset(bitmap, 0, (n + 7) / 8);
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256]; edjob_t jobs[256];
+    size_t per = ((n + threads - 1) / threads + 7) & ~(size_t)7;
+    int started = 0;
+    for (int t = 0; t < threads; ++t) {
+        size_t lo = (size_t)t * per, hi = lo + per; if (lo >= n) break; if (hi > n) hi = n;
+        jobs[t] = (edjob_t){seed, tuples, first, lo, hi, bitmap};
+        pthread_create(&th[t], NULL, ed_worker, &jobs[t]); ++started;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+}

@@ -208,3 +208,30 @@ def test_device_message_front_end_sha512_and_mod_l(emul):
         emul.sbve_ed_msg_frontend(sig, pk, msg, mlen, t)
         k = int.from_bytes(hashlib.sha512(sig[:32] + pk + msg).digest(), "little") % L
         assert t.raw == sig + pk + k.to_bytes(32, "little"), mlen
+
+
+def test_openssl_batch_check_agrees_with_the_generator_and_the_oracle_verifier(oracle, openssl_check):
+    """oracle/openssl_check.c: sbvssl_ed25519_verify_gen_batch rebuilds the generator's messages from (seed, index) and runs
+    EVP_DigestVerify on what the tuples carry — the third opinion the GPU tier holds the full-size configs[4] bitmap against.
+    Here: whole batch and an offset slice, against the generator's flags and the oracle's verifier."""
+    n, seed = 3000, 0x5B7F2026
+    oracle.sbvo_ed25519_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int]
+    oracle.sbvo_ed25519_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+    openssl_check.sbvssl_ed25519_verify_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_size_t,
+                                                              ctypes.c_void_p, ctypes.c_int]
+    tup = ctypes.create_string_buffer(128 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_ed25519_gen_batch(seed, n, 37, 4, tup, exp, 4)
+    want = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_ed25519_verify_batch(tup.raw, n, want, 4)
+    ssl = ctypes.create_string_buffer((n + 7) // 8)
+    openssl_check.sbvssl_ed25519_verify_gen_batch(seed, tup.raw, 0, n, ssl, 4)
+    assert ssl.raw == want.raw == exp.raw
+    assert sum(bin(b).count("1") for b in ssl.raw) == n - n // 4
+    part = ctypes.create_string_buffer(100)
+    openssl_check.sbvssl_ed25519_verify_gen_batch(seed, tup.raw[128 * 1600:128 * 2400], 1600, 800, part, 3)
+    assert part.raw == exp.raw[200:300]
+    wrong_seed = ctypes.create_string_buffer((n + 7) // 8)
+    openssl_check.sbvssl_ed25519_verify_gen_batch(seed + 1, tup.raw, 0, n, wrong_seed, 4)
+    assert wrong_seed.raw == bytes((n + 7) // 8)                     # other messages: nothing verifies

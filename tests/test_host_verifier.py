@@ -628,6 +628,28 @@ def test_concurrent_first_callers_share_one_proposal_digest(hx):
     assert hx.verify_consenter_sig(sigs[0], other)[0] == INVALID          # bound to the proposal it was signed for
 
 
+def test_verify_proposal_prefetches_the_digest_for_the_commit_votes(hx):
+    """VerifyProposal hands Proposal.Digest() (ASN.1 + SHA-256, pkg/types/types.go:50-69) to a worker thread;
+    the memo travels with the Proposal OBJECT, as internal/bft/view.go passes the same v.inFlightProposal to VerifyProposal
+    (:555) and to every VerifyConsenterSig (:834).  One object through both calls: the slot is there when VerifyProposal
+    returns, the worker has let go of the caller's object, the digest equals a direct computation, and the vote verifies
+    against it; a vote for another proposal does not."""
+    S = ctypes.c_size_t
+    hx.lib.sbvh_test_proposal_then_vote.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, S, ctypes.c_char_p, S,
+                                                    ctypes.c_char_p, S, ctypes.c_char_p, S, ctypes.c_char_p, S, ctypes.c_int64]
+    for nreq in (1, 40, 3000):
+        reqs = [hx.request("alice%d" % (i % 3), "p%d-%d" % (nreq, i), payload=bytes(100)) for i in range(nreq)]
+        prop = (hostlib.payload_encode(reqs), b"hdr", b"md%d" % nreq, 0)
+        sid, val, msg = hx.sign_proposal(1, prop, b"aux")
+        p, h, m, vs = prop
+        r = hx.lib.sbvh_test_proposal_then_vote(hx.v, sid, val, len(val), msg, len(msg), p, len(p), h, len(h), m, len(m), vs)
+        assert r & 0xff == OK and (r >> 8) & 0xff == OK and r >> 16 == 7, hex(r)
+        # a vote signed for ANOTHER proposal: VerifyProposal fine, the binding check refuses it
+        sid2, val2, msg2 = hx.sign_proposal(1, (p, b"other", m, vs), b"aux")
+        r = hx.lib.sbvh_test_proposal_then_vote(hx.v, sid2, val2, len(val2), msg2, len(msg2), p, len(p), h, len(h), m, len(m), vs)
+        assert r & 0xff == OK and (r >> 8) & 0xff == INVALID and r >> 16 == 7, hex(r)
+
+
 def test_commit_signatures_digest_matches_go_asn1(lib):
     """f2: CommitSignaturesDigest (internal/bft/util.go:564-595) = SHA-256(asn1.Marshal(IntDoubleBytes{[]IntDoubleByte{A int64; B, C
     []byte}})), restated independently here with struct.pack-level DER: SEQUENCE{SEQUENCE OF SEQUENCE{INTEGER, OCTET STRING,
