@@ -348,7 +348,9 @@ SBV_HD bool verify29_lane_generic_rec(const Scratch& s, const uint8_t* tuples, s
 // ---- registered-key form, several lanes per signature (the latency form, BASELINE.json's second metric) -------------------
 // The 50 comb terms of u1 * G + u2 * Q are independent, so SBV_COOP_LANES lanes each sum every SBV_COOP_LANES-th term and
 // the partial sums meet in a butterfly of exact XYZZ additions (pt29_add): ~10 additions deep instead of 50.
-SBV_HD void keyed29_partial_lane(xyzz& R, const u256& u1, const u256& u2, const apt* qtab, const gcomb& gc, int sub) {
+// lanes = lanes per signature (a power of two): SBV_COOP_LANES in the throughput-sized latency kernels, SBV_SMALL_LANES in the
+// one-launch form of a commit quorum.
+SBV_HD void keyed29_partial_lane(xyzz& R, const u256& u1, const u256& u2, const apt* qtab, const gcomb& gc, int sub, int lanes = SBV_COOP_LANES) {
     u288 k1;
     gcomb_recode(k1, u1, gc.bits, gc.windows);
     u256 k2;
@@ -369,8 +371,8 @@ SBV_HD void keyed29_partial_lane(xyzz& R, const u256& u1, const u256& u2, const 
     raw_apt cur;
     raw_apt_load(cur, locate(sub, neg, skip));
     SBV_NOUNROLL
-    for (int t = sub; t < kSteps; t += SBV_COOP_LANES) {
-        const int tn = t + SBV_COOP_LANES < kSteps ? t + SBV_COOP_LANES : t;
+    for (int t = sub; t < kSteps; t += lanes) {
+        const int tn = t + lanes < kSteps ? t + lanes : t;
         bool negn, skipn;
         raw_apt nxt;
         raw_apt_load(nxt, locate(tn, negn, skipn));

@@ -27,6 +27,11 @@ hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slo
 #define SBV_SMALL_MAX 32
 hipError_t launch_p256_verify_keyed_small(const void* d_in, size_t n, u32 nkeys, const apt* d_ktab, const uint8_t* d_kvalid, const gcomb& d_gcomb,
                                           uint8_t* d_out, u32* d_done, hipStream_t stream);
+// the same with stage A on the host (host_prep_small writes the records r | u1 | u2 and the slots; k_p256_verify_prepared_small:
+// 16 lanes per signature)
+hipError_t launch_p256_verify_prepared_small(const void* d_in, size_t n, u32 nkeys, const apt* d_ktab, const uint8_t* d_kvalid, const gcomb& d_gcomb,
+                                             uint8_t* d_out, u32* d_done, hipStream_t stream);
+void host_prep_small(const uint8_t* rsh, const u32* slots, size_t n, u32* rec, u32* slot_out);
 void host_build_gcomb(int bits, apt* out);   // `bits`-wide comb of G, 8 x 32 Montgomery domain: gcomb_entries(bits) entries
 hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const uint8_t* d_sigs, const u64* d_soff, size_t n,
                                u32* d_rsh, hipStream_t stream);

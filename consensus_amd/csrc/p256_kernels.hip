@@ -18,6 +18,7 @@
 //
 // No MFMA: this is 256-bit modular integer arithmetic (v_mad_i64_i32 into 64-bit columns, p256_fe29.h).
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <stdlib.h>
 
 #include <thread>
@@ -238,6 +239,124 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_small
     if (threadIdx.x == 0) {
         __threadfence_system();
         __hip_atomic_fetch_add(done, here, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// The latency form with stage A on the HOST (round 4).  A commit quorum is 15 signatures: their stage A — one modular inversion
+// shared by Montgomery's trick and four multiplications mod N each — is ~10 us of one CPU core (host_prep_small below: the same
+// prep_chunk29 the stage-A kernel runs, compiled for the host), against a 600-step division chain of ~40 us on a lane of a
+// 2.4 GHz SIMD that 63 other lanes wait for.  The device keeps what is parallel: the 13 + 33 comb terms of u1 G + u2 Q, here
+// SBV_SMALL_LANES = 16 lanes per signature (3 terms per lane, then a 4-level butterfly of exact XYZZ additions: 7 dependent
+// additions instead of the 9 of the 8-lane form).
+// in: n records of 24 words r | u1 | u2 (plain 256-bit integers, least significant word first), then at word
+// SBV_SMALL_MAX * 24 the n key slots; a slot >= nkeys (the host writes 0xFFFFFFFF for a signature that failed the range checks)
+// is a reject.  Verdict bytes and the completion counter as in k_p256_verify_keyed_small.
+#define SBV_SMALL_LANES 16
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_prepared_small(const u32* __restrict__ in, u32 n, u32 nkeys,
+                                                                                 const apt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
+                                                                                 gcomb g16, uint8_t* __restrict__ out, u32* __restrict__ done) {
+    constexpr int kSigs = SBV_VERIFY_BLOCK / SBV_SMALL_LANES;         // signatures per workgroup
+    __shared__ u32 rec[kSigs * 24];
+    __shared__ u32 slot_s[kSigs];
+    __shared__ u32 verdict_s[kSigs];
+    const u32 first = blockIdx.x * kSigs;
+    const u32 here = n - first < (u32)kSigs ? n - first : (u32)kSigs;
+    {   // the input lives in HOST memory: 16-byte loads, one per lane (whole PCIe bursts), into LDS
+        const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)first * 24);
+        for (u32 e = threadIdx.x; e < here * 6; e += SBV_VERIFY_BLOCK) {
+            const uint4 v = src[e];
+            rec[4 * e] = v.x; rec[4 * e + 1] = v.y; rec[4 * e + 2] = v.z; rec[4 * e + 3] = v.w;
+        }
+        if (threadIdx.x < here) slot_s[threadIdx.x] = in[SBV_SMALL_MAX * 24 + first + threadIdx.x];
+        if (threadIdx.x < kSigs) verdict_s[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const u32 g = threadIdx.x / SBV_SMALL_LANES;
+    const int sub = (int)(threadIdx.x % SBV_SMALL_LANES);
+    const bool active = g < here;
+    u256 r, u1, u2;
+    SBV_UNROLL
+    for (int l = 0; l < 8; ++l) { r.v[l] = 0; u1.v[l] = 0; u2.v[l] = 0; }
+    xyzz R;
+    pt29_set_inf(R);
+    bool ok = false;
+    if (active) {
+        const u32* t = rec + g * 24;                                  // every lane of the group reads the same words: LDS broadcasts
+        SBV_UNROLL
+        for (int l = 0; l < 8; ++l) { r.v[l] = t[l]; u1.v[l] = t[8 + l]; u2.v[l] = t[16 + l]; }
+        u32 slot = slot_s[g];
+        ok = slot < nkeys;
+        if (!ok) slot = 0;
+        ok = ok && kvalid[slot] != 0;
+        keyed29_partial_lane(R, u1, u2, ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW), g16, sub, SBV_SMALL_LANES);
+    }
+    SBV_NOUNROLL
+    for (int off = SBV_SMALL_LANES / 2; off >= 1; off >>= 1) {
+        xyzz P;
+        SBV_UNROLL
+        for (int l = 0; l < 9; ++l) {
+            P.X.v[l] = __shfl_xor(R.X.v[l], off, 64);
+            P.Y.v[l] = __shfl_xor(R.Y.v[l], off, 64);
+            P.ZZ.v[l] = __shfl_xor(R.ZZ.v[l], off, 64);
+            P.ZZZ.v[l] = __shfl_xor(R.ZZZ.v[l], off, 64);
+        }
+        P.inf = __shfl_xor(R.inf ? 1 : 0, off, 64) != 0;
+        pt29_add(R, P);
+    }
+    if (active && sub == 0) verdict_s[g] = ok && pt29_rx_matches(R, r) ? 1u : 0u;
+    __syncthreads();
+    if (threadIdx.x < kSigs / 4) {                                     // 4 lanes, one 32-bit store each: 4 verdict bytes
+        const u32 w = verdict_s[4 * threadIdx.x] | (verdict_s[4 * threadIdx.x + 1] << 8) | (verdict_s[4 * threadIdx.x + 2] << 16) |
+                      (verdict_s[4 * threadIdx.x + 3] << 24);
+        reinterpret_cast<u32*>(out)[first / 4 + threadIdx.x] = w;       // first is a multiple of 16
+        __threadfence_system();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_fetch_add(done, here, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t launch_p256_verify_prepared_small(const void* d_in, size_t n, u32 nkeys, const apt* d_ktab, const uint8_t* d_kvalid, const gcomb& d_gtab,
+                                             uint8_t* d_out, u32* d_done, hipStream_t stream) {
+    if (n == 0 || n > SBV_SMALL_MAX) return hipErrorInvalidValue;
+    const size_t lanes = n * SBV_SMALL_LANES;
+    hipLaunchKernelGGL(k_p256_verify_prepared_small, dim3((unsigned)((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK)), dim3(SBV_VERIFY_BLOCK), 0, stream,
+                       static_cast<const u32*>(d_in), (u32)n, nkeys, d_ktab, d_kvalid, d_gtab, d_out, d_done);
+    return hipGetLastError();
+}
+
+// Host half of the latency form: stage A of n <= SBV_SMALL_MAX records r | s | hash (96 bytes each, big-endian, as the C-ABI
+// takes them) -> rec: n x 24 words r | u1 | u2 and slot_out[i] = slots[i], or 0xFFFFFFFF when r or s is out of range.  It IS
+// the stage-A lane of the kernels (p256_core.h: prep_chunk29<false>, one chunk of n tuples: ONE inversion for the whole
+// quorum), compiled for the host; product code, not a fallback: the verdict still comes from the comb kernel.
+namespace {
+struct HostRecWords {
+    const uint8_t* base;
+    struct W {
+        const uint8_t* p;
+        u32 operator[](int i) const { u32 v; memcpy(&v, p + 4 * i, 4); return v; }
+    };
+    W operator()(int, size_t idx) const { return W{base + 96 * idx}; }
+};
+}  // namespace
+void host_prep_small(const uint8_t* rsh, const u32* slots, size_t n, u32* rec, u32* slot_out) {
+    constexpr size_t cap = SBV_SMALL_MAX;
+    if (n > cap) n = cap;
+    u32 pr[8 * cap], pu1[8 * cap], pu2[8 * cap], psm[8 * cap];
+    uint8_t ok[cap];
+    Scratch s{pr, pu1, pu2, nullptr, nullptr, psm, ok, cap};
+    prep_chunk29<false>(HostRecWords{rsh}, n, s, 0, 1, (int)n);
+    for (size_t i = 0; i < n; ++i) {
+        u256 t;
+        soa_load(t, s.r, cap, i);
+        memcpy(rec + 24 * i, t.v, 32);
+        soa_load(t, s.u1, cap, i);
+        memcpy(rec + 24 * i + 8, t.v, 32);
+        soa_load(t, s.u2, cap, i);
+        memcpy(rec + 24 * i + 16, t.v, 32);
+        slot_out[i] = ok[i] ? slots[i] : 0xFFFFFFFFu;
     }
 }
 

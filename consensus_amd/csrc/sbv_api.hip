@@ -939,11 +939,20 @@ extern "C" int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* s
             HIP_TRY(SBV_EDEVICE, hipHostGetDevicePointer(&c.d_small_in, c.h_small_in, 0));
             HIP_TRY(SBV_EDEVICE, hipHostGetDevicePointer(&c.d_small_out, c.h_small_out, 0));
         }
-        memcpy(c.h_small_in, rsh, n * 96);
-        memcpy(c.h_small_in + SBV_SMALL_MAX * 96, slots, n * sizeof(u32));
+        static const bool host_prep = [] { const char* e = getenv("SBV_SMALL_HOSTPREP"); return !(e && e[0] == '0'); }();     // A/B hook of round 4
+        if (host_prep) sbv::host_prep_small(rsh, slots, n, reinterpret_cast<u32*>(c.h_small_in), reinterpret_cast<u32*>(c.h_small_in + SBV_SMALL_MAX * 96));
+        else {
+            memcpy(c.h_small_in, rsh, n * 96);
+            memcpy(c.h_small_in + SBV_SMALL_MAX * 96, slots, n * sizeof(u32));
+        }
         volatile u32* done = reinterpret_cast<volatile u32*>(c.h_small_out + SBV_SMALL_MAX);
         *done = 0;
         std::atomic_thread_fence(std::memory_order_seq_cst);
+        if (host_prep)
+            HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_prepared_small(c.d_small_in, n, (u32)c.nkeys, c.d_ktab, c.d_kvalid, sbv::gcomb_make(c.d_g16r, c.g_bits),
+                                                                      static_cast<uint8_t*>(c.d_small_out),
+                                                                      reinterpret_cast<u32*>(static_cast<uint8_t*>(c.d_small_out) + SBV_SMALL_MAX), c.stream));
+        else
         HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_keyed_small(c.d_small_in, n, (u32)c.nkeys, c.d_ktab, c.d_kvalid, sbv::gcomb_make(c.d_g16r, c.g_bits),
                                                                static_cast<uint8_t*>(c.d_small_out),
                                                                reinterpret_cast<u32*>(static_cast<uint8_t*>(c.d_small_out) + SBV_SMALL_MAX), c.stream));

@@ -236,38 +236,48 @@ static inline void cpu_relax() {
 }
 
 Coalescer::Coalescer(std::shared_ptr<Backend> be, size_t max_batch, std::chrono::microseconds max_wait)
-    : be_(be), max_batch_(max_batch ? max_batch : 1), max_wait_(max_wait), th_([this] { run(); }) {}
+    : be_(be), max_batch_(max_batch ? max_batch : 1), max_wait_(max_wait) {}
 
-Coalescer::~Coalescer() {
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        stop_ = true;
-    }
-    cv_job_.notify_all();
-    th_.join();
-}
+Coalescer::~Coalescer() {}      // no thread of its own: a submitter never returns before its job is done
 
+// Concurrent single-signature calls are merged by the callers themselves: the first submitter that finds no leader BECOMES
+// the leader (it is awake and on a core already — a dispatcher thread would have to be woken first: 30-60 us of futex latency at
+// the head of a ~100 us round trip, which is what round 3's M2 paid), polls the queue for the rest of the burst, ships the
+// batch and hands the verdicts out; everybody else spins on its own job's flag.  When the leader is done and jobs that arrived
+// during its backend call are still queued, leadership passes to one of their (spinning) owners.
 int Coalescer::submit(const uint8_t tuple[160], long slot, bool ed25519, bool k256, std::string* err) {
     Job j;
     memcpy(j.tuple, tuple, ed25519 ? 128 : 160);
     j.slot = slot;
     j.ed25519 = ed25519;
     j.k256 = k256;
+    bool lead = false;
     {
         std::lock_guard<std::mutex> lk(mu_);
         q_.push_back(&j);
         qn_.store(q_.size(), std::memory_order_release);
         ++st_.calls;
+        if (!leader_) { leader_ = true; leader_flag_.store(true, std::memory_order_release); lead = true; }
     }
-    cv_job_.notify_one();
-    // A quorum-sized batch is back in ~130 us; a futex sleep + wake-up costs 30-60 us on each side of it.  Spin for the
+    // A quorum-sized batch is back in ~100 us; a futex sleep + wake-up costs 30-60 us on each side of it.  Spin for the
     // expected round trip (the caller would otherwise have burnt ~100 us of CPU verifying on its own), then sleep.
     const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
-    while (!j.done.load(std::memory_order_acquire)) {
+    for (;;) {
+        if (lead) {
+            serve_as_leader();
+            lead = false;
+            if (j.done.load(std::memory_order_acquire)) break;      // always: the leader's own job is in its first batch
+        }
+        if (j.done.load(std::memory_order_acquire)) break;
+        if (!leader_flag_.load(std::memory_order_acquire)) {        // the leader left while this job was still queued: take over
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!leader_ && !j.done.load(std::memory_order_acquire)) { leader_ = true; leader_flag_.store(true, std::memory_order_release); lead = true; }
+            continue;
+        }
         if (std::chrono::steady_clock::now() > spin_until) {
             std::unique_lock<std::mutex> lk(mu_);
-            cv_done_.wait(lk, [&] { return j.done.load(std::memory_order_acquire); });
-            break;
+            cv_done_.wait(lk, [&] { return j.done.load(std::memory_order_acquire) || !leader_; });
+            continue;
         }
         cpu_relax();
     }
@@ -327,41 +337,48 @@ CoalescerStats Coalescer::stats() {
     return st_;
 }
 
-void Coalescer::run() {
+// mu_ NOT held; leader_ is this thread.  Ships batches until the queue is empty at the moment it looks, then steps down.
+void Coalescer::serve_as_leader() {
     std::vector<Job*> batch;
     std::vector<uint8_t> tuples, bitmap;
+    bool first_batch = true;
     for (;;) {
         {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_job_.wait(lk, [&] { return stop_ || !q_.empty(); });
-            if (stop_ && q_.empty()) return;
-            // First job is here: give concurrent callers a short window to join the batch.  The window is tens of
-            // microseconds — below the kernel's timer slack, so a timed condition-variable wait would oversleep it by a
-            // multiple; the dispatcher polls the queue length instead and leaves early when the expected burst is complete
-            // or nothing new has arrived for a quiet period: a quarter of the window while no burst size is known, half of it
-            // when one is (the votes of a burst arrive a few microseconds apart and must not be cut into several serial round
-            // trips; but a LONE call — VerifyRequest from HandleRequest, the serial verifyPrevCommitSignatures loop of
-            // internal/bft/view.go:630-644, a view-change VerifySignature — must not sit out the whole window with this thread
-            // spinning either: at N = 16 that was 15 x 50 us per sequence).
-            const auto t_first = std::chrono::steady_clock::now();
-            const auto deadline = t_first + max_wait_;
-            const auto quiet = max_wait_ / 4;
-            lk.unlock();
-            size_t seen = 1;
-            auto last = t_first;
-            for (;;) {
-                const auto now = std::chrono::steady_clock::now();
-                const size_t have = qn_.load(std::memory_order_acquire);
-                const size_t hint = burst_hint_.load(std::memory_order_relaxed);
-                if (have >= max_batch_ || (hint && have >= hint) || now >= deadline) break;
-                if (have != seen) { seen = have; last = now; }
-                else if (now - last >= (hint ? 2 * quiet : quiet)) break;
-                cpu_relax();
+            // The first job (the leader's own) is here: give concurrent callers a short window to join the batch.  The window
+            // is tens of microseconds — below the kernel's timer slack — so the leader polls the queue length and leaves early
+            // when the expected burst is complete or nothing new has arrived for a quiet period: a quarter of the window while
+            // no burst size is known, half of it when one is (the votes of a burst arrive a few microseconds apart and must
+            // not be cut into several serial round trips; but a LONE call — VerifyRequest from HandleRequest, the serial
+            // verifyPrevCommitSignatures loop of internal/bft/view.go:630-644, a view-change VerifySignature — must not sit
+            // out the whole window either: at N = 16 that was 15 x 50 us per sequence).  Later batches of the same leadership
+            // (jobs that arrived during the backend call) go out at once.
+            if (first_batch) {
+                const auto t_first = std::chrono::steady_clock::now();
+                const auto deadline = t_first + max_wait_;
+                const auto quiet = max_wait_ / 4;
+                size_t seen = 1;
+                auto last = t_first;
+                for (;;) {
+                    const auto now = std::chrono::steady_clock::now();
+                    const size_t have = qn_.load(std::memory_order_acquire);
+                    const size_t hint = burst_hint_.load(std::memory_order_relaxed);
+                    if (have >= max_batch_ || (hint && have >= hint) || now >= deadline) break;
+                    if (have != seen) { seen = have; last = now; }
+                    else if (now - last >= (hint ? 2 * quiet : quiet)) break;
+                    cpu_relax();
+                }
             }
-            lk.lock();
+            first_batch = false;
+            std::lock_guard<std::mutex> lk(mu_);
             batch.clear();
             while (!q_.empty() && batch.size() < max_batch_) { batch.push_back(q_.front()); q_.pop_front(); }
             qn_.store(q_.size(), std::memory_order_release);
+            if (batch.empty()) {                       // nothing left: step down (a job queued from now on finds no leader)
+                leader_ = false;
+                leader_flag_.store(false, std::memory_order_release);
+                cv_done_.notify_all();
+                return;
+            }
             ++st_.batches;
             if (batch.size() > st_.max_batch) st_.max_batch = batch.size();
         }

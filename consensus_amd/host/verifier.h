@@ -74,8 +74,8 @@ struct CoalescerStats {
     uint64_t max_batch = 0;
 };
 
-// Collects concurrent single-tuple submissions into one backend batch: a dispatcher thread takes the
-// first pending tuple, waits up to `max_wait` for more (or until `max_batch`), and ships them in one
+// Collects concurrent single-tuple submissions into one backend batch: the first submitter of a burst becomes its
+// leader (no dispatcher thread to wake), waits up to `max_wait` for more (or until `max_batch`), and ships them in one
 // call.  This is what turns the <= N-1 goroutines of View.processCommits (view.go:537-541) into one
 // GPU micro-batch.  submit_many() bypasses the wait (a VerifyProposal already is a batch).
 class Coalescer {
@@ -103,18 +103,18 @@ class Coalescer {
 
  private:
     struct Job { uint8_t tuple[160]; long slot = -1; bool ed25519 = false; bool k256 = false; int result = -100; std::string err; std::atomic<bool> done{false}; };
-    void run();
+    void serve_as_leader();
     std::shared_ptr<Backend> be_;
     size_t max_batch_;
     std::chrono::microseconds max_wait_;
     std::mutex mu_;
-    std::condition_variable cv_job_, cv_done_;
+    std::condition_variable cv_done_;
+    bool leader_ = false;                   // under mu_: some submitter is serving the queue
+    std::atomic<bool> leader_flag_{false};  // the same, readable by the spinning submitters without the lock
     std::deque<Job*> q_;
     std::atomic<size_t> qn_{0};            // q_.size(), readable without the lock by the spinning dispatcher
     std::atomic<size_t> burst_hint_{0};
-    bool stop_ = false;
     CoalescerStats st_;
-    std::thread th_;
 };
 
 // Signature scheme of a Verifier / Signer pair.  P256: ECDSA over SHA-256, DER signatures, 64-byte Qx|Qy keys (Go

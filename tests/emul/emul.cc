@@ -380,7 +380,31 @@ int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
     return valid;
 }
 
-static bool g_keyed_coop = false, g_keyed_small = false;
+static bool g_keyed_coop = false, g_keyed_small = false, g_keyed_prepared = false;
+static std::vector<u32> g_prep_rec, g_prep_slot;
+// the host half of the prepared latency form, as consensus_amd/csrc/p256_kernels.hip: host_prep_small does it
+struct EmulRecWords {
+    const uint8_t* base;
+    struct W {
+        const uint8_t* p;
+        u32 operator[](int i) const { u32 v; memcpy(&v, p + 4 * i, 4); return v; }
+    };
+    W operator()(int, size_t idx) const { return W{base + 96 * idx}; }
+};
+static void emul_host_prep_small(const uint8_t* rsh, const u32* slots, size_t n, u32* rec, u32* slot_out) {
+    const size_t cap = 32;
+    u32 pr[8 * 32], pu1[8 * 32], pu2[8 * 32], psm[8 * 32];
+    uint8_t ok[32];
+    Scratch s{pr, pu1, pu2, nullptr, nullptr, psm, ok, cap};
+    prep_chunk29<false>(EmulRecWords{rsh}, n, s, 0, 1, (int)n);
+    for (size_t i = 0; i < n; ++i) {
+        u256 t;
+        soa_load(t, s.r, cap, i); memcpy(rec + 24 * i, t.v, 32);
+        soa_load(t, s.u1, cap, i); memcpy(rec + 24 * i + 8, t.v, 32);
+        soa_load(t, s.u2, cap, i); memcpy(rec + 24 * i + 16, t.v, 32);
+        slot_out[i] = ok[i] ? slots[i] : 0xFFFFFFFFu;
+    }
+}
 // registered-key form: rsh = n x 96 B (r|s|hash), slots[i] indexes keys (nkeys x 64 B, Qx|Qy)
 void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n, const uint8_t* keys, u32 nkeys,
                                   uint8_t* bitmap, int block, int T) {
@@ -431,21 +455,36 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
                 a = a2; b = b2;
                 okk = ok1 && slots[i] < nkeys && kvalid[slot] != 0;
             }
-            xyzz part[SBV_COOP_LANES];
-            for (int sub = 0; sub < SBV_COOP_LANES; ++sub) keyed29_partial_lane(part[sub], a, b, &ktab[per_key * slot], g16rtab(), sub);
-            for (int off = SBV_COOP_LANES / 2; off >= 1; off >>= 1) {
-                xyzz nxt[SBV_COOP_LANES];
-                for (int sub = 0; sub < SBV_COOP_LANES; ++sub) { nxt[sub] = part[sub]; pt29_add(nxt[sub], part[sub ^ off]); }
-                for (int sub = 0; sub < SBV_COOP_LANES; ++sub) part[sub] = nxt[sub];
+            if (g_keyed_prepared) {    // k_p256_verify_prepared_small: stage A by the host half (one chunk of all n records, ONE inversion)
+                if (n <= 32) {
+                    if (i == 0) {
+                        g_prep_rec.assign(24 * n, 0); g_prep_slot.assign(n, 0);
+                        emul_host_prep_small(rsh, slots, n, g_prep_rec.data(), g_prep_slot.data());
+                    }
+                    u256 r2, a2, b2;
+                    memcpy(r2.v, &g_prep_rec[24 * i], 32); memcpy(a2.v, &g_prep_rec[24 * i + 8], 32); memcpy(b2.v, &g_prep_rec[24 * i + 16], 32);
+                    const bool ok1 = g_prep_slot[i] != 0xFFFFFFFFu;
+                    if (ok1 != (s.ok[i] != 0) || !eq256(rr, r2) || (ok1 && (!eq256(a, a2) || !eq256(b, b2)))) g_small_disagreements++;
+                    a = a2; b = b2; rr = r2;
+                    okk = g_prep_slot[i] < nkeys && kvalid[slot] != 0;
+                }
+            }
+            const int L = g_keyed_prepared ? 16 : SBV_COOP_LANES;      // SBV_SMALL_LANES of the prepared form
+            xyzz part[16];
+            for (int sub = 0; sub < L; ++sub) keyed29_partial_lane(part[sub], a, b, &ktab[per_key * slot], g16rtab(), sub, L);
+            for (int off = L / 2; off >= 1; off >>= 1) {
+                xyzz nxt[16];
+                for (int sub = 0; sub < L; ++sub) { nxt[sub] = part[sub]; pt29_add(nxt[sub], part[sub ^ off]); }
+                for (int sub = 0; sub < L; ++sub) part[sub] = nxt[sub];
             }
             accept = okk && pt29_rx_matches(part[0], rr);
-            for (int sub = 1; sub < SBV_COOP_LANES; ++sub)           // every lane of the group must hold the same point
+            for (int sub = 1; sub < L; ++sub)           // every lane of the group must hold the same point
                 if ((okk && pt29_rx_matches(part[sub], rr)) != accept) g_coop_disagreements++;
         }
         if (accept) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
     }
 }
-void sbve_set_keyed_coop(int on) { g_keyed_coop = on != 0; g_keyed_small = on == 2; }       // 2: the one-launch latency form (stage A in registers)
+void sbve_set_keyed_coop(int on) { g_keyed_coop = on != 0; g_keyed_small = on == 2; g_keyed_prepared = on == 3; }   // 2: the one-launch latency form (stage A in registers); 3: the prepared form (stage A by the host half, 16 lanes per signature)
 unsigned long sbve_small_disagreements() { return g_small_disagreements; }
 unsigned long sbve_coop_disagreements() { return g_coop_disagreements; }
 

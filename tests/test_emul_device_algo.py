@@ -244,6 +244,24 @@ def test_registered_key_form_matches_generic_verdicts(emul, oracle, golden_vecto
         bad = [i for i in range(total) if got4[i] != want[i]]
         assert not bad, bad[:10]
         assert emul.sbve_small_disagreements() == 0 and emul.sbve_coop_disagreements() == 0
+        # the prepared latency form (round 4: host_prep_small + k_p256_verify_prepared_small): stage A of a whole call (<= 32
+        # records) as ONE chunk with one inversion on the host half, 16 lanes per signature and a 4-level butterfly on the
+        # device half.  Every golden vector, in calls of 1..32 records (out-of-range r / s sit beside honest ones in a chunk:
+        # the product chain must stay invertible); r | u1 | u2 must be those of the kernels' chunked stage A.
+        emul.sbve_set_keyed_coop(3)
+        off, sizes, k = 0, [1, 2, 15, 32, 31, 16, 7], 0
+        got5 = []
+        while off < total:
+            m = min(sizes[k % len(sizes)], total - off)
+            k += 1
+            bm5 = ctypes.create_string_buffer((m + 7) // 8)
+            sub = (ctypes.c_uint32 * m)(*slots[off:off + m])
+            emul.sbve_p256_verify_batch_keyed(rsh[96 * off:96 * (off + m)], sub, m, b"".join(keys), len(keys), bm5, 64, 1)
+            got5 += _bitmap_list(bm5.raw, m)
+            off += m
+        bad = [i for i in range(total) if got5[i] != want[i]]
+        assert not bad, bad[:10]
+        assert emul.sbve_small_disagreements() == 0 and emul.sbve_coop_disagreements() == 0
     finally:
         emul.sbve_set_keyed_coop(0)
 

@@ -1,8 +1,18 @@
 #!/usr/bin/env python3
 """Latency of the registered-key host entry for quorum-sized batches (n = 1, 15, 64): median wall time of sbv_p256_verify_batch_keyed
-over 300 calls, through ctypes.  SBV_SMALL=0 in the environment selects the staged path (copies + two launches) for the A/B."""
-import ctypes, json, os, sys, time
+over 300 calls, through ctypes.  SBV_SMALL=0 in the environment selects the staged path (copies + two launches) for the A/B.
+With arguments: one fresh process per environment variant, e.g. `latency_small.py default SBV_SMALL=0`."""
+import ctypes, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1:        # A/B: one fresh process per variant (NAME=VAL+NAME=VAL or "default"), two passes
+    for rep in (1, 2):
+        for var in sys.argv[1:]:
+            env = dict(os.environ)
+            if var != "default":
+                env.update(kv.split("=", 1) for kv in var.split("+"))
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=300)
+            print(json.dumps({"variant": var, "pass": rep, "result": json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else r.stderr[-400:]}), flush=True)
+    sys.exit(0)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import consensus_amd as sbv
