@@ -8,6 +8,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -28,15 +29,52 @@ typedef std::string bytes;
 struct ProposalDigestSlot {
     std::mutex mu;
     std::condition_variable cv;
-    bool ready = false;       // digest is final
+    bool ready = false;       // digest is final (under mu, for the waiters)
     bool released = false;    // the worker no longer reads the caller's Proposal (it holds the marshalled bytes)
-    bytes digest;
+    std::atomic<bool> ready_flag{false};   // the same as `ready`, readable without the lock: the N-1 votes of a burst ask at the same instant
+    bytes digest;             // immutable once ready
 };
 
 struct Proposal {                 // pkg/types/types.go:18-23
     bytes payload, header, metadata;
     int64_t verification_sequence = 0;
-    mutable std::shared_ptr<ProposalDigestSlot> digest_slot;   // see ProposalDigestSlot; never part of the value
+
+    Proposal() = default;
+    Proposal(const Proposal& o) : payload(o.payload), header(o.header), metadata(o.metadata), verification_sequence(o.verification_sequence), slot_(o.digest_slot()) {}
+    Proposal(Proposal&& o) noexcept : payload(std::move(o.payload)), header(std::move(o.header)), metadata(std::move(o.metadata)),
+                                      verification_sequence(o.verification_sequence), slot_(o.digest_slot()) {}
+    Proposal& operator=(const Proposal& o) {
+        if (this != &o) { payload = o.payload; header = o.header; metadata = o.metadata; verification_sequence = o.verification_sequence; set_slot(o.digest_slot()); }
+        return *this;
+    }
+    Proposal& operator=(Proposal&& o) noexcept {
+        if (this != &o) { payload = std::move(o.payload); header = std::move(o.header); metadata = std::move(o.metadata); verification_sequence = o.verification_sequence; set_slot(o.digest_slot()); }
+        return *this;
+    }
+    // The digest slot of this object (see ProposalDigestSlot; never part of the value).  Guarded by a spin flag of its own: the
+    // free-function atomics on shared_ptr take a pooled pthread mutex, and 15 votes asking at once queued on it for ~1 us each.
+    std::shared_ptr<ProposalDigestSlot> digest_slot() const {
+        lock();
+        std::shared_ptr<ProposalDigestSlot> s = slot_;
+        unlock();
+        return s;
+    }
+    // installs `fresh` when no slot is there yet; returns the slot that is there afterwards, *installed = whether it is `fresh`
+    std::shared_ptr<ProposalDigestSlot> digest_slot_install(const std::shared_ptr<ProposalDigestSlot>& fresh, bool* installed) const {
+        lock();
+        *installed = !slot_;
+        if (!slot_) slot_ = fresh;
+        std::shared_ptr<ProposalDigestSlot> s = slot_;
+        unlock();
+        return s;
+    }
+
+ private:
+    void set_slot(std::shared_ptr<ProposalDigestSlot> s) const { lock(); slot_.swap(s); unlock(); }
+    void lock() const { while (slot_lock_.test_and_set(std::memory_order_acquire)) {} }
+    void unlock() const { slot_lock_.clear(std::memory_order_release); }
+    mutable std::atomic_flag slot_lock_ = ATOMIC_FLAG_INIT;
+    mutable std::shared_ptr<ProposalDigestSlot> slot_;
 };
 struct Signature {                // pkg/types/types.go:25-29
     uint64_t id = 0;

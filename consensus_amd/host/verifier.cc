@@ -252,8 +252,10 @@ int Coalescer::submit(const uint8_t tuple[160], long slot, bool ed25519, bool k2
     j.ed25519 = ed25519;
     j.k256 = k256;
     bool lead = false;
+    static const bool trace = [] { const char* e = getenv("SBVH_TRACE"); return e && e[0] == '1'; }();
+    if (trace) j.t_push = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
     {
-        std::lock_guard<std::mutex> lk(mu_);
+        std::lock_guard<SpinLock> lk(mu_);
         q_.push_back(&j);
         qn_.store(q_.size(), std::memory_order_release);
         ++st_.calls;
@@ -270,13 +272,15 @@ int Coalescer::submit(const uint8_t tuple[160], long slot, bool ed25519, bool k2
         }
         if (j.done.load(std::memory_order_acquire)) break;
         if (!leader_flag_.load(std::memory_order_acquire)) {        // the leader left while this job was still queued: take over
-            std::lock_guard<std::mutex> lk(mu_);
+            std::lock_guard<SpinLock> lk(mu_);
             if (!leader_ && !j.done.load(std::memory_order_acquire)) { leader_ = true; leader_flag_.store(true, std::memory_order_release); lead = true; }
             continue;
         }
         if (std::chrono::steady_clock::now() > spin_until) {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_done_.wait(lk, [&] { return j.done.load(std::memory_order_acquire) || !leader_; });
+            std::unique_lock<std::mutex> lk(sleep_mu_);
+            sleepers_.fetch_add(1, std::memory_order_seq_cst);
+            cv_done_.wait(lk, [&] { return j.done.load(std::memory_order_acquire) || !leader_flag_.load(std::memory_order_acquire); });
+            sleepers_.fetch_sub(1, std::memory_order_acq_rel);
             continue;
         }
         cpu_relax();
@@ -287,7 +291,7 @@ int Coalescer::submit(const uint8_t tuple[160], long slot, bool ed25519, bool k2
 
 int Coalescer::submit_many(const uint8_t* tuples, size_t n, uint8_t* bitmap) {
     {
-        std::lock_guard<std::mutex> lk(mu_);
+        std::lock_guard<SpinLock> lk(mu_);
         ++st_.batches;
         if (n > st_.max_batch) st_.max_batch = n;
     }
@@ -296,7 +300,7 @@ int Coalescer::submit_many(const uint8_t* tuples, size_t n, uint8_t* bitmap) {
 
 int Coalescer::submit_many_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap) {
     {
-        std::lock_guard<std::mutex> lk(mu_);
+        std::lock_guard<SpinLock> lk(mu_);
         ++st_.batches;
         if (n > st_.max_batch) st_.max_batch = n;
     }
@@ -305,7 +309,7 @@ int Coalescer::submit_many_ed25519(const uint8_t* tuples128, size_t n, uint8_t* 
 
 int Coalescer::submit_many_k256(const uint8_t* tuples, size_t n, uint8_t* bitmap) {
     {
-        std::lock_guard<std::mutex> lk(mu_);
+        std::lock_guard<SpinLock> lk(mu_);
         ++st_.batches;
         if (n > st_.max_batch) st_.max_batch = n;
     }
@@ -316,7 +320,7 @@ int Coalescer::submit_many_msgs_keyed(const uint8_t* msgs, const uint64_t* moff,
                                       size_t n, uint8_t* bitmap) {
     const int rc = be_->verify_msgs_keyed(msgs, moff, sigs, soff, slots, n, bitmap);
     if (rc != -2) {
-        std::lock_guard<std::mutex> lk(mu_);
+        std::lock_guard<SpinLock> lk(mu_);
         ++st_.batches;
         if (n > st_.max_batch) st_.max_batch = n;
     }
@@ -325,7 +329,7 @@ int Coalescer::submit_many_msgs_keyed(const uint8_t* msgs, const uint64_t* moff,
 
 int Coalescer::submit_many_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap) {
     {
-        std::lock_guard<std::mutex> lk(mu_);
+        std::lock_guard<SpinLock> lk(mu_);
         ++st_.batches;
         if (n > st_.max_batch) st_.max_batch = n;
     }
@@ -333,16 +337,21 @@ int Coalescer::submit_many_keyed(const uint8_t* rsh, const uint32_t* slots, size
 }
 
 CoalescerStats Coalescer::stats() {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<SpinLock> lk(mu_);
     return st_;
 }
 
 // mu_ NOT held; leader_ is this thread.  Ships batches until the queue is empty at the moment it looks, then steps down.
 void Coalescer::serve_as_leader() {
+    // SBVH_TRACE=1: one line per backend batch on stderr (size, time spent collecting, backend call)
+    static const bool trace = [] { const char* e = getenv("SBVH_TRACE"); return e && e[0] == '1'; }();
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_lead = trace ? now_us() : 0;
     std::vector<Job*> batch;
     std::vector<uint8_t> tuples, bitmap;
     bool first_batch = true;
     for (;;) {
+        bool wake_sleepers = false, stepped_down = false;
         {
             // The first job (the leader's own) is here: give concurrent callers a short window to join the batch.  The window
             // is tens of microseconds — below the kernel's timer slack — so the leader polls the queue length and leaves early
@@ -369,20 +378,33 @@ void Coalescer::serve_as_leader() {
                 }
             }
             first_batch = false;
-            std::lock_guard<std::mutex> lk(mu_);
+            std::lock_guard<SpinLock> lk(mu_);
             batch.clear();
             while (!q_.empty() && batch.size() < max_batch_) { batch.push_back(q_.front()); q_.pop_front(); }
             qn_.store(q_.size(), std::memory_order_release);
             if (batch.empty()) {                       // nothing left: step down (a job queued from now on finds no leader)
                 leader_ = false;
                 leader_flag_.store(false, std::memory_order_release);
-                cv_done_.notify_all();
-                return;
+                std::atomic_thread_fence(std::memory_order_seq_cst);          // as below: flag first, then look for sleepers
+                wake_sleepers = sleepers_.load(std::memory_order_seq_cst) > 0;
+                stepped_down = true;
             }
-            ++st_.batches;
-            if (batch.size() > st_.max_batch) st_.max_batch = batch.size();
+            if (!stepped_down) {
+                ++st_.batches;
+                if (batch.size() > st_.max_batch) st_.max_batch = batch.size();
+            }
+        }
+        if (stepped_down) {
+            if (wake_sleepers) { std::lock_guard<std::mutex> lk(sleep_mu_); cv_done_.notify_all(); }
+            return;
         }
         const size_t n = batch.size();
+        const double t_ship = trace ? now_us() : 0;
+        if (trace && n > 1) {
+            std::string a;
+            for (size_t i = 0; i < n; ++i) a += " " + std::to_string((int)(batch[i]->t_push - t_lead));
+            fprintf(stderr, "[sbvh] coalescer arrivals (us after the leader took over):%s\n", a.c_str());
+        }
         bitmap.assign((n + 7) / 8, 0);
         bool all_keyed = true;
         for (size_t i = 0; i < n; ++i) all_keyed = all_keyed && batch[i]->slot >= 0;
@@ -406,8 +428,9 @@ void Coalescer::serve_as_leader() {
             rc = be_->verify(tuples.data(), n, bitmap.data());
         }
         const std::string err_text = rc != 0 ? std::string(sbv_last_error()) : std::string();     // this thread made the failing call
+        if (trace) fprintf(stderr, "[sbvh] coalescer batch n=%zu: %.0f us since this leader started, backend %.0f us\n", n, t_ship - t_lead, now_us() - t_ship);
         {
-            std::lock_guard<std::mutex> lk(mu_);
+            std::lock_guard<SpinLock> lk(mu_);
             for (size_t i = 0; i < n; ++i) {
                 Job* job = batch[i];        // not touched after done: the submitter's stack frame may be gone
                 job->result = rc != 0 ? (rc < 0 ? rc : -1) : ((bitmap[i >> 3] >> (i & 7)) & 1);
@@ -415,7 +438,10 @@ void Coalescer::serve_as_leader() {
                 job->done.store(true, std::memory_order_release);
             }
         }
-        cv_done_.notify_all();
+        // store(done) above, load(sleepers_) here, and a sleeper does the mirror image (count itself, then look at done): without
+        // a full fence between the two both sides may read the old value and the sleeper would never be woken
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        if (sleepers_.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lk(sleep_mu_); cv_done_.notify_all(); }
     }
 }
 
@@ -458,29 +484,32 @@ void Verifier::RegisterConsenter(uint64_t id, const uint8_t* q) {
     const long slot = ed() || k256() ? -1 : co_.backend().register_key(q);     // -1: no key registry (Ed25519: grouped per batch; secp256k1: no combs yet)
     bytes key((const char*)q, key_bytes());
     key.resize(64, '\0');
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<SpinLock> lk(mu_);
     consenters_[id] = key;
     consenter_slot_[id] = slot;
-    co_.set_burst_hint(consenters_.size() > 1 ? consenters_.size() - 1 : 0);      // a commit burst is N-1 votes (view.go:537-541)
+    // A commit burst is N-1 votes (view.go:537-541).  Shipping already at Quorum-1 votes (what the View waits for, view.go:531)
+    // was measured in round 4 and lost: 125-136 us to the Quorum-1-th accept against 81-88 us with one batch of N-1
+    // (profiles/r04/m2_trace_r04h.txt).
+    co_.set_burst_hint(consenters_.size() > 1 ? consenters_.size() - 1 : 0);
 }
 // Clients are a registry too (the application hands their keys to the Verifier), so their keys take the same
 // registered-key slots as the consenters': VerifyRequest / VerifyProposal then run 50 table additions per
 // signature instead of the 256-doubling chain of a key the device has never seen.
 void Verifier::RegisterClient(const std::string& client_id, const uint8_t* q) {
     bool on_device;
-    { std::lock_guard<std::mutex> lk(mu_); on_device = opt_.device_client_keys; }
+    { std::lock_guard<SpinLock> lk(mu_); on_device = opt_.device_client_keys; }
     const long slot = ed() || k256() || !on_device ? -1 : co_.backend().register_key(q);     // -1: no key registry (Ed25519: grouped per batch; secp256k1: no combs yet)
     bytes key((const char*)q, key_bytes());
     key.resize(64, '\0');
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<SpinLock> lk(mu_);
     clients_[client_id] = key;
     client_slot_[client_id] = slot;
 }
-void Verifier::SetVerificationSequence(uint64_t s) { std::lock_guard<std::mutex> lk(mu_); seq_ = s; }
-uint64_t Verifier::VerificationSequence() { std::lock_guard<std::mutex> lk(mu_); return seq_; }
+void Verifier::SetVerificationSequence(uint64_t s) { std::lock_guard<SpinLock> lk(mu_); seq_ = s; }
+uint64_t Verifier::VerificationSequence() { std::lock_guard<SpinLock> lk(mu_); return seq_; }
 
 bool Verifier::consenter_key(uint64_t id, uint8_t q[64], long* slot) {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<SpinLock> lk(mu_);
     auto it = consenters_.find(id);
     if (it == consenters_.end()) return false;
     memcpy(q, it->second.data(), 64);
@@ -488,7 +517,7 @@ bool Verifier::consenter_key(uint64_t id, uint8_t q[64], long* slot) {
     return true;
 }
 bool Verifier::client_key(const std::string& id, uint8_t q[64], long* slot) {
-    std::lock_guard<std::mutex> lk(mu_);
+    std::lock_guard<SpinLock> lk(mu_);
     auto it = clients_.find(id);
     if (it == clients_.end()) return false;
     memcpy(q, it->second.data(), 64);
@@ -545,7 +574,7 @@ Status Verifier::verify_one(const uint8_t q[64], const bytes& msg, const bytes& 
     std::string key;
     if (opt_.cache_verified) {
         key = cache_key(q, msg, sig);
-        std::lock_guard<std::mutex> lk(cache_mu_);
+        std::lock_guard<SpinLock> lk(cache_mu_);
         auto it = cache_.find(key);
         if (it != cache_.end()) return it->second ? Status::Ok() : Status::Invalid("invalid signature (cached)");
     }
@@ -556,7 +585,7 @@ Status Verifier::verify_one(const uint8_t q[64], const bytes& msg, const bytes& 
     const int r = co_.submit(t, ed() || k256() ? -1 : slot, ed(), k256(), &err);
     if (r < 0) return Status::Unavailable("backend error: " + err);
     if (opt_.cache_verified) {
-        std::lock_guard<std::mutex> lk(cache_mu_);
+        std::lock_guard<SpinLock> lk(cache_mu_);
         if (cache_.size() > (1u << 20)) cache_.clear();
         cache_[key] = r == 1;
     }
@@ -574,28 +603,33 @@ Status Verifier::VerifySignature(const Signature& s) {        // viewchanger.go:
 // of View.processCommits (view.go:537-541) all ask for the digest of the same proposal at the same moment.  Whoever installs
 // the slot computes (or, from VerifyProposal, hands the computation to the worker); everybody else waits for `ready`.
 bytes Verifier::digest_of(const Proposal& p) {
-    std::shared_ptr<ProposalDigestSlot> slot = std::atomic_load(&p.digest_slot);
+    std::shared_ptr<ProposalDigestSlot> slot = p.digest_slot();
     if (!slot) {
         auto fresh = std::make_shared<ProposalDigestSlot>();
-        if (std::atomic_compare_exchange_strong(&p.digest_slot, &slot, fresh)) {
+        bool mine = false;
+        slot = p.digest_slot_install(fresh, &mine);
+        if (mine) {
             bytes d = proposal_digest_raw(p);
             std::lock_guard<std::mutex> lk(fresh->mu);
             fresh->digest = std::move(d);
             fresh->ready = fresh->released = true;
+            fresh->ready_flag.store(true, std::memory_order_release);
             fresh->cv.notify_all();
             return fresh->digest;
         }
     }
+    if (slot->ready_flag.load(std::memory_order_acquire)) return slot->digest;      // the burst's path: no lock, the digest is immutable
     std::unique_lock<std::mutex> lk(slot->mu);
     slot->cv.wait(lk, [&] { return slot->ready; });
     return slot->digest;
 }
 
 void Verifier::digest_prefetch(const Proposal& p, std::shared_ptr<ProposalDigestSlot>* slot_out) {
-    std::shared_ptr<ProposalDigestSlot> slot = std::atomic_load(&p.digest_slot);
-    if (slot) return;                                   // computed, or on its way
+    if (p.digest_slot()) return;                        // computed, or on its way
     auto fresh = std::make_shared<ProposalDigestSlot>();
-    if (!std::atomic_compare_exchange_strong(&p.digest_slot, &slot, fresh)) return;
+    bool mine = false;
+    (void)p.digest_slot_install(fresh, &mine);
+    if (!mine) return;
     *slot_out = fresh;
     std::lock_guard<std::mutex> lk(dw_mu_);
     if (!dw_thread_.joinable()) dw_thread_ = std::thread([this] { digest_worker(); });
@@ -623,6 +657,7 @@ void Verifier::digest_worker() {
         std::lock_guard<std::mutex> lk(job.slot->mu);
         job.slot->digest = std::move(d);
         job.slot->ready = true;
+        job.slot->ready_flag.store(true, std::memory_order_release);
         job.slot->cv.notify_all();
     }
 }
@@ -706,7 +741,7 @@ Status Verifier::VerifyProposal(const Proposal& p, std::vector<RequestInfo>* req
     std::map<std::string, bytes> clients;           // snapshot: the workers must not contend on mu_
     std::map<std::string, long> client_slots;
     {
-        std::lock_guard<std::mutex> lk(mu_);
+        std::lock_guard<SpinLock> lk(mu_);
         clients = clients_;
         client_slots = client_slot_;
     }
@@ -816,7 +851,7 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
     std::map<uint64_t, bytes> keys;                 // snapshot: the workers must not contend on mu_
     std::map<uint64_t, long> key_slots;
     {
-        std::lock_guard<std::mutex> lk(mu_);
+        std::lock_guard<SpinLock> lk(mu_);
         keys = consenters_;
         key_slots = consenter_slot_;
     }

@@ -68,6 +68,29 @@ std::shared_ptr<Backend> make_sbv_backend(int device);     // device >= 0: sbv_i
 typedef int (*backend_fn)(const uint8_t* tuples, size_t n, uint8_t* bitmap, void* user);
 std::shared_ptr<Backend> make_callback_backend(backend_fn fn, void* user, bool with_key_registry = false);
 
+// A lock for critical sections of a few dozen instructions that N-1 threads hit in the same microsecond (a burst of commit
+// votes: view.go:537-541).  Under that pattern std::mutex parks the losers in the kernel — one futex wake-up (5-10 us) per
+// hand-over, 15-24 us until the last of 15 votes was queued (profiles/r04/m2_trace_r04h.txt) — a spinning lock hands over in
+// ~100 ns.  BasicLockable: works with std::lock_guard / std::unique_lock.
+class SpinLock {
+ public:
+    void lock() {
+        // test-and-test-and-set: the waiters spin on a shared (read-only) copy of the line and only the one that sees it free
+        // tries the exchange, so a hand-over is one line transfer instead of a storm of them
+        while (f_.exchange(true, std::memory_order_acquire)) {
+            while (f_.load(std::memory_order_relaxed)) {
+#if defined(__x86_64__) || defined(__i386__)
+                __builtin_ia32_pause();
+#endif
+            }
+        }
+    }
+    void unlock() { f_.store(false, std::memory_order_release); }
+
+ private:
+    std::atomic<bool> f_{false};
+};
+
 struct CoalescerStats {
     uint64_t calls = 0;        // single-signature submissions
     uint64_t batches = 0;      // backend invocations
@@ -102,13 +125,15 @@ class Coalescer {
     void set_burst_hint(size_t n) { burst_hint_.store(n, std::memory_order_relaxed); }
 
  private:
-    struct Job { uint8_t tuple[160]; long slot = -1; bool ed25519 = false; bool k256 = false; int result = -100; std::string err; std::atomic<bool> done{false}; };
+    struct Job { uint8_t tuple[160]; long slot = -1; bool ed25519 = false; bool k256 = false; int result = -100; std::string err; std::atomic<bool> done{false}; double t_push = 0; };
     void serve_as_leader();
     std::shared_ptr<Backend> be_;
     size_t max_batch_;
     std::chrono::microseconds max_wait_;
-    std::mutex mu_;
+    SpinLock mu_;                           // the queue, the leader flag, the statistics
+    std::mutex sleep_mu_;                   // only for submitters that gave up spinning (cv_done_)
     std::condition_variable cv_done_;
+    std::atomic<int> sleepers_{0};
     bool leader_ = false;                   // under mu_: some submitter is serving the queue
     std::atomic<bool> leader_flag_{false};  // the same, readable by the spinning submitters without the lock
     std::deque<Job*> q_;
@@ -145,7 +170,7 @@ class Verifier {
     void RegisterConsenter(uint64_t id, const uint8_t* q);
     void RegisterClient(const std::string& client_id, const uint8_t* q);
     void SetVerificationSequence(uint64_t s);
-    void SetDeviceClientKeys(bool on) { std::lock_guard<std::mutex> lk(mu_); opt_.device_client_keys = on; }     // applies to clients registered afterwards
+    void SetDeviceClientKeys(bool on) { std::lock_guard<SpinLock> lk(mu_); opt_.device_client_keys = on; }     // applies to clients registered afterwards
 
     // ---- api.Verifier ---------------------------------------------------------------------------
     Status VerifyProposal(const Proposal& proposal, std::vector<RequestInfo>* requests);
@@ -174,7 +199,7 @@ class Verifier {
     size_t key_bytes() const { return ed() ? 32 : 64; }
     Status verify_one(const uint8_t q[64], const bytes& msg, const bytes& sig, long slot = -1);
     std::string cache_key(const uint8_t q[64], const bytes& msg, const bytes& sig) const;
-    std::mutex mu_;
+    SpinLock mu_;
     std::map<uint64_t, bytes> consenters_;
     std::map<uint64_t, long> consenter_slot_;
     std::map<std::string, long> client_slot_;       // backend key slot per client, -1 without a registry
@@ -182,7 +207,7 @@ class Verifier {
     uint64_t seq_ = 0;
     VerifierOptions opt_;
     Coalescer co_;
-    std::mutex cache_mu_;
+    SpinLock cache_mu_;
     std::unordered_map<std::string, bool> cache_;
     // Grow-only staging arrays of the raw-messages batch path, page-locked when the backend offers it: handing
     // pageable memory to a ~100 MB batch costs more in the runtime's pinning than the kernels take.

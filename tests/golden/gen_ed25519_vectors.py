@@ -36,6 +36,16 @@ RFC = [("9d61b19deffd5a60ba844af492ec2cc44449c5697b326919703bac031cae7f60", "d75
 for i, (sk, pk, m, s) in enumerate(RFC):
     assert ed.public_key(bytes.fromhex(sk)) == bytes.fromhex(pk) and ed.sign(bytes.fromhex(sk), bytes.fromhex(m)) == bytes.fromhex(s)
     add(f"rfc8032_test{i + 1}", bytes.fromhex(pk), bytes.fromhex(m), bytes.fromhex(s), "rfc8032", "RFC 8032 section 7.1")
+# RFC 8032 section 7.1 "TEST SHA(abc)" (round 4): the message is SHA-512("abc"), 64 bytes.  Transcribed from the published text;
+# the transcription is self-checking — the seed must give the public key, the deterministic signer must reproduce the
+# signature bit for bit and the verifier must accept it (asserted here), which no mistyped vector survives.  The fourth
+# vector of that section (TEST 1024, a 1023-byte message) is not here: its message cannot be reproduced offline.
+import hashlib
+sk, pk, m, s = ("833fe62409237b9d62ec77587520911e9a759cec1d19755b7da901b96dca3d42", "ec172b93ad5e563bf4932c70e1245034c35467ef2efd4d64ebf819683467e2bf",
+                hashlib.sha512(b"abc").hexdigest(),
+                "dc2a4459e7369633a52b1bf277839a00201009a3efbf3ecb69bea2186c26b58909351fc9ac90b3ecfdfbc7c66431e0303dca179c138ac17ad9bef1177331a704")
+assert ed.public_key(bytes.fromhex(sk)) == bytes.fromhex(pk) and ed.sign(bytes.fromhex(sk), bytes.fromhex(m)) == bytes.fromhex(s)
+add("rfc8032_test_sha_abc", bytes.fromhex(pk), bytes.fromhex(m), bytes.fromhex(s), "rfc8032", "RFC 8032 section 7.1, TEST SHA(abc)")
 
 # honest + flips
 for i in range(16):

@@ -10,6 +10,7 @@
 #   ab:<log2,..>:<variant>:<variant>...   tools/ab_env.py in ONE process (variant = NAME=VAL+NAME=VAL or "default")
 #   abfresh:<log2,..>:<variant>:...       the same, a fresh process per variant, two passes (per-process knobs)
 #   py:<script>[:args...]         python tools/<script> args   (anything else a session needs)
+#   trace:<script>[:args...]      the same under rocprofv3 --kernel-trace --stats -> kernel_stats_<script>.csv
 #   isa                           tools/isa_stats.sh (static ISA statistics; needs no GPU, here for the record of the build)
 set -u
 TAG=${1:?tag}; shift
@@ -97,6 +98,20 @@ PY
     py)
       name=$(basename "${a1%.py}")
       ( timeout 900 python "tools/$a1" $(echo "${a2:-}:${rest:-}" | tr ':' ' ') > "$OUT/$name.out" 2> "$OUT/$name.err"; echo "rc=$?" >> "$OUT/$name.err" ); tail -30 "$OUT/$name.out"; tail -3 "$OUT/$name.err" ;;
+    trace)          # trace:<script>[:args...]  rocprofv3 --kernel-trace --stats of python tools/<script>: per-kernel durations
+      name=$(basename "${a1%.py}")
+      ( cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/tr_$name" -o p -- python "$ROOT/tools/$a1" $(echo "${a2:-}:${rest:-}" | tr ':' ' ') > "$OUT/trace_$name.log" 2>&1; echo "rc=$?" >> "$OUT/trace_$name.log" )
+      cp "$OUT/tr_$name/p_kernel_stats.csv" "$OUT/kernel_stats_$name.csv" 2>/dev/null; rm -rf "$OUT/tr_$name"
+      python3 - "$OUT/kernel_stats_$name.csv" <<'PY'
+import csv, sys
+try:
+    for r in csv.DictReader(open(sys.argv[1])):
+        if "sbv::" in r["Name"]:
+            print("%-34s calls %6s  avg %9.1f us  min %9.1f  max %9.1f" % (r["Name"].split("(")[0].replace("sbv::", ""), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
+except Exception as e:
+    print("no stats", e)
+PY
+      ;;
     isa) bash tools/isa_stats.sh > "$OUT/isa_stats.txt" 2>&1; grep "^==" "$OUT/isa_stats.txt" | cut -c1-200 ;;
     *) echo "unknown step $step" ;;
   esac
