@@ -240,30 +240,6 @@ SBV_HD void prep_chunk29(TupleWords words, size_t n, const Scratch& sc_, size_t 
     }
 }
 
-// Stage A of ONE signature, entirely in registers (the latency kernel of small registered-key batches: a commit quorum
-// is 15 signatures, internal/bft/view.go:531-541).  Same rules and results as prep_chunk29 with T = 1: range checks on r and
-// s, e = hash mod N, w = s^-1, u1 = e w, u2 = r w (plain integers mod N).  The inversion works on the plain s directly, so
-// a lone signature needs one division-step chain and three multiplications.
-SBV_HD bool stage_a_single(const u256& r, const u256& s, const u256& hash, u256& u1, u256& u2) {
-    const sc n_ = sc_n();
-    const bool ok = !is_zero256(r) && lt256(r, n_) && !is_zero256(s) && lt256(s, n_);
-    u256 e = hash;
-    sc_cond_sub_n(e, e, 0);                     // hashToNat: e < 2^256 < 2N
-    u256 one = {{1, 0, 0, 0, 0, 0, 0, 0}}, sv, w;
-    select256(sv, ok, s, one);                  // keep the inversion's input in [1, N)
-    modinv30(w, sv, modinfo30_p256_order());
-    fe29 wl, wM, eL, rL, u;
-    f29_unpack(wl, w.v);
-    s29_mul(wM, wl, s29_r2());                  // w in Montgomery form: Montgomery(w) * plain(x) = plain(w x)
-    f29_unpack(eL, e.v);
-    f29_unpack(rL, r.v);                        // garbage-but-bounded when r >= N: the verdict is already false
-    s29_mul(u, wM, eL);
-    s29_store_canon(u1, u);
-    s29_mul(u, wM, rL);
-    s29_store_canon(u2, u);
-    return ok;
-}
-
 // ---- stage B ----------------------------------------------------------------------------------------
 #define SBV_QTAB_ENTRIES 8
 #define SBV_GTAB_WINDOWS 33

@@ -18,17 +18,11 @@ hipError_t launch_p256_prep_blocks(const uint8_t* d_tuples, size_t n, const Scra
 hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
                                     const uint8_t* d_kvalid, const gcomb& d_gcomb, uint8_t* d_bitmap, uint8_t* d_rerun,
                                     hipStream_t stream);
-// latency form of small registered-key batches in one launch (p256_kernels.hip: k_p256_verify_keyed_small).  d_in: the device
-// view of a page-locked buffer holding n x 96 bytes r|s|hash and, at byte SBV_SMALL_MAX * 96, n u32 key slots; d_out: one
-// verdict byte per signature; d_done: system-scope counter, += 1 per signature when its verdict is visible.
-// One workgroup's worth: measured on MI355X (profiles/r03/latency_small_r03g.jsonl, kernel trace r03h) the one-launch form takes
-// 85-100 us for up to 32 signatures (the staged path: 48 us stage A + 49 us comb kernel + copies = 131 us per call), but with a
-// second workgroup its median doubles (180 us), so 33+ signatures keep the staged path.
+// latency form of small registered-key batches in one launch (p256_kernels.hip: host_prep_small + k_p256_verify_prepared_small).
+// d_in: the device view of a page-locked buffer holding n records r | u1 | u2 (24 words each, written by host_prep_small) and,
+// at byte SBV_SMALL_MAX * 96, n u32 key slots; d_out: one verdict byte per signature; d_done: system-scope counter, += the
+// workgroup's signatures when their verdicts are visible.  Up to two workgroups of 16 signatures.
 #define SBV_SMALL_MAX 32
-hipError_t launch_p256_verify_keyed_small(const void* d_in, size_t n, u32 nkeys, const apt* d_ktab, const uint8_t* d_kvalid, const gcomb& d_gcomb,
-                                          uint8_t* d_out, u32* d_done, hipStream_t stream);
-// the same with stage A on the host (host_prep_small writes the records r | u1 | u2 and the slots; k_p256_verify_prepared_small:
-// 16 lanes per signature)
 hipError_t launch_p256_verify_prepared_small(const void* d_in, size_t n, u32 nkeys, const apt* d_ktab, const uint8_t* d_kvalid, const gcomb& d_gcomb,
                                              uint8_t* d_out, u32* d_done, hipStream_t stream);
 void host_prep_small(const uint8_t* rsh, const u32* slots, size_t n, u32* rec, u32* slot_out);

@@ -12,7 +12,7 @@
 //                         256 doublings on the carry-free field (p256_comb29.h: verify29_lane_generic).
 //   k_p256_verify_keyed   registered keys: 13 + 33 comb additions per lane, no doublings.
 //   k_p256_verify_keyed_coop   the same for batches <= 32768: 8 lanes per signature, butterfly of exact XYZZ additions.
-//   k_p256_verify_keyed_small  batches <= 64 in ONE launch: stage A in registers, records / verdicts in mapped host memory.
+//   k_p256_verify_prepared_small  batches <= 32 in ONE launch: stage A on the host (host_prep_small), records / verdicts in mapped host memory, 16 lanes per signature.
 //   k_p256_sign           batch signing (RFC 6979), k_msg_frontend: SHA-256 + strict DER in front of the keyed kernels.
 // The accept bits are gathered with a 64-wide ballot and written as bitmap bytes.
 //
@@ -152,105 +152,20 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_coop(
     }
 }
 
-// The latency form in ONE launch (n <= SBV_SMALL_MAX: a commit quorum, a handful of serial single verifications): stage A
-// of a signature runs in lane 0 of its 8-lane group straight from the caller's page-locked input (mapped into the device's
-// address space: no staging copy, no scratch round trip), u1 / u2 / r reach the other lanes by shuffles, the 46 comb terms
-// and the butterfly are those of k_p256_verify_keyed_coop, and the verdict is written as one byte per signature into mapped
-// host memory followed by a system-scope counter the host polls — no copy back, no stream synchronisation on the way out.
-// in: n x 96 bytes r | s | hash (big-endian), then at byte SBV_SMALL_MAX * 96 the n key slots.
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_small(const u32* __restrict__ in, u32 n, u32 nkeys,
-                                                                              const apt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
-                                                                              gcomb g16, uint8_t* __restrict__ out, u32* __restrict__ done) {
-    // The input lives in HOST memory: a lane-by-lane dword walk over it is one PCIe read per dword (measured: 64 signatures
-    // took 230 us that way, 15 took 128).  The workgroup's 32 records (3 KB) are fetched with 16-byte loads, one per lane —
-    // whole PCIe bursts — into LDS, and the verdicts leave as one 32-bit word per 4 signatures plus ONE counter update.
-    constexpr int kSigs = SBV_VERIFY_BLOCK / SBV_COOP_LANES;          // signatures per workgroup
-    __shared__ u32 rec[kSigs * 24];
-    __shared__ u32 slot_s[kSigs];
-    __shared__ u32 verdict_s[kSigs];
-    const u32 first = blockIdx.x * kSigs;
-    const u32 here = n - first < (u32)kSigs ? n - first : (u32)kSigs;   // signatures of this workgroup (the launch covers no empty one)
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)first * 24);
-        for (u32 e = threadIdx.x; e < here * 6; e += SBV_VERIFY_BLOCK) {
-            const uint4 v = src[e];
-            rec[4 * e] = v.x; rec[4 * e + 1] = v.y; rec[4 * e + 2] = v.z; rec[4 * e + 3] = v.w;
-        }
-        if (threadIdx.x < here) slot_s[threadIdx.x] = in[SBV_SMALL_MAX * 24 + first + threadIdx.x];
-        if (threadIdx.x < kSigs) verdict_s[threadIdx.x] = 0;
-    }
-    __syncthreads();
-    const u32 g = threadIdx.x / SBV_COOP_LANES;                        // signature of this lane inside the workgroup
-    const int sub = (int)(threadIdx.x % SBV_COOP_LANES);
-    const bool active = g < here;
-    u256 r, u1, u2;
-    SBV_UNROLL
-    for (int l = 0; l < 8; ++l) { r.v[l] = 0; u1.v[l] = 0; u2.v[l] = 0; }
-    u32 okw = 0, slot = 0;
-    if (active && sub == 0) {
-        const u32* t = rec + g * 24;
-        u256 s, h;
-        tuple_field(r, t, 0);
-        tuple_field(s, t, 1);
-        tuple_field(h, t, 2);
-        okw = stage_a_single(r, s, h, u1, u2) ? 1u : 0u;
-        slot = slot_s[g];
-    }
-    const int leader = (int)(threadIdx.x & 63u) & ~(SBV_COOP_LANES - 1);
-    SBV_UNROLL
-    for (int l = 0; l < 8; ++l) {
-        r.v[l] = (u32)__shfl((int)r.v[l], leader, 64);
-        u1.v[l] = (u32)__shfl((int)u1.v[l], leader, 64);
-        u2.v[l] = (u32)__shfl((int)u2.v[l], leader, 64);
-    }
-    okw = (u32)__shfl((int)okw, leader, 64);
-    slot = (u32)__shfl((int)slot, leader, 64);
-    xyzz R;
-    pt29_set_inf(R);
-    bool ok = false;
-    if (active) {
-        ok = okw != 0 && slot < nkeys;
-        if (slot >= nkeys) slot = 0;
-        ok = ok && kvalid[slot] != 0;
-        keyed29_partial_lane(R, u1, u2, ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW), g16, sub);
-    }
-    SBV_NOUNROLL
-    for (int off = SBV_COOP_LANES / 2; off >= 1; off >>= 1) {
-        xyzz P;
-        SBV_UNROLL
-        for (int l = 0; l < 9; ++l) {
-            P.X.v[l] = __shfl_xor(R.X.v[l], off, 64);
-            P.Y.v[l] = __shfl_xor(R.Y.v[l], off, 64);
-            P.ZZ.v[l] = __shfl_xor(R.ZZ.v[l], off, 64);
-            P.ZZZ.v[l] = __shfl_xor(R.ZZZ.v[l], off, 64);
-        }
-        P.inf = __shfl_xor(R.inf ? 1 : 0, off, 64) != 0;
-        pt29_add(R, P);
-    }
-    if (active && sub == 0) verdict_s[g] = ok && pt29_rx_matches(R, r) ? 1u : 0u;
-    __syncthreads();
-    if (threadIdx.x < kSigs / 4) {                                     // 8 lanes, one 32-bit store each: 4 verdict bytes
-        const u32 w = verdict_s[4 * threadIdx.x] | (verdict_s[4 * threadIdx.x + 1] << 8) | (verdict_s[4 * threadIdx.x + 2] << 16) |
-                      (verdict_s[4 * threadIdx.x + 3] << 24);
-        reinterpret_cast<u32*>(out)[first / 4 + threadIdx.x] = w;       // first is a multiple of 32
-        __threadfence_system();                                          // visible to the host before the counter says so
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence_system();
-        __hip_atomic_fetch_add(done, here, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-// The latency form with stage A on the HOST (round 4).  A commit quorum is 15 signatures: their stage A — one modular inversion
-// shared by Montgomery's trick and four multiplications mod N each — is ~10 us of one CPU core (host_prep_small below: the same
-// prep_chunk29 the stage-A kernel runs, compiled for the host), against a 600-step division chain of ~40 us on a lane of a
-// 2.4 GHz SIMD that 63 other lanes wait for.  The device keeps what is parallel: the 13 + 33 comb terms of u1 G + u2 Q, here
-// SBV_SMALL_LANES = 16 lanes per signature (3 terms per lane, then a 4-level butterfly of exact XYZZ additions: 7 dependent
-// additions instead of the 9 of the 8-lane form).
+// The latency form in ONE launch (n <= SBV_SMALL_MAX: a commit quorum, a handful of serial single verifications), stage A on
+// the HOST.  A commit quorum is 15 signatures: their stage A — one modular inversion shared by Montgomery's trick and four
+// multiplications mod N each — is ~7 us of one CPU core (host_prep_small below: the same prep_chunk29 the stage-A kernel runs,
+// compiled for the host), against a 600-step division chain of ~40 us on ONE lane of a 2.4 GHz SIMD that 63 other lanes wait
+// for.  The device keeps what is parallel: the 13 + 33 comb terms of u1 G + u2 Q, SBV_SMALL_LANES = 16 lanes per signature
+// (3 terms per lane, then a 4-level butterfly of exact XYZZ additions: 7 dependent additions instead of the 9 of the 8-lane
+// form).  The records come from the caller's page-locked buffer (mapped into the device's address space: no staging copy),
+// every verdict goes back as a byte in mapped host memory followed by a system-scope counter the host polls — no copy back,
+// no stream synchronisation on the way out.  Measured (profiles/r04/latency_small_r04d.jsonl, kernel_stats_latency_small_r04f.csv):
+// a 15-signature call 136 -> 58 us, a lone signature 111 -> 54 us against round 3's form with stage A in lane 0 of each group
+// (k_p256_verify_keyed_small, removed); the kernel itself 85-100 -> 38-43 us.
 // in: n records of 24 words r | u1 | u2 (plain 256-bit integers, least significant word first), then at word
 // SBV_SMALL_MAX * 24 the n key slots; a slot >= nkeys (the host writes 0xFFFFFFFF for a signature that failed the range checks)
-// is a reject.  Verdict bytes and the completion counter as in k_p256_verify_keyed_small.
+// is a reject.
 #define SBV_SMALL_LANES 16
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_prepared_small(const u32* __restrict__ in, u32 n, u32 nkeys,
                                                                                  const apt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
@@ -358,15 +273,6 @@ void host_prep_small(const uint8_t* rsh, const u32* slots, size_t n, u32* rec, u
         memcpy(rec + 24 * i + 16, t.v, 32);
         slot_out[i] = ok[i] ? slots[i] : 0xFFFFFFFFu;
     }
-}
-
-hipError_t launch_p256_verify_keyed_small(const void* d_in, size_t n, u32 nkeys, const apt* d_ktab, const uint8_t* d_kvalid, const gcomb& d_gtab,
-                                          uint8_t* d_out, u32* d_done, hipStream_t stream) {
-    if (n == 0 || n > SBV_SMALL_MAX) return hipErrorInvalidValue;
-    const size_t lanes = n * SBV_COOP_LANES;
-    hipLaunchKernelGGL(k_p256_verify_keyed_small, dim3((unsigned)((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK)), dim3(SBV_VERIFY_BLOCK), 0, stream,
-                       static_cast<const u32*>(d_in), (u32)n, nkeys, d_ktab, d_kvalid, d_gtab, d_out, d_done);
-    return hipGetLastError();
 }
 
 // Generic form (public key in the tuple), carry-free field: per-signature AFFINE window table in HBM (p256_comb29.h:

@@ -89,7 +89,7 @@ struct Context {
     sbv::kapt* d_k256_gtab = nullptr;   // secp256k1 comb of G (17 x 32768 entries), built on first use
     sbv::kapt* d_k256_gcomb = nullptr;  // the grouped step's wider comb of G (SBV_K256_G_BITS, default 20: 13 x 2^19 entries), built on first use
     int k256_gbits = 16;
-    // latency form of small registered-key batches (k_p256_verify_keyed_small): page-locked buffers mapped into the device's
+    // latency form of small registered-key batches (k_p256_verify_prepared_small): page-locked buffers mapped into the device's
     // address space — input records + slots, one verdict byte per signature + the completion counter the host polls
     uint8_t* h_small_in = nullptr; void* d_small_in = nullptr;
     uint8_t* h_small_out = nullptr; void* d_small_out = nullptr;
@@ -930,32 +930,24 @@ extern "C" int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* s
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
     if (n <= SBV_SMALL_MAX && c.small_enabled) {
-        // The latency form: ONE launch, no staging copies.  The records go into a page-locked buffer the kernel reads over
-        // PCIe, every verdict comes back as a byte in mapped host memory, and this thread polls the completion counter
-        // instead of sleeping in a stream synchronisation (a commit quorum: 15 signatures, internal/bft/view.go:531-541).
+        // The latency form: ONE launch, no staging copies.  Stage A runs here on the host (host_prep_small), its records go into
+        // a page-locked buffer the kernel reads over PCIe, every verdict comes back as a byte in mapped host memory, and this
+        // thread polls the completion counter instead of sleeping in a stream synchronisation (a commit quorum: 15
+        // signatures, internal/bft/view.go:531-541).
         if (!c.h_small_in) {
             HIP_TRY(SBV_ENOMEM, hipHostMalloc(&c.h_small_in, SBV_SMALL_MAX * (96 + 4), hipHostMallocMapped));
             HIP_TRY(SBV_ENOMEM, hipHostMalloc(&c.h_small_out, SBV_SMALL_MAX + 64, hipHostMallocMapped));
             HIP_TRY(SBV_EDEVICE, hipHostGetDevicePointer(&c.d_small_in, c.h_small_in, 0));
             HIP_TRY(SBV_EDEVICE, hipHostGetDevicePointer(&c.d_small_out, c.h_small_out, 0));
         }
-        static const bool host_prep = [] { const char* e = getenv("SBV_SMALL_HOSTPREP"); return !(e && e[0] == '0'); }();     // A/B hook of round 4
-        if (host_prep) sbv::host_prep_small(rsh, slots, n, reinterpret_cast<u32*>(c.h_small_in), reinterpret_cast<u32*>(c.h_small_in + SBV_SMALL_MAX * 96));
-        else {
-            memcpy(c.h_small_in, rsh, n * 96);
-            memcpy(c.h_small_in + SBV_SMALL_MAX * 96, slots, n * sizeof(u32));
-        }
+        // stage A of the call on this thread (one inversion for all n signatures), straight into the mapped buffer
+        sbv::host_prep_small(rsh, slots, n, reinterpret_cast<u32*>(c.h_small_in), reinterpret_cast<u32*>(c.h_small_in + SBV_SMALL_MAX * 96));
         volatile u32* done = reinterpret_cast<volatile u32*>(c.h_small_out + SBV_SMALL_MAX);
         *done = 0;
         std::atomic_thread_fence(std::memory_order_seq_cst);
-        if (host_prep)
-            HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_prepared_small(c.d_small_in, n, (u32)c.nkeys, c.d_ktab, c.d_kvalid, sbv::gcomb_make(c.d_g16r, c.g_bits),
-                                                                      static_cast<uint8_t*>(c.d_small_out),
-                                                                      reinterpret_cast<u32*>(static_cast<uint8_t*>(c.d_small_out) + SBV_SMALL_MAX), c.stream));
-        else
-        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_keyed_small(c.d_small_in, n, (u32)c.nkeys, c.d_ktab, c.d_kvalid, sbv::gcomb_make(c.d_g16r, c.g_bits),
-                                                               static_cast<uint8_t*>(c.d_small_out),
-                                                               reinterpret_cast<u32*>(static_cast<uint8_t*>(c.d_small_out) + SBV_SMALL_MAX), c.stream));
+        HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_prepared_small(c.d_small_in, n, (u32)c.nkeys, c.d_ktab, c.d_kvalid, sbv::gcomb_make(c.d_g16r, c.g_bits),
+                                                                  static_cast<uint8_t*>(c.d_small_out),
+                                                                  reinterpret_cast<u32*>(static_cast<uint8_t*>(c.d_small_out) + SBV_SMALL_MAX), c.stream));
         const auto give_up = t0 + std::chrono::milliseconds(5);
         while (*done < (u32)n) {
             if (std::chrono::steady_clock::now() > give_up) break;     // slow box / fault: let the runtime tell which

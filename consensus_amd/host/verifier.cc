@@ -356,11 +356,13 @@ void Coalescer::serve_as_leader() {
             // The first job (the leader's own) is here: give concurrent callers a short window to join the batch.  The window
             // is tens of microseconds — below the kernel's timer slack — so the leader polls the queue length and leaves early
             // when the expected burst is complete or nothing new has arrived for a quiet period: a quarter of the window while
-            // no burst size is known, half of it when one is (the votes of a burst arrive a few microseconds apart and must
-            // not be cut into several serial round trips; but a LONE call — VerifyRequest from HandleRequest, the serial
-            // verifyPrevCommitSignatures loop of internal/bft/view.go:630-644, a view-change VerifySignature — must not sit
-            // out the whole window either: at N = 16 that was 15 x 50 us per sequence).  Later batches of the same leadership
-            // (jobs that arrived during the backend call) go out at once.
+            // no burst size is known, half of it when one is (the votes of a burst arrive a microsecond apart — measured,
+            // profiles/r04/m2_trace_r04k.txt: the second vote 0-5 us after the leader, the fifteenth after 6-12 — and must
+            // not be cut into several serial round trips), but only a SIXTH of it (8 us) while the leader is still alone: a LONE
+            // call — VerifyRequest from HandleRequest, the serial verifyPrevCommitSignatures loop of
+            // internal/bft/view.go:630-644, a view-change VerifySignature — must not sit out the window (at N = 16 that was
+            // 10 x 25 us per sequence).  Later batches of the same leadership (jobs that arrived during the backend call) go
+            // out at once.
             if (first_batch) {
                 const auto t_first = std::chrono::steady_clock::now();
                 const auto deadline = t_first + max_wait_;
@@ -373,7 +375,7 @@ void Coalescer::serve_as_leader() {
                     const size_t hint = burst_hint_.load(std::memory_order_relaxed);
                     if (have >= max_batch_ || (hint && have >= hint) || now >= deadline) break;
                     if (have != seen) { seen = have; last = now; }
-                    else if (now - last >= (hint ? 2 * quiet : quiet)) break;
+                    else if (now - last >= (have == 1 ? max_wait_ / 6 : (hint ? 2 * quiet : quiet))) break;    // alone so far: a sixth of the window (8 us)
                     cpu_relax();
                 }
             }

@@ -19,12 +19,14 @@ type Options struct {
 	// Scheme: SchemeP256 (default), SchemeEd25519 or SchemeSecp256k1.  One Verifier = one scheme.
 	Scheme Scheme
 	// GPUMin: batches with fewer signatures are verified with the standard library on the calling goroutines' cores.
-	// Through the registered-key route a K = 100 proposal takes 0.27 ms on the device (16 cores need ~0.6 ms), a burst of
-	// 15 commit votes ~0.2 ms (15 idle cores: ~0.1 ms) — DESIGN.md section 5.  The default sends everything from 32
-	// signatures on to the device; 0 = always use the backend.
+	// Through the registered-key route a K = 100 proposal takes 0.27 ms on the device (16 cores need ~0.6 ms); a burst of
+	// 15 commit votes 73-75 us through the C++ mirror since round 4 (one launch of the prepared-scalars latency kernel;
+	// 15 idle cores: ~100 us, one crypto/ecdsa verification) — DESIGN.md section 5.  The default sends everything from 8
+	// signatures on to the device (a burst at N >= 10; the 3 votes of a 4-node cluster stay on the CPU); 0 = always
+	// use the backend.
 	GPUMin int
-	// CoalesceWait / CoalesceMax: the longest the dispatcher holds the first single-signature call back while it waits
-	// for the rest of a burst, and how many calls it ships at once.
+	// CoalesceWait / CoalesceMax: the longest the leader of a burst holds the first single-signature call back while it
+	// waits for the rest of the burst, and how many calls it ships at once.
 	CoalesceWait time.Duration
 	CoalesceMax  int
 	// CacheVerified keeps verdicts of single-signature calls (commit signatures of sequence s reappear at s+1).
@@ -35,7 +37,7 @@ type Options struct {
 }
 
 // DefaultOptions are sized for a node with a GPU backend.
-var DefaultOptions = Options{GPUMin: 32, CoalesceWait: 50 * time.Microsecond, CoalesceMax: 4096, CacheVerified: true, DeviceClientKeys: true}
+var DefaultOptions = Options{GPUMin: 8, CoalesceWait: 50 * time.Microsecond, CoalesceMax: 4096, CacheVerified: true, DeviceClientKeys: true}
 
 // verdict of one coalesced job: a batch nobody could judge (device fault with no CPU verifier for the scheme) is its own
 // state — it must reach the caller as an error and must never be cached as "invalid".
@@ -57,9 +59,10 @@ type Verifier struct {
 	opt     Options
 	backend Backend
 	cpu     Backend // the standard library (cpuBackend); an interface so that tests can take it away
-	jobs    chan *job
-	stop    chan struct{}
-	wg      sync.WaitGroup
+	qmu     sync.Mutex // the queue of pending single-signature jobs and the leader flag
+	queue   []*job
+	leader  bool  // some caller is serving the queue (serve)
+	pending int32 // len(queue), readable without the lock by the collecting leader
 	burst   int32 // expected size of a burst of single-signature calls: N - 1 commit votes (internal/bft/view.go:537-541); 0 = unknown
 
 	mu         sync.RWMutex
@@ -94,17 +97,12 @@ func New(backend Backend, opt Options) *Verifier {
 	if opt.CoalesceMax <= 0 {
 		opt.CoalesceMax = 4096
 	}
-	v := &Verifier{opt: opt, backend: backend, cpu: cpuBackend{}, jobs: make(chan *job, 4096), stop: make(chan struct{}),
-		consenters: map[uint64]regKey{}, clients: map[string]regKey{}, cache: map[[32]byte]bool{}}
-	v.wg.Add(1)
-	go v.dispatch()
-	return v
+	return &Verifier{opt: opt, backend: backend, cpu: cpuBackend{}, consenters: map[uint64]regKey{}, clients: map[string]regKey{},
+		cache: map[[32]byte]bool{}}
 }
 
-// Close stops the dispatcher and releases the backend.
+// Close releases the backend (there is no goroutine to stop: concurrent calls are merged by the callers themselves, serve).
 func (v *Verifier) Close() {
-	close(v.stop)
-	v.wg.Wait()
 	v.backend.Close()
 }
 
@@ -206,48 +204,65 @@ func (v *Verifier) verifyBatch(items []Item) []bool {
 	return ok
 }
 
-// dispatch merges concurrent single-signature calls into one batch: it takes the first pending job and polls the queue —
-// spin, then yield; no timer: Go's timers fire 50-100 us late at this scale, which is the whole budget — until
+// serve merges concurrent single-signature calls into one batch WITHOUT a dispatcher goroutine: the first caller that finds
+// no leader becomes the leader (it is running already; a parked dispatcher would have to be woken first, and at this scale the
+// wake-up is a large part of the round trip — the C++ mirror measured 191 -> 73 us for a burst of 15 votes with this and a
+// faster kernel, profiles/r04/m2_trace_r04k.txt).  The leader polls the queue — spin, then yield; no timer: Go's timers fire
+// 50-100 us late at this scale, which is the whole budget — until
 //
 //	the expected burst is in (N - 1 votes: the goroutines of View.processCommits arrive within microseconds of one
 //	another, internal/bft/view.go:537-541), or
-//	nothing has arrived for a quiet period of CoalesceWait / 4 (a lone call — VerifyRequest from HandleRequest, the serial
-//	loop of verifyPrevCommitSignatures, internal/bft/view.go:630-644 — is not held back for the whole window), or
-//	CoalesceWait has passed since the first job, or CoalesceMax jobs are queued.
+//	nothing has arrived for a quiet period: CoalesceWait / 6 while the leader is still alone (a lone call — VerifyRequest
+//	from HandleRequest, the serial loop of verifyPrevCommitSignatures, internal/bft/view.go:630-644 — is not held back for
+//	the whole window), CoalesceWait / 4 otherwise, or
+//	CoalesceWait has passed since it took over, or CoalesceMax jobs are queued,
 //
-// Counterpart of consensus_amd/host/verifier.cc: Coalescer::run.
-func (v *Verifier) dispatch() {
-	defer v.wg.Done()
+// ships the batch, hands the verdicts out and goes on with whatever queued up meanwhile (at once, no second window); it steps
+// down when it finds the queue empty, under the same lock a new job is appended with, so no job is ever left without a leader.
+// Counterpart of consensus_amd/host/verifier.cc: Coalescer::submit / serve_as_leader.
+func (v *Verifier) serve() {
+	first := true
 	for {
-		var first *job
-		select {
-		case <-v.stop:
+		if first {
+			start := time.Now()
+			lastArrival := start
+			seen := 1
+			hint := int(atomic.LoadInt32(&v.burst))
+			for {
+				have := int(atomic.LoadInt32(&v.pending))
+				if have >= v.opt.CoalesceMax || (hint > 0 && have >= hint) {
+					break
+				}
+				now := time.Now()
+				if have != seen {
+					seen, lastArrival = have, now
+				}
+				quiet := v.opt.CoalesceWait / 4
+				if have == 1 {
+					quiet = v.opt.CoalesceWait / 6
+				}
+				if now.Sub(start) >= v.opt.CoalesceWait || now.Sub(lastArrival) >= quiet {
+					break
+				}
+				runtime.Gosched()
+			}
+			first = false
+		}
+		v.qmu.Lock()
+		n := len(v.queue)
+		if n > v.opt.CoalesceMax {
+			n = v.opt.CoalesceMax
+		}
+		if n == 0 {
+			v.leader = false
+			v.qmu.Unlock()
 			return
-		case first = <-v.jobs:
 		}
-		batch := []*job{first}
-		start := time.Now()
-		lastArrival := start
-		quiet := v.opt.CoalesceWait / 4
-		hint := int(atomic.LoadInt32(&v.burst))
-	collect:
-		for len(batch) < v.opt.CoalesceMax {
-			select {
-			case j := <-v.jobs:
-				batch = append(batch, j)
-				lastArrival = time.Now()
-				continue
-			default:
-			}
-			if hint > 0 && len(batch) >= hint {
-				break collect
-			}
-			now := time.Now()
-			if now.Sub(start) >= v.opt.CoalesceWait || now.Sub(lastArrival) >= quiet {
-				break collect
-			}
-			runtime.Gosched()
-		}
+		batch := make([]*job, n)
+		copy(batch, v.queue[:n])
+		v.queue = append(v.queue[:0], v.queue[n:]...)
+		atomic.StoreInt32(&v.pending, int32(len(v.queue)))
+		v.qmu.Unlock()
 		items := make([]Item, len(batch))
 		for i, j := range batch {
 			items[i] = j.item
@@ -264,6 +279,23 @@ func (v *Verifier) dispatch() {
 			}
 		}
 	}
+}
+
+// submit queues one job, serves the queue if nobody else does, and waits for the job's verdict.
+func (v *Verifier) submit(it Item) verdict {
+	j := &job{item: it, done: make(chan verdict, 1)}
+	v.qmu.Lock()
+	v.queue = append(v.queue, j)
+	atomic.StoreInt32(&v.pending, int32(len(v.queue)))
+	lead := !v.leader
+	if lead {
+		v.leader = true
+	}
+	v.qmu.Unlock()
+	if lead {
+		v.serve() // returns with the queue empty: this job's verdict is in its channel
+	}
+	return <-j.done
 }
 
 // cacheKey must be injective in (key, signature, message): both variable-length fields are length-prefixed.  With a plain
@@ -306,9 +338,7 @@ func (v *Verifier) verifyOne(k regKey, msg, sig []byte) bool {
 		}
 		ok = verdict[0]
 	} else {
-		j := &job{item: k.item(msg, sig), done: make(chan verdict, 1)}
-		v.jobs <- j
-		switch <-j.done {
+		switch v.submit(k.item(msg, sig)) {
 		case verdictUnknown:
 			return false // as on the direct path: a device fault is an error for the caller and must not be remembered as "invalid"
 		case verdictValid:

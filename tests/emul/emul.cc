@@ -380,7 +380,7 @@ int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
     return valid;
 }
 
-static bool g_keyed_coop = false, g_keyed_small = false, g_keyed_prepared = false;
+static bool g_keyed_coop = false, g_keyed_prepared = false;
 static std::vector<u32> g_prep_rec, g_prep_slot;
 // the host half of the prepared latency form, as consensus_amd/csrc/p256_kernels.hip: host_prep_small does it
 struct EmulRecWords {
@@ -446,15 +446,6 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
             soa_load(a, s.u1, s.cap, i);
             soa_load(b, s.u2, s.cap, i);
             soa_load(rr, s.r, s.cap, i);
-            if (g_keyed_small) {       // k_p256_verify_keyed_small: stage A of the one signature in registers, straight from the record
-                u256 sv, hv, a2, b2;
-                HostWords::W w{rsh + 96 * i};
-                tuple_field(rr, w, 0); tuple_field(sv, w, 1); tuple_field(hv, w, 2);
-                const bool ok1 = stage_a_single(rr, sv, hv, a2, b2);
-                if (ok1 != (s.ok[i] != 0) || (ok1 && (!eq256(a, a2) || !eq256(b, b2)))) g_small_disagreements++;
-                a = a2; b = b2;
-                okk = ok1 && slots[i] < nkeys && kvalid[slot] != 0;
-            }
             if (g_keyed_prepared) {    // k_p256_verify_prepared_small: stage A by the host half (one chunk of all n records, ONE inversion)
                 if (n <= 32) {
                     if (i == 0) {
@@ -484,7 +475,7 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
         if (accept) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
     }
 }
-void sbve_set_keyed_coop(int on) { g_keyed_coop = on != 0; g_keyed_small = on == 2; g_keyed_prepared = on == 3; }   // 2: the one-launch latency form (stage A in registers); 3: the prepared form (stage A by the host half, 16 lanes per signature)
+void sbve_set_keyed_coop(int on) { g_keyed_coop = on != 0; g_keyed_prepared = on == 3; }   // 1: 8 lanes per signature (k_p256_verify_keyed_coop); 3: the one-launch latency form (stage A by the host half, 16 lanes per signature)
 unsigned long sbve_small_disagreements() { return g_small_disagreements; }
 unsigned long sbve_coop_disagreements() { return g_coop_disagreements; }
 

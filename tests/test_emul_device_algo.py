@@ -234,17 +234,8 @@ def test_registered_key_form_matches_generic_verdicts(emul, oracle, golden_vecto
         bad = [i for i in range(total) if got3[i] != want[i]]
         assert not bad, bad[:10]
         assert emul.sbve_coop_disagreements() == 0
-        # the one-launch latency form (k_p256_verify_keyed_small): stage A of each signature in registers (stage_a_single: the
-        # inversion on the plain s) must give the range verdict and u1 / u2 of stage A's chunked form, and the same accept bits
         emul.sbve_small_disagreements.restype = ctypes.c_ulong
-        emul.sbve_set_keyed_coop(2)
-        bm4 = ctypes.create_string_buffer((total + 7) // 8)
-        emul.sbve_p256_verify_batch_keyed(rsh, arr, total, b"".join(keys), len(keys), bm4, 64, 1)
-        got4 = _bitmap_list(bm4.raw, total)
-        bad = [i for i in range(total) if got4[i] != want[i]]
-        assert not bad, bad[:10]
-        assert emul.sbve_small_disagreements() == 0 and emul.sbve_coop_disagreements() == 0
-        # the prepared latency form (round 4: host_prep_small + k_p256_verify_prepared_small): stage A of a whole call (<= 32
+        # the one-launch latency form (host_prep_small + k_p256_verify_prepared_small): stage A of a whole call (<= 32
         # records) as ONE chunk with one inversion on the host half, 16 lanes per signature and a 4-level butterfly on the
         # device half.  Every golden vector, in calls of 1..32 records (out-of-range r / s sit beside honest ones in a chunk:
         # the product chain must stay invertible); r | u1 | u2 must be those of the kernels' chunked stage A.

@@ -208,9 +208,10 @@ def test_registered_key_form_equals_generic_verdicts(gpu, oracle, golden_vectors
         gotm = sbv.bitmap_to_list(gpu.verify_batch_keyed(rsh[:96 * m], [reg[s] for s in slots[:m]], m), m)
         badm = [i for i in range(m) if gotm[i] != want[i]]
         assert not badm, (m, badm[:10])
-    # batches <= 32 take the one-launch latency form (k_p256_verify_keyed_small: stage A in registers, input and verdicts in
-    # mapped host memory): every golden vector through it, 32 at a time, and again 15 at a time (a commit quorum)
-    for width in (32, 15):
+    # batches <= 32 take the one-launch latency form (host_prep_small + k_p256_verify_prepared_small: stage A on the host half
+    # with one inversion per call, 16 lanes per signature, records and verdicts in mapped host memory): every golden vector
+    # through it, 32 at a time, 15 at a time (a commit quorum: out-of-range r / s share an inversion with honest ones), 1 at a time
+    for width in (32, 15, 1):
         for lo in range(0, len(vs), width):
             m = min(width, len(vs) - lo)
             gotm = sbv.bitmap_to_list(gpu.verify_batch_keyed(rsh[96 * lo:96 * (lo + m)], [reg[s] for s in slots[lo:lo + m]], m), m)
