@@ -580,7 +580,8 @@ def leg_m2(tuples, n):
         rc = lib.sbvh_replay(v, 16, 10, 15, 0, min(64, os.cpu_count() or 8), ctypes.byref(res))
         lib.sbvh_verifier_free(v)
         out["gpu"] = res.commit_quorum_us if rc == 0 and res.status == 0 else None
-        out["gpu_note"] = "median over 15 sequences, coalescer window 50 us included, registered consenter keys, 8-lanes-per-signature kernel"
+        out["gpu_note"] = ("median over 15 sequences; 15 warm voter threads call VerifyConsenterSig at once, the leader-combining coalescer hands the burst to "
+                           "the one-launch latency form (stage A of the quorum on the host with one inversion, 16 lanes per signature, mapped host memory in and out); registered consenter keys")
     except Exception as e:      # noqa: BLE001
         out["gpu_error"] = repr(e)
     import numpy as np

@@ -68,16 +68,16 @@ SBV_HD void ept_load(ept& p, const u32* src) {
     fe25_load_raw(p.X, src); fe25_load_raw(p.Y, src + 10); fe25_load_raw(p.Z, src + 20); fe25_load_raw(p.T, src + 30);
 }
 
-// jbases: [groups][32] extended points 2^(8j) * (-A); valid[g] = the key decompressed.  One call produces
+// jbases: [groups][32] extended points 2^(8j) * (-A); *valid_of_slot (the byte of the group's table slot) = the key decompressed.  One call produces
 // bases j_first..j_last; a call with j_first > 0 continues the doubling chain from base j_first - 1.
-SBV_HD void ed_keytab_bases_lane(const uint8_t* tuples, u32 gidx, const GroupState& g, u32* jbases, uint8_t* valid,
+SBV_HD void ed_keytab_bases_lane(const uint8_t* tuples, u32 gidx, const GroupState& g, u32* jbases, uint8_t* valid_of_slot,
                                  int j_first, int j_last) {
     u32* out = jbases + (size_t)gidx * (SBV_ED_KEY_WINDOWS * SBV_ED_JBASE_DWORDS);
     ept t;
     if (j_first == 0) {
         ept A;
         const bool ok = ed_tuple_key_load(tuples, g.group_rep[gidx], A);
-        valid[gidx] = ok ? 1 : 0;         // an invalid key still gets a (garbage) table; it is never used
+        *valid_of_slot = ok ? 1 : 0;      // an invalid key still gets a (garbage) table; it is never used
         t = A;
         fe25_neg(t.X, A.X);
         fe25_neg(t.T, A.T);

@@ -35,24 +35,27 @@ __global__ __launch_bounds__(256) void k_ed_group_split(size_t n, GroupState g) 
     group_split_emit(i, s, active && s == SBV_GROUP_NONE, active && s != SBV_GROUP_NONE, false, g);
 }
 
+// only the groups whose tables are built in this batch (cold: not found in the key-table cache)
 __global__ __launch_bounds__(64) void k_ed_keytab_bases(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jbases,
-                                                        uint8_t* __restrict__ valid, int j_first, int j_last) {
+                                                        uint8_t* __restrict__ valid, const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
+                                                        int j_first, int j_last) {
     const u32 k = blockIdx.x * 64 + threadIdx.x;
-    if (k < group_count(g)) ed_keytab_bases_lane(tuples, k, g, jbases, valid, j_first, j_last);
+    if (k < group_count(g) && cold[k]) ed_keytab_bases_lane(tuples, k, g, jbases, valid + tslot[k], j_first, j_last);
 }
 
 // lanes = groups x j_count x parts
 __global__ __launch_bounds__(64) void k_ed_keytab_window(GroupState g, const u32* __restrict__ jbases, u32* __restrict__ tmp,
-                                                         aniels* __restrict__ ktab, int j_first, int j_count, int parts) {
+                                                         aniels* __restrict__ ktab, const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
+                                                         int j_first, int j_count, int parts) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;
     const u32 part = lane % (u32)parts;
     const u32 kw = lane / (u32)parts;
     const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
-    if (key >= group_count(g)) return;
+    if (key >= group_count(g) || !cold[key]) return;
     const size_t w = (size_t)key * SBV_ED_KEY_WINDOWS + j;
     ed_keytab_window_lane(jbases + w * SBV_ED_JBASE_DWORDS, (int)part, parts,
                           tmp + w * (size_t)(SBV_ED_KEY_PER_WINDOW * SBV_ED_WINDOW_TMP_WORDS) + (size_t)part * (SBV_ED_KEY_PER_WINDOW / parts) * SBV_ED_WINDOW_TMP_WORDS,
-                          ktab + w * SBV_ED_KEY_PER_WINDOW);
+                          ktab + ((size_t)tslot[key] * SBV_ED_KEY_WINDOWS + j) * SBV_ED_KEY_PER_WINDOW);
 }
 
 // The one-lane kernel (ed25519_verify_lane) over the ungrouped list, at the 3 waves/SIMD budget of the throughput
@@ -76,6 +79,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_gph
 
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_qphase(const uint8_t* __restrict__ tuples, GroupState g,
                                                                   const aniels* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
+                                                                  const u32* __restrict__ tslot, u32 table_slots,
                                                                   u32* __restrict__ gacc, size_t cap, const uint8_t* __restrict__ okb,
                                                                   uint8_t* __restrict__ acc, int j0, int j1, int last) {
     if (g.sorted) {
@@ -87,14 +91,16 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_qph
         const u32 L = ((blockIdx.x & 7u) * per + local) * SBV_VERIFY_BLOCK + threadIdx.x;
         if (L >= lanes) return;
         const u32 t = g.grp_idx[L];
-        const bool v = ed_qphase_lane(tuples, t, g.grp_of[L], group_count(g), ktab, kvalid, gacc, cap, okb, j0, j1, last != 0, true);
+        const u32 grp = g.grp_of[L];
+        const bool v = ed_qphase_lane(tuples, t, grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE, table_slots, ktab, kvalid, gacc, cap, okb, j0, j1, last != 0, true);
         if (last) acc[t] = v ? 1 : 0;
         return;
     }
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= g.counters[1]) return;
     const u32 t = g.grp_idx[L];
-    const bool v = ed_qphase_lane(tuples, t, g.slots[t], group_count(g), ktab, kvalid, gacc, cap, okb, j0, j1, last != 0);
+    const u32 grp = g.slots[t];
+    const bool v = ed_qphase_lane(tuples, t, grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE, table_slots, ktab, kvalid, gacc, cap, okb, j0, j1, last != 0);
     if (last) acc[t] = v ? 1 : 0;
 }
 
@@ -125,8 +131,11 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     const unsigned gn = (unsigned)((n + 255) / 256);
     const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
     hipLaunchKernelGGL(k_ed_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
-    hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g, KeyCache{});
+    hipLaunchKernelGGL((k_group_assign_t<128, 64, 8>), dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g, eb.kc);
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
+    hipLaunchKernelGGL((k_key_cache_lookup_t<128, 64, 8>), dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, eb.kc, b.tslot, b.cold);
+    hipLaunchKernelGGL((k_key_cache_insert_t<128, 64, 8>), dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, eb.kc, b.tslot);
+    const u32 table_slots = eb.kc.cap + b.max_groups;
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
     if (g.sorted) {
         const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
@@ -145,17 +154,17 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
         const int j_first = SBV_ED_KEY_WINDOWS * c / chunks, j_end = SBV_ED_KEY_WINDOWS * (c + 1) / chunks;
         const int j_count = j_end - j_first;
         hipLaunchKernelGGL(k_ed_keytab_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jbases, eb.kvalid,
-                           j_first, j_end - 1);
+                           b.tslot, b.cold, j_first, j_end - 1);
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
         hipStream_t tb = y.side_b;      // one table stream: the windows of the odd chunks on a second stream measured slower (round 4: 4.55 -> 4.67 ms)
         SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[c], 0));
         const size_t wl = (size_t)b.max_groups * j_count * parts;
         hipLaunchKernelGGL(k_ed_keytab_window, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.jbases, b.tmp, eb.ktab,
-                           j_first, j_count, parts);
+                           b.tslot, b.cold, j_first, j_count, parts);
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
-        hipLaunchKernelGGL(k_ed_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.gacc, b.gacc_cap,
+        hipLaunchKernelGGL(k_ed_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.tslot, table_slots, b.gacc, b.gacc_cap,
                            eb.okb, b.acc, j_first, j_end, c + 1 == chunks ? 1 : 0);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }

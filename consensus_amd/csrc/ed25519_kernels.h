@@ -9,11 +9,13 @@ hipError_t launch_ed25519_verify(const uint8_t* d_tuples, size_t n, u32* d_qtab,
                                  hipStream_t stream);
 // device buffers of the Ed25519 grouped step that the P-256 GroupBuffers do not already provide
 struct EdGroupBuffers {
-    aniels* ktab = nullptr;       // [max_groups][32 x 128] per-batch combs of -A
+    aniels* ktab = nullptr;       // [kc.cap + max_groups][32 x 128] combs of -A: slots [0, kc.cap) = this scheme's persistent key-table
+                                  // cache (round 4), [kc.cap, kc.cap + max_groups) = per batch
     uint8_t* okb = nullptr;       // [cap] S < L && k < L
-    uint8_t* kvalid = nullptr;    // [max_groups] 1 = the group's key decompressed.  NOT GroupBuffers::kvalid: bytes [0, kc.cap) of
+    uint8_t* kvalid = nullptr;    // [kc.cap + max_groups] 1 = the slot's key decompressed.  NOT GroupBuffers::kvalid: bytes [0, kc.cap) of
                                   // that array belong to the P-256 key-table cache and outlive the batch — an Ed25519 batch writing
                                   // its own group verdicts there invalidated cached P-256 keys (found in round 3 by test order)
+    KeyCache kc = {};             // keyed by the 32 key bytes (padded to the cache's 16 words)
     size_t cap = 0;
     u32 max_groups = 0;
 };

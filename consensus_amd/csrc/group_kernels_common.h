@@ -12,11 +12,37 @@ __device__ __forceinline__ u32 group_count(const GroupState& g) {
     return c < g.max_groups ? c : g.max_groups;
 }
 
-// kc: the persistent key-table cache (P-256; kc.enabled = 0 for Ed25519 and when the cache is off): cached keys are grouped
-// whatever their count in this batch
+// kc: the scheme's persistent key-table cache (kc.enabled = 0 when it is off): cached keys are grouped whatever their count
+// in this batch.  STRIDE / OFF / WORDS = the tuple format's key location (p256_group.h: group_insert_lane_t)
+template <int STRIDE, int OFF, int WORDS>
+static __global__ __launch_bounds__(256) void k_group_assign_t(const uint8_t* __restrict__ tuples, size_t n, GroupState g, KeyCache kc) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) group_assign_lane_t<STRIDE, OFF, WORDS>(tuples, i, g, kc);
+}
 static __global__ __launch_bounds__(256) void k_group_assign(const uint8_t* __restrict__ tuples, size_t n, GroupState g, KeyCache kc) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) group_assign_lane(tuples, i, g, kc);
+}
+
+// Every group of the batch finds its table slot (p256_group.h: persistent key-table cache), in two small launches of
+// 64-lane workgroups.  The lookup is read-only: everything in the table was inserted by earlier batches, i.e. by earlier
+// kernels; the insert places the misses (atomics only; the keys of one batch are distinct, so nobody needs to read what a
+// neighbour just wrote).  (One 1024-lane workgroup did both with a barrier in between; it had to wait ~130 us for a whole CU
+// to drain while stage A and the split kernel filled the device, at the head of the table-building chain.)
+template <int STRIDE, int OFF, int WORDS>
+static __global__ __launch_bounds__(64) void k_key_cache_lookup_t(const uint8_t* __restrict__ tuples, GroupState g, KeyCache kc,
+                                                                  u32* __restrict__ tslot, uint8_t* __restrict__ cold) {
+    const u32 k = blockIdx.x * 64 + threadIdx.x;
+    if (k == 0) { kc.count[1] = 0; kc.count[2] = 0; }       // hits / misses of this batch: counted by the insert kernel
+    if (k >= group_count(g)) return;
+    key_cache_phase_lookup<STRIDE, OFF, WORDS>(tuples, g, kc, k, tslot, cold);
+}
+template <int STRIDE, int OFF, int WORDS>
+static __global__ __launch_bounds__(64) void k_key_cache_insert_t(const uint8_t* __restrict__ tuples, GroupState g, KeyCache kc,
+                                                                  u32* __restrict__ tslot) {
+    const u32 k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= group_count(g)) return;
+    key_cache_phase_insert<STRIDE, OFF, WORDS>(tuples, g, kc, k, tslot);
 }
 
 static __global__ __launch_bounds__(256) void k_pack_bitmap(const uint8_t* __restrict__ acc, size_t n, uint8_t* __restrict__ bitmap) {

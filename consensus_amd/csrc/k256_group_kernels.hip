@@ -6,8 +6,9 @@
 //   side_a: insert assign | chain chunk 0 | chain chunk 1
 //   side_b:        wait(assign) classify keycheck sort | wait(chain c) rows fill of chunk c
 //
-// No persistent key cache on this curve (k256_group.h says why): every grouped key's comb is built in the call, in the per-batch
-// area of the comb pool.
+// The curve has a comb pool and a persistent key-table cache of its own (KeyPool: slots [0, kc.cap) are kept between batches,
+// [kc.cap, kc.cap + max_groups) are the per-batch area) — NOT the P-256 one: cache slots are found by the 64 key bytes, and a byte
+// string can be a point of both curves, so a shared table would let a crafted key be verified against the other curve's comb.
 #include <hip/hip_runtime.h>
 
 #include <thread>
@@ -69,35 +70,39 @@ struct k256_quad_dev {
         }
     }
 };
-// lanes = groups x 4; table slot of group k = slot0 + k (the per-batch area of the comb pool)
+// lanes = groups x 4; only the groups whose tables are built in this batch (cold); table slot of group k = tslot[k]
 __global__ __launch_bounds__(64) void k_k256_chain(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jstate, u32* __restrict__ bases,
-                                                   uint8_t* __restrict__ valid, int j_first, int j_last) {
+                                                   uint8_t* __restrict__ valid, const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
+                                                   int j_first, int j_last) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;
     const u32 k = lane >> 2;
-    if (k >= group_count(g)) return;
+    if (k >= group_count(g) || !cold[k]) return;
     k256_quad_dev q;
     q.r = (int)(lane & 3u);
-    k256_chain_run(q, tuples, k, g, jstate, bases, valid + k, j_first, j_last);
+    k256_chain_run(q, tuples, k, g, jstate, bases, valid + tslot[k], j_first, j_last);
 }
 __global__ __launch_bounds__(64, 2) void k_k256_rows(GroupState g, const u32* __restrict__ bases, u32* __restrict__ tmp, kapt* __restrict__ ktab,
-                                                     int j_first, int j_count) {
+                                                     const u32* __restrict__ tslot, const uint8_t* __restrict__ cold, int j_first, int j_count) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;
     const u32 which = lane & 1u, kw = lane >> 1;
     const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
-    if (key >= group_count(g)) return;
+    if (key >= group_count(g) || !cold[key]) return;
     if (which == 1 && j == SBV_GTAB_WINDOWS - 1) return;
     const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
     k256_rows_lane(bases + w * SBV_K256_BASES_STRIDE, (int)which, j == SBV_GTAB_WINDOWS - 1,
-                   tmp + w * SBV_K256_WINDOW_TMP + (size_t)which * SBV_K256_ROWS_TMP_WORDS, ktab + w * SBV_GTAB_PER_WINDOW);
+                   tmp + w * SBV_K256_WINDOW_TMP + (size_t)which * SBV_K256_ROWS_TMP_WORDS,
+                   ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
 }
 // lanes = groups x j_count x 7
-__global__ __launch_bounds__(64) void k_k256_fill(GroupState g, u32* __restrict__ tmp, kapt* __restrict__ ktab, int j_first, int j_count) {
+__global__ __launch_bounds__(64) void k_k256_fill(GroupState g, u32* __restrict__ tmp, kapt* __restrict__ ktab, const u32* __restrict__ tslot,
+                                                  const uint8_t* __restrict__ cold, int j_first, int j_count) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;
     const u32 r = lane % 7u, kw = lane / 7u;
     const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
-    if (key >= group_count(g) || j == SBV_GTAB_WINDOWS - 1) return;
+    if (key >= group_count(g) || j == SBV_GTAB_WINDOWS - 1 || !cold[key]) return;
     const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
-    k256_fill_lane(1 + (int)r, tmp + w * SBV_K256_WINDOW_TMP + (size_t)r * SBV_K256_FILL_TMP_WORDS, ktab + w * SBV_GTAB_PER_WINDOW);
+    k256_fill_lane(1 + (int)r, tmp + w * SBV_K256_WINDOW_TMP + (size_t)r * SBV_K256_FILL_TMP_WORDS,
+                   ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
 }
 
 // generic stage B over the ungrouped list (first blocks) + u1 * G over the key-sorted list
@@ -115,6 +120,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_gphase_generic(Scr
     if (i < g.counters[1]) k256_gphase_lane_sorted(s, g.grp_idx[i], i, gc, gacc);
 }
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_qphase(Scratch s, GroupState g, const kapt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
+                                                                   const u32* __restrict__ tslot, u32 table_slots,
                                                                    u32* __restrict__ gacc, uint8_t* __restrict__ acc, int j0, int j1, int last) {
     // key-sorted list, XCD-aware block order (p256_group_kernels.hip: k_verify_keyed_q)
     const u32 lanes = g.counters[1];
@@ -125,13 +131,13 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_qphase(Scratch s, 
     if (L >= lanes) return;
     const u32 t = g.grp_idx[L];
     const u32 grp = g.grp_of[L];
-    const bool v = k256_qphase_lane_sorted(s, t, L, grp < group_count(g) ? grp : SBV_GROUP_NONE, group_count(g), ktab, kvalid, gacc, j0, j1, last != 0);
+    const bool v = k256_qphase_lane_sorted(s, t, L, grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
     if (last) acc[t] = v ? 1 : 0;
 }
 
-// stage A + stage B of a grouped secp256k1 batch.  ev_fork must have been recorded on `stream` first.  The per-batch area of the
-// comb pool (b.ktab + kc.cap keys, b.kvalid + kc.cap) holds this batch's tables; group k uses slot k of it.
-hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_in, size_t n, const GroupBuffers& b, u32* d_qtab,
+// stage A + stage B of a grouped secp256k1 batch.  ev_fork must have been recorded on `stream` first.  kp: this curve's comb
+// pool and key-table cache; b supplies the grouping arrays, the chain records, tslot / cold and the accumulators.
+hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_in, size_t n, const GroupBuffers& b, const KeyPool& kp, u32* d_qtab,
                                       const kapt* d_gtab, const kapt* d_gcomb, int gcomb_bits, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y, hipEvent_t* prof, int* prof_pairs) {
     if (n == 0) return hipSuccess;
     GroupState g;
@@ -143,8 +149,9 @@ hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     Scratch s = s_in;
     s.rec = b.rec;
     const size_t sort_lds = (size_t)b.max_groups * sizeof(u32);
-    kapt* ktab = reinterpret_cast<kapt*>(b.ktab) + (size_t)b.kc.cap * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
-    uint8_t* kvalid = b.kvalid + b.kc.cap;
+    kapt* ktab = reinterpret_cast<kapt*>(kp.ktab);
+    uint8_t* kvalid = kp.kvalid;
+    const u32 table_slots = kp.kc.cap + b.max_groups;
     hipError_t e;
 #define SBV_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
     SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_fork, 0));
@@ -155,8 +162,10 @@ hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     const unsigned gn = (unsigned)((n + 255) / 256);
     const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
     hipLaunchKernelGGL(k_k256_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
-    hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g, KeyCache{});
+    hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g, kp.kc);
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
+    hipLaunchKernelGGL((k_key_cache_lookup_t<160, 96, 16>), dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, kp.kc, b.tslot, b.cold);
+    hipLaunchKernelGGL((k_key_cache_insert_t<160, 96, 16>), dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, kp.kc, b.tslot);
     {   // stage A: SBV_K256_PREP_T tuples per lane share one inversion (Montgomery's trick).  Measured in round 4
         // (profiles/r04/ab_k256_prep_t_r04a.jsonl): 1 / 4 / 8 tuples per inversion 4.97 / 4.79 / 4.68 ms per 2^20 step.
         const size_t per_block = (size_t)64 * SBV_K256_PREP_T;
@@ -175,17 +184,17 @@ hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     const int chunks = 2;
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks, j_count = j_end - j_first;
-        hipLaunchKernelGGL(k_k256_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases, kvalid, j_first, j_end - 1);
+        hipLaunchKernelGGL(k_k256_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases, kvalid, b.tslot, b.cold, j_first, j_end - 1);
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
         hipStream_t tb = y.tstreams > 1 && y.side_t && (c & 1) ? y.side_t : y.side_b;     // as the P-256 step: rows + fill of chunk 1 do not queue behind chunk 0's
         SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[c], 0));
         const size_t wl = (size_t)b.max_groups * j_count * 2, fl = (size_t)b.max_groups * j_count * 7;
-        hipLaunchKernelGGL(k_k256_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.tmp, ktab, j_first, j_count);
-        hipLaunchKernelGGL(k_k256_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, ktab, j_first, j_count);
+        hipLaunchKernelGGL(k_k256_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.tmp, ktab, b.tslot, b.cold, j_first, j_count);
+        hipLaunchKernelGGL(k_k256_fill, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, ktab, b.tslot, b.cold, j_first, j_count);
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
-        hipLaunchKernelGGL(k_k256_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, ktab, kvalid, b.gacc, b.acc, j_first, j_end,
+        hipLaunchKernelGGL(k_k256_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, ktab, kvalid, b.tslot, table_slots, b.gacc, b.acc, j_first, j_end,
                            c + 1 == chunks ? 1 : 0);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }

@@ -270,20 +270,26 @@ SBV_HD u32 key_cache_insert(const KeyCache& kc, const u32 w[16]) {
     }
     return slot;
 }
-// A representative takes a table slot when its key is used often enough in THIS batch — or when the persistent cache already
-// holds its comb (kc.enabled; P-256 only), however few of its signatures the batch carries: a warm key costs nothing to
+// A representative takes a table slot when its key is used often enough in THIS batch — or when the scheme's persistent cache
+// already holds its comb (kc.enabled), however few of its signatures the batch carries: a warm key costs nothing to
 // "build", so even a batch of a few thousand tuples then runs the comb phases instead of 256 doublings per signature.
 // The lookup is read-only (everything in the cache was inserted by earlier batches) and runs for the representatives below
-// the threshold only.
-SBV_HD void group_assign_lane(const uint8_t* tuples, size_t i, const GroupState& g, const KeyCache& kc) {
+// the threshold only.  STRIDE / OFF / WORDS: where a tuple format keeps its key (group_insert_lane_t); the cache compares
+// 16 words, a shorter key (Ed25519: 8) is padded with zeros.
+template <int STRIDE, int OFF, int WORDS>
+SBV_HD void key_words16_t(const uint8_t* tuples, size_t i, u32 w[16]) {
+    const u32* k = reinterpret_cast<const u32*>(tuples + i * STRIDE + OFF);
+    SBV_UNROLL
+    for (int j = 0; j < 16; ++j) w[j] = j < WORDS ? k[j] : 0u;
+}
+template <int STRIDE, int OFF, int WORDS>
+SBV_HD void group_assign_lane_t(const uint8_t* tuples, size_t i, const GroupState& g, const KeyCache& kc) {
     u32 s = SBV_GROUP_NONE;
     if (g.rep[i] == (u32)i) {
         bool take = g.cnt[i] >= g.min_samples;
         if (!take && kc.enabled) {
             u32 w[16];
-            const u32* k = tuple_key_words(tuples, i);
-            SBV_UNROLL
-            for (int j = 0; j < 16; ++j) w[j] = k[j];
+            key_words16_t<STRIDE, OFF, WORDS>(tuples, i, w);
             take = key_cache_lookup(kc, w) != SBV_GROUP_NONE;
         }
         if (take) {
@@ -293,15 +299,48 @@ SBV_HD void group_assign_lane(const uint8_t* tuples, size_t i, const GroupState&
     }
     g.slot_of[i] = s;
 }
+SBV_HD void group_assign_lane(const uint8_t* tuples, size_t i, const GroupState& g, const KeyCache& kc) {
+    group_assign_lane_t<160, 96, 16>(tuples, i, g, kc);
+}
 SBV_HD void group_assign_lane(size_t i, const GroupState& g) {
     KeyCache off = {};
     group_assign_lane(nullptr, i, g, off);
 }
 
+template <int STRIDE, int OFF, int WORDS>
+SBV_HD void key_cache_group_key_t(const uint8_t* tuples, const GroupState& g, u32 gidx, u32 w[16]) {
+    key_words16_t<STRIDE, OFF, WORDS>(tuples, g.group_rep[gidx], w);
+}
 SBV_HD void key_cache_group_key(const uint8_t* tuples, const GroupState& g, u32 gidx, u32 w[16]) {
-    const u32* k = tuple_key_words(tuples, g.group_rep[gidx]);
-    SBV_UNROLL
-    for (int j = 0; j < 16; ++j) w[j] = k[j];
+    key_cache_group_key_t<160, 96, 16>(tuples, g, gidx, w);
+}
+// The two phases every group of a batch goes through (device: k_key_cache_lookup / k_key_cache_insert of
+// group_kernels_common.h; the emulator runs them group by group): tslot[k] = table slot of group k, cold[k] = 1 when its
+// tables are built in this batch.  A miss with the cache off or full takes slot kc.cap + k of the scheme's pool (the
+// per-batch area).
+template <int STRIDE, int OFF, int WORDS>
+SBV_HD void key_cache_phase_lookup(const uint8_t* tuples, const GroupState& g, const KeyCache& kc, u32 k, u32* tslot, uint8_t* cold) {
+    u32 slot = SBV_GROUP_NONE;
+    if (kc.enabled) {
+        u32 w[16];
+        key_cache_group_key_t<STRIDE, OFF, WORDS>(tuples, g, k, w);
+        slot = key_cache_lookup(kc, w);
+    }
+    tslot[k] = slot;
+    cold[k] = slot == SBV_GROUP_NONE ? 1 : 0;
+}
+template <int STRIDE, int OFF, int WORDS>
+SBV_HD void key_cache_phase_insert(const uint8_t* tuples, const GroupState& g, const KeyCache& kc, u32 k, u32* tslot) {
+    const bool miss = tslot[k] == SBV_GROUP_NONE;
+    if (kc.enabled) SBV_ATOMIC_ADD(&kc.count[miss ? 2 : 1], 1u);
+    if (!miss) return;
+    u32 slot = SBV_GROUP_NONE;
+    if (kc.enabled) {
+        u32 w[16];
+        key_cache_group_key_t<STRIDE, OFF, WORDS>(tuples, g, k, w);
+        slot = key_cache_insert(kc, w);
+    }
+    tslot[k] = slot == SBV_GROUP_NONE ? kc.cap + k : slot;
 }
 
 // ---- per-batch key tables ----------------------------------------------------------------------------

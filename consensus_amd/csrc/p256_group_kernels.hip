@@ -80,41 +80,6 @@ __global__ __launch_bounds__(256) void k_group_keycheck(const uint8_t* __restric
 // tmp layout (u32 words): one strip of SBV_KT29_WINDOW_TMP words per (key, window), shared by the rows and the fill kernel
 // (same stream, never concurrent).
 #define SBV_KT29_WINDOW_TMP (7 * SBV_KT29_FILL_TMP_WORDS)
-// Every group of the batch finds its table slot (p256_group.h: persistent key-table cache), in two small launches of
-// 64-lane workgroups.  k_key_cache_lookup is read-only: everything in the table was inserted by earlier batches, i.e. by
-// earlier kernels; k_key_cache_insert places the misses (atomics only; the keys of one batch are distinct, so nobody needs
-// to read what a neighbour just wrote).  (One 1024-lane workgroup did both with a barrier in between; it had to wait ~130 us
-// for a whole CU to drain while stage A and the split kernel filled the device, at the head of the table-building chain.)
-__global__ __launch_bounds__(64) void k_key_cache_lookup(const uint8_t* __restrict__ tuples, GroupState g, KeyCache kc,
-                                                         u32* __restrict__ tslot, uint8_t* __restrict__ cold) {
-    const u32 k = blockIdx.x * 64 + threadIdx.x;
-    if (k == 0) { kc.count[1] = 0; kc.count[2] = 0; }       // hits / misses of this batch: counted by k_key_cache_insert
-    if (k >= group_count(g)) return;
-    u32 slot = SBV_GROUP_NONE;
-    if (kc.enabled) {
-        u32 w[16];
-        key_cache_group_key(tuples, g, k, w);
-        slot = key_cache_lookup(kc, w);
-    }
-    tslot[k] = slot;
-    cold[k] = slot == SBV_GROUP_NONE ? 1 : 0;
-}
-__global__ __launch_bounds__(64) void k_key_cache_insert(const uint8_t* __restrict__ tuples, GroupState g, KeyCache kc,
-                                                         u32* __restrict__ tslot) {
-    const u32 k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= group_count(g)) return;
-    const bool miss = tslot[k] == SBV_GROUP_NONE;
-    if (kc.enabled) atomicAdd(&kc.count[miss ? 2 : 1], 1u);
-    if (!miss) return;
-    u32 slot = SBV_GROUP_NONE;
-    if (kc.enabled) {
-        u32 w[16];
-        key_cache_group_key(tuples, g, k, w);
-        slot = key_cache_insert(kc, w);
-    }
-    tslot[k] = slot == SBV_GROUP_NONE ? kc.cap + k : slot;       // cache off or full: the per-batch area
-}
-
 // The table kernels are a few hundred lanes of latency-bound chains on the critical path of the step, sharing SIMDs with
 // the throughput kernels (G phase, Q phase, stage A): raise their wave priority so the arbiter issues them first.
 #ifndef SBV_TABLE_PRIO
@@ -351,8 +316,8 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     hipLaunchKernelGGL(k_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
     hipLaunchKernelGGL(k_group_assign, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g, b.kc);
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
-    hipLaunchKernelGGL(k_key_cache_lookup, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.kc, b.tslot, b.cold);
-    hipLaunchKernelGGL(k_key_cache_insert, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.kc, b.tslot);
+    hipLaunchKernelGGL((k_key_cache_lookup_t<160, 96, 16>), dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.kc, b.tslot, b.cold);
+    hipLaunchKernelGGL((k_key_cache_insert_t<160, 96, 16>), dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.kc, b.tslot);
     // stage A
     const size_t pbt = prep_block_tuples(n);
     const unsigned pblocks = (unsigned)((n + pbt - 1) / pbt);

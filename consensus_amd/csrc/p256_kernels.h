@@ -59,6 +59,15 @@ struct GroupBuffers {
     size_t cap = 0;
     size_t gacc_cap = 0;        // the scratch capacity gacc was sized for
 };
+// A scheme's comb pool with its persistent key-table cache (secp256k1; the Ed25519 step keeps the same three things in its
+// EdGroupBuffers, the P-256 step in GroupBuffers): table slots [0, kc.cap) are kept between batches, [kc.cap, kc.cap + max_groups)
+// are rebuilt per batch.  One pool per scheme: a slot is found by the key BYTES, and the same bytes can be a point of two curves.
+struct KeyPool {
+    void* ktab = nullptr;       // (kc.cap + max_groups) x SBV_KEYTAB_ENTRIES 64-byte affine entries
+    uint8_t* kvalid = nullptr;  // (kc.cap + max_groups)
+    KeyCache kc = {};
+    u32 max_groups = 0;
+};
 // streams and events of the grouped step; owned by the context.  `chunks` (1..SBV_GROUP_MAX_CHUNKS) = how
 // many pieces the 33 key-comb windows are built and consumed in.
 #define SBV_GROUP_MAX_CHUNKS 4
@@ -94,7 +103,7 @@ hipError_t launch_k256_verify(const uint8_t* d_tuples, size_t n, const Scratch& 
 void host_build_k256_gtable(kapt* out);
 // grouped step on this curve (k256_group_kernels.hip): stage A + stage B; ev_fork recorded on `stream` by the caller
 // d_gtab: the 16-bit comb (the generic lanes of the ungrouped list), d_gcomb: the `gcomb_bits`-wide comb of the G phase
-hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b, u32* d_qtab,
+hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s, size_t n, const GroupBuffers& b, const KeyPool& kp, u32* d_qtab,
                                       const kapt* d_gtab, const kapt* d_gcomb, int gcomb_bits, uint8_t* d_bitmap, hipStream_t stream, const GroupSync& y,
                                       hipEvent_t* prof = nullptr, int* prof_pairs = nullptr);      // prof: 4 events, a pair around each of the two k_k256_qphase launches
 void host_build_k256_gcomb(int bits, kapt* out);     // ceil(257 / bits) << (bits - 1) entries

@@ -76,11 +76,14 @@ struct Context {
     // the call, and below ~2^17 tuples building tables costs more latency (~2 ms) than the doubling kernel takes (1.3-1.5 ms):
     // group_min_batch_cold applies then.  sbv_p256_set_grouping(min_batch != 0) sets both.
     size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17;
-    size_t group_min_batch_ed = (size_t)1 << 18;     // Ed25519 keeps no tables between batches: its cold crossover (round 2)
-    size_t group_min_batch_k256 = (size_t)1 << 17;   // secp256k1: per-batch tables only (k256_group.h)
+    size_t group_min_batch_ed = (size_t)1 << 18;     // Ed25519 with its key-table cache off: the cold crossover (round 2); with it on, group_min_batch
+    size_t group_min_batch_k256 = (size_t)1 << 17;   // secp256k1 with its key-table cache off; with it on, group_min_batch
     u32 group_min_count = 64, group_max = 2048;
-    bool kc_enabled = true;             // persistent key-table cache (p256_group.h)
-    u32 kc_cap = 4096;                  // cached keys (270 KiB of HBM each)
+    // persistent key-table caches, one per scheme (SBV_SCHEME_*: P-256, secp256k1, Ed25519; p256_group.h): on / off and
+    // cached keys (270 KiB of HBM per ECDSA key, 384 KiB per Ed25519 key)
+    bool kc_on[3] = {true, true, true};
+    u32 kc_caps[3] = {4096, 1024, 1024};
+    sbv::KeyPool k256pool;              // secp256k1: comb pool + key-table cache of its own
     // message front end staging (grown on demand)
     uint8_t* d_msgs = nullptr; size_t msgs_cap = 0;
     uint8_t* d_sigs = nullptr; size_t sigs_cap = 0;
@@ -118,7 +121,7 @@ constexpr int kMaxDevices = 16;
 // lost, and after sbv_init_all it configures ALL devices, not just the default one.  Guarded by g_set_mu (a leaf lock).
 struct Settings {
     bool group_enabled = true; size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17, group_min_batch_ed = (size_t)1 << 18, group_min_batch_k256 = (size_t)1 << 17; u32 group_min_count = 64, group_max = 2048;
-    bool kc_enabled = true; u32 kc_cap = 4096;
+    bool kc_on[3] = {true, true, true}; u32 kc_caps[3] = {4096, 1024, 1024};
     int profiling = 0;
 } g_settings;
 std::mutex g_set_mu;
@@ -206,6 +209,33 @@ std::vector<hipEvent_t*> group_events(Context& c) {
     return v;
 }
 
+// device arrays of one persistent key-table cache (p256_group.h: KeyCache) for `K` keys
+int key_cache_alloc(sbv::KeyCache& kc, size_t K, bool enabled) {
+    size_t kht = 1024;
+    while (kht < 4 * (K ? K : 1)) kht *= 2;
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&kc.ht, kht * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&kc.keys, (K ? K : 1) * 16 * sizeof(u32)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&kc.count, 4 * sizeof(u32)));
+    HIP_TRY(SBV_EDEVICE, hipMemset(kc.ht, 0, kht * sizeof(u32)));
+    HIP_TRY(SBV_EDEVICE, hipMemset(kc.count, 0, 4 * sizeof(u32)));
+    kc.ht_mask = (u32)(kht - 1);
+    kc.cap = (u32)K;
+    kc.enabled = enabled ? 1u : 0u;
+    return SBV_OK;
+}
+void key_cache_free(sbv::KeyCache& kc) {
+    void* ptrs[] = {kc.ht, kc.keys, kc.count};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    kc = sbv::KeyCache{};
+}
+// forget every cached key (the tables stay where they are; nothing points at them any more)
+hipError_t key_cache_forget(sbv::KeyCache& kc) {
+    if (!kc.ht) return hipSuccess;
+    hipError_t e = hipMemset(kc.ht, 0, ((size_t)kc.ht_mask + 1) * sizeof(u32));
+    if (e == hipSuccess) e = hipMemset(kc.count, 0, 4 * sizeof(u32));
+    return e;
+}
+
 void free_group_buffers(Context& c) {
     sbv::GroupBuffers& b = c.grp;
     void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.jbases, b.bases, b.jstate, b.ktab, b.kvalid, b.tmp, b.acc, b.gacc,
@@ -215,14 +245,19 @@ void free_group_buffers(Context& c) {
     if (c.edgrp.ktab) (void)hipFree(c.edgrp.ktab);
     if (c.edgrp.okb) (void)hipFree(c.edgrp.okb);
     if (c.edgrp.kvalid) (void)hipFree(c.edgrp.kvalid);
+    key_cache_free(c.edgrp.kc);
     c.edgrp = sbv::EdGroupBuffers();
+    if (c.k256pool.ktab) (void)hipFree(c.k256pool.ktab);
+    if (c.k256pool.kvalid) (void)hipFree(c.k256pool.kvalid);
+    key_cache_free(c.k256pool.kc);
+    c.k256pool = sbv::KeyPool();
 }
 
 int ensure_group_buffers(Context& c, size_t n) {
     sbv::GroupBuffers& b = c.grp;
-    if (b.cap >= n && b.max_groups == c.group_max && b.gacc_cap == c.cap && b.kc.cap == c.kc_cap) {
+    if (b.cap >= n && b.max_groups == c.group_max && b.gacc_cap == c.cap && b.kc.cap == c.kc_caps[0]) {
         b.min_count = c.group_min_count;
-        b.kc.enabled = c.kc_enabled ? 1u : 0u;
+        b.kc.enabled = c.kc_on[0] ? 1u : 0u;
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
@@ -249,21 +284,15 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jstate, G * (size_t)36 * sizeof(u32)));                                  // SBV_KT29_STATE_WORDS
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 40 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride; 36 words (P-256: XYZZ, 9-limb coordinates) or 40 (Ed25519: extended, 10-limb coordinates) per tuple
     // comb pool: slots [0, kc_cap) belong to the persistent key-table cache, [kc_cap, kc_cap + G) are rebuilt per batch
-    const size_t K = c.kc_cap;
-    size_t kht = 1024;
-    while (kht < 4 * (K ? K : 1)) kht *= 2;
+    const size_t K = c.kc_caps[0];
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ktab, (K + G) * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, K + G));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tslot, G * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.cold, G));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kc.ht, kht * sizeof(u32)));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kc.keys, (K ? K : 1) * 16 * sizeof(u32)));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kc.count, 4 * sizeof(u32)));
-    HIP_TRY(SBV_EDEVICE, hipMemset(b.kc.ht, 0, kht * sizeof(u32)));
-    HIP_TRY(SBV_EDEVICE, hipMemset(b.kc.count, 0, 4 * sizeof(u32)));
-    b.kc.ht_mask = (u32)(kht - 1);
-    b.kc.cap = (u32)K;
-    b.kc.enabled = c.kc_enabled ? 1u : 0u;
+    {
+        const int krc = key_cache_alloc(b.kc, K, c.kc_on[0]);
+        if (krc != SBV_OK) return krc;
+    }
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tmp, G * SBV_GTAB_WINDOWS * (size_t)(SBV_GTAB_PER_WINDOW * 40) * sizeof(u32)));     // Ed25519: 128 x 40 raw limbs per (key, window)
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.acc, cap));
     b.ht_mask = (u32)(ht - 1);
@@ -278,27 +307,65 @@ int ensure_ed_group_buffers(Context& c, size_t n) {
     int rc = ensure_group_buffers(c, n);
     if (rc != SBV_OK) return rc;
     sbv::EdGroupBuffers& e = c.edgrp;
-    if (e.cap >= c.grp.cap && e.max_groups == c.grp.max_groups) return SBV_OK;
+    const size_t K = c.kc_caps[2];
+    if (e.cap >= c.grp.cap && e.max_groups == c.grp.max_groups && e.kc.ht && e.kc.cap == K) {
+        e.kc.enabled = c.kc_on[2] ? 1u : 0u;
+        return SBV_OK;
+    }
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
     if (e.ktab) (void)hipFree(e.ktab);
     if (e.okb) (void)hipFree(e.okb);
     if (e.kvalid) (void)hipFree(e.kvalid);
+    key_cache_free(e.kc);
     e = sbv::EdGroupBuffers();
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&e.ktab, (size_t)c.grp.max_groups * SBV_ED_KEYTAB_ENTRIES_PER_KEY * sizeof(sbv::aniels)));
+    // comb pool of this scheme: slots [0, K) = its persistent key-table cache, [K, K + max_groups) per batch
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&e.ktab, (K + c.grp.max_groups) * (size_t)SBV_ED_KEYTAB_ENTRIES_PER_KEY * sizeof(sbv::aniels)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&e.okb, c.grp.cap));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&e.kvalid, c.grp.max_groups));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&e.kvalid, K + c.grp.max_groups));
+    rc = key_cache_alloc(e.kc, K, c.kc_on[2]);
+    if (rc != SBV_OK) return rc;
     e.cap = c.grp.cap;
     e.max_groups = c.grp.max_groups;
     return SBV_OK;
 }
 
+// secp256k1: the grouping arrays of the P-256 step + this curve's own comb pool and key-table cache
+int ensure_k256_group_buffers(Context& c, size_t n) {
+    int rc = ensure_group_buffers(c, n);
+    if (rc != SBV_OK) return rc;
+    sbv::KeyPool& kp = c.k256pool;
+    const size_t K = c.kc_caps[1];
+    if (kp.ktab && kp.max_groups == c.grp.max_groups && kp.kc.cap == K) {
+        kp.kc.enabled = c.kc_on[1] ? 1u : 0u;
+        return SBV_OK;
+    }
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    if (kp.ktab) (void)hipFree(kp.ktab);
+    if (kp.kvalid) (void)hipFree(kp.kvalid);
+    key_cache_free(kp.kc);
+    kp = sbv::KeyPool();
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&kp.ktab, (K + c.grp.max_groups) * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&kp.kvalid, K + c.grp.max_groups));
+    rc = key_cache_alloc(kp.kc, K, c.kc_on[1]);
+    if (rc != SBV_OK) return rc;
+    kp.max_groups = c.grp.max_groups;
+    return SBV_OK;
+}
+
 // one chunk (n <= cap) of Ed25519 tuples on `stream`: grouped step or the one-lane kernel
 int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream, hipEvent_t* dom = nullptr, int* dom_pairs = nullptr) {
-    if (c.group_enabled && n >= c.group_min_batch_ed) {
+    // with the scheme's key-table cache on, nearly every batch takes the grouped step (as for P-256: cached keys are grouped whatever
+    // their count, and a cold batch leaves its combs behind); with it off the cold crossover applies
+    if (c.group_enabled && n >= (c.kc_on[2] ? c.group_min_batch : c.group_min_batch_ed)) {
         const int rc = ensure_ed_group_buffers(c, n);
         if (rc != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
-        HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify_grouped(d_tuples, n, c.grp, c.edgrp, c.d_qtab, c.d_btab, d_bitmap, stream, c.gsync, dom, dom_pairs));
+        const hipError_t ge = sbv::launch_ed25519_verify_grouped(d_tuples, n, c.grp, c.edgrp, c.d_qtab, c.d_btab, d_bitmap, stream, c.gsync, dom, dom_pairs);
+        if (ge != hipSuccess) {          // a slot is published before its tables are built (see enqueue()): forget the cache
+            (void)hipDeviceSynchronize();
+            (void)key_cache_forget(c.edgrp.kc);
+            return fail(SBV_EDEVICE, "launch_ed25519_verify_grouped", ge);
+        }
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, sbv::launch_ed25519_verify(d_tuples, n, c.d_qtab, c.d_btab, d_bitmap, stream));
@@ -311,7 +378,7 @@ int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bi
 int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream,
             hipEvent_t after_prep, hipEvent_t* dom = nullptr, int* dom_pairs = nullptr, bool* was_grouped = nullptr, size_t decide_n = 0) {
     const sbv::Scratch s = scratch_view(c);
-    const bool grouped = c.group_enabled && (decide_n ? decide_n : n) >= (c.kc_enabled ? c.group_min_batch : c.group_min_batch_cold);
+    const bool grouped = c.group_enabled && (decide_n ? decide_n : n) >= (c.kc_on[0] ? c.group_min_batch : c.group_min_batch_cold);
     if (was_grouped) *was_grouped = grouped;
     if (grouped) {
         const int rc = ensure_group_buffers(c, n);
@@ -341,10 +408,7 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
             // k_key_cache_insert publishes a slot before its tables are built: a step that failed half-way may leave slots
             // whose combs never were.  Forget the whole cache (best effort, after draining what did get enqueued).
             (void)hipDeviceSynchronize();
-            if (c.grp.kc.ht) {
-                (void)hipMemset(c.grp.kc.ht, 0, ((size_t)c.grp.kc.ht_mask + 1) * sizeof(u32));
-                (void)hipMemset(c.grp.kc.count, 0, 4 * sizeof(u32));
-            }
+            (void)key_cache_forget(c.grp.kc);
             return fail(SBV_EDEVICE, "launch_p256_verify_grouped", ge);
         }
         return SBV_OK;
@@ -485,7 +549,7 @@ int init_context(Context& c, int device) {
         c.group_enabled = g_settings.group_enabled; c.group_min_batch = g_settings.group_min_batch;
         c.group_min_batch_cold = g_settings.group_min_batch_cold; c.group_min_batch_ed = g_settings.group_min_batch_ed; c.group_min_batch_k256 = g_settings.group_min_batch_k256;
         c.group_min_count = g_settings.group_min_count; c.group_max = g_settings.group_max;
-        c.kc_enabled = g_settings.kc_enabled; c.kc_cap = g_settings.kc_cap;
+        for (int k = 0; k < 3; ++k) { c.kc_on[k] = g_settings.kc_on[k]; c.kc_caps[k] = g_settings.kc_caps[k]; }
         c.profiling = g_settings.profiling;
     }
     if (const char* e = getenv("SBV_SMALL")) c.small_enabled = e[0] != '0';
@@ -1121,15 +1185,21 @@ namespace {
 // one chunk (m <= cap) of secp256k1 tuples on `stream`: the grouped step (k256_group_kernels.hip) or the one-lane kernel
 int enqueue_k256(Context& c, const uint8_t* d_tuples, size_t m, uint8_t* d_bitmap, hipStream_t stream, hipEvent_t* dom = nullptr, int* dom_pairs = nullptr) {
     const sbv::Scratch s = scratch_view(c);
-    if (c.group_enabled && m >= c.group_min_batch_k256) {
-        int rc = ensure_group_buffers(c, m);
+    if (c.group_enabled && m >= (c.kc_on[1] ? c.group_min_batch : c.group_min_batch_k256)) {
+        int rc = ensure_k256_group_buffers(c, m);
         if (rc != SBV_OK) return rc;
+        if (m < ((size_t)1 << 18) && c.grp.min_count > 32) c.grp.min_count = 32;     // no stragglers on the one-lane path below 2^18 (enqueue() has the numbers)
         if ((rc = ensure_k256_gcomb(c)) != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
         sbv::GroupSync y = c.gsync;                 // second table stream: the context's own, when the caller's runs the step (enqueue() says why)
         if (y.tstreams > 1 && stream != c.stream) y.side_t = c.stream;
         else y.tstreams = 1;
-        HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify_grouped(d_tuples, s, m, c.grp, c.d_qtab, c.d_k256_gtab, c.d_k256_gcomb, c.k256_gbits, d_bitmap, stream, y, dom, dom_pairs));
+        const hipError_t ge = sbv::launch_k256_verify_grouped(d_tuples, s, m, c.grp, c.k256pool, c.d_qtab, c.d_k256_gtab, c.d_k256_gcomb, c.k256_gbits, d_bitmap, stream, y, dom, dom_pairs);
+        if (ge != hipSuccess) {
+            (void)hipDeviceSynchronize();
+            (void)key_cache_forget(c.k256pool.kc);
+            return fail(SBV_EDEVICE, "launch_k256_verify_grouped", ge);
+        }
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, sbv::launch_k256_verify(d_tuples, m, s, c.d_qtab, c.d_k256_gtab, d_bitmap, stream));
@@ -1413,50 +1483,59 @@ extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min
     return SBV_OK;
 }
 
-extern "C" int sbv_p256_key_cache(int enabled, uint32_t capacity) {
+namespace {
+sbv::KeyCache* scheme_cache(Context& c, int scheme) {
+    return scheme == SBV_SCHEME_P256 ? &c.grp.kc : scheme == SBV_SCHEME_SECP256K1 ? &c.k256pool.kc : &c.edgrp.kc;
+}
+}  // namespace
+
+extern "C" int sbv_key_cache(int scheme, int enabled, uint32_t capacity) {
+    if (scheme < 0 || scheme > 2) return SBV_EINVAL;
     Settings st;
     {
         std::lock_guard<std::mutex> lk(g_set_mu);
-        g_settings.kc_enabled = enabled != 0;
-        if (capacity) g_settings.kc_cap = capacity;
+        g_settings.kc_on[scheme] = enabled != 0;
+        if (capacity) g_settings.kc_caps[scheme] = capacity;
         st = g_settings;
     }
     int rc = SBV_OK;
     for (Context* cp : live_contexts()) {
         std::lock_guard<std::mutex> lk(cp->mu);
         Context& c = *cp;
-        c.kc_enabled = st.kc_enabled;
-        c.kc_cap = st.kc_cap;                       // a new capacity takes effect (and empties the cache) at the next grouped batch
-        if (c.ready && c.grp.kc.ht) {
+        c.kc_on[scheme] = st.kc_on[scheme];
+        c.kc_caps[scheme] = st.kc_caps[scheme];     // a new capacity takes effect (and empties the cache) at the next grouped batch
+        sbv::KeyCache& kc = *scheme_cache(c, scheme);
+        if (c.ready && kc.ht) {
             hipError_t e = hipSetDevice(c.device);
             if (e == hipSuccess) e = hipDeviceSynchronize();
-            c.grp.kc.enabled = c.kc_enabled ? 1u : 0u;
-            if (e == hipSuccess && !c.kc_enabled) {  // switching it off forgets everything: the next "on" starts cold
-                e = hipMemset(c.grp.kc.ht, 0, ((size_t)c.grp.kc.ht_mask + 1) * sizeof(u32));
-                if (e == hipSuccess) e = hipMemset(c.grp.kc.count, 0, 4 * sizeof(u32));
-            }
-            if (e != hipSuccess) rc = fail(SBV_EDEVICE, "sbv_p256_key_cache", e);
+            kc.enabled = c.kc_on[scheme] ? 1u : 0u;
+            if (e == hipSuccess && !c.kc_on[scheme]) e = key_cache_forget(kc);   // switching it off forgets everything: the next "on" starts cold
+            if (e != hipSuccess) rc = fail(SBV_EDEVICE, "sbv_key_cache", e);
         }
     }
     return rc;
 }
+extern "C" int sbv_p256_key_cache(int enabled, uint32_t capacity) { return sbv_key_cache(SBV_SCHEME_P256, enabled, capacity); }
 
-extern "C" int sbv_p256_key_cache_stats(uint32_t out[4]) {
+extern "C" int sbv_key_cache_stats(int scheme, uint32_t out[4]) {
+    if (scheme < 0 || scheme > 2) return SBV_EINVAL;
     SBV_ENTER(c);
     if (!c.ready) return SBV_ENOTINIT;
     if (!out) return SBV_EINVAL;
     out[0] = out[1] = out[2] = 0;
-    out[3] = c.kc_cap;
-    if (!c.grp.kc.count) return SBV_OK;
+    out[3] = c.kc_caps[scheme];
+    const sbv::KeyCache& kc = *scheme_cache(c, scheme);
+    if (!kc.count) return SBV_OK;
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
     uint32_t h[3];
-    HIP_TRY(SBV_EDEVICE, hipMemcpy(h, c.grp.kc.count, sizeof h, hipMemcpyDeviceToHost));
-    out[0] = h[0] < c.grp.kc.cap ? h[0] : c.grp.kc.cap;
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(h, kc.count, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = h[0] < kc.cap ? h[0] : kc.cap;
     out[1] = h[1];
     out[2] = h[2];
     return SBV_OK;
 }
+extern "C" int sbv_p256_key_cache_stats(uint32_t out[4]) { return sbv_key_cache_stats(SBV_SCHEME_P256, out); }
 
 extern "C" int sbv_profile_enable(int on) {
     const int level = on == 2 ? 2 : (on != 0 ? 1 : 0);
@@ -1764,7 +1843,7 @@ int verify_shard(Context& c, const uint8_t* h_tuples, size_t m, size_t group, u3
     if (!c.ready) { g_err = "device not initialised"; return SBV_ENOTINIT; }
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
     const size_t gran = shard_granule(group);
-    const size_t want_piece = c.kc_enabled && c.group_enabled ? g_shard_piece : kMaxChunk;
+    const size_t want_piece = c.kc_on[0] && c.group_enabled ? g_shard_piece : kMaxChunk;
     size_t chunk = (want_piece < kMaxChunk ? want_piece : kMaxChunk) / gran * gran;
     if (chunk == 0) chunk = kMaxChunk / gran * gran;
     if (chunk == 0) { g_err = "group too large"; return SBV_EINVAL; }

@@ -88,6 +88,18 @@ int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uin
  * batch that hit / missed, out[3] = capacity.  bench.py measures its headline with the cache OFF (every step cold). */
 int sbv_p256_key_cache(int enabled, uint32_t capacity);
 int sbv_p256_key_cache_stats(uint32_t out[4]);
+/* The same cache for every signature scheme of the library (round 4).  Consenter and client traffic on the secp256k1 and
+ * Ed25519 variants is the same handful of keys forever (internal/bft/view.go:631, 834), so their grouped steps keep their
+ * per-key combs too — each scheme in a pool of its OWN: a slot is found by the key bytes, and the same 64 bytes can be a
+ * point of both ECDSA curves (a shared table would let a crafted key be verified against the other curve's comb).
+ * scheme = SBV_SCHEME_*; defaults: on, 4096 (P-256) / 1024 (secp256k1: 270 KiB per key) / 1024 (Ed25519: 384 KiB per key)
+ * keys.  With a scheme's cache on, its batches take the grouped step from 64 tuples (sbv_p256_set_grouping's min_batch).
+ * sbv_p256_key_cache(e, c) == sbv_key_cache(SBV_SCHEME_P256, e, c). */
+#define SBV_SCHEME_P256 0
+#define SBV_SCHEME_SECP256K1 1
+#define SBV_SCHEME_ED25519 2
+int sbv_key_cache(int scheme, int enabled, uint32_t capacity);
+int sbv_key_cache_stats(int scheme, uint32_t out[4]);
 
 /* Same, on device-resident buffers, asynchronous on `hip_stream` (a hipStream_t; NULL = the
  * default stream).  d_tuples: n*160 bytes, 16-byte aligned.  d_bitmap: ceil(n/8) bytes.
