@@ -256,6 +256,26 @@ def leg_sharded(sbv, tuples, valid, n, steps):
             "last_call_us": {"h2d": info.h2d_us, "kernels": info.kernels_us, "gather": info.gather_us, "total": info.total_us}}
 
 
+def variant_warm_leg(sbv, torch, scheme, call, d_b, expect, n, steps):
+    """The same batch of a variant scheme with that scheme's persistent key-table cache ON (sbv_key_cache(scheme), the library's
+    default): the first call builds and keeps the 1024 keys' combs, the timed calls find them."""
+    sbv.key_cache(True, 0, scheme)
+    try:
+        call()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            call()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        entries, hits, misses, cap = sbv.key_cache_stats(scheme)
+        return {"value": n * steps / dt, "unit": "verifies/s", "ms_per_step": 1e3 * dt / steps,
+                "bitmap_correct": bool((d_b.cpu().numpy() == expect).all()),
+                "cache": {"keys_cached": entries, "groups_hit_last_step": hits, "groups_missed_last_step": misses, "capacity": cap}}
+    finally:
+        sbv.key_cache(False, 0, scheme)
+
+
 def leg_ed25519(sbv, torch, n, steps, stream, cpu=False):
     """BASELINE.json configs[4]: 2^20 Ed25519 signatures, 1024 keys, 7/8 valid, R|S|A|k tuples resident in HBM."""
     import numpy as np
@@ -276,6 +296,7 @@ def leg_ed25519(sbv, torch, n, steps, stream, cpu=False):
             pass
     d_t = torch.from_numpy(tuples).cuda()
     d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
+    sbv.key_cache(False, 0, sbv.SCHEME_ED25519)      # `value` of this leg is the cold number (every step builds every comb), as the headline's
     sbv.ed25519_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     sbv.profile_read_dominant(); sbv.profile_read()
@@ -302,14 +323,21 @@ def leg_ed25519(sbv, torch, n, steps, stream, cpu=False):
     out["roofline"] = variant_roofline("k_ed_qphase", 128.125, lanes, (32.0 / per_step) / 48.0, dom_us, dom_launches)
     if cpu:
         out["cpu_baseline"] = cpu_baseline_variant("ed25519", tuples, n, got)
+    try:
+        out["warm_key_cache"] = variant_warm_leg(sbv, torch, sbv.SCHEME_ED25519,
+                                                 lambda: sbv.ed25519_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream), d_b, expect, n, steps)
+    except Exception as e:      # noqa: BLE001
+        out["warm_key_cache"] = {"error": repr(e)}
+    finally:
+        sbv.key_cache(True, 0, sbv.SCHEME_ED25519)    # the library's default
     return out
 
 
 def leg_secp256k1(sbv, torch, n, steps, stream, cpu=False):
     """The "other curves" variant: n secp256k1 signatures, 1024 keys, 7/8 valid, 160-byte tuples resident in
-    HBM, through the grouped step of this curve (k256_group.h: per-batch key combs, every step cold — there is no key cache
-    for this curve); `one_lane` is the same batch with grouping off (256 doublings per signature).  Signatures come from the
-    host library's RFC 6979 signer."""
+    HBM, through the grouped step of this curve (k256_group.h: per-batch key combs; `value` with the curve's key-table cache OFF,
+    every step cold, `warm_key_cache` with it on); `one_lane` is the same batch with grouping off (256 doublings per signature).
+    Signatures come from the host library's RFC 6979 signer."""
     import numpy as np
     cache = f"/tmp/sbv_k256_batch_{n}.npz"
     if os.path.exists(cache):
@@ -328,6 +356,7 @@ def leg_secp256k1(sbv, torch, n, steps, stream, cpu=False):
             pass
     d_t = torch.from_numpy(tuples).cuda()
     d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
+    sbv.key_cache(False, 0, sbv.SCHEME_SECP256K1)
     sbv.secp256k1_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
     sbv.profile_read_dominant(); sbv.profile_read()
@@ -354,6 +383,13 @@ def leg_secp256k1(sbv, torch, n, steps, stream, cpu=False):
                                        dom_us, dom_launches)
     if cpu:
         out["cpu_baseline"] = cpu_baseline_variant("secp256k1", tuples, n, got)
+    try:
+        out["warm_key_cache"] = variant_warm_leg(sbv, torch, sbv.SCHEME_SECP256K1,
+                                                 lambda: sbv.secp256k1_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream), d_b, expect, n, steps)
+    except Exception as e:      # noqa: BLE001
+        out["warm_key_cache"] = {"error": repr(e)}
+    finally:
+        sbv.key_cache(True, 0, sbv.SCHEME_SECP256K1)
     sbv.set_grouping(False)
     try:
         sbv.secp256k1_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)

@@ -252,11 +252,15 @@ def set_grouping(enabled: bool, min_batch: int = 0, min_count: int = 0, max_grou
     _check(load().sbv_p256_set_grouping(1 if enabled else 0, min_batch, min_count, max_groups))
 
 
-def key_cache(enabled: bool, capacity: int = 0) -> None:
-    """sbv_p256_key_cache: the persistent key-table cache of the grouped step (off also empties it)."""
+SCHEME_P256, SCHEME_SECP256K1, SCHEME_ED25519 = 0, 1, 2
+
+
+def key_cache(enabled: bool, capacity: int = 0, scheme: int = SCHEME_P256) -> None:
+    """sbv_key_cache: the persistent key-table cache of a scheme's grouped step (off also empties it); the default is the
+    P-256 one (sbv_p256_key_cache)."""
     lib = load()
-    lib.sbv_p256_key_cache.argtypes = [ctypes.c_int, ctypes.c_uint32]
-    _check(lib.sbv_p256_key_cache(1 if enabled else 0, capacity))
+    lib.sbv_key_cache.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+    _check(lib.sbv_key_cache(scheme, 1 if enabled else 0, capacity))
 
 
 def sign_batch(keys: bytes, digests: bytes, key_index=None):
@@ -280,10 +284,12 @@ def sign_batch_dev(d_keys_ptr: int, n_keys: int, d_index_ptr: int, d_digests_ptr
     _check(lib.sbv_p256_sign_batch_dev(d_keys_ptr, n_keys, d_index_ptr or None, d_digests_ptr, n, d_sigs_ptr, d_ok_ptr, stream or None))
 
 
-def key_cache_stats():
+def key_cache_stats(scheme: int = SCHEME_P256):
     """(cached keys, groups of the last grouped batch that hit, that missed, capacity)"""
     out = (ctypes.c_uint32 * 4)()
-    _check(load().sbv_p256_key_cache_stats(out))
+    lib = load()
+    lib.sbv_key_cache_stats.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    _check(lib.sbv_key_cache_stats(scheme, out))
     return out[0], out[1], out[2], out[3]
 
 

@@ -151,6 +151,36 @@ void sbve_key_cache(int enabled, u32 cap) {
     g_kc.cap = cap; g_kc.enabled = enabled && cap ? 1u : 0u;
 }
 void sbve_key_cache_stats(u32 out[3]) { out[0] = g_kc.count ? g_kc_count[0] : 0; out[1] = g_kc.count ? g_kc_count[1] : 0; out[2] = g_kc.count ? g_kc_count[2] : 0; }
+// the other two schemes' caches (sbv_key_cache(SBV_SCHEME_SECP256K1 / SBV_SCHEME_ED25519)): scheme 1 = secp256k1, 2 = Ed25519
+struct EmulKeyCache {
+    KeyCache kc = {};
+    void* pool = nullptr;          // cap x per-key table bytes
+    size_t key_bytes = 0;
+    std::vector<uint8_t> valid;
+    std::vector<u32> ht, keys, count;
+    void reset(int enabled, u32 cap, size_t bytes_per_key) {
+        free(pool);
+        pool = nullptr;
+        key_bytes = bytes_per_key;
+        size_t h = 16;
+        while (h < 4 * (size_t)(cap ? cap : 1)) h *= 2;
+        ht.assign(h, 0); keys.assign((size_t)(cap ? cap : 1) * 16, 0); count.assign(4, 0); valid.assign(cap ? cap : 1, 0);
+        if (cap) { pool = aligned_alloc(64, (size_t)cap * bytes_per_key); memset(pool, 0xA5, (size_t)cap * bytes_per_key); }
+        kc.ht = ht.data(); kc.ht_mask = (u32)(h - 1); kc.keys = keys.data(); kc.count = count.data();
+        kc.cap = cap; kc.enabled = enabled && cap ? 1u : 0u;
+    }
+};
+static EmulKeyCache g_kc_k256, g_kc_ed;
+void sbve_scheme_key_cache(int scheme, int enabled, u32 cap) {
+    if (scheme == 1) g_kc_k256.reset(enabled, cap, (size_t)SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW * sizeof(kapt));
+    else if (scheme == 2) g_kc_ed.reset(enabled, cap, (size_t)SBV_ED_KEYTAB_ENTRIES * sizeof(aniels));
+    else sbve_key_cache(enabled, cap);
+}
+void sbve_scheme_key_cache_stats(int scheme, u32 out[3]) {
+    if (scheme == 0) { sbve_key_cache_stats(out); return; }
+    const EmulKeyCache& e = scheme == 1 ? g_kc_k256 : g_kc_ed;
+    for (int i = 0; i < 3; ++i) out[i] = e.count.size() ? e.count[i] : 0;
+}
 void sbve_set_group_chunks(int c) { g_group_chunks = c < 1 ? 1 : (c > 4 ? 4 : c); }
 static void emul_window_rows_fill(const u32* recs, bool top, u32* tmp, apt* row);
 void sbve_set_group_coop(int on) { g_group_coop = on != 0; }     // k_group_coop instead of the G phase + Q launches (key-sorted step only)
@@ -231,20 +261,8 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     std::vector<uint8_t> cold(ng1, 1);
     KeyCache kc = g_kc;
     if (kc.enabled) kc.count[1] = kc.count[2] = 0;
-    for (u32 k = 0; k < ngroups; ++k) {
-        u32 w[16];
-        key_cache_group_key(tuples, g, k, w);
-        tslot[k] = kc.enabled ? key_cache_lookup(kc, w) : SBV_GROUP_NONE;
-        cold[k] = tslot[k] == SBV_GROUP_NONE ? 1 : 0;
-        if (kc.enabled) kc.count[cold[k] ? 2 : 1]++;
-    }
-    for (u32 k = 0; k < ngroups; ++k) {
-        if (tslot[k] != SBV_GROUP_NONE) continue;
-        u32 w[16];
-        key_cache_group_key(tuples, g, k, w);
-        const u32 slot = kc.enabled ? key_cache_insert(kc, w) : SBV_GROUP_NONE;
-        tslot[k] = slot == SBV_GROUP_NONE ? kc.cap + k : slot;
-    }
+    for (u32 k = 0; k < ngroups; ++k) key_cache_phase_lookup<160, 96, 16>(tuples, g, kc, k, tslot.data(), cold.data());
+    for (u32 k = 0; k < ngroups; ++k) key_cache_phase_insert<160, 96, 16>(tuples, g, kc, k, tslot.data());
     auto table_of = [&](u32 k) -> apt* { return tslot[k] < kc.cap ? g_kc_ktab + (size_t)tslot[k] * per_key : ktab + (size_t)k * per_key; };
     auto valid_of = [&](u32 k) -> uint8_t* { return tslot[k] < kc.cap ? &g_kc_valid[tslot[k]] : &kvalid[k]; };
     memset(bitmap, 0, (n + 7) / 8);
@@ -525,8 +543,9 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     g.slots = slots.data(); g.max_groups = max_groups;
     group_set_threshold(g, min_count);
     std::vector<uint8_t> accb(cap, 0xEE), okb(cap, 0);
+    KeyCache kc = g_kc_ed.kc;            // this scheme's persistent key-table cache (off unless sbve_scheme_key_cache(2, ...) switched it on)
     for (size_t i = 0; i < n; ++i) ed_group_insert_lane(tuples, i, g);
-    for (size_t i = 0; i < n; ++i) group_assign_lane(i, g);
+    for (size_t i = 0; i < n; ++i) group_assign_lane_t<128, 64, 8>(tuples, i, g, kc);      // cached keys are grouped whatever their count
     const u32 ngroups = counters[0] < max_groups ? counters[0] : max_groups;
     if (g.sorted) {                      // key-sorted list: classify, then the counting sort of p256_group.h (scatter walked backwards)
         for (size_t i = 0; i < n; ++i) ed_group_classify_lane(i, g);
@@ -544,22 +563,34 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     const size_t ng1 = ngroups ? ngroups : 1;
     u32* jbases = (u32*)aligned_alloc(16, ng1 * SBV_ED_KEY_WINDOWS * SBV_ED_JBASE_DWORDS * 4);
     aniels* ktab = (aniels*)aligned_alloc(64, ng1 * SBV_ED_KEYTAB_ENTRIES * sizeof(aniels));
+    memset(ktab, 0xA5, ng1 * SBV_ED_KEYTAB_ENTRIES * sizeof(aniels));
     std::vector<uint8_t> kvalid(ng1, 0);
     u32* tmpa = (u32*)aligned_alloc(16, SBV_ED_KEY_PER_WINDOW * SBV_ED_WINDOW_TMP_WORDS * 4);
+    // the two phases of the key-table cache (k_key_cache_lookup_t / _insert_t), group by group
+    std::vector<u32> tslot(ng1, SBV_GROUP_NONE);
+    std::vector<uint8_t> cold(ng1, 1);
+    if (kc.enabled) kc.count[1] = kc.count[2] = 0;
+    for (u32 k = 0; k < ngroups; ++k) key_cache_phase_lookup<128, 64, 8>(tuples, g, kc, k, tslot.data(), cold.data());
+    for (u32 k = 0; k < ngroups; ++k) key_cache_phase_insert<128, 64, 8>(tuples, g, kc, k, tslot.data());
+    auto table_of = [&](u32 k) -> aniels* { return tslot[k] < kc.cap ? (aniels*)g_kc_ed.pool + (size_t)tslot[k] * SBV_ED_KEYTAB_ENTRIES : ktab + (size_t)k * SBV_ED_KEYTAB_ENTRIES; };
+    auto valid_of = [&](u32 k) -> uint8_t* { return tslot[k] < kc.cap ? &g_kc_ed.valid[tslot[k]] : &kvalid[k]; };
     memset(bitmap, 0, (n + 7) / 8);
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_ED_KEY_WINDOWS * c / chunks, j_end = SBV_ED_KEY_WINDOWS * (c + 1) / chunks;
-        for (u32 k = 0; k < ngroups; ++k) ed_keytab_bases_lane(tuples, k, g, jbases, kvalid.data(), j_first, j_end - 1);
         for (u32 k = 0; k < ngroups; ++k)
-            for (int j = j_first; j < j_end; ++j)
+            if (cold[k]) ed_keytab_bases_lane(tuples, k, g, jbases, valid_of(k), j_first, j_end - 1);
+        for (u32 k = 0; k < ngroups; ++k)
+            for (int j = j_first; j < j_end && cold[k]; ++j)
                 for (int part = 0; part < parts; ++part) {
                     const size_t w = (size_t)k * SBV_ED_KEY_WINDOWS + j;
-                    ed_keytab_window_lane(jbases + w * SBV_ED_JBASE_DWORDS, part, parts, tmpa, ktab + w * SBV_ED_KEY_PER_WINDOW);
+                    ed_keytab_window_lane(jbases + w * SBV_ED_JBASE_DWORDS, part, parts, tmpa, table_of(k) + (size_t)j * SBV_ED_KEY_PER_WINDOW);
                 }
         const bool last = c + 1 == chunks;
         for (u32 L = 0; L < counters[1]; ++L) {
             const u32 t = grp_idx[L];
-            const bool v = ed_qphase_lane(tuples, t, g.sorted ? grp_of[L] : slots[t], ngroups, ktab, kvalid.data(), gacc, cap, okb.data(), j_first, j_end, last, tm);
+            const u32 grp = g.sorted ? grp_of[L] : slots[t];
+            const bool v = grp < ngroups ? ed_qphase_lane(tuples, t, 0, 1, table_of(grp), valid_of(grp), gacc, cap, okb.data(), j_first, j_end, last, tm)
+                                         : ed_qphase_lane(tuples, t, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc, cap, okb.data(), j_first, j_end, last, tm);
             if (last && v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
         }
     }
@@ -756,8 +787,9 @@ void sbve_k256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     g.group_rep = group_rep.data(); g.counters = counters.data(); g.grp_idx = grp_idx.data(); g.ung_idx = ung_idx.data();
     g.slots = slots.data(); g.max_groups = max_groups;
     group_set_threshold(g, min_count);
+    KeyCache kc = g_kc_k256.kc;          // this curve's persistent key-table cache (off unless sbve_scheme_key_cache(1, ...) switched it on)
     for (size_t i = 0; i < n; ++i) group_insert_lane(tuples, i, g);
-    for (size_t i = 0; i < n; ++i) group_assign_lane(i, g);
+    for (size_t i = 0; i < n; ++i) group_assign_lane(tuples, i, g, kc);          // cached keys are grouped whatever their count
     std::vector<uint8_t> accb(cap, 0xEE);
     for (size_t i = 0; i < n; ++i) group_classify_lane(i, g);
     for (size_t L = counters[4]; L-- > 0;) k256_keycheck_lane(tuples, L, g, accb.data());
@@ -772,15 +804,24 @@ void sbve_k256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     kapt* ktab = (kapt*)aligned_alloc(64, ng1 * per_key * sizeof(kapt));
     memset(ktab, 0xA5, ng1 * per_key * sizeof(kapt));
     std::vector<uint8_t> kvalid(ng1, 0);
+    // the two phases of the key-table cache (k_key_cache_lookup_t / _insert_t), group by group
+    std::vector<u32> tslot(ng1, SBV_GROUP_NONE);
+    std::vector<uint8_t> cold(ng1, 1);
+    if (kc.enabled) kc.count[1] = kc.count[2] = 0;
+    for (u32 k = 0; k < ngroups; ++k) key_cache_phase_lookup<160, 96, 16>(tuples, g, kc, k, tslot.data(), cold.data());
+    for (u32 k = 0; k < ngroups; ++k) key_cache_phase_insert<160, 96, 16>(tuples, g, kc, k, tslot.data());
+    auto table_of = [&](u32 k) -> kapt* { return tslot[k] < kc.cap ? (kapt*)g_kc_k256.pool + (size_t)tslot[k] * per_key : ktab + (size_t)k * per_key; };
+    auto valid_of = [&](u32 k) -> uint8_t* { return tslot[k] < kc.cap ? &g_kc_k256.valid[tslot[k]] : &kvalid[k]; };
     memset(bitmap, 0, (n + 7) / 8);
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
         for (u32 k = 0; k < ngroups; ++k) {
+            if (!cold[k]) continue;              // a cached key: its comb is already in the pool
             k256_quad_host q;
-            k256_chain_run(q, tuples, k, g, jstate.data(), bases.data(), &kvalid[k], j_first, j_end - 1);
+            k256_chain_run(q, tuples, k, g, jstate.data(), bases.data(), valid_of(k), j_first, j_end - 1);
             for (int j = j_first; j < j_end; ++j) {
                 const size_t w = (size_t)k * SBV_GTAB_WINDOWS + j;
-                kapt* row = ktab + w * SBV_GTAB_PER_WINDOW;
+                kapt* row = table_of(k) + (size_t)j * SBV_GTAB_PER_WINDOW;
                 for (int which = 0; which < 2; ++which) {
                     if (which == 1 && j == SBV_GTAB_WINDOWS - 1) continue;
                     k256_rows_lane(bases.data() + w * SBV_K256_BASES_STRIDE, which, j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
@@ -792,7 +833,8 @@ void sbve_k256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
         const bool last = c + 1 == chunks;
         for (u32 L = 0; L < counters[1]; ++L) {
             const u32 t = grp_idx[L], grp = grp_of[L];
-            const bool v = k256_qphase_lane_sorted(s, t, L, grp < ngroups ? grp : SBV_GROUP_NONE, ngroups, ktab, kvalid.data(), gacc.data(), j_first, j_end, last);
+            const bool v = grp < ngroups ? k256_qphase_lane_sorted(s, t, L, 0, 1, table_of(grp), valid_of(grp), gacc.data(), j_first, j_end, last)
+                                         : k256_qphase_lane_sorted(s, t, L, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc.data(), j_first, j_end, last);
             if (last && v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
         }
     }

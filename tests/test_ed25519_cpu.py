@@ -186,6 +186,68 @@ def test_grouped_by_key_inside_the_batch_matches_plain_kernel(emul, oracle, ed_v
             assert stats[0] == 0 and stats[2] == total
 
 
+def test_persistent_key_table_cache_of_this_scheme_never_changes_verdicts(emul, oracle, ed_vectors):
+    """sbv_key_cache(SBV_SCHEME_ED25519): the combs of -A a grouped batch builds are kept in the scheme's own pool (slots found
+    by the 32 key bytes).  Cold batch, warm batch over the same keys (key-sorted and compaction order), overflow of a small
+    cache, an undecompressable key cached as invalid, a warm key grouped below the count threshold, the golden vectors' odd keys
+    (non-canonical, small order) through cached tables; verdicts always equal the one-lane kernel's and the generator's."""
+    emul.sbve_ed25519_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32,
+                                                       ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    emul.sbve_scheme_key_cache.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+    oracle.sbvo_ed25519_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int]
+    bad_key = next(y.to_bytes(32, "little") for y in range(2, 60) if ed.decompress(y.to_bytes(32, "little")) is None)
+    stats = (ctypes.c_uint32 * 4)()
+    cstats = (ctypes.c_uint32 * 3)()
+
+    def batch(seed, m, nkeys):
+        tup = ctypes.create_string_buffer(128 * m)
+        exp = ctypes.create_string_buffer((m + 7) // 8)
+        oracle.sbvo_ed25519_gen_batch(seed, m, nkeys, 5, tup, exp, 4)
+        return tup.raw, _bits(exp.raw, m)
+
+    def run(blob, want, chunks=2, sort=1):
+        total = len(blob) // 128
+        plain = ctypes.create_string_buffer((total + 7) // 8)
+        emul.sbve_ed25519_verify_batch(blob, ctypes.c_size_t(total), plain)
+        assert _bits(plain.raw, total) == want
+        emul.sbve_set_group_sort(sort)
+        bm = ctypes.create_string_buffer((total + 7) // 8)
+        emul.sbve_ed25519_verify_batch_grouped(blob, total, bm, 8, 64, 12, chunks, 4, stats)
+        emul.sbve_set_group_sort(1)
+        got = _bits(bm.raw, total)
+        assert got == want, [i for i in range(total) if got[i] != want[i]][:8]
+        emul.sbve_scheme_key_cache_stats(2, cstats)
+        return cstats[0], cstats[1], cstats[2]
+
+    try:
+        emul.sbve_scheme_key_cache(2, 1, 16)
+        a, wa = batch(0xE1, 300, 6)
+        t0 = bytearray(a[:128])
+        t0[64:96] = bad_key
+        junk = bytes(t0) * 20
+        assert run(a + junk, wa + [False] * 20) == (7, 0, 7)
+        b, wb = batch(0xE1, 350, 6)
+        assert run(b + junk, wb + [False] * 20, chunks=4) == (7, 7, 0)
+        assert run(b + junk, wb + [False] * 20, chunks=1, sort=0) == (7, 7, 0)
+        c, wc = batch(0xE2, 500, 12)
+        assert run(c + a, wc + wa) == (16, 6, 12)
+        assert run(c + a, wc + wa) == (16, 15, 3)
+        d, wd = batch(0xE1, 30, 6)
+        entries, hits, misses = run(d, wd)
+        assert hits >= 4 and misses == 0 and stats[1] >= 20, (hits, misses, list(stats))
+        emul.sbve_scheme_key_cache(2, 1, 64)                  # a fresh cache: the golden vectors' keys, each 9 times, twice
+        blob = _tuples(ed_vectors) * 9
+        want = [v["accept"] for v in ed_vectors] * 9
+        e1 = run(blob, want)
+        e2 = run(blob, want)
+        assert e1[1] == 0 and e1[2] > 5 and e2[2] == 0 and e2[1] == e1[2], (e1, e2)
+        emul.sbve_scheme_key_cache(2, 0, 64)
+        assert run(blob, want)[1:] == (0, 0)
+    finally:
+        emul.sbve_scheme_key_cache(2, 0, 0)
+
+
 def test_device_message_front_end_sha512_and_mod_l(emul):
     """sha512_dev.h: the 512-bit reduction mod L against big ints (edge values: 0, L-1, L, 2L, 2^252 multiples, 2^512-1)
     and the whole lane — SHA-512(R|A|M) mod L — against hashlib for message lengths around the block boundaries."""

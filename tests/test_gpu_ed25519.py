@@ -172,3 +172,59 @@ def test_device_message_front_end_equals_host_tuple_builder(gpu, oracle):
     got = sbv.bitmap_to_list(gpu.ed25519_verify_msgs(sigs, pks, msgs), n)
     via_tuples = sbv.bitmap_to_list(gpu.ed25519_verify_batch(gpu.ed25519_make_tuples(sigs, pks, msgs), n), n)
     assert got == via_tuples == want
+
+
+def test_key_table_cache_of_this_scheme_on_gpu(gpu, oracle, openssl_check):
+    """sbv_key_cache(SBV_SCHEME_ED25519) (round 4): the combs of -A a grouped batch builds stay in the scheme's own pool.  Cold,
+    warm (same 300 keys, other signatures: every group hits), a warm batch of 4096 tuples (grouped by the cache alone), a
+    capacity below the key set, the golden vectors' odd keys (non-canonical, small order, undecompressable) cached and reused,
+    cache off.  Every bitmap equals the oracle's verifier and OpenSSL."""
+    E = sbv.SCHEME_ED25519
+    n = 1 << 17
+
+    def run(seed, tup, exp, m):
+        want = exp.raw[:(m + 7) // 8]
+        assert _oracle_verdicts(oracle, tup.raw, m) == want
+        assert _openssl_verdicts(openssl_check, seed, tup.raw, m) == want
+        got = gpu.ed25519_verify_batch(tup.raw[:128 * m], m)
+        assert got == want, [i for i in range(len(want)) if got[i] != want[i]][:8]
+        return gpu.key_cache_stats(E)
+
+    a, ea = _gen(oracle, 0xEDC1, n, 300, 7)
+    b, eb = _gen(oracle, 0xEDC1, n + 384, 300, 5)
+    small, es = _gen(oracle, 0xEDC1, 4096, 300, 7)
+    try:
+        gpu.set_grouping(True, 64, 64, 2048)
+        gpu.key_cache(False, 0, E)
+        gpu.key_cache(True, 1024, E)
+        entries, hits, misses, cap = run(0xEDC1, a, ea, n)
+        assert hits == 0 and misses >= 300 and entries == misses and cap == 1024, (entries, hits, misses, cap)
+        first = entries
+        entries, hits, misses, cap = run(0xEDC1, b, eb, n + 384)
+        assert misses == 0 and hits == first and entries == first, (entries, hits, misses)
+        entries, hits, misses, cap = run(0xEDC1, small, es, 4096)
+        groups, grouped, generic, rejected = gpu.last_group_stats()
+        assert misses == 0 and hits >= 290 and grouped > 3500, (hits, misses, groups, grouped, generic, rejected)
+        gpu.key_cache(False, 0, E)
+        gpu.key_cache(True, 256, E)
+        entries, hits, misses, cap = run(0xEDC1, a, ea, n)
+        assert entries == 256 and cap == 256
+        entries, hits, misses, cap = run(0xEDC1, a, ea, n)
+        assert hits == 256 and misses == first - 256
+        # golden vectors x 80 (every key of theirs passes the count threshold): cold, then warm
+        gpu.key_cache(False, 0, E)
+        gpu.key_cache(True, 1024, E)
+        vs = json.load(open(os.path.join(GOLDEN, "ed25519_vectors.json")))["vectors"]
+        blob = b"".join(ed.pack_tuple(bytes.fromhex(v["pk"]), bytes.fromhex(v["msg"]), bytes.fromhex(v["sig"])) for v in vs) * 80
+        want = [v["accept"] for v in vs] * 80
+        for rep in range(2):
+            got = sbv.bitmap_to_list(gpu.ed25519_verify_batch(blob, len(want)), len(want))
+            assert got == want, (rep, [i for i in range(len(want)) if got[i] != want[i]][:8])
+            entries, hits, misses, cap = gpu.key_cache_stats(E)
+            assert (hits == 0 and misses > 5) if rep == 0 else (misses == 0 and hits > 5), (rep, entries, hits, misses)
+        gpu.key_cache(False, 0, E)
+        assert run(0xEDC1, a, ea, n)[:3] == (0, 0, 0)
+    finally:
+        gpu.key_cache(False, 0, E)
+        gpu.key_cache(True, 1024, E)
+        gpu.set_grouping(True, 131072, 64, 2048)

@@ -144,3 +144,74 @@ def test_grouped_step_equals_the_one_lane_kernel_and_openssl(gpu, koracle, opens
             assert gpu.secp256k1_verify_batch(tup.raw, n) == want
         finally:
             gpu.set_grouping(True)
+
+
+def test_key_table_cache_of_this_curve_on_gpu(gpu, oracle, koracle, openssl_check):
+    """sbv_key_cache(SBV_SCHEME_SECP256K1) (round 4): the curve's own comb pool keeps the tables a grouped batch built.  Cold batch,
+    warm batch (other signatures of the same 300 keys: all hits, no table kernel has work), a capacity below the key set
+    (overflow rebuilt per batch), a warm batch of 4096 tuples (grouped although every key is far below the count threshold),
+    cache off; and the two ECDSA curves cannot meet in a table: a P-256 batch verified on P-256 leaves this cache empty, the
+    same bytes offered to THIS curve are all rejected (their keys are no points here) and are cached as invalid, after which
+    both curves still give their own verdicts.  Every bitmap equals the oracle's and OpenSSL's."""
+    openssl_check.sbvssl_k256_verify_batch.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+    K = sbv.SCHEME_SECP256K1
+    n = 1 << 17
+
+    def run(tup, exp, m=n):
+        ssl = ctypes.create_string_buffer((m + 7) // 8)
+        openssl_check.sbvssl_k256_verify_batch(tup, m, ssl, THREADS)
+        want = exp.raw[:(m + 7) // 8]
+        assert ssl.raw == want
+        got = gpu.secp256k1_verify_batch(tup.raw[:160 * m], m)
+        assert got == want, [i for i in range(len(want)) if got[i] != want[i]][:8]
+        return gpu.key_cache_stats(K)
+
+    a, ea = _gen(koracle, 0x4B01, n, 300, 7)
+    b, eb = _gen(koracle, 0x4B01, n + 512, 300, 5)        # same seed: the same 300 keys, other signatures and corruptions
+    c, ec = _gen(koracle, 0x4B02, n, 300, 7)
+    try:
+        gpu.key_cache(False, 0, K)
+        gpu.key_cache(True, 1024, K)
+        entries, hits, misses, cap = run(a, ea)
+        assert hits == 0 and misses >= 300 and entries == misses and cap == 1024, (entries, hits, misses, cap)
+        first = entries
+        entries, hits, misses, cap = run(b, eb, n + 512)
+        assert misses == 0 and hits == first and entries == first, (entries, hits, misses)
+        small, es = _gen(koracle, 0x4B01, 4096, 300, 7)     # ~13 signatures per key: only the cache makes them groups
+        entries, hits, misses, cap = run(small, es, 4096)
+        groups, grouped, generic, rejected = gpu.last_group_stats()
+        assert misses == 0 and hits >= 290 and grouped > 3500 and generic == 0, (hits, misses, groups, grouped, generic, rejected)
+        entries, hits, misses, cap = run(c, ec)
+        assert hits == 0 and misses >= 300 and entries == first + misses
+        gpu.key_cache(False, 0, K)
+        gpu.key_cache(True, 256, K)                         # smaller than one batch's key set
+        entries, hits, misses, cap = run(a, ea)
+        assert entries == 256 and cap == 256
+        entries, hits, misses, cap = run(a, ea)
+        assert hits == 256 and misses == first - 256
+        # the two curves: P-256 tuples (valid there) through both entries
+        gpu.key_cache(False, 0, K)
+        gpu.key_cache(True, 1024, K)
+        gpu.key_cache(False)
+        gpu.key_cache(True, 4096)
+        oracle.sbvo_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        p, ep = ctypes.create_string_buffer(160 * n), ctypes.create_string_buffer(n // 8)
+        oracle.sbvo_gen_batch(0x4B03, n, 200, 7, p, ep, THREADS)
+        for _ in range(2):
+            assert gpu.verify_batch(p.raw, n) == ep.raw
+            assert gpu.key_cache_stats(K)[0] == 0
+            pe = gpu.key_cache_stats()[0]
+            assert pe >= 200
+            got = gpu.secp256k1_verify_batch(p.raw, n)
+            assert got == bytes(n // 8)                      # not one key of that batch is a point of this curve
+            assert gpu.key_cache_stats()[0] == pe
+        assert gpu.key_cache_stats(K)[0] >= 200              # cached here as invalid keys
+        entries, hits, misses, cap = run(a, ea)               # and this curve's honest batch is untouched by them
+        gpu.key_cache(False, 0, K)
+        entries, hits, misses, cap = run(a, ea)
+        assert (entries, hits, misses) == (0, 0, 0)
+    finally:
+        gpu.key_cache(False, 0, K)
+        gpu.key_cache(True, 1024, K)
+        gpu.key_cache(False)
+        gpu.key_cache(True, 4096)

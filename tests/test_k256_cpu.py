@@ -278,6 +278,60 @@ def test_emulated_grouped_step_equals_the_oracle_and_the_one_lane_path(emul, kor
         emul.sbve_set_k256_prep_t(1)
 
 
+def test_persistent_key_table_cache_of_this_curve_never_changes_verdicts(emul, koracle, k256_vectors):
+    """sbv_key_cache(SBV_SCHEME_SECP256K1): the curve's own comb pool keeps the tables a grouped batch built.  Batch 1 is cold
+    (every group misses, builds and stays), batch 2 over the same keys is warm (no chain / rows / fill lane runs for a hit), a
+    cache too small for all keys overflows into the per-batch area, a key cached as INVALID (off the curve) stays rejected, a
+    cached key is grouped however few of its signatures a batch carries, and switching the cache off forgets everything.
+    Verdicts always equal the oracle's.  The P-256 cache is a different object: filling this one leaves that one empty."""
+    emul.sbve_k256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    emul.sbve_scheme_key_cache.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+    off = next(bytes.fromhex(v["tuple"]) for v in k256_vectors if not v["accept"] and "off" in v["name"] and "curve" in v["name"])
+    stats = (ctypes.c_uint32 * 4)()
+    cstats = (ctypes.c_uint32 * 3)()
+
+    def batch(seed, n, nkeys):
+        tup = ctypes.create_string_buffer(160 * n)
+        exp = ctypes.create_string_buffer((n + 7) // 8)
+        koracle.sbvo_k256_gen_batch(seed, n, nkeys, 5, tup, exp, 4)
+        return tup.raw, bits(exp.raw, n)
+
+    def run(blob, want, chunks=2):
+        total = len(blob) // 160
+        ob = ctypes.create_string_buffer((total + 7) // 8)
+        koracle.sbvo_k256_verify_batch(blob, total, ob, 4)
+        assert bits(ob.raw, total) == want
+        bm = ctypes.create_string_buffer((total + 7) // 8)
+        emul.sbve_k256_verify_batch_grouped(blob, total, bm, 8, 64, 12, chunks, stats)
+        got = bits(bm.raw, total)
+        assert got == want, [i for i in range(total) if got[i] != want[i]][:8]
+        emul.sbve_scheme_key_cache_stats(1, cstats)
+        return cstats[0], cstats[1], cstats[2]
+
+    try:
+        emul.sbve_scheme_key_cache(1, 1, 16)
+        a, wa = batch(0x71, 400, 6)
+        assert run(a + off * 20, wa + [False] * 20) == (7, 0, 7)          # 6 signer keys + the repeated off-curve key, all cold
+        b, wb = batch(0x71, 500, 6)                                       # same seed -> same keys, other signatures
+        assert run(b + off * 20, wb + [False] * 20, chunks=3) == (7, 7, 0)      # everything warm; the invalid key still rejected
+        c, wc = batch(0x72, 600, 12)                                      # 12 new keys: 7 + 12 > 16 -> three overflow per batch
+        assert run(c + a, wc + wa) == (16, 6, 12)
+        assert run(c + a, wc + wa, chunks=1) == (16, 15, 3)               # the 9 that fitted are warm now, 3 stay cold every time
+        d, wd = batch(0x71, 30, 6)                                        # 5 signatures per key: far below the threshold of 8
+        entries, hits, misses = run(d, wd)
+        assert hits >= 4 and misses == 0, (hits, misses)
+        assert stats[1] >= 20 and stats[2] == 0 and stats[1] + stats[3] == 30, list(stats)
+        emul.sbve_key_cache_stats(cstats)
+        assert cstats[0] == 0                                             # the P-256 cache saw none of it
+        emul.sbve_scheme_key_cache(1, 0, 16)                              # off: same verdicts, nothing cached, the small batch is generic again
+        assert run(c + a, wc + wa)[1:] == (0, 0)
+        run(d, wd)
+        assert stats[1] == 0 and stats[2] >= 20
+    finally:
+        emul.sbve_scheme_key_cache(1, 0, 0)
+
+
 def test_wide_comb_of_G_walk_matches_the_python_twin(emul):
     """The grouped step's G phase walks a `bits`-wide signed comb (20 bits on the device: 13 additions from 436 MB); the same
     recoding and table builder with 10-, 13- and 16-bit windows against u1 * G from big integers, edge scalars included."""
