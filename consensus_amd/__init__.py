@@ -248,11 +248,14 @@ def verify_msgs_keyed(msgs, sigs_der, slots) -> bytes:
 
 
 def set_grouping(enabled: bool, min_batch: int = 0, min_count: int = 0, max_groups: int = 0) -> None:
-    """In-step grouping of generic batches by public key (0 keeps a value); see include/sbv.h."""
-    _check(load().sbv_p256_set_grouping(1 if enabled else 0, min_batch, min_count, max_groups))
+    """In-step grouping of generic batches by public key (0 keeps a value; min_batch = GROUP_MIN_BATCH_DEFAULT restores the
+    built-in thresholds); see include/sbv.h."""
+    lib = load()
+    _check(lib.sbv_p256_set_grouping(1 if enabled else 0, min_batch, min_count, max_groups))
 
 
 SCHEME_P256, SCHEME_SECP256K1, SCHEME_ED25519 = 0, 1, 2
+GROUP_MIN_BATCH_DEFAULT = (1 << 64) - 1     # (size_t)-1
 
 
 def key_cache(enabled: bool, capacity: int = 0, scheme: int = SCHEME_P256) -> None:

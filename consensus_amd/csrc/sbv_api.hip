@@ -236,12 +236,23 @@ hipError_t key_cache_forget(sbv::KeyCache& kc) {
     return e;
 }
 
-void free_group_buffers(Context& c) {
+// keep_pools: the comb pools and key-table caches of the three schemes depend on (cache capacity, max_groups) only — a batch larger
+// than any before regrows the per-tuple arrays and must leave every cached comb where it is
+void free_group_buffers(Context& c, bool keep_pools = false) {
     sbv::GroupBuffers& b = c.grp;
-    void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.jbases, b.bases, b.jstate, b.ktab, b.kvalid, b.tmp, b.acc, b.gacc,
-                    b.gcount, b.grp_of, b.ung_cand, b.rec, b.tslot, b.cold, b.kc.ht, b.kc.keys, b.kc.count};
+    void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.jbases, b.bases, b.jstate, b.tmp, b.acc, b.gacc,
+                    b.gcount, b.grp_of, b.ung_cand, b.rec, b.tslot, b.cold};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    sbv::apt* const ktab = b.ktab;
+    uint8_t* const kvalid = b.kvalid;
+    const sbv::KeyCache kc = b.kc;
     b = sbv::GroupBuffers();
+    if (keep_pools) {
+        b.ktab = ktab; b.kvalid = kvalid; b.kc = kc;
+        return;
+    }
+    void* pool[] = {ktab, kvalid, kc.ht, kc.keys, kc.count};
+    for (void* p : pool) if (p) (void)hipFree(p);
     if (c.edgrp.ktab) (void)hipFree(c.edgrp.ktab);
     if (c.edgrp.okb) (void)hipFree(c.edgrp.okb);
     if (c.edgrp.kvalid) (void)hipFree(c.edgrp.kvalid);
@@ -261,7 +272,8 @@ int ensure_group_buffers(Context& c, size_t n) {
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
-    free_group_buffers(c);
+    const bool keep_pools = b.ktab && b.kvalid && b.kc.ht && b.max_groups == c.group_max && b.kc.cap == c.kc_caps[0];
+    free_group_buffers(c, keep_pools);
     const size_t cap = (n + 1023) & ~(size_t)1023;
     size_t ht = 1024;
     while (ht < 2 * cap) ht *= 2;
@@ -285,14 +297,15 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 40 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride; 36 words (P-256: XYZZ, 9-limb coordinates) or 40 (Ed25519: extended, 10-limb coordinates) per tuple
     // comb pool: slots [0, kc_cap) belong to the persistent key-table cache, [kc_cap, kc_cap + G) are rebuilt per batch
     const size_t K = c.kc_caps[0];
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ktab, (K + G) * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, K + G));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tslot, G * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.cold, G));
-    {
+    if (!keep_pools) {
+        HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ktab, (K + G) * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
+        HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, K + G));
         const int krc = key_cache_alloc(b.kc, K, c.kc_on[0]);
         if (krc != SBV_OK) return krc;
     }
+    b.kc.enabled = c.kc_on[0] ? 1u : 0u;
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tmp, G * SBV_GTAB_WINDOWS * (size_t)(SBV_GTAB_PER_WINDOW * 40) * sizeof(u32)));     // Ed25519: 128 x 40 raw limbs per (key, window)
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.acc, cap));
     b.ht_mask = (u32)(ht - 1);
@@ -308,24 +321,31 @@ int ensure_ed_group_buffers(Context& c, size_t n) {
     if (rc != SBV_OK) return rc;
     sbv::EdGroupBuffers& e = c.edgrp;
     const size_t K = c.kc_caps[2];
-    if (e.cap >= c.grp.cap && e.max_groups == c.grp.max_groups && e.kc.ht && e.kc.cap == K) {
+    // The comb pool and its cache depend on (K, max_groups) only: a batch larger than any before must not empty the cache
+    // (found on the GPU in round 4: the warm batch of the cache test was 384 tuples longer than the cold one and missed every key).
+    const bool pool_ok = e.ktab && e.max_groups == c.grp.max_groups && e.kc.ht && e.kc.cap == K;
+    if (pool_ok && e.okb && e.cap >= c.grp.cap) {
         e.kc.enabled = c.kc_on[2] ? 1u : 0u;
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
-    if (e.ktab) (void)hipFree(e.ktab);
     if (e.okb) (void)hipFree(e.okb);
-    if (e.kvalid) (void)hipFree(e.kvalid);
-    key_cache_free(e.kc);
-    e = sbv::EdGroupBuffers();
-    // comb pool of this scheme: slots [0, K) = its persistent key-table cache, [K, K + max_groups) per batch
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&e.ktab, (K + c.grp.max_groups) * (size_t)SBV_ED_KEYTAB_ENTRIES_PER_KEY * sizeof(sbv::aniels)));
+    e.okb = nullptr; e.cap = 0;
+    if (!pool_ok) {
+        if (e.ktab) (void)hipFree(e.ktab);
+        if (e.kvalid) (void)hipFree(e.kvalid);
+        key_cache_free(e.kc);
+        e = sbv::EdGroupBuffers();
+        // comb pool of this scheme: slots [0, K) = its persistent key-table cache, [K, K + max_groups) per batch
+        HIP_TRY(SBV_ENOMEM, hipMalloc(&e.ktab, (K + c.grp.max_groups) * (size_t)SBV_ED_KEYTAB_ENTRIES_PER_KEY * sizeof(sbv::aniels)));
+        HIP_TRY(SBV_ENOMEM, hipMalloc(&e.kvalid, K + c.grp.max_groups));
+        rc = key_cache_alloc(e.kc, K, c.kc_on[2]);
+        if (rc != SBV_OK) return rc;
+        e.max_groups = c.grp.max_groups;
+    }
     HIP_TRY(SBV_ENOMEM, hipMalloc(&e.okb, c.grp.cap));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&e.kvalid, K + c.grp.max_groups));
-    rc = key_cache_alloc(e.kc, K, c.kc_on[2]);
-    if (rc != SBV_OK) return rc;
     e.cap = c.grp.cap;
-    e.max_groups = c.grp.max_groups;
+    e.kc.enabled = c.kc_on[2] ? 1u : 0u;
     return SBV_OK;
 }
 
@@ -1470,7 +1490,11 @@ extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min
     {
         std::lock_guard<std::mutex> lk(g_set_mu);
         g_settings.group_enabled = enabled != 0;
-        if (min_batch) g_settings.group_min_batch = g_settings.group_min_batch_cold = g_settings.group_min_batch_ed = g_settings.group_min_batch_k256 = min_batch;
+        if (min_batch == SBV_GROUP_MIN_BATCH_DEFAULT) {          // back to the built-in thresholds (one per scheme and cache state)
+            const Settings d;
+            g_settings.group_min_batch = d.group_min_batch; g_settings.group_min_batch_cold = d.group_min_batch_cold;
+            g_settings.group_min_batch_ed = d.group_min_batch_ed; g_settings.group_min_batch_k256 = d.group_min_batch_k256;
+        } else if (min_batch) g_settings.group_min_batch = g_settings.group_min_batch_cold = g_settings.group_min_batch_ed = g_settings.group_min_batch_k256 = min_batch;
         if (min_count) g_settings.group_min_count = min_count;
         if (max_groups) g_settings.group_max = max_groups;
         st = g_settings;

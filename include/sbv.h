@@ -74,8 +74,10 @@ int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitma
  * `min_batch` = batches from this size on take the grouped step.  Defaults: enabled; min_batch 64 while the key-table cache is
  * on (a warm batch of a few thousand tuples skips the 256 doublings per signature), 2^17 while it is off (nothing outlives the
  * call then, and below ~2^17 building tables costs more latency than the doubling kernel takes); min_count 64; max_groups 2048.
- * Passing a non-zero min_batch sets both thresholds; 0 for a numeric argument keeps its current value.  Env: SBV_GROUP=0
+ * Passing a non-zero min_batch sets both thresholds (and the variant schemes'); SBV_GROUP_MIN_BATCH_DEFAULT restores the built-in
+ * ones; 0 for a numeric argument keeps its current value.  Env: SBV_GROUP=0
  * disables, SBV_GROUP_MIN_BATCH=<n>.  What IS remembered between calls is the key-table cache. */
+#define SBV_GROUP_MIN_BATCH_DEFAULT ((size_t)-1)
 int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uint32_t max_groups);
 
 /* Persistent key-table cache.  The comb a grouped batch builds for a key is a pure function of the key's 64 bytes, and

@@ -197,9 +197,10 @@ def test_key_table_cache_of_this_curve_on_gpu(gpu, oracle, koracle, openssl_chec
         oracle.sbvo_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         p, ep = ctypes.create_string_buffer(160 * n), ctypes.create_string_buffer(n // 8)
         oracle.sbvo_gen_batch(0x4B03, n, 200, 7, p, ep, THREADS)
-        for _ in range(2):
+        for rep in range(2):
             assert gpu.verify_batch(p.raw, n) == ep.raw
-            assert gpu.key_cache_stats(K)[0] == 0
+            ke = gpu.key_cache_stats(K)[0]                   # the P-256 entry never touches this curve's cache: empty before this
+            assert ke == 0 if rep == 0 else ke >= 200        # curve has seen those bytes, their keys cached as invalid afterwards
             pe = gpu.key_cache_stats()[0]
             assert pe >= 200
             got = gpu.secp256k1_verify_batch(p.raw, n)

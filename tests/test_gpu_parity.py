@@ -344,7 +344,7 @@ def test_in_step_key_grouping_equals_generic(gpu, oracle, golden_vectors):
             bad = [i for i in range(total) if got[i] != want[i]]
             assert not bad, (min_count, max_groups, bad[:8])
     finally:
-        gpu.set_grouping(True, 131072, 64, 2048)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 64, 2048)
 
 
 def test_coop_form_of_the_grouped_step_on_the_gpu(oracle, golden_vectors):
@@ -405,7 +405,7 @@ def test_grouped_vs_ungrouped_full_batch(gpu):
             tm = gpu.last_timing()
             times[mode] = (tm.prep_us, tm.verify_us)
     finally:
-        gpu.set_grouping(True, 131072, 64, 2048)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 64, 2048)
     print(f"\n[2^20] grouped: prep {times[True][0]:.0f} us stageB {times[True][1]:.0f} us | ungrouped: prep {times[False][0]:.0f} us "
           f"stageB {times[False][1]:.0f} us")
 
@@ -481,6 +481,46 @@ def test_persistent_key_table_cache_on_gpu(gpu, oracle):
     finally:
         gpu.key_cache(False)
         gpu.key_cache(True, 4096)
+
+
+def test_key_table_caches_survive_buffer_growth(gpu, oracle):
+    """A batch larger than any before regrows the per-tuple arrays of the grouped step; the comb pools and key-table caches of the
+    three schemes depend on (capacity, max_groups) only and must stay (round 4: the first GPU run of the Ed25519 cache test missed
+    every key on its warm batch because that batch was 384 tuples longer than the cold one).  Another max_groups first: every
+    buffer of the grouped step is then allocated afresh, sized for the small batch that follows."""
+    oracle.sbvo_ed25519_gen_batch.argtypes = oracle.sbvo_k256_gen_batch.argtypes = oracle.sbvo_gen_batch.argtypes
+    threads = os.cpu_count() or 1
+    legs = [(sbv.SCHEME_P256, oracle.sbvo_gen_batch, 160, gpu.verify_batch),
+            (sbv.SCHEME_SECP256K1, oracle.sbvo_k256_gen_batch, 160, gpu.secp256k1_verify_batch),
+            (sbv.SCHEME_ED25519, oracle.sbvo_ed25519_gen_batch, 128, gpu.ed25519_verify_batch)]
+
+    def batch(gen, width, n):
+        tup, exp = ctypes.create_string_buffer(width * n), ctypes.create_string_buffer(n // 8)
+        gen(0x6A0, n, 40, 7, tup, exp, threads)          # the same seed: the same 40 keys at every size
+        return tup.raw, exp.raw
+
+    try:
+        gpu.set_grouping(True, 64, 64, 1024)
+        for scheme, gen, width, verify in legs:
+            gpu.key_cache(False, 0, scheme)
+            gpu.key_cache(True, 512, scheme)
+        small = {s: batch(g, w, 1 << 13) for s, g, w, _ in legs}
+        big = {s: batch(g, w, 1 << 15) for s, g, w, _ in legs}
+        first = {}
+        for scheme, gen, width, verify in legs:             # cold, every scheme at 2^13: the buffers are sized for 8192 tuples
+            assert verify(small[scheme][0], 1 << 13) == small[scheme][1]
+            entries, hits, misses, cap = gpu.key_cache_stats(scheme)
+            assert hits == 0 and misses >= 40 and entries == misses and cap == 512, (scheme, entries, hits, misses, cap)
+            first[scheme] = entries
+        for scheme, gen, width, verify in legs:             # four times the tuples: growth; every key must still be found
+            assert verify(big[scheme][0], 1 << 15) == big[scheme][1]
+            entries, hits, misses, cap = gpu.key_cache_stats(scheme)
+            assert misses == 0 and hits == first[scheme] and entries == first[scheme], (scheme, entries, hits, misses)
+    finally:
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 64, 2048)
+        gpu.key_cache(False); gpu.key_cache(True, 4096)
+        for scheme in (sbv.SCHEME_SECP256K1, sbv.SCHEME_ED25519):
+            gpu.key_cache(False, 0, scheme); gpu.key_cache(True, 1024, scheme)
 
 
 def test_key_sorted_list_and_compaction_order_give_the_same_bitmap():
