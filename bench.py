@@ -477,6 +477,59 @@ def leg_replay_550k(sbv, synth):
             "note": "PCIe-inclusive (88 MB of tuples from host memory per call); key-table cache warm as for a replaying replica"}
 
 
+def leg_consenter_keys(sbv, synth, torch, stream, steps):
+    """configs[3]'s signatures as a replica that has REGISTERED its consenters verifies them (VerifyConsenterSig /
+    VerifyConsenterSigBatch: internal/bft/view.go:631, 834; decision replay controller.go:587-633): 550 000 records r|s|hash +
+    key slot, 16 keys, resident in HBM, through sbv_p256_verify_batch_keyed_dev — with the 8-bit combs every registered key has
+    (13 + 32.2 additions) and with the consenters' wide combs (sbv_p256_widen_keys, round 4: 13 + 16 additions at 16 bits)."""
+    import numpy as np
+    group, props = 11, 50000
+    n = group * props
+    tuples, valid = synth.gen_batch(SEED + 0x300, n, 16, 8)
+    t2 = tuples.reshape(n, 160)
+    keys, counts = np.unique(t2[:, 96:160], axis=0, return_counts=True)
+    keys = keys[counts >= 64]
+    sbv.clear_keys()
+    reg = sbv.register_keys([bytes(k) for k in keys])
+    slots_of = dict(zip((bytes(k) for k in keys), reg))
+    slots = np.fromiter((slots_of.get(bytes(k), 0xFFFFFFFF) for k in t2[:, 96:160]), dtype=np.uint32, count=n)
+    d_rsh = torch.from_numpy(np.ascontiguousarray(t2[:, :96]).reshape(-1)).cuda()
+    d_slots = torch.from_numpy(slots).cuda()
+    d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
+
+    def timed():
+        sbv.verify_batch_keyed_dev(d_rsh.data_ptr(), d_slots.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        sbv.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sbv.verify_batch_keyed_dev(d_rsh.data_ptr(), d_slots.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        kp, kv, kl = sbv.profile_read()
+        sbv.profile_enable(False)
+        return {"sigs_per_s": n * steps / dt, "ms_per_call": 1e3 * dt / steps,
+                "kernel_us": {"k_p256_prep_keyed": kp / max(1, kl), "k_p256_verify_keyed": kv / max(1, kl)},
+                "bitmap_correct": bool((d_b.cpu().numpy() == valid).all())}
+
+    out = {"signatures": n, "proposals": props, "group": group, "distinct_keys": int(len(keys))}
+    try:
+        out["combs_8bit"] = timed()
+        bits = int(os.environ.get("SBV_BENCH_WIDE_BITS", "16"))
+        sbv.wide_keys(bits, 64)
+        t0 = time.perf_counter()
+        sbv.widen_keys(reg)
+        build_s = time.perf_counter() - t0
+        wide, wbits, wmax, kib = sbv.wide_key_stats()
+        out["combs_wide"] = dict(timed(), bits=wbits, wide_keys=wide, MiB_per_key=kib / 1024.0, build_s_host=build_s)
+        out["speedup"] = out["combs_wide"]["sigs_per_s"] / out["combs_8bit"]["sigs_per_s"]
+    finally:
+        sbv.clear_keys()
+    out["note"] = ("device-resident records (60.6 MB), 1/8 corrupted; the sharded generic entry's figure for the same signatures is "
+                   "replay_550k (PCIe-inclusive, key-table cache)")
+    return out
+
+
 def leg_front_end(sbv, tuples, valid, n_all):
     """SURVEY §8f row 1 measured end to end: raw messages + DER signatures + key slots in HOST memory -> accept bitmap in host
     memory through sbv_p256_verify_msgs_keyed (SHA-256 and the strict DER parse run on the device).  2^18 signatures of the
@@ -817,6 +870,7 @@ def main():
                          ("m2_commit_quorum_us", lambda: leg_m2(tuples, n)),
                          ("verify_proposal_k10000_us", leg_proposals),
                          ("replay_550k", lambda: leg_replay_550k(sbv, synth)),
+                         ("consenter_keys_550k", lambda: leg_consenter_keys(sbv, synth, torch, stream, max(2, args.steps // 2))),
                          ("front_end_msgs_per_s", lambda: leg_front_end(sbv, tuples, valid, n))):
             try:
                 extra[name] = fn()

@@ -161,6 +161,31 @@ def clear_keys() -> None:
     _check(load().sbv_p256_clear_keys())
 
 
+def wide_keys(bits: int = 16, max_keys: int = 64) -> None:
+    """sbv_p256_wide_keys: width and cap of the wide combs sbv_p256_widen_keys builds (bits = 0: off); see include/sbv.h."""
+    lib = load()
+    lib.sbv_p256_wide_keys.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    _check(lib.sbv_p256_wide_keys(bits, max_keys))
+
+
+def widen_keys(slots) -> None:
+    """sbv_p256_widen_keys: a wide comb for each of these registered slots (the consenters')."""
+    slots = list(slots)
+    arr = (ctypes.c_uint32 * max(1, len(slots)))(*slots)
+    lib = load()
+    lib.sbv_p256_widen_keys.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    _check(lib.sbv_p256_widen_keys(arr, len(slots)))
+
+
+def wide_key_stats():
+    """(slots holding a wide comb, bits, max_keys, KiB per key)"""
+    out = (ctypes.c_uint32 * 4)()
+    lib = load()
+    lib.sbv_p256_wide_key_stats.argtypes = [ctypes.c_void_p]
+    _check(lib.sbv_p256_wide_key_stats(out))
+    return out[0], out[1], out[2], out[3]
+
+
 def verify_batch_keyed(rsh: bytes, slots, n: Optional[int] = None) -> bytes:
     """Registered-key form: rsh = n x 96 bytes (r|s|hash), slots = n key slots."""
     if n is None:

@@ -92,8 +92,8 @@ SBV_HD void gcomb_digit(const u288& k, int bits, int j, u32& idx, bool& neg, boo
     skip = d == 0;
 }
 
-// R = u1 * G   (add_to_R: R += u1 * G)
-SBV_HD void gphase29_point(xyzz& R, const u256& u1, const gcomb& gc, bool add_to_R = false) {
+// R = u1 * G   (add_to_R: R += u1 * G; flip: every digit's sign is inverted, i.e. R (+)= u1 * (-P) for the comb of P)
+SBV_HD void gphase29_point(xyzz& R, const u256& u1, const gcomb& gc, bool add_to_R = false, bool flip = false) {
     u288 k1;
     gcomb_recode(k1, u1, gc.bits, gc.windows);
     if (!add_to_R) pt29_set_inf(R);
@@ -111,7 +111,7 @@ SBV_HD void gphase29_point(xyzz& R, const u256& u1, const gcomb& gc, bool add_to
         if (!skip) {
             apt29 q;
             raw_apt_unpack(q, cur);
-            pt29_madd(R, q, neg);
+            pt29_madd(R, q, neg != flip);
         }
         cur = nxt; neg = negn; skip = skipn;
     }
@@ -146,6 +146,42 @@ SBV_HD bool wave_any(bool x) {
     return x;
 #endif
 }
+SBV_HD bool wave_all(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __all(x) != 0;
+#else
+    return x;
+#endif
+}
+
+// Wide combs of the consenters' keys (round 4).  The consenters of a SmartBFT cluster are a handful of keys that sign every vote of
+// every decision for a whole epoch (pkg/types/types.go:25-29; internal/bft/view.go:531-541, 631, 834): a registered slot the host
+// marks as such (sbv_p256_widen_keys) owns, besides its 8-bit comb, a `bits`-wide one laid out exactly like the comb of G (gcomb) —
+// tab[idx[slot] * stride + (j << (bits-1)) + (m-1)] = m * 2^(bits j) * Q — so u2 * Q costs ceil(257 / bits) additions instead of
+// 33 (16 bits: 35.7 MB per key and 16 additions once the sign trick below has emptied the carry window; 20 bits: 436 MB and 13;
+// HBM holds 288 GB).  idx[slot] = SBV_WIDE_NONE for every other slot.  A wavefront takes the wide path only when ALL its lanes hold
+// wide slots (wave-uniform: no lane pays for both loops), any other wavefront uses the 8-bit combs every key keeps.
+#define SBV_WIDE_NONE 0xFFFFFFFFu
+struct widekeys { const apt* tab; const u32* idx; size_t stride; int bits; int windows; };
+SBV_HD widekeys widekeys_none() { widekeys w = {nullptr, nullptr, 0, 16, 17}; return w; }
+SBV_HD widekeys widekeys_make(const apt* tab, const u32* idx, int bits) {
+    widekeys w = {tab, tab ? idx : nullptr, gcomb_entries(bits), bits, (257 + bits - 1) / bits};
+    return w;
+}
+// slot: already clamped below the registry's size
+SBV_HD u32 widekeys_index(const widekeys& wk, u32 slot) { return wk.idx ? wk.idx[slot] : SBV_WIDE_NONE; }
+// R += u2 * Q from wide comb number widx.  u2 * Q = (n - u2) * (-Q): a scalar with its top bit set is replaced by n - u2 < 2^255 with
+// every digit's sign flipped (as qphase29_point does), so that the top window of a comb whose width divides 256 is a carry that
+// almost never comes (the loop skips it per lane, a wavefront pays for it only if one of its lanes carries).
+SBV_HD void wide_qphase29_point(xyzz& R, const u256& u2in, const widekeys& wk, u32 widx) {
+    const bool flip = (u2in.v[7] >> 31) != 0;
+    u256 u2, nmu;
+    (void)sub256(nmu, sc_n(), u2in);
+    select256(u2, flip, nmu, u2in);
+    gcomb kc = {wk.tab + (size_t)widx * wk.stride, wk.bits, wk.windows};
+    gphase29_point(R, u2, kc, true, flip);
+}
+
 SBV_HD void qphase29_point(xyzz& R, const u256& u2in, const apt* qtab, int j0, int j1) {
     const bool flip = (u2in.v[7] >> 31) != 0;
     u256 u2, nmu;
@@ -213,7 +249,7 @@ SBV_HD bool qphase29_lane_sorted(const Scratch& s, size_t t, size_t L, u32 slot,
 
 // registered key: u1 * G + u2 * Q in one pass
 SBV_HD bool verify29_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys, const apt* ktab, const uint8_t* kvalid,
-                                const gcomb& gc) {
+                                const gcomb& gc, const widekeys& wk) {
     u256 r, u1, u2;
     soa_load(r, s.r, s.cap, i);
     soa_load(u1, s.u1, s.cap, i);
@@ -224,7 +260,9 @@ SBV_HD bool verify29_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys,
     const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
     xyzz R;
     gphase29_point(R, u1, gc);
-    qphase29_point(R, u2, qtab, 0, SBV_GTAB_WINDOWS);
+    const u32 widx = widekeys_index(wk, slot);
+    if (wave_all(widx != SBV_WIDE_NONE)) wide_qphase29_point(R, u2, wk, widx);
+    else qphase29_point(R, u2, qtab, 0, SBV_GTAB_WINDOWS);
     return ok && pt29_rx_matches(R, r);
 }
 
@@ -350,18 +388,33 @@ SBV_HD bool verify29_lane_generic_rec(const Scratch& s, const uint8_t* tuples, s
 // the partial sums meet in a butterfly of exact XYZZ additions (pt29_add): ~10 additions deep instead of 50.
 // lanes = lanes per signature (a power of two): SBV_COOP_LANES in the throughput-sized latency kernels, SBV_SMALL_LANES in the
 // one-launch form of a commit quorum.
-SBV_HD void keyed29_partial_lane(xyzz& R, const u256& u1, const u256& u2, const apt* qtab, const gcomb& gc, int sub, int lanes = SBV_COOP_LANES) {
+// wide: the key's wide comb kwv (widekeys above; the caller decided wave-uniformly) replaces the 33 windows of qtab.
+SBV_HD void keyed29_partial_lane(xyzz& R, const u256& u1, const u256& u2in, const apt* qtab, const gcomb& gc, int sub, int lanes = SBV_COOP_LANES,
+                                 bool wide = false, gcomb kwv = gcomb_make(nullptr, 16)) {
     u288 k1;
     gcomb_recode(k1, u1, gc.bits, gc.windows);
+    // narrow comb: u2 + 0x80..80 (carry window 32); wide comb: the sign trick of wide_qphase29_point, then the comb-of-G recoding
+    const bool flip = wide && (u2in.v[7] >> 31) != 0;
+    u256 u2, nmu;
+    (void)sub256(nmu, sc_n(), u2in);
+    select256(u2, flip, nmu, u2in);
     u256 k2;
     const u32 top2 = add_const_limbs(k2, u2, 0x80808080u);
+    u288 k2w;
+    gcomb_recode(k2w, u2, kwv.bits, kwv.windows);
     pt29_set_inf(R);
-    const int kSteps = gc.windows + SBV_GTAB_WINDOWS;
+    const int kSteps = gc.windows + (wide ? kwv.windows : SBV_GTAB_WINDOWS);
     auto locate = [&](int t, bool& neg, bool& skip) -> const apt* {
         if (t < gc.windows) {
             u32 idx;
             gcomb_digit(k1, gc.bits, t, idx, neg, skip);
             return gc.tab + ((size_t)t << (gc.bits - 1)) + idx;
+        }
+        if (wide) {
+            u32 idx;
+            gcomb_digit(k2w, kwv.bits, t - gc.windows, idx, neg, skip);
+            neg = neg != flip;
+            return kwv.tab + ((size_t)(t - gc.windows) << (kwv.bits - 1)) + idx;
         }
         int idx;
         comb_digit(k2, top2, t - gc.windows, idx, neg, skip);

@@ -685,14 +685,19 @@ inline void build_g16_window(int j, apt* out_row) {
     comb_window(bases[j], SBV_G16_PER_WINDOW, out_row);
 }
 
-// window j of the `bits`-wide comb of G (8 x 32 Montgomery domain; converted for the carry-free kernels by apt_to_r261)
+// window j of the `bits`-wide comb of the affine point (px, py): out_row[m-1] = m * 2^(bits j) * P, m = 1..2^(bits-1) (8 x 32
+// Montgomery domain; converted for the carry-free kernels by apt_to_r261).  Windows are independent: one host thread each.
+inline void build_comb_window_of(const u256& px, const u256& py, int bits, int j, apt* out_row) {
+    apt* bases = new apt[j + 1];
+    comb_bases(px, py, bits, j + 1, bases);
+    comb_window(bases[j], 1 << (bits - 1), out_row);
+    delete[] bases;
+}
+// the same for G: the fixed-base comb of the G phase
 inline void build_gcomb_window(int bits, int j, apt* out_row) {
     const u256 gx = {{0xD898C296u, 0xF4A13945u, 0x2DEB33A0u, 0x77037D81u, 0x63A440F2u, 0xF8BCE6E5u, 0xE12C4247u, 0x6B17D1F2u}};
     const u256 gy = {{0x37BF51F5u, 0xCBB64068u, 0x6B315ECEu, 0x2BCE3357u, 0x7C0F9E16u, 0x8EE7EB4Au, 0xFE1A7F9Bu, 0x4FE342E2u}};
-    apt* bases = new apt[j + 1];
-    comb_bases(gx, gy, bits, j + 1, bases);
-    comb_window(bases[j], 1 << (bits - 1), out_row);
-    delete[] bases;
+    build_comb_window_of(gx, gy, bits, j, out_row);
 }
 
 }  // namespace sbv

@@ -16,7 +16,7 @@ hipError_t launch_p256_prep(const uint8_t* d_tuples, size_t n, const Scratch& s,
 size_t prep_block_tuples(size_t n);
 hipError_t launch_p256_prep_blocks(const uint8_t* d_tuples, size_t n, const Scratch& s, hipStream_t stream, unsigned block_lo, unsigned block_hi);
 hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
-                                    const uint8_t* d_kvalid, const gcomb& d_gcomb, uint8_t* d_bitmap, uint8_t* d_rerun,
+                                    const uint8_t* d_kvalid, const gcomb& d_gcomb, const widekeys& wk, uint8_t* d_bitmap, uint8_t* d_rerun,
                                     hipStream_t stream);
 // latency form of small registered-key batches in one launch (p256_kernels.hip: host_prep_small + k_p256_verify_prepared_small).
 // d_in: the device view of a page-locked buffer holding n records r | u1 | u2 (24 words each, written by host_prep_small) and,
@@ -24,13 +24,15 @@ hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slo
 // workgroup's signatures when their verdicts are visible.  Up to two workgroups of 16 signatures.
 #define SBV_SMALL_MAX 32
 hipError_t launch_p256_verify_prepared_small(const void* d_in, size_t n, u32 nkeys, const apt* d_ktab, const uint8_t* d_kvalid, const gcomb& d_gcomb,
-                                             uint8_t* d_out, u32* d_done, hipStream_t stream);
+                                             const widekeys& wk, uint8_t* d_out, u32* d_done, hipStream_t stream);
 void host_prep_small(const uint8_t* rsh, const u32* slots, size_t n, u32* rec, u32* slot_out);
 void host_build_gcomb(int bits, apt* out);   // `bits`-wide comb of G, 8 x 32 Montgomery domain: gcomb_entries(bits) entries
 hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const uint8_t* d_sigs, const u64* d_soff, size_t n,
                                u32* d_rsh, hipStream_t stream);
 // comb table (33 x 128 affine multiples, R = 2^261 domain) of a registered key; false if the key is not a valid curve point
 bool host_build_key_table(const uint8_t q[64], apt* out);
+// `bits`-wide comb of a registered key (p256_comb29.h: widekeys), gcomb_entries(bits) entries, R = 2^261 domain
+bool host_build_wide_key_table(const uint8_t q[64], int bits, apt* out, int threads);
 #define SBV_KEYTAB_ENTRIES (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW)
 // d_rerun: ceil(n/64) bytes of per-wavefront flags (fast pass -> exact pass)
 hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const gcomb& d_gcomb, uint8_t* d_bitmap, uint8_t* d_rerun,

@@ -93,10 +93,43 @@ __device__ __forceinline__ void finish_wave(bool accept, size_t i, size_t n, uin
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed(Scratch s, size_t n, const u32* __restrict__ slots,
                                                                           u32 nkeys, const apt* __restrict__ ktab,
                                                                           const uint8_t* __restrict__ kvalid,
-                                                                          gcomb g16r, uint8_t* __restrict__ bitmap) {
+                                                                          gcomb g16r, widekeys wk, uint8_t* __restrict__ bitmap,
+                                                                          const uint8_t* __restrict__ rerun) {
     const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
-    bool accept = false;
-    if (i < n) accept = verify29_lane_keyed(s, i, slots[i], nkeys, ktab, kvalid, g16r);
+    if (rerun && !rerun[i >> 6]) return;          // second pass of the wide split: only the wavefronts the wide kernel left
+    // the tail lanes of the last wavefront replay tuple n - 1 (their verdicts are dropped): every lane of a wavefront takes part in
+    // the wave-uniform choice between the wide and the 8-bit combs inside verify29_lane_keyed
+    const size_t ii = i < n ? i : n - 1;
+    const bool accept = verify29_lane_keyed(s, ii, slots[ii], nkeys, ktab, kvalid, g16r, wk) && i < n;
+    finish_wave(accept, i, n, bitmap);
+}
+
+// The same for wavefronts whose signatures ALL belong to widened slots (sbv_p256_widen_keys: the consenters), and nothing else:
+// two loops over combs of the same shape (13 windows of G, 16-17 of the key), no 8-bit loop in the kernel — it fits 3 waves per
+// SIMD like the G phase of the grouped step, which matters because every addition's table entry is a 64-byte gather from tables
+// far larger than any cache (436 MB of G, 35.7 MB per key).  A wavefront with a lane outside the wide set writes rerun = 1 and
+// leaves; k_p256_verify_keyed then runs over exactly those.
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_p256_verify_keyed_wide(Scratch s, size_t n, const u32* __restrict__ slots,
+                                                                               u32 nkeys, const uint8_t* __restrict__ kvalid,
+                                                                               gcomb g16r, widekeys wk, uint8_t* __restrict__ bitmap,
+                                                                               uint8_t* __restrict__ rerun) {
+    const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    const size_t ii = i < n ? i : n - 1;
+    u32 slot = slots[ii];
+    const bool in_range = slot < nkeys;
+    if (!in_range) slot = 0;
+    const u32 widx = widekeys_index(wk, slot);
+    const bool wide = wave_all(widx != SBV_WIDE_NONE);
+    if ((threadIdx.x & 63) == 0) rerun[i >> 6] = wide ? 0 : 1;
+    if (!wide) return;
+    u256 r, u1, u2;
+    soa_load(u1, s.u1, s.cap, ii);
+    soa_load(u2, s.u2, s.cap, ii);
+    xyzz R;
+    gphase29_point(R, u1, g16r);
+    wide_qphase29_point(R, u2, wk, widx);
+    soa_load(r, s.r, s.cap, ii);
+    const bool accept = i < n && s.ok[ii] != 0 && in_range && kvalid[slot] != 0 && pt29_rx_matches(R, r);
     finish_wave(accept, i, n, bitmap);
 }
 
@@ -105,7 +138,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed(Scrat
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_coop(Scratch s, size_t n, const u32* __restrict__ slots,
                                                                             u32 nkeys, const apt* __restrict__ ktab,
                                                                             const uint8_t* __restrict__ kvalid,
-                                                                            gcomb g16, uint8_t* __restrict__ bitmap) {
+                                                                            gcomb g16, widekeys wk, uint8_t* __restrict__ bitmap) {
     const size_t lane_g = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     const size_t i = lane_g / SBV_COOP_LANES;
     const int sub = (int)(lane_g % SBV_COOP_LANES);
@@ -113,15 +146,18 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_coop(
     xyzz R;
     pt29_set_inf(R);
     bool ok = false;
+    u32 slot = active ? slots[i] : 0u;
+    const bool in_range = slot < nkeys;
+    if (!in_range) slot = 0;
+    const u32 widx = active ? widekeys_index(wk, slot) : 0u;
+    const bool wide = wave_all(widx != SBV_WIDE_NONE);               // wave-uniform: all 8 signatures of the wavefront hold wide slots
     if (active) {
-        u32 slot = slots[i];
-        ok = s.ok[i] != 0 && slot < nkeys;
-        if (slot >= nkeys) slot = 0;
-        ok = ok && kvalid[slot] != 0;
+        ok = s.ok[i] != 0 && in_range && kvalid[slot] != 0;
         u256 u1, u2;
         soa_load(u1, s.u1, s.cap, i);
         soa_load(u2, s.u2, s.cap, i);
-        keyed29_partial_lane(R, u1, u2, ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW), g16, sub);
+        const gcomb kw = {wk.tab + (size_t)(wide ? widx : 0u) * wk.stride, wk.bits, wk.windows};
+        keyed29_partial_lane(R, u1, u2, ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW), g16, sub, SBV_COOP_LANES, wide, kw);
     }
     // butterfly: after log2(lanes) exchanges every lane of the group holds the whole sum
     SBV_NOUNROLL
@@ -169,7 +205,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed_coop(
 #define SBV_SMALL_LANES 16
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_prepared_small(const u32* __restrict__ in, u32 n, u32 nkeys,
                                                                                  const apt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
-                                                                                 gcomb g16, uint8_t* __restrict__ out, u32* __restrict__ done) {
+                                                                                 gcomb g16, widekeys wk, uint8_t* __restrict__ out, u32* __restrict__ done) {
     constexpr int kSigs = SBV_VERIFY_BLOCK / SBV_SMALL_LANES;         // signatures per workgroup
     __shared__ u32 rec[kSigs * 24];
     __shared__ u32 slot_s[kSigs];
@@ -195,15 +231,20 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_prepared_sm
     xyzz R;
     pt29_set_inf(R);
     bool ok = false;
+    u32 slot = active ? slot_s[g] : 0u;
+    // a commit quorum is signed by consenters only: with their wide combs (p256_comb29.h: widekeys) the 13 + 16 terms are two per
+    // lane instead of three — 6 dependent additions instead of 7.  Wave-uniform: the 4 signatures of the wavefront all hold wide slots.
+    const bool in_range = slot < nkeys;           // a rejected record carries slot 0xFFFFFFFF
+    if (!in_range) slot = 0;
+    const u32 widx = active ? widekeys_index(wk, slot) : 0u;
+    const bool wide = wave_all(widx != SBV_WIDE_NONE);
     if (active) {
         const u32* t = rec + g * 24;                                  // every lane of the group reads the same words: LDS broadcasts
         SBV_UNROLL
         for (int l = 0; l < 8; ++l) { r.v[l] = t[l]; u1.v[l] = t[8 + l]; u2.v[l] = t[16 + l]; }
-        u32 slot = slot_s[g];
-        ok = slot < nkeys;
-        if (!ok) slot = 0;
-        ok = ok && kvalid[slot] != 0;
-        keyed29_partial_lane(R, u1, u2, ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW), g16, sub, SBV_SMALL_LANES);
+        ok = in_range && kvalid[slot] != 0;
+        const gcomb kw = {wk.tab + (size_t)(wide ? widx : 0u) * wk.stride, wk.bits, wk.windows};
+        keyed29_partial_lane(R, u1, u2, ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW), g16, sub, SBV_SMALL_LANES, wide, kw);
     }
     SBV_NOUNROLL
     for (int off = SBV_SMALL_LANES / 2; off >= 1; off >>= 1) {
@@ -234,11 +275,11 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_prepared_sm
 }
 
 hipError_t launch_p256_verify_prepared_small(const void* d_in, size_t n, u32 nkeys, const apt* d_ktab, const uint8_t* d_kvalid, const gcomb& d_gtab,
-                                             uint8_t* d_out, u32* d_done, hipStream_t stream) {
+                                             const widekeys& wk, uint8_t* d_out, u32* d_done, hipStream_t stream) {
     if (n == 0 || n > SBV_SMALL_MAX) return hipErrorInvalidValue;
     const size_t lanes = n * SBV_SMALL_LANES;
     hipLaunchKernelGGL(k_p256_verify_prepared_small, dim3((unsigned)((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK)), dim3(SBV_VERIFY_BLOCK), 0, stream,
-                       static_cast<const u32*>(d_in), (u32)n, nkeys, d_ktab, d_kvalid, d_gtab, d_out, d_done);
+                       static_cast<const u32*>(d_in), (u32)n, nkeys, d_ktab, d_kvalid, d_gtab, wk, d_out, d_done);
     return hipGetLastError();
 }
 
@@ -375,19 +416,30 @@ static size_t coop_max_batch() {
     return v;
 }
 
+// SBV_KEYED_WIDE_SPLIT=0: one kernel decides per wavefront between the wide and the 8-bit combs (2 waves per SIMD)
+static bool wide_split() {
+    static const bool v = [] { const char* e = getenv("SBV_KEYED_WIDE_SPLIT"); return !e || e[0] != '0'; }();
+    return v;
+}
+
 hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
-                                    const uint8_t* d_kvalid, const gcomb& d_gtab, uint8_t* d_bitmap, uint8_t* d_rerun,
+                                    const uint8_t* d_kvalid, const gcomb& d_gtab, const widekeys& wk, uint8_t* d_bitmap, uint8_t* d_rerun,
                                     hipStream_t stream) {
     if (n == 0) return hipSuccess;
     if (n <= coop_max_batch()) {      // small batch: latency matters, lanes are plentiful
         const size_t lanes = n * SBV_COOP_LANES;
         hipLaunchKernelGGL(k_p256_verify_keyed_coop, dim3((unsigned)((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK)),
-                           dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab, d_kvalid, d_gtab, d_bitmap);
+                           dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab, d_kvalid, d_gtab, wk, d_bitmap);
         return hipGetLastError();
     }
     const unsigned grid = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
-    (void)d_rerun;
-    hipLaunchKernelGGL(k_p256_verify_keyed, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab, d_kvalid, d_gtab, d_bitmap);
+    if (wk.idx && d_rerun && wide_split()) {        // some slots are wide: their wavefronts first (3 waves per SIMD), then whatever is left
+        hipLaunchKernelGGL(k_p256_verify_keyed_wide, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_kvalid, d_gtab, wk, d_bitmap, d_rerun);
+        hipLaunchKernelGGL(k_p256_verify_keyed, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab, d_kvalid, d_gtab, widekeys_none(), d_bitmap,
+                           (const uint8_t*)d_rerun);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_p256_verify_keyed, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab, d_kvalid, d_gtab, wk, d_bitmap, (const uint8_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -435,6 +487,30 @@ bool host_build_key_table(const uint8_t q[64], apt* out) {
     if (!key_is_valid(x, y)) return false;
     build_comb_table(x, y, out);
     for (size_t k = 0; k < (size_t)SBV_KEYTAB_ENTRIES; ++k) { apt t; apt_to_r261(t, out[k]); out[k] = t; }
+    return true;
+}
+
+
+// `bits`-wide comb of a registered key (p256_comb29.h: widekeys) for the carry-free kernels: gcomb_entries(bits) entries, window j
+// at out + (j << (bits-1)).  One host thread per window (`threads` > 0 caps them); false = not a point of the curve.
+bool host_build_wide_key_table(const uint8_t q[64], int bits, apt* out, int threads) {
+    u256 x, y;
+    from_be32(x, q);
+    from_be32(y, q + 32);
+    if (!key_is_valid(x, y)) return false;
+    const int windows = (257 + bits - 1) / bits;
+    const size_t per = (size_t)1 << (bits - 1);
+    int nt = threads > 0 && threads < windows ? threads : windows;
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([=] {
+            for (int j = t; j < windows; j += nt) {
+                apt* row = out + (size_t)j * per;
+                build_comb_window_of(x, y, bits, j, row);
+                for (size_t k = 0; k < per; ++k) { apt c; apt_to_r261(c, row[k]); row[k] = c; }
+            }
+        });
+    for (auto& t : th) t.join();
     return true;
 }
 

@@ -103,6 +103,14 @@ struct Context {
     u32* d_slots = nullptr;             // staging for the host-pointer keyed entry (cap entries)
     size_t key_cap = 0, nkeys = 0;
     std::unordered_map<std::string, u32> key_index;
+    // wide combs of the slots sbv_p256_widen_keys named (p256_comb29.h: widekeys): comb w of gcomb_entries(kwide_bits) entries belongs
+    // to slot wide_slots[w]; d_kwidx[slot] = w or SBV_WIDE_NONE (key_cap entries, grown with d_kvalid)
+    sbv::apt* d_kwide = nullptr;
+    u32* d_kwidx = nullptr;
+    size_t kwide_cap = 0;
+    std::vector<u32> wide_slots;
+    int kwide_bits = 16;
+    u32 kwide_max = 64;
     int profiling = 0;                     // 0 off, 1 = step triples + dominant-kernel pairs, 2 = dominant-kernel pairs only
     std::vector<hipEvent_t> prof_events;   // triples: before prep, after prep, after verify
     std::vector<hipEvent_t> prof_dom;      // pairs around the dominant kernel of grouped batches (nullptr pair = ungrouped)
@@ -123,6 +131,7 @@ struct Settings {
     bool group_enabled = true; size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17, group_min_batch_ed = (size_t)1 << 18, group_min_batch_k256 = (size_t)1 << 17; u32 group_min_count = 64, group_max = 2048;
     bool kc_on[3] = {true, true, true}; u32 kc_caps[3] = {4096, 1024, 1024};
     int profiling = 0;
+    int wide_bits = 16; u32 wide_max = 64;          // sbv_p256_wide_keys; env SBV_KEYED_WIDE_BITS (0 = off), SBV_KEYED_WIDE_MAX
 } g_settings;
 std::mutex g_set_mu;
 std::unique_ptr<Context> g_ctxs[kMaxDevices];
@@ -132,6 +141,13 @@ std::mutex g_mu;                     // the registry above, init / shutdown, and
 Context* default_ctx() {
     std::lock_guard<std::mutex> lk(g_mu);
     return g_def ? g_def : &g_null;
+}
+// every initialised context, for the process-wide setters
+std::vector<Context*> live_contexts() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::vector<Context*> v;
+    for (auto& up : g_ctxs) if (up) v.push_back(up.get());
+    return v;
 }
 // every single-device entry point: lock the default context for the duration of the call
 #define SBV_ENTER(c)                                  \
@@ -441,12 +457,14 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
     return SBV_OK;
 }
 
+sbv::widekeys wide_of(const Context& c) { return c.wide_slots.empty() ? sbv::widekeys_none() : sbv::widekeys_make(c.d_kwide, c.d_kwidx, c.kwide_bits); }
+
 int enqueue_keyed(Context& c, const uint8_t* d_rsh, const u32* d_slots, size_t n, uint8_t* d_bitmap, hipStream_t stream,
                   hipEvent_t after_prep) {
     const sbv::Scratch s = scratch_view(c);
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_rsh, n, s, stream, true));
     if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
-    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_keyed(s, n, d_slots, (u32)c.nkeys, c.d_ktab, c.d_kvalid, sbv::gcomb_make(c.d_g16r, c.g_bits), d_bitmap, c.d_rerun, stream));
+    HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_keyed(s, n, d_slots, (u32)c.nkeys, c.d_ktab, c.d_kvalid, sbv::gcomb_make(c.d_g16r, c.g_bits), wide_of(c), d_bitmap, c.d_rerun, stream));
     return SBV_OK;
 }
 
@@ -458,14 +476,20 @@ int ensure_key_capacity(Context& c, size_t want) {
     while (cap < want) cap *= 2;
     sbv::apt* nt = nullptr;
     uint8_t* nv = nullptr;
+    u32* nw = nullptr;
     HIP_TRY(SBV_ENOMEM, hipMalloc(&nt, cap * kKeyTabBytes));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&nv, cap));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&nw, cap * sizeof(u32)));
     HIP_TRY(SBV_EDEVICE, hipMemset(nv, 0, cap));
+    HIP_TRY(SBV_EDEVICE, hipMemset(nw, 0xFF, cap * sizeof(u32)));      // SBV_WIDE_NONE
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());          // nothing in flight may still read the old tables
     if (c.nkeys) {
         HIP_TRY(SBV_EDEVICE, hipMemcpy(nt, c.d_ktab, c.nkeys * kKeyTabBytes, hipMemcpyDeviceToDevice));
         HIP_TRY(SBV_EDEVICE, hipMemcpy(nv, c.d_kvalid, c.nkeys, hipMemcpyDeviceToDevice));
+        HIP_TRY(SBV_EDEVICE, hipMemcpy(nw, c.d_kwidx, c.nkeys * sizeof(u32), hipMemcpyDeviceToDevice));
     }
+    if (c.d_kwidx) (void)hipFree(c.d_kwidx);
+    c.d_kwidx = nw;
     if (c.d_btab) (void)hipFree(c.d_btab);
     c.d_btab = nullptr;
     if (c.d_k256_gcomb == c.d_k256_gtab) c.d_k256_gcomb = nullptr;      // 16-bit configuration: the grouped step borrows this table
@@ -571,7 +595,10 @@ int init_context(Context& c, int device) {
         c.group_min_count = g_settings.group_min_count; c.group_max = g_settings.group_max;
         for (int k = 0; k < 3; ++k) { c.kc_on[k] = g_settings.kc_on[k]; c.kc_caps[k] = g_settings.kc_caps[k]; }
         c.profiling = g_settings.profiling;
+        c.kwide_bits = g_settings.wide_bits; c.kwide_max = g_settings.wide_max;
     }
+    if (const char* e = getenv("SBV_KEYED_WIDE_BITS")) { const int v = atoi(e); if (v == 0) c.kwide_max = 0; else if (v >= 10 && v <= 20) c.kwide_bits = v; }
+    if (const char* e = getenv("SBV_KEYED_WIDE_MAX")) { const long v = atol(e); if (v >= 0 && v <= 4096) c.kwide_max = (u32)v; }
     if (const char* e = getenv("SBV_SMALL")) c.small_enabled = e[0] != '0';
     if (const char* e = getenv("SBV_GROUP")) c.group_enabled = e[0] != '0';
     if (const char* e = getenv("SBV_GROUP_MIN_BATCH")) { const long v = atol(e); if (v > 0) c.group_min_batch = c.group_min_batch_cold = c.group_min_batch_ed = c.group_min_batch_k256 = (size_t)v; }
@@ -665,6 +692,9 @@ int shutdown_context(Context& c) {
     if (c.d_ktab) (void)hipFree(c.d_ktab);
     if (c.d_kvalid) (void)hipFree(c.d_kvalid);
     c.d_ktab = nullptr; c.d_kvalid = nullptr; c.key_cap = c.nkeys = 0;
+    if (c.d_kwide) (void)hipFree(c.d_kwide);
+    if (c.d_kwidx) (void)hipFree(c.d_kwidx);
+    c.d_kwide = nullptr; c.d_kwidx = nullptr; c.kwide_cap = 0; c.wide_slots.clear();
     c.key_index.clear();
     if (c.h_small_in) (void)hipHostFree(c.h_small_in);
     if (c.h_small_out) (void)hipHostFree(c.h_small_out);
@@ -904,6 +934,106 @@ extern "C" int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* a
     return SBV_OK;
 }
 
+namespace {
+// Wide combs for `slots` (those that have none yet), kwide_max at most in total: built on the host like the 8-bit ones (one thread
+// per window, the same field code as the kernels), uploaded key by key.  16 bits: 35.7 MB and ~0.1 s per key; 20 bits: 436 MB
+// and about a second.
+int widen_slots(Context& c, const std::vector<u32>& slots) {
+    std::vector<u32> todo;
+    {
+        std::vector<uint8_t> has(c.nkeys, 0);
+        for (u32 sl : c.wide_slots) if (sl < has.size()) has[sl] = 1;
+        for (u32 sl : slots) {
+            if (sl >= c.nkeys) { g_err = "sbv_p256_widen_keys: slot is not registered"; return SBV_EINVAL; }
+            if (!has[sl] && c.wide_slots.size() + todo.size() < (size_t)c.kwide_max) { has[sl] = 1; todo.push_back(sl); }
+        }
+    }
+    if (todo.empty()) return SBV_OK;
+    const size_t stride = sbv::gcomb_entries(c.kwide_bits);
+    const size_t want = c.wide_slots.size() + todo.size();
+    if (want > c.kwide_cap) {
+        size_t cap = c.kwide_cap ? c.kwide_cap : 4;
+        while (cap < want) cap *= 2;
+        if (cap > c.kwide_max) cap = c.kwide_max;
+        sbv::apt* nt = nullptr;
+        HIP_TRY(SBV_ENOMEM, hipMalloc(&nt, cap * stride * sizeof(sbv::apt)));
+        HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());          // nothing in flight may still read the old tables
+        if (!c.wide_slots.empty()) {
+            const hipError_t e = hipMemcpy(nt, c.d_kwide, c.wide_slots.size() * stride * sizeof(sbv::apt), hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) { (void)hipFree(nt); return fail(SBV_EDEVICE, "wide combs: copy", e); }
+        }
+        if (c.d_kwide) (void)hipFree(c.d_kwide);
+        c.d_kwide = nt;
+        c.kwide_cap = cap;
+    }
+    std::vector<const std::string*> key_of(c.nkeys, nullptr);
+    for (const auto& kv : c.key_index) if (kv.second < key_of.size()) key_of[kv.second] = &kv.first;
+    std::vector<sbv::apt> tab(stride);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    for (u32 sl : todo) {
+        const std::string* k = key_of[sl];
+        if (!k || k->size() != 64 || !sbv::host_build_wide_key_table((const uint8_t*)k->data(), c.kwide_bits, tab.data(), (int)(hw > 32 ? 32 : hw)))
+            memset((void*)tab.data(), 0, stride * sizeof(sbv::apt));     // not a point: kvalid[slot] = 0 rejects its signatures whatever the lanes add
+        const u32 w = (u32)c.wide_slots.size();
+        HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_kwide + (size_t)w * stride, tab.data(), stride * sizeof(sbv::apt), hipMemcpyHostToDevice));
+        HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_kwidx + sl, &w, sizeof(u32), hipMemcpyHostToDevice));      // published after its table is complete
+        c.wide_slots.push_back(sl);
+    }
+    return SBV_OK;
+}
+int drop_wide_keys(Context& c) {
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    if (c.d_kwidx && c.key_cap) HIP_TRY(SBV_EDEVICE, hipMemset(c.d_kwidx, 0xFF, c.key_cap * sizeof(u32)));
+    if (c.d_kwide) (void)hipFree(c.d_kwide);
+    c.d_kwide = nullptr; c.kwide_cap = 0; c.wide_slots.clear();
+    return SBV_OK;
+}
+}  // namespace
+
+extern "C" int sbv_p256_wide_keys(int bits, uint32_t max_keys) {
+    if (bits != 0 && (bits < 10 || bits > 20)) return SBV_EINVAL;
+    if (max_keys > 4096) return SBV_EINVAL;
+    {
+        std::lock_guard<std::mutex> lk(g_set_mu);
+        if (bits) g_settings.wide_bits = bits;
+        g_settings.wide_max = bits ? max_keys : 0u;
+    }
+    int rc = SBV_OK;
+    for (Context* cp : live_contexts()) {
+        std::lock_guard<std::mutex> lk(cp->mu);
+        Context& c = *cp;
+        if (!c.ready) continue;
+        if (hipSetDevice(c.device) != hipSuccess) { rc = SBV_EDEVICE; continue; }
+        const u32 nmax = bits ? max_keys : 0u;
+        const std::vector<u32> had = c.wide_slots;
+        const bool rebuild = (bits && bits != c.kwide_bits) || nmax < had.size();       // another width, or fewer keys than it holds
+        if (rebuild) { const int r = drop_wide_keys(c); if (r != SBV_OK) { rc = r; continue; } }
+        if (bits) c.kwide_bits = bits;
+        c.kwide_max = nmax;
+        if (rebuild && nmax) { const int r = widen_slots(c, had); if (r != SBV_OK) rc = r; }
+    }
+    return rc;
+}
+
+extern "C" int sbv_p256_widen_keys(const uint32_t* slots, size_t m) {
+    SBV_ENTER(c);
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (m == 0) return SBV_OK;
+    if (!slots) { g_err = "null pointer"; return SBV_EINVAL; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    return widen_slots(c, std::vector<u32>(slots, slots + m));
+}
+
+extern "C" int sbv_p256_wide_key_stats(uint32_t out[4]) {
+    SBV_ENTER(c);
+    if (!c.ready) return SBV_ENOTINIT;
+    if (!out) return SBV_EINVAL;
+    out[0] = (u32)c.wide_slots.size(); out[1] = (u32)c.kwide_bits; out[2] = c.kwide_max;
+    out[3] = (u32)((sbv::gcomb_entries(c.kwide_bits) * sizeof(sbv::apt)) >> 10);      // KiB per key
+    return SBV_OK;
+}
+
 extern "C" int sbv_p256_register_keys(const uint8_t* keys, size_t m, uint32_t* slots_out) {
     SBV_ENTER(c);
     if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
@@ -965,6 +1095,8 @@ extern "C" int sbv_p256_clear_keys(void) {
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
     c.key_index.clear();
     c.nkeys = 0;
+    if (c.d_kwidx && c.key_cap) HIP_TRY(SBV_EDEVICE, hipMemset(c.d_kwidx, 0xFF, c.key_cap * sizeof(u32)));
+    c.wide_slots.clear();        // the allocation stays for the next registry
     return SBV_OK;
 }
 
@@ -1030,7 +1162,7 @@ extern "C" int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* s
         *done = 0;
         std::atomic_thread_fence(std::memory_order_seq_cst);
         HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_prepared_small(c.d_small_in, n, (u32)c.nkeys, c.d_ktab, c.d_kvalid, sbv::gcomb_make(c.d_g16r, c.g_bits),
-                                                                  static_cast<uint8_t*>(c.d_small_out),
+                                                                  wide_of(c), static_cast<uint8_t*>(c.d_small_out),
                                                                   reinterpret_cast<u32*>(static_cast<uint8_t*>(c.d_small_out) + SBV_SMALL_MAX), c.stream));
         const auto give_up = t0 + std::chrono::milliseconds(5);
         while (*done < (u32)n) {
@@ -1474,16 +1606,6 @@ extern "C" void* sbv_host_alloc(size_t bytes) {
 extern "C" void sbv_host_free(void* p) {
     if (p) (void)hipHostFree(p);
 }
-
-namespace {
-// every initialised context, for the process-wide setters
-std::vector<Context*> live_contexts() {
-    std::lock_guard<std::mutex> lk(g_mu);
-    std::vector<Context*> v;
-    for (auto& up : g_ctxs) if (up) v.push_back(up.get());
-    return v;
-}
-}  // namespace
 
 extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uint32_t max_groups) {
     Settings st;

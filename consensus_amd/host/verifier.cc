@@ -134,6 +134,11 @@ class SbvBackend : public Backend {
         uint32_t slot = 0;
         return sbv_p256_register_keys(q, 1, &slot) == SBV_OK ? (long)slot : -1;
     }
+    void widen_key(long slot) override {
+        if (rc_ != SBV_OK || slot < 0) return;
+        const uint32_t s = (uint32_t)slot;
+        (void)sbv_p256_widen_keys(&s, 1);              // best effort: without its wide comb the key keeps the 8-bit one
+    }
     int verify_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap) override {
         if (rc_ != SBV_OK) return rc_;
         return sbv_p256_verify_batch_keyed(rsh, slots, n, bitmap);
@@ -484,6 +489,7 @@ void* Verifier::staging(Staging& s, size_t bytes) {
 
 void Verifier::RegisterConsenter(uint64_t id, const uint8_t* q) {
     const long slot = ed() || k256() ? -1 : co_.backend().register_key(q);     // -1: no key registry (Ed25519: grouped per batch; secp256k1: no combs yet)
+    if (slot >= 0) co_.backend().widen_key(slot);      // consenters sign every vote of the epoch: 16 comb additions per u2 * Q instead of 32
     bytes key((const char*)q, key_bytes());
     key.resize(64, '\0');
     std::lock_guard<SpinLock> lk(mu_);

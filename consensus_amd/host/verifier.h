@@ -46,6 +46,9 @@ class Backend {
     // register_key returns a slot >= 0, or -1 when the backend has no key registry (then callers
     // use verify() with the key carried in the tuple).
     virtual long register_key(const uint8_t q[64]) { (void)q; return -1; }
+    // The slot belongs to a consenter: a key that signs every vote of every decision of the epoch (internal/bft/view.go:531-541,
+    // 631, 834).  The product backend gives it a wide comb (include/sbv.h: sbv_p256_widen_keys); a no-op elsewhere.
+    virtual void widen_key(long slot) { (void)slot; }
     virtual uint64_t keyed_batches() { return 0; }      // test hook: how many verify_keyed batches ran
     // Page-locked staging memory (include/sbv.h: sbv_host_alloc); nullptr = none available, the caller uses the heap
     virtual void* host_alloc(size_t bytes) { (void)bytes; return nullptr; }

@@ -49,6 +49,10 @@ type Backend interface {
 	// RegisterKey gives the device a P-256 key it will see again (consenters, clients) and returns its comb slot;
 	// -1 when there is no registry (then items carry Slot = -1 and travel as generic tuples with the key inline).
 	RegisterKey(pub *ecdsa.PublicKey) int32
+	// WidenKey marks a registered slot as a consenter's: a key that signs every vote of every decision of the epoch
+	// (internal/bft/view.go:531-541, 631, 834).  The device gives it a second, 16-bit-window comb (sbv_p256_widen_keys:
+	// 35.7 MB of HBM, u2*Q in 16 additions instead of 32); a no-op for a backend without a registry.
+	WidenKey(slot int32)
 	// SignBatch is the batch form of api.Signer.Sign for P-256 (sbv_p256_sign_batch: RFC 6979 nonces): signature i =
 	// ECDSA(keys[keyIndex[i]], digests[i]) as r|s, 64 bytes; ok[i] = false when the key or index is unusable.
 	// A backend without batch signing returns ErrNoBatchSigner and the Signer signs one by one with crypto/ecdsa.
@@ -101,6 +105,7 @@ func (cpuBackend) Verify(scheme Scheme, items []Item) ([]bool, error) {
 	return ok, nil
 }
 func (cpuBackend) RegisterKey(*ecdsa.PublicKey) int32 { return -1 }
+func (cpuBackend) WidenKey(int32)                      {}
 func (cpuBackend) SignBatch([][32]byte, []uint32, [][32]byte) ([][64]byte, []bool, error) {
 	return nil, nil, ErrNoBatchSigner
 }

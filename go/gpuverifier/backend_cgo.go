@@ -289,6 +289,18 @@ func (b *gpuBackend) RegisterKey(pub *ecdsa.PublicKey) int32 {
 	return slot
 }
 
+// WidenKey: sbv_p256_widen_keys for one slot (best effort: a slot that gets no wide comb keeps its 8-bit one, verdicts are the same).
+func (b *gpuBackend) WidenKey(slot int32) {
+	if slot < 0 {
+		return
+	}
+	b.on(func() {
+		var s C.uint32_t
+		s = C.uint32_t(slot)
+		C.sbv_p256_widen_keys(&s, C.size_t(1))
+	})
+}
+
 // SignBatch: sbv_p256_sign_batch (RFC 6979 nonces on the device; not constant-time — see include/sbv.h).
 func (b *gpuBackend) SignBatch(keys [][32]byte, keyIndex []uint32, digests [][32]byte) (sigs [][64]byte, ok []bool, err error) {
 	n := len(digests)

@@ -113,6 +113,9 @@ func (v *Verifier) RegisterConsenter(id uint64, pub *ecdsa.PublicKey) {
 	k := regKey{pub: pub, raw: p256Raw(pub), slot: -1}
 	if v.opt.Scheme == SchemeP256 {
 		k.slot = v.backend.RegisterKey(pub)
+		if k.slot >= 0 {
+			v.backend.WidenKey(k.slot) // consenters sign every vote of the epoch: the wide comb halves their u2*Q
+		}
 	}
 	v.mu.Lock()
 	v.consenters[id] = k

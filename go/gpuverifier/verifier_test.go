@@ -193,6 +193,7 @@ type recordingBackend struct {
 	keyed    int // batches in which every item had a slot
 	generic  int
 	sizes    []int
+	widened  []int32
 	failNext bool
 	failAll  bool
 }
@@ -207,6 +208,12 @@ func (b *recordingBackend) RegisterKey(pub *ecdsa.PublicKey) int32 {
 	}
 	b.keys = append(b.keys, pub)
 	return int32(len(b.keys) - 1)
+}
+
+func (b *recordingBackend) WidenKey(slot int32) {
+	b.mu.Lock()
+	defer b.mu.Unlock()
+	b.widened = append(b.widened, slot)
 }
 
 func (b *recordingBackend) Verify(scheme Scheme, items []Item) ([]bool, error) {

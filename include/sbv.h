@@ -122,6 +122,20 @@ int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, vo
 int sbv_p256_register_keys(const uint8_t* keys, size_t m, uint32_t* slots_out);
 int sbv_p256_key_count(void);
 int sbv_p256_clear_keys(void);
+/* Wide combs for the consenters' keys (round 4).  The consenters of a cluster are a handful of keys that sign every vote of every
+ * decision for a whole epoch (pkg/types/types.go:25-29; internal/bft/view.go:531-541 collects 2f+1 of their commit signatures per
+ * decision, view.go:631 and :834 verify them; reconfiguration replaces the set: pkg/consensus/consensus.go:185-252), and HBM holds
+ * 288 GB: sbv_p256_widen_keys gives the named registered slots a second, `bits`-wide comb (the layout of the comb of G), after
+ * which u2*Q is ceil(257 / bits) additions instead of 32.2 — 16 bits: 16 additions, 35.7 MB and ~0.1 s of host time per key;
+ * 20 bits: 13 additions, 436 MB and about a second per key.  A wavefront whose signatures all belong to wide slots takes the wide
+ * combs, any other the 8-bit combs every key keeps; verdicts are identical.  Slots that are wide already are skipped, slots
+ * beyond `max_keys` wide ones stay narrow (no error); an unregistered slot is SBV_EINVAL.
+ * sbv_p256_wide_keys sets the width and the cap for every device (defaults: 16 bits, 64 keys; bits = 0 switches the feature off
+ * and frees the tables; another width rebuilds the combs of the slots already widened).  Env: SBV_KEYED_WIDE_BITS (0 = off),
+ * SBV_KEYED_WIDE_MAX.  stats: out[0] = wide slots, out[1] = bits, out[2] = max_keys, out[3] = KiB per key. */
+int sbv_p256_wide_keys(int bits, uint32_t max_keys);
+int sbv_p256_widen_keys(const uint32_t* slots, size_t m);
+int sbv_p256_wide_key_stats(uint32_t out[4]);
 /* rsh: n x 96 bytes (r|s|hash, big-endian), slots: n key slots.  Takes over VerifyConsenterSig
  * (view.go:631, 834), VerifySignature (viewchanger.go:598...) and decision replay for registered
  * signers.  An out-of-range slot is a reject, not an error. */

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <string.h>
 #include <thread>
+#include <string>
 #include <vector>
 
 #include "../../consensus_amd/csrc/p256_core.h"
@@ -399,6 +400,9 @@ int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
 }
 
 static bool g_keyed_coop = false, g_keyed_prepared = false;
+// wide combs of the first registered slots (p256_comb29.h: widekeys; libsbv: sbv_p256_wide_keys): 0 keys = off
+static int g_keyed_wide_bits = 16;
+static u32 g_keyed_wide_n = 0;
 static std::vector<u32> g_prep_rec, g_prep_slot;
 // the host half of the prepared latency form, as consensus_amd/csrc/p256_kernels.hip: host_prep_small does it
 struct EmulRecWords {
@@ -437,23 +441,57 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
     for (size_t b = 0; b < nblocks; ++b)
         for (int t = 0; t < block; ++t) prep_chunk29<false>(hw, n, s, b * per_block + t, (size_t)block, T);
     const size_t per_key = (size_t)SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW;
-    std::vector<apt> ktab(per_key * (nkeys ? nkeys : 1));
-    std::vector<uint8_t> kvalid(nkeys ? nkeys : 1, 0);
-    for (u32 k = 0; k < nkeys; ++k) {
-        u256 x, y;
-        from_be32(x, keys + 64 * k);
-        from_be32(y, keys + 64 * k + 32);
-        kvalid[k] = key_is_valid(x, y) ? 1 : 0;
-        if (kvalid[k]) {
-            build_comb_table(x, y, &ktab[per_key * k]);
-            for (size_t e = 0; e < per_key; ++e) { apt t; apt_to_r261(t, ktab[per_key * k + e]); ktab[per_key * k + e] = t; }
+    // the registry of one test is the same from call to call: its tables are kept (what sbv_p256_register_keys does once)
+    static std::string reg_keys, wide_keys;
+    static std::vector<apt> ktab, wtab;
+    static std::vector<uint8_t> kvalid;
+    static int wide_bits_built = 0;
+    const std::string keys_now((const char*)keys, 64 * (size_t)nkeys);
+    if (keys_now != reg_keys || ktab.empty()) {
+        reg_keys = keys_now;
+        wide_keys.clear();
+        ktab.assign(per_key * (nkeys ? nkeys : 1), apt{});
+        kvalid.assign(nkeys ? nkeys : 1, 0);
+        for (u32 k = 0; k < nkeys; ++k) {
+            u256 x, y;
+            from_be32(x, keys + 64 * k);
+            from_be32(y, keys + 64 * k + 32);
+            kvalid[k] = key_is_valid(x, y) ? 1 : 0;
+            if (kvalid[k]) {
+                build_comb_table(x, y, &ktab[per_key * k]);
+                for (size_t e = 0; e < per_key; ++e) { apt t; apt_to_r261(t, ktab[per_key * k + e]); ktab[per_key * k + e] = t; }
+            }
         }
     }
+    // wide combs of slots [0, nw): what extend_wide_keys (sbv_api.hip) builds at registration
+    const u32 nw = g_keyed_wide_n < nkeys ? g_keyed_wide_n : nkeys;
+    const size_t wstride = gcomb_entries(g_keyed_wide_bits);
+    const std::string wide_now((const char*)keys, 64 * (size_t)nw);
+    if (wide_now != wide_keys || wide_bits_built != g_keyed_wide_bits || wtab.empty()) {
+        wide_keys = wide_now;
+        wide_bits_built = g_keyed_wide_bits;
+        wtab.assign(nw ? nw * wstride : 1, apt{});
+        for (u32 k = 0; k < nw; ++k) {
+            if (!kvalid[k]) continue;                      // zeros, as the library leaves them: kvalid rejects whatever the lanes add
+            u256 x, y;
+            from_be32(x, keys + 64 * k);
+            from_be32(y, keys + 64 * k + 32);
+            const int windows = (257 + g_keyed_wide_bits - 1) / g_keyed_wide_bits;
+            for (int j = 0; j < windows; ++j) {
+                apt* row = &wtab[k * wstride + ((size_t)j << (g_keyed_wide_bits - 1))];
+                build_comb_window_of(x, y, g_keyed_wide_bits, j, row);
+                for (size_t e = 0; e < ((size_t)1 << (g_keyed_wide_bits - 1)); ++e) { apt t; apt_to_r261(t, row[e]); row[e] = t; }
+            }
+        }
+    }
+    std::vector<u32> widx(nkeys ? nkeys : 1, SBV_WIDE_NONE);       // d_kwidx: the library maps any subset of the slots; here the first nw
+    for (u32 k = 0; k < nw; ++k) widx[k] = k;
+    const widekeys wk = nw ? widekeys_make(wtab.data(), widx.data(), g_keyed_wide_bits) : widekeys_none();
     memset(bitmap, 0, (n + 7) / 8);
     for (size_t i = 0; i < n; ++i) {
         bool accept;
         if (!g_keyed_coop) {
-            accept = verify29_lane_keyed(s, i, slots[i], nkeys, ktab.data(), kvalid.data(), g16rtab());
+            accept = verify29_lane_keyed(s, i, slots[i], nkeys, ktab.data(), kvalid.data(), g16rtab(), wk);
         } else {
             // k_p256_verify_keyed_coop: SBV_COOP_LANES partial sums, xor-butterfly of exact XYZZ additions
             u32 slot = slots[i];
@@ -480,7 +518,11 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
             }
             const int L = g_keyed_prepared ? 16 : SBV_COOP_LANES;      // SBV_SMALL_LANES of the prepared form
             xyzz part[16];
-            for (int sub = 0; sub < L; ++sub) keyed29_partial_lane(part[sub], a, b, &ktab[per_key * slot], g16rtab(), sub, L);
+            // the kernels decide per wavefront (wave_all over its 8 / 4 signatures); a signature alone is the strictest case of it
+            const u32 wi = widekeys_index(wk, slot);            // slot is clamped already; a rejected record keeps ok = false whatever its comb
+            const bool wide = wi != SBV_WIDE_NONE;
+            const gcomb kw = {wk.tab + (size_t)(wide ? wi : 0u) * wk.stride, wk.bits, wk.windows};
+            for (int sub = 0; sub < L; ++sub) keyed29_partial_lane(part[sub], a, b, &ktab[per_key * slot], g16rtab(), sub, L, wide, kw);
             for (int off = L / 2; off >= 1; off >>= 1) {
                 xyzz nxt[16];
                 for (int sub = 0; sub < L; ++sub) { nxt[sub] = part[sub]; pt29_add(nxt[sub], part[sub ^ off]); }
@@ -494,6 +536,7 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
     }
 }
 void sbve_set_keyed_coop(int on) { g_keyed_coop = on != 0; g_keyed_prepared = on == 3; }   // 1: 8 lanes per signature (k_p256_verify_keyed_coop); 3: the one-launch latency form (stage A by the host half, 16 lanes per signature)
+void sbve_set_keyed_wide(int bits, unsigned n_wide) { if (bits >= 8 && bits <= 20) g_keyed_wide_bits = bits; g_keyed_wide_n = n_wide; }
 unsigned long sbve_small_disagreements() { return g_small_disagreements; }
 unsigned long sbve_coop_disagreements() { return g_coop_disagreements; }
 

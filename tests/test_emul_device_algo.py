@@ -299,6 +299,76 @@ def test_key_comb_scalars_around_the_sign_flip_and_the_carry_window(emul, oracle
     emul.sbve_set_group_chunks(3)
 
 
+def test_wide_combs_of_a_small_registry_give_the_same_verdicts(emul, oracle, golden_vectors):
+    """sbv_p256_wide_keys (p256_comb29.h: widekeys): the first registered slots own a `bits`-wide comb laid out like the comb of G;
+    a lane (on the device: a wavefront) whose slot is wide takes ceil(257 / bits) additions from it instead of 33 from the 8-bit
+    comb.  Same verdicts as the oracle on the golden tuple vectors (invalid keys included: their wide table is never trusted) and
+    on a seeded batch, with every key wide, with only some (wide and narrow lanes side by side), through the one-lane form, the
+    8-lane latency form and the prepared one-launch form; then forged signatures whose u2 walks the edges of the wide recoding:
+    the sign flip at 2^255 and the carry window of a width that divides 256."""
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+    n = 300
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0x51DE, n, 5, 3, tup, exp, 4)
+    rng = random.Random(0x51DE)
+    d = rng.randrange(1, N)
+    Q = ec.pt_mul(d, ec.G)
+    forged = []
+    for bits in (16, 10):                                                   # thresholds of both widths in one list
+        windows = -(-257 // bits)
+        S = sum(1 << (bits * j + bits - 1) for j in range(windows - 1))
+        T = (1 << (bits * (windows - 1))) - S                               # u2 + S reaches the top window from here on
+        for u2 in (T - 1, T, T + 1, 2**255 - 1, 2**255, 2**255 + 1, N - 1, N - 2, 1, 2, (N - 1) // 2, (N + 1) // 2, N - T, N - T + 1, N - T - 1,
+                   2**255 - 2**239, 2**255 - 2**239 - 1, 2**255 - 2**239 + 1, (1 << (bits - 1)), (1 << (bits - 1)) - 1, (1 << bits) - 1, 1 << bits):
+            u2 %= N
+            if u2 == 0:
+                continue
+            u1 = rng.randrange(0, N)
+            Rp = ec.pt_add(ec.pt_mul(u1, ec.G), ec.pt_mul(u2, Q))
+            r = Rp[0] % N
+            s_ = r * pow(u2, -1, N) % N
+            e = u1 * s_ % N
+            forged.append(r.to_bytes(32, "big") + s_.to_bytes(32, "big") + e.to_bytes(32, "big") + Q[0].to_bytes(32, "big") + Q[1].to_bytes(32, "big"))
+            bad = bytearray(forged[-1]); bad[70] ^= 4
+            forged.append(bytes(bad))
+    allt = b"".join(forged) + tup.raw + blob                                # the forged key gets slot 0, the seeded keys 1..5
+    total = len(allt) // 160
+    want = [bool(oracle.sbvo_p256_verify_tuple(allt[160 * i:160 * i + 160])) for i in range(total)]
+    assert want[:len(forged)] == [True, False] * (len(forged) // 2)
+    assert want[len(forged):len(forged) + n] == _bitmap_list(exp.raw, n)
+    rsh, slots, keys = split_keyed(allt)
+    arr = (ctypes.c_uint32 * total)(*slots)
+    emul.sbve_set_keyed_wide.argtypes = [ctypes.c_int, ctypes.c_uint]
+    emul.sbve_coop_disagreements.restype = ctypes.c_ulong
+    emul.sbve_small_disagreements.restype = ctypes.c_ulong
+
+    def run(form):
+        emul.sbve_set_keyed_coop(form)
+        got = []
+        step = total if form != 3 else 29
+        for off in range(0, total, step):
+            m = min(step, total - off)
+            bm = ctypes.create_string_buffer((m + 7) // 8)
+            sub = (ctypes.c_uint32 * m)(*slots[off:off + m])
+            emul.sbve_p256_verify_batch_keyed(rsh[96 * off:96 * (off + m)], sub, m, b"".join(keys), len(keys), bm, 64, 4)
+            got += _bitmap_list(bm.raw, m)
+        return got
+
+    try:
+        for bits, nwide, forms in ((10, len(keys), (0, 1, 3)), (10, 3, (0, 3)), (16, 2, (0, 1, 3)), (13, 1, (0,))):
+            emul.sbve_set_keyed_wide(bits, nwide)
+            for form in forms:
+                got = run(form)
+                bad = [i for i in range(total) if got[i] != want[i]]
+                assert not bad, (bits, nwide, form, bad[:10])
+        assert emul.sbve_coop_disagreements() == 0 and emul.sbve_small_disagreements() == 0
+    finally:
+        emul.sbve_set_keyed_wide(16, 0)
+        emul.sbve_set_keyed_coop(0)
+
+
 def test_fast_conditional_subtraction_is_exact_or_flags(emul):
     """FAST mode: either the result equals the exact one, or the sticky word is 0xFFFFFFFF."""
     emul.sbve_fe_add_fast.restype = ctypes.c_uint32

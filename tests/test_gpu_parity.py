@@ -223,6 +223,94 @@ def test_registered_key_form_equals_generic_verdicts(gpu, oracle, golden_vectors
     assert gpu.key_count() == 0
 
 
+def test_wide_combs_of_consenter_keys_on_gpu(gpu, oracle, golden_vectors):
+    """sbv_p256_widen_keys / sbv_p256_wide_keys (round 4): registered slots named as consenters' get a second, wide comb; wavefronts
+    whose signatures all belong to wide slots take 13 + ceil(257 / bits) additions, every other wavefront the 8-bit combs.  The
+    golden tuple vectors (their invalid keys included: a widened slot of a key that is no point still rejects), forged signatures
+    whose u2 walks the edges of the wide recoding (sign flip at 2^255, carry window of a width dividing 256) and a seeded batch,
+    through the one-lane kernel (> 32768), the 8-lane latency kernel (ragged sizes) and the one-launch form (<= 32), with some
+    slots wide, all of them, another width (rebuilt in place), and the feature off: always the oracle's verdicts."""
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+    n = 36000
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0x51DE, n, 6, 3, tup, exp, os.cpu_count() or 1)
+    rng = random.Random(0x51DE)
+    d = rng.randrange(1, ec.N)
+    Q = ec.pt_mul(d, ec.G)
+    forged = []
+    for bits in (16, 18):
+        windows = -(-257 // bits)
+        S = sum(1 << (bits * j + bits - 1) for j in range(windows - 1))
+        T = (1 << (bits * (windows - 1))) - S
+        for u2 in (T - 1, T, T + 1, 2**255 - 1, 2**255, 2**255 + 1, ec.N - 1, ec.N - 2, 1, 2, (ec.N - 1) // 2, (ec.N + 1) // 2, ec.N - T, ec.N - T + 1,
+                   2**255 - 2**239, 2**255 - 2**239 + 1, (1 << (bits - 1)), (1 << (bits - 1)) - 1, (1 << bits) - 1, 1 << bits):
+            u2 %= ec.N
+            if u2 == 0:
+                continue
+            u1 = rng.randrange(0, ec.N)
+            Rp = ec.pt_add(ec.pt_mul(u1, ec.G), ec.pt_mul(u2, Q))
+            r = Rp[0] % ec.N
+            s_ = r * pow(u2, -1, ec.N) % ec.N
+            e = u1 * s_ % ec.N
+            forged.append(r.to_bytes(32, "big") + s_.to_bytes(32, "big") + e.to_bytes(32, "big") + Q[0].to_bytes(32, "big") + Q[1].to_bytes(32, "big"))
+            bad = bytearray(forged[-1]); bad[70] ^= 4
+            forged.append(bytes(bad))
+    nf = len(forged)
+    allt = b"".join(forged) + blob + tup.raw                    # forged key first, then the golden keys, then the 6 seeded ones
+    total = len(allt) // 160
+    want = [True, False] * (nf // 2) + [v["accept"] for v in vs] + sbv.bitmap_to_list(exp.raw, n)
+    assert [bool(oracle.sbvo_p256_verify_tuple(t)) for t in forged] == want[:nf]
+    rsh, slots, keys = _split_keyed(allt)
+    gpu.clear_keys()
+
+    def check(tag):
+        sl = [reg[s] for s in slots]
+        got = sbv.bitmap_to_list(gpu.verify_batch_keyed(rsh, sl, total), total)                   # > 32768: one lane per signature
+        bad = [i for i in range(total) if got[i] != want[i]]
+        assert not bad, (tag, bad[:10])
+        lo = nf + len(vs)                                                                          # the seeded part: its keys are wide in every configuration
+        for a, m in ((0, 1), (0, 7), (0, nf), (0, nf + len(vs) + 100), (lo, 8), (lo, 64), (lo + 3, 5000), (lo, 32768)):
+            gotm = sbv.bitmap_to_list(gpu.verify_batch_keyed(rsh[96 * a:96 * (a + m)], sl[a:a + m], m), m)
+            badm = [i for i in range(m) if gotm[i] != want[a + i]]
+            assert not badm, (tag, a, m, badm[:10])
+        for width in (32, 15, 1):                                                                  # the one-launch form
+            for a in list(range(0, nf + len(vs), width)) + [lo, lo + 32]:
+                m = min(width, total - a)
+                gotm = sbv.bitmap_to_list(gpu.verify_batch_keyed(rsh[96 * a:96 * (a + m)], sl[a:a + m], m), m)
+                badm = [a + i for i in range(m) if gotm[i] != want[a + i]]
+                assert not badm, (tag, width, a, badm)
+
+    try:
+        gpu.wide_keys(16, 64)
+        reg = gpu.register_keys(keys)
+        assert gpu.wide_key_stats()[0] == 0                      # registering alone builds no wide comb
+        check("8-bit combs only")
+        seeded = reg[-6:]
+        odd = [reg[0]] + reg[1:len(keys) - 6:7]                  # the forged key and every 7th golden key (valid and invalid ones)
+        gpu.widen_keys(seeded + odd)
+        wide, bits, cap, kib = gpu.wide_key_stats()
+        assert wide == len(set(seeded + odd)) and bits == 16 and cap == 64 and kib == 17 * 32768 * 64 // 1024
+        gpu.widen_keys(seeded)                                   # idempotent
+        assert gpu.wide_key_stats()[0] == wide
+        check("16 bits, some slots")
+        gpu.wide_keys(18, 64)                                    # another width: the same slots, rebuilt
+        assert gpu.wide_key_stats()[:2] == (wide, 18)
+        check("18 bits, some slots")
+        gpu.wide_keys(16, 8)                                     # a cap below what it holds: the first 8 stay
+        assert gpu.wide_key_stats()[0] == 8
+        check("16 bits, cap 8")
+        with pytest.raises(Exception):
+            gpu.widen_keys([len(keys) + 5])                      # not a registered slot
+        gpu.wide_keys(0, 0)
+        assert gpu.wide_key_stats()[0] == 0
+        check("off")
+    finally:
+        gpu.wide_keys(16, 64)
+        gpu.clear_keys()
+
+
 def test_registered_key_full_batch_2_20(gpu):
     """2^20 signatures against 1024 registered keys (the headline batch re-expressed with key slots)."""
     import sys
