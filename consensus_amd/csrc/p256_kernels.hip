@@ -88,48 +88,20 @@ __device__ __forceinline__ void finish_wave(bool accept, size_t i, size_t n, uin
     }
 }
 
-// Stage B, registered-key form: 17 + 33 mixed additions per lane from two combs (G and the key's), on the carry-free
-// field (p256_comb29.h); both tables in the R = 2^261 domain.
+// Stage B, registered-key form: 13 + 33 mixed additions per lane from two combs (G and the key's), on the carry-free
+// field (p256_comb29.h); both tables in the R = 2^261 domain.  A wavefront whose lanes all hold widened slots (the consenters':
+// sbv_p256_widen_keys) takes the key's wide comb instead: 13 + 16 additions at 16 bits (550 000 signatures of 16 keys: 1.66 -> 1.25 ms,
+// 1.14 ms at 20 bits; profiles/r04/ab_wide_r04k.jsonl).  A wide-only kernel at 3 waves per SIMD with this one as second pass over
+// the wavefronts it left was measured in the same session and removed: 1.25 / 1.19 ms against 1.25 / 1.14 for the single kernel.
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_p256_verify_keyed(Scratch s, size_t n, const u32* __restrict__ slots,
                                                                           u32 nkeys, const apt* __restrict__ ktab,
                                                                           const uint8_t* __restrict__ kvalid,
-                                                                          gcomb g16r, widekeys wk, uint8_t* __restrict__ bitmap,
-                                                                          const uint8_t* __restrict__ rerun) {
+                                                                          gcomb g16r, widekeys wk, uint8_t* __restrict__ bitmap) {
     const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
-    if (rerun && !rerun[i >> 6]) return;          // second pass of the wide split: only the wavefronts the wide kernel left
     // the tail lanes of the last wavefront replay tuple n - 1 (their verdicts are dropped): every lane of a wavefront takes part in
     // the wave-uniform choice between the wide and the 8-bit combs inside verify29_lane_keyed
     const size_t ii = i < n ? i : n - 1;
     const bool accept = verify29_lane_keyed(s, ii, slots[ii], nkeys, ktab, kvalid, g16r, wk) && i < n;
-    finish_wave(accept, i, n, bitmap);
-}
-
-// The same for wavefronts whose signatures ALL belong to widened slots (sbv_p256_widen_keys: the consenters), and nothing else:
-// two loops over combs of the same shape (13 windows of G, 16-17 of the key), no 8-bit loop in the kernel — it fits 3 waves per
-// SIMD like the G phase of the grouped step, which matters because every addition's table entry is a 64-byte gather from tables
-// far larger than any cache (436 MB of G, 35.7 MB per key).  A wavefront with a lane outside the wide set writes rerun = 1 and
-// leaves; k_p256_verify_keyed then runs over exactly those.
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 3) void k_p256_verify_keyed_wide(Scratch s, size_t n, const u32* __restrict__ slots,
-                                                                               u32 nkeys, const uint8_t* __restrict__ kvalid,
-                                                                               gcomb g16r, widekeys wk, uint8_t* __restrict__ bitmap,
-                                                                               uint8_t* __restrict__ rerun) {
-    const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
-    const size_t ii = i < n ? i : n - 1;
-    u32 slot = slots[ii];
-    const bool in_range = slot < nkeys;
-    if (!in_range) slot = 0;
-    const u32 widx = widekeys_index(wk, slot);
-    const bool wide = wave_all(widx != SBV_WIDE_NONE);
-    if ((threadIdx.x & 63) == 0) rerun[i >> 6] = wide ? 0 : 1;
-    if (!wide) return;
-    u256 r, u1, u2;
-    soa_load(u1, s.u1, s.cap, ii);
-    soa_load(u2, s.u2, s.cap, ii);
-    xyzz R;
-    gphase29_point(R, u1, g16r);
-    wide_qphase29_point(R, u2, wk, widx);
-    soa_load(r, s.r, s.cap, ii);
-    const bool accept = i < n && s.ok[ii] != 0 && in_range && kvalid[slot] != 0 && pt29_rx_matches(R, r);
     finish_wave(accept, i, n, bitmap);
 }
 
@@ -416,12 +388,6 @@ static size_t coop_max_batch() {
     return v;
 }
 
-// SBV_KEYED_WIDE_SPLIT=0: one kernel decides per wavefront between the wide and the 8-bit combs (2 waves per SIMD)
-static bool wide_split() {
-    static const bool v = [] { const char* e = getenv("SBV_KEYED_WIDE_SPLIT"); return !e || e[0] != '0'; }();
-    return v;
-}
-
 hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slots, u32 nkeys, const apt* d_ktab,
                                     const uint8_t* d_kvalid, const gcomb& d_gtab, const widekeys& wk, uint8_t* d_bitmap, uint8_t* d_rerun,
                                     hipStream_t stream) {
@@ -433,13 +399,8 @@ hipError_t launch_p256_verify_keyed(const Scratch& s, size_t n, const u32* d_slo
         return hipGetLastError();
     }
     const unsigned grid = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
-    if (wk.idx && d_rerun && wide_split()) {        // some slots are wide: their wavefronts first (3 waves per SIMD), then whatever is left
-        hipLaunchKernelGGL(k_p256_verify_keyed_wide, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_kvalid, d_gtab, wk, d_bitmap, d_rerun);
-        hipLaunchKernelGGL(k_p256_verify_keyed, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab, d_kvalid, d_gtab, widekeys_none(), d_bitmap,
-                           (const uint8_t*)d_rerun);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(k_p256_verify_keyed, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab, d_kvalid, d_gtab, wk, d_bitmap, (const uint8_t*)nullptr);
+    (void)d_rerun;
+    hipLaunchKernelGGL(k_p256_verify_keyed, dim3(grid), dim3(SBV_VERIFY_BLOCK), 0, stream, s, n, d_slots, nkeys, d_ktab, d_kvalid, d_gtab, wk, d_bitmap);
     return hipGetLastError();
 }
 

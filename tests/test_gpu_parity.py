@@ -287,8 +287,13 @@ def test_wide_combs_of_consenter_keys_on_gpu(gpu, oracle, golden_vectors):
         reg = gpu.register_keys(keys)
         assert gpu.wide_key_stats()[0] == 0                      # registering alone builds no wide comb
         check("8-bit combs only")
-        seeded = reg[-6:]
-        odd = [reg[0]] + reg[1:len(keys) - 6:7]                  # the forged key and every 7th golden key (valid and invalid ones)
+        slot_of = dict(zip(keys, reg))
+        from collections import Counter
+        often = Counter(tup.raw[160 * i + 96:160 * i + 160] for i in range(n))
+        seeded = [slot_of[k] for k, c in often.items() if c >= 64]          # the 6 signers (corrupted keys appear once each)
+        assert len(seeded) == 6
+        gkeys = list(dict.fromkeys(blob[160 * i + 96:160 * i + 160] for i in range(len(vs))))
+        odd = [reg[0]] + [slot_of[k] for k in gkeys[::7]]        # the forged key and every 7th golden key (valid and invalid ones)
         gpu.widen_keys(seeded + odd)
         wide, bits, cap, kib = gpu.wide_key_stats()
         assert wide == len(set(seeded + odd)) and bits == 16 and cap == 64 and kib == 17 * 32768 * 64 // 1024
