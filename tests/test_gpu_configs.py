@@ -126,8 +126,22 @@ def test_config3_550000_consenter_signatures_and_quorum(gpu, oracle, openssl_che
     rsh = b"".join(raw[160 * i:160 * i + 96] for i in range(n))
     slots = [slot_of.get(raw[160 * i + 96:160 * i + 160], 0xFFFFFFFF) for i in range(n)]
     keyed = gpu.verify_batch_keyed(rsh, slots, n)
-    gpu.clear_keys()
     assert keyed == got, _diff(keyed, got)          # a corrupted key is rejected by either form
+    # ... and with the consenters' wide combs (sbv_p256_widen_keys, round 4: 13 + 16 additions), which is what a Verifier that
+    # registered its consenters runs; then 11 of the 16 only: wavefronts of wide and of 8-bit slots side by side
+    try:
+        gpu.wide_keys(16, 64)
+        gpu.widen_keys(list(slot_of.values()))
+        assert gpu.wide_key_stats()[0] == 16
+        wide = gpu.verify_batch_keyed(rsh, slots, n)
+        assert wide == got, _diff(wide, got)
+        gpu.wide_keys(16, 11)
+        assert gpu.wide_key_stats()[0] == 11
+        some = gpu.verify_batch_keyed(rsh, slots, n)
+        assert some == got, _diff(some, got)
+    finally:
+        gpu.wide_keys(16, 64)
+        gpu.clear_keys()
     bits = sbv.bitmap_to_list(got, n)
     want = sbv.bitmap_to_list(a, n)
     decided_gpu = sum(1 for p in range(P) if sum(bits[p * Q:(p + 1) * Q]) >= Q - 1)

@@ -26,7 +26,11 @@ def test_sign_then_verify_through_the_gpu(lib):
         s = lib.sbvh_signer_new(7, hashlib.sha256(b"gpu-node").digest())
         q = ctypes.create_string_buffer(64)
         lib.sbvh_signer_public_key(s, q)
+        import consensus_amd as sbv
+        before = sbv.wide_key_stats()[0]
         lib.sbvh_register_consenter(v, 7, q.raw)
+        # RegisterConsenter hands the key to the device AND widens it (sbv_p256_widen_keys): consenters sign every vote of the epoch
+        assert sbv.wide_key_stats()[0] in (before, before + 1) and sbv.wide_key_stats()[0] >= 1
         out = ctypes.create_string_buffer(80)
         msg = b"raw view data"
         n = lib.sbvh_sign(s, msg, len(msg), out, 80)
