@@ -11,7 +11,8 @@
 //   ed_keytab_bases     per grouped key: decompress, negate, 2^(8j) * (-A), j = 0..31 (extended coordinates)
 //   ed_keytab_window    per (key, window, part): the affine-Niels multiples, Montgomery-trick normalised
 //   ed_gphase           [S]B for every tuple + the S < L, k < L checks
-//   ed_qphase           += [k](-A) from the key's comb, windows [j0, j1); the last chunk encodes and compares
+//   ed_qphase           += [k](-A) from the key's comb, windows [j0, j1); the last chunk marks the tuples still pending
+//   ed_finish           encode(R) == R_enc for the pending tuples, one inversion per 8 tuples
 //
 // Shared host/device source (tests/emul runs the same functions sequentially).
 #pragma once
@@ -199,8 +200,8 @@ SBV_HD void ed_gphase_lane(const uint8_t* tuples, size_t i, const aniels* btab, 
     else ed_gacc_store(gacc, cap, i, R);
 }
 
-// R (from gacc) += windows [j0, j1) of [k](-A) from the key's comb.  `last` -> the verdict is returned; otherwise
-// R goes back to gacc and the return value is meaningless.
+// R (from gacc) += windows [j0, j1) of [k](-A) from the key's comb; R goes back to gacc.  `last` -> the return value is the
+// tuple's pending flag (see ed_finish_lane); otherwise it is meaningless.
 SBV_HD bool ed_qphase_lane(const uint8_t* tuples, size_t i, u32 slot, u32 nkeys, const aniels* ktab, const uint8_t* kvalid,
                            u32* gacc, size_t cap, const uint8_t* okb, int j0, int j1, bool last, bool tuple_major = false) {
     const u32* w = ed_tuple_words(tuples, i);
@@ -230,15 +231,71 @@ SBV_HD bool ed_qphase_lane(const uint8_t* tuples, size_t i, u32 slot, u32 nkeys,
         ed_add_aniels(R, e, d < 0, d == 0);
         cur = nxt; d = dn;
     }
-    if (!last) {
-        if (tuple_major) ed_gacc_store_tm(gacc, i, R);
-        else ed_gacc_store(gacc, cap, i, R);
-        return false;
-    }
-    u32 renc[8];
+    // Every chunk parks R; after the last one the return value says whether the tuple is still a candidate (range checks passed,
+    // its key is a point): the encoding comparison — one field inversion per tuple if done here, a third of the lane's whole
+    // instruction count — is left to ed_finish_lane, which shares one inversion among SBV_ED_FINISH_T tuples.
+    if (tuple_major) ed_gacc_store_tm(gacc, i, R);
+    else ed_gacc_store(gacc, cap, i, R);
+    return last && ok;
+}
+
+// ---- finish: encode(R) == R_enc for every pending tuple, ONE inversion per SBV_ED_FINISH_T tuples (Montgomery's trick) --------
+// crypto/ed25519.Verify compares encodings byte for byte, and the encoding needs x = X/Z, y = Y/Z.  Done per lane at the end of
+// the Q phase the inversion (division steps, ~30 000 wave instructions with the lanes' divergent step counts) ran in all 16 384
+// wavefronts of a 2^20 batch; here a lane takes T consecutive tuples, multiplies the Z of the pending ones together (the running
+// prefix parks in the T slot of the tuple's accumulator record, which nobody needs any more), inverts the product once and walks
+// back: 5 multiplications per tuple and 1/T of an inversion.  acc[i] == SBV_ED_PENDING marks a pending tuple (written by the last Q
+// chunk); it becomes the verdict.  Z of a pending tuple is never 0 (complete addition law on valid points); a zero is rejected
+// on its own anyway so that it cannot poison its neighbours' product.
+#define SBV_ED_FINISH_T 8
+#define SBV_ED_PENDING 2
+SBV_HD void ed_gacc_load_fe(fe25& r, const u32* gacc, size_t cap, size_t i, int coord, bool tuple_major) {
     SBV_UNROLL
-    for (int j = 0; j < 8; ++j) renc[j] = w[j];
-    return ok && ed_encoding_matches(R, renc);
+    for (int l = 0; l < 10; ++l) r.v[l] = (i32)(tuple_major ? gacc[i * SBV_ED_GACC_WORDS + 10 * coord + l] : gacc[(size_t)(10 * coord + l) * cap + i]);
+}
+SBV_HD void ed_gacc_store_fe(u32* gacc, size_t cap, size_t i, int coord, bool tuple_major, const fe25& a) {
+    SBV_UNROLL
+    for (int l = 0; l < 10; ++l) {
+        if (tuple_major) gacc[i * SBV_ED_GACC_WORDS + 10 * coord + l] = (u32)a.v[l];
+        else gacc[(size_t)(10 * coord + l) * cap + i] = (u32)a.v[l];
+    }
+}
+SBV_HD void ed_finish_lane(const uint8_t* tuples, size_t n, size_t i0, u32* gacc, size_t cap, uint8_t* acc, bool tuple_major) {
+    fe25 prod = fe25_one();
+    SBV_NOUNROLL
+    for (int j = 0; j < SBV_ED_FINISH_T; ++j) {
+        const size_t i = i0 + (size_t)j;
+        if (i >= n || acc[i] != SBV_ED_PENDING) continue;
+        fe25 Z;
+        ed_gacc_load_fe(Z, gacc, cap, i, 2, tuple_major);
+        if (fe25_is_zero(Z)) { acc[i] = 0; continue; }
+        ed_gacc_store_fe(gacc, cap, i, 3, tuple_major, prod);      // product of the pending Z before this one
+        fe25_mul(prod, Z, prod);
+    }
+    fe25 inv;
+    fe25_inv_gcd(inv, prod);
+    SBV_NOUNROLL
+    for (int j = SBV_ED_FINISH_T - 1; j >= 0; --j) {
+        const size_t i = i0 + (size_t)j;
+        if (i >= n || acc[i] != SBV_ED_PENDING) continue;
+        fe25 Z, pre, X, Y, zi, x, y;
+        ed_gacc_load_fe(Z, gacc, cap, i, 2, tuple_major);
+        ed_gacc_load_fe(pre, gacc, cap, i, 3, tuple_major);
+        ed_gacc_load_fe(X, gacc, cap, i, 0, tuple_major);
+        ed_gacc_load_fe(Y, gacc, cap, i, 1, tuple_major);
+        fe25_mul(zi, pre, inv);                                     // 1 / Z_i
+        fe25_mul(inv, Z, inv);
+        fe25_mul(x, X, zi);
+        fe25_mul(y, Y, zi);
+        u256 yw;
+        fe25_freeze(yw, y);
+        yw.v[7] |= (fe25_is_negative(x) ? 1u : 0u) << 31;
+        const u32* w = ed_tuple_words(tuples, i);
+        u32 diff = 0;
+        SBV_UNROLL
+        for (int k = 0; k < 8; ++k) diff |= yw.v[k] ^ w[k];
+        acc[i] = diff == 0 ? 1 : 0;
+    }
 }
 
 // tuple words straight from HBM (the ungrouped list is sparse: no LDS staging)

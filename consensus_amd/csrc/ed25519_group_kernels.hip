@@ -93,7 +93,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_qph
         const u32 t = g.grp_idx[L];
         const u32 grp = g.grp_of[L];
         const bool v = ed_qphase_lane(tuples, t, grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE, table_slots, ktab, kvalid, gacc, cap, okb, j0, j1, last != 0, true);
-        if (last) acc[t] = v ? 1 : 0;
+        if (last) acc[t] = v ? SBV_ED_PENDING : 0;
         return;
     }
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
@@ -101,7 +101,15 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_qph
     const u32 t = g.grp_idx[L];
     const u32 grp = g.slots[t];
     const bool v = ed_qphase_lane(tuples, t, grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE, table_slots, ktab, kvalid, gacc, cap, okb, j0, j1, last != 0);
-    if (last) acc[t] = v ? 1 : 0;
+    if (last) acc[t] = v ? SBV_ED_PENDING : 0;
+}
+
+// encode(R) == R_enc for the tuples the last Q chunk left pending: a lane takes SBV_ED_FINISH_T consecutive tuples and ONE
+// inversion (ed25519_group.h: ed_finish_lane).  Few registers, 2^20 / 8 lanes: every wavefront of it is resident at once.
+__global__ __launch_bounds__(256) void k_ed_finish(const uint8_t* __restrict__ tuples, size_t n, u32* __restrict__ gacc, size_t cap,
+                                                   uint8_t* __restrict__ acc, int tuple_major) {
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * SBV_ED_FINISH_T;
+    if (i0 < n) ed_finish_lane(tuples, n, i0, gacc, cap, acc, tuple_major != 0);
 }
 
 hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, const GroupBuffers& b, const EdGroupBuffers& eb,
@@ -128,6 +136,7 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     SBV_TRY(hipMemsetAsync(b.cnt, 0, n * sizeof(u32), y.side_a));
     SBV_TRY(hipMemsetAsync(b.counters, 0, SBV_GROUP_COUNTERS * sizeof(u32), y.side_a));
     if (g.sorted) SBV_TRY(hipMemsetAsync(b.gcount, 0, (size_t)b.max_groups * sizeof(u32), y.side_a));
+    SBV_TRY(hipMemsetAsync(b.acc, 0, n, y.side_a));      // no stale "pending" marker can survive a batch that was cut short
     const unsigned gn = (unsigned)((n + 255) / 256);
     const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
     hipLaunchKernelGGL(k_ed_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
@@ -167,6 +176,10 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
         hipLaunchKernelGGL(k_ed_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.tslot, table_slots, b.gacc, b.gacc_cap,
                            eb.okb, b.acc, j_first, j_end, c + 1 == chunks ? 1 : 0);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
+    }
+    {   // the pending tuples' encodings: one inversion per SBV_ED_FINISH_T tuples
+        const size_t fl = (n + SBV_ED_FINISH_T - 1) / SBV_ED_FINISH_T;
+        hipLaunchKernelGGL(k_ed_finish, dim3((unsigned)((fl + 255) / 256)), dim3(256), 0, stream, d_tuples, n, b.gacc, b.gacc_cap, b.acc, (int)g.sorted);
     }
     // side_a, behind the last bases: the ungrouped list
     SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_split, 0));

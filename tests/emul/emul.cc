@@ -634,8 +634,16 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
             const u32 grp = g.sorted ? grp_of[L] : slots[t];
             const bool v = grp < ngroups ? ed_qphase_lane(tuples, t, 0, 1, table_of(grp), valid_of(grp), gacc, cap, okb.data(), j_first, j_end, last, tm)
                                          : ed_qphase_lane(tuples, t, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc, cap, okb.data(), j_first, j_end, last, tm);
-            if (last && v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+            if (last) accb[t] = v ? SBV_ED_PENDING : 0;
         }
+    }
+    // k_ed_finish: the pending tuples' encodings, one inversion per SBV_ED_FINISH_T consecutive tuples
+    for (u32 L = 0; L < counters[2]; ++L) accb[ung_idx[L]] = 0;         // the ungrouped list's verdicts come from the one-lane kernel below
+    for (size_t i0 = 0; i0 < n; i0 += SBV_ED_FINISH_T) ed_finish_lane(tuples, n, i0, gacc, cap, accb.data(), tm);
+    for (u32 L = 0; L < counters[1]; ++L) {
+        const u32 t = grp_idx[L];
+        if (accb[t] == 1) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+        else if (accb[t] != 0) ++g_sort_violations;                      // a marker the finish pass left behind
     }
     u32* qtab = (u32*)aligned_alloc(16, SBV_ED_QTAB_ENTRIES * SBV_ED_PT_WORDS * 4);
     for (u32 L = 0; L < counters[2]; ++L) {

@@ -14,7 +14,7 @@ import collections, re, sys, os
 tmp = sys.argv[1]
 want = {"p256_group_kernels": ["k_verify_keyed_q", "k_gphase_generic", "k_gphase_sorted", "k_keytab29_chain", "k_keytab29_rows", "k_keytab29_fill", "k_keytab29_entries", "k_keytab29_fill_parts", "k_keytab29_fill_sym", "k_group_coop", "k_group_sort_count", "k_group_sort_scan",
                                "k_group_sort_scatter", "k_group_classify", "k_group_keycheck"],
-        "ed25519_group_kernels": ["k_ed_qphase", "k_ed_gphase"], "k256_kernels": ["k_k256_verify", "k_k256_prep"],
+        "ed25519_group_kernels": ["k_ed_qphase", "k_ed_gphase", "k_ed_finish"], "k256_kernels": ["k_k256_verify", "k_k256_prep"],
         "p256_kernels": ["k_p256_prep", "k_p256_verify", "k_p256_verify_keyed", "k_p256_verify_keyed_coop", "k_p256_verify_prepared_small"]}
 print("# static ISA statistics of the hot kernels (hipcc --offload-arch=gfx950 -O3), sources as committed; tools/isa_stats.sh")
 for f, kernels in want.items():
