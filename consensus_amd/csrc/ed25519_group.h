@@ -54,12 +54,28 @@ SBV_HD bool ed_group_split_lane(size_t i, const GroupState& g) {
     return true;
 }
 
-// key-sorted step: classification only; the ungrouped list is built directly (no key check on this curve, see above), the
-// grouped one by the counting sort of p256_group.h
+// key-sorted step, pass 1: classification only.  The ungrouped tuples become CANDIDATES (ung_cand, counters[4]); the grouped list
+// is built by the counting sort of p256_group.h.
 SBV_HD void ed_group_classify_lane(size_t i, const GroupState& g) {
     const u32 s = g.slot_of[g.rep[i]];
     g.slots[i] = s;
-    if (s == SBV_GROUP_NONE) g.ung_idx[SBV_ATOMIC_ADD(&g.counters[2], 1u)] = (u32)i;
+    if (s == SBV_GROUP_NONE) g.ung_cand[SBV_ATOMIC_ADD(&g.counters[4], 1u)] = (u32)i;
+}
+// pass 2, over the compacted candidates only (round 4; the P-256 step's k_group_keycheck on this curve): a candidate whose key does
+// not decompress is rejected here, the others form the ungrouped list of the one-lane kernel.  About half of all 32-byte strings are
+// no points, and an ungrouped tuple is nearly always one whose key a bit flip hit: without this pass every wavefront of the one-lane
+// kernel (a ~460 000-instruction chain) ran to its end for the half of its lanes that had left after the square root.  The check
+// costs that square root once more (~20 000 instructions) on 4 % of the batch's lanes; in ONE pass over all tuples it cost as much
+// as the whole [S]B phase (see ed_group_split_lane), which is why it waited for the compaction.
+SBV_HD void ed_group_keycheck_lane(const uint8_t* tuples, u32 L, const GroupState& g, uint8_t* acc) {
+    const u32 i = g.ung_cand[L];
+    ept A;
+    if (ed_tuple_key_load(tuples, i, A)) {
+        g.ung_idx[SBV_ATOMIC_ADD(&g.counters[2], 1u)] = i;
+    } else {
+        acc[i] = 0;
+        SBV_ATOMIC_ADD(&g.counters[3], 1u);
+    }
 }
 
 SBV_HD void ept_store(u32* dst, const ept& p) {

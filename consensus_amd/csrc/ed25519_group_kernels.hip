@@ -70,6 +70,26 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_gen
     acc[t] = ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab + (size_t)L * (SBV_ED_QTAB_ENTRIES * SBV_ED_PT_WORDS), btab) ? 1 : 0;
 }
 
+// key-sorted step, pass 2: the ungrouped candidates whose key is a point -> ung_idx (ed25519_group.h: ed_group_keycheck_lane)
+__global__ __launch_bounds__(256) void k_ed_keycheck(const uint8_t* __restrict__ tuples, GroupState g, uint8_t* __restrict__ acc) {
+    const u32 L = blockIdx.x * 256 + threadIdx.x;
+    const u32 cands = g.counters[4];
+    if (blockIdx.x * 256u >= cands) return;            // whole workgroup idle (uniform: the barriers below are not reached by anyone)
+    const bool active = L < cands;
+    u32 i = 0;
+    bool ok = false;
+    if (active) {
+        i = g.ung_cand[L];
+        ept A;
+        ok = ed_tuple_key_load(tuples, i, A);
+        if (!ok) acc[i] = 0;
+    }
+    const unsigned long long mr = __ballot(active && !ok);
+    if ((threadIdx.x & 63) == 0 && mr) atomicAdd(&g.counters[3], (u32)__popcll(mr));
+    const u32 pos = group_compact_pos(active && ok, &g.counters[2]);
+    if (active && ok) g.ung_idx[pos] = i;
+}
+
 // [S]B for every tuple of the batch
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_gphase(const uint8_t* __restrict__ tuples, size_t n, const aniels* __restrict__ btab,
                                                                   u32* __restrict__ gacc, size_t cap, uint8_t* __restrict__ okb, int tuple_major) {
@@ -120,7 +140,7 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
     g.counters = b.counters; g.grp_idx = b.grp_idx; g.ung_idx = b.ung_idx; g.slots = b.slots;
     g.max_groups = b.max_groups;
-    g.gcount = b.gcount; g.gcursor = b.gcount ? b.gcount + b.max_groups : nullptr; g.grp_of = b.grp_of; g.ung_cand = nullptr;
+    g.gcount = b.gcount; g.gcursor = b.gcount ? b.gcount + b.max_groups : nullptr; g.grp_of = b.grp_of; g.ung_cand = b.ung_cand;
     // key-sorted grouped list (p256_group.h): the Q phase walks runs of equal keys; the accumulator is tuple-major so that the
     // G phase can still start at once, in tuple order
     const size_t sort_lds = (size_t)b.max_groups * sizeof(u32);
@@ -148,7 +168,8 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
     if (g.sorted) {
         const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
-        hipLaunchKernelGGL(k_group_classify, dim3(gn), dim3(256), 0, y.side_b, n, g, b.ung_idx, b.counters + 2);
+        hipLaunchKernelGGL(k_group_classify, dim3(gn), dim3(256), 0, y.side_b, n, g, b.ung_cand, b.counters + 4);
+        hipLaunchKernelGGL(k_ed_keycheck, dim3(gn), dim3(256), 0, y.side_b, d_tuples, g, b.acc);
         hipLaunchKernelGGL(k_group_sort_count, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
         hipLaunchKernelGGL(k_group_sort_scan, dim3(1), dim3(1024), 0, y.side_b, g);
         hipLaunchKernelGGL(k_group_sort_scatter, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);

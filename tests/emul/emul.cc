@@ -578,9 +578,9 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     uint8_t* tuples = (uint8_t*)aligned_alloc(16, cap * 128);           // the kernels read 16-byte vectors
     memcpy(tuples, tuples_in, n * 128);
     std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(max_groups ? max_groups : 1), counters(SBV_GROUP_COUNTERS, 0),
-        grp_idx(cap, 0xFFFFFFFFu), ung_idx(cap), slots(cap), gcount(2 * (size_t)(max_groups ? max_groups : 1), 0), grp_of(cap, 0xFFFFFFFFu);
+        grp_idx(cap, 0xFFFFFFFFu), ung_idx(cap), ung_cand(cap), slots(cap), gcount(2 * (size_t)(max_groups ? max_groups : 1), 0), grp_of(cap, 0xFFFFFFFFu);
     GroupState g{};
-    g.gcount = gcount.data(); g.gcursor = gcount.data() + (max_groups ? max_groups : 1); g.grp_of = grp_of.data(); g.sorted = (u32)g_group_sort;
+    g.gcount = gcount.data(); g.gcursor = gcount.data() + (max_groups ? max_groups : 1); g.grp_of = grp_of.data(); g.ung_cand = ung_cand.data(); g.sorted = (u32)g_group_sort;
     g.ht = ht.data(); g.ht_mask = (u32)(((size_t)1 << ht_bits) - 1); g.rep = rep.data(); g.cnt = cnt.data(); g.slot_of = slot_of.data();
     g.group_rep = group_rep.data(); g.counters = counters.data(); g.grp_idx = grp_idx.data(); g.ung_idx = ung_idx.data();
     g.slots = slots.data(); g.max_groups = max_groups;
@@ -592,6 +592,7 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     const u32 ngroups = counters[0] < max_groups ? counters[0] : max_groups;
     if (g.sorted) {                      // key-sorted list: classify, then the counting sort of p256_group.h (scatter walked backwards)
         for (size_t i = 0; i < n; ++i) ed_group_classify_lane(i, g);
+        for (u32 L = 0; L < counters[4]; ++L) ed_group_keycheck_lane(tuples, L, g, accb.data());     // k_ed_keycheck: candidates whose key is no point leave here
         for (size_t i = 0; i < n; ++i) group_sort_count_lane(i, g);
         group_sort_scan_seq(g, ngroups);
         for (size_t i = n; i-- > 0;) group_sort_scatter_lane(i, g);

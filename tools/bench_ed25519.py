@@ -30,6 +30,8 @@ else:
     tuples = np.zeros(n * 128, dtype=np.uint8); expect = np.zeros((n + 7) // 8, dtype=np.uint8)
     h.sbvh_ed25519_gen_batch(0x5B7F2026, n, 1024, 8, tuples.ctypes.data, expect.ctypes.data, os.cpu_count() or 1)
     np.savez(cache, tuples=tuples, expect=expect)
+if os.environ.get("SBV_ED_COLD"):        # every step builds every comb (the headline convention); default: the scheme's key-table cache stays on
+    sbv.key_cache(False, 0, sbv.SCHEME_ED25519)
 d_t = torch.from_numpy(tuples).cuda()
 d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
 stream = torch.cuda.current_stream()

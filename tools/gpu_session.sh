@@ -101,7 +101,23 @@ PY
     trace)          # trace:<script>[:args...]  rocprofv3 --kernel-trace --stats of python tools/<script>: per-kernel durations
       name=$(basename "${a1%.py}")
       ( cd /tmp; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/tr_$name" -o p -- python "$ROOT/tools/$a1" $(echo "${a2:-}:${rest:-}" | tr ':' ' ') > "$OUT/trace_$name.log" 2>&1; echo "rc=$?" >> "$OUT/trace_$name.log" )
-      cp "$OUT/tr_$name/p_kernel_stats.csv" "$OUT/kernel_stats_$name.csv" 2>/dev/null; rm -rf "$OUT/tr_$name"
+      cp "$OUT/tr_$name/p_kernel_stats.csv" "$OUT/kernel_stats_$name.csv" 2>/dev/null
+      python3 - "$OUT/tr_$name/p_kernel_trace.csv" "$OUT/timeline_$name.txt" <<'PY'
+import csv, sys
+try:
+    rows = [r for r in csv.DictReader(open(sys.argv[1])) if "sbv::" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    last = max(i for i, r in enumerate(rows) if "group_insert" in r["Kernel_Name"] or "k_p256_prep" in r["Kernel_Name"] or "k_k256_prep" in r["Kernel_Name"])
+    firsts = [i for i, r in enumerate(rows) if "group_insert" in r["Kernel_Name"]]
+    start = firsts[-1] if firsts else last
+    t0 = int(rows[start]["Start_Timestamp"])
+    with open(sys.argv[2], "w") as f:
+        for r in rows[start:]:
+            f.write("%-28s start %8.3f ms  end %8.3f ms\n" % (r["Kernel_Name"].split("(")[0].replace("sbv::", "").replace("void ", ""), (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6))
+except Exception as e:
+    print("no timeline", e)
+PY
+      rm -rf "$OUT/tr_$name"
       python3 - "$OUT/kernel_stats_$name.csv" <<'PY'
 import csv, sys
 try:
