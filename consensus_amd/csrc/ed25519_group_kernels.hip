@@ -169,7 +169,6 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     if (g.sorted) {
         const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
         hipLaunchKernelGGL(k_group_classify, dim3(gn), dim3(256), 0, y.side_b, n, g, b.ung_cand, b.counters + 4);
-        hipLaunchKernelGGL(k_ed_keycheck, dim3(gn), dim3(256), 0, y.side_b, d_tuples, g, b.acc);
         hipLaunchKernelGGL(k_group_sort_count, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
         hipLaunchKernelGGL(k_group_sort_scan, dim3(1), dim3(1024), 0, y.side_b, g);
         hipLaunchKernelGGL(k_group_sort_scatter, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
@@ -204,6 +203,9 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     }
     // side_a, behind the last bases: the ungrouped list
     SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_split, 0));
+    // the candidates whose key is a point -> ung_idx, right in front of the kernel that needs it: on side_b before the sort it held
+    // up the first table windows (4.33 ms per cold 2^20 step against 4.08 here; without any key check 4.52: profiles/r04/ab_ed_keycheck_r04n.jsonl)
+    if (g.sorted) hipLaunchKernelGGL(k_ed_keycheck, dim3(gn), dim3(256), 0, y.side_a, d_tuples, g, b.acc);
     hipLaunchKernelGGL(k_ed_generic_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, d_tuples, g, d_qtab, d_btab, b.acc);
     SBV_TRY(hipEventRecord(y.ev_generic, y.side_a));
     SBV_TRY(hipStreamWaitEvent(stream, y.ev_generic, 0));
