@@ -146,6 +146,8 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     const size_t sort_lds = (size_t)b.max_groups * sizeof(u32);
     g.sorted = y.sorted && b.gcount && b.grp_of && sort_lds <= 64 * 1024 ? 1u : 0u;
     group_set_threshold(g, b.min_count);
+    // 2 chunks (the context's setting) also after the finish left the Q phase: 3 / 4 chunks 4.41-4.51 / 4.36-4.45 ms against 4.19-4.33 per cold 2^20
+    // step, 3.33-3.35 / 3.38-3.42 against 3.20-3.23 warm (profiles/r04/ab_ed_chunks_r04o.jsonl)
     const int chunks = y.chunks < 1 ? 1 : (y.chunks > SBV_GROUP_MAX_CHUNKS ? SBV_GROUP_MAX_CHUNKS : y.chunks);
     const int parts = SBV_KEYTAB_PARTS_DEFAULT;     // lanes per (key, window) of the table kernel (2 / 4 / 8 / 16 measured in round 2)
     hipError_t e;
