@@ -177,6 +177,16 @@ def widen_keys(slots) -> None:
     _check(lib.sbv_p256_widen_keys(arr, len(slots)))
 
 
+def wide_selfcheck(slot: int) -> bool:
+    """sbv_p256_wide_selfcheck: the device-built wide comb of `slot` equals the host builder's output byte for byte."""
+    lib = load()
+    lib.sbv_p256_wide_selfcheck.argtypes = [ctypes.c_uint32]
+    rc = lib.sbv_p256_wide_selfcheck(slot)
+    if rc < 0:
+        _check(rc)
+    return rc == 1
+
+
 def wide_key_stats():
     """(slots holding a wide comb, bits, max_keys, KiB per key)"""
     out = (ctypes.c_uint32 * 4)()

@@ -666,6 +666,30 @@ inline void comb_bases(const u256& px, const u256& py, int wbits, int windows, a
         fe_mul(base.y, nb.Y, zi3);
     }
 }
+// The two base points per window the device-side builder of a wide comb starts from (p256_widetab29.h):
+// B[j] = 2^(wbits*j) * P and C[j] = 2^hb * B[j], affine.
+inline void comb_bases_bc(const u256& px, const u256& py, int wbits, int hb, int windows, apt* B, apt* C) {
+    apt base;
+    fe_to_mont(base.x, px);
+    fe_to_mont(base.y, py);
+    auto to_affine = [](apt& out, const jpt& p) {
+        fe zi, zi2, zi3;
+        fe_inv(zi, p.Z);
+        fe_sqr(zi2, zi);
+        fe_mul(zi3, zi2, zi);
+        fe_mul(out.x, p.X, zi2);
+        fe_mul(out.y, p.Y, zi3);
+    };
+    for (int j = 0; j < windows; ++j) {
+        B[j] = base;
+        jpt nb;
+        nb.X = base.x; nb.Y = base.y; nb.Z = fe_one();
+        for (int i = 0; i < hb; ++i) pt_dbl(nb, nb);
+        to_affine(C[j], nb);
+        for (int i = hb; i < wbits; ++i) pt_dbl(nb, nb);
+        to_affine(base, nb);
+    }
+}
 inline void build_comb_table(const u256& px, const u256& py, apt* out) {
     apt bases[SBV_GTAB_WINDOWS];
     comb_bases(px, py, 8, SBV_GTAB_WINDOWS, bases);

@@ -5,6 +5,7 @@
 #include "p256_core.h"
 #include "p256_comb29.h"
 #include "p256_group.h"
+#include "p256_widetab29.h"
 
 #define SBV_TUPLE_BYTES 160
 #define SBV_VERIFY_BLOCK 256
@@ -33,6 +34,11 @@ hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const u
 bool host_build_key_table(const uint8_t q[64], apt* out);
 // `bits`-wide comb of a registered key (p256_comb29.h: widekeys), gcomb_entries(bits) entries, R = 2^261 domain
 bool host_build_wide_key_table(const uint8_t q[64], int bits, apt* out, int threads);
+// the same comb built on the device (p256_widetab29.h): host_wide_bases gives a key's 2 * windows base points, launch_widetab_build
+// fills the combs of `nkeys` keys (d_widx[k] = index of key k's comb in d_tab); scratch words: widetab_tmp_words(nkeys, bits)
+bool host_wide_bases(const uint8_t q[64], int bits, apt* out);
+size_t widetab_tmp_words(u32 nkeys, int bits);
+hipError_t launch_widetab_build(const apt* d_bases, const u32* d_widx, u32 nkeys, int bits, u32* d_tmp, apt* d_tab, hipStream_t stream);
 #define SBV_KEYTAB_ENTRIES (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW)
 // d_rerun: ceil(n/64) bytes of per-wavefront flags (fast pass -> exact pass)
 hipError_t launch_p256_verify(const Scratch& s, size_t n, u32* d_qtab, const gcomb& d_gcomb, uint8_t* d_bitmap, uint8_t* d_rerun,

@@ -26,6 +26,7 @@
 
 #include "p256_core.h"
 #include "p256_kernels.h"
+#include "p256_widetab29.h"
 #include "p256_sign.h"
 #include "p256_comb29.h"
 #include "sha256_dev.h"
@@ -451,6 +452,61 @@ bool host_build_key_table(const uint8_t q[64], apt* out) {
     return true;
 }
 
+
+// ---- wide combs built on the device (p256_widetab29.h) -----------------------------------------------------------------------
+// bases: per key 2 * windows affine points (B_0 .. B_{W-1}, then C_0 .. C_{W-1}), canonical R = 2^261 words; tab: the wide comb
+// pool; widx[k]: index of key k's comb in it.
+__global__ __launch_bounds__(64) void k_widetab_chains(const apt* __restrict__ bases, const u32* __restrict__ widx, u32 nkeys, widebuild w, size_t stride,
+                                                      u32* __restrict__ tmp, apt* __restrict__ tab) {
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 per_key = (u32)w.windows * 2u;
+    if (lane >= nkeys * per_key) return;
+    const u32 k = lane / per_key, j = (lane % per_key) >> 1, role = lane & 1u;
+    const apt* kb = bases + (size_t)k * per_key;
+    widetab_chain_role(w, kb + j, kb + w.windows + j, (int)role, tmp + (size_t)lane * widebuild_chain_len(w) * SBV_WIDETAB_REC_WORDS,
+                       tab + (size_t)widx[k] * stride + (size_t)j * w.per_window);
+}
+__global__ __launch_bounds__(256) void k_widetab_fill(const u32* __restrict__ widx, u32 nkeys, widebuild w, size_t stride, apt* __restrict__ tab) {
+    const size_t lane = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u32 chunks = widebuild_fill_chunks(w);
+    const size_t per_window = (size_t)(w.giants - 1) * chunks;
+    const size_t per_key = per_window * (size_t)w.windows;
+    if (lane >= per_key * nkeys) return;
+    const u32 k = (u32)(lane / per_key);
+    const size_t r = lane % per_key;
+    const u32 j = (u32)(r / per_window);
+    const size_t q = r % per_window;
+    const u32 g = 1u + (u32)(q / chunks), c = (u32)(q % chunks);
+    widetab_fill_lane(w, g, 1u + c * SBV_WIDETAB_T, tab + (size_t)widx[k] * stride + (size_t)j * w.per_window);
+}
+// d_bases / d_widx: device copies for `nkeys` keys; d_tmp: nkeys * windows * 2 * widebuild_chain_len * SBV_WIDETAB_REC_WORDS words
+hipError_t launch_widetab_build(const apt* d_bases, const u32* d_widx, u32 nkeys, int bits, u32* d_tmp, apt* d_tab, hipStream_t stream) {
+    if (nkeys == 0) return hipSuccess;
+    const widebuild w = widebuild_make(bits);
+    const size_t stride = gcomb_entries(bits);
+    const u32 chain_lanes = nkeys * (u32)w.windows * 2u;
+    hipLaunchKernelGGL(k_widetab_chains, dim3((chain_lanes + 63) / 64), dim3(64), 0, stream, d_bases, d_widx, nkeys, w, stride, d_tmp, d_tab);
+    if (w.giants > 1) {
+        const size_t fill_lanes = (size_t)nkeys * w.windows * (w.giants - 1) * widebuild_fill_chunks(w);
+        hipLaunchKernelGGL(k_widetab_fill, dim3((unsigned)((fill_lanes + 255) / 256)), dim3(256), 0, stream, d_widx, nkeys, w, stride, d_tab);
+    }
+    return hipGetLastError();
+}
+size_t widetab_tmp_words(u32 nkeys, int bits) {
+    const widebuild w = widebuild_make(bits);
+    return (size_t)nkeys * w.windows * 2 * widebuild_chain_len(w) * SBV_WIDETAB_REC_WORDS;
+}
+// the host half: the 2 * windows base points of a key (B_j, then C_j), canonical R = 2^261 words; false = not a point of the curve
+bool host_wide_bases(const uint8_t q[64], int bits, apt* out) {
+    u256 x, y;
+    from_be32(x, q);
+    from_be32(y, q + 32);
+    if (!key_is_valid(x, y)) return false;
+    const widebuild w = widebuild_make(bits);
+    comb_bases_bc(x, y, bits, w.hb, w.windows, out, out + w.windows);
+    for (int k = 0; k < 2 * w.windows; ++k) { apt c; apt_to_r261(c, out[k]); out[k] = c; }
+    return true;
+}
 
 // `bits`-wide comb of a registered key (p256_comb29.h: widekeys) for the carry-free kernels: gcomb_entries(bits) entries, window j
 // at out + (j << (bits-1)).  One host thread per window (`threads` > 0 caps them); false = not a point of the curve.

@@ -968,17 +968,60 @@ int widen_slots(Context& c, const std::vector<u32>& slots) {
     }
     std::vector<const std::string*> key_of(c.nkeys, nullptr);
     for (const auto& kv : c.key_index) if (kv.second < key_of.size()) key_of[kv.second] = &kv.first;
-    std::vector<sbv::apt> tab(stride);
+    // Built on the device (p256_widetab29.h): the host computes 2 * windows base points per key (microseconds), two launches fill
+    // the combs of all the keys of this call.  SBV_KEYED_WIDE_HOST=1 keeps the host builder (one thread per window: 0.1 - 1.3 s per key).
+    static const bool host_build = [] { const char* e = getenv("SBV_KEYED_WIDE_HOST"); return e && e[0] == '1'; }();
+    const sbv::widebuild wb = sbv::widebuild_make(c.kwide_bits);
+    std::vector<sbv::apt> bases;
+    std::vector<u32> widx_of, slot_of_build;
+    std::vector<sbv::apt> tab(host_build ? stride : 0);
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 1;
     for (u32 sl : todo) {
         const std::string* k = key_of[sl];
-        if (!k || k->size() != 64 || !sbv::host_build_wide_key_table((const uint8_t*)k->data(), c.kwide_bits, tab.data(), (int)(hw > 32 ? 32 : hw)))
-            memset((void*)tab.data(), 0, stride * sizeof(sbv::apt));     // not a point: kvalid[slot] = 0 rejects its signatures whatever the lanes add
         const u32 w = (u32)c.wide_slots.size();
-        HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_kwide + (size_t)w * stride, tab.data(), stride * sizeof(sbv::apt), hipMemcpyHostToDevice));
-        HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_kwidx + sl, &w, sizeof(u32), hipMemcpyHostToDevice));      // published after its table is complete
+        bool have = false;
+        if (k && k->size() == 64) {
+            if (host_build) {
+                have = sbv::host_build_wide_key_table((const uint8_t*)k->data(), c.kwide_bits, tab.data(), (int)(hw > 32 ? 32 : hw));
+                if (have) HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_kwide + (size_t)w * stride, tab.data(), stride * sizeof(sbv::apt), hipMemcpyHostToDevice));
+            } else {
+                bases.resize(bases.size() + 2 * (size_t)wb.windows);
+                have = sbv::host_wide_bases((const uint8_t*)k->data(), c.kwide_bits, bases.data() + bases.size() - 2 * (size_t)wb.windows);
+                if (have) { widx_of.push_back(w); slot_of_build.push_back(sl); }
+                else bases.resize(bases.size() - 2 * (size_t)wb.windows);
+            }
+        }
+        // not a point: kvalid[slot] = 0 rejects its signatures whatever the lanes add; its comb is zeros
+        if (!have) HIP_TRY(SBV_EDEVICE, hipMemset(c.d_kwide + (size_t)w * stride, 0, stride * sizeof(sbv::apt)));
         c.wide_slots.push_back(sl);
+        if (host_build || !have) HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_kwidx + sl, &w, sizeof(u32), hipMemcpyHostToDevice));      // published after its table is complete
+    }
+    if (!widx_of.empty()) {
+        const u32 nb = (u32)widx_of.size();
+        sbv::apt* d_bases = nullptr;
+        u32* d_w = nullptr;
+        u32* d_tmp = nullptr;
+        int rc = SBV_OK;
+        auto cleanup = [&] { if (d_bases) (void)hipFree(d_bases); if (d_w) (void)hipFree(d_w); if (d_tmp) (void)hipFree(d_tmp); };
+        hipError_t e = hipMalloc(&d_bases, bases.size() * sizeof(sbv::apt));
+        if (e == hipSuccess) e = hipMalloc(&d_w, nb * sizeof(u32));
+        if (e == hipSuccess) e = hipMalloc(&d_tmp, sbv::widetab_tmp_words(nb, c.kwide_bits) * sizeof(u32));
+        if (e != hipSuccess) rc = fail(SBV_ENOMEM, "wide combs: scratch", e);
+        if (rc == SBV_OK) {
+            e = hipMemcpy(d_bases, bases.data(), bases.size() * sizeof(sbv::apt), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_w, widx_of.data(), nb * sizeof(u32), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = sbv::launch_widetab_build(d_bases, d_w, nb, c.kwide_bits, d_tmp, c.d_kwide, c.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
+            if (e != hipSuccess) rc = fail(SBV_EDEVICE, "wide combs: build", e);
+        }
+        if (rc == SBV_OK)        // published after the tables are complete
+            for (u32 i = 0; i < nb && rc == SBV_OK; ++i) {
+                e = hipMemcpy(c.d_kwidx + slot_of_build[i], &widx_of[i], sizeof(u32), hipMemcpyHostToDevice);
+                if (e != hipSuccess) rc = fail(SBV_EDEVICE, "wide combs: publish", e);
+            }
+        cleanup();
+        if (rc != SBV_OK) return rc;     // the slots stay narrow (their index was never published); their combs are unused space
     }
     return SBV_OK;
 }
@@ -1023,6 +1066,28 @@ extern "C" int sbv_p256_widen_keys(const uint32_t* slots, size_t m) {
     if (!slots) { g_err = "null pointer"; return SBV_EINVAL; }
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
     return widen_slots(c, std::vector<u32>(slots, slots + m));
+}
+
+// Diagnostics: is the device-resident wide comb of `slot` byte for byte what the host builder (the kernels' field code on the CPU,
+// one thread per window) produces for that key?  1 = equal, 0 = different, < 0 = error (not widened, device fault).
+extern "C" int sbv_p256_wide_selfcheck(uint32_t slot) {
+    SBV_ENTER(c);
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    size_t w = c.wide_slots.size();
+    for (size_t i = 0; i < c.wide_slots.size(); ++i) if (c.wide_slots[i] == slot) w = i;
+    if (w == c.wide_slots.size()) { g_err = "sbv_p256_wide_selfcheck: the slot has no wide comb"; return SBV_EINVAL; }
+    const std::string* key = nullptr;
+    for (const auto& kv : c.key_index) if (kv.second == slot) key = &kv.first;
+    if (!key) return SBV_EINVAL;
+    const size_t stride = sbv::gcomb_entries(c.kwide_bits);
+    std::vector<sbv::apt> want(stride), got(stride);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (!sbv::host_build_wide_key_table((const uint8_t*)key->data(), c.kwide_bits, want.data(), (int)(hw > 32 ? 32 : (hw ? hw : 1))))
+        memset((void*)want.data(), 0, stride * sizeof(sbv::apt));
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(got.data(), c.d_kwide + w * stride, stride * sizeof(sbv::apt), hipMemcpyDeviceToHost));
+    return memcmp(got.data(), want.data(), stride * sizeof(sbv::apt)) == 0 ? 1 : 0;
 }
 
 extern "C" int sbv_p256_wide_key_stats(uint32_t out[4]) {

@@ -126,8 +126,8 @@ int sbv_p256_clear_keys(void);
  * decision for a whole epoch (pkg/types/types.go:25-29; internal/bft/view.go:531-541 collects 2f+1 of their commit signatures per
  * decision, view.go:631 and :834 verify them; reconfiguration replaces the set: pkg/consensus/consensus.go:185-252), and HBM holds
  * 288 GB: sbv_p256_widen_keys gives the named registered slots a second, `bits`-wide comb (the layout of the comb of G), after
- * which u2*Q is ceil(257 / bits) additions instead of 32.2 — 16 bits: 16 additions, 35.7 MB and ~0.1 s of host time per key;
- * 20 bits: 13 additions, 436 MB and about a second per key.  A wavefront whose signatures all belong to wide slots takes the wide
+ * which u2*Q is ceil(257 / bits) additions instead of 32.2 — 16 bits: 16 additions, 35.7 MB per key; 20 bits: 13 additions,
+ * 436 MB per key.  A wavefront whose signatures all belong to wide slots takes the wide
  * combs, any other the 8-bit combs every key keeps; verdicts are identical.  Slots that are wide already are skipped, slots
  * beyond `max_keys` wide ones stay narrow (no error); an unregistered slot is SBV_EINVAL.
  * sbv_p256_wide_keys sets the width and the cap for every device (defaults: 16 bits, 64 keys; bits = 0 switches the feature off
@@ -136,6 +136,10 @@ int sbv_p256_clear_keys(void);
 int sbv_p256_wide_keys(int bits, uint32_t max_keys);
 int sbv_p256_widen_keys(const uint32_t* slots, size_t m);
 int sbv_p256_wide_key_stats(uint32_t out[4]);
+/* The combs are built on the device (consensus_amd/csrc/p256_widetab29.h: two launches for all the keys of a call, ~2 ms for 16
+ * keys at 16 bits); SBV_KEYED_WIDE_HOST=1 selects the host builder.  Diagnostics: sbv_p256_wide_selfcheck(slot) = 1 when the
+ * device-resident comb of `slot` equals the host builder's output byte for byte, 0 when it differs. */
+int sbv_p256_wide_selfcheck(uint32_t slot);
 /* rsh: n x 96 bytes (r|s|hash, big-endian), slots: n key slots.  Takes over VerifyConsenterSig
  * (view.go:631, 834), VerifySignature (viewchanger.go:598...) and decision replay for registered
  * signers.  An out-of-range slot is a reject, not an error. */

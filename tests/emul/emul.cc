@@ -18,6 +18,7 @@
 #include "../../consensus_amd/csrc/sha512_dev.h"
 #include "../../consensus_amd/csrc/sha256_dev.h"
 #include "../../consensus_amd/csrc/p256_group.h"
+#include "../../consensus_amd/csrc/p256_widetab29.h"
 #include "../../consensus_amd/csrc/p256_pt29.h"
 #include "../../consensus_amd/csrc/p256_keytab29.h"
 #include "../../consensus_amd/csrc/p256_sign.h"
@@ -536,6 +537,43 @@ void sbve_p256_verify_batch_keyed(const uint8_t* rsh, const u32* slots, size_t n
     }
 }
 void sbve_set_keyed_coop(int on) { g_keyed_coop = on != 0; g_keyed_prepared = on == 3; }   // 1: 8 lanes per signature (k_p256_verify_keyed_coop); 3: the one-launch latency form (stage A by the host half, 16 lanes per signature)
+// The device-side builder of a wide comb (p256_widetab29.h: k_widetab_chains + k_widetab_fill), lane by lane, against the host
+// builder (build_comb_window_of + apt_to_r261: what host_build_wide_key_table does).  Returns the number of differing entries
+// (0 = byte for byte equal), or (size_t)-1 when the key is no point.
+size_t sbve_widetab_build_mismatches(const uint8_t* key64, int bits) {
+    u256 x, y;
+    from_be32(x, key64);
+    from_be32(y, key64 + 32);
+    if (!key_is_valid(x, y)) return (size_t)-1;
+    const widebuild w = widebuild_make(bits);
+    const size_t stride = gcomb_entries(bits);
+    std::vector<apt> bases(2 * (size_t)w.windows);
+    comb_bases_bc(x, y, bits, w.hb, w.windows, bases.data(), bases.data() + w.windows);
+    for (auto& b : bases) { apt c; apt_to_r261(c, b); b = c; }
+    std::vector<apt> tab(stride);
+    memset((void*)tab.data(), 0xA5, stride * sizeof(apt));                 // an entry nobody wrote must not look like a point
+    std::vector<u32> tmp((size_t)widebuild_chain_len(w) * SBV_WIDETAB_REC_WORDS);
+    for (int j = 0; j < w.windows; ++j)
+        for (int role = 0; role < 2; ++role)
+            widetab_chain_role(w, &bases[j], &bases[w.windows + j], role, tmp.data(), &tab[(size_t)j * w.per_window]);
+    const u32 chunks = widebuild_fill_chunks(w);
+    for (int j = 0; j < w.windows; ++j)
+        for (u32 g = 1; g < w.giants; ++g)
+            for (u32 c = chunks; c-- > 0;)                                  // any order: lanes are independent
+                widetab_fill_lane(w, g, 1u + c * SBV_WIDETAB_T, &tab[(size_t)j * w.per_window]);
+    std::vector<apt> want(w.per_window);
+    size_t bad = 0;
+    for (int j = 0; j < w.windows; ++j) {
+        build_comb_window_of(x, y, bits, j, want.data());
+        for (size_t e = 0; e < w.per_window; ++e) {
+            apt t;
+            apt_to_r261(t, want[e]);
+            if (memcmp(&t, &tab[(size_t)j * w.per_window + e], sizeof(apt)) != 0) ++bad;
+        }
+    }
+    return bad;
+}
+
 void sbve_set_keyed_wide(int bits, unsigned n_wide) { if (bits >= 8 && bits <= 20) g_keyed_wide_bits = bits; g_keyed_wide_n = n_wide; }
 unsigned long sbve_small_disagreements() { return g_small_disagreements; }
 unsigned long sbve_coop_disagreements() { return g_coop_disagreements; }

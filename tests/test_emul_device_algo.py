@@ -369,6 +369,26 @@ def test_wide_combs_of_a_small_registry_give_the_same_verdicts(emul, oracle, gol
         emul.sbve_set_keyed_coop(0)
 
 
+def test_wide_comb_built_by_the_device_algorithm_equals_the_host_builder(emul, golden_vectors):
+    """p256_widetab29.h (k_widetab_chains + k_widetab_fill: baby / giant chains with one inversion per lane, then affine + affine
+    additions sharing one inversion among 16 denominators) lane by lane against the host builder, byte for byte, for several widths
+    (even and odd: the baby / giant split differs), a random key, G itself and a golden-vector key; a key that is no point is
+    refused by the host half."""
+    emul.sbve_widetab_build_mismatches.restype = ctypes.c_size_t
+    emul.sbve_widetab_build_mismatches.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    rng = random.Random(0x71DE)
+    keys = [ec.pt_mul(rng.randrange(1, N), ec.G), ec.G]
+    vs = [v for v in golden_vectors if v["kind"] == "tuple" and v["accept"]]
+    t = bytes.fromhex(vs[0]["tuple"])
+    keys.append((int.from_bytes(t[96:128], "big"), int.from_bytes(t[128:160], "big")))
+    for i, (qx, qy) in enumerate(keys):
+        kb = qx.to_bytes(32, "big") + qy.to_bytes(32, "big")
+        for bits in ((10, 11, 13, 16) if i == 0 else (12,)):
+            assert emul.sbve_widetab_build_mismatches(kb, bits) == 0, (i, bits)
+    bad = (keys[0][0]).to_bytes(32, "big") + ((keys[0][1] + 1) % ec.P).to_bytes(32, "big")
+    assert emul.sbve_widetab_build_mismatches(bad, 12) == 2**64 - 1
+
+
 def test_fast_conditional_subtraction_is_exact_or_flags(emul):
     """FAST mode: either the result equals the exact one, or the sticky word is 0xFFFFFFFF."""
     emul.sbve_fe_add_fast.restype = ctypes.c_uint32

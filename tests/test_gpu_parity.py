@@ -299,10 +299,20 @@ def test_wide_combs_of_consenter_keys_on_gpu(gpu, oracle, golden_vectors):
         assert wide == len(set(seeded + odd)) and bits == 16 and cap == 64 and kib == 17 * 32768 * 64 // 1024
         gpu.widen_keys(seeded)                                   # idempotent
         assert gpu.wide_key_stats()[0] == wide
+        # the combs are built on the device (p256_widetab29.h): byte for byte the host builder's tables — a seeded key, the forged
+        # key, a golden key that is a point and one that is not (its comb is zeros on both sides)
+        for sl in (seeded[0], seeded[5], reg[0], odd[1], odd[-1]):
+            assert gpu.wide_selfcheck(sl), sl
+        with pytest.raises(Exception):
+            gpu.wide_selfcheck(max(reg) + 1)                     # no such wide slot
         check("16 bits, some slots")
         gpu.wide_keys(18, 64)                                    # another width: the same slots, rebuilt
         assert gpu.wide_key_stats()[:2] == (wide, 18)
+        assert gpu.wide_selfcheck(seeded[1]) and gpu.wide_selfcheck(reg[0])
         check("18 bits, some slots")
+        gpu.wide_keys(20, 64)                                    # 436 MB per key: the widest the entry takes
+        assert gpu.wide_key_stats()[:2] == (wide, 20) and gpu.wide_selfcheck(seeded[2])
+        check("20 bits, some slots")
         gpu.wide_keys(16, 8)                                     # a cap below what it holds: the first 8 stay
         assert gpu.wide_key_stats()[0] == 8
         check("16 bits, cap 8")
