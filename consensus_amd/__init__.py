@@ -161,7 +161,10 @@ def clear_keys() -> None:
     _check(load().sbv_p256_clear_keys())
 
 
-def wide_keys(bits: int = 16, max_keys: int = 64) -> None:
+WIDE_BITS_AUTO = 1
+
+
+def wide_keys(bits: int = WIDE_BITS_AUTO, max_keys: int = 64) -> None:
     """sbv_p256_wide_keys: width and cap of the wide combs sbv_p256_widen_keys builds (bits = 0: off); see include/sbv.h."""
     lib = load()
     lib.sbv_p256_wide_keys.argtypes = [ctypes.c_int, ctypes.c_uint32]

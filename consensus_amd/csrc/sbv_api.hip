@@ -109,7 +109,8 @@ struct Context {
     u32* d_kwidx = nullptr;
     size_t kwide_cap = 0;
     std::vector<u32> wide_slots;
-    int kwide_bits = 16;
+    int kwide_bits = 20;
+    bool kwide_auto = true;             // width by the number of widened keys: 20 bits up to kWideAutoSplit keys, 16 beyond (sbv_p256_wide_keys)
     u32 kwide_max = 64;
     int profiling = 0;                     // 0 off, 1 = step triples + dominant-kernel pairs, 2 = dominant-kernel pairs only
     std::vector<hipEvent_t> prof_events;   // triples: before prep, after prep, after verify
@@ -131,7 +132,7 @@ struct Settings {
     bool group_enabled = true; size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17, group_min_batch_ed = (size_t)1 << 18, group_min_batch_k256 = (size_t)1 << 17; u32 group_min_count = 64, group_max = 2048;
     bool kc_on[3] = {true, true, true}; u32 kc_caps[3] = {4096, 1024, 1024};
     int profiling = 0;
-    int wide_bits = 16; u32 wide_max = 64;          // sbv_p256_wide_keys; env SBV_KEYED_WIDE_BITS (0 = off), SBV_KEYED_WIDE_MAX
+    int wide_bits = SBV_WIDE_BITS_AUTO; u32 wide_max = 64;          // sbv_p256_wide_keys; env SBV_KEYED_WIDE_BITS (0 = off, 1 = auto), SBV_KEYED_WIDE_MAX
 } g_settings;
 std::mutex g_set_mu;
 std::unique_ptr<Context> g_ctxs[kMaxDevices];
@@ -595,9 +596,9 @@ int init_context(Context& c, int device) {
         c.group_min_count = g_settings.group_min_count; c.group_max = g_settings.group_max;
         for (int k = 0; k < 3; ++k) { c.kc_on[k] = g_settings.kc_on[k]; c.kc_caps[k] = g_settings.kc_caps[k]; }
         c.profiling = g_settings.profiling;
-        c.kwide_bits = g_settings.wide_bits; c.kwide_max = g_settings.wide_max;
+        c.kwide_auto = g_settings.wide_bits == SBV_WIDE_BITS_AUTO; c.kwide_bits = c.kwide_auto ? 20 : g_settings.wide_bits; c.kwide_max = g_settings.wide_max;
     }
-    if (const char* e = getenv("SBV_KEYED_WIDE_BITS")) { const int v = atoi(e); if (v == 0) c.kwide_max = 0; else if (v >= 10 && v <= 20) c.kwide_bits = v; }
+    if (const char* e = getenv("SBV_KEYED_WIDE_BITS")) { const int v = atoi(e); if (v == 0) c.kwide_max = 0; else if (v == SBV_WIDE_BITS_AUTO) c.kwide_auto = true; else if (v >= 10 && v <= 20) { c.kwide_bits = v; c.kwide_auto = false; } }
     if (const char* e = getenv("SBV_KEYED_WIDE_MAX")) { const long v = atol(e); if (v >= 0 && v <= 4096) c.kwide_max = (u32)v; }
     if (const char* e = getenv("SBV_SMALL")) c.small_enabled = e[0] != '0';
     if (const char* e = getenv("SBV_GROUP")) c.group_enabled = e[0] != '0';
@@ -938,6 +939,8 @@ namespace {
 // Wide combs for `slots` (those that have none yet), kwide_max at most in total: built on the host like the 8-bit ones (one thread
 // per window, the same field code as the kernels), uploaded key by key.  16 bits: 35.7 MB and ~0.1 s per key; 20 bits: 436 MB
 // and about a second.
+constexpr size_t kWideAutoSplit = 16;
+int drop_wide_keys(Context& c);
 int widen_slots(Context& c, const std::vector<u32>& slots) {
     std::vector<u32> todo;
     {
@@ -949,6 +952,20 @@ int widen_slots(Context& c, const std::vector<u32>& slots) {
         }
     }
     if (todo.empty()) return SBV_OK;
+    if (c.kwide_auto) {
+        // The width follows the size of the consenter set: 20-bit combs (13 additions, 436 MB per key) while at most kWideAutoSplit
+        // keys are wide — a 16-node cluster holds 7 GB of them — and 16-bit combs (16 additions, 35.7 MB) beyond; crossing the line
+        // rebuilds what was there (two launches: milliseconds).
+        const int want_bits = c.wide_slots.size() + todo.size() <= kWideAutoSplit ? 20 : 16;
+        if (want_bits != c.kwide_bits) {
+            std::vector<u32> all = c.wide_slots;
+            all.insert(all.end(), todo.begin(), todo.end());
+            const int r = drop_wide_keys(c);
+            if (r != SBV_OK) return r;
+            c.kwide_bits = want_bits;
+            todo = all;
+        }
+    }
     const size_t stride = sbv::gcomb_entries(c.kwide_bits);
     const size_t want = c.wide_slots.size() + todo.size();
     if (want > c.kwide_cap) {
@@ -1035,7 +1052,7 @@ int drop_wide_keys(Context& c) {
 }  // namespace
 
 extern "C" int sbv_p256_wide_keys(int bits, uint32_t max_keys) {
-    if (bits != 0 && (bits < 10 || bits > 20)) return SBV_EINVAL;
+    if (bits != 0 && bits != SBV_WIDE_BITS_AUTO && (bits < 10 || bits > 20)) return SBV_EINVAL;
     if (max_keys > 4096) return SBV_EINVAL;
     {
         std::lock_guard<std::mutex> lk(g_set_mu);
@@ -1049,10 +1066,14 @@ extern "C" int sbv_p256_wide_keys(int bits, uint32_t max_keys) {
         if (!c.ready) continue;
         if (hipSetDevice(c.device) != hipSuccess) { rc = SBV_EDEVICE; continue; }
         const u32 nmax = bits ? max_keys : 0u;
-        const std::vector<u32> had = c.wide_slots;
-        const bool rebuild = (bits && bits != c.kwide_bits) || nmax < had.size();       // another width, or fewer keys than it holds
+        std::vector<u32> had = c.wide_slots;
+        if (had.size() > nmax) had.resize(nmax);
+        int want_bits = c.kwide_bits;
+        if (bits == SBV_WIDE_BITS_AUTO) want_bits = had.size() <= kWideAutoSplit ? 20 : 16;
+        else if (bits) want_bits = bits;
+        const bool rebuild = want_bits != c.kwide_bits || nmax < c.wide_slots.size();       // another width, or fewer keys than it holds
         if (rebuild) { const int r = drop_wide_keys(c); if (r != SBV_OK) { rc = r; continue; } }
-        if (bits) c.kwide_bits = bits;
+        if (bits) { c.kwide_auto = bits == SBV_WIDE_BITS_AUTO; c.kwide_bits = want_bits; }
         c.kwide_max = nmax;
         if (rebuild && nmax) { const int r = widen_slots(c, had); if (r != SBV_OK) rc = r; }
     }

@@ -130,9 +130,12 @@ int sbv_p256_clear_keys(void);
  * 436 MB per key.  A wavefront whose signatures all belong to wide slots takes the wide
  * combs, any other the 8-bit combs every key keeps; verdicts are identical.  Slots that are wide already are skipped, slots
  * beyond `max_keys` wide ones stay narrow (no error); an unregistered slot is SBV_EINVAL.
- * sbv_p256_wide_keys sets the width and the cap for every device (defaults: 16 bits, 64 keys; bits = 0 switches the feature off
- * and frees the tables; another width rebuilds the combs of the slots already widened).  Env: SBV_KEYED_WIDE_BITS (0 = off),
- * SBV_KEYED_WIDE_MAX.  stats: out[0] = wide slots, out[1] = bits, out[2] = max_keys, out[3] = KiB per key. */
+ * sbv_p256_wide_keys sets the width and the cap for every device.  Default: bits = SBV_WIDE_BITS_AUTO, 64 keys — 20-bit combs
+ * while at most 16 slots are wide (a 16-node cluster: 7 GB), 16-bit combs beyond (64 keys: 2.3 GB); crossing the line rebuilds
+ * what was there, on the device, in milliseconds.  An explicit width (10..20) is kept whatever the count; bits = 0 switches the
+ * feature off and frees the tables; another width rebuilds the combs of the slots already widened.  Env: SBV_KEYED_WIDE_BITS
+ * (0 = off, 1 = auto), SBV_KEYED_WIDE_MAX.  stats: out[0] = wide slots, out[1] = bits, out[2] = max_keys, out[3] = KiB per key. */
+#define SBV_WIDE_BITS_AUTO 1
 int sbv_p256_wide_keys(int bits, uint32_t max_keys);
 int sbv_p256_widen_keys(const uint32_t* slots, size_t m);
 int sbv_p256_wide_key_stats(uint32_t out[4]);

@@ -139,8 +139,13 @@ def test_config3_550000_consenter_signatures_and_quorum(gpu, oracle, openssl_che
         assert gpu.wide_key_stats()[0] == 11
         some = gpu.verify_batch_keyed(rsh, slots, n)
         assert some == got, _diff(some, got)
+        gpu.wide_keys()                                  # the default: width by count — 16 keys get 20-bit combs
+        gpu.widen_keys(list(slot_of.values()))
+        assert gpu.wide_key_stats()[:2] == (16, 20)
+        auto = gpu.verify_batch_keyed(rsh, slots, n)
+        assert auto == got, _diff(auto, got)
     finally:
-        gpu.wide_keys(16, 64)
+        gpu.wide_keys()
         gpu.clear_keys()
     bits = sbv.bitmap_to_list(got, n)
     want = sbv.bitmap_to_list(a, n)

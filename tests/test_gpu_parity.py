@@ -321,8 +321,16 @@ def test_wide_combs_of_consenter_keys_on_gpu(gpu, oracle, golden_vectors):
         gpu.wide_keys(0, 0)
         assert gpu.wide_key_stats()[0] == 0
         check("off")
+        # the default policy: the width follows the number of wide keys — 20 bits up to 16 of them, 16 bits beyond (what was there is rebuilt)
+        gpu.wide_keys(sbv.WIDE_BITS_AUTO, 64)
+        gpu.widen_keys(seeded)
+        assert gpu.wide_key_stats()[:3] == (6, 20, 64) and gpu.wide_selfcheck(seeded[3])
+        check("auto, 6 keys")
+        gpu.widen_keys(odd)
+        assert gpu.wide_key_stats()[:2] == (wide, 16) and wide > 16 and gpu.wide_selfcheck(seeded[3]) and gpu.wide_selfcheck(odd[2])
+        check("auto, more than 16 keys")
     finally:
-        gpu.wide_keys(16, 64)
+        gpu.wide_keys()                                          # the default: auto, 64 keys
         gpu.clear_keys()
 
 

@@ -50,4 +50,5 @@ for n, nkeys in ((550000, 16), (1 << 16, 16), (1 << 20, 4)):
         print(json.dumps({"n": n, "keys": int(len(keys)), "combs": f"{bits}-bit", "wide_keys": w[0], "MiB_per_key": round(w[3] / 1024.0, 1), "build_s": round(build, 2),
                           "ms": ms, "M_per_s": round(n / ms / 1e3, 1), "ok": ok}), flush=True)
     sbv.wide_keys(0, 0)
+sbv.wide_keys()
 sbv.clear_keys()
