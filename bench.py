@@ -522,7 +522,7 @@ def leg_consenter_keys(sbv, synth, torch, stream, steps):
         sbv.widen_keys(reg)
         build_s = time.perf_counter() - t0
         wide, wbits, wmax, kib = sbv.wide_key_stats()
-        out["combs_wide"] = dict(timed(), bits=wbits, wide_keys=wide, MiB_per_key=kib / 1024.0, build_s_host=build_s)
+        out["combs_wide"] = dict(timed(), bits=wbits, wide_keys=wide, MiB_per_key=kib / 1024.0, build_s=build_s)
         out["speedup"] = out["combs_wide"]["sigs_per_s"] / out["combs_8bit"]["sigs_per_s"]
     finally:
         sbv.wide_keys()              # back to the default policy

@@ -50,8 +50,9 @@ type Backend interface {
 	// -1 when there is no registry (then items carry Slot = -1 and travel as generic tuples with the key inline).
 	RegisterKey(pub *ecdsa.PublicKey) int32
 	// WidenKey marks a registered slot as a consenter's: a key that signs every vote of every decision of the epoch
-	// (internal/bft/view.go:531-541, 631, 834).  The device gives it a second, 16-bit-window comb (sbv_p256_widen_keys:
-	// 35.7 MB of HBM, u2*Q in 16 additions instead of 32); a no-op for a backend without a registry.
+	// (internal/bft/view.go:531-541, 631, 834).  The device gives it a second, wide comb (sbv_p256_widen_keys: built on the
+	// device in milliseconds; 20-bit windows = 436 MB of HBM and u2*Q in 13 additions instead of 32 while at most 16 slots are
+	// wide, 16-bit windows beyond); a no-op for a backend without a registry.
 	WidenKey(slot int32)
 	// SignBatch is the batch form of api.Signer.Sign for P-256 (sbv_p256_sign_batch: RFC 6979 nonces): signature i =
 	// ECDSA(keys[keyIndex[i]], digests[i]) as r|s, 64 bytes; ok[i] = false when the key or index is unusable.
