@@ -520,6 +520,57 @@ int sbvh_replay(void* h, int n_nodes, int K, int sequences, int decisions, int t
     return 0;
 }
 
+// Decision replay with faults (VerifyConsenterSigBatch: internal/bft/viewchanger.go:681-727 walks a decision's signatures and
+// counts the valid ones of distinct signers; controller.go:587-633 replays decisions).  `decisions` proposals x Q signatures
+// of an n_nodes cluster in ONE batch, every 7th signature spoiled, cycling through four ways a signature of a decision can be
+// wrong: 0 a flipped byte in its value, 1 a signer the Verifier does not know, 2 a message bound to ANOTHER proposal,
+// 3 a valid signature by another consenter's key under this signer's ID.  counts: [0] spoiled signatures, [1] spoiled ones
+// accepted (must be 0), [2] honest signatures, [3] honest ones rejected (must be 0).  Returns the Status code of the batch call.
+int sbvh_batch_faults(void* h, int n_nodes, int decisions, int threads, uint64_t counts[4]) {
+    Verifier& V = *((VHandle*)h)->v;
+    const Scheme scheme = V.scheme();
+    int Q = 0, f = 0;
+    compute_quorum((uint64_t)n_nodes, &Q, &f);
+    std::vector<std::unique_ptr<Signer>> nodes;
+    for (int i = 0; i < n_nodes; ++i) {
+        uint8_t sk[32];
+        const std::string seed = "batch-faults-node-" + std::to_string(i);
+        sha256(seed.data(), seed.size(), sk);
+        sk[0] &= 0x7f;
+        nodes.emplace_back(new Signer((uint64_t)(i + 1), sk, scheme));
+        V.RegisterConsenter((uint64_t)(i + 1), nodes.back()->public_key());
+    }
+    std::vector<Proposal> props((size_t)decisions + 1);
+    for (size_t d = 0; d < props.size(); ++d) { props[d].payload = "faulty-decision-" + std::to_string(d); props[d].header = "h"; props[d].metadata = "m"; }
+    std::vector<Signature> sigs((size_t)decisions * Q);
+    std::vector<uint8_t> spoiled(sigs.size(), 0);
+    parallel_for((size_t)decisions, threads, [&](size_t d) {
+        for (int j = 0; j < Q; ++j) {
+            const size_t i = d * Q + j;
+            const int signer = (int)((d + j) % n_nodes);
+            if (i % 7 != 3) { sigs[i] = nodes[signer]->SignProposal(props[d], "aux"); continue; }
+            spoiled[i] = 1;
+            switch ((i / 7) % 4) {
+                case 0: sigs[i] = nodes[signer]->SignProposal(props[d], "aux"); sigs[i].value[sigs[i].value.size() / 2] ^= 0x10; break;
+                case 1: sigs[i] = nodes[signer]->SignProposal(props[d], "aux"); sigs[i].id += 1000; break;
+                case 2: sigs[i] = nodes[signer]->SignProposal(props[d + 1], "aux"); break;
+                default: sigs[i] = nodes[(signer + 1) % n_nodes]->SignProposal(props[d], "aux"); sigs[i].id = (uint64_t)(signer + 1); break;
+            }
+        }
+    });
+    std::vector<const Proposal*> pp(sigs.size());
+    for (size_t i = 0; i < sigs.size(); ++i) pp[i] = &props[i / Q];
+    std::vector<uint8_t> ok;
+    const Status st = V.VerifyConsenterSigBatch(sigs, pp, &ok);
+    counts[0] = counts[1] = counts[2] = counts[3] = 0;
+    if (!st.ok()) return st.code;
+    for (size_t i = 0; i < sigs.size(); ++i) {
+        if (spoiled[i]) { ++counts[0]; counts[1] += ok[i] ? 1 : 0; }
+        else { ++counts[2]; counts[3] += ok[i] ? 0 : 1; }
+    }
+    return 0;
+}
+
 // SURVEY.md §8 a12 (chain_emul.cc): handles[i] = node i+1's Verifier.  ledgers: n_nodes x blocks x 32 bytes (Proposal.Digest()
 // of each delivered block, in order), ledger_len[n_nodes] = blocks delivered, signer_masks[n_nodes x blocks] = bit (id-1) per
 // signature handed to Deliver, counters[3] = rejected proposals, dropped votes, backend-unavailable answers.

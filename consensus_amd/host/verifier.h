@@ -191,6 +191,7 @@ class Verifier {
     Status VerifyConsenterSigBatch(const std::vector<Signature>& sigs, const std::vector<const Proposal*>& props,
                                    std::vector<uint8_t>* out);
     CoalescerStats stats() { return co_.stats(); }
+    Scheme scheme() const { return opt_.scheme; }
 
  private:
     bool consenter_key(uint64_t id, uint8_t q[64], long* slot = nullptr);

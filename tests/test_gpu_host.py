@@ -182,6 +182,22 @@ def test_config3_decision_replay_50000_x_11_on_gpu(lib):
         lib.sbvh_verifier_free(v)
 
 
+def test_decision_batch_rejects_exactly_the_spoiled_signatures_on_gpu(lib):
+    """50 000 decisions x 11 signatures of a 16-node cluster (configs[3]'s shape) in one VerifyConsenterSigBatch with every 7th
+    signature spoiled in one of four ways (flipped value byte, unknown signer, message bound to another proposal, another
+    consenter's valid signature under this signer's ID): through the device front end and the consenters' wide combs none of
+    the 78 571 spoiled signatures is accepted and none of the honest ones rejected."""
+    v = _new(lib)
+    try:
+        counts = (ctypes.c_uint64 * 4)()
+        assert lib.sbvh_batch_faults(v, 16, 50000, 16, counts) == 0
+        spoiled, spoiled_accepted, honest, honest_rejected = list(counts)
+        assert spoiled + honest == 550000 and spoiled == len(range(3, 550000, 7))
+        assert spoiled_accepted == 0 and honest_rejected == 0
+    finally:
+        lib.sbvh_verifier_free(v)
+
+
 def test_host_verifier_over_all_gpus_of_the_node(lib):
     """Backend device = -1: sbv_init_all + sbv_p256_verify_batch_sharded behind the same api.Verifier (one Verifier per
     replica process drives every GPU of its node: pkg/consensus/consensus.go:35).  On this box that is one GPU."""

@@ -467,6 +467,23 @@ def test_replay_driver_runs_the_reference_call_pattern(lib, oracle, backend_kind
 
 
 @pytest.mark.parametrize("backend_kind", [1, 2])
+def test_decision_batch_rejects_exactly_the_spoiled_signatures(lib, oracle, backend_kind):
+    """VerifyConsenterSigBatch over 40 decisions x Q signatures of a 7-node cluster with every 7th signature spoiled in one of four
+    ways (flipped value byte, unknown signer, message bound to another proposal, another consenter's valid signature under this
+    signer's ID): none of the spoiled ones is accepted, none of the honest ones rejected — through host-built tuples (kind 1) and
+    through the raw-messages front end with key slots (kind 2, as libsbv has)."""
+    hx = Harness(lib, oracle, wait_us=200, backend_kind=backend_kind)
+    try:
+        counts = (ctypes.c_uint64 * 4)()
+        assert lib.sbvh_batch_faults(hx.v, 7, 40, 4, counts) == 0
+        spoiled, spoiled_accepted, honest, honest_rejected = list(counts)
+        assert spoiled == len([i for i in range(40 * 5) if i % 7 == 3]) and honest == 40 * 5 - spoiled      # Q = 5 at N = 7
+        assert spoiled_accepted == 0 and honest_rejected == 0
+    finally:
+        hx.close()
+
+
+@pytest.mark.parametrize("backend_kind", [1, 2])
 def test_concurrent_mixed_calls_are_safe_and_correct(lib, oracle, backend_kind):
     """The reference calls its Verifier from several goroutines at once (view.go:537-541 commit votes, controller.go:239
     leader requests, pool pruning): proposals, single requests and commit votes from 8 threads at a time must all get
