@@ -74,6 +74,7 @@ void* sbvh_verifier_new(int backend_kind, int device, backend_fn fn, void* user,
 }
 void sbvh_verifier_free(void* h) { delete (VHandle*)h; }
 uint64_t sbvh_backend_keyed_batches(void* h) { return ((VHandle*)h)->be->keyed_batches(); }
+uint64_t sbvh_backend_widened_keys(void* h) { return ((VHandle*)h)->be->widened_keys(); }
 void sbvh_register_consenter(void* h, uint64_t id, const uint8_t q[64]) { ((VHandle*)h)->v->RegisterConsenter(id, q); }
 void sbvh_register_client(void* h, const char* client, const uint8_t q[64]) { ((VHandle*)h)->v->RegisterClient(client, q); }
 // 0: clients registered from now on get no comb slot on the device (their request signatures go as generic tuples)

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -210,6 +211,13 @@ class CallbackBackend : public Backend {
         return fn_(tuples.data(), n, bitmap, user_);
     }
     uint64_t keyed_batches() override { std::lock_guard<std::mutex> lk(mu_); return keyed_batches_; }
+    // stand-in for sbv_p256_widen_keys: remembers which slots were named consenters' (idempotent, like the library)
+    void widen_key(long slot) override {
+        if (!registry_ || slot < 0) return;
+        std::lock_guard<std::mutex> lk(mu_);
+        if ((size_t)slot < keys_.size() && std::find(widened_.begin(), widened_.end(), slot) == widened_.end()) widened_.push_back(slot);
+    }
+    uint64_t widened_keys() override { std::lock_guard<std::mutex> lk(mu_); return widened_.size(); }
     // the stand-in knows which scheme its test runs: the same callback receives the 128-byte tuples
     int verify_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap) override { return fn_(tuples128, n, bitmap, user_); }
     int verify_k256(const uint8_t* tuples, size_t n, uint8_t* bitmap) override { return fn_(tuples, n, bitmap, user_); }
@@ -217,6 +225,7 @@ class CallbackBackend : public Backend {
     backend_fn fn_;
     void* user_;
     bool registry_;
+    std::vector<long> widened_;
     std::mutex mu_;
     std::vector<std::string> keys_;
     uint64_t keyed_batches_ = 0;

@@ -50,6 +50,7 @@ class Backend {
     // 631, 834).  The product backend gives it a wide comb (include/sbv.h: sbv_p256_widen_keys); a no-op elsewhere.
     virtual void widen_key(long slot) { (void)slot; }
     virtual uint64_t keyed_batches() { return 0; }      // test hook: how many verify_keyed batches ran
+    virtual uint64_t widened_keys() { return 0; }       // test hook: how many distinct slots widen_key was given
     // Page-locked staging memory (include/sbv.h: sbv_host_alloc); nullptr = none available, the caller uses the heap
     virtual void* host_alloc(size_t bytes) { (void)bytes; return nullptr; }
     virtual void host_free(void* p) { (void)p; }

@@ -295,6 +295,8 @@ func TestBadCommit(t *testing.T) {
 	_, err = h.v.VerifyConsenterSig(stolen, prop)
 	assert.Error(t, err)
 	assert.True(t, be.keyed >= 3 && be.generic == 0, "consenter signatures must take the keyed route: %d keyed, %d generic", be.keyed, be.generic)
+	// RegisterConsenter names every consenter's slot for a wide comb (Backend.WidenKey -> sbv_p256_widen_keys); clients' slots are not named
+	assert.Equal(t, []int32{0, 1, 2, 3}, be.widened)
 }
 
 // TestNormalPath mirrors internal/bft/view_test.go:533: one view taken through pre-prepare, prepare and commit to a

@@ -75,6 +75,8 @@ def load():
     lib.sbvh_chain_emulate.argtypes = [ctypes.POINTER(V), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64),
                                        ctypes.POINTER(ctypes.c_uint64)]
+    lib.sbvh_backend_widened_keys.argtypes = [V]
+    lib.sbvh_backend_widened_keys.restype = ctypes.c_uint64
     lib.sbvh_batch_faults.argtypes = [V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     lib.sbvh_replay.argtypes = [V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ReplayResult)]
     return lib

@@ -307,8 +307,15 @@ def test_registered_client_and_consenter_keys_take_the_keyed_backend_path(lib, o
         sig = hx.sign_proposal(2, prop, b"aux")
         assert hx.verify_consenter_sig(sig, prop)[0] == OK
         assert lib.sbvh_backend_keyed_batches(hx.v) >= 5
+        # RegisterConsenter also names the slot a consenter's (Backend::widen_key -> sbv_p256_widen_keys: the wide comb); clients are not
+        assert lib.sbvh_backend_widened_keys(hx.v) == 4          # the harness's 4 nodes, none of its clients
     finally:
         hx.close()
+    plain = Harness(lib, oracle, backend_kind=1, wait_us=10)     # a backend without a registry: nothing to widen
+    try:
+        assert lib.sbvh_backend_widened_keys(plain.v) == 0
+    finally:
+        plain.close()
 
 
 def test_proposal_mixing_slotted_and_unslotted_clients_goes_the_generic_way(lib, oracle):
