@@ -210,7 +210,7 @@ func (v *Verifier) verifyBatch(items []Item) []bool {
 // serve merges concurrent single-signature calls into one batch WITHOUT a dispatcher goroutine: the first caller that finds
 // no leader becomes the leader (it is running already; a parked dispatcher would have to be woken first, and at this scale the
 // wake-up is a large part of the round trip — the C++ mirror measured 191 -> 73 us for a burst of 15 votes with this and a
-// faster kernel, profiles/r04/m2_trace_r04k.txt).  The leader polls the queue — spin, then yield; no timer: Go's timers fire
+// faster kernel, profiles/r04/m2_trace_r04h.txt).  The leader polls the queue — spin, then yield; no timer: Go's timers fire
 // 50-100 us late at this scale, which is the whole budget — until
 //
 //	the expected burst is in (N - 1 votes: the goroutines of View.processCommits arrive within microseconds of one

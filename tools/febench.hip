@@ -3,7 +3,7 @@
 // addition of p256_pt29.h).  For each: a dependent chain of field multiplications / squarings per lane, and a
 // chain of comb-style mixed additions with table gathers (the shape of the G phase / Q phase kernels), at the
 // launch bounds the verify kernels use.  Results of the two forms are cross-checked on the host (same points).
-// Prints one JSON object per line (profiles/r02/febench.jsonl).
+// Prints one JSON object per line (profiles/r02/febench_w*.jsonl).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
