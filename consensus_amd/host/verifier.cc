@@ -371,7 +371,7 @@ void Coalescer::serve_as_leader() {
             // is tens of microseconds — below the kernel's timer slack — so the leader polls the queue length and leaves early
             // when the expected burst is complete or nothing new has arrived for a quiet period: a quarter of the window while
             // no burst size is known, half of it when one is (the votes of a burst arrive a microsecond apart — measured,
-            // profiles/r04/m2_trace_r04h.txt: the second vote 0-5 us after the leader, the fifteenth after 6-12 — and must
+            // profiles/r04/m2_trace_r04h.txt: a batch of 15 is complete 15-24 us after its leader started; SBVH_TRACE=1 prints every arrival — and must
             // not be cut into several serial round trips), but only a SIXTH of it (8 us) while the leader is still alone: a LONE
             // call — VerifyRequest from HandleRequest, the serial verifyPrevCommitSignatures loop of
             // internal/bft/view.go:630-644, a view-change VerifySignature — must not sit out the window (at N = 16 that was
