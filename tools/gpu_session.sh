@@ -25,7 +25,7 @@ for step in "$@"; do
   case "$kind" in
     pytest)
       if [ -n "${a1:-}" ]; then run "pytest_$(echo "$a1" | tr -c 'A-Za-z0-9_\n' '_')" 1500 python -m pytest tests -m gpu -q -k "$a1"; tail -4 "$OUT"/pytest_*.log | tail -6
-      else run pytest_gpu 2400 python -m pytest tests -m gpu -q -rs; tail -6 "$OUT/pytest_gpu.log"; fi ;;
+      else run pytest_gpu 2400 python -m pytest tests -m gpu -q -rs --durations=25; tail -6 "$OUT/pytest_gpu.log"; fi ;;
     bench)
       name=${a1:-driver_flags}
       ( timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ${a2:-} > "$OUT/bench_$name.json" 2> "$OUT/bench_$name.err"; echo "rc=$?" >> "$OUT/bench_$name.err" )
