@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Randomised campaign over the CPU emulation of the device algorithms added in round 4 (tests/emul, built with the field contract
+checks on: an operand outside its bounds aborts the process).  No GPU needed.
+
+  wide     p256_widetab29.h: the device-side builder of a wide comb against the host builder, byte for byte, random keys, widths 10-13
+  keyed    the registered-key lanes with every slot widened (one-lane form, 8-lane form, prepared one-launch form) against the oracle
+           on seeded batches with corrupted tuples
+  ed       the Ed25519 grouped step (key check over the ungrouped candidates, batched finish) against the oracle on seeded batches
+
+usage: fuzz_emul.py <minutes> [workers]      one JSON line per worker at the end; exit status 1 on any mismatch."""
+import ctypes, json, multiprocessing as mp, os, random, sys, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def worker(args):
+    wid, minutes = args
+    import p256_py as ec
+    emul = ctypes.CDLL(os.path.join(ROOT, "tests", "emul", "libsbv_emul.so"))
+    oracle = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsbv_oracle.so"))
+    emul.sbve_widetab_build_mismatches.restype = ctypes.c_size_t
+    emul.sbve_widetab_build_mismatches.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    emul.sbve_p256_verify_batch_keyed.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    emul.sbve_set_keyed_wide.argtypes = [ctypes.c_int, ctypes.c_uint]
+    emul.sbve_ed25519_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    gen_args = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    oracle.sbvo_gen_batch.argtypes = gen_args
+    oracle.sbvo_ed25519_gen_batch.argtypes = gen_args
+    rng = random.Random(0xF022 + wid)
+    out = {"worker": wid, "wide_keys": 0, "keyed_tuples": 0, "ed_tuples": 0, "mismatches": 0}
+    t_end = time.time() + 60 * minutes
+    it = 0
+    while time.time() < t_end:
+        it += 1
+        kind = it % 3
+        if kind == 0:
+            q = ec.pt_mul(rng.randrange(1, ec.N), ec.G)
+            kb = q[0].to_bytes(32, "big") + q[1].to_bytes(32, "big")
+            bits = rng.choice((10, 10, 11, 12, 13))
+            bad = emul.sbve_widetab_build_mismatches(kb, bits)
+            out["wide_keys"] += 1
+            if bad != 0:
+                out["mismatches"] += 1
+                out.setdefault("first", ["wide", kb.hex(), bits, int(bad)])
+        elif kind == 1:
+            n, nkeys = rng.choice((200, 333, 517)), rng.choice((1, 2, 5))
+            seed = rng.randrange(1 << 32)
+            tup = ctypes.create_string_buffer(160 * n)
+            exp = ctypes.create_string_buffer((n + 7) // 8)
+            oracle.sbvo_gen_batch(seed, n, nkeys, rng.choice((2, 3, 5)), tup, exp, 1)
+            keys, index, rsh, slots = [], {}, bytearray(), []
+            raw = tup.raw
+            for i in range(n):
+                k = raw[160 * i + 96:160 * i + 160]
+                if k not in index:
+                    index[k] = len(keys); keys.append(k)
+                rsh += raw[160 * i:160 * i + 96]; slots.append(index[k])
+            arr = (ctypes.c_uint32 * n)(*slots)
+            emul.sbve_set_keyed_wide(rng.choice((10, 11, 12)), len(keys))
+            for form in (0, 1):
+                emul.sbve_set_keyed_coop(form)
+                bm = ctypes.create_string_buffer((n + 7) // 8)
+                emul.sbve_p256_verify_batch_keyed(bytes(rsh), arr, n, b"".join(keys), len(keys), bm, 64, 4)
+                out["keyed_tuples"] += n
+                if bm.raw != exp.raw:
+                    out["mismatches"] += 1
+                    out.setdefault("first", ["keyed", seed, n, nkeys, form])
+            emul.sbve_set_keyed_coop(0)
+            emul.sbve_set_keyed_wide(16, 0)
+        else:
+            n, nkeys = rng.choice((300, 700, 1100)), rng.choice((3, 7, 20))
+            seed = rng.randrange(1 << 32)
+            tup = ctypes.create_string_buffer(128 * n)
+            exp = ctypes.create_string_buffer((n + 7) // 8)
+            oracle.sbvo_ed25519_gen_batch(seed, n, nkeys, rng.choice((2, 3, 5)), tup, exp, 1)
+            bm = ctypes.create_string_buffer((n + 7) // 8)
+            emul.sbve_ed25519_verify_batch_grouped(tup.raw, n, bm, rng.choice((1, 8, 40)), 64, 12, rng.choice((1, 2, 3)), rng.choice((2, 4, 8)), None)
+            out["ed_tuples"] += n
+            if bm.raw != exp.raw:
+                out["mismatches"] += 1
+                out.setdefault("first", ["ed", seed, n, nkeys])
+    return out
+
+
+if __name__ == "__main__":
+    minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+    workers = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    with mp.Pool(workers) as pool:
+        res = pool.map(worker, [(w, minutes) for w in range(workers)])
+    for r in res:
+        print(json.dumps(r))
+    total = {k: sum(r[k] for r in res) for k in ("wide_keys", "keyed_tuples", "ed_tuples", "mismatches")}
+    print(json.dumps({"total": total, "minutes": minutes, "workers": workers}))
+    sys.exit(1 if total["mismatches"] else 0)
