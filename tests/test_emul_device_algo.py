@@ -389,6 +389,19 @@ def test_wide_comb_built_by_the_device_algorithm_equals_the_host_builder(emul, g
     assert emul.sbve_widetab_build_mismatches(bad, 12) == 2**64 - 1
 
 
+def test_fuzz_campaign_tool_runs_clean(emul, oracle):
+    """tools/fuzz_emul.py (the randomised campaign over the emulated kernels; `emul` and `oracle` built the libraries it loads):
+    a few seconds of it, two processes, every kind of iteration at least once, no mismatch."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(HERE)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_emul.py"), "0.1", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-600:] + r.stderr[-600:]
+    total = json.loads(r.stdout.strip().splitlines()[-1])["total"]
+    assert total["mismatches"] == 0 and all(total[k] > 0 for k in ("wide_keys", "keyed_tuples", "ed_tuples", "p256g_tuples", "k256g_tuples")), total
+
+
 def test_fast_conditional_subtraction_is_exact_or_flags(emul):
     """FAST mode: either the result equals the exact one, or the sticky word is 0xFFFFFFFF."""
     emul.sbve_fe_add_fast.restype = ctypes.c_uint32

@@ -6,6 +6,8 @@ checks on: an operand outside its bounds aborts the process).  No GPU needed.
   keyed    the registered-key lanes with every slot widened (one-lane form, 8-lane form, prepared one-launch form) against the oracle
            on seeded batches with corrupted tuples
   ed       the Ed25519 grouped step (key check over the ungrouped candidates, batched finish) against the oracle on seeded batches
+  p256g    the P-256 grouped step (sorted / compaction order, 1-4 chunks, the one-launch latency form, key-table cache on / off)
+  k256g    the secp256k1 grouped step (1-3 chunks, stage-A chunking, its key-table cache on / off)
 
 usage: fuzz_emul.py <minutes> [workers]      one JSON line per worker at the end; exit status 1 on any mismatch."""
 import ctypes, json, multiprocessing as mp, os, random, sys, time
@@ -27,13 +29,18 @@ def worker(args):
     gen_args = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
     oracle.sbvo_gen_batch.argtypes = gen_args
     oracle.sbvo_ed25519_gen_batch.argtypes = gen_args
+    emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    emul.sbve_k256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    emul.sbve_key_cache.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    emul.sbve_scheme_key_cache.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+    oracle.sbvo_k256_gen_batch.argtypes = gen_args
     rng = random.Random(0xF022 + wid)
-    out = {"worker": wid, "wide_keys": 0, "keyed_tuples": 0, "ed_tuples": 0, "mismatches": 0}
+    out = {"worker": wid, "wide_keys": 0, "keyed_tuples": 0, "ed_tuples": 0, "p256g_tuples": 0, "k256g_tuples": 0, "mismatches": 0}
     t_end = time.time() + 60 * minutes
     it = 0
     while time.time() < t_end:
         it += 1
-        kind = it % 3
+        kind = it % 5
         if kind == 0:
             q = ec.pt_mul(rng.randrange(1, ec.N), ec.G)
             kb = q[0].to_bytes(32, "big") + q[1].to_bytes(32, "big")
@@ -68,6 +75,36 @@ def worker(args):
                     out.setdefault("first", ["keyed", seed, n, nkeys, form])
             emul.sbve_set_keyed_coop(0)
             emul.sbve_set_keyed_wide(16, 0)
+        elif kind == 3 or kind == 4:
+            p256 = kind == 3
+            n, nkeys = rng.choice((300, 640, 1000)), rng.choice((2, 5, 12))
+            seed = rng.randrange(1 << 32)
+            tup = ctypes.create_string_buffer(160 * n)
+            exp = ctypes.create_string_buffer((n + 7) // 8)
+            (oracle.sbvo_gen_batch if p256 else oracle.sbvo_k256_gen_batch)(seed, n, nkeys, rng.choice((2, 3, 7)), tup, exp, 1)
+            cache = rng.random() < 0.5
+            if p256:
+                emul.sbve_set_group_sort(rng.choice((0, 1, 1)))
+                emul.sbve_set_group_chunks(rng.choice((1, 2, 3, 4)))
+                emul.sbve_set_group_coop(rng.choice((0, 0, 1)))
+                emul.sbve_key_cache(1 if cache else 0, 64)
+            else:
+                emul.sbve_set_k256_prep_t(rng.choice((1, 4, 8)))
+                emul.sbve_scheme_key_cache(1, 1 if cache else 0, 64)
+            for rep in range(2 if cache else 1):                      # with the cache: a cold pass, then a warm one over the same keys
+                bm = ctypes.create_string_buffer((n + 7) // 8)
+                if p256:
+                    emul.sbve_p256_verify_batch_grouped(tup.raw, n, bm, rng.choice((1, 8, 30)), rng.choice((4, 64)), 12, None)
+                else:
+                    emul.sbve_k256_verify_batch_grouped(tup.raw, n, bm, rng.choice((1, 8, 30)), rng.choice((4, 64)), 12, rng.choice((1, 2, 3)), None)
+                out["p256g_tuples" if p256 else "k256g_tuples"] += n
+                if bm.raw != exp.raw:
+                    out["mismatches"] += 1
+                    out.setdefault("first", ["p256g" if p256 else "k256g", seed, n, nkeys, cache, rep])
+            if p256:
+                emul.sbve_key_cache(0, 64); emul.sbve_set_group_sort(1); emul.sbve_set_group_chunks(3); emul.sbve_set_group_coop(0)
+            else:
+                emul.sbve_scheme_key_cache(1, 0, 64)
         else:
             n, nkeys = rng.choice((300, 700, 1100)), rng.choice((3, 7, 20))
             seed = rng.randrange(1 << 32)
@@ -90,6 +127,6 @@ if __name__ == "__main__":
         res = pool.map(worker, [(w, minutes) for w in range(workers)])
     for r in res:
         print(json.dumps(r))
-    total = {k: sum(r[k] for r in res) for k in ("wide_keys", "keyed_tuples", "ed_tuples", "mismatches")}
+    total = {k: sum(r[k] for r in res) for k in ("wide_keys", "keyed_tuples", "ed_tuples", "p256g_tuples", "k256g_tuples", "mismatches")}
     print(json.dumps({"total": total, "minutes": minutes, "workers": workers}))
     sys.exit(1 if total["mismatches"] else 0)
