@@ -38,7 +38,7 @@ def worker(args):
     out = {"worker": wid, "wide_keys": 0, "keyed_tuples": 0, "ed_tuples": 0, "p256g_tuples": 0, "k256g_tuples": 0, "mismatches": 0}
     t_end = time.time() + 60 * minutes
     it = 0
-    while time.time() < t_end:
+    while time.time() < t_end or it < 5:          # at least one iteration of every kind, however short the run
         it += 1
         kind = it % 5
         if kind == 0:
@@ -73,6 +73,20 @@ def worker(args):
                 if bm.raw != exp.raw:
                     out["mismatches"] += 1
                     out.setdefault("first", ["keyed", seed, n, nkeys, form])
+            # the prepared one-launch form (stage A of a call on the host half, 16 lanes per signature): calls of 1..32 records
+            emul.sbve_set_keyed_coop(3)
+            off, got = 0, []
+            while off < n:
+                m = min(rng.choice((1, 2, 15, 31, 32)), n - off)
+                sub = (ctypes.c_uint32 * m)(*slots[off:off + m])
+                bm = ctypes.create_string_buffer((m + 7) // 8)
+                emul.sbve_p256_verify_batch_keyed(bytes(rsh[96 * off:96 * (off + m)]), sub, m, b"".join(keys), len(keys), bm, 64, 1)
+                got += [(bm.raw[i >> 3] >> (i & 7)) & 1 for i in range(m)]
+                off += m
+            out["keyed_tuples"] += n
+            if got != [(exp.raw[i >> 3] >> (i & 7)) & 1 for i in range(n)]:
+                out["mismatches"] += 1
+                out.setdefault("first", ["prepared", seed, n, nkeys])
             emul.sbve_set_keyed_coop(0)
             emul.sbve_set_keyed_wide(16, 0)
         elif kind == 3 or kind == 4:
@@ -117,6 +131,13 @@ def worker(args):
             if bm.raw != exp.raw:
                 out["mismatches"] += 1
                 out.setdefault("first", ["ed", seed, n, nkeys])
+    # the emulator's own cross-checks: every lane of a multi-lane group ended with the same point; the host half of the prepared
+    # form computed the scalars the stage-A kernel computes
+    emul.sbve_coop_disagreements.restype = ctypes.c_ulong
+    emul.sbve_small_disagreements.restype = ctypes.c_ulong
+    emul.sbve_group_sort_violations.restype = ctypes.c_ulong
+    out["lane_disagreements"] = int(emul.sbve_coop_disagreements()) + int(emul.sbve_small_disagreements()) + int(emul.sbve_group_sort_violations())
+    out["mismatches"] += out["lane_disagreements"]
     return out
 
 
