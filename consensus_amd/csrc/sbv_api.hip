@@ -994,6 +994,13 @@ int widen_slots(Context& c, const std::vector<u32>& slots) {
     std::vector<sbv::apt> tab(host_build ? stride : 0);
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 1;
+    const size_t first_new = c.wide_slots.size();
+    // a failure below leaves the registry as it was before this call: the slots named here stay on their 8-bit combs and may be named again
+    auto rollback = [&] {
+        const u32 none = SBV_WIDE_NONE;
+        for (size_t i = first_new; i < c.wide_slots.size(); ++i) (void)hipMemcpy(c.d_kwidx + c.wide_slots[i], &none, sizeof(u32), hipMemcpyHostToDevice);
+        c.wide_slots.resize(first_new);
+    };
     for (u32 sl : todo) {
         const std::string* k = key_of[sl];
         const u32 w = (u32)c.wide_slots.size();
@@ -1001,7 +1008,7 @@ int widen_slots(Context& c, const std::vector<u32>& slots) {
         if (k && k->size() == 64) {
             if (host_build) {
                 have = sbv::host_build_wide_key_table((const uint8_t*)k->data(), c.kwide_bits, tab.data(), (int)(hw > 32 ? 32 : hw));
-                if (have) HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_kwide + (size_t)w * stride, tab.data(), stride * sizeof(sbv::apt), hipMemcpyHostToDevice));
+                if (have) { const hipError_t e = hipMemcpy(c.d_kwide + (size_t)w * stride, tab.data(), stride * sizeof(sbv::apt), hipMemcpyHostToDevice); if (e != hipSuccess) { rollback(); return fail(SBV_EDEVICE, "wide combs: upload", e); } }
             } else {
                 bases.resize(bases.size() + 2 * (size_t)wb.windows);
                 have = sbv::host_wide_bases((const uint8_t*)k->data(), c.kwide_bits, bases.data() + bases.size() - 2 * (size_t)wb.windows);
@@ -1010,9 +1017,12 @@ int widen_slots(Context& c, const std::vector<u32>& slots) {
             }
         }
         // not a point: kvalid[slot] = 0 rejects its signatures whatever the lanes add; its comb is zeros
-        if (!have) HIP_TRY(SBV_EDEVICE, hipMemset(c.d_kwide + (size_t)w * stride, 0, stride * sizeof(sbv::apt)));
+        if (!have) { const hipError_t e = hipMemset(c.d_kwide + (size_t)w * stride, 0, stride * sizeof(sbv::apt)); if (e != hipSuccess) { rollback(); return fail(SBV_EDEVICE, "wide combs: zero", e); } }
         c.wide_slots.push_back(sl);
-        if (host_build || !have) HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_kwidx + sl, &w, sizeof(u32), hipMemcpyHostToDevice));      // published after its table is complete
+        if (host_build || !have) {      // published after its table is complete
+            const hipError_t e = hipMemcpy(c.d_kwidx + sl, &w, sizeof(u32), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { rollback(); return fail(SBV_EDEVICE, "wide combs: publish", e); }
+        }
     }
     if (!widx_of.empty()) {
         const u32 nb = (u32)widx_of.size();
@@ -1038,7 +1048,7 @@ int widen_slots(Context& c, const std::vector<u32>& slots) {
                 if (e != hipSuccess) rc = fail(SBV_EDEVICE, "wide combs: publish", e);
             }
         cleanup();
-        if (rc != SBV_OK) return rc;     // the slots stay narrow (their index was never published); their combs are unused space
+        if (rc != SBV_OK) { rollback(); return rc; }
     }
     return SBV_OK;
 }

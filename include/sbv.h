@@ -129,7 +129,8 @@ int sbv_p256_clear_keys(void);
  * which u2*Q is ceil(257 / bits) additions instead of 32.2 — 16 bits: 16 additions, 35.7 MB per key; 20 bits: 13 additions,
  * 436 MB per key.  A wavefront whose signatures all belong to wide slots takes the wide
  * combs, any other the 8-bit combs every key keeps; verdicts are identical.  Slots that are wide already are skipped, slots
- * beyond `max_keys` wide ones stay narrow (no error); an unregistered slot is SBV_EINVAL.
+ * beyond `max_keys` wide ones stay narrow (no error); an unregistered slot is SBV_EINVAL.  On a device fault the call returns
+ * SBV_EDEVICE / SBV_ENOMEM and leaves the registry as it was: the named slots keep their 8-bit combs and may be named again.
  * sbv_p256_wide_keys sets the width and the cap for every device.  Default: bits = SBV_WIDE_BITS_AUTO, 64 keys — 20-bit combs
  * while at most 16 slots are wide (a 16-node cluster: 7 GB), 16-bit combs beyond (64 keys: 2.3 GB); crossing the line rebuilds
  * what was there, on the device, in milliseconds.  An explicit width (10..20) is kept whatever the count; bits = 0 switches the
