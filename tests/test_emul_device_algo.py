@@ -399,7 +399,7 @@ def test_fuzz_campaign_tool_runs_clean(emul, oracle):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_emul.py"), "0.1", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-600:] + r.stderr[-600:]
     total = json.loads(r.stdout.strip().splitlines()[-1])["total"]
-    assert total["mismatches"] == 0 and all(total[k] > 0 for k in ("wide_keys", "keyed_tuples", "ed_tuples", "p256g_tuples", "k256g_tuples")), total
+    assert total["mismatches"] == 0 and all(total[k] > 0 for k in ("wide_keys", "keyed_tuples", "ed_tuples", "p256g_tuples", "k256g_tuples", "one_tuples")), total
 
 
 def test_fast_conditional_subtraction_is_exact_or_flags(emul):

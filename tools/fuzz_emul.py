@@ -8,6 +8,7 @@ checks on: an operand outside its bounds aborts the process).  No GPU needed.
   ed       the Ed25519 grouped step (key check over the ungrouped candidates, batched finish) against the oracle on seeded batches
   p256g    the P-256 grouped step (sorted / compaction order, 1-4 chunks, the one-launch latency form, key-table cache on / off)
   k256g    the secp256k1 grouped step (1-3 chunks, stage-A chunking, its key-table cache on / off)
+  one      the one-lane kernels of the three schemes (all-distinct keys / small batches: 256 doublings per signature)
 
 usage: fuzz_emul.py <minutes> [workers]      one JSON line per worker at the end; exit status 1 on any mismatch."""
 import ctypes, json, multiprocessing as mp, os, random, sys, time
@@ -31,16 +32,19 @@ def worker(args):
     oracle.sbvo_ed25519_gen_batch.argtypes = gen_args
     emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
     emul.sbve_k256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    emul.sbve_p256_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    emul.sbve_k256_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
+    emul.sbve_ed25519_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
     emul.sbve_key_cache.argtypes = [ctypes.c_int, ctypes.c_uint32]
     emul.sbve_scheme_key_cache.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
     oracle.sbvo_k256_gen_batch.argtypes = gen_args
     rng = random.Random(0xF022 + wid)
-    out = {"worker": wid, "wide_keys": 0, "keyed_tuples": 0, "ed_tuples": 0, "p256g_tuples": 0, "k256g_tuples": 0, "mismatches": 0}
+    out = {"worker": wid, "wide_keys": 0, "keyed_tuples": 0, "ed_tuples": 0, "p256g_tuples": 0, "k256g_tuples": 0, "one_tuples": 0, "mismatches": 0}
     t_end = time.time() + 60 * minutes
     it = 0
-    while time.time() < t_end or it < 5:          # at least one iteration of every kind, however short the run
+    while time.time() < t_end or it < 6:          # at least one iteration of every kind, however short the run
         it += 1
-        kind = it % 5
+        kind = it % 6
         if kind == 0:
             q = ec.pt_mul(rng.randrange(1, ec.N), ec.G)
             kb = q[0].to_bytes(32, "big") + q[1].to_bytes(32, "big")
@@ -89,6 +93,25 @@ def worker(args):
                 out.setdefault("first", ["prepared", seed, n, nkeys])
             emul.sbve_set_keyed_coop(0)
             emul.sbve_set_keyed_wide(16, 0)
+        elif kind == 5:
+            which = (it // 6) % 3
+            n = rng.choice((60, 130))
+            seed = rng.randrange(1 << 32)
+            width = 128 if which == 2 else 160
+            tup = ctypes.create_string_buffer(width * n)
+            exp = ctypes.create_string_buffer((n + 7) // 8)
+            (oracle.sbvo_gen_batch, oracle.sbvo_k256_gen_batch, oracle.sbvo_ed25519_gen_batch)[which](seed, n, rng.choice((3, n)), rng.choice((2, 3, 5)), tup, exp, 1)
+            bm = ctypes.create_string_buffer((n + 7) // 8)
+            if which == 0:
+                emul.sbve_p256_verify_batch(tup.raw, n, bm, 64, rng.choice((1, 4, 8)))
+            elif which == 1:
+                emul.sbve_k256_verify_batch(tup.raw, n, bm)
+            else:
+                emul.sbve_ed25519_verify_batch(tup.raw, n, bm)
+            out["one_tuples"] += n
+            if bm.raw != exp.raw:
+                out["mismatches"] += 1
+                out.setdefault("first", ["one", which, seed, n])
         elif kind == 3 or kind == 4:
             p256 = kind == 3
             n, nkeys = rng.choice((300, 640, 1000)), rng.choice((2, 5, 12))
@@ -148,6 +171,6 @@ if __name__ == "__main__":
         res = pool.map(worker, [(w, minutes) for w in range(workers)])
     for r in res:
         print(json.dumps(r))
-    total = {k: sum(r[k] for r in res) for k in ("wide_keys", "keyed_tuples", "ed_tuples", "p256g_tuples", "k256g_tuples", "mismatches")}
+    total = {k: sum(r[k] for r in res) for k in ("wide_keys", "keyed_tuples", "ed_tuples", "p256g_tuples", "k256g_tuples", "one_tuples", "mismatches")}
     print(json.dumps({"total": total, "minutes": minutes, "workers": workers}))
     sys.exit(1 if total["mismatches"] else 0)
