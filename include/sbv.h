@@ -114,8 +114,8 @@ int sbv_p256_verify_batch_dev(const void* d_tuples, size_t n, void* d_bitmap, vo
  * builds a fixed-base comb for it (33 x 128 affine multiples, 270 KiB of HBM per key) once, after
  * which a verification against that key needs NO point doublings: R = u1*G + u2*Q is 13 + 32.2 = 45.2 mixed
  * additions on average (13 from the 20-bit comb of G, 32 key-comb windows + the rarely needed carry window; ~5x fewer field
- * multiplications than the generic form).  Batches of at most 32 signatures take a one-launch latency form (stage A in
- * registers, records and verdicts in mapped host memory), up to 32768 the 8-lanes-per-signature kernel.  Verdicts are identical to
+ * multiplications than the generic form).  Batches of at most 32 signatures take a one-launch latency form (stage A of the
+ * call on the calling CPU thread with one inversion, records and verdicts in mapped host memory, 16 lanes per signature), up to 32768 the 8-lanes-per-signature kernel.  Verdicts are identical to
  * the generic entry points: a key that crypto/ecdsa would refuse (coordinate >= p, off curve) still
  * gets a slot, flagged invalid, and every signature against it is rejected.
  *   keys: m x 64 bytes (Qx|Qy big-endian).  slots_out[i] = slot of keys[i] (equal keys share a slot). */
@@ -140,8 +140,8 @@ int sbv_p256_clear_keys(void);
 int sbv_p256_wide_keys(int bits, uint32_t max_keys);
 int sbv_p256_widen_keys(const uint32_t* slots, size_t m);
 int sbv_p256_wide_key_stats(uint32_t out[4]);
-/* The combs are built on the device (consensus_amd/csrc/p256_widetab29.h: two launches for all the keys of a call, ~2 ms for 16
- * keys at 16 bits); SBV_KEYED_WIDE_HOST=1 selects the host builder.  Diagnostics: sbv_p256_wide_selfcheck(slot) = 1 when the
+/* The combs are built on the device (consensus_amd/csrc/p256_widetab29.h: two launches for all the keys of a call: 0.01 s for 16
+ * keys at 16 bits, 0.03 s at 20 bits, measured); SBV_KEYED_WIDE_HOST=1 selects the host builder.  Diagnostics: sbv_p256_wide_selfcheck(slot) = 1 when the
  * device-resident comb of `slot` equals the host builder's output byte for byte, 0 when it differs. */
 int sbv_p256_wide_selfcheck(uint32_t slot);
 /* rsh: n x 96 bytes (r|s|hash, big-endian), slots: n key slots.  Takes over VerifyConsenterSig
