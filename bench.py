@@ -477,6 +477,58 @@ def leg_replay_550k(sbv, synth):
             "note": "PCIe-inclusive (88 MB of tuples from host memory per call); key-table cache warm as for a replaying replica"}
 
 
+def leg_replay_550k_keyed(sbv, synth):
+    """configs[3] through the REGISTERED-key sharded entry (round 5: sbv_p256_verify_batch_keyed_sharded): the same 50 000 x 11
+    signatures as replay_550k, as a replica that registered its 16 consenters ships them — 96-byte records r | s | hash + a 4-byte
+    key slot from page-locked host memory (100 B per signature over PCIe instead of 160), the consenters' wide combs resident on
+    every device, uploads in pieces beside the kernels, quorum bits by distinct slot.  PCIe-inclusive, host pointers in and out."""
+    import numpy as np
+    group, quorum, props = 11, 10, 50000
+    n = group * props
+    tuples, valid = synth.gen_batch(SEED + 0x300, n, 16, 8)
+    t2 = tuples.reshape(n, 160)
+    keys, counts = np.unique(t2[:, 96:160], axis=0, return_counts=True)
+    keys = keys[counts >= 64]
+    sbv.init_all()
+    sbv.clear_keys()
+    reg = sbv.register_keys([bytes(k) for k in keys])
+    sbv.widen_keys(reg)                                        # what RegisterConsenter does: 16 keys -> 20-bit combs
+    slots_of = dict(zip((bytes(k) for k in keys), reg))
+    slots = np.fromiter((slots_of.get(bytes(k), 0xFFFFFFFF) for k in t2[:, 96:160]), dtype=np.uint32, count=n)
+    p_rsh, p_slots = sbv.host_alloc(n * 96), sbv.host_alloc(n * 4)
+    if not p_rsh or not p_slots:
+        raise RuntimeError("sbv_host_alloc failed")
+    try:
+        h_rsh = np.ctypeslib.as_array((ctypes.c_uint8 * (n * 96)).from_address(p_rsh))
+        h_slots = np.ctypeslib.as_array((ctypes.c_uint32 * n).from_address(p_slots))
+        h_rsh[:] = np.ascontiguousarray(t2[:, :96]).reshape(-1)
+        h_slots[:] = slots
+        got = np.zeros((n + 7) // 8, dtype=np.uint8)
+        qgot = np.zeros((props + 7) // 8, dtype=np.uint8)
+        info = sbv.verify_batch_keyed_sharded(p_rsh, p_slots, n, got.ctypes.data, group, quorum, qgot.ctypes.data)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            info = sbv.verify_batch_keyed_sharded(p_rsh, p_slots, n, got.ctypes.data, group, quorum, qgot.ctypes.data)
+            ts.append(time.perf_counter() - t0)
+        wide = sbv.wide_key_stats()
+    finally:
+        sbv.host_free(p_rsh); sbv.host_free(p_slots)
+        sbv.wide_keys()
+        sbv.clear_keys()
+    dt = sorted(ts)[len(ts) // 2]
+    bits = np.unpackbits(got, bitorder="little")[:n].reshape(props, group)
+    qbits = np.unpackbits(qgot, bitorder="little")[:props]
+    want_bits = np.unpackbits(valid, bitorder="little")[:n].reshape(props, group)
+    want_q = (want_bits.sum(axis=1) >= quorum).astype(np.uint8)       # the 11 signers of a proposal are distinct by construction
+    return {"proposals": props, "signatures": n, "group": group, "quorum": quorum, "sigs_per_s": n / dt, "ms_per_call": 1e3 * dt,
+            "best_ms_per_call": 1e3 * min(ts), "proposals_with_quorum": int(qbits.sum()),
+            "accept_bitmap_correct": bool((bits == want_bits).all()), "quorum_bits_equal_generator_rule": bool((qbits == want_q).all()),
+            "devices": info.devices, "shards": info.shards, "wide_keys": wide[0], "wide_bits": wide[1],
+            "last_call_us": {"h2d": info.h2d_us, "kernels": info.kernels_us, "gather": info.gather_us, "total": info.total_us},
+            "note": "PCIe-inclusive (55 MB of records + slots from page-locked host memory per call), registered consenter keys with their wide combs"}
+
+
 def leg_consenter_keys(sbv, synth, torch, stream, steps):
     """configs[3]'s signatures as a replica that has REGISTERED its consenters verifies them (VerifyConsenterSig /
     VerifyConsenterSigBatch: internal/bft/view.go:631, 834; decision replay controller.go:587-633): 550 000 records r|s|hash +
@@ -872,6 +924,7 @@ def main():
                          ("m2_commit_quorum_us", lambda: leg_m2(tuples, n)),
                          ("verify_proposal_k10000_us", leg_proposals),
                          ("replay_550k", lambda: leg_replay_550k(sbv, synth)),
+                         ("replay_550k_keyed", lambda: leg_replay_550k_keyed(sbv, synth)),
                          ("consenter_keys_550k", lambda: leg_consenter_keys(sbv, synth, torch, stream, max(2, args.steps // 2))),
                          ("front_end_msgs_per_s", lambda: leg_front_end(sbv, tuples, valid, n))):
             try:

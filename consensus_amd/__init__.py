@@ -417,6 +417,42 @@ def verify_batch_sharded(host_ptr: int, n: int, out_ptr: int, group: int = 0, qu
     return info
 
 
+def verify_batch_keyed_sharded(rsh_ptr: int, slots_ptr: int, n: int, out_ptr: int, group: int = 0, quorum: int = 0,
+                               quorum_out_ptr: int = 0) -> ShardInfo:
+    """sbv_p256_verify_batch_keyed_sharded on raw pointers: n x 96-byte records r | s | hash + n u32 key slots, split over every
+    initialised device (each holds a replica of the key registry and of the consenters' wide combs); quorum bits by distinct slot."""
+    lib = load()
+    lib.sbv_p256_verify_batch_keyed_sharded.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32,
+                                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ShardInfo)]
+    info = ShardInfo()
+    _check(lib.sbv_p256_verify_batch_keyed_sharded(rsh_ptr, slots_ptr, n, group, quorum, out_ptr, quorum_out_ptr or None, ctypes.byref(info)))
+    return info
+
+
+def verify_msgs_keyed_sharded(msgs, sigs_der, slots, group: int = 0, quorum: int = 0):
+    """sbv_p256_verify_msgs_keyed_sharded: raw messages + DER signatures + key slots over every initialised device, SHA-256 and the
+    DER parse on the devices, uploads in pieces.  Returns (accept bitmap, quorum bitmap or None, ShardInfo)."""
+    lib = load()
+    lib.sbv_p256_verify_msgs_keyed_sharded.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
+                                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                                       ctypes.POINTER(ShardInfo)]
+    n = len(msgs)
+    mo = (ctypes.c_uint64 * (n + 1))()
+    so = (ctypes.c_uint64 * (n + 1))()
+    a = b = 0
+    for i in range(n):
+        mo[i], so[i] = a, b
+        a += len(msgs[i]); b += len(sigs_der[i])
+    mo[n], so[n] = a, b
+    arr = (ctypes.c_uint32 * max(1, n))(*slots)
+    out = ctypes.create_string_buffer(max(1, (n + 7) // 8))
+    props = n // group if group else 0
+    qout = ctypes.create_string_buffer(max(1, (props + 7) // 8)) if group and quorum else None
+    info = ShardInfo()
+    _check(lib.sbv_p256_verify_msgs_keyed_sharded(b"".join(msgs), mo, b"".join(sigs_der), so, arr, n, group, quorum, out, qout, ctypes.byref(info)))
+    return out.raw[:(n + 7) // 8], (qout.raw[:(props + 7) // 8] if qout is not None else None), info
+
+
 def shard_mode(by_key: bool, parts: int = 0) -> None:
     """sbv_shard_mode: how the sharded entry partitions a batch that spans devices (contiguous ranges / by key hash); parts = 0
     means one part per device, more parts than devices run one after another on their device."""

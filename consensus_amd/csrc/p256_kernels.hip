@@ -333,12 +333,14 @@ hipError_t launch_p256_sign(const uint8_t* d_keys, u32 n_keys, const u32* d_key_
 // Message front end: lane i hashes message i (SHA-256) and parses DER signature i,
 // emitting the 96-byte r|s|hash record the registered-key stage A consumes.  Input is variable length,
 // so lanes read their own byte ranges (offset tables); the 96-byte records are written back contiguous.
+// mbase / sbase: the offset-table values of the first byte held in msgs / sigs (a PIECE of a larger batch carries the batch's own
+// offsets: sbv_p256_verify_msgs_keyed_sharded uploads slices of the caller's tables as they are)
 __global__ __launch_bounds__(256) void k_msg_frontend(const uint8_t* __restrict__ msgs, const u64* __restrict__ moff,
                                                       const uint8_t* __restrict__ sigs, const u64* __restrict__ soff,
-                                                      size_t n, u32* __restrict__ rsh) {
+                                                      size_t n, u32* __restrict__ rsh, u64 mbase, u64 sbase) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const u64 m0 = moff[i], m1 = moff[i + 1], s0 = soff[i], s1 = soff[i + 1];
+    const u64 m0 = moff[i] - mbase, m1 = moff[i + 1] - mbase, s0 = soff[i] - sbase, s1 = soff[i + 1] - sbase;
     u32 rec[24];
     msg_frontend_lane(msgs + m0, (size_t)(m1 - m0), sigs + s0, (size_t)(s1 - s0), rec);
 #pragma unroll
@@ -346,9 +348,9 @@ __global__ __launch_bounds__(256) void k_msg_frontend(const uint8_t* __restrict_
 }
 
 hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const uint8_t* d_sigs, const u64* d_soff, size_t n,
-                               u32* d_rsh, hipStream_t stream) {
+                               u32* d_rsh, hipStream_t stream, u64 mbase, u64 sbase) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_msg_frontend, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_msgs, d_moff, d_sigs, d_soff, n, d_rsh);
+    hipLaunchKernelGGL(k_msg_frontend, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_msgs, d_moff, d_sigs, d_soff, n, d_rsh, mbase, sbase);
     return hipGetLastError();
 }
 

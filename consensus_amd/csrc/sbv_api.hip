@@ -12,6 +12,9 @@
 
 #include <dlfcn.h>
 
+#include <functional>
+
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <memory>
@@ -19,6 +22,7 @@
 #include <cstring>
 #include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -143,6 +147,19 @@ Context* default_ctx() {
     std::lock_guard<std::mutex> lk(g_mu);
     return g_def ? g_def : &g_null;
 }
+// The key registry is PROCESS-wide (round 5): types.Signature.ID selects a consenter's key on whichever device a shard of a
+// decision batch lands (internal/bft/viewchanger.go:681-727; BASELINE configs[3]: the commit signatures of 50 000 proposals over the
+// 8 GPUs of a node), so a slot must mean the same key on every device.  g_reg is the one source of slot numbers; every context
+// holds a replica of the combs (8-bit comb per key, wide combs of the widened slots) that sync_registry() brings up to date —
+// eagerly when a key is registered / widened and when a device is initialised later, and once more in front of every sharded
+// registered-key call (a device whose replication failed is retried there and fails THAT call, never silently rejects).
+// Lock order: g_reg_mu -> g_mu -> Context::mu.  Registration takes g_reg_mu exclusively, the sharded registered-key entry shared.
+struct Registry {
+    std::vector<std::string> keys;                    // slot -> the 64 key bytes
+    std::unordered_map<std::string, u32> index;       // key bytes -> slot
+    std::vector<u32> wide;                            // slots named to sbv_p256_widen_keys, in the order they were named
+} g_reg;
+std::shared_mutex g_reg_mu;
 // every initialised context, for the process-wide setters
 std::vector<Context*> live_contexts() {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -616,7 +633,10 @@ Context* context_of(int device, bool create) {          // g_mu held by the call
 }
 }  // namespace
 
+namespace { int sync_registry(Context& c); }
+
 extern "C" int sbv_init(int device) {
+    std::shared_lock<std::shared_mutex> rl(g_reg_mu);
     Context* c;
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -626,7 +646,11 @@ extern "C" int sbv_init(int device) {
     int rc;
     {
         std::lock_guard<std::mutex> lk(c->mu);
+        const bool was_ready = c->ready;
         rc = init_context(*c, device);
+        // a device that joins after keys were registered gets its replica of the registry now (best effort: the sharded
+        // registered-key entry retries and reports)
+        if (rc == SBV_OK && !was_ready && !g_reg.keys.empty()) (void)sync_registry(*c);
     }
     if (rc == SBV_OK) {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -645,7 +669,10 @@ void rccl_teardown();
 struct ShardBuffers { uint8_t* d_gather = nullptr; size_t gather_cap = 0; uint8_t* d_q = nullptr; size_t q_cap = 0;
                       uint8_t* d_on = nullptr; size_t on_cap = 0; uint8_t* d_onq = nullptr; size_t onq_cap = 0;
                       uint8_t* d_full = nullptr; size_t full_cap = 0;          // key-affine mode: the whole batch on every device
-                      uint8_t* d_stage2 = nullptr; size_t stage2_cap = 0; };   // second upload slot of verify_shard (the first is Context::d_tuples)
+                      uint8_t* d_stage2 = nullptr; size_t stage2_cap = 0;      // second upload slot of verify_shard (the first is Context::d_tuples)
+                      uint8_t* d_slots2 = nullptr; size_t slots2_cap = 0;      // ... and of verify_shard_keyed's key slots (the first is Context::d_slots)
+                      uint8_t* d_msgs2 = nullptr; size_t msgs2_cap = 0; uint8_t* d_sigs2 = nullptr; size_t sigs2_cap = 0;       // verify_shard_msgs: second upload slot
+                      uint8_t* d_moff2 = nullptr; size_t moff2_cap = 0; uint8_t* d_soff2 = nullptr; size_t soff2_cap = 0; };  // (the first is Context::d_msgs / d_sigs / d_moff / d_soff)
 ShardBuffers g_shard[kMaxDevices];
 std::mutex g_sharded_mu;
 // staging of the key-affine partition (part_enqueue below), per device, under that device's context lock
@@ -666,6 +693,8 @@ int shutdown_context(Context& c) {
         if (sb.d_onq) (void)hipFree(sb.d_onq);
         if (sb.d_full) (void)hipFree(sb.d_full);
         if (sb.d_stage2) (void)hipFree(sb.d_stage2);
+        if (sb.d_slots2) (void)hipFree(sb.d_slots2);
+        for (uint8_t* p : {sb.d_msgs2, sb.d_sigs2, sb.d_moff2, sb.d_soff2}) if (p) (void)hipFree(p);
         sb = ShardBuffers();
         PartBuffers& pb = g_part[c.device];
         if (pb.d_dense) (void)hipFree(pb.d_dense);
@@ -727,6 +756,8 @@ int shutdown_context(Context& c) {
 }  // namespace
 
 extern "C" int sbv_shutdown(void) {
+    std::unique_lock<std::shared_mutex> rl(g_reg_mu);
+    g_reg = Registry();
     std::lock_guard<std::mutex> lk(g_mu);
     rccl_teardown();
     for (auto& up : g_ctxs) {
@@ -1064,11 +1095,13 @@ int drop_wide_keys(Context& c) {
 extern "C" int sbv_p256_wide_keys(int bits, uint32_t max_keys) {
     if (bits != 0 && bits != SBV_WIDE_BITS_AUTO && (bits < 10 || bits > 20)) return SBV_EINVAL;
     if (max_keys > 4096) return SBV_EINVAL;
+    std::unique_lock<std::shared_mutex> rl(g_reg_mu);
     {
         std::lock_guard<std::mutex> lk(g_set_mu);
         if (bits) g_settings.wide_bits = bits;
         g_settings.wide_max = bits ? max_keys : 0u;
     }
+    if (g_reg.wide.size() > (bits ? max_keys : 0u)) g_reg.wide.resize(bits ? max_keys : 0u);      // what every device keeps (the first ones named)
     int rc = SBV_OK;
     for (Context* cp : live_contexts()) {
         std::lock_guard<std::mutex> lk(cp->mu);
@@ -1090,13 +1123,77 @@ extern "C" int sbv_p256_wide_keys(int bits, uint32_t max_keys) {
     return rc;
 }
 
-extern "C" int sbv_p256_widen_keys(const uint32_t* slots, size_t m) {
-    SBV_ENTER(c);
-    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
-    if (m == 0) return SBV_OK;
-    if (!slots) { g_err = "null pointer"; return SBV_EINVAL; }
+namespace {
+// c.mu held, the device current.  Appends `count` keys (slots c.nkeys, c.nkeys + 1, ...) with their host-built 8-bit combs.  The
+// index is only extended AFTER both uploads succeeded: an entry left behind by a failed call would hand its slot number to the
+// next fresh key, and the first key's ID would then resolve to another signer's comb.
+int append_keys(Context& c, const std::string* keys, const sbv::apt* tabs, const uint8_t* valid, size_t count) {
+    if (count == 0) return SBV_OK;
+    const int rc = ensure_key_capacity(c, c.nkeys + count);
+    if (rc != SBV_OK) return rc;
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_ktab + c.nkeys * (size_t)SBV_KEYTAB_ENTRIES, tabs, count * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt), hipMemcpyHostToDevice));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_kvalid + c.nkeys, valid, count, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < count; ++i) c.key_index.emplace(keys[i], (u32)(c.nkeys + i));
+    c.nkeys += count;
+    return SBV_OK;
+}
+// the 8-bit combs of `count` keys, built on the host (one-time setup, the same field code as the kernels), in parallel
+void build_key_tables(const std::string* keys, size_t count, std::vector<sbv::apt>& tabs, std::vector<uint8_t>& valid) {
+    tabs.resize(count * (size_t)SBV_KEYTAB_ENTRIES);
+    valid.assign(count, 0);
+    size_t nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 64) nt = 64;
+    if (nt > count) nt = count;
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            for (size_t j = t; j < count; j += nt)
+                valid[j] = sbv::host_build_key_table((const uint8_t*)keys[j].data(), &tabs[j * (size_t)SBV_KEYTAB_ENTRIES]) ? 1 : 0;
+        });
+    for (auto& x : th) x.join();
+}
+// g_reg_mu (shared or exclusive) and c.mu held.  Brings device c's replica of the registry up to the process-wide one: the 8-bit
+// combs of the slots it has not seen, then the wide combs of the widened slots it lacks (built on the device: milliseconds).
+int sync_registry(Context& c) {
+    if (!c.ready) { g_err = "device not initialised"; return SBV_ENOTINIT; }
+    if (c.nkeys == g_reg.keys.size() && c.wide_slots.size() >= (g_reg.wide.size() < (size_t)c.kwide_max ? g_reg.wide.size() : (size_t)c.kwide_max)) return SBV_OK;
     HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
-    return widen_slots(c, std::vector<u32>(slots, slots + m));
+    if (c.nkeys > g_reg.keys.size()) { g_err = "device registry ahead of the process registry"; return SBV_EDEVICE; }
+    if (c.nkeys < g_reg.keys.size()) {
+        const size_t first = c.nkeys, count = g_reg.keys.size() - first;
+        std::vector<sbv::apt> tabs;
+        std::vector<uint8_t> valid;
+        build_key_tables(g_reg.keys.data() + first, count, tabs, valid);
+        const int rc = append_keys(c, g_reg.keys.data() + first, tabs.data(), valid.data(), count);
+        if (rc != SBV_OK) return rc;
+    }
+    return g_reg.wide.empty() ? SBV_OK : widen_slots(c, g_reg.wide);      // skips the slots that are wide already, keeps the order
+}
+}  // namespace
+
+extern "C" int sbv_p256_widen_keys(const uint32_t* slots, size_t m) {
+    std::unique_lock<std::shared_mutex> rl(g_reg_mu);
+    Context* def = default_ctx();
+    {
+        std::lock_guard<std::mutex> lk(def->mu);
+        Context& c = *def;
+        if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+        if (m == 0) return SBV_OK;
+        if (!slots) { g_err = "null pointer"; return SBV_EINVAL; }
+        HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+        const int rc = widen_slots(c, std::vector<u32>(slots, slots + m));
+        if (rc != SBV_OK) return rc;
+    }
+    for (size_t i = 0; i < m; ++i)
+        if (std::find(g_reg.wide.begin(), g_reg.wide.end(), slots[i]) == g_reg.wide.end()) g_reg.wide.push_back(slots[i]);
+    // the other devices of the node: best effort now, retried by the sharded registered-key entry
+    for (Context* cp : live_contexts()) {
+        if (cp == def) continue;
+        std::lock_guard<std::mutex> lk(cp->mu);
+        if (cp->ready) (void)sync_registry(*cp);
+    }
+    return SBV_OK;
 }
 
 // Diagnostics: is the device-resident wide comb of `slot` byte for byte what the host builder (the kernels' field code on the CPU,
@@ -1131,51 +1228,51 @@ extern "C" int sbv_p256_wide_key_stats(uint32_t out[4]) {
 }
 
 extern "C" int sbv_p256_register_keys(const uint8_t* keys, size_t m, uint32_t* slots_out) {
-    SBV_ENTER(c);
-    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
-    if (m == 0) return SBV_OK;
-    if (!keys || !slots_out) { g_err = "null pointer"; return SBV_EINVAL; }
-    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
-    // de-duplicate, assign slots.  The index is only extended AFTER both uploads succeeded: an entry left behind by a
-    // failed call would hand its slot number to the next fresh key, and the first key's ID would then resolve to another
-    // signer's comb.
-    std::vector<size_t> fresh;                      // indices into keys[] that need a table
-    std::unordered_map<std::string, u32> pending;
-    for (size_t i = 0; i < m; ++i) {
-        const std::string k((const char*)keys + 64 * i, 64);
-        auto it = c.key_index.find(k);
-        if (it != c.key_index.end()) { slots_out[i] = it->second; continue; }
-        auto pt = pending.find(k);
-        if (pt != pending.end()) { slots_out[i] = pt->second; continue; }
-        const u32 slot = (u32)(c.nkeys + fresh.size());
-        pending.emplace(k, slot);
-        fresh.push_back(i);
-        slots_out[i] = slot;
-    }
-    if (fresh.empty()) return SBV_OK;
-    int rc = ensure_key_capacity(c, c.nkeys + fresh.size());
-    if (rc != SBV_OK) return rc;
-    // tables are built on the host (one-time setup, same field code as the kernels), in parallel
-    std::vector<sbv::apt> tabs(fresh.size() * (size_t)SBV_KEYTAB_ENTRIES);
-    std::vector<uint8_t> valid(fresh.size(), 0);
+    std::unique_lock<std::shared_mutex> rl(g_reg_mu);
+    Context* def = default_ctx();
+    std::vector<std::string> fresh;                 // keys that need a slot, in slot order
     {
-        size_t nt = std::thread::hardware_concurrency();
-        if (nt == 0) nt = 1;
-        if (nt > 64) nt = 64;
-        if (nt > fresh.size()) nt = fresh.size();
-        std::vector<std::thread> th;
-        for (size_t t = 0; t < nt; ++t)
-            th.emplace_back([&, t] {
-                for (size_t j = t; j < fresh.size(); j += nt)
-                    valid[j] = sbv::host_build_key_table(keys + 64 * fresh[j], &tabs[j * (size_t)SBV_KEYTAB_ENTRIES]) ? 1 : 0;
-            });
-        for (auto& x : th) x.join();
+        std::lock_guard<std::mutex> lk(def->mu);
+        Context& c = *def;
+        if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+        if (m == 0) return SBV_OK;
+        if (!keys || !slots_out) { g_err = "null pointer"; return SBV_EINVAL; }
+        HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+        if (c.nkeys != g_reg.keys.size()) {           // an earlier replication of the default device failed half-way: finish it first
+            const int rc = sync_registry(c);
+            if (rc != SBV_OK) return rc;
+        }
+        // de-duplicate, assign slots from the process-wide index
+        std::unordered_map<std::string, u32> pending;
+        for (size_t i = 0; i < m; ++i) {
+            const std::string k((const char*)keys + 64 * i, 64);
+            auto it = g_reg.index.find(k);
+            if (it != g_reg.index.end()) { slots_out[i] = it->second; continue; }
+            auto pt = pending.find(k);
+            if (pt != pending.end()) { slots_out[i] = pt->second; continue; }
+            const u32 slot = (u32)(g_reg.keys.size() + fresh.size());
+            pending.emplace(k, slot);
+            fresh.push_back(k);
+            slots_out[i] = slot;
+        }
+        if (fresh.empty()) return SBV_OK;
+        std::vector<sbv::apt> tabs;
+        std::vector<uint8_t> valid;
+        build_key_tables(fresh.data(), fresh.size(), tabs, valid);
+        // the default device first: its failure fails the call and leaves the registry as it was
+        const int rc = append_keys(c, fresh.data(), tabs.data(), valid.data(), fresh.size());
+        if (rc != SBV_OK) return rc;
+        for (const std::string& k : fresh) { g_reg.index.emplace(k, (u32)g_reg.keys.size()); g_reg.keys.push_back(k); }
+        // the other devices of the node take the same tables (built once): best effort now, retried by the sharded registered-key entry
+        for (Context* cp : live_contexts()) {
+            if (cp == def) continue;
+            std::lock_guard<std::mutex> lk2(cp->mu);
+            if (!cp->ready || hipSetDevice(cp->device) != hipSuccess) continue;
+            if (cp->nkeys + fresh.size() == g_reg.keys.size()) (void)append_keys(*cp, fresh.data(), tabs.data(), valid.data(), fresh.size());
+            else (void)sync_registry(*cp);
+        }
+        (void)hipSetDevice(c.device);
     }
-    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_ktab + c.nkeys * (size_t)SBV_KEYTAB_ENTRIES, tabs.data(), tabs.size() * sizeof(sbv::apt),
-                                   hipMemcpyHostToDevice));
-    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_kvalid + c.nkeys, valid.data(), valid.size(), hipMemcpyHostToDevice));
-    for (auto& kv : pending) c.key_index.emplace(kv.first, kv.second);
-    c.nkeys += fresh.size();
     return SBV_OK;
 }
 
@@ -1185,15 +1282,24 @@ extern "C" int sbv_p256_key_count(void) {
 }
 
 extern "C" int sbv_p256_clear_keys(void) {
-    SBV_ENTER(c);
-    if (!c.ready) return SBV_ENOTINIT;
-    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
-    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
-    c.key_index.clear();
-    c.nkeys = 0;
-    if (c.d_kwidx && c.key_cap) HIP_TRY(SBV_EDEVICE, hipMemset(c.d_kwidx, 0xFF, c.key_cap * sizeof(u32)));
-    c.wide_slots.clear();        // the allocation stays for the next registry
-    return SBV_OK;
+    std::unique_lock<std::shared_mutex> rl(g_reg_mu);
+    Context* def = default_ctx();
+    { std::lock_guard<std::mutex> lk(def->mu); if (!def->ready) return SBV_ENOTINIT; }
+    int rc = SBV_OK;
+    for (Context* cp : live_contexts()) {
+        std::lock_guard<std::mutex> lk(cp->mu);
+        Context& c = *cp;
+        if (!c.ready) continue;
+        hipError_t e = hipSetDevice(c.device);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        c.key_index.clear();
+        c.nkeys = 0;
+        if (e == hipSuccess && c.d_kwidx && c.key_cap) e = hipMemset(c.d_kwidx, 0xFF, c.key_cap * sizeof(u32));
+        c.wide_slots.clear();        // the allocation stays for the next registry
+        if (e != hipSuccess) rc = fail(SBV_EDEVICE, "sbv_p256_clear_keys", e);
+    }
+    g_reg = Registry();
+    return rc;
 }
 
 extern "C" int sbv_p256_verify_batch_keyed_dev(const void* d_rsh, const void* d_slots, size_t n, void* d_bitmap, void* hip_stream) {
@@ -2143,6 +2249,207 @@ int verify_shard(Context& c, const uint8_t* h_tuples, size_t m, size_t group, u3
     return rc;
 }
 
+// The registered-key form of k_quorum_bits: signature t of a proposal carries a key SLOT (equal keys share a slot: sbv_p256_register_keys),
+// so ">= quorum accepted signatures by distinct signers" (internal/bft/viewchanger.go:681-727) counts distinct accepted slots.
+__global__ __launch_bounds__(256) void k_quorum_bits_slots(const u32* __restrict__ slots, const uint8_t* __restrict__ bitmap,
+                                                           size_t nprops, u32 group, u32 quorum, uint8_t* __restrict__ qbitmap) {
+    const size_t pidx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    bool decided = false;
+    if (pidx < nprops) {
+        const size_t first = pidx * group;
+        u32 count = 0;
+        for (u32 i = 0; i < group; ++i) {
+            const size_t t = first + i;
+            if (!((bitmap[t >> 3] >> (t & 7)) & 1u)) continue;
+            const u32 si = slots[t];
+            bool dup = false;
+            for (u32 j = 0; j < i && !dup; ++j) {
+                const size_t u = first + j;
+                dup = ((bitmap[u >> 3] >> (u & 7)) & 1u) && slots[u] == si;
+            }
+            if (!dup) ++count;
+        }
+        decided = count >= quorum;
+    }
+    const unsigned long long m = __ballot(decided);
+    const int lane = threadIdx.x & 63;
+    const size_t wave_first = pidx - (size_t)lane;
+    if (lane < 8) {
+        const size_t byte = (wave_first >> 3) + (size_t)lane;
+        if (byte < ((nprops + 7) >> 3)) qbitmap[byte] = (uint8_t)(m >> (8 * lane));
+    }
+}
+
+// Tuples per upload piece of a registered-key shard (SBV_SHARD_PIECE_KEYED).  No table is built per batch, so a piece only has to
+// fill the device: 2^17 signatures = two wavefronts on every SIMD, above the 8-lanes-per-signature latency form's range.
+size_t g_shard_piece_keyed = (size_t)1 << 17;
+
+// One device's share of a sharded registered-key call; c.mu and g_reg_mu (shared) held.  The same two upload slots as verify_shard:
+// 96-byte records r | s | hash and their 4-byte slots — 100 B per signature over PCIe instead of 160 — of piece i + 1 travel on
+// the copy stream beside stage A + B of piece i; quorum bits by distinct slot.
+int verify_shard_keyed(Context& c, const uint8_t* h_rsh, const u32* h_slots, size_t m, size_t group, u32 quorum, uint8_t* d_slot, uint8_t* d_qslot,
+                       double* h2d_us, double* kern_us) {
+    if (!c.ready) { g_err = "device not initialised"; return SBV_ENOTINIT; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    int rc = sync_registry(c);                 // this device's replica of the key registry (a no-op when it is current)
+    if (rc != SBV_OK) return rc;
+    if (c.nkeys == 0) { g_err = "no keys registered"; return SBV_EINVAL; }
+    const size_t gran = shard_granule(group);
+    size_t chunk = (g_shard_piece_keyed < kMaxChunk ? g_shard_piece_keyed : kMaxChunk) / gran * gran;
+    if (chunk == 0) chunk = kMaxChunk / gran * gran;
+    if (chunk == 0) { g_err = "group too large"; return SBV_EINVAL; }
+    const size_t pieces = (m + chunk - 1) / chunk;
+    rc = ensure_capacity(c, m < chunk ? m : chunk);
+    if (rc != SBV_OK) return rc;
+    ShardBuffers& sbuf = g_shard[c.device];
+    if (pieces > 1) {
+        rc = grow_bytes(sbuf.d_stage2, sbuf.stage2_cap, chunk * SBV_TUPLE_BYTES);
+        if (rc == SBV_OK) rc = grow_bytes(sbuf.d_slots2, sbuf.slots2_cap, chunk * sizeof(u32));
+        if (rc != SBV_OK) return rc;
+        if (!c.copy_stream && hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking) != hipSuccess) { g_err = "hipStreamCreate failed"; return SBV_EDEVICE; }
+    }
+    hipStream_t up = pieces > 1 ? c.copy_stream : c.stream;
+    uint8_t* stage[2] = {c.d_tuples, pieces > 1 ? sbuf.d_stage2 : c.d_tuples};
+    u32* sstage[2] = {c.d_slots, pieces > 1 ? reinterpret_cast<u32*>(sbuf.d_slots2) : c.d_slots};
+    std::vector<hipEvent_t> ev(3 * pieces, nullptr);
+    auto drop_events = [&] { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
+    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) { drop_events(); g_err = "hipEventCreate failed"; return SBV_EDEVICE; }
+    hipError_t he = hipSuccess;
+    auto step = [&](hipError_t r) { if (he == hipSuccess) he = r; };
+    if (c.busy_valid) {
+        step(hipStreamWaitEvent(c.stream, c.busy, 0));
+        if (pieces > 1) step(hipStreamWaitEvent(up, c.busy, 0));
+    }
+    size_t i = 0;
+    for (size_t off = 0; off < m && rc == SBV_OK && he == hipSuccess; off += chunk, ++i) {
+        const size_t k = m - off < chunk ? m - off : chunk;
+        uint8_t* d_in = stage[i & 1];
+        u32* d_sl = sstage[i & 1];
+        if (i >= 2) step(hipStreamWaitEvent(up, ev[3 * (i - 2) + 2], 0));       // the slot's previous kernels are done with it
+        step(hipEventRecord(ev[3 * i], up));
+        step(hipMemcpyAsync(d_in, h_rsh + off * 96, k * 96, hipMemcpyHostToDevice, up));
+        step(hipMemcpyAsync(d_sl, h_slots + off, k * sizeof(u32), hipMemcpyHostToDevice, up));
+        step(hipEventRecord(ev[3 * i + 1], up));
+        if (pieces > 1) step(hipStreamWaitEvent(c.stream, ev[3 * i + 1], 0));
+        if (he != hipSuccess) break;
+        rc = enqueue_keyed(c, d_in, d_sl, k, d_slot + off / 8, c.stream, nullptr);
+        if (rc != SBV_OK) break;
+        if (d_qslot && group > 0 && quorum > 0) {
+            const size_t props = k / group;
+            if (props)
+                hipLaunchKernelGGL(k_quorum_bits_slots, dim3((unsigned)((props + 255) / 256)), dim3(256), 0, c.stream, d_sl, d_slot + off / 8,
+                                   props, (u32)group, quorum, d_qslot + (off / group) / 8);
+        }
+        step(hipEventRecord(ev[3 * i + 2], c.stream));
+    }
+    if (pieces > 1) step(hipStreamSynchronize(up));
+    step(hipStreamSynchronize(c.stream));
+    if (rc == SBV_OK && he != hipSuccess) rc = fail(SBV_EDEVICE, "verify_shard_keyed", he);
+    if (rc == SBV_OK) {
+        if (h2d_us) for (size_t j = 0; j < pieces; ++j) *h2d_us += 1e3 * ms_between(ev[3 * j], ev[3 * j + 1]);
+        if (kern_us) *kern_us += 1e3 * ms_between(ev[1], ev[3 * (pieces - 1) + 2]);
+    }
+    drop_events();
+    c.busy_valid = false;
+    return rc;
+}
+
+// One device's share of a sharded raw-messages call (SURVEY.md section 8f row 1 across the node); c.mu and g_reg_mu (shared) held.
+// Piece i = signatures [first + i * chunk, ...): its message bytes, DER signatures, the slices of the caller's two offset tables as
+// they are (the kernel subtracts the slice's base) and its key slots go up on the copy stream into one of two staging sets while
+// SHA-256 + DER (k_msg_frontend), stage A and stage B of the previous piece run on c.stream.  The front end's records land in
+// Context::d_tuples: kernels of all pieces are ordered on one stream, so one record buffer serves.
+int verify_shard_msgs(Context& c, const uint8_t* msgs, const uint64_t* moff, const uint8_t* sigs, const uint64_t* soff, const u32* h_slots,
+                      size_t first, size_t m, size_t group, u32 quorum, uint8_t* d_slot, uint8_t* d_qslot, double* h2d_us, double* kern_us) {
+    if (!c.ready) { g_err = "device not initialised"; return SBV_ENOTINIT; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    int rc = sync_registry(c);
+    if (rc != SBV_OK) return rc;
+    if (c.nkeys == 0) { g_err = "no keys registered"; return SBV_EINVAL; }
+    const size_t gran = shard_granule(group);
+    size_t chunk = (g_shard_piece_keyed < kMaxChunk ? g_shard_piece_keyed : kMaxChunk) / gran * gran;
+    if (chunk == 0) chunk = kMaxChunk / gran * gran;
+    if (chunk == 0) { g_err = "group too large"; return SBV_EINVAL; }
+    const size_t pieces = (m + chunk - 1) / chunk;
+    size_t max_mb = 0, max_sb = 0;                 // staging for the largest piece, grown before anything is enqueued
+    for (size_t off = 0; off < m; off += chunk) {
+        const size_t k = m - off < chunk ? m - off : chunk;
+        const size_t mb = (size_t)(moff[first + off + k] - moff[first + off]), sb = (size_t)(soff[first + off + k] - soff[first + off]);
+        if (mb > max_mb) max_mb = mb;
+        if (sb > max_sb) max_sb = sb;
+    }
+    const size_t kmax = m < chunk ? m : chunk;
+    rc = ensure_capacity(c, kmax);
+    if (rc == SBV_OK) rc = grow(c.d_msgs, c.msgs_cap, max_mb + 16);
+    if (rc == SBV_OK) rc = grow(c.d_sigs, c.sigs_cap, max_sb + 16);
+    if (rc == SBV_OK) rc = grow(c.d_moff, c.moff_cap, kmax + 1);
+    if (rc == SBV_OK) rc = grow(c.d_soff, c.soff_cap, kmax + 1);
+    ShardBuffers& sbuf = g_shard[c.device];
+    if (rc == SBV_OK && pieces > 1) {
+        rc = grow_bytes(sbuf.d_msgs2, sbuf.msgs2_cap, max_mb + 16);
+        if (rc == SBV_OK) rc = grow_bytes(sbuf.d_sigs2, sbuf.sigs2_cap, max_sb + 16);
+        if (rc == SBV_OK) rc = grow_bytes(sbuf.d_moff2, sbuf.moff2_cap, (kmax + 1) * sizeof(uint64_t));
+        if (rc == SBV_OK) rc = grow_bytes(sbuf.d_soff2, sbuf.soff2_cap, (kmax + 1) * sizeof(uint64_t));
+        if (rc == SBV_OK) rc = grow_bytes(sbuf.d_slots2, sbuf.slots2_cap, kmax * sizeof(u32));
+        if (rc == SBV_OK && !c.copy_stream && hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking) != hipSuccess) { g_err = "hipStreamCreate failed"; rc = SBV_EDEVICE; }
+    }
+    if (rc != SBV_OK) return rc;
+    hipStream_t up = pieces > 1 ? c.copy_stream : c.stream;
+    const bool two = pieces > 1;
+    uint8_t* st_msgs[2] = {c.d_msgs, two ? sbuf.d_msgs2 : c.d_msgs};
+    uint8_t* st_sigs[2] = {c.d_sigs, two ? sbuf.d_sigs2 : c.d_sigs};
+    uint64_t* st_moff[2] = {c.d_moff, two ? reinterpret_cast<uint64_t*>(sbuf.d_moff2) : c.d_moff};
+    uint64_t* st_soff[2] = {c.d_soff, two ? reinterpret_cast<uint64_t*>(sbuf.d_soff2) : c.d_soff};
+    u32* st_slots[2] = {c.d_slots, two ? reinterpret_cast<u32*>(sbuf.d_slots2) : c.d_slots};
+    std::vector<hipEvent_t> ev(3 * pieces, nullptr);
+    auto drop_events = [&] { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
+    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) { drop_events(); g_err = "hipEventCreate failed"; return SBV_EDEVICE; }
+    hipError_t he = hipSuccess;
+    auto step = [&](hipError_t r) { if (he == hipSuccess) he = r; };
+    if (c.busy_valid) {
+        step(hipStreamWaitEvent(c.stream, c.busy, 0));
+        if (two) step(hipStreamWaitEvent(up, c.busy, 0));
+    }
+    size_t i = 0;
+    for (size_t off = 0; off < m && rc == SBV_OK && he == hipSuccess; off += chunk, ++i) {
+        const size_t k = m - off < chunk ? m - off : chunk;
+        const size_t a = first + off;
+        const uint64_t mbase = moff[a], sbase = soff[a];
+        const size_t mb = (size_t)(moff[a + k] - mbase), sb = (size_t)(soff[a + k] - sbase);
+        const int w = (int)(i & 1);
+        if (i >= 2) step(hipStreamWaitEvent(up, ev[3 * (i - 2) + 2], 0));       // the staging set's previous kernels are done with it
+        step(hipEventRecord(ev[3 * i], up));
+        if (mb) step(hipMemcpyAsync(st_msgs[w], msgs + mbase, mb, hipMemcpyHostToDevice, up));
+        if (sb) step(hipMemcpyAsync(st_sigs[w], sigs + sbase, sb, hipMemcpyHostToDevice, up));
+        step(hipMemcpyAsync(st_moff[w], moff + a, (k + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
+        step(hipMemcpyAsync(st_soff[w], soff + a, (k + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
+        step(hipMemcpyAsync(st_slots[w], h_slots + a, k * sizeof(u32), hipMemcpyHostToDevice, up));
+        step(hipEventRecord(ev[3 * i + 1], up));
+        if (two) step(hipStreamWaitEvent(c.stream, ev[3 * i + 1], 0));
+        if (he != hipSuccess) break;
+        step(sbv::launch_msg_frontend(st_msgs[w], st_moff[w], st_sigs[w], st_soff[w], k, reinterpret_cast<u32*>(c.d_tuples), c.stream, mbase, sbase));
+        if (he != hipSuccess) break;
+        rc = enqueue_keyed(c, c.d_tuples, st_slots[w], k, d_slot + off / 8, c.stream, nullptr);
+        if (rc != SBV_OK) break;
+        if (d_qslot && group > 0 && quorum > 0) {
+            const size_t props = k / group;
+            if (props)
+                hipLaunchKernelGGL(k_quorum_bits_slots, dim3((unsigned)((props + 255) / 256)), dim3(256), 0, c.stream, st_slots[w], d_slot + off / 8,
+                                   props, (u32)group, quorum, d_qslot + (off / group) / 8);
+        }
+        step(hipEventRecord(ev[3 * i + 2], c.stream));
+    }
+    if (two) step(hipStreamSynchronize(up));
+    step(hipStreamSynchronize(c.stream));
+    if (rc == SBV_OK && he != hipSuccess) rc = fail(SBV_EDEVICE, "verify_shard_msgs", he);
+    if (rc == SBV_OK) {
+        if (h2d_us) for (size_t j = 0; j < pieces; ++j) *h2d_us += 1e3 * ms_between(ev[3 * j], ev[3 * j + 1]);
+        if (kern_us) *kern_us += 1e3 * ms_between(ev[1], ev[3 * (pieces - 1) + 2]);
+    }
+    drop_events();
+    c.busy_valid = false;
+    return rc;
+}
 
 }  // namespace
 
@@ -2205,6 +2512,7 @@ extern "C" int sbv_init_all(void) {
     }
     if (const char* e = getenv("SBV_SHARD_MIN")) { const long v = atol(e); if (v > 0) { g_shard_min = g_shard_min_few = (size_t)v; g_shard_min_env = true; } }
     if (const char* e = getenv("SBV_SHARD_PIECE")) { const long v = atol(e); if (v >= 512) g_shard_piece = (size_t)v; }
+    if (const char* e = getenv("SBV_SHARD_PIECE_KEYED")) { const long v = atol(e); if (v >= 512) g_shard_piece_keyed = (size_t)v; }
     if (const char* e = getenv("SBV_SHARD_MODE")) g_shard_mode.store(strcmp(e, "keys") == 0 ? 1 : 0);
     if (const char* e = getenv("SBV_SHARD_PARTS")) { const long v = atol(e); if (v >= 0 && v <= 64) g_shard_parts.store((unsigned)v); }
     const char* force = getenv("SBV_RCCL");
@@ -2340,29 +2648,16 @@ int sharded_by_key(const uint8_t* tuples, size_t n, size_t group, u32 quorum, ui
 }
 }  // namespace
 
-extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, size_t group, uint32_t quorum, uint8_t* accept_bitmap,
-                                             uint8_t* quorum_bitmap, sbv_shard_info* info) {
-    if (info) memset(info, 0, sizeof *info);
-    if (n == 0) return SBV_OK;
-    if (!tuples || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
-    if (quorum_bitmap && (group == 0 || quorum == 0 || quorum > group || group > 64)) { g_err = "quorum bits need 0 < quorum <= group <= 64"; return SBV_EINVAL; }
-    const auto t0 = std::chrono::steady_clock::now();
-    std::vector<int> devs;
-    bool use_rccl;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        devs = g_devs;
-        if (devs.empty() && g_def) devs.push_back(g_def->device);     // sbv_init only: one device
-        use_rccl = g_rccl.ready && g_rccl.comms.size() == devs.size();   // the communicator spans exactly these devices
-    }
-    if (devs.empty()) { g_err = "sbv_init_all / sbv_init has not succeeded"; return SBV_ENOTINIT; }
-    if (g_shard_mode.load() == 1) {
-        unsigned parts = g_shard_parts.load();
-        if (parts == 0) parts = (unsigned)devs.size();
-        if (parts > 1 && n >= parts) return sharded_by_key(tuples, n, group, quorum, accept_bitmap, quorum_bitmap, info, devs, parts, use_rccl);
-    }
+namespace {
+// The contiguous partition shared by the generic and the registered-key sharded entries: plan, one host thread per shard (each
+// under its device's lock, running `shard_fn` on tuples [first, first + count) with the device's slot of the gather buffer and its
+// quorum slot), the in-place all-gather when more than one device took part, the final copies.
+using ShardFn = std::function<int(Context&, size_t first, size_t count, uint8_t* d_bits, uint8_t* d_q, double* h2d_us, double* kern_us)>;
+int sharded_contiguous(size_t n, size_t group, u32 quorum, uint8_t* accept_bitmap, uint8_t* quorum_bitmap, sbv_shard_info* info,
+                       const std::vector<int>& devs, bool use_rccl, size_t min_per_device, const ShardFn& shard_fn,
+                       std::chrono::steady_clock::time_point t0) {
     size_t first[kMaxDevices + 1];
-    const size_t shards = sbv_shard_plan(n, (int)devs.size(), group, sbv_shard_min_for(tuples, n, group), first);
+    const size_t shards = sbv_shard_plan(n, (int)devs.size(), group, min_per_device, first);
     const size_t per = shards > 1 ? first[1] - first[0] : ((n + shard_granule(group) - 1) / shard_granule(group) * shard_granule(group));
     const size_t sb = per / 8;                                          // bitmap bytes per shard slot
     const size_t qb = group ? (per / group + 7) / 8 : 0;                // quorum bytes per shard slot
@@ -2398,8 +2693,7 @@ extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, si
         if (rc == SBV_OK) rc = grow_bytes(d_bits, bits_cap, sb * ranks + 64);
         if (rc == SBV_OK && quorum_bitmap) rc = grow_bytes(d_qb, qb_cap, qb + 64);
         if (rc == SBV_OK)
-            rc = verify_shard(*c, tuples + first[k] * SBV_TUPLE_BYTES, first[k + 1] - first[k], group, quorum, d_bits + k * sb,
-                              quorum_bitmap ? d_qb : nullptr, &h2d[k], &kern[k]);
+            rc = shard_fn(*c, first[k], first[k + 1] - first[k], d_bits + k * sb, quorum_bitmap ? d_qb : nullptr, &h2d[k], &kern[k]);
         if (rc == SBV_OK && quorum_bitmap) {
             const size_t props = (first[k + 1] - first[k]) / group;
             if (props && hipMemcpy(quorum_bitmap + (first[k] / group) / 8, d_qb, (props + 7) / 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SBV_EDEVICE;
@@ -2454,6 +2748,100 @@ extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, si
         info->total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     }
     return SBV_OK;
+}
+}  // namespace
+
+extern "C" int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, size_t group, uint32_t quorum, uint8_t* accept_bitmap,
+                                             uint8_t* quorum_bitmap, sbv_shard_info* info) {
+    if (info) memset(info, 0, sizeof *info);
+    if (n == 0) return SBV_OK;
+    if (!tuples || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
+    if (quorum_bitmap && (group == 0 || quorum == 0 || quorum > group || group > 64)) { g_err = "quorum bits need 0 < quorum <= group <= 64"; return SBV_EINVAL; }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<int> devs;
+    bool use_rccl;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        devs = g_devs;
+        if (devs.empty() && g_def) devs.push_back(g_def->device);     // sbv_init only: one device
+        use_rccl = g_rccl.ready && g_rccl.comms.size() == devs.size();   // the communicator spans exactly these devices
+    }
+    if (devs.empty()) { g_err = "sbv_init_all / sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (g_shard_mode.load() == 1) {
+        unsigned parts = g_shard_parts.load();
+        if (parts == 0) parts = (unsigned)devs.size();
+        if (parts > 1 && n >= parts) return sharded_by_key(tuples, n, group, quorum, accept_bitmap, quorum_bitmap, info, devs, parts, use_rccl);
+    }
+    return sharded_contiguous(n, group, quorum, accept_bitmap, quorum_bitmap, info, devs, use_rccl, sbv_shard_min_for(tuples, n, group),
+                              [&](Context& c, size_t first, size_t count, uint8_t* d_bits, uint8_t* d_q, double* h2d_us, double* kern_us) {
+                                  return verify_shard(c, tuples + first * SBV_TUPLE_BYTES, count, group, quorum, d_bits, d_q, h2d_us, kern_us);
+                              }, t0);
+}
+
+// The registered-key form of the sharded entry (round 5; include/sbv.h): the same plan, pieces, quorum bits and collective over
+// 96-byte records + key slots, every device holding a replica of the registry and of the consenters' wide combs.
+extern "C" int sbv_p256_verify_batch_keyed_sharded(const uint8_t* rsh, const uint32_t* slots, size_t n, size_t group, uint32_t quorum,
+                                                   uint8_t* accept_bitmap, uint8_t* quorum_bitmap, sbv_shard_info* info) {
+    if (info) memset(info, 0, sizeof *info);
+    if (n == 0) return SBV_OK;
+    if (!rsh || !slots || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
+    if (quorum_bitmap && (group == 0 || quorum == 0 || quorum > group || group > 64)) { g_err = "quorum bits need 0 < quorum <= group <= 64"; return SBV_EINVAL; }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::shared_lock<std::shared_mutex> rl(g_reg_mu);        // the registry does not change under a call that replicates / reads it
+    std::vector<int> devs;
+    bool use_rccl;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        devs = g_devs;
+        if (devs.empty() && g_def) devs.push_back(g_def->device);
+        use_rccl = g_rccl.ready && g_rccl.comms.size() == devs.size();
+    }
+    if (devs.empty()) { g_err = "sbv_init_all / sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (g_reg.keys.empty()) { g_err = "no keys registered"; return SBV_EINVAL; }
+    // nothing is built per batch on this path (the combs are resident), so the few-signers minimum applies whatever the registry holds
+    return sharded_contiguous(n, group, quorum, accept_bitmap, quorum_bitmap, info, devs, use_rccl, g_shard_min_env ? g_shard_min : g_shard_min_few,
+                              [&](Context& c, size_t first, size_t count, uint8_t* d_bits, uint8_t* d_q, double* h2d_us, double* kern_us) {
+                                  return verify_shard_keyed(c, rsh + first * 96, slots + first, count, group, quorum, d_bits, d_q, h2d_us, kern_us);
+                              }, t0);
+}
+
+// Raw messages + DER signatures + key slots, sharded (SHA-256 and the DER parse on every device's share).
+extern "C" int sbv_p256_verify_msgs_keyed_sharded(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* sigs, const uint64_t* sig_offsets,
+                                                  const uint32_t* slots, size_t n, size_t group, uint32_t quorum, uint8_t* accept_bitmap,
+                                                  uint8_t* quorum_bitmap, sbv_shard_info* info) {
+    if (info) memset(info, 0, sizeof *info);
+    if (n == 0) return SBV_OK;
+    if (!msg_offsets || !sig_offsets || !slots || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
+    if (quorum_bitmap && (group == 0 || quorum == 0 || quorum > group || group > 64)) { g_err = "quorum bits need 0 < quorum <= group <= 64"; return SBV_EINVAL; }
+    // the devices dereference the offset tables: they must start at 0 and never decrease
+    if (msg_offsets[0] != 0 || sig_offsets[0] != 0) { g_err = "offset tables must start at 0"; return SBV_EINVAL; }
+    {
+        std::atomic<int> bad(0);
+        const size_t nt = n > ((size_t)1 << 16) ? 8 : 1;             // 2 x 550 000 comparisons: a few threads
+        std::vector<std::thread> th;
+        auto scan = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (msg_offsets[i + 1] < msg_offsets[i] || sig_offsets[i + 1] < sig_offsets[i]) { bad.store(1); return; } };
+        for (size_t t = 1; t < nt; ++t) th.emplace_back(scan, n * t / nt, n * (t + 1) / nt);
+        scan(0, n / nt);
+        for (auto& t : th) t.join();
+        if (bad.load()) { g_err = "offset table is not monotone"; return SBV_EINVAL; }
+    }
+    if ((msg_offsets[n] && !msgs) || (sig_offsets[n] && !sigs)) { g_err = "null pointer"; return SBV_EINVAL; }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::shared_lock<std::shared_mutex> rl(g_reg_mu);
+    std::vector<int> devs;
+    bool use_rccl;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        devs = g_devs;
+        if (devs.empty() && g_def) devs.push_back(g_def->device);
+        use_rccl = g_rccl.ready && g_rccl.comms.size() == devs.size();
+    }
+    if (devs.empty()) { g_err = "sbv_init_all / sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    if (g_reg.keys.empty()) { g_err = "no keys registered"; return SBV_EINVAL; }
+    return sharded_contiguous(n, group, quorum, accept_bitmap, quorum_bitmap, info, devs, use_rccl, g_shard_min_env ? g_shard_min : g_shard_min_few,
+                              [&](Context& c, size_t first, size_t count, uint8_t* d_bits, uint8_t* d_q, double* h2d_us, double* kern_us) {
+                                  return verify_shard_msgs(c, msgs, msg_offsets, sigs, sig_offsets, slots, first, count, group, quorum, d_bits, d_q, h2d_us, kern_us);
+                              }, t0);
 }
 
 extern "C" int sbv_p256_verify_batch_dev_part(const void* d_tuples, size_t n, uint32_t part, uint32_t parts, void* d_bitmap_words,

@@ -142,6 +142,10 @@ class SbvBackend : public Backend {
     }
     int verify_keyed(const uint8_t* rsh, const uint32_t* slots, size_t n, uint8_t* bitmap) override {
         if (rc_ != SBV_OK) return rc_;
+        // A decision-replay batch (controller.go:587-633: 50 000 decisions x 11 signatures) takes the sharded registered-key entry:
+        // every GPU of the node holds the consenters' combs, uploads run in pieces beside the kernels (also on one device); a vote
+        // burst or a proposal's worth of signatures stays on the latency forms of the first device.
+        if (n > 32768) return sbv_p256_verify_batch_keyed_sharded(rsh, slots, n, 0, 0, bitmap, nullptr, nullptr);
         return sbv_p256_verify_batch_keyed(rsh, slots, n, bitmap);
     }
     int verify_ed25519(const uint8_t* tuples128, size_t n, uint8_t* bitmap) override {
@@ -157,7 +161,8 @@ class SbvBackend : public Backend {
     int verify_msgs_keyed(const uint8_t* msgs, const uint64_t* moff, const uint8_t* sigs, const uint64_t* soff,
                           const uint32_t* slots, size_t n, uint8_t* bitmap) override {
         if (rc_ != SBV_OK) return rc_;
-        if (n > ((size_t)1 << 21)) return -2;          // the front end takes one chunk; larger batches use tuples
+        // a decision-replay batch: every GPU of the node, uploads in pieces beside SHA-256 + DER + verification of the piece before
+        if (n > 32768) return sbv_p256_verify_msgs_keyed_sharded(msgs, moff, sigs, soff, slots, n, 0, 0, bitmap, nullptr, nullptr);
         return sbv_p256_verify_msgs_keyed(msgs, moff, sigs, soff, slots, n, bitmap);
     }
  private:
@@ -863,8 +868,6 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
     const double t_start = trace ? now() : 0;
     double t_pass1 = 0, t_layout = 0, t_backend = 0;
     std::vector<uint8_t> bitmap((n + 7) / 8, 0), pre(n, 1);
-    std::vector<uint32_t> slots(n, 0);
-    std::atomic<int> unkeyed(0);
     std::map<uint64_t, bytes> keys;                 // snapshot: the workers must not contend on mu_
     std::map<uint64_t, long> key_slots;
     {
@@ -872,6 +875,127 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
         keys = consenters_;
         key_slots = consenter_slot_;
     }
+    // P-256 with every consenter registered on the backend (what RegisterConsenter does over libsbv): ONE pass over the Signature
+    // objects' bytes.  The two passes + serial offset loop this replaces cost twice the GPU's time (profiles/r04/
+    // replay_verifier_r04q.jsonl: 8.3 ms for 550 000 signatures, 2.7 of them in the backend).
+    //   raw-messages route (default): the workers check signer and binding and copy message + DER signature into page-locked
+    //     staging memory; SHA-256 and the DER parse run on the devices (sbv_p256_verify_msgs_keyed_sharded: every GPU of the node,
+    //     uploads in pieces beside the kernels).  Offsets come from a two-level prefix sum: per-chunk byte totals from the sizes
+    //     alone (no heap block touched), a serial scan over the few dozen chunks, then each chunk numbers its own signatures.
+    //   records route (SBVH_REPLAY_RECORDS=1, and for a backend without the front end): the workers also hash and parse and write
+    //     96-byte records r | s | SHA-256(msg) (sbv_p256_verify_batch_keyed_sharded: 100 B per signature over PCIe instead of ~140,
+    //     at ~150 ns of SHA-256 per signature on the host — the better trade only when host cores are plentiful).
+    // A pre-rejected signature (unknown signer, message not bound to its proposal) travels with slot 0xFFFFFFFF: no such key, rejected.
+    static const bool replay_records = [] { const char* e = getenv("SBVH_REPLAY_RECORDS"); return e && e[0] == '1'; }();
+    bool all_slotted = n && !ed() && !k256() && !keys.empty();
+    for (const auto& kv : keys) { const auto ks = key_slots.find(kv.first); if (ks == key_slots.end() || ks->second < 0) all_slotted = false; }
+    if (all_slotted) {
+        // dense id -> slot table when the ids are small (they are node numbers), else the map
+        uint64_t max_id = 0;
+        for (const auto& kv : key_slots) max_id = kv.first > max_id ? kv.first : max_id;
+        std::vector<int64_t> slot_of_id;
+        if (max_id < 4096) { slot_of_id.assign(max_id + 1, -1); for (const auto& kv : key_slots) if (keys.count(kv.first)) slot_of_id[kv.first] = kv.second; }
+        auto slot_of = [&](uint64_t id) -> int64_t {
+            if (!slot_of_id.empty()) return id < slot_of_id.size() ? slot_of_id[id] : -1;
+            const auto ks = key_slots.find(id);
+            return ks != key_slots.end() && keys.count(id) ? ks->second : -1;
+        };
+        // signer known and message bound to the proposal it is presented with?  (thread-local memo of the last proposal's digest)
+        struct Binder {
+            Verifier* v; const Proposal* last = nullptr; bytes digest;
+            bool bound(const Proposal* p, const bytes& m) {
+                if (p != last) { last = p; digest = v->digest_of(*p); }
+                return m.size() >= 40 && memcmp(m.data(), "SBV1", 4) == 0 && memcmp(m.data() + 4, digest.data(), 32) == 0 && consenter_msg_split(m, nullptr, nullptr);
+            }
+        };
+        std::lock_guard<std::mutex> staging_lock(staging_mu_);
+        uint32_t* dslots = (uint32_t*)staging(st_slots_, n * sizeof(uint32_t));
+        if (!dslots) return Status::Unavailable("out of host memory");
+        int krc = -2;
+        if (!replay_records) {
+            WorkerPool& pool = WorkerPool::get();
+            size_t jobs = n / 1024;
+            if (jobs > 4 * (pool.size() + 1)) jobs = 4 * (pool.size() + 1);
+            if (jobs == 0) jobs = 1;
+            const size_t per = (n + jobs - 1) / jobs;
+            std::vector<uint64_t> msum(jobs + 1, 0), ssum(jobs + 1, 0);
+            const std::function<void(size_t)> sizes = [&](size_t k) {
+                const size_t lo = k * per, hi = lo + per < n ? lo + per : n;
+                uint64_t a = 0, b = 0;
+                for (size_t i = lo; i < hi; ++i) { a += sigs[i].msg.size(); b += sigs[i].value.size(); }
+                msum[k + 1] = a; ssum[k + 1] = b;
+            };
+            const double t_a = trace ? now() : 0;
+            pool.run(jobs, sizes);
+            const double t_b = trace ? now() : 0;
+            for (size_t k = 0; k < jobs; ++k) { msum[k + 1] += msum[k]; ssum[k + 1] += ssum[k]; }
+            uint64_t* moff = (uint64_t*)staging(st_moff_, (n + 1) * sizeof(uint64_t));
+            uint64_t* soff = (uint64_t*)staging(st_soff_, (n + 1) * sizeof(uint64_t));
+            uint8_t* mbuf = (uint8_t*)staging(st_msgs_, msum[jobs] + 1);
+            uint8_t* sbuf = (uint8_t*)staging(st_sigs_, ssum[jobs] + 1);
+            if (!moff || !soff || !mbuf || !sbuf) return Status::Unavailable("out of host memory");
+            const std::function<void(size_t)> layout = [&](size_t k) {
+                const size_t lo = k * per, hi = lo + per < n ? lo + per : n;
+                uint64_t a = msum[k], b = ssum[k];
+                Binder bd{this};
+                for (size_t i = lo; i < hi; ++i) {
+                    const Signature& sg = sigs[i];
+                    if (i + 6 < hi) {       // the two heap blocks of a Signature a few iterations ahead (dependent misses otherwise)
+                        __builtin_prefetch(sigs[i + 6].msg.data());
+                        __builtin_prefetch(sigs[i + 6].value.data());
+                        __builtin_prefetch(sigs[i + 6].value.data() + 64);
+                    }
+                    moff[i] = a; soff[i] = b;
+                    memcpy(mbuf + a, sg.msg.data(), sg.msg.size());
+                    memcpy(sbuf + b, sg.value.data(), sg.value.size());
+                    a += sg.msg.size(); b += sg.value.size();
+                    const int64_t slot = slot_of(sg.id);
+                    const bool good = slot >= 0 && bd.bound(props[i], sg.msg);
+                    if (!good) pre[i] = 0;
+                    dslots[i] = good ? (uint32_t)slot : 0xFFFFFFFFu;
+                }
+            };
+            const double t_c = trace ? now() : 0;
+            pool.run(jobs, layout);
+            moff[n] = msum[jobs]; soff[n] = ssum[jobs];
+            if (trace) fprintf(stderr, "[sbvh trace] replay layout: setup %.0f us, sizes %.0f us, staging %.0f us, copy + binding %.0f us (%zu chunks)\n", t_a - t_start, t_b - t_a, t_c - t_b, now() - t_c, jobs);
+            if (trace) t_pass1 = t_layout = now();
+            krc = co_.submit_many_msgs_keyed(mbuf, moff, sbuf, soff, dslots, n, bitmap.data());
+            if (trace) t_backend = now();
+        }
+        if (krc == -2) {
+            uint8_t* rsh = (uint8_t*)staging(st_msgs_, n * 96);
+            if (!rsh) return Status::Unavailable("out of host memory");
+            parallel_chunks(n, [&](size_t lo, size_t hi) {
+                Binder bd{this};
+                for (size_t i = lo; i < hi; ++i) {
+                    const Signature& sg = sigs[i];
+                    const int64_t slot = slot_of(sg.id);
+                    uint8_t* rec = rsh + i * 96;
+                    if (slot < 0 || !bd.bound(props[i], sg.msg)) { pre[i] = 0; memset(rec, 0, 96); dslots[i] = 0xFFFFFFFFu; continue; }
+                    sbv_p256_parse_der((const uint8_t*)sg.value.data(), sg.value.size(), rec);              // a parse failure leaves r = s = 0
+                    sha256(sg.msg.data(), sg.msg.size(), rec + 64);
+                    dslots[i] = (uint32_t)slot;
+                }
+            });
+            if (trace) t_pass1 = t_layout = now();
+            krc = co_.submit_many_keyed(rsh, dslots, n, bitmap.data());
+            if (trace) t_backend = now();
+        }
+        if (krc != -2) {
+            if (krc != 0) return Status::Unavailable(std::string("backend error: ") + sbv_last_error());
+            out->resize(n);
+            uint8_t* o = out->data();
+            parallel_chunks(n, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) o[i] = pre[i] && ((bitmap[i >> 3] >> (i & 7)) & 1); });
+            if (trace)
+                fprintf(stderr, "[sbvh trace] VerifyConsenterSigBatch n=%zu (registered keys, %s): host pass %.0f us, backend %.0f us, total %.0f us\n", n,
+                        replay_records ? "records" : "raw messages", t_pass1 - t_start, t_backend - t_layout, now() - t_start);
+            return Status::Ok();
+        }
+        std::fill(pre.begin(), pre.end(), 1);       // a backend with neither entry: the general route below
+    }
+    std::vector<uint32_t> slots(n, 0);
+    std::atomic<int> unkeyed(0);
     // pass 1 (host, parallel): signer known? message bound to its proposal?  No hashing of messages here.
     parallel_chunks(n, [&](size_t lo, size_t hi) {
         const Proposal* last = nullptr;

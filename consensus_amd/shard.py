@@ -117,3 +117,59 @@ def sharded_verify_by_key(tuples, n: int, verify_fn: Optional[Callable] = None, 
     full = packed.tobytes()[:(n + 7) // 8]
     q = quorum_bits(tuples, full, n, group, quorum) if group and quorum else None
     return full, q
+
+
+# ---- registered-key form (libsbv.so: sbv_p256_verify_batch_keyed_sharded) -------------------------------------------------
+# configs[3] as BASELINE.json words it: the consenters' commit signatures travel as 96-byte records r | s | hash plus a 4-byte key
+# slot (types.Signature.ID -> registry slot), every rank holds a replica of the registry, shards are whole proposals (granule
+# lcm(512, 8 * group)), and the only exchange is the all-gather of the bitmap shards.  Quorum bits count DISTINCT accepted slots.
+RSH_BYTES = 96
+
+
+def keyed_granule(group: int) -> int:
+    import math
+    g8 = 8 * (group or 1)
+    return 512 // math.gcd(512, g8) * g8
+
+
+def quorum_bits_slots(slots, bitmap: bytes, n: int, group: int, quorum: int) -> bytes:
+    """numpy twin of the device's k_quorum_bits_slots: bit p = proposal p has >= quorum accepted signatures by distinct slots."""
+    import numpy as np
+    props = n // group
+    bits = np.unpackbits(np.frombuffer(bitmap, dtype=np.uint8), bitorder="little")[:props * group].reshape(props, group).astype(bool)
+    sl = np.asarray(slots, dtype=np.int64)[:props * group].reshape(props, group)
+    out = np.zeros(props, dtype=np.uint8)
+    for p in range(props):
+        out[p] = 1 if len(set(sl[p][bits[p]].tolist())) >= quorum else 0
+    return np.packbits(out, bitorder="little").tobytes()
+
+
+def sharded_verify_keyed(rsh, slots, n: int, verify_fn: Optional[Callable] = None, group: int = 0, quorum: int = 0, device: str = "cpu"):
+    """Every rank passes the same (rsh, slots, n); rank g verifies the contiguous range of whole proposals the plan gives it
+    against ITS replica of the key registry (`verify_fn(rsh_bytes, slot_list, m) -> bitmap`; default: the HIP registered-key
+    entry).  Returns (full accept bitmap, per-proposal quorum bitmap or None) on every rank."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if verify_fn is None:
+        import consensus_amd
+        verify_fn = consensus_amd.verify_batch_keyed
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    gran = keyed_granule(group)
+    lo, hi = shard_bounds(n, world, rank, gran)
+    cap = shard_capacity_bytes(n, world, gran)
+    sl = np.asarray(slots, dtype=np.uint32)
+    local = bytes(verify_fn(bytes(rsh[lo * RSH_BYTES:hi * RSH_BYTES]), sl[lo:hi].tolist(), hi - lo)) if hi > lo else b""
+    if world == 1:
+        full = local
+    else:
+        send = torch.zeros(cap, dtype=torch.uint8, device=device)
+        if local:
+            send[:len(local)] = torch.frombuffer(bytearray(local), dtype=torch.uint8).to(device)
+        recv = torch.zeros(cap * world, dtype=torch.uint8, device=device)
+        dist.all_gather_into_tensor(recv, send)
+        full = bytes(recv.cpu().numpy().tobytes())[:(n + 7) // 8]
+    q = quorum_bits_slots(sl, full, n, group, quorum) if group and quorum else None
+    return full, q

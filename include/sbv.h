@@ -294,6 +294,26 @@ size_t sbv_shard_min_for(const uint8_t* tuples, size_t n, size_t group);
 int sbv_p256_verify_batch_sharded(const uint8_t* tuples, size_t n, size_t group, uint32_t quorum, uint8_t* accept_bitmap,
                                   uint8_t* quorum_bitmap, sbv_shard_info* info);
 int sbv_p256_verify_batch_on(int device, const uint8_t* tuples, size_t n, uint8_t* accept_bitmap);
+/* The registered-key form of the sharded entry (round 5): configs[3] as BASELINE.json words it — "11 consenter sigs x 50k proposals
+ * sharded over 8 GPUs" — on the consenters' resident combs.  rsh: n x 96 bytes r | s | hash, slots: n key slots (100 B per signature
+ * over PCIe instead of 160).  The key registry is process-wide: sbv_p256_register_keys / sbv_p256_widen_keys replicate a key's 8-bit
+ * comb and a consenter's wide comb onto every initialised device (a device initialised later, or one whose replication failed, is
+ * brought up to date in front of the call; if that fails the call returns < 0 — a stale device never answers "invalid"), so a slot
+ * means the same key wherever its shard lands.  Plan, pieces (2^17 signatures; SBV_SHARD_PIECE_KEYED), collective and info as for
+ * sbv_p256_verify_batch_sharded with the few-signers minimum (2^16 per device); quorum bit p = proposal p carries >= quorum accepted
+ * signatures by DISTINCT slots (equal keys share a slot), the rule of internal/bft/viewchanger.go:681-727 for the signatures
+ * internal/bft/view.go:531-541 collects.  Also the pipelined host-pointer entry for large registered-key batches on ONE device
+ * (sbv_init only): the upload of piece i + 1 runs beside the kernels of piece i.  An out-of-range slot is a reject, not an error. */
+int sbv_p256_verify_batch_keyed_sharded(const uint8_t* rsh, const uint32_t* slots, size_t n, size_t group, uint32_t quorum,
+                                        uint8_t* accept_bitmap, uint8_t* quorum_bitmap, sbv_shard_info* info);
+/* ... and its raw-messages form: sbv_p256_verify_msgs_keyed's inputs (messages and DER signatures packed back to back, their offset
+ * tables, key slots) through the same plan — SHA-256 and the strict DER parse run on every device over its share, piece by piece
+ * beside the uploads, so a replaying replica's host pass only lays bytes out (decision replay: internal/bft/controller.go:587-633;
+ * the signatures of a decision: pkg/types/types.go:31-34).  No 2^21 limit: pieces are launches.  Equivalent to
+ * crypto/ecdsa.VerifyASN1(key[slots[i]], sha256(msg i), sig i) for every i; quorum bits as above. */
+int sbv_p256_verify_msgs_keyed_sharded(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* sigs, const uint64_t* sig_offsets,
+                                       const uint32_t* slots, size_t n, size_t group, uint32_t quorum, uint8_t* accept_bitmap,
+                                       uint8_t* quorum_bitmap, sbv_shard_info* info);
 /* Key-affine partition (the other way to spread a batch: by signer instead of by position).  A contiguous split hands every
  * device signatures of every signer, so every device builds every key's tables — the part of a cold step that does not shrink
  * with the shard.  With sbv_shard_mode(1, parts) the sharded entry partitions by a hash of the public key: part p (on device

@@ -133,6 +133,10 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
     with pytest.raises(sbv.SbvError) as ei:
         sbv.verify_batch_on(0, ctypes.addressof(ctypes.create_string_buffer(160 * 8)), 8, ctypes.addressof(out))
     assert ei.value.code == -5
+    with pytest.raises(sbv.SbvError) as ei:      # the registered-key sharded entry: no device, no registry -> not initialised, never a verdict
+        sbv.verify_batch_keyed_sharded(ctypes.addressof(ctypes.create_string_buffer(96 * 8)), ctypes.addressof((ctypes.c_uint32 * 8)()), 8,
+                                       ctypes.addressof(out))
+    assert ei.value.code == -5
 
 
 def test_shard_plan_split_logic():

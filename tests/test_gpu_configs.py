@@ -210,6 +210,100 @@ def test_sharded_entry_world_of_one_with_rccl_and_quorum_bits(oracle):
         sbv.shutdown()
 
 
+def test_config3_registered_key_sharded_entry_550000(oracle, openssl_check):
+    """configs[3] as BASELINE.json words it, on the consenters' resident combs: sbv_p256_verify_batch_keyed_sharded over
+    550 000 = 50 000 x 11 records r | s | hash + key slots, 16 registered consenter keys with their wide combs.  Accept bitmap ==
+    oracle == OpenSSL == the generic sharded entry on every signature; quorum bits (>= Q - 1 accepted signatures by distinct SLOTS)
+    == the generic entry's (distinct KEYS) == the rule restated in Python; with SBV_RCCL=1 the bitmap travels through the
+    one-rank all-gather.  Then: duplicate signers, unknown slots, a ragged batch, uploads in small pieces, 8-bit combs only."""
+    import numpy as np
+    from consensus_amd import shard
+    os.environ["SBV_RCCL"] = "1"
+    os.environ["SBV_SHARD_MIN"] = str(1 << 16)
+    try:
+        sbv.shutdown()
+        ndev = sbv.init_all()
+        assert ndev >= 1
+        P, Q = 50000, 11
+        n = P * Q
+        tup, exp = _gen(oracle, 0xC3, n, 16, 8)
+        a, b = _cpu_opinions(oracle, openssl_check, tup, n)
+        assert a == b == exp
+        t2 = np.frombuffer(tup.raw, dtype=np.uint8).reshape(n, 160)
+        keys, counts = np.unique(t2[:, 96:160], axis=0, return_counts=True)
+        signer_keys = [bytes(k) for k in keys[counts > 1000]]
+        assert len(signer_keys) == 16
+        sbv.clear_keys()
+        slot_of = dict(zip(signer_keys, sbv.register_keys(signer_keys)))
+        sbv.widen_keys(list(slot_of.values()))
+        assert sbv.wide_key_stats()[:2] == (16, 20)
+        slots = np.fromiter((slot_of.get(bytes(k), 0xFFFFFFFF) for k in t2[:, 96:160]), dtype=np.uint32, count=n)
+        rsh = np.ascontiguousarray(t2[:, :96]).reshape(-1)
+
+        def keyed(rsh_a, slots_a, m, group=Q, quorum=Q - 1):
+            got = np.zeros((m + 7) // 8, dtype=np.uint8)
+            qb = np.zeros(((m // group if group else 0) + 7) // 8 + 1, dtype=np.uint8)
+            info = sbv.verify_batch_keyed_sharded(rsh_a.ctypes.data, slots_a.ctypes.data, m, got.ctypes.data, group, quorum,
+                                                  qb.ctypes.data if group else 0)
+            return got.tobytes(), qb.tobytes()[:((m // group if group else 0) + 7) // 8], info
+
+        got, qb, info = keyed(rsh, slots, n)
+        assert got == a, _diff(got, a)                                   # every one of the 550 000 verdicts: oracle and OpenSSL
+        assert info.devices == ndev and info.mode == 1 and info.h2d_us > 0 and info.kernels_us > 0
+        g2 = ctypes.create_string_buffer((n + 7) // 8)
+        q2 = ctypes.create_string_buffer((P + 7) // 8)
+        sbv.verify_batch_sharded(ctypes.addressof(tup), n, ctypes.addressof(g2), group=Q, quorum=Q - 1, quorum_out_ptr=ctypes.addressof(q2))
+        assert g2.raw == got and q2.raw == qb                            # == the generic sharded entry, bitmap and quorum bits
+        assert qb == shard.quorum_bits_slots(slots, got, n, Q, Q - 1) == shard.quorum_bits(tup.raw, got, n, Q, Q - 1)
+        assert 0 < sum(sbv.bitmap_to_list(qb, P)) < P
+        # duplicate signers must not count twice: proposal 0 becomes ten copies of ONE valid signature + one more signer
+        bits = sbv.bitmap_to_list(got, Q)
+        i0 = next(i for i in range(Q) if bits[i])
+        m2 = 5632 * 2
+        r2, s2 = rsh[:96 * m2].copy(), slots[:m2].copy()
+        for j in range(Q - 1):
+            r2[96 * j:96 * (j + 1)] = rsh[96 * i0:96 * (i0 + 1)]
+            s2[j] = slots[i0]
+        gd, qd, _ = keyed(r2, s2, m2)
+        assert sbv.bitmap_to_list(gd, Q)[:Q - 1] == [True] * (Q - 1) and sbv.bitmap_to_list(qd, 1) == [False]
+        assert gd[2:] == got[2:m2 // 8] and qd[1:] == qb[1:len(qd)]      # everything else as before (replica route: one device, no split)
+        # an unknown / out-of-range slot is a reject, not an error
+        s3 = slots[:4096].copy()
+        s3[::7] = 0xFFFFFFFF
+        s3[3::7] = 1 << 20
+        g3, _, _ = keyed(rsh[:96 * 4096], s3, 4096, 0, 0)
+        w3 = sbv.bitmap_to_list(got, 4096)
+        assert sbv.bitmap_to_list(g3, 4096) == [w3[i] and i % 7 not in (0, 3) for i in range(4096)]
+        # ragged size, no groups
+        m4 = 100003
+        g4, _, _ = keyed(rsh[:96 * m4], slots[:m4], m4, 0, 0)
+        assert sbv.bitmap_to_list(g4, m4) == sbv.bitmap_to_list(got, m4)
+        # the 8-bit combs every key keeps give the same verdicts (wide combs off frees them on every device)
+        sbv.wide_keys(0, 0)
+        assert sbv.wide_key_stats()[0] == 0
+        g5, q5, _ = keyed(rsh, slots, n)
+        assert g5 == got and q5 == qb
+        sbv.wide_keys()
+        sbv.widen_keys(list(slot_of.values()))
+        # uploads in small pieces beside the kernels: 11 264-signature pieces alternate between the two slots
+        os.environ["SBV_SHARD_PIECE_KEYED"] = "16384"
+        sbv.shutdown()
+        assert sbv.init_all() >= 1
+        assert dict(zip(signer_keys, sbv.register_keys(signer_keys))) == slot_of      # a fresh process-wide registry: the same slot numbers
+        sbv.widen_keys(list(slot_of.values()))
+        g6, q6, info = keyed(rsh, slots, n)
+        assert g6 == got and q6 == qb and info.h2d_us > 0
+    finally:
+        for k in ("SBV_RCCL", "SBV_SHARD_MIN", "SBV_SHARD_PIECE_KEYED"):
+            os.environ.pop(k, None)
+        try:
+            sbv.wide_keys()
+            sbv.clear_keys()
+        except sbv.SbvError:
+            pass
+        sbv.shutdown()
+
+
 # ---- key-affine partition (VERDICT r2 #2): device g verifies the tuples of "its" keys only ------------------------------
 def test_two_threads_in_the_sharded_entry_keep_their_own_bitmaps(oracle):
     """the all-gather phase of a sharded call used to run without the device's lock, so a second caller

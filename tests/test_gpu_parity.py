@@ -433,6 +433,71 @@ def test_device_message_frontend(gpu, oracle, golden_vectors):
     gpu.clear_keys()
 
 
+def test_sharded_message_frontend_in_pieces(oracle):
+    """sbv_p256_verify_msgs_keyed_sharded (round 5): 70 000 raw messages of 0..300 bytes + DER signatures + key slots over 5 registered
+    keys, uploaded in 11-piece fashion (SBV_SHARD_PIECE_KEYED = 7168: each piece carries a slice of the caller's offset tables with
+    its base subtracted on the device) == the one-launch front end == VerifyASN1's verdict by construction (signatures from the
+    device's RFC 6979 signer; every 5th message altered after signing, every 11th signature truncated, every 13th slot unknown);
+    quorum bits by distinct slot == the numpy twin; forced one-rank RCCL all-gather."""
+    import hashlib
+    import random
+    from consensus_amd import shard
+    rng = random.Random(777)
+    os.environ["SBV_RCCL"] = "1"
+    os.environ["SBV_SHARD_PIECE_KEYED"] = "7168"
+    try:
+        sbv.shutdown()
+        assert sbv.init_all() >= 1
+        n, nk, G, Qm = 70000, 5, 7, 5
+        ds = [rng.randrange(1, ec.N) for _ in range(nk)]
+        pubs = [ec.pt_mul(d, ec.G) for d in ds]
+        slots_of = sbv.register_keys([q[0].to_bytes(32, "big") + q[1].to_bytes(32, "big") for q in pubs])
+        msgs = [bytes([i & 255, (i >> 8) & 255, (i >> 16) & 255]) * rng.choice([0, 1, 10, 18, 19, 21, 33, 100]) for i in range(n)]
+        digests = b"".join(hashlib.sha256(m).digest() for m in msgs)
+        kidx = [(i * 3 + i // G) % nk for i in range(n)]
+        rs, okb = sbv.sign_batch(b"".join(d.to_bytes(32, "big") for d in ds), digests, kidx)
+        assert okb == b"\x01" * n
+        sigs, slots, want = [], [], []
+        for i in range(n):
+            sig = ec.der_encode_sig(int.from_bytes(rs[64 * i:64 * i + 32], "big"), int.from_bytes(rs[64 * i + 32:64 * i + 64], "big"))
+            good = True
+            if i % 5 == 2:
+                msgs[i] = msgs[i] + b"!"
+                good = False
+            if i % 11 == 3:
+                sig = sig[:-1]
+                good = False
+            slot = slots_of[kidx[i]]
+            if i % 13 == 4:
+                slot = 0xFFFFFFFF if i % 2 else 1000
+                good = False
+            sigs.append(sig); slots.append(slot); want.append(good)
+        got, qb, info = sbv.verify_msgs_keyed_sharded(msgs, sigs, slots, G, Qm)
+        bits = sbv.bitmap_to_list(got, n)
+        assert bits == want, [i for i in range(n) if bits[i] != want[i]][:10]
+        assert info.mode == 1 and info.h2d_us > 0
+        assert qb == shard.quorum_bits_slots(slots, got, n, G, Qm)
+        assert 0 < sum(sbv.bitmap_to_list(qb, n // G)) < n // G
+        m = 30000                                   # the one-launch front end on a prefix (its own staging, no pieces)
+        assert sbv.verify_msgs_keyed(msgs[:m], sigs[:m], slots[:m]) == got[:m // 8]
+        # empty messages / empty signatures at piece boundaries, n not a multiple of anything
+        m2 = 7168 * 2 + 5
+        msgs2, sigs2 = list(msgs[:m2]), list(sigs[:m2])
+        for j in (0, 7167, 7168, m2 - 1):
+            sigs2[j] = b""
+        got2, _, _ = sbv.verify_msgs_keyed_sharded(msgs2, sigs2, slots[:m2])
+        assert sbv.bitmap_to_list(got2, m2) == [want[i] and i not in (0, 7167, 7168, m2 - 1) for i in range(m2)]
+    finally:
+        os.environ.pop("SBV_RCCL", None)
+        os.environ.pop("SBV_SHARD_PIECE_KEYED", None)
+        try:
+            sbv.clear_keys()
+        except sbv.SbvError:
+            pass
+        sbv.shutdown()
+        sbv.init(0)
+
+
 def test_in_step_key_grouping_equals_generic(gpu, oracle, golden_vectors):
     """sbv_p256_set_grouping: tuples grouped by key on the device, per-batch comb tables, registered-key kernel for
     the grouped ones — verdicts must equal the plain generic kernel in every configuration."""
