@@ -32,7 +32,7 @@ double now_us() {
 }
 Proposal make_prop(const void* payload, size_t pl, const void* header, size_t hl, const void* meta, size_t ml, int64_t vseq) {
     Proposal p;
-    p.payload = B(payload, pl); p.header = B(header, hl); p.metadata = B(meta, ml); p.verification_sequence = vseq;
+    p.set_payload(B(payload, pl)); p.set_header(B(header, hl)); p.set_metadata(B(meta, ml)); p.set_verification_sequence(vseq);
     return p;
 }
 void parallel_for(size_t n, int threads, const std::function<void(size_t)>& fn) {
@@ -121,6 +121,73 @@ int sbvh_test_proposal_then_vote(void* h, uint64_t id, const void* value, size_t
     const Status st2 = V.VerifyConsenterSig(s, p, &aux);
     return (st1.code & 0xff) | ((st2.code & 0xff) << 8) | (flags << 16);
 }
+// the Proposal.Digest() memo must not go stale.  `value` / `msg` = node `id`'s commit signature over the proposal
+// (payload, header, meta, vseq).  Returns a bit mask of WRONG answers (0 = all right):
+//   1   the vote over p is not accepted for p                       2   ... for a copy q of p (shares the memo)
+//   4   accepted for q after q.set_payload("tampered")              8   ... while p, untouched, is no longer accepted
+//   16  accepted for p after p.set_header(...) in place             32  not accepted again once p has its old header back
+//   64  accepted for r = std::move(p) with its metadata changed     128 accepted for the moved-from p
+//   256 accepted for a copy assigned over another proposal whose sequence was then bumped
+int sbvh_test_digest_memo(void* h, uint64_t id, const void* value, size_t vl, const void* msg, size_t ml,
+                          const void* payload, size_t pl, const void* header, size_t hl, const void* meta, size_t mtl, int64_t vseq) {
+    Verifier& V = *((VHandle*)h)->v;
+    Signature s; s.id = id; s.value = B(value, vl); s.msg = B(msg, ml);
+    bytes aux;
+    auto ok = [&](const Proposal& x) { return V.VerifyConsenterSig(s, x, &aux).ok(); };
+    int wrong = 0;
+    Proposal p = make_prop(payload, pl, header, hl, meta, mtl, vseq);
+    if (!ok(p)) wrong |= 1;                                   // the digest is memoised on p from here on
+    Proposal q = p;
+    if (!ok(q)) wrong |= 2;
+    q.set_payload(p.payload() + "tampered");
+    if (ok(q)) wrong |= 4;
+    if (!ok(p)) wrong |= 8;
+    const bytes old_header = p.header();
+    p.set_header(old_header + "x");
+    if (ok(p)) wrong |= 16;
+    p.set_header(old_header);
+    if (!ok(p)) wrong |= 32;
+    Proposal r = std::move(p);
+    r.set_metadata(r.metadata() + "y");
+    if (ok(r)) wrong |= 64;
+    if (ok(p)) wrong |= 128;                                  // moved-from: empty fields, no slot
+    Proposal t = make_prop("other", 5, "h", 1, "m", 1, 7);
+    (void)ok(t);                                              // t has a memo of its own
+    t = make_prop(payload, pl, header, hl, meta, mtl, vseq);
+    (void)ok(t);
+    t.set_verification_sequence(vseq + 1);
+    if (ok(t)) wrong |= 256;
+    return wrong;
+}
+// under sustained concurrent single-signature traffic no caller may be held inside the coalescer after its own
+// verdict is ready.  `threads` threads call VerifySignature(id, value, msg) back to back for duration_ms; out[0] = fewest calls any
+// thread completed, out[1] = most, out[2] = the longest single call in microseconds, out[3] = calls that did not return OK.
+int sbvh_test_sustained_load(void* h, uint64_t id, const void* value, size_t vl, const void* msg, size_t ml, int threads, int duration_ms,
+                             double out[4]) {
+    Verifier& V = *((VHandle*)h)->v;
+    Signature s; s.id = id; s.value = B(value, vl); s.msg = B(msg, ml);
+    std::vector<uint64_t> calls((size_t)threads, 0), bad((size_t)threads, 0);
+    std::vector<double> worst((size_t)threads, 0.0);
+    const double t_end = now_us() + 1e3 * duration_ms;
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t)
+        th.emplace_back([&, t] {
+            while (now_us() < t_end) {
+                const double t0 = now_us();
+                if (!V.VerifySignature(s).ok()) ++bad[(size_t)t];
+                const double dt = now_us() - t0;
+                if (dt > worst[(size_t)t]) worst[(size_t)t] = dt;
+                ++calls[(size_t)t];
+            }
+        });
+    for (auto& x : th) x.join();
+    out[0] = (double)*std::min_element(calls.begin(), calls.end());
+    out[1] = (double)*std::max_element(calls.begin(), calls.end());
+    out[2] = *std::max_element(worst.begin(), worst.end());
+    out[3] = 0;
+    for (uint64_t b : bad) out[3] += (double)b;
+    return 0;
+}
 size_t sbvh_auxiliary_data(void* h, const void* msg, size_t ml, void* out, size_t cap) {
     return put(((VHandle*)h)->v->AuxiliaryData(B(msg, ml)), out, cap);
 }
@@ -148,7 +215,7 @@ int sbvh_verify_proposal(void* h, const void* payload, size_t pl, const void* he
     return st.code;
 }
 size_t sbvh_requests_from_proposal(void* h, const void* payload, size_t pl, void* infos_out, size_t cap, size_t* count) {
-    Proposal p; p.payload = B(payload, pl);
+    Proposal p; p.set_payload(B(payload, pl));
     const auto infos = ((VHandle*)h)->v->RequestsFromProposal(p);
     bytes s;
     for (const auto& ri : infos) { s += ri.client_id; s.push_back('\0'); s += ri.id; s.push_back('\0'); }
@@ -406,9 +473,9 @@ int sbvh_replay(void* h, int n_nodes, int K, int sequences, int decisions, int t
                                              bytes(32, (char)(i & 0xff)));
             reqs[i] = request_encode(u, clients[(size_t)c]->Sign(u));
         });
-        props[(size_t)s].payload = payload_encode(reqs);
-        props[(size_t)s].header = "hdr-" + std::to_string(s);
-        props[(size_t)s].metadata = "md-" + std::to_string(s);
+        props[(size_t)s].set_payload(payload_encode(reqs));
+        props[(size_t)s].set_header("hdr-" + std::to_string(s));
+        props[(size_t)s].set_metadata("md-" + std::to_string(s));
     }
     // commit signatures of every node on every proposal
     std::vector<std::vector<Signature>> commits((size_t)sequences, std::vector<Signature>((size_t)n_nodes));
@@ -421,8 +488,8 @@ int sbvh_replay(void* h, int n_nodes, int K, int sequences, int decisions, int t
     std::vector<Signature> dsigs((size_t)decisions * Q);
     if (decisions > 0) {
         parallel_for((size_t)decisions, threads, [&](size_t d) {
-            dprops[d].payload = "decision-payload-" + std::to_string(d);
-            dprops[d].header = "h"; dprops[d].metadata = "m";
+            dprops[d].set_payload("decision-payload-" + std::to_string(d));
+            dprops[d].set_header("h"); dprops[d].set_metadata("m");
             for (int j = 0; j < Q; ++j) dsigs[d * Q + j] = nodes[(d + j) % n_nodes]->SignProposal(dprops[d], "aux");
         });
     }
@@ -542,7 +609,7 @@ int sbvh_batch_faults(void* h, int n_nodes, int decisions, int threads, uint64_t
         V.RegisterConsenter((uint64_t)(i + 1), nodes.back()->public_key());
     }
     std::vector<Proposal> props((size_t)decisions + 1);
-    for (size_t d = 0; d < props.size(); ++d) { props[d].payload = "faulty-decision-" + std::to_string(d); props[d].header = "h"; props[d].metadata = "m"; }
+    for (size_t d = 0; d < props.size(); ++d) { props[d].set_payload("faulty-decision-" + std::to_string(d)); props[d].set_header("h"); props[d].set_metadata("m"); }
     std::vector<Signature> sigs((size_t)decisions * Q);
     std::vector<uint8_t> spoiled(sigs.size(), 0);
     parallel_for((size_t)decisions, threads, [&](size_t d) {

@@ -91,10 +91,10 @@ int chain_emulate(const std::vector<Verifier*>& verifiers, const ChainEmulOption
             reqs.push_back(request_encode(u, forge ? mallory.Sign(u) : alice.Sign(u)));
         }
         Proposal p;
-        p.payload = payload_encode(reqs);
-        p.header = u64be((uint64_t)seq) + prev_hash + sha(p.payload);                         // BlockHeader{Sequence, PrevHash, DataHash}
+        p.set_payload(payload_encode(reqs));
+        p.set_header(u64be((uint64_t)seq) + prev_hash + sha(p.payload()));                        // BlockHeader{Sequence, PrevHash, DataHash}
         const std::vector<Signature>& prev_sigs = last[(size_t)leader].signatures;
-        p.metadata = u64be(0) + u64be((uint64_t)seq) + commit_signatures_digest(prev_sigs);   // view, sequence, prev commit digest
+        p.set_metadata(u64be(0) + u64be((uint64_t)seq) + commit_signatures_digest(prev_sigs));  // view, sequence, prev commit digest
 
         // ---- followers: verifyProposal ---------------------------------------------------------------------------
         std::vector<int> accepted((size_t)N, 1);
@@ -113,7 +113,7 @@ int chain_emulate(const std::vector<Verifier*>& verifiers, const ChainEmulOption
                     if (st.code == Status::UNAVAILABLE) { ++res->unavailable; return -2; }
                     if (!st.ok()) { ok = false; break; }
                 }
-                ok = ok && commit_signatures_digest(prev_sigs) == p.metadata.substr(16);
+                ok = ok && commit_signatures_digest(prev_sigs) == p.metadata().substr(16);
             }
             accepted[(size_t)i] = ok ? 1 : 0;
         }
@@ -177,7 +177,7 @@ int chain_emulate(const std::vector<Verifier*>& verifiers, const ChainEmulOption
             last[(size_t)i].proposal = p;
             last[(size_t)i].signatures = sigs;
         }
-        if (decided[(size_t)leader]) prev_hash = sha(p.header);
+        if (decided[(size_t)leader]) prev_hash = sha(p.header());
         // a node that did not decide would sync in the reference (out of scope: Synchronizer); keep it in step so that the
         // emulation can go on — its ledger simply lacks the block
         for (int i = 0; i < N; ++i)

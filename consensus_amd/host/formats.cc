@@ -44,10 +44,10 @@ const char kHex[] = "0123456789abcdef";
 
 bytes asn1_marshal_proposal(const Proposal& p) {
     bytes body;
-    der_octets(body, p.payload);
-    der_octets(body, p.header);
-    der_octets(body, p.metadata);
-    der_int64(body, p.verification_sequence);
+    der_octets(body, p.payload());
+    der_octets(body, p.header());
+    der_octets(body, p.metadata());
+    der_int64(body, p.verification_sequence());
     bytes out;
     out.push_back(0x30);
     der_len(out, body.size());

@@ -24,8 +24,12 @@ typedef std::string bytes;
 // recomputes it three times per sequence (internal/bft/view.go:435, 443, 524) and every VerifyConsenterSig must bind its
 // message to it; it passes the SAME proposal value to VerifyProposal (view.go:555) and, a round trip later, to every
 // VerifyConsenterSig of that sequence (view.go:834).  The memo therefore travels with the object — no table of proposals, no
-// payload comparison, no copy kept — as a lazily computed field does.  Contract: a Proposal is immutable once a Verifier has
-// seen it (as in the reference, where these are protobuf-decoded bytes nobody writes to); copies share the slot.
+// payload comparison, no copy kept — as a lazily computed field does.
+//
+// It cannot go stale: the four fields of a Proposal are PRIVATE, every mutator drops the object's slot, a copy
+// shares the slot of its source (equal contents at that moment; a later mutation of either object drops only that object's
+// slot), and a moved-from object loses its slot together with its contents.  A caller that reuses one Proposal variable across
+// sequences therefore gets a fresh digest after every change, as the reference's per-call Digest() would give it.
 struct ProposalDigestSlot {
     std::mutex mu;
     std::condition_variable cv;
@@ -35,22 +39,31 @@ struct ProposalDigestSlot {
     bytes digest;             // immutable once ready
 };
 
-struct Proposal {                 // pkg/types/types.go:18-23
-    bytes payload, header, metadata;
-    int64_t verification_sequence = 0;
-
+class Proposal {                  // pkg/types/types.go:18-23
+ public:
     Proposal() = default;
-    Proposal(const Proposal& o) : payload(o.payload), header(o.header), metadata(o.metadata), verification_sequence(o.verification_sequence), slot_(o.digest_slot()) {}
-    Proposal(Proposal&& o) noexcept : payload(std::move(o.payload)), header(std::move(o.header)), metadata(std::move(o.metadata)),
-                                      verification_sequence(o.verification_sequence), slot_(o.digest_slot()) {}
+    Proposal(bytes payload, bytes header, bytes metadata, int64_t verification_sequence = 0)
+        : payload_(std::move(payload)), header_(std::move(header)), metadata_(std::move(metadata)), verification_sequence_(verification_sequence) {}
+    Proposal(const Proposal& o) : payload_(o.payload_), header_(o.header_), metadata_(o.metadata_), verification_sequence_(o.verification_sequence_), slot_(o.digest_slot()) {}
+    Proposal(Proposal&& o) noexcept : payload_(std::move(o.payload_)), header_(std::move(o.header_)), metadata_(std::move(o.metadata_)),
+                                      verification_sequence_(o.verification_sequence_), slot_(o.take_slot()) {}
     Proposal& operator=(const Proposal& o) {
-        if (this != &o) { payload = o.payload; header = o.header; metadata = o.metadata; verification_sequence = o.verification_sequence; set_slot(o.digest_slot()); }
+        if (this != &o) { payload_ = o.payload_; header_ = o.header_; metadata_ = o.metadata_; verification_sequence_ = o.verification_sequence_; set_slot(o.digest_slot()); }
         return *this;
     }
     Proposal& operator=(Proposal&& o) noexcept {
-        if (this != &o) { payload = std::move(o.payload); header = std::move(o.header); metadata = std::move(o.metadata); verification_sequence = o.verification_sequence; set_slot(o.digest_slot()); }
+        if (this != &o) { payload_ = std::move(o.payload_); header_ = std::move(o.header_); metadata_ = std::move(o.metadata_); verification_sequence_ = o.verification_sequence_; set_slot(o.take_slot()); }
         return *this;
     }
+    const bytes& payload() const { return payload_; }
+    const bytes& header() const { return header_; }
+    const bytes& metadata() const { return metadata_; }
+    int64_t verification_sequence() const { return verification_sequence_; }
+    // every mutator drops this object's digest slot: the next digest_of() hashes the new contents
+    void set_payload(bytes v) { payload_ = std::move(v); set_slot(nullptr); }
+    void set_header(bytes v) { header_ = std::move(v); set_slot(nullptr); }
+    void set_metadata(bytes v) { metadata_ = std::move(v); set_slot(nullptr); }
+    void set_verification_sequence(int64_t v) { verification_sequence_ = v; set_slot(nullptr); }
     // The digest slot of this object (see ProposalDigestSlot; never part of the value).  Guarded by a spin flag of its own: the
     // free-function atomics on shared_ptr take a pooled pthread mutex, and 15 votes asking at once queued on it for ~1 us each.
     std::shared_ptr<ProposalDigestSlot> digest_slot() const {
@@ -71,8 +84,11 @@ struct Proposal {                 // pkg/types/types.go:18-23
 
  private:
     void set_slot(std::shared_ptr<ProposalDigestSlot> s) const { lock(); slot_.swap(s); unlock(); }
+    std::shared_ptr<ProposalDigestSlot> take_slot() const { std::shared_ptr<ProposalDigestSlot> s; lock(); slot_.swap(s); unlock(); return s; }
     void lock() const { while (slot_lock_.test_and_set(std::memory_order_acquire)) {} }
     void unlock() const { slot_lock_.clear(std::memory_order_release); }
+    bytes payload_, header_, metadata_;
+    int64_t verification_sequence_ = 0;
     mutable std::atomic_flag slot_lock_ = ATOMIC_FLAG_INIT;
     mutable std::shared_ptr<ProposalDigestSlot> slot_;
 };

@@ -262,8 +262,8 @@ Coalescer::~Coalescer() {}      // no thread of its own: a submitter never retur
 // Concurrent single-signature calls are merged by the callers themselves: the first submitter that finds no leader BECOMES
 // the leader (it is awake and on a core already — a dispatcher thread would have to be woken first: 30-60 us of futex latency at
 // the head of a ~100 us round trip, which is what round 3's M2 paid), polls the queue for the rest of the burst, ships the
-// batch and hands the verdicts out; everybody else spins on its own job's flag.  When the leader is done and jobs that arrived
-// during its backend call are still queued, leadership passes to one of their (spinning) owners.
+// batch and hands the verdicts out; everybody else spins on its own job's flag.  When the leader's own job is done it steps down
+// at once; if jobs that arrived during its backend call are still queued, leadership passes to one of their (spinning) owners.
 int Coalescer::submit(const uint8_t tuple[160], long slot, bool ed25519, bool k256, std::string* err) {
     Job j;
     memcpy(j.tuple, tuple, ed25519 ? 128 : 160);
@@ -285,7 +285,7 @@ int Coalescer::submit(const uint8_t tuple[160], long slot, bool ed25519, bool k2
     const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(400);
     for (;;) {
         if (lead) {
-            serve_as_leader();
+            serve_as_leader(&j.done);
             lead = false;
             if (j.done.load(std::memory_order_acquire)) break;      // always: the leader's own job is in its first batch
         }
@@ -360,8 +360,12 @@ CoalescerStats Coalescer::stats() {
     return st_;
 }
 
-// mu_ NOT held; leader_ is this thread.  Ships batches until the queue is empty at the moment it looks, then steps down.
-void Coalescer::serve_as_leader() {
+// mu_ NOT held; leader_ is this thread.  Ships batches until ITS OWN job is done, then steps down — also when jobs that arrived
+// during its backend call are still queued: one of their owners (each is spinning or sleeping in submit()) takes over through the
+// takeover path there.  A leader that kept serving until it found the queue empty could be held inside submit() for as long as
+// concurrent VerifyRequest / VerifySignature traffic kept arriving — the consensus thread verifying a commit vote would not
+// return although its verdict was ready.
+void Coalescer::serve_as_leader(const std::atomic<bool>* own_done) {
     // SBVH_TRACE=1: one line per backend batch on stderr (size, time spent collecting, backend call)
     static const bool trace = [] { const char* e = getenv("SBVH_TRACE"); return e && e[0] == '1'; }();
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -462,7 +466,18 @@ void Coalescer::serve_as_leader() {
         // store(done) above, load(sleepers_) here, and a sleeper does the mirror image (count itself, then look at done): without
         // a full fence between the two both sides may read the old value and the sleeper would never be woken
         std::atomic_thread_fence(std::memory_order_seq_cst);
-        if (sleepers_.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lk(sleep_mu_); cv_done_.notify_all(); }
+        bool wake = sleepers_.load(std::memory_order_seq_cst) > 0;
+        const bool step_down = own_done && own_done->load(std::memory_order_acquire);
+        if (step_down) {
+            // this caller's verdict is ready: hand the queue (if anything is in it) to one of the waiting owners
+            std::lock_guard<SpinLock> lk(mu_);
+            leader_ = false;
+            leader_flag_.store(false, std::memory_order_release);
+            std::atomic_thread_fence(std::memory_order_seq_cst);          // flag first, then look for sleepers (they count themselves, then look at the flag)
+            wake = wake || sleepers_.load(std::memory_order_seq_cst) > 0;
+        }
+        if (wake) { std::lock_guard<std::mutex> lk(sleep_mu_); cv_done_.notify_all(); }
+        if (step_down) return;
     }
 }
 
@@ -722,7 +737,7 @@ Status Verifier::VerifyRequest(const bytes& raw, RequestInfo* info) {   // contr
 std::vector<RequestInfo> Verifier::RequestsFromProposal(const Proposal& p) {   // view.go:395, 419
     std::vector<RequestInfo> out;
     std::vector<bytes> reqs;
-    if (!payload_split(p.payload, &reqs)) return out;
+    if (!payload_split(p.payload(), &reqs)) return out;
     for (const bytes& raw : reqs) out.push_back(RequestID(raw));
     return out;
 }
@@ -737,9 +752,9 @@ Status Verifier::VerifyProposal(const Proposal& p, std::vector<RequestInfo>* req
     // Nothing of the payload is copied: the requests are parsed where they lie (formats.h: RequestView), and what the
     // backend needs is laid out straight from there.
     std::vector<std::pair<size_t, size_t>> reqs;
-    if (!payload_split_views(p.payload, &reqs)) return Status::Invalid("malformed proposal payload");
+    if (!payload_split_views(p.payload(), &reqs)) return Status::Invalid("malformed proposal payload");
     if (trace) t_split = now();
-    if ((uint64_t)p.verification_sequence != VerificationSequence()) return Status::Invalid("verification sequence mismatch");
+    if ((uint64_t)p.verification_sequence() != VerificationSequence()) return Status::Invalid("verification sequence mismatch");
     // Proposal.Digest() starts NOW on the worker thread, beside everything below (and beside the prepare round that follows):
     // the first commit vote of this proposal finds it ready instead of hashing 1.7 MB (view.go:524, 834).  This call does not
     // return before the worker has stopped reading `p` (it marshals first — 0.1-0.2 ms — and hashes its own bytes).
@@ -769,7 +784,7 @@ Status Verifier::VerifyProposal(const Proposal& p, std::vector<RequestInfo>* req
     }
     std::vector<uint32_t> slots(n, 0);
     std::atomic<int> unkeyed(0);        // some client has no backend key slot: the whole batch goes the generic way
-    const bytes& pl = p.payload;
+    const bytes& pl = p.payload();
     parallel_chunks(n, [&](size_t lo, size_t hi) {
         bool any_unkeyed = false;       // one store per chunk: 10 000 stores to one cache line from every worker cost 0.4 ms
         for (size_t i = lo; i < hi; ++i) {

@@ -130,7 +130,7 @@ class Coalescer {
 
  private:
     struct Job { uint8_t tuple[160]; long slot = -1; bool ed25519 = false; bool k256 = false; int result = -100; std::string err; std::atomic<bool> done{false}; double t_push = 0; };
-    void serve_as_leader();
+    void serve_as_leader(const std::atomic<bool>* own_done);
     std::shared_ptr<Backend> be_;
     size_t max_batch_;
     std::chrono::microseconds max_wait_;

@@ -23,6 +23,7 @@ const (
 	rshBytes     = 96      // r | s | hash             (registered-key form)
 	frontEndMax  = 1 << 21 // sbv_p256_verify_msgs_keyed / sbv_ed25519_verify_msgs take one chunk of at most 2^21
 	frontEndFrom = 64      // below this many signatures the host hashes and parses itself (one upload instead of five)
+	shardedFrom  = 32768   // above this many registered-key signatures: every GPU of the node, uploads in pieces beside the kernels
 )
 
 // gpuBackend talks to libsbv.so.  All device work is funnelled through ONE goroutine locked to its OS thread
@@ -30,6 +31,8 @@ const (
 //
 // Counterpart of consensus_amd/host/verifier.cc: class SbvBackend — the same four routes:
 //
+//	every item has a slot, n > shardedFrom     sbv_p256_verify_msgs_keyed_sharded  the same inputs over every GPU of the node (decision replay:
+//	                                           50 000 decisions x 11 commit signatures, internal/bft/controller.go:587-633), in pieces
 //	every item has a slot, n >= frontEndFrom   sbv_p256_verify_msgs_keyed   raw messages + DER + slots (SHA-256 and DER on the device)
 //	every item has a slot                      sbv_p256_verify_batch_keyed  96-byte r|s|hash records + slots
 //	otherwise                                  sbv_p256_verify_batch_sharded generic tuples, all GPUs of the node
@@ -142,6 +145,18 @@ func (b *gpuBackend) verifyP256(items []Item) ([]bool, error) {
 		slots := make([]uint32, n)
 		for i := range items {
 			slots[i] = uint32(items[i].Slot)
+		}
+		if n > shardedFrom {
+			// the whole batch in one call: the library splits it by device and by piece (every device holds a replica of the key
+			// registry and of the consenters' wide combs; no 2^21 limit on this entry)
+			msgs, moff := packMsgs(func(i int) []byte { return items[i].Msg }, n)
+			sigs, soff := packMsgs(func(i int) []byte { return items[i].Sig }, n)
+			rc := C.sbv_p256_verify_msgs_keyed_sharded(u8(msgs), (*C.uint64_t)(unsafe.Pointer(&moff[0])), u8(sigs),
+				(*C.uint64_t)(unsafe.Pointer(&soff[0])), (*C.uint32_t)(unsafe.Pointer(&slots[0])), C.size_t(n), 0, 0, u8(bitmap), nil, nil)
+			if rc != 0 {
+				return nil, lastError()
+			}
+			return bitmapToBools(bitmap, n), nil
 		}
 		if n >= frontEndFrom {
 			for lo := 0; lo < n; lo += frontEndMax {

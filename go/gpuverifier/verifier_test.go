@@ -10,6 +10,7 @@ import (
 	"fmt"
 	"sync"
 	"testing"
+	"time"
 
 	bft "github.com/hyperledger-labs/SmartBFT/pkg/types"
 	"github.com/stretchr/testify/assert"
@@ -527,3 +528,84 @@ func TestCoalescedDeviceFaultIsNotCachedAsInvalid(t *testing.T) {
 type failingBackend struct{ cpuBackend } // RegisterKey, SignBatch, Close from the embedded value
 
 func (failingBackend) Verify(Scheme, []Item) ([]bool, error) { return nil, errors.New("no verifier") }
+
+// ADVICE r4 (high): the reference recomputes Proposal.Digest() on every call; a memo must therefore never answer for bytes
+// it did not hash.  A caller that decodes the next proposal into the SAME buffers (same slice identity, other contents) must
+// get a fresh digest: the vote over the old contents is refused, a vote over the new contents accepted.
+func TestDigestMemoIsValidatedAgainstTheBytes(t *testing.T) {
+	opt := DefaultOptions
+	opt.CacheVerified = false
+	h := newHarness(t, 4, opt)
+	defer h.v.Close()
+	payload := PayloadEncode(nil)
+	buf := append([]byte(nil), payload...)
+	prop := bft.Proposal{Payload: buf, Header: []byte("h"), Metadata: []byte("m")}
+	vote := h.nodes[1].SignProposal(prop, nil)
+	_, err := h.v.VerifyConsenterSig(*vote, prop)
+	assert.NoError(t, err) // the digest of prop is memoised from here on
+	// copy-then-mutate: another Proposal value over its own buffer is a different entry
+	q := prop
+	q.Payload = append(append([]byte(nil), payload...), 't')
+	_, err = h.v.VerifyConsenterSig(*vote, q)
+	assert.Error(t, err)
+	// in-place rewrite of the decode buffer: same slices, other bytes
+	buf[len(buf)-1] ^= 0x40
+	_, err = h.v.VerifyConsenterSig(*vote, prop)
+	assert.Error(t, err, "a vote over the OLD contents must not be accepted for the rewritten buffer")
+	fresh := h.nodes[1].SignProposal(bft.Proposal{Payload: append([]byte(nil), buf...), Header: []byte("h"), Metadata: []byte("m")}, nil)
+	_, err = h.v.VerifyConsenterSig(*fresh, prop)
+	assert.NoError(t, err, "a vote over the NEW contents is accepted: the digest was recomputed")
+	buf[len(buf)-1] ^= 0x40 // and back
+	_, err = h.v.VerifyConsenterSig(*vote, prop)
+	assert.NoError(t, err)
+}
+
+// slowBackend delays every batch: the queue of a busy Verifier is then never empty when its leader looks.
+type slowBackend struct {
+	Backend
+	delay time.Duration
+}
+
+func (s slowBackend) Verify(scheme Scheme, items []Item) ([]bool, error) {
+	time.Sleep(s.delay)
+	return s.Backend.Verify(scheme, items)
+}
+
+// ADVICE r4 (medium): the caller that becomes leader returns once ITS job is done; sustained concurrent traffic must not hold it.
+func TestLeaderIsNotHeldBySustainedTraffic(t *testing.T) {
+	be, err := NewDeviceBackend()
+	assert.NoError(t, err)
+	opt := DefaultOptions
+	opt.CacheVerified = false
+	opt.GPUMin = 1 // every single-signature call takes the coalescer (verifyOne)
+	v := New(slowBackend{Backend: be, delay: 3 * time.Millisecond}, opt)
+	defer v.Close()
+	k, _ := ecdsa.GenerateKey(elliptic.P256(), rand.Reader)
+	s := &Signer{ID: 1, Key: k}
+	v.RegisterConsenter(1, &k.PublicKey)
+	msg := []byte("view data")
+	sig := bft.Signature{ID: 1, Value: s.Sign(msg), Msg: msg}
+	deadline := time.Now().Add(400 * time.Millisecond)
+	var wg sync.WaitGroup
+	calls := make([]int, 6)
+	worst := make([]time.Duration, 6)
+	for g := range calls {
+		wg.Add(1)
+		go func(g int) {
+			defer wg.Done()
+			for time.Now().Before(deadline) {
+				t0 := time.Now()
+				assert.NoError(t, v.VerifySignature(sig))
+				if d := time.Since(t0); d > worst[g] {
+					worst[g] = d
+				}
+				calls[g]++
+			}
+		}(g)
+	}
+	wg.Wait()
+	for g := range calls {
+		assert.GreaterOrEqual(t, calls[g], 20, "a held leader completes ONE call in the whole run")
+		assert.Less(t, worst[g], 60*time.Millisecond)
+	}
+}

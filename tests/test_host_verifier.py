@@ -719,3 +719,55 @@ def test_commit_signatures_digest_matches_go_asn1(lib):
             assert k == 0
         else:
             assert k == 32 and out.raw == want, sigs[:1]
+
+
+def test_proposal_digest_memo_cannot_go_stale(lib, oracle):
+    """a commit signature over proposal p must NOT be accepted for a copy of p whose payload was changed, for p
+    after an in-place change, for a moved-from / re-assigned object — the memo of Proposal.Digest() travels with the object and
+    every mutator drops it (consensus_amd/host/formats.h).  Cache off, so that every answer comes from digest binding + backend."""
+    hx = Harness(lib, oracle, wait_us=50, cache=0)
+    try:
+        prop = (b"payload-of-sequence-1", b"hdr", b"md", 3)
+        sid, val, msg = hx.sign_proposal(1, prop, b"aux")
+        lib.sbvh_test_digest_memo.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                              ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                              ctypes.c_int64]
+        p, h, m, vs = prop
+        wrong = lib.sbvh_test_digest_memo(hx.v, sid, val, len(val), msg, len(msg), p, len(p), h, len(h), m, len(m), vs)
+        assert wrong == 0, bin(wrong)
+    finally:
+        hx.close()
+
+
+def test_a_leader_is_not_held_by_sustained_traffic(lib, oracle):
+    """the coalescer's leader used to ship batches until it found the queue EMPTY; with 6 threads verifying back
+    to back over a backend that takes 3 ms per batch the queue never is, and the first leader stayed inside submit() for the
+    whole run although its verdict was ready after the first batch.  Now a leader steps down as soon as its own job is done:
+    every thread completes many calls and no single call lasts more than a few batches."""
+    import time
+    hx = Harness(lib, oracle, wait_us=50, cache=0)
+    inner = hx._cb
+
+    def slow(tuples, n, bitmap, user):
+        time.sleep(0.003)
+        return inner(tuples, n, bitmap, user)
+
+    slow_cb = hostlib.BACKEND_FN(slow)
+    v = lib.sbvh_verifier_new(1, 0, slow_cb, None, 4096, 50, 0)
+    try:
+        q = ctypes.create_string_buffer(64)
+        lib.sbvh_signer_public_key(hx.nodes[0], q)
+        lib.sbvh_register_consenter(v, 1, q.raw)
+        msg = b"view-data-bytes"
+        val = hx.sign(hx.nodes[0], msg)
+        lib.sbvh_test_sustained_load.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+        out = (ctypes.c_double * 4)()
+        assert lib.sbvh_test_sustained_load(v, 1, val, len(val), msg, len(msg), 6, 400, out) == 0
+        fewest, most, worst_us, bad = list(out)
+        assert bad == 0
+        assert fewest >= 20, (fewest, most, worst_us)            # ~130 batches of 3 ms fit into 400 ms; a held leader completed ONE call
+        assert worst_us < 60000, (fewest, most, worst_us)        # a handful of batches, not the whole run
+    finally:
+        lib.sbvh_verifier_free(v)
+        hx.close()
