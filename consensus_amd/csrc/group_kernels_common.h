@@ -52,7 +52,7 @@ static __global__ __launch_bounds__(256) void k_pack_bitmap(const uint8_t* __res
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const size_t i = b * 8 + k;
-        if (i < n && acc[i]) v |= 1u << k;
+        if (i < n && acc[i] == 1) v |= 1u << k;       // exactly "accepted": a tuple left in a transient state (SBV_ED_PENDING) by a step that never finished it is a REJECT
     }
     bitmap[b] = (uint8_t)v;
 }

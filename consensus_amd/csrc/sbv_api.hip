@@ -972,6 +972,16 @@ namespace {
 // and about a second.
 constexpr size_t kWideAutoSplit = 16;
 int drop_wide_keys(Context& c);
+// A wide-comb pool may take HBM only while a reserve stays free for everything that is sized per batch (the scratch of a 2^21-tuple
+// launch, the grouping arrays and comb pools of the three schemes: ~8 GB): min(16 GB, a quarter of the device).  On an MI355X
+// (288 GB) the 7 GB of a 16-node cluster's 20-bit combs are far inside; on a smaller or crowded device the policy steps down to
+// 16 bits and then to "no wide combs" instead of leaving later batches with SBV_ENOMEM.
+bool wide_pool_fits(size_t extra_bytes) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return true;
+    const size_t reserve = total_b / 4 < ((size_t)16 << 30) ? total_b / 4 : ((size_t)16 << 30);
+    return free_b > extra_bytes && free_b - extra_bytes >= reserve;
+}
 int widen_slots(Context& c, const std::vector<u32>& slots) {
     std::vector<u32> todo;
     {
@@ -987,7 +997,10 @@ int widen_slots(Context& c, const std::vector<u32>& slots) {
         // The width follows the size of the consenter set: 20-bit combs (13 additions, 436 MB per key) while at most kWideAutoSplit
         // keys are wide — a 16-node cluster holds 7 GB of them — and 16-bit combs (16 additions, 35.7 MB) beyond; crossing the line
         // rebuilds what was there (two launches: milliseconds).
-        const int want_bits = c.wide_slots.size() + todo.size() <= kWideAutoSplit ? 20 : 16;
+        int want_bits = c.wide_slots.size() + todo.size() <= kWideAutoSplit ? 20 : 16;
+        // the 20-bit pool is sized ONCE for a full 16-key set (no doubling, no old + new copies side by side): does it fit?
+        if (want_bits == 20 && !(c.kwide_bits == 20 && c.kwide_cap >= kWideAutoSplit) &&
+            !wide_pool_fits((kWideAutoSplit < c.kwide_max ? kWideAutoSplit : (size_t)c.kwide_max) * sbv::gcomb_entries(20) * sizeof(sbv::apt))) want_bits = 16;
         if (want_bits != c.kwide_bits) {
             std::vector<u32> all = c.wide_slots;
             all.insert(all.end(), todo.begin(), todo.end());
@@ -1000,9 +1013,11 @@ int widen_slots(Context& c, const std::vector<u32>& slots) {
     const size_t stride = sbv::gcomb_entries(c.kwide_bits);
     const size_t want = c.wide_slots.size() + todo.size();
     if (want > c.kwide_cap) {
-        size_t cap = c.kwide_cap ? c.kwide_cap : 4;
+        // 18-20-bit combs: a 16-key pool at once (the auto policy never holds more at 20 bits).  Narrower combs: 64 keys at once (2.3 GB at 16 bits).  Doubling beyond.
+        size_t cap = c.kwide_cap ? c.kwide_cap : (c.kwide_bits >= 18 ? kWideAutoSplit : 64);
         while (cap < want) cap *= 2;
         if (cap > c.kwide_max) cap = c.kwide_max;
+        if (!wide_pool_fits(cap * stride * sizeof(sbv::apt))) return SBV_OK;      // no room beside the reserve: the slots keep their 8-bit combs (same verdicts)
         sbv::apt* nt = nullptr;
         HIP_TRY(SBV_ENOMEM, hipMalloc(&nt, cap * stride * sizeof(sbv::apt)));
         HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());          // nothing in flight may still read the old tables
