@@ -139,7 +139,7 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     GroupState g;
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
     g.counters = b.counters; g.grp_idx = b.grp_idx; g.ung_idx = b.ung_idx; g.slots = b.slots;
-    g.max_groups = b.max_groups;
+    g.max_groups = b.max_groups; g.seed = b.seed;
     g.gcount = b.gcount; g.gcursor = b.gcount ? b.gcount + b.max_groups : nullptr; g.grp_of = b.grp_of; g.ung_cand = b.ung_cand;
     // key-sorted grouped list (p256_group.h): the Q phase walks runs of equal keys; the accumulator is tuple-major so that the
     // G phase can still start at once, in tuple order

@@ -142,7 +142,7 @@ hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     if (n == 0) return hipSuccess;
     GroupState g;
     g.ht = b.ht; g.ht_mask = b.ht_mask; g.rep = b.rep; g.cnt = b.cnt; g.slot_of = b.slot_of; g.group_rep = b.group_rep;
-    g.counters = b.counters; g.grp_idx = b.grp_idx; g.ung_idx = b.ung_idx; g.slots = b.slots; g.max_groups = b.max_groups;
+    g.counters = b.counters; g.grp_idx = b.grp_idx; g.ung_idx = b.ung_idx; g.slots = b.slots; g.max_groups = b.max_groups; g.seed = b.seed;
     g.gcount = b.gcount; g.gcursor = b.gcount + b.max_groups; g.grp_of = b.grp_of; g.ung_cand = b.ung_cand;
     g.sorted = 1u;
     group_set_threshold(g, b.min_count);

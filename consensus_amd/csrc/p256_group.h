@@ -44,6 +44,15 @@ SBV_HD u32 host_add(u32* p, u32 v) { const u32 old = *p; *p = old + v; return ol
 
 #define SBV_GROUP_NONE 0xFFFFFFFFu
 #define SBV_GROUP_COUNTERS 8
+// Hash-flooding defence of the two open-addressing tables below (in a BFT library the adversary is the
+// design point, and the keys of a batch are attacker-chosen bytes that are inserted BEFORE any curve check):
+//   * both hashes are keyed with a per-context random seed (GroupState::seed, KeyCache::seed): key bytes that collide under one
+//     seed are unrelated under another, so collisions cannot be precomputed;
+//   * a probe sequence is followed for at most SBV_GROUP_MAX_PROBES entries.  A tuple that has not found its key by then simply
+//     stays UNGROUPED (it represents itself and takes the generic kernel: same verdict, no table), a cache lookup answers "not
+//     cached".  At the tables' load factors (<= 0.5 and <= 0.25) a random key needs more than 64 probes with negligible
+//     probability; whatever an adversary manages, insert work per tuple is bounded by 64 comparisons of 64 bytes instead of n.
+#define SBV_GROUP_MAX_PROBES 64u
 
 struct GroupState {
     u32* ht;          // hash table, ht_mask + 1 entries, zeroed before every batch
@@ -65,6 +74,7 @@ struct GroupState {
     u32 min_count;    // requested threshold (users of a key in this batch)
     u32 sample_mask;  // tuples with group_sampled(i, sample_mask) are counted
     u32 min_samples;  // threshold on the sampled count
+    u32 seed;         // key of the grouping hash (per context, random; 0 in the emulator unless a test sets it)
 };
 
 // Sampling rate for a threshold: exact counting for small thresholds (tests, tiny batches), otherwise
@@ -117,17 +127,17 @@ SBV_HD void group_insert_lane_t(const uint8_t* tuples, size_t i, const GroupStat
     // every key word goes into the hash: the batch's corrupted tuples are single-bit variants of the signers'
     // keys, and a hash that skips words sends each variant down its original's probe chain (measured: ~30
     // probes per wavefront, 1 ms per batch)
-    u32 h = 0x9E3779B1u;
+    u32 h = 0x9E3779B1u ^ g.seed;
     SBV_UNROLL
     for (int j = 0; j < WORDS; ++j) {
         h = (h ^ w[j]) * 0x85EBCA77u;
         h ^= h >> 15;
     }
-    h *= 0xC2B2AE3Du;
+    h = (h ^ (g.seed * 0x27D4EB2Fu)) * 0xC2B2AE3Du;      // the seed once more behind the last key word: the final mix is keyed too
     h ^= h >> 16;
     u32 slot = h & g.ht_mask;
-    u32 mine = (u32)i;
-    for (u32 probes = 0; probes <= g.ht_mask; ++probes) {
+    u32 mine = (u32)i;              // no group found within the probe bound: the tuple represents itself (ungrouped, generic kernel)
+    for (u32 probes = 0; probes < SBV_GROUP_MAX_PROBES && probes <= g.ht_mask; ++probes) {
         u32 v = g.ht[slot];
         if (v == 0) v = SBV_ATOMIC_CAS(&g.ht[slot], 0u, (u32)i + 1u);
         if (v == 0) break;                                   // claimed: this tuple represents its key
@@ -228,21 +238,23 @@ struct KeyCache {
     u32* count;       // [0] slots handed out (may overshoot cap), [1] hits, [2] misses of the current batch
     u32 cap;
     u32 enabled;
+    u32 seed;         // key of key_hash16 (per cache, random, fixed while the cache holds entries)
 };
-SBV_HD u32 key_hash16(const u32 w[16]) {
-    u32 h = 0x9E3779B1u;
+SBV_HD u32 key_hash16(const u32 w[16], u32 seed) {
+    u32 h = 0x9E3779B1u ^ seed;
     SBV_UNROLL
     for (int j = 0; j < 16; ++j) {
         h = (h ^ w[j]) * 0x85EBCA77u;
         h ^= h >> 15;
     }
-    h *= 0xC2B2AE3Du;
+    h = (h ^ (seed * 0x27D4EB2Fu)) * 0xC2B2AE3Du;
     return h ^ (h >> 16);
 }
-// read-only phase: slot of a cached key, or NONE
+// read-only phase: slot of a cached key, or NONE (also when the key is not among the first SBV_GROUP_MAX_PROBES entries of its
+// probe sequence: the group is then built as a cold one — same verdicts)
 SBV_HD u32 key_cache_lookup(const KeyCache& kc, const u32 w[16]) {
-    u32 p = key_hash16(w) & kc.ht_mask;
-    for (u32 probes = 0; probes <= kc.ht_mask; ++probes) {
+    u32 p = key_hash16(w, kc.seed) & kc.ht_mask;
+    for (u32 probes = 0; probes < SBV_GROUP_MAX_PROBES && probes <= kc.ht_mask; ++probes) {
         const u32 v = kc.ht[p];
         if (v == 0) return SBV_GROUP_NONE;
         const u32* o = kc.keys + (size_t)(v - 1) * 16;
@@ -263,8 +275,10 @@ SBV_HD u32 key_cache_insert(const KeyCache& kc, const u32 w[16]) {
     u32* o = kc.keys + (size_t)slot * 16;
     SBV_UNROLL
     for (int j = 0; j < 16; ++j) o[j] = w[j];
-    u32 p = key_hash16(w) & kc.ht_mask;
-    for (u32 probes = 0; probes <= kc.ht_mask; ++probes) {
+    // within the probe bound, or not published at all: the slot then serves this batch only (its table is built and used through
+    // tslot) and later batches rebuild the key — a cost an adversary who cannot see the seed cannot aim
+    u32 p = key_hash16(w, kc.seed) & kc.ht_mask;
+    for (u32 probes = 0; probes < SBV_GROUP_MAX_PROBES && probes <= kc.ht_mask; ++probes) {
         if (SBV_ATOMIC_CAS(&kc.ht[p], 0u, slot + 1u) == 0u) break;
         p = (p + 1) & kc.ht_mask;
     }

@@ -65,6 +65,7 @@ struct GroupBuffers {
     u32* ung_cand = nullptr;    // [cap] key-sorted step: ungrouped candidates before the key check
     u32* rec = nullptr;         // [scratch cap][SBV_REC_WORDS] stage A's per-tuple records (Scratch::rec) for the key-sorted list
     u32 max_groups = 0, min_count = 0;
+    u32 seed = 0;               // key of the grouping hash table (GroupState::seed): random per context
     size_t cap = 0;
     size_t gacc_cap = 0;        // the scratch capacity gacc was sized for
 };

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <atomic>
 #include <mutex>
+#include <random>
 #include <shared_mutex>
 #include <string>
 #include <thread>
@@ -243,6 +244,19 @@ std::vector<hipEvent_t*> group_events(Context& c) {
     return v;
 }
 
+// Keys of the grouping / key-cache hashes (p256_group.h: hash-flooding defence): one fresh 32-bit value per table from the OS's
+// entropy source, never exported.  SBV_HASH_SEED=<hex> pins it — for tests that must reproduce a collision pattern (seed 0 is the
+// unkeyed hash of rounds 1-4), never for production.
+u32 fresh_hash_seed() {
+    static const char* pinned = getenv("SBV_HASH_SEED");
+    if (pinned) return (u32)strtoul(pinned, nullptr, 16);
+    static std::mutex mu;
+    static std::random_device rd;
+    std::lock_guard<std::mutex> lk(mu);
+    const u32 t = (u32)std::chrono::steady_clock::now().time_since_epoch().count();
+    return (u32)rd() ^ ((u32)rd() << 16) ^ (t * 0x9E3779B1u);
+}
+
 // device arrays of one persistent key-table cache (p256_group.h: KeyCache) for `K` keys
 int key_cache_alloc(sbv::KeyCache& kc, size_t K, bool enabled) {
     size_t kht = 1024;
@@ -255,6 +269,7 @@ int key_cache_alloc(sbv::KeyCache& kc, size_t K, bool enabled) {
     kc.ht_mask = (u32)(kht - 1);
     kc.cap = (u32)K;
     kc.enabled = enabled ? 1u : 0u;
+    kc.seed = fresh_hash_seed();           // fixed for as long as this table holds entries
     return SBV_OK;
 }
 void key_cache_free(sbv::KeyCache& kc) {
@@ -343,6 +358,7 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tmp, G * SBV_GTAB_WINDOWS * (size_t)(SBV_GTAB_PER_WINDOW * 40) * sizeof(u32)));     // Ed25519: 128 x 40 raw limbs per (key, window)
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.acc, cap));
     b.ht_mask = (u32)(ht - 1);
+    b.seed = fresh_hash_seed();            // the per-batch grouping table is empty at the start of every batch: any seed will do, a secret one is the point
     b.max_groups = (u32)G;
     b.min_count = c.group_min_count;
     b.cap = cap;

@@ -184,6 +184,8 @@ void sbve_scheme_key_cache_stats(int scheme, u32 out[3]) {
     for (int i = 0; i < 3; ++i) out[i] = e.count.size() ? e.count[i] : 0;
 }
 void sbve_set_group_chunks(int c) { g_group_chunks = c < 1 ? 1 : (c > 4 ? 4 : c); }
+static u32 g_hash_seed = 0;        // GroupState::seed of the emulated grouped steps (the library draws a random one per context)
+void sbve_set_hash_seed(u32 s) { g_hash_seed = s; }
 static void emul_window_rows_fill(const u32* recs, bool top, u32* tmp, apt* row);
 void sbve_set_group_coop(int on) { g_group_coop = on != 0; }     // k_group_coop instead of the G phase + Q launches (key-sorted step only)
 // grouped form: generic tuples, keys grouped inside the call (p256_group.h), emulated sequentially.
@@ -210,6 +212,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(max_groups ? max_groups : 1), counters(SBV_GROUP_COUNTERS, 0), ung_cand(cap),
         grp_idx(cap, 0xFFFFFFFFu), ung_idx(cap), slots(cap), gcount(2 * (size_t)(max_groups ? max_groups : 1), 0), grp_of(cap, 0xFFFFFFFFu);
     GroupState g{};
+    g.seed = g_hash_seed;
     g.gcount = gcount.data(); g.gcursor = gcount.data() + (max_groups ? max_groups : 1); g.grp_of = grp_of.data(); g.ung_cand = ung_cand.data(); g.sorted = (u32)g_group_sort;
     g.ht = ht.data(); g.ht_mask = (u32)(((size_t)1 << ht_bits) - 1); g.rep = rep.data(); g.cnt = cnt.data(); g.slot_of = slot_of.data();
     g.group_rep = group_rep.data(); g.counters = counters.data(); g.grp_idx = grp_idx.data(); g.ung_idx = ung_idx.data();
@@ -384,6 +387,7 @@ int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
     memcpy(tup.data() + 96, key64, 64);
     u32 rep0 = 0, counters[SBV_GROUP_COUNTERS] = {1};
     GroupState g{};
+    g.seed = g_hash_seed;
     g.group_rep = &rep0; g.counters = counters; g.max_groups = 1;
     std::vector<u32> bases((size_t)SBV_GTAB_WINDOWS * SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS, 0xA5A5A5A5u), jstate(SBV_KT29_STATE_WORDS), tmpa(7 * SBV_KT29_FILL_TMP_WORDS);
     uint8_t valid = 0xEE;
@@ -618,6 +622,7 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(max_groups ? max_groups : 1), counters(SBV_GROUP_COUNTERS, 0),
         grp_idx(cap, 0xFFFFFFFFu), ung_idx(cap), ung_cand(cap), slots(cap), gcount(2 * (size_t)(max_groups ? max_groups : 1), 0), grp_of(cap, 0xFFFFFFFFu);
     GroupState g{};
+    g.seed = g_hash_seed;
     g.gcount = gcount.data(); g.gcursor = gcount.data() + (max_groups ? max_groups : 1); g.grp_of = grp_of.data(); g.ung_cand = ung_cand.data(); g.sorted = (u32)g_group_sort;
     g.ht = ht.data(); g.ht_mask = (u32)(((size_t)1 << ht_bits) - 1); g.rep = rep.data(); g.cnt = cnt.data(); g.slot_of = slot_of.data();
     g.group_rep = group_rep.data(); g.counters = counters.data(); g.grp_idx = grp_idx.data(); g.ung_idx = ung_idx.data();
@@ -872,6 +877,7 @@ void sbve_k256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     std::vector<u32> ht((size_t)1 << ht_bits, 0), rep(cap), cnt(cap, 0), slot_of(cap), group_rep(G), counters(SBV_GROUP_COUNTERS, 0), ung_cand(cap),
         grp_idx(cap, 0xFFFFFFFFu), ung_idx(cap), slots(cap), gcount(2 * (size_t)G, 0), grp_of(cap, 0xFFFFFFFFu);
     GroupState g{};
+    g.seed = g_hash_seed;
     g.gcount = gcount.data(); g.gcursor = gcount.data() + G; g.grp_of = grp_of.data(); g.ung_cand = ung_cand.data(); g.sorted = 1;
     g.ht = ht.data(); g.ht_mask = (u32)(((size_t)1 << ht_bits) - 1); g.rep = rep.data(); g.cnt = cnt.data(); g.slot_of = slot_of.data();
     g.group_rep = group_rep.data(); g.counters = counters.data(); g.grp_idx = grp_idx.data(); g.ung_idx = ung_idx.data();

@@ -725,3 +725,46 @@ def test_variable_time_division_steps_equal_the_constant_time_ones_and_the_inver
         for x in xs:
             assert emul.sbve_modinv30_both(limbs(x), which, a, b) == 1, (which, hex(x))
             assert val(a) == (pow(x, -1, m) if x else 0), (which, hex(x))
+
+
+# ---- hash-flooding defence of the grouping table (p256_group.h: SBV_GROUP_MAX_PROBES, GroupState::seed) -------------------------
+from hashflood import colliding_keys, grouping_hash  # noqa: E402,F401
+
+
+def test_probe_bound_keeps_insert_work_bounded_and_verdicts_identical(emul, oracle):
+    """600 distinct keys that all land in ONE slot of the grouping table under seed 0, each signing 3 tuples, beside
+    an honest batch.  With the unkeyed hash (seed 0) the probe bound cuts the chain: the first SBV_GROUP_MAX_PROBES keys of the
+    chain group as always, every later tuple represents itself and takes the generic kernel — verdicts unchanged (these keys are
+    no curve points: all rejected), the honest tuples unaffected.  Under another seed the same keys spread out and group."""
+    import random
+    rng = random.Random(99)
+    emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    emul.sbve_set_hash_seed.argtypes = [ctypes.c_uint32]
+    ht_bits = 12
+    keys = colliding_keys(600, ht_bits, 0, rng)
+    assert len(set(keys)) == 600
+    n = 700
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0x77, n, 5, 6, tup, exp, 4)
+    junk = b"".join(tup.raw[160 * (j % n):160 * (j % n) + 96] + k for j, k in enumerate(keys * 3))     # real r | s | hash, crafted keys
+    allt = tup.raw + junk
+    total = len(allt) // 160
+    want = _bitmap_list(exp.raw, n) + [False] * (total - n)
+    stats = (ctypes.c_uint32 * 4)()
+    res = {}
+    try:
+        for seed in (0, 0x5EED1234):
+            emul.sbve_set_hash_seed(seed)
+            bm = ctypes.create_string_buffer((total + 7) // 8)
+            emul.sbve_p256_verify_batch_grouped(allt, total, bm, 2, 4096, ht_bits, stats)
+            assert _bitmap_list(bm.raw, total) == want, seed
+            assert stats[1] + stats[2] + stats[3] == total
+            res[seed] = list(stats)
+    finally:
+        emul.sbve_set_hash_seed(0)
+    # seed 0: at most 64 + a few of the crafted keys can be found within the bound; the others' 3 x ~536 tuples are ungrouped
+    # (rejected for their key: stats[3]).  Another seed: every crafted key groups (3 uses >= the threshold of 2).
+    assert res[0][0] <= 5 + 64 + 8 and res[0][3] >= 3 * (600 - 64 - 8)
+    assert res[0x5EED1234][0] >= 5 + 600 - 8 and res[0x5EED1234][3] < 50
