@@ -171,6 +171,47 @@ def leg_warm_cache(sbv, torch, d_tuples, d_bitmap, valid, n, steps, stream):
         sbv.key_cache(False)
 
 
+def leg_key_count_sweep(sbv, synth, torch, n, stream, key_counts=None, reps=3):
+    """Throughput as a function of DISTINCT KEYS (missing #7 / next #3): the headline rests on 1024 signers; a
+    VerifyProposal of K mostly-distinct clients (internal/bft/view.go:553-559; config.go:94-98 lets K be anything) lands elsewhere
+    on this curve.  n tuples (7/8 valid) over 256 ... n distinct keys, device-resident, cold (key-table cache off: every step builds
+    what it uses) and warm (cache on, second pass on), with what the grouping step decided (groups, tuples through tables,
+    tuples through the one-lane kernel) and the whole bitmap checked against the generator's at every point."""
+    import numpy as np
+    out = []
+    for K in (key_counts or (256, 1024, 4096, 16384, 65536, 262144, n)):
+        K = min(K, n)
+        tuples, valid = synth.gen_batch(SEED + 0x900 + K, n, K, 8)
+        d_t = torch.from_numpy(tuples).cuda()
+        d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
+        point = {"keys": K, "signatures_per_key": n / K}
+        for mode in ("cold", "warm"):
+            sbv.key_cache(mode == "warm")
+            try:
+                sbv.verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(reps):
+                    t0 = time.perf_counter()
+                    sbv.verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                dt = sorted(ts)[len(ts) // 2]
+                g = sbv.last_group_stats()
+                point[mode] = {"verifies_per_s": n / dt, "ms": 1e3 * dt, "groups": g[0], "tuples_through_tables": g[1],
+                               "tuples_one_lane_kernel": g[2], "bitmap_correct": bool((d_b.cpu().numpy() == valid).all())}
+            finally:
+                sbv.key_cache(False)
+        out.append(point)
+        del d_t, d_b
+    worst = 0.0
+    for a, b in zip(out, out[1:]):
+        if b["signatures_per_key"] >= 16:
+            worst = max(worst, a["cold"]["verifies_per_s"] / b["cold"]["verifies_per_s"])
+    return {"tuples": n, "points": out, "largest_cold_step_between_adjacent_points_down_to_16_sigs_per_key": worst,
+            "all_bitmaps_correct": all(p[m]["bitmap_correct"] for p in out for m in ("cold", "warm"))}
+
+
 def leg_all_valid(sbv, synth, torch, n, steps, stream):
     """The same batch shape with every signature valid ("also report all-valid")."""
     import numpy as np
@@ -774,6 +815,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--primary-only", action="store_true", help="skip the secondary legs (grouping off, registered keys): quick A/B runs")
     ap.add_argument("--warm-leg", action="store_true", help="with --primary-only: still run the warm-key-cache leg")
+    ap.add_argument("--legs", default="", help="comma-separated names of the secondary legs to run (default: all of them); dev sessions")
     args = ap.parse_args()
 
     import numpy as np
@@ -916,6 +958,7 @@ def main():
     if world == 1 and not args.primary_only:
         for name, fn in (("warm_key_cache", lambda: leg_warm_cache(sbv, torch, d_tuples, d_bitmap, valid, n, max(2, args.steps // 2), stream)),
                          ("all_valid", lambda: leg_all_valid(sbv, synth, torch, n, max(2, args.steps // 2), stream)),
+                         ("key_count_sweep", lambda: leg_key_count_sweep(sbv, synth, torch, n, stream)),
                          ("end_to_end", lambda: leg_end_to_end(sbv, tuples, valid, n, max(2, args.steps // 2))),
                          ("sharded_entry", lambda: leg_sharded(sbv, tuples, valid, n, max(2, args.steps // 2))),
                          ("ed25519", lambda: leg_ed25519(sbv, torch, n, max(2, args.steps // 2), stream, not args.no_cpu_baseline)),
@@ -927,6 +970,8 @@ def main():
                          ("replay_550k_keyed", lambda: leg_replay_550k_keyed(sbv, synth)),
                          ("consenter_keys_550k", lambda: leg_consenter_keys(sbv, synth, torch, stream, max(2, args.steps // 2))),
                          ("front_end_msgs_per_s", lambda: leg_front_end(sbv, tuples, valid, n))):
+            if args.legs and name not in args.legs.split(","):
+                continue
             try:
                 extra[name] = fn()
             except Exception as e:      # noqa: BLE001 - the headline number must not depend on a secondary leg

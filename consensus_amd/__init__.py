@@ -513,5 +513,15 @@ def last_group_stats():
     return out[0], out[1], out[2], out[3]
 
 
+def last_table_classes():
+    """(groups verified from a full table, groups filled in this batch, grouped tuples served by the rows-only pass) of the last grouped
+    P-256 batch (sbv_p256_last_table_classes)."""
+    out = (ctypes.c_uint32 * 3)()
+    lib = load()
+    lib.sbv_p256_last_table_classes.argtypes = [ctypes.c_void_p]
+    _check(lib.sbv_p256_last_table_classes(out))
+    return out[0], out[1], out[2]
+
+
 def bitmap_to_list(bm: bytes, n: int):
     return [bool((bm[i >> 3] >> (i & 7)) & 1) for i in range(n)]

@@ -210,8 +210,66 @@ SBV_HD void qphase29_point(xyzz& R, const u256& u2in, const apt* qtab, int j0, i
         cur = nxt; neg = negn; skip = skipn;
     }
 }
+// ---- the NARROW view of a key's comb (round 5) ------------------------------------------------------------------------------------
+// The rows step of the table builder (p256_keytab29.h) leaves, in every 128-entry window row j, the babies b * B_j (b = 1..8, entries
+// 0..7) and the giants 16 a * B_j (a = 1..8, entries 15, 31, ..., 127); the fill step derives the other 112 entries from them and costs
+// three quarters of a table.  Babies and giants alone ARE a comb with 4-bit windows — b * 2^(8j) Q and a * 2^(8j+4) Q — so a key
+// that signs too few tuples of a batch to earn a full table is verified from its rows alone: the same signed 8-bit digit d of u2,
+// |d| = 16 a + b with a = (|d| + 7) >> 4 in 0..8 and b in -7..8, costs two exact additions (giant, then baby; zero parts skipped:
+// 1.83 per window on average) instead of one.  A full table holds the same entries, so a wavefront that mixes both kinds of key
+// takes this path for all its lanes.  Break-even against the one-lane doubling kernel: ~4 signatures per key (a table without its
+// fill costs ~3 generic verifications, a narrow verification 72 additions instead of 256 doublings + 64 additions); against the
+// full table: ~250 signatures per key (the fill's ~14 M instructions buy 26 fewer additions per signature).
+SBV_HD void narrow_split(int idx, bool skip, int& gi, int& bi, bool& bneg) {
+    const int ad = skip ? 0 : idx + 1;
+    const int a = (ad + 7) >> 4;
+    const int b = ad - 16 * a;
+    gi = a ? 16 * a - 1 : -1;
+    bi = b ? (b < 0 ? -b : b) - 1 : -1;
+    bneg = b < 0;
+}
+SBV_HD void qphase29_point_narrow(xyzz& R, const u256& u2in, const apt* qtab, int j0, int j1) {
+    const bool flip = (u2in.v[7] >> 31) != 0;
+    u256 u2, nmu;
+    (void)sub256(nmu, sc_n(), u2in);
+    select256(u2, flip, nmu, u2in);
+    u256 k2;
+    const u32 top2 = add_const_limbs(k2, u2, 0x80808080u);
+    if (j1 == SBV_GTAB_WINDOWS && !wave_any(top2 != 0)) j1 = SBV_GTAB_WINDOWS - 1;
+    if (j0 >= j1) return;
+    int idx, gi, bi; bool neg, skip, bneg;
+    comb_digit(k2, top2, j0, idx, neg, skip);
+    narrow_split(idx, skip, gi, bi, bneg);
+    raw_apt cg, cb;                                   // the current window's giant and baby (entry 0 stands in for an absent part: never added)
+    raw_apt_load(cg, qtab + (size_t)j0 * SBV_GTAB_PER_WINDOW + (gi < 0 ? 0 : gi));
+    raw_apt_load(cb, qtab + (size_t)j0 * SBV_GTAB_PER_WINDOW + (bi < 0 ? 0 : bi));
+    SBV_NOUNROLL
+    for (int j = j0; j < j1; ++j) {
+        const int jn = j + 1 < j1 ? j + 1 : j1 - 1;
+        int idxn, gin, bin; bool negn, skipn, bnegn;
+        comb_digit(k2, top2, jn, idxn, negn, skipn);
+        narrow_split(idxn, skipn, gin, bin, bnegn);
+        raw_apt ng;                                   // the next giant is fetched one addition ahead, the next baby after the giant's addition
+        raw_apt_load(ng, qtab + (size_t)jn * SBV_GTAB_PER_WINDOW + (gin < 0 ? 0 : gin));
+        if (gi >= 0) {
+            apt29 q;
+            raw_apt_unpack(q, cg);
+            pt29_madd(R, q, neg != flip);
+        }
+        raw_apt nb;
+        raw_apt_load(nb, qtab + (size_t)jn * SBV_GTAB_PER_WINDOW + (bin < 0 ? 0 : bin));
+        if (bi >= 0) {
+            apt29 q;
+            raw_apt_unpack(q, cb);
+            pt29_madd(R, q, (neg != flip) != bneg);
+        }
+        cg = ng; cb = nb; neg = negn; gi = gin; bi = bin; bneg = bnegn;
+    }
+}
+
 // Q phase of the grouped step.  `last` -> the verdict is returned; otherwise R goes back to gacc for the next chunk
 // of windows and the return value is meaningless.
+template <bool NARROW = false>
 SBV_HD bool qphase29_lane(const Scratch& s, size_t i, u32 slot, u32 nkeys, const apt* ktab, const uint8_t* kvalid,
                           u32* gacc, int j0, int j1, bool last) {
     u256 u2;
@@ -222,13 +280,15 @@ SBV_HD bool qphase29_lane(const Scratch& s, size_t i, u32 slot, u32 nkeys, const
     const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
     xyzz R;
     gacc29_load(R, gacc, s.cap, i);
-    qphase29_point(R, u2, qtab, j0, j1);
+    if (NARROW) qphase29_point_narrow(R, u2, qtab, j0, j1);
+    else qphase29_point(R, u2, qtab, j0, j1);
     if (!last) { gacc29_store(gacc, s.cap, i, R); return false; }
     u256 r;
     soa_load(r, s.r, s.cap, i);
     return ok && pt29_rx_matches(R, r);
 }
 
+template <bool NARROW = false>
 SBV_HD bool qphase29_lane_sorted(const Scratch& s, size_t t, size_t L, u32 slot, u32 nkeys, const apt* ktab, const uint8_t* kvalid,
                                  u32* gacc, int j0, int j1, bool last) {
     u256 u2;
@@ -239,7 +299,8 @@ SBV_HD bool qphase29_lane_sorted(const Scratch& s, size_t t, size_t L, u32 slot,
     const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
     xyzz R;
     gacc29_load(R, gacc, s.cap, L);
-    qphase29_point(R, u2, qtab, j0, j1);
+    if (NARROW) qphase29_point_narrow(R, u2, qtab, j0, j1);
+    else qphase29_point(R, u2, qtab, j0, j1);
     if (!last) { gacc29_store(gacc, s.cap, L, R); return false; }
     u256 r;
     rec_load256(r, s.rec, t, SBV_REC_R);

@@ -77,11 +77,13 @@ struct GroupState {
     u32 seed;         // key of the grouping hash (per context, random; 0 in the emulator unless a test sets it)
 };
 
-// Sampling rate for a threshold: exact counting for small thresholds (tests, tiny batches), otherwise
-// every 2^k-th tuple with at least 8 expected samples at the threshold.
+// Sampling rate for a threshold: thresholds from 16 on count every 8th tuple, smaller ones (tests, tiny batches) count exactly.
+// The counting atomics sit on the path to the G phase, so the rate does NOT grow when the threshold drops from round 1-4's 64 (8
+// samples) to round 5's default of 16 (a key's rows pay from ~4 signatures on, p256_comb29.h): a key then passes with 2 of its
+// every-8th tuples — a soft edge (a 16-use key passes with probability 0.61, a 32-use key 0.91, a 64-use key 0.998, a 4-use key
+// 0.08), which only decides who gets a table, never a verdict.
 SBV_HD void group_set_threshold(GroupState& g, u32 min_count) {
-    u32 shift = 0;
-    while (shift < 6 && (min_count >> (shift + 1)) >= 8) ++shift;
+    const u32 shift = min_count >= 16 ? 3u : 0u;
     g.min_count = min_count;
     g.sample_mask = (1u << shift) - 1u;
     const u32 ms = min_count >> shift;
@@ -355,6 +357,32 @@ SBV_HD void key_cache_phase_insert(const uint8_t* tuples, const GroupState& g, c
         slot = key_cache_insert(kc, w);
     }
     tslot[k] = slot == SBV_GROUP_NONE ? kc.cap + k : slot;
+}
+
+// ---- table classes (round 5) ------------------------------------------------------------------------------------------------
+// Every group gets its ROWS (babies and giants of every window: a comb with 4-bit windows, p256_comb29.h: qphase29_point_narrow);
+// the FILL — three quarters of a table's cost — is spent only on keys that sign at least `full_min` tuples of this batch, or whose
+// cached table was filled by an earlier batch.  full[k] = group k's lanes may take one addition per window; needfill[k] = run the
+// fill for it in this batch (a cold key that earns it, or a cached narrow table whose key has become hot: an upgrade — its rows are
+// there, only the fill runs).  kfull[slot] remembers the state of a table slot across batches (cache slots; a per-batch slot is
+// always cold).  count: the group's exact size from the counting sort, or the sampled count scaled up.
+#define SBV_FULL_TABLE_MIN_DEFAULT 256u
+SBV_HD void group_table_class_lane(u32 k, const GroupState& g, const u32* tslot, const uint8_t* cold, const uint8_t* kfull, u32 table_slots,
+                                   u32 full_min, uint8_t* full, uint8_t* needfill) {
+    const u32 count = g.sorted ? g.gcount[k] : g.cnt[g.group_rep[k]] * (g.sample_mask + 1u);
+    const u32 slot = tslot[k];
+    const bool already = slot < table_slots && !cold[k] && kfull[slot] != 0;
+    const bool wants = count >= full_min;
+    full[k] = already || wants ? 1 : 0;
+    needfill[k] = wants && !already ? 1 : 0;
+}
+// after every fill of the batch has run: what the slots hold now
+SBV_HD void group_table_mark_lane(u32 k, const u32* tslot, const uint8_t* cold, const uint8_t* full, const uint8_t* needfill, u32 table_slots,
+                                  uint8_t* kfull) {
+    const u32 slot = tslot[k];
+    if (slot >= table_slots) return;
+    if (cold[k]) kfull[slot] = full[k];
+    else if (needfill[k]) kfull[slot] = 1;
 }
 
 // ---- per-batch key tables ----------------------------------------------------------------------------

@@ -108,53 +108,104 @@ struct keychain_quad_dev {
         }
     }
 };
+// The table kernels run on BOUNDED grids (round 5): a launch holds at most SBV_TABLE_GRID_BLOCKS workgroups of 64 lanes and every
+// lane walks its share of the work items in a grid-stride loop.  The number of groups is known on the device only, and a batch may
+// now hold up to 65 536 of them (sbv_p256_set_grouping): a grid sized for the capacity would dispatch ~140 000 empty workgroups per
+// launch on the headline batch (1024 groups), and scratch indexed by (key, window) would take 44 GB.  With the bound, the headline
+// batch still runs every item in one pass (its 2 176 fill workgroups fit), a 16 384-key batch loops, and the per-lane scratch of the
+// rows / fill steps is indexed by the RESIDENT lane: 2 parities x 4096 x 64 lanes x 675 words = 1.4 GB.
+#define SBV_TABLE_GRID_BLOCKS 4096u
 // lanes = groups x 4 (p256_keytab29.h: keychain29_run); a quad lives or exits as a whole
 __global__ __launch_bounds__(64) void k_keytab29_chain(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jstate,
                                                        u32* __restrict__ bases, uint8_t* __restrict__ valid,
                                                        const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
                                                        int j_first, int j_last, u32 rec_mask) {
-    const u32 lane = blockIdx.x * 64 + threadIdx.x;
-    const u32 k = lane >> 2;
-    if (k >= group_count(g) || !cold[k]) return;
-    table_prio();
-    keychain_quad_dev q;
-    q.r = (int)(lane & 3u);
-    keychain29_run(q, tuples, k, g, jstate, bases, valid + tslot[k], j_first, j_last, rec_mask);
+    const u32 groups = group_count(g);
+    for (u32 lane = blockIdx.x * 64 + threadIdx.x; (lane >> 2) < groups; lane += gridDim.x * 64) {
+        const u32 k = lane >> 2;
+        if (!cold[k]) continue;
+        table_prio();
+        keychain_quad_dev q;
+        q.r = (int)(lane & 3u);
+        keychain29_run(q, tuples, k, g, jstate, bases, valid + tslot[k], j_first, j_last, rec_mask);
+    }
 }
 // lanes = groups x j_count x 2: lane 0 of a window builds the babies b B_j, b = 1..8, lane 1 the giants 16 a B_j, a = 1..8
+// tmp: this launch's scratch, SBV_KT29_ROWS_TMP_WORDS words per resident lane
 #ifndef SBV_ROWS_WAVES
 #define SBV_ROWS_WAVES 2
 #endif
 __global__ __launch_bounds__(64, SBV_ROWS_WAVES) void k_keytab29_rows(GroupState g, const u32* __restrict__ bases, u32* __restrict__ tmp,
                                                       apt* __restrict__ ktab, const u32* __restrict__ tslot,
                                                       const uint8_t* __restrict__ cold, int j_first, int j_count) {
-    const u32 lane = blockIdx.x * 64 + threadIdx.x;
-    const u32 which = lane & 1u, kw = lane >> 1;
-    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
-    if (key >= group_count(g) || !cold[key]) return;
-    if (which == 1 && j == SBV_GTAB_WINDOWS - 1) return;          // the top window has no giants
-    table_prio();
-    const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
-    u32* t = tmp + w * SBV_KT29_WINDOW_TMP + (size_t)which * SBV_KT29_ROWS_TMP_WORDS;
-    keytab29_rows_lane(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), (int)which, j == SBV_GTAB_WINDOWS - 1, t,
-                       ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
+    const u32 total = group_count(g) * (u32)j_count * 2u;               // <= 65 536 x 33 x 2: fits 32 bits
+    for (u32 base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {        // the loop state is wave-uniform: it lives in scalar registers
+        const u32 lane = base + threadIdx.x;
+        if (lane >= total) break;
+        const u32 which = lane & 1u;
+        const u32 kw = lane >> 1;
+        const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
+        if (!cold[key]) continue;
+        if (which == 1 && j == SBV_GTAB_WINDOWS - 1) continue;          // the top window has no giants
+        table_prio();
+        const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
+        u32* t = tmp + (size_t)(blockIdx.x * 64 + threadIdx.x) * SBV_KT29_ROWS_TMP_WORDS;
+        keytab29_rows_lane(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), (int)which, j == SBV_GTAB_WINDOWS - 1, t,
+                           ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
+    }
 }
 
 // The fill step (symmetric form, p256_keytab29.h): lanes = groups x j_count x 8, lane a - 1 of a window fills both sides of giant 16 a.
 // Measured against round 3's one-sided fill (15 denominators per lane, babies 1..16 from the rows step) in round 4
 // (profiles/r04/ab_chunk0_symfill_r04a.jsonl): cold 2^20 3.34 -> 3.22 ms, 2^19 2.23 -> 2.08, 2^18 1.77 -> 1.62; the one-sided
 // kernel and the two wide forms of round 3 (one lane per entry; rows split over lanes — both measured slower) left the library.
+// Round 5: only for the groups that earn a full table (needfill, p256_group.h: group_table_class_lane); tmp: 72 words per resident lane.
+#define SBV_KT29_FILL_LANE_WORDS (8 * 9)
 __global__ __launch_bounds__(64) void k_keytab29_fill_sym(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab,
-                                                          const u32* __restrict__ tslot, const uint8_t* __restrict__ cold, int j_first,
+                                                          const u32* __restrict__ tslot, const uint8_t* __restrict__ needfill, int j_first,
                                                           int j_count) {
-    const u32 lane = blockIdx.x * 64 + threadIdx.x;
-    const u32 r = lane & 7u, kw = lane >> 3;
-    const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
-    if (key >= group_count(g) || j == SBV_GTAB_WINDOWS - 1 || !cold[key]) return;
-    table_prio();
-    const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
-    keytab29_fill_sym_lane(1 + (int)r, tmp + w * SBV_KT29_WINDOW_TMP + (size_t)r * SBV_KT29_FILL_TMP_WORDS / 2,
-                           ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
+    const u32 total = group_count(g) * (u32)j_count * 8u;               // <= 65 536 x 33 x 8: fits 32 bits
+    for (u32 base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {
+        const u32 lane = base + threadIdx.x;
+        if (lane >= total) break;
+        const u32 r = lane & 7u;
+        const u32 kw = lane >> 3;
+        const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
+        if (j == SBV_GTAB_WINDOWS - 1 || !needfill[key]) continue;
+        table_prio();
+        u32* t = tmp + (size_t)(blockIdx.x * 64 + threadIdx.x) * SBV_KT29_FILL_LANE_WORDS;
+        keytab29_fill_sym_lane(1 + (int)r, t, ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
+    }
+}
+// scratch words of ONE launch of the rows / fill kernels (the launcher gives the two table streams a region each)
+#define SBV_TABLE_TMP_WORDS ((size_t)SBV_TABLE_GRID_BLOCKS * 64 * SBV_KT29_ROWS_TMP_WORDS)
+
+// Table classes of the batch's groups and, at the end of the step, what the slots hold (p256_group.h).  One lane per group.
+__global__ __launch_bounds__(256) void k_group_table_class(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
+                                                           const uint8_t* __restrict__ kfull, u32 table_slots, u32 full_min,
+                                                           uint8_t* __restrict__ full, uint8_t* __restrict__ needfill) {
+    const u32 groups = group_count(g);
+    for (u32 k = blockIdx.x * 256 + threadIdx.x; k < groups; k += gridDim.x * 256) {
+        group_table_class_lane(k, g, tslot, cold, kfull, table_slots, full_min, full, needfill);
+        if (full[k]) atomicAdd(&g.counters[5], 1u);           // statistics only (sbv_p256_last_table_classes)
+        if (needfill[k]) atomicAdd(&g.counters[6], 1u);
+    }
+}
+__global__ __launch_bounds__(256) void k_group_table_mark(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
+                                                          const uint8_t* __restrict__ full, const uint8_t* __restrict__ needfill, u32 table_slots,
+                                                          uint8_t* __restrict__ kfull) {
+    const u32 groups = group_count(g);
+    for (u32 k = blockIdx.x * 256 + threadIdx.x; k < groups; k += gridDim.x * 256) group_table_mark_lane(k, tslot, cold, full, needfill, table_slots, kfull);
+}
+// The counting sort for batches with more groups than one LDS histogram holds (> 16 384: 2^20 tuples over 65 536 keys): a tile sees a
+// key at most a few times, so the histogram would be all flush and no merge — plain global atomics (p256_group.h: group_sort_*_lane).
+__global__ __launch_bounds__(256) void k_group_sort_count_direct(size_t n, GroupState g) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) group_sort_count_lane(i, g);
+}
+__global__ __launch_bounds__(256) void k_group_sort_scatter_direct(size_t n, GroupState g) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) group_sort_scatter_lane(i, g);
 }
 
 // One launch, two jobs.  Blocks [0, generic_blocks): the generic stage B (doubling kernel) over the
@@ -190,9 +241,15 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_GPHASE_WAVES) void k_gphase_s
     if (i < g.counters[1]) gphase29_lane_sorted(s, g.grp_idx[i], i, g16r, gacc);
 }
 
-// Q phase over the grouped list: windows [j0, j1) of the per-batch key combs
+// Q phase over the grouped list: windows [j0, j1) of the per-batch key combs.
+// Round 5: a wavefront whose lanes ALL belong to groups with a full table (full[group]) is served by the launches of the chunks
+// (NARROW = false: one addition per window, as before); any other wavefront — keys that got rows only, or a mix at the seam of two
+// runs — waits for the ONE launch after the last chunk (NARROW = true: windows 0..32 from babies and giants, two additions per
+// window).  Both instantiations evaluate the same predicate on the same data, so every lane is served exactly once.
+template <bool NARROW>
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_keyed_q(Scratch s, GroupState g, const apt* __restrict__ ktab,
                                                                     const uint8_t* __restrict__ kvalid, const u32* __restrict__ tslot,
+                                                                    const uint8_t* __restrict__ full,
                                                                     u32 table_slots, u32* __restrict__ gacc,
                                                                     uint8_t* __restrict__ acc, int j0, int j1, int last) {
     if (g.sorted) {
@@ -208,8 +265,14 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
         if (L >= lanes) return;
         const u32 t = g.grp_idx[L];
         const u32 grp = g.grp_of[L];
-        const u32 ts = grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE;
-        const bool v = qphase29_lane_sorted(s, t, L, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
+        const bool known = grp < group_count(g);
+        if (wave_all(known && full[known ? grp : 0u] != 0) == NARROW) return;      // the other instantiation's wavefront
+        if (NARROW) {                                                              // statistics only: lanes served by the narrow pass
+            const unsigned long long am = __ballot(true);
+            if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)am) - 1u) atomicAdd(&g.counters[7], (u32)__popcll(am));
+        }
+        const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
+        const bool v = qphase29_lane_sorted<NARROW>(s, t, L, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
         if (last) acc[t] = v ? 1 : 0;
         return;
     }
@@ -217,8 +280,10 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
     if (L >= g.counters[1]) return;
     const u32 t = g.grp_idx[L];
     const u32 grp = g.slots[t];                                        // group of this tuple -> its table slot (cache or per-batch area)
-    const u32 ts = grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE;
-    const bool v = qphase29_lane(s, t, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
+    const bool known = grp < group_count(g);
+    if (wave_all(known && full[known ? grp : 0u] != 0) == NARROW) return;
+    const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
+    const bool v = qphase29_lane<NARROW>(s, t, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
     if (last) acc[t] = v ? 1 : 0;
 }
 
@@ -293,15 +358,20 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     g.counters = b.counters; g.grp_idx = b.grp_idx; g.ung_idx = b.ung_idx; g.slots = b.slots;
     g.max_groups = b.max_groups; g.seed = b.seed;
     g.gcount = b.gcount; g.gcursor = b.gcount ? b.gcount + b.max_groups : nullptr; g.grp_of = b.grp_of; g.ung_cand = b.ung_cand;
-    // key-sorted grouped list: needs the per-tuple records of stage A and one LDS word per group
+    // key-sorted grouped list: needs the per-tuple records of stage A; one LDS word per group while the histogram fits (<= 16 384
+    // groups), plain global atomics beyond (k_group_sort_*_direct)
     const size_t sort_lds = (size_t)b.max_groups * sizeof(u32);
-    g.sorted = y.sorted && s_in.rec && b.gcount && b.grp_of && b.ung_cand && sort_lds <= 64 * 1024 ? 1u : 0u;
+    const bool sort_direct = sort_lds > 64 * 1024;
+    g.sorted = y.sorted && s_in.rec && b.gcount && b.grp_of && b.ung_cand ? 1u : 0u;
     // Stage A writes EITHER the per-tuple records (key-sorted step: every reader takes them) OR the limb-major planes
     Scratch s = s_in;
     if (!g.sorted) s.rec = nullptr;
     group_set_threshold(g, b.min_count);
     const int chunks = y.chunks < 1 ? 1 : (y.chunks > SBV_GROUP_MAX_CHUNKS ? SBV_GROUP_MAX_CHUNKS : y.chunks);
     const bool coop = g.sorted && y.coop_max && n <= y.coop_max;      // k_group_coop instead of the G phase and the Q launches
+    // table classes (p256_group.h): the coop launch reads any entry of a row, so its batches (<= 2^15 tuples) fill every table
+    const u32 full_min = coop ? 0u : b.full_min;
+    const u32 table_slots = b.kc.cap + b.max_groups;
     hipError_t e;
 #define SBV_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
     // The side streams may not touch the group buffers before everything already enqueued on `stream` (the
@@ -318,6 +388,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     SBV_TRY(hipEventRecord(y.ev_assign, y.side_a));
     hipLaunchKernelGGL((k_key_cache_lookup_t<160, 96, 16>), dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.kc, b.tslot, b.cold);
     hipLaunchKernelGGL((k_key_cache_insert_t<160, 96, 16>), dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.kc, b.tslot);
+    SBV_TRY(hipEventRecord(y.ev_cache, y.side_a));        // tslot / cold are final: the table classes (side_b) need them
     // stage A
     const size_t pbt = prep_block_tuples(n);
     const unsigned pblocks = (unsigned)((n + pbt - 1) / pbt);
@@ -330,9 +401,18 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         hipLaunchKernelGGL(k_group_classify, dim3(gn), dim3(256), 0, y.side_b, n, g, b.ung_cand, b.counters + 4);
         hipLaunchKernelGGL(k_group_keycheck, dim3(gn), dim3(256), 0, y.side_b, d_tuples, g, b.acc);
         const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
-        hipLaunchKernelGGL(k_group_sort_count, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
+        if (sort_direct) hipLaunchKernelGGL(k_group_sort_count_direct, dim3(gn), dim3(256), 0, y.side_b, n, g);
+        else hipLaunchKernelGGL(k_group_sort_count, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
         hipLaunchKernelGGL(k_group_sort_scan, dim3(1), dim3(1024), 0, y.side_b, g);
-        hipLaunchKernelGGL(k_group_sort_scatter, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
+    }
+    // table classes: after the exact counts (gcount survives the scan; the scatter moves gcursor only) and after the cache assigned the slots
+    SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_cache, 0));
+    hipLaunchKernelGGL(k_group_table_class, dim3(64), dim3(256), 0, y.side_b, g, b.tslot, b.cold, b.kfull, table_slots, full_min, b.full, b.needfill);
+    SBV_TRY(hipEventRecord(y.ev_class, y.side_b));
+    if (g.sorted) {
+        const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
+        if (sort_direct) hipLaunchKernelGGL(k_group_sort_scatter_direct, dim3(gn), dim3(256), 0, y.side_b, n, g);
+        else hipLaunchKernelGGL(k_group_sort_scatter, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
     }
     SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
     // The generic stage B over the ungrouped list (keys that repeat too rarely for a table: a 2.3 ms chain per lane, so it starts
@@ -353,15 +433,17 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [j_first, j_end)
         const int j_count = j_end - j_first;
-        hipStream_t tb = y.tstreams > 1 && y.side_t && (c & 1) ? y.side_t : y.side_b;     // rows + fill of this chunk
-        hipLaunchKernelGGL(k_keytab29_chain, dim3((b.max_groups * 4 + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases,
+        const bool on_t = y.tstreams > 1 && y.side_t && (c & 1);
+        hipStream_t tb = on_t ? y.side_t : y.side_b;     // rows + fill of this chunk
+        u32* ttmp = b.tmp + (on_t ? SBV_TABLE_TMP_WORDS : 0);          // per-lane scratch of this stream's table kernels (never two launches of one stream at a time)
+        auto bounded = [](size_t lanes) { const size_t blocks = (lanes + 63) / 64; return (unsigned)(blocks < SBV_TABLE_GRID_BLOCKS ? (blocks ? blocks : 1) : SBV_TABLE_GRID_BLOCKS); };
+        hipLaunchKernelGGL(k_keytab29_chain, dim3(bounded((size_t)b.max_groups * 4)), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases,
                            b.kvalid, b.tslot, b.cold, j_first, j_end - 1, 0x11u);
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
         SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[c], 0));
-        const size_t wl = (size_t)b.max_groups * j_count * 2;
-        hipLaunchKernelGGL(k_keytab29_rows, dim3((unsigned)((wl + 63) / 64)), dim3(64), 0, tb, g, b.bases, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
-        const size_t fl = (size_t)b.max_groups * j_count * 8;
-        hipLaunchKernelGGL(k_keytab29_fill_sym, dim3((unsigned)((fl + 63) / 64)), dim3(64), 0, tb, g, b.tmp, b.ktab, b.tslot, b.cold, j_first, j_count);
+        if (on_t) SBV_TRY(hipStreamWaitEvent(tb, y.ev_class, 0));      // side_b has it in stream order
+        hipLaunchKernelGGL(k_keytab29_rows, dim3(bounded((size_t)b.max_groups * j_count * 2)), dim3(64), 0, tb, g, b.bases, ttmp, b.ktab, b.tslot, b.cold, j_first, j_count);
+        hipLaunchKernelGGL(k_keytab29_fill_sym, dim3(bounded((size_t)b.max_groups * j_count * 8)), dim3(64), 0, tb, g, ttmp, b.ktab, b.tslot, b.needfill, j_first, j_count);
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         const bool last = c + 1 == chunks;
@@ -370,15 +452,19 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
             if (prof) SBV_TRY(hipEventRecord(prof[0], stream));
             const size_t lanes = n * SBV_COOP_LANES;
             hipLaunchKernelGGL(k_group_coop, dim3((unsigned)((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK)), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab,
-                               b.kvalid, b.tslot, b.kc.cap + b.max_groups, d_g16r, b.acc);
+                               b.kvalid, b.tslot, table_slots, d_g16r, b.acc);
             if (prof) SBV_TRY(hipEventRecord(prof[1], stream));
             continue;
         }
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
-        hipLaunchKernelGGL(k_verify_keyed_q, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.kc.cap + b.max_groups, b.gacc, b.acc,
+        hipLaunchKernelGGL(k_verify_keyed_q<false>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, table_slots, b.gacc, b.acc,
                            j_first, j_end, last ? 1 : 0);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
+    // the wavefronts with a key that has rows only: all 33 windows in one launch, two additions per window (every table is complete here)
+    if (!coop) hipLaunchKernelGGL(k_verify_keyed_q<true>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, table_slots, b.gacc,
+                                  b.acc, 0, SBV_GTAB_WINDOWS, 1);
+    hipLaunchKernelGGL(k_group_table_mark, dim3(64), dim3(256), 0, stream, g, b.tslot, b.cold, b.full, b.needfill, table_slots, b.kfull);
     hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
 #undef SBV_TRY
     if (prof && prof_pairs) *prof_pairs = coop ? 1 : chunks;

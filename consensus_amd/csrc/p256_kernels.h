@@ -66,6 +66,10 @@ struct GroupBuffers {
     u32* rec = nullptr;         // [scratch cap][SBV_REC_WORDS] stage A's per-tuple records (Scratch::rec) for the key-sorted list
     u32 max_groups = 0, min_count = 0;
     u32 seed = 0;               // key of the grouping hash table (GroupState::seed): random per context
+    // table classes (p256_group.h, round 5): [max_groups] this batch's groups — one addition per window allowed / run the fill now;
+    // [kc.cap + max_groups] what a table slot holds across batches; the per-key signature count from which a full table pays
+    uint8_t *full = nullptr, *needfill = nullptr, *kfull = nullptr;
+    u32 full_min = 256;
     size_t cap = 0;
     size_t gacc_cap = 0;        // the scratch capacity gacc was sized for
 };
@@ -87,6 +91,7 @@ struct GroupSync {
     hipStream_t side_t = nullptr;   // P-256, secp256k1: not owned — rows + fill of the odd chunks when tstreams = 2 (the context's own stream while the caller's runs the step)
     int tstreams = 2;               // SBV_GROUP_TSTREAMS (1, 2): 1 = every chunk's rows + fill queue up on side_b.  2: rows of chunk 1 start when ITS chain ends, not when fill of chunk 0 does — cold 2^18 2.04 -> 1.70 ms, 2^17 2.54 -> 2.23, 2^20 unchanged (profiles/r03/ab_sched_r03m.jsonl).  The Ed25519 step keeps one table stream (measured in round 4: 4.55 -> 4.67 ms with two, profiles/r04/ab_ed_tstreams_r04a.jsonl)
     hipEvent_t ev_fork = nullptr, ev_assign = nullptr, ev_split = nullptr, ev_generic = nullptr;
+    hipEvent_t ev_cache = nullptr, ev_class = nullptr;       // P-256: table slots assigned (side_a) / table classes decided (side_b)
     hipEvent_t ev_bases[SBV_GROUP_MAX_CHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
     int chunks = 1;
     int sorted = 1;                 // key-sorted grouped list + XCD-aware Q phase (SBV_GROUP_SORT=0: the split's compaction order; the form the step falls back to when a batch has more groups than one LDS histogram holds)

@@ -83,11 +83,14 @@ struct Context {
     size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17;
     size_t group_min_batch_ed = (size_t)1 << 18;     // Ed25519 with its key-table cache off: the cold crossover (round 2); with it on, group_min_batch
     size_t group_min_batch_k256 = (size_t)1 << 17;   // secp256k1 with its key-table cache off; with it on, group_min_batch
-    u32 group_min_count = 64, group_max = 2048;
+    // Round 5: a key earns a table (its ROWS: a comb with 4-bit windows) from ~16 uses in a batch — soft threshold, sampled — and the
+    // fill that makes it a full 8-bit comb from group_full_min uses; up to 65 536 groups per batch (p256_group.h: table classes).
+    // group_min_count = 0: the built-in default — 16 for the P-256 step (tables in classes), 64 for the Ed25519 / secp256k1 steps (always full tables)
+    u32 group_min_count = 0, group_max = 65536, group_full_min = 256;
     // persistent key-table caches, one per scheme (SBV_SCHEME_*: P-256, secp256k1, Ed25519; p256_group.h): on / off and
     // cached keys (270 KiB of HBM per ECDSA key, 384 KiB per Ed25519 key)
     bool kc_on[3] = {true, true, true};
-    u32 kc_caps[3] = {4096, 1024, 1024};
+    u32 kc_caps[3] = {16384, 1024, 1024};
     sbv::KeyPool k256pool;              // secp256k1: comb pool + key-table cache of its own
     // message front end staging (grown on demand)
     uint8_t* d_msgs = nullptr; size_t msgs_cap = 0;
@@ -134,8 +137,8 @@ constexpr int kMaxDevices = 16;
 // context when it is initialised and applied to every live context when they change — a setter called before sbv_init is not
 // lost, and after sbv_init_all it configures ALL devices, not just the default one.  Guarded by g_set_mu (a leaf lock).
 struct Settings {
-    bool group_enabled = true; size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17, group_min_batch_ed = (size_t)1 << 18, group_min_batch_k256 = (size_t)1 << 17; u32 group_min_count = 64, group_max = 2048;
-    bool kc_on[3] = {true, true, true}; u32 kc_caps[3] = {4096, 1024, 1024};
+    bool group_enabled = true; size_t group_min_batch = 64, group_min_batch_cold = (size_t)1 << 17, group_min_batch_ed = (size_t)1 << 18, group_min_batch_k256 = (size_t)1 << 17; u32 group_min_count = 0, group_max = 65536;
+    bool kc_on[3] = {true, true, true}; u32 kc_caps[3] = {16384, 1024, 1024};
     int profiling = 0;
     int wide_bits = SBV_WIDE_BITS_AUTO; u32 wide_max = 64;          // sbv_p256_wide_keys; env SBV_KEYED_WIDE_BITS (0 = off, 1 = auto), SBV_KEYED_WIDE_MAX
 } g_settings;
@@ -188,6 +191,10 @@ int fail(int code, const char* what, hipError_t e) {
     } while (0)
 
 constexpr size_t kMaxChunk = (size_t)1 << 21;   // tuples per launch; bounds scratch at ~3.3 GB
+// Groups per batch of the Ed25519 / secp256k1 grouped steps.  Their tables are always full 8-bit combs (no rows-only class) at the
+// threshold of 64 uses they always had, so round 5's 65 536 groups of the P-256 step would only size their pools (384 KiB per key);
+// they keep the capacity they were measured with.
+constexpr size_t kVariantGroups = 2048;
 
 void free_buffers(Context& c) {
     if (c.d_tuples) (void)hipFree(c.d_tuples);
@@ -238,7 +245,7 @@ sbv::Scratch scratch_view(const Context& c) {
 
 std::vector<hipEvent_t*> group_events(Context& c) {
     sbv::GroupSync& y = c.gsync;
-    std::vector<hipEvent_t*> v = {&y.ev_fork, &y.ev_assign, &y.ev_split, &y.ev_generic};
+    std::vector<hipEvent_t*> v = {&y.ev_fork, &y.ev_assign, &y.ev_split, &y.ev_generic, &y.ev_cache, &y.ev_class};
     for (int i = 0; i < SBV_GROUP_MAX_CHUNKS; ++i) v.push_back(&y.ev_bases[i]);
     for (int i = 0; i < SBV_GROUP_MAX_CHUNKS; ++i) v.push_back(&y.ev_tables[i]);
     return v;
@@ -290,17 +297,18 @@ hipError_t key_cache_forget(sbv::KeyCache& kc) {
 void free_group_buffers(Context& c, bool keep_pools = false) {
     sbv::GroupBuffers& b = c.grp;
     void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.jbases, b.bases, b.jstate, b.tmp, b.acc, b.gacc,
-                    b.gcount, b.grp_of, b.ung_cand, b.rec, b.tslot, b.cold};
+                    b.gcount, b.grp_of, b.ung_cand, b.rec, b.tslot, b.cold, b.full, b.needfill};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     sbv::apt* const ktab = b.ktab;
     uint8_t* const kvalid = b.kvalid;
+    uint8_t* const kfull = b.kfull;
     const sbv::KeyCache kc = b.kc;
     b = sbv::GroupBuffers();
     if (keep_pools) {
-        b.ktab = ktab; b.kvalid = kvalid; b.kc = kc;
+        b.ktab = ktab; b.kvalid = kvalid; b.kfull = kfull; b.kc = kc;
         return;
     }
-    void* pool[] = {ktab, kvalid, kc.ht, kc.keys, kc.count};
+    void* pool[] = {ktab, kvalid, kfull, kc.ht, kc.keys, kc.count};
     for (void* p : pool) if (p) (void)hipFree(p);
     if (c.edgrp.ktab) (void)hipFree(c.edgrp.ktab);
     if (c.edgrp.okb) (void)hipFree(c.edgrp.okb);
@@ -316,12 +324,13 @@ void free_group_buffers(Context& c, bool keep_pools = false) {
 int ensure_group_buffers(Context& c, size_t n) {
     sbv::GroupBuffers& b = c.grp;
     if (b.cap >= n && b.max_groups == c.group_max && b.gacc_cap == c.cap && b.kc.cap == c.kc_caps[0]) {
-        b.min_count = c.group_min_count;
+        b.min_count = c.group_min_count ? c.group_min_count : 16u;
+        b.full_min = c.group_full_min;
         b.kc.enabled = c.kc_on[0] ? 1u : 0u;
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
-    const bool keep_pools = b.ktab && b.kvalid && b.kc.ht && b.max_groups == c.group_max && b.kc.cap == c.kc_caps[0];
+    const bool keep_pools = b.ktab && b.kvalid && b.kfull && b.kc.ht && b.max_groups == c.group_max && b.kc.cap == c.kc_caps[0];
     free_group_buffers(c, keep_pools);
     const size_t cap = (n + 1023) & ~(size_t)1023;
     size_t ht = 1024;
@@ -340,7 +349,10 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.grp_of, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ung_cand, cap * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.rec, c.cap * (size_t)SBV_REC_WORDS * sizeof(u32)));    // indexed like the scratch planes
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jbases, G * SBV_GTAB_WINDOWS * (size_t)40 * sizeof(u32)));   // 40 dwords = one Jacobian base (p256_group.h)
+    const size_t Gv = G < kVariantGroups ? G : kVariantGroups;            // what the Ed25519 / secp256k1 steps use of these arrays (variant_groups())
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jbases, Gv * SBV_GTAB_WINDOWS * (size_t)40 * sizeof(u32)));   // Ed25519 only: 40 dwords = one Jacobian base (p256_group.h)
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.full, G));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.needfill, G));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.bases, G * SBV_GTAB_WINDOWS * (size_t)(8 * 36) * sizeof(u32)));       // p256_keytab29.h: SBV_KT29_POINTS_PER_WINDOW records of SBV_KT29_REC_WORDS
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.jstate, G * (size_t)36 * sizeof(u32)));                                  // SBV_KT29_STATE_WORDS
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.gacc, 40 * c.cap * sizeof(u32)));       // limb-major with the scratch's stride; 36 words (P-256: XYZZ, 9-limb coordinates) or 40 (Ed25519: extended, 10-limb coordinates) per tuple
@@ -351,19 +363,38 @@ int ensure_group_buffers(Context& c, size_t n) {
     if (!keep_pools) {
         HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ktab, (K + G) * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
         HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, K + G));
+        HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kfull, K + G));
+        HIP_TRY(SBV_EDEVICE, hipMemset(b.kfull, 0, K + G));
         const int krc = key_cache_alloc(b.kc, K, c.kc_on[0]);
         if (krc != SBV_OK) return krc;
     }
     b.kc.enabled = c.kc_on[0] ? 1u : 0u;
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tmp, G * SBV_GTAB_WINDOWS * (size_t)(SBV_GTAB_PER_WINDOW * 40) * sizeof(u32)));     // Ed25519: 128 x 40 raw limbs per (key, window)
+    {   // scratch of the table kernels: P-256 indexes it by resident lane (two table streams x SBV_TABLE_GRID_BLOCKS x 64 lanes x 675 words,
+        // p256_group_kernels.hip), the Ed25519 step by (key, window): 128 x 40 raw limbs each, for the groups that step may hold
+        const size_t p256_words = 2 * (size_t)4096 * 64 * (15 * 45);
+        const size_t ed_words = Gv * SBV_GTAB_WINDOWS * (size_t)(SBV_GTAB_PER_WINDOW * 40);
+        HIP_TRY(SBV_ENOMEM, hipMalloc(&b.tmp, (p256_words > ed_words ? p256_words : ed_words) * sizeof(u32)));
+    }
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.acc, cap));
     b.ht_mask = (u32)(ht - 1);
     b.seed = fresh_hash_seed();            // the per-batch grouping table is empty at the start of every batch: any seed will do, a secret one is the point
     b.max_groups = (u32)G;
-    b.min_count = c.group_min_count;
+    b.min_count = c.group_min_count ? c.group_min_count : 16u;
+    b.full_min = c.group_full_min;
     b.cap = cap;
     b.gacc_cap = c.cap;
     return SBV_OK;
+}
+
+// The Ed25519 / secp256k1 steps see the shared grouping arrays with THEIR group capacity and threshold (kVariantGroups; 64 uses unless
+// sbv_p256_set_grouping named one): a view of c.grp, never stored.
+u32 variant_groups(const Context& c) { return c.grp.max_groups < kVariantGroups ? c.grp.max_groups : (u32)kVariantGroups; }
+sbv::GroupBuffers variant_view(const Context& c, size_t n) {
+    sbv::GroupBuffers bv = c.grp;
+    bv.max_groups = variant_groups(c);
+    bv.min_count = c.group_min_count ? c.group_min_count : 64u;
+    if (n < ((size_t)1 << 18) && bv.min_count > 32) bv.min_count = 32;     // no stragglers on the one-lane path below 2^18 (enqueue() has the numbers)
+    return bv;
 }
 
 int ensure_ed_group_buffers(Context& c, size_t n) {
@@ -373,7 +404,8 @@ int ensure_ed_group_buffers(Context& c, size_t n) {
     const size_t K = c.kc_caps[2];
     // The comb pool and its cache depend on (K, max_groups) only: a batch larger than any before must not empty the cache
     // (found on the GPU in round 4: the warm batch of the cache test was 384 tuples longer than the cold one and missed every key).
-    const bool pool_ok = e.ktab && e.max_groups == c.grp.max_groups && e.kc.ht && e.kc.cap == K;
+    const u32 vg = variant_groups(c);
+    const bool pool_ok = e.ktab && e.max_groups == vg && e.kc.ht && e.kc.cap == K;
     if (pool_ok && e.okb && e.cap >= c.grp.cap) {
         e.kc.enabled = c.kc_on[2] ? 1u : 0u;
         return SBV_OK;
@@ -387,11 +419,11 @@ int ensure_ed_group_buffers(Context& c, size_t n) {
         key_cache_free(e.kc);
         e = sbv::EdGroupBuffers();
         // comb pool of this scheme: slots [0, K) = its persistent key-table cache, [K, K + max_groups) per batch
-        HIP_TRY(SBV_ENOMEM, hipMalloc(&e.ktab, (K + c.grp.max_groups) * (size_t)SBV_ED_KEYTAB_ENTRIES_PER_KEY * sizeof(sbv::aniels)));
-        HIP_TRY(SBV_ENOMEM, hipMalloc(&e.kvalid, K + c.grp.max_groups));
+        HIP_TRY(SBV_ENOMEM, hipMalloc(&e.ktab, (K + vg) * (size_t)SBV_ED_KEYTAB_ENTRIES_PER_KEY * sizeof(sbv::aniels)));
+        HIP_TRY(SBV_ENOMEM, hipMalloc(&e.kvalid, K + vg));
         rc = key_cache_alloc(e.kc, K, c.kc_on[2]);
         if (rc != SBV_OK) return rc;
-        e.max_groups = c.grp.max_groups;
+        e.max_groups = vg;
     }
     HIP_TRY(SBV_ENOMEM, hipMalloc(&e.okb, c.grp.cap));
     e.cap = c.grp.cap;
@@ -405,7 +437,8 @@ int ensure_k256_group_buffers(Context& c, size_t n) {
     if (rc != SBV_OK) return rc;
     sbv::KeyPool& kp = c.k256pool;
     const size_t K = c.kc_caps[1];
-    if (kp.ktab && kp.max_groups == c.grp.max_groups && kp.kc.cap == K) {
+    const u32 vg = variant_groups(c);
+    if (kp.ktab && kp.max_groups == vg && kp.kc.cap == K) {
         kp.kc.enabled = c.kc_on[1] ? 1u : 0u;
         return SBV_OK;
     }
@@ -414,11 +447,11 @@ int ensure_k256_group_buffers(Context& c, size_t n) {
     if (kp.kvalid) (void)hipFree(kp.kvalid);
     key_cache_free(kp.kc);
     kp = sbv::KeyPool();
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&kp.ktab, (K + c.grp.max_groups) * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&kp.kvalid, K + c.grp.max_groups));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&kp.ktab, (K + vg) * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&kp.kvalid, K + vg));
     rc = key_cache_alloc(kp.kc, K, c.kc_on[1]);
     if (rc != SBV_OK) return rc;
-    kp.max_groups = c.grp.max_groups;
+    kp.max_groups = vg;
     return SBV_OK;
 }
 
@@ -430,7 +463,7 @@ int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bi
         const int rc = ensure_ed_group_buffers(c, n);
         if (rc != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
-        const hipError_t ge = sbv::launch_ed25519_verify_grouped(d_tuples, n, c.grp, c.edgrp, c.d_qtab, c.d_btab, d_bitmap, stream, c.gsync, dom, dom_pairs);
+        const hipError_t ge = sbv::launch_ed25519_verify_grouped(d_tuples, n, variant_view(c, n), c.edgrp, c.d_qtab, c.d_btab, d_bitmap, stream, c.gsync, dom, dom_pairs);
         if (ge != hipSuccess) {          // a slot is published before its tables are built (see enqueue()): forget the cache
             (void)hipDeviceSynchronize();
             (void)key_cache_forget(c.edgrp.kc);
@@ -493,9 +526,12 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
 
 sbv::widekeys wide_of(const Context& c) { return c.wide_slots.empty() ? sbv::widekeys_none() : sbv::widekeys_make(c.d_kwide, c.d_kwidx, c.kwide_bits); }
 
+// scratch_off: first tuple slot of the scratch planes this launch may use (the sharded registered-key entries run two pieces at a
+// time, each in its own half of the planes)
 int enqueue_keyed(Context& c, const uint8_t* d_rsh, const u32* d_slots, size_t n, uint8_t* d_bitmap, hipStream_t stream,
-                  hipEvent_t after_prep) {
-    const sbv::Scratch s = scratch_view(c);
+                  hipEvent_t after_prep, size_t scratch_off = 0) {
+    sbv::Scratch s = scratch_view(c);
+    if (scratch_off) { s.r += scratch_off; s.u1 += scratch_off; s.u2 += scratch_off; s.qx += scratch_off; s.qy += scratch_off; s.sm += scratch_off; s.ok += scratch_off; }
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_prep(d_rsh, n, s, stream, true));
     if (after_prep) HIP_TRY(SBV_EDEVICE, hipEventRecord(after_prep, stream));
     HIP_TRY(SBV_EDEVICE, sbv::launch_p256_verify_keyed(s, n, d_slots, (u32)c.nkeys, c.d_ktab, c.d_kvalid, sbv::gcomb_make(c.d_g16r, c.g_bits), wide_of(c), d_bitmap, c.d_rerun, stream));
@@ -633,6 +669,7 @@ int init_context(Context& c, int device) {
     }
     if (const char* e = getenv("SBV_KEYED_WIDE_BITS")) { const int v = atoi(e); if (v == 0) c.kwide_max = 0; else if (v == SBV_WIDE_BITS_AUTO) c.kwide_auto = true; else if (v >= 10 && v <= 20) { c.kwide_bits = v; c.kwide_auto = false; } }
     if (const char* e = getenv("SBV_KEYED_WIDE_MAX")) { const long v = atol(e); if (v >= 0 && v <= 4096) c.kwide_max = (u32)v; }
+    if (const char* e = getenv("SBV_FULL_TABLE_MIN")) { const long v = atol(e); if (v >= 0) c.group_full_min = (u32)v; }
     if (const char* e = getenv("SBV_SMALL")) c.small_enabled = e[0] != '0';
     if (const char* e = getenv("SBV_GROUP")) c.group_enabled = e[0] != '0';
     if (const char* e = getenv("SBV_GROUP_MIN_BATCH")) { const long v = atol(e); if (v > 0) c.group_min_batch = c.group_min_batch_cold = c.group_min_batch_ed = c.group_min_batch_k256 = (size_t)v; }
@@ -1573,13 +1610,12 @@ int enqueue_k256(Context& c, const uint8_t* d_tuples, size_t m, uint8_t* d_bitma
     if (c.group_enabled && m >= (c.kc_on[1] ? c.group_min_batch : c.group_min_batch_k256)) {
         int rc = ensure_k256_group_buffers(c, m);
         if (rc != SBV_OK) return rc;
-        if (m < ((size_t)1 << 18) && c.grp.min_count > 32) c.grp.min_count = 32;     // no stragglers on the one-lane path below 2^18 (enqueue() has the numbers)
         if ((rc = ensure_k256_gcomb(c)) != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
         sbv::GroupSync y = c.gsync;                 // second table stream: the context's own, when the caller's runs the step (enqueue() says why)
         if (y.tstreams > 1 && stream != c.stream) y.side_t = c.stream;
         else y.tstreams = 1;
-        const hipError_t ge = sbv::launch_k256_verify_grouped(d_tuples, s, m, c.grp, c.k256pool, c.d_qtab, c.d_k256_gtab, c.d_k256_gcomb, c.k256_gbits, d_bitmap, stream, y, dom, dom_pairs);
+        const hipError_t ge = sbv::launch_k256_verify_grouped(d_tuples, s, m, variant_view(c, m), c.k256pool, c.d_qtab, c.d_k256_gtab, c.d_k256_gcomb, c.k256_gbits, d_bitmap, stream, y, dom, dom_pairs);
         if (ge != hipSuccess) {
             (void)hipDeviceSynchronize();
             (void)key_cache_forget(c.k256pool.kc);
@@ -1849,6 +1885,7 @@ extern "C" int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min
             const Settings d;
             g_settings.group_min_batch = d.group_min_batch; g_settings.group_min_batch_cold = d.group_min_batch_cold;
             g_settings.group_min_batch_ed = d.group_min_batch_ed; g_settings.group_min_batch_k256 = d.group_min_batch_k256;
+            g_settings.group_min_count = d.group_min_count;          // ... and the per-scheme default thresholds (a non-zero min_count below still applies)
         } else if (min_batch) g_settings.group_min_batch = g_settings.group_min_batch_cold = g_settings.group_min_batch_ed = g_settings.group_min_batch_k256 = min_batch;
         if (min_count) g_settings.group_min_count = min_count;
         if (max_groups) g_settings.group_max = max_groups;
@@ -1957,6 +1994,20 @@ extern "C" int sbv_p256_last_group_stats(uint32_t out[4]) {
     out[1] = h[1];
     out[2] = h[2];
     out[3] = h[3];
+    return SBV_OK;
+}
+
+extern "C" int sbv_p256_last_table_classes(uint32_t out[3]) {
+    SBV_ENTER(c);
+    if (!c.ready) return SBV_ENOTINIT;
+    if (!out) return SBV_EINVAL;
+    out[0] = out[1] = out[2] = 0;
+    if (!c.grp.counters) return SBV_OK;
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    uint32_t h[SBV_GROUP_COUNTERS];
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(h, c.grp.counters, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = h[5]; out[1] = h[6]; out[2] = h[7];
     return SBV_OK;
 }
 
@@ -2318,6 +2369,16 @@ size_t g_shard_piece_keyed = (size_t)1 << 17;
 // One device's share of a sharded registered-key call; c.mu and g_reg_mu (shared) held.  The same two upload slots as verify_shard:
 // 96-byte records r | s | hash and their 4-byte slots — 100 B per signature over PCIe instead of 160 — of piece i + 1 travel on
 // the copy stream beside stage A + B of piece i; quorum bits by distinct slot.
+// pieces of a registered-key shard: as many as the configured piece size asks for, then EQUAL sizes (a multiple of the granule) —
+// a short last piece would fall into the 8-lanes-per-signature latency kernel and every piece fills the device for about one round
+size_t keyed_piece(size_t m, size_t gran) {
+    size_t chunk = (g_shard_piece_keyed < kMaxChunk / 2 ? g_shard_piece_keyed : kMaxChunk / 2) / gran * gran;
+    if (chunk == 0) chunk = gran;
+    const size_t pieces = (m + chunk - 1) / chunk;
+    size_t per = ((m + pieces - 1) / pieces + gran - 1) / gran * gran;
+    return per < chunk ? per : chunk;
+}
+
 int verify_shard_keyed(Context& c, const uint8_t* h_rsh, const u32* h_slots, size_t m, size_t group, u32 quorum, uint8_t* d_slot, uint8_t* d_qslot,
                        double* h2d_us, double* kern_us) {
     if (!c.ready) { g_err = "device not initialised"; return SBV_ENOTINIT; }
@@ -2326,55 +2387,60 @@ int verify_shard_keyed(Context& c, const uint8_t* h_rsh, const u32* h_slots, siz
     if (rc != SBV_OK) return rc;
     if (c.nkeys == 0) { g_err = "no keys registered"; return SBV_EINVAL; }
     const size_t gran = shard_granule(group);
-    size_t chunk = (g_shard_piece_keyed < kMaxChunk ? g_shard_piece_keyed : kMaxChunk) / gran * gran;
-    if (chunk == 0) chunk = kMaxChunk / gran * gran;
-    if (chunk == 0) { g_err = "group too large"; return SBV_EINVAL; }
+    if (gran > kMaxChunk / 2) { g_err = "group too large"; return SBV_EINVAL; }
+    const size_t chunk = keyed_piece(m, gran);
     const size_t pieces = (m + chunk - 1) / chunk;
-    rc = ensure_capacity(c, m < chunk ? m : chunk);
+    const bool two = pieces > 1;
+    // Two pieces are in flight: piece i + 1 is uploaded (copy stream) and runs its stage A (second kernel stream, its own half of
+    // the scratch planes) while stage B of piece i still fills the device — stage A is a short latency-bound chain that would
+    // otherwise stand between two stage-B launches on one stream (measured: 5 pieces of 2^17 on one stream 1.57 ms of kernels for
+    // 550 000 signatures against 1.05 ms in one launch; profiles/r05/).
+    rc = ensure_capacity(c, two ? 2 * chunk : m);
     if (rc != SBV_OK) return rc;
     ShardBuffers& sbuf = g_shard[c.device];
-    if (pieces > 1) {
+    if (two) {
         rc = grow_bytes(sbuf.d_stage2, sbuf.stage2_cap, chunk * SBV_TUPLE_BYTES);
         if (rc == SBV_OK) rc = grow_bytes(sbuf.d_slots2, sbuf.slots2_cap, chunk * sizeof(u32));
         if (rc != SBV_OK) return rc;
         if (!c.copy_stream && hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking) != hipSuccess) { g_err = "hipStreamCreate failed"; return SBV_EDEVICE; }
     }
-    hipStream_t up = pieces > 1 ? c.copy_stream : c.stream;
-    uint8_t* stage[2] = {c.d_tuples, pieces > 1 ? sbuf.d_stage2 : c.d_tuples};
-    u32* sstage[2] = {c.d_slots, pieces > 1 ? reinterpret_cast<u32*>(sbuf.d_slots2) : c.d_slots};
+    hipStream_t up = two ? c.copy_stream : c.stream;
+    hipStream_t ks[2] = {c.stream, two ? c.gsync.side_a : c.stream};      // the grouped step's side stream is idle on this path (a process gets four hardware queues)
+    uint8_t* stage[2] = {c.d_tuples, two ? sbuf.d_stage2 : c.d_tuples};
+    u32* sstage[2] = {c.d_slots, two ? reinterpret_cast<u32*>(sbuf.d_slots2) : c.d_slots};
     std::vector<hipEvent_t> ev(3 * pieces, nullptr);
     auto drop_events = [&] { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
     for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) { drop_events(); g_err = "hipEventCreate failed"; return SBV_EDEVICE; }
     hipError_t he = hipSuccess;
     auto step = [&](hipError_t r) { if (he == hipSuccess) he = r; };
     if (c.busy_valid) {
-        step(hipStreamWaitEvent(c.stream, c.busy, 0));
-        if (pieces > 1) step(hipStreamWaitEvent(up, c.busy, 0));
+        step(hipStreamWaitEvent(ks[0], c.busy, 0));
+        if (two) { step(hipStreamWaitEvent(ks[1], c.busy, 0)); step(hipStreamWaitEvent(up, c.busy, 0)); }
     }
     size_t i = 0;
     for (size_t off = 0; off < m && rc == SBV_OK && he == hipSuccess; off += chunk, ++i) {
         const size_t k = m - off < chunk ? m - off : chunk;
-        uint8_t* d_in = stage[i & 1];
-        u32* d_sl = sstage[i & 1];
-        if (i >= 2) step(hipStreamWaitEvent(up, ev[3 * (i - 2) + 2], 0));       // the slot's previous kernels are done with it
+        const int w = (int)(i & 1);
+        if (i >= 2) step(hipStreamWaitEvent(up, ev[3 * (i - 2) + 2], 0));       // the staging set's previous kernels are done with it
         step(hipEventRecord(ev[3 * i], up));
-        step(hipMemcpyAsync(d_in, h_rsh + off * 96, k * 96, hipMemcpyHostToDevice, up));
-        step(hipMemcpyAsync(d_sl, h_slots + off, k * sizeof(u32), hipMemcpyHostToDevice, up));
+        step(hipMemcpyAsync(stage[w], h_rsh + off * 96, k * 96, hipMemcpyHostToDevice, up));
+        step(hipMemcpyAsync(sstage[w], h_slots + off, k * sizeof(u32), hipMemcpyHostToDevice, up));
         step(hipEventRecord(ev[3 * i + 1], up));
-        if (pieces > 1) step(hipStreamWaitEvent(c.stream, ev[3 * i + 1], 0));
+        if (two) step(hipStreamWaitEvent(ks[w], ev[3 * i + 1], 0));
         if (he != hipSuccess) break;
-        rc = enqueue_keyed(c, d_in, d_sl, k, d_slot + off / 8, c.stream, nullptr);
+        rc = enqueue_keyed(c, stage[w], sstage[w], k, d_slot + off / 8, ks[w], nullptr, w ? chunk : 0);
         if (rc != SBV_OK) break;
         if (d_qslot && group > 0 && quorum > 0) {
             const size_t props = k / group;
             if (props)
-                hipLaunchKernelGGL(k_quorum_bits_slots, dim3((unsigned)((props + 255) / 256)), dim3(256), 0, c.stream, d_sl, d_slot + off / 8,
+                hipLaunchKernelGGL(k_quorum_bits_slots, dim3((unsigned)((props + 255) / 256)), dim3(256), 0, ks[w], sstage[w], d_slot + off / 8,
                                    props, (u32)group, quorum, d_qslot + (off / group) / 8);
         }
-        step(hipEventRecord(ev[3 * i + 2], c.stream));
+        step(hipEventRecord(ev[3 * i + 2], ks[w]));
     }
-    if (pieces > 1) step(hipStreamSynchronize(up));
-    step(hipStreamSynchronize(c.stream));
+    // drain in every case: the staging sets and the caller's host buffers must not be in use when this returns
+    if (two) { step(hipStreamSynchronize(up)); step(hipStreamSynchronize(ks[1])); }
+    step(hipStreamSynchronize(ks[0]));
     if (rc == SBV_OK && he != hipSuccess) rc = fail(SBV_EDEVICE, "verify_shard_keyed", he);
     if (rc == SBV_OK) {
         if (h2d_us) for (size_t j = 0; j < pieces; ++j) *h2d_us += 1e3 * ms_between(ev[3 * j], ev[3 * j + 1]);
@@ -2398,9 +2464,8 @@ int verify_shard_msgs(Context& c, const uint8_t* msgs, const uint64_t* moff, con
     if (rc != SBV_OK) return rc;
     if (c.nkeys == 0) { g_err = "no keys registered"; return SBV_EINVAL; }
     const size_t gran = shard_granule(group);
-    size_t chunk = (g_shard_piece_keyed < kMaxChunk ? g_shard_piece_keyed : kMaxChunk) / gran * gran;
-    if (chunk == 0) chunk = kMaxChunk / gran * gran;
-    if (chunk == 0) { g_err = "group too large"; return SBV_EINVAL; }
+    if (gran > kMaxChunk / 2) { g_err = "group too large"; return SBV_EINVAL; }
+    const size_t chunk = keyed_piece(m, gran);
     const size_t pieces = (m + chunk - 1) / chunk;
     size_t max_mb = 0, max_sb = 0;                 // staging for the largest piece, grown before anything is enqueued
     for (size_t off = 0; off < m; off += chunk) {
@@ -2410,7 +2475,7 @@ int verify_shard_msgs(Context& c, const uint8_t* msgs, const uint64_t* moff, con
         if (sb > max_sb) max_sb = sb;
     }
     const size_t kmax = m < chunk ? m : chunk;
-    rc = ensure_capacity(c, kmax);
+    rc = ensure_capacity(c, pieces > 1 ? 2 * chunk : kmax);        // two pieces in flight, each in its half of the scratch planes and of the record buffer
     if (rc == SBV_OK) rc = grow(c.d_msgs, c.msgs_cap, max_mb + 16);
     if (rc == SBV_OK) rc = grow(c.d_sigs, c.sigs_cap, max_sb + 16);
     if (rc == SBV_OK) rc = grow(c.d_moff, c.moff_cap, kmax + 1);
@@ -2427,6 +2492,8 @@ int verify_shard_msgs(Context& c, const uint8_t* msgs, const uint64_t* moff, con
     if (rc != SBV_OK) return rc;
     hipStream_t up = pieces > 1 ? c.copy_stream : c.stream;
     const bool two = pieces > 1;
+    hipStream_t ks[2] = {c.stream, two ? c.gsync.side_a : c.stream};      // as verify_shard_keyed: front end + stage A of piece i + 1 beside stage B of piece i
+    uint8_t* recs[2] = {c.d_tuples, two ? c.d_tuples + chunk * 96 : c.d_tuples};      // the front end's 96-byte records (Context::d_tuples holds 160 bytes per scratch slot)
     uint8_t* st_msgs[2] = {c.d_msgs, two ? sbuf.d_msgs2 : c.d_msgs};
     uint8_t* st_sigs[2] = {c.d_sigs, two ? sbuf.d_sigs2 : c.d_sigs};
     uint64_t* st_moff[2] = {c.d_moff, two ? reinterpret_cast<uint64_t*>(sbuf.d_moff2) : c.d_moff};
@@ -2438,8 +2505,8 @@ int verify_shard_msgs(Context& c, const uint8_t* msgs, const uint64_t* moff, con
     hipError_t he = hipSuccess;
     auto step = [&](hipError_t r) { if (he == hipSuccess) he = r; };
     if (c.busy_valid) {
-        step(hipStreamWaitEvent(c.stream, c.busy, 0));
-        if (two) step(hipStreamWaitEvent(up, c.busy, 0));
+        step(hipStreamWaitEvent(ks[0], c.busy, 0));
+        if (two) { step(hipStreamWaitEvent(ks[1], c.busy, 0)); step(hipStreamWaitEvent(up, c.busy, 0)); }
     }
     size_t i = 0;
     for (size_t off = 0; off < m && rc == SBV_OK && he == hipSuccess; off += chunk, ++i) {
@@ -2456,22 +2523,22 @@ int verify_shard_msgs(Context& c, const uint8_t* msgs, const uint64_t* moff, con
         step(hipMemcpyAsync(st_soff[w], soff + a, (k + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, up));
         step(hipMemcpyAsync(st_slots[w], h_slots + a, k * sizeof(u32), hipMemcpyHostToDevice, up));
         step(hipEventRecord(ev[3 * i + 1], up));
-        if (two) step(hipStreamWaitEvent(c.stream, ev[3 * i + 1], 0));
+        if (two) step(hipStreamWaitEvent(ks[w], ev[3 * i + 1], 0));
         if (he != hipSuccess) break;
-        step(sbv::launch_msg_frontend(st_msgs[w], st_moff[w], st_sigs[w], st_soff[w], k, reinterpret_cast<u32*>(c.d_tuples), c.stream, mbase, sbase));
+        step(sbv::launch_msg_frontend(st_msgs[w], st_moff[w], st_sigs[w], st_soff[w], k, reinterpret_cast<u32*>(recs[w]), ks[w], mbase, sbase));
         if (he != hipSuccess) break;
-        rc = enqueue_keyed(c, c.d_tuples, st_slots[w], k, d_slot + off / 8, c.stream, nullptr);
+        rc = enqueue_keyed(c, recs[w], st_slots[w], k, d_slot + off / 8, ks[w], nullptr, w ? chunk : 0);
         if (rc != SBV_OK) break;
         if (d_qslot && group > 0 && quorum > 0) {
             const size_t props = k / group;
             if (props)
-                hipLaunchKernelGGL(k_quorum_bits_slots, dim3((unsigned)((props + 255) / 256)), dim3(256), 0, c.stream, st_slots[w], d_slot + off / 8,
+                hipLaunchKernelGGL(k_quorum_bits_slots, dim3((unsigned)((props + 255) / 256)), dim3(256), 0, ks[w], st_slots[w], d_slot + off / 8,
                                    props, (u32)group, quorum, d_qslot + (off / group) / 8);
         }
-        step(hipEventRecord(ev[3 * i + 2], c.stream));
+        step(hipEventRecord(ev[3 * i + 2], ks[w]));
     }
-    if (two) step(hipStreamSynchronize(up));
-    step(hipStreamSynchronize(c.stream));
+    if (two) { step(hipStreamSynchronize(up)); step(hipStreamSynchronize(ks[1])); }
+    step(hipStreamSynchronize(ks[0]));
     if (rc == SBV_OK && he != hipSuccess) rc = fail(SBV_EDEVICE, "verify_shard_msgs", he);
     if (rc == SBV_OK) {
         if (h2d_us) for (size_t j = 0; j < pieces; ++j) *h2d_us += 1e3 * ms_between(ev[3 * j], ev[3 * j + 1]);

@@ -73,7 +73,9 @@ int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitma
  * take the no-doubling kernels; everything else takes the generic kernel inside the same step.  Verdicts are identical.
  * `min_batch` = batches from this size on take the grouped step.  Defaults: enabled; min_batch 64 while the key-table cache is
  * on (a warm batch of a few thousand tuples skips the 256 doublings per signature), 2^17 while it is off (nothing outlives the
- * call then, and below ~2^17 building tables costs more latency than the doubling kernel takes); min_count 64; max_groups 2048.
+ * call then, and below ~2^17 building tables costs more latency than the doubling kernel takes); min_count 16 for P-256 (a soft,
+ * sampled threshold: 2 of a key's every-8th tuples; the Ed25519 / secp256k1 steps, whose tables are always full, keep 64 and at most
+ * 2048 groups); max_groups 65536 (round 5; 2048 before — a 2^20 batch over 4096 keys sent half its tuples to the one-lane kernel).
  * Passing a non-zero min_batch sets both thresholds (and the variant schemes'); SBV_GROUP_MIN_BATCH_DEFAULT restores the built-in
  * ones; 0 for a numeric argument keeps its current value.  Env: SBV_GROUP=0
  * disables, SBV_GROUP_MIN_BATCH=<n>.  What IS remembered between calls is the key-table cache. */
@@ -85,7 +87,7 @@ int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uin
  * pkg/consensus/consensus.go:185-252), so the tables are kept in HBM (270 KiB per key) and later batches only build the
  * tables of keys they have not met: a "warm" batch skips the doubling chains and the table kernels altogether.  Verdicts
  * cannot depend on it (a slot is found by comparing all 64 key bytes and holds exactly what the batch would have built).
- * enabled: default 1; switching it off also empties it.  capacity: keys kept (default 4096; 0 = unchanged); when full,
+ * enabled: default 1; switching it off also empties it.  capacity: keys kept (default 16384; 0 = unchanged); when full,
  * further keys are simply rebuilt per batch.  stats: out[0] = cached keys, out[1] / out[2] = groups of the last grouped
  * batch that hit / missed, out[3] = capacity.  bench.py measures its headline with the cache OFF (every step cold). */
 int sbv_p256_key_cache(int enabled, uint32_t capacity);
@@ -94,7 +96,7 @@ int sbv_p256_key_cache_stats(uint32_t out[4]);
  * Ed25519 variants is the same handful of keys forever (internal/bft/view.go:631, 834), so their grouped steps keep their
  * per-key combs too — each scheme in a pool of its OWN: a slot is found by the key bytes, and the same 64 bytes can be a
  * point of both ECDSA curves (a shared table would let a crafted key be verified against the other curve's comb).
- * scheme = SBV_SCHEME_*; defaults: on, 4096 (P-256) / 1024 (secp256k1: 270 KiB per key) / 1024 (Ed25519: 384 KiB per key)
+ * scheme = SBV_SCHEME_*; defaults: on, 16384 (P-256) / 1024 (secp256k1: 270 KiB per key) / 1024 (Ed25519: 384 KiB per key)
  * keys.  With a scheme's cache on, its batches take the grouped step from 64 tuples (sbv_p256_set_grouping's min_batch).
  * sbv_p256_key_cache(e, c) == sbv_key_cache(SBV_SCHEME_P256, e, c). */
 #define SBV_SCHEME_P256 0
@@ -241,6 +243,14 @@ int sbv_profile_read_dominant(double* dominant_us, uint64_t* dominant_launches);
  * the per-batch key tables, out[2] = tuples verified by the generic kernel, out[3] = ungrouped tuples rejected
  * for their public key alone (pointFromAffine: coordinate >= p or off the curve).  Synchronises the device. */
 int sbv_p256_last_group_stats(uint32_t out[4]);
+/* Table classes of the most recent grouped P-256 batch (round 5; consensus_amd/csrc/p256_group.h).  Every grouped key gets its ROWS —
+ * the babies b * 2^(8j) Q and giants 16 a * 2^(8j) Q of every window: a comb with 4-bit windows, two additions per window — which pay
+ * from ~4 signatures per key; the FILL that completes the 8-bit comb (three quarters of a table's cost, one addition per window) is
+ * spent on keys that sign at least 256 tuples of the batch (SBV_FULL_TABLE_MIN), also later: a key cached with rows only is upgraded
+ * by the first batch in which it is hot.  out[0] = groups verified from a full table, out[1] = groups whose table was filled in this
+ * batch, out[2] = grouped tuples served by the rows-only pass.  Verdicts never depend on the class.  Synchronises the device.
+ * K arbitrary clients per proposal: internal/bft/view.go:553-559. */
+int sbv_p256_last_table_classes(uint32_t out[3]);
 
 /* Page-locked host memory for the host-pointer entries.  Handing pageable memory to a 100 MB batch makes the HIP
  * runtime pin (or bounce) it inside the call — measured at 25 ms for a 550 000-signature replay batch whose kernels

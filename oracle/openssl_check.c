@@ -122,3 +122,66 @@ void sbvssl_ed25519_verify_gen_batch(uint32_t seed, const uint8_t *tuples, size_
     }
     for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
 }
+
+/* ---- a strict-DER judge for VerifyASN1, built only from OpenSSL primitives ---------------------------------------
+ * The DER / encoding classes of the golden vectors used to be confirmed by the builder's C restatement and the builder's Python
+ * twin only — one author, one reading of Go's crypto/ecdsa.parseSignature (x/crypto/cryptobyte).  This is a third opinion that
+ * shares no parsing code with either:
+ *     d2i_ECDSA_SIG            OpenSSL's own ASN.1 decoder (BER-tolerant)
+ *     all input consumed       cryptobyte: !input.Empty() after the SEQUENCE is an error
+ *     r, s not negative        cryptobyte ReadASN1Integer into []byte refuses a set sign bit
+ *     i2d_ECDSA_SIG == input   byte for byte: whatever BER liberty the decoder took (non-minimal lengths, padded or non-minimal
+ *                              integers, indefinite forms) cannot survive a canonical DER re-encoding
+ *     ECDSA_do_verify          on the hash AS GIVEN (any length: OpenSSL truncates to the leftmost 32 bytes and takes a shorter
+ *                              digest as the integer it spells, which is hashToNat's rule)
+ * Returns 1 = accept, 0 = reject.  The key goes through EC_KEY_set_public_key_affine_coordinates (coordinates < p, on the curve). */
+int sbvssl_p256_verify_asn1(const uint8_t qx[32], const uint8_t qy[32], const uint8_t *hash, size_t hlen, const uint8_t *der, size_t dlen) {
+    int ok = 0;
+    const unsigned char *p = der;
+    ECDSA_SIG *sig = dlen ? d2i_ECDSA_SIG(NULL, &p, (long)dlen) : NULL;
+    unsigned char *re = NULL;
+    EC_KEY *key = NULL;
+    BIGNUM *x = NULL, *y = NULL;
+    if (!sig || (size_t)(p - der) != dlen) goto done;
+    {
+        const BIGNUM *r = NULL, *s = NULL;
+        ECDSA_SIG_get0(sig, &r, &s);
+        if (!r || !s || BN_is_negative(r) || BN_is_negative(s)) goto done;
+    }
+    {
+        const int rl = i2d_ECDSA_SIG(sig, &re);
+        if (rl < 0 || (size_t)rl != dlen || memcmp(re, der, dlen) != 0) goto done;
+    }
+    key = EC_KEY_new_by_curve_name(NID_X9_62_prime256v1);
+    x = BN_bin2bn(qx, 32, NULL);
+    y = BN_bin2bn(qy, 32, NULL);
+    if (!key || !x || !y || EC_KEY_set_public_key_affine_coordinates(key, x, y) != 1) goto done;
+    {
+        static const unsigned char none = 0;
+        ok = ECDSA_do_verify(hlen ? hash : &none, (int)hlen, sig, key) == 1;
+    }
+done:
+    OPENSSL_free(re);
+    BN_free(x); BN_free(y);
+    EC_KEY_free(key);
+    ECDSA_SIG_free(sig);
+    return ok;
+}
+/* the parse half alone: 1 = the judge above would hand (r, s) to the verification */
+int sbvssl_p256_der_is_strict(const uint8_t *der, size_t dlen) {
+    const unsigned char *p = der;
+    ECDSA_SIG *sig = dlen ? d2i_ECDSA_SIG(NULL, &p, (long)dlen) : NULL;
+    unsigned char *re = NULL;
+    int ok = 0;
+    if (sig && (size_t)(p - der) == dlen) {
+        const BIGNUM *r = NULL, *s = NULL;
+        ECDSA_SIG_get0(sig, &r, &s);
+        if (r && s && !BN_is_negative(r) && !BN_is_negative(s)) {
+            const int rl = i2d_ECDSA_SIG(sig, &re);
+            ok = rl >= 0 && (size_t)rl == dlen && memcmp(re, der, dlen) == 0;
+        }
+    }
+    OPENSSL_free(re);
+    ECDSA_SIG_free(sig);
+    return ok;
+}

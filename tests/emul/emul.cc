@@ -140,6 +140,7 @@ unsigned long sbve_group_sort_violations() { return g_sort_violations; }
 // persistent key-table cache of the emulated grouped step (sbve_key_cache resets it)
 static KeyCache g_kc = {};
 static apt* g_kc_ktab = nullptr;
+static std::vector<uint8_t> g_kc_full;       // kfull of the emulated P-256 key-table cache's slots (p256_group.h: table classes)
 static std::vector<uint8_t> g_kc_valid;
 static std::vector<u32> g_kc_ht, g_kc_keys, g_kc_count;
 void sbve_key_cache(int enabled, u32 cap) {
@@ -151,6 +152,7 @@ void sbve_key_cache(int enabled, u32 cap) {
     if (cap) g_kc_ktab = (apt*)aligned_alloc(64, (size_t)cap * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW * sizeof(apt));
     g_kc.ht = g_kc_ht.data(); g_kc.ht_mask = (u32)(ht - 1); g_kc.keys = g_kc_keys.data(); g_kc.count = g_kc_count.data();
     g_kc.cap = cap; g_kc.enabled = enabled && cap ? 1u : 0u;
+    g_kc_full.assign(cap ? cap : 1, 0);
 }
 void sbve_key_cache_stats(u32 out[3]) { out[0] = g_kc.count ? g_kc_count[0] : 0; out[1] = g_kc.count ? g_kc_count[1] : 0; out[2] = g_kc.count ? g_kc_count[2] : 0; }
 // the other two schemes' caches (sbv_key_cache(SBV_SCHEME_SECP256K1 / SBV_SCHEME_ED25519)): scheme 1 = secp256k1, 2 = Ed25519
@@ -184,9 +186,15 @@ void sbve_scheme_key_cache_stats(int scheme, u32 out[3]) {
     for (int i = 0; i < 3; ++i) out[i] = e.count.size() ? e.count[i] : 0;
 }
 void sbve_set_group_chunks(int c) { g_group_chunks = c < 1 ? 1 : (c > 4 ? 4 : c); }
+static u32 g_full_min = 256;       // GroupBuffers::full_min: uses of a key in a batch from which its table is filled (p256_group.h: table classes)
+void sbve_set_full_table_min(u32 v) { g_full_min = v; }
+static u32 g_last_classes[3] = {0, 0, 0};    // last grouped P-256 batch: groups with a full table, groups filled in this batch, lanes served by the narrow pass
+void sbve_last_table_classes(u32 out[3]) { for (int i = 0; i < 3; ++i) out[i] = g_last_classes[i]; }
 static u32 g_hash_seed = 0;        // GroupState::seed of the emulated grouped steps (the library draws a random one per context)
 void sbve_set_hash_seed(u32 s) { g_hash_seed = s; }
 static void emul_window_rows_fill(const u32* recs, bool top, u32* tmp, apt* row);
+static void emul_window_rows(const u32* recs, bool top, u32* tmp, apt* row);
+static void emul_window_fill(bool top, u32* tmp, apt* row);
 void sbve_set_group_coop(int on) { g_group_coop = on != 0; }     // k_group_coop instead of the G phase + Q launches (key-sorted step only)
 // grouped form: generic tuples, keys grouped inside the call (p256_group.h), emulated sequentially.
 // stats_out[0..3] = groups, grouped tuples, ungrouped tuples, ungrouped tuples rejected for their key.
@@ -270,6 +278,21 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     for (u32 k = 0; k < ngroups; ++k) key_cache_phase_insert<160, 96, 16>(tuples, g, kc, k, tslot.data());
     auto table_of = [&](u32 k) -> apt* { return tslot[k] < kc.cap ? g_kc_ktab + (size_t)tslot[k] * per_key : ktab + (size_t)k * per_key; };
     auto valid_of = [&](u32 k) -> uint8_t* { return tslot[k] < kc.cap ? &g_kc_valid[tslot[k]] : &kvalid[k]; };
+    // table classes (p256_group.h; k_group_table_class): kfull = [cache slots | this batch's per-batch slots], as on the device
+    const u32 table_slots = kc.cap + (u32)ng1;
+    if (g_kc_full.size() < kc.cap) g_kc_full.assign(kc.cap, 0);
+    std::vector<uint8_t> kfull(table_slots, 0), full(ng1, 0), needfill(ng1, 0);
+    memcpy(kfull.data(), g_kc_full.data(), kc.cap);
+    const u32 full_min = g_group_coop && g.sorted ? 0u : g_full_min;      // the coop launch reads any entry of a row
+    for (u32 k = 0; k < ngroups; ++k) group_table_class_lane(k, g, tslot.data(), cold.data(), kfull.data(), table_slots, full_min, full.data(), needfill.data());
+    g_last_classes[0] = g_last_classes[1] = g_last_classes[2] = 0;
+    for (u32 k = 0; k < ngroups; ++k) { g_last_classes[0] += full[k]; g_last_classes[1] += needfill[k]; }
+    // which lanes of the grouped list the chunk launches serve (wavefronts of 64 whose lanes ALL hold full tables) and which the narrow pass
+    std::vector<uint8_t> wave_full((counters[1] + 63) / 64 + 1, 1);
+    for (u32 L = 0; L < counters[1]; ++L) {
+        const u32 grp = g.sorted ? grp_of[L] : slots[grp_idx[L]];
+        if (!(grp < ngroups && full[grp])) wave_full[L / 64] = 0;
+    }
     memset(bitmap, 0, (n + 7) / 8);
     const int chunks = g_group_chunks;
     for (int c = 0; c < chunks; ++c) {
@@ -280,11 +303,14 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
                 keychain29_run(q, tuples, k, g, jstate.data(), bases, valid_of(k), j_first, j_end - 1, 0x11u);
             }
         for (u32 k = 0; k < ngroups; ++k)
-            for (int j = j_first; j < j_end && cold[k]; ++j) {
+            for (int j = j_first; j < j_end && cold[k]; ++j) {        // k_keytab29_rows: every cold group
                 const size_t w = (size_t)k * SBV_GTAB_WINDOWS + j;
                 apt* row = table_of(k) + (size_t)j * SBV_GTAB_PER_WINDOW;
-                emul_window_rows_fill(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
+                emul_window_rows(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
             }
+        for (u32 k = 0; k < ngroups; ++k)
+            for (int j = j_first; j < j_end && needfill[k]; ++j)      // k_keytab29_fill_sym: the groups that earn a full table (cold, or a cached narrow one: upgrade)
+                emul_window_fill(j == SBV_GTAB_WINDOWS - 1, tmpa.data(), table_of(k) + (size_t)j * SBV_GTAB_PER_WINDOW);
         const bool last = c + 1 == chunks;
         if (g_group_coop && g.sorted) {
             if (!last) continue;
@@ -316,7 +342,8 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             }
             continue;
         }
-        for (u32 L = 0; L < counters[1]; ++L) {
+        for (u32 L = 0; L < counters[1]; ++L) {                       // k_verify_keyed_q<false>: the wavefronts whose lanes all hold full tables
+            if (!wave_full[L / 64]) continue;
             const u32 t = grp_idx[L];
             const u32 grp = g.sorted ? grp_of[L] : slots[t];
             bool v;
@@ -327,6 +354,33 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             if (last && v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
         }
     }
+    if (!(g_group_coop && g.sorted)) {
+        // k_verify_keyed_q<true>: every other wavefront, all 33 windows from babies and giants (two additions per window).  Entries the
+        // fill never wrote must not be read: poison them first (0xA5 is what a fresh per-batch table holds; a cached table's unfilled
+        // entries are poisoned here too), so that a stray read shows as a wrong verdict.
+        for (u32 k = 0; k < ngroups; ++k) {
+            if (full[k]) continue;
+            apt* tab = table_of(k);
+            for (int j = 0; j < SBV_GTAB_WINDOWS - 1; ++j)
+                for (int m = 1; m <= SBV_GTAB_PER_WINDOW; ++m)
+                    if (m > 8 && (m & 15) != 0) memset((void*)(tab + (size_t)j * SBV_GTAB_PER_WINDOW + m - 1), 0xA5, sizeof(apt));
+        }
+        for (u32 L = 0; L < counters[1]; ++L) {
+            if (wave_full[L / 64]) continue;
+            ++g_last_classes[2];
+            const u32 t = grp_idx[L];
+            const u32 grp = g.sorted ? grp_of[L] : slots[t];
+            bool v;
+            if (g.sorted) v = grp < ngroups ? qphase29_lane_sorted<true>(s, t, L, 0, 1, table_of(grp), valid_of(grp), gacc.data(), 0, SBV_GTAB_WINDOWS, true)
+                                            : qphase29_lane_sorted<true>(s, t, L, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc.data(), 0, SBV_GTAB_WINDOWS, true);
+            else v = grp < ngroups ? qphase29_lane<true>(s, t, 0, 1, table_of(grp), valid_of(grp), gacc.data(), 0, SBV_GTAB_WINDOWS, true)
+                                   : qphase29_lane<true>(s, t, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc.data(), 0, SBV_GTAB_WINDOWS, true);
+            if (v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+        }
+    }
+    // k_group_table_mark: what the cache slots hold from now on
+    for (u32 k = 0; k < ngroups; ++k) group_table_mark_lane(k, tslot.data(), cold.data(), full.data(), needfill.data(), table_slots, kfull.data());
+    memcpy(g_kc_full.data(), kfull.data(), kc.cap);
     u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB29_WORDS * 4);
     for (u32 L = 0; L < counters[2]; ++L) {
         const u32 t = ung_idx[L];
@@ -340,13 +394,19 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
 // rows + fill of one (key, window) the way the launcher does it: k_keytab29_rows (two lanes), then k_keytab29_fill_sym (lane
 // a - 1 fills both sides of giant 16 a; the lanes run in descending order here so that a lane that wrongly depended on
 // another's output would show)
-static void emul_window_rows_fill(const u32* recs, bool top, u32* tmp, apt* row) {
+static void emul_window_rows(const u32* recs, bool top, u32* tmp, apt* row) {
     for (int which = 0; which < 2; ++which) {
         if (which == 1 && top) continue;
         keytab29_rows_lane(recs, which, top, tmp, row);
     }
+}
+static void emul_window_fill(bool top, u32* tmp, apt* row) {
     if (top) return;
     for (int a = 8; a >= 1; --a) keytab29_fill_sym_lane(a, tmp + (size_t)(a - 1) * (SBV_KT29_FILL_TMP_WORDS / 2), row);
+}
+static void emul_window_rows_fill(const u32* recs, bool top, u32* tmp, apt* row) {
+    emul_window_rows(recs, top, tmp, row);
+    emul_window_fill(top, tmp, row);
 }
 
 // n doublings of the affine point (x, y) (plain words) through the quad-cooperative chain of the table builder

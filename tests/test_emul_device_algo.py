@@ -768,3 +768,63 @@ def test_probe_bound_keeps_insert_work_bounded_and_verdicts_identical(emul, orac
     # (rejected for their key: stats[3]).  Another seed: every crafted key groups (3 uses >= the threshold of 2).
     assert res[0][0] <= 5 + 64 + 8 and res[0][3] >= 3 * (600 - 64 - 8)
     assert res[0x5EED1234][0] >= 5 + 600 - 8 and res[0x5EED1234][3] < 50
+
+
+def test_table_classes_rows_only_full_and_upgrade(emul, oracle, golden_vectors):
+    """Round 5, p256_group.h "table classes": every grouped key gets its ROWS (babies + giants: a comb with 4-bit windows, two
+    additions per window, p256_comb29.h: qphase29_point_narrow); the fill is spent on keys with >= full_min uses in the batch.  A batch
+    mixing hot keys (full tables), lukewarm keys (rows only) and the golden edge vectors must give the generic verdicts, in 1, 2 and
+    3 chunks; the unfilled entries of a rows-only table are poisoned by the emulator before the narrow pass, so a stray read shows.
+    Through the key-table cache: a key cached with rows only is verified from them by a later batch (no rebuild), and is UPGRADED
+    (fill only) by a batch in which it has become hot; a cached full table stays full for a batch that carries two of its tuples."""
+    emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    emul.sbve_key_cache.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    emul.sbve_set_full_table_min.argtypes = [ctypes.c_uint32]
+    emul.sbve_last_table_classes.argtypes = [ctypes.c_void_p]
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+    stats = (ctypes.c_uint32 * 4)()
+    cls = (ctypes.c_uint32 * 3)()
+
+    def batch(seed, n, nkeys):
+        tup = ctypes.create_string_buffer(160 * n)
+        exp = ctypes.create_string_buffer((n + 7) // 8)
+        oracle.sbvo_gen_batch(seed, n, nkeys, 6, tup, exp, 4)
+        return tup.raw, _bitmap_list(exp.raw, n)
+
+    def run(allt, want, min_count=4):
+        total = len(allt) // 160
+        bm = ctypes.create_string_buffer((total + 7) // 8)
+        emul.sbve_p256_verify_batch_grouped(allt, total, bm, min_count, 256, 12, stats)
+        got = _bitmap_list(bm.raw, total)
+        assert got == want, [i for i in range(total) if got[i] != want[i]][:8]
+        emul.sbve_last_table_classes(cls)
+        return list(stats), list(cls)
+
+    hot, whot = batch(0xA1, 600, 3)             # 3 keys x 200 uses
+    luke, wluke = batch(0xA2, 300, 20)          # 20 keys x 15 uses
+    try:
+        emul.sbve_set_full_table_min(64)
+        for chunks in (1, 2, 3):
+            emul.sbve_set_group_chunks(chunks)
+            st, c = run(hot + luke + blob, whot + wluke + [v["accept"] for v in vs])
+            # full: the 3 hot keys (the golden vectors reuse a few keys, none 64 times); the narrow pass serves the lukewarm keys' lanes and the seams
+            assert c[0] == 3 and c[1] == 3, (chunks, c)
+            assert c[2] >= 300 and st[1] >= 880, (chunks, c, st)
+        emul.sbve_set_group_chunks(2)
+        # through the cache
+        emul.sbve_key_cache(1, 64)
+        st, c = run(luke, wluke)
+        assert c[:2] == [0, 0] and c[2] == st[1] >= 260            # 20 keys cached with rows only
+        st, c = run(luke[:160 * 100], wluke[:100])                  # warm, still rows only: nothing rebuilt, verified from the cached rows
+        assert c[:2] == [0, 0] and c[2] == st[1]
+        big, wbig = batch(0xA2, 2000, 20)                           # the same 20 keys, now 100 uses each: upgrade = fill only
+        st, c = run(big, wbig)
+        assert c[0] == 20 and c[1] == 20, c
+        st, c = run(luke[:160 * 40], wluke[:40])                    # two uses per key: the cached tables are full, one addition per window
+        assert c[0] == 20 and c[1] == 0 and c[2] < 64, c
+    finally:
+        emul.sbve_key_cache(0, 0)
+        emul.sbve_set_full_table_min(256)
+        emul.sbve_set_group_chunks(3)

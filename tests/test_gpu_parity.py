@@ -448,7 +448,7 @@ def test_sharded_message_frontend_in_pieces(oracle):
     try:
         sbv.shutdown()
         assert sbv.init_all() >= 1
-        n, nk, G, Qm = 70000, 5, 7, 5
+        n, nk, G, Qm = 70000, 5, 7, 3
         ds = [rng.randrange(1, ec.N) for _ in range(nk)]
         pubs = [ec.pt_mul(d, ec.G) for d in ds]
         slots_of = sbv.register_keys([q[0].to_bytes(32, "big") + q[1].to_bytes(32, "big") for q in pubs])
@@ -724,3 +724,59 @@ print("sorted=%s ok" % os.environ.get("SBV_GROUP_SORT", "1"))
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SBV_GROUP_SORT=sort), capture_output=True, text=True,
                              timeout=300, cwd=root)
         assert out.returncode == 0 and "sorted=%s ok" % sort in out.stdout, out.stdout + out.stderr
+
+
+def test_table_classes_on_the_device(gpu, oracle, golden_vectors):
+    """Round 5: one batch over keys of very different frequency — 8 hot keys (16 384 uses each: full 8-bit combs),
+    4 000 lukewarm keys (32 uses: rows only, two additions per window), 30 000 keys used once (the one-lane kernel) and the golden
+    edge vectors — cold with the cache off, cold and warm with it on, and an UPGRADE: a later batch in which 400 of the lukewarm
+    keys have become hot fills their cached rows-only tables.  Every verdict == the generator's expectation (which the whole-batch
+    oracle / OpenSSL tests pin) and == the pinned verdict of each golden vector; the class counters say which path served what."""
+    import numpy as np
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    gold = np.frombuffer(b"".join(bytes.fromhex(v["tuple"]) for v in vs), dtype=np.uint8).reshape(len(vs), 160)
+    gold_want = np.array([1 if v["accept"] else 0 for v in vs], dtype=np.uint8)
+
+    def gen(seed, n, nkeys, inv=7):
+        tup = ctypes.create_string_buffer(160 * n)
+        exp = ctypes.create_string_buffer((n + 7) // 8)
+        oracle.sbvo_gen_batch(seed, n, nkeys, inv, tup, exp, os.cpu_count() or 1)
+        return (np.frombuffer(tup, dtype=np.uint8).reshape(n, 160).copy(),
+                np.unpackbits(np.frombuffer(exp, dtype=np.uint8), bitorder="little")[:n].copy())
+
+    def run(t, want):
+        n = len(want)
+        got = ctypes.create_string_buffer((n + 7) // 8)
+        buf = np.ascontiguousarray(t).reshape(-1)
+        gpu.verify_batch_ptr(buf.ctypes.data, n, ctypes.addressof(got))
+        bits = np.unpackbits(np.frombuffer(got, dtype=np.uint8), bitorder="little")[:n]
+        bad = np.nonzero(bits != want)[0]
+        assert len(bad) == 0, bad[:8]
+        return gpu.last_group_stats(), gpu.last_table_classes()
+
+    hot, whot = gen(0x51, 8 * 16384, 8)
+    luke, wluke = gen(0x52, 4000 * 32, 4000)
+    once, wonce = gen(0x53, 30000, 30000)
+    t = np.concatenate([hot, luke, once, gold])
+    w = np.concatenate([whot, wluke, wonce, gold_want])
+    perm = np.random.default_rng(5).permutation(len(w))
+    t, w = t[perm], w[perm]
+    try:
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
+        gpu.key_cache(False)
+        st, cl = run(t, w)
+        assert st[0] >= 8 + 3000 and cl[0] == 8 and cl[1] == 8, (st, cl)       # 8 full tables; ~91 % of the 32-use keys pass the soft threshold
+        assert cl[2] >= 3000 * 32 * 0.8 and st[2] >= 25000, (st, cl)            # rows-only pass; single-use keys on the one-lane kernel
+        gpu.key_cache(True)
+        st, cl = run(t, w)                                                      # cold, tables kept
+        st2, cl2 = run(t, w)                                                    # warm: nothing is built, the classes are remembered per slot
+        assert cl2[0] == 8 and cl2[1] == 0 and st2[0] >= st[0], (st2, cl2)
+        # upgrade: 400 of the lukewarm keys (the generator derives key i from (seed, i)) now sign 512 tuples each
+        up, wup = gen(0x52, 400 * 512, 400)
+        st3, cl3 = run(up, wup)
+        assert cl3[0] >= 380 and cl3[1] >= 300, (st3, cl3)                      # filled now, from the rows an earlier batch cached
+        st4, cl4 = run(t, w)                                                    # the mixed batch again: those keys' slots are full now
+        assert cl4[0] >= 8 + 300 and cl4[1] == 0, (st4, cl4)
+    finally:
+        gpu.key_cache(True)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)

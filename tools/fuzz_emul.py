@@ -6,7 +6,7 @@ checks on: an operand outside its bounds aborts the process).  No GPU needed.
   keyed    the registered-key lanes with every slot widened (one-lane form, 8-lane form, prepared one-launch form) against the oracle
            on seeded batches with corrupted tuples
   ed       the Ed25519 grouped step (key check over the ungrouped candidates, batched finish) against the oracle on seeded batches
-  p256g    the P-256 grouped step (sorted / compaction order, 1-4 chunks, the one-launch latency form, key-table cache on / off)
+  p256g    the P-256 grouped step (sorted / compaction order, 1-4 chunks, the one-launch latency form, key-table cache on / off; round 5: table classes — rows only / full / upgrade)
   k256g    the secp256k1 grouped step (1-3 chunks, stage-A chunking, its key-table cache on / off)
   one      the one-lane kernels of the three schemes (all-distinct keys / small batches: 256 doublings per signature)
 
@@ -36,6 +36,7 @@ def worker(args):
     emul.sbve_k256_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
     emul.sbve_ed25519_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
     emul.sbve_key_cache.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    emul.sbve_set_full_table_min.argtypes = [ctypes.c_uint32]
     emul.sbve_scheme_key_cache.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
     oracle.sbvo_k256_gen_batch.argtypes = gen_args
     rng = random.Random(0xF022 + wid)
@@ -131,6 +132,8 @@ def worker(args):
             for rep in range(2 if cache else 1):                      # with the cache: a cold pass, then a warm one over the same keys
                 bm = ctypes.create_string_buffer((n + 7) // 8)
                 if p256:
+                    # round 5, table classes: rows only / full tables / a mix, and through the cache an upgrade (rows-only slot, then hot)
+                    emul.sbve_set_full_table_min(rng.choice((0, 16, 64, 200, 10**6)))
                     emul.sbve_p256_verify_batch_grouped(tup.raw, n, bm, rng.choice((1, 8, 30)), rng.choice((4, 64)), 12, None)
                 else:
                     emul.sbve_k256_verify_batch_grouped(tup.raw, n, bm, rng.choice((1, 8, 30)), rng.choice((4, 64)), 12, rng.choice((1, 2, 3)), None)
