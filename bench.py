@@ -237,12 +237,17 @@ def leg_end_to_end(sbv, tuples, valid, n, steps):
     import threading
     import numpy as np
     out = {}
-    for kind in ("pinned", "pageable"):
+    for kind in ("pinned", "pinned_key_cache_on", "pageable"):
         ptrs = []
+        # "pinned_key_cache_on": the library's DEFAULT configuration (the rest of this run switches the key-table cache off so that the
+        # headline is cold).  With it on, one caller's batch goes up in pieces beside its own kernels (round 5: sbv_api.hip,
+        # verify_in_pieces): what a single VerifyProposal caller gets (internal/bft/view.go:555).
+        cache_on = kind == "pinned_key_cache_on"
+        sbv.key_cache(cache_on)
         try:
             srcs = []
             for _ in range(2):
-                if kind == "pinned":
+                if kind.startswith("pinned"):
                     ptr = sbv.host_alloc(n * 160)
                     if not ptr:
                         raise RuntimeError("sbv_host_alloc failed")
@@ -274,6 +279,7 @@ def leg_end_to_end(sbv, tuples, valid, n, steps):
         except Exception as e:      # noqa: BLE001 - a secondary leg must not take the headline down
             out[kind] = {"error": repr(e)}
         finally:
+            sbv.key_cache(False)
             for ptr in ptrs:
                 sbv.host_free(ptr)
     return out

@@ -200,10 +200,12 @@ __global__ __launch_bounds__(256) void k_group_table_mark(GroupState g, const u3
 // The counting sort for batches with more groups than one LDS histogram holds (> 16 384: 2^20 tuples over 65 536 keys): a tile sees a
 // key at most a few times, so the histogram would be all flush and no merge — plain global atomics (p256_group.h: group_sort_*_lane).
 __global__ __launch_bounds__(256) void k_group_sort_count_direct(size_t n, GroupState g) {
+    if (group_count(g) <= SBV_SORT_LDS_GROUPS) return;        // the LDS-histogram kernels' batch (group_kernels_common.h)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) group_sort_count_lane(i, g);
 }
 __global__ __launch_bounds__(256) void k_group_sort_scatter_direct(size_t n, GroupState g) {
+    if (group_count(g) <= SBV_SORT_LDS_GROUPS) return;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) group_sort_scatter_lane(i, g);
 }
@@ -360,8 +362,8 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     g.gcount = b.gcount; g.gcursor = b.gcount ? b.gcount + b.max_groups : nullptr; g.grp_of = b.grp_of; g.ung_cand = b.ung_cand;
     // key-sorted grouped list: needs the per-tuple records of stage A; one LDS word per group while the histogram fits (<= 16 384
     // groups), plain global atomics beyond (k_group_sort_*_direct)
-    const size_t sort_lds = (size_t)b.max_groups * sizeof(u32);
-    const bool sort_direct = sort_lds > 64 * 1024;
+    const bool sort_direct = b.max_groups > SBV_SORT_LDS_GROUPS;            // capacity beyond one histogram: launch the direct kernels too
+    const size_t sort_lds = (size_t)(sort_direct ? SBV_SORT_LDS_GROUPS : b.max_groups) * sizeof(u32);
     g.sorted = y.sorted && s_in.rec && b.gcount && b.grp_of && b.ung_cand ? 1u : 0u;
     // Stage A writes EITHER the per-tuple records (key-sorted step: every reader takes them) OR the limb-major planes
     Scratch s = s_in;
@@ -401,8 +403,8 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         hipLaunchKernelGGL(k_group_classify, dim3(gn), dim3(256), 0, y.side_b, n, g, b.ung_cand, b.counters + 4);
         hipLaunchKernelGGL(k_group_keycheck, dim3(gn), dim3(256), 0, y.side_b, d_tuples, g, b.acc);
         const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
+        hipLaunchKernelGGL(k_group_sort_count, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
         if (sort_direct) hipLaunchKernelGGL(k_group_sort_count_direct, dim3(gn), dim3(256), 0, y.side_b, n, g);
-        else hipLaunchKernelGGL(k_group_sort_count, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
         hipLaunchKernelGGL(k_group_sort_scan, dim3(1), dim3(1024), 0, y.side_b, g);
     }
     // table classes: after the exact counts (gcount survives the scan; the scatter moves gcursor only) and after the cache assigned the slots
@@ -411,8 +413,8 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     SBV_TRY(hipEventRecord(y.ev_class, y.side_b));
     if (g.sorted) {
         const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
+        hipLaunchKernelGGL(k_group_sort_scatter, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
         if (sort_direct) hipLaunchKernelGGL(k_group_sort_scatter_direct, dim3(gn), dim3(256), 0, y.side_b, n, g);
-        else hipLaunchKernelGGL(k_group_sort_scatter, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
     }
     SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
     // The generic stage B over the ungrouped list (keys that repeat too rarely for a table: a 2.3 ms chain per lane, so it starts
@@ -429,6 +431,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     } else {
         hipLaunchKernelGGL(k_gphase_generic, dim3(gv + gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, gv, (size_t)0, n);
     }
+    SBV_TRY(hipEventRecord(y.ev_generic, stream));         // the G phase is enqueued: the accumulators of the rows-only pass are final behind this event
     // Chunks of windows: the chain on side_a, rows + fill on side_b (odd chunks on side_t), the Q phase on stream.
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [j_first, j_end)
@@ -456,14 +459,22 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
             if (prof) SBV_TRY(hipEventRecord(prof[1], stream));
             continue;
         }
+        if (last) {
+            // The wavefronts with a key that has rows only: all 33 windows, two additions per window — a ~60-addition chain per lane.
+            // On side_a (idle once the chains are done), BESIDE the last chunk's launch instead of behind it: needs the G phase and the
+            // rows of every chunk (ev_tables of all chunks are ordered before this point on `stream`; side_a waits for them itself).
+            SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_generic, 0));
+            for (int cc = 0; cc < chunks; ++cc) SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_tables[cc], 0));
+            hipLaunchKernelGGL(k_verify_keyed_q<true>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, s, g, b.ktab, b.kvalid, b.tslot, b.full, table_slots, b.gacc,
+                               b.acc, 0, SBV_GTAB_WINDOWS, 1);
+            SBV_TRY(hipEventRecord(y.ev_narrow, y.side_a));
+        }
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
         hipLaunchKernelGGL(k_verify_keyed_q<false>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, table_slots, b.gacc, b.acc,
                            j_first, j_end, last ? 1 : 0);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
-    // the wavefronts with a key that has rows only: all 33 windows in one launch, two additions per window (every table is complete here)
-    if (!coop) hipLaunchKernelGGL(k_verify_keyed_q<true>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, table_slots, b.gacc,
-                                  b.acc, 0, SBV_GTAB_WINDOWS, 1);
+    if (!coop) SBV_TRY(hipStreamWaitEvent(stream, y.ev_narrow, 0));
     hipLaunchKernelGGL(k_group_table_mark, dim3(64), dim3(256), 0, stream, g, b.tslot, b.cold, b.full, b.needfill, table_slots, b.kfull);
     hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
 #undef SBV_TRY

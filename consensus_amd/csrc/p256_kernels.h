@@ -92,6 +92,7 @@ struct GroupSync {
     int tstreams = 2;               // SBV_GROUP_TSTREAMS (1, 2): 1 = every chunk's rows + fill queue up on side_b.  2: rows of chunk 1 start when ITS chain ends, not when fill of chunk 0 does — cold 2^18 2.04 -> 1.70 ms, 2^17 2.54 -> 2.23, 2^20 unchanged (profiles/r03/ab_sched_r03m.jsonl).  The Ed25519 step keeps one table stream (measured in round 4: 4.55 -> 4.67 ms with two, profiles/r04/ab_ed_tstreams_r04a.jsonl)
     hipEvent_t ev_fork = nullptr, ev_assign = nullptr, ev_split = nullptr, ev_generic = nullptr;
     hipEvent_t ev_cache = nullptr, ev_class = nullptr;       // P-256: table slots assigned (side_a) / table classes decided (side_b)
+    hipEvent_t ev_narrow = nullptr;                          // P-256: the rows-only pass (side_a) is done
     hipEvent_t ev_bases[SBV_GROUP_MAX_CHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
     int chunks = 1;
     int sorted = 1;                 // key-sorted grouped list + XCD-aware Q phase (SBV_GROUP_SORT=0: the split's compaction order; the form the step falls back to when a batch has more groups than one LDS histogram holds)

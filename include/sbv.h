@@ -77,7 +77,8 @@ int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitma
  * sampled threshold: 2 of a key's every-8th tuples; the Ed25519 / secp256k1 steps, whose tables are always full, keep 64 and at most
  * 2048 groups); max_groups 65536 (round 5; 2048 before — a 2^20 batch over 4096 keys sent half its tuples to the one-lane kernel).
  * Passing a non-zero min_batch sets both thresholds (and the variant schemes'); SBV_GROUP_MIN_BATCH_DEFAULT restores the built-in
- * ones; 0 for a numeric argument keeps its current value.  Env: SBV_GROUP=0
+ * ones together with the built-in min_count and max_groups (a non-zero min_count / max_groups in the same call still applies);
+ * 0 for a numeric argument keeps its current value.  Env: SBV_GROUP=0
  * disables, SBV_GROUP_MIN_BATCH=<n>.  What IS remembered between calls is the key-table cache. */
 #define SBV_GROUP_MIN_BATCH_DEFAULT ((size_t)-1)
 int sbv_p256_set_grouping(int enabled, size_t min_batch, uint32_t min_count, uint32_t max_groups);

@@ -122,7 +122,7 @@ def test_in_step_key_grouping_equals_plain_kernel(gpu, oracle):
             bad = [i for i in range(total) if got[i] != want[i]]
             assert not bad, (min_count, max_groups, bad[:8])
     finally:
-        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 64, 2048)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
 
 
 def test_grouped_vs_plain_full_batch(gpu, oracle):
@@ -139,7 +139,7 @@ def test_grouped_vs_plain_full_batch(gpu, oracle):
             assert got.raw == exp.raw, mode
             times[mode] = gpu.last_timing().verify_us
     finally:
-        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 64, 2048)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
     print(f"\n[ed25519 2^20] grouped {times[True]:.0f} us ({n / times[True]:.1f} M/s) | one lane per signature {times[False]:.0f} us "
           f"({n / times[False]:.1f} M/s)")
 
@@ -227,4 +227,4 @@ def test_key_table_cache_of_this_scheme_on_gpu(gpu, oracle, openssl_check):
     finally:
         gpu.key_cache(False, 0, E)
         gpu.key_cache(True, 1024, E)
-        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 64, 2048)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)

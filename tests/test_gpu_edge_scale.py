@@ -34,7 +34,7 @@ COPIES = 64
 def gpu():
     sbv.init(0)
     yield sbv
-    sbv.set_grouping(True, 0, 64, 0)
+    sbv.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
     sbv.key_cache(True, 4096)
 
 
@@ -105,7 +105,7 @@ def test_p256_edge_vectors_spliced_into_the_headline_batch_cache_off_warm_overfl
         got = _run_ptr(gpu, batch, n)
         assert _report(got, want, where, names) is None, ("grouping off", _report(got, want, where, names))
     finally:
-        gpu.set_grouping(True, 0, 64, 0)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
         gpu.key_cache(True, 4096)
 
 
@@ -131,7 +131,7 @@ def test_p256_edge_vectors_spliced_into_a_chunked_ragged_batch(gpu):
                 got = _run_ptr(gpu, batch, n)
                 assert _report(got, want, where, names) is None, (label, rnd, _report(got, want, where, names))
     finally:
-        gpu.set_grouping(True, 0, 64, 0)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
         gpu.key_cache(True, 4096)
 
 
@@ -155,7 +155,7 @@ def test_ed25519_edge_vectors_spliced_into_2_20(gpu, oracle):
             rep = _report(_bits(got.tobytes(), n), want, where, names)
             assert rep is None, (grouping, rep)
         finally:
-            gpu.set_grouping(True, 0, 64, 0)
+            gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
 
 
 def test_secp256k1_edge_vectors_spliced_into_2_20(gpu, oracle):
@@ -212,4 +212,4 @@ def test_ed25519_batches_leave_the_p256_key_cache_alone(gpu, oracle):
         entries, hits, misses, cap = gpu.key_cache_stats()
         assert hits >= 300 and misses == 0
     finally:
-        gpu.set_grouping(True, 0, 64, 0)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)

@@ -520,7 +520,7 @@ def test_in_step_key_grouping_equals_generic(gpu, oracle, golden_vectors):
             bad = [i for i in range(total) if got[i] != want[i]]
             assert not bad, (min_count, max_groups, bad[:8])
     finally:
-        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 64, 2048)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
 
 
 def test_coop_form_of_the_grouped_step_on_the_gpu(oracle, golden_vectors):
@@ -581,7 +581,7 @@ def test_grouped_vs_ungrouped_full_batch(gpu):
             tm = gpu.last_timing()
             times[mode] = (tm.prep_us, tm.verify_us)
     finally:
-        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 64, 2048)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
     print(f"\n[2^20] grouped: prep {times[True][0]:.0f} us stageB {times[True][1]:.0f} us | ungrouped: prep {times[False][0]:.0f} us "
           f"stageB {times[False][1]:.0f} us")
 
@@ -693,7 +693,7 @@ def test_key_table_caches_survive_buffer_growth(gpu, oracle):
             entries, hits, misses, cap = gpu.key_cache_stats(scheme)
             assert misses == 0 and hits == first[scheme] and entries == first[scheme], (scheme, entries, hits, misses)
     finally:
-        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 64, 2048)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
         gpu.key_cache(False); gpu.key_cache(True, 4096)
         for scheme in (sbv.SCHEME_SECP256K1, sbv.SCHEME_ED25519):
             gpu.key_cache(False, 0, scheme); gpu.key_cache(True, 1024, scheme)
