@@ -144,10 +144,15 @@ def variant_roofline(kernel, bytes_per_verify, lanes, share, dominant_us, domina
         return None
     kern_s = dominant_us / dominant_launches * 1e-6
     achieved = bytes_per_verify * lanes * share / kern_s / 1e9
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+    traffic = None                  # per-launch HBM bytes of this kernel from a rocprofv3 --pmc run over THIS leg (tools/gpu_session.sh pmc, tools/traffic_from_pmc.py)
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(kernel + "_hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
             "kernel": kernel, "avg_launch_us": dominant_us / dominant_launches, "launches": int(dominant_launches), "units_per_launch": int(lanes),
             "share_of_a_tuples_stage_b_per_launch": share,
-            "note": "integer-ALU bound like the P-256 step (DESIGN.md 4.8); traffic: no PMC pass was run for this leg"}
+            "note": "integer-ALU bound like the P-256 step (DESIGN.md 4.8); traffic: PMC counters of a builder session (profiles/traffic.json), null when no pass covered this kernel"}
 
 
 def leg_warm_cache(sbv, torch, d_tuples, d_bitmap, valid, n, steps, stream):

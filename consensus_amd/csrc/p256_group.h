@@ -82,13 +82,18 @@ struct GroupState {
 // samples) to round 5's default of 16 (a key's rows pay from ~4 signatures on, p256_comb29.h): a key then passes with 2 of its
 // every-8th tuples — a soft edge (a 16-use key passes with probability 0.61, a 32-use key 0.91, a 64-use key 0.998, a 4-use key
 // 0.08), which only decides who gets a table, never a verdict.
-SBV_HD void group_set_threshold(GroupState& g, u32 min_count) {
-    const u32 shift = min_count >= 16 ? 3u : 0u;
+SBV_HD void group_set_sampling(GroupState& g, u32 min_count, u32 shift) {
     g.min_count = min_count;
     g.sample_mask = (1u << shift) - 1u;
     const u32 ms = min_count >> shift;
     g.min_samples = ms ? ms : 1u;
 }
+SBV_HD void group_set_threshold(GroupState& g, u32 min_count) { group_set_sampling(g, min_count, min_count >= 16 ? 3u : 0u); }
+// The P-256 step's built-in default (round 5, sbv_api.hip): 8 uses counted on every 4th tuple = 2 samples.  A 16-use key passes with
+// probability 0.94, an 8-use key 0.63, a 4-use key 0.26 (its rows cost what its four generic verifications would: no loss), a key
+// used once never.  Measured against every-8th / 16 uses on the 2^20 sweep (profiles/r05): the 65 536-key point.
+#define SBV_GROUP_MIN_COUNT_DEFAULT 8u
+#define SBV_GROUP_SAMPLE_SHIFT_DEFAULT 2
 
 // Which tuples are counted: a multiplicative hash of the index, NOT its low bits — batches are often laid
 // out round-robin over the signers (tuple i signed by key i mod K), and `i & mask` would then count only

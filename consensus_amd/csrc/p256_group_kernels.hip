@@ -124,6 +124,7 @@ __global__ __launch_bounds__(64) void k_keytab29_chain(const uint8_t* __restrict
     for (u32 lane = blockIdx.x * 64 + threadIdx.x; (lane >> 2) < groups; lane += gridDim.x * 64) {
         const u32 k = lane >> 2;
         if (!cold[k]) continue;
+        if (j_first > 0 && valid[tslot[k]] == 0) continue;      // the first chunk found the key invalid: no table (p256_keytab29.h)
         table_prio();
         keychain_quad_dev q;
         q.r = (int)(lane & 3u);
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(64) void k_keytab29_chain(const uint8_t* __restrict
 #endif
 __global__ __launch_bounds__(64, SBV_ROWS_WAVES) void k_keytab29_rows(GroupState g, const u32* __restrict__ bases, u32* __restrict__ tmp,
                                                       apt* __restrict__ ktab, const u32* __restrict__ tslot,
-                                                      const uint8_t* __restrict__ cold, int j_first, int j_count) {
+                                                      const uint8_t* __restrict__ cold, const uint8_t* __restrict__ kvalid, int j_first, int j_count) {
     const u32 total = group_count(g) * (u32)j_count * 2u;               // <= 65 536 x 33 x 2: fits 32 bits
     for (u32 base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {        // the loop state is wave-uniform: it lives in scalar registers
         const u32 lane = base + threadIdx.x;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(64, SBV_ROWS_WAVES) void k_keytab29_rows(GroupState
         const u32 which = lane & 1u;
         const u32 kw = lane >> 1;
         const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
-        if (!cold[key]) continue;
+        if (!cold[key] || kvalid[tslot[key]] == 0) continue;            // nothing to build, or a key that is no point: no table
         if (which == 1 && j == SBV_GTAB_WINDOWS - 1) continue;          // the top window has no giants
         table_prio();
         const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
@@ -162,8 +163,8 @@ __global__ __launch_bounds__(64, SBV_ROWS_WAVES) void k_keytab29_rows(GroupState
 // Round 5: only for the groups that earn a full table (needfill, p256_group.h: group_table_class_lane); tmp: 72 words per resident lane.
 #define SBV_KT29_FILL_LANE_WORDS (8 * 9)
 __global__ __launch_bounds__(64) void k_keytab29_fill_sym(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab,
-                                                          const u32* __restrict__ tslot, const uint8_t* __restrict__ needfill, int j_first,
-                                                          int j_count) {
+                                                          const u32* __restrict__ tslot, const uint8_t* __restrict__ needfill,
+                                                          const uint8_t* __restrict__ kvalid, int j_first, int j_count) {
     const u32 total = group_count(g) * (u32)j_count * 8u;               // <= 65 536 x 33 x 8: fits 32 bits
     for (u32 base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {
         const u32 lane = base + threadIdx.x;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(64) void k_keytab29_fill_sym(GroupState g, u32* __r
         const u32 r = lane & 7u;
         const u32 kw = lane >> 3;
         const u32 key = kw / (u32)j_count, j = (u32)j_first + kw % (u32)j_count;
-        if (j == SBV_GTAB_WINDOWS - 1 || !needfill[key]) continue;
+        if (j == SBV_GTAB_WINDOWS - 1 || !needfill[key] || kvalid[tslot[key]] == 0) continue;
         table_prio();
         u32* t = tmp + (size_t)(blockIdx.x * 64 + threadIdx.x) * SBV_KT29_FILL_LANE_WORDS;
         keytab29_fill_sym_lane(1 + (int)r, t, ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
@@ -274,6 +275,8 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
             if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)am) - 1u) atomicAdd(&g.counters[7], (u32)__popcll(am));
         }
         const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
+        // a wavefront whose keys are all refused by pointFromAffine (or have no slot): rejected without touching a table (there is none)
+        if (wave_all(!(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0)) { if (last) acc[t] = 0; return; }
         const bool v = qphase29_lane_sorted<NARROW>(s, t, L, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
         if (last) acc[t] = v ? 1 : 0;
         return;
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
     const bool known = grp < group_count(g);
     if (wave_all(known && full[known ? grp : 0u] != 0) == NARROW) return;
     const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
+    if (wave_all(!(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0)) { if (last) acc[t] = 0; return; }
     const bool v = qphase29_lane<NARROW>(s, t, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
     if (last) acc[t] = v ? 1 : 0;
 }
@@ -368,7 +372,8 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     // Stage A writes EITHER the per-tuple records (key-sorted step: every reader takes them) OR the limb-major planes
     Scratch s = s_in;
     if (!g.sorted) s.rec = nullptr;
-    group_set_threshold(g, b.min_count);
+    if (b.sample_shift >= 0) group_set_sampling(g, b.min_count, (u32)b.sample_shift);
+    else group_set_threshold(g, b.min_count);
     const int chunks = y.chunks < 1 ? 1 : (y.chunks > SBV_GROUP_MAX_CHUNKS ? SBV_GROUP_MAX_CHUNKS : y.chunks);
     const bool coop = g.sorted && y.coop_max && n <= y.coop_max;      // k_group_coop instead of the G phase and the Q launches
     // table classes (p256_group.h): the coop launch reads any entry of a row, so its batches (<= 2^15 tuples) fill every table
@@ -445,8 +450,8 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
         SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[c], 0));
         if (on_t) SBV_TRY(hipStreamWaitEvent(tb, y.ev_class, 0));      // side_b has it in stream order
-        hipLaunchKernelGGL(k_keytab29_rows, dim3(bounded((size_t)b.max_groups * j_count * 2)), dim3(64), 0, tb, g, b.bases, ttmp, b.ktab, b.tslot, b.cold, j_first, j_count);
-        hipLaunchKernelGGL(k_keytab29_fill_sym, dim3(bounded((size_t)b.max_groups * j_count * 8)), dim3(64), 0, tb, g, ttmp, b.ktab, b.tslot, b.needfill, j_first, j_count);
+        hipLaunchKernelGGL(k_keytab29_rows, dim3(bounded((size_t)b.max_groups * j_count * 2)), dim3(64), 0, tb, g, b.bases, ttmp, b.ktab, b.tslot, b.cold, b.kvalid, j_first, j_count);
+        hipLaunchKernelGGL(k_keytab29_fill_sym, dim3(bounded((size_t)b.max_groups * j_count * 8)), dim3(64), 0, tb, g, ttmp, b.ktab, b.tslot, b.needfill, b.kvalid, j_first, j_count);
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         const bool last = c + 1 == chunks;

@@ -66,6 +66,7 @@ struct GroupBuffers {
     u32* rec = nullptr;         // [scratch cap][SBV_REC_WORDS] stage A's per-tuple records (Scratch::rec) for the key-sorted list
     u32 max_groups = 0, min_count = 0;
     u32 seed = 0;               // key of the grouping hash table (GroupState::seed): random per context
+    int sample_shift = -1;      // >= 0: count every 2^shift-th tuple against min_count (the P-256 default); -1: group_set_threshold's rule (explicit thresholds, the variants)
     // table classes (p256_group.h, round 5): [max_groups] this batch's groups — one addition per window allowed / run the fill now;
     // [kc.cap + max_groups] what a table slot holds across batches; the per-key signature count from which a full table pays
     uint8_t *full = nullptr, *needfill = nullptr, *kfull = nullptr;

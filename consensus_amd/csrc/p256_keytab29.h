@@ -218,6 +218,11 @@ SBV_HD void keychain29_run(QX& q, const uint8_t* tuples, u32 gidx, const GroupSt
             if (q.role(i) == 0) *valid = ok ? 1 : 0;
             keychain29_start(q.s[i], x, y);
         }
+        // A key pointFromAffine refuses gets NO table (round 5): nothing is recorded, the rows / fill steps and the later chunks of the
+        // chain skip its slot (valid = 0), the Q phase rejects its lanes without reading a row.  Bit-flipped variants of the signers'
+        // keys that repeat in a batch became groups when the threshold dropped to a handful of uses; their 256 doublings and 33 rows
+        // were 0.15 ms of a cold step for verdicts that are "reject" whatever the table holds.  The quad decides as one (same key).
+        if (!ok) return;
     } else {
         SBV_UNROLL
         for (int i = 0; i < QX::N; ++i) kchain_load(q.s[i], st);

@@ -85,8 +85,10 @@ struct Context {
     size_t group_min_batch_k256 = (size_t)1 << 17;   // secp256k1 with its key-table cache off; with it on, group_min_batch
     // Round 5: a key earns a table (its ROWS: a comb with 4-bit windows) from ~16 uses in a batch — soft threshold, sampled — and the
     // fill that makes it a full 8-bit comb from group_full_min uses; up to 65 536 groups per batch (p256_group.h: table classes).
-    // group_min_count = 0: the built-in default — 16 for the P-256 step (tables in classes), 64 for the Ed25519 / secp256k1 steps (always full tables)
+    // group_min_count = 0: the built-in default — 8 uses counted on every 4th tuple for the P-256 step (tables in classes), 64 for the
+    // Ed25519 / secp256k1 steps (always full tables)
     u32 group_min_count = 0, group_max = 65536, group_full_min = 256;
+    int group_sample_shift = SBV_GROUP_SAMPLE_SHIFT_DEFAULT;     // SBV_GROUP_SAMPLE_SHIFT (0..6): the P-256 default threshold's sampling rate
     // persistent key-table caches, one per scheme (SBV_SCHEME_*: P-256, secp256k1, Ed25519; p256_group.h): on / off and
     // cached keys (270 KiB of HBM per ECDSA key, 384 KiB per Ed25519 key)
     bool kc_on[3] = {true, true, true};
@@ -324,7 +326,8 @@ void free_group_buffers(Context& c, bool keep_pools = false) {
 int ensure_group_buffers(Context& c, size_t n) {
     sbv::GroupBuffers& b = c.grp;
     if (b.cap >= n && b.max_groups == c.group_max && b.gacc_cap == c.cap && b.kc.cap == c.kc_caps[0]) {
-        b.min_count = c.group_min_count ? c.group_min_count : 16u;
+        b.min_count = c.group_min_count ? c.group_min_count : SBV_GROUP_MIN_COUNT_DEFAULT;
+        b.sample_shift = c.group_min_count ? -1 : c.group_sample_shift;
         b.full_min = c.group_full_min;
         b.kc.enabled = c.kc_on[0] ? 1u : 0u;
         return SBV_OK;
@@ -379,7 +382,8 @@ int ensure_group_buffers(Context& c, size_t n) {
     b.ht_mask = (u32)(ht - 1);
     b.seed = fresh_hash_seed();            // the per-batch grouping table is empty at the start of every batch: any seed will do, a secret one is the point
     b.max_groups = (u32)G;
-    b.min_count = c.group_min_count ? c.group_min_count : 16u;
+    b.min_count = c.group_min_count ? c.group_min_count : SBV_GROUP_MIN_COUNT_DEFAULT;
+    b.sample_shift = c.group_min_count ? -1 : c.group_sample_shift;
     b.full_min = c.group_full_min;
     b.cap = cap;
     b.gacc_cap = c.cap;
@@ -393,6 +397,7 @@ sbv::GroupBuffers variant_view(const Context& c, size_t n) {
     sbv::GroupBuffers bv = c.grp;
     bv.max_groups = variant_groups(c);
     bv.min_count = c.group_min_count ? c.group_min_count : 64u;
+    bv.sample_shift = -1;
     if (n < ((size_t)1 << 18) && bv.min_count > 32) bv.min_count = 32;     // no stragglers on the one-lane path below 2^18 (enqueue() has the numbers)
     return bv;
 }
@@ -492,7 +497,7 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
         // to 2.2-2.5 ms (profiles/r03/sweep_sizes_r03a.jsonl: 2582 tuples on the one-lane path); 32 uses, counted on every
         // 4th tuple (32 +- 4.9 samples against 8), loses none.  At full size the configured threshold stands: twice the
         // counting atomics in k_group_insert, which is on the path to the G phase.
-        if (n < ((size_t)1 << 18) && c.grp.min_count > 32) c.grp.min_count = 32;
+        if (n < ((size_t)1 << 18) && c.grp.min_count > 32) c.grp.min_count = 32;      // (explicit thresholds only: the default is 8)
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
     }
     if (grouped) {           // stage A is enqueued by the grouped launcher
@@ -669,6 +674,7 @@ int init_context(Context& c, int device) {
     }
     if (const char* e = getenv("SBV_KEYED_WIDE_BITS")) { const int v = atoi(e); if (v == 0) c.kwide_max = 0; else if (v == SBV_WIDE_BITS_AUTO) c.kwide_auto = true; else if (v >= 10 && v <= 20) { c.kwide_bits = v; c.kwide_auto = false; } }
     if (const char* e = getenv("SBV_KEYED_WIDE_MAX")) { const long v = atol(e); if (v >= 0 && v <= 4096) c.kwide_max = (u32)v; }
+    if (const char* e = getenv("SBV_GROUP_SAMPLE_SHIFT")) { const int v = atoi(e); if (v >= 0 && v <= 6) c.group_sample_shift = v; }
     if (const char* e = getenv("SBV_FULL_TABLE_MIN")) { const long v = atol(e); if (v >= 0) c.group_full_min = (u32)v; }
     if (const char* e = getenv("SBV_SMALL")) c.small_enabled = e[0] != '0';
     if (const char* e = getenv("SBV_GROUP")) c.group_enabled = e[0] != '0';
@@ -926,38 +932,28 @@ int grow_slot(Context& c, StageSlot& sl, size_t m) {
 }
 }  // namespace
 
-namespace { int verify_in_pieces(Context& c, const uint8_t* tuples, size_t n, uint8_t* accept_bitmap, sbv_timing* tm); }
-
 extern "C" int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitmap) {
     Context* cp = default_ctx();
     Context& c = *cp;
     if (n == 0) { std::lock_guard<std::mutex> lk(c.mu); if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; } return SBV_OK; }
     if (!tuples || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
     const auto t0 = std::chrono::steady_clock::now();
-    // ONE caller with a large batch (VerifyProposal is one caller: internal/bft/view.go:555): its own upload and its own kernels
-    // overlap — pieces of 2^18 tuples through two upload slots, the copy of piece i + 1 beside the kernels of piece i (verify_shard,
-    // the sharded entry's per-device worker).  Needs the key-table cache: the first piece builds the signers' combs, the later ones
-    // find them; with the cache off every piece would rebuild every table and whole launches win (below).  Measured: one submitting
-    // thread 152 M/s (H2D 3.0 ms, then kernels 3.4 ms) before, profiles/r05 after.
+    // ONE caller with a large batch (VerifyProposal is one caller: internal/bft/view.go:555) used to upload, THEN verify: 152 M/s with
+    // one submitting thread against 280 with two.  With the key-table cache on (the default) its batch is now cut into pieces of 2^18
+    // tuples that take the two staging slots in turn — the upload of piece i + 1 runs beside the kernels of piece i, the first piece
+    // builds the signers' combs, the later ones find them — through the same slot protocol concurrent callers share, so two callers
+    // still interleave.  With the cache off every piece would rebuild every table: whole launches, as before.
+    size_t piece = kMaxChunk;
     {
-        std::unique_lock<std::mutex> lk(c.mu);
-        if (c.ready && n >= ((size_t)1 << 19) && c.kc_on[0] && c.group_enabled && !c.stage[0].used && !c.stage[1].used) {
-            sbv_timing tm{};
-            tm.n = n;
-            const int rc = verify_in_pieces(c, tuples, n, accept_bitmap, &tm);
-            if (rc == SBV_OK) {
-                tm.total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-                c.timing = tm;
-            }
-            return rc;
-        }
+        std::lock_guard<std::mutex> lk(c.mu);
+        if (c.ready && n >= ((size_t)1 << 19) && c.kc_on[0] && c.group_enabled) piece = (size_t)1 << 18;
     }
     sbv_timing tm{};
     tm.n = n;
     std::vector<Outstanding> out;           // at most two
     int rc = SBV_OK;
-    for (size_t off = 0; off < n && rc == SBV_OK; off += kMaxChunk) {
-        const size_t m = n - off < kMaxChunk ? n - off : kMaxChunk;
+    for (size_t off = 0; off < n && rc == SBV_OK; off += piece) {          // piece is a multiple of 8: whole bitmap bytes
+        const size_t m = n - off < piece ? n - off : piece;
         std::unique_lock<std::mutex> lk(c.mu);
         if (!c.ready) { g_err = "sbv_init has not succeeded"; rc = SBV_ENOTINIT; break; }
         // a slot: never wait for one while holding one (two multi-chunk callers would deadlock) — collect first

@@ -298,18 +298,18 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
         for (u32 k = 0; k < ngroups; ++k)
-            if (cold[k]) {               // k_keytab29_chain: the four lanes of the key's quad in lockstep
+            if (cold[k] && (j_first == 0 || *valid_of(k))) {               // k_keytab29_chain: the four lanes of the key's quad in lockstep (an invalid key stops after its check)
                 keychain_quad_host q;
                 keychain29_run(q, tuples, k, g, jstate.data(), bases, valid_of(k), j_first, j_end - 1, 0x11u);
             }
         for (u32 k = 0; k < ngroups; ++k)
-            for (int j = j_first; j < j_end && cold[k]; ++j) {        // k_keytab29_rows: every cold group
+            for (int j = j_first; j < j_end && cold[k] && *valid_of(k); ++j) {        // k_keytab29_rows: every cold group whose key is a point
                 const size_t w = (size_t)k * SBV_GTAB_WINDOWS + j;
                 apt* row = table_of(k) + (size_t)j * SBV_GTAB_PER_WINDOW;
                 emul_window_rows(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
             }
         for (u32 k = 0; k < ngroups; ++k)
-            for (int j = j_first; j < j_end && needfill[k]; ++j)      // k_keytab29_fill_sym: the groups that earn a full table (cold, or a cached narrow one: upgrade)
+            for (int j = j_first; j < j_end && needfill[k] && *valid_of(k); ++j)      // k_keytab29_fill_sym: the groups that earn a full table (cold, or a cached narrow one: upgrade)
                 emul_window_fill(j == SBV_GTAB_WINDOWS - 1, tmpa.data(), table_of(k) + (size_t)j * SBV_GTAB_PER_WINDOW);
         const bool last = c + 1 == chunks;
         if (g_group_coop && g.sorted) {
@@ -346,6 +346,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             if (!wave_full[L / 64]) continue;
             const u32 t = grp_idx[L];
             const u32 grp = g.sorted ? grp_of[L] : slots[t];
+            if (grp < ngroups && !*valid_of(grp)) continue;           // a key that is no point has no table: rejected (the device computes on whatever the slot holds and drops the result)
             bool v;
             if (g.sorted) v = grp < ngroups ? qphase29_lane_sorted(s, t, L, 0, 1, table_of(grp), valid_of(grp), gacc.data(), j_first, j_end, last)
                                             : qphase29_lane_sorted(s, t, L, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc.data(), j_first, j_end, last);
@@ -370,6 +371,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             ++g_last_classes[2];
             const u32 t = grp_idx[L];
             const u32 grp = g.sorted ? grp_of[L] : slots[t];
+            if (grp < ngroups && !*valid_of(grp)) continue;
             bool v;
             if (g.sorted) v = grp < ngroups ? qphase29_lane_sorted<true>(s, t, L, 0, 1, table_of(grp), valid_of(grp), gacc.data(), 0, SBV_GTAB_WINDOWS, true)
                                             : qphase29_lane_sorted<true>(s, t, L, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc.data(), 0, SBV_GTAB_WINDOWS, true);
@@ -455,7 +457,9 @@ int sbve_keytab_build(const uint8_t* key64, int chunks, u32* table) {
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
         keychain_quad_host q;
+        if (c > 0 && !valid) break;          // as the kernels: a key pointFromAffine refuses gets no table (the chain stops after its check, rows / fill skip the slot)
         keychain29_run(q, tup.data(), 0, g, jstate.data(), bases.data(), &valid, j_first, j_end - 1, 0x11u);
+        if (!valid) break;
         for (int j = j_first; j < j_end; ++j) {
             apt* row = ktab + (size_t)j * SBV_GTAB_PER_WINDOW;
             emul_window_rows_fill(bases.data() + (size_t)j * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
