@@ -89,10 +89,11 @@ SBV_HD void group_set_sampling(GroupState& g, u32 min_count, u32 shift) {
     g.min_samples = ms ? ms : 1u;
 }
 SBV_HD void group_set_threshold(GroupState& g, u32 min_count) { group_set_sampling(g, min_count, min_count >= 16 ? 3u : 0u); }
-// The P-256 step's built-in default (round 5, sbv_api.hip): 8 uses counted on every 4th tuple = 2 samples.  A 16-use key passes with
-// probability 0.94, an 8-use key 0.63, a 4-use key 0.26 (its rows cost what its four generic verifications would: no loss), a key
-// used once never.  Measured against every-8th / 16 uses on the 2^20 sweep (profiles/r05): the 65 536-key point.
-#define SBV_GROUP_MIN_COUNT_DEFAULT 8u
+// The P-256 step's built-in default (round 5, sbv_api.hip): 12 uses counted on every 4th tuple = 3 samples.  A 32-use key passes with
+// probability 0.99, a 16-use key 0.80, an 8-use key 0.32, a 4-use key 0.05, a key used once never.  With 2 samples (8 uses) a quarter
+// of the 4-use keys of a 2^20 batch over 262 144 keys took tables that do not pay at 4 signatures: 46 M/s against the one-lane
+// kernel's 60 (profiles/r05/key_sweep_r05e).
+#define SBV_GROUP_MIN_COUNT_DEFAULT 12u
 #define SBV_GROUP_SAMPLE_SHIFT_DEFAULT 2
 
 // Which tuples are counted: a multiplicative hash of the index, NOT its low bits — batches are often laid

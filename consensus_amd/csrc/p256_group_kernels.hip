@@ -269,14 +269,17 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
         const u32 t = g.grp_idx[L];
         const u32 grp = g.grp_of[L];
         const bool known = grp < group_count(g);
-        if (wave_all(known && full[known ? grp : 0u] != 0) == NARROW) return;      // the other instantiation's wavefront
+        const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
+        const bool dead = !(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0;     // no slot, or a key that is no point: "reject" whatever is added
+        // a dead lane never drags its wavefront to the two-addition path: its verdict needs no table at all (the bit-flipped variants of the
+        // signers' keys sit in runs of a handful of lanes between the signers' own runs)
+        if (wave_all(dead || (known && full[known ? grp : 0u] != 0)) == NARROW) return;      // the other instantiation's wavefront
         if (NARROW) {                                                              // statistics only: lanes served by the narrow pass
             const unsigned long long am = __ballot(true);
             if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)am) - 1u) atomicAdd(&g.counters[7], (u32)__popcll(am));
         }
-        const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
         // a wavefront whose keys are all refused by pointFromAffine (or have no slot): rejected without touching a table (there is none)
-        if (wave_all(!(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0)) { if (last) acc[t] = 0; return; }
+        if (wave_all(dead)) { if (last) acc[t] = 0; return; }
         const bool v = qphase29_lane_sorted<NARROW>(s, t, L, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
         if (last) acc[t] = v ? 1 : 0;
         return;
@@ -286,9 +289,10 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
     const u32 t = g.grp_idx[L];
     const u32 grp = g.slots[t];                                        // group of this tuple -> its table slot (cache or per-batch area)
     const bool known = grp < group_count(g);
-    if (wave_all(known && full[known ? grp : 0u] != 0) == NARROW) return;
     const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
-    if (wave_all(!(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0)) { if (last) acc[t] = 0; return; }
+    const bool dead = !(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0;
+    if (wave_all(dead || (known && full[known ? grp : 0u] != 0)) == NARROW) return;
+    if (wave_all(dead)) { if (last) acc[t] = 0; return; }
     const bool v = qphase29_lane<NARROW>(s, t, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
     if (last) acc[t] = v ? 1 : 0;
 }

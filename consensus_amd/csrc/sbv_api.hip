@@ -2928,8 +2928,9 @@ extern "C" int sbv_p256_verify_msgs_keyed_sharded(const uint8_t* msgs, const uin
     if (n == 0) return SBV_OK;
     if (!msg_offsets || !sig_offsets || !slots || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
     if (quorum_bitmap && (group == 0 || quorum == 0 || quorum > group || group > 64)) { g_err = "quorum bits need 0 < quorum <= group <= 64"; return SBV_EINVAL; }
-    // the devices dereference the offset tables: they must start at 0 and never decrease
-    if (msg_offsets[0] != 0 || sig_offsets[0] != 0) { g_err = "offset tables must start at 0"; return SBV_EINVAL; }
+    // the devices dereference the offset tables: they must never decrease.  They need NOT start at 0 here: msgs / sigs are the bases the
+    // offsets refer to, so a caller that laid a large batch out once can hand over slices of its tables (the host Verifier ships a
+    // decision-replay batch in a few slices while its workers still lay out the next one).
     {
         std::atomic<int> bad(0);
         const size_t nt = n > ((size_t)1 << 16) ? 8 : 1;             // 2 x 550 000 comparisons: a few threads

@@ -73,8 +73,8 @@ int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitma
  * take the no-doubling kernels; everything else takes the generic kernel inside the same step.  Verdicts are identical.
  * `min_batch` = batches from this size on take the grouped step.  Defaults: enabled; min_batch 64 while the key-table cache is
  * on (a warm batch of a few thousand tuples skips the 256 doublings per signature), 2^17 while it is off (nothing outlives the
- * call then, and below ~2^17 building tables costs more latency than the doubling kernel takes); min_count 8 for P-256 (a soft,
- * sampled threshold: 2 of a key's every-4th tuples; the Ed25519 / secp256k1 steps, whose tables are always full, keep 64 and at most
+ * call then, and below ~2^17 building tables costs more latency than the doubling kernel takes); min_count 12 for P-256 (a soft,
+ * sampled threshold: 3 of a key's every-4th tuples; the Ed25519 / secp256k1 steps, whose tables are always full, keep 64 and at most
  * 2048 groups); max_groups 65536 (round 5; 2048 before — a 2^20 batch over 4096 keys sent half its tuples to the one-lane kernel).
  * Passing a non-zero min_batch sets both thresholds (and the variant schemes'); SBV_GROUP_MIN_BATCH_DEFAULT restores the built-in
  * ones together with the built-in min_count and max_groups (a non-zero min_count / max_groups in the same call still applies);
@@ -320,7 +320,8 @@ int sbv_p256_verify_batch_keyed_sharded(const uint8_t* rsh, const uint32_t* slot
 /* ... and its raw-messages form: sbv_p256_verify_msgs_keyed's inputs (messages and DER signatures packed back to back, their offset
  * tables, key slots) through the same plan — SHA-256 and the strict DER parse run on every device over its share, piece by piece
  * beside the uploads, so a replaying replica's host pass only lays bytes out (decision replay: internal/bft/controller.go:587-633;
- * the signatures of a decision: pkg/types/types.go:31-34).  No 2^21 limit: pieces are launches.  Equivalent to
+ * the signatures of a decision: pkg/types/types.go:31-34).  No 2^21 limit: pieces are launches.  The offset tables need not start
+ * at 0 (msgs / sigs are the bases they refer to: a slice of a larger batch's tables is a valid argument).  Equivalent to
  * crypto/ecdsa.VerifyASN1(key[slots[i]], sha256(msg i), sig i) for every i; quorum bits as above. */
 int sbv_p256_verify_msgs_keyed_sharded(const uint8_t* msgs, const uint64_t* msg_offsets, const uint8_t* sigs, const uint64_t* sig_offsets,
                                        const uint32_t* slots, size_t n, size_t group, uint32_t quorum, uint8_t* accept_bitmap,

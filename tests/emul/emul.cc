@@ -291,7 +291,8 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     std::vector<uint8_t> wave_full((counters[1] + 63) / 64 + 1, 1);
     for (u32 L = 0; L < counters[1]; ++L) {
         const u32 grp = g.sorted ? grp_of[L] : slots[grp_idx[L]];
-        if (!(grp < ngroups && full[grp])) wave_full[L / 64] = 0;
+        const bool dead = !(grp < ngroups) || !*valid_of(grp);        // no slot, or a key that is no point: never drags its wavefront to the narrow pass
+        if (!dead && !full[grp]) wave_full[L / 64] = 0;
     }
     memset(bitmap, 0, (n + 7) / 8);
     const int chunks = g_group_chunks;
