@@ -289,11 +289,13 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     for (u32 k = 0; k < ngroups; ++k) { g_last_classes[0] += full[k]; g_last_classes[1] += needfill[k]; }
     // which lanes of the grouped list the chunk launches serve (wavefronts of 64 whose lanes ALL hold full tables) and which the narrow pass
     std::vector<uint8_t> wave_full((counters[1] + 63) / 64 + 1, 1);
-    for (u32 L = 0; L < counters[1]; ++L) {
-        const u32 grp = g.sorted ? grp_of[L] : slots[grp_idx[L]];
-        const bool dead = !(grp < ngroups) || !*valid_of(grp);        // no slot, or a key that is no point: never drags its wavefront to the narrow pass
-        if (!dead && !full[grp]) wave_full[L / 64] = 0;
-    }
+    auto decide_waves = [&] {            // the kernels decide at Q time: the first chunk of the chain has judged every cold key by then
+        for (u32 L = 0; L < counters[1]; ++L) {
+            const u32 grp = g.sorted ? grp_of[L] : slots[grp_idx[L]];
+            const bool dead = !(grp < ngroups) || !*valid_of(grp);        // no slot, or a key that is no point: never drags its wavefront to the narrow pass
+            if (!dead && !full[grp]) wave_full[L / 64] = 0;
+        }
+    };
     memset(bitmap, 0, (n + 7) / 8);
     const int chunks = g_group_chunks;
     for (int c = 0; c < chunks; ++c) {
@@ -313,6 +315,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             for (int j = j_first; j < j_end && needfill[k] && *valid_of(k); ++j)      // k_keytab29_fill_sym: the groups that earn a full table (cold, or a cached narrow one: upgrade)
                 emul_window_fill(j == SBV_GTAB_WINDOWS - 1, tmpa.data(), table_of(k) + (size_t)j * SBV_GTAB_PER_WINDOW);
         const bool last = c + 1 == chunks;
+        if (c == 0) decide_waves();
         if (g_group_coop && g.sorted) {
             if (!last) continue;
             // k_group_coop: SBV_COOP_LANES partial sums per grouped tuple (comb of G + the key's table), xor-butterfly of exact
