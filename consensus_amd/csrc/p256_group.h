@@ -93,7 +93,7 @@ SBV_HD void group_set_threshold(GroupState& g, u32 min_count) { group_set_sampli
 // probability 0.99, a 16-use key 0.80, an 8-use key 0.32, a 4-use key 0.05, a key used once never.  With 2 samples (8 uses) a quarter
 // of the 4-use keys of a 2^20 batch over 262 144 keys took tables that do not pay at 4 signatures: 46 M/s against the one-lane
 // kernel's 60 (profiles/r05/key_sweep_r05e).
-#define SBV_GROUP_MIN_COUNT_DEFAULT 12u
+#define SBV_GROUP_MIN_COUNT_DEFAULT 8u
 #define SBV_GROUP_SAMPLE_SHIFT_DEFAULT 2
 
 // Which tuples are counted: a multiplicative hash of the index, NOT its low bits — batches are often laid
@@ -111,17 +111,32 @@ SBV_HD const u32* tuple_key_words(const uint8_t* tuples, size_t i) {
     return reinterpret_cast<const u32*>(tuples + i * 160 + 96);       // 16-byte aligned: 160 i + 96
 }
 
-// pointFromAffine's verdict on tuple idx's public key (coordinates < p, on the curve); x, y = the key in
-// Montgomery form (garbage when the verdict is false)
-SBV_HD bool tuple_key_load(const uint8_t* tuples, size_t idx, fe& x, fe& y) {
+// pointFromAffine's verdict on tuple idx's key, on the carry-free field: coordinates < p, y^2 = x^3 - 3x + b.
+// x, y: the key in the R = 2^261 domain, tight (garbage when the verdict is false).
+SBV_HD bool key29_load(const uint8_t* tuples, size_t idx, fe29& x, fe29& y) {
     const u32* k = tuple_key_words(tuples, idx);
     u256 qx, qy;
     SBV_UNROLL
     for (int l = 0; l < 8; ++l) { qx.v[l] = bswap32(k[7 - l]); qy.v[l] = bswap32(k[8 + 7 - l]); }
     const fe p_ = fe_p();
-    fe_to_mont(x, qx);
-    fe_to_mont(y, qy);
-    return lt256(qx, p_) && lt256(qy, p_) && pt_on_curve(x, y);
+    f29_from_plain(x, qx);
+    f29_from_plain(y, qy);
+    fe29 lhs, t, rhs;
+    f29_sqr(lhs, y);
+    f29_sqr(t, x);
+    f29_mul(rhs, t, x);
+    f29_sub(rhs, rhs, x);
+    f29_sub(rhs, rhs, x);
+    f29_sub(rhs, rhs, x);
+    f29_add(rhs, rhs, f29_b());
+    f29_sub(t, lhs, rhs);
+    return lt256(qx, p_) && lt256(qy, p_) && f29_is_zero(t);
+}
+// the verdict alone (the grouping kernels' key check; round 5: on the carry-free field like everything else in the product — the
+// 8 x 32 Montgomery form of round 1 left the product headers)
+SBV_HD bool tuple_key_ok(const uint8_t* tuples, size_t idx) {
+    fe29 x, y;
+    return key29_load(tuples, idx, x, y);
 }
 
 // Key location of a tuple format: STRIDE bytes per tuple, key = WORDS dwords at byte OFF (16-byte aligned).
@@ -169,8 +184,7 @@ SBV_HD bool group_split_lane(const uint8_t* tuples, size_t i, const GroupState& 
     const u32 s = g.slot_of[g.rep[i]];
     if (s == SBV_GROUP_NONE) {
         g.slots[i] = SBV_GROUP_NONE;
-        fe x, y;
-        if (!tuple_key_load(tuples, i, x, y)) {
+        if (!tuple_key_ok(tuples, i)) {
             acc[i] = 0;
             SBV_ATOMIC_ADD(&g.counters[3], 1u);
             return false;
@@ -194,8 +208,7 @@ SBV_HD void group_classify_lane(size_t i, const GroupState& g) {
 }
 SBV_HD bool group_keycheck_lane(const uint8_t* tuples, size_t L, const GroupState& g, uint8_t* acc) {
     const u32 i = g.ung_cand[L];
-    fe x, y;
-    if (!tuple_key_load(tuples, i, x, y)) {
+    if (!tuple_key_ok(tuples, i)) {
         acc[i] = 0;
         SBV_ATOMIC_ADD(&g.counters[3], 1u);
         return false;
@@ -396,27 +409,6 @@ SBV_HD void group_table_mark_lane(u32 k, const u32* tslot, const uint8_t* cold, 
 // valid[g] = pointFromAffine verdict.  One call produces bases j_first..j_last; a call with j_first > 0
 // continues the doubling chain from base j_first - 1 left by the previous chunk.
 #define SBV_JBASE_DWORDS 40
-SBV_HD void keytab_bases_lane(const uint8_t* tuples, u32 gidx, const GroupState& g, u32* jbases, uint8_t* valid,
-                              int j_first, int j_last) {
-    u32* out = jbases + (size_t)gidx * (SBV_GTAB_WINDOWS * SBV_JBASE_DWORDS);
-    jpt t;
-    if (j_first == 0) {
-        const bool ok = tuple_key_load(tuples, g.group_rep[gidx], t.X, t.Y);
-        t.Z = fe_one();
-        valid[gidx] = ok ? 1 : 0;        // an invalid key still gets a (garbage) table; it is never used
-    } else {
-        const u32* prev = out + (size_t)(j_first - 1) * SBV_JBASE_DWORDS;
-        fe_load16(t.X, prev); fe_load16(t.Y, prev + 8); fe_load16(t.Z, prev + 16);
-    }
-    SBV_NOUNROLL
-    for (int j = j_first; j <= j_last; ++j) {
-        if (j > 0) {
-            SBV_NOUNROLL
-            for (int d = 0; d < 8; ++d) pt_dbl(t, t);
-        }
-        qent_store(out + (size_t)j * SBV_JBASE_DWORDS, t);
-    }
-}
 
 // One part of one (key, window): row[k-1] = k * base for k = part*E + 1 .. part*E + E, affine.
 // Several lanes per window instead of one: the lane first reaches (part*E) * base with 7 doubling /
@@ -425,48 +417,5 @@ SBV_HD void keytab_bases_lane(const uint8_t* tuples, u32 gidx, const GroupState&
 // Every addition is exact (the second entry of part 0 is base + base: the doubling branch).
 #define SBV_KEYTAB_PARTS_DEFAULT 4
 #define SBV_KEYTAB_TMP_DWORDS_PER_WINDOW (SBV_GTAB_PER_WINDOW * 32)
-SBV_HD void keytab_window_lane(const u32* jbase, int part, int parts, u32* tmp, apt* row) {
-    const int E = SBV_GTAB_PER_WINDOW / parts;     // parts is a power of two <= 16
-    u32* pts = tmp;                   // E * 24 dwords
-    u32* pre = tmp + E * 24;          // E * 8 dwords
-    qent base;
-    qent_load(base, jbase);
-    jpt t;
-    pt_set_inf(t);
-    const int m = part * E;           // start multiple
-    SBV_NOUNROLL
-    for (int bit = 6; bit >= 0; --bit) {
-        pt_dbl(t, t);                                        // infinity stays infinity
-        pt_add_qent(t, base, false, ((m >> bit) & 1) == 0);  // exact: handles t = infinity
-    }
-    fe acc = fe_one();
-    SBV_NOUNROLL
-    for (int k = 0; k < E; ++k) {
-        pt_add_qent(t, base, false, false);                  // (m + k + 1) * base
-        fe_store16(pts + k * 24, t.X); fe_store16(pts + k * 24 + 8, t.Y); fe_store16(pts + k * 24 + 16, t.Z);
-        fe_store16(pre + k * 8, acc);
-        fe_mul(acc, acc, t.Z);
-    }
-    fe inv;
-    fe_inv_gcd(inv, acc);             // garbage in, garbage out for an invalid key (never used: valid = 0)
-    SBV_NOUNROLL
-    for (int k = E - 1; k >= 0; --k) {
-        fe X, Y, Z, pk, zi, zi2, zi3;
-        fe_load16(X, pts + k * 24); fe_load16(Y, pts + k * 24 + 8); fe_load16(Z, pts + k * 24 + 16);
-        fe_load16(pk, pre + k * 8);
-        fe_mul(zi, inv, pk);
-        fe_mul(inv, inv, Z);
-        fe_sqr(zi2, zi);
-        fe_mul(zi3, zi2, zi);
-        apt a;
-        fe_mul(a.x, X, zi2);
-        fe_mul(a.y, Y, zi3);
-        // the Q phase runs on the carry-free field (p256_comb29.h): its tables hold x * 2^261, this kernel computes x * 2^256
-        fe_mul32(a.x, a.x);
-        fe_mul32(a.y, a.y);
-        fe_store16(reinterpret_cast<u32*>(row + m + k), a.x);
-        fe_store16(reinterpret_cast<u32*>(row + m + k) + 8, a.y);
-    }
-}
 
 }  // namespace sbv

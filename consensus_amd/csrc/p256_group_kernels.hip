@@ -50,8 +50,7 @@ __global__ __launch_bounds__(256) void k_group_split(const uint8_t* __restrict__
     const bool grp = active && s != SBV_GROUP_NONE;
     bool key_rejected = false;
     if (ung) {                      // key filter of group_split_lane
-        fe x, y;
-        if (!tuple_key_load(tuples, i, x, y)) { acc[i] = 0; ung = false; key_rejected = true; }
+        if (!tuple_key_ok(tuples, i)) { acc[i] = 0; ung = false; key_rejected = true; }
     }
     group_split_emit(i, s, ung, grp, key_rejected, g);
 }
@@ -66,8 +65,7 @@ __global__ __launch_bounds__(256) void k_group_keycheck(const uint8_t* __restric
     bool ok = false;
     if (active) {
         i = g.ung_cand[L];
-        fe x, y;
-        ok = tuple_key_load(tuples, i, x, y);
+        ok = tuple_key_ok(tuples, i);
         if (!ok) acc[i] = 0;
     }
     const unsigned long long mr = __ballot(active && !ok);

@@ -157,27 +157,6 @@ SBV_HD void keychain29_dbl(QX& q) {
     for (int i = 0; i < QX::N; ++i) keychain29_finish(q.s[i], X3[i], Z3[i], XX[i], YY[i]);
 }
 
-// pointFromAffine's verdict on tuple idx's key, on the carry-free field: coordinates < p, y^2 = x^3 - 3x + b.
-// x, y: the key in the R = 2^261 domain, tight (garbage when the verdict is false).
-SBV_HD bool key29_load(const uint8_t* tuples, size_t idx, fe29& x, fe29& y) {
-    const u32* k = tuple_key_words(tuples, idx);
-    u256 qx, qy;
-    SBV_UNROLL
-    for (int l = 0; l < 8; ++l) { qx.v[l] = bswap32(k[7 - l]); qy.v[l] = bswap32(k[8 + 7 - l]); }
-    const fe p_ = fe_p();
-    f29_from_plain(x, qx);
-    f29_from_plain(y, qy);
-    fe29 lhs, t, rhs;
-    f29_sqr(lhs, y);
-    f29_sqr(t, x);
-    f29_mul(rhs, t, x);
-    f29_sub(rhs, rhs, x);
-    f29_sub(rhs, rhs, x);
-    f29_sub(rhs, rhs, x);
-    f29_add(rhs, rhs, f29_b());
-    f29_sub(t, lhs, rhs);
-    return lt256(qx, p_) && lt256(qy, p_) && f29_is_zero(t);
-}
 // the chain's first point: (x : y : 1 : -3)
 SBV_HD void keychain29_start(kchain& s, const fe29& x, const fe29& y) {
     fe29 t;

@@ -976,7 +976,8 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
             // A large batch goes to the backend in a few SLICES (whole layout chunks), each shipped by a helper thread while the workers
             // lay out the next one: host pass and device work overlap instead of adding up (profiles/r05: 1.6 + 2.6 ms for 550 000
             // signatures back to back).  The offsets are global — the backend takes a slice of the tables with the buffers' bases.
-            const size_t slices = n >= ((size_t)1 << 18) && jobs >= 8 ? 4 : 1;
+            static const size_t slices_cfg = [] { const char* e = getenv("SBVH_REPLAY_SLICES"); const long v = e ? atol(e) : 0; return v >= 1 && v <= 16 ? (size_t)v : (size_t)4; }();
+            const size_t slices = n >= ((size_t)1 << 18) && jobs >= 2 * slices_cfg ? slices_cfg : 1;
             if (slices == 1) {
                 pool.run(jobs, layout);
                 if (trace) fprintf(stderr, "[sbvh trace] replay layout: setup %.0f us, sizes %.0f us, staging %.0f us, copy + binding %.0f us (%zu chunks)\n", t_a - t_start, t_b - t_a, t_c - t_b, now() - t_c, jobs);
@@ -998,7 +999,9 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
                         }
                         const size_t a = first_of(sl), b = first_of(sl + 1);
                         if (b <= a || src != 0) continue;
+                        const double ts0 = trace ? now() : 0;
                         const int r = co_.submit_many_msgs_keyed(mbuf, moff + a, sbuf, soff + a, dslots + a, b - a, bitmap.data() + a / 8);
+                        if (trace) fprintf(stderr, "[sbvh trace]   slice %zu: %zu signatures, shipped %.0f us after the call started, backend %.0f us\n", sl, b - a, ts0 - t_start, now() - ts0);
                         if (r != 0) { src = r; serr = sbv_last_error(); }       // the library's error text is per thread: keep this thread's
                     }
                 });

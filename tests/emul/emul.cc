@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../consensus_amd/csrc/p256_core.h"
+#include "p256_legacy_m32.h"
 #include "../../consensus_amd/csrc/ed25519_core.h"
 #include "../../consensus_amd/csrc/ed25519_group.h"
 #include "../../consensus_amd/csrc/sha512_dev.h"

@@ -13,6 +13,7 @@
 
 #include "../consensus_amd/csrc/ed25519_kernels.h"
 #include "../consensus_amd/csrc/p256_kernels.h"
+#include "../tests/emul/p256_legacy_m32.h"
 
 using namespace sbv;
 
