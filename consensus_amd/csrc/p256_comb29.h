@@ -220,14 +220,16 @@ SBV_HD void qphase29_point(xyzz& R, const u256& u2in, const apt* qtab, int j0, i
 // takes this path for all its lanes.  Break-even against the one-lane doubling kernel: ~4 signatures per key (a table without its
 // fill costs ~3 generic verifications, a narrow verification 72 additions instead of 256 doublings + 64 additions); against the
 // full table: ~250 signatures per key (the fill's ~14 M instructions buy 26 fewer additions per signature).
+// The pass reads a key's COMPACT rows (p256_keytab29.h: 16 entries per window — babies at 0..7, giant 16 a at 7 + a): gi / bi index them.
 SBV_HD void narrow_split(int idx, bool skip, int& gi, int& bi, bool& bneg) {
     const int ad = skip ? 0 : idx + 1;
     const int a = (ad + 7) >> 4;
     const int b = ad - 16 * a;
-    gi = a ? 16 * a - 1 : -1;
+    gi = a ? 7 + a : -1;
     bi = b ? (b < 0 ? -b : b) - 1 : -1;
     bneg = b < 0;
 }
+#define SBV_NARROW_PER_WINDOW 16
 SBV_HD void qphase29_point_narrow(xyzz& R, const u256& u2in, const apt* qtab, int j0, int j1) {
     const bool flip = (u2in.v[7] >> 31) != 0;
     u256 u2, nmu;
@@ -241,8 +243,8 @@ SBV_HD void qphase29_point_narrow(xyzz& R, const u256& u2in, const apt* qtab, in
     comb_digit(k2, top2, j0, idx, neg, skip);
     narrow_split(idx, skip, gi, bi, bneg);
     raw_apt cg, cb;                                   // the current window's giant and baby (entry 0 stands in for an absent part: never added)
-    raw_apt_load(cg, qtab + (size_t)j0 * SBV_GTAB_PER_WINDOW + (gi < 0 ? 0 : gi));
-    raw_apt_load(cb, qtab + (size_t)j0 * SBV_GTAB_PER_WINDOW + (bi < 0 ? 0 : bi));
+    raw_apt_load(cg, qtab + (size_t)j0 * SBV_NARROW_PER_WINDOW + (gi < 0 ? 0 : gi));
+    raw_apt_load(cb, qtab + (size_t)j0 * SBV_NARROW_PER_WINDOW + (bi < 0 ? 0 : bi));
     SBV_NOUNROLL
     for (int j = j0; j < j1; ++j) {
         const int jn = j + 1 < j1 ? j + 1 : j1 - 1;
@@ -250,14 +252,14 @@ SBV_HD void qphase29_point_narrow(xyzz& R, const u256& u2in, const apt* qtab, in
         comb_digit(k2, top2, jn, idxn, negn, skipn);
         narrow_split(idxn, skipn, gin, bin, bnegn);
         raw_apt ng;                                   // the next giant is fetched one addition ahead, the next baby after the giant's addition
-        raw_apt_load(ng, qtab + (size_t)jn * SBV_GTAB_PER_WINDOW + (gin < 0 ? 0 : gin));
+        raw_apt_load(ng, qtab + (size_t)jn * SBV_NARROW_PER_WINDOW + (gin < 0 ? 0 : gin));
         if (gi >= 0) {
             apt29 q;
             raw_apt_unpack(q, cg);
             pt29_madd(R, q, neg != flip);
         }
         raw_apt nb;
-        raw_apt_load(nb, qtab + (size_t)jn * SBV_GTAB_PER_WINDOW + (bin < 0 ? 0 : bin));
+        raw_apt_load(nb, qtab + (size_t)jn * SBV_NARROW_PER_WINDOW + (bin < 0 ? 0 : bin));
         if (bi >= 0) {
             apt29 q;
             raw_apt_unpack(q, cb);
@@ -269,6 +271,7 @@ SBV_HD void qphase29_point_narrow(xyzz& R, const u256& u2in, const apt* qtab, in
 
 // Q phase of the grouped step.  `last` -> the verdict is returned; otherwise R goes back to gacc for the next chunk
 // of windows and the return value is meaningless.
+// NARROW: ktab = the pool of COMPACT rows (SBV_GTAB_WINDOWS x SBV_NARROW_PER_WINDOW entries per slot) instead of the pool of full tables
 template <bool NARROW = false>
 SBV_HD bool qphase29_lane(const Scratch& s, size_t i, u32 slot, u32 nkeys, const apt* ktab, const uint8_t* kvalid,
                           u32* gacc, int j0, int j1, bool last) {
@@ -277,7 +280,7 @@ SBV_HD bool qphase29_lane(const Scratch& s, size_t i, u32 slot, u32 nkeys, const
     bool ok = s.ok[i] != 0 && slot < nkeys;
     if (slot >= nkeys) slot = 0;
     ok = ok && kvalid[slot] != 0;
-    const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
+    const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * (NARROW ? SBV_NARROW_PER_WINDOW : SBV_GTAB_PER_WINDOW));
     xyzz R;
     gacc29_load(R, gacc, s.cap, i);
     if (NARROW) qphase29_point_narrow(R, u2, qtab, j0, j1);
@@ -296,7 +299,7 @@ SBV_HD bool qphase29_lane_sorted(const Scratch& s, size_t t, size_t L, u32 slot,
     bool ok = slot < nkeys;
     if (slot >= nkeys) slot = 0;
     ok = ok && kvalid[slot] != 0;
-    const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
+    const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * (NARROW ? SBV_NARROW_PER_WINDOW : SBV_GTAB_PER_WINDOW));
     xyzz R;
     gacc29_load(R, gacc, s.cap, L);
     if (NARROW) qphase29_point_narrow(R, u2, qtab, j0, j1);

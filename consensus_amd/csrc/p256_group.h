@@ -89,12 +89,13 @@ SBV_HD void group_set_sampling(GroupState& g, u32 min_count, u32 shift) {
     g.min_samples = ms ? ms : 1u;
 }
 SBV_HD void group_set_threshold(GroupState& g, u32 min_count) { group_set_sampling(g, min_count, min_count >= 16 ? 3u : 0u); }
-// The P-256 step's built-in default (round 5, sbv_api.hip): 12 uses counted on every 4th tuple = 3 samples.  A 32-use key passes with
-// probability 0.99, a 16-use key 0.80, an 8-use key 0.32, a 4-use key 0.05, a key used once never.  With 2 samples (8 uses) a quarter
-// of the 4-use keys of a 2^20 batch over 262 144 keys took tables that do not pay at 4 signatures: 46 M/s against the one-lane
-// kernel's 60 (profiles/r05/key_sweep_r05e).
+// The P-256 step's built-in default (round 5, sbv_api.hip): 8 uses, counted EXACTLY (every tuple).  Measured on the 2^20 sweep
+// (profiles/r05/key_sweep_shift*_r05g.txt, one box, one session): exact / every 2nd / every 4th tuple — headline 325.0 / 324.6 / 320.8 M/s
+// (the counting atomics spread over >= 1024 words and cost nothing measurable; the sampled thresholds instead admit repeated
+// bit-flipped variants of the signers' keys as groups: 1024 / 1072 / 2170 groups), 65 536 keys x 16 uses 79.5 / 80.4 / 80.0 M/s,
+// 262 144 keys x 4 uses 60.8 / 55.5 / 46.1 M/s (a 4-use key's rows do not pay; a soft threshold lets a quarter of them through).
 #define SBV_GROUP_MIN_COUNT_DEFAULT 8u
-#define SBV_GROUP_SAMPLE_SHIFT_DEFAULT 2
+#define SBV_GROUP_SAMPLE_SHIFT_DEFAULT 0
 
 // Which tuples are counted: a multiplicative hash of the index, NOT its low bits — batches are often laid
 // out round-robin over the signers (tuple i signed by key i mod K), and `i & mask` would then count only

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64) void k_keytab29_chain(const uint8_t* __restrict
 #define SBV_ROWS_WAVES 2
 #endif
 __global__ __launch_bounds__(64, SBV_ROWS_WAVES) void k_keytab29_rows(GroupState g, const u32* __restrict__ bases, u32* __restrict__ tmp,
-                                                      apt* __restrict__ ktab, const u32* __restrict__ tslot,
+                                                      apt* __restrict__ ktab, apt* __restrict__ ntab, const u32* __restrict__ tslot,
                                                       const uint8_t* __restrict__ cold, const uint8_t* __restrict__ kvalid, int j_first, int j_count) {
     const u32 total = group_count(g) * (u32)j_count * 2u;               // <= 65 536 x 33 x 2: fits 32 bits
     for (u32 base = blockIdx.x * 64; base < total; base += gridDim.x * 64) {        // the loop state is wave-uniform: it lives in scalar registers
@@ -150,7 +150,8 @@ __global__ __launch_bounds__(64, SBV_ROWS_WAVES) void k_keytab29_rows(GroupState
         const size_t w = (size_t)key * SBV_GTAB_WINDOWS + j;
         u32* t = tmp + (size_t)(blockIdx.x * 64 + threadIdx.x) * SBV_KT29_ROWS_TMP_WORDS;
         keytab29_rows_lane(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), (int)which, j == SBV_GTAB_WINDOWS - 1, t,
-                           ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
+                           ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW,
+                           ntab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_NTAB_PER_WINDOW);
     }
 }
 
@@ -452,7 +453,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
         SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[c], 0));
         if (on_t) SBV_TRY(hipStreamWaitEvent(tb, y.ev_class, 0));      // side_b has it in stream order
-        hipLaunchKernelGGL(k_keytab29_rows, dim3(bounded((size_t)b.max_groups * j_count * 2)), dim3(64), 0, tb, g, b.bases, ttmp, b.ktab, b.tslot, b.cold, b.kvalid, j_first, j_count);
+        hipLaunchKernelGGL(k_keytab29_rows, dim3(bounded((size_t)b.max_groups * j_count * 2)), dim3(64), 0, tb, g, b.bases, ttmp, b.ktab, b.ntab, b.tslot, b.cold, b.kvalid, j_first, j_count);
         hipLaunchKernelGGL(k_keytab29_fill_sym, dim3(bounded((size_t)b.max_groups * j_count * 8)), dim3(64), 0, tb, g, ttmp, b.ktab, b.tslot, b.needfill, b.kvalid, j_first, j_count);
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
@@ -472,7 +473,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
             // rows of every chunk (ev_tables of all chunks are ordered before this point on `stream`; side_a waits for them itself).
             SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_generic, 0));
             for (int cc = 0; cc < chunks; ++cc) SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_tables[cc], 0));
-            hipLaunchKernelGGL(k_verify_keyed_q<true>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, s, g, b.ktab, b.kvalid, b.tslot, b.full, table_slots, b.gacc,
+            hipLaunchKernelGGL(k_verify_keyed_q<true>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, s, g, b.ntab, b.kvalid, b.tslot, b.full, table_slots, b.gacc,
                                b.acc, 0, SBV_GTAB_WINDOWS, 1);
             SBV_TRY(hipEventRecord(y.ev_narrow, y.side_a));
         }

@@ -56,6 +56,7 @@ struct GroupBuffers {
     u32* bases = nullptr;       // [max_groups][33][2] chain records of 36 words: B_j = 2^(8j) Q and 16 B_j, modified Jacobian (p256_keytab29.h)
     u32* jstate = nullptr;      // [max_groups][27] the doubling chain between chunks of windows
     apt* ktab = nullptr; uint8_t* kvalid = nullptr; u32* tmp = nullptr; uint8_t* acc = nullptr;
+    apt* ntab = nullptr;        // [kc.cap + max_groups][33 x 16] compact rows (babies + giants) of every table slot: what the rows-only pass reads (p256_keytab29.h)
     KeyCache kc = {};           // persistent key-table cache: slots [0, kc.cap) of ktab / kvalid; [kc.cap, kc.cap + max_groups) = per batch
     u32* tslot = nullptr;       // [max_groups] table slot of each group of the current batch
     uint8_t* cold = nullptr;    // [max_groups] 1 = the group's tables are built in this batch

@@ -235,7 +235,13 @@ SBV_HD void keychain29_run(QX& q, const uint8_t* tuples, u32 gidx, const GroupSt
 // (the addition formulas do not depend on the curve's coefficients; the one doubling takes a4 = T = -3 Z^4 from the chain),
 // and a multiple (X' : Y' : ZZ' : ZZZ') maps back as x = X' / (ZZ' Z^2), y = Y' / (ZZZ' Z^3).  Z joins the lane's ONE
 // inversion (Montgomery's trick over Z and the ZZZ' of the chain).
-SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32* tmp, apt* row) {
+// crow (optional): the window's 16 entries of the key's COMPACT rows — babies 1..8 at 0..7, giants 16 a at 7 + a — a second copy
+// of exactly what this lane writes into `row`.  The rows-only pass of the Q phase (p256_comb29.h: qphase29_point_narrow) gathers
+// from it: 33 KB per key instead of 16 used entries strewn over 270 KB, which is what kept a 2^20 batch over 65 536 keys at a
+// quarter of its issue rate (17 GB of table address space behind every gather; profiles/r05).
+#define SBV_NTAB_PER_WINDOW 16
+#define SBV_NTAB_ENTRIES (SBV_GTAB_WINDOWS * SBV_NTAB_PER_WINDOW)
+SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32* tmp, apt* row, apt* crow = nullptr) {
     const int babies = 8;                                                 // the symmetric fill needs babies 1..8 only
     kchain B;
     kchain_load(B, base2 + which * 4 * SBV_KT29_REC_WORDS);               // record 0 = B, record 4 = 16 B
@@ -278,6 +284,7 @@ SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32
         f29_mul(a.x, bx, zi2);
         f29_mul(a.y, by, zi3);
         apt29_store_canon(row + (which == 0 ? 0 : 15), a);
+        if (crow) apt29_store_canon(crow + (which == 0 ? 0 : 8), a);
     }
     SBV_NOUNROLL
     for (int k = n - 1; k >= 0; --k) {
@@ -295,6 +302,7 @@ SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32
         f29_mul(a.y, Y, i3);
         const int mult = which == 0 ? k + 2 : 16 * (k + 2);               // this point is mult * B
         apt29_store_canon(row + mult - 1, a);
+        if (crow) apt29_store_canon(crow + (which == 0 ? k + 1 : 9 + k), a);
     }
 }
 

@@ -302,15 +302,16 @@ void free_group_buffers(Context& c, bool keep_pools = false) {
                     b.gcount, b.grp_of, b.ung_cand, b.rec, b.tslot, b.cold, b.full, b.needfill};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     sbv::apt* const ktab = b.ktab;
+    sbv::apt* const ntab = b.ntab;
     uint8_t* const kvalid = b.kvalid;
     uint8_t* const kfull = b.kfull;
     const sbv::KeyCache kc = b.kc;
     b = sbv::GroupBuffers();
     if (keep_pools) {
-        b.ktab = ktab; b.kvalid = kvalid; b.kfull = kfull; b.kc = kc;
+        b.ktab = ktab; b.ntab = ntab; b.kvalid = kvalid; b.kfull = kfull; b.kc = kc;
         return;
     }
-    void* pool[] = {ktab, kvalid, kfull, kc.ht, kc.keys, kc.count};
+    void* pool[] = {ktab, ntab, kvalid, kfull, kc.ht, kc.keys, kc.count};
     for (void* p : pool) if (p) (void)hipFree(p);
     if (c.edgrp.ktab) (void)hipFree(c.edgrp.ktab);
     if (c.edgrp.okb) (void)hipFree(c.edgrp.okb);
@@ -333,7 +334,7 @@ int ensure_group_buffers(Context& c, size_t n) {
         return SBV_OK;
     }
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
-    const bool keep_pools = b.ktab && b.kvalid && b.kfull && b.kc.ht && b.max_groups == c.group_max && b.kc.cap == c.kc_caps[0];
+    const bool keep_pools = b.ktab && b.ntab && b.kvalid && b.kfull && b.kc.ht && b.max_groups == c.group_max && b.kc.cap == c.kc_caps[0];
     free_group_buffers(c, keep_pools);
     const size_t cap = (n + 1023) & ~(size_t)1023;
     size_t ht = 1024;
@@ -365,6 +366,7 @@ int ensure_group_buffers(Context& c, size_t n) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&b.cold, G));
     if (!keep_pools) {
         HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ktab, (K + G) * (size_t)SBV_KEYTAB_ENTRIES * sizeof(sbv::apt)));
+        HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ntab, (K + G) * (size_t)(SBV_GTAB_WINDOWS * 16) * sizeof(sbv::apt)));      // compact rows: 33 KiB per slot
         HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, K + G));
         HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kfull, K + G));
         HIP_TRY(SBV_EDEVICE, hipMemset(b.kfull, 0, K + G));

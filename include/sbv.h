@@ -73,8 +73,8 @@ int sbv_p256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* accept_bitma
  * take the no-doubling kernels; everything else takes the generic kernel inside the same step.  Verdicts are identical.
  * `min_batch` = batches from this size on take the grouped step.  Defaults: enabled; min_batch 64 while the key-table cache is
  * on (a warm batch of a few thousand tuples skips the 256 doublings per signature), 2^17 while it is off (nothing outlives the
- * call then, and below ~2^17 building tables costs more latency than the doubling kernel takes); min_count 12 for P-256 (a soft,
- * sampled threshold: 3 of a key's every-4th tuples; the Ed25519 / secp256k1 steps, whose tables are always full, keep 64 and at most
+ * call then, and below ~2^17 building tables costs more latency than the doubling kernel takes); min_count 8 for P-256 (counted
+ * exactly; the Ed25519 / secp256k1 steps, whose tables are always full, keep 64 and at most
  * 2048 groups); max_groups 65536 (round 5; 2048 before — a 2^20 batch over 4096 keys sent half its tuples to the one-lane kernel).
  * Passing a non-zero min_batch sets both thresholds (and the variant schemes'); SBV_GROUP_MIN_BATCH_DEFAULT restores the built-in
  * ones together with the built-in min_count and max_groups (a non-zero min_count / max_groups in the same call still applies);

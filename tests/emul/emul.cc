@@ -141,12 +141,16 @@ unsigned long sbve_group_sort_violations() { return g_sort_violations; }
 // persistent key-table cache of the emulated grouped step (sbve_key_cache resets it)
 static KeyCache g_kc = {};
 static apt* g_kc_ktab = nullptr;
+static apt* g_kc_ntab = nullptr;            // compact rows of the cache's slots (GroupBuffers::ntab)
 static std::vector<uint8_t> g_kc_full;       // kfull of the emulated P-256 key-table cache's slots (p256_group.h: table classes)
 static std::vector<uint8_t> g_kc_valid;
 static std::vector<u32> g_kc_ht, g_kc_keys, g_kc_count;
 void sbve_key_cache(int enabled, u32 cap) {
     free(g_kc_ktab);
     g_kc_ktab = nullptr;
+    free(g_kc_ntab);
+    g_kc_ntab = nullptr;
+    if (cap) g_kc_ntab = (apt*)aligned_alloc(64, (size_t)cap * SBV_NTAB_ENTRIES * sizeof(apt));
     size_t ht = 16;
     while (ht < 4 * (size_t)(cap ? cap : 1)) ht *= 2;
     g_kc_ht.assign(ht, 0); g_kc_keys.assign((size_t)(cap ? cap : 1) * 16, 0); g_kc_count.assign(4, 0); g_kc_valid.assign(cap ? cap : 1, 0);
@@ -194,7 +198,7 @@ void sbve_last_table_classes(u32 out[3]) { for (int i = 0; i < 3; ++i) out[i] = 
 static u32 g_hash_seed = 0;        // GroupState::seed of the emulated grouped steps (the library draws a random one per context)
 void sbve_set_hash_seed(u32 s) { g_hash_seed = s; }
 static void emul_window_rows_fill(const u32* recs, bool top, u32* tmp, apt* row);
-static void emul_window_rows(const u32* recs, bool top, u32* tmp, apt* row);
+static void emul_window_rows(const u32* recs, bool top, u32* tmp, apt* row, apt* crow = nullptr);
 static void emul_window_fill(bool top, u32* tmp, apt* row);
 void sbve_set_group_coop(int on) { g_group_coop = on != 0; }     // k_group_coop instead of the G phase + Q launches (key-sorted step only)
 // grouped form: generic tuples, keys grouped inside the call (p256_group.h), emulated sequentially.
@@ -278,6 +282,9 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     for (u32 k = 0; k < ngroups; ++k) key_cache_phase_lookup<160, 96, 16>(tuples, g, kc, k, tslot.data(), cold.data());
     for (u32 k = 0; k < ngroups; ++k) key_cache_phase_insert<160, 96, 16>(tuples, g, kc, k, tslot.data());
     auto table_of = [&](u32 k) -> apt* { return tslot[k] < kc.cap ? g_kc_ktab + (size_t)tslot[k] * per_key : ktab + (size_t)k * per_key; };
+    apt* ntab = (apt*)aligned_alloc(64, ng1 * (size_t)SBV_NTAB_ENTRIES * sizeof(apt));      // compact rows of the per-batch slots
+    memset((void*)ntab, 0xA5, ng1 * (size_t)SBV_NTAB_ENTRIES * sizeof(apt));
+    auto ntable_of = [&](u32 k) -> apt* { return tslot[k] < kc.cap ? g_kc_ntab + (size_t)tslot[k] * SBV_NTAB_ENTRIES : ntab + (size_t)k * SBV_NTAB_ENTRIES; };
     auto valid_of = [&](u32 k) -> uint8_t* { return tslot[k] < kc.cap ? &g_kc_valid[tslot[k]] : &kvalid[k]; };
     // table classes (p256_group.h; k_group_table_class): kfull = [cache slots | this batch's per-batch slots], as on the device
     const u32 table_slots = kc.cap + (u32)ng1;
@@ -310,7 +317,8 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             for (int j = j_first; j < j_end && cold[k] && *valid_of(k); ++j) {        // k_keytab29_rows: every cold group whose key is a point
                 const size_t w = (size_t)k * SBV_GTAB_WINDOWS + j;
                 apt* row = table_of(k) + (size_t)j * SBV_GTAB_PER_WINDOW;
-                emul_window_rows(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row);
+                emul_window_rows(bases + w * (SBV_KT29_POINTS_PER_WINDOW * SBV_KT29_REC_WORDS), j == SBV_GTAB_WINDOWS - 1, tmpa.data(), row,
+                                 ntable_of(k) + (size_t)j * SBV_NTAB_PER_WINDOW);
             }
         for (u32 k = 0; k < ngroups; ++k)
             for (int j = j_first; j < j_end && needfill[k] && *valid_of(k); ++j)      // k_keytab29_fill_sym: the groups that earn a full table (cold, or a cached narrow one: upgrade)
@@ -378,10 +386,10 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             const u32 grp = g.sorted ? grp_of[L] : slots[t];
             if (grp < ngroups && !*valid_of(grp)) continue;
             bool v;
-            if (g.sorted) v = grp < ngroups ? qphase29_lane_sorted<true>(s, t, L, 0, 1, table_of(grp), valid_of(grp), gacc.data(), 0, SBV_GTAB_WINDOWS, true)
-                                            : qphase29_lane_sorted<true>(s, t, L, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc.data(), 0, SBV_GTAB_WINDOWS, true);
-            else v = grp < ngroups ? qphase29_lane<true>(s, t, 0, 1, table_of(grp), valid_of(grp), gacc.data(), 0, SBV_GTAB_WINDOWS, true)
-                                   : qphase29_lane<true>(s, t, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc.data(), 0, SBV_GTAB_WINDOWS, true);
+            if (g.sorted) v = grp < ngroups ? qphase29_lane_sorted<true>(s, t, L, 0, 1, ntable_of(grp), valid_of(grp), gacc.data(), 0, SBV_GTAB_WINDOWS, true)
+                                            : qphase29_lane_sorted<true>(s, t, L, SBV_GROUP_NONE, 1, ntab, kvalid.data(), gacc.data(), 0, SBV_GTAB_WINDOWS, true);
+            else v = grp < ngroups ? qphase29_lane<true>(s, t, 0, 1, ntable_of(grp), valid_of(grp), gacc.data(), 0, SBV_GTAB_WINDOWS, true)
+                                   : qphase29_lane<true>(s, t, SBV_GROUP_NONE, 1, ntab, kvalid.data(), gacc.data(), 0, SBV_GTAB_WINDOWS, true);
             if (v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
         }
     }
@@ -394,17 +402,17 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
         const bool v = s.rec ? verify29_lane_generic_rec(s, tuples, t, qtab, g16rtab()) : verify29_lane_generic(s, t, qtab, g16rtab());
         if (v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
     }
-    free(qtab); free(ktab); free(bases);
+    free(qtab); free(ktab); free(ntab); free(bases);
     if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }
 }
 
 // rows + fill of one (key, window) the way the launcher does it: k_keytab29_rows (two lanes), then k_keytab29_fill_sym (lane
 // a - 1 fills both sides of giant 16 a; the lanes run in descending order here so that a lane that wrongly depended on
 // another's output would show)
-static void emul_window_rows(const u32* recs, bool top, u32* tmp, apt* row) {
+static void emul_window_rows(const u32* recs, bool top, u32* tmp, apt* row, apt* crow) {
     for (int which = 0; which < 2; ++which) {
         if (which == 1 && top) continue;
-        keytab29_rows_lane(recs, which, top, tmp, row);
+        keytab29_rows_lane(recs, which, top, tmp, row, crow);
     }
 }
 static void emul_window_fill(bool top, u32* tmp, apt* row) {
@@ -412,7 +420,7 @@ static void emul_window_fill(bool top, u32* tmp, apt* row) {
     for (int a = 8; a >= 1; --a) keytab29_fill_sym_lane(a, tmp + (size_t)(a - 1) * (SBV_KT29_FILL_TMP_WORDS / 2), row);
 }
 static void emul_window_rows_fill(const u32* recs, bool top, u32* tmp, apt* row) {
-    emul_window_rows(recs, top, tmp, row);
+    emul_window_rows(recs, top, tmp, row, nullptr);
     emul_window_fill(top, tmp, row);
 }
 
