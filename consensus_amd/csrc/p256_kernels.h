@@ -29,8 +29,9 @@ hipError_t launch_p256_verify_prepared_small(const void* d_in, size_t n, u32 nke
 void host_prep_small(const uint8_t* rsh, const u32* slots, size_t n, u32* rec, u32* slot_out);
 void host_build_gcomb(int bits, apt* out);   // `bits`-wide comb of G, 8 x 32 Montgomery domain: gcomb_entries(bits) entries
 // mbase / sbase: value of the offset tables at the first byte of d_msgs / d_sigs (0 for a whole batch; a piece keeps the batch's offsets)
+// mbytes / sbytes: bytes uploaded behind d_msgs / d_sigs; a lane whose offsets are not monotone or leave them gets an empty message and signature (reject)
 hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const uint8_t* d_sigs, const u64* d_soff, size_t n,
-                               u32* d_rsh, hipStream_t stream, u64 mbase = 0, u64 sbase = 0);
+                               u32* d_rsh, hipStream_t stream, u64 mbase, u64 sbase, u64 mbytes, u64 sbytes);
 // comb table (33 x 128 affine multiples, R = 2^261 domain) of a registered key; false if the key is not a valid curve point
 bool host_build_key_table(const uint8_t q[64], apt* out);
 // `bits`-wide comb of a registered key (p256_comb29.h: widekeys), gcomb_entries(bits) entries, R = 2^261 domain

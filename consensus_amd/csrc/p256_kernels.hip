@@ -335,12 +335,17 @@ hipError_t launch_p256_sign(const uint8_t* d_keys, u32 n_keys, const u32* d_key_
 // so lanes read their own byte ranges (offset tables); the 96-byte records are written back contiguous.
 // mbase / sbase: the offset-table values of the first byte held in msgs / sigs (a PIECE of a larger batch carries the batch's own
 // offsets: sbv_p256_verify_msgs_keyed_sharded uploads slices of the caller's tables as they are)
+// mbytes / sbytes: bytes of msgs / sigs that were uploaded.  Every lane checks ITS OWN slice of the offset tables against them
+// (monotone, inside the upload): an entry that is not turns into an empty message and an empty signature — a DER failure, r = s = 0,
+// rejected — instead of a read outside the staging buffers.  (The host used to scan both tables with 8 threads before every call:
+// 0.2-0.3 ms of thread start-up per call, profiles/r05; it now checks the piece boundaries only.)
 __global__ __launch_bounds__(256) void k_msg_frontend(const uint8_t* __restrict__ msgs, const u64* __restrict__ moff,
                                                       const uint8_t* __restrict__ sigs, const u64* __restrict__ soff,
-                                                      size_t n, u32* __restrict__ rsh, u64 mbase, u64 sbase) {
+                                                      size_t n, u32* __restrict__ rsh, u64 mbase, u64 sbase, u64 mbytes, u64 sbytes) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const u64 m0 = moff[i] - mbase, m1 = moff[i + 1] - mbase, s0 = soff[i] - sbase, s1 = soff[i + 1] - sbase;
+    u64 m0 = moff[i] - mbase, m1 = moff[i + 1] - mbase, s0 = soff[i] - sbase, s1 = soff[i + 1] - sbase;
+    if (!(m0 <= m1 && m1 <= mbytes && s0 <= s1 && s1 <= sbytes)) { m0 = m1 = 0; s0 = s1 = 0; }      // unsigned: an offset below the base wraps far above the bound
     u32 rec[24];
     msg_frontend_lane(msgs + m0, (size_t)(m1 - m0), sigs + s0, (size_t)(s1 - s0), rec);
 #pragma unroll
@@ -348,9 +353,9 @@ __global__ __launch_bounds__(256) void k_msg_frontend(const uint8_t* __restrict_
 }
 
 hipError_t launch_msg_frontend(const uint8_t* d_msgs, const u64* d_moff, const uint8_t* d_sigs, const u64* d_soff, size_t n,
-                               u32* d_rsh, hipStream_t stream, u64 mbase, u64 sbase) {
+                               u32* d_rsh, hipStream_t stream, u64 mbase, u64 sbase, u64 mbytes, u64 sbytes) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_msg_frontend, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_msgs, d_moff, d_sigs, d_soff, n, d_rsh, mbase, sbase);
+    hipLaunchKernelGGL(k_msg_frontend, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_msgs, d_moff, d_sigs, d_soff, n, d_rsh, mbase, sbase, mbytes, sbytes);
     return hipGetLastError();
 }
 

@@ -1755,7 +1755,7 @@ extern "C" int sbv_p256_verify_msgs_keyed(const uint8_t* msgs, const uint64_t* m
     HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_soff, sig_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
     HIP_TRY(SBV_EDEVICE, hipMemcpyAsync(c.d_slots, slots, n * sizeof(u32), hipMemcpyHostToDevice, c.stream));
     HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[1], c.stream));
-    HIP_TRY(SBV_EDEVICE, sbv::launch_msg_frontend(c.d_msgs, c.d_moff, c.d_sigs, c.d_soff, n, reinterpret_cast<u32*>(c.d_tuples), c.stream));
+    HIP_TRY(SBV_EDEVICE, sbv::launch_msg_frontend(c.d_msgs, c.d_moff, c.d_sigs, c.d_soff, n, reinterpret_cast<u32*>(c.d_tuples), c.stream, 0, 0, mbytes, sbytes));
     rc = enqueue_keyed(c, c.d_tuples, c.d_slots, n, c.d_bitmap, c.stream, c.ev[2]);
     if (rc != SBV_OK) return rc;
     HIP_TRY(SBV_EDEVICE, hipEventRecord(c.ev[3], c.stream));
@@ -2489,6 +2489,14 @@ int verify_shard_msgs(Context& c, const uint8_t* msgs, const uint64_t* moff, con
     size_t max_mb = 0, max_sb = 0;                 // staging for the largest piece, grown before anything is enqueued
     for (size_t off = 0; off < m; off += chunk) {
         const size_t k = m - off < chunk ? m - off : chunk;
+        // the piece boundaries of the caller's tables size the uploads: they must be monotone and plausible (a piece of k signatures
+        // with more than 64 KiB per message / 4 KiB per signature on average is a corrupt table, not a batch); everything between two
+        // boundaries is checked lane by lane on the device (k_msg_frontend)
+        if (moff[first + off + k] < moff[first + off] || soff[first + off + k] < soff[first + off] ||
+            moff[first + off + k] - moff[first + off] > (uint64_t)k * 65536 || soff[first + off + k] - soff[first + off] > (uint64_t)k * 4096) {
+            g_err = "offset table is not monotone";
+            return SBV_EINVAL;
+        }
         const size_t mb = (size_t)(moff[first + off + k] - moff[first + off]), sb = (size_t)(soff[first + off + k] - soff[first + off]);
         if (mb > max_mb) max_mb = mb;
         if (sb > max_sb) max_sb = sb;
@@ -2544,7 +2552,7 @@ int verify_shard_msgs(Context& c, const uint8_t* msgs, const uint64_t* moff, con
         step(hipEventRecord(ev[3 * i + 1], up));
         if (two) step(hipStreamWaitEvent(ks[w], ev[3 * i + 1], 0));
         if (he != hipSuccess) break;
-        step(sbv::launch_msg_frontend(st_msgs[w], st_moff[w], st_sigs[w], st_soff[w], k, reinterpret_cast<u32*>(recs[w]), ks[w], mbase, sbase));
+        step(sbv::launch_msg_frontend(st_msgs[w], st_moff[w], st_sigs[w], st_soff[w], k, reinterpret_cast<u32*>(recs[w]), ks[w], mbase, sbase, mb, sb));
         if (he != hipSuccess) break;
         rc = enqueue_keyed(c, recs[w], st_slots[w], k, d_slot + off / 8, ks[w], nullptr, w ? chunk : 0);
         if (rc != SBV_OK) break;
@@ -2930,19 +2938,9 @@ extern "C" int sbv_p256_verify_msgs_keyed_sharded(const uint8_t* msgs, const uin
     if (n == 0) return SBV_OK;
     if (!msg_offsets || !sig_offsets || !slots || !accept_bitmap) { g_err = "null pointer"; return SBV_EINVAL; }
     if (quorum_bitmap && (group == 0 || quorum == 0 || quorum > group || group > 64)) { g_err = "quorum bits need 0 < quorum <= group <= 64"; return SBV_EINVAL; }
-    // the devices dereference the offset tables: they must never decrease.  They need NOT start at 0 here: msgs / sigs are the bases the
-    // offsets refer to, so a caller that laid a large batch out once can hand over slices of its tables (the host Verifier ships a
-    // decision-replay batch in a few slices while its workers still lay out the next one).
-    {
-        std::atomic<int> bad(0);
-        const size_t nt = n > ((size_t)1 << 16) ? 8 : 1;             // 2 x 550 000 comparisons: a few threads
-        std::vector<std::thread> th;
-        auto scan = [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) if (msg_offsets[i + 1] < msg_offsets[i] || sig_offsets[i + 1] < sig_offsets[i]) { bad.store(1); return; } };
-        for (size_t t = 1; t < nt; ++t) th.emplace_back(scan, n * t / nt, n * (t + 1) / nt);
-        scan(0, n / nt);
-        for (auto& t : th) t.join();
-        if (bad.load()) { g_err = "offset table is not monotone"; return SBV_EINVAL; }
-    }
+    // The offset tables must never decrease: the piece boundaries are checked on the host (verify_shard_msgs), every entry between them by
+    // its lane on the device (k_msg_frontend: an entry out of order or outside the upload becomes an empty message + signature = reject).
+    // They need NOT start at 0 here: msgs / sigs are the bases the offsets refer to (a slice of a larger batch's tables is a valid argument).
     if ((msg_offsets[n] && !msgs) || (sig_offsets[n] && !sigs)) { g_err = "null pointer"; return SBV_EINVAL; }
     const auto t0 = std::chrono::steady_clock::now();
     std::shared_lock<std::shared_mutex> rl(g_reg_mu);
