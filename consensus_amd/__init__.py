@@ -429,9 +429,10 @@ def verify_batch_keyed_sharded(rsh_ptr: int, slots_ptr: int, n: int, out_ptr: in
     return info
 
 
-def verify_msgs_keyed_sharded(msgs, sigs_der, slots, group: int = 0, quorum: int = 0):
+def verify_msgs_keyed_sharded(msgs, sigs_der, slots, group: int = 0, quorum: int = 0, offsets=None):
     """sbv_p256_verify_msgs_keyed_sharded: raw messages + DER signatures + key slots over every initialised device, SHA-256 and the
-    DER parse on the devices, uploads in pieces.  Returns (accept bitmap, quorum bitmap or None, ShardInfo)."""
+    DER parse on the devices, uploads in pieces.  Returns (accept bitmap, quorum bitmap or None, ShardInfo).
+    offsets = (msg_offsets, sig_offsets): use these tables instead of the ones the byte strings imply (tests of malformed tables)."""
     lib = load()
     lib.sbv_p256_verify_msgs_keyed_sharded.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64),
                                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
@@ -444,6 +445,9 @@ def verify_msgs_keyed_sharded(msgs, sigs_der, slots, group: int = 0, quorum: int
         mo[i], so[i] = a, b
         a += len(msgs[i]); b += len(sigs_der[i])
     mo[n], so[n] = a, b
+    if offsets is not None:
+        for i in range(n + 1):
+            mo[i], so[i] = offsets[0][i], offsets[1][i]
     arr = (ctypes.c_uint32 * max(1, n))(*slots)
     out = ctypes.create_string_buffer(max(1, (n + 7) // 8))
     props = n // group if group else 0

@@ -487,6 +487,23 @@ def test_sharded_message_frontend_in_pieces(oracle):
             sigs2[j] = b""
         got2, _, _ = sbv.verify_msgs_keyed_sharded(msgs2, sigs2, slots[:m2])
         assert sbv.bitmap_to_list(got2, m2) == [want[i] and i not in (0, 7167, 7168, m2 - 1) for i in range(m2)]
+        # malformed offset tables: an entry out of order INSIDE a piece costs its neighbours' verdicts (their byte ranges are wrong:
+        # rejected), never a read outside the upload and never another lane's verdict; a piece BOUNDARY out of order is refused
+        mo, so, a, b = [0], [0], 0, 0
+        for i in range(m2):
+            a += len(msgs2[i]); b += len(sigs2[i])
+            mo.append(a); so.append(b)
+        bad_mo = list(mo)
+        bad_mo[100] = mo[100] + (1 << 40)                      # tuples 99 and 100 see a range that leaves the upload / runs backwards
+        got3, _, _ = sbv.verify_msgs_keyed_sharded(msgs2, sigs2, slots[:m2], offsets=(bad_mo, so))
+        w3 = sbv.bitmap_to_list(got2, m2)
+        w3[99] = w3[100] = False
+        assert sbv.bitmap_to_list(got3, m2) == w3
+        bad_so = list(so)
+        bad_so[5120] = so[10240] + 5                           # 14 341 signatures go up as 3 equal pieces of 5 120: this boundary now lies behind the next one
+        with pytest.raises(sbv.SbvError) as ei:
+            sbv.verify_msgs_keyed_sharded(msgs2, sigs2, slots[:m2], offsets=(mo, bad_so))
+        assert ei.value.code == -2
     finally:
         os.environ.pop("SBV_RCCL", None)
         os.environ.pop("SBV_SHARD_PIECE_KEYED", None)
