@@ -973,52 +973,13 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
             };
             const double t_c = trace ? now() : 0;
             moff[n] = msum[jobs]; soff[n] = ssum[jobs];
-            // A large batch goes to the backend in a few SLICES (whole layout chunks), each shipped by a helper thread while the workers
-            // lay out the next one: host pass and device work overlap instead of adding up (profiles/r05: 1.6 + 2.6 ms for 550 000
-            // signatures back to back).  The offsets are global — the backend takes a slice of the tables with the buffers' bases.
-            static const size_t slices_cfg = [] { const char* e = getenv("SBVH_REPLAY_SLICES"); const long v = e ? atol(e) : 0; return v >= 1 && v <= 16 ? (size_t)v : (size_t)4; }();
-            const size_t slices = n >= ((size_t)1 << 18) && jobs >= 2 * slices_cfg ? slices_cfg : 1;
-            if (slices == 1) {
-                pool.run(jobs, layout);
-                if (trace) fprintf(stderr, "[sbvh trace] replay layout: setup %.0f us, sizes %.0f us, staging %.0f us, copy + binding %.0f us (%zu chunks)\n", t_a - t_start, t_b - t_a, t_c - t_b, now() - t_c, jobs);
-                if (trace) t_pass1 = t_layout = now();
-                krc = co_.submit_many_msgs_keyed(mbuf, moff, sbuf, soff, dslots, n, bitmap.data());
-                if (trace) t_backend = now();
-            } else {
-                std::mutex sm;
-                std::condition_variable scv;
-                size_t laid_out = 0;                       // slices whose bytes are in place
-                int src = 0;
-                std::string serr;
-                auto first_of = [&](size_t sl) { const size_t j = jobs * sl / slices; return j * per < n ? j * per : n; };
-                std::thread shipper([&] {
-                    for (size_t sl = 0; sl < slices; ++sl) {
-                        {
-                            std::unique_lock<std::mutex> lk(sm);
-                            scv.wait(lk, [&] { return laid_out > sl; });
-                        }
-                        const size_t a = first_of(sl), b = first_of(sl + 1);
-                        if (b <= a || src != 0) continue;
-                        const double ts0 = trace ? now() : 0;
-                        const int r = co_.submit_many_msgs_keyed(mbuf, moff + a, sbuf, soff + a, dslots + a, b - a, bitmap.data() + a / 8);
-                        if (trace) fprintf(stderr, "[sbvh trace]   slice %zu: %zu signatures, shipped %.0f us after the call started, backend %.0f us\n", sl, b - a, ts0 - t_start, now() - ts0);
-                        if (r != 0) { src = r; serr = sbv_last_error(); }       // the library's error text is per thread: keep this thread's
-                    }
-                });
-                for (size_t sl = 0; sl < slices; ++sl) {
-                    const size_t j0 = jobs * sl / slices, j1 = jobs * (sl + 1) / slices;
-                    const std::function<void(size_t)> part = [&](size_t k) { layout(j0 + k); };
-                    if (j1 > j0) pool.run(j1 - j0, part);
-                    { std::lock_guard<std::mutex> lk(sm); laid_out = sl + 1; }
-                    scv.notify_all();
-                }
-                if (trace) t_pass1 = t_layout = now();
-                shipper.join();
-                if (trace) t_backend = now();
-                if (trace) fprintf(stderr, "[sbvh trace] replay layout in %zu slices: setup %.0f us, sizes %.0f us, copy + binding (beside the backend) %.0f us, backend tail %.0f us\n", slices, t_a - t_start, t_b - t_a, t_pass1 - t_c, t_backend - t_pass1);
-                krc = src;
-                if (krc != 0 && krc != -2) return Status::Unavailable(std::string("backend error: ") + serr);
-            }
+            // (Shipping the batch in 2 or 4 slices, each by a helper thread while the workers lay out the next one, was measured in round 5
+            // and lost: 4.07 ms in one call against 4.19 / 4.47 — a backend call has ~0.3 ms of fixed cost, more than the overlap wins.)
+            pool.run(jobs, layout);
+            if (trace) fprintf(stderr, "[sbvh trace] replay layout: setup %.0f us, sizes %.0f us, staging %.0f us, copy + binding %.0f us (%zu chunks)\n", t_a - t_start, t_b - t_a, t_c - t_b, now() - t_c, jobs);
+            if (trace) t_pass1 = t_layout = now();
+            krc = co_.submit_many_msgs_keyed(mbuf, moff, sbuf, soff, dslots, n, bitmap.data());
+            if (trace) t_backend = now();
         }
         if (krc == -2) {
             uint8_t* rsh = (uint8_t*)staging(st_msgs_, n * 96);

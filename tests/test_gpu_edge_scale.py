@@ -98,7 +98,8 @@ def test_p256_edge_vectors_spliced_into_the_headline_batch_cache_off_warm_overfl
                 got = _run_ptr(gpu, batch, n)
                 assert _report(got, want, where, names) is None, (label, rnd, _report(got, want, where, names))
             groups, grouped, generic, rejected = gpu.last_group_stats()
-            assert groups >= 1024 and grouped > 900000, (label, groups, grouped, generic, rejected)
+            # with the cache on, one caller's 2^20 tuples go up in four pieces of 2^18 beside their own kernels (round 5): the statistics are the last piece's
+            assert groups >= 1024 and grouped > (900000 if label == "cache off" else 225000), (label, groups, grouped, generic, rejected)
         # the all-distinct-keys kernel on the same spliced batch
         gpu.key_cache(False)
         gpu.set_grouping(False)
