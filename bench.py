@@ -161,6 +161,7 @@ def leg_warm_cache(sbv, torch, d_tuples, d_bitmap, valid, n, steps, stream):
     as the headline (which is measured with the cache off: every step cold)."""
     sbv.key_cache(True)
     try:
+        sbv.hot_keys(1024, 0xFFFFFFFF)      # `value`: the 8-bit tables only (no key ever gets hot enough) ...
         sbv.verify_batch_dev(d_tuples.data_ptr(), n, d_bitmap.data_ptr(), stream.cuda_stream)      # fills the cache
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -169,10 +170,41 @@ def leg_warm_cache(sbv, torch, d_tuples, d_bitmap, valid, n, steps, stream):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         entries, hits, misses, cap = sbv.key_cache_stats()
-        return {"value": n * steps / dt, "unit": "verifies/s", "ms_per_step": 1e3 * dt / steps,
-                "bitmap_correct": bool((d_bitmap.cpu().numpy() == valid).all()),
-                "cache": {"keys_cached": entries, "groups_hit_last_step": hits, "groups_missed_last_step": misses, "capacity": cap}}
+        out = {"value": n * steps / dt, "unit": "verifies/s", "ms_per_step": 1e3 * dt / steps,
+               "bitmap_correct": bool((d_bitmap.cpu().numpy() == valid).all()),
+               "cache": {"keys_cached": entries, "groups_hit_last_step": hits, "groups_missed_last_step": misses, "capacity": cap}}
+        # ... `hot_keys`: the library's default (promotion from 4096 hits on, 16 keys per batch): the batches it takes until every signer
+        # owns a 16-bit comb, timed as they go, then the same measurement with the wide pass serving the batch
+        try:
+            sbv.hot_keys(1024, 4096)
+            ramp = []
+            for _ in range(160):
+                t0 = time.perf_counter()
+                sbv.verify_batch_dev(d_tuples.data_ptr(), n, d_bitmap.data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize()
+                ramp.append(time.perf_counter() - t0)
+                promoted, pool, wide_lanes, min_hits = sbv.hot_key_stats()
+                if promoted >= min(entries, pool):
+                    break
+            sbv.verify_batch_dev(d_tuples.data_ptr(), n, d_bitmap.data_ptr(), stream.cuda_stream)  # the last promotions are published behind the batch that made them
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sbv.verify_batch_dev(d_tuples.data_ptr(), n, d_bitmap.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            dth = time.perf_counter() - t0
+            promoted, pool, wide_lanes, min_hits = sbv.hot_key_stats()
+            out["hot_keys"] = {"value": n * steps / dth, "unit": "verifies/s", "ms_per_step": 1e3 * dth / steps,
+                               "bitmap_correct": bool((d_bitmap.cpu().numpy() == valid).all()),
+                               "promoted_keys": promoted, "pool_keys": pool, "min_hits": min_hits, "tuples_through_the_wide_pass_last_step": wide_lanes,
+                               "batches_until_all_promoted": len(ramp), "ms_per_batch_while_promoting_median": 1e3 * sorted(ramp)[len(ramp) // 2],
+                               "combs_equal_host_builder": [bool(sbv.hot_selfcheck(i)) for i in (0, max(0, promoted - 1))] if promoted else [],
+                               "note": "generic tuples, keys inside the tuples: slots with >= min_hits verified tuples own a 16-bit comb (35.7 MB each), built on the device behind the verdicts"}
+        except Exception as e:      # noqa: BLE001
+            out["hot_keys"] = {"error": repr(e)}
+        return out
     finally:
+        sbv.hot_keys(1024, 4096)
         sbv.key_cache(False)
 
 
@@ -190,11 +222,27 @@ def leg_key_count_sweep(sbv, synth, torch, n, stream, key_counts=None, reps=3):
         d_t = torch.from_numpy(tuples).cuda()
         d_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device="cuda")
         point = {"keys": K, "signatures_per_key": n / K}
-        for mode in ("cold", "warm"):
-            sbv.key_cache(mode == "warm")
+        for mode in ("cold", "warm", "hot"):
+            # warm: the cached 8-bit tables alone (promotion threshold out of reach); hot: the default policy once it has settled — up to
+            # 1024 of the keys that passed 4096 hits own a 16-bit comb (points with fewer than 1024 tuples per key take a few batches)
+            if mode == "hot" and K > 16384:
+                continue
+            sbv.key_cache(mode != "cold")
             try:
+                sbv.hot_keys(1024, 4096 if mode == "hot" else 0xFFFFFFFF)
                 sbv.verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
                 torch.cuda.synchronize()
+                if mode == "hot":
+                    last = -1
+                    for i in range(400):
+                        sbv.verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+                        torch.cuda.synchronize()
+                        promoted = sbv.hot_key_stats()[0]
+                        if promoted >= min(K, 1024) or (i > 70 and promoted == last and promoted == 0):
+                            break
+                        last = promoted
+                    sbv.verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)
+                    torch.cuda.synchronize()
                 ts = []
                 for _ in range(reps):
                     t0 = time.perf_counter()
@@ -205,7 +253,11 @@ def leg_key_count_sweep(sbv, synth, torch, n, stream, key_counts=None, reps=3):
                 g = sbv.last_group_stats()
                 point[mode] = {"verifies_per_s": n / dt, "ms": 1e3 * dt, "groups": g[0], "tuples_through_tables": g[1],
                                "tuples_one_lane_kernel": g[2], "bitmap_correct": bool((d_b.cpu().numpy() == valid).all())}
+                if mode == "hot":
+                    hs = sbv.hot_key_stats()
+                    point[mode]["promoted_keys"], point[mode]["tuples_through_the_wide_pass"] = hs[0], hs[2]
             finally:
+                sbv.hot_keys(1024, 4096)
                 sbv.key_cache(False)
         out.append(point)
         del d_t, d_b
@@ -214,7 +266,7 @@ def leg_key_count_sweep(sbv, synth, torch, n, stream, key_counts=None, reps=3):
         if b["signatures_per_key"] >= 16:
             worst = max(worst, a["cold"]["verifies_per_s"] / b["cold"]["verifies_per_s"])
     return {"tuples": n, "points": out, "largest_cold_step_between_adjacent_points_down_to_16_sigs_per_key": worst,
-            "all_bitmaps_correct": all(p[m]["bitmap_correct"] for p in out for m in ("cold", "warm"))}
+            "all_bitmaps_correct": all(p[m]["bitmap_correct"] for p in out for m in ("cold", "warm", "hot") if m in p)}
 
 
 def leg_all_valid(sbv, synth, torch, n, steps, stream):

@@ -405,6 +405,46 @@ SBV_HD void group_table_mark_lane(u32 k, const u32* tslot, const uint8_t* cold, 
     else if (needfill[k]) kfull[slot] = 1;
 }
 
+// ---- hot keys: wide combs in the generic path (round 5) -------------------------------------------------------------
+// The registered-key entry gives a consenter's slot a 16- or 20-bit comb (u2 * Q in 16 / 13 additions instead of 32); keys that arrive
+// INSIDE generic tuples — client keys of VerifyProposal (internal/bft/view.go:553-559), consenters of a replica that registered
+// nothing — never got one.  A cache slot now counts the tuples verified against it (khits) and, once that count passes
+// `promote_min` is PROMOTED: a 16-bit comb (17 windows x 32 768 entries, 35.7 MB; HBM holds 288 GB —
+// 1024 hot keys are 36.5 GB) is built on the device by the registered path's builder (p256_widetab29.h), whose base points
+// B_j = 2^(16 j) Q and C_j = 2^8 B_j ARE entries of the key's 8-bit table (row 2j / 2j + 1, entry 1): no host round trip, at most
+// SBV_PROMOTE_MAX keys per batch, behind the batch's verdicts.  Later batches verify a promoted key's tuples from the wide comb in
+// one launch that needs no table of the batch at all (p256_group_kernels.hip: the wide pass).  Verdicts cannot depend on it: same
+// exact group law, and a slot's comb is a function of its key's 64 bytes.
+//   kwide[slot]   wide comb of a cache slot, or SBV_WIDE_NONE           khits[slot]   tuples verified against the slot so far
+//   wide[k]       this batch's group k may take the wide pass           hot[0..3]     wide combs handed out | promotions of this batch |
+//                                                                                     lanes of the wide pass | (spare)
+#define SBV_PROMOTE_MAX 64u
+#define SBV_HOT_BITS 16
+SBV_HD void group_hot_class_lane(u32 k, const GroupState& g, const u32* tslot, const uint8_t* cold, u32 cache_cap, const u32* kwide, u32* khits,
+                                 uint8_t* wide) {
+    const u32 slot = tslot[k];
+    bool w = false;
+    if (slot < cache_cap) {
+        const u32 count = g.sorted ? g.gcount[k] : g.cnt[g.group_rep[k]] * (g.sample_mask + 1u);
+        khits[slot] += count;                                   // one group per slot and batch: no atomics
+        w = !cold[k] && kwide[slot] != 0xFFFFFFFFu;
+    }
+    wide[k] = w ? 1 : 0;
+}
+// end of the batch: group k asks for a wide comb when its slot is cached, valid (its 8-bit rows, full or not, hold the builder's base
+// points), hot and has none yet.  plist[2 i] = slot, plist[2 i + 1] = wide index of promotion i.
+SBV_HD void group_promote_select_lane(u32 k, const u32* tslot, const uint8_t* kvalid, u32 cache_cap, const u32* kwide,
+                                      const u32* khits, u32 promote_min, u32 wide_cap, u32* hot, u32* plist) {
+    const u32 slot = tslot[k];
+    if (slot >= cache_cap || !kvalid[slot] || kwide[slot] != 0xFFFFFFFFu || khits[slot] < promote_min) return;
+    if (hot[0] >= wide_cap) return;                             // the pool is full (the counter only grows: a stale read costs one atomic)
+    const u32 i = SBV_ATOMIC_ADD(&hot[1], 1u);
+    if (i >= SBV_PROMOTE_MAX) return;                           // this batch's quota: the key is asked again by the next batch
+    const u32 w = SBV_ATOMIC_ADD(&hot[0], 1u);
+    plist[2 * i] = w < wide_cap ? slot : 0xFFFFFFFFu;           // past the pool's end: an empty entry
+    plist[2 * i + 1] = w;
+}
+
 // ---- per-batch key tables ----------------------------------------------------------------------------
 // jbases: [groups][33] Jacobian 2^(8j) * Q with cached Z^2, Z^3 (qent layout, 40 dwords);
 // valid[g] = pointFromAffine verdict.  One call produces bases j_first..j_last; a call with j_first > 0

@@ -181,15 +181,64 @@ __global__ __launch_bounds__(64) void k_keytab29_fill_sym(GroupState g, u32* __r
 #define SBV_TABLE_TMP_WORDS ((size_t)SBV_TABLE_GRID_BLOCKS * 64 * SBV_KT29_ROWS_TMP_WORDS)
 
 // Table classes of the batch's groups and, at the end of the step, what the slots hold (p256_group.h).  One lane per group.
+// hot: the wide-comb state of the cache slots (p256_group.h: hot keys); kwide == nullptr = feature off / no pool
+struct HotKeys { const apt* wtab; u32* kwide; u32* khits; u32* hot; u32* plist; u32 cache_cap, wide_cap, promote_min; };
 __global__ __launch_bounds__(256) void k_group_table_class(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
                                                            const uint8_t* __restrict__ kfull, u32 table_slots, u32 full_min,
-                                                           uint8_t* __restrict__ full, uint8_t* __restrict__ needfill) {
+                                                           uint8_t* __restrict__ full, uint8_t* __restrict__ needfill,
+                                                           HotKeys hk, uint8_t* __restrict__ wide) {
     const u32 groups = group_count(g);
     for (u32 k = blockIdx.x * 256 + threadIdx.x; k < groups; k += gridDim.x * 256) {
         group_table_class_lane(k, g, tslot, cold, kfull, table_slots, full_min, full, needfill);
+        if (hk.kwide && g.sorted) group_hot_class_lane(k, g, tslot, cold, hk.cache_cap, hk.kwide, hk.khits, wide);
+        else wide[k] = 0;
         if (full[k]) atomicAdd(&g.counters[5], 1u);           // statistics only (sbv_p256_last_table_classes)
         if (needfill[k]) atomicAdd(&g.counters[6], 1u);
     }
+}
+// ---- promotion of hot cache slots to wide combs (p256_group.h: hot keys; p256_widetab29.h: the builder of the registered path) ----------
+// select (one lane per group) -> bases (the 2 x 17 base points of each promotion, gathered from the key's 8-bit table) -> chains + fill
+// (the builder's lanes, for the promotions this batch really made) -> publish (kwide[slot] = index: later batches take the wide pass)
+__global__ __launch_bounds__(256) void k_promote_select(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ kvalid, HotKeys hk) {
+    const u32 groups = group_count(g);
+    for (u32 k = blockIdx.x * 256 + threadIdx.x; k < groups; k += gridDim.x * 256)
+        group_promote_select_lane(k, tslot, kvalid, hk.cache_cap, hk.kwide, hk.khits, hk.promote_min, hk.wide_cap, hk.hot, hk.plist);
+}
+__device__ __forceinline__ u32 promote_live(const u32* hot) { const u32 c = hot[1]; return c < SBV_PROMOTE_MAX ? c : SBV_PROMOTE_MAX; }
+__global__ __launch_bounds__(64) void k_promote_bases(const u32* __restrict__ plist, const u32* __restrict__ hot, const apt* __restrict__ ktab, apt* __restrict__ pbases) {
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 W = (257 + SBV_HOT_BITS - 1) / SBV_HOT_BITS;          // 17
+    const u32 i = lane / (2 * W), e = lane % (2 * W);
+    if (i < promote_live(hot)) promote_base_lane(i, e, plist, ktab, pbases);
+}
+__global__ __launch_bounds__(64) void k_promote_chains(const apt* __restrict__ pbases, const u32* __restrict__ plist, const u32* __restrict__ hot, widebuild w,
+                                                       size_t stride, u32* __restrict__ tmp, apt* __restrict__ wtab) {
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 per_key = (u32)w.windows * 2u;
+    const u32 i = lane / per_key, j = (lane % per_key) >> 1, role = lane & 1u;
+    if (i >= promote_live(hot) || plist[2 * i] == 0xFFFFFFFFu) return;
+    const apt* kb = pbases + (size_t)i * per_key;
+    widetab_chain_role(w, kb + j, kb + w.windows + j, (int)role, tmp + (size_t)lane * widebuild_chain_len(w) * SBV_WIDETAB_REC_WORDS,
+                       wtab + (size_t)plist[2 * i + 1] * stride + (size_t)j * w.per_window);
+}
+__global__ __launch_bounds__(256) void k_promote_fill(const u32* __restrict__ plist, const u32* __restrict__ hot, widebuild w, size_t stride, apt* __restrict__ wtab) {
+    const size_t lane = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const u32 chunks = widebuild_fill_chunks(w);
+    const size_t per_window = (size_t)(w.giants - 1) * chunks;
+    const size_t per_key = per_window * (size_t)w.windows;
+    const u32 i = (u32)(lane / per_key);
+    if (i >= promote_live(hot) || plist[2 * i] == 0xFFFFFFFFu) return;
+    const size_t r = lane % per_key;
+    const u32 j = (u32)(r / per_window);
+    const size_t q = r % per_window;
+    const u32 gi = 1u + (u32)(q / chunks), c = (u32)(q % chunks);
+    widetab_fill_lane(w, gi, 1u + c * SBV_WIDETAB_T, wtab + (size_t)plist[2 * i + 1] * stride + (size_t)j * w.per_window);
+}
+__global__ __launch_bounds__(64) void k_promote_publish(const u32* __restrict__ plist, const u32* __restrict__ hot, u32* __restrict__ kwide) {
+    const u32 i = threadIdx.x;
+    if (i >= promote_live(hot)) return;
+    const u32 slot = plist[2 * i];
+    if (slot != 0xFFFFFFFFu) kwide[slot] = plist[2 * i + 1];
 }
 __global__ __launch_bounds__(256) void k_group_table_mark(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
                                                           const uint8_t* __restrict__ full, const uint8_t* __restrict__ needfill, u32 table_slots,
@@ -244,14 +293,27 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_GPHASE_WAVES) void k_gphase_s
 }
 
 // Q phase over the grouped list: windows [j0, j1) of the per-batch key combs.
-// Round 5: a wavefront whose lanes ALL belong to groups with a full table (full[group]) is served by the launches of the chunks
-// (NARROW = false: one addition per window, as before); any other wavefront — keys that got rows only, or a mix at the seam of two
-// runs — waits for the ONE launch after the last chunk (NARROW = true: windows 0..32 from babies and giants, two additions per
-// window).  Both instantiations evaluate the same predicate on the same data, so every lane is served exactly once.
-template <bool NARROW>
+// Round 5 — one instantiation per table class, every wavefront served by exactly one of them (all three evaluate the same predicate on
+// the same data):
+//   MODE 2 (wide)    ALL lanes' keys own a wide comb (hot cache slots, p256_group.h): u2 * Q in 17 additions from the 16-bit comb, ONE launch
+//                    right behind the G phase — it needs no table of this batch;
+//   MODE 0 (full)    otherwise, ALL lanes' keys own a full 8-bit comb: the launches of the chunks, one addition per window, as before;
+//   MODE 1 (narrow)  any other wavefront — a key with rows only, or a mix at the seam of two runs: ONE launch behind the last rows, windows
+//                    0..32 from the compact rows (babies and giants), two additions per window.
+// A lane whose key pointFromAffine refuses (or that has no slot) is "dead": rejected whatever is added, it never decides its wavefront's class.
+#define SBV_Q_FULL 0
+#define SBV_Q_NARROW 1
+#define SBV_Q_WIDE 2
+__device__ __forceinline__ int q_wave_class(bool dead, bool w, bool f) {
+    if (wave_all(dead)) return 3;
+    if (wave_all(dead || w)) return SBV_Q_WIDE;
+    if (wave_all(dead || w || f)) return SBV_Q_FULL;
+    return SBV_Q_NARROW;
+}
+template <int MODE>
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_keyed_q(Scratch s, GroupState g, const apt* __restrict__ ktab,
                                                                     const uint8_t* __restrict__ kvalid, const u32* __restrict__ tslot,
-                                                                    const uint8_t* __restrict__ full,
+                                                                    const uint8_t* __restrict__ full, const uint8_t* __restrict__ wide, widekeys wk, u32* __restrict__ wstat,
                                                                     u32 table_slots, u32* __restrict__ gacc,
                                                                     uint8_t* __restrict__ acc, int j0, int j1, int last) {
     if (g.sorted) {
@@ -270,19 +332,28 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
         const bool known = grp < group_count(g);
         const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
         const bool dead = !(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0;     // no slot, or a key that is no point: "reject" whatever is added
-        // a dead lane never drags its wavefront to the two-addition path: its verdict needs no table at all (the bit-flipped variants of the
-        // signers' keys sit in runs of a handful of lanes between the signers' own runs)
-        if (wave_all(dead || (known && full[known ? grp : 0u] != 0)) == NARROW) return;      // the other instantiation's wavefront
-        if (NARROW) {                                                              // statistics only: lanes served by the narrow pass
+        const int cls = q_wave_class(dead, !dead && wide[grp] != 0, !dead && full[grp] != 0);
+        if (cls == 3) { if (MODE == SBV_Q_FULL && last) acc[t] = 0; return; }                 // rejected without touching a table (there is none)
+        if (cls != MODE) return;                                                              // another instantiation's wavefront
+        if (MODE != SBV_Q_FULL) {                                                             // statistics only: lanes of the rows-only / the wide pass
             const unsigned long long am = __ballot(true);
-            if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)am) - 1u) atomicAdd(&g.counters[7], (u32)__popcll(am));
+            if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)am) - 1u) atomicAdd(MODE == SBV_Q_NARROW ? &g.counters[7] : wstat, (u32)__popcll(am));
         }
-        // a wavefront whose keys are all refused by pointFromAffine (or have no slot): rejected without touching a table (there is none)
-        if (wave_all(dead)) { if (last) acc[t] = 0; return; }
-        const bool v = qphase29_lane_sorted<NARROW>(s, t, L, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
+        if (MODE == SBV_Q_WIDE) {
+            u256 u2, r;
+            rec_load256(u2, s.rec, t, SBV_REC_U2);
+            xyzz R;
+            gacc29_load(R, gacc, s.cap, L);
+            wide_qphase29_point(R, u2, wk, dead ? 0u : wk.idx[ts]);                           // a dead lane of a wide wavefront walks comb 0: its verdict is false anyway
+            rec_load256(r, s.rec, t, SBV_REC_R);
+            acc[t] = !dead && s.rec[(size_t)t * SBV_REC_WORDS + SBV_REC_OK] != 0 && pt29_rx_matches(R, r) ? 1 : 0;
+            return;
+        }
+        const bool v = qphase29_lane_sorted<MODE == SBV_Q_NARROW>(s, t, L, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
         if (last) acc[t] = v ? 1 : 0;
         return;
     }
+    // compaction order (SBV_GROUP_SORT=0): no wide pass (the class kernel leaves wide[] empty)
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= g.counters[1]) return;
     const u32 t = g.grp_idx[L];
@@ -290,9 +361,10 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
     const bool known = grp < group_count(g);
     const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
     const bool dead = !(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0;
-    if (wave_all(dead || (known && full[known ? grp : 0u] != 0)) == NARROW) return;
-    if (wave_all(dead)) { if (last) acc[t] = 0; return; }
-    const bool v = qphase29_lane<NARROW>(s, t, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
+    const int cls = q_wave_class(dead, false, !dead && full[grp] != 0);
+    if (cls == 3) { if (MODE == SBV_Q_FULL && last) acc[t] = 0; return; }
+    if (cls != MODE || MODE == SBV_Q_WIDE) return;
+    const bool v = qphase29_lane<MODE == SBV_Q_NARROW>(s, t, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
     if (last) acc[t] = v ? 1 : 0;
 }
 
@@ -351,7 +423,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_group_coop(Scratch s, G
 // chain (four lanes per key / a few lanes per window / the rare ungrouped tuples), so the chains run beside each other and
 // beside the throughput kernels:
 //
-//   stream: prep | wait(split) { generic stage B over the ungrouped list, G phase } wait(tables c) Q-phase chunk c ... pack
+//   stream: prep | wait(split) { generic stage B over the ungrouped list, G phase } wide pass | wait(tables c) Q-phase chunk c ... pack
 //   side_a: insert assign cache | chain chunk 0 | chain chunk 1 | ...
 //   side_b:        wait(assign) classify keycheck sort | wait(chain c) rows + fill of chunk c   (odd chunks: side_t, if given)
 //
@@ -382,15 +454,23 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     // table classes (p256_group.h): the coop launch reads any entry of a row, so its batches (<= 2^15 tuples) fill every table
     const u32 full_min = coop ? 0u : b.full_min;
     const u32 table_slots = b.kc.cap + b.max_groups;
+    // hot keys (p256_group.h): only with the cache on, a pool to promote into and the key-sorted list
+    const bool hot_on = b.wtab && b.kwide && b.kc.enabled && g.sorted;
+    const HotKeys hk = {b.wtab, hot_on ? b.kwide : nullptr, b.khits, b.hot, b.plist, b.kc.cap, b.wide_cap, b.promote_min};
+    const widekeys wk = hot_on ? widekeys_make(b.wtab, b.kwide, SBV_HOT_BITS) : widekeys_none();
     hipError_t e;
 #define SBV_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
     // The side streams may not touch the group buffers before everything already enqueued on `stream` (the
     // previous batch's readers of those buffers) has run; ev_fork was recorded by the caller BEFORE stage A.
     SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_fork, 0));
+    // ... nor before the previous batch's promotions are published (side_b, behind that batch's verdicts): they read hot[] and plist,
+    // and this batch's wide pass reads the combs they write (an event never recorded yet waits for nothing)
+    if (hot_on) SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_promoted, 0));
     SBV_TRY(hipMemsetAsync(b.ht, 0, ((size_t)b.ht_mask + 1) * sizeof(u32), y.side_a));
     SBV_TRY(hipMemsetAsync(b.cnt, 0, n * sizeof(u32), y.side_a));
     SBV_TRY(hipMemsetAsync(b.counters, 0, SBV_GROUP_COUNTERS * sizeof(u32), y.side_a));
     if (g.sorted) SBV_TRY(hipMemsetAsync(b.gcount, 0, (size_t)b.max_groups * sizeof(u32), y.side_a));
+    if (hot_on) SBV_TRY(hipMemsetAsync(b.hot + 1, 0, 2 * sizeof(u32), y.side_a));        // promotions and wide-pass lanes of THIS batch
     const unsigned gn = (unsigned)((n + 255) / 256);
     const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
     hipLaunchKernelGGL(k_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
@@ -417,7 +497,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     }
     // table classes: after the exact counts (gcount survives the scan; the scatter moves gcursor only) and after the cache assigned the slots
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_cache, 0));
-    hipLaunchKernelGGL(k_group_table_class, dim3(64), dim3(256), 0, y.side_b, g, b.tslot, b.cold, b.kfull, table_slots, full_min, b.full, b.needfill);
+    hipLaunchKernelGGL(k_group_table_class, dim3(64), dim3(256), 0, y.side_b, g, b.tslot, b.cold, b.kfull, table_slots, full_min, b.full, b.needfill, hk, b.wide);
     SBV_TRY(hipEventRecord(y.ev_class, y.side_b));
     if (g.sorted) {
         const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
@@ -439,7 +519,14 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     } else {
         hipLaunchKernelGGL(k_gphase_generic, dim3(gv + gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, gv, (size_t)0, n);
     }
-    SBV_TRY(hipEventRecord(y.ev_generic, stream));         // the G phase is enqueued: the accumulators of the rows-only pass are final behind this event
+    SBV_TRY(hipEventRecord(y.ev_generic, stream));         // the G phase is enqueued: the accumulators of the rows-only and the wide pass are final behind this event
+    if (hot_on && !coop) {
+        // the wide pass: the wavefronts whose keys all own a wide comb — 17 additions from the 16-bit combs, no table of this batch needed:
+        // on `stream` right behind the G phase, while the side streams build the tables of the chunks' launches (on side_a it would
+        // stand in front of the chains of the batch's cold keys)
+        hipLaunchKernelGGL(k_verify_keyed_q<SBV_Q_WIDE>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
+                           table_slots, b.gacc, b.acc, 0, SBV_GTAB_WINDOWS, 1);
+    }
     // Chunks of windows: the chain on side_a, rows + fill on side_b (odd chunks on side_t), the Q phase on stream.
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [j_first, j_end)
@@ -473,17 +560,33 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
             // rows of every chunk (ev_tables of all chunks are ordered before this point on `stream`; side_a waits for them itself).
             SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_generic, 0));
             for (int cc = 0; cc < chunks; ++cc) SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_tables[cc], 0));
-            hipLaunchKernelGGL(k_verify_keyed_q<true>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, s, g, b.ntab, b.kvalid, b.tslot, b.full, table_slots, b.gacc,
-                               b.acc, 0, SBV_GTAB_WINDOWS, 1);
+            hipLaunchKernelGGL(k_verify_keyed_q<SBV_Q_NARROW>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, s, g, b.ntab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
+                               table_slots, b.gacc, b.acc, 0, SBV_GTAB_WINDOWS, 1);
             SBV_TRY(hipEventRecord(y.ev_narrow, y.side_a));
         }
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
-        hipLaunchKernelGGL(k_verify_keyed_q<false>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, table_slots, b.gacc, b.acc,
-                           j_first, j_end, last ? 1 : 0);
+        hipLaunchKernelGGL(k_verify_keyed_q<SBV_Q_FULL>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
+                           table_slots, b.gacc, b.acc, j_first, j_end, last ? 1 : 0);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
     if (!coop) SBV_TRY(hipStreamWaitEvent(stream, y.ev_narrow, 0));
     hipLaunchKernelGGL(k_group_table_mark, dim3(64), dim3(256), 0, stream, g, b.tslot, b.cold, b.full, b.needfill, table_slots, b.kfull);
+    if (hot_on) {
+        // promotions (p256_group.h: hot keys): which slots, and their base points, on `stream` (two tiny launches: the next batch may
+        // overwrite tslot and the per-batch tables); the builder and the publication on side_b, behind the caller's verdicts — the next
+        // batch's table classes are ordered behind them on that stream
+        hipLaunchKernelGGL(k_promote_select, dim3(64), dim3(256), 0, stream, g, b.tslot, b.kvalid, hk);
+        const widebuild wb = widebuild_make(SBV_HOT_BITS);
+        hipLaunchKernelGGL(k_promote_bases, dim3((SBV_PROMOTE_MAX * 2 * (u32)wb.windows + 63) / 64), dim3(64), 0, stream, b.plist, b.hot, b.ktab, b.pbases);
+        SBV_TRY(hipEventRecord(y.ev_promote, stream));
+        SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_promote, 0));
+        const size_t stride = gcomb_entries(SBV_HOT_BITS);
+        hipLaunchKernelGGL(k_promote_chains, dim3((SBV_PROMOTE_MAX * (u32)wb.windows * 2u + 63) / 64), dim3(64), 0, y.side_b, b.pbases, b.plist, b.hot, wb, stride, b.ptmp, b.wtab);
+        const size_t fill_lanes = (size_t)SBV_PROMOTE_MAX * wb.windows * (wb.giants - 1) * widebuild_fill_chunks(wb);
+        hipLaunchKernelGGL(k_promote_fill, dim3((unsigned)((fill_lanes + 255) / 256)), dim3(256), 0, y.side_b, b.plist, b.hot, wb, stride, b.wtab);
+        hipLaunchKernelGGL(k_promote_publish, dim3(1), dim3(64), 0, y.side_b, b.plist, b.hot, b.kwide);
+        SBV_TRY(hipEventRecord(y.ev_promoted, y.side_b));
+    }
     hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
 #undef SBV_TRY
     if (prof && prof_pairs) *prof_pairs = coop ? 1 : chunks;

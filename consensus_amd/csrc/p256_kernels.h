@@ -73,6 +73,15 @@ struct GroupBuffers {
     // [kc.cap + max_groups] what a table slot holds across batches; the per-key signature count from which a full table pays
     uint8_t *full = nullptr, *needfill = nullptr, *kfull = nullptr;
     u32 full_min = 256;
+    // hot keys (p256_group.h, round 5): wide combs of promoted cache slots and their bookkeeping; wtab == nullptr = off
+    apt* wtab = nullptr;          // [wide_cap][gcomb_entries(SBV_HOT_BITS)]
+    u32 *kwide = nullptr, *khits = nullptr;     // [kc.cap]
+    u32* hot = nullptr;           // [4] wide combs handed out | promotions of this batch | lanes of the wide pass | spare
+    u32* plist = nullptr;         // [2 x SBV_PROMOTE_MAX] (slot, wide index)
+    apt* pbases = nullptr;        // [SBV_PROMOTE_MAX][2 x 17] base points of the promotions under construction
+    u32* ptmp = nullptr;          // the builder's chain scratch for SBV_PROMOTE_MAX keys
+    uint8_t* wide = nullptr;      // [max_groups] this batch's groups that may take the wide pass
+    u32 wide_cap = 0, promote_min = 4096;
     size_t cap = 0;
     size_t gacc_cap = 0;        // the scratch capacity gacc was sized for
 };
@@ -96,6 +105,8 @@ struct GroupSync {
     hipEvent_t ev_fork = nullptr, ev_assign = nullptr, ev_split = nullptr, ev_generic = nullptr;
     hipEvent_t ev_cache = nullptr, ev_class = nullptr;       // P-256: table slots assigned (side_a) / table classes decided (side_b)
     hipEvent_t ev_narrow = nullptr;                          // P-256: the rows-only pass (side_a) is done
+    hipEvent_t ev_promote = nullptr;                         // P-256: this batch's promotions are selected (stream): side_b builds them
+    hipEvent_t ev_promoted = nullptr;                        // P-256: ... and published (side_b): the next batch's side_a waits for it
     hipEvent_t ev_bases[SBV_GROUP_MAX_CHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
     int chunks = 1;
     int sorted = 1;                 // key-sorted grouped list + XCD-aware Q phase (SBV_GROUP_SORT=0: the split's compaction order; the form the step falls back to when a batch has more groups than one LDS histogram holds)

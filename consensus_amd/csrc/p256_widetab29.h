@@ -82,6 +82,21 @@ SBV_HD void widetab_chain_role(const widebuild& w, const apt* B, const apt* C, i
     else widetab_chain_lane(C, w.giants, tmp, row + (w.babies - 1), w.babies);      // entry m = g * babies sits at index g * babies - 1
 }
 
+// Hot keys (p256_group.h): base point e of promotion i, gathered from the 8-bit comb of its cache slot.  e < W: B_j = 2^(16 j) Q = entry 1
+// of row 2 j; e >= W: C_j = 2^8 B_j = entry 1 of row 2 j + 1 (rows and full tables alike hold entry 1 of every row).  The top window
+// (j = 16) only ever serves its entry 1, the carry of the signed recoding of a scalar below 2^255; its giants are never read, and
+// C_16 = Q keeps every sum of the builder's fill there well defined (g Q = +- b 2^256 Q would need g = +- b (2^256 mod n) mod n, far
+// outside 1..127).  16-bit combs only (two 8-bit rows per window).
+SBV_HD void promote_base_lane(u32 i, u32 e, const u32* plist, const apt* ktab, apt* pbases) {
+    const u32 W = (257 + 16 - 1) / 16;          // 17
+    const u32 slot = plist[2 * i];
+    if (slot == 0xFFFFFFFFu) return;
+    const apt* tab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
+    const u32 j = e < W ? e : e - W;
+    const u32 row = e < W ? 2 * j : (j + 1 < W ? 2 * j + 1 : 0u);
+    pbases[(size_t)i * 2 * W + e] = tab[(size_t)row * SBV_GTAB_PER_WINDOW];
+}
+
 // entries m = g * babies + b for b = b0 .. b0 + SBV_WIDETAB_T - 1 (clipped to babies - 1) of one window, 1 <= g < giants
 SBV_HD void widetab_fill_lane(const widebuild& w, u32 g, u32 b0, apt* row) {
     const u32 b1 = b0 + SBV_WIDETAB_T - 1 < w.babies - 1 ? b0 + SBV_WIDETAB_T - 1 : w.babies - 1;

@@ -89,6 +89,8 @@ struct Context {
     // Ed25519 / secp256k1 steps (always full tables)
     u32 group_min_count = 0, group_max = 65536, group_full_min = 256;
     int group_sample_shift = SBV_GROUP_SAMPLE_SHIFT_DEFAULT;     // SBV_GROUP_SAMPLE_SHIFT (0..6): the P-256 default threshold's sampling rate
+    // hot keys (p256_group.h): wide combs for cache slots that keep being hit — how many (0 = off; 35.7 MB each) and from how many tuples on
+    u32 hot_keys = 1024, hot_min_hits = 4096;
     // persistent key-table caches, one per scheme (SBV_SCHEME_*: P-256, secp256k1, Ed25519; p256_group.h): on / off and
     // cached keys (270 KiB of HBM per ECDSA key, 384 KiB per Ed25519 key)
     bool kc_on[3] = {true, true, true};
@@ -143,6 +145,7 @@ struct Settings {
     bool kc_on[3] = {true, true, true}; u32 kc_caps[3] = {16384, 1024, 1024};
     int profiling = 0;
     int wide_bits = SBV_WIDE_BITS_AUTO; u32 wide_max = 64;          // sbv_p256_wide_keys; env SBV_KEYED_WIDE_BITS (0 = off, 1 = auto), SBV_KEYED_WIDE_MAX
+    u32 hot_keys = 1024, hot_min_hits = 4096;                       // sbv_p256_hot_keys; env SBV_HOT_KEYS (0 = off), SBV_HOT_MIN_HITS
 } g_settings;
 std::mutex g_set_mu;
 std::unique_ptr<Context> g_ctxs[kMaxDevices];
@@ -247,7 +250,7 @@ sbv::Scratch scratch_view(const Context& c) {
 
 std::vector<hipEvent_t*> group_events(Context& c) {
     sbv::GroupSync& y = c.gsync;
-    std::vector<hipEvent_t*> v = {&y.ev_fork, &y.ev_assign, &y.ev_split, &y.ev_generic, &y.ev_cache, &y.ev_class, &y.ev_narrow};
+    std::vector<hipEvent_t*> v = {&y.ev_fork, &y.ev_assign, &y.ev_split, &y.ev_generic, &y.ev_cache, &y.ev_class, &y.ev_narrow, &y.ev_promote, &y.ev_promoted};
     for (int i = 0; i < SBV_GROUP_MAX_CHUNKS; ++i) v.push_back(&y.ev_bases[i]);
     for (int i = 0; i < SBV_GROUP_MAX_CHUNKS; ++i) v.push_back(&y.ev_tables[i]);
     return v;
@@ -294,24 +297,36 @@ hipError_t key_cache_forget(sbv::KeyCache& kc) {
     return e;
 }
 
+// the P-256 cache was emptied: its slots' wide combs belong to nobody any more
+hipError_t hot_forget(sbv::GroupBuffers& b) {
+    if (!b.kwide) return hipSuccess;
+    hipError_t e = hipMemset(b.kwide, 0xFF, (size_t)b.kc.cap * sizeof(u32));
+    if (e == hipSuccess) e = hipMemset(b.khits, 0, (size_t)b.kc.cap * sizeof(u32));
+    if (e == hipSuccess) e = hipMemset(b.hot, 0, 4 * sizeof(u32));
+    return e;
+}
+
 // keep_pools: the comb pools and key-table caches of the three schemes depend on (cache capacity, max_groups) only — a batch larger
 // than any before regrows the per-tuple arrays and must leave every cached comb where it is
 void free_group_buffers(Context& c, bool keep_pools = false) {
     sbv::GroupBuffers& b = c.grp;
     void* ptrs[] = {b.ht, b.rep, b.cnt, b.slot_of, b.group_rep, b.counters, b.grp_idx, b.ung_idx, b.slots, b.jbases, b.bases, b.jstate, b.tmp, b.acc, b.gacc,
-                    b.gcount, b.grp_of, b.ung_cand, b.rec, b.tslot, b.cold, b.full, b.needfill};
+                    b.gcount, b.grp_of, b.ung_cand, b.rec, b.tslot, b.cold, b.full, b.needfill, b.wide};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     sbv::apt* const ktab = b.ktab;
     sbv::apt* const ntab = b.ntab;
     uint8_t* const kvalid = b.kvalid;
     uint8_t* const kfull = b.kfull;
     const sbv::KeyCache kc = b.kc;
+    const sbv::GroupBuffers old = b;                 // the hot-key pool travels with the other pools
     b = sbv::GroupBuffers();
     if (keep_pools) {
         b.ktab = ktab; b.ntab = ntab; b.kvalid = kvalid; b.kfull = kfull; b.kc = kc;
+        b.wtab = old.wtab; b.kwide = old.kwide; b.khits = old.khits; b.hot = old.hot; b.plist = old.plist; b.pbases = old.pbases; b.ptmp = old.ptmp;
+        b.wide_cap = old.wide_cap; b.promote_min = old.promote_min;
         return;
     }
-    void* pool[] = {ktab, ntab, kvalid, kfull, kc.ht, kc.keys, kc.count};
+    void* pool[] = {ktab, ntab, kvalid, kfull, kc.ht, kc.keys, kc.count, old.wtab, old.kwide, old.khits, old.hot, old.plist, old.pbases, old.ptmp};
     for (void* p : pool) if (p) (void)hipFree(p);
     if (c.edgrp.ktab) (void)hipFree(c.edgrp.ktab);
     if (c.edgrp.okb) (void)hipFree(c.edgrp.okb);
@@ -324,12 +339,14 @@ void free_group_buffers(Context& c, bool keep_pools = false) {
     c.k256pool = sbv::KeyPool();
 }
 
+bool wide_pool_fits(size_t extra_bytes);
 int ensure_group_buffers(Context& c, size_t n) {
     sbv::GroupBuffers& b = c.grp;
     if (b.cap >= n && b.max_groups == c.group_max && b.gacc_cap == c.cap && b.kc.cap == c.kc_caps[0]) {
         b.min_count = c.group_min_count ? c.group_min_count : SBV_GROUP_MIN_COUNT_DEFAULT;
         b.sample_shift = c.group_min_count ? -1 : c.group_sample_shift;
         b.full_min = c.group_full_min;
+        b.promote_min = c.hot_min_hits;
         b.kc.enabled = c.kc_on[0] ? 1u : 0u;
         return SBV_OK;
     }
@@ -372,7 +389,31 @@ int ensure_group_buffers(Context& c, size_t n) {
         HIP_TRY(SBV_EDEVICE, hipMemset(b.kfull, 0, K + G));
         const int krc = key_cache_alloc(b.kc, K, c.kc_on[0]);
         if (krc != SBV_OK) return krc;
+        // hot keys: the pool of wide combs for promoted cache slots (p256_group.h), as large as asked for if that leaves the reserve free
+        // (wide_pool_fits: 1024 keys x 35.7 MB = 36.5 GB of the 288), smaller or absent otherwise — verdicts never depend on it
+        b.wide_cap = 0;
+        if (c.hot_keys && K) {
+            const size_t per = sbv::gcomb_entries(SBV_HOT_BITS) * sizeof(sbv::apt);
+            size_t want = c.hot_keys;
+            while (want && !wide_pool_fits(want * per)) want /= 2;
+            if (want) {
+                const size_t W = (257 + SBV_HOT_BITS - 1) / SBV_HOT_BITS;
+                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.wtab, want * per));
+                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kwide, K * sizeof(u32)));
+                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.khits, K * sizeof(u32)));
+                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.hot, 4 * sizeof(u32)));
+                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.plist, 2 * SBV_PROMOTE_MAX * sizeof(u32)));
+                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.pbases, SBV_PROMOTE_MAX * 2 * W * sizeof(sbv::apt)));
+                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ptmp, sbv::widetab_tmp_words(SBV_PROMOTE_MAX, SBV_HOT_BITS) * sizeof(u32)));
+                HIP_TRY(SBV_EDEVICE, hipMemset(b.kwide, 0xFF, K * sizeof(u32)));
+                HIP_TRY(SBV_EDEVICE, hipMemset(b.khits, 0, K * sizeof(u32)));
+                HIP_TRY(SBV_EDEVICE, hipMemset(b.hot, 0, 4 * sizeof(u32)));
+                b.wide_cap = (u32)want;
+            }
+        }
     }
+    b.promote_min = c.hot_min_hits;
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&b.wide, G));
     b.kc.enabled = c.kc_on[0] ? 1u : 0u;
     {   // scratch of the table kernels: P-256 indexes it by resident lane (two table streams x SBV_TABLE_GRID_BLOCKS x 64 lanes x 675 words,
         // p256_group_kernels.hip), the Ed25519 step by (key, window): 128 x 40 raw limbs each, for the groups that step may hold
@@ -519,6 +560,7 @@ int enqueue(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hi
             // whose combs never were.  Forget the whole cache (best effort, after draining what did get enqueued).
             (void)hipDeviceSynchronize();
             (void)key_cache_forget(c.grp.kc);
+            (void)hot_forget(c.grp);
             return fail(SBV_EDEVICE, "launch_p256_verify_grouped", ge);
         }
         return SBV_OK;
@@ -673,7 +715,10 @@ int init_context(Context& c, int device) {
         for (int k = 0; k < 3; ++k) { c.kc_on[k] = g_settings.kc_on[k]; c.kc_caps[k] = g_settings.kc_caps[k]; }
         c.profiling = g_settings.profiling;
         c.kwide_auto = g_settings.wide_bits == SBV_WIDE_BITS_AUTO; c.kwide_bits = c.kwide_auto ? 20 : g_settings.wide_bits; c.kwide_max = g_settings.wide_max;
+        c.hot_keys = g_settings.hot_keys; c.hot_min_hits = g_settings.hot_min_hits;
     }
+    if (const char* e = getenv("SBV_HOT_KEYS")) { const long v = atol(e); if (v >= 0 && v <= 4096) c.hot_keys = (u32)v; }
+    if (const char* e = getenv("SBV_HOT_MIN_HITS")) { const long v = atol(e); if (v >= 1) c.hot_min_hits = (u32)v; }
     if (const char* e = getenv("SBV_KEYED_WIDE_BITS")) { const int v = atoi(e); if (v == 0) c.kwide_max = 0; else if (v == SBV_WIDE_BITS_AUTO) c.kwide_auto = true; else if (v >= 10 && v <= 20) { c.kwide_bits = v; c.kwide_auto = false; } }
     if (const char* e = getenv("SBV_KEYED_WIDE_MAX")) { const long v = atol(e); if (v >= 0 && v <= 4096) c.kwide_max = (u32)v; }
     if (const char* e = getenv("SBV_GROUP_SAMPLE_SHIFT")) { const int v = atoi(e); if (v >= 0 && v <= 6) c.group_sample_shift = v; }
@@ -1945,6 +1990,7 @@ extern "C" int sbv_key_cache(int scheme, int enabled, uint32_t capacity) {
             if (e == hipSuccess) e = hipDeviceSynchronize();
             kc.enabled = c.kc_on[scheme] ? 1u : 0u;
             if (e == hipSuccess && !c.kc_on[scheme]) e = key_cache_forget(kc);   // switching it off forgets everything: the next "on" starts cold
+            if (e == hipSuccess && !c.kc_on[scheme] && scheme == SBV_SCHEME_P256) e = hot_forget(c.grp);
             if (e != hipSuccess) rc = fail(SBV_EDEVICE, "sbv_key_cache", e);
         }
     }
@@ -2014,6 +2060,73 @@ extern "C" int sbv_p256_last_group_stats(uint32_t out[4]) {
     out[2] = h[2];
     out[3] = h[3];
     return SBV_OK;
+}
+
+extern "C" int sbv_p256_hot_keys(uint32_t max_keys, uint32_t min_hits) {
+    if (max_keys > 4096) return SBV_EINVAL;
+    {
+        std::lock_guard<std::mutex> lk(g_set_mu);
+        g_settings.hot_keys = max_keys;
+        if (min_hits) g_settings.hot_min_hits = min_hits;
+    }
+    int rc = SBV_OK;
+    for (Context* cp : live_contexts()) {
+        std::lock_guard<std::mutex> lk(cp->mu);
+        Context& c = *cp;
+        if (min_hits) c.hot_min_hits = min_hits;
+        if (c.hot_keys == max_keys) continue;
+        c.hot_keys = max_keys;
+        if (!c.ready || !c.grp.ktab) continue;
+        // another pool size: the comb pools are rebuilt (with the cache) by the next grouped batch
+        hipError_t e = hipSetDevice(c.device);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { rc = fail(SBV_EDEVICE, "sbv_p256_hot_keys", e); continue; }
+        free_group_buffers(c);
+    }
+    return rc;
+}
+
+extern "C" int sbv_p256_hot_key_stats(uint32_t out[4]) {
+    SBV_ENTER(c);
+    if (!c.ready) return SBV_ENOTINIT;
+    if (!out) return SBV_EINVAL;
+    out[0] = out[2] = 0;
+    out[1] = c.grp.wide_cap;
+    out[3] = c.hot_min_hits;
+    if (!c.grp.hot) return SBV_OK;
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    uint32_t h[4];
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(h, c.grp.hot, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = h[0] < c.grp.wide_cap ? h[0] : c.grp.wide_cap;
+    out[2] = h[2];
+    return SBV_OK;
+}
+
+// Diagnostics: is promoted comb number `index` what the host builder produces for its key?  Windows 0..15 byte for byte; of the top
+// window (the carry of the signed recoding) the babies, of which entry 1 is the only one ever read.  1 = equal, 0 = different.
+extern "C" int sbv_p256_hot_selfcheck(uint32_t index) {
+    SBV_ENTER(c);
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    sbv::GroupBuffers& b = c.grp;
+    if (!b.wtab || !b.kwide) { g_err = "no hot-key pool"; return SBV_EINVAL; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.device));
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    std::vector<u32> kw(b.kc.cap);
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(kw.data(), b.kwide, kw.size() * sizeof(u32), hipMemcpyDeviceToHost));
+    size_t slot = kw.size();
+    for (size_t i = 0; i < kw.size(); ++i) if (kw[i] == index) slot = i;
+    if (slot == kw.size()) { g_err = "sbv_p256_hot_selfcheck: no promoted key has this index"; return SBV_EINVAL; }
+    uint8_t key[64];
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(key, b.kc.keys + slot * 16, 64, hipMemcpyDeviceToHost));
+    const size_t stride = sbv::gcomb_entries(SBV_HOT_BITS), per = (size_t)1 << (SBV_HOT_BITS - 1);
+    std::vector<sbv::apt> want(stride), got(stride);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (!sbv::host_build_wide_key_table(key, SBV_HOT_BITS, want.data(), (int)(hw > 32 ? 32 : (hw ? hw : 1)))) return 0;
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(got.data(), b.wtab + (size_t)index * stride, stride * sizeof(sbv::apt), hipMemcpyDeviceToHost));
+    const size_t W = stride / per;                                            // 17
+    if (memcmp(got.data(), want.data(), (W - 1) * per * sizeof(sbv::apt)) != 0) return 0;
+    return memcmp(got.data() + (W - 1) * per, want.data() + (W - 1) * per, (((size_t)1 << (SBV_HOT_BITS / 2)) - 1) * sizeof(sbv::apt)) == 0 ? 1 : 0;
 }
 
 extern "C" int sbv_p256_last_table_classes(uint32_t out[3]) {

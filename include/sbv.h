@@ -252,6 +252,18 @@ int sbv_p256_last_group_stats(uint32_t out[4]);
  * batch, out[2] = grouped tuples served by the rows-only pass.  Verdicts never depend on the class.  Synchronises the device.
  * K arbitrary clients per proposal: internal/bft/view.go:553-559. */
 int sbv_p256_last_table_classes(uint32_t out[3]);
+/* Hot keys (round 5): wide combs in the GENERIC path.  A key that arrives inside tuples — a client key of VerifyProposal
+ * (internal/bft/view.go:553-559), a consenter of a replica that registered nothing — and keeps being hit is promoted: once the
+ * key-table cache has verified `min_hits` tuples against its slot, a 16-bit comb (35.7 MB; up to `max_keys` of them, default 1024 =
+ * 36.5 GB of the 288, less if the device lacks the room) is built on the device behind a batch's verdicts, at most 64 keys per batch,
+ * from base points the slot's 8-bit table already holds.  Later batches verify its tuples in 13 + 17 comb additions instead of
+ * 13 + 32, in one launch that needs no table of the batch.  Needs the key-table cache (on by default); verdicts never depend on it.
+ * max_keys = 0 switches it off; min_hits = 0 keeps the current value (default 4096).  Env: SBV_HOT_KEYS, SBV_HOT_MIN_HITS.
+ * stats: out[0] = promoted keys, out[1] = pool capacity, out[2] = tuples the wide pass served in the last grouped batch,
+ * out[3] = min_hits.  sbv_p256_hot_selfcheck(i) = 1 when promoted comb i equals the host builder's output for its key. */
+int sbv_p256_hot_keys(uint32_t max_keys, uint32_t min_hits);
+int sbv_p256_hot_key_stats(uint32_t out[4]);
+int sbv_p256_hot_selfcheck(uint32_t index);
 
 /* Page-locked host memory for the host-pointer entries.  Handing pageable memory to a 100 MB batch makes the HIP
  * runtime pin (or bounce) it inside the call — measured at 25 ms for a 550 000-signature replay batch whose kernels

@@ -145,6 +145,48 @@ static apt* g_kc_ntab = nullptr;            // compact rows of the cache's slots
 static std::vector<uint8_t> g_kc_full;       // kfull of the emulated P-256 key-table cache's slots (p256_group.h: table classes)
 static std::vector<uint8_t> g_kc_valid;
 static std::vector<u32> g_kc_ht, g_kc_keys, g_kc_count;
+// hot keys (p256_group.h): the wide-comb pool of the emulated cache, its per-slot index and hit counters, hot[] as on the device
+static u32 g_hot_cap = 0, g_hot_min = 4096;
+static apt* g_hot_wtab = nullptr;
+static std::vector<u32> g_hot_kwide, g_hot_khits;
+static u32 g_hot[4] = {0, 0, 0, 0};
+static void hot_reset() { g_hot_kwide.assign(g_kc.cap ? g_kc.cap : 1, SBV_WIDE_NONE); g_hot_khits.assign(g_kc.cap ? g_kc.cap : 1, 0); memset(g_hot, 0, sizeof g_hot); }
+void sbve_hot_keys(u32 cap, u32 min_hits) {       // after sbve_key_cache (which forgets the promotions, like the library)
+    free(g_hot_wtab);
+    g_hot_wtab = nullptr;
+    g_hot_cap = cap;
+    if (min_hits) g_hot_min = min_hits;
+    if (cap) {
+        g_hot_wtab = (apt*)aligned_alloc(64, (size_t)cap * gcomb_entries(SBV_HOT_BITS) * sizeof(apt));
+        memset((void*)g_hot_wtab, 0xA5, (size_t)cap * gcomb_entries(SBV_HOT_BITS) * sizeof(apt));        // an entry nobody wrote must not look like a point
+    }
+    hot_reset();
+}
+void sbve_hot_stats(u32 out[4]) { out[0] = g_hot[0] < g_hot_cap ? g_hot[0] : g_hot_cap; out[1] = g_hot_cap; out[2] = g_hot[2]; out[3] = g_hot_min; }
+// promoted comb `index` against the host builder (build_comb_window_of + apt_to_r261), as sbv_p256_hot_selfcheck compares: every entry
+// of windows 0..15, the babies of the top window.  Number of differing entries, or (size_t)-1 if nobody owns the index.
+size_t sbve_hot_comb_mismatches(u32 index) {
+    size_t slot = g_hot_kwide.size();
+    for (size_t i = 0; i < g_hot_kwide.size(); ++i) if (g_hot_kwide[i] == index) slot = i;
+    if (slot == g_hot_kwide.size() || !g_hot_wtab) return (size_t)-1;
+    u256 x, y;
+    from_be32(x, (const uint8_t*)&g_kc_keys[slot * 16]);
+    from_be32(y, (const uint8_t*)&g_kc_keys[slot * 16] + 32);
+    const widebuild w = widebuild_make(SBV_HOT_BITS);
+    const apt* tab = g_hot_wtab + (size_t)index * gcomb_entries(SBV_HOT_BITS);
+    std::vector<apt> want(w.per_window);
+    size_t bad = 0;
+    for (int j = 0; j < w.windows; ++j) {
+        build_comb_window_of(x, y, SBV_HOT_BITS, j, want.data());
+        const size_t lim = j + 1 < w.windows ? w.per_window : w.babies - 1;
+        for (size_t e = 0; e < lim; ++e) {
+            apt t;
+            apt_to_r261(t, want[e]);
+            if (memcmp(&t, &tab[(size_t)j * w.per_window + e], sizeof(apt)) != 0) ++bad;
+        }
+    }
+    return bad;
+}
 void sbve_key_cache(int enabled, u32 cap) {
     free(g_kc_ktab);
     g_kc_ktab = nullptr;
@@ -158,6 +200,7 @@ void sbve_key_cache(int enabled, u32 cap) {
     g_kc.ht = g_kc_ht.data(); g_kc.ht_mask = (u32)(ht - 1); g_kc.keys = g_kc_keys.data(); g_kc.count = g_kc_count.data();
     g_kc.cap = cap; g_kc.enabled = enabled && cap ? 1u : 0u;
     g_kc_full.assign(cap ? cap : 1, 0);
+    hot_reset();
 }
 void sbve_key_cache_stats(u32 out[3]) { out[0] = g_kc.count ? g_kc_count[0] : 0; out[1] = g_kc.count ? g_kc_count[1] : 0; out[2] = g_kc.count ? g_kc_count[2] : 0; }
 // the other two schemes' caches (sbv_key_cache(SBV_SCHEME_SECP256K1 / SBV_SCHEME_ED25519)): scheme 1 = secp256k1, 2 = Ed25519
@@ -295,14 +338,30 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     for (u32 k = 0; k < ngroups; ++k) group_table_class_lane(k, g, tslot.data(), cold.data(), kfull.data(), table_slots, full_min, full.data(), needfill.data());
     g_last_classes[0] = g_last_classes[1] = g_last_classes[2] = 0;
     for (u32 k = 0; k < ngroups; ++k) { g_last_classes[0] += full[k]; g_last_classes[1] += needfill[k]; }
+    // hot keys (k_group_table_class's second half): hits of the slots, and which groups may take the wide pass
+    const bool hot_on = g_hot_wtab && kc.enabled && g.sorted;
+    std::vector<uint8_t> wide(ng1, 0);
+    if (hot_on) {
+        if (g_hot_kwide.size() < kc.cap) hot_reset();
+        g_hot[1] = g_hot[2] = 0;
+        for (u32 k = 0; k < ngroups; ++k) group_hot_class_lane(k, g, tslot.data(), cold.data(), kc.cap, g_hot_kwide.data(), g_hot_khits.data(), wide.data());
+    }
+    const widekeys wk = hot_on ? widekeys_make(g_hot_wtab, g_hot_kwide.data(), SBV_HOT_BITS) : widekeys_none();
     // which lanes of the grouped list the chunk launches serve (wavefronts of 64 whose lanes ALL hold full tables) and which the narrow pass
-    std::vector<uint8_t> wave_full((counters[1] + 63) / 64 + 1, 1);
+    // (q_wave_class: 3 = every lane dead, 2 = wide pass, 0 = the chunks' launches, 1 = rows-only pass)
+    std::vector<uint8_t> wave_cls((counters[1] + 63) / 64 + 1, 3);
     auto decide_waves = [&] {            // the kernels decide at Q time: the first chunk of the chain has judged every cold key by then
+        std::vector<uint8_t> all_dead(wave_cls.size(), 1), all_w(wave_cls.size(), 1), all_f(wave_cls.size(), 1);
         for (u32 L = 0; L < counters[1]; ++L) {
             const u32 grp = g.sorted ? grp_of[L] : slots[grp_idx[L]];
             const bool dead = !(grp < ngroups) || !*valid_of(grp);        // no slot, or a key that is no point: never drags its wavefront to the narrow pass
-            if (!dead && !full[grp]) wave_full[L / 64] = 0;
+            if (dead) continue;
+            all_dead[L / 64] = 0;
+            const bool w = wide[grp] != 0;
+            if (!w) all_w[L / 64] = 0;
+            if (!w && !full[grp]) all_f[L / 64] = 0;
         }
+        for (size_t wv = 0; wv < wave_cls.size(); ++wv) wave_cls[wv] = all_dead[wv] ? 3 : (all_w[wv] ? 2 : (all_f[wv] ? 0 : 1));
     };
     memset(bitmap, 0, (n + 7) / 8);
     const int chunks = g_group_chunks;
@@ -356,7 +415,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             continue;
         }
         for (u32 L = 0; L < counters[1]; ++L) {                       // k_verify_keyed_q<false>: the wavefronts whose lanes all hold full tables
-            if (!wave_full[L / 64]) continue;
+            if (wave_cls[L / 64] != 0) continue;
             const u32 t = grp_idx[L];
             const u32 grp = g.sorted ? grp_of[L] : slots[t];
             if (grp < ngroups && !*valid_of(grp)) continue;           // a key that is no point has no table: rejected (the device computes on whatever the slot holds and drops the result)
@@ -380,7 +439,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
                     if (m > 8 && (m & 15) != 0) memset((void*)(tab + (size_t)j * SBV_GTAB_PER_WINDOW + m - 1), 0xA5, sizeof(apt));
         }
         for (u32 L = 0; L < counters[1]; ++L) {
-            if (wave_full[L / 64]) continue;
+            if (wave_cls[L / 64] != 1) continue;
             ++g_last_classes[2];
             const u32 t = grp_idx[L];
             const u32 grp = g.sorted ? grp_of[L] : slots[t];
@@ -393,9 +452,54 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             if (v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
         }
     }
+    if (hot_on && !(g_group_coop && g.sorted)) {
+        // k_verify_keyed_q<SBV_Q_WIDE>: the wavefronts whose live lanes all own a wide comb — u2 * Q from the 16-bit comb of the slot
+        for (u32 L = 0; L < counters[1]; ++L) {
+            if (wave_cls[L / 64] != 2) continue;
+            ++g_hot[2];
+            const u32 t = grp_idx[L];
+            const u32 grp = grp_of[L];
+            const u32 ts = grp < ngroups ? tslot[grp] : SBV_GROUP_NONE;
+            const bool dead = !(ts < table_slots) || !*valid_of(grp);
+            u256 u2, rr;
+            rec_load256(u2, s.rec, t, SBV_REC_U2);
+            rec_load256(rr, s.rec, t, SBV_REC_R);
+            xyzz R;
+            gacc29_load(R, gacc.data(), s.cap, L);
+            wide_qphase29_point(R, u2, wk, dead ? 0u : wk.idx[ts]);
+            if (!dead && s.rec[(size_t)t * SBV_REC_WORDS + SBV_REC_OK] != 0 && pt29_rx_matches(R, rr)) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+        }
+    }
     // k_group_table_mark: what the cache slots hold from now on
     for (u32 k = 0; k < ngroups; ++k) group_table_mark_lane(k, tslot.data(), cold.data(), full.data(), needfill.data(), table_slots, kfull.data());
     memcpy(g_kc_full.data(), kfull.data(), kc.cap);
+    if (hot_on) {
+        // promotions: k_promote_select -> _bases -> _chains -> _fill -> _publish, lane by lane (groups visited backwards: the order is free)
+        std::vector<u32> plist(2 * SBV_PROMOTE_MAX, 0xDEADBEEFu);
+        for (u32 k = ngroups; k-- > 0;)
+            group_promote_select_lane(k, tslot.data(), g_kc_valid.data(), kc.cap, g_hot_kwide.data(), g_hot_khits.data(), g_hot_min, g_hot_cap, g_hot, plist.data());
+        const u32 live = g_hot[1] < SBV_PROMOTE_MAX ? g_hot[1] : SBV_PROMOTE_MAX;
+        const widebuild w = widebuild_make(SBV_HOT_BITS);
+        const size_t stride = gcomb_entries(SBV_HOT_BITS);
+        std::vector<apt> pb((size_t)SBV_PROMOTE_MAX * 2 * w.windows);
+        memset((void*)pb.data(), 0xA5, pb.size() * sizeof(apt));
+        for (u32 i = 0; i < live; ++i)
+            for (u32 e = 0; e < 2u * w.windows; ++e) promote_base_lane(i, e, plist.data(), g_kc_ktab, pb.data());
+        std::vector<u32> tmpw((size_t)widebuild_chain_len(w) * SBV_WIDETAB_REC_WORDS);
+        const u32 fchunks = widebuild_fill_chunks(w);
+        for (u32 i = 0; i < live; ++i) {
+            if (plist[2 * i] == 0xFFFFFFFFu) continue;
+            const apt* kb = pb.data() + (size_t)i * 2 * w.windows;
+            apt* comb = g_hot_wtab + (size_t)plist[2 * i + 1] * stride;
+            for (int j = 0; j < w.windows; ++j)
+                for (int role = 1; role >= 0; --role) widetab_chain_role(w, kb + j, kb + w.windows + j, role, tmpw.data(), comb + (size_t)j * w.per_window);
+            for (int j = 0; j < w.windows; ++j)
+                for (u32 gi = 1; gi < w.giants; ++gi)
+                    for (u32 c = fchunks; c-- > 0;) widetab_fill_lane(w, gi, 1u + c * SBV_WIDETAB_T, comb + (size_t)j * w.per_window);
+        }
+        for (u32 i = 0; i < live; ++i)
+            if (plist[2 * i] != 0xFFFFFFFFu) g_hot_kwide[plist[2 * i]] = plist[2 * i + 1];
+    }
     u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB29_WORDS * 4);
     for (u32 L = 0; L < counters[2]; ++L) {
         const u32 t = ung_idx[L];

@@ -828,3 +828,74 @@ def test_table_classes_rows_only_full_and_upgrade(emul, oracle, golden_vectors):
         emul.sbve_key_cache(0, 0)
         emul.sbve_set_full_table_min(256)
         emul.sbve_set_group_chunks(3)
+
+
+def test_hot_keys_promotion_wide_pass_and_budget(emul, oracle, golden_vectors):
+    """Round 5, p256_group.h "hot keys": a cache slot whose hit count passes min_hits gets a 16-bit comb, built by the promote lanes
+    (p256_group_kernels.hip: k_promote_*) from base points gathered out of its 8-bit table; later batches verify its tuples in the
+    wide pass.  Cold -> warm -> promoted, a pool smaller than the demand (budget overflow: the third key keeps its 8-bit table), mixed
+    wavefronts (wide / full / rows-only keys and the golden edge vectors in one sorted list), the promoted combs byte for byte against
+    the host builder, and forgetting the promotions with the cache."""
+    emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    emul.sbve_key_cache.argtypes = [ctypes.c_int, ctypes.c_uint32]
+    emul.sbve_hot_keys.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    emul.sbve_hot_stats.argtypes = [ctypes.c_void_p]
+    emul.sbve_hot_comb_mismatches.argtypes = [ctypes.c_uint32]
+    emul.sbve_hot_comb_mismatches.restype = ctypes.c_size_t
+    emul.sbve_set_full_table_min.argtypes = [ctypes.c_uint32]
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    blob = b"".join(bytes.fromhex(v["tuple"]) for v in vs)
+    wblob = [v["accept"] for v in vs]
+    stats = (ctypes.c_uint32 * 4)()
+    hs = (ctypes.c_uint32 * 4)()
+
+    def batch(seed, n, nkeys):
+        tup = ctypes.create_string_buffer(160 * n)
+        exp = ctypes.create_string_buffer((n + 7) // 8)
+        oracle.sbvo_gen_batch(seed, n, nkeys, 6, tup, exp, 4)
+        return tup.raw, _bitmap_list(exp.raw, n)
+
+    def run(allt, want):
+        total = len(allt) // 160
+        bm = ctypes.create_string_buffer((total + 7) // 8)
+        emul.sbve_p256_verify_batch_grouped(allt, total, bm, 4, 256, 12, stats)
+        got = _bitmap_list(bm.raw, total)
+        assert got == want, [i for i in range(total) if got[i] != want[i]][:8]
+        emul.sbve_hot_stats(hs)
+        return list(hs)
+
+    hot, whot = batch(0xB1, 600, 3)             # 3 keys x 200 uses
+    luke, wluke = batch(0xB2, 300, 20)          # 20 keys x 15 uses: rows only
+    try:
+        emul.sbve_set_full_table_min(64)
+        emul.sbve_set_group_chunks(2)
+        emul.sbve_key_cache(1, 64)
+        emul.sbve_hot_keys(2, 300)              # a pool of two combs, promotion from 300 hits on
+        h = run(hot + luke, whot + wluke)       # cold: 200 hits per hot key
+        assert h[:3] == [0, 2, 0], h
+        h = run(hot, whot)                      # warm: 400 hits -> three keys ask, two combs exist
+        assert h[:3] == [2, 2, 0], h
+        assert emul.sbve_hot_comb_mismatches(0) == 0 and emul.sbve_hot_comb_mismatches(1) == 0
+        assert emul.sbve_hot_comb_mismatches(2) == ctypes.c_size_t(-1).value
+        h = run(hot, whot)                      # promoted: two of three keys' runs through the wide pass (minus the seams' wavefronts)
+        assert h[0] == 2 and 200 <= h[2] <= 400, h
+        # mixed wavefronts: wide, full (the third hot key), rows-only keys and the edge vectors (keys that are no point, r / s out of range ...)
+        for chunks in (1, 3):
+            emul.sbve_set_group_chunks(chunks)
+            h = run(luke[:160 * 150] + hot + blob + luke[160 * 150:], wluke[:150] + whot + wblob + wluke[150:])
+            assert h[0] == 2 and h[2] >= 128, h
+        h = run(hot[:160 * 90], whot[:90])      # a few tuples per promoted key: still the wide pass where a wavefront is all theirs
+        assert h[0] == 2
+        emul.sbve_key_cache(1, 64)              # the cache forgets its slots: so must the promotions
+        h = run(hot, whot)
+        assert h[:3] == [0, 2, 0], h
+        emul.sbve_hot_keys(0, 300)              # off: nothing is counted or promoted
+        for _ in range(3):
+            h = run(hot, whot)
+        assert h[:3] == [0, 0, 0], h
+    finally:
+        emul.sbve_hot_keys(0, 4096)
+        emul.sbve_key_cache(0, 0)
+        emul.sbve_set_full_table_min(256)
+        emul.sbve_set_group_chunks(3)

@@ -797,3 +797,79 @@ def test_table_classes_on_the_device(gpu, oracle, golden_vectors):
     finally:
         gpu.key_cache(True)
         gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
+
+
+def test_hot_keys_on_the_device(gpu, oracle, golden_vectors):
+    """Round 5, p256_group.h "hot keys": cache slots that keep being hit are promoted to 16-bit combs built on the
+    device, and later batches verify their tuples in the wide pass.  Cold -> warm -> promoted with a pool smaller than the demand
+    (budget overflow: 12 hot keys, 8 combs), the promoted combs byte for byte against the host builder (sbv_p256_hot_selfcheck), mixed
+    wavefronts (promoted keys, full 8-bit tables, rows-only keys, single-use keys and the golden edge vectors in one permuted batch),
+    promotions forgotten with the cache, and the feature off.  Every verdict == the generator's expectation / the pinned verdicts."""
+    import numpy as np
+    vs = [v for v in golden_vectors if v["kind"] == "tuple"]
+    gold = np.frombuffer(b"".join(bytes.fromhex(v["tuple"]) for v in vs), dtype=np.uint8).reshape(len(vs), 160)
+    gold_want = np.array([1 if v["accept"] else 0 for v in vs], dtype=np.uint8)
+
+    def gen(seed, n, nkeys, inv=7):
+        tup = ctypes.create_string_buffer(160 * n)
+        exp = ctypes.create_string_buffer((n + 7) // 8)
+        oracle.sbvo_gen_batch(seed, n, nkeys, inv, tup, exp, os.cpu_count() or 1)
+        return (np.frombuffer(tup, dtype=np.uint8).reshape(n, 160).copy(),
+                np.unpackbits(np.frombuffer(exp, dtype=np.uint8), bitorder="little")[:n].copy())
+
+    def run(t, want):
+        n = len(want)
+        got = ctypes.create_string_buffer((n + 7) // 8)
+        buf = np.ascontiguousarray(t).reshape(-1)
+        gpu.verify_batch_ptr(buf.ctypes.data, n, ctypes.addressof(got))
+        bits = np.unpackbits(np.frombuffer(got, dtype=np.uint8), bitorder="little")[:n]
+        bad = np.nonzero(bits != want)[0]
+        assert len(bad) == 0, bad[:8]
+        return gpu.hot_key_stats()
+
+    hot, whot = gen(0x61, 12 * 4096, 12)            # 12 keys x 4096 uses
+    mid, wmid = gen(0x62, 40 * 512, 40)             # full 8-bit tables, never hot enough
+    luke, wluke = gen(0x63, 1000 * 32, 1000)        # rows only
+    once, wonce = gen(0x64, 5000, 5000)             # the one-lane kernel
+    mix = np.concatenate([hot, mid, luke, once, gold])
+    wmix = np.concatenate([whot, wmid, wluke, wonce, gold_want])
+    perm = np.random.default_rng(6).permutation(len(wmix))
+    mix, wmix = mix[perm], wmix[perm]
+    try:
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
+        gpu.key_cache(False)
+        gpu.key_cache(True)                         # an empty cache
+        gpu.hot_keys(8, 6000)                       # a pool of 8 combs; promotion from 6000 hits on
+        h = run(hot, whot)                          # cold: 4096 hits per key
+        assert h[:3] == (0, 8, 0), h
+        h = run(mix, wmix)                          # warm: 8192 hits -> 12 keys ask at the end of this batch, 8 combs exist
+        assert h[1] == 8 and h[2] == 0, h
+        h = run(hot, whot)                          # promoted: 8 of the 12 keys' runs through the wide pass
+        assert h[0] == 8 and 8 * 4096 * 0.8 <= h[2] <= 8 * 4096, h      # (a corrupted key byte moves a tuple out of its signer's run)
+        for i in range(8):
+            assert gpu.hot_selfcheck(i), i
+        for _ in range(2):
+            h = run(mix, wmix)                      # mixed wavefronts, twice (nothing left to promote: the pool is full)
+            assert h[0] == 8 and h[2] >= 8 * 4096 * 0.75, h
+        small, wsmall = hot[:3000], whot[:3000]     # the latency form (k_group_coop) serves small batches: no wide pass, same verdicts
+        h = run(small, wsmall)
+        assert h[0] == 8, h
+        gpu.key_cache(False)                        # forgets the slots and with them the promotions
+        gpu.key_cache(True)
+        h = run(hot, whot)
+        assert h[:3] == (0, 8, 0), h
+        gpu.hot_keys(0, 0)                          # off
+        for _ in range(3):
+            h = run(hot, whot)
+        assert h[:3] == (0, 0, 0), h
+        gpu.hot_keys(1024, 4096)                    # the default: 12 hot keys all fit; promoted behind the second batch (a signer's run is a little short of 4096)
+        run(hot, whot)
+        run(hot, whot)
+        h = run(hot, whot)
+        assert h[0] == 12 and h[1] >= 12 and h[2] >= 12 * 4096 * 0.8, h
+        run(mix, wmix)
+        assert gpu.hot_selfcheck(11)
+    finally:
+        gpu.hot_keys(1024, 4096)
+        gpu.key_cache(True)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)

@@ -37,6 +37,10 @@ def worker(args):
     emul.sbve_ed25519_verify_batch.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p]
     emul.sbve_key_cache.argtypes = [ctypes.c_int, ctypes.c_uint32]
     emul.sbve_set_full_table_min.argtypes = [ctypes.c_uint32]
+    emul.sbve_hot_keys.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    emul.sbve_hot_stats.argtypes = [ctypes.c_void_p]
+    emul.sbve_hot_comb_mismatches.argtypes = [ctypes.c_uint32]
+    emul.sbve_hot_comb_mismatches.restype = ctypes.c_size_t
     emul.sbve_scheme_key_cache.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
     oracle.sbvo_k256_gen_batch.argtypes = gen_args
     rng = random.Random(0xF022 + wid)
@@ -126,10 +130,15 @@ def worker(args):
                 emul.sbve_set_group_chunks(rng.choice((1, 2, 3, 4)))
                 emul.sbve_set_group_coop(rng.choice((0, 0, 1)))
                 emul.sbve_key_cache(1 if cache else 0, 64)
+                # round 5, hot keys: a small pool of 16-bit combs (each costs the emulator about a second), promotion after the first or
+                # the second pass; the third pass verifies the promoted keys' tuples in the wide pass
+                hot = cache and rng.random() < 0.35
+                emul.sbve_hot_keys(rng.choice((1, 2, 3)) if hot else 0, rng.choice((40, 150, 400)))
             else:
+                hot = False
                 emul.sbve_set_k256_prep_t(rng.choice((1, 4, 8)))
                 emul.sbve_scheme_key_cache(1, 1 if cache else 0, 64)
-            for rep in range(2 if cache else 1):                      # with the cache: a cold pass, then a warm one over the same keys
+            for rep in range((3 if hot else 2) if cache else 1):      # with the cache: a cold pass, then a warm one over the same keys
                 bm = ctypes.create_string_buffer((n + 7) // 8)
                 if p256:
                     # round 5, table classes: rows only / full tables / a mix, and through the cache an upgrade (rows-only slot, then hot)
@@ -141,6 +150,15 @@ def worker(args):
                 if bm.raw != exp.raw:
                     out["mismatches"] += 1
                     out.setdefault("first", ["p256g" if p256 else "k256g", seed, n, nkeys, cache, rep])
+            if hot:
+                hs = (ctypes.c_uint32 * 4)()
+                emul.sbve_hot_stats(hs)
+                out["hot_promotions"] = out.get("hot_promotions", 0) + hs[0]
+                out["hot_wide_tuples"] = out.get("hot_wide_tuples", 0) + hs[2]
+                if hs[0] and emul.sbve_hot_comb_mismatches(hs[0] - 1) != 0:
+                    out["mismatches"] += 1
+                    out.setdefault("first", ["hot comb", seed, n, nkeys])
+                emul.sbve_hot_keys(0, 4096)
             if p256:
                 emul.sbve_key_cache(0, 64); emul.sbve_set_group_sort(1); emul.sbve_set_group_chunks(3); emul.sbve_set_group_coop(0)
             else:
