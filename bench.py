@@ -417,14 +417,15 @@ def leg_ed25519(sbv, torch, n, steps, stream, cpu=False):
     out = {"metric": "Ed25519 verifies/sec at batch=1M (configs[4])", "value": n * steps / dt, "unit": "verifies/s",
            "ms_per_step": 1e3 * dt / steps, "bitmap_correct": bool((got == expect).all()),
            "algorithmic_GBps": 128.125 * n * steps / dt / 1e9}
-    # k_ed_qphase: one launch per chunk of the 32 key-comb windows; a tuple's stage B is 16 additions from the comb of B (G phase)
-    # + 32 from the key's comb, so a launch executes (32 / launches per step) / 48 of it.  Lanes = every tuple of the batch but
+    # k_ed_qphase: one launch per chunk of the 32 key-comb windows; a tuple's stage B is 13 additions from the comb of B (G phase)
+    # + 32 from the key's comb, so a launch executes (32 / launches per step) / 45 of it.  Lanes = every tuple of the batch but
     # the few whose key repeats too rarely to be grouped (1024 keys x 1024 uses: none).
     per_step = max(1, int(round(dom_launches / max(1, steps))))
     _, lanes, n_ung, n_rej = sbv.last_group_stats()
     if lanes + n_ung + n_rej != n:
         lanes = n
-    out["roofline"] = variant_roofline("k_ed_qphase", 128.125, lanes, (32.0 / per_step) / 48.0, dom_us, dom_launches)
+    b_windows = -(-254 // int(os.environ.get("SBV_ED_B_BITS", "20")))      # additions of the G phase: 13 from the 20-bit comb of B (the default)
+    out["roofline"] = variant_roofline("k_ed_qphase", 128.125, lanes, (32.0 / per_step) / (32.0 + b_windows), dom_us, dom_launches)
     if cpu:
         out["cpu_baseline"] = cpu_baseline_variant("ed25519", tuples, n, got)
     try:

@@ -277,9 +277,17 @@ SBV_HD bool ed25519_verify_lane(Words w, u32* qtab, const aniels* btab) {
     return ok && ed_encoding_matches(R, renc);
 }
 
+// the grouped step's comb of B (ed25519_group.h: ed_add_sB_comb)
+struct edcomb { const aniels* tab; int bits; int windows; };
+SBV_HD int edcomb_windows(int bits) { return (254 + bits - 1) / bits; }
+SBV_HD size_t edcomb_entries(int bits) { return (size_t)edcomb_windows(bits) << (bits - 1); }
+SBV_HD edcomb edcomb_make(const aniels* tab, int bits) { edcomb c = {tab, bits, edcomb_windows(bits)}; return c; }
+
 // ---- base-point comb (host, once per init; also tests/emul) --------------------------------------------
-// window j (0..15) of the 16-bit comb, callable from several host threads
-inline void build_ed_b16_window(int j, aniels* out_row) {
+// window j of a `bits`-wide comb of B: out_row[k - 1] = k * 2^(bits j) * B for k = 1 .. 2^(bits-1), canonical affine-Niels entries.
+// Callable from several host threads; the row is produced in blocks of 32 768 entries (one inversion each) so that a 20-bit window
+// (524 288 entries) needs no more host memory than a 16-bit one.
+inline void build_ed_b_window(int bits, int j, aniels* out_row) {
     const u32 bxw[8] = {0x8F25D51Au, 0xC9562D60u, 0x9525A7B2u, 0x692CC760u, 0xFDD6DC5Cu, 0xC0A4E231u, 0xCD6E53FEu, 0x216936D3u};
     const u32 byw[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};
     fe25 bx, by;
@@ -288,35 +296,39 @@ inline void build_ed_b16_window(int j, aniels* out_row) {
     const fe25 d2 = fe25_2d();
     ept base;
     base.X = bx; base.Y = by; base.Z = fe25_one(); fe25_mul(base.T, bx, by);
-    for (int i = 0; i < 16 * j; ++i) ed_dbl(base, base);          // 2^(16j) * B, projective
+    for (int i = 0; i < bits * j; ++i) ed_dbl(base, base);          // 2^(bits j) * B, projective
     pniels bn;
     ed_to_pniels(bn, base);
-    const int n = SBV_ED_B16_PER_WINDOW;
-    fe25* X = new fe25[n]; fe25* Y = new fe25[n]; fe25* Z = new fe25[n]; fe25* pre = new fe25[n];
+    const size_t total = (size_t)1 << (bits - 1);
+    const size_t blk = total < 32768 ? total : 32768;
+    fe25* X = new fe25[blk]; fe25* Y = new fe25[blk]; fe25* Z = new fe25[blk]; fe25* pre = new fe25[blk];
     ept t = base;
-    fe25 acc = fe25_one();
-    for (int k = 0; k < n; ++k) {                                  // (k+1) * base, Z's multiplied up for Montgomery's trick
-        if (k > 0) ed_add_pniels(t, bn, false, false);
-        X[k] = t.X; Y[k] = t.Y; Z[k] = t.Z;
-        pre[k] = acc;
-        fe25_mul(acc, acc, t.Z);
-    }
-    fe25 inv;
-    fe25_inv(inv, acc);
-    for (int k = n - 1; k >= 0; --k) {
-        fe25 zi, x, y;
-        fe25_mul(zi, inv, pre[k]);
-        fe25_mul(inv, inv, Z[k]);
-        fe25_mul(x, X[k], zi);
-        fe25_mul(y, Y[k], zi);
-        aniels_r a;
-        fe25_add(a.ypx, y, x);
-        fe25_sub(a.ymx, y, x);
-        fe25_mul(a.xy2d, x, y);
-        fe25_mul(a.xy2d, a.xy2d, d2);
-        aniels_store(out_row + k, a);
+    for (size_t b0 = 0; b0 < total; b0 += blk) {
+        fe25 acc = fe25_one();
+        for (size_t k = 0; k < blk; ++k) {                           // (b0 + k + 1) * base, Z's multiplied up for Montgomery's trick
+            if (b0 + k > 0) ed_add_pniels(t, bn, false, false);
+            X[k] = t.X; Y[k] = t.Y; Z[k] = t.Z;
+            pre[k] = acc;
+            fe25_mul(acc, acc, t.Z);
+        }
+        fe25 inv;
+        fe25_inv(inv, acc);
+        for (size_t k = blk; k-- > 0;) {
+            fe25 zi, x, y;
+            fe25_mul(zi, inv, pre[k]);
+            fe25_mul(inv, inv, Z[k]);
+            fe25_mul(x, X[k], zi);
+            fe25_mul(y, Y[k], zi);
+            aniels_r a;
+            fe25_add(a.ypx, y, x);
+            fe25_sub(a.ymx, y, x);
+            fe25_mul(a.xy2d, x, y);
+            fe25_mul(a.xy2d, a.xy2d, d2);
+            aniels_store(out_row + b0 + k, a);
+        }
     }
     delete[] X; delete[] Y; delete[] Z; delete[] pre;
 }
+inline void build_ed_b16_window(int j, aniels* out_row) { build_ed_b_window(16, j, out_row); }
 
 }  // namespace sbv

@@ -201,8 +201,34 @@ SBV_HD void ed_gacc_load_tm(ept& R, const u32* gacc, size_t i) {
     for (int l = 0; l < 10; ++l) { R.X.v[l] = (i32)w[l]; R.Y.v[l] = (i32)w[10 + l]; R.Z.v[l] = (i32)w[20 + l]; R.T.v[l] = (i32)w[30 + l]; }
 }
 
-// [S]B (16-bit comb `btab`) for tuple i -> gacc; okb[i] = S < L and k < L (SetCanonicalBytes(S); a reduced k is always < L)
-SBV_HD void ed_gphase_lane(const uint8_t* tuples, size_t i, const aniels* btab, u32* gacc, size_t cap, uint8_t* okb, bool tuple_major = false) {
+// The grouped step's comb of B: `bits`-wide signed windows as the ECDSA steps' combs of G (p256_comb29.h: gcomb_recode / gcomb_digit),
+// tab[(j << (bits-1)) + (m-1)] = m * 2^(bits j) * B.  S < L < 2^253, so windows = ceil(254 / bits) keeps S + the recoding offsets
+// inside the windows: 16 additions at 16 bits (50 MB, also the one-lane kernel's table), 13 at 20 bits (654 MB; HBM holds 288 GB).
+// (struct edcomb: ed25519_core.h)
+// R += [S]B; the next entry is fetched one addition ahead
+SBV_HD void ed_add_sB_comb(ept& R, const u256& S, const edcomb& bc) {
+    u288 ss;
+    gcomb_recode(ss, S, bc.bits, bc.windows);
+    u32 idx; bool neg, skip;
+    gcomb_digit(ss, bc.bits, 0, idx, neg, skip);
+    raw_aniels cur;
+    raw_aniels_load(cur, bc.tab + idx);
+    SBV_NOUNROLL
+    for (int j = 0; j < bc.windows; ++j) {
+        const int jn = j + 1 < bc.windows ? j + 1 : bc.windows - 1;
+        u32 idxn; bool negn, skipn;
+        gcomb_digit(ss, bc.bits, jn, idxn, negn, skipn);
+        raw_aniels nxt;
+        raw_aniels_load(nxt, bc.tab + ((size_t)jn << (bc.bits - 1)) + idxn);
+        aniels_r e;
+        raw_aniels_unpack(e, cur);
+        ed_add_aniels(R, e, neg, skip);
+        cur = nxt; neg = negn; skip = skipn;
+    }
+}
+
+// [S]B (comb `bc`) for tuple i -> gacc; okb[i] = S < L and k < L (SetCanonicalBytes(S); a reduced k is always < L)
+SBV_HD void ed_gphase_lane(const uint8_t* tuples, size_t i, const edcomb& bc, u32* gacc, size_t cap, uint8_t* okb, bool tuple_major = false) {
     const u32* w = ed_tuple_words(tuples, i);
     u256 S, k;
     SBV_UNROLL
@@ -211,7 +237,7 @@ SBV_HD void ed_gphase_lane(const uint8_t* tuples, size_t i, const aniels* btab, 
     okb[i] = (lt256(S, L) && lt256(k, L)) ? 1 : 0;
     ept R;
     ed_set_ident(R);
-    ed_add_sB(R, S, btab);
+    ed_add_sB_comb(R, S, bc);
     if (tuple_major) ed_gacc_store_tm(gacc, i, R);
     else ed_gacc_store(gacc, cap, i, R);
 }

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_ed_keycheck(const uint8_t* __restrict__
 }
 
 // [S]B for every tuple of the batch
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_gphase(const uint8_t* __restrict__ tuples, size_t n, const aniels* __restrict__ btab,
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_gphase(const uint8_t* __restrict__ tuples, size_t n, edcomb btab,
                                                                   u32* __restrict__ gacc, size_t cap, uint8_t* __restrict__ okb, int tuple_major) {
     const size_t i = (size_t)blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (i < n) ed_gphase_lane(tuples, i, btab, gacc, cap, okb, tuple_major != 0);
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_ed_finish(const uint8_t* __restrict__ t
 }
 
 hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, const GroupBuffers& b, const EdGroupBuffers& eb,
-                                         u32* d_qtab, const aniels* d_btab, uint8_t* d_bitmap, hipStream_t stream,
+                                         u32* d_qtab, const aniels* d_btab, const edcomb& bcomb, uint8_t* d_bitmap, hipStream_t stream,
                                          const GroupSync& y, hipEvent_t* prof, int* prof_pairs) {
     if (n == 0) return hipSuccess;
     GroupState g;
@@ -179,8 +179,10 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     }
     SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
     // stream: the G phase needs nothing but the tuples
-    hipLaunchKernelGGL(k_ed_gphase, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, n, d_btab, b.gacc, b.gacc_cap, eb.okb, (int)g.sorted);
+    hipLaunchKernelGGL(k_ed_gphase, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, n, bcomb, b.gacc, b.gacc_cap, eb.okb, (int)g.sorted);
     SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
+    // (an uneven split — a first chunk of 6-12 windows so that the first Q launch starts earlier — was measured in round 5 and loses:
+    // 4.11-4.46 ms per cold 2^20 step against 4.08-4.12, profiles/r05/ab_ed_chunk0_r05m.jsonl)
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_ED_KEY_WINDOWS * c / chunks, j_end = SBV_ED_KEY_WINDOWS * (c + 1) / chunks;
         const int j_count = j_end - j_first;

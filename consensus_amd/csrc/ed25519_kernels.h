@@ -22,11 +22,12 @@ struct EdGroupBuffers {
 // Grouped step (ed25519_group.h).  `b` supplies the grouping arrays, jbases, tmp, acc and gacc (32 words per
 // tuple, stride b.gacc_cap); ev_fork of `y` must have been recorded on `stream` before the call.
 hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, const GroupBuffers& b, const EdGroupBuffers& eb,
-                                         u32* d_qtab, const aniels* d_btab, uint8_t* d_bitmap, hipStream_t stream,
+                                         u32* d_qtab, const aniels* d_btab, const edcomb& bcomb, uint8_t* d_bitmap, hipStream_t stream,
                                          const GroupSync& y, hipEvent_t* prof = nullptr, int* prof_pairs = nullptr);   // prof: 2 * chunks events, a pair around every k_ed_qphase launch
 // message front end: raw signatures / keys / messages -> 128-byte tuples on the device (sha512_dev.h)
 hipError_t launch_ed_msg_frontend(const uint8_t* d_sigs, const uint8_t* d_pks, const uint8_t* d_msgs, const u64* d_moff, size_t n,
                                   u32* d_tuples, hipStream_t stream);
 #define SBV_ED_KEYTAB_ENTRIES_PER_KEY 4096   // 32 windows x 128 entries (ed25519_group.h)
-void host_build_ed_b16(aniels* out);      // 16 x 32768 affine-Niels multiples of B: the comb the device kernels use
+void host_build_ed_b16(aniels* out);      // 16 x 32768 affine-Niels multiples of B: the comb of the one-lane kernel
+void host_build_ed_bcomb(int bits, aniels* out);   // edcomb_entries(bits) entries: the grouped step's comb (SBV_ED_B_BITS, default 20), one host thread per window
 }  // namespace sbv

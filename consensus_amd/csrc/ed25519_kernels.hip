@@ -93,4 +93,10 @@ void host_build_ed_b16(aniels* out) {
     for (auto& t : th) t.join();
 }
 
+void host_build_ed_bcomb(int bits, aniels* out) {
+    std::vector<std::thread> th;
+    for (int j = 0; j < edcomb_windows(bits); ++j) th.emplace_back([bits, j, out] { build_ed_b_window(bits, j, out + ((size_t)j << (bits - 1))); });
+    for (auto& t : th) t.join();
+}
+
 }  // namespace sbv

@@ -100,7 +100,9 @@ struct Context {
     uint8_t* d_msgs = nullptr; size_t msgs_cap = 0;
     uint8_t* d_sigs = nullptr; size_t sigs_cap = 0;
     uint64_t* d_moff = nullptr; uint64_t* d_soff = nullptr; size_t moff_cap = 0, soff_cap = 0;
-    sbv::aniels* d_btab = nullptr;      // Ed25519 base-point comb, built on first use
+    sbv::aniels* d_btab = nullptr;      // Ed25519 base-point comb (16 bits: the one-lane kernel's), built on first use
+    sbv::aniels* d_ed_bcomb = nullptr;  // the grouped step's wider comb of B (SBV_ED_B_BITS, default 20: 13 x 2^19 entries = 654 MB); == d_btab at 16 bits
+    int ed_bbits = 16;
     sbv::kapt* d_k256_gtab = nullptr;   // secp256k1 comb of G (17 x 32768 entries), built on first use
     sbv::kapt* d_k256_gcomb = nullptr;  // the grouped step's wider comb of G (SBV_K256_G_BITS, default 20: 13 x 2^19 entries), built on first use
     int k256_gbits = 16;
@@ -503,15 +505,17 @@ int ensure_k256_group_buffers(Context& c, size_t n) {
     return SBV_OK;
 }
 
+int ensure_ed_bcomb(Context& c);
 // one chunk (n <= cap) of Ed25519 tuples on `stream`: grouped step or the one-lane kernel
 int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bitmap, hipStream_t stream, hipEvent_t* dom = nullptr, int* dom_pairs = nullptr) {
     // with the scheme's key-table cache on, nearly every batch takes the grouped step (as for P-256: cached keys are grouped whatever
     // their count, and a cold batch leaves its combs behind); with it off the cold crossover applies
     if (c.group_enabled && n >= (c.kc_on[2] ? c.group_min_batch : c.group_min_batch_ed)) {
-        const int rc = ensure_ed_group_buffers(c, n);
+        int rc = ensure_ed_group_buffers(c, n);
         if (rc != SBV_OK) return rc;
+        if ((rc = ensure_ed_bcomb(c)) != SBV_OK) return rc;
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
-        const hipError_t ge = sbv::launch_ed25519_verify_grouped(d_tuples, n, variant_view(c, n), c.edgrp, c.d_qtab, c.d_btab, d_bitmap, stream, c.gsync, dom, dom_pairs);
+        const hipError_t ge = sbv::launch_ed25519_verify_grouped(d_tuples, n, variant_view(c, n), c.edgrp, c.d_qtab, c.d_btab, sbv::edcomb_make(c.d_ed_bcomb, c.ed_bbits), d_bitmap, stream, c.gsync, dom, dom_pairs);
         if (ge != hipSuccess) {          // a slot is published before its tables are built (see enqueue()): forget the cache
             (void)hipDeviceSynchronize();
             (void)key_cache_forget(c.edgrp.kc);
@@ -609,6 +613,8 @@ int ensure_key_capacity(Context& c, size_t want) {
     }
     if (c.d_kwidx) (void)hipFree(c.d_kwidx);
     c.d_kwidx = nw;
+    if (c.d_ed_bcomb && c.d_ed_bcomb != c.d_btab) (void)hipFree(c.d_ed_bcomb);
+    c.d_ed_bcomb = nullptr;
     if (c.d_btab) (void)hipFree(c.d_btab);
     c.d_btab = nullptr;
     if (c.d_k256_gcomb == c.d_k256_gtab) c.d_k256_gcomb = nullptr;      // 16-bit configuration: the grouped step borrows this table
@@ -814,6 +820,8 @@ int shutdown_context(Context& c) {
     c.d_gtab = nullptr;
     if (c.d_g16r) (void)hipFree(c.d_g16r);
     c.d_g16r = nullptr;
+    if (c.d_ed_bcomb && c.d_ed_bcomb != c.d_btab) (void)hipFree(c.d_ed_bcomb);
+    c.d_ed_bcomb = nullptr;
     if (c.d_btab) (void)hipFree(c.d_btab);
     c.d_btab = nullptr;
     if (c.d_k256_gcomb && c.d_k256_gcomb != c.d_k256_gtab) (void)hipFree(c.d_k256_gcomb);
@@ -1547,12 +1555,32 @@ extern "C" int sbv_p256_verify_batch_keyed(const uint8_t* rsh, const uint32_t* s
 }
 
 namespace {
+std::vector<sbv::aniels> g_h_ed_b16, g_h_ed_bcomb;     // built once per process, uploaded to each context on its first Ed25519 call
+std::once_flag g_ed_b16_once, g_ed_bcomb_once;
+int g_ed_bbits = 20;
 int ensure_ed_table(Context& c) {
     if (c.d_btab) return SBV_OK;
-    std::vector<sbv::aniels> h(SBV_ED_B16_ENTRIES);      // 16-bit comb of B: 50 MB, built by 16 host threads in ~0.2 s
-    sbv::host_build_ed_b16(h.data());
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_btab, h.size() * sizeof(sbv::aniels)));
-    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_btab, h.data(), h.size() * sizeof(sbv::aniels), hipMemcpyHostToDevice));
+    std::call_once(g_ed_b16_once, [] {
+        g_h_ed_b16.resize(SBV_ED_B16_ENTRIES);          // 16-bit comb of B: 50 MB, built by 16 host threads in ~0.2 s
+        sbv::host_build_ed_b16(g_h_ed_b16.data());
+    });
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_btab, g_h_ed_b16.size() * sizeof(sbv::aniels)));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_btab, g_h_ed_b16.data(), g_h_ed_b16.size() * sizeof(sbv::aniels), hipMemcpyHostToDevice));
+    return SBV_OK;
+}
+// the grouped step's comb of B (ed25519_group.h: edcomb)
+int ensure_ed_bcomb(Context& c) {
+    if (c.d_ed_bcomb) return SBV_OK;
+    std::call_once(g_ed_bcomb_once, [] {
+        if (const char* e = getenv("SBV_ED_B_BITS")) { const int v = atoi(e); if (v >= 12 && v <= 22) g_ed_bbits = v; }
+        if (g_ed_bbits == 16) return;                   // the one-lane kernel's table serves
+        g_h_ed_bcomb.resize(sbv::edcomb_entries(g_ed_bbits));
+        sbv::host_build_ed_bcomb(g_ed_bbits, g_h_ed_bcomb.data());
+    });
+    c.ed_bbits = g_ed_bbits;
+    if (g_ed_bbits == 16) { c.d_ed_bcomb = c.d_btab; return SBV_OK; }
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_ed_bcomb, g_h_ed_bcomb.size() * sizeof(sbv::aniels)));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_ed_bcomb, g_h_ed_bcomb.data(), g_h_ed_bcomb.size() * sizeof(sbv::aniels), hipMemcpyHostToDevice));
     return SBV_OK;
 }
 }  // namespace

@@ -781,6 +781,40 @@ static const aniels* btab() {
     }
     return g_btab;
 }
+// the grouped step's comb of B at another width (ed25519_group.h: edcomb; libsbv: SBV_ED_B_BITS, default 20).  The emulator's default
+// stays 16 (the one-lane table, no second build); tests switch to 12 / 13 / 19 / 20 bits
+static aniels* g_ed_bcomb = nullptr;
+static int g_ed_bbits = 16, g_ed_bbits_built = 0;
+void sbve_set_ed_b_bits(int bits) { if (bits >= 8 && bits <= 20) g_ed_bbits = bits; }
+static edcomb ed_bcomb() {
+    if (g_ed_bbits == 16) return edcomb_make(btab(), 16);
+    if (g_ed_bbits_built != g_ed_bbits) {
+        free(g_ed_bcomb);
+        g_ed_bcomb = (aniels*)aligned_alloc(64, sizeof(aniels) * edcomb_entries(g_ed_bbits));
+        std::vector<std::thread> th;
+        const int bits = g_ed_bbits;
+        for (int j = 0; j < edcomb_windows(bits); ++j) th.emplace_back([bits, j] { build_ed_b_window(bits, j, g_ed_bcomb + ((size_t)j << (bits - 1))); });
+        for (auto& t : th) t.join();
+        g_ed_bbits_built = bits;
+    }
+    return edcomb_make(g_ed_bcomb, g_ed_bbits);
+}
+// [S]B through the grouped step's comb walk (ed25519_group.h: ed_add_sB_comb) at the width set by sbve_set_ed_b_bits -> encode(R)
+void sbve_ed_comb_mul(const u32* s8, uint8_t out32[32]) {
+    u256 S;
+    memcpy(&S, s8, 32);
+    ept R;
+    ed_set_ident(R);
+    ed_add_sB_comb(R, S, ed_bcomb());
+    fe25 zi, x, y;
+    fe25_inv(zi, R.Z);
+    fe25_mul(x, R.X, zi);
+    fe25_mul(y, R.Y, zi);
+    u256 yw;
+    fe25_freeze(yw, y);
+    yw.v[7] |= (fe25_is_negative(x) ? 1u : 0u) << 31;
+    memcpy(out32, &yw, 32);
+}
 struct EdWords {
     const uint8_t* p;
     u32 operator[](int i) const { u32 v; memcpy(&v, p + 4 * i, 4); return v; }
@@ -827,7 +861,8 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     }
     const bool tm = g.sorted != 0;       // tuple-major accumulator records
     u32* gacc = (u32*)aligned_alloc(16, (size_t)SBV_ED_GACC_WORDS * cap * 4);
-    for (size_t i = 0; i < n; ++i) ed_gphase_lane(tuples, i, btab(), gacc, cap, okb.data(), tm);
+    const edcomb bc = ed_bcomb();
+    for (size_t i = 0; i < n; ++i) ed_gphase_lane(tuples, i, bc, gacc, cap, okb.data(), tm);
     const size_t ng1 = ngroups ? ngroups : 1;
     u32* jbases = (u32*)aligned_alloc(16, ng1 * SBV_ED_KEY_WINDOWS * SBV_ED_JBASE_DWORDS * 4);
     aniels* ktab = (aniels*)aligned_alloc(64, ng1 * SBV_ED_KEYTAB_ENTRIES * sizeof(aniels));

@@ -304,3 +304,46 @@ def test_openssl_batch_check_agrees_with_the_generator_and_the_oracle_verifier(o
     wrong_seed = ctypes.create_string_buffer((n + 7) // 8)
     openssl_check.sbvssl_ed25519_verify_gen_batch(seed + 1, tup.raw, 0, n, wrong_seed, 4)
     assert wrong_seed.raw == bytes((n + 7) // 8)                     # other messages: nothing verifies
+
+
+def test_comb_of_B_at_other_widths(emul, oracle, ed_vectors):
+    """Round 5: the grouped step's comb of B is `bits` wide (ed25519_group.h: edcomb; libsbv default 20 bits = 13 additions instead of
+    16).  [S]B through the comb walk == the big-int twin for edge scalars (0, 1, L - 1, 2^252, every digit at its extreme, the top window
+    alone) and random ones at 12, 13, 19 and 20 bits; the grouped emulation over the golden vectors + a seeded batch gives the same
+    bitmap at each width."""
+    import random
+    emul.sbve_set_ed_b_bits.argtypes = [ctypes.c_int]
+    emul.sbve_ed_comb_mul.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    emul.sbve_ed25519_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32,
+                                                       ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    rng = random.Random(0xB175)
+    blob = _tuples(ed_vectors)
+    m = 500
+    tup = ctypes.create_string_buffer(128 * m)
+    exp = ctypes.create_string_buffer((m + 7) // 8)
+    oracle.sbvo_ed25519_gen_batch(0xED26, m, 5, 4, tup, exp, 4)
+    allt = blob + tup.raw
+    total = len(allt) // 128
+    want = [v["accept"] for v in ed_vectors] + _bits(exp.raw, m)
+    try:
+        for bits in (12, 13, 19, 20, 16):
+            emul.sbve_set_ed_b_bits(bits)
+            half = 1 << (bits - 1)
+            windows = -(-254 // bits)
+            scalars = [0, 1, 2, ed.L - 1, ed.L - 2, 1 << 252, (1 << 252) - 1, (1 << 253) - 1,
+                       half, half - 1, half + 1, (1 << bits) - 1, 1 << bits,
+                       sum(half << (bits * j) for j in range(windows)) % (1 << 253),          # every digit -> 0 after the offset: skip everywhere
+                       sum((half - 1) << (bits * j) for j in range(windows)) % (1 << 253),     # every digit -1
+                       sum(((1 << bits) - 1) << (bits * j) for j in range(windows)) % (1 << 253),
+                       1 << (bits * (windows - 1)), (1 << 253) - (1 << (bits * (windows - 1)))]
+            scalars += [rng.randrange(1 << 253) for _ in range(24 if bits < 19 else 8)]
+            out = ctypes.create_string_buffer(32)
+            for sc in scalars:
+                emul.sbve_ed_comb_mul((ctypes.c_uint32 * 8)(*[(sc >> (32 * i)) & 0xFFFFFFFF for i in range(8)]), out)
+                assert out.raw == ed.encode(ed.pt_mul(sc, ed.B)), (bits, hex(sc))
+            bm = ctypes.create_string_buffer((total + 7) // 8)
+            emul.sbve_ed25519_verify_batch_grouped(allt, total, bm, 8, 64, 12, 2, 4, None)
+            got = _bits(bm.raw, total)
+            assert got == want, (bits, [i for i in range(total) if got[i] != want[i]][:8])
+    finally:
+        emul.sbve_set_ed_b_bits(16)
