@@ -297,17 +297,19 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_GPHASE_WAVES) void k_gphase_s
 // the same data):
 //   MODE 2 (wide)    ALL lanes' keys own a wide comb (hot cache slots, p256_group.h): u2 * Q in 17 additions from the 16-bit comb, ONE launch
 //                    right behind the G phase — it needs no table of this batch;
-//   MODE 0 (full)    otherwise, ALL lanes' keys own a full 8-bit comb: the launches of the chunks, one addition per window, as before;
+//   MODE 0 (full)    otherwise, ALL lanes' keys own a full 8-bit comb (wide or not): the launches of the chunks, one addition per window, as before;
 //   MODE 1 (narrow)  any other wavefront — a key with rows only, or a mix at the seam of two runs: ONE launch behind the last rows, windows
 //                    0..32 from the compact rows (babies and giants), two additions per window.
 // A lane whose key pointFromAffine refuses (or that has no slot) is "dead": rejected whatever is added, it never decides its wavefront's class.
 #define SBV_Q_FULL 0
 #define SBV_Q_NARROW 1
 #define SBV_Q_WIDE 2
+// (a key with a wide comb keeps its 8-bit table, FULL OR ROWS ONLY — promotion does not ask which: in a mixed wavefront it counts as
+// what that table is)
 __device__ __forceinline__ int q_wave_class(bool dead, bool w, bool f) {
     if (wave_all(dead)) return 3;
     if (wave_all(dead || w)) return SBV_Q_WIDE;
-    if (wave_all(dead || w || f)) return SBV_Q_FULL;
+    if (wave_all(dead || f)) return SBV_Q_FULL;
     return SBV_Q_NARROW;
 }
 template <int MODE>

@@ -196,7 +196,10 @@ void sbve_key_cache(int enabled, u32 cap) {
     size_t ht = 16;
     while (ht < 4 * (size_t)(cap ? cap : 1)) ht *= 2;
     g_kc_ht.assign(ht, 0); g_kc_keys.assign((size_t)(cap ? cap : 1) * 16, 0); g_kc_count.assign(4, 0); g_kc_valid.assign(cap ? cap : 1, 0);
-    if (cap) g_kc_ktab = (apt*)aligned_alloc(64, (size_t)cap * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW * sizeof(apt));
+    if (cap) {
+        g_kc_ktab = (apt*)aligned_alloc(64, (size_t)cap * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW * sizeof(apt));
+        memset((void*)g_kc_ktab, 0xA5, (size_t)cap * SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW * sizeof(apt));     // an entry nobody wrote must not look like a point (nor like the table an earlier cache held there)
+    }
     g_kc.ht = g_kc_ht.data(); g_kc.ht_mask = (u32)(ht - 1); g_kc.keys = g_kc_keys.data(); g_kc.count = g_kc_count.data();
     g_kc.cap = cap; g_kc.enabled = enabled && cap ? 1u : 0u;
     g_kc_full.assign(cap ? cap : 1, 0);
@@ -359,12 +362,23 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             all_dead[L / 64] = 0;
             const bool w = wide[grp] != 0;
             if (!w) all_w[L / 64] = 0;
-            if (!w && !full[grp]) all_f[L / 64] = 0;
+            if (!full[grp]) all_f[L / 64] = 0;               // a promoted key's 8-bit table may be rows only: in a mixed wavefront it counts as what it is
         }
         for (size_t wv = 0; wv < wave_cls.size(); ++wv) wave_cls[wv] = all_dead[wv] ? 3 : (all_w[wv] ? 2 : (all_f[wv] ? 0 : 1));
     };
     memset(bitmap, 0, (n + 7) / 8);
     const int chunks = g_group_chunks;
+    // entries the fill never wrote must not be read by ANY pass: poison them in the warm rows-only tables before the first launch (the
+    // cold ones sit in memory that was poisoned when it was allocated), so that a stray read shows as a wrong verdict
+    auto poison_unfilled = [&](u32 k) {
+        apt* tab = table_of(k);
+        for (int j = 0; j < SBV_GTAB_WINDOWS - 1; ++j)
+            for (int m = 1; m <= SBV_GTAB_PER_WINDOW; ++m)
+                if (m > 8 && (m & 15) != 0) memset((void*)(tab + (size_t)j * SBV_GTAB_PER_WINDOW + m - 1), 0xA5, sizeof(apt));
+    };
+    if (!(g_group_coop && g.sorted))
+        for (u32 k = 0; k < ngroups; ++k)
+            if (!cold[k] && !full[k] && tslot[k] < table_slots) poison_unfilled(k);
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;
         for (u32 k = 0; k < ngroups; ++k)

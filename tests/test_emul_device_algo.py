@@ -890,6 +890,26 @@ def test_hot_keys_promotion_wide_pass_and_budget(emul, oracle, golden_vectors):
         emul.sbve_key_cache(1, 64)              # the cache forgets its slots: so must the promotions
         h = run(hot, whot)
         assert h[:3] == [0, 2, 0], h
+        # a promoted key whose 8-bit table holds ROWS ONLY (no batch gave it full_min uses) in a wavefront it shares with a full-table
+        # key that owns no wide comb: its lanes must go through the rows-only pass, never through the chunks' launches (found by the GPU
+        # tier in round 5: a 2^18-tuple piece holds 256 +- a few tuples per signer, the line between the classes)
+        emul.sbve_key_cache(1, 64)
+        emul.sbve_set_full_table_min(10**6)     # nobody earns a full table ...
+        emul.sbve_hot_keys(3, 300)
+        for _ in range(2):
+            run(hot, whot)                      # ... and the three hot keys are promoted with rows only
+        assert list(hs)[0] == 3
+        solo, wsolo = batch(0xB3, 100, 1)       # one more key, 100 tuples: a full table from now on, no wide comb (the pool is spent)
+        emul.sbve_set_full_table_min(64)
+        for chunks in (1, 2, 3):
+            emul.sbve_set_group_chunks(chunks)
+            for cut in (60, 90):                # ~20 / ~30 tuples per promoted key: below full_min, their cached tables stay rows only
+                h = run(hot[:160 * cut] + solo, whot[:cut] + wsolo)
+                assert h[0] == 3, h
+                h = run(solo + hot[:160 * cut], wsolo + whot[:cut])
+        emul.sbve_set_full_table_min(64)
+        emul.sbve_key_cache(1, 64)
+        emul.sbve_hot_keys(2, 300)
         emul.sbve_hot_keys(0, 300)              # off: nothing is counted or promoted
         for _ in range(3):
             h = run(hot, whot)

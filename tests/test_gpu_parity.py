@@ -858,6 +858,21 @@ def test_hot_keys_on_the_device(gpu, oracle, golden_vectors):
         gpu.key_cache(True)
         h = run(hot, whot)
         assert h[:3] == (0, 8, 0), h
+        # promoted keys whose 8-bit tables hold ROWS ONLY (200 uses per batch: a full table takes 256) next to full-table keys without a
+        # wide comb: a wavefront that mixes them belongs to the rows-only pass.  (The first full run of the tier with hot keys on found the
+        # chunks' launches reading unfilled entries here; the emulator test of the same name now holds the scenario too.)  Batches above
+        # 2^15 tuples: the latency form fills every table.
+        gpu.hot_keys(64, 600)
+        rows, wrows = gen(0x65, 200 * 200, 200)
+        for _ in range(6):                          # ~188 hits per key and batch: promoted behind the fourth, the wide pass from the fifth on
+            h = run(rows, wrows)
+        assert h[0] == 64 and h[2] > 0, h
+        solo, wsolo = gen(0x66, 20 * 400, 20)
+        both, wboth = np.concatenate([rows, solo]), np.concatenate([wrows, wsolo])
+        for seed in (1, 2, 3):
+            perm2 = np.random.default_rng(seed).permutation(len(wboth))
+            h = run(both[perm2], wboth[perm2])
+            assert h[0] == 64, h
         gpu.hot_keys(0, 0)                          # off
         for _ in range(3):
             h = run(hot, whot)
