@@ -425,9 +425,9 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_group_coop(Scratch s, G
 // chain (four lanes per key / a few lanes per window / the rare ungrouped tuples), so the chains run beside each other and
 // beside the throughput kernels:
 //
-//   stream: prep | wait(split) { generic stage B over the ungrouped list, G phase } wide pass | wait(tables c) Q-phase chunk c ... pack
-//   side_a: insert assign cache | chain chunk 0 | chain chunk 1 | ...
-//   side_b:        wait(assign) classify keycheck sort | wait(chain c) rows + fill of chunk c   (odd chunks: side_t, if given)
+//   stream: prep | wait(split) { generic stage B over the ungrouped list, G phase } wait(tables c) Q-phase chunk c ... pack
+//   side_a: insert assign cache | chain chunk 0 | chain chunk 1 | ... | wait(G phase) wide pass
+//   side_b:        wait(assign) classify keycheck sort | wait(chain c) rows + fill of chunk c   (odd chunks: side_t, if given) | rows-only pass | promotions
 //
 // Forms that were built, measured and rejected in rounds 2-4 are no longer in the library (DESIGN.md section 7 keeps the
 // numbers): stage A + G phase in slices, table pieces finer than the Q chunks, an uneven first chunk, one lane per table entry,
@@ -522,13 +522,6 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         hipLaunchKernelGGL(k_gphase_generic, dim3(gv + gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, s, n, g, d_qtab, d_g16, d_g16r, b.gacc, b.acc, gv, (size_t)0, n);
     }
     SBV_TRY(hipEventRecord(y.ev_generic, stream));         // the G phase is enqueued: the accumulators of the rows-only and the wide pass are final behind this event
-    if (hot_on && !coop) {
-        // the wide pass: the wavefronts whose keys all own a wide comb — 17 additions from the 16-bit combs, no table of this batch needed:
-        // on `stream` right behind the G phase, while the side streams build the tables of the chunks' launches (on side_a it would
-        // stand in front of the chains of the batch's cold keys)
-        hipLaunchKernelGGL(k_verify_keyed_q<SBV_Q_WIDE>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
-                           table_slots, b.gacc, b.acc, 0, SBV_GTAB_WINDOWS, 1);
-    }
     // Chunks of windows: the chain on side_a, rows + fill on side_b (odd chunks on side_t), the Q phase on stream.
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_GTAB_WINDOWS * c / chunks, j_end = SBV_GTAB_WINDOWS * (c + 1) / chunks;   // [j_first, j_end)
@@ -540,6 +533,16 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         hipLaunchKernelGGL(k_keytab29_chain, dim3(bounded((size_t)b.max_groups * 4)), dim3(64), 0, y.side_a, d_tuples, g, b.jstate, b.bases,
                            b.kvalid, b.tslot, b.cold, j_first, j_end - 1, 0x11u);
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
+        if (hot_on && !coop && c + 1 == chunks) {
+            // The wide pass: the wavefronts whose keys all own a wide comb — 17 additions from the 16-bit combs, no table of this batch
+            // needed.  On side_a behind the LAST chain (in front of them it would hold up the tables of the batch's cold keys; on
+            // `stream` it ran before the chunks' launches instead of beside them: with a quarter of the lanes wide it is a 0.87 ms
+            // latency chain at low occupancy, timeline_hot_4096_r05q.txt), as soon as the G phase is done.
+            SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_generic, 0));
+            hipLaunchKernelGGL(k_verify_keyed_q<SBV_Q_WIDE>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
+                               table_slots, b.gacc, b.acc, 0, SBV_GTAB_WINDOWS, 1);
+            SBV_TRY(hipEventRecord(y.ev_wide, y.side_a));
+        }
         SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[c], 0));
         if (on_t) SBV_TRY(hipStreamWaitEvent(tb, y.ev_class, 0));      // side_b has it in stream order
         hipLaunchKernelGGL(k_keytab29_rows, dim3(bounded((size_t)b.max_groups * j_count * 2)), dim3(64), 0, tb, g, b.bases, ttmp, b.ktab, b.ntab, b.tslot, b.cold, b.kvalid, j_first, j_count);
@@ -558,13 +561,13 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         }
         if (last) {
             // The wavefronts with a key that has rows only: all 33 windows, two additions per window — a ~60-addition chain per lane.
-            // On side_a (idle once the chains are done), BESIDE the last chunk's launch instead of behind it: needs the G phase and the
-            // rows of every chunk (ev_tables of all chunks are ordered before this point on `stream`; side_a waits for them itself).
-            SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_generic, 0));
-            for (int cc = 0; cc < chunks; ++cc) SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_tables[cc], 0));
-            hipLaunchKernelGGL(k_verify_keyed_q<SBV_Q_NARROW>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, s, g, b.ntab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
+            // On side_b (idle once the last fill is done), BESIDE the last chunk's launch instead of behind it: needs the G phase and
+            // the rows of every chunk (side_b has its own in stream order and waits for the other table stream's).
+            SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_generic, 0));
+            for (int cc = 0; cc < chunks; ++cc) SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_tables[cc], 0));
+            hipLaunchKernelGGL(k_verify_keyed_q<SBV_Q_NARROW>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_b, s, g, b.ntab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
                                table_slots, b.gacc, b.acc, 0, SBV_GTAB_WINDOWS, 1);
-            SBV_TRY(hipEventRecord(y.ev_narrow, y.side_a));
+            SBV_TRY(hipEventRecord(y.ev_narrow, y.side_b));
         }
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
         hipLaunchKernelGGL(k_verify_keyed_q<SBV_Q_FULL>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
@@ -572,6 +575,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
     if (!coop) SBV_TRY(hipStreamWaitEvent(stream, y.ev_narrow, 0));
+    if (hot_on && !coop) SBV_TRY(hipStreamWaitEvent(stream, y.ev_wide, 0));
     hipLaunchKernelGGL(k_group_table_mark, dim3(64), dim3(256), 0, stream, g, b.tslot, b.cold, b.full, b.needfill, table_slots, b.kfull);
     if (hot_on) {
         // promotions (p256_group.h: hot keys): which slots, and their base points, on `stream` (two tiny launches: the next batch may

@@ -106,6 +106,7 @@ struct GroupSync {
     hipEvent_t ev_cache = nullptr, ev_class = nullptr;       // P-256: table slots assigned (side_a) / table classes decided (side_b)
     hipEvent_t ev_narrow = nullptr;                          // P-256: the rows-only pass (side_a) is done
     hipEvent_t ev_promote = nullptr;                         // P-256: this batch's promotions are selected (stream): side_b builds them
+    hipEvent_t ev_wide = nullptr;                            // P-256: the wide pass (side_a) is done
     hipEvent_t ev_promoted = nullptr;                        // P-256: ... and published (side_b): the next batch's side_a waits for it
     hipEvent_t ev_bases[SBV_GROUP_MAX_CHUNKS] = {}, ev_tables[SBV_GROUP_MAX_CHUNKS] = {};
     int chunks = 1;

@@ -252,7 +252,7 @@ sbv::Scratch scratch_view(const Context& c) {
 
 std::vector<hipEvent_t*> group_events(Context& c) {
     sbv::GroupSync& y = c.gsync;
-    std::vector<hipEvent_t*> v = {&y.ev_fork, &y.ev_assign, &y.ev_split, &y.ev_generic, &y.ev_cache, &y.ev_class, &y.ev_narrow, &y.ev_promote, &y.ev_promoted};
+    std::vector<hipEvent_t*> v = {&y.ev_fork, &y.ev_assign, &y.ev_split, &y.ev_generic, &y.ev_cache, &y.ev_class, &y.ev_narrow, &y.ev_promote, &y.ev_promoted, &y.ev_wide};
     for (int i = 0; i < SBV_GROUP_MAX_CHUNKS; ++i) v.push_back(&y.ev_bases[i]);
     for (int i = 0; i < SBV_GROUP_MAX_CHUNKS; ++i) v.push_back(&y.ev_tables[i]);
     return v;

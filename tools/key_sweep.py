@@ -26,4 +26,7 @@ for p in res["points"]:
         p["keys"], p["cold"]["verifies_per_s"] / 1e6, p["cold"]["ms"], p["cold"]["groups"], p["cold"]["tuples_through_tables"], p["cold"]["tuples_one_lane_kernel"],
         p["warm"]["verifies_per_s"] / 1e6, p["warm"]["ms"], p["warm"]["groups"], p["warm"]["tuples_through_tables"],
         p["cold"]["bitmap_correct"] and p["warm"]["bitmap_correct"]), file=sys.stderr)
+    if "hot" in p:
+        print("              hot  %7.1f M/s %7.2f ms (promoted %5d, wide-pass tuples %8d)  ok %s" % (
+            p["hot"]["verifies_per_s"] / 1e6, p["hot"]["ms"], p["hot"]["promoted_keys"], p["hot"]["tuples_through_the_wide_pass"], p["hot"]["bitmap_correct"]), file=sys.stderr)
 print(json.dumps(res))
