@@ -154,6 +154,8 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
 #define SBV_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
     // ev_fork was recorded by the caller on `stream` before anything of this batch (see the P-256 launcher)
     SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_fork, 0));
+    // the P-256 step's tail (table marks, promotion select: p256_group_kernels.hip) reads tslot / cold, which this scheme's grouping shares
+    SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_promoted, 0));
     SBV_TRY(hipMemsetAsync(b.ht, 0, ((size_t)b.ht_mask + 1) * sizeof(u32), y.side_a));
     SBV_TRY(hipMemsetAsync(b.cnt, 0, n * sizeof(u32), y.side_a));
     SBV_TRY(hipMemsetAsync(b.counters, 0, SBV_GROUP_COUNTERS * sizeof(u32), y.side_a));

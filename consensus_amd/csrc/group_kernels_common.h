@@ -121,18 +121,26 @@ static __global__ __launch_bounds__(256) void k_group_classify(size_t n, GroupSt
 // handful of times, so the LDS histogram turns a million global atomics on ~1000 hot words into groups x tiles of them.
 #define SBV_SORT_PER_LANE 8
 #define SBV_SORT_TILE (1024 * SBV_SORT_PER_LANE)
-// Groups one LDS histogram holds (64 KiB of dynamic LDS).  A batch with more groups (round 5: up to 65 536) takes the *_direct kernels
-// instead — plain global atomics, which is what the histogram degenerates to when a tile sees each key once.  Both variants are
-// launched for every batch and each decides ON THE DEVICE (the group count is known there only) whether the batch is its own: with
-// few hot keys the direct form serialises on a handful of words (16 consenter keys: 0.4 ms per 2^18 tuples, measured in round 5).
+// Groups one LDS histogram holds (64 KiB of dynamic LDS).  A batch with more groups (round 5: up to 65 536) takes plain global atomics
+// instead, which is what the histogram degenerates to when a tile sees each key once.  The kernels decide ON THE DEVICE (the group
+// count is known there only): with few hot keys the direct form serialises on a handful of words (16 consenter keys: 0.4 ms per 2^18
+// tuples, measured in round 5).  One launch either way: as two kernels per step the empty one still cost its launch on the sort's chain.
 #define SBV_SORT_LDS_GROUPS 16384u
 static __global__ __launch_bounds__(1024) void k_group_sort_count(size_t n, GroupState g) {
     extern __shared__ u32 sort_lh[];
     const u32 groups = group_count(g);
-    if (groups == 0 || groups > SBV_SORT_LDS_GROUPS) return;
+    if (groups == 0) return;
+    const size_t base = (size_t)blockIdx.x * SBV_SORT_TILE;
+    if (groups > SBV_SORT_LDS_GROUPS) {           // more groups than one histogram holds: plain global atomics (wave-uniform branch)
+#pragma unroll
+        for (int q = 0; q < SBV_SORT_PER_LANE; ++q) {
+            const size_t i = base + (size_t)q * 1024 + threadIdx.x;
+            if (i < n) group_sort_count_lane(i, g);
+        }
+        return;
+    }
     for (u32 k = threadIdx.x; k < groups; k += 1024) sort_lh[k] = 0;
     __syncthreads();
-    const size_t base = (size_t)blockIdx.x * SBV_SORT_TILE;
 #pragma unroll
     for (int q = 0; q < SBV_SORT_PER_LANE; ++q) {
         const size_t i = base + (size_t)q * 1024 + threadIdx.x;
@@ -172,10 +180,18 @@ static __global__ __launch_bounds__(1024) void k_group_sort_scan(GroupState g) {
 static __global__ __launch_bounds__(1024) void k_group_sort_scatter(size_t n, GroupState g) {
     extern __shared__ u32 sort_lh[];
     const u32 groups = group_count(g);
-    if (groups == 0 || groups > SBV_SORT_LDS_GROUPS) return;
+    if (groups == 0) return;
+    const size_t base = (size_t)blockIdx.x * SBV_SORT_TILE;
+    if (groups > SBV_SORT_LDS_GROUPS) {
+#pragma unroll
+        for (int q = 0; q < SBV_SORT_PER_LANE; ++q) {
+            const size_t i = base + (size_t)q * 1024 + threadIdx.x;
+            if (i < n) group_sort_scatter_lane(i, g);
+        }
+        return;
+    }
     for (u32 k = threadIdx.x; k < groups; k += 1024) sort_lh[k] = 0;
     __syncthreads();
-    const size_t base = (size_t)blockIdx.x * SBV_SORT_TILE;
     u32 grp[SBV_SORT_PER_LANE], rank[SBV_SORT_PER_LANE];
 #pragma unroll
     for (int q = 0; q < SBV_SORT_PER_LANE; ++q) {

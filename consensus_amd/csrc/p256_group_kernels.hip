@@ -246,19 +246,6 @@ __global__ __launch_bounds__(256) void k_group_table_mark(GroupState g, const u3
     const u32 groups = group_count(g);
     for (u32 k = blockIdx.x * 256 + threadIdx.x; k < groups; k += gridDim.x * 256) group_table_mark_lane(k, tslot, cold, full, needfill, table_slots, kfull);
 }
-// The counting sort for batches with more groups than one LDS histogram holds (> 16 384: 2^20 tuples over 65 536 keys): a tile sees a
-// key at most a few times, so the histogram would be all flush and no merge — plain global atomics (p256_group.h: group_sort_*_lane).
-__global__ __launch_bounds__(256) void k_group_sort_count_direct(size_t n, GroupState g) {
-    if (group_count(g) <= SBV_SORT_LDS_GROUPS) return;        // the LDS-histogram kernels' batch (group_kernels_common.h)
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) group_sort_count_lane(i, g);
-}
-__global__ __launch_bounds__(256) void k_group_sort_scatter_direct(size_t n, GroupState g) {
-    if (group_count(g) <= SBV_SORT_LDS_GROUPS) return;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) group_sort_scatter_lane(i, g);
-}
-
 // One launch, two jobs.  Blocks [0, generic_blocks): the generic stage B (doubling kernel) over the
 // ungrouped list — keys that repeat too rarely for a table; a 2.3 ms serial chain per lane on ~5 % of the
 // tuples, so it has to start as early as possible and run BESIDE the throughput work, at the same
@@ -442,9 +429,8 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     g.max_groups = b.max_groups; g.seed = b.seed;
     g.gcount = b.gcount; g.gcursor = b.gcount ? b.gcount + b.max_groups : nullptr; g.grp_of = b.grp_of; g.ung_cand = b.ung_cand;
     // key-sorted grouped list: needs the per-tuple records of stage A; one LDS word per group while the histogram fits (<= 16 384
-    // groups), plain global atomics beyond (k_group_sort_*_direct)
-    const bool sort_direct = b.max_groups > SBV_SORT_LDS_GROUPS;            // capacity beyond one histogram: launch the direct kernels too
-    const size_t sort_lds = (size_t)(sort_direct ? SBV_SORT_LDS_GROUPS : b.max_groups) * sizeof(u32);
+    // groups), plain global atomics beyond (the kernels decide: group_kernels_common.h)
+    const size_t sort_lds = (size_t)(b.max_groups > SBV_SORT_LDS_GROUPS ? SBV_SORT_LDS_GROUPS : b.max_groups) * sizeof(u32);
     g.sorted = y.sorted && s_in.rec && b.gcount && b.grp_of && b.ung_cand ? 1u : 0u;
     // Stage A writes EITHER the per-tuple records (key-sorted step: every reader takes them) OR the limb-major planes
     Scratch s = s_in;
@@ -465,14 +451,13 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     // The side streams may not touch the group buffers before everything already enqueued on `stream` (the
     // previous batch's readers of those buffers) has run; ev_fork was recorded by the caller BEFORE stage A.
     SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_fork, 0));
-    // ... nor before the previous batch's promotions are published (side_b, behind that batch's verdicts): they read hot[] and plist,
-    // and this batch's wide pass reads the combs they write (an event never recorded yet waits for nothing)
-    if (hot_on) SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_promoted, 0));
+    // ... nor before the previous batch's tail on side_b (table marks, promotion select: the readers of tslot and of the class bytes) is
+    // through (an event never recorded yet waits for nothing)
+    SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_promoted, 0));
     SBV_TRY(hipMemsetAsync(b.ht, 0, ((size_t)b.ht_mask + 1) * sizeof(u32), y.side_a));
     SBV_TRY(hipMemsetAsync(b.cnt, 0, n * sizeof(u32), y.side_a));
     SBV_TRY(hipMemsetAsync(b.counters, 0, SBV_GROUP_COUNTERS * sizeof(u32), y.side_a));
     if (g.sorted) SBV_TRY(hipMemsetAsync(b.gcount, 0, (size_t)b.max_groups * sizeof(u32), y.side_a));
-    if (hot_on) SBV_TRY(hipMemsetAsync(b.hot + 1, 0, 2 * sizeof(u32), y.side_a));        // promotions and wide-pass lanes of THIS batch
     const unsigned gn = (unsigned)((n + 255) / 256);
     const unsigned gv = (unsigned)((n + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK);
     hipLaunchKernelGGL(k_group_insert, dim3(gn), dim3(256), 0, y.side_a, d_tuples, n, g);
@@ -487,6 +472,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     SBV_TRY(launch_p256_prep_blocks(d_tuples, n, s, stream, 0, pblocks));
     // side_b: split
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
+    if (hot_on) SBV_TRY(hipMemsetAsync(b.hot + 1, 0, 2 * sizeof(u32), y.side_b));        // promotions and wide-pass lanes of THIS batch: behind the previous batch's builder, which reads hot[1]
     if (!g.sorted) hipLaunchKernelGGL(k_group_split, dim3(gn), dim3(256), 0, y.side_b, d_tuples, n, g, b.acc);
     if (g.sorted) {             // classify, check the ungrouped candidates' keys, counting sort of the grouped tuples by key;
                                 // ev_split then also stands for "the sorted list is final"
@@ -494,19 +480,18 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         hipLaunchKernelGGL(k_group_keycheck, dim3(gn), dim3(256), 0, y.side_b, d_tuples, g, b.acc);
         const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
         hipLaunchKernelGGL(k_group_sort_count, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
-        if (sort_direct) hipLaunchKernelGGL(k_group_sort_count_direct, dim3(gn), dim3(256), 0, y.side_b, n, g);
         hipLaunchKernelGGL(k_group_sort_scan, dim3(1), dim3(1024), 0, y.side_b, g);
     }
-    // table classes: after the exact counts (gcount survives the scan; the scatter moves gcursor only) and after the cache assigned the slots
-    SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_cache, 0));
-    hipLaunchKernelGGL(k_group_table_class, dim3(64), dim3(256), 0, y.side_b, g, b.tslot, b.cold, b.kfull, table_slots, full_min, b.full, b.needfill, hk, b.wide);
-    SBV_TRY(hipEventRecord(y.ev_class, y.side_b));
     if (g.sorted) {
         const unsigned tiles = (unsigned)((n + SBV_SORT_TILE - 1) / SBV_SORT_TILE);
         hipLaunchKernelGGL(k_group_sort_scatter, dim3(tiles), dim3(1024), sort_lds, y.side_b, n, g);
-        if (sort_direct) hipLaunchKernelGGL(k_group_sort_scatter_direct, dim3(gn), dim3(256), 0, y.side_b, n, g);
     }
     SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
+    // table classes: after the exact counts (gcount survives the scan; the scatter moves gcursor only) and after the cache assigned the
+    // slots; behind the scatter, so that the G phase (which waits for the sorted list, not for the classes) starts a launch earlier
+    SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_cache, 0));
+    hipLaunchKernelGGL(k_group_table_class, dim3(64), dim3(256), 0, y.side_b, g, b.tslot, b.cold, b.kfull, table_slots, full_min, b.full, b.needfill, hk, b.wide);
+    SBV_TRY(hipEventRecord(y.ev_class, y.side_b));
     // The generic stage B over the ungrouped list (keys that repeat too rarely for a table: a 2.3 ms chain per lane, so it starts
     // as early as possible and runs beside the throughput work) and the G phase.  group_count() is final after the assignment;
     // the ungrouped list (and the sorted list) after the split.
@@ -539,6 +524,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
             // `stream` it ran before the chunks' launches instead of beside them: with a quarter of the lanes wide it is a 0.87 ms
             // latency chain at low occupancy, timeline_hot_4096_r05q.txt), as soon as the G phase is done.
             SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_generic, 0));
+            SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_class, 0));
             hipLaunchKernelGGL(k_verify_keyed_q<SBV_Q_WIDE>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
                                table_slots, b.gacc, b.acc, 0, SBV_GTAB_WINDOWS, 1);
             SBV_TRY(hipEventRecord(y.ev_wide, y.side_a));
@@ -576,24 +562,29 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     }
     if (!coop) SBV_TRY(hipStreamWaitEvent(stream, y.ev_narrow, 0));
     if (hot_on && !coop) SBV_TRY(hipStreamWaitEvent(stream, y.ev_wide, 0));
-    hipLaunchKernelGGL(k_group_table_mark, dim3(64), dim3(256), 0, stream, g, b.tslot, b.cold, b.full, b.needfill, table_slots, b.kfull);
+    // `stream` has the verdict bytes: pack them; everything else is the batch's tail and runs on side_b, off the caller's path
+    SBV_TRY(hipEventRecord(y.ev_promote, stream));
+    hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
+    SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_promote, 0));
+    hipLaunchKernelGGL(k_group_table_mark, dim3(64), dim3(256), 0, y.side_b, g, b.tslot, b.cold, b.full, b.needfill, table_slots, b.kfull);
     if (hot_on) {
-        // promotions (p256_group.h: hot keys): which slots, and their base points, on `stream` (two tiny launches: the next batch may
-        // overwrite tslot and the per-batch tables); the builder and the publication on side_b, behind the caller's verdicts — the next
-        // batch's table classes are ordered behind them on that stream
-        hipLaunchKernelGGL(k_promote_select, dim3(64), dim3(256), 0, stream, g, b.tslot, b.kvalid, hk);
+        // promotions (p256_group.h: hot keys): which slots, and their base points (two tiny launches that read tslot and the tables)
+        hipLaunchKernelGGL(k_promote_select, dim3(64), dim3(256), 0, y.side_b, g, b.tslot, b.kvalid, hk);
         const widebuild wb = widebuild_make(SBV_HOT_BITS);
-        hipLaunchKernelGGL(k_promote_bases, dim3((SBV_PROMOTE_MAX * 2 * (u32)wb.windows + 63) / 64), dim3(64), 0, stream, b.plist, b.hot, b.ktab, b.pbases);
-        SBV_TRY(hipEventRecord(y.ev_promote, stream));
-        SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_promote, 0));
+        hipLaunchKernelGGL(k_promote_bases, dim3((SBV_PROMOTE_MAX * 2 * (u32)wb.windows + 63) / 64), dim3(64), 0, y.side_b, b.plist, b.hot, b.ktab, b.pbases);
+    }
+    // ev_promoted: the tail no longer reads tslot, the class bytes or the per-batch tables — the next batch's side_a (which rewrites them)
+    // waits for it; the builder and the publication follow on side_b, in front of the next batch's own side_b work (its table classes
+    // read kwide, its hot[] reset sits there too) and of its wide pass (behind the G phase, which waits for that side_b work)
+    SBV_TRY(hipEventRecord(y.ev_promoted, y.side_b));
+    if (hot_on) {
+        const widebuild wb = widebuild_make(SBV_HOT_BITS);
         const size_t stride = gcomb_entries(SBV_HOT_BITS);
         hipLaunchKernelGGL(k_promote_chains, dim3((SBV_PROMOTE_MAX * (u32)wb.windows * 2u + 63) / 64), dim3(64), 0, y.side_b, b.pbases, b.plist, b.hot, wb, stride, b.ptmp, b.wtab);
         const size_t fill_lanes = (size_t)SBV_PROMOTE_MAX * wb.windows * (wb.giants - 1) * widebuild_fill_chunks(wb);
         hipLaunchKernelGGL(k_promote_fill, dim3((unsigned)((fill_lanes + 255) / 256)), dim3(256), 0, y.side_b, b.plist, b.hot, wb, stride, b.wtab);
         hipLaunchKernelGGL(k_promote_publish, dim3(1), dim3(64), 0, y.side_b, b.plist, b.hot, b.kwide);
-        SBV_TRY(hipEventRecord(y.ev_promoted, y.side_b));
     }
-    hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);
 #undef SBV_TRY
     if (prof && prof_pairs) *prof_pairs = coop ? 1 : chunks;
     return hipGetLastError();
