@@ -1,29 +1,31 @@
 // p256_group.h — grouping a batch of generic tuples by public key, inside the step.
 //
 // Signers repeat: BASELINE.json's headline batch has 1024 distinct keys in 2^20 tuples; SmartBFT's
-// consenters are a handful.  For a key used by many tuples of ONE batch it pays to
-// build that key's comb table once (about 25 generic verifications' worth of work) and verify all
-// its signatures with the registered-key kernel (50 mixed additions, no doublings) instead of
-// paying 256 doublings per signature.  Everything here happens inside every call — nothing is
-// remembered from one batch to the next, and verdicts are identical to the generic path:
+// consenters are a handful.  For a key used by several tuples of ONE batch it pays to
+// build that key's comb table once and verify all its signatures without doublings instead of paying
+// 256 doublings per signature.  Verdicts are identical to the generic path.  The lanes of the step, in
+// the order the launcher (p256_group_kernels.hip) runs them:
 //
 //   group_insert   every tuple inserts its 64-byte key into an open-addressing hash table in HBM
 //                  (32-bit entries = representative tuple index + 1, claimed with atomicCAS; a hash
 //                  hit is only trusted after comparing all 64 key bytes, so collisions cost a probe,
-//                  never a wrong group); a SAMPLE of the tuples (every 2^k-th) counts itself on its
-//                  representative — a million atomicAdds cost ~1 ms on MI355X, and the count only
-//                  decides whether a table is worth building, never a verdict
-//   group_assign   representatives with >= min_samples sampled users take a table slot (atomic counter)
-//   group_split    tuples are compacted into a "grouped" and an "ungrouped" index list; ungrouped tuples
-//                  with a key that pointFromAffine refuses are rejected on the spot
-//   keytab_bases   per grouped key: validate it (pointFromAffine rules), 2^(8j) * Q for j = 0..32, Jacobian
-//                  (no normalisation: the windows add them with the full Jacobian formula), in chunks
-//                  of windows so that table building and use can be pipelined
-//   keytab_window  per (key, window): the 128 affine multiples, Montgomery-trick normalised, stored for the carry-free
-//                  field of the Q phase (R = 2^261 domain)
-//   gphase         u1 * G for every tuple (p256_core.h), independent of all of the above
-// then the Q phase (qphase29_lane, p256_comb29.h) runs over the grouped list and the generic stage B over the
-// ungrouped one.
+//                  never a wrong group; seeded and probe-bounded since round 5: "chosen keys" below)
+//                  and counts itself on its representative (exactly, since round 5; the sampled form
+//                  of rounds 1-4 stays behind group_set_sampling)
+//   group_assign   representatives with >= min_count users, and every key the persistent cache holds,
+//                  take a group index (atomic counter; up to 65 536 per batch)
+//   key_cache_*    the group's table slot: its cache slot, or a per-batch slot
+//   classify / keycheck / sort_*   the grouped tuples as a list sorted by group (counting sort), the
+//                  ungrouped ones as a list of their own; ungrouped tuples with a key that
+//                  pointFromAffine refuses are rejected on the spot
+//   table_class    which groups get rows only, which a full 8-bit table, which own a wide comb ("table
+//                  classes", "hot keys" below)
+//   keychain / rows / fill (p256_keytab29.h)   per cold group: validate the key, 2^(8j) * Q for j = 0..32,
+//                  babies and giants of every window, then (full tables only) the other 112 entries,
+//                  in chunks of windows so that table building and use are pipelined
+//   gphase         u1 * G for every grouped tuple (p256_comb29.h), independent of the tables
+// then the Q phase (qphase29_lane*, p256_comb29.h) runs over the grouped list in one instantiation per
+// table class and the generic stage B over the ungrouped list.
 //
 // Shared host/device source (tests/emul runs the same functions sequentially).
 #pragma once
