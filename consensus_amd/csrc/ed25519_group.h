@@ -111,6 +111,88 @@ SBV_HD void ed_keytab_bases_lane(const uint8_t* tuples, u32 gidx, const GroupSta
     }
 }
 
+// ---- the same chain on FOUR lanes per key (round 5; VERDICT r4 #5: "quad-lane base chain as P-256 got") ------------------------
+// ed_dbl is 4 squarings, then 4 products of their sums: two levels deep.  The four lanes of a quad hold the whole point; at level 1
+// lane r squares X / Y / Z / X + Y, the squares travel by DPP quad_perm broadcasts (full-rate register moves, no LDS), every lane
+// forms e, f, g, h, at level 2 lane r multiplies f e / h g / f g / e h = X3 / Y3 / Z3 / T3, and the products are broadcast again:
+// 2 multiplications deep per doubling instead of 8 in a row.  Operation for operation what ed_dbl does on the same operands, so the
+// recorded bases are BYTE FOR BYTE those of ed_keytab_bases_lane (tests/test_ed25519_cpu.py compares them); the limb bounds are
+// ed_dbl's.  The exchange policy is a template parameter as in p256_keytab29.h: one lane + DPP on the device
+// (ed25519_group_kernels.hip), four lanes stepped in lockstep in tests/emul.
+struct edchain_quad_host {
+    static const int N = 4;
+    ept s[4];
+    int role(int i) const { return i; }
+    void bcast(fe25 out[4], const fe25 in[4], int src) const { for (int i = 0; i < 4; ++i) out[i] = in[src]; }
+};
+SBV_HD void edchain_l1(fe25& P, const ept& s, int role) {
+    fe25 xy, in;
+    fe25_add(xy, s.X, s.Y);
+    fe25_select(in, role == 0, s.X, xy);
+    fe25_select(in, role == 1, s.Y, in);
+    fe25_select(in, role == 2, s.Z, in);
+    fe25_sqr(P, in);
+}
+SBV_HD void edchain_l2(fe25& P, const fe25& xx, const fe25& yy, const fe25& zz, const fe25& xy2, int role) {
+    fe25 zz2, e, g, h, f, a, b;
+    fe25_add(zz2, zz, zz);
+    fe25_add(h, yy, xx);
+    fe25_sub(g, yy, xx);
+    fe25_sub(e, xy2, h);
+    fe25_sub(f, zz2, g);
+    fe25_select(a, role == 1, h, f);           // first operand:  f | h | f | e     (ed_dbl's operand order: the bounds are per operand)
+    fe25_select(a, role == 3, e, a);
+    fe25_select(b, role == 0, e, g);           // second operand: e | g | g | h
+    fe25_select(b, role == 3, h, b);
+    fe25_mul(P, a, b);
+}
+template <class QX>
+SBV_HD void edchain_dbl(QX& q) {
+    fe25 P[QX::N], xx[QX::N], yy[QX::N], zz[QX::N], xy2[QX::N];
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) edchain_l1(P[i], q.s[i], q.role(i));
+    q.bcast(xx, P, 0); q.bcast(yy, P, 1); q.bcast(zz, P, 2); q.bcast(xy2, P, 3);
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) edchain_l2(P[i], xx[i], yy[i], zz[i], xy2[i], q.role(i));
+    q.bcast(xx, P, 0); q.bcast(yy, P, 1); q.bcast(zz, P, 2); q.bcast(xy2, P, 3);
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) { q.s[i].X = xx[i]; q.s[i].Y = yy[i]; q.s[i].Z = zz[i]; q.s[i].T = xy2[i]; }
+}
+// the whole chain of one chunk for one quad: what ed_keytab_bases_lane does, lane `role` storing coordinate `role` of every base
+template <class QX>
+SBV_HD void edchain_run(QX& q, const uint8_t* tuples, u32 gidx, const GroupState& g, u32* jbases, uint8_t* valid_of_slot, int j_first, int j_last) {
+    u32* out = jbases + (size_t)gidx * (SBV_ED_KEY_WINDOWS * SBV_ED_JBASE_DWORDS);
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) {
+        if (j_first == 0) {
+            ept A;
+            const bool ok = ed_tuple_key_load(tuples, g.group_rep[gidx], A);     // every lane of the quad: same key, same verdict
+            if (q.role(i) == 0) *valid_of_slot = ok ? 1 : 0;
+            q.s[i] = A;
+            fe25_neg(q.s[i].X, A.X);
+            fe25_neg(q.s[i].T, A.T);
+        } else {
+            ept_load(q.s[i], out + (size_t)(j_first - 1) * SBV_ED_JBASE_DWORDS);
+        }
+    }
+    SBV_NOUNROLL
+    for (int j = j_first; j <= j_last; ++j) {
+        if (j > 0) {
+            SBV_NOUNROLL
+            for (int d = 0; d < 8; ++d) edchain_dbl(q);
+        }
+        SBV_UNROLL
+        for (int i = 0; i < QX::N; ++i) {
+            const int r = q.role(i);
+            fe25 c;
+            fe25_select(c, r == 0, q.s[i].X, q.s[i].T);
+            fe25_select(c, r == 1, q.s[i].Y, c);
+            fe25_select(c, r == 2, q.s[i].Z, c);
+            fe25_store_raw(out + (size_t)j * SBV_ED_JBASE_DWORDS + 10 * r, c);
+        }
+    }
+}
+
 // One part of one (key, window): row[k-1] = k * base for k = part*E + 1 .. part*E + E as affine-Niels points.
 // `tmp` = private scratch of E * SBV_ED_WINDOW_TMP_WORDS dwords (X, Y, Z and the running product of the Zs, raw limbs).
 #define SBV_ED_WINDOW_TMP_WORDS 40

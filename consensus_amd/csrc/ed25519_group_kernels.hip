@@ -35,12 +35,33 @@ __global__ __launch_bounds__(256) void k_ed_group_split(size_t n, GroupState g) 
     group_split_emit(i, s, active && s == SBV_GROUP_NONE, active && s != SBV_GROUP_NONE, false, g);
 }
 
-// only the groups whose tables are built in this batch (cold: not found in the key-table cache)
+// only the groups whose tables are built in this batch (cold: not found in the key-table cache).  Four lanes per key (ed25519_group.h:
+// edchain_run); a quad lives or exits as a whole.
+struct edchain_quad_dev {
+    static const int N = 1;
+    ept s[1];
+    int r;
+    __device__ __forceinline__ int role(int) const { return r; }
+    __device__ __forceinline__ void bcast(fe25 out[1], const fe25 in[1], int src) const {
+        SBV_UNROLL
+        for (int l = 0; l < 10; ++l) {
+            const int v = in[0].v[l];
+            out[0].v[l] = src == 0 ? __builtin_amdgcn_mov_dpp(v, 0x00, 0xF, 0xF, true)
+                        : src == 1 ? __builtin_amdgcn_mov_dpp(v, 0x55, 0xF, 0xF, true)
+                        : src == 2 ? __builtin_amdgcn_mov_dpp(v, 0xAA, 0xF, 0xF, true)
+                                   : __builtin_amdgcn_mov_dpp(v, 0xFF, 0xF, 0xF, true);
+        }
+    }
+};
 __global__ __launch_bounds__(64) void k_ed_keytab_bases(const uint8_t* __restrict__ tuples, GroupState g, u32* __restrict__ jbases,
                                                         uint8_t* __restrict__ valid, const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
                                                         int j_first, int j_last) {
-    const u32 k = blockIdx.x * 64 + threadIdx.x;
-    if (k < group_count(g) && cold[k]) ed_keytab_bases_lane(tuples, k, g, jbases, valid + tslot[k], j_first, j_last);
+    const u32 lane = blockIdx.x * 64 + threadIdx.x;
+    const u32 k = lane >> 2;
+    if (k >= group_count(g) || !cold[k]) return;
+    edchain_quad_dev q;
+    q.r = (int)(lane & 3u);
+    edchain_run(q, tuples, k, g, jbases, valid + tslot[k], j_first, j_last);
 }
 
 // lanes = groups x j_count x parts
@@ -188,7 +209,7 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_ED_KEY_WINDOWS * c / chunks, j_end = SBV_ED_KEY_WINDOWS * (c + 1) / chunks;
         const int j_count = j_end - j_first;
-        hipLaunchKernelGGL(k_ed_keytab_bases, dim3((b.max_groups + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jbases, eb.kvalid,
+        hipLaunchKernelGGL(k_ed_keytab_bases, dim3((b.max_groups * 4u + 63) / 64), dim3(64), 0, y.side_a, d_tuples, g, b.jbases, eb.kvalid,
                            b.tslot, b.cold, j_first, j_end - 1);
         SBV_TRY(hipEventRecord(y.ev_bases[c], y.side_a));
         hipStream_t tb = y.side_b;      // one table stream: the windows of the odd chunks on a second stream measured slower (round 4: 4.55 -> 4.67 ms)

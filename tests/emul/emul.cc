@@ -795,6 +795,8 @@ static const aniels* btab() {
     }
     return g_btab;
 }
+static unsigned long g_ed_chain_mismatches = 0;      // quad-lane base chain against the one-lane chain: bases or key verdicts that differ
+unsigned long sbve_ed_chain_mismatches() { return g_ed_chain_mismatches; }
 // the grouped step's comb of B at another width (ed25519_group.h: edcomb; libsbv: SBV_ED_B_BITS, default 20).  The emulator's default
 // stays 16 (the one-lane table, no second build); tests switch to 12 / 13 / 19 / 20 bits
 static aniels* g_ed_bcomb = nullptr;
@@ -895,7 +897,19 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_ED_KEY_WINDOWS * c / chunks, j_end = SBV_ED_KEY_WINDOWS * (c + 1) / chunks;
         for (u32 k = 0; k < ngroups; ++k)
-            if (cold[k]) ed_keytab_bases_lane(tuples, k, g, jbases, valid_of(k), j_first, j_end - 1);
+            if (cold[k]) {
+                // k_ed_keytab_bases: the four lanes of the key's quad in lockstep (edchain_run) — and, as the reference of the byte-for-byte
+                // claim, the one-lane chain on a copy of the same state (the chain of a later chunk continues from the recorded base)
+                u32* mine = jbases + (size_t)k * (SBV_ED_KEY_WINDOWS * SBV_ED_JBASE_DWORDS);
+                std::vector<u32> ref(mine, mine + SBV_ED_KEY_WINDOWS * SBV_ED_JBASE_DWORDS);
+                uint8_t vref = 0xEE;
+                ed_keytab_bases_lane(tuples, k, g, ref.data() - (size_t)k * (SBV_ED_KEY_WINDOWS * SBV_ED_JBASE_DWORDS), &vref, j_first, j_end - 1);
+                edchain_quad_host q;
+                edchain_run(q, tuples, k, g, jbases, valid_of(k), j_first, j_end - 1);
+                if (memcmp(ref.data() + (size_t)j_first * SBV_ED_JBASE_DWORDS, mine + (size_t)j_first * SBV_ED_JBASE_DWORDS, (size_t)(j_end - j_first) * SBV_ED_JBASE_DWORDS * 4) != 0 ||
+                    (j_first == 0 && vref != *valid_of(k)))
+                    ++g_ed_chain_mismatches;
+            }
         for (u32 k = 0; k < ngroups; ++k)
             for (int j = j_first; j < j_end && cold[k]; ++j)
                 for (int part = 0; part < parts; ++part) {
