@@ -41,6 +41,7 @@ def worker(args):
     emul.sbve_hot_stats.argtypes = [ctypes.c_void_p]
     emul.sbve_hot_comb_mismatches.argtypes = [ctypes.c_uint32]
     emul.sbve_hot_comb_mismatches.restype = ctypes.c_size_t
+    emul.sbve_ed_chain_mismatches.restype = ctypes.c_ulong
     emul.sbve_scheme_key_cache.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
     oracle.sbvo_k256_gen_batch.argtypes = gen_args
     rng = random.Random(0xF022 + wid)
@@ -172,6 +173,9 @@ def worker(args):
             bm = ctypes.create_string_buffer((n + 7) // 8)
             emul.sbve_ed25519_verify_batch_grouped(tup.raw, n, bm, rng.choice((1, 8, 40)), 64, 12, rng.choice((1, 2, 3)), rng.choice((2, 4, 8)), None)
             out["ed_tuples"] += n
+            if emul.sbve_ed_chain_mismatches() != 0:                  # round 5: the quad-lane base chain against the one-lane chain, every cold key
+                out["mismatches"] += 1
+                out.setdefault("first", ["ed quad chain", seed, n, nkeys])
             if bm.raw != exp.raw:
                 out["mismatches"] += 1
                 out.setdefault("first", ["ed", seed, n, nkeys])
