@@ -297,8 +297,8 @@ def leg_end_to_end(sbv, tuples, valid, n, steps):
     for kind in ("pinned", "pinned_key_cache_on", "pageable"):
         ptrs = []
         # "pinned_key_cache_on": the library's DEFAULT configuration (the rest of this run switches the key-table cache off so that the
-        # headline is cold).  With it on, one caller's batch goes up in pieces beside its own kernels (round 5: sbv_api.hip,
-        # verify_in_pieces): what a single VerifyProposal caller gets (internal/bft/view.go:555).
+        # headline is cold).  With it on, one caller's batch goes up in 2^18-tuple pieces beside its own kernels (round 5: sbv_api.hip,
+        # sbv_p256_verify_batch through the two staging slots): what a single VerifyProposal caller gets (internal/bft/view.go:555).
         cache_on = kind == "pinned_key_cache_on"
         sbv.key_cache(cache_on)
         try:
