@@ -420,6 +420,20 @@ SBV_HD void group_table_mark_lane(u32 k, const u32* tslot, const uint8_t* cold, 
 //   kwide[slot]   wide comb of a cache slot, or SBV_WIDE_NONE           khits[slot]   tuples verified against the slot so far
 //   wide[k]       this batch's group k may take the wide pass           hot[0..3]     wide combs handed out | promotions of this batch |
 //                                                                                     lanes of the wide pass | (spare)
+// Which pass serves a wavefront of the grouped list (p256_group_kernels.hip: k_verify_keyed_q<MODE>), from three wave-level facts.  A lane
+// whose key is no point (or has no slot) is dead; a key with a wide comb keeps its 8-bit table, full OR rows only — promotion does not
+// ask which —, so in a mixed wavefront it counts as what that table is.  One function for the kernels and the emulator: in round 5 the
+// two copies of this rule shared a bug.
+#define SBV_Q_FULL 0
+#define SBV_Q_NARROW 1
+#define SBV_Q_WIDE 2
+#define SBV_Q_NONE 3
+SBV_HD int group_wave_class(bool all_dead, bool all_dead_or_wide, bool all_dead_or_full) {
+    if (all_dead) return SBV_Q_NONE;
+    if (all_dead_or_wide) return SBV_Q_WIDE;
+    if (all_dead_or_full) return SBV_Q_FULL;
+    return SBV_Q_NARROW;
+}
 #define SBV_PROMOTE_MAX 64u
 #define SBV_HOT_BITS 16
 SBV_HD void group_hot_class_lane(u32 k, const GroupState& g, const u32* tslot, const uint8_t* cold, u32 cache_cap, const u32* kwide, u32* khits,

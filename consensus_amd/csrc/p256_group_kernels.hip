@@ -288,16 +288,10 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_GPHASE_WAVES) void k_gphase_s
 //   MODE 1 (narrow)  any other wavefront — a key with rows only, or a mix at the seam of two runs: ONE launch behind the last rows, windows
 //                    0..32 from the compact rows (babies and giants), two additions per window.
 // A lane whose key pointFromAffine refuses (or that has no slot) is "dead": rejected whatever is added, it never decides its wavefront's class.
-#define SBV_Q_FULL 0
-#define SBV_Q_NARROW 1
-#define SBV_Q_WIDE 2
 // (a key with a wide comb keeps its 8-bit table, FULL OR ROWS ONLY — promotion does not ask which: in a mixed wavefront it counts as
 // what that table is)
 __device__ __forceinline__ int q_wave_class(bool dead, bool w, bool f) {
-    if (wave_all(dead)) return 3;
-    if (wave_all(dead || w)) return SBV_Q_WIDE;
-    if (wave_all(dead || f)) return SBV_Q_FULL;
-    return SBV_Q_NARROW;
+    return group_wave_class(wave_all(dead), wave_all(dead || w), wave_all(dead || f));      // the rule itself: p256_group.h, shared with tests/emul
 }
 template <int MODE>
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_keyed_q(Scratch s, GroupState g, const apt* __restrict__ ktab,
@@ -322,7 +316,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
         const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
         const bool dead = !(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0;     // no slot, or a key that is no point: "reject" whatever is added
         const int cls = q_wave_class(dead, !dead && wide[grp] != 0, !dead && full[grp] != 0);
-        if (cls == 3) { if (MODE == SBV_Q_FULL && last) acc[t] = 0; return; }                 // rejected without touching a table (there is none)
+        if (cls == SBV_Q_NONE) { if (MODE == SBV_Q_FULL && last) acc[t] = 0; return; }                 // rejected without touching a table (there is none)
         if (cls != MODE) return;                                                              // another instantiation's wavefront
         if (MODE != SBV_Q_FULL) {                                                             // statistics only: lanes of the rows-only / the wide pass
             const unsigned long long am = __ballot(true);
@@ -351,7 +345,7 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
     const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
     const bool dead = !(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0;
     const int cls = q_wave_class(dead, false, !dead && full[grp] != 0);
-    if (cls == 3) { if (MODE == SBV_Q_FULL && last) acc[t] = 0; return; }
+    if (cls == SBV_Q_NONE) { if (MODE == SBV_Q_FULL && last) acc[t] = 0; return; }
     if (cls != MODE || MODE == SBV_Q_WIDE) return;
     const bool v = qphase29_lane<MODE == SBV_Q_NARROW>(s, t, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
     if (last) acc[t] = v ? 1 : 0;

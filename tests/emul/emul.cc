@@ -351,8 +351,8 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     }
     const widekeys wk = hot_on ? widekeys_make(g_hot_wtab, g_hot_kwide.data(), SBV_HOT_BITS) : widekeys_none();
     // which lanes of the grouped list the chunk launches serve (wavefronts of 64 whose lanes ALL hold full tables) and which the narrow pass
-    // (q_wave_class: 3 = every lane dead, 2 = wide pass, 0 = the chunks' launches, 1 = rows-only pass)
-    std::vector<uint8_t> wave_cls((counters[1] + 63) / 64 + 1, 3);
+    // (group_wave_class: SBV_Q_NONE = every lane dead, SBV_Q_WIDE, SBV_Q_FULL = the chunks' launches, SBV_Q_NARROW = rows-only pass)
+    std::vector<uint8_t> wave_cls((counters[1] + 63) / 64 + 1, SBV_Q_NONE);
     auto decide_waves = [&] {            // the kernels decide at Q time: the first chunk of the chain has judged every cold key by then
         std::vector<uint8_t> all_dead(wave_cls.size(), 1), all_w(wave_cls.size(), 1), all_f(wave_cls.size(), 1);
         for (u32 L = 0; L < counters[1]; ++L) {
@@ -364,7 +364,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             if (!w) all_w[L / 64] = 0;
             if (!full[grp]) all_f[L / 64] = 0;               // a promoted key's 8-bit table may be rows only: in a mixed wavefront it counts as what it is
         }
-        for (size_t wv = 0; wv < wave_cls.size(); ++wv) wave_cls[wv] = all_dead[wv] ? 3 : (all_w[wv] ? 2 : (all_f[wv] ? 0 : 1));
+        for (size_t wv = 0; wv < wave_cls.size(); ++wv) wave_cls[wv] = (uint8_t)group_wave_class(all_dead[wv] != 0, all_w[wv] != 0, all_f[wv] != 0);      // the kernels' own rule (p256_group.h)
     };
     memset(bitmap, 0, (n + 7) / 8);
     const int chunks = g_group_chunks;
@@ -429,7 +429,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
             continue;
         }
         for (u32 L = 0; L < counters[1]; ++L) {                       // k_verify_keyed_q<false>: the wavefronts whose lanes all hold full tables
-            if (wave_cls[L / 64] != 0) continue;
+            if (wave_cls[L / 64] != SBV_Q_FULL) continue;
             const u32 t = grp_idx[L];
             const u32 grp = g.sorted ? grp_of[L] : slots[t];
             if (grp < ngroups && !*valid_of(grp)) continue;           // a key that is no point has no table: rejected (the device computes on whatever the slot holds and drops the result)
@@ -453,7 +453,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
                     if (m > 8 && (m & 15) != 0) memset((void*)(tab + (size_t)j * SBV_GTAB_PER_WINDOW + m - 1), 0xA5, sizeof(apt));
         }
         for (u32 L = 0; L < counters[1]; ++L) {
-            if (wave_cls[L / 64] != 1) continue;
+            if (wave_cls[L / 64] != SBV_Q_NARROW) continue;
             ++g_last_classes[2];
             const u32 t = grp_idx[L];
             const u32 grp = g.sorted ? grp_of[L] : slots[t];
@@ -469,7 +469,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     if (hot_on && !(g_group_coop && g.sorted)) {
         // k_verify_keyed_q<SBV_Q_WIDE>: the wavefronts whose live lanes all own a wide comb — u2 * Q from the 16-bit comb of the slot
         for (u32 L = 0; L < counters[1]; ++L) {
-            if (wave_cls[L / 64] != 2) continue;
+            if (wave_cls[L / 64] != SBV_Q_WIDE) continue;
             ++g_hot[2];
             const u32 t = grp_idx[L];
             const u32 grp = grp_of[L];
