@@ -209,3 +209,19 @@ def test_signing_refuses_without_a_gpu():
     with pytest.raises(sbv.SbvError) as ei:
         sbv.sign_batch((1).to_bytes(32, "big"), bytes(32))
     assert ei.value.code == -5
+
+
+def test_traffic_json_names_the_kernels_bench_reports_on():
+    """bench.py reads `roofline.traffic` of its three legs from profiles/traffic.json by kernel name (written by
+    tools/traffic_from_pmc.py from the PMC passes of a builder session).  A renamed kernel — round 5 made k_verify_keyed_q a template —
+    would silently turn the figure into null: the names bench.py asks for must be in the file, with plausible per-launch bytes."""
+    import json
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    src = open(os.path.join(root, "bench.py")).read()
+    asked = set(re.findall(r'variant_roofline\("(\w+)"', src)) | {"k_verify_keyed_q"}
+    assert asked >= {"k_verify_keyed_q", "k_ed_qphase", "k_k256_qphase"}
+    for k in asked:
+        v = t.get(k + "_hbm_bytes_per_launch")
+        assert isinstance(v, int) and 10**7 < v < 10**10, (k, v)
