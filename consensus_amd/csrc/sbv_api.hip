@@ -399,18 +399,23 @@ int ensure_group_buffers(Context& c, size_t n) {
             size_t want = c.hot_keys;
             while (want && !wide_pool_fits(want * per)) want /= 2;
             if (want) {
+                // an OPTIONAL pool: a failed allocation leaves the hot keys off (same verdicts), it never fails the batch
                 const size_t W = (257 + SBV_HOT_BITS - 1) / SBV_HOT_BITS;
-                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.wtab, want * per));
-                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kwide, K * sizeof(u32)));
-                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.khits, K * sizeof(u32)));
-                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.hot, 4 * sizeof(u32)));
-                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.plist, 2 * SBV_PROMOTE_MAX * sizeof(u32)));
-                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.pbases, SBV_PROMOTE_MAX * 2 * W * sizeof(sbv::apt)));
-                HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ptmp, sbv::widetab_tmp_words(SBV_PROMOTE_MAX, SBV_HOT_BITS) * sizeof(u32)));
-                HIP_TRY(SBV_EDEVICE, hipMemset(b.kwide, 0xFF, K * sizeof(u32)));
-                HIP_TRY(SBV_EDEVICE, hipMemset(b.khits, 0, K * sizeof(u32)));
-                HIP_TRY(SBV_EDEVICE, hipMemset(b.hot, 0, 4 * sizeof(u32)));
-                b.wide_cap = (u32)want;
+                const bool got = hipMalloc(&b.wtab, want * per) == hipSuccess && hipMalloc(&b.kwide, K * sizeof(u32)) == hipSuccess &&
+                                 hipMalloc(&b.khits, K * sizeof(u32)) == hipSuccess && hipMalloc(&b.hot, 4 * sizeof(u32)) == hipSuccess &&
+                                 hipMalloc(&b.plist, 2 * SBV_PROMOTE_MAX * sizeof(u32)) == hipSuccess &&
+                                 hipMalloc(&b.pbases, SBV_PROMOTE_MAX * 2 * W * sizeof(sbv::apt)) == hipSuccess &&
+                                 hipMalloc(&b.ptmp, sbv::widetab_tmp_words(SBV_PROMOTE_MAX, SBV_HOT_BITS) * sizeof(u32)) == hipSuccess &&
+                                 hipMemset(b.kwide, 0xFF, K * sizeof(u32)) == hipSuccess && hipMemset(b.khits, 0, K * sizeof(u32)) == hipSuccess &&
+                                 hipMemset(b.hot, 0, 4 * sizeof(u32)) == hipSuccess;
+                if (got) {
+                    b.wide_cap = (u32)want;
+                } else {
+                    (void)hipGetLastError();
+                    void* part[] = {b.wtab, b.kwide, b.khits, b.hot, b.plist, b.pbases, b.ptmp};
+                    for (void* q : part) if (q) (void)hipFree(q);
+                    b.wtab = nullptr; b.kwide = nullptr; b.khits = nullptr; b.hot = nullptr; b.plist = nullptr; b.pbases = nullptr; b.ptmp = nullptr;
+                }
             }
         }
     }
