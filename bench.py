@@ -2,7 +2,10 @@
 """bench.py — ECDSA P-256 verifies/sec at batch = 2^20 per GPU (BASELINE.json configs[1]).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 without a launcher (WORLD_SIZE unset): bench.py starts its own N ranks through torch.distributed.run on 127.0.0.1 and
+    rank 0 prints the line; under the driver's own `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+    it runs as one of the ranks.  --dry-run: the N-rank plumbing over gloo on CPUs (no GPU, no verification, value 0): the CPU
+    tier's rehearsal of the launch path.
 
 A step = one pass of the hot path (stage A + stage B kernels, through the C-ABI's
 device-pointer entry) over one batch of 2^20 synthetic tuples already resident in HBM.  With
@@ -886,6 +889,89 @@ def leg_m2(tuples, n):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become the launcher (VERDICT r5 #1a: this form used to die with
+    SystemExit before touching a GPU).  One rank per GPU on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this driver
+    env["SBV_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args, world, rank):
+    """The N-rank plumbing of the scaling run without a GPU: gloo, each rank's shard of the global batch, the all-gather of the bitmap
+    shards, the max-over-ranks clock, rank 0's one JSON line.  NOTHING is verified (libsbv.so has no CPU path and the oracle is not the
+    product): every rank contributes the generator's own expected bitmap; `value` is 0 and the line says dry_run."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import synth
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    n = args.tuples
+    tuples, valid = shard_of_rank(synth, np, dist if world > 1 else None, rank, n)
+    nbytes = (n + 7) // 8
+    mine = torch.from_numpy(np.ascontiguousarray(valid))
+    gathered = torch.zeros(nbytes * world, dtype=torch.uint8)
+    for _ in range(args.warmup):
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, mine)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, mine)
+        else:
+            gathered[:nbytes] = mine
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        allt = torch.zeros(world, dtype=torch.float64)
+        dist.all_gather_into_tensor(allt, t)
+        per_rank = [float(x) for x in allt]
+    ok = bool((gathered[rank * nbytes:(rank + 1) * nbytes].numpy() == valid).all())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "ECDSA P-256 verifies/sec at batch=1M", "value": 0.0, "unit": "verifies/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * max(per_rank) / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic", "dry_run": True,
+            "config": {"workload": "DRY RUN of the N-rank launch path over gloo: no GPU, no verification", "tuples_per_gpu": n,
+                       "global_batch": n * world, "parallelism": f"shard-by-tuple x{world} + all-gather of bitmaps (gloo)"},
+            "per_rank_ms_per_step": [1e3 * x / max(1, args.steps) for x in per_rank], "bitmap_correct": ok,
+            "self_launched": os.environ.get("SBV_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def shard_of_rank(synth, np, dist, rank, n):
+    """Rank r's shard of the global batch: the synthetic batch of SURVEY 8d (seed 0x5B7F2026: 1024 signers, 7/8 valid), its tuples
+    rotated by r * 4099 positions — every GPU of the node sees the same signers, as the replicas of one cluster do, in its own order.
+    Generating 2^20 signatures takes ~30 s of every host core, so rank 0 generates (or finds the /tmp cache) and the others load it."""
+    if dist is not None and rank != 0:
+        dist.barrier()
+    tuples, valid = synth.gen_batch(SEED, n)
+    if dist is not None and rank == 0:
+        dist.barrier()
+    if rank:
+        k = (rank * 4099) % n
+        t2 = np.roll(tuples.reshape(n, 160), -k, axis=0).reshape(-1)
+        bits = np.unpackbits(valid, bitorder="little")[:n]
+        valid = np.packbits(np.roll(bits, -k), bitorder="little")
+        tuples = np.ascontiguousarray(t2)
+    return tuples, valid
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -896,7 +982,10 @@ def main():
     ap.add_argument("--primary-only", action="store_true", help="skip the secondary legs (grouping off, registered keys): quick A/B runs")
     ap.add_argument("--warm-leg", action="store_true", help="with --primary-only: still run the warm-key-cache leg")
     ap.add_argument("--legs", default="", help="comma-separated names of the secondary legs to run (default: all of them); dev sessions")
+    ap.add_argument("--dry-run", action="store_true", help="the N-rank launch path over gloo on CPUs: no GPU, nothing verified (CPU tier)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
 
     import numpy as np
     import torch
@@ -909,27 +998,41 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus disagree")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: bench.py measures the HIP path only (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    t_init = time.perf_counter()
     sbv.init(local_rank)
+    init_s = time.perf_counter() - t_init      # host tables (once per process) + this device's two comb uploads
     sbv.key_cache(False)       # the headline is the COLD number: every step rebuilds every key's tables (nothing cached between steps)
 
     n = args.tuples
-    tuples, valid = synth.gen_batch(SEED + rank, n)            # rank r holds shard r of the global batch
+    tuples, valid = shard_of_rank(synth, np, dist if world > 1 else None, rank, n)            # rank r holds shard r of the global batch
     d_tuples = torch.from_numpy(tuples).cuda()
     nbytes = (n + 7) // 8
     d_bitmap = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
     d_all = torch.zeros(nbytes * world, dtype=torch.uint8, device="cuda") if world > 1 else None
     stream = torch.cuda.current_stream()
 
-    def step():
+    gather_events = []
+
+    def step(timed=False):
         sbv.verify_batch_dev(d_tuples.data_ptr(), n, d_bitmap.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_bitmap)
+            # the batch outgrew one GPU: RCCL all-gather of the per-rank accept bitmaps (128 KiB per rank) over xGMI
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                dist.all_gather_into_tensor(d_all, d_bitmap)
+                e1.record(stream)
+                gather_events.append((e0, e1))
+            else:
+                dist.all_gather_into_tensor(d_all, d_bitmap)
 
     def fence():
         torch.cuda.synchronize()
@@ -948,9 +1051,11 @@ def main():
     sbv.profile_enable(prof_level)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(True)
     fence()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
+    gather_ms = sum(a.elapsed_time(b) for a, b in gather_events) / len(gather_events) if gather_events else 0.0
     dominant_us, dominant_launches = sbv.profile_read_dominant()
     sbv.profile_read()
     sbv.profile_enable(True)
@@ -969,7 +1074,13 @@ def main():
     was_grouped = (n_grouped + n_ungrouped + n_key_rejected) == n
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    per_rank_ms = [1e3 * my_elapsed / args.steps]
+    per_rank_dom_us = [dominant_us / max(1, dominant_launches)]
     if world > 1:
+        allt = torch.zeros(2 * world, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(allt, torch.tensor([per_rank_ms[0], per_rank_dom_us[0]], dtype=torch.float64, device="cuda"))
+        per_rank_ms = [float(x) for x in allt[0::2]]
+        per_rank_dom_us = [float(x) for x in allt[1::2]]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -1080,11 +1191,15 @@ def main():
         else:
             dom_name, dom_units, share = "k_p256_verify", n, 1.0
         achieved = ALGO_BYTES_PER_VERIFY * dom_units * share / kern_s / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")      # per-launch HBM bytes from a rocprofv3 --pmc run
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom_name + "_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom_name + "_hbm_bytes_per_launch")
+                # NOT measured in this run: counters need their own rocprofv3 --pmc passes (tools/gpu_session.sh pmc); the figure is the
+                # committed summary of the builder session named here (say so in the line)
+                traffic_source = "profiles/traffic.json - " + str(tj.get("source", "rocprofv3 --pmc passes of a builder session"))
             except Exception:
                 traffic = None
         line = {
@@ -1096,7 +1211,10 @@ def main():
                                    "accept-bitmap out; 1024 keys, 7/8 valid + 1/8 single-bit-corrupted",
                        "tuples_per_gpu": n, "global_batch": n * world,
                        "parallelism": "shard-by-tuple" + (f" x{world} + RCCL all-gather of bitmaps" if world > 1 else "")},
-            "bitmap_correct": ok,
+            "bitmap_correct": ok, "init_s": init_s,
+            "per_rank_ms_per_step": per_rank_ms, "per_rank_dominant_kernel_us": per_rank_dom_us,
+            "all_gather_ms": gather_ms if world > 1 else None,
+            "self_launched": os.environ.get("SBV_BENCH_SELF_LAUNCHED") == "1",
             "kernel_us": {"k_p256_prep": prep_us, "stage_b_all_kernels": verify_us,
                           dom_name: dominant_us / max(1, dominant_launches), dom_name + "_launches_per_step": dom_launches_per_step,
                           "launches": launches},
@@ -1105,7 +1223,7 @@ def main():
                              "key_sorted_list": os.environ.get("SBV_GROUP_SORT", "1") != "0",
                              "note": "in-step grouping by public key and counting sort of the grouped tuples by key (consensus_amd/csrc/p256_group.h); all of it is inside the timed region"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": dom_name, "units_per_launch": dom_units, "share_of_a_tuples_stage_b_per_launch": share,
                          "note": "algorithmic bytes = 160.125 B/verify x tuples that launch processed x the share of their "
                                  "stage B it executes / its avg duration (HIP events on the launch stream); the path is "

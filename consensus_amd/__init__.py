@@ -527,6 +527,16 @@ def last_table_classes():
     return out[0], out[1], out[2]
 
 
+def pool_stats():
+    """sbv_p256_pool_stats: dict of the grouped step's pools on the default device (cached keys, groups per batch, shrunk, fallbacks for
+    lack of memory, hot-key combs, contexts sharing the GPU)."""
+    out = (ctypes.c_uint32 * 6)()
+    lib = load()
+    lib.sbv_p256_pool_stats.argtypes = [ctypes.c_void_p]
+    _check(lib.sbv_p256_pool_stats(out))
+    return {"cache_keys": out[0], "groups_per_batch": out[1], "shrunk": bool(out[2]), "nomem_fallbacks": out[3], "hot_pool": out[4], "gpu_share": out[5]}
+
+
 def hot_keys(max_keys: int = 1024, min_hits: int = 0) -> None:
     """sbv_p256_hot_keys: wide combs for hot cache slots of the generic path (0 keys = off)."""
     lib = load()

@@ -45,7 +45,7 @@ SBV_HD u32 host_add(u32* p, u32 v) { const u32 old = *p; *p = old + v; return ol
 #endif
 
 #define SBV_GROUP_NONE 0xFFFFFFFFu
-#define SBV_GROUP_COUNTERS 8
+#define SBV_GROUP_COUNTERS 12
 // Hash-flooding defence of the two open-addressing tables below (in a BFT library the adversary is the
 // design point, and the keys of a batch are attacker-chosen bytes that are inserted BEFORE any curve check):
 //   * both hashes are keyed with a per-context random seed (GroupState::seed, KeyCache::seed): key bytes that collide under one
@@ -64,6 +64,7 @@ struct GroupState {
     u32* slot_of;     // [n] table slot of a representative, or NONE
     u32* group_rep;   // [max_groups] representative tuple of slot g
     u32* counters;    // [0] groups handed out, [1] grouped tuples, [2] ungrouped tuples, [3] rejected for their key, [4] ungrouped candidates (SBV_GROUP_COUNTERS words, zeroed)
+                      // P-256 table classes: [5] groups with a full table, [6] groups filled in this batch, [7] lanes of the rows-only pass, [8] groups that may take the wide pass
     u32* grp_idx;     // [n] compacted grouped tuple indices
     u32* ung_idx;     // [n] compacted ungrouped tuple indices
     u32* slots;       // [n] group of every tuple (SBV_GROUP_NONE for the ungrouped and rejected ones)
@@ -436,29 +437,88 @@ SBV_HD int group_wave_class(bool all_dead, bool all_dead_or_wide, bool all_dead_
 }
 #define SBV_PROMOTE_MAX 64u
 #define SBV_HOT_BITS 16
-SBV_HD void group_hot_class_lane(u32 k, const GroupState& g, const u32* tslot, const uint8_t* cold, u32 cache_cap, const u32* kwide, u32* khits,
-                                 uint8_t* wide) {
+SBV_HD void group_hot_class_lane(u32 k, const GroupState& g, const u32* tslot, const uint8_t* cold, u32 cache_cap, const u32* kwide, uint8_t* wide) {
+    (void)g;
     const u32 slot = tslot[k];
-    bool w = false;
-    if (slot < cache_cap) {
-        const u32 count = g.sorted ? g.gcount[k] : g.cnt[g.group_rep[k]] * (g.sample_mask + 1u);
-        khits[slot] += count;                                   // one group per slot and batch: no atomics
-        w = !cold[k] && kwide[slot] != 0xFFFFFFFFu;
-    }
-    wide[k] = w ? 1 : 0;
+    wide[k] = slot < cache_cap && !cold[k] && kwide[slot] != 0xFFFFFFFFu ? 1 : 0;
 }
+// ---- life cycle of the hot keys (round 6) --------------------------------------------------------------------
+// Round 5 counted every tuple GROUPED under a slot, never forgot a count and never took a comb back: 4 096 garbage signatures under
+// each of 1 024 valid curve points filled the pool for good, and a long-running node kept the combs of yesterday's clients
+// (signer sets change on reconfiguration: pkg/consensus/consensus.go:185-252).  Now:
+//   * a slot's count grows by the tuples of the batch that were ACCEPTED under it (the tail of the step reads the verdict bytes;
+//     garbage earns nothing);
+//   * every SBV_HOT_DECAY_EVERY-th grouped batch halves every count (a clock sweep over the cache slots): a key must keep signing
+//     ~promote_min / 2 DECAY_EVERY tuples per batch to stay above the threshold, a key that stopped falls below it within
+//     DECAY_EVERY * log2(count / promote_min) batches;
+//   * when the pool is full, a slot that has earned a comb takes the comb of the owner with the LOWEST count — if that count is at
+//     most half its own (hysteresis: two keys of similar heat never trade a 35.7 MB comb back and forth); wowner[w] = the slot
+//     that owns comb w.  The victim keeps its 8-bit table and is served from it again from the next batch on.
+// Counts saturate far below 2^32.  Verdicts never depend on any of this (a comb is a function of its key's 64 bytes).
+#define SBV_HOT_DECAY_EVERY 16u
+#define SBV_HOT_HITS_MAX 0x3FFFFFFFu
+SBV_HD void hot_decay_lane(u32 slot, u32* khits) { khits[slot] >>= 1; }
+// one accepted tuple (or `count` of them: a wavefront's lanes of one slot) under cache slot `slot`
+SBV_HD void hot_hit(u32 slot, u32 count, u32* khits) {
+    const u32 before = SBV_ATOMIC_ADD(&khits[slot], count);
+    if (before > SBV_HOT_HITS_MAX) khits[slot] = SBV_HOT_HITS_MAX;          // saturation; a racing add at the ceiling loses at most its own count
+}
+// lane L of the grouped list: the cache slot its accepted tuple counts for, or SBV_GROUP_NONE
+SBV_HD u32 hot_hit_slot(const GroupState& g, u32 L, u32 groups, const u32* tslot, const uint8_t* acc, u32 cache_cap) {
+    const u32 t = g.grp_idx[L];
+    const u32 grp = g.sorted ? g.grp_of[L] : g.slots[t];
+    if (!(grp < groups) || acc[t] != 1) return SBV_GROUP_NONE;
+    const u32 slot = tslot[grp];
+    return slot < cache_cap ? slot : SBV_GROUP_NONE;
+}
+// Eviction, one candidate at a time.  hot_evict_scan: lane `lane` of `lanes` looks at owners w = lane, lane + lanes, ... that were not
+// handed out in this batch (taken: one bit per comb) and keeps the coldest (lowest count, then lowest index: deterministic across any
+// number of lanes); hot_evict_better merges two lanes' findings; hot_evict_ok is the hysteresis.
+SBV_HD bool hot_evict_better(u32 h, u32 w, u32 best_h, u32 best_w) { return h < best_h || (h == best_h && w < best_w); }
+SBV_HD void hot_evict_scan(const u32* khits, const u32* wowner, const u32* taken, u32 wide_cap, u32 cache_cap, u32 lane, u32 lanes, u32& best_h, u32& best_w) {
+    best_h = 0xFFFFFFFFu; best_w = 0xFFFFFFFFu;
+    for (u32 w = lane; w < wide_cap; w += lanes) {
+        if ((taken[w >> 5] >> (w & 31)) & 1u) continue;
+        const u32 owner = wowner[w];
+        if (owner >= cache_cap) continue;                       // never handed out (cannot happen with a full pool) or owner forgotten
+        const u32 h = khits[owner];
+        if (hot_evict_better(h, w, best_h, best_w)) { best_h = h; best_w = w; }
+    }
+}
+SBV_HD bool hot_evict_ok(u32 cand_hits, u32 victim_hits) { return victim_hits <= cand_hits / 2; }
 // end of the batch: group k asks for a wide comb when its slot is cached, valid (its 8-bit rows, full or not, hold the builder's base
 // points), hot and has none yet.  plist[2 i] = slot, plist[2 i + 1] = wide index of promotion i.
+// elist: the slots that found the pool full, candidates of this batch's evictions (hot[3] counts them; round 6)
 SBV_HD void group_promote_select_lane(u32 k, const u32* tslot, const uint8_t* kvalid, u32 cache_cap, const u32* kwide,
-                                      const u32* khits, u32 promote_min, u32 wide_cap, u32* hot, u32* plist) {
+                                      const u32* khits, u32 promote_min, u32 wide_cap, u32* hot, u32* plist, u32* elist) {
     const u32 slot = tslot[k];
     if (slot >= cache_cap || !kvalid[slot] || kwide[slot] != 0xFFFFFFFFu || khits[slot] < promote_min) return;
-    if (hot[0] >= wide_cap) return;                             // the pool is full (the counter only grows: a stale read costs one atomic)
+    if (hot[0] >= wide_cap) {                                   // the pool is full (the counter only grows: a stale read costs one atomic)
+        const u32 e = SBV_ATOMIC_ADD(&hot[3], 1u);
+        if (e < SBV_PROMOTE_MAX) elist[e] = slot;
+        return;
+    }
     const u32 i = SBV_ATOMIC_ADD(&hot[1], 1u);
     if (i >= SBV_PROMOTE_MAX) return;                           // this batch's quota: the key is asked again by the next batch
     const u32 w = SBV_ATOMIC_ADD(&hot[0], 1u);
-    plist[2 * i] = w < wide_cap ? slot : 0xFFFFFFFFu;           // past the pool's end: an empty entry
+    if (w >= wide_cap) {                                        // past the pool's end: an empty entry, and the slot becomes an eviction candidate
+        const u32 e = SBV_ATOMIC_ADD(&hot[3], 1u);
+        if (e < SBV_PROMOTE_MAX) elist[e] = slot;
+    }
+    plist[2 * i] = w < wide_cap ? slot : 0xFFFFFFFFu;
     plist[2 * i + 1] = w;
+}
+// The evictions of a batch, by ONE agent (a workgroup's lane 0 on the device after its lanes' scans were merged; the emulator alone):
+// candidate c of `cands` gets comb best_w when hot_evict_ok; plist entries are appended behind the batch's ordinary promotions.
+// Returns the new number of plist entries.
+SBV_HD u32 hot_evict_commit(u32 cand_slot, u32 best_h, u32 best_w, u32* khits, u32* kwide, u32* wowner, u32* taken, u32 entries, u32* plist) {
+    if (best_w == 0xFFFFFFFFu || entries >= SBV_PROMOTE_MAX || !hot_evict_ok(khits[cand_slot], best_h)) return entries;
+    kwide[wowner[best_w]] = 0xFFFFFFFFu;                        // the victim is served from its 8-bit table again
+    wowner[best_w] = cand_slot;
+    taken[best_w >> 5] |= 1u << (best_w & 31);
+    plist[2 * entries] = cand_slot;
+    plist[2 * entries + 1] = best_w;
+    return entries + 1;
 }
 
 // ---- per-batch key tables ----------------------------------------------------------------------------

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void k_keytab29_fill_sym(GroupState g, u32* __r
 
 // Table classes of the batch's groups and, at the end of the step, what the slots hold (p256_group.h).  One lane per group.
 // hot: the wide-comb state of the cache slots (p256_group.h: hot keys); kwide == nullptr = feature off / no pool
-struct HotKeys { const apt* wtab; u32* kwide; u32* khits; u32* hot; u32* plist; u32 cache_cap, wide_cap, promote_min; };
+struct HotKeys { const apt* wtab; u32* kwide; u32* khits; u32* hot; u32* plist; u32 cache_cap, wide_cap, promote_min; u32* wowner; u32* elist; };
 __global__ __launch_bounds__(256) void k_group_table_class(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
                                                            const uint8_t* __restrict__ kfull, u32 table_slots, u32 full_min,
                                                            uint8_t* __restrict__ full, uint8_t* __restrict__ needfill,
@@ -190,19 +190,69 @@ __global__ __launch_bounds__(256) void k_group_table_class(GroupState g, const u
     const u32 groups = group_count(g);
     for (u32 k = blockIdx.x * 256 + threadIdx.x; k < groups; k += gridDim.x * 256) {
         group_table_class_lane(k, g, tslot, cold, kfull, table_slots, full_min, full, needfill);
-        if (hk.kwide && g.sorted) group_hot_class_lane(k, g, tslot, cold, hk.cache_cap, hk.kwide, hk.khits, wide);
+        if (hk.kwide && g.sorted) group_hot_class_lane(k, g, tslot, cold, hk.cache_cap, hk.kwide, wide);
         else wide[k] = 0;
-        if (full[k]) atomicAdd(&g.counters[5], 1u);           // statistics only (sbv_p256_last_table_classes)
+        if (full[k]) atomicAdd(&g.counters[5], 1u);           // sbv_p256_last_table_classes; and [5] == groups tells the rows-only pass that it has no wavefront
         if (needfill[k]) atomicAdd(&g.counters[6], 1u);
+        if (wide[k]) atomicAdd(&g.counters[8], 1u);           // [8] == 0 tells the wide pass the same
     }
 }
 // ---- promotion of hot cache slots to wide combs (p256_group.h: hot keys; p256_widetab29.h: the builder of the registered path) ----------
 // select (one lane per group) -> bases (the 2 x 17 base points of each promotion, gathered from the key's 8-bit table) -> chains + fill
 // (the builder's lanes, for the promotions this batch really made) -> publish (kwide[slot] = index: later batches take the wide pass)
+// Life cycle of the hot keys (p256_group.h, round 6): the clock sweep, the hits of the batch's ACCEPTED tuples, the evictions.
+__global__ __launch_bounds__(256) void k_hot_decay(HotKeys hk) {
+    const u32 slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot < hk.cache_cap) hot_decay_lane(slot, hk.khits);
+}
+// one lane per lane of the grouped list; the sorted list makes wavefronts of one slot the rule: one atomic per wavefront then
+__global__ __launch_bounds__(256) void k_group_hits(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ acc, HotKeys hk) {
+    const u32 L = blockIdx.x * 256 + threadIdx.x;
+    const u32 slot = L < g.counters[1] ? hot_hit_slot(g, L, group_count(g), tslot, acc, hk.cache_cap) : SBV_GROUP_NONE;
+    const unsigned long long hits = __ballot(slot != SBV_GROUP_NONE);
+    if (!hits) return;
+    const int leader = __ffsll((long long)hits) - 1;
+    const u32 first = (u32)__shfl((int)slot, leader, 64);
+    if (__all(slot == SBV_GROUP_NONE || slot == first)) {
+        if ((int)(threadIdx.x & 63) == leader) hot_hit(first, (u32)__popcll(hits), hk.khits);
+    } else if (slot != SBV_GROUP_NONE) {
+        hot_hit(slot, 1u, hk.khits);
+    }
+}
 __global__ __launch_bounds__(256) void k_promote_select(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ kvalid, HotKeys hk) {
     const u32 groups = group_count(g);
     for (u32 k = blockIdx.x * 256 + threadIdx.x; k < groups; k += gridDim.x * 256)
-        group_promote_select_lane(k, tslot, kvalid, hk.cache_cap, hk.kwide, hk.khits, hk.promote_min, hk.wide_cap, hk.hot, hk.plist);
+        group_promote_select_lane(k, tslot, kvalid, hk.cache_cap, hk.kwide, hk.khits, hk.promote_min, hk.wide_cap, hk.hot, hk.plist, hk.elist);
+}
+// ONE workgroup: for each slot that found the pool full, its 1024 lanes scan the owners for the coldest comb not handed out in this
+// batch, lane 0 merges and commits (hot_evict_commit: the hysteresis, kwide of the victim, wowner, the plist entry the builder reads).
+#define SBV_HOT_POOL_MAX 4096u
+__global__ __launch_bounds__(1024) void k_promote_evict(HotKeys hk) {
+    __shared__ u32 taken[SBV_HOT_POOL_MAX / 32];
+    __shared__ u32 sh_h[16], sh_w[16];
+    __shared__ u32 entries;
+    const u32 tid = threadIdx.x;
+    const u32 ncand = hk.hot[3] < SBV_PROMOTE_MAX ? hk.hot[3] : SBV_PROMOTE_MAX;
+    if (ncand == 0 || hk.wide_cap > SBV_HOT_POOL_MAX) return;             // uniform
+    for (u32 i = tid; i < SBV_HOT_POOL_MAX / 32; i += 1024) taken[i] = 0;
+    if (tid == 0) entries = hk.hot[1] < SBV_PROMOTE_MAX ? hk.hot[1] : SBV_PROMOTE_MAX;
+    __syncthreads();
+    for (u32 c = 0; c < ncand; ++c) {
+        u32 bh, bw;
+        hot_evict_scan(hk.khits, hk.wowner, taken, hk.wide_cap, hk.cache_cap, tid, 1024u, bh, bw);
+        for (int off = 32; off >= 1; off >>= 1) {
+            const u32 oh = (u32)__shfl_xor((int)bh, off, 64), ow = (u32)__shfl_xor((int)bw, off, 64);
+            if (hot_evict_better(oh, ow, bh, bw)) { bh = oh; bw = ow; }
+        }
+        if ((tid & 63) == 0) { sh_h[tid >> 6] = bh; sh_w[tid >> 6] = bw; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < 16; ++i) if (hot_evict_better(sh_h[i], sh_w[i], bh, bw)) { bh = sh_h[i]; bw = sh_w[i]; }
+            entries = hot_evict_commit(hk.elist[c], bh, bw, hk.khits, hk.kwide, hk.wowner, taken, entries, hk.plist);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) hk.hot[1] = entries;
 }
 __device__ __forceinline__ u32 promote_live(const u32* hot) { const u32 c = hot[1]; return c < SBV_PROMOTE_MAX ? c : SBV_PROMOTE_MAX; }
 __global__ __launch_bounds__(64) void k_promote_bases(const u32* __restrict__ plist, const u32* __restrict__ hot, const apt* __restrict__ ktab, apt* __restrict__ pbases) {
@@ -234,11 +284,11 @@ __global__ __launch_bounds__(256) void k_promote_fill(const u32* __restrict__ pl
     const u32 gi = 1u + (u32)(q / chunks), c = (u32)(q % chunks);
     widetab_fill_lane(w, gi, 1u + c * SBV_WIDETAB_T, wtab + (size_t)plist[2 * i + 1] * stride + (size_t)j * w.per_window);
 }
-__global__ __launch_bounds__(64) void k_promote_publish(const u32* __restrict__ plist, const u32* __restrict__ hot, u32* __restrict__ kwide) {
+__global__ __launch_bounds__(64) void k_promote_publish(const u32* __restrict__ plist, const u32* __restrict__ hot, u32* __restrict__ kwide, u32* __restrict__ wowner) {
     const u32 i = threadIdx.x;
     if (i >= promote_live(hot)) return;
     const u32 slot = plist[2 * i];
-    if (slot != 0xFFFFFFFFu) kwide[slot] = plist[2 * i + 1];
+    if (slot != 0xFFFFFFFFu) { kwide[slot] = plist[2 * i + 1]; wowner[plist[2 * i + 1]] = slot; }
 }
 __global__ __launch_bounds__(256) void k_group_table_mark(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
                                                           const uint8_t* __restrict__ full, const uint8_t* __restrict__ needfill, u32 table_slots,
@@ -299,6 +349,12 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
                                                                     const uint8_t* __restrict__ full, const uint8_t* __restrict__ wide, widekeys wk, u32* __restrict__ wstat,
                                                                     u32 table_slots, u32* __restrict__ gacc,
                                                                     uint8_t* __restrict__ acc, int j0, int j1, int last) {
+    // The rows-only and the wide pass are launched beside the chunks' launches for every batch, over the whole grouped list; in most
+    // batches — the headline's 1 024 hot signers, a consenter replay — no group is of their class, and every wavefront used to load its
+    // lane's group, slot and class bytes to find that out (16 384 wavefronts alive for 0.8 ms beside the Q phase).  The
+    // class kernel counts the groups of each class: one scalar load per workgroup settles it.
+    if (MODE == SBV_Q_NARROW && g.counters[5] >= group_count(g)) return;      // every group owns a full table: no wavefront can be rows-only
+    if (MODE == SBV_Q_WIDE && g.counters[8] == 0) return;                     // no group may take the wide pass
     if (g.sorted) {
         // Key-sorted list: consecutive blocks hold consecutive keys.  The dispatcher deals workgroups round-robin over the
         // 8 XCDs (block b -> XCD b % 8, MI355X_MICROARCH.md "Workgroup dispatch"; a speed assumption only), so block b takes
@@ -438,7 +494,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     const u32 table_slots = b.kc.cap + b.max_groups;
     // hot keys (p256_group.h): only with the cache on, a pool to promote into and the key-sorted list
     const bool hot_on = b.wtab && b.kwide && b.kc.enabled && g.sorted;
-    const HotKeys hk = {b.wtab, hot_on ? b.kwide : nullptr, b.khits, b.hot, b.plist, b.kc.cap, b.wide_cap, b.promote_min};
+    const HotKeys hk = {b.wtab, hot_on ? b.kwide : nullptr, b.khits, b.hot, b.plist, b.kc.cap, b.wide_cap, b.promote_min, b.wowner, b.elist};
     const widekeys wk = hot_on ? widekeys_make(b.wtab, b.kwide, SBV_HOT_BITS) : widekeys_none();
     hipError_t e;
 #define SBV_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
@@ -466,7 +522,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     SBV_TRY(launch_p256_prep_blocks(d_tuples, n, s, stream, 0, pblocks));
     // side_b: split
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_assign, 0));
-    if (hot_on) SBV_TRY(hipMemsetAsync(b.hot + 1, 0, 2 * sizeof(u32), y.side_b));        // promotions and wide-pass lanes of THIS batch: behind the previous batch's builder, which reads hot[1]
+    if (hot_on) SBV_TRY(hipMemsetAsync(b.hot + 1, 0, 3 * sizeof(u32), y.side_b));        // promotions and wide-pass lanes of THIS batch: behind the previous batch's builder, which reads hot[1]
     if (!g.sorted) hipLaunchKernelGGL(k_group_split, dim3(gn), dim3(256), 0, y.side_b, d_tuples, n, g, b.acc);
     if (g.sorted) {             // classify, check the ungrouped candidates' keys, counting sort of the grouped tuples by key;
                                 // ev_split then also stands for "the sorted list is final"
@@ -562,8 +618,13 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_promote, 0));
     hipLaunchKernelGGL(k_group_table_mark, dim3(64), dim3(256), 0, y.side_b, g, b.tslot, b.cold, b.full, b.needfill, table_slots, b.kfull);
     if (hot_on) {
-        // promotions (p256_group.h: hot keys): which slots, and their base points (two tiny launches that read tslot and the tables)
+        // the life cycle (round 6): the clock sweep every SBV_HOT_DECAY_EVERY-th batch, then this batch's accepted tuples
+        if (b.hot_tick % SBV_HOT_DECAY_EVERY == SBV_HOT_DECAY_EVERY - 1) hipLaunchKernelGGL(k_hot_decay, dim3((b.kc.cap + 255) / 256), dim3(256), 0, y.side_b, hk);
+        hipLaunchKernelGGL(k_group_hits, dim3(gn), dim3(256), 0, y.side_b, g, b.tslot, b.acc, hk);
+        // promotions (p256_group.h: hot keys): which slots (the evictions when the pool is full), and their base points (tiny launches
+        // that read tslot and the tables)
         hipLaunchKernelGGL(k_promote_select, dim3(64), dim3(256), 0, y.side_b, g, b.tslot, b.kvalid, hk);
+        hipLaunchKernelGGL(k_promote_evict, dim3(1), dim3(1024), 0, y.side_b, hk);
         const widebuild wb = widebuild_make(SBV_HOT_BITS);
         hipLaunchKernelGGL(k_promote_bases, dim3((SBV_PROMOTE_MAX * 2 * (u32)wb.windows + 63) / 64), dim3(64), 0, y.side_b, b.plist, b.hot, b.ktab, b.pbases);
     }
@@ -577,7 +638,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         hipLaunchKernelGGL(k_promote_chains, dim3((SBV_PROMOTE_MAX * (u32)wb.windows * 2u + 63) / 64), dim3(64), 0, y.side_b, b.pbases, b.plist, b.hot, wb, stride, b.ptmp, b.wtab);
         const size_t fill_lanes = (size_t)SBV_PROMOTE_MAX * wb.windows * (wb.giants - 1) * widebuild_fill_chunks(wb);
         hipLaunchKernelGGL(k_promote_fill, dim3((unsigned)((fill_lanes + 255) / 256)), dim3(256), 0, y.side_b, b.plist, b.hot, wb, stride, b.wtab);
-        hipLaunchKernelGGL(k_promote_publish, dim3(1), dim3(64), 0, y.side_b, b.plist, b.hot, b.kwide);
+        hipLaunchKernelGGL(k_promote_publish, dim3(1), dim3(64), 0, y.side_b, b.plist, b.hot, b.kwide, b.wowner);
     }
 #undef SBV_TRY
     if (prof && prof_pairs) *prof_pairs = coop ? 1 : chunks;

@@ -78,6 +78,9 @@ struct GroupBuffers {
     u32 *kwide = nullptr, *khits = nullptr;     // [kc.cap]
     u32* hot = nullptr;           // [4] wide combs handed out | promotions of this batch | lanes of the wide pass | spare
     u32* plist = nullptr;         // [2 x SBV_PROMOTE_MAX] (slot, wide index)
+    u32* wowner = nullptr;        // [wide_cap] the cache slot that owns comb w (round 6: evictions), SBV_WIDE_NONE before its first owner
+    u32* elist = nullptr;         // [SBV_PROMOTE_MAX] slots that found the pool full in this batch: the eviction candidates
+    u32 hot_tick = 0;             // grouped batches with hot keys on so far: every SBV_HOT_DECAY_EVERY-th halves the hit counters
     apt* pbases = nullptr;        // [SBV_PROMOTE_MAX][2 x 17] base points of the promotions under construction
     u32* ptmp = nullptr;          // the builder's chain scratch for SBV_PROMOTE_MAX keys
     uint8_t* wide = nullptr;      // [max_groups] this batch's groups that may take the wide pass

@@ -919,8 +919,10 @@ Status Verifier::VerifyConsenterSigBatch(const std::vector<Signature>& sigs, con
         struct Binder {
             Verifier* v; const Proposal* last = nullptr; bytes digest;
             bool bound(const Proposal* p, const bytes& m) {
+                if (!p) return false;                            // a signature presented without its proposal is bound to nothing
                 if (p != last) { last = p; digest = v->digest_of(*p); }
-                return m.size() >= 40 && memcmp(m.data(), "SBV1", 4) == 0 && memcmp(m.data() + 4, digest.data(), 32) == 0 && consenter_msg_split(m, nullptr, nullptr);
+                // digest.size() is part of the predicate: the comparison reads 32 bytes of it
+                return digest.size() == 32 && m.size() >= 40 && memcmp(m.data(), "SBV1", 4) == 0 && memcmp(m.data() + 4, digest.data(), 32) == 0 && consenter_msg_split(m, nullptr, nullptr);
             }
         };
         std::lock_guard<std::mutex> staging_lock(staging_mu_);

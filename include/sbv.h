@@ -252,6 +252,14 @@ int sbv_p256_last_group_stats(uint32_t out[4]);
  * batch, out[2] = grouped tuples served by the rows-only pass.  Verdicts never depend on the class.  Synchronises the device.
  * K arbitrary clients per proposal: internal/bft/view.go:553-559. */
 int sbv_p256_last_table_classes(uint32_t out[3]);
+/* Pools of the grouped P-256 step on the default device (round 6).  The defaults — a key-table cache of 16 384 keys and 65 536 groups per
+ * batch: 25 GB of combs — are sized for a 288 GB MI355X; a device that cannot hold them (a shared or smaller part, one of several
+ * contexts folded onto one GPU by SBV_LOGICAL_DEVICES) gets halved pools instead of SBV_ENOMEM, and a batch whose pools cannot be
+ * allocated at all is verified by the one-lane kernel: a Verifier must stay live (internal/bft/view.go:387-392 deposes a leader on a
+ * VerifyProposal error).  out[0] = cached keys the pool holds, out[1] = groups per batch, out[2] = 1 when either is smaller than asked
+ * for, out[3] = grouped batches that fell back to the one-lane kernel for lack of memory, out[4] = combs of the hot-key pool,
+ * out[5] = contexts sharing this GPU.  out[0..1] are 0 before the first grouped batch.  Rates change with the pools, verdicts never. */
+int sbv_p256_pool_stats(uint32_t out[6]);
 /* Hot keys (round 5): wide combs in the GENERIC path.  A key that arrives inside tuples — a client key of VerifyProposal
  * (internal/bft/view.go:553-559), a consenter of a replica that registered nothing — and keeps being hit is promoted: once the
  * key-table cache has verified `min_hits` tuples against its slot, a 16-bit comb (35.7 MB; up to `max_keys` of them, default 1024 =
@@ -306,6 +314,11 @@ typedef struct sbv_shard_info {
     double gather_us;         /* all-gather + final D2H                                      */
     double total_us;
 } sbv_shard_info;
+/* SBV_LOGICAL_DEVICES=G (environment, read at initialisation; round 6): sbv_init accepts G device indices and sbv_init_all creates G
+ * contexts, context i on HIP device i % (visible devices), every pool budget divided by the contexts that share a GPU.  One MI355X then
+ * runs the sharded entries exactly as a G-GPU node would — G shards from G host threads, shard offsets > 0, idle contexts, the bitmap
+ * gathered through the host (an RCCL communicator needs one rank per physical device) — which is how the one-GPU test tier covers them.
+ * sbv_init_all initialises its devices in parallel, one host thread each. */
 int sbv_init_all(void);
 int sbv_initialised_devices(int* out, int max);
 size_t sbv_shard_plan(size_t n, int devices, size_t group, size_t min_per_device, size_t* first);

@@ -148,9 +148,14 @@ static std::vector<u32> g_kc_ht, g_kc_keys, g_kc_count;
 // hot keys (p256_group.h): the wide-comb pool of the emulated cache, its per-slot index and hit counters, hot[] as on the device
 static u32 g_hot_cap = 0, g_hot_min = 4096;
 static apt* g_hot_wtab = nullptr;
-static std::vector<u32> g_hot_kwide, g_hot_khits;
+static std::vector<u32> g_hot_kwide, g_hot_khits, g_hot_wowner;
 static u32 g_hot[4] = {0, 0, 0, 0};
-static void hot_reset() { g_hot_kwide.assign(g_kc.cap ? g_kc.cap : 1, SBV_WIDE_NONE); g_hot_khits.assign(g_kc.cap ? g_kc.cap : 1, 0); memset(g_hot, 0, sizeof g_hot); }
+static u32 g_hot_tick = 0;          // GroupBuffers::hot_tick: the clock of the decay
+static u32 g_hot_evictions = 0;     // combs that changed owner so far (test statistics)
+static void hot_reset() {
+    g_hot_kwide.assign(g_kc.cap ? g_kc.cap : 1, SBV_WIDE_NONE); g_hot_khits.assign(g_kc.cap ? g_kc.cap : 1, 0); memset(g_hot, 0, sizeof g_hot);
+    g_hot_wowner.assign(g_hot_cap ? g_hot_cap : 1, SBV_WIDE_NONE); g_hot_tick = 0; g_hot_evictions = 0;
+}
 void sbve_hot_keys(u32 cap, u32 min_hits) {       // after sbve_key_cache (which forgets the promotions, like the library)
     free(g_hot_wtab);
     g_hot_wtab = nullptr;
@@ -162,6 +167,18 @@ void sbve_hot_keys(u32 cap, u32 min_hits) {       // after sbve_key_cache (which
     }
     hot_reset();
 }
+// hit counter of the cache slot that holds `key` (64 bytes), or 0xFFFFFFFF; out[0] = evictions so far, out[1] = decay clock
+u32 sbve_hot_hits_of_key(const uint8_t* key) {
+    for (size_t sl = 0; sl < g_hot_khits.size() && sl < g_kc.cap; ++sl)
+        if (memcmp(&g_kc_keys[sl * 16], key, 64) == 0) return g_hot_khits[sl];
+    return 0xFFFFFFFFu;
+}
+u32 sbve_hot_wide_of_key(const uint8_t* key) {
+    for (size_t sl = 0; sl < g_hot_kwide.size() && sl < g_kc.cap; ++sl)
+        if (memcmp(&g_kc_keys[sl * 16], key, 64) == 0) return g_hot_kwide[sl];
+    return 0xFFFFFFFEu;
+}
+void sbve_hot_life(u32 out[2]) { out[0] = g_hot_evictions; out[1] = g_hot_tick; }
 void sbve_hot_stats(u32 out[4]) { out[0] = g_hot[0] < g_hot_cap ? g_hot[0] : g_hot_cap; out[1] = g_hot_cap; out[2] = g_hot[2]; out[3] = g_hot_min; }
 // promoted comb `index` against the host builder (build_comb_window_of + apt_to_r261), as sbv_p256_hot_selfcheck compares: every entry
 // of windows 0..15, the babies of the top window.  Number of differing entries, or (size_t)-1 if nobody owns the index.
@@ -346,8 +363,9 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     std::vector<uint8_t> wide(ng1, 0);
     if (hot_on) {
         if (g_hot_kwide.size() < kc.cap) hot_reset();
-        g_hot[1] = g_hot[2] = 0;
-        for (u32 k = 0; k < ngroups; ++k) group_hot_class_lane(k, g, tslot.data(), cold.data(), kc.cap, g_hot_kwide.data(), g_hot_khits.data(), wide.data());
+        g_hot[1] = g_hot[2] = g_hot[3] = 0;
+        ++g_hot_tick;
+        for (u32 k = 0; k < ngroups; ++k) group_hot_class_lane(k, g, tslot.data(), cold.data(), kc.cap, g_hot_kwide.data(), wide.data());
     }
     const widekeys wk = hot_on ? widekeys_make(g_hot_wtab, g_hot_kwide.data(), SBV_HOT_BITS) : widekeys_none();
     // which lanes of the grouped list the chunk launches serve (wavefronts of 64 whose lanes ALL hold full tables) and which the narrow pass
@@ -489,9 +507,36 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     memcpy(g_kc_full.data(), kfull.data(), kc.cap);
     if (hot_on) {
         // promotions: k_promote_select -> _bases -> _chains -> _fill -> _publish, lane by lane (groups visited backwards: the order is free)
-        std::vector<u32> plist(2 * SBV_PROMOTE_MAX, 0xDEADBEEFu);
+        // the life cycle first (k_hot_decay, k_group_hits): the clock sweep, then the ACCEPTED tuples of the grouped list
+        if (g_hot_tick % SBV_HOT_DECAY_EVERY == SBV_HOT_DECAY_EVERY - 1) for (u32 sl = 0; sl < kc.cap; ++sl) hot_decay_lane(sl, g_hot_khits.data());
+        {
+            std::vector<uint8_t> accb(n);
+            for (size_t i = 0; i < n; ++i) accb[i] = (bitmap[i >> 3] >> (i & 7)) & 1u;
+            for (u32 L = 0; L < counters[1]; ++L) {
+                const u32 sl = hot_hit_slot(g, L, ngroups, tslot.data(), accb.data(), kc.cap);
+                if (sl != SBV_GROUP_NONE) hot_hit(sl, 1u, g_hot_khits.data());
+            }
+        }
+        std::vector<u32> plist(2 * SBV_PROMOTE_MAX, 0xDEADBEEFu), elist(SBV_PROMOTE_MAX, 0xDEADBEEFu);
         for (u32 k = ngroups; k-- > 0;)
-            group_promote_select_lane(k, tslot.data(), g_kc_valid.data(), kc.cap, g_hot_kwide.data(), g_hot_khits.data(), g_hot_min, g_hot_cap, g_hot, plist.data());
+            group_promote_select_lane(k, tslot.data(), g_kc_valid.data(), kc.cap, g_hot_kwide.data(), g_hot_khits.data(), g_hot_min, g_hot_cap, g_hot, plist.data(), elist.data());
+        {   // k_promote_evict: one agent, the same scan / merge / commit functions (p256_group.h); 3 "lanes" so that the merge runs too
+            const u32 ncand = g_hot[3] < SBV_PROMOTE_MAX ? g_hot[3] : SBV_PROMOTE_MAX;
+            u32 entries = g_hot[1] < SBV_PROMOTE_MAX ? g_hot[1] : SBV_PROMOTE_MAX;
+            std::vector<u32> taken((g_hot_cap + 31) / 32 + 1, 0);
+            for (u32 c = 0; c < ncand; ++c) {
+                u32 bh = 0xFFFFFFFFu, bw = 0xFFFFFFFFu;
+                for (u32 lane = 0; lane < 3; ++lane) {
+                    u32 h, w;
+                    hot_evict_scan(g_hot_khits.data(), g_hot_wowner.data(), taken.data(), g_hot_cap, kc.cap, lane, 3u, h, w);
+                    if (hot_evict_better(h, w, bh, bw)) { bh = h; bw = w; }
+                }
+                const u32 before = entries;
+                entries = hot_evict_commit(elist[c], bh, bw, g_hot_khits.data(), g_hot_kwide.data(), g_hot_wowner.data(), taken.data(), entries, plist.data());
+                g_hot_evictions += entries - before;
+            }
+            if (ncand) g_hot[1] = entries;
+        }
         const u32 live = g_hot[1] < SBV_PROMOTE_MAX ? g_hot[1] : SBV_PROMOTE_MAX;
         const widebuild w = widebuild_make(SBV_HOT_BITS);
         const size_t stride = gcomb_entries(SBV_HOT_BITS);
@@ -512,7 +557,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
                     for (u32 c = fchunks; c-- > 0;) widetab_fill_lane(w, gi, 1u + c * SBV_WIDETAB_T, comb + (size_t)j * w.per_window);
         }
         for (u32 i = 0; i < live; ++i)
-            if (plist[2 * i] != 0xFFFFFFFFu) g_hot_kwide[plist[2 * i]] = plist[2 * i + 1];
+            if (plist[2 * i] != 0xFFFFFFFFu) { g_hot_kwide[plist[2 * i]] = plist[2 * i + 1]; g_hot_wowner[plist[2 * i + 1]] = plist[2 * i]; }
     }
     u32* qtab = (u32*)aligned_alloc(16, SBV_QTAB29_WORDS * 4);
     for (u32 L = 0; L < counters[2]; ++L) {

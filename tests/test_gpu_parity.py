@@ -403,12 +403,6 @@ def test_device_message_frontend(gpu, oracle, golden_vectors):
     d = 0x1234567
     q = ec.pt_mul(d, ec.G)
     keyslot = gpu.register_keys([q[0].to_bytes(32, "big") + q[1].to_bytes(32, "big")])[0]
-    for v in golden_vectors:
-        if v["kind"] != "asn1" or v["class"] != "der":
-            continue
-        # re-sign a fresh message, then splice the vector's DER *structure* is not possible in general:
-        # use the vector's own sig against its own key/hash only for verdict "reject by parser" cases
-        pass
     for i in range(3000):
         mlen = rng.choice([0, 1, 31, 55, 56, 64, 100, 300])
         m = bytes(rng.getrandbits(8) for _ in range(mlen))
@@ -431,6 +425,115 @@ def test_device_message_frontend(gpu, oracle, golden_vectors):
     assert not bad, bad[:10]
     assert sum(want) > 500 and sum(want) < 2500
     gpu.clear_keys()
+
+
+def _der_class_cases(golden_vectors):
+    """(name, message, signature bytes, 64-byte key, golden verdict or None) for the device parser: the 28 DER classes of
+    tests/golden/p256_vectors.json — their hash IS SHA-256(b"der classes") (tests/golden/gen_p256_vectors.py), so the vectors' own bytes
+    go through the device's SHA-256 + parser unchanged — and the same shapes applied to s (the golden set bends r): non-minimal,
+    negative, 0xFF-padded, empty, 33 bytes, = N, long-form length, wrong tag."""
+    import hashlib
+    msg = b"der classes"
+    vs = [v for v in golden_vectors if v["kind"] == "asn1" and v["class"] == "der"]
+    assert len(vs) == 28 and all(v["hash"] == hashlib.sha256(msg).hexdigest() for v in vs)
+    key = bytes.fromhex(vs[0]["qx"]) + bytes.fromhex(vs[0]["qy"])
+    assert all(bytes.fromhex(v["qx"]) + bytes.fromhex(v["qy"]) == key for v in vs)
+    cases = [(v["name"], msg, bytes.fromhex(v["sig"]), key, bool(v["accept"])) for v in vs]
+    good = bytes.fromhex(next(v["sig"] for v in vs if v["name"] == "der_good"))
+    rl = good[3]
+    rmin, smin = good[4:4 + rl], good[4 + rl + 2:]
+    assert good[2] == 2 and good[4 + rl] == 2 and good[4 + rl + 1] == len(smin)
+
+    def der_len(n):
+        return bytes([n]) if n < 128 else bytes([0x81, n])
+
+    def der_int(b):
+        return b"\x02" + der_len(len(b)) + b
+
+    def der_seq(body):
+        return b"\x30" + der_len(len(body)) + body
+
+    nn = ec.N.to_bytes(32, "big")
+    snb = smin[1:] if smin[0] == 0 else smin            # s without its sign byte: top bit set -> negative as an INTEGER
+    extra = {
+        "s_33_bytes": der_seq(der_int(rmin) + der_int(b"\x01" + bytes(32))),
+        "s_eq_N": der_seq(der_int(rmin) + der_int(b"\x00" + nn)),
+        "s_eq_N_minus_1": der_seq(der_int(rmin) + der_int(b"\x00" + (ec.N - 1).to_bytes(32, "big"))),
+        "s_empty_int": der_seq(der_int(rmin) + der_int(b"")),
+        "s_negative": der_seq(der_int(rmin) + der_int(snb if snb[0] & 0x80 else b"\x80" + snb)),
+        "s_ff_padded": der_seq(der_int(rmin) + der_int(b"\xff" + (snb if snb[0] & 0x80 else b"\x80" + snb))),
+        "s_int_len_long_form": der_seq(der_int(rmin) + b"\x02\x81" + bytes([len(smin)]) + smin),
+        "s_wrong_int_tag": der_seq(der_int(rmin) + b"\x03" + der_int(smin)[1:]),
+        "both_33_bytes": der_seq(der_int(b"\x01" + bytes(32)) + der_int(b"\x01" + bytes(32))),
+        "r_34_bytes_leading_zeros": der_seq(der_int(b"\x00\x00" + rmin[-32:]) + der_int(smin)),
+        "len_4_bytes": b"\x30\x84\x00\x00\x00" + bytes([len(good) - 2]) + good[2:],
+        "len_2_bytes_nonminimal": b"\x30\x82\x00" + bytes([len(good) - 2]) + good[2:],
+        "seq_in_seq": der_seq(good),
+        "one_byte": b"\x30",
+        "int_runs_past_seq": der_seq(der_int(rmin) + b"\x02" + bytes([len(smin) + 1]) + smin),
+        "good_again": good,
+    }
+    cases += [(name, msg, sig, key, None) for name, sig in extra.items()]
+    return cases
+
+
+def test_device_der_parser_all_golden_classes(gpu, oracle, openssl_check, golden_vectors):
+    """VERDICT r5 #4 / Weak #1: the 28 golden DER classes and the same shapes bent on s — negative and non-minimal INTEGERs, three
+    integers, empty INTEGER, indefinite / 4- and 5-byte lengths, 33-byte r and s, r = N — through the DEVICE parser (k_msg_frontend:
+    sbv_p256_verify_msgs_keyed, and the sharded front end) on the GPU, each verdict against the golden one, the oracle's
+    sbvo_p256_verify_asn1 (types.Signature.Value: pkg/types/types.go:25-29; SURVEY 8c rule 1) and the strict-DER OpenSSL judge.
+    The hash-LENGTH classes of the golden set cannot reach this entry by construction — the device computes SHA-256(Msg) itself,
+    always 32 bytes; they are diffed on the GPU as tuples (test_golden_vectors) and through the host's left-pad / truncation."""
+    import hashlib
+    openssl_check.sbvssl_p256_verify_asn1.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    openssl_check.sbvssl_p256_der_is_strict.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    cases = _der_class_cases(golden_vectors)
+    key = cases[0][3]
+    h = hashlib.sha256(b"der classes").digest()
+    want = []
+    for name, msg, sig, k, golden in cases:
+        o = bool(oracle.sbvo_p256_verify_asn1(k[:32], k[32:], h, 32, sig, len(sig)))
+        j = bool(openssl_check.sbvssl_p256_verify_asn1(k[:32], k[32:], h, 32, sig, len(sig)))
+        assert o == j, (name, o, j)                      # the oracle and the strict-DER OpenSSL judge agree on every class
+        if golden is not None:
+            assert o == golden, (name, o, golden)
+        if o:
+            assert openssl_check.sbvssl_p256_der_is_strict(sig, len(sig)) == 1, name
+        want.append(o)
+    assert sum(want) >= 4 and want.count(False) >= 35
+    gpu.clear_keys()
+    try:
+        slot = gpu.register_keys([key])[0]
+        # every class alone in a call, then all of them in one call (lanes of one wavefront parse different shapes), then interleaved
+        # with 4 000 honest signatures so that the batch takes the throughput kernels instead of the latency form
+        for i, (name, msg, sig, _, _) in enumerate(cases):
+            got = sbv.bitmap_to_list(gpu.verify_msgs_keyed([msg], [sig], [slot]), 1)
+            assert got == [want[i]], (name, got, want[i])
+        msgs = [c[1] for c in cases]
+        sigs = [c[2] for c in cases]
+        got = sbv.bitmap_to_list(gpu.verify_msgs_keyed(msgs, sigs, [slot] * len(cases)), len(cases))
+        assert got == want, [cases[i][0] for i in range(len(cases)) if got[i] != want[i]]
+        good = next(c[2] for c in cases if c[0] == "der_good")
+        big_m, big_s, big_w = [], [], []
+        for rep in range(100):
+            for i, c in enumerate(cases):
+                big_m += [c[1], b"der classes"]
+                big_s += [c[2], good]
+                big_w += [want[i], True]
+        got = sbv.bitmap_to_list(gpu.verify_msgs_keyed(big_m, big_s, [slot] * len(big_m)), len(big_m))
+        assert got == big_w, [i for i in range(len(big_m)) if got[i] != big_w[i]][:10]
+        # the sharded front end: the same batch in pieces (each piece carries a slice of the offset tables)
+        os.environ["SBV_SHARD_PIECE_KEYED"] = "1024"
+        sbv.shutdown()
+        assert sbv.init_all() >= 1
+        slot = sbv.register_keys([key])[0]
+        got2, _, info = sbv.verify_msgs_keyed_sharded(big_m, big_s, [slot] * len(big_m))
+        assert sbv.bitmap_to_list(got2, len(big_m)) == big_w
+    finally:
+        os.environ.pop("SBV_SHARD_PIECE_KEYED", None)
+        sbv.shutdown()
+        sbv.init(0)
+        gpu.clear_keys()
 
 
 def test_sharded_message_frontend_in_pieces(oracle):

@@ -201,3 +201,27 @@ def test_der_mutations_three_opinions(oracle, openssl_check, golden_vectors):
         n_strict += strict
         n_accept += c
     assert 300 < n_accept < n_strict < 3500
+
+
+def test_der_shapes_bent_on_s_oracle_equals_strict_openssl(oracle, openssl_check, golden_vectors):
+    """The case list the GPU tier feeds through the DEVICE parser (tests/test_gpu_parity.py: _der_class_cases — the 28 golden DER
+    classes plus the same shapes applied to s, 4-byte lengths, nested sequences): here the two CPU opinions on it, so that the GPU test's
+    expectation is pinned before a GPU is involved."""
+    import hashlib
+    from test_gpu_parity import _der_class_cases
+    openssl_check.sbvssl_p256_verify_asn1.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    openssl_check.sbvssl_p256_der_is_strict.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    h = hashlib.sha256(b"der classes").digest()
+    cases = _der_class_cases(golden_vectors)
+    assert len(cases) == 28 + 16
+    accepted = []
+    for name, msg, sig, k, golden in cases:
+        o = bool(oracle.sbvo_p256_verify_asn1(k[:32], k[32:], h, 32, sig, len(sig)))
+        j = bool(openssl_check.sbvssl_p256_verify_asn1(k[:32], k[32:], h, 32, sig, len(sig)))
+        t = ec.verify_asn1(int.from_bytes(k[:32], "big"), int.from_bytes(k[32:], "big"), h, sig)
+        assert o == j == t, (name, o, j, t)
+        if golden is not None:
+            assert o == golden, name
+        if o:
+            accepted.append(name)
+    assert sorted(accepted) == sorted(["der_good", "der_both_high_bit_valid", "der_short_r_valid", "good_again"]), accepted
