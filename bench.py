@@ -180,15 +180,20 @@ def leg_warm_cache(sbv, torch, d_tuples, d_bitmap, valid, n, steps, stream):
         # owns a 16-bit comb, timed as they go, then the same measurement with the wide pass serving the batch
         try:
             sbv.hot_keys(1024, 4096)
-            ramp = []
+            # (round 6: a slot earns its comb with ACCEPTED tuples — the 128 signers under which this synthetic batch puts all its
+            # corrupted signatures never do: the ramp ends when three batches in a row promoted nobody)
+            ramp, last, still = [], -1, 0
             for _ in range(160):
                 t0 = time.perf_counter()
                 sbv.verify_batch_dev(d_tuples.data_ptr(), n, d_bitmap.data_ptr(), stream.cuda_stream)
                 torch.cuda.synchronize()
                 ramp.append(time.perf_counter() - t0)
                 promoted, pool, wide_lanes, min_hits = sbv.hot_key_stats()
-                if promoted >= min(entries, pool):
+                still = still + 1 if promoted == last and promoted > 0 else 0
+                last = promoted
+                if promoted >= min(entries, pool) or still >= 3:
                     break
+            ramp = ramp[:len(ramp) - still] if still else ramp
             sbv.verify_batch_dev(d_tuples.data_ptr(), n, d_bitmap.data_ptr(), stream.cuda_stream)  # the last promotions are published behind the batch that made them
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -200,7 +205,7 @@ def leg_warm_cache(sbv, torch, d_tuples, d_bitmap, valid, n, steps, stream):
             out["hot_keys"] = {"value": n * steps / dth, "unit": "verifies/s", "ms_per_step": 1e3 * dth / steps,
                                "bitmap_correct": bool((d_bitmap.cpu().numpy() == valid).all()),
                                "promoted_keys": promoted, "pool_keys": pool, "min_hits": min_hits, "tuples_through_the_wide_pass_last_step": wide_lanes,
-                               "batches_until_all_promoted": len(ramp), "ms_per_batch_while_promoting_median": 1e3 * sorted(ramp)[len(ramp) // 2],
+                               "batches_until_all_promoted": len(ramp), "keys_cached": entries, "ms_per_batch_while_promoting_median": 1e3 * sorted(ramp)[len(ramp) // 2],
                                "combs_equal_host_builder": [bool(sbv.hot_selfcheck(i)) for i in (0, max(0, promoted - 1))] if promoted else [],
                                "note": "generic tuples, keys inside the tuples: slots with >= min_hits verified tuples own a 16-bit comb (35.7 MB each), built on the device behind the verdicts"}
         except Exception as e:      # noqa: BLE001

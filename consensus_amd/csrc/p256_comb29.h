@@ -93,17 +93,40 @@ SBV_HD void gcomb_digit(const u288& k, int bits, int j, u32& idx, bool& neg, boo
 }
 
 // R = u1 * G   (add_to_R: R += u1 * G; flip: every digit's sign is inverted, i.e. R (+)= u1 * (-P) for the comb of P)
-SBV_HD void gphase29_point(xyzz& R, const u256& u1, const gcomb& gc, bool add_to_R = false, bool flip = false) {
+SBV_HD bool wave_any(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __any(x) != 0;
+#else
+    return x;
+#endif
+}
+SBV_HD bool wave_all(bool x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __all(x) != 0;
+#else
+    return x;
+#endif
+}
+// (j0, j1): only the windows [j0, j1) — the key-comb chunks of the grouped step; top_on_demand: the top window holds nothing but the carry of
+// the signed recoding, and is walked only when a lane of the wavefront carries (wave-uniform loop bound)
+SBV_HD void gphase29_point(xyzz& R, const u256& u1, const gcomb& gc, bool add_to_R = false, bool flip = false, int j0 = 0, int j1 = -1,
+                           bool top_on_demand = false) {
     u288 k1;
     gcomb_recode(k1, u1, gc.bits, gc.windows);
     if (!add_to_R) pt29_set_inf(R);
+    if (j1 < 0) j1 = gc.windows;
     u32 idx; bool neg, skip;
-    gcomb_digit(k1, gc.bits, 0, idx, neg, skip);
+    if (top_on_demand && j1 == gc.windows) {
+        gcomb_digit(k1, gc.bits, gc.windows - 1, idx, neg, skip);
+        if (!wave_any(!skip)) j1 = gc.windows - 1;
+    }
+    if (j0 >= j1) return;
+    gcomb_digit(k1, gc.bits, j0, idx, neg, skip);
     raw_apt cur;
-    raw_apt_load(cur, gc.tab + idx);
+    raw_apt_load(cur, gc.tab + ((size_t)j0 << (gc.bits - 1)) + idx);
     SBV_NOUNROLL
-    for (int j = 0; j < gc.windows; ++j) {
-        const int jn = j + 1 < gc.windows ? j + 1 : gc.windows - 1;
+    for (int j = j0; j < j1; ++j) {
+        const int jn = j + 1 < j1 ? j + 1 : j1 - 1;
         u32 idxn; bool negn, skipn;
         gcomb_digit(k1, gc.bits, jn, idxn, negn, skipn);
         raw_apt nxt;
@@ -139,20 +162,6 @@ SBV_HD void gphase29_lane_sorted(const Scratch& s, size_t t, size_t L, const gco
 // every wavefront paid a 33rd addition.  u2 * Q = (n - u2) * (-Q) (Q has order n), so a scalar with its top bit set is replaced
 // by n - u2 < 2^255 with every digit's sign flipped: the carry then needs a top byte of 0x7F (0.4 % of the lanes), and the loop
 // bound becomes wave-uniform — a wavefront runs window 32 only if one of its lanes carries (22 % of the wavefronts).
-SBV_HD bool wave_any(bool x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __any(x) != 0;
-#else
-    return x;
-#endif
-}
-SBV_HD bool wave_all(bool x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __all(x) != 0;
-#else
-    return x;
-#endif
-}
 
 // Wide combs of the consenters' keys (round 4).  The consenters of a SmartBFT cluster are a handful of keys that sign every vote of
 // every decision for a whole epoch (pkg/types/types.go:25-29; internal/bft/view.go:531-541, 631, 834): a registered slot the host
@@ -187,28 +196,10 @@ SBV_HD void qphase29_point(xyzz& R, const u256& u2in, const apt* qtab, int j0, i
     u256 u2, nmu;
     (void)sub256(nmu, sc_n(), u2in);                  // u2in < n always (stage A reduces it); garbage for an out-of-range lane, whose verdict is already false
     select256(u2, flip, nmu, u2in);
-    u256 k2;
-    const u32 top2 = add_const_limbs(k2, u2, 0x80808080u);
-    if (j1 == SBV_GTAB_WINDOWS && !wave_any(top2 != 0)) j1 = SBV_GTAB_WINDOWS - 1;
-    if (j0 >= j1) return;
-    int idx; bool neg, skip;
-    comb_digit(k2, top2, j0, idx, neg, skip);
-    raw_apt cur;
-    raw_apt_load(cur, qtab + (size_t)j0 * SBV_GTAB_PER_WINDOW + idx);
-    SBV_NOUNROLL
-    for (int j = j0; j < j1; ++j) {
-        const int jn = j + 1 < j1 ? j + 1 : j1 - 1;
-        int idxn; bool negn, skipn;
-        comb_digit(k2, top2, jn, idxn, negn, skipn);
-        raw_apt nxt;
-        raw_apt_load(nxt, qtab + (size_t)jn * SBV_GTAB_PER_WINDOW + idxn);
-        if (!skip) {
-            apt29 q;
-            raw_apt_unpack(q, cur);
-            pt29_madd(R, q, neg != flip);
-        }
-        cur = nxt; neg = negn; skip = skipn;
-    }
+    // a key's 8-bit comb IS a comb in the layout of the comb of G (gcomb) with bits = 8 and 33 windows: the same walker (round 6 — the
+    // dedicated loop of rounds 2-5 indexed the recoded scalar's register array dynamically and needed 247 VGPRs; this one fits 168)
+    const gcomb kc = {qtab, 8, SBV_GTAB_WINDOWS};
+    gphase29_point(R, u2, kc, true, flip, j0, j1, true);
 }
 // ---- the NARROW view of a key's comb (round 5) ------------------------------------------------------------------------------------
 // The rows step of the table builder (p256_keytab29.h) leaves, in every 128-entry window row j, the babies b * B_j (b = 1..8, entries
@@ -304,7 +295,18 @@ SBV_HD bool qphase29_lane_sorted(const Scratch& s, size_t t, size_t L, u32 slot,
     gacc29_load(R, gacc, s.cap, L);
     if (NARROW) qphase29_point_narrow(R, u2, qtab, j0, j1);
     else qphase29_point(R, u2, qtab, j0, j1);
-    if (!last) { gacc29_store(gacc, s.cap, L, R); return false; }
+    if (!last) {
+        // The accumulator goes back where it came from.  Left alone, the compiler keeps the 36 load addresses (72 VGPRs: the planes are
+        // `cap` words apart, no immediate offset reaches) alive across the whole comb loop for these stores — the difference between 168
+        // VGPRs and 66 spilled dwords at 3 waves per SIMD.  An opaque copy of the position makes it compute them again (a hundred
+        // instructions once per launch).
+        size_t Ls = L;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(Ls));
+#endif
+        gacc29_store(gacc, s.cap, Ls, R);
+        return false;
+    }
     u256 r;
     rec_load256(r, s.rec, t, SBV_REC_R);
     ok = ok && s.rec[t * SBV_REC_WORDS + SBV_REC_OK] != 0;

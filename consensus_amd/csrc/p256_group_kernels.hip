@@ -30,8 +30,10 @@
 #ifndef SBV_COMB29_WAVES
 #define SBV_COMB29_WAVES 2
 #endif
+// Q phase (round 6): the chunks' launches and the wide pass fit 168 VGPRs without a spill once each form is a kernel of its own
+// (k_verify_keyed_q<MODE, LAST>) — 3 waves per SIMD like the G phase; the rows-only pass (two table entries in flight per window) stays at 2
 #ifndef SBV_QPHASE_WAVES
-#define SBV_QPHASE_WAVES SBV_COMB29_WAVES
+#define SBV_QPHASE_WAVES 3
 #endif
 
 namespace sbv {
@@ -343,56 +345,64 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_GPHASE_WAVES) void k_gphase_s
 __device__ __forceinline__ int q_wave_class(bool dead, bool w, bool f) {
     return group_wave_class(wave_all(dead), wave_all(dead || w), wave_all(dead || f));      // the rule itself: p256_group.h, shared with tests/emul
 }
-template <int MODE>
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_keyed_q(Scratch s, GroupState g, const apt* __restrict__ ktab,
+// Round 6: LAST (the launch that turns the sum into a verdict) is a template parameter, and the compaction-order form is a kernel of its
+// own (k_verify_keyed_q_list).  With `last` a run-time flag one kernel held both continuations of the comb loop — park the accumulator,
+// or compare R.x with r — and the compaction-order copy of the loop beside them: 247 VGPRs, 2 waves per SIMD (128 spilled dwords at 3,
+// rounds 3-5).  Each of the forms alone is the G phase's loop with another table: 168 VGPRs, nothing spilled, 3 waves per SIMD.
+template <int MODE, bool LAST>
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, MODE == SBV_Q_NARROW ? SBV_COMB29_WAVES : SBV_QPHASE_WAVES) void k_verify_keyed_q(Scratch s, GroupState g, const apt* __restrict__ ktab,
                                                                     const uint8_t* __restrict__ kvalid, const u32* __restrict__ tslot,
                                                                     const uint8_t* __restrict__ full, const uint8_t* __restrict__ wide, widekeys wk, u32* __restrict__ wstat,
                                                                     u32 table_slots, u32* __restrict__ gacc,
-                                                                    uint8_t* __restrict__ acc, int j0, int j1, int last) {
+                                                                    uint8_t* __restrict__ acc, int j0, int j1) {
     // The rows-only and the wide pass are launched beside the chunks' launches for every batch, over the whole grouped list; in most
     // batches — the headline's 1 024 hot signers, a consenter replay — no group is of their class, and every wavefront used to load its
     // lane's group, slot and class bytes to find that out (16 384 wavefronts alive for 0.8 ms beside the Q phase).  The
     // class kernel counts the groups of each class: one scalar load per workgroup settles it.
     if (MODE == SBV_Q_NARROW && g.counters[5] >= group_count(g)) return;      // every group owns a full table: no wavefront can be rows-only
     if (MODE == SBV_Q_WIDE && g.counters[8] == 0) return;                     // no group may take the wide pass
-    if (g.sorted) {
-        // Key-sorted list: consecutive blocks hold consecutive keys.  The dispatcher deals workgroups round-robin over the
-        // 8 XCDs (block b -> XCD b % 8, MI355X_MICROARCH.md "Workgroup dispatch"; a speed assumption only), so block b takes
-        // logical block (b % 8) * per + b / 8: every XCD walks its own contiguous eighth of the list and a key's comb rows are
-        // fetched into ONE L2.  `per` comes from the live lane count, not the launch's upper bound, so the eighths are even.
-        const u32 lanes = g.counters[1];
-        const u32 per = ((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK + 7) >> 3;
-        const u32 local = blockIdx.x >> 3;
-        if (local >= per) return;
-        const u32 L = ((blockIdx.x & 7u) * per + local) * SBV_VERIFY_BLOCK + threadIdx.x;
-        if (L >= lanes) return;
-        const u32 t = g.grp_idx[L];
-        const u32 grp = g.grp_of[L];
-        const bool known = grp < group_count(g);
-        const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
-        const bool dead = !(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0;     // no slot, or a key that is no point: "reject" whatever is added
-        const int cls = q_wave_class(dead, !dead && wide[grp] != 0, !dead && full[grp] != 0);
-        if (cls == SBV_Q_NONE) { if (MODE == SBV_Q_FULL && last) acc[t] = 0; return; }                 // rejected without touching a table (there is none)
-        if (cls != MODE) return;                                                              // another instantiation's wavefront
-        if (MODE != SBV_Q_FULL) {                                                             // statistics only: lanes of the rows-only / the wide pass
-            const unsigned long long am = __ballot(true);
-            if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)am) - 1u) atomicAdd(MODE == SBV_Q_NARROW ? &g.counters[7] : wstat, (u32)__popcll(am));
-        }
-        if (MODE == SBV_Q_WIDE) {
-            u256 u2, r;
-            rec_load256(u2, s.rec, t, SBV_REC_U2);
-            xyzz R;
-            gacc29_load(R, gacc, s.cap, L);
-            wide_qphase29_point(R, u2, wk, dead ? 0u : wk.idx[ts]);                           // a dead lane of a wide wavefront walks comb 0: its verdict is false anyway
-            rec_load256(r, s.rec, t, SBV_REC_R);
-            acc[t] = !dead && s.rec[(size_t)t * SBV_REC_WORDS + SBV_REC_OK] != 0 && pt29_rx_matches(R, r) ? 1 : 0;
-            return;
-        }
-        const bool v = qphase29_lane_sorted<MODE == SBV_Q_NARROW>(s, t, L, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
-        if (last) acc[t] = v ? 1 : 0;
+    // Key-sorted list: consecutive blocks hold consecutive keys.  The dispatcher deals workgroups round-robin over the
+    // 8 XCDs (block b -> XCD b % 8, MI355X_MICROARCH.md "Workgroup dispatch"; a speed assumption only), so block b takes
+    // logical block (b % 8) * per + b / 8: every XCD walks its own contiguous eighth of the list and a key's comb rows are
+    // fetched into ONE L2.  `per` comes from the live lane count, not the launch's upper bound, so the eighths are even.
+    const u32 lanes = g.counters[1];
+    const u32 per = ((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK + 7) >> 3;
+    const u32 local = blockIdx.x >> 3;
+    if (local >= per) return;
+    const u32 L = ((blockIdx.x & 7u) * per + local) * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (L >= lanes) return;
+    const u32 t = g.grp_idx[L];
+    const u32 grp = g.grp_of[L];
+    const bool known = grp < group_count(g);
+    const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
+    const bool dead = !(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0;     // no slot, or a key that is no point: "reject" whatever is added
+    const int cls = q_wave_class(dead, !dead && wide[grp] != 0, !dead && full[grp] != 0);
+    if (cls == SBV_Q_NONE) { if (MODE == SBV_Q_FULL && LAST) acc[t] = 0; return; }                 // rejected without touching a table (there is none)
+    if (cls != MODE) return;                                                              // another instantiation's wavefront
+    if (MODE != SBV_Q_FULL) {                                                             // statistics only: lanes of the rows-only / the wide pass
+        const unsigned long long am = __ballot(true);
+        if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)am) - 1u) atomicAdd(MODE == SBV_Q_NARROW ? &g.counters[7] : wstat, (u32)__popcll(am));
+    }
+    if (MODE == SBV_Q_WIDE) {
+        u256 u2, r;
+        rec_load256(u2, s.rec, t, SBV_REC_U2);
+        xyzz R;
+        gacc29_load(R, gacc, s.cap, L);
+        wide_qphase29_point(R, u2, wk, dead ? 0u : wk.idx[ts]);                           // a dead lane of a wide wavefront walks comb 0: its verdict is false anyway
+        rec_load256(r, s.rec, t, SBV_REC_R);
+        acc[t] = !dead && s.rec[(size_t)t * SBV_REC_WORDS + SBV_REC_OK] != 0 && pt29_rx_matches(R, r) ? 1 : 0;
         return;
     }
-    // compaction order (SBV_GROUP_SORT=0): no wide pass (the class kernel leaves wide[] empty)
+    const bool v = qphase29_lane_sorted<MODE == SBV_Q_NARROW>(s, t, L, ts, table_slots, ktab, kvalid, gacc, j0, j1, LAST);
+    if (LAST) acc[t] = v ? 1 : 0;
+}
+// compaction order (SBV_GROUP_SORT=0): no wide pass (the class kernel leaves wide[] empty)
+template <int MODE>
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_verify_keyed_q_list(Scratch s, GroupState g, const apt* __restrict__ ktab,
+                                                                    const uint8_t* __restrict__ kvalid, const u32* __restrict__ tslot,
+                                                                    const uint8_t* __restrict__ full, u32 table_slots, u32* __restrict__ gacc,
+                                                                    uint8_t* __restrict__ acc, int j0, int j1, int last) {
+    if (MODE == SBV_Q_NARROW && g.counters[5] >= group_count(g)) return;
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= g.counters[1]) return;
     const u32 t = g.grp_idx[L];
@@ -402,7 +412,11 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_k
     const bool dead = !(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0;
     const int cls = q_wave_class(dead, false, !dead && full[grp] != 0);
     if (cls == SBV_Q_NONE) { if (MODE == SBV_Q_FULL && last) acc[t] = 0; return; }
-    if (cls != MODE || MODE == SBV_Q_WIDE) return;
+    if (cls != MODE) return;
+    if (MODE == SBV_Q_NARROW) {
+        const unsigned long long am = __ballot(true);
+        if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)am) - 1u) atomicAdd(&g.counters[7], (u32)__popcll(am));
+    }
     const bool v = qphase29_lane<MODE == SBV_Q_NARROW>(s, t, ts, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
     if (last) acc[t] = v ? 1 : 0;
 }
@@ -575,8 +589,8 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
             // latency chain at low occupancy, timeline_hot_4096_r05q.txt), as soon as the G phase is done.
             SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_generic, 0));
             SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_class, 0));
-            hipLaunchKernelGGL(k_verify_keyed_q<SBV_Q_WIDE>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
-                               table_slots, b.gacc, b.acc, 0, SBV_GTAB_WINDOWS, 1);
+            hipLaunchKernelGGL((k_verify_keyed_q<SBV_Q_WIDE, true>), dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
+                               table_slots, b.gacc, b.acc, 0, SBV_GTAB_WINDOWS);
             SBV_TRY(hipEventRecord(y.ev_wide, y.side_a));
         }
         SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[c], 0));
@@ -601,13 +615,19 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
             // the rows of every chunk (side_b has its own in stream order and waits for the other table stream's).
             SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_generic, 0));
             for (int cc = 0; cc < chunks; ++cc) SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_tables[cc], 0));
-            hipLaunchKernelGGL(k_verify_keyed_q<SBV_Q_NARROW>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_b, s, g, b.ntab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
-                               table_slots, b.gacc, b.acc, 0, SBV_GTAB_WINDOWS, 1);
+            if (g.sorted) hipLaunchKernelGGL((k_verify_keyed_q<SBV_Q_NARROW, true>), dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_b, s, g, b.ntab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
+                                             table_slots, b.gacc, b.acc, 0, SBV_GTAB_WINDOWS);
+            else hipLaunchKernelGGL(k_verify_keyed_q_list<SBV_Q_NARROW>, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, y.side_b, s, g, b.ntab, b.kvalid, b.tslot, b.full,
+                                    table_slots, b.gacc, b.acc, 0, SBV_GTAB_WINDOWS, 1);
             SBV_TRY(hipEventRecord(y.ev_narrow, y.side_b));
         }
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
-        hipLaunchKernelGGL(k_verify_keyed_q<SBV_Q_FULL>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
-                           table_slots, b.gacc, b.acc, j_first, j_end, last ? 1 : 0);
+        if (!g.sorted) hipLaunchKernelGGL(k_verify_keyed_q_list<SBV_Q_FULL>, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full,
+                                          table_slots, b.gacc, b.acc, j_first, j_end, last ? 1 : 0);
+        else if (last) hipLaunchKernelGGL((k_verify_keyed_q<SBV_Q_FULL, true>), dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
+                                          table_slots, b.gacc, b.acc, j_first, j_end);
+        else hipLaunchKernelGGL((k_verify_keyed_q<SBV_Q_FULL, false>), dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
+                                table_slots, b.gacc, b.acc, j_first, j_end);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
     if (!coop) SBV_TRY(hipStreamWaitEvent(stream, y.ev_narrow, 0));
