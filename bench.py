@@ -835,6 +835,26 @@ def leg_projected_strong_scaling(sbv, torch, d_tuples, valid, n, stream, base_ms
     return out
 
 
+# upper bucket edges of the reference's LatencyBatchProcessing histogram (pkg/api/metrics.go:427-435), in microseconds: what a node's
+# own metrics would show of these latencies — everything measured here lands in the first bucket (<= 5 ms), which is why the line also
+# carries percentiles
+LATENCY_BUCKETS_S = [0.005, 0.01, 0.015, 0.05, 0.1, 1, 10]
+LATENCY_BUCKETS_US = [e * 1e6 for e in LATENCY_BUCKETS_S]
+
+
+def dist_summary(samples_us, what):
+    xs = sorted(samples_us)
+    n = len(xs)
+    pick = lambda q: xs[min(n - 1, int(q * n))]            # noqa: E731
+    counts, prev = [], 0
+    for edge in LATENCY_BUCKETS_US:
+        c = sum(1 for x in xs if x <= edge)
+        counts.append(c - prev)
+        prev = c
+    return {"n": n, "p50": pick(0.50), "p90": pick(0.90), "p99": pick(0.99), "max": xs[-1], "min": xs[0], "mean": sum(xs) / n, "unit": "us",
+            "reference_histogram_buckets_le_s": LATENCY_BUCKETS_S, "reference_histogram_counts": counts, "what": what}
+
+
 def leg_m2(tuples, n):
     """BASELINE.json's second metric — commit-quorum latency at N = 16 (Q = 11): wall time from "15 commit signatures in
     host memory" to ">= 10 accepted" (SURVEY.md §8d M2).  (a) gpu: the 15 concurrent VerifyConsenterSig calls of
@@ -852,6 +872,21 @@ def leg_m2(tuples, n):
         rc = lib.sbvh_replay(v, 16, 10, 15, 0, min(64, os.cpu_count() or 8), ctypes.byref(res))
         lib.sbvh_verifier_free(v)
         out["gpu"] = res.commit_quorum_us if rc == 0 and res.status == 0 else None
+        # the DISTRIBUTION: 1000 sequences of the same harness (K = 10 requests per proposal, so that a sequence is
+        # VerifyProposal -> previous commits -> the burst of 15 votes, as a View runs it), every sequence's figure kept
+        try:
+            v = lib.sbvh_verifier_new(0, 0, cb, None, 1 << 20, 50, 0)
+            nseq = 1000
+            q_us = (ctypes.c_double * nseq)()
+            p_us = (ctypes.c_double * nseq)()
+            res2 = hostlib.ReplayResult()
+            rc2 = lib.sbvh_replay_samples(v, 16, 10, nseq, min(64, os.cpu_count() or 8), ctypes.byref(res2), q_us, p_us)
+            lib.sbvh_verifier_free(v)
+            if rc2 == 0 and res2.status == 0:
+                out["gpu_distribution"] = dist_summary(list(q_us), "15 concurrent VerifyConsenterSig -> 10 accepted, N = 16, through the Verifier's coalescer")
+                out["verify_proposal_k10_distribution"] = dist_summary(list(p_us), "VerifyProposal of the same sequences (10 request signatures: the latency form of the registered-key path)")
+        except Exception as e:      # noqa: BLE001
+            out["gpu_distribution"] = {"error": repr(e)}
         out["gpu_note"] = ("median over 15 sequences; 15 warm voter threads call VerifyConsenterSig at once, the leader-combining coalescer hands the burst to "
                            "the one-launch latency form (stage A of the quorum on the host with one inversion, 16 lanes per signature, mapped host memory in and out); registered consenter keys")
     except Exception as e:      # noqa: BLE001
@@ -873,11 +908,12 @@ def leg_m2(tuples, n):
             ts.append(1e6 * (time.perf_counter() - t0))
         out[name] = sorted(ts)[len(ts) // 2]
         ts1 = []
-        for _ in range(25):
+        for _ in range(1000):
             t0 = time.perf_counter()
             f(valid15.ctypes.data, 1, bm, 1)
             ts1.append(1e6 * (time.perf_counter() - t0))
         out[name.replace("cpu_15_threads", "cpu_one_verify")] = sorted(ts1)[len(ts1) // 2]
+        out[name.replace("cpu_15_threads", "cpu_one_verify") + "_distribution"] = dist_summary(ts1, "one verification on one warm core, 1000 in a row")
     one = out.get("cpu_one_verify_openssl") or out.get("cpu_one_verify_oracle_port")
     if one is not None and out.get("gpu") is not None:
         # What a Verifier that may use either pays for the quorum: 15 goroutines on 15 free cores finish in ONE verification's

@@ -537,6 +537,15 @@ def pool_stats():
     return {"cache_keys": out[0], "groups_per_batch": out[1], "shrunk": bool(out[2]), "nomem_fallbacks": out[3], "hot_pool": out[4], "gpu_share": out[5]}
 
 
+def debug_hot_check(device: int = 0):
+    """sbv_debug_hot_check: tuple of the 8 diagnostic words for context `device` (slow: a host build per promoted comb)."""
+    out = (ctypes.c_uint32 * 8)()
+    lib = load()
+    lib.sbv_debug_hot_check.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    _check(lib.sbv_debug_hot_check(device, out))
+    return tuple(out)
+
+
 def hot_keys(max_keys: int = 1024, min_hits: int = 0) -> None:
     """sbv_p256_hot_keys: wide combs for hot cache slots of the generic path (0 keys = off)."""
     lib = load()

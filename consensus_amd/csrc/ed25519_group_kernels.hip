@@ -17,6 +17,9 @@
 
 namespace sbv {
 
+#ifndef SBV_ED_QPHASE_WAVES
+#define SBV_ED_QPHASE_WAVES 3
+#endif
 #ifndef SBV_ED_GROUP_WAVES
 #define SBV_ED_GROUP_WAVES 2      // waves/SIMD the comb kernels are compiled for: 234 VGPRs and no scratch at 2; 168 + 268 B of spills at 3, same speed (profiles/r02/ed25519_ab_r02.txt)
 #endif
@@ -118,25 +121,31 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_gph
     if (i < n) ed_gphase_lane(tuples, i, btab, gacc, cap, okb, tuple_major != 0);
 }
 
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_qphase(const uint8_t* __restrict__ tuples, GroupState g,
+// Round 6: the key-sorted form and the compaction-order form are kernels of their own, LAST is a template parameter (what the P-256 Q
+// phase gained from the same split: each form alone needs far fewer registers than the kernel that held them all)
+template <bool LAST>
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_QPHASE_WAVES) void k_ed_qphase(const uint8_t* __restrict__ tuples, GroupState g,
+                                                                  const aniels* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
+                                                                  const u32* __restrict__ tslot, u32 table_slots,
+                                                                  u32* __restrict__ gacc, size_t cap, const uint8_t* __restrict__ okb,
+                                                                  uint8_t* __restrict__ acc, int j0, int j1) {
+    // key-sorted list, XCD-aware block order (see k_verify_keyed_q): block b takes logical block (b % 8) * per + b / 8
+    const u32 lanes = g.counters[1];
+    const u32 per = ((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK + 7) >> 3;
+    const u32 local = blockIdx.x >> 3;
+    if (local >= per) return;
+    const u32 L = ((blockIdx.x & 7u) * per + local) * SBV_VERIFY_BLOCK + threadIdx.x;
+    if (L >= lanes) return;
+    const u32 t = g.grp_idx[L];
+    const u32 grp = g.grp_of[L];
+    const bool v = ed_qphase_lane(tuples, t, grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE, table_slots, ktab, kvalid, gacc, cap, okb, j0, j1, LAST, true);
+    if (LAST) acc[t] = v ? SBV_ED_PENDING : 0;
+}
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_qphase_list(const uint8_t* __restrict__ tuples, GroupState g,
                                                                   const aniels* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
                                                                   const u32* __restrict__ tslot, u32 table_slots,
                                                                   u32* __restrict__ gacc, size_t cap, const uint8_t* __restrict__ okb,
                                                                   uint8_t* __restrict__ acc, int j0, int j1, int last) {
-    if (g.sorted) {
-        // key-sorted list, XCD-aware block order (see k_verify_keyed_q): block b takes logical block (b % 8) * per + b / 8
-        const u32 lanes = g.counters[1];
-        const u32 per = ((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK + 7) >> 3;
-        const u32 local = blockIdx.x >> 3;
-        if (local >= per) return;
-        const u32 L = ((blockIdx.x & 7u) * per + local) * SBV_VERIFY_BLOCK + threadIdx.x;
-        if (L >= lanes) return;
-        const u32 t = g.grp_idx[L];
-        const u32 grp = g.grp_of[L];
-        const bool v = ed_qphase_lane(tuples, t, grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE, table_slots, ktab, kvalid, gacc, cap, okb, j0, j1, last != 0, true);
-        if (last) acc[t] = v ? SBV_ED_PENDING : 0;
-        return;
-    }
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= g.counters[1]) return;
     const u32 t = g.grp_idx[L];
@@ -220,8 +229,12 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
-        hipLaunchKernelGGL(k_ed_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.tslot, table_slots, b.gacc, b.gacc_cap,
-                           eb.okb, b.acc, j_first, j_end, c + 1 == chunks ? 1 : 0);
+        if (!g.sorted) hipLaunchKernelGGL(k_ed_qphase_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.tslot, table_slots, b.gacc, b.gacc_cap,
+                                          eb.okb, b.acc, j_first, j_end, c + 1 == chunks ? 1 : 0);
+        else if (c + 1 == chunks) hipLaunchKernelGGL(k_ed_qphase<true>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.tslot, table_slots,
+                                                     b.gacc, b.gacc_cap, eb.okb, b.acc, j_first, j_end);
+        else hipLaunchKernelGGL(k_ed_qphase<false>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.tslot, table_slots,
+                                b.gacc, b.gacc_cap, eb.okb, b.acc, j_first, j_end);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
     {   // the pending tuples' encodings: one inversion per SBV_ED_FINISH_T tuples

@@ -359,7 +359,14 @@ SBV_HD bool k256_qphase_lane_sorted(const Scratch& s, size_t t, size_t L, u32 sl
     kjpt R;
     k256_gacc_load(R, gacc, s.cap, L);
     k256_qphase_point(R, u2, qtab, j0, j1);
-    if (!last) { k256_gacc_store(gacc, s.cap, L, R); return false; }
+    if (!last) {
+        size_t Ls = L;                     // an opaque copy: the store addresses are computed again instead of living through the loop (p256_comb29.h)
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(Ls));
+#endif
+        k256_gacc_store(gacc, s.cap, Ls, R);
+        return false;
+    }
     u256 r;
     rec_load256(r, s.rec, t, SBV_REC_R);
     ok = ok && s.rec[t * SBV_REC_WORDS + SBV_REC_OK] != 0;

@@ -119,9 +119,14 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_gphase_generic(Scr
     const size_t i = (size_t)(blockIdx.x - generic_blocks) * SBV_VERIFY_BLOCK + threadIdx.x;
     if (i < g.counters[1]) k256_gphase_lane_sorted(s, g.grp_idx[i], i, gc, gacc);
 }
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_qphase(Scratch s, GroupState g, const kapt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
+// (round 6: LAST is a template parameter, as in the P-256 Q phase — one continuation of the comb loop per kernel)
+#ifndef SBV_K256_QPHASE_WAVES
+#define SBV_K256_QPHASE_WAVES 2      // 3 waves: 17-25 spilled dwords (the Jacobian addition on 64-bit columns needs them), measured no faster in rounds 3-4
+#endif
+template <bool LAST>
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_K256_QPHASE_WAVES) void k_k256_qphase(Scratch s, GroupState g, const kapt* __restrict__ ktab, const uint8_t* __restrict__ kvalid,
                                                                    const u32* __restrict__ tslot, u32 table_slots,
-                                                                   u32* __restrict__ gacc, uint8_t* __restrict__ acc, int j0, int j1, int last) {
+                                                                   u32* __restrict__ gacc, uint8_t* __restrict__ acc, int j0, int j1) {
     // key-sorted list, XCD-aware block order (p256_group_kernels.hip: k_verify_keyed_q)
     const u32 lanes = g.counters[1];
     const u32 per = ((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK + 7) >> 3;
@@ -131,8 +136,8 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, 2) void k_k256_qphase(Scratch s, 
     if (L >= lanes) return;
     const u32 t = g.grp_idx[L];
     const u32 grp = g.grp_of[L];
-    const bool v = k256_qphase_lane_sorted(s, t, L, grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE, table_slots, ktab, kvalid, gacc, j0, j1, last != 0);
-    if (last) acc[t] = v ? 1 : 0;
+    const bool v = k256_qphase_lane_sorted(s, t, L, grp < group_count(g) ? tslot[grp] : SBV_GROUP_NONE, table_slots, ktab, kvalid, gacc, j0, j1, LAST);
+    if (LAST) acc[t] = v ? 1 : 0;
 }
 
 // stage A + stage B of a grouped secp256k1 batch.  ev_fork must have been recorded on `stream` first.  kp: this curve's comb
@@ -196,8 +201,8 @@ hipError_t launch_k256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
-        hipLaunchKernelGGL(k_k256_qphase, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, ktab, kvalid, b.tslot, table_slots, b.gacc, b.acc, j_first, j_end,
-                           c + 1 == chunks ? 1 : 0);
+        if (c + 1 == chunks) hipLaunchKernelGGL(k_k256_qphase<true>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, ktab, kvalid, b.tslot, table_slots, b.gacc, b.acc, j_first, j_end);
+        else hipLaunchKernelGGL(k_k256_qphase<false>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, ktab, kvalid, b.tslot, table_slots, b.gacc, b.acc, j_first, j_end);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
     hipLaunchKernelGGL(k_pack_bitmap, dim3((unsigned)(((n + 7) / 8 + 255) / 256)), dim3(256), 0, stream, b.acc, n, d_bitmap);

@@ -206,6 +206,21 @@ int fail(int code, const char* what, hipError_t e) {
         if (e_ != hipSuccess) return fail(code, #call, e_);     \
     } while (0)
 
+// Fill device memory and WAIT for the fill.  hipMemset of device memory returns before the fill has run — it is ordered in the NULL
+// stream only — and every stream of this library is created hipStreamNonBlocking: nothing orders their kernels behind the null stream.
+// Rounds 4-5 initialised the key-table cache (hash table, entry counter), the class bytes and the hot-key bookkeeping with bare
+// hipMemset calls and launched the first grouped batch right behind them; normally the fill wins by milliseconds.  With eight contexts
+// on one GPU (SBV_LOGICAL_DEVICES, round 6) the null stream is shared and busy with the other contexts' table uploads: in one start-up of
+// ~60 a context's late fill wiped the cache entries its first batch had just published, the next batch re-inserted every key into
+// re-used slots, and the wide combs promoted for the old slot numbers then served other keys — honest signatures rejected from the third
+// batch on (tools/stress_logical.py; profiles/r06/stress_logical_*).  A device-side race of this kind is a correctness bug on any
+// device count.
+hipError_t memset_now(void* p, int v, size_t bytes) {
+    hipError_t e = hipMemset(p, v, bytes);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    return e;
+}
+
 constexpr size_t kMaxChunk = (size_t)1 << 21;   // tuples per launch; bounds scratch at ~3.3 GB
 // Groups per batch of the Ed25519 / secp256k1 grouped steps.  Their tables are always full 8-bit combs (no rows-only class) at the
 // threshold of 64 uses they always had, so round 5's 65 536 groups of the P-256 step would only size their pools (384 KiB per key);
@@ -287,8 +302,8 @@ int key_cache_alloc(sbv::KeyCache& kc, size_t K, bool enabled) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&kc.ht, kht * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&kc.keys, (K ? K : 1) * 16 * sizeof(u32)));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&kc.count, 4 * sizeof(u32)));
-    HIP_TRY(SBV_EDEVICE, hipMemset(kc.ht, 0, kht * sizeof(u32)));
-    HIP_TRY(SBV_EDEVICE, hipMemset(kc.count, 0, 4 * sizeof(u32)));
+    HIP_TRY(SBV_EDEVICE, memset_now(kc.ht, 0, kht * sizeof(u32)));
+    HIP_TRY(SBV_EDEVICE, memset_now(kc.count, 0, 4 * sizeof(u32)));
     kc.ht_mask = (u32)(kht - 1);
     kc.cap = (u32)K;
     kc.enabled = enabled ? 1u : 0u;
@@ -303,18 +318,18 @@ void key_cache_free(sbv::KeyCache& kc) {
 // forget every cached key (the tables stay where they are; nothing points at them any more)
 hipError_t key_cache_forget(sbv::KeyCache& kc) {
     if (!kc.ht) return hipSuccess;
-    hipError_t e = hipMemset(kc.ht, 0, ((size_t)kc.ht_mask + 1) * sizeof(u32));
-    if (e == hipSuccess) e = hipMemset(kc.count, 0, 4 * sizeof(u32));
+    hipError_t e = memset_now(kc.ht, 0, ((size_t)kc.ht_mask + 1) * sizeof(u32));
+    if (e == hipSuccess) e = memset_now(kc.count, 0, 4 * sizeof(u32));
     return e;
 }
 
 // the P-256 cache was emptied: its slots' wide combs belong to nobody any more
 hipError_t hot_forget(sbv::GroupBuffers& b) {
     if (!b.kwide) return hipSuccess;
-    hipError_t e = hipMemset(b.kwide, 0xFF, (size_t)b.kc.cap * sizeof(u32));
-    if (e == hipSuccess) e = hipMemset(b.khits, 0, (size_t)b.kc.cap * sizeof(u32));
-    if (e == hipSuccess) e = hipMemset(b.hot, 0, 4 * sizeof(u32));
-    if (e == hipSuccess && b.wowner) e = hipMemset(b.wowner, 0xFF, (size_t)b.wide_cap * sizeof(u32));
+    hipError_t e = memset_now(b.kwide, 0xFF, (size_t)b.kc.cap * sizeof(u32));
+    if (e == hipSuccess) e = memset_now(b.khits, 0, (size_t)b.kc.cap * sizeof(u32));
+    if (e == hipSuccess) e = memset_now(b.hot, 0, 4 * sizeof(u32));
+    if (e == hipSuccess && b.wowner) e = memset_now(b.wowner, 0xFF, (size_t)b.wide_cap * sizeof(u32));
     return e;
 }
 
@@ -433,7 +448,7 @@ int ensure_group_buffers(Context& c, size_t n) {
         HIP_TRY(SBV_ENOMEM, hipMalloc(&b.ntab, (K + G) * (size_t)(SBV_GTAB_WINDOWS * 16) * sizeof(sbv::apt)));      // compact rows: 33 KiB per slot
         HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kvalid, K + G));
         HIP_TRY(SBV_ENOMEM, hipMalloc(&b.kfull, K + G));
-        HIP_TRY(SBV_EDEVICE, hipMemset(b.kfull, 0, K + G));
+        HIP_TRY(SBV_EDEVICE, memset_now(b.kfull, 0, K + G));
         const int krc = key_cache_alloc(b.kc, K, c.kc_on[0]);
         if (krc != SBV_OK) return krc;
         // hot keys: the pool of wide combs for promoted cache slots (p256_group.h), as large as asked for if that leaves the reserve free
@@ -452,9 +467,9 @@ int ensure_group_buffers(Context& c, size_t n) {
                                  hipMalloc(&b.pbases, SBV_PROMOTE_MAX * 2 * W * sizeof(sbv::apt)) == hipSuccess &&
                                  hipMalloc(&b.ptmp, sbv::widetab_tmp_words(SBV_PROMOTE_MAX, SBV_HOT_BITS) * sizeof(u32)) == hipSuccess &&
                                  hipMalloc(&b.wowner, want * sizeof(u32)) == hipSuccess && hipMalloc(&b.elist, SBV_PROMOTE_MAX * sizeof(u32)) == hipSuccess &&
-                                 hipMemset(b.wowner, 0xFF, want * sizeof(u32)) == hipSuccess &&
-                                 hipMemset(b.kwide, 0xFF, K * sizeof(u32)) == hipSuccess && hipMemset(b.khits, 0, K * sizeof(u32)) == hipSuccess &&
-                                 hipMemset(b.hot, 0, 4 * sizeof(u32)) == hipSuccess;
+                                 memset_now(b.wowner, 0xFF, want * sizeof(u32)) == hipSuccess &&
+                                 memset_now(b.kwide, 0xFF, K * sizeof(u32)) == hipSuccess && memset_now(b.khits, 0, K * sizeof(u32)) == hipSuccess &&
+                                 memset_now(b.hot, 0, 4 * sizeof(u32)) == hipSuccess;
                 if (got) {
                     b.wide_cap = (u32)want;
                 } else {
@@ -675,13 +690,14 @@ int ensure_key_capacity(Context& c, size_t want) {
     HIP_TRY(SBV_ENOMEM, hipMalloc(&nt, cap * kKeyTabBytes));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&nv, cap));
     HIP_TRY(SBV_ENOMEM, hipMalloc(&nw, cap * sizeof(u32)));
-    HIP_TRY(SBV_EDEVICE, hipMemset(nv, 0, cap));
-    HIP_TRY(SBV_EDEVICE, hipMemset(nw, 0xFF, cap * sizeof(u32)));      // SBV_WIDE_NONE
+    HIP_TRY(SBV_EDEVICE, memset_now(nv, 0, cap));
+    HIP_TRY(SBV_EDEVICE, memset_now(nw, 0xFF, cap * sizeof(u32)));      // SBV_WIDE_NONE
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());          // nothing in flight may still read the old tables
     if (c.nkeys) {
         HIP_TRY(SBV_EDEVICE, hipMemcpy(nt, c.d_ktab, c.nkeys * kKeyTabBytes, hipMemcpyDeviceToDevice));
         HIP_TRY(SBV_EDEVICE, hipMemcpy(nv, c.d_kvalid, c.nkeys, hipMemcpyDeviceToDevice));
         HIP_TRY(SBV_EDEVICE, hipMemcpy(nw, c.d_kwidx, c.nkeys * sizeof(u32), hipMemcpyDeviceToDevice));
+        HIP_TRY(SBV_EDEVICE, hipStreamSynchronize(nullptr));     // device-to-device copies are ordered in the null stream only (see memset_now)
     }
     if (c.d_kwidx) (void)hipFree(c.d_kwidx);
     c.d_kwidx = nw;
@@ -1244,7 +1260,7 @@ int widen_slots(Context& c, const std::vector<u32>& slots) {
         HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());          // nothing in flight may still read the old tables
         if (!c.wide_slots.empty()) {
             const hipError_t e = hipMemcpy(nt, c.d_kwide, c.wide_slots.size() * stride * sizeof(sbv::apt), hipMemcpyDeviceToDevice);
-            if (e != hipSuccess) { (void)hipFree(nt); return fail(SBV_EDEVICE, "wide combs: copy", e); }
+            if (e != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(nt); return fail(SBV_EDEVICE, "wide combs: copy", e); }
         }
         if (c.d_kwide) (void)hipFree(c.d_kwide);
         c.d_kwide = nt;
@@ -1284,7 +1300,7 @@ int widen_slots(Context& c, const std::vector<u32>& slots) {
             }
         }
         // not a point: kvalid[slot] = 0 rejects its signatures whatever the lanes add; its comb is zeros
-        if (!have) { const hipError_t e = hipMemset(c.d_kwide + (size_t)w * stride, 0, stride * sizeof(sbv::apt)); if (e != hipSuccess) { rollback(); return fail(SBV_EDEVICE, "wide combs: zero", e); } }
+        if (!have) { const hipError_t e = memset_now(c.d_kwide + (size_t)w * stride, 0, stride * sizeof(sbv::apt)); if (e != hipSuccess) { rollback(); return fail(SBV_EDEVICE, "wide combs: zero", e); } }
         c.wide_slots.push_back(sl);
         if (host_build || !have) {      // published after its table is complete
             const hipError_t e = hipMemcpy(c.d_kwidx + sl, &w, sizeof(u32), hipMemcpyHostToDevice);
@@ -1321,7 +1337,7 @@ int widen_slots(Context& c, const std::vector<u32>& slots) {
 }
 int drop_wide_keys(Context& c) {
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
-    if (c.d_kwidx && c.key_cap) HIP_TRY(SBV_EDEVICE, hipMemset(c.d_kwidx, 0xFF, c.key_cap * sizeof(u32)));
+    if (c.d_kwidx && c.key_cap) HIP_TRY(SBV_EDEVICE, memset_now(c.d_kwidx, 0xFF, c.key_cap * sizeof(u32)));
     if (c.d_kwide) (void)hipFree(c.d_kwide);
     c.d_kwide = nullptr; c.kwide_cap = 0; c.wide_slots.clear();
     return SBV_OK;
@@ -1538,7 +1554,7 @@ extern "C" int sbv_p256_clear_keys(void) {
         if (e == hipSuccess) e = hipDeviceSynchronize();
         c.key_index.clear();
         c.nkeys = 0;
-        if (e == hipSuccess && c.d_kwidx && c.key_cap) e = hipMemset(c.d_kwidx, 0xFF, c.key_cap * sizeof(u32));
+        if (e == hipSuccess && c.d_kwidx && c.key_cap) e = memset_now(c.d_kwidx, 0xFF, c.key_cap * sizeof(u32));
         c.wide_slots.clear();        // the allocation stays for the next registry
         if (e != hipSuccess) rc = fail(SBV_EDEVICE, "sbv_p256_clear_keys", e);
     }
@@ -2232,6 +2248,73 @@ extern "C" int sbv_p256_hot_key_stats(uint32_t out[4]) {
     HIP_TRY(SBV_EDEVICE, hipMemcpy(h, c.grp.hot, sizeof h, hipMemcpyDeviceToHost));
     out[0] = h[0] < c.grp.wide_cap ? h[0] : c.grp.wide_cap;
     out[2] = h[2];
+    return SBV_OK;
+}
+
+// Diagnostics (round 6): every promoted comb of context `device` against the host builder, and the consistency of kwide / wowner.
+// out[0] = promoted slots, out[1] = combs that differ, out[2] = first differing comb's index, out[3] = its first differing entry,
+// out[4] = number of differing entries in it, out[5] = kwide / wowner inconsistencies, out[6] = slots whose kwide index is shared with
+// another slot, out[7] = hot[0].  Slow (a host build per comb); tests and tools only.
+extern "C" int sbv_debug_hot_check(int device, uint32_t out[8]) {
+    Context* cp;
+    { std::lock_guard<std::mutex> lk(g_mu); cp = context_of(device, false); }
+    if (!cp || !out) return SBV_EINVAL;
+    std::lock_guard<std::mutex> lkc(cp->mu);
+    Context& c = *cp;
+    if (!c.ready) return SBV_ENOTINIT;
+    sbv::GroupBuffers& b = c.grp;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    if (!b.wtab || !b.kwide) return SBV_OK;
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.hip_dev));
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    std::vector<u32> kw(b.kc.cap), wo(b.wide_cap), hot(4);
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(kw.data(), b.kwide, kw.size() * sizeof(u32), hipMemcpyDeviceToHost));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(wo.data(), b.wowner, wo.size() * sizeof(u32), hipMemcpyDeviceToHost));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(hot.data(), b.hot, 4 * sizeof(u32), hipMemcpyDeviceToHost));
+    out[7] = hot[0];
+    if (getenv("SBV_DEBUG_HOT_DUMP")) {          // tools/stress_logical.py: the whole bookkeeping of the context on stderr
+        u32 cnt[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(cnt, b.kc.count, sizeof cnt, hipMemcpyDeviceToHost);
+        const u32 entries = cnt[0] < b.kc.cap ? cnt[0] : b.kc.cap;
+        std::vector<u32> keys((size_t)entries * 16), kh(b.kc.cap);
+        std::vector<uint8_t> kv(entries), kf(entries);
+        (void)hipMemcpy(keys.data(), b.kc.keys, keys.size() * sizeof(u32), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(kh.data(), b.khits, kh.size() * sizeof(u32), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(kv.data(), b.kvalid, entries, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(kf.data(), b.kfull, entries, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[hot dump ctx %d] cache entries %u (hits %u misses %u) hot %u %u %u %u tick %u\n", c.device, cnt[0], cnt[1], cnt[2], hot[0], hot[1], hot[2], hot[3], b.hot_tick);
+        std::unordered_map<std::string, u32> seen;
+        for (u32 sl = 0; sl < entries; ++sl) {
+            const std::string k((const char*)&keys[(size_t)sl * 16], 64);
+            const auto it = seen.find(k);
+            const int dup = it == seen.end() ? -1 : (int)it->second;
+            if (it == seen.end()) seen.emplace(k, sl);
+            if (kh[sl] || kw[sl] != 0xFFFFFFFFu || dup >= 0)
+                fprintf(stderr, "  slot %u key %08x%08x valid %u full %u hits %u wide %d dup_of %d\n", sl, keys[(size_t)sl * 16], keys[(size_t)sl * 16 + 1], kv[sl], kf[sl], kh[sl], (int)kw[sl], dup);
+        }
+    }
+    const size_t stride = sbv::gcomb_entries(SBV_HOT_BITS), per = (size_t)1 << (SBV_HOT_BITS - 1);
+    const size_t W = stride / per;
+    std::vector<sbv::apt> want(stride), got(stride);
+    std::vector<u32> users(b.wide_cap, 0);
+    unsigned hw = std::thread::hardware_concurrency();
+    for (size_t slot = 0; slot < kw.size(); ++slot) {
+        const u32 w = kw[slot];
+        if (w == 0xFFFFFFFFu) continue;
+        ++out[0];
+        if (w >= b.wide_cap) { ++out[5]; continue; }
+        if (wo[w] != slot) ++out[5];
+        if (users[w]++) ++out[6];
+        uint8_t key[64];
+        HIP_TRY(SBV_EDEVICE, hipMemcpy(key, b.kc.keys + slot * 16, 64, hipMemcpyDeviceToHost));
+        if (!sbv::host_build_wide_key_table(key, SBV_HOT_BITS, want.data(), (int)(hw > 32 ? 32 : (hw ? hw : 1)))) continue;
+        HIP_TRY(SBV_EDEVICE, hipMemcpy(got.data(), b.wtab + (size_t)w * stride, stride * sizeof(sbv::apt), hipMemcpyDeviceToHost));
+        size_t bad = 0, first = 0;
+        const size_t lim = (W - 1) * per + (((size_t)1 << (SBV_HOT_BITS / 2)) - 1);
+        for (size_t e = 0; e < lim; ++e)
+            if (memcmp(&got[e], &want[e], sizeof(sbv::apt)) != 0) { if (!bad) first = e; ++bad; }
+        if (bad) { if (!out[1]) { out[2] = w; out[3] = (u32)first; out[4] = (u32)bad; } ++out[1]; }
+    }
     return SBV_OK;
 }
 

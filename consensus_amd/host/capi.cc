@@ -437,7 +437,19 @@ static double median(std::vector<double> v) {
 //   VerifyProposal(K sigs)  ->  verifyPrevCommitSignatures (Q-1 serial calls, view.go:630)
 //   -> processCommits: N-1 concurrent VerifyConsenterSig calls, wait for Q-1 (view.go:537-541, 531)
 // and, when decisions > 0, config 4: `decisions` proposals x Q signatures verified as one batch.
+static int replay_core(void* h, int n_nodes, int K, int sequences, int decisions, int threads, sbvh_replay_result* out,
+                       double* quorum_samples_us, double* proposal_samples_us);
 int sbvh_replay(void* h, int n_nodes, int K, int sequences, int decisions, int threads, sbvh_replay_result* out) {
+    return replay_core(h, n_nodes, K, sequences, decisions, threads, out, nullptr, nullptr);
+}
+// The same run with every sequence's figures kept (round 6): quorum_us[s] = "N - 1 votes in host memory -> Q - 1 accepted"
+// of sequence s, proposal_us[s] = its VerifyProposal.  LatencyBatchProcessing (internal/bft/view.go:345, 396; buckets
+// pkg/api/metrics.go:427-435) is a histogram: a median of 15 says nothing about its tail.
+int sbvh_replay_samples(void* h, int n_nodes, int K, int sequences, int threads, sbvh_replay_result* out, double* quorum_us, double* proposal_us) {
+    return replay_core(h, n_nodes, K, sequences, 0, threads, out, quorum_us, proposal_us);
+}
+static int replay_core(void* h, int n_nodes, int K, int sequences, int decisions, int threads, sbvh_replay_result* out,
+                       double* quorum_samples_us, double* proposal_samples_us) {
     Verifier& V = *((VHandle*)h)->v;
     memset(out, 0, sizeof *out);
     int Q = 0, F = 0;
@@ -558,6 +570,8 @@ int sbvh_replay(void* h, int n_nodes, int K, int sequences, int decisions, int t
         { std::lock_guard<std::mutex> lk(m); t_quorum.push_back(t_done - t0); }
     }
     stop_voters();
+    if (quorum_samples_us) for (size_t i = 0; i < t_quorum.size(); ++i) quorum_samples_us[i] = t_quorum[i];
+    if (proposal_samples_us) for (size_t i = 0; i < t_prop.size(); ++i) proposal_samples_us[i] = t_prop[i];
     out->verify_proposal_us = median(t_prop);
     out->prev_commits_us = median(t_prev);
     out->commit_quorum_us = median(t_quorum);

@@ -260,6 +260,10 @@ int sbv_p256_last_table_classes(uint32_t out[3]);
  * for, out[3] = grouped batches that fell back to the one-lane kernel for lack of memory, out[4] = combs of the hot-key pool,
  * out[5] = contexts sharing this GPU.  out[0..1] are 0 before the first grouped batch.  Rates change with the pools, verdicts never. */
 int sbv_p256_pool_stats(uint32_t out[6]);
+/* Diagnostics (tests / tools): every promoted hot-key comb of context `device` compared with the host builder, and the consistency of the
+ * pool's bookkeeping.  out[0] promoted slots, [1] combs that differ, [2] the first such comb, [3] its first differing entry, [4] how many of
+ * its entries differ, [5] index / owner inconsistencies, [6] combs claimed by more than one slot, [7] combs handed out so far.  Slow. */
+int sbv_debug_hot_check(int device, uint32_t out[8]);
 /* Hot keys (round 5): wide combs in the GENERIC path.  A key that arrives inside tuples — a client key of VerifyProposal
  * (internal/bft/view.go:553-559), a consenter of a replica that registered nothing — and keeps being hit is promoted: once the
  * key-table cache has verified `min_hits` tuples against its slot, a 16-bit comb (35.7 MB; up to `max_keys` of them, default 1024 =

@@ -79,6 +79,8 @@ def load():
     lib.sbvh_backend_widened_keys.restype = ctypes.c_uint64
     lib.sbvh_batch_faults.argtypes = [V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     lib.sbvh_replay.argtypes = [V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ReplayResult)]
+    lib.sbvh_replay_samples.argtypes = [V, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ReplayResult),
+                                        ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     return lib
 
 

@@ -308,6 +308,36 @@ def test_config3_over_8_logical_devices(oracle):
         sbv.shutdown()
 
 
+def test_start_up_of_eight_contexts_does_not_race_with_their_first_batches(oracle):
+    """Round 6 found a device-side race as old as the key-table cache: its hash table, entry counter and the hot keys' bookkeeping were
+    initialised with bare hipMemset calls — ordered in the NULL stream only — right in front of the first grouped batch on the library's
+    non-blocking streams.  With eight contexts starting on one GPU the null stream is busy, and in one start-up of ~60 a late fill wiped
+    what the first batch had just published; from the third batch on honest signatures of up to 8 of the 16 signers were rejected
+    (profiles/r06/stress_logical_before_fix_*).  sbv_api.hip: memset_now().  Ten start-ups here (tools/stress_logical.py runs hundreds):
+    every verdict of four calls each, and the bookkeeping of a context checked against the host builder."""
+    import numpy as np
+    os.environ["SBV_LOGICAL_DEVICES"] = "8"
+    os.environ["SBV_SHARD_MIN"] = str(1 << 16)
+    try:
+        P, Q = 50000, 11
+        n = P * Q
+        tup, exp = _gen(oracle, 0xC3, n, 16, 8)
+        for cycle in range(10):
+            sbv.shutdown()
+            assert sbv.init_all() == 8
+            for call in range(4):
+                got = ctypes.create_string_buffer((n + 7) // 8)
+                sbv.verify_batch_sharded(ctypes.addressof(tup), n, ctypes.addressof(got), group=Q, quorum=Q - 1)
+                assert got.raw == exp, (cycle, call, _diff(got.raw, exp))
+            if cycle in (0, 9):
+                promoted, differ, _, _, _, inconsistent, shared, handed_out = sbv.debug_hot_check(cycle % 8)
+                assert promoted == handed_out and promoted >= 10 and differ == 0 and inconsistent == 0 and shared == 0
+    finally:
+        os.environ.pop("SBV_LOGICAL_DEVICES", None)
+        os.environ.pop("SBV_SHARD_MIN", None)
+        sbv.shutdown()
+
+
 def test_small_device_gets_smaller_pools_not_enomem(oracle):
     """the grouping pools default to 25 GB (65 536 groups + 16 384 cached keys); round 5 returned SBV_ENOMEM for every
     grouped batch on a device that could not hold them.  SBV_POOL_BUDGET_MB stands in for the small device: the pools are halved until

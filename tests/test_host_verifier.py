@@ -473,6 +473,31 @@ def test_replay_driver_runs_the_reference_call_pattern(lib, oracle, backend_kind
         hx.close()
 
 
+def test_replay_samples_keep_every_sequence_and_the_distribution_summary(lib, oracle):
+    """sbvh_replay_samples (round 6): the replay harness with every sequence's commit-quorum and VerifyProposal time kept — what
+    bench.py's M2 leg turns into p50 / p99 / max and into the counts of the reference's LatencyBatchProcessing buckets
+    (pkg/api/metrics.go:427-435; observed at internal/bft/view.go:345, 396)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    hx = Harness(lib, oracle, wait_us=300, backend_kind=2)
+    try:
+        nseq = 12
+        q = (ctypes.c_double * nseq)()
+        p = (ctypes.c_double * nseq)()
+        res = hostlib.ReplayResult()
+        assert lib.sbvh_replay_samples(hx.v, 7, 5, nseq, 4, ctypes.byref(res), q, p) == 0 and res.status == 0
+        qs, ps = list(q), list(p)
+        assert all(x > 0 for x in qs) and all(x > 0 for x in ps)
+        assert sorted(qs)[nseq // 2] == res.commit_quorum_us and sorted(ps)[nseq // 2] == res.verify_proposal_us
+        d = bench.dist_summary(qs, "test")
+        assert d["n"] == nseq and d["min"] <= d["p50"] <= d["p90"] <= d["p99"] <= d["max"]
+        assert d["reference_histogram_buckets_le_s"] == [0.005, 0.01, 0.015, 0.05, 0.1, 1, 10] and sum(d["reference_histogram_counts"]) == nseq
+        assert bench.dist_summary([1.0, 6000.0, 2e4, 2e7], "x")["reference_histogram_counts"] == [1, 1, 0, 1, 0, 0, 0]
+    finally:
+        hx.close()
+
+
 @pytest.mark.parametrize("backend_kind", [1, 2])
 def test_decision_batch_rejects_exactly_the_spoiled_signatures(lib, oracle, backend_kind):
     """VerifyConsenterSigBatch over 40 decisions x Q signatures of a 7-node cluster with every 7th signature spoiled in one of four
