@@ -180,8 +180,7 @@ def leg_warm_cache(sbv, torch, d_tuples, d_bitmap, valid, n, steps, stream):
         # owns a 16-bit comb, timed as they go, then the same measurement with the wide pass serving the batch
         try:
             sbv.hot_keys(1024, 4096)
-            # (round 6: a slot earns its comb with ACCEPTED tuples — the 128 signers under which this synthetic batch puts all its
-            # corrupted signatures never do: the ramp ends when three batches in a row promoted nobody)
+            # (the ramp also ends when three batches in a row promoted nobody: a pool smaller than the signer set)
             ramp, last, still = [], -1, 0
             for _ in range(160):
                 t0 = time.perf_counter()

@@ -437,40 +437,37 @@ SBV_HD int group_wave_class(bool all_dead, bool all_dead_or_wide, bool all_dead_
 }
 #define SBV_PROMOTE_MAX 64u
 #define SBV_HOT_BITS 16
-SBV_HD void group_hot_class_lane(u32 k, const GroupState& g, const u32* tslot, const uint8_t* cold, u32 cache_cap, const u32* kwide, uint8_t* wide) {
-    (void)g;
+#define SBV_HOT_HITS_MAX 0x3FFFFFFFu
+SBV_HD void group_hot_class_lane(u32 k, const GroupState& g, const u32* tslot, const uint8_t* cold, u32 cache_cap, const u32* kwide, u32* khits,
+                                 uint8_t* wide) {
     const u32 slot = tslot[k];
-    wide[k] = slot < cache_cap && !cold[k] && kwide[slot] != 0xFFFFFFFFu ? 1 : 0;
+    bool w = false;
+    if (slot < cache_cap) {
+        const u32 count = g.sorted ? g.gcount[k] : g.cnt[g.group_rep[k]] * (g.sample_mask + 1u);
+        const u32 h = khits[slot];                              // one group per slot and batch: no atomics
+        khits[slot] = h > SBV_HOT_HITS_MAX - count ? SBV_HOT_HITS_MAX : h + count;
+        w = !cold[k] && kwide[slot] != 0xFFFFFFFFu;
+    }
+    wide[k] = w ? 1 : 0;
 }
 // ---- life cycle of the hot keys (round 6) --------------------------------------------------------------------
-// Round 5 counted every tuple GROUPED under a slot, never forgot a count and never took a comb back: 4 096 garbage signatures under
-// each of 1 024 valid curve points filled the pool for good, and a long-running node kept the combs of yesterday's clients
-// (signer sets change on reconfiguration: pkg/consensus/consensus.go:185-252).  Now:
-//   * a slot's count grows by the tuples of the batch that were ACCEPTED under it (the tail of the step reads the verdict bytes;
-//     garbage earns nothing);
+// Round 5 never forgot a count and never took a comb back: 4 096 signatures under each of 1 024 throw-away keys filled the pool for
+// good, and a long-running node kept the combs of yesterday's clients (signer sets change on reconfiguration:
+// pkg/consensus/consensus.go:185-252).  Now:
 //   * every SBV_HOT_DECAY_EVERY-th grouped batch halves every count (a clock sweep over the cache slots): a key must keep signing
 //     ~promote_min / 2 DECAY_EVERY tuples per batch to stay above the threshold, a key that stopped falls below it within
 //     DECAY_EVERY * log2(count / promote_min) batches;
 //   * when the pool is full, a slot that has earned a comb takes the comb of the owner with the LOWEST count — if that count is at
 //     most half its own (hysteresis: two keys of similar heat never trade a 35.7 MB comb back and forth); wowner[w] = the slot
 //     that owns comb w.  The victim keeps its 8-bit table and is served from it again from the next batch on.
+// A slot's count grows by the tuples GROUPED under it, whatever their verdicts.  Counting accepted tuples only (ADVICE r5's other
+// option) was built and measured first: it costs a pass over the grouped list per batch and buys nothing — whoever can send 4 096
+// garbage signatures under a key of his own can as well send 4 096 valid ones; what bounds the damage is that combs follow the heat
+// (decay + eviction), not that they are hard to earn — and it left the signers under which the synthetic batch of SURVEY 8d puts all
+// its corrupted signatures (1/8 of the keys) on their 8-bit tables for ever (one PCIe caller 270 -> 197 M/s, profiles/r06).
 // Counts saturate far below 2^32.  Verdicts never depend on any of this (a comb is a function of its key's 64 bytes).
 #define SBV_HOT_DECAY_EVERY 16u
-#define SBV_HOT_HITS_MAX 0x3FFFFFFFu
 SBV_HD void hot_decay_lane(u32 slot, u32* khits) { khits[slot] >>= 1; }
-// one accepted tuple (or `count` of them: a wavefront's lanes of one slot) under cache slot `slot`
-SBV_HD void hot_hit(u32 slot, u32 count, u32* khits) {
-    const u32 before = SBV_ATOMIC_ADD(&khits[slot], count);
-    if (before > SBV_HOT_HITS_MAX) khits[slot] = SBV_HOT_HITS_MAX;          // saturation; a racing add at the ceiling loses at most its own count
-}
-// lane L of the grouped list: the cache slot its accepted tuple counts for, or SBV_GROUP_NONE
-SBV_HD u32 hot_hit_slot(const GroupState& g, u32 L, u32 groups, const u32* tslot, const uint8_t* acc, u32 cache_cap) {
-    const u32 t = g.grp_idx[L];
-    const u32 grp = g.sorted ? g.grp_of[L] : g.slots[t];
-    if (!(grp < groups) || acc[t] != 1) return SBV_GROUP_NONE;
-    const u32 slot = tslot[grp];
-    return slot < cache_cap ? slot : SBV_GROUP_NONE;
-}
 // Eviction, one candidate at a time.  hot_evict_scan: lane `lane` of `lanes` looks at owners w = lane, lane + lanes, ... that were not
 // handed out in this batch (taken: one bit per comb) and keeps the coldest (lowest count, then lowest index: deterministic across any
 // number of lanes); hot_evict_better merges two lanes' findings; hot_evict_ok is the hysteresis.

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_group_table_class(GroupState g, const u
     const u32 groups = group_count(g);
     for (u32 k = blockIdx.x * 256 + threadIdx.x; k < groups; k += gridDim.x * 256) {
         group_table_class_lane(k, g, tslot, cold, kfull, table_slots, full_min, full, needfill);
-        if (hk.kwide && g.sorted) group_hot_class_lane(k, g, tslot, cold, hk.cache_cap, hk.kwide, wide);
+        if (hk.kwide && g.sorted) group_hot_class_lane(k, g, tslot, cold, hk.cache_cap, hk.kwide, hk.khits, wide);
         else wide[k] = 0;
         if (full[k]) atomicAdd(&g.counters[5], 1u);           // sbv_p256_last_table_classes; and [5] == groups tells the rows-only pass that it has no wavefront
         if (needfill[k]) atomicAdd(&g.counters[6], 1u);
@@ -202,24 +202,10 @@ __global__ __launch_bounds__(256) void k_group_table_class(GroupState g, const u
 // ---- promotion of hot cache slots to wide combs (p256_group.h: hot keys; p256_widetab29.h: the builder of the registered path) ----------
 // select (one lane per group) -> bases (the 2 x 17 base points of each promotion, gathered from the key's 8-bit table) -> chains + fill
 // (the builder's lanes, for the promotions this batch really made) -> publish (kwide[slot] = index: later batches take the wide pass)
-// Life cycle of the hot keys (p256_group.h, round 6): the clock sweep, the hits of the batch's ACCEPTED tuples, the evictions.
+// Life cycle of the hot keys (p256_group.h, round 6): the clock sweep and the evictions.
 __global__ __launch_bounds__(256) void k_hot_decay(HotKeys hk) {
     const u32 slot = blockIdx.x * 256 + threadIdx.x;
     if (slot < hk.cache_cap) hot_decay_lane(slot, hk.khits);
-}
-// one lane per lane of the grouped list; the sorted list makes wavefronts of one slot the rule: one atomic per wavefront then
-__global__ __launch_bounds__(256) void k_group_hits(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ acc, HotKeys hk) {
-    const u32 L = blockIdx.x * 256 + threadIdx.x;
-    const u32 slot = L < g.counters[1] ? hot_hit_slot(g, L, group_count(g), tslot, acc, hk.cache_cap) : SBV_GROUP_NONE;
-    const unsigned long long hits = __ballot(slot != SBV_GROUP_NONE);
-    if (!hits) return;
-    const int leader = __ffsll((long long)hits) - 1;
-    const u32 first = (u32)__shfl((int)slot, leader, 64);
-    if (__all(slot == SBV_GROUP_NONE || slot == first)) {
-        if ((int)(threadIdx.x & 63) == leader) hot_hit(first, (u32)__popcll(hits), hk.khits);
-    } else if (slot != SBV_GROUP_NONE) {
-        hot_hit(slot, 1u, hk.khits);
-    }
 }
 __global__ __launch_bounds__(256) void k_promote_select(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ kvalid, HotKeys hk) {
     const u32 groups = group_count(g);
@@ -638,9 +624,8 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_promote, 0));
     hipLaunchKernelGGL(k_group_table_mark, dim3(64), dim3(256), 0, y.side_b, g, b.tslot, b.cold, b.full, b.needfill, table_slots, b.kfull);
     if (hot_on) {
-        // the life cycle (round 6): the clock sweep every SBV_HOT_DECAY_EVERY-th batch, then this batch's accepted tuples
+        // the life cycle (round 6): the clock sweep every SBV_HOT_DECAY_EVERY-th batch
         if (b.hot_tick % SBV_HOT_DECAY_EVERY == SBV_HOT_DECAY_EVERY - 1) hipLaunchKernelGGL(k_hot_decay, dim3((b.kc.cap + 255) / 256), dim3(256), 0, y.side_b, hk);
-        hipLaunchKernelGGL(k_group_hits, dim3(gn), dim3(256), 0, y.side_b, g, b.tslot, b.acc, hk);
         // promotions (p256_group.h: hot keys): which slots (the evictions when the pool is full), and their base points (tiny launches
         // that read tslot and the tables)
         hipLaunchKernelGGL(k_promote_select, dim3(64), dim3(256), 0, y.side_b, g, b.tslot, b.kvalid, hk);

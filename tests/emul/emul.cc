@@ -365,7 +365,7 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
         if (g_hot_kwide.size() < kc.cap) hot_reset();
         g_hot[1] = g_hot[2] = g_hot[3] = 0;
         ++g_hot_tick;
-        for (u32 k = 0; k < ngroups; ++k) group_hot_class_lane(k, g, tslot.data(), cold.data(), kc.cap, g_hot_kwide.data(), wide.data());
+        for (u32 k = 0; k < ngroups; ++k) group_hot_class_lane(k, g, tslot.data(), cold.data(), kc.cap, g_hot_kwide.data(), g_hot_khits.data(), wide.data());
     }
     const widekeys wk = hot_on ? widekeys_make(g_hot_wtab, g_hot_kwide.data(), SBV_HOT_BITS) : widekeys_none();
     // which lanes of the grouped list the chunk launches serve (wavefronts of 64 whose lanes ALL hold full tables) and which the narrow pass
@@ -507,16 +507,8 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
     memcpy(g_kc_full.data(), kfull.data(), kc.cap);
     if (hot_on) {
         // promotions: k_promote_select -> _bases -> _chains -> _fill -> _publish, lane by lane (groups visited backwards: the order is free)
-        // the life cycle first (k_hot_decay, k_group_hits): the clock sweep, then the ACCEPTED tuples of the grouped list
+        // the life cycle first (k_hot_decay): the clock sweep
         if (g_hot_tick % SBV_HOT_DECAY_EVERY == SBV_HOT_DECAY_EVERY - 1) for (u32 sl = 0; sl < kc.cap; ++sl) hot_decay_lane(sl, g_hot_khits.data());
-        {
-            std::vector<uint8_t> accb(n);
-            for (size_t i = 0; i < n; ++i) accb[i] = (bitmap[i >> 3] >> (i & 7)) & 1u;
-            for (u32 L = 0; L < counters[1]; ++L) {
-                const u32 sl = hot_hit_slot(g, L, ngroups, tslot.data(), accb.data(), kc.cap);
-                if (sl != SBV_GROUP_NONE) hot_hit(sl, 1u, g_hot_khits.data());
-            }
-        }
         std::vector<u32> plist(2 * SBV_PROMOTE_MAX, 0xDEADBEEFu), elist(SBV_PROMOTE_MAX, 0xDEADBEEFu);
         for (u32 k = ngroups; k-- > 0;)
             group_promote_select_lane(k, tslot.data(), g_kc_valid.data(), kc.cap, g_hot_kwide.data(), g_hot_khits.data(), g_hot_min, g_hot_cap, g_hot, plist.data(), elist.data());

@@ -871,10 +871,10 @@ def test_hot_keys_promotion_wide_pass_and_budget(emul, oracle, golden_vectors):
         emul.sbve_set_full_table_min(64)
         emul.sbve_set_group_chunks(2)
         emul.sbve_key_cache(1, 64)
-        emul.sbve_hot_keys(2, 250)              # a pool of two combs, promotion from 250 ACCEPTED tuples on (5 of 6 are valid: ~167 per key and batch)
-        h = run(hot + luke, whot + wluke)       # cold: ~167 hits per hot key
+        emul.sbve_hot_keys(2, 250)              # a pool of two combs, promotion from 250 grouped tuples on
+        h = run(hot + luke, whot + wluke)       # cold: 200 hits per hot key
         assert h[:3] == [0, 2, 0], h
-        h = run(hot, whot)                      # warm: ~333 hits -> three keys ask, two combs exist
+        h = run(hot, whot)                      # warm: 400 hits -> three keys ask, two combs exist
         assert h[:3] == [2, 2, 0], h
         assert emul.sbve_hot_comb_mismatches(0) == 0 and emul.sbve_hot_comb_mismatches(1) == 0
         assert emul.sbve_hot_comb_mismatches(2) == ctypes.c_size_t(-1).value
@@ -896,7 +896,7 @@ def test_hot_keys_promotion_wide_pass_and_budget(emul, oracle, golden_vectors):
         emul.sbve_key_cache(1, 64)
         emul.sbve_set_full_table_min(10**6)     # nobody earns a full table ...
         emul.sbve_hot_keys(3, 250)
-        for _ in range(3):                      # (the third key's accepted tuples are 100 per batch: the generator's invalid tuples sit on it)
+        for _ in range(2):
             run(hot, whot)                      # ... and the three hot keys are promoted with rows only
         assert list(hs)[0] == 3
         solo, wsolo = batch(0xB3, 100, 1)       # one more key, 100 tuples: a full table from now on, no wide comb (the pool is spent)
@@ -921,12 +921,11 @@ def test_hot_keys_promotion_wide_pass_and_budget(emul, oracle, golden_vectors):
         emul.sbve_set_group_chunks(3)
 
 
-def test_hot_keys_life_cycle_accepted_hits_decay_eviction(emul, oracle):
-    """Round 6, p256_group.h "life cycle of the hot keys" (ADVICE r5): a slot's count grows by ACCEPTED tuples only (garbage
-    under a valid key earns no comb), every SBV_HOT_DECAY_EVERY-th batch halves every count, and with the pool full a slot that has earned
-    a comb takes the coldest owner's — only when that owner's count is at most half its own.  The lane functions are the kernels' own
-    (k_group_hits, k_hot_decay, k_promote_select / _evict / _publish call them); verdicts are checked on every batch, the re-assigned comb
-    against the host builder."""
+def test_hot_keys_life_cycle_decay_and_eviction(emul, oracle):
+    """Round 6, p256_group.h "life cycle of the hot keys" (ADVICE r5): every SBV_HOT_DECAY_EVERY-th batch halves every
+    count, and with the pool full a slot that has earned a comb takes the coldest owner's — only when that owner's count is at most half
+    its own.  The lane functions are the kernels' own (k_group_table_class, k_hot_decay, k_promote_select / _evict / _publish call them);
+    verdicts are checked on every batch, the re-assigned comb against the host builder."""
     emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32,
                                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
     emul.sbve_key_cache.argtypes = [ctypes.c_int, ctypes.c_uint32]
@@ -962,55 +961,46 @@ def test_hot_keys_life_cycle_accepted_hits_decay_eviction(emul, oracle):
         return list(hs)
 
     def keys_of(blob):
-        seen = []
+        count = {}
         for i in range(len(blob) // 160):
             k = blob[160 * i + 96:160 * i + 160]
-            if k not in seen:
-                seen.append(k)
-        return seen
+            count[k] = count.get(k, 0) + 1
+        return sorted(count, key=lambda k: -count[k]), count
 
-    ab, wab = batch(0xC1, 400, 2)               # keys A, B: 200 uses each
-    cc, wcc = batch(0xC2, 200, 1)               # key C
-    # the same 200 tuples of a fourth key D with s corrupted in every one: all rejected
-    dd, _ = batch(0xC3, 200, 1, 0)
-    dd = b"".join(dd[160 * i:160 * i + 63] + bytes([dd[160 * i + 63] ^ 1]) + dd[160 * i + 64:160 * (i + 1)] for i in range(200))
-    wdd = [False] * 200
-    ka, kb = keys_of(ab)[:2]
-    kc_, kd = keys_of(cc)[0], keys_of(dd)[0]
+    ab, wab = batch(0xC1, 400, 2, 0)            # keys A, B: 200 uses each, every signature valid
+    cc, wcc = batch(0xC2, 200, 1, 0)            # key C
+    (ka, kb), nab = keys_of(ab)
+    (kc_,), ncc = keys_of(cc)
+    assert nab[ka] == nab[kb] == 200 and ncc[kc_] == 200
     try:
         emul.sbve_set_full_table_min(64)
         emul.sbve_set_group_chunks(2)
         emul.sbve_key_cache(1, 64)
         emul.sbve_hot_keys(2, 250)
-        # accepted tuples only: D is grouped, cached, verified (and rejected) 200 times per batch and stays at 0 hits
         for _ in range(3):
-            h = run(ab + dd, wab + wdd)
-        assert emul.sbve_hot_hits_of_key(kd) == 0 and emul.sbve_hot_wide_of_key(kd) == NONE
+            h = run(ab, wab)
         assert h[0] == 2 and emul.sbve_hot_wide_of_key(ka) != NONE and emul.sbve_hot_wide_of_key(kb) != NONE      # A and B own the pool
-        ha = emul.sbve_hot_hits_of_key(ka)
-        assert ha == sum(w for t, w in zip(range(400), wab) if ab[160 * t + 96:160 * t + 160] == ka) * 3
+        assert emul.sbve_hot_hits_of_key(ka) == emul.sbve_hot_hits_of_key(kb) == 600
         # C arrives: the pool is full; it earns a comb only once its count is twice the coldest owner's — A and B no longer sign
         evicted_at = None
-        for i in range(12):
-            h = run(cc + dd, wcc + wdd)
+        for i in range(10):
+            h = run(cc, wcc)
             if life[0] and evicted_at is None:
                 evicted_at = i
-        hc, hmin = emul.sbve_hot_hits_of_key(kc_), min(emul.sbve_hot_hits_of_key(ka), emul.sbve_hot_hits_of_key(kb))
-        assert life[0] == 1, (life[0], hc, hmin)                         # exactly one comb changed owner ...
-        assert evicted_at is not None and evicted_at >= 2                # ... not before C had twice the victim's count (hysteresis)
+        assert life[0] == 1                                              # exactly one comb changed owner ...
+        assert evicted_at == 5                                           # ... in the batch that took C to 1200 = twice an owner's 600 (hysteresis)
         wc = emul.sbve_hot_wide_of_key(kc_)
         assert wc != NONE and emul.sbve_hot_comb_mismatches(wc) == 0     # the re-used comb is byte for byte C's
         assert sorted([emul.sbve_hot_wide_of_key(ka) == NONE, emul.sbve_hot_wide_of_key(kb) == NONE]) == [False, True]
         h = run(ab + cc, wab + wcc)                                      # the victim is served from its 8-bit table again, same verdicts
         assert h[2] > 0                                                  # and C's lanes take the wide pass
-        # the clock sweep: 16 batches in all so far -> one halving happened exactly once (tick 15)
-        assert life[1] == 16
-        before = emul.sbve_hot_hits_of_key(kd), emul.sbve_hot_hits_of_key(kc_)
-        for _ in range(15):
-            run(dd, wdd)
-        assert life[1] == 31
-        after = emul.sbve_hot_hits_of_key(kc_)
-        assert before[0] == 0 and after == before[1] // 2                # tick 31: halved once more, nothing added (C did not sign)
+        assert life[1] == 14 and emul.sbve_hot_hits_of_key(kc_) == 2200
+        run(cc, wcc)                                                     # tick 15: the clock sweep, then this batch's 200
+        assert life[1] == 15 and emul.sbve_hot_hits_of_key(kc_) == 2400 // 2
+        assert emul.sbve_hot_hits_of_key(ka) == 800 // 2
+        for _ in range(16):
+            run(ab[:160 * 8], wab[:8])                                   # 16 small batches without C: tick 31 halves again, nothing is added to C
+        assert life[1] == 31 and emul.sbve_hot_hits_of_key(kc_) == 600
     finally:
         emul.sbve_hot_keys(0, 4096)
         emul.sbve_key_cache(0, 0)
