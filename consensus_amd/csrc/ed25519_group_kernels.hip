@@ -26,7 +26,8 @@ namespace sbv {
 
 __global__ __launch_bounds__(256) void k_ed_group_insert(const uint8_t* __restrict__ tuples, size_t n, GroupState g) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) ed_group_insert_lane(tuples, i, g);
+    (void)i;
+    group_insert_block<128, 64, 8>(tuples, n, g);
 }
 
 // Same result as ed_group_split_lane (compaction: group_split_emit)

@@ -12,6 +12,48 @@ __device__ __forceinline__ u32 group_count(const GroupState& g) {
     return c < g.max_groups ? c : g.max_groups;
 }
 
+// The insert kernel of every scheme: one lane per tuple finds its key's representative; the counts go to g.cnt AGGREGATED per
+// workgroup (round 6).  One atomic per tuple was fine for the headline's 1 024 signers (1 000 increments per counter), but a
+// consenter batch — configs[3]: 550 000 signatures by 16 keys whose representatives are tuples 0..15, i.e. 16 counters in ONE cache
+// line — serialised 34 000 device-scope atomics per counter in one memory channel: k_group_insert 1.40 ms and, stalled behind it,
+// stage A 1.43 ms of a 3.2 ms call (profiles/r06/kernel_stats_replay_r06l.csv).  Now: the lanes of a wavefront that share a
+// representative elect a leader (ballot / readlane loop, one round per distinct representative), the leaders meet in a 512-entry
+// LDS table keyed by the representative, and the workgroup flushes one atomic per distinct representative.
+template <int STRIDE, int OFF, int WORDS>
+static __device__ __forceinline__ void group_insert_block(const uint8_t* __restrict__ tuples, size_t n, const GroupState& g) {
+    __shared__ u32 skey[512], scnt[512];
+    const unsigned tid = threadIdx.x;
+    for (unsigned t = tid; t < 512; t += blockDim.x) { skey[t] = 0xFFFFFFFFu; scnt[t] = 0; }
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + tid;
+    u32 mine = 0xFFFFFFFFu;
+    bool want = false;
+    if (i < n) {
+        mine = group_find_rep_t<STRIDE, OFF, WORDS>(tuples, i, g);
+        want = group_sampled((u32)i, g.sample_mask);
+    }
+    unsigned long long todo = __ballot(want);
+    const int lane = (int)(tid & 63u);
+    while (todo) {                                          // wave-uniform loop: one round per distinct representative
+        const int leader = __ffsll((long long)todo) - 1;
+        const u32 r = (u32)__shfl((int)mine, leader, 64);
+        const unsigned long long same = __ballot(want && mine == r);
+        if (lane == leader) {
+            const u32 c = (u32)__popcll(same);
+            u32 h = (r * 0x9E3779B1u) >> 23;                // 9 bits
+            for (int probes = 0; probes < 512; ++probes) {
+                const u32 prev = atomicCAS(&skey[h], 0xFFFFFFFFu, r);
+                if (prev == 0xFFFFFFFFu || prev == r) { atomicAdd(&scnt[h], c); break; }
+                h = (h + 1u) & 511u;
+            }
+        }
+        todo &= ~same;
+    }
+    __syncthreads();
+    for (unsigned t = tid; t < 512; t += blockDim.x)
+        if (skey[t] != 0xFFFFFFFFu) atomicAdd(&g.cnt[skey[t]], scnt[t]);
+}
+
 // kc: the scheme's persistent key-table cache (kc.enabled = 0 when it is off): cached keys are grouped whatever their count
 // in this batch.  STRIDE / OFF / WORDS = the tuple format's key location (p256_group.h: group_insert_lane_t)
 template <int STRIDE, int OFF, int WORDS>

@@ -5,8 +5,9 @@
 //
 //   stage A  k256_prep_lane     range checks (1 <= r, s < n; Qx, Qy < p), e = hash mod n, w = s^-1 mod n (division steps),
 //                               u1 = e w, u2 = r w  -> the limb-major scratch planes of p256_core.h
-//   stage B  k256_verify_lane   Q on the curve; the 8 affine multiples of Q (Jacobian chain, one inversion); u2 * Q with 64 signed
-//                               4-bit windows (4 doublings of 3M + 4S and one mixed addition of 8M + 3S each); + u1 * G from a signed 16-bit
+//   stage B  k256_verify_lane   Q on the curve; the 8 affine multiples of Q (Jacobian chain, one inversion); u2 * Q = k1 Q + k2 phi(Q)
+//                               (GLV, round 6) with 32 signed 4-bit windows (4 doublings of 3M + 4S and two mixed additions of 8M + 3S
+//                               each: 128 doublings instead of 256); + u1 * G from a signed 16-bit
 //                               comb of G (17 mixed additions, 17 x 32768 affine entries = 35.7 MB, built once per process);
 //                               accept iff R != infinity and R.x = r (mod n), tested without an inversion: X = r Z^2 or
 //                               X = (r + n) Z^2 when r + n < p
@@ -248,9 +249,7 @@ SBV_HD void kfe_load_raw(kfe& a, const u32* src) {
 }
 
 SBV_HD bool k256_verify_lane(const Scratch& s, size_t i, u32* qtab, const kapt* gtab) {
-    u256 r, u1, u2, qxw, qyw;
-    soa_load(r, s.r, s.cap, i);
-    soa_load(u1, s.u1, s.cap, i);
+    u256 u2, qxw, qyw;          // r and u1 are fetched where they are used, behind the doubling loop: 16 registers less across it
     soa_load(u2, s.u2, s.cap, i);
     soa_load(qxw, s.qx, s.cap, i);
     soa_load(qyw, s.qy, s.cap, i);
@@ -290,24 +289,52 @@ SBV_HD bool k256_verify_lane(const Scratch& s, size_t i, u32* qtab, const kapt* 
             kapt_store(tab + (k - 1), X, Y);
         }
     }
-    // u2 * Q: k = u2 + sum_j 8 * 16^j; nibble j of k, minus 8, is the signed digit of window j; the carry is window 64
-    u256 k2;
-    const u32 top2 = add_const_limbs(k2, u2, 0x88888888u);
+    // u2 * Q = k1 * (+-Q) + k2 * (+-phi(Q)), phi(x, y) = (beta x, y): the GLV decomposition (k256_sc.h: ksc_split_lambda) halves the
+    // doublings — 128 instead of 256, with two table additions per 4-bit window instead of one (round 6).  Both halves are below 2^128:
+    // k_i + sum_j 8 * 16^j over 32 nibbles; nibble j, minus 8, is the signed digit of window j and the carry into bit 128 is window 32.
+    // phi of a table entry is one multiplication by beta, done at use (33 per signature: three additions' worth).
+    u256 k1, k2;
+    bool n1, n2;
+    ksc_split_lambda(k1, n1, k2, n2, u2);
+    const u256 eights = {{0x88888888u, 0x88888888u, 0x88888888u, 0x88888888u, 0u, 0u, 0u, 0u}};
+    u256 kk1, kk2;
+    (void)add256(kk1, k1, eights);
+    (void)add256(kk2, k2, eights);
+    // beta as nine 29-bit limbs (k256_sc.h: k256_beta_words): compile-time constants live in scalar registers, not in nine VGPRs across the loop
+    const kfe beta = {{0x119501EE, 0x09CB6143, 0x1D626570, 0x0092EA25, 0x034E99CF, 0x03CF561A, 0x1C41B991, 0x056CAF80, 0x007AE96A}};
     kjpt R;
     kpt_set_inf(R);
-    kpt_madd(R, R, qx, qy, false, top2 == 0);
+    {
+        kfe bx;
+        kfe_mul(bx, qx, beta);
+        kpt_madd(R, R, qx, qy, n1, kk1.v[4] == 0);
+        kpt_madd(R, R, bx, qy, n2, kk2.v[4] == 0);
+    }
     SBV_NOUNROLL
-    for (int j = 63; j >= 0; --j) {
+    for (int j = 31; j >= 0; --j) {
         SBV_NOUNROLL
         for (int d = 0; d < 4; ++d) kpt_dbl(R, R);
-        const int dg = (int)((k2.v[j >> 3] >> ((j & 7) * 4)) & 15u) - 8;
-        const int ad = dg < 0 ? -dg : dg;
+        u32 w1 = 0, w2 = 0;
+        SBV_UNROLL
+        for (int w = 0; w < 4; ++w) { w1 = (j >> 3) == w ? kk1.v[w] : w1; w2 = (j >> 3) == w ? kk2.v[w] : w2; }
+        const int d1 = (int)((w1 >> ((j & 7) * 4)) & 15u) - 8;
+        const int d2 = (int)((w2 >> ((j & 7) * 4)) & 15u) - 8;
+        const int a1 = d1 < 0 ? -d1 : d1, a2 = d2 < 0 ? -d2 : d2;
         kfe x, y;
-        kapt_load(x, y, tab + (ad == 0 ? 0 : ad - 1));
-        kpt_madd(R, R, x, y, dg < 0, dg == 0);
+        kapt_load(x, y, tab + (a1 == 0 ? 0 : a1 - 1));
+        kpt_madd(R, R, x, y, (d1 < 0) != n1, d1 == 0);
+        kapt_load(x, y, tab + (a2 == 0 ? 0 : a2 - 1));
+        kfe_mul(x, x, beta);
+        kpt_madd(R, R, x, y, (d2 < 0) != n2, d2 == 0);
     }
-    k256_add_u1G(R, u1, gtab);
+    {
+        u256 u1;
+        soa_load(u1, s.u1, s.cap, i);
+        k256_add_u1G(R, u1, gtab);
+    }
     if (R.inf) return false;
+    u256 r;
+    soa_load(r, s.r, s.cap, i);
     // R.x mod n == r  <=>  X == r Z^2, or X == (r + n) Z^2 when r + n < p  (R.x in [n, p) wraps once: p < 2 n)
     kfe zz, c1, t;
     kfe_sqr(zz, R.Z);

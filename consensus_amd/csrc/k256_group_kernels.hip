@@ -33,8 +33,7 @@ __global__ __launch_bounds__(64) void k_k256_prep_chunk(const uint8_t* __restric
     k256_prep_chunk(words, n, s, first, (size_t)64, T);
 }
 __global__ __launch_bounds__(256) void k_k256_group_insert(const uint8_t* __restrict__ tuples, size_t n, GroupState g) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) group_insert_lane(tuples, i, g);
+    group_insert_block<160, 96, 16>(tuples, n, g);
 }
 __global__ __launch_bounds__(256) void k_k256_keycheck(const uint8_t* __restrict__ tuples, GroupState g, uint8_t* __restrict__ acc) {
     const u32 L = blockIdx.x * 256 + threadIdx.x;

@@ -338,8 +338,9 @@ SBV_HD bool verify29_lane_keyed(const Scratch& s, size_t i, u32 slot, u32 nkeys,
 // traffic per signature instead of 10 KB), a Jacobian accumulator (4 doublings of 3M + 5S and one mixed addition per
 // window, fused reductions), then + u1 * G from the comb of G.  qtab: this lane's 8 x 16 words.
 #define SBV_QTAB29_WORDS (8 * 16 + 7 * 45 + 5)        // table + raw chain records, rounded to 448 words = 1792 bytes
-SBV_HD bool verify29_generic_core(const u256& r, const u256& u1, const u256& u2, const u256& qx, const u256& qy, bool ok,
-                                  u32* qtab, const gcomb& gc) {
+// Two halves, so that the lane fetches r and u1 BEHIND the doubling loop instead of holding their 16 words across it (round 6: the
+// one-lane kernel's spills): verify29_generic_q leaves u2 * Q in S, verify29_generic_finish adds u1 * G and compares.
+SBV_HD void verify29_generic_q(xyzz& S, bool& ok, const u256& u2, const u256& qx, const u256& qy, u32* qtab) {
     apt29 Q;
     f29_from_plain(Q.x, qx);
     f29_from_plain(Q.y, qy);
@@ -419,34 +420,49 @@ SBV_HD bool verify29_generic_core(const u256& r, const u256& u1, const u256& u2,
             pt29_madd_jacx(R, e, d < 0);
         }
     }
-    xyzz S;
     S.inf = R.inf;
     S.X = R.X; S.Y = R.Y;
     f29_sqrx(S.ZZ, R.Z);
     f29_mulx(S.ZZZ, R.Z, S.ZZ);
+}
+SBV_HD bool verify29_generic_finish(xyzz& S, const u256& r, const u256& u1, bool ok, const gcomb& gc) {
     gphase29_point(S, u1, gc, true);
     return ok && pt29_rx_matches(S, r);
 }
+SBV_HD bool verify29_generic_core(const u256& r, const u256& u1, const u256& u2, const u256& qx, const u256& qy, bool ok,
+                                  u32* qtab, const gcomb& gc) {
+    xyzz S;
+    verify29_generic_q(S, ok, u2, qx, qy, qtab);
+    return verify29_generic_finish(S, r, u1, ok, gc);
+}
 SBV_HD bool verify29_lane_generic(const Scratch& s, size_t i, u32* qtab, const gcomb& gc) {
-    u256 r, u1, u2, qx, qy;
-    soa_load(r, s.r, s.cap, i);
-    soa_load(u1, s.u1, s.cap, i);
+    u256 u2, qx, qy;
     soa_load(u2, s.u2, s.cap, i);
     soa_load(qx, s.qx, s.cap, i);
     soa_load(qy, s.qy, s.cap, i);
-    return verify29_generic_core(r, u1, u2, qx, qy, s.ok[i] != 0, qtab, gc);
+    bool ok = s.ok[i] != 0;
+    xyzz S;
+    verify29_generic_q(S, ok, u2, qx, qy, qtab);
+    u256 r, u1;
+    soa_load(u1, s.u1, s.cap, i);
+    soa_load(r, s.r, s.cap, i);
+    return verify29_generic_finish(S, r, u1, ok, gc);
 }
 // The same lane inside the key-sorted grouped step: stage A left no limb-major planes (prep_chunk29), so u1 | u2 | r | ok come
 // from the tuple's record and the public key from the tuple itself (stage A's range checks on it are part of `ok`).
 SBV_HD bool verify29_lane_generic_rec(const Scratch& s, const uint8_t* tuples, size_t i, u32* qtab, const gcomb& gc) {
-    u256 r, u1, u2, qx, qy;
-    rec_load256(u1, s.rec, i, SBV_REC_U1);
+    u256 u2, qx, qy;
     rec_load256(u2, s.rec, i, SBV_REC_U2);
-    rec_load256(r, s.rec, i, SBV_REC_R);
     const u32* k = reinterpret_cast<const u32*>(tuples + i * 160 + 96);
     SBV_UNROLL
     for (int l = 0; l < 8; ++l) { qx.v[l] = bswap32(k[7 - l]); qy.v[l] = bswap32(k[8 + 7 - l]); }
-    return verify29_generic_core(r, u1, u2, qx, qy, s.rec[i * SBV_REC_WORDS + SBV_REC_OK] != 0, qtab, gc);
+    bool ok = s.rec[i * SBV_REC_WORDS + SBV_REC_OK] != 0;
+    xyzz S;
+    verify29_generic_q(S, ok, u2, qx, qy, qtab);
+    u256 r, u1;
+    rec_load256(u1, s.rec, i, SBV_REC_U1);
+    rec_load256(r, s.rec, i, SBV_REC_R);
+    return verify29_generic_finish(S, r, u1, ok, gc);
 }
 
 // ---- registered-key form, several lanes per signature (the latency form, BASELINE.json's second metric) -------------------

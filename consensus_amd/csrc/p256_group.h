@@ -145,8 +145,11 @@ SBV_HD bool tuple_key_ok(const uint8_t* tuples, size_t idx) {
 
 // Key location of a tuple format: STRIDE bytes per tuple, key = WORDS dwords at byte OFF (16-byte aligned).
 // P-256: 160 / 96 / 16 (Qx|Qy); Ed25519: 128 / 64 / 8 (A_enc).
+// group_find_rep_t: the representative of tuple i's key (claims the hash-table entry when the key is new) -> g.rep[i]; the caller
+// counts the tuple: group_insert_lane_t one atomic per tuple (the emulator; any caller without a workgroup), the kernels through
+// group_count_block (group_kernels_common.h: aggregated per workgroup — a consenter batch puts 34 000 tuples on each of 16 counters).
 template <int STRIDE, int OFF, int WORDS>
-SBV_HD void group_insert_lane_t(const uint8_t* tuples, size_t i, const GroupState& g) {
+SBV_HD u32 group_find_rep_t(const uint8_t* tuples, size_t i, const GroupState& g) {
     const u32* k = reinterpret_cast<const u32*>(tuples + i * STRIDE + OFF);
     u32 w[WORDS];
     SBV_UNROLL
@@ -176,6 +179,11 @@ SBV_HD void group_insert_lane_t(const uint8_t* tuples, size_t i, const GroupStat
         slot = (slot + 1) & g.ht_mask;
     }
     g.rep[i] = mine;
+    return mine;
+}
+template <int STRIDE, int OFF, int WORDS>
+SBV_HD void group_insert_lane_t(const uint8_t* tuples, size_t i, const GroupState& g) {
+    const u32 mine = group_find_rep_t<STRIDE, OFF, WORDS>(tuples, i, g);
     if (group_sampled((u32)i, g.sample_mask)) SBV_ATOMIC_ADD(&g.cnt[mine], 1u);
 }
 SBV_HD void group_insert_lane(const uint8_t* tuples, size_t i, const GroupState& g) { group_insert_lane_t<160, 96, 16>(tuples, i, g); }

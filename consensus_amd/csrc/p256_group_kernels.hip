@@ -39,8 +39,7 @@
 namespace sbv {
 
 __global__ __launch_bounds__(256) void k_group_insert(const uint8_t* __restrict__ tuples, size_t n, GroupState g) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) group_insert_lane(tuples, i, g);
+    group_insert_block<160, 96, 16>(tuples, n, g);
 }
 // Same result as group_split_lane (compaction: group_split_emit)
 __global__ __launch_bounds__(256) void k_group_split(const uint8_t* __restrict__ tuples, size_t n, GroupState g, uint8_t* __restrict__ acc) {

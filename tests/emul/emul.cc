@@ -1064,6 +1064,16 @@ int sbve_k256_mul2(const u32* k8, const u32* x8, const u32* y8, const u32* l8, u
     return 1;
 }
 // the whole path: stage A (k256_prep_lane) + stage B (k256_verify_lane), lane by lane
+// GLV decomposition of a scalar (k256_sc.h: ksc_split_lambda): out = k1[8] | k2[8] | neg1 | neg2
+void sbve_k256_split_lambda(const u32* k8, u32* out18) {
+    u256 k, k1, k2;
+    for (int i = 0; i < 8; ++i) k.v[i] = k8[i];
+    bool n1, n2;
+    ksc_split_lambda(k1, n1, k2, n2, k);
+    for (int i = 0; i < 8; ++i) { out18[i] = k1.v[i]; out18[8 + i] = k2.v[i]; }
+    out18[16] = n1 ? 1u : 0u;
+    out18[17] = n2 ? 1u : 0u;
+}
 void sbve_k256_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap) {
     size_t cap = (n + 63) & ~(size_t)63;
     if (cap == 0) cap = 64;

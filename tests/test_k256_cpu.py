@@ -188,6 +188,52 @@ def test_scalar_operations_match_bigint(emul):
         assert val(out) == x % N, hex(x)
 
 
+def test_glv_decomposition_of_scalars(emul):
+    """Round 6, k256_sc.h: ksc_split_lambda — k = (+-k1) + (+-k2) lambda (mod n) with k1, k2 < 2^128, for 200 000 random scalars and the
+    edge scalars (0, 1, n - 1, n (reduced first), 2^256 - 1, lambda, n - lambda, the lattice vectors' neighbourhoods); the constants
+    lambda, beta, g1, g2, -b1, -b2 are re-derived here from (n, lambda) by the extended Euclidean algorithm rather than trusted."""
+    import math
+    import random
+    n, p = ec.N, ec.P
+    lam = 0x5363AD4CC05C30E0A5261C028812645A122E22EA20816678DF02967C1B23BD72
+    beta = 0x7AE96A2B657C07106E64479EAC3434E99CF0497512F58995C1396C28719501EE
+    assert pow(lam, 3, n) == 1 and lam != 1 and pow(beta, 3, p) == 1 and beta != 1
+    lg = ec.pt_mul(lam, ec.G)
+    assert lg == (beta * ec.G[0] % p, ec.G[1])                     # phi(G) = lambda G
+    # the lattice basis from the extended Euclidean algorithm on (n, lambda)
+    r0, r1, t0, t1, rows = n, lam, 0, 1, []
+    while r1:
+        q = r0 // r1
+        r0, r1, t0, t1 = r1, r0 - q * r1, t1, t0 - q * t1
+        rows.append((r0, t0))
+    i = next(i for i, (r, _) in enumerate(rows) if r < math.isqrt(n))
+    a1, b1 = rows[i][0], -rows[i][1]
+    cands = [(rows[i - 1][0], -rows[i - 1][1]), (rows[i + 1][0], -rows[i + 1][1])]
+    a2, b2 = min(cands, key=lambda v: v[0] ** 2 + v[1] ** 2)
+    assert (a1 + b1 * lam) % n == 0 and (a2 + b2 * lam) % n == 0
+    assert -b1 == 0xE4437ED6010E88286F547FA90ABFE4C3 and (-b2) % n == 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFE8A280AC50774346DD765CDA83DB1562C
+    assert (2 ** 384 * b2 + n // 2) // n == 0x3086D221A7D46BCDE86C90E49284EB153DAA8A1471E8CA7FE893209A45DBB031
+    assert (2 ** 384 * (-b1) + n // 2) // n == 0xE4437ED6010E88286F547FA90ABFE4C4221208AC9DF506C61571B4AE8AC47F71
+    emul.sbve_k256_split_lambda.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    rng = random.Random(0x6157)
+    ks = [0, 1, 2, n - 1, n, n + 1, 2 ** 256 - 1, lam, n - lam, lam + 1, (n + 1) // 2, n // 2, a1, a2, abs(b1), abs(b2), 2 ** 128, 2 ** 128 - 1, 2 ** 255]
+    ks += [rng.randrange(n) for _ in range(200000)]
+    kin = (ctypes.c_uint32 * 8)()
+    out = (ctypes.c_uint32 * 18)()
+    worst = 0
+    for k in ks:
+        for j in range(8):
+            kin[j] = (k >> (32 * j)) & 0xFFFFFFFF
+        emul.sbve_k256_split_lambda(kin, out)
+        k1 = sum(out[j] << (32 * j) for j in range(8))
+        k2 = sum(out[8 + j] << (32 * j) for j in range(8))
+        s1, s2 = (-k1 if out[16] else k1), (-k2 if out[17] else k2)
+        assert (s1 + s2 * lam - k) % n == 0, hex(k)
+        assert k1 < 2 ** 128 and k2 < 2 ** 128, (hex(k), hex(k1), hex(k2))
+        worst = max(worst, k1.bit_length(), k2.bit_length())
+    assert worst == 128
+
+
 def test_point_layer_and_comb_of_G_match_the_python_twin(emul):
     rng = random.Random(13)
     out = (ctypes.c_uint32 * 16)()
