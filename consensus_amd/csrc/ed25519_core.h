@@ -278,10 +278,16 @@ SBV_HD bool ed25519_verify_lane(Words w, u32* qtab, const aniels* btab) {
 }
 
 // the grouped step's comb of B (ed25519_group.h: ed_add_sB_comb)
-struct edcomb { const aniels* tab; int bits; int windows; };
+// pitch: bytes from one entry to the next — 96 (the entries packed, as the host builder writes them) or 128 (round 6: every entry in a
+// 128-byte line of its own: a 96-byte entry at a 96-byte pitch straddles two lines of the 654 MB table in 3 positions of 4, and the G
+// phase's gathers out of a table far beyond the 256 MB Infinity Cache moved 2.8 GB per launch for 1.3 GB of entries, profiles/traffic.json)
+struct edcomb { const aniels* tab; int bits; int windows; u32 pitch; };
 SBV_HD int edcomb_windows(int bits) { return (254 + bits - 1) / bits; }
 SBV_HD size_t edcomb_entries(int bits) { return (size_t)edcomb_windows(bits) << (bits - 1); }
-SBV_HD edcomb edcomb_make(const aniels* tab, int bits) { edcomb c = {tab, bits, edcomb_windows(bits)}; return c; }
+SBV_HD edcomb edcomb_make(const aniels* tab, int bits, u32 pitch = (u32)sizeof(aniels)) { edcomb c = {tab, bits, edcomb_windows(bits), pitch}; return c; }
+SBV_HD const aniels* edcomb_entry(const edcomb& c, size_t index) {
+    return reinterpret_cast<const aniels*>(reinterpret_cast<const uint8_t*>(c.tab) + index * c.pitch);
+}
 
 // ---- base-point comb (host, once per init; also tests/emul) --------------------------------------------
 // window j of a `bits`-wide comb of B: out_row[k - 1] = k * 2^(bits j) * B for k = 1 .. 2^(bits-1), canonical affine-Niels entries.

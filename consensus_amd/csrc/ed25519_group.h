@@ -294,14 +294,14 @@ SBV_HD void ed_add_sB_comb(ept& R, const u256& S, const edcomb& bc) {
     u32 idx; bool neg, skip;
     gcomb_digit(ss, bc.bits, 0, idx, neg, skip);
     raw_aniels cur;
-    raw_aniels_load(cur, bc.tab + idx);
+    raw_aniels_load(cur, edcomb_entry(bc, idx));
     SBV_NOUNROLL
     for (int j = 0; j < bc.windows; ++j) {
         const int jn = j + 1 < bc.windows ? j + 1 : bc.windows - 1;
         u32 idxn; bool negn, skipn;
         gcomb_digit(ss, bc.bits, jn, idxn, negn, skipn);
         raw_aniels nxt;
-        raw_aniels_load(nxt, bc.tab + ((size_t)jn << (bc.bits - 1)) + idxn);
+        raw_aniels_load(nxt, edcomb_entry(bc, ((size_t)jn << (bc.bits - 1)) + idxn));
         aniels_r e;
         raw_aniels_unpack(e, cur);
         ed_add_aniels(R, e, neg, skip);

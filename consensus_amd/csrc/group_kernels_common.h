@@ -34,6 +34,17 @@ static __device__ __forceinline__ void group_insert_block(const uint8_t* __restr
     }
     unsigned long long todo = __ballot(want);
     const int lane = (int)(tid & 63u);
+    if (todo) {
+        // A wavefront whose first representative is nobody else's (the headline batch: 64 consecutive tuples of 64 signers) gains nothing
+        // from the rounds below — 64 of them, one lane at work in each, on the path to the G phase (+0.25 ms per 2^20 step when every
+        // wavefront took them, profiles/r06/bench_driver_flags_r06m.json): its lanes count for themselves, as rounds 1-5 did.
+        const int first = __ffsll((long long)todo) - 1;
+        const u32 r0 = (u32)__shfl((int)mine, first, 64);
+        if (__popcll(__ballot(want && mine == r0)) < 2) {
+            if (want) atomicAdd(&g.cnt[mine], 1u);
+            todo = 0;
+        }
+    }
     while (todo) {                                          // wave-uniform loop: one round per distinct representative
         const int leader = __ffsll((long long)todo) - 1;
         const u32 r = (u32)__shfl((int)mine, leader, 64);

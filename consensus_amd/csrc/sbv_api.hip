@@ -108,6 +108,7 @@ struct Context {
     sbv::aniels* d_btab = nullptr;      // Ed25519 base-point comb (16 bits: the one-lane kernel's), built on first use
     sbv::aniels* d_ed_bcomb = nullptr;  // the grouped step's wider comb of B (SBV_ED_B_BITS, default 20: 13 x 2^19 entries = 654 MB); == d_btab at 16 bits
     int ed_bbits = 16;
+    u32 ed_bpitch = 96;                 // bytes from one entry of d_ed_bcomb to the next (ed25519_core.h: edcomb)
     sbv::kapt* d_k256_gtab = nullptr;   // secp256k1 comb of G (17 x 32768 entries), built on first use
     sbv::kapt* d_k256_gcomb = nullptr;  // the grouped step's wider comb of G (SBV_K256_G_BITS, default 20: 13 x 2^19 entries), built on first use
     int k256_gbits = 16;
@@ -602,7 +603,7 @@ int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bi
     if (grouped && !group_buffers_or_fallback(c, n, [&] { const int r = ensure_ed_group_buffers(c, n); return r != SBV_OK ? r : ensure_ed_bcomb(c); }, grouped)) return g_last_rc;
     if (grouped) {
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
-        const hipError_t ge = sbv::launch_ed25519_verify_grouped(d_tuples, n, variant_view(c, n), c.edgrp, c.d_qtab, c.d_btab, sbv::edcomb_make(c.d_ed_bcomb, c.ed_bbits), d_bitmap, stream, c.gsync, dom, dom_pairs);
+        const hipError_t ge = sbv::launch_ed25519_verify_grouped(d_tuples, n, variant_view(c, n), c.edgrp, c.d_qtab, c.d_btab, sbv::edcomb_make(c.d_ed_bcomb, c.ed_bbits, c.ed_bpitch), d_bitmap, stream, c.gsync, dom, dom_pairs);
         if (ge != hipSuccess) {          // a slot is published before its tables are built (see enqueue()): forget the cache
             (void)hipDeviceSynchronize();
             (void)key_cache_forget(c.edgrp.kc);
@@ -1699,9 +1700,14 @@ int ensure_ed_bcomb(Context& c) {
         sbv::host_build_ed_bcomb(g_ed_bbits, g_h_ed_bcomb.data());
     });
     c.ed_bbits = g_ed_bbits;
+    c.ed_bpitch = (u32)sizeof(sbv::aniels);
     if (g_ed_bbits == 16) { c.d_ed_bcomb = c.d_btab; return SBV_OK; }
-    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_ed_bcomb, g_h_ed_bcomb.size() * sizeof(sbv::aniels)));
-    HIP_TRY(SBV_EDEVICE, hipMemcpy(c.d_ed_bcomb, g_h_ed_bcomb.data(), g_h_ed_bcomb.size() * sizeof(sbv::aniels), hipMemcpyHostToDevice));
+    // one 128-byte line per entry (ed25519_core.h: edcomb::pitch; SBV_ED_B_PITCH=96 keeps the packed layout for A/B runs): 872 MB instead of 654
+    u32 pitch = 128;
+    if (const char* e = getenv("SBV_ED_B_PITCH")) { if (atoi(e) == 96) pitch = 96; }
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&c.d_ed_bcomb, g_h_ed_bcomb.size() * (size_t)pitch));
+    HIP_TRY(SBV_EDEVICE, hipMemcpy2D(c.d_ed_bcomb, pitch, g_h_ed_bcomb.data(), sizeof(sbv::aniels), sizeof(sbv::aniels), g_h_ed_bcomb.size(), hipMemcpyHostToDevice));
+    c.ed_bpitch = pitch;
     return SBV_OK;
 }
 }  // namespace
@@ -2644,7 +2650,13 @@ int verify_shard(Context& c, const uint8_t* h_tuples, size_t m, size_t group, u3
     size_t chunk = (want_piece < kMaxChunk ? want_piece : kMaxChunk) / gran * gran;
     if (chunk == 0) chunk = kMaxChunk / gran * gran;
     if (chunk == 0) { g_err = "group too large"; return SBV_EINVAL; }
-    const size_t pieces = (m + chunk - 1) / chunk;
+    size_t pieces = (m + chunk - 1) / chunk;
+    if (pieces > 1) {
+        // EQUAL pieces (round 6): 550 000 signatures in pieces of 2^18 used to end with a piece of 32 000 that paid the step's fixed
+        // chain (grouping, sort, classes: ~0.4 ms) for a tenth of the work, behind the last upload
+        const size_t even = ((m + pieces - 1) / pieces + gran - 1) / gran * gran;
+        if (even && even <= chunk) { chunk = even; pieces = (m + chunk - 1) / chunk; }
+    }
     int rc = ensure_capacity(c, m < chunk ? m : chunk);
     if (rc != SBV_OK) return rc;
     ShardBuffers& sbuf = g_shard[c.device];

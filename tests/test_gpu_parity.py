@@ -991,3 +991,64 @@ def test_hot_keys_on_the_device(gpu, oracle, golden_vectors):
         gpu.hot_keys(1024, 4096)
         gpu.key_cache(True)
         gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
+
+
+def test_hot_key_pool_follows_a_changing_signer_set(gpu, oracle):
+    """Round 6 (p256_group.h "life cycle of the hot keys") on the device: a pool of 8 wide combs, three disjoint sets
+    of 8 signers one after another (a reconfiguration replaces the consenters: pkg/consensus/consensus.go:185-252).  The set that
+    signs NOW takes the pool over from the set that stopped — k_promote_evict hands a comb over once its owner's count is at most half
+    the newcomer's — every comb a new owner got is byte for byte the host builder's for ITS key (sbv_debug_hot_check), the clock sweep
+    halves the counts, and every verdict of every batch is the generator's.  Then the rate: two batches after a rotation has settled the
+    new set runs through the wide pass."""
+    import numpy as np
+
+    def gen(seed, n, nkeys, inv=0):
+        tup = ctypes.create_string_buffer(160 * n)
+        exp = ctypes.create_string_buffer((n + 7) // 8)
+        oracle.sbvo_gen_batch(seed, n, nkeys, inv, tup, exp, os.cpu_count() or 1)
+        return (np.frombuffer(tup, dtype=np.uint8).reshape(n, 160).copy(),
+                np.unpackbits(np.frombuffer(exp, dtype=np.uint8), bitorder="little")[:n].copy())
+
+    def run(t, want):
+        n = len(want)
+        got = ctypes.create_string_buffer((n + 7) // 8)
+        buf = np.ascontiguousarray(t).reshape(-1)
+        gpu.verify_batch_ptr(buf.ctypes.data, n, ctypes.addressof(got))
+        bits = np.unpackbits(np.frombuffer(got, dtype=np.uint8), bitorder="little")[:n]
+        bad = np.nonzero(bits != want)[0]
+        assert len(bad) == 0, bad[:8]
+        return gpu.hot_key_stats()
+
+    sets = [gen(0x71 + k, 8 * 8192, 8, 9) for k in range(3)]          # 8 signers x 8192 signatures, 1/9 of them corrupted
+    try:
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
+        gpu.key_cache(False)
+        gpu.key_cache(True)
+        gpu.hot_keys(8, 4096)
+        handed_out_before = 0
+        for k, (t, w) in enumerate(sets):
+            settled_at = None
+            for call in range(14):
+                h = run(t, w)
+                promoted, differ, _, _, _, inconsistent, shared, handed_out = gpu.debug_hot_check(0) if call in (3, 13) else (0,) * 8
+                if call in (3, 13):
+                    assert differ == 0 and inconsistent == 0 and shared == 0 and promoted == 8, (k, call, promoted, differ, inconsistent, shared)
+                if settled_at is None and h[2] >= 8 * 8192 * 0.85:      # (nearly) the whole batch through the wide pass: this set owns the pool
+                    settled_at = call
+            # set 0 finds an empty pool (promoted behind its first batch); a later set has to out-count the owners: 2 x their count
+            assert settled_at is not None and (settled_at <= 2 if k == 0 else settled_at <= 12), (k, settled_at)
+            h = run(t, w)
+            assert h[0] == 8 and h[1] == 8 and h[2] >= 8 * 8192 * 0.85, h
+        # all three sets in one batch: 24 hot signers, 8 combs — the pool stays with whoever holds it (hysteresis), verdicts as ever
+        t3 = np.concatenate([s[0] for s in sets])
+        w3 = np.concatenate([s[1] for s in sets])
+        perm = np.random.default_rng(3).permutation(len(w3))
+        for _ in range(3):
+            h = run(t3[perm], w3[perm])
+            assert h[0] == 8, h
+        promoted, differ, _, _, _, inconsistent, shared, _ = gpu.debug_hot_check(0)
+        assert promoted == 8 and differ == 0 and inconsistent == 0 and shared == 0
+    finally:
+        gpu.hot_keys(1024, 4096)
+        gpu.key_cache(True)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
