@@ -20,13 +20,22 @@ out = {
               "Per launch = mean over the dispatches of the profiled run.",
     "launch": "2^20 tuples",
 }
+# round 6: the chunks' launches of the cold step are two instantiations (<0, false> parks the accumulator, <0, true> compares);
+# bench.py's `roofline` is about their average launch, as its HIP-event average is
+for base, insts in (("k_verify_keyed_q", ("void k_verify_keyed_q<0, false>", "void k_verify_keyed_q<0, true>")),
+                    ("k_ed_qphase", ("void k_ed_qphase<false>", "void k_ed_qphase<true>")),
+                    ("k_k256_qphase", ("void k_k256_qphase<false>", "void k_k256_qphase<true>"))):
+    full = [summary[k] for k in insts if k in summary]
+    if len(full) == 2:
+        summary[base] = {c: {"mean": sum(x[c]["mean"] for x in full) / 2, "dispatches": sum(x[c]["dispatches"] for x in full)}
+                         for c in ("FETCH_SIZE", "WRITE_SIZE") if all(c in x for x in full)}
 for k, c in sorted(summary.items()):
     f = c.get("FETCH_SIZE", {}).get("mean")
     w = c.get("WRITE_SIZE", {}).get("mean")
     if f is None or w is None:
         continue
     name = k.replace("void ", "")
-    if name == "k_verify_keyed_q<0>":          # the chunks' launches of the cold step: the instantiation bench.py's `roofline` is about
+    if name == "k_verify_keyed_q<0>":          # rounds 2-5: the one instantiation of the chunks' launches
         name = "k_verify_keyed_q"
     out[name + "_fetch_kib_raw"] = f
     out[name + "_write_kib_raw"] = w
