@@ -211,7 +211,8 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
         hipLaunchKernelGGL(k_ed_group_split, dim3(gn), dim3(256), 0, y.side_b, n, g);
     }
     SBV_TRY(hipEventRecord(y.ev_split, y.side_b));
-    // stream: the G phase needs nothing but the tuples
+    // stream: the G phase needs nothing but the tuples.  (Holding it back until the grouping's first kernels are through, so that the head
+    // of the table pipeline does not share the CUs with it, was measured in round 6 and changes nothing: 3.84 against 3.81 ms cold.)
     hipLaunchKernelGGL(k_ed_gphase, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, n, bcomb, b.gacc, b.gacc_cap, eb.okb, (int)g.sorted);
     SBV_TRY(hipStreamWaitEvent(stream, y.ev_split, 0));
     // (an uneven split — a first chunk of 6-12 windows so that the first Q launch starts earlier — was measured in round 5 and loses:

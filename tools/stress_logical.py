@@ -26,14 +26,27 @@ def main():
     os.environ["SBV_SHARD_MIN"] = str(1 << 16)
     bad_calls = 0
     qgot = np.zeros((props + 7) // 8, dtype=np.uint8)
+    all_entries = os.environ.get("STRESS_ENTRIES", "generic") == "all"       # also the registered-key and the message entries, alternating
+    t2 = tuples.reshape(n, 160)
+    keys, counts = np.unique(t2[:, 96:160], axis=0, return_counts=True)
+    signer_keys = [bytes(k) for k in keys[counts > 1000]]
+    rsh = np.ascontiguousarray(t2[:, :96]).reshape(-1)
     for rnd in range(rounds):
         sbv.shutdown()
         assert sbv.init_all() == contexts
         sbv.key_cache(True)
+        slots = None
+        if all_entries:
+            slot_of = dict(zip(signer_keys, sbv.register_keys(signer_keys)))
+            sbv.widen_keys(list(slot_of.values()))
+            slots = np.fromiter((slot_of.get(bytes(k), 0xFFFFFFFF) for k in t2[:, 96:160]), dtype=np.uint32, count=n)
         for call in range(calls):
             got = np.zeros((n + 7) // 8, dtype=np.uint8)
             t0 = time.perf_counter()
-            info = sbv.verify_batch_sharded(tuples.ctypes.data, n, got.ctypes.data, group, quorum, qgot.ctypes.data)
+            if all_entries and call % 2 == 1:
+                info = sbv.verify_batch_keyed_sharded(rsh.ctypes.data, slots.ctypes.data, n, got.ctypes.data, group, quorum, qgot.ctypes.data)
+            else:
+                info = sbv.verify_batch_sharded(tuples.ctypes.data, n, got.ctypes.data, group, quorum, qgot.ctypes.data)
             ms = 1e3 * (time.perf_counter() - t0)
             bits = np.unpackbits(got, bitorder="little")[:n]
             diff = np.nonzero(bits != want)[0]
