@@ -316,6 +316,31 @@ func (b *gpuBackend) WidenKey(slot int32) {
 	})
 }
 
+// PoolStats is what the grouped P-256 step really holds on the default device (sbv_p256_pool_stats; round 6).  The pools are sized for a
+// 288 GB MI355X; a shared or smaller device gets halved pools instead of an error, and a batch whose pools cannot be allocated at all is
+// verified by the one-lane kernel — an operator reads here which of the two happened (NomemFallbacks > 0: give the replica more HBM).
+type PoolStats struct {
+	CacheKeys, GroupsPerBatch uint32 // 0 before the first grouped batch
+	Shrunk                    bool   // smaller than asked for
+	NomemFallbacks            uint32 // grouped batches that took the one-lane kernel for lack of memory
+	HotPool                   uint32 // 16-bit combs of the hot-key pool
+	GPUShare                  uint32 // contexts sharing the GPU (SBV_LOGICAL_DEVICES)
+}
+
+// PoolStats: sbv_p256_pool_stats.
+func (b *gpuBackend) PoolStats() (st PoolStats, err error) {
+	b.on(func() {
+		var out [6]C.uint32_t
+		if rc := C.sbv_p256_pool_stats((*C.uint32_t)(unsafe.Pointer(&out[0]))); rc != 0 {
+			err = lastError()
+			return
+		}
+		st = PoolStats{CacheKeys: uint32(out[0]), GroupsPerBatch: uint32(out[1]), Shrunk: out[2] != 0, NomemFallbacks: uint32(out[3]),
+			HotPool: uint32(out[4]), GPUShare: uint32(out[5])}
+	})
+	return st, err
+}
+
 // SignBatch: sbv_p256_sign_batch (RFC 6979 nonces on the device; not constant-time — see include/sbv.h).
 func (b *gpuBackend) SignBatch(keys [][32]byte, keyIndex []uint32, digests [][32]byte) (sigs [][64]byte, ok []bool, err error) {
 	n := len(digests)

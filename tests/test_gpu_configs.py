@@ -240,6 +240,14 @@ def test_config3_over_8_logical_devices(oracle):
         qb = ctypes.create_string_buffer((P + 7) // 8)
         info = sbv.verify_batch_sharded(ctypes.addressof(tup), n, ctypes.addressof(got), group=Q, quorum=Q - 1, quorum_out_ptr=ctypes.addressof(qb))
         assert got.raw == exp, _diff(got.raw, exp)
+        m_or = 11 * 8000                                                          # the oracle's own verdicts on the first 8 000 proposals, and one
+        ob = ctypes.create_string_buffer(m_or // 8)                               # whole shard further in (shard 5: offsets > 0)
+        oracle.sbvo_p256_verify_batch(ctypes.addressof(tup), m_or, ctypes.addressof(ob), THREADS)
+        assert got.raw[:m_or // 8] == ob.raw
+        s5, e5 = first[5], first[6]
+        ob5 = ctypes.create_string_buffer((e5 - s5) // 8)
+        oracle.sbvo_p256_verify_batch(ctypes.addressof(tup) + 160 * s5, e5 - s5, ctypes.addressof(ob5), THREADS)
+        assert got.raw[s5 // 8:e5 // 8] == ob5.raw
         assert info.devices == 8 and info.shards == 8 and info.mode == 2          # 8 shards, gathered through the host
         assert info.tuples_per_shard == first[1] and info.h2d_us > 0 and info.kernels_us > 0
         want_q = shard.quorum_bits(tup.raw, exp, n, Q, Q - 1)
