@@ -11,6 +11,8 @@
 // Launch sizes that depend on device-side counters use the upper bound; surplus lanes exit at once.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "group_kernels_common.h"
 #include "p256_kernels.h"
 #include "p256_keytab29.h"
@@ -381,6 +383,124 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, MODE == SBV_Q_NARROW ? SBV_COMB29
     const bool v = qphase29_lane_sorted<MODE == SBV_Q_NARROW>(s, t, L, ts, table_slots, ktab, kvalid, gacc, j0, j1, LAST);
     if (LAST) acc[t] = v ? 1 : 0;
 }
+// ---- the LDS-staged form of the chunks' launches (round 6; VERDICT r5 #3, north_star "LDS-staged ... tables") ------------------------
+// A workgroup of the key-sorted list nearly always holds ONE key (256 lanes in runs of ~1000).  Such a workgroup stages the window's
+// row — 128 entries, 8 KB — in LDS with two coalesced 16-byte loads per lane instead of 256 random 64-byte gathers through the vector
+// cache, two buffers (16 KB per workgroup, 48 KB per CU at 3 workgroups), one barrier per window: row j + 1 is fetched into registers
+// while the additions of row j run, and written to the other buffer behind them.  A workgroup at the seam of two keys (or with a
+// rows-only / wide wavefront) takes the ordinary path.  Opt-in (SBV_QPHASE_LDS=1): measured against the gathers in
+// profiles/r06/ab_qphase_lds_*; DESIGN.md section 7 has the verdict.
+template <bool LAST>
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_QPHASE_WAVES) void k_verify_keyed_q_lds(Scratch s, GroupState g, const apt* __restrict__ ktab,
+                                                                    const uint8_t* __restrict__ kvalid, const u32* __restrict__ tslot,
+                                                                    const uint8_t* __restrict__ full, const uint8_t* __restrict__ wide,
+                                                                    u32 table_slots, u32* __restrict__ gacc,
+                                                                    uint8_t* __restrict__ acc, int j0, int j1) {
+    struct alignas(16) q4 { u32 x, y, z, w; };
+    __shared__ q4 rows[2][SBV_GTAB_PER_WINDOW * 4];          // 2 x 128 entries x 64 B
+    __shared__ u32 wave_slot[SBV_VERIFY_BLOCK / 64];
+    __shared__ u32 blk_top;
+    const u32 lanes = g.counters[1];
+    const u32 per = ((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK + 7) >> 3;
+    const u32 local = blockIdx.x >> 3;
+    if (local >= per) return;                                               // whole workgroup: no barrier has been reached
+    const u32 tid = threadIdx.x;
+    const u32 L = ((blockIdx.x & 7u) * per + local) * SBV_VERIFY_BLOCK + tid;
+    const bool in = L < lanes;
+    const u32 t = in ? g.grp_idx[L] : 0u;
+    const u32 grp = in ? g.grp_of[L] : 0xFFFFFFFFu;
+    const bool known = in && grp < group_count(g);
+    const u32 ts = known ? tslot[grp] : SBV_GROUP_NONE;
+    const bool dead = !(ts < table_slots) || kvalid[ts < table_slots ? ts : 0u] == 0;
+    const int cls = q_wave_class(dead, !dead && wide[known ? grp : 0u] != 0, !dead && full[known ? grp : 0u] != 0);
+    // what this wavefront wants from the workgroup: 0xFFFFFFFE = nothing (every lane dead), a slot = its live lanes all use that
+    // slot's full table, SBV_GROUP_NONE = anything else (two keys, a rows-only or a wide wavefront)
+    u32 want = 0xFFFFFFFEu;
+    if (cls != SBV_Q_NONE) {
+        const unsigned long long live = __ballot(!dead);
+        const u32 first = (u32)__shfl((int)ts, __ffsll((long long)live) - 1, 64);
+        want = cls == SBV_Q_FULL && __all(dead || ts == first) ? first : SBV_GROUP_NONE;
+    }
+    if ((tid & 63u) == 0) wave_slot[tid >> 6] = want;
+    if (tid == 0) blk_top = 0;
+    __syncthreads();
+    u32 slot = 0xFFFFFFFEu;
+    bool uniform = true;
+    SBV_UNROLL
+    for (int w = 0; w < SBV_VERIFY_BLOCK / 64; ++w) {
+        const u32 v = wave_slot[w];
+        if (v == 0xFFFFFFFEu) continue;
+        if (v == SBV_GROUP_NONE || (slot != 0xFFFFFFFEu && v != slot)) uniform = false;
+        slot = v;
+    }
+    if (!uniform || slot == 0xFFFFFFFEu) {                                  // the ordinary path, wavefront by wavefront (no barrier below)
+        if (!in) return;
+        if (cls == SBV_Q_NONE) { if (LAST) acc[t] = 0; return; }
+        if (cls != SBV_Q_FULL) return;
+        const bool v = qphase29_lane_sorted<false>(s, t, L, ts, table_slots, ktab, kvalid, gacc, j0, j1, LAST);
+        if (LAST) acc[t] = v ? 1 : 0;
+        return;
+    }
+    // ---- one key for the whole workgroup: rows through LDS ------------------------------------------------------------------------
+    const bool livel = !dead;                                               // dead and out-of-range lanes walk along (barriers) and add nothing
+    const apt* qtab = ktab + (size_t)slot * (SBV_GTAB_WINDOWS * SBV_GTAB_PER_WINDOW);
+    u256 u2in;
+    SBV_UNROLL
+    for (int w = 0; w < 8; ++w) u2in.v[w] = 0;
+    if (livel) rec_load256(u2in, s.rec, t, SBV_REC_U2);
+    const bool flip = (u2in.v[7] >> 31) != 0;
+    u256 u2, nmu;
+    (void)sub256(nmu, sc_n(), u2in);
+    select256(u2, flip, nmu, u2in);
+    u288 k;
+    gcomb_recode(k, u2, 8, SBV_GTAB_WINDOWS);
+    u32 idx; bool neg, skip;
+    if (j1 == SBV_GTAB_WINDOWS) {                                           // the carry window only if a lane of the WORKGROUP carries
+        gcomb_digit(k, 8, SBV_GTAB_WINDOWS - 1, idx, neg, skip);
+        if (wave_any(livel && !skip) && (tid & 63u) == 0) atomicOr(&blk_top, 1u);
+    }
+    xyzz R;
+    pt29_set_inf(R);
+    if (livel) gacc29_load(R, gacc, s.cap, L);
+    const q4* grow = reinterpret_cast<const q4*>(qtab + (size_t)j0 * SBV_GTAB_PER_WINDOW);
+    q4 pa = grow[2 * tid], pb = grow[2 * tid + 1];
+    rows[j0 & 1][2 * tid] = pa; rows[j0 & 1][2 * tid + 1] = pb;
+    __syncthreads();                                                        // row j0 and blk_top are in place
+    if (j1 == SBV_GTAB_WINDOWS && blk_top == 0) j1 = SBV_GTAB_WINDOWS - 1;
+    SBV_NOUNROLL
+    for (int j = j0; j < j1; ++j) {
+        const bool more = j + 1 < j1;
+        if (more) {
+            const q4* nrow = reinterpret_cast<const q4*>(qtab + (size_t)(j + 1) * SBV_GTAB_PER_WINDOW);
+            pa = nrow[2 * tid]; pb = nrow[2 * tid + 1];
+        }
+        gcomb_digit(k, 8, j, idx, neg, skip);
+        if (livel && !skip) {
+            const q4* e = &rows[j & 1][idx * 4];
+            raw_apt cur;
+            const q4 a = e[0], b = e[1], c = e[2], d = e[3];
+            cur.w[0] = a.x; cur.w[1] = a.y; cur.w[2] = a.z; cur.w[3] = a.w; cur.w[4] = b.x; cur.w[5] = b.y; cur.w[6] = b.z; cur.w[7] = b.w;
+            cur.w[8] = c.x; cur.w[9] = c.y; cur.w[10] = c.z; cur.w[11] = c.w; cur.w[12] = d.x; cur.w[13] = d.y; cur.w[14] = d.z; cur.w[15] = d.w;
+            apt29 q;
+            raw_apt_unpack(q, cur);
+            pt29_madd(R, q, neg != flip);
+        }
+        if (more) { rows[(j + 1) & 1][2 * tid] = pa; rows[(j + 1) & 1][2 * tid + 1] = pb; }
+        __syncthreads();
+    }
+    if (!in) return;
+    if (dead) { if (LAST) acc[t] = 0; return; }
+    if (!LAST) {
+        size_t Ls = L;
+        asm volatile("" : "+v"(Ls));
+        gacc29_store(gacc, s.cap, Ls, R);
+        return;
+    }
+    u256 r;
+    rec_load256(r, s.rec, t, SBV_REC_R);
+    acc[t] = s.rec[(size_t)t * SBV_REC_WORDS + SBV_REC_OK] != 0 && pt29_rx_matches(R, r) ? 1 : 0;
+}
+
 // compaction order (SBV_GROUP_SORT=0): no wide pass (the class kernel leaves wide[] empty)
 template <int MODE>
 __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_COMB29_WAVES) void k_verify_keyed_q_list(Scratch s, GroupState g, const apt* __restrict__ ktab,
@@ -495,6 +615,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
     const bool hot_on = b.wtab && b.kwide && b.kc.enabled && g.sorted;
     const HotKeys hk = {b.wtab, hot_on ? b.kwide : nullptr, b.khits, b.hot, b.plist, b.kc.cap, b.wide_cap, b.promote_min, b.wowner, b.elist};
     const widekeys wk = hot_on ? widekeys_make(b.wtab, b.kwide, SBV_HOT_BITS) : widekeys_none();
+    static const bool q_lds = [] { const char* v = getenv("SBV_QPHASE_LDS"); return v && v[0] == '1'; }();      // the LDS-staged form of the chunks' launches (opt-in)
     hipError_t e;
 #define SBV_TRY(x) do { if ((e = (x)) != hipSuccess) return e; } while (0)
     // The side streams may not touch the group buffers before everything already enqueued on `stream` (the
@@ -609,6 +730,10 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
         if (!g.sorted) hipLaunchKernelGGL(k_verify_keyed_q_list<SBV_Q_FULL>, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full,
                                           table_slots, b.gacc, b.acc, j_first, j_end, last ? 1 : 0);
+        else if (q_lds && last) hipLaunchKernelGGL((k_verify_keyed_q_lds<true>), dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide,
+                                                   table_slots, b.gacc, b.acc, j_first, j_end);
+        else if (q_lds) hipLaunchKernelGGL((k_verify_keyed_q_lds<false>), dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide,
+                                           table_slots, b.gacc, b.acc, j_first, j_end);
         else if (last) hipLaunchKernelGGL((k_verify_keyed_q<SBV_Q_FULL, true>), dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,
                                           table_slots, b.gacc, b.acc, j_first, j_end);
         else hipLaunchKernelGGL((k_verify_keyed_q<SBV_Q_FULL, false>), dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, s, g, b.ktab, b.kvalid, b.tslot, b.full, b.wide, wk, b.hot + 2,

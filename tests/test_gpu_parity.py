@@ -1054,3 +1054,44 @@ def test_hot_key_pool_follows_a_changing_signer_set(gpu, oracle):
         gpu.hot_keys(1024, 4096)
         gpu.key_cache(True)
         gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
+
+
+def test_lds_staged_form_of_the_q_phase_gives_the_same_verdicts(oracle, golden_vectors):
+    """SBV_QPHASE_LDS=1 (round 6; VERDICT r5 #3, north_star "LDS-staged ... tables"): the chunks' launches stage a key-uniform workgroup's
+    comb rows in LDS (two coalesced loads per lane and window instead of a 64-byte gather; two buffers, one barrier per window),
+    workgroups at the seam of two keys take the gathers.  Measured 4 % slower per launch than the gathers and moving the same HBM bytes
+    (profiles/r06/ab_qphase_lds_r06v.jsonl, pmc_qphase_lds_vs_gather_r06w.json) — it stays opt-in; here its verdicts: 2^18 tuples over
+    300 keys (runs that end inside workgroups), the golden edge vectors spliced in, cold and warm, two chunk settings."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, json, os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle"))
+import numpy as np
+import consensus_amd as sbv
+oracle = ctypes.CDLL(os.path.join("oracle", "libsbv_oracle.so"))
+oracle.sbvo_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+vs = [v for v in json.load(open(os.path.join("tests", "golden", "p256_vectors.json")))["vectors"] if v["kind"] == "tuple"]
+n = 1 << 18
+tup = ctypes.create_string_buffer(160 * n); exp = ctypes.create_string_buffer(n // 8)
+oracle.sbvo_gen_batch(0x1D5, n, 300, 8, tup, exp, os.cpu_count() or 1)
+t = np.frombuffer(tup, dtype=np.uint8).reshape(n, 160).copy()
+w = np.unpackbits(np.frombuffer(exp, dtype=np.uint8), bitorder="little")[:n].copy()
+for k, v in enumerate(vs):                       # the edge vectors spliced in, spread over the batch
+    i = (k * 1201 + 7) % n
+    t[i] = np.frombuffer(bytes.fromhex(v["tuple"]), dtype=np.uint8); w[i] = 1 if v["accept"] else 0
+sbv.init(0)
+for cache in (False, True, True):
+    sbv.key_cache(cache)
+    got = ctypes.create_string_buffer(n // 8)
+    sbv.verify_batch_ptr(t.reshape(-1).ctypes.data, n, ctypes.addressof(got))
+    bits = np.unpackbits(np.frombuffer(got, dtype=np.uint8), bitorder="little")[:n]
+    bad = np.nonzero(bits != w)[0]
+    assert len(bad) == 0, (cache, bad[:8])
+print("lds ok", sbv.last_group_stats())
+"""
+    for chunks in ("2", "3"):
+        env = dict(os.environ, SBV_QPHASE_LDS="1", SBV_GROUP_CHUNKS=chunks, SBV_GROUP_MIN_BATCH="64")
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert out.returncode == 0 and "lds ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
