@@ -196,26 +196,24 @@ SBV_HD void edchain_run(QX& q, const uint8_t* tuples, u32 gidx, const GroupState
 // One part of one (key, window): row[k-1] = k * base for k = part*E + 1 .. part*E + E as affine-Niels points.
 // `tmp` = private scratch of E * SBV_ED_WINDOW_TMP_WORDS dwords (X, Y, Z and the running product of the Zs, raw limbs).
 #define SBV_ED_WINDOW_TMP_WORDS 40
-SBV_HD void ed_keytab_window_lane(const u32* jbase, int part, int parts, u32* tmp, aniels* row) {
-    const int E = SBV_ED_KEY_PER_WINDOW / parts;      // parts is a power of two <= 16
+// The multiples (m0 + 1 .. m0 + E) * base as affine-Niels entries at row + (m - 1) * pitch: a double-and-add ladder of `mbits` steps to
+// m0 * base, E unified additions, ONE inversion for the lane's E points (Montgomery's trick).  tmp: E * 40 words.  Shared by the 8-bit
+// per-batch combs (ed_keytab_window_lane: E = 128 / parts, 7 ladder steps, 96-byte pitch) and, since round 6, the 16-bit combs of hot
+// keys (ed_widetab_lane: E = 32, 15 ladder steps, 128-byte pitch).
+SBV_HD void ed_comb_part_lane(const pniels& base, u32 m0, int E, int mbits, u32* tmp, uint8_t* row, u32 pitch) {
     u32* pts = tmp;                   // E * 30 dwords
     u32* pre = tmp + E * 30;          // E * 10 dwords
-    ept b;
-    ept_load(b, jbase);
-    pniels base;
-    ed_to_pniels(base, b);
     ept t;
     ed_set_ident(t);
-    const int m = part * E;           // start multiple
     SBV_NOUNROLL
-    for (int bit = 6; bit >= 0; --bit) {
+    for (int bit = mbits - 1; bit >= 0; --bit) {
         ed_dbl(t, t);
-        ed_add_pniels(t, base, false, ((m >> bit) & 1) == 0);
+        ed_add_pniels(t, base, false, ((m0 >> bit) & 1u) == 0);
     }
     fe25 acc = fe25_one();
     SBV_NOUNROLL
     for (int k = 0; k < E; ++k) {
-        ed_add_pniels(t, base, false, false);                 // (m + k + 1) * base
+        ed_add_pniels(t, base, false, false);                 // (m0 + k + 1) * base
         fe25_store_raw(pts + k * 30, t.X); fe25_store_raw(pts + k * 30 + 10, t.Y); fe25_store_raw(pts + k * 30 + 20, t.Z);
         fe25_store_raw(pre + k * 10, acc);
         fe25_mul(acc, acc, t.Z);
@@ -237,8 +235,43 @@ SBV_HD void ed_keytab_window_lane(const u32* jbase, int part, int parts, u32* tm
         fe25_sub(a.ymx, y, x);
         fe25_mul(a.xy2d, x, y);
         fe25_mul(a.xy2d, a.xy2d, d2);
-        aniels_store(row + m + k, a);
+        aniels_store(reinterpret_cast<aniels*>(row + (size_t)(m0 + (u32)k) * pitch), a);
     }
+}
+SBV_HD void ed_keytab_window_lane(const u32* jbase, int part, int parts, u32* tmp, aniels* row) {
+    const int E = SBV_ED_KEY_PER_WINDOW / parts;      // parts is a power of two <= 16
+    ept b;
+    ept_load(b, jbase);
+    pniels base;
+    ed_to_pniels(base, b);
+    ed_comb_part_lane(base, (u32)(part * E), E, 7, tmp, reinterpret_cast<uint8_t*>(row), (u32)sizeof(aniels));
+}
+
+// ---- hot keys of this scheme (round 6; VERDICT r5 #5, Missing #5: "hot keys as P-256 has") ---------------------------------------------
+// A cached key that keeps signing gets a 16-bit comb of -A in the layout of the comb of B: comb[(j << 15) + (m - 1)] = m * 2^(16 j) * (-A),
+// 16 windows x 32 768 entries at a 128-byte pitch = 64 MiB (HBM holds 288 GB): [k](-A) is 16 additions instead of 32, walked by the very
+// function that walks the comb of B (ed_add_sB_comb).  The bookkeeping — counts per cache slot, promotion threshold, clock sweep,
+// eviction with hysteresis — is the P-256 step's (p256_group.h: group_hot_class_lane, group_promote_select_lane, hot_evict_*), on this
+// scheme's own arrays.  The builder needs no doubling chain: B_j = 2^(16 j) (-A) is entry 1 of row 2 j of the slot's 8-bit comb, an
+// affine-Niels point, i.e. a projective-Niels point with Z = 1; lane (j, part) walks to (32 part) B_j and emits 32 multiples.
+#define SBV_ED_HOT_BITS 16
+#define SBV_ED_HOT_WINDOWS 16
+#define SBV_ED_HOT_PER_WINDOW 32768u
+#define SBV_ED_HOT_PITCH 128u
+#define SBV_ED_HOT_COMB_BYTES ((size_t)SBV_ED_HOT_WINDOWS * SBV_ED_HOT_PER_WINDOW * SBV_ED_HOT_PITCH)      // 64 MiB
+#define SBV_ED_HOT_LANE_ENTRIES 32
+#define SBV_ED_HOT_PARTS (SBV_ED_HOT_PER_WINDOW / SBV_ED_HOT_LANE_ENTRIES)                                 // 1024 lanes per window
+#define SBV_ED_HOT_TMP_WORDS (SBV_ED_HOT_LANE_ENTRIES * SBV_ED_WINDOW_TMP_WORDS)                            // per resident lane
+// key_tab: the promoted slot's 8-bit comb; comb: its wide comb (SBV_ED_HOT_COMB_BYTES)
+SBV_HD void ed_widetab_lane(const aniels* key_tab, u32 j, u32 part, u32* tmp, uint8_t* comb) {
+    raw_aniels e;
+    raw_aniels_load(e, key_tab + (size_t)(2 * j) * SBV_ED_KEY_PER_WINDOW);
+    aniels_r a;
+    raw_aniels_unpack(a, e);
+    pniels base;
+    base.YpX = a.ypx; base.YmX = a.ymx; base.Z = fe25_one(); base.T2d = a.xy2d;
+    ed_comb_part_lane(base, part * SBV_ED_HOT_LANE_ENTRIES, SBV_ED_HOT_LANE_ENTRIES, 15, tmp,
+                      comb + (size_t)j * SBV_ED_HOT_PER_WINDOW * SBV_ED_HOT_PITCH, SBV_ED_HOT_PITCH);
 }
 
 // gacc: SBV_ED_GACC_WORDS words per tuple (X, Y, Z, T raw limbs), limb-major: word w of tuple i at gacc[w * cap + i]
@@ -361,6 +394,21 @@ SBV_HD bool ed_qphase_lane(const uint8_t* tuples, size_t i, u32 slot, u32 nkeys,
     if (tuple_major) ed_gacc_store_tm(gacc, i, R);
     else ed_gacc_store(gacc, cap, i, R);
     return last && ok;
+}
+
+// The wide pass of a hot key's tuple: R (tuple-major gacc) += [k](-A) from the slot's 16-bit comb, all 16 windows in one go; the return
+// value is the tuple's pending flag, as ed_qphase_lane's after the last chunk.
+SBV_HD bool ed_qphase_wide_lane(const uint8_t* tuples, size_t i, bool slot_ok, const uint8_t* comb, u32* gacc, const uint8_t* okb) {
+    const u32* w = ed_tuple_words(tuples, i);
+    u256 k;
+    SBV_UNROLL
+    for (int j = 0; j < 8; ++j) k.v[j] = w[24 + j];
+    ept R;
+    ed_gacc_load_tm(R, gacc, i);
+    const edcomb kc = edcomb_make(reinterpret_cast<const aniels*>(comb), SBV_ED_HOT_BITS, SBV_ED_HOT_PITCH);
+    ed_add_sB_comb(R, k, kc);         // the comb is of -A: the same walker as the comb of B
+    ed_gacc_store_tm(gacc, i, R);
+    return slot_ok && okb[i] != 0;
 }
 
 // ---- finish: encode(R) == R_enc for every pending tuple, ONE inversion per SBV_ED_FINISH_T tuples (Montgomery's trick) --------

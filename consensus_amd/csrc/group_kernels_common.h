@@ -98,6 +98,57 @@ static __global__ __launch_bounds__(64) void k_key_cache_insert_t(const uint8_t*
     key_cache_phase_insert<STRIDE, OFF, WORDS>(tuples, g, kc, k, tslot);
 }
 
+// ---- hot keys: the scheme-independent kernels (p256_group.h "hot keys" / "life cycle"; round 6: shared with the Ed25519 step) ----------
+// wtab: the pool of wide combs (a scheme's own entry type: opaque here); kwide == nullptr = feature off / no pool
+struct HotKeys { const void* wtab; u32* kwide; u32* khits; u32* hot; u32* plist; u32 cache_cap, wide_cap, promote_min; u32* wowner; u32* elist; };
+static __device__ __forceinline__ u32 promote_live(const u32* hot) { const u32 c = hot[1]; return c < SBV_PROMOTE_MAX ? c : SBV_PROMOTE_MAX; }
+// Life cycle of the hot keys (p256_group.h, round 6): the clock sweep and the evictions.
+static __global__ __launch_bounds__(256) void k_hot_decay(HotKeys hk) {
+    const u32 slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot < hk.cache_cap) hot_decay_lane(slot, hk.khits);
+}
+static __global__ __launch_bounds__(256) void k_promote_select(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ kvalid, HotKeys hk) {
+    const u32 groups = group_count(g);
+    for (u32 k = blockIdx.x * 256 + threadIdx.x; k < groups; k += gridDim.x * 256)
+        group_promote_select_lane(k, tslot, kvalid, hk.cache_cap, hk.kwide, hk.khits, hk.promote_min, hk.wide_cap, hk.hot, hk.plist, hk.elist);
+}
+// ONE workgroup: for each slot that found the pool full, its 1024 lanes scan the owners for the coldest comb not handed out in this
+// batch, lane 0 merges and commits (hot_evict_commit: the hysteresis, kwide of the victim, wowner, the plist entry the builder reads).
+#define SBV_HOT_POOL_MAX 4096u
+static __global__ __launch_bounds__(1024) void k_promote_evict(HotKeys hk) {
+    __shared__ u32 taken[SBV_HOT_POOL_MAX / 32];
+    __shared__ u32 sh_h[16], sh_w[16];
+    __shared__ u32 entries;
+    const u32 tid = threadIdx.x;
+    const u32 ncand = hk.hot[3] < SBV_PROMOTE_MAX ? hk.hot[3] : SBV_PROMOTE_MAX;
+    if (ncand == 0 || hk.wide_cap > SBV_HOT_POOL_MAX) return;             // uniform
+    for (u32 i = tid; i < SBV_HOT_POOL_MAX / 32; i += 1024) taken[i] = 0;
+    if (tid == 0) entries = hk.hot[1] < SBV_PROMOTE_MAX ? hk.hot[1] : SBV_PROMOTE_MAX;
+    __syncthreads();
+    for (u32 c = 0; c < ncand; ++c) {
+        u32 bh, bw;
+        hot_evict_scan(hk.khits, hk.wowner, taken, hk.wide_cap, hk.cache_cap, tid, 1024u, bh, bw);
+        for (int off = 32; off >= 1; off >>= 1) {
+            const u32 oh = (u32)__shfl_xor((int)bh, off, 64), ow = (u32)__shfl_xor((int)bw, off, 64);
+            if (hot_evict_better(oh, ow, bh, bw)) { bh = oh; bw = ow; }
+        }
+        if ((tid & 63) == 0) { sh_h[tid >> 6] = bh; sh_w[tid >> 6] = bw; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 1; i < 16; ++i) if (hot_evict_better(sh_h[i], sh_w[i], bh, bw)) { bh = sh_h[i]; bw = sh_w[i]; }
+            entries = hot_evict_commit(hk.elist[c], bh, bw, hk.khits, hk.kwide, hk.wowner, taken, entries, hk.plist);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) hk.hot[1] = entries;
+}
+static __global__ __launch_bounds__(64) void k_promote_publish(const u32* __restrict__ plist, const u32* __restrict__ hot, u32* __restrict__ kwide, u32* __restrict__ wowner) {
+    const u32 i = threadIdx.x;
+    if (i >= promote_live(hot)) return;
+    const u32 slot = plist[2 * i];
+    if (slot != 0xFFFFFFFFu) { kwide[slot] = plist[2 * i + 1]; wowner[plist[2 * i + 1]] = slot; }
+}
+
 static __global__ __launch_bounds__(256) void k_pack_bitmap(const uint8_t* __restrict__ acc, size_t n, uint8_t* __restrict__ bitmap) {
     const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x;           // bitmap byte
     if (b >= ((n + 7) >> 3)) return;

@@ -185,7 +185,6 @@ __global__ __launch_bounds__(64) void k_keytab29_fill_sym(GroupState g, u32* __r
 
 // Table classes of the batch's groups and, at the end of the step, what the slots hold (p256_group.h).  One lane per group.
 // hot: the wide-comb state of the cache slots (p256_group.h: hot keys); kwide == nullptr = feature off / no pool
-struct HotKeys { const apt* wtab; u32* kwide; u32* khits; u32* hot; u32* plist; u32 cache_cap, wide_cap, promote_min; u32* wowner; u32* elist; };
 __global__ __launch_bounds__(256) void k_group_table_class(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
                                                            const uint8_t* __restrict__ kfull, u32 table_slots, u32 full_min,
                                                            uint8_t* __restrict__ full, uint8_t* __restrict__ needfill,
@@ -203,47 +202,6 @@ __global__ __launch_bounds__(256) void k_group_table_class(GroupState g, const u
 // ---- promotion of hot cache slots to wide combs (p256_group.h: hot keys; p256_widetab29.h: the builder of the registered path) ----------
 // select (one lane per group) -> bases (the 2 x 17 base points of each promotion, gathered from the key's 8-bit table) -> chains + fill
 // (the builder's lanes, for the promotions this batch really made) -> publish (kwide[slot] = index: later batches take the wide pass)
-// Life cycle of the hot keys (p256_group.h, round 6): the clock sweep and the evictions.
-__global__ __launch_bounds__(256) void k_hot_decay(HotKeys hk) {
-    const u32 slot = blockIdx.x * 256 + threadIdx.x;
-    if (slot < hk.cache_cap) hot_decay_lane(slot, hk.khits);
-}
-__global__ __launch_bounds__(256) void k_promote_select(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ kvalid, HotKeys hk) {
-    const u32 groups = group_count(g);
-    for (u32 k = blockIdx.x * 256 + threadIdx.x; k < groups; k += gridDim.x * 256)
-        group_promote_select_lane(k, tslot, kvalid, hk.cache_cap, hk.kwide, hk.khits, hk.promote_min, hk.wide_cap, hk.hot, hk.plist, hk.elist);
-}
-// ONE workgroup: for each slot that found the pool full, its 1024 lanes scan the owners for the coldest comb not handed out in this
-// batch, lane 0 merges and commits (hot_evict_commit: the hysteresis, kwide of the victim, wowner, the plist entry the builder reads).
-#define SBV_HOT_POOL_MAX 4096u
-__global__ __launch_bounds__(1024) void k_promote_evict(HotKeys hk) {
-    __shared__ u32 taken[SBV_HOT_POOL_MAX / 32];
-    __shared__ u32 sh_h[16], sh_w[16];
-    __shared__ u32 entries;
-    const u32 tid = threadIdx.x;
-    const u32 ncand = hk.hot[3] < SBV_PROMOTE_MAX ? hk.hot[3] : SBV_PROMOTE_MAX;
-    if (ncand == 0 || hk.wide_cap > SBV_HOT_POOL_MAX) return;             // uniform
-    for (u32 i = tid; i < SBV_HOT_POOL_MAX / 32; i += 1024) taken[i] = 0;
-    if (tid == 0) entries = hk.hot[1] < SBV_PROMOTE_MAX ? hk.hot[1] : SBV_PROMOTE_MAX;
-    __syncthreads();
-    for (u32 c = 0; c < ncand; ++c) {
-        u32 bh, bw;
-        hot_evict_scan(hk.khits, hk.wowner, taken, hk.wide_cap, hk.cache_cap, tid, 1024u, bh, bw);
-        for (int off = 32; off >= 1; off >>= 1) {
-            const u32 oh = (u32)__shfl_xor((int)bh, off, 64), ow = (u32)__shfl_xor((int)bw, off, 64);
-            if (hot_evict_better(oh, ow, bh, bw)) { bh = oh; bw = ow; }
-        }
-        if ((tid & 63) == 0) { sh_h[tid >> 6] = bh; sh_w[tid >> 6] = bw; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 1; i < 16; ++i) if (hot_evict_better(sh_h[i], sh_w[i], bh, bw)) { bh = sh_h[i]; bw = sh_w[i]; }
-            entries = hot_evict_commit(hk.elist[c], bh, bw, hk.khits, hk.kwide, hk.wowner, taken, entries, hk.plist);
-        }
-        __syncthreads();
-    }
-    if (tid == 0) hk.hot[1] = entries;
-}
-__device__ __forceinline__ u32 promote_live(const u32* hot) { const u32 c = hot[1]; return c < SBV_PROMOTE_MAX ? c : SBV_PROMOTE_MAX; }
 __global__ __launch_bounds__(64) void k_promote_bases(const u32* __restrict__ plist, const u32* __restrict__ hot, const apt* __restrict__ ktab, apt* __restrict__ pbases) {
     const u32 lane = blockIdx.x * 64 + threadIdx.x;
     const u32 W = (257 + SBV_HOT_BITS - 1) / SBV_HOT_BITS;          // 17
@@ -272,12 +230,6 @@ __global__ __launch_bounds__(256) void k_promote_fill(const u32* __restrict__ pl
     const size_t q = r % per_window;
     const u32 gi = 1u + (u32)(q / chunks), c = (u32)(q % chunks);
     widetab_fill_lane(w, gi, 1u + c * SBV_WIDETAB_T, wtab + (size_t)plist[2 * i + 1] * stride + (size_t)j * w.per_window);
-}
-__global__ __launch_bounds__(64) void k_promote_publish(const u32* __restrict__ plist, const u32* __restrict__ hot, u32* __restrict__ kwide, u32* __restrict__ wowner) {
-    const u32 i = threadIdx.x;
-    if (i >= promote_live(hot)) return;
-    const u32 slot = plist[2 * i];
-    if (slot != 0xFFFFFFFFu) { kwide[slot] = plist[2 * i + 1]; wowner[plist[2 * i + 1]] = slot; }
 }
 __global__ __launch_bounds__(256) void k_group_table_mark(GroupState g, const u32* __restrict__ tslot, const uint8_t* __restrict__ cold,
                                                           const uint8_t* __restrict__ full, const uint8_t* __restrict__ needfill, u32 table_slots,
