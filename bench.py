@@ -400,7 +400,7 @@ def variant_warm_leg(sbv, torch, scheme, call, d_b, expect, n, steps):
         sbv.key_cache(False, 0, scheme)
 
 
-def leg_ed25519(sbv, torch, n, steps, stream, cpu=False):
+def leg_ed25519(sbv, torch, n, steps, stream, cpu=False, hot=True):
     """BASELINE.json configs[4]: 2^20 Ed25519 signatures, 1024 keys, 7/8 valid, R|S|A|k tuples resident in HBM."""
     import numpy as np
     cache = f"/tmp/sbv_ed_batch_{n}.npz"
@@ -449,11 +449,57 @@ def leg_ed25519(sbv, torch, n, steps, stream, cpu=False):
     if cpu:
         out["cpu_baseline"] = cpu_baseline_variant("ed25519", tuples, n, got)
     try:
+        try:
+            sbv.ed_hot_keys(0, 0)       # the warm figure is the cached 8-bit combs alone; the hot keys have a leg of their own below
+        except AttributeError:          # (an older build of the library under tools/ab_lib.sh)
+            pass
         out["warm_key_cache"] = variant_warm_leg(sbv, torch, sbv.SCHEME_ED25519,
                                                  lambda: sbv.ed25519_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream), d_b, expect, n, steps)
     except Exception as e:      # noqa: BLE001
         out["warm_key_cache"] = {"error": repr(e)}
+    # the scheme's hot keys (sbv_ed25519_hot_keys, opt-in): the calls it takes until every signer owns a 16-bit comb of -A, then the
+    # settled rate — [k](-A) in 16 additions from that comb instead of 32
+    if not hot:
+        sbv.ed_hot_keys(1024, 4096)
+        sbv.key_cache(True, 0, sbv.SCHEME_ED25519)
+        return out
+    try:
+        call = lambda: sbv.ed25519_verify_batch_dev(d_t.data_ptr(), n, d_b.data_ptr(), stream.cuda_stream)      # noqa: E731
+        sbv.key_cache(True, 0, sbv.SCHEME_ED25519)
+        sbv.ed_hot_keys(1024, 512)
+        calls, promoted, pool = 0, 0, 1
+        t0 = time.perf_counter()
+        while calls < 48 and promoted < min(pool, 1024):
+            call()
+            torch.cuda.synchronize()
+            calls += 1
+            promoted, pool = sbv.ed_hot_key_stats()[:2]
+            if pool == 0:
+                break
+        ramp_s = time.perf_counter() - t0
+        if pool:
+            call()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                call()
+            torch.cuda.synchronize()
+            dth = time.perf_counter() - t0
+            promoted, pool, wide_lanes, min_hits = sbv.ed_hot_key_stats()
+            out["hot_keys"] = {"value": n * steps / dth, "unit": "verifies/s", "ms_per_step": 1e3 * dth / steps,
+                               "bitmap_correct": bool((d_b.cpu().numpy() == expect).all()), "promoted": promoted, "pool": pool,
+                               "tuples_served_wide_last_step": wide_lanes, "min_hits": min_hits, "calls_until_settled": calls,
+                               "ramp_s": ramp_s, "comb_bytes": 64 << 20,
+                               "combs_equal_host_builder": [bool(sbv.ed_hot_selfcheck(i)) for i in (0, max(0, promoted - 1))] if promoted else []}
+        else:
+            out["hot_keys"] = {"error": "no room for the pool"}
+    except Exception as e:      # noqa: BLE001
+        out["hot_keys"] = {"error": repr(e)}
     finally:
+        try:
+            sbv.ed_hot_keys(1024, 4096)     # the library's default
+        except Exception:      # noqa: BLE001  (a library build without the entry: tools/ab_lib.sh against an older one)
+            pass
         sbv.key_cache(True, 0, sbv.SCHEME_ED25519)    # the library's default
     return out
 

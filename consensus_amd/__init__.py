@@ -571,5 +571,30 @@ def hot_selfcheck(index: int) -> bool:
     return rc == 1
 
 
+def ed_hot_keys(max_keys: int = 1024, min_hits: int = 0) -> None:
+    """sbv_ed25519_hot_keys: 16-bit combs of -A for hot cache slots of the Ed25519 variant (0 keys = off)."""
+    lib = load()
+    lib.sbv_ed25519_hot_keys.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    _check(lib.sbv_ed25519_hot_keys(max_keys, min_hits))
+
+
+def ed_hot_key_stats():
+    """(promoted keys, pool capacity, tuples of the last grouped Ed25519 batch served by the wide pass, min_hits)"""
+    out = (ctypes.c_uint32 * 4)()
+    lib = load()
+    lib.sbv_ed25519_hot_key_stats.argtypes = [ctypes.c_void_p]
+    _check(lib.sbv_ed25519_hot_key_stats(out))
+    return out[0], out[1], out[2], out[3]
+
+
+def ed_hot_selfcheck(index: int) -> bool:
+    lib = load()
+    lib.sbv_ed25519_hot_selfcheck.argtypes = [ctypes.c_uint32]
+    rc = lib.sbv_ed25519_hot_selfcheck(index)
+    if rc < 0:
+        _check(rc)
+    return rc == 1
+
+
 def bitmap_to_list(bm: bytes, n: int):
     return [bool((bm[i >> 3] >> (i & 7)) & 1) for i in range(n)]

@@ -289,20 +289,26 @@ SBV_HD const aniels* edcomb_entry(const edcomb& c, size_t index) {
     return reinterpret_cast<const aniels*>(reinterpret_cast<const uint8_t*>(c.tab) + index * c.pitch);
 }
 
+// hot keys (ed25519_group.h): the 16-bit comb of -A of a promoted cache slot
+#define SBV_ED_HOT_BITS 16
+#define SBV_ED_HOT_WINDOWS 16
+#define SBV_ED_HOT_PER_WINDOW 32768u
+#define SBV_ED_HOT_PITCH 128u
+#define SBV_ED_HOT_COMB_BYTES ((size_t)SBV_ED_HOT_WINDOWS * SBV_ED_HOT_PER_WINDOW * SBV_ED_HOT_PITCH)      // 64 MiB
+#define SBV_ED_HOT_LANE_ENTRIES 32
+#define SBV_ED_HOT_PARTS (SBV_ED_HOT_PER_WINDOW / SBV_ED_HOT_LANE_ENTRIES)                                 // 1024 lanes per window
+#define SBV_ED_HOT_TMP_WORDS (SBV_ED_HOT_LANE_ENTRIES * 40)                                                 // per resident lane (SBV_ED_WINDOW_TMP_WORDS each)
+#define SBV_ED_HOT_BUILD_BLOCKS 2048u                                                                      // the builder's grid: 64 lanes each, 8 wavefronts per CU
+
 // ---- base-point comb (host, once per init; also tests/emul) --------------------------------------------
 // window j of a `bits`-wide comb of B: out_row[k - 1] = k * 2^(bits j) * B for k = 1 .. 2^(bits-1), canonical affine-Niels entries.
 // Callable from several host threads; the row is produced in blocks of 32 768 entries (one inversion each) so that a 20-bit window
 // (524 288 entries) needs no more host memory than a 16-bit one.
-inline void build_ed_b_window(int bits, int j, aniels* out_row) {
-    const u32 bxw[8] = {0x8F25D51Au, 0xC9562D60u, 0x9525A7B2u, 0x692CC760u, 0xFDD6DC5Cu, 0xC0A4E231u, 0xCD6E53FEu, 0x216936D3u};
-    const u32 byw[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};
-    fe25 bx, by;
-    fe25_from_words(bx, bxw); fe25_carry(bx, bx);
-    fe25_from_words(by, byw); fe25_carry(by, by);
+// (build_ed_window_of: the same row for any point P — the host reference of the hot keys' combs of -A, ed25519_group.h)
+inline void build_ed_window_of(const ept& P, int bits, int j, aniels* out_row) {
     const fe25 d2 = fe25_2d();
-    ept base;
-    base.X = bx; base.Y = by; base.Z = fe25_one(); fe25_mul(base.T, bx, by);
-    for (int i = 0; i < bits * j; ++i) ed_dbl(base, base);          // 2^(bits j) * B, projective
+    ept base = P;
+    for (int i = 0; i < bits * j; ++i) ed_dbl(base, base);          // 2^(bits j) * P, projective
     pniels bn;
     ed_to_pniels(bn, base);
     const size_t total = (size_t)1 << (bits - 1);
@@ -334,6 +340,16 @@ inline void build_ed_b_window(int bits, int j, aniels* out_row) {
         }
     }
     delete[] X; delete[] Y; delete[] Z; delete[] pre;
+}
+inline void build_ed_b_window(int bits, int j, aniels* out_row) {
+    const u32 bxw[8] = {0x8F25D51Au, 0xC9562D60u, 0x9525A7B2u, 0x692CC760u, 0xFDD6DC5Cu, 0xC0A4E231u, 0xCD6E53FEu, 0x216936D3u};
+    const u32 byw[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};
+    fe25 bx, by;
+    fe25_from_words(bx, bxw); fe25_carry(bx, bx);
+    fe25_from_words(by, byw); fe25_carry(by, by);
+    ept base;
+    base.X = bx; base.Y = by; base.Z = fe25_one(); fe25_mul(base.T, bx, by);
+    build_ed_window_of(base, bits, j, out_row);
 }
 inline void build_ed_b16_window(int j, aniels* out_row) { build_ed_b_window(16, j, out_row); }
 

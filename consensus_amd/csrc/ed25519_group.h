@@ -254,14 +254,7 @@ SBV_HD void ed_keytab_window_lane(const u32* jbase, int part, int parts, u32* tm
 // eviction with hysteresis — is the P-256 step's (p256_group.h: group_hot_class_lane, group_promote_select_lane, hot_evict_*), on this
 // scheme's own arrays.  The builder needs no doubling chain: B_j = 2^(16 j) (-A) is entry 1 of row 2 j of the slot's 8-bit comb, an
 // affine-Niels point, i.e. a projective-Niels point with Z = 1; lane (j, part) walks to (32 part) B_j and emits 32 multiples.
-#define SBV_ED_HOT_BITS 16
-#define SBV_ED_HOT_WINDOWS 16
-#define SBV_ED_HOT_PER_WINDOW 32768u
-#define SBV_ED_HOT_PITCH 128u
-#define SBV_ED_HOT_COMB_BYTES ((size_t)SBV_ED_HOT_WINDOWS * SBV_ED_HOT_PER_WINDOW * SBV_ED_HOT_PITCH)      // 64 MiB
-#define SBV_ED_HOT_LANE_ENTRIES 32
-#define SBV_ED_HOT_PARTS (SBV_ED_HOT_PER_WINDOW / SBV_ED_HOT_LANE_ENTRIES)                                 // 1024 lanes per window
-#define SBV_ED_HOT_TMP_WORDS (SBV_ED_HOT_LANE_ENTRIES * SBV_ED_WINDOW_TMP_WORDS)                            // per resident lane
+// (the constants: ed25519_core.h, where the host side sees them too)
 // key_tab: the promoted slot's 8-bit comb; comb: its wide comb (SBV_ED_HOT_COMB_BYTES)
 SBV_HD void ed_widetab_lane(const aniels* key_tab, u32 j, u32 part, u32* tmp, uint8_t* comb) {
     raw_aniels e;

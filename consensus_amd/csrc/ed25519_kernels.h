@@ -18,6 +18,17 @@ struct EdGroupBuffers {
     KeyCache kc = {};             // keyed by the 32 key bytes (padded to the cache's 16 words)
     size_t cap = 0;
     u32 max_groups = 0;
+    // hot keys of this scheme (ed25519_group.h, round 6): 16-bit combs of -A for promoted cache slots and the bookkeeping the P-256
+    // step keeps in GroupBuffers (same meaning, same kernels: group_kernels_common.h); wtab == nullptr = off
+    uint8_t* wtab = nullptr;      // [wide_cap] combs of SBV_ED_HOT_COMB_BYTES (16 x 32 768 entries at a 128-byte pitch)
+    u32 *kwide = nullptr, *khits = nullptr;     // [kc.cap]
+    u32* hot = nullptr;           // [4] combs handed out | promotions of this batch | lanes of the wide pass | eviction candidates
+    u32* plist = nullptr;         // [2 x SBV_PROMOTE_MAX] (slot, comb)
+    u32* wowner = nullptr;        // [wide_cap]
+    u32* elist = nullptr;         // [SBV_PROMOTE_MAX]
+    u32* ptmp = nullptr;          // the builder's scratch: SBV_ED_HOT_TMP_WORDS per resident lane
+    uint8_t* wide = nullptr;      // [max_groups] this batch's groups whose slot owns a comb
+    u32 wide_cap = 0, promote_min = 4096, hot_tick = 0;
 };
 // Grouped step (ed25519_group.h).  `b` supplies the grouping arrays, jbases, tmp, acc and gacc (32 words per
 // tuple, stride b.gacc_cap); ev_fork of `y` must have been recorded on `stream` before the call.

@@ -93,6 +93,7 @@ struct Context {
     int group_sample_shift = SBV_GROUP_SAMPLE_SHIFT_DEFAULT;     // SBV_GROUP_SAMPLE_SHIFT (0..6): the P-256 default threshold's sampling rate
     // hot keys (p256_group.h): wide combs for cache slots that keep being hit — how many (0 = off; 35.7 MB each) and from how many tuples on
     u32 hot_keys = 1024, hot_min_hits = 4096;
+    u32 ed_hot_keys = 1024, ed_hot_min_hits = 4096;
     bool pools_shrunk = false;          // fit_group_pools() gave this device smaller pools than asked for (sbv_p256_pool_stats)
     unsigned group_nomem_events = 0;    // how often a grouped batch fell back to the one-lane kernel for lack of memory (sbv_p256_pool_stats)
     unsigned group_nomem_skip = 0;      // grouped batches to run ungrouped before the pools are tried again (after an SBV_ENOMEM)
@@ -156,6 +157,7 @@ struct Settings {
     int profiling = 0;
     int wide_bits = SBV_WIDE_BITS_AUTO; u32 wide_max = 64;          // sbv_p256_wide_keys; env SBV_KEYED_WIDE_BITS (0 = off, 1 = auto), SBV_KEYED_WIDE_MAX
     u32 hot_keys = 1024, hot_min_hits = 4096;                       // sbv_p256_hot_keys; env SBV_HOT_KEYS (0 = off), SBV_HOT_MIN_HITS
+    u32 ed_hot_keys = 1024, ed_hot_min_hits = 4096;                 // sbv_ed25519_hot_keys; env SBV_ED_HOT_KEYS (0 = off), SBV_ED_HOT_MIN_HITS
 } g_settings;
 std::mutex g_set_mu;
 std::unique_ptr<Context> g_ctxs[kMaxDevices];
@@ -334,6 +336,22 @@ hipError_t hot_forget(sbv::GroupBuffers& b) {
     return e;
 }
 
+// the same for the Ed25519 scheme's pool (ed25519_group.h: hot keys)
+hipError_t ed_hot_forget(sbv::EdGroupBuffers& e) {
+    if (!e.kwide) return hipSuccess;
+    hipError_t r = memset_now(e.kwide, 0xFF, (size_t)e.kc.cap * sizeof(u32));
+    if (r == hipSuccess) r = memset_now(e.khits, 0, (size_t)e.kc.cap * sizeof(u32));
+    if (r == hipSuccess) r = memset_now(e.hot, 0, 4 * sizeof(u32));
+    if (r == hipSuccess) r = memset_now(e.wowner, 0xFF, (size_t)e.wide_cap * sizeof(u32));
+    return r;
+}
+void ed_hot_free(sbv::EdGroupBuffers& e) {
+    void* part[] = {e.wtab, e.kwide, e.khits, e.hot, e.plist, e.wowner, e.elist, e.ptmp, e.wide};
+    for (void* q : part) if (q) (void)hipFree(q);
+    e.wtab = nullptr; e.kwide = nullptr; e.khits = nullptr; e.hot = nullptr; e.plist = nullptr; e.wowner = nullptr; e.elist = nullptr;
+    e.ptmp = nullptr; e.wide = nullptr; e.wide_cap = 0;
+}
+
 // keep_pools: the comb pools and key-table caches of the three schemes depend on (cache capacity, max_groups) only — a batch larger
 // than any before regrows the per-tuple arrays and must leave every cached comb where it is
 void free_group_buffers(Context& c, bool keep_pools = false) {
@@ -361,6 +379,7 @@ void free_group_buffers(Context& c, bool keep_pools = false) {
     if (c.edgrp.okb) (void)hipFree(c.edgrp.okb);
     if (c.edgrp.kvalid) (void)hipFree(c.edgrp.kvalid);
     key_cache_free(c.edgrp.kc);
+    ed_hot_free(c.edgrp);
     c.edgrp = sbv::EdGroupBuffers();
     if (c.k256pool.ktab) (void)hipFree(c.k256pool.ktab);
     if (c.k256pool.kvalid) (void)hipFree(c.k256pool.kvalid);
@@ -368,7 +387,7 @@ void free_group_buffers(Context& c, bool keep_pools = false) {
     c.k256pool = sbv::KeyPool();
 }
 
-bool wide_pool_fits(const Context& c, size_t extra_bytes);
+bool wide_pool_fits(const Context& c, size_t extra_bytes, unsigned percent = 15);
 // HBM that everything sized by (cache capacity K, groups per batch G) takes: the comb pool (270 KiB per slot), the compact rows
 // (33 KiB), the class bytes, and per group the builder's base records and chain state.
 size_t group_pool_bytes(size_t K, size_t G) {
@@ -525,6 +544,7 @@ int ensure_ed_group_buffers(Context& c, size_t n) {
     // (found on the GPU in round 4: the warm batch of the cache test was 384 tuples longer than the cold one and missed every key).
     const u32 vg = variant_groups(c);
     const bool pool_ok = e.ktab && e.max_groups == vg && e.kc.ht && e.kc.cap == K;
+    e.promote_min = c.ed_hot_min_hits;
     if (pool_ok && e.okb && e.cap >= c.grp.cap) {
         e.kc.enabled = c.kc_on[2] ? 1u : 0u;
         return SBV_OK;
@@ -536,6 +556,7 @@ int ensure_ed_group_buffers(Context& c, size_t n) {
         if (e.ktab) (void)hipFree(e.ktab);
         if (e.kvalid) (void)hipFree(e.kvalid);
         key_cache_free(e.kc);
+        ed_hot_free(e);
         e = sbv::EdGroupBuffers();
         // comb pool of this scheme: slots [0, K) = its persistent key-table cache, [K, K + max_groups) per batch
         HIP_TRY(SBV_ENOMEM, hipMalloc(&e.ktab, (K + vg) * (size_t)SBV_ED_KEYTAB_ENTRIES_PER_KEY * sizeof(sbv::aniels)));
@@ -543,8 +564,28 @@ int ensure_ed_group_buffers(Context& c, size_t n) {
         rc = key_cache_alloc(e.kc, K, c.kc_on[2]);
         if (rc != SBV_OK) return rc;
         e.max_groups = vg;
+        // hot keys of this scheme: an OPTIONAL pool of 64 MiB combs, as large as asked for if the device has the room (wide_pool_fits),
+        // smaller or absent otherwise — a failed allocation leaves the feature off, it never fails the batch; verdicts never depend on it
+        if (c.ed_hot_keys && K) {
+            size_t want = c.ed_hot_keys > 4096 ? 4096 : c.ed_hot_keys;
+            const size_t scratch = (size_t)SBV_ED_HOT_BUILD_BLOCKS * 64 * SBV_ED_HOT_TMP_WORDS * sizeof(u32);
+            while (want && !wide_pool_fits(c, want * SBV_ED_HOT_COMB_BYTES + scratch, 25)) want /= 2;       // an opt-in pool: 1024 combs are 64 GiB of the 288
+            if (want) {
+                const bool got = hipMalloc(&e.wtab, want * SBV_ED_HOT_COMB_BYTES) == hipSuccess && hipMalloc(&e.kwide, K * sizeof(u32)) == hipSuccess &&
+                                 hipMalloc(&e.khits, K * sizeof(u32)) == hipSuccess && hipMalloc(&e.hot, 4 * sizeof(u32)) == hipSuccess &&
+                                 hipMalloc(&e.plist, 2 * SBV_PROMOTE_MAX * sizeof(u32)) == hipSuccess && hipMalloc(&e.ptmp, scratch) == hipSuccess &&
+                                 hipMalloc(&e.wowner, want * sizeof(u32)) == hipSuccess && hipMalloc(&e.elist, SBV_PROMOTE_MAX * sizeof(u32)) == hipSuccess &&
+                                 hipMalloc(&e.wide, vg) == hipSuccess;
+                if (got) e.wide_cap = (u32)want;
+                if (!got || ed_hot_forget(e) != hipSuccess || memset_now(e.wide, 0, vg) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ed_hot_free(e);
+                }
+            }
+        }
     }
     HIP_TRY(SBV_ENOMEM, hipMalloc(&e.okb, c.grp.cap));
+    e.promote_min = c.ed_hot_min_hits;
     e.cap = c.grp.cap;
     e.kc.enabled = c.kc_on[2] ? 1u : 0u;
     return SBV_OK;
@@ -603,10 +644,12 @@ int enqueue_ed25519(Context& c, const uint8_t* d_tuples, size_t n, uint8_t* d_bi
     if (grouped && !group_buffers_or_fallback(c, n, [&] { const int r = ensure_ed_group_buffers(c, n); return r != SBV_OK ? r : ensure_ed_bcomb(c); }, grouped)) return g_last_rc;
     if (grouped) {
         HIP_TRY(SBV_EDEVICE, hipEventRecord(c.gsync.ev_fork, stream));
+        if (c.edgrp.wtab && c.edgrp.kc.enabled) ++c.edgrp.hot_tick;     // the clock of the hot keys' decay
         const hipError_t ge = sbv::launch_ed25519_verify_grouped(d_tuples, n, variant_view(c, n), c.edgrp, c.d_qtab, c.d_btab, sbv::edcomb_make(c.d_ed_bcomb, c.ed_bbits, c.ed_bpitch), d_bitmap, stream, c.gsync, dom, dom_pairs);
         if (ge != hipSuccess) {          // a slot is published before its tables are built (see enqueue()): forget the cache
             (void)hipDeviceSynchronize();
             (void)key_cache_forget(c.edgrp.kc);
+            (void)ed_hot_forget(c.edgrp);
             return fail(SBV_EDEVICE, "launch_ed25519_verify_grouped", ge);
         }
         return SBV_OK;
@@ -824,9 +867,12 @@ int init_context(Context& c, int device) {
         c.profiling = g_settings.profiling;
         c.kwide_auto = g_settings.wide_bits == SBV_WIDE_BITS_AUTO; c.kwide_bits = c.kwide_auto ? 20 : g_settings.wide_bits; c.kwide_max = g_settings.wide_max;
         c.hot_keys = g_settings.hot_keys; c.hot_min_hits = g_settings.hot_min_hits;
+        c.ed_hot_keys = g_settings.ed_hot_keys; c.ed_hot_min_hits = g_settings.ed_hot_min_hits;
     }
     if (const char* e = getenv("SBV_HOT_KEYS")) { const long v = atol(e); if (v >= 0 && v <= 4096) c.hot_keys = (u32)v; }
     if (const char* e = getenv("SBV_HOT_MIN_HITS")) { const long v = atol(e); if (v >= 1) c.hot_min_hits = (u32)v; }
+    if (const char* e = getenv("SBV_ED_HOT_KEYS")) { const long v = atol(e); if (v >= 0 && v <= 4096) c.ed_hot_keys = (u32)v; }
+    if (const char* e = getenv("SBV_ED_HOT_MIN_HITS")) { const long v = atol(e); if (v >= 1) c.ed_hot_min_hits = (u32)v; }
     if (const char* e = getenv("SBV_KEYED_WIDE_BITS")) { const int v = atoi(e); if (v == 0) c.kwide_max = 0; else if (v == SBV_WIDE_BITS_AUTO) c.kwide_auto = true; else if (v >= 10 && v <= 20) { c.kwide_bits = v; c.kwide_auto = false; } }
     if (const char* e = getenv("SBV_KEYED_WIDE_MAX")) { const long v = atol(e); if (v >= 0 && v <= 4096) c.kwide_max = (u32)v; }
     if (const char* e = getenv("SBV_GROUP_SAMPLE_SHIFT")) { const int v = atoi(e); if (v >= 0 && v <= 6) c.group_sample_shift = v; }
@@ -1205,11 +1251,11 @@ int drop_wide_keys(Context& c);
 // 16 bits and then to "no wide combs" instead of leaving later batches with SBV_ENOMEM.
 // With several contexts on one GPU (SBV_LOGICAL_DEVICES) a pool may also take no more than 15 % of the device divided by the contexts
 // that share it: 43 GB alone on a 288 GB part (the 1024-key hot pool is 36.5), 5.4 GB as one of eight.
-bool wide_pool_fits(const Context& c, size_t extra_bytes) {
+bool wide_pool_fits(const Context& c, size_t extra_bytes, unsigned percent) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return true;
     const size_t reserve = total_b / 4 < ((size_t)16 << 30) ? total_b / 4 : ((size_t)16 << 30);
-    size_t cap = total_b / 100 * 15 / (size_t)(c.mem_share > 0 ? c.mem_share : 1);
+    size_t cap = total_b / 100 * percent / (size_t)(c.mem_share > 0 ? c.mem_share : 1);
     if (const char* e = getenv("SBV_POOL_BUDGET_MB")) { const long v = atol(e); if (v > 0) cap = (size_t)v << 20; }
     return extra_bytes <= cap && free_b > extra_bytes && free_b - extra_bytes >= reserve;
 }
@@ -2145,6 +2191,7 @@ extern "C" int sbv_key_cache(int scheme, int enabled, uint32_t capacity) {
             kc.enabled = c.kc_on[scheme] ? 1u : 0u;
             if (e == hipSuccess && !c.kc_on[scheme]) e = key_cache_forget(kc);   // switching it off forgets everything: the next "on" starts cold
             if (e == hipSuccess && !c.kc_on[scheme] && scheme == SBV_SCHEME_P256) e = hot_forget(c.grp);
+            if (e == hipSuccess && !c.kc_on[scheme] && scheme == SBV_SCHEME_ED25519) e = ed_hot_forget(c.edgrp);
             if (e != hipSuccess) rc = fail(SBV_EDEVICE, "sbv_key_cache", e);
         }
     }
@@ -2255,6 +2302,87 @@ extern "C" int sbv_p256_hot_key_stats(uint32_t out[4]) {
     out[0] = h[0] < c.grp.wide_cap ? h[0] : c.grp.wide_cap;
     out[2] = h[2];
     return SBV_OK;
+}
+
+// Hot keys of the Ed25519 scheme (ed25519_group.h): the pool of 16-bit combs of -A
+extern "C" int sbv_ed25519_hot_keys(uint32_t max_keys, uint32_t min_hits) {
+    if (max_keys > 4096) return SBV_EINVAL;
+    {
+        std::lock_guard<std::mutex> lk(g_set_mu);
+        g_settings.ed_hot_keys = max_keys;
+        if (min_hits) g_settings.ed_hot_min_hits = min_hits;
+    }
+    int rc = SBV_OK;
+    for (Context* cp : live_contexts()) {
+        std::lock_guard<std::mutex> lk(cp->mu);
+        Context& c = *cp;
+        if (min_hits) c.ed_hot_min_hits = min_hits;
+        if (c.ed_hot_keys == max_keys) continue;
+        c.ed_hot_keys = max_keys;
+        if (!c.ready || !c.edgrp.ktab) continue;
+        // another pool size: this scheme's comb pool (with its cache) is rebuilt by the next grouped batch
+        hipError_t e = hipSetDevice(c.hip_dev);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { rc = fail(SBV_EDEVICE, "sbv_ed25519_hot_keys", e); continue; }
+        sbv::EdGroupBuffers& eb = c.edgrp;
+        if (eb.ktab) (void)hipFree(eb.ktab);
+        if (eb.okb) (void)hipFree(eb.okb);
+        if (eb.kvalid) (void)hipFree(eb.kvalid);
+        key_cache_free(eb.kc);
+        ed_hot_free(eb);
+        eb = sbv::EdGroupBuffers();
+    }
+    return rc;
+}
+
+extern "C" int sbv_ed25519_hot_key_stats(uint32_t out[4]) {
+    SBV_ENTER(c);
+    if (!c.ready) return SBV_ENOTINIT;
+    if (!out) return SBV_EINVAL;
+    out[0] = out[2] = 0;
+    out[1] = c.edgrp.wide_cap;
+    out[3] = c.ed_hot_min_hits;
+    if (!c.edgrp.hot) return SBV_OK;
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.hip_dev));
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    uint32_t h[4];
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(h, c.edgrp.hot, sizeof h, hipMemcpyDeviceToHost));
+    out[0] = h[0] < c.edgrp.wide_cap ? h[0] : c.edgrp.wide_cap;
+    out[2] = h[2];
+    return SBV_OK;
+}
+
+// 1 = promoted comb `index` equals the host builder's comb of -A for its key, entry by entry (canonical affine-Niels entries)
+extern "C" int sbv_ed25519_hot_selfcheck(uint32_t index) {
+    SBV_ENTER(c);
+    if (!c.ready) { g_err = "sbv_init has not succeeded"; return SBV_ENOTINIT; }
+    sbv::EdGroupBuffers& b = c.edgrp;
+    if (!b.wtab || !b.kwide || index >= b.wide_cap) { g_err = "no such comb in the Ed25519 hot-key pool"; return SBV_EINVAL; }
+    HIP_TRY(SBV_EDEVICE, hipSetDevice(c.hip_dev));
+    HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
+    std::vector<u32> kw(b.kc.cap);
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(kw.data(), b.kwide, kw.size() * sizeof(u32), hipMemcpyDeviceToHost));
+    size_t slot = kw.size();
+    for (size_t i = 0; i < kw.size(); ++i) if (kw[i] == index) slot = i;
+    if (slot == kw.size()) { g_err = "sbv_ed25519_hot_selfcheck: no promoted key has this index"; return SBV_EINVAL; }
+    u32 key[8];
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(key, b.kc.keys + slot * 16, 32, hipMemcpyDeviceToHost));
+    sbv::ept A;
+    if (!sbv::ed_decompress(A, key)) return 0;                          // only valid keys are promoted
+    sbv::fe25_neg(A.X, A.X);
+    sbv::fe25_neg(A.T, A.T);
+    std::vector<sbv::aniels> want((size_t)SBV_ED_HOT_WINDOWS * SBV_ED_HOT_PER_WINDOW);
+    {
+        std::vector<std::thread> th;
+        for (int j = 0; j < SBV_ED_HOT_WINDOWS; ++j)
+            th.emplace_back([&, j] { sbv::build_ed_window_of(A, SBV_ED_HOT_BITS, j, want.data() + (size_t)j * SBV_ED_HOT_PER_WINDOW); });
+        for (auto& t : th) t.join();
+    }
+    std::vector<uint8_t> got(SBV_ED_HOT_COMB_BYTES);
+    HIP_TRY(SBV_EDEVICE, hipMemcpy(got.data(), b.wtab + (size_t)index * SBV_ED_HOT_COMB_BYTES, got.size(), hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < want.size(); ++e)
+        if (memcmp(got.data() + e * SBV_ED_HOT_PITCH, &want[e], sizeof(sbv::aniels)) != 0) return 0;
+    return 1;
 }
 
 // Diagnostics (round 6): every promoted comb of context `device` against the host builder, and the consistency of kwide / wowner.

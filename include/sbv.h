@@ -276,6 +276,17 @@ int sbv_debug_hot_check(int device, uint32_t out[8]);
 int sbv_p256_hot_keys(uint32_t max_keys, uint32_t min_hits);
 int sbv_p256_hot_key_stats(uint32_t out[4]);
 int sbv_p256_hot_selfcheck(uint32_t index);
+/* The same for the Ed25519 variant (round 6): a cache slot of that scheme whose count passes `min_hits` gets a 16-bit comb of -A
+ * (16 windows x 32 768 affine-Niels entries at a 128-byte pitch = 64 MiB), built on the device from base points the slot's 8-bit comb
+ * holds; later batches add [k](-A) for its tuples in 16 additions instead of 32, in one launch that needs no table of the batch.  Same
+ * bookkeeping as above (counts per slot, decay, eviction with hysteresis).  Default: up to 1024 keys (64 GiB of the 288; fewer if the
+ * device lacks the room) from 4096 hits on; max_keys = 0 switches it off; env SBV_ED_HOT_KEYS, SBV_ED_HOT_MIN_HITS.  A comb costs
+ * about 80 us of device time to build, behind a batch's verdicts, and saves about 0.5 ns per tuple verified from it afterwards: it
+ * pays for signers that stay (consenters), which is what the decaying count selects.  Verdicts never depend on it.  stats /
+ * selfcheck as for P-256. */
+int sbv_ed25519_hot_keys(uint32_t max_keys, uint32_t min_hits);
+int sbv_ed25519_hot_key_stats(uint32_t out[4]);
+int sbv_ed25519_hot_selfcheck(uint32_t index);
 
 /* Page-locked host memory for the host-pointer entries.  Handing pageable memory to a 100 MB batch makes the HIP
  * runtime pin (or bounce) it inside the call — measured at 25 ms for a 550 000-signature replay batch whose kernels

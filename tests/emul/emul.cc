@@ -879,6 +879,56 @@ void sbve_ed25519_verify_batch(const uint8_t* tuples, size_t n, uint8_t* bitmap)
         if (ed25519_verify_lane(EdWords{tuples + 128 * i}, qtab, btab())) bitmap[i >> 3] |= (uint8_t)(1u << (i & 7));
     free(qtab);
 }
+// hot keys of the Ed25519 scheme (ed25519_group.h; EdGroupBuffers' pool): the library's state, emulated
+static uint8_t* g_ed_hot_wtab = nullptr;
+static std::vector<u32> g_ed_hot_kwide, g_ed_hot_khits, g_ed_hot_wowner;
+static u32 g_ed_hot[4] = {0, 0, 0, 0};
+static u32 g_ed_hot_cap = 0, g_ed_hot_min = 4096, g_ed_hot_tick = 0, g_ed_hot_evictions = 0;
+void sbve_ed_hot_keys(u32 cap, u32 min_hits) {       // after sbve_scheme_key_cache(2, ...): a new cache forgets the promotions, like the library
+    free(g_ed_hot_wtab);
+    g_ed_hot_wtab = nullptr;
+    g_ed_hot_cap = cap;
+    if (min_hits) g_ed_hot_min = min_hits;
+    if (cap) {
+        g_ed_hot_wtab = (uint8_t*)aligned_alloc(128, (size_t)cap * SBV_ED_HOT_COMB_BYTES);
+        memset(g_ed_hot_wtab, 0xA5, (size_t)cap * SBV_ED_HOT_COMB_BYTES);
+    }
+    const u32 K = g_kc_ed.kc.cap ? g_kc_ed.kc.cap : 1;
+    g_ed_hot_kwide.assign(K, SBV_WIDE_NONE); g_ed_hot_khits.assign(K, 0); g_ed_hot_wowner.assign(cap ? cap : 1, SBV_WIDE_NONE);
+    memset(g_ed_hot, 0, sizeof g_ed_hot);
+    g_ed_hot_tick = 0; g_ed_hot_evictions = 0;
+}
+// out[0] = promoted keys, [1] = pool capacity, [2] = tuples the wide pass served in the last batch, [3] = min_hits, [4] = evictions so far, [5] = the decay's clock
+void sbve_ed_hot_stats(u32 out[6]) {
+    out[0] = g_ed_hot[0] < g_ed_hot_cap ? g_ed_hot[0] : g_ed_hot_cap; out[1] = g_ed_hot_cap; out[2] = g_ed_hot[2]; out[3] = g_ed_hot_min;
+    out[4] = g_ed_hot_evictions; out[5] = g_ed_hot_tick;
+}
+static size_t ed_hot_slot_of_key(const uint8_t* key32) {
+    for (size_t sl = 0; sl < g_kc_ed.kc.cap; ++sl)
+        if (memcmp(&g_kc_ed.keys[sl * 16], key32, 32) == 0) return sl;
+    return (size_t)-1;
+}
+u32 sbve_ed_hot_hits_of_key(const uint8_t* key32) { const size_t sl = ed_hot_slot_of_key(key32); return sl == (size_t)-1 || sl >= g_ed_hot_khits.size() ? 0xFFFFFFFFu : g_ed_hot_khits[sl]; }
+u32 sbve_ed_hot_wide_of_key(const uint8_t* key32) { const size_t sl = ed_hot_slot_of_key(key32); return sl == (size_t)-1 || sl >= g_ed_hot_kwide.size() ? 0xFFFFFFFEu : g_ed_hot_kwide[sl]; }
+// promoted comb `index` against the host builder of combs (ed25519_core.h: build_ed_window_of) on -A, as sbv_ed25519_hot_selfcheck
+// compares: the number of differing entries, or (size_t)-1 if nobody owns the index
+size_t sbve_ed_hot_comb_mismatches(u32 index) {
+    size_t slot = g_ed_hot_kwide.size();
+    for (size_t i = 0; i < g_ed_hot_kwide.size(); ++i) if (g_ed_hot_kwide[i] == index) slot = i;
+    if (slot == g_ed_hot_kwide.size() || !g_ed_hot_wtab) return (size_t)-1;
+    ept A;
+    if (!ed_decompress(A, &g_kc_ed.keys[slot * 16])) return (size_t)-2;
+    fe25_neg(A.X, A.X);
+    fe25_neg(A.T, A.T);
+    std::vector<aniels> want((size_t)SBV_ED_HOT_WINDOWS * SBV_ED_HOT_PER_WINDOW);
+    std::vector<std::thread> th;
+    for (int j = 0; j < SBV_ED_HOT_WINDOWS; ++j) th.emplace_back([&, j] { build_ed_window_of(A, SBV_ED_HOT_BITS, j, want.data() + (size_t)j * SBV_ED_HOT_PER_WINDOW); });
+    for (auto& t : th) t.join();
+    const uint8_t* comb = g_ed_hot_wtab + (size_t)index * SBV_ED_HOT_COMB_BYTES;
+    size_t bad = 0;
+    for (size_t e = 0; e < want.size(); ++e) if (memcmp(comb + e * SBV_ED_HOT_PITCH, &want[e], sizeof(aniels)) != 0) ++bad;
+    return bad;
+}
 // grouped form (ed25519_group.h), emulated sequentially with the device pipeline's chunking.
 // stats_out[0..3] = groups, grouped tuples, ungrouped tuples, ungrouped tuples rejected for their key.
 void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8_t* bitmap, u32 min_count, u32 max_groups,
@@ -931,6 +981,29 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     auto table_of = [&](u32 k) -> aniels* { return tslot[k] < kc.cap ? (aniels*)g_kc_ed.pool + (size_t)tslot[k] * SBV_ED_KEYTAB_ENTRIES : ktab + (size_t)k * SBV_ED_KEYTAB_ENTRIES; };
     auto valid_of = [&](u32 k) -> uint8_t* { return tslot[k] < kc.cap ? &g_kc_ed.valid[tslot[k]] : &kvalid[k]; };
     memset(bitmap, 0, (n + 7) / 8);
+    // hot keys (k_ed_hot_class; the wavefronts of the wide pass: ed_wave_is_wide) — with the cache on, a pool and the key-sorted list
+    const bool hot_on = g_ed_hot_cap && g_ed_hot_wtab && kc.enabled && g.sorted && g_ed_hot_kwide.size() >= kc.cap;
+    std::vector<uint8_t> wide(ng1, 0), wave_wide((counters[1] + 63) / 64 + 1, 0);
+    if (hot_on) {
+        ++g_ed_hot_tick;
+        g_ed_hot[1] = g_ed_hot[2] = g_ed_hot[3] = 0;
+        for (u32 k = 0; k < ngroups; ++k) group_hot_class_lane(k, g, tslot.data(), cold.data(), kc.cap, g_ed_hot_kwide.data(), g_ed_hot_khits.data(), wide.data());
+        for (u32 w = 0; w * 64 < counters[1]; ++w) {
+            bool all = true;
+            for (u32 L = w * 64; L < counters[1] && L < (w + 1) * 64; ++L) all = all && grp_of[L] < ngroups && wide[grp_of[L]] != 0;
+            wave_wide[w] = all ? 1 : 0;
+        }
+        // k_ed_qphase_wide: [k](-A) from the slot's 16-bit comb, before any table of this batch exists
+        for (u32 L = 0; L < counters[1]; ++L) {
+            if (!wave_wide[L / 64]) continue;
+            ++g_ed_hot[2];
+            const u32 t = grp_idx[L];
+            const u32 grp = grp_of[L];
+            const u32 slot = tslot[grp];
+            const bool v = ed_qphase_wide_lane(tuples, t, g_kc_ed.valid[slot] != 0, g_ed_hot_wtab + (size_t)g_ed_hot_kwide[slot] * SBV_ED_HOT_COMB_BYTES, gacc, okb.data());
+            accb[t] = v ? SBV_ED_PENDING : 0;
+        }
+    }
     for (int c = 0; c < chunks; ++c) {
         const int j_first = SBV_ED_KEY_WINDOWS * c / chunks, j_end = SBV_ED_KEY_WINDOWS * (c + 1) / chunks;
         for (u32 k = 0; k < ngroups; ++k)
@@ -955,12 +1028,54 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
                 }
         const bool last = c + 1 == chunks;
         for (u32 L = 0; L < counters[1]; ++L) {
+            if (wave_wide[L / 64]) continue;                             // the wide pass's wavefront
             const u32 t = grp_idx[L];
             const u32 grp = g.sorted ? grp_of[L] : slots[t];
             const bool v = grp < ngroups ? ed_qphase_lane(tuples, t, 0, 1, table_of(grp), valid_of(grp), gacc, cap, okb.data(), j_first, j_end, last, tm)
                                          : ed_qphase_lane(tuples, t, SBV_GROUP_NONE, 1, ktab, kvalid.data(), gacc, cap, okb.data(), j_first, j_end, last, tm);
             if (last) accb[t] = v ? SBV_ED_PENDING : 0;
         }
+    }
+    if (hot_on) {
+        // the tail: k_hot_decay, k_promote_select, k_promote_evict (the functions of p256_group.h on this scheme's arrays, groups visited
+        // backwards: the order is free), k_ed_promote_window, k_promote_publish
+        if (g_ed_hot_tick % SBV_HOT_DECAY_EVERY == SBV_HOT_DECAY_EVERY - 1) for (u32 sl = 0; sl < kc.cap; ++sl) hot_decay_lane(sl, g_ed_hot_khits.data());
+        std::vector<u32> plist(2 * SBV_PROMOTE_MAX, 0xDEADBEEFu), elist(SBV_PROMOTE_MAX, 0xDEADBEEFu);
+        for (u32 k = ngroups; k-- > 0;)
+            group_promote_select_lane(k, tslot.data(), g_kc_ed.valid.data(), kc.cap, g_ed_hot_kwide.data(), g_ed_hot_khits.data(), g_ed_hot_min, g_ed_hot_cap, g_ed_hot,
+                                      plist.data(), elist.data());
+        {
+            const u32 ncand = g_ed_hot[3] < SBV_PROMOTE_MAX ? g_ed_hot[3] : SBV_PROMOTE_MAX;
+            u32 entries = g_ed_hot[1] < SBV_PROMOTE_MAX ? g_ed_hot[1] : SBV_PROMOTE_MAX;
+            std::vector<u32> taken((g_ed_hot_cap + 31) / 32 + 1, 0);
+            for (u32 c = 0; c < ncand; ++c) {
+                u32 bh = 0xFFFFFFFFu, bw = 0xFFFFFFFFu;
+                for (u32 lane = 0; lane < 3; ++lane) {
+                    u32 h, w;
+                    hot_evict_scan(g_ed_hot_khits.data(), g_ed_hot_wowner.data(), taken.data(), g_ed_hot_cap, kc.cap, lane, 3u, h, w);
+                    if (hot_evict_better(h, w, bh, bw)) { bh = h; bw = w; }
+                }
+                const u32 before = entries;
+                entries = hot_evict_commit(elist[c], bh, bw, g_ed_hot_khits.data(), g_ed_hot_kwide.data(), g_ed_hot_wowner.data(), taken.data(), entries, plist.data());
+                g_ed_hot_evictions += entries - before;
+            }
+            if (ncand) g_ed_hot[1] = entries;
+        }
+        const u32 live = g_ed_hot[1] < SBV_PROMOTE_MAX ? g_ed_hot[1] : SBV_PROMOTE_MAX;
+        for (u32 i = 0; i < live; ++i) {
+            if (plist[2 * i] == 0xFFFFFFFFu) continue;
+            const aniels* key_tab = (const aniels*)g_kc_ed.pool + (size_t)plist[2 * i] * SBV_ED_KEYTAB_ENTRIES;
+            uint8_t* comb = g_ed_hot_wtab + (size_t)plist[2 * i + 1] * SBV_ED_HOT_COMB_BYTES;
+            std::vector<std::thread> th;                                 // lanes are independent: one host thread per window
+            for (u32 j = 0; j < SBV_ED_HOT_WINDOWS; ++j)
+                th.emplace_back([=] {
+                    std::vector<u32> tmpj(SBV_ED_HOT_TMP_WORDS);
+                    for (u32 part = SBV_ED_HOT_PARTS; part-- > 0;) ed_widetab_lane(key_tab, j, part, tmpj.data(), comb);
+                });
+            for (auto& t : th) t.join();
+        }
+        for (u32 i = 0; i < live; ++i)
+            if (plist[2 * i] != 0xFFFFFFFFu) { g_ed_hot_kwide[plist[2 * i]] = plist[2 * i + 1]; g_ed_hot_wowner[plist[2 * i + 1]] = plist[2 * i]; }
     }
     // k_ed_finish: the pending tuples' encodings, one inversion per SBV_ED_FINISH_T consecutive tuples
     for (u32 L = 0; L < counters[2]; ++L) accb[ung_idx[L]] = 0;         // the ungrouped list's verdicts come from the one-lane kernel below

@@ -257,6 +257,100 @@ def test_persistent_key_table_cache_of_this_scheme_never_changes_verdicts(emul, 
         emul.sbve_scheme_key_cache(2, 0, 0)
 
 
+def test_hot_keys_of_this_scheme_never_change_verdicts(emul, oracle, ed_vectors):
+    """ed25519_group.h "hot keys" (round 6): a cache slot whose count passes the threshold gets a 16-bit comb of -A, built
+    lane by lane (ed_widetab_lane) from base points its 8-bit comb holds; later batches serve the wavefronts whose lanes are all
+    hot from it (ed_qphase_wide_lane).  Every promoted comb equals the host builder's entry by entry; verdicts equal the one-lane
+    kernel's and the generator's before, during and after promotion, also for the golden vectors' odd keys (non-canonical
+    encodings, points of small order — whose multiples pass through the identity); a full pool hands a comb to a hotter key
+    (the P-256 step's eviction rule on this scheme's arrays); switching the pool off leaves the verdicts where they were."""
+    emul.sbve_ed25519_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32,
+                                                       ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    emul.sbve_scheme_key_cache.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+    emul.sbve_ed_hot_keys.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    emul.sbve_ed_hot_stats.argtypes = [ctypes.c_void_p]
+    emul.sbve_ed_hot_comb_mismatches.argtypes = [ctypes.c_uint32]
+    emul.sbve_ed_hot_comb_mismatches.restype = ctypes.c_size_t
+    emul.sbve_ed_hot_wide_of_key.argtypes = [ctypes.c_char_p]
+    emul.sbve_ed_hot_wide_of_key.restype = ctypes.c_uint32
+    emul.sbve_ed_hot_hits_of_key.argtypes = [ctypes.c_char_p]
+    emul.sbve_ed_hot_hits_of_key.restype = ctypes.c_uint32
+    oracle.sbvo_ed25519_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int]
+    NONE = 0xFFFFFFFF
+    hs = (ctypes.c_uint32 * 6)()
+
+    def batch(seed, m, nkeys):
+        tup = ctypes.create_string_buffer(128 * m)
+        exp = ctypes.create_string_buffer((m + 7) // 8)
+        oracle.sbvo_ed25519_gen_batch(seed, m, nkeys, 5, tup, exp, 4)
+        return tup.raw, _bits(exp.raw, m)
+
+    def keys_of(blob):                                     # the signers (a corrupted key is a key of its own, seen once)
+        seen = {}
+        for i in range(len(blob) // 128):
+            seen[blob[128 * i + 64:128 * i + 96]] = seen.get(blob[128 * i + 64:128 * i + 96], 0) + 1
+        return sorted(k for k, c in seen.items() if c >= 8)
+
+    def run(blob, want, chunks=2, plain_check=False):
+        total = len(blob) // 128
+        if plain_check:
+            plain = ctypes.create_string_buffer((total + 7) // 8)
+            emul.sbve_ed25519_verify_batch(blob, ctypes.c_size_t(total), plain)
+            assert _bits(plain.raw, total) == want
+        bm = ctypes.create_string_buffer((total + 7) // 8)
+        emul.sbve_ed25519_verify_batch_grouped(blob, total, bm, 8, 64, 12, chunks, 4, None)
+        got = _bits(bm.raw, total)
+        assert got == want, [i for i in range(total) if got[i] != want[i]][:8]
+        emul.sbve_ed_hot_stats(hs)
+        return list(hs)
+
+    try:
+        emul.sbve_scheme_key_cache(2, 1, 16)
+        emul.sbve_ed_hot_keys(2, 250)                     # a pool of two combs, promotion from 250 grouped tuples on
+        a, wa = batch(0xA7, 900, 3)                       # three keys, 300 tuples each, every 5th corrupted
+        ka = keys_of(a)
+        assert len(ka) == 3
+        st = run(a, wa, plain_check=True)                 # cold: all three pass the threshold, two combs exist
+        assert st[0] == 2 and st[2] == 0 and st[4] == 0, st
+        assert emul.sbve_ed_hot_comb_mismatches(0) == 0 and emul.sbve_ed_hot_comb_mismatches(1) == 0
+        assert emul.sbve_ed_hot_comb_mismatches(2) == ctypes.c_size_t(-1).value
+        owners = [k for k in ka if emul.sbve_ed_hot_wide_of_key(k) != NONE]
+        assert len(owners) == 2
+        b, wb = batch(0xA7, 960, 3)
+        st = run(b, wb, chunks=4, plain_check=True)       # warm: the two owners' wavefronts take the wide pass
+        assert 256 <= st[2] <= 640 and st[0] == 2 and st[4] == 0, st      # a similar key never takes a comb away (hysteresis)
+        # the third key alone, hot: twice its rivals' count is enough for the comb of the colder owner
+        loser = next(k for k in ka if k not in owners)
+        only = b"".join(b[128 * i:128 * i + 128] for i in range(960) if b[128 * i + 64:128 * i + 96] == loser)
+        wonly = [wb[i] for i in range(960) if b[128 * i + 64:128 * i + 96] == loser]
+        for _ in range(3):
+            st = run(only * 2, wonly * 2)
+            if st[4]:
+                break
+        assert st[4] == 1 and st[0] == 2, st
+        w = emul.sbve_ed_hot_wide_of_key(loser)
+        assert w in (0, 1) and emul.sbve_ed_hot_comb_mismatches(w) == 0
+        assert sum(1 for k in ka if emul.sbve_ed_hot_wide_of_key(k) != NONE) == 2
+        st = run(b, wb)                                   # everybody again: the victim is served from its 8-bit comb
+        assert st[2] >= 256, st
+        # the golden vectors' keys, 40 tuples each, promoted from 30 on
+        emul.sbve_scheme_key_cache(2, 1, 64)
+        emul.sbve_ed_hot_keys(6, 30)
+        blob = _tuples(ed_vectors) * 40
+        want = [v["accept"] for v in ed_vectors] * 40
+        s1 = run(blob, want, plain_check=True)
+        s2 = run(blob, want)
+        assert 1 <= s1[0] <= 6 and s2[2] >= 64, (s1, s2)
+        for i in range(s2[0]):
+            assert emul.sbve_ed_hot_comb_mismatches(i) == 0, i
+        emul.sbve_ed_hot_keys(0, 30)                      # off: same verdicts, nothing served wide
+        assert run(blob, want)[2] == 0
+    finally:
+        emul.sbve_ed_hot_keys(0, 4096)
+        emul.sbve_scheme_key_cache(2, 0, 0)
+
+
 def test_device_message_front_end_sha512_and_mod_l(emul):
     """sha512_dev.h: the 512-bit reduction mod L against big ints (edge values: 0, L-1, L, 2L, 2^252 multiples, 2^512-1)
     and the whole lane — SHA-512(R|A|M) mod L — against hashlib for message lengths around the block boundaries."""

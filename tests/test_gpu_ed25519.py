@@ -144,6 +144,60 @@ def test_grouped_vs_plain_full_batch(gpu, oracle):
           f"({n / times[False]:.1f} M/s)")
 
 
+def test_hot_keys_of_this_scheme_on_the_device(gpu, oracle):
+    """sbv_ed25519_hot_keys (ed25519_group.h "hot keys", round 6): cache slots that keep signing get 16-bit combs of -A, built on the
+    device behind a batch's verdicts (64 promotions per batch at most); the wavefronts whose lanes are all hot take the wide pass.
+    Verdicts equal the generator's in every batch — cold, during the promotions, served wide, with the pool full and with the
+    feature switched off again — and promoted combs equal the host builder's, entry by entry.  Also the golden vectors' odd keys
+    (non-canonical encodings, small order) promoted from 30 uses on."""
+    n, nkeys = 1 << 18, 96
+    tup, exp = _gen(oracle, 0x60D5EED, n, nkeys, 8)
+    lib = sbv.load()
+
+    def run(t=tup, m=n, want=exp.raw):
+        got = ctypes.create_string_buffer((m + 7) // 8)
+        sbv._check(lib.sbv_ed25519_verify_batch(ctypes.addressof(t), m, ctypes.addressof(got)))
+        assert got.raw == want
+        return gpu.ed_hot_key_stats(), gpu.last_timing().verify_us
+
+    try:
+        gpu.ed_hot_keys(64, 1024)
+        (promoted, cap, wide, min_hits), t_cold = run()          # cold: the keys' 8-bit combs are built, nobody is served wide yet
+        if cap == 0:
+            pytest.skip("no room for the pool on this device")
+        assert cap == 64 and min_hits == 1024 and wide == 0 and promoted == 64, (promoted, cap, wide)
+        (promoted, _, wide, _), t_hot = run()                    # 64 of the 96 signers are served from their combs
+        assert promoted == 64 and n // 2 < wide < n * 3 // 4, (promoted, wide)
+        for i in (0, 31, 63):
+            assert gpu.ed_hot_selfcheck(i), i
+        for _ in range(3):                                       # the pool stays full: similar keys never trade combs; verdicts stay
+            (promoted, _, wide2, _), _ = run()
+        assert promoted == 64 and n // 2 < wide2 < n * 3 // 4
+        assert gpu.ed_hot_selfcheck(5)
+        gpu.ed_hot_keys(0, 1024)
+        (promoted, cap, wide, _), t_warm = run()                 # off: the pool is gone (and with it this scheme's cache: a cold batch)
+        assert (promoted, cap, wide) == (0, 0, 0)
+        (_, _, _, _), t_warm = run()
+        print(f"\n[ed25519 2^18 over {nkeys} signers] cold {t_cold:.0f} us | 64 hot signers {t_hot:.0f} us | cache only {t_warm:.0f} us")
+        # the golden vectors' keys through combs of their own
+        vs = json.load(open(os.path.join(GOLDEN, "ed25519_vectors.json")))["vectors"]
+        blob = b"".join(ed.pack_tuple(bytes.fromhex(v["pk"]), bytes.fromhex(v["msg"]), bytes.fromhex(v["sig"])) for v in vs) * 40
+        want = [v["accept"] for v in vs] * 40
+        gpu.set_grouping(True, 1, 8, 64)
+        gpu.ed_hot_keys(64, 30)
+        for rnd in range(3):
+            got = sbv.bitmap_to_list(gpu.ed25519_verify_batch(blob, len(want)), len(want))
+            assert got == want, (rnd, [i for i in range(len(want)) if got[i] != want[i]][:8])
+        promoted, cap, wide, _ = gpu.ed_hot_key_stats()
+        assert 4 <= promoted <= 64, (promoted, cap, wide)
+        print(f"[ed25519 golden keys x 40] {promoted} promoted, {wide} of {len(want)} tuples served wide")
+        for i in range(promoted):
+            assert gpu.ed_hot_selfcheck(i), i
+    finally:
+        gpu.ed_hot_keys(1024, 4096)                              # the library's default
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
+
+
 def test_device_message_front_end_equals_host_tuple_builder(gpu, oracle):
     """sbv_ed25519_verify_msgs (SHA-512 + mod L on the device, sha512_dev.h) == sbv_ed25519_make_tuples + verify_batch on the
     golden vectors and on signed messages of every length around the SHA-512 block boundaries, some tampered."""

@@ -43,6 +43,10 @@ def worker(args):
     emul.sbve_hot_comb_mismatches.restype = ctypes.c_size_t
     emul.sbve_ed_chain_mismatches.restype = ctypes.c_ulong
     emul.sbve_scheme_key_cache.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
+    emul.sbve_ed_hot_keys.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    emul.sbve_ed_hot_stats.argtypes = [ctypes.c_void_p]
+    emul.sbve_ed_hot_comb_mismatches.argtypes = [ctypes.c_uint32]
+    emul.sbve_ed_hot_comb_mismatches.restype = ctypes.c_size_t
     oracle.sbvo_k256_gen_batch.argtypes = gen_args
     rng = random.Random(0xF022 + wid)
     out = {"worker": wid, "wide_keys": 0, "keyed_tuples": 0, "ed_tuples": 0, "p256g_tuples": 0, "k256g_tuples": 0, "one_tuples": 0, "mismatches": 0}
@@ -171,8 +175,31 @@ def worker(args):
             exp = ctypes.create_string_buffer((n + 7) // 8)
             oracle.sbvo_ed25519_gen_batch(seed, n, nkeys, rng.choice((2, 3, 5)), tup, exp, 1)
             bm = ctypes.create_string_buffer((n + 7) // 8)
-            emul.sbve_ed25519_verify_batch_grouped(tup.raw, n, bm, rng.choice((1, 8, 40)), 64, 12, rng.choice((1, 2, 3)), rng.choice((2, 4, 8)), None)
-            out["ed_tuples"] += n
+            # round 6, this scheme's cache and hot keys: a small pool of 16-bit combs of -A (each costs the emulator about a second), promoted by
+            # the first or the second pass; later passes serve the all-hot wavefronts from them
+            ed_cache = rng.random() < 0.5
+            ed_hot = ed_cache and rng.random() < 0.5
+            if ed_cache:
+                emul.sbve_scheme_key_cache(2, 1, rng.choice((4, 16, 64)))
+                emul.sbve_ed_hot_keys(rng.choice((1, 2, 3)) if ed_hot else 0, rng.choice((40, 150, 400)))
+            for rep in range((3 if ed_hot else 2) if ed_cache else 1):
+                bm = ctypes.create_string_buffer((n + 7) // 8)
+                emul.sbve_ed25519_verify_batch_grouped(tup.raw, n, bm, rng.choice((1, 8, 40)), 64, 12, rng.choice((1, 2, 3)), rng.choice((2, 4, 8)), None)
+                out["ed_tuples"] += n
+                if bm.raw != exp.raw:
+                    out["mismatches"] += 1
+                    out.setdefault("first", ["ed cached" if ed_cache else "ed", seed, n, nkeys, ed_hot, rep])
+            if ed_hot:
+                hs = (ctypes.c_uint32 * 6)()
+                emul.sbve_ed_hot_stats(hs)
+                out["ed_hot_promotions"] = out.get("ed_hot_promotions", 0) + hs[0]
+                out["ed_hot_wide_tuples"] = out.get("ed_hot_wide_tuples", 0) + hs[2]
+                if hs[0] and emul.sbve_ed_hot_comb_mismatches(hs[0] - 1) != 0:
+                    out["mismatches"] += 1
+                    out.setdefault("first", ["ed hot comb", seed, n, nkeys])
+            if ed_cache:
+                emul.sbve_ed_hot_keys(0, 4096)
+                emul.sbve_scheme_key_cache(2, 0, 0)
             if emul.sbve_ed_chain_mismatches() != 0:                  # round 5: the quad-lane base chain against the one-lane chain, every cold key
                 out["mismatches"] += 1
                 out.setdefault("first", ["ed quad chain", seed, n, nkeys])
