@@ -230,8 +230,10 @@ SBV_HD bool ed_encoding_matches(const ept& R, const u32* renc) {
 
 // One tuple -> accept?  `w` indexes the tuple's 32 little-endian dwords, `qtab` = 8 x 32 dwords of
 // private table space (16-byte aligned), `btab` = the 16-bit comb of B (ed_add_sB).
+// (xy != nullptr: X | Y of the key, 20 raw limbs, as a key check in front left them — the grouped step's ungrouped list, whose keys were
+// all decompressed once already: the square root is not taken twice)
 template <typename Words>
-SBV_HD bool ed25519_verify_lane(Words w, u32* qtab, const aniels* btab) {
+SBV_HD bool ed25519_verify_lane(Words w, u32* qtab, const aniels* btab, const u32* xy = nullptr) {
     u32 renc[8], pk[8];
     u256 S, k;
     SBV_UNROLL
@@ -239,7 +241,14 @@ SBV_HD bool ed25519_verify_lane(Words w, u32* qtab, const aniels* btab) {
     const u256 L = ed_L();
     bool ok = lt256(S, L) && lt256(k, L);        // SetCanonicalBytes(S); also covers sig[63] & 0xE0
     ept A;
-    ok = ed_decompress(A, pk) && ok;
+    if (xy) {
+        fe25_load_raw(A.X, xy);
+        fe25_load_raw(A.Y, xy + 10);
+        A.Z = fe25_one();
+        fe25_mul(A.T, A.X, A.Y);
+    } else {
+        ok = ed_decompress(A, pk) && ok;
+    }
     // table of k * (-A), k = 1..8
     {
         ept nA = A;
@@ -289,6 +298,7 @@ SBV_HD const aniels* edcomb_entry(const edcomb& c, size_t index) {
     return reinterpret_cast<const aniels*>(reinterpret_cast<const uint8_t*>(c.tab) + index * c.pitch);
 }
 
+#define SBV_ED_UNGXY_WORDS 20     // ed25519_group.h: X | Y of an ungrouped tuple's key, from the key check to the quad form of the one-lane kernel
 // hot keys (ed25519_group.h): the 16-bit comb of -A of a promoted cache slot
 #define SBV_ED_HOT_BITS 16
 #define SBV_ED_HOT_WINDOWS 16

@@ -67,11 +67,14 @@ SBV_HD void ed_group_classify_lane(size_t i, const GroupState& g) {
 // kernel (a ~460 000-instruction chain) ran to its end for the half of its lanes that had left after the square root.  The check
 // costs that square root once more (~20 000 instructions) on 4 % of the batch's lanes; in ONE pass over all tuples it cost as much
 // as the whole [S]B phase (see ed_group_split_lane), which is why it waited for the compaction.
-SBV_HD void ed_group_keycheck_lane(const uint8_t* tuples, u32 L, const GroupState& g, uint8_t* acc) {
+// ungxy (round 6, may be null): X | Y of the accepted keys, 20 raw limbs per position of the list, for the quad form of the one-lane kernel
+SBV_HD void ed_group_keycheck_lane(const uint8_t* tuples, u32 L, const GroupState& g, uint8_t* acc, u32* ungxy = nullptr) {
     const u32 i = g.ung_cand[L];
     ept A;
     if (ed_tuple_key_load(tuples, i, A)) {
-        g.ung_idx[SBV_ATOMIC_ADD(&g.counters[2], 1u)] = i;
+        const u32 pos = SBV_ATOMIC_ADD(&g.counters[2], 1u);
+        g.ung_idx[pos] = i;
+        if (ungxy) { fe25_store_raw(ungxy + (size_t)pos * SBV_ED_UNGXY_WORDS, A.X); fe25_store_raw(ungxy + (size_t)pos * SBV_ED_UNGXY_WORDS + 10, A.Y); }
     } else {
         acc[i] = 0;
         SBV_ATOMIC_ADD(&g.counters[3], 1u);
@@ -468,5 +471,162 @@ struct EdGlobalTuple {
     const u32* p;
     SBV_HD u32 operator[](int i) const { return p[i]; }
 };
+
+// ---- the ungrouped list on FOUR lanes per tuple (round 6) ---------------------------------------------------------------------------
+// Once a scheme's combs are cached the one-lane kernel over the ungrouped list — a few hundred wavefronts, each a serial chain of 256
+// doublings and 80 additions per lane — is the step's critical path (1.1 ms of a 2.2 ms hot step, profiles/r06/timeline_ed_hot_r06z.txt).
+// Here the four lanes of a quad hold one tuple's point and every doubling / addition is two multiplications deep instead of eight
+// (edchain_dbl above; edquad_add below, the same split of ed_add_pniels: lane r multiplies (Y-X)(Y2-X2) | (Y+X)(Y2+X2) | T 2dT2 | Z Z2,
+// the products travel by DPP broadcasts, lane r multiplies E F | G H | F G | E H).  An affine-Niels entry (the comb of B) is the same
+// addition with Z2 = 1.  The key arrives decompressed from the key check in front (ed_group_keycheck_lane keeps X and Y of the keys it
+// accepts): the square root is not taken twice.  Same group law on the same inputs as ed25519_verify_lane, so the same verdicts
+// (tests/emul runs both on every ungrouped tuple).
+// `op` = this lane's level-1 multiplier: role 0 -> Y2 - X2, 1 -> Y2 + X2, 2 -> 2 d T2, 3 -> Z2 (already swapped / negated for -q)
+template <class QX>
+SBV_HD void edquad_add(QX& q, const fe25 op[QX::N], bool skip) {
+    if (skip) return;                  // the same digit in the four lanes of a quad
+    fe25 P[QX::N], a[QX::N], b[QX::N], c[QX::N], d[QX::N];
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) {
+        const ept& s = q.s[i];
+        const int r = q.role(i);
+        fe25 ymx, ypx, in;
+        fe25_sub(ymx, s.Y, s.X);
+        fe25_add(ypx, s.Y, s.X);
+        fe25_select(in, r == 0, ymx, ypx);
+        fe25_select(in, r == 2, s.T, in);
+        fe25_select(in, r == 3, s.Z, in);
+        fe25_mul(P[i], in, op[i]);
+    }
+    q.bcast(a, P, 0); q.bcast(b, P, 1); q.bcast(c, P, 2); q.bcast(d, P, 3);
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) {
+        const int r = q.role(i);
+        fe25 dd, e, f, g, h, lhs, rhs;
+        fe25_add(dd, d[i], d[i]);
+        fe25_sub(e, b[i], a[i]);          // bounds as in ed_add_pniels: a, b, c tight; dd, e, h <= 2; f, g <= 3
+        fe25_sub(f, dd, c[i]);
+        fe25_add(g, dd, c[i]);
+        fe25_add(h, b[i], a[i]);
+        fe25_select(lhs, r == 1, g, f);   // first operand:  f | g | f | e
+        fe25_select(lhs, r == 3, e, lhs);
+        fe25_select(rhs, r == 0, e, h);   // second operand: e | h | g | h
+        fe25_select(rhs, r == 2, g, rhs);
+        fe25_mul(P[i], lhs, rhs);
+    }
+    q.bcast(a, P, 0); q.bcast(b, P, 1); q.bcast(c, P, 2); q.bcast(d, P, 3);
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) { q.s[i].X = a[i]; q.s[i].Y = b[i]; q.s[i].Z = c[i]; q.s[i].T = d[i]; }
+}
+// this lane's multiplier out of a projective-Niels table entry (pn_store layout: Y+X | Y-X | Z | 2dT, ten raw limbs each)
+SBV_HD void edquad_op_pniels(fe25& op, const u32* entry, int role, bool neg) {
+    const int coord = role == 0 ? (neg ? 0 : 1) : role == 1 ? (neg ? 1 : 0) : role == 2 ? 3 : 2;
+    fe25_load_raw(op, entry + 10 * coord);
+    fe25_cneg(op, op, neg && role == 2);
+}
+// ... and out of a packed affine-Niels entry (y+x | y-x | 2dxy, eight words each); Z2 = 1
+struct edquad_words { u32 w[8]; };
+SBV_HD void edquad_fetch_aniels(edquad_words& o, const aniels* entry, int role, bool neg) {
+    const int coord = role == 0 ? (neg ? 0 : 1) : role == 1 ? (neg ? 1 : 0) : 2;      // role 3 fetches 2dxy too and ignores it
+    const f25_q4* s = reinterpret_cast<const f25_q4*>(entry) + 2 * coord;
+    const f25_q4 lo = s[0], hi = s[1];
+    o.w[0] = lo.x; o.w[1] = lo.y; o.w[2] = lo.z; o.w[3] = lo.w; o.w[4] = hi.x; o.w[5] = hi.y; o.w[6] = hi.z; o.w[7] = hi.w;
+}
+SBV_HD void edquad_op_aniels(fe25& op, const edquad_words& e, int role, bool neg) {
+    fe25 t;
+    fe25_from_words(t, e.w);
+    fe25_cneg(t, t, neg && role == 2);
+    fe25_select(op, role == 3, fe25_one(), t);
+}
+// One ungrouped tuple on a quad -> accept?  `xy` = X | Y of the decompressed key (20 raw limbs, from the key check), `qtab` = the
+// tuple's 8 x 40 words of table space, `b16` = the 16-bit comb of B of the one-lane kernel.  Every lane returns the verdict.
+template <class QX, typename Words>
+SBV_HD void ed25519_verify_quad(QX& q, Words w, const u32* xy, u32* qtab, const aniels* b16, bool out[QX::N]) {
+    u32 renc[8];
+    u256 S, k;
+    SBV_UNROLL
+    for (int i = 0; i < 8; ++i) { renc[i] = w[i]; S.v[i] = w[8 + i]; k.v[i] = w[24 + i]; }
+    const u256 L = ed_L();
+    const bool ok = lt256(S, L) && lt256(k, L);
+    const fe25 d2 = fe25_2d();
+    // -A, and the table of m (-A), m = 1 .. 8: lane r keeps coordinate r of every entry
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) {
+        ept& s = q.s[i];
+        fe25 x;
+        fe25_load_raw(x, xy);
+        fe25_load_raw(s.Y, xy + 10);
+        fe25_mul(s.T, x, s.Y);
+        fe25_neg(s.X, x);
+        fe25_neg(s.T, s.T);
+        s.Z = fe25_one();
+    }
+    SBV_NOUNROLL
+    for (int m = 1; m <= SBV_ED_QTAB_ENTRIES; ++m) {
+        if (m == 2) edchain_dbl(q);
+        else if (m > 2) {
+            fe25 op[QX::N];
+            SBV_UNROLL
+            for (int i = 0; i < QX::N; ++i) edquad_op_pniels(op[i], qtab, q.role(i), false);
+            edquad_add(q, op, false);
+        }
+        SBV_UNROLL
+        for (int i = 0; i < QX::N; ++i) {
+            const ept& s = q.s[i];
+            const int r = q.role(i);
+            fe25 ypx, ymx, t2d, c;
+            fe25_add(ypx, s.Y, s.X);
+            fe25_sub(ymx, s.Y, s.X);
+            fe25_mul(t2d, s.T, d2);
+            fe25_select(c, r == 0, ypx, ymx);
+            fe25_select(c, r == 2, s.Z, c);
+            fe25_select(c, r == 3, t2d, c);
+            fe25_store_raw(qtab + (m - 1) * SBV_ED_PT_WORDS + 10 * r, c);
+        }
+    }
+    u256 kk;
+    (void)add_const_limbs(kk, k, 0x88888888u);
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) ed_set_ident(q.s[i]);
+    SBV_NOUNROLL
+    for (int win = 63; win >= 0; --win) {
+        SBV_NOUNROLL
+        for (int t = 0; t < 4; ++t) edchain_dbl(q);
+        const int d = (int)((ed_word_at(kk, win >> 3) >> ((win & 7) * 4)) & 15u) - 8;
+        const int ad = d < 0 ? -d : d;
+        fe25 op[QX::N];
+        SBV_UNROLL
+        for (int i = 0; i < QX::N; ++i) edquad_op_pniels(op[i], qtab + (ad == 0 ? 0 : ad - 1) * SBV_ED_PT_WORDS, q.role(i), d < 0);
+        edquad_add(q, op, d == 0);
+    }
+    // + [S]B from the 16-bit comb, the next entry fetched one addition ahead (ed_add_sB)
+    {
+        u256 ss;
+        (void)add_const_limbs(ss, S, 0x80008000u);
+        int d = (int)(ss.v[0] & 0xFFFFu) - 32768;
+        edquad_words cur[QX::N];
+        SBV_UNROLL
+        for (int i = 0; i < QX::N; ++i) edquad_fetch_aniels(cur[i], b16 + ((d < 0 ? -d : d) == 0 ? 0 : (d < 0 ? -d : d) - 1), q.role(i), d < 0);
+        SBV_NOUNROLL
+        for (int j = 0; j < SBV_ED_B16_WINDOWS; ++j) {
+            const int jn = j + 1 < SBV_ED_B16_WINDOWS ? j + 1 : j;
+            const int dn = (int)((ed_word_at(ss, jn >> 1) >> ((jn & 1) * 16)) & 0xFFFFu) - 32768;
+            const int adn = dn < 0 ? -dn : dn;
+            edquad_words nxt[QX::N];
+            fe25 op[QX::N];
+            SBV_UNROLL
+            for (int i = 0; i < QX::N; ++i) {
+                edquad_fetch_aniels(nxt[i], b16 + (size_t)jn * SBV_ED_B16_PER_WINDOW + (adn == 0 ? 0 : adn - 1), q.role(i), dn < 0);
+                edquad_op_aniels(op[i], cur[i], q.role(i), d < 0);
+            }
+            edquad_add(q, op, d == 0);
+            SBV_UNROLL
+            for (int i = 0; i < QX::N; ++i) cur[i] = nxt[i];
+            d = dn;
+        }
+    }
+    SBV_UNROLL
+    for (int i = 0; i < QX::N; ++i) out[i] = ok && ed_encoding_matches(q.s[i], renc);
+}
 
 }  // namespace sbv

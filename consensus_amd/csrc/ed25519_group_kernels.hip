@@ -100,18 +100,23 @@ __global__ __launch_bounds__(64) void k_ed_keytab_window(GroupState g, const u32
 // The one-lane kernel (ed25519_verify_lane) over the ungrouped list, at the 3 waves/SIMD budget of the throughput
 // kernels it runs beside.  A ~2.5 ms serial chain per lane: it goes on side_a behind the last bases so that it
 // gates nothing but the final pack.
-__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_generic_list(const uint8_t* __restrict__ tuples, GroupState g,
+#ifndef SBV_ED_ONE_WAVES
+#define SBV_ED_ONE_WAVES SBV_ED_GROUP_WAVES
+#endif
+// ungxy (may be null): the keys as the key check decompressed them (key-sorted step)
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_ONE_WAVES) void k_ed_generic_list(const uint8_t* __restrict__ tuples, GroupState g,
                                                                         u32* __restrict__ qtab, const aniels* __restrict__ btab,
-                                                                        uint8_t* __restrict__ acc) {
+                                                                        uint8_t* __restrict__ acc, const u32* __restrict__ ungxy) {
     const u32 L = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= g.counters[2]) return;
     ed_chain_prio();
     const u32 t = g.ung_idx[L];
-    acc[t] = ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab + (size_t)L * (SBV_ED_QTAB_ENTRIES * SBV_ED_PT_WORDS), btab) ? 1 : 0;
+    acc[t] = ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab + (size_t)L * (SBV_ED_QTAB_ENTRIES * SBV_ED_PT_WORDS), btab,
+                                 ungxy ? ungxy + (size_t)L * SBV_ED_UNGXY_WORDS : nullptr) ? 1 : 0;
 }
 
 // key-sorted step, pass 2: the ungrouped candidates whose key is a point -> ung_idx (ed25519_group.h: ed_group_keycheck_lane)
-__global__ __launch_bounds__(256) void k_ed_keycheck(const uint8_t* __restrict__ tuples, GroupState g, uint8_t* __restrict__ acc) {
+__global__ __launch_bounds__(256) void k_ed_keycheck(const uint8_t* __restrict__ tuples, GroupState g, uint8_t* __restrict__ acc, u32* __restrict__ ungxy) {
     const u32 L = blockIdx.x * 256 + threadIdx.x;
     const u32 cands = g.counters[4];
     if (blockIdx.x * 256u >= cands) return;            // whole workgroup idle (uniform: the barriers below are not reached by anyone)
@@ -119,16 +124,32 @@ __global__ __launch_bounds__(256) void k_ed_keycheck(const uint8_t* __restrict__
     const bool active = L < cands;
     u32 i = 0;
     bool ok = false;
+    ept A;
     if (active) {
         i = g.ung_cand[L];
-        ept A;
         ok = ed_tuple_key_load(tuples, i, A);
         if (!ok) acc[i] = 0;
     }
     const unsigned long long mr = __ballot(active && !ok);
     if ((threadIdx.x & 63) == 0 && mr) atomicAdd(&g.counters[3], (u32)__popcll(mr));
     const u32 pos = group_compact_pos(active && ok, &g.counters[2]);
-    if (active && ok) g.ung_idx[pos] = i;
+    if (active && ok) {
+        g.ung_idx[pos] = i;
+        if (ungxy) { fe25_store_raw(ungxy + (size_t)pos * SBV_ED_UNGXY_WORDS, A.X); fe25_store_raw(ungxy + (size_t)pos * SBV_ED_UNGXY_WORDS + 10, A.Y); }
+    }
+}
+// The ungrouped list on four lanes per tuple (ed25519_group.h: ed25519_verify_quad): 4 x as many wavefronts, each a chain a third as long
+__global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_generic_quad(const uint8_t* __restrict__ tuples, GroupState g, const u32* __restrict__ ungxy,
+                                                                        u32* qtab, const aniels* __restrict__ btab, uint8_t* __restrict__ acc) {
+    const u32 lane = blockIdx.x * SBV_VERIFY_BLOCK + threadIdx.x;
+    const u32 L = lane >> 2;
+    if (L >= g.counters[2]) return;                   // a quad lives or leaves as a whole
+    const u32 t = g.ung_idx[L];
+    edchain_quad_dev q;
+    q.r = (int)(lane & 3u);
+    bool v[1];
+    ed25519_verify_quad(q, EdGlobalTuple{ed_tuple_words(tuples, t)}, ungxy + (size_t)L * SBV_ED_UNGXY_WORDS, qtab + (size_t)L * (SBV_ED_QTAB_ENTRIES * SBV_ED_PT_WORDS), btab, v);
+    if (q.r == 0) acc[t] = v[0] ? 1 : 0;
 }
 
 // [S]B for every tuple of the batch
@@ -306,7 +327,12 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
     SBV_TRY(hipStreamWaitEvent(y.side_a, y.ev_split, 0));
     // the candidates whose key is a point -> ung_idx, right in front of the kernel that needs it: on side_b before the sort it held
     // up the first table windows (4.33 ms per cold 2^20 step against 4.08 here; without any key check 4.52: profiles/r04/ab_ed_keycheck_r04n.jsonl)
-    if (g.sorted) hipLaunchKernelGGL(k_ed_keycheck, dim3(gn), dim3(256), 0, y.side_a, d_tuples, g, b.acc);
+    // the ungrouped list on four lanes per tuple (the key check hands over the decompressed keys); SBV_ED_UNGROUPED_QUAD=0: the one-lane kernel
+    static const bool quad_env = [] { const char* e = getenv("SBV_ED_UNGROUPED_QUAD"); return e && atoi(e) != 0; }();
+    static const bool keep_keys = [] { const char* e = getenv("SBV_ED_UNGROUPED_KEYS"); return !e || atoi(e) != 0; }();
+    const u32* ungxy = keep_keys && g.sorted ? eb.ungxy : nullptr;     // the key check keeps the keys it decompressed
+    const bool quad = quad_env && ungxy;
+    if (g.sorted) hipLaunchKernelGGL(k_ed_keycheck, dim3(gn), dim3(256), 0, y.side_a, d_tuples, g, b.acc, const_cast<u32*>(ungxy));
     // Once the combs are cached the one-lane kernel's chain (1.1 ms alone) is the step's critical path, and the key check in front of it
     // took 0.7 ms instead of 0.1 whenever its workgroups had to queue up behind those of the first Q launch (timeline_ed_hot_r06x.txt):
     // that launch now waits for the key check.  A cold step's first Q launch waits for tables anyway.
@@ -315,7 +341,8 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
         SBV_TRY(hipEventRecord(y.ev_narrow, y.side_a));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_narrow, 0));
     }
-    hipLaunchKernelGGL(k_ed_generic_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, d_tuples, g, d_qtab, d_btab, b.acc);
+    if (quad) hipLaunchKernelGGL(k_ed_generic_quad, dim3(4 * gv), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, d_tuples, g, ungxy, d_qtab, d_btab, b.acc);
+    else hipLaunchKernelGGL(k_ed_generic_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, y.side_a, d_tuples, g, d_qtab, d_btab, b.acc, ungxy);
     SBV_TRY(hipEventRecord(y.ev_generic, y.side_a));
     if (hot_on) {
         // the wide pass first: it needs the G phase and the classes, no table of this batch — it runs while side_a / side_b build them

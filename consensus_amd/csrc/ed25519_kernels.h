@@ -12,6 +12,7 @@ struct EdGroupBuffers {
     aniels* ktab = nullptr;       // [kc.cap + max_groups][32 x 128] combs of -A: slots [0, kc.cap) = this scheme's persistent key-table
                                   // cache (round 4), [kc.cap, kc.cap + max_groups) = per batch
     uint8_t* okb = nullptr;       // [cap] S < L && k < L
+    u32* ungxy = nullptr;         // [cap][20] X | Y of the ungrouped list's keys, left by the key check for the quad form of the one-lane kernel
     uint8_t* kvalid = nullptr;    // [kc.cap + max_groups] 1 = the slot's key decompressed.  NOT GroupBuffers::kvalid: bytes [0, kc.cap) of
                                   // that array belong to the P-256 key-table cache and outlive the batch — an Ed25519 batch writing
                                   // its own group verdicts there invalidated cached P-256 keys (found in round 3 by test order)

@@ -377,6 +377,7 @@ void free_group_buffers(Context& c, bool keep_pools = false) {
     for (void* p : pool) if (p) (void)hipFree(p);
     if (c.edgrp.ktab) (void)hipFree(c.edgrp.ktab);
     if (c.edgrp.okb) (void)hipFree(c.edgrp.okb);
+    if (c.edgrp.ungxy) (void)hipFree(c.edgrp.ungxy);
     if (c.edgrp.kvalid) (void)hipFree(c.edgrp.kvalid);
     key_cache_free(c.edgrp.kc);
     ed_hot_free(c.edgrp);
@@ -551,7 +552,8 @@ int ensure_ed_group_buffers(Context& c, size_t n) {
     }
     HIP_TRY(SBV_EDEVICE, hipDeviceSynchronize());
     if (e.okb) (void)hipFree(e.okb);
-    e.okb = nullptr; e.cap = 0;
+    if (e.ungxy) (void)hipFree(e.ungxy);
+    e.okb = nullptr; e.ungxy = nullptr; e.cap = 0;
     if (!pool_ok) {
         if (e.ktab) (void)hipFree(e.ktab);
         if (e.kvalid) (void)hipFree(e.kvalid);
@@ -585,6 +587,7 @@ int ensure_ed_group_buffers(Context& c, size_t n) {
         }
     }
     HIP_TRY(SBV_ENOMEM, hipMalloc(&e.okb, c.grp.cap));
+    HIP_TRY(SBV_ENOMEM, hipMalloc(&e.ungxy, c.grp.cap * (size_t)SBV_ED_UNGXY_WORDS * sizeof(u32)));
     e.promote_min = c.ed_hot_min_hits;
     e.cap = c.grp.cap;
     e.kc.enabled = c.kc_on[2] ? 1u : 0u;
@@ -2327,6 +2330,7 @@ extern "C" int sbv_ed25519_hot_keys(uint32_t max_keys, uint32_t min_hits) {
         sbv::EdGroupBuffers& eb = c.edgrp;
         if (eb.ktab) (void)hipFree(eb.ktab);
         if (eb.okb) (void)hipFree(eb.okb);
+        if (eb.ungxy) (void)hipFree(eb.ungxy);
         if (eb.kvalid) (void)hipFree(eb.kvalid);
         key_cache_free(eb.kc);
         ed_hot_free(eb);

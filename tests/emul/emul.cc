@@ -834,6 +834,8 @@ static const aniels* btab() {
 }
 static unsigned long g_ed_chain_mismatches = 0;      // quad-lane base chain against the one-lane chain: bases or key verdicts that differ
 unsigned long sbve_ed_chain_mismatches() { return g_ed_chain_mismatches; }
+static unsigned long g_ed_quad_mismatches = 0;       // quad form of the one-lane kernel against the one-lane kernel: verdicts that differ (any of the four lanes)
+unsigned long sbve_ed_quad_mismatches() { return g_ed_quad_mismatches; }
 // the grouped step's comb of B at another width (ed25519_group.h: edcomb; libsbv: SBV_ED_B_BITS, default 20).  The emulator's default
 // stays 16 (the one-lane table, no second build); tests switch to 12 / 13 / 19 / 20 bits
 static aniels* g_ed_bcomb = nullptr;
@@ -947,13 +949,14 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     g.slots = slots.data(); g.max_groups = max_groups;
     group_set_threshold(g, min_count);
     std::vector<uint8_t> accb(cap, 0xEE), okb(cap, 0);
+    std::vector<u32> ungxy(cap * SBV_ED_UNGXY_WORDS, 0xDEADBEEFu);
     KeyCache kc = g_kc_ed.kc;            // this scheme's persistent key-table cache (off unless sbve_scheme_key_cache(2, ...) switched it on)
     for (size_t i = 0; i < n; ++i) ed_group_insert_lane(tuples, i, g);
     for (size_t i = 0; i < n; ++i) group_assign_lane_t<128, 64, 8>(tuples, i, g, kc);      // cached keys are grouped whatever their count
     const u32 ngroups = counters[0] < max_groups ? counters[0] : max_groups;
     if (g.sorted) {                      // key-sorted list: classify, then the counting sort of p256_group.h (scatter walked backwards)
         for (size_t i = 0; i < n; ++i) ed_group_classify_lane(i, g);
-        for (u32 L = 0; L < counters[4]; ++L) ed_group_keycheck_lane(tuples, L, g, accb.data());     // k_ed_keycheck: candidates whose key is no point leave here
+        for (u32 L = 0; L < counters[4]; ++L) ed_group_keycheck_lane(tuples, L, g, accb.data(), ungxy.data());     // k_ed_keycheck: candidates whose key is no point leave here
         for (size_t i = 0; i < n; ++i) group_sort_count_lane(i, g);
         group_sort_scan_seq(g, ngroups);
         for (size_t i = n; i-- > 0;) group_sort_scatter_lane(i, g);
@@ -1088,7 +1091,22 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
     u32* qtab = (u32*)aligned_alloc(16, SBV_ED_QTAB_ENTRIES * SBV_ED_PT_WORDS * 4);
     for (u32 L = 0; L < counters[2]; ++L) {
         const u32 t = ung_idx[L];
-        if (ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab, btab())) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
+        const bool v1 = ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab, btab());
+        bool v = v1;
+        if (g.sorted) {
+            // k_ed_generic_list on the key the key check left behind (no second square root) ...
+            v = ed25519_verify_lane(EdGlobalTuple{ed_tuple_words(tuples, t)}, qtab, btab(), ungxy.data() + (size_t)L * SBV_ED_UNGXY_WORDS);
+            if (v != v1) ++g_ed_quad_mismatches;
+            // ... and (SBV_ED_UNGROUPED_QUAD=1)
+            // k_ed_generic_quad: the four lanes of the tuple's quad in lockstep, on the key the key check left behind — and the one-lane
+            // kernel's verdict beside it
+            edchain_quad_host q;
+            bool v4[4];
+            ed25519_verify_quad(q, EdGlobalTuple{ed_tuple_words(tuples, t)}, ungxy.data() + (size_t)L * SBV_ED_UNGXY_WORDS, qtab, btab(), v4);
+            if (v4[0] != v1 || v4[1] != v1 || v4[2] != v1 || v4[3] != v1) ++g_ed_quad_mismatches;
+            if (L & 1) v = v4[L & 3];
+        }
+        if (v) bitmap[t >> 3] |= (uint8_t)(1u << (t & 7));
     }
     free(qtab); free(tmpa); free(ktab); free(jbases); free(tuples); free(gacc);
     if (stats_out) { stats_out[0] = ngroups; stats_out[1] = counters[1]; stats_out[2] = counters[2]; stats_out[3] = counters[3]; }

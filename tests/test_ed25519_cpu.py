@@ -163,6 +163,7 @@ def test_grouped_by_key_inside_the_batch_matches_plain_kernel(emul, oracle, ed_v
     stats = (ctypes.c_uint32 * 4)()
     emul.sbve_group_sort_violations.restype = ctypes.c_ulong
     emul.sbve_ed_chain_mismatches.restype = ctypes.c_ulong
+    emul.sbve_ed_quad_mismatches.restype = ctypes.c_ulong
     violations = emul.sbve_group_sort_violations()
     for min_count, max_groups, ht_bits, chunks, parts in [(8, 64, 12, 2, 4), (8, 64, 12, 1, 8), (64, 64, 12, 4, 16), (1, 4096, 12, 3, 2),
                                                           (8, 3, 12, 2, 4), (2, 64, 11, 2, 4), (10**6, 64, 12, 2, 4)]:
@@ -182,6 +183,7 @@ def test_grouped_by_key_inside_the_batch_matches_plain_kernel(emul, oracle, ed_v
             assert r1 >= 40                   # the 40 copies of the undecompressable key are below this threshold: candidates, then rejected
         assert emul.sbve_group_sort_violations() == violations
         assert emul.sbve_ed_chain_mismatches() == 0      # round 5: the quad-lane base chain records byte for byte what the one-lane chain does
+        assert emul.sbve_ed_quad_mismatches() == 0       # round 6: the quad form of the one-lane kernel (key-sorted step) gives the one-lane verdicts
         got = _bits(bm.raw, total)
         bad = [i for i in range(total) if got[i] != want[i]]
         assert not bad, (min_count, max_groups, ht_bits, chunks, parts, bad[:8])

@@ -198,6 +198,46 @@ def test_hot_keys_of_this_scheme_on_the_device(gpu, oracle):
         gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
 
 
+def test_quad_form_of_the_one_lane_kernel_gives_the_same_verdicts():
+    """SBV_ED_UNGROUPED_QUAD=1 (round 6): the ungrouped list of the key-sorted step on four lanes per tuple (ed25519_group.h:
+    ed25519_verify_quad — doublings and additions two multiplications deep, DPP broadcasts inside the quad, the key as the key check
+    decompressed it).  Built to shorten the chain that gates a warm step; measured: the step is bound by the ALU work the ungrouped
+    tuples and the Q phase share, not by the chain's length, and the quad form adds work (profiles/r06/ab_ed_ungrouped_quad_*_r06ac.jsonl:
+    warm 2.69 -> 2.78 ms) — it stays opt-in.  Here its verdicts in a process of its own (the switch is read once): the golden
+    vectors (small-order and non-canonical keys, S >= L) and a batch of 40 000 tuples over 30 000 keys, all ungrouped."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, json, os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import consensus_amd as sbv
+import ed25519_py as ed
+oracle = ctypes.CDLL(os.path.join("oracle", "libsbv_oracle.so"))
+oracle.sbvo_ed25519_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+vs = json.load(open(os.path.join("tests", "golden", "ed25519_vectors.json")))["vectors"]
+blob = b"".join(ed.pack_tuple(bytes.fromhex(v["pk"]), bytes.fromhex(v["msg"]), bytes.fromhex(v["sig"])) for v in vs)
+want = [v["accept"] for v in vs]
+n = 40000
+tup = ctypes.create_string_buffer(128 * n); exp = ctypes.create_string_buffer((n + 7) // 8)
+oracle.sbvo_ed25519_gen_batch(0x0AD5, n, 30000, 4, tup, exp, os.cpu_count() or 1)
+allt = blob * 3 + tup.raw
+want = want * 3 + sbv.bitmap_to_list(exp.raw, n)
+sbv.init(0)
+sbv.set_grouping(True, 1, 8, 64)
+for rnd in range(2):
+    got = sbv.bitmap_to_list(sbv.ed25519_verify_batch(allt, len(want)), len(want))
+    bad = [i for i in range(len(want)) if got[i] != want[i]]
+    assert not bad, (rnd, bad[:8])
+groups, grouped, ungrouped, rejected = sbv.last_group_stats()
+assert ungrouped > 15000, (groups, grouped, ungrouped, rejected)
+print("quad ok", groups, grouped, ungrouped, rejected)
+"""
+    env = dict(os.environ, SBV_ED_UNGROUPED_QUAD="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "quad ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 def test_device_message_front_end_equals_host_tuple_builder(gpu, oracle):
     """sbv_ed25519_verify_msgs (SHA-512 + mod L on the device, sha512_dev.h) == sbv_ed25519_make_tuples + verify_batch on the
     golden vectors and on signed messages of every length around the SHA-512 block boundaries, some tampered."""

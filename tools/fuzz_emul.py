@@ -42,6 +42,7 @@ def worker(args):
     emul.sbve_hot_comb_mismatches.argtypes = [ctypes.c_uint32]
     emul.sbve_hot_comb_mismatches.restype = ctypes.c_size_t
     emul.sbve_ed_chain_mismatches.restype = ctypes.c_ulong
+    emul.sbve_ed_quad_mismatches.restype = ctypes.c_ulong
     emul.sbve_scheme_key_cache.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_uint32]
     emul.sbve_ed_hot_keys.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
     emul.sbve_ed_hot_stats.argtypes = [ctypes.c_void_p]
@@ -200,6 +201,9 @@ def worker(args):
             if ed_cache:
                 emul.sbve_ed_hot_keys(0, 4096)
                 emul.sbve_scheme_key_cache(2, 0, 0)
+            if emul.sbve_ed_quad_mismatches() != 0:                   # round 6: the quad form of the one-lane kernel against the one-lane kernel, every ungrouped tuple
+                out["mismatches"] += 1
+                out.setdefault("first", ["ed quad one-lane", seed, n, nkeys])
             if emul.sbve_ed_chain_mismatches() != 0:                  # round 5: the quad-lane base chain against the one-lane chain, every cold key
                 out["mismatches"] += 1
                 out.setdefault("first", ["ed quad chain", seed, n, nkeys])
