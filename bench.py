@@ -1238,7 +1238,8 @@ def main():
                          ("key_count_sweep", lambda: leg_key_count_sweep(sbv, synth, torch, n, stream)),
                          ("end_to_end", lambda: leg_end_to_end(sbv, tuples, valid, n, max(2, args.steps // 2))),
                          ("sharded_entry", lambda: leg_sharded(sbv, tuples, valid, n, max(2, args.steps // 2))),
-                         ("ed25519", lambda: leg_ed25519(sbv, torch, n, max(2, args.steps // 2), stream, not args.no_cpu_baseline)),
+                         ("ed25519", lambda: leg_ed25519(sbv, torch, n, max(2, args.steps // 2), stream, not args.no_cpu_baseline,
+                                                         os.environ.get("SBV_BENCH_ED_HOT", "1") != "0")),      # 0: PMC passes (the hot leg's near-empty Q launches would dilute the per-launch counters)
                          ("secp256k1", lambda: leg_secp256k1(sbv, torch, n, max(2, args.steps // 2), stream, not args.no_cpu_baseline)),
                          ("projected_strong_scaling", lambda: leg_projected_strong_scaling(sbv, torch, d_tuples, valid, n, stream, 1e3 * elapsed / args.steps)),
                          ("m2_commit_quorum_us", lambda: leg_m2(tuples, n)),

@@ -65,7 +65,7 @@ PY
       for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_VALU"; do
         set -- $pass; pname=$1; shift
         # the primary leg AND the Ed25519 / secp256k1 legs (round 5: their roofline.traffic used to be null: no PMC pass covered them)
-        ( cd /tmp; timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$pname" -o p -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --legs ed25519,secp256k1 > "$OUT/pmc_$pname.log" 2>&1; echo "rc=$?" >> "$OUT/pmc_$pname.log" )
+        ( cd /tmp; SBV_BENCH_ED_HOT=0 timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$pname" -o p -- python "$ROOT/bench.py" --steps 4 --warmup 2 --no-cpu-baseline --legs ed25519,secp256k1 > "$OUT/pmc_$pname.log" 2>&1; echo "rc=$?" >> "$OUT/pmc_$pname.log" )
       done
       python3 - "$OUT" <<'PY'
 import csv, collections, json, os, sys
