@@ -209,7 +209,7 @@ def test_quad_form_of_the_one_lane_kernel_gives_the_same_verdicts():
     import sys
     code = r"""
 import ctypes, json, os, sys
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "oracle"))
 import consensus_amd as sbv
 import ed25519_py as ed
 oracle = ctypes.CDLL(os.path.join("oracle", "libsbv_oracle.so"))
