@@ -161,24 +161,6 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_gph
 
 // Round 6: the key-sorted form and the compaction-order form are kernels of their own, LAST is a template parameter (what the P-256 Q
 // phase gained from the same split: each form alone needs far fewer registers than the kernel that held them all)
-// Which lanes of the key-sorted list a workgroup takes.  Workgroup b runs on XCD b % 8; a key's comb should be fetched into ONE L2, so
-// an XCD takes contiguous pieces of the list — until round 6 one piece each, an eighth of the list (as the P-256 Q phase).  With hot keys
-// that is a trap: promoted slots are the keys cached first, groups are numbered by first appearance, so the promoted keys can sit in one
-// half of the sorted list — the wide pass then ran on four XCDs and the chunks' launches on the other four, each as long as a launch
-// over all lanes (a half-hot 2^20 step 2.96 ms against 2.59 from the 8-bit combs alone, profiles/r06/timeline_ed_half_hot_r06ak.txt).
-// Now the list is dealt out in chunks of C workgroups, chunk c to XCD c % 8, C = a 64th of the list's workgroups (at most 64, i.e.
-// 16 384 lanes = about 16 keys of the headline batch: a key in 16 straddles two L2s).  false = no lanes for this workgroup.
-#define SBV_ED_SORTED_GRID_SLACK 576u     // grid = workgroups of n lanes + this many: covers every (lanes, C) at run time
-__device__ __forceinline__ bool ed_sorted_block(u32 lanes, u32& first_lane) {
-    const u32 T = (lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK;
-    u32 C = T >> 6;
-    C = C < 1u ? 1u : (C > 64u ? 64u : C);
-    const u32 xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
-    const u32 lb = ((local / C) * 8u + xcd) * C + local % C;
-    if (lb >= T) return false;
-    first_lane = lb * SBV_VERIFY_BLOCK;
-    return true;
-}
 // hot keys: does every (active) lane of this wavefront belong to a group whose cache slot owns a 16-bit comb?
 __device__ __forceinline__ bool ed_wave_is_wide(u32 grp, const GroupState& g, const uint8_t* __restrict__ wide) {
     const bool w = grp < group_count(g) && wide[grp] != 0;
@@ -190,11 +172,12 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_QPHASE_WAVES) void k_ed_qp
                                                                   const u32* __restrict__ tslot, u32 table_slots,
                                                                   u32* __restrict__ gacc, size_t cap, const uint8_t* __restrict__ okb,
                                                                   uint8_t* __restrict__ acc, int j0, int j1, const uint8_t* __restrict__ wide) {
-    // key-sorted list, XCD-aware workgroup order (ed_sorted_block)
+    // key-sorted list, XCD-aware block order (see k_verify_keyed_q): block b takes logical block (b % 8) * per + b / 8
     const u32 lanes = g.counters[1];
-    u32 L0;
-    if (!ed_sorted_block(lanes, L0)) return;
-    const u32 L = L0 + threadIdx.x;
+    const u32 per = ((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK + 7) >> 3;
+    const u32 local = blockIdx.x >> 3;
+    if (local >= per) return;
+    const u32 L = ((blockIdx.x & 7u) * per + local) * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= lanes) return;
     const u32 t = g.grp_idx[L];
     const u32 grp = g.grp_of[L];
@@ -212,9 +195,10 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, SBV_ED_GROUP_WAVES) void k_ed_qph
                                                                   u32* __restrict__ gacc, const uint8_t* __restrict__ okb, uint8_t* __restrict__ acc) {
     if (g.counters[8] == 0) return;                                   // no group of this batch owns a comb
     const u32 lanes = g.counters[1];
-    u32 L0;
-    if (!ed_sorted_block(lanes, L0)) return;
-    const u32 L = L0 + threadIdx.x;
+    const u32 per = ((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK + 7) >> 3;
+    const u32 local = blockIdx.x >> 3;
+    if (local >= per) return;
+    const u32 L = ((blockIdx.x & 7u) * per + local) * SBV_VERIFY_BLOCK + threadIdx.x;
     if (L >= lanes) return;
     const u32 t = g.grp_idx[L];
     const u32 grp = g.grp_of[L];
@@ -376,9 +360,9 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c], stream));
         if (!g.sorted) hipLaunchKernelGGL(k_ed_qphase_list, dim3(gv), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.tslot, table_slots, b.gacc, b.gacc_cap,
                                           eb.okb, b.acc, j_first, j_end, c + 1 == chunks ? 1 : 0);
-        else if (c + 1 == chunks) hipLaunchKernelGGL(k_ed_qphase<true>, dim3(gv + SBV_ED_SORTED_GRID_SLACK), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.tslot, table_slots,
+        else if (c + 1 == chunks) hipLaunchKernelGGL(k_ed_qphase<true>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.tslot, table_slots,
                                                      b.gacc, b.gacc_cap, eb.okb, b.acc, j_first, j_end, wide);
-        else hipLaunchKernelGGL(k_ed_qphase<false>, dim3(gv + SBV_ED_SORTED_GRID_SLACK), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.tslot, table_slots,
+        else hipLaunchKernelGGL(k_ed_qphase<false>, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, stream, d_tuples, g, eb.ktab, eb.kvalid, b.tslot, table_slots,
                                 b.gacc, b.gacc_cap, eb.okb, b.acc, j_first, j_end, wide);
         if (prof) SBV_TRY(hipEventRecord(prof[2 * c + 1], stream));
     }
@@ -389,7 +373,7 @@ hipError_t launch_ed25519_verify_grouped(const uint8_t* d_tuples, size_t n, cons
         // Like the first Q launch it lets the ungrouped list's key check go first.
         SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_class, 0));
         if (g.sorted && keycheck_first) SBV_TRY(hipStreamWaitEvent(y.side_b, y.ev_narrow, 0));
-        hipLaunchKernelGGL(k_ed_qphase_wide, dim3(gv + SBV_ED_SORTED_GRID_SLACK), dim3(SBV_VERIFY_BLOCK), 0, y.side_b, d_tuples, g, eb.kvalid, b.tslot, wide, eb.kwide, eb.wtab,
+        hipLaunchKernelGGL(k_ed_qphase_wide, dim3((gv + 7u) & ~7u), dim3(SBV_VERIFY_BLOCK), 0, y.side_b, d_tuples, g, eb.kvalid, b.tslot, wide, eb.kwide, eb.wtab,
                            eb.hot + 2, b.gacc, eb.okb, b.acc);
         SBV_TRY(hipEventRecord(y.ev_wide, y.side_b));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_wide, 0));

@@ -263,12 +263,13 @@ static __global__ __launch_bounds__(1024) void k_group_sort_count(size_t n, Grou
 static __global__ __launch_bounds__(1024) void k_group_sort_scan(GroupState g) {
     __shared__ u32 part[1024];
     const u32 groups = group_count(g);
-    const u32 per = (groups + 1023) / 1024;
+    const u32 rows = group_sort_rows(groups), P = group_sort_positions(groups);      // the runs' order in the list: p256_group.h
+    const u32 per = (P + 1023) / 1024;
     const u32 lo = threadIdx.x * per;
     u32 hi = lo + per;
-    if (hi > groups) hi = groups;
+    if (hi > P) hi = P;
     u32 sum = 0;
-    for (u32 k = lo; k < hi; ++k) sum += g.gcount[k];
+    for (u32 p = lo; p < hi; ++p) { const u32 k = group_sort_group_at(p, rows); if (k < groups) sum += g.gcount[k]; }
     part[threadIdx.x] = sum;
     __syncthreads();
     for (u32 d = 1; d < 1024; d <<= 1) {            // Hillis-Steele inclusive scan
@@ -278,7 +279,7 @@ static __global__ __launch_bounds__(1024) void k_group_sort_scan(GroupState g) {
         __syncthreads();
     }
     u32 run = part[threadIdx.x] - sum;
-    for (u32 k = lo; k < hi; ++k) { g.gcursor[k] = run; run += g.gcount[k]; }
+    for (u32 p = lo; p < hi; ++p) { const u32 k = group_sort_group_at(p, rows); if (k < groups) { g.gcursor[k] = run; run += g.gcount[k]; } }
     if (threadIdx.x == 1023) g.counters[1] = part[1023];
 }
 static __global__ __launch_bounds__(1024) void k_group_sort_scatter(size_t n, GroupState g) {

@@ -243,9 +243,25 @@ SBV_HD void group_sort_count_lane(size_t i, const GroupState& g) {
     const u32 s = g.slots[i];
     if (s != SBV_GROUP_NONE) SBV_ATOMIC_ADD(&g.gcount[s], 1u);
 }
+// The order of the groups' runs in the list (round 6): 0, 8, 16, ..., 1, 9, 17, ... instead of 0, 1, 2, ...  Groups are numbered by first
+// appearance and cache slots by first caching, so the classes of a batch — hot keys, cold keys, rows-only tables — tend to be RANGES of
+// group numbers; with the runs in numerical order a class was a range of the list, i.e. the share of a few XCDs (every XCD walks one
+// contiguous eighth, so that a key's comb is fetched into one L2): a pass over half the lanes took as long as one over all of them
+// (profiles/r06/timeline_ed_half_hot_r06ak.txt).  With the runs dealt out by group number modulo 8 every eighth of the list holds every
+// eighth group of any range.  Position p of rows * 8 -> group (p % rows) * 8 + p / rows; a position past the last group is an empty run.
+#ifndef SBV_SORT_STRIDE8
+#define SBV_SORT_STRIDE8 1
+#endif
+SBV_HD u32 group_sort_rows(u32 groups) { return SBV_SORT_STRIDE8 ? (groups + 7u) >> 3 : groups; }
+SBV_HD u32 group_sort_positions(u32 groups) { return SBV_SORT_STRIDE8 ? group_sort_rows(groups) * 8u : groups; }
+SBV_HD u32 group_sort_group_at(u32 p, u32 rows) { return SBV_SORT_STRIDE8 ? (p % rows) * 8u + p / rows : p; }
 SBV_HD void group_sort_scan_seq(const GroupState& g, u32 groups) {
     u32 run = 0;
-    for (u32 k = 0; k < groups; ++k) { g.gcursor[k] = run; run += g.gcount[k]; }
+    const u32 rows = group_sort_rows(groups), P = group_sort_positions(groups);
+    for (u32 p = 0; p < P; ++p) {
+        const u32 k = group_sort_group_at(p, rows);
+        if (k < groups) { g.gcursor[k] = run; run += g.gcount[k]; }
+    }
     g.counters[1] = run;
 }
 SBV_HD void group_sort_scatter_lane(size_t i, const GroupState& g) {

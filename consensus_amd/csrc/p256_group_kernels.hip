@@ -304,6 +304,9 @@ __global__ __launch_bounds__(SBV_VERIFY_BLOCK, MODE == SBV_Q_NARROW ? SBV_COMB29
     // 8 XCDs (block b -> XCD b % 8, MI355X_MICROARCH.md "Workgroup dispatch"; a speed assumption only), so block b takes
     // logical block (b % 8) * per + b / 8: every XCD walks its own contiguous eighth of the list and a key's comb rows are
     // fetched into ONE L2.  `per` comes from the live lane count, not the launch's upper bound, so the eighths are even.
+    // (The runs of the list come in the order 0, 8, 16, ..., 1, 9, ... of their groups since round 6 — p256_group.h: group_sort_group_at —
+    // so that a class of groups, e.g. the hot keys, is spread over all eight XCDs.  Dealing the list out in 64 chunks per XCD instead
+    // was measured too: the Q launch 936 -> 996 us, profiles/r06/ab_p256_chunked_xcd_r06an.jsonl.)
     const u32 lanes = g.counters[1];
     const u32 per = ((lanes + SBV_VERIFY_BLOCK - 1) / SBV_VERIFY_BLOCK + 7) >> 3;
     const u32 local = blockIdx.x >> 3;

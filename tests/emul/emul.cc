@@ -137,6 +137,15 @@ static unsigned long g_coop_disagreements = 0, g_small_disagreements = 0;     //
 static int g_group_chunks = 3, g_group_sort = 1, g_group_coop = 0;
 void sbve_set_group_sort(int on) { g_group_sort = on ? 1 : 0; }
 static unsigned long g_sort_violations = 0;
+// the key-sorted list's invariant: every group's lanes form ONE run, and the runs come in the order of group_sort_scan_seq (p256_group.h)
+struct RunOrder {
+    std::vector<u32> pos;            // position of group k in the scan's order
+    explicit RunOrder(u32 groups) : pos(groups ? groups : 1, 0) {
+        const u32 rows = group_sort_rows(groups), P = group_sort_positions(groups);
+        for (u32 p = 0; p < P; ++p) { const u32 k = group_sort_group_at(p, rows); if (k < groups) pos[k] = p; }
+    }
+    bool ok(u32 prev, u32 cur) const { return cur < pos.size() && (prev == SBV_GROUP_NONE || (prev < pos.size() && pos[prev] <= pos[cur])); }
+};
 unsigned long sbve_group_sort_violations() { return g_sort_violations; }
 // persistent key-table cache of the emulated grouped step (sbve_key_cache resets it)
 static KeyCache g_kc = {};
@@ -311,14 +320,15 @@ void sbve_p256_verify_batch_grouped(const uint8_t* tuples, size_t n, uint8_t* bi
         // both the tuple order and the device's — verdicts may not depend on it
         for (size_t i = n; i-- > 0;) group_sort_scatter_lane(i, g);
         // invariants of the sorted list (the test reads the violation counter): a permutation of exactly the grouped tuples,
-        // non-decreasing groups, grp_of consistent with the per-tuple group
+        // one run per group in the scan's order (RunOrder), grp_of consistent with the per-tuple group
         size_t grouped = 0;
         for (size_t i = 0; i < n; ++i) grouped += slots[i] != SBV_GROUP_NONE;
         if (grouped != counters[1]) ++g_sort_violations;
         std::vector<uint8_t> seen(cap, 0);
+        const RunOrder run_order(ngroups);
         for (u32 L = 0; L < counters[1]; ++L) {
             const u32 t = grp_idx[L];
-            if (t >= n || seen[t] || slots[t] != grp_of[L] || (L && grp_of[L - 1] > grp_of[L])) { ++g_sort_violations; continue; }
+            if (t >= n || seen[t] || slots[t] != grp_of[L] || !run_order.ok(L ? grp_of[L - 1] : SBV_GROUP_NONE, grp_of[L])) { ++g_sort_violations; continue; }
             seen[t] = 1;
         }
     }
@@ -960,8 +970,9 @@ void sbve_ed25519_verify_batch_grouped(const uint8_t* tuples_in, size_t n, uint8
         for (size_t i = 0; i < n; ++i) group_sort_count_lane(i, g);
         group_sort_scan_seq(g, ngroups);
         for (size_t i = n; i-- > 0;) group_sort_scatter_lane(i, g);
+        const RunOrder run_order(ngroups);
         for (u32 L = 0; L < counters[1]; ++L)
-            if (grp_idx[L] >= n || slots[grp_idx[L]] != grp_of[L] || (L && grp_of[L - 1] > grp_of[L])) ++g_sort_violations;
+            if (grp_idx[L] >= n || slots[grp_idx[L]] != grp_of[L] || !run_order.ok(L ? grp_of[L - 1] : SBV_GROUP_NONE, grp_of[L])) ++g_sort_violations;
     } else {
         for (size_t i = 0; i < n; ++i) ed_group_split_lane(i, g);
     }
