@@ -198,6 +198,42 @@ def test_hot_keys_of_this_scheme_on_the_device(gpu, oracle):
         gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
 
 
+def test_hot_key_pool_of_this_scheme_follows_a_changing_signer_set(gpu, oracle):
+    """The life cycle of the hot keys (p256_group.h: decay, eviction with hysteresis — the shared kernels k_hot_decay / k_promote_select /
+    k_promote_evict / k_promote_publish) on this scheme's pool, on the device: 8 combs, three disjoint sets of 8 signers one after
+    another.  The set that signs now takes the pool over from the set that stopped; every comb a new owner got equals the host
+    builder's comb of -A for ITS key (sbv_ed25519_hot_selfcheck); every verdict of every batch is the generator's."""
+    n = 8 * 8192
+    sets = [_gen(oracle, 0xE71 + k, n, 8, 9) for k in range(3)]
+    lib = sbv.load()
+
+    def run(tup, exp):
+        got = ctypes.create_string_buffer((n + 7) // 8)
+        sbv._check(lib.sbv_ed25519_verify_batch(ctypes.addressof(tup), n, ctypes.addressof(got)))
+        assert got.raw == exp.raw
+        return gpu.ed_hot_key_stats()
+
+    try:
+        gpu.set_grouping(True, 1, 8, 64)
+        gpu.ed_hot_keys(8, 4096)
+        for k, (tup, exp) in enumerate(sets):
+            settled_at = None
+            for call in range(48):
+                h = run(tup, exp)
+                if h[2] >= n * 0.80:                           # (nearly) the whole batch through the wide pass: this set owns the pool
+                    settled_at = call
+                    break
+            assert settled_at is not None and (settled_at <= 2 if k == 0 else 3 <= settled_at), (k, settled_at)
+            for _ in range(2):
+                h = run(tup, exp)
+            assert h[0] == 8 and h[1] == 8 and h[2] >= n * 0.80, (k, h)
+            for i in range(8):
+                assert gpu.ed_hot_selfcheck(i), (k, i)
+    finally:
+        gpu.ed_hot_keys(1024, 4096)
+        gpu.set_grouping(True, sbv.GROUP_MIN_BATCH_DEFAULT, 0, 0)
+
+
 def test_quad_form_of_the_one_lane_kernel_gives_the_same_verdicts():
     """SBV_ED_UNGROUPED_QUAD=1 (round 6): the ungrouped list of the key-sorted step on four lanes per tuple (ed25519_group.h:
     ed25519_verify_quad — doublings and additions two multiplications deep, DPP broadcasts inside the quad, the key as the key check
