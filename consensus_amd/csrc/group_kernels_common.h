@@ -125,6 +125,25 @@ static __global__ __launch_bounds__(1024) void k_promote_evict(HotKeys hk) {
     for (u32 i = tid; i < SBV_HOT_POOL_MAX / 32; i += 1024) taken[i] = 0;
     if (tid == 0) entries = hk.hot[1] < SBV_PROMOTE_MAX ? hk.hot[1] : SBV_PROMOTE_MAX;
     __syncthreads();
+    {   // A full pool of keys about as hot as the candidates is the steady state of a signer set larger than the pool: 64 candidates per
+        // batch, none of which may take a comb, cost 64 scans = 0.1 ms on the stream the next batch's sort waits on
+        // (profiles/r06/timeline_p256_half_hot_r06aw.txt).  One scan settles it: if the coldest owner is too hot for the HOTTEST candidate
+        // (hot_evict_ok), it is too hot for every candidate.
+        u32 mc = 0;
+        for (u32 c = tid; c < ncand; c += 1024) { const u32 h = hk.khits[hk.elist[c]]; mc = h > mc ? h : mc; }
+        u32 bh, bw;
+        hot_evict_scan(hk.khits, hk.wowner, taken, hk.wide_cap, hk.cache_cap, tid, 1024u, bh, bw);
+        for (int off = 32; off >= 1; off >>= 1) {
+            const u32 om = (u32)__shfl_xor((int)mc, off, 64), oh = (u32)__shfl_xor((int)bh, off, 64);
+            mc = om > mc ? om : mc;
+            bh = oh < bh ? oh : bh;
+        }
+        if ((tid & 63) == 0) { sh_h[tid >> 6] = bh; sh_w[tid >> 6] = mc; }
+        __syncthreads();
+        for (int i = 0; i < 16; ++i) { bh = sh_h[i] < bh ? sh_h[i] : bh; mc = sh_w[i] > mc ? sh_w[i] : mc; }
+        __syncthreads();
+        if (bh == 0xFFFFFFFFu || !hot_evict_ok(mc, bh)) return;          // uniform: every lane holds the same two numbers
+    }
     for (u32 c = 0; c < ncand; ++c) {
         u32 bh, bw;
         hot_evict_scan(hk.khits, hk.wowner, taken, hk.wide_cap, hk.cache_cap, tid, 1024u, bh, bw);
