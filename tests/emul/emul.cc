@@ -147,6 +147,13 @@ struct RunOrder {
     bool ok(u32 prev, u32 cur) const { return cur < pos.size() && (prev == SBV_GROUP_NONE || (prev < pos.size() && pos[prev] <= pos[cur])); }
 };
 unsigned long sbve_group_sort_violations() { return g_sort_violations; }
+// the order of the groups' runs in the key-sorted list (p256_group.h: group_sort_group_at): out[p] = group at position p of
+// group_sort_positions(groups), SBV_GROUP_NONE for an empty position; returns the number of positions
+u32 sbve_group_sort_order(u32 groups, u32* out) {
+    const u32 rows = group_sort_rows(groups), P = group_sort_positions(groups);
+    for (u32 p = 0; p < P; ++p) { const u32 k = group_sort_group_at(p, rows); out[p] = k < groups ? k : SBV_GROUP_NONE; }
+    return P;
+}
 // persistent key-table cache of the emulated grouped step (sbve_key_cache resets it)
 static KeyCache g_kc = {};
 static apt* g_kc_ktab = nullptr;

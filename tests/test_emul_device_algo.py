@@ -501,6 +501,29 @@ def test_grouped_by_key_inside_the_batch_matches_generic(emul, oracle, golden_ve
     emul.sbve_set_group_chunks(3)
 
 
+def test_order_of_the_runs_in_the_key_sorted_list(emul):
+    """p256_group.h group_sort_group_at (round 6): the runs of the key-sorted list come in the order 0, 8, 16, ..., 1, 9, 17, ... of their
+    groups, so that a RANGE of group numbers (the hot keys: groups are numbered by first appearance, cache slots by first caching) is
+    spread over all eight contiguous eighths of the list — one per XCD.  For every group count: each group exactly once, at most 7 empty
+    positions, and any range of 8 m consecutive groups puts exactly m groups into every eighth of the positions."""
+    emul.sbve_group_sort_order.argtypes = [ctypes.c_uint32, ctypes.c_void_p]
+    emul.sbve_group_sort_order.restype = ctypes.c_uint32
+    NONE = 0xFFFFFFFF
+    for groups in list(range(0, 70)) + [255, 256, 257, 1000, 1024, 4095, 4096, 65535, 65536]:
+        out = (ctypes.c_uint32 * (groups + 8))()
+        P = emul.sbve_group_sort_order(groups, out)
+        assert groups <= P <= groups + 7 and P % 8 == 0
+        order = [out[p] for p in range(P)]
+        assert sorted(k for k in order if k != NONE) == list(range(groups))
+        if groups >= 64:
+            rows = P // 8
+            m = groups // 16                                   # a range of 8 m groups somewhere in the middle
+            lo = (groups - 8 * m) // 2 // 8 * 8
+            for x in range(8):
+                inside = sum(1 for k in order[x * rows:(x + 1) * rows] if k != NONE and lo <= k < lo + 8 * m)
+                assert inside == m, (groups, x, inside, m)
+
+
 def test_key_sorted_grouped_list_equals_compaction_order(emul, oracle, golden_vectors):
     """The key-sorted grouped list (p256_group.h: group_sort_*, per-tuple records of stage A, accumulators parked at the
     sorted position) gives the verdicts of the split's compaction order, and the list it builds is a permutation of exactly
