@@ -180,6 +180,44 @@ __global__ __launch_bounds__(64) void k_keytab29_fill_sym(GroupState g, u32* __r
         keytab29_fill_sym_lane(1 + (int)r, t, ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
     }
 }
+// The same with ONE inversion per window (round 6): workgroups of 8 wavefronts = 64 windows; every lane leaves the product of its eight
+// denominators in LDS, the first wavefront turns the 64 x 8 products into their inverses with 64 inversions (keytab29_fill_group_inverses:
+// the inversions of eight wavefronts packed into one), every lane walks back with its own.
+#define SBV_FILL_SHARED_BLOCK 512
+__global__ __launch_bounds__(SBV_FILL_SHARED_BLOCK) void k_keytab29_fill_shared(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab,
+                                                          const u32* __restrict__ tslot, const uint8_t* __restrict__ needfill,
+                                                          const uint8_t* __restrict__ kvalid, int j_first, int j_count) {
+    __shared__ u32 sh[(SBV_FILL_SHARED_BLOCK / 8) * 16 * 9];
+    const u32 total = group_count(g) * (u32)j_count * 8u;
+    const u32 tid = threadIdx.x;
+    u32* w = sh + (tid >> 3) * (16 * 9);
+    for (u32 base = blockIdx.x * SBV_FILL_SHARED_BLOCK; base < total; base += gridDim.x * SBV_FILL_SHARED_BLOCK) {      // uniform in the workgroup
+        const u32 lane = base + tid;
+        const u32 r = lane & 7u;
+        const u32 kw = lane >> 3;
+        bool active = lane < total;
+        u32 key = 0, j = 0;
+        if (active) {
+            key = kw / (u32)j_count; j = (u32)j_first + kw % (u32)j_count;
+            active = !(j == SBV_GTAB_WINDOWS - 1 || !needfill[key] || kvalid[tslot[key]] == 0);
+        }
+        if (!__syncthreads_or(active ? 1 : 0)) continue;            // nothing to fill in these 64 windows (cached keys)
+        u32* t = tmp + (size_t)(blockIdx.x * SBV_FILL_SHARED_BLOCK + tid) * SBV_KT29_FILL_LANE_WORDS;
+        apt* row = active ? ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW : nullptr;
+        fe29 acc = f29_one();
+        if (active) { table_prio(); keytab29_fill_sym_acc(1 + (int)r, t, row, acc); }
+        f29_store_raw(w + r * 9, acc);
+        __syncthreads();
+        if (tid < SBV_FILL_SHARED_BLOCK / 8) keytab29_fill_group_inverses(sh + tid * (16 * 9));
+        __syncthreads();
+        if (active) {
+            fe29 inv;
+            f29_load_raw(inv, w + r * 9);
+            keytab29_fill_sym_finish(1 + (int)r, t, row, inv);
+        }
+        __syncthreads();                                             // the next round rewrites sh
+    }
+}
 // scratch words of ONE launch of the rows / fill kernels (the launcher gives the two table streams a region each)
 #define SBV_TABLE_TMP_WORDS ((size_t)SBV_TABLE_GRID_BLOCKS * 64 * SBV_KT29_ROWS_TMP_WORDS)
 
@@ -657,7 +695,11 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         SBV_TRY(hipStreamWaitEvent(tb, y.ev_bases[c], 0));
         if (on_t) SBV_TRY(hipStreamWaitEvent(tb, y.ev_class, 0));      // side_b has it in stream order
         hipLaunchKernelGGL(k_keytab29_rows, dim3(bounded((size_t)b.max_groups * j_count * 2)), dim3(64), 0, tb, g, b.bases, ttmp, b.ktab, b.ntab, b.tslot, b.cold, b.kvalid, j_first, j_count);
-        hipLaunchKernelGGL(k_keytab29_fill_sym, dim3(bounded((size_t)b.max_groups * j_count * 8)), dim3(64), 0, tb, g, ttmp, b.ktab, b.tslot, b.needfill, b.kvalid, j_first, j_count);
+        // one inversion per window (default since round 6: Q launch 926-939 -> 872-883 us beside it, cold step -0.5 %, profiles/r06/ab_fill_*_r06bd.jsonl); SBV_FILL_SHARED=0: one per lane
+        static const bool fill_shared = [] { const char* e = getenv("SBV_FILL_SHARED"); return !e || atoi(e) != 0; }();
+        if (fill_shared) hipLaunchKernelGGL(k_keytab29_fill_shared, dim3((bounded((size_t)b.max_groups * j_count * 8) + 7u) / 8u), dim3(SBV_FILL_SHARED_BLOCK), 0, tb, g, ttmp, b.ktab, b.tslot,
+                                            b.needfill, b.kvalid, j_first, j_count);
+        else hipLaunchKernelGGL(k_keytab29_fill_sym, dim3(bounded((size_t)b.max_groups * j_count * 8)), dim3(64), 0, tb, g, ttmp, b.ktab, b.tslot, b.needfill, b.kvalid, j_first, j_count);
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
         SBV_TRY(hipStreamWaitEvent(stream, y.ev_tables[c], 0));
         const bool last = c + 1 == chunks;

@@ -312,10 +312,12 @@ SBV_HD void keytab29_rows_lane(const u32* base2, int which, bool top_window, u32
 // instead of fifteen, and the rows step only has to build babies 2..8 (7 additions instead of 15).  Entry 8 is a baby and is
 // not written again (a = 1, b = 8); entries 9..15 come from giant 16.  Lanes write disjoint entries and read only babies
 // 1..8 and their own giant, which the rows step wrote.  tmp: 8 x 9 words.
-SBV_HD void keytab29_fill_sym_lane(int a, u32* tmp, apt* row) {
+// In three steps since round 6, so that the lanes of a window can share ONE inversion (keytab29_fill_group_inverses): the product
+// of the lane's eight denominators | its inverse | the walk back.
+SBV_HD void keytab29_fill_sym_acc(int a, u32* tmp, const apt* row, fe29& acc) {
     apt29 G;
     apt29_load(G, reinterpret_cast<const u32*>(row + 16 * a - 1));
-    fe29 acc = f29_one();
+    acc = f29_one();
     SBV_NOUNROLL
     for (int b = 1; b <= 8; ++b) {
         apt29 S;
@@ -325,8 +327,42 @@ SBV_HD void keytab29_fill_sym_lane(int a, u32* tmp, apt* row) {
         f29_store_raw(tmp + (b - 1) * 9, acc);
         f29_mul(acc, acc, d);
     }
+}
+// w: 16 x 9 words of one window — the eight lanes' products in w[0..8), scratch behind them.  On return w[r] = 1 / product r:
+// Montgomery's trick over the lanes, one inversion per window instead of one per lane (an inversion is three quarters of a fill
+// lane's instructions).  No denominator of a valid key is 0 (babies and giants are distinct multiples of a point of prime order);
+// a zero would cost the whole window, not one lane, which is why the fill skips keys that are no points.
+SBV_HD void keytab29_fill_group_inverses(u32* w) {
+    fe29 acc = f29_one();
+    SBV_NOUNROLL
+    for (int r = 0; r < 8; ++r) {
+        fe29 v;
+        f29_load_raw(v, w + r * 9);
+        f29_store_raw(w + (8 + r) * 9, acc);
+        f29_mul(acc, acc, v);
+    }
     fe29 inv;
     f29_inv(inv, acc);
+    SBV_NOUNROLL
+    for (int r = 7; r >= 0; --r) {
+        fe29 v, pre, t;
+        f29_load_raw(v, w + r * 9);
+        f29_load_raw(pre, w + (8 + r) * 9);
+        f29_mul(t, inv, pre);
+        f29_mul(inv, inv, v);
+        f29_store_raw(w + r * 9, t);
+    }
+}
+SBV_HD void keytab29_fill_sym_finish(int a, u32* tmp, apt* row, fe29 inv);
+SBV_HD void keytab29_fill_sym_lane(int a, u32* tmp, apt* row) {
+    fe29 acc, inv;
+    keytab29_fill_sym_acc(a, tmp, row, acc);
+    f29_inv(inv, acc);
+    keytab29_fill_sym_finish(a, tmp, row, inv);
+}
+SBV_HD void keytab29_fill_sym_finish(int a, u32* tmp, apt* row, fe29 inv) {
+    apt29 G;
+    apt29_load(G, reinterpret_cast<const u32*>(row + 16 * a - 1));
     SBV_NOUNROLL
     for (int b = 8; b >= 1; --b) {
         apt29 S, r;

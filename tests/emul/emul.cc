@@ -279,6 +279,8 @@ void sbve_set_hash_seed(u32 s) { g_hash_seed = s; }
 static void emul_window_rows_fill(const u32* recs, bool top, u32* tmp, apt* row);
 static void emul_window_rows(const u32* recs, bool top, u32* tmp, apt* row, apt* crow = nullptr);
 static void emul_window_fill(bool top, u32* tmp, apt* row);
+static bool g_fill_shared = true;       // SBV_FILL_SHARED: one inversion per window in the fill (k_keytab29_fill_shared)
+void sbve_set_fill_shared(int on) { g_fill_shared = on != 0; }
 void sbve_set_group_coop(int on) { g_group_coop = on != 0; }     // k_group_coop instead of the G phase + Q launches (key-sorted step only)
 // grouped form: generic tuples, keys grouped inside the call (p256_group.h), emulated sequentially.
 // stats_out[0..3] = groups, grouped tuples, ungrouped tuples, ungrouped tuples rejected for their key.
@@ -589,7 +591,23 @@ static void emul_window_rows(const u32* recs, bool top, u32* tmp, apt* row, apt*
 }
 static void emul_window_fill(bool top, u32* tmp, apt* row) {
     if (top) return;
-    for (int a = 8; a >= 1; --a) keytab29_fill_sym_lane(a, tmp + (size_t)(a - 1) * (SBV_KT29_FILL_TMP_WORDS / 2), row);
+    if (!g_fill_shared) {
+        for (int a = 8; a >= 1; --a) keytab29_fill_sym_lane(a, tmp + (size_t)(a - 1) * (SBV_KT29_FILL_TMP_WORDS / 2), row);
+        return;
+    }
+    // k_keytab29_fill_shared: the eight lanes' products, ONE inversion for the window, the eight walks back
+    u32 w[16 * 9];
+    for (int a = 8; a >= 1; --a) {
+        fe29 acc;
+        keytab29_fill_sym_acc(a, tmp + (size_t)(a - 1) * (SBV_KT29_FILL_TMP_WORDS / 2), row, acc);
+        f29_store_raw(w + (a - 1) * 9, acc);
+    }
+    keytab29_fill_group_inverses(w);
+    for (int a = 1; a <= 8; ++a) {
+        fe29 inv;
+        f29_load_raw(inv, w + (a - 1) * 9);
+        keytab29_fill_sym_finish(a, tmp + (size_t)(a - 1) * (SBV_KT29_FILL_TMP_WORDS / 2), row, inv);
+    }
 }
 static void emul_window_rows_fill(const u32* recs, bool top, u32* tmp, apt* row) {
     emul_window_rows(recs, top, tmp, row, nullptr);

@@ -501,6 +501,38 @@ def test_grouped_by_key_inside_the_batch_matches_generic(emul, oracle, golden_ve
     emul.sbve_set_group_chunks(3)
 
 
+def test_fill_with_one_inversion_per_window_builds_the_same_tables(emul, oracle):
+    """p256_keytab29.h (round 6): keytab29_fill_sym_acc / keytab29_fill_group_inverses / keytab29_fill_sym_finish — the eight lanes of a
+    window share ONE inversion (k_keytab29_fill_shared).  Table entries are stored canonically, so the filled tables and with them
+    every verdict must equal the per-lane form's: a batch whose keys all earn full tables (threshold 8), 1 to 4 chunks."""
+    emul.sbve_p256_verify_batch_grouped.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_uint32, ctypes.c_uint32,
+                                                    ctypes.c_uint32, ctypes.c_void_p]
+    oracle.sbvo_gen_batch.argtypes = [ctypes.c_uint32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    n = 700
+    tup = ctypes.create_string_buffer(160 * n)
+    exp = ctypes.create_string_buffer((n + 7) // 8)
+    oracle.sbvo_gen_batch(0xF111, n, 9, 5, tup, exp, 4)
+    stats = (ctypes.c_uint32 * 4)()
+    classes = (ctypes.c_uint32 * 3)()
+    try:
+        emul.sbve_set_full_table_min(8)
+        for chunks in (1, 2, 3, 4):
+            emul.sbve_set_group_chunks(chunks)
+            got = []
+            for shared in (0, 1):
+                emul.sbve_set_fill_shared(shared)
+                bm = ctypes.create_string_buffer((n + 7) // 8)
+                emul.sbve_p256_verify_batch_grouped(tup.raw, n, bm, 8, 64, 12, stats)
+                emul.sbve_last_table_classes(classes)
+                assert classes[0] >= 9 and classes[1] >= 9 and classes[2] == 0, list(classes)      # every signer's table was filled in this batch
+                got.append(bm.raw)
+            assert got[0] == got[1] == exp.raw, chunks
+    finally:
+        emul.sbve_set_fill_shared(1)                     # the library's default
+        emul.sbve_set_full_table_min(256)
+        emul.sbve_set_group_chunks(3)
+
+
 def test_order_of_the_runs_in_the_key_sorted_list(emul):
     """p256_group.h group_sort_group_at (round 6): the runs of the key-sorted list come in the order 0, 8, 16, ..., 1, 9, 17, ... of their
     groups, so that a RANGE of group numbers (the hot keys: groups are numbered by first appearance, cache slots by first caching) is
