@@ -180,10 +180,14 @@ __global__ __launch_bounds__(64) void k_keytab29_fill_sym(GroupState g, u32* __r
         keytab29_fill_sym_lane(1 + (int)r, t, ktab + ((size_t)tslot[key] * SBV_GTAB_WINDOWS + j) * SBV_GTAB_PER_WINDOW);
     }
 }
-// The same with ONE inversion per window (round 6): workgroups of 8 wavefronts = 64 windows; every lane leaves the product of its eight
-// denominators in LDS, the first wavefront turns the 64 x 8 products into their inverses with 64 inversions (keytab29_fill_group_inverses:
-// the inversions of eight wavefronts packed into one), every lane walks back with its own.
-#define SBV_FILL_SHARED_BLOCK 512
+// The same with ONE inversion per window (round 6): a workgroup takes SBV_FILL_SHARED_BLOCK / 8 windows; every lane leaves the product of its
+// eight denominators in LDS, the first lanes turn the windows' 8 products each into their inverses with one inversion per window
+// (keytab29_fill_group_inverses: the inversions of the workgroup's wavefronts packed into one), every lane walks back with its own.
+// 256 lanes = 4 wavefronts = 32 windows per workgroup: 512 packs the inversions 8 : 1 but needs eight free wave slots on ONE CU beside the G
+// phase (cold 3.25-3.28 ms), 128 packs 2 : 1 (3.24-3.28); 256: 3.20-3.21 (profiles/r06/ab_fill_block_r06bg.jsonl; one per lane: 3.27-3.32)
+#ifndef SBV_FILL_SHARED_BLOCK
+#define SBV_FILL_SHARED_BLOCK 256
+#endif
 __global__ __launch_bounds__(SBV_FILL_SHARED_BLOCK) void k_keytab29_fill_shared(GroupState g, u32* __restrict__ tmp, apt* __restrict__ ktab,
                                                           const u32* __restrict__ tslot, const uint8_t* __restrict__ needfill,
                                                           const uint8_t* __restrict__ kvalid, int j_first, int j_count) {
@@ -697,7 +701,7 @@ hipError_t launch_p256_verify_grouped(const uint8_t* d_tuples, const Scratch& s_
         hipLaunchKernelGGL(k_keytab29_rows, dim3(bounded((size_t)b.max_groups * j_count * 2)), dim3(64), 0, tb, g, b.bases, ttmp, b.ktab, b.ntab, b.tslot, b.cold, b.kvalid, j_first, j_count);
         // one inversion per window (default since round 6: Q launch 926-939 -> 872-883 us beside it, cold step -0.5 %, profiles/r06/ab_fill_*_r06bd.jsonl); SBV_FILL_SHARED=0: one per lane
         static const bool fill_shared = [] { const char* e = getenv("SBV_FILL_SHARED"); return !e || atoi(e) != 0; }();
-        if (fill_shared) hipLaunchKernelGGL(k_keytab29_fill_shared, dim3((bounded((size_t)b.max_groups * j_count * 8) + 7u) / 8u), dim3(SBV_FILL_SHARED_BLOCK), 0, tb, g, ttmp, b.ktab, b.tslot,
+        if (fill_shared) hipLaunchKernelGGL(k_keytab29_fill_shared, dim3((bounded((size_t)b.max_groups * j_count * 8) + (SBV_FILL_SHARED_BLOCK / 64) - 1u) / (SBV_FILL_SHARED_BLOCK / 64)), dim3(SBV_FILL_SHARED_BLOCK), 0, tb, g, ttmp, b.ktab, b.tslot,
                                             b.needfill, b.kvalid, j_first, j_count);
         else hipLaunchKernelGGL(k_keytab29_fill_sym, dim3(bounded((size_t)b.max_groups * j_count * 8)), dim3(64), 0, tb, g, ttmp, b.ktab, b.tslot, b.needfill, b.kvalid, j_first, j_count);
         SBV_TRY(hipEventRecord(y.ev_tables[c], tb));
